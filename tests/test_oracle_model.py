@@ -1,0 +1,56 @@
+"""CPU: the torch-eager restatement (oracle/model_oracle.py) must reproduce the golden vectors
+recorded from the imported reference (oracle/make_golden.py).  This is what pins the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+from pcr_amd import testing as T
+import model_oracle as MO
+
+TOL = 2e-5   # same ATen ops on the same machine class; observed max |d| is ~1e-6
+
+
+def _sd(name):
+    return T.seeded_state_dict(T.load_manifest(os.path.join(GOLDEN, name + "_manifest.json")), 0)
+
+
+@pytest.mark.parametrize("case", ["pt_n128_randn", "pt_n128_dup", "pt_n256_box", "pt_n1024_randn"])
+def test_pt_oracle_matches_reference_golden(case):
+    g = load_golden(case)
+    m = g["meta"]
+    s1, s2 = T.synthetic_pairs(m["pairs"], m["n"], m["input_seed"], m["kind"])
+    st = {}
+    with torch.no_grad():
+        logits = MO.pt_pairs(_sd("pt"), s1, s2, m["backbone_list"], stages=st)
+    assert np.abs(logits.numpy() - g["logits"]).max() < TOL
+    for k, v in g.items():
+        if k in ("meta", "logits"):
+            continue
+        got = st[k].numpy()
+        if k.endswith("knn_sorted"):
+            if m["kind"] == "dup":
+                continue          # exact ties: ids interchangeable, covered by feature parity below
+            assert (got == v).all(), k
+        else:
+            assert np.abs(got - v).max() < TOL, (k, np.abs(got - v).max())
+
+
+def test_pointnet_oracle_matches_reference_golden():
+    g = load_golden("pointnet_n256_randn")
+    m = g["meta"]
+    s1, s2 = T.synthetic_pairs(m["pairs"], m["n"], m["input_seed"], m["kind"])
+    st = {}
+    with torch.no_grad():
+        logits = MO.pointnet_pairs(_sd("pointnet"), s1, s2, stages=st)
+    for k in ("h1", "h2", "enc_max", "enc_mean"):
+        assert np.abs(st[k].numpy() - g[k]).max() < 5e-5, k
+    assert np.abs(logits.numpy() - g["logits"]).max() < TOL
+
+
+def test_eval_metric_fixture():
+    g = load_golden("eval_metric")
+    acc = ((torch.sigmoid(torch.from_numpy(g["logits"])) > 0.5).float() == torch.from_numpy(g["gt"])).float().mean()
+    assert abs(float(acc) - float(g["val_match_acc"])) < 1e-7
