@@ -1,0 +1,198 @@
+/*
+ * pcr.h -- C ABI of libpcr_hip.so, the MI355X (gfx950) implementation of the siamese
+ * point-cloud ReID hot path of bentherien/point-cloud-reid.
+ *
+ * Conventions (all entry points):
+ *   - plain `extern "C"`, raw DEVICE pointers, sizes as int, a hipStream_t passed as void*;
+ *   - outputs are caller-allocated (as in the reference's pybind11 wrappers, e.g.
+ *     mmdet3d/ops/ball_query/src/ball_query.cpp:30-43: dims first, tensors after, outputs
+ *     pre-allocated by the Python side);
+ *   - the call only ENQUEUES work on `stream`: no allocation, no synchronisation;
+ *   - returns a pcr_status (0 = ok).  Unlike the reference launchers, which fprintf + exit(-1)
+ *     on a launch error (e.g. ball_query_cuda.cu:73-77), nothing here ever exits the process;
+ *   - all float data is IEEE binary32, all index data int32, tensors contiguous, layouts as in
+ *     the reference op they replace (cited per function).
+ *
+ * Section A replaces the reference's native extension modules one for one.
+ * Section B are the fused model kernels, which have no native counterpart in the reference
+ * (its model path is an unfused chain of ATen calls); each cites the Python it computes.
+ */
+#ifndef PCR_H_
+#define PCR_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *pcr_stream_t; /* hipStream_t */
+
+enum pcr_status {
+  PCR_OK = 0,
+  PCR_ERR_INVALID = 1, /* bad size / null pointer / unsupported configuration */
+  PCR_ERR_LAUNCH = 2   /* hipLaunchKernel reported an error (hipGetLastError) */
+};
+
+/* ABI version (bumped whenever a signature changes) and human-readable status. */
+int pcr_abi_version(void);
+const char *pcr_status_string(int status);
+
+/* ---------------------------------------------------------------- A. point ops ------- */
+
+/* furthest_point_sampling_wrapper (ops/furthest_point_sample/src/furthest_point_sample.cpp:32-43,
+ * kernel furthest_point_sample_cuda.cu:25-141).  xyz (B,N,3); temp (B,N) in/out scratch that the
+ * caller fills with 1e10 (furthest_point_sample.py:29) and that holds the final min-distances on
+ * return; idx (B,M) int32.  Start index 0; tie rule identical to the reference's per-thread scan +
+ * halving merge tree for block = min(1024, 2^floor(log2 N)).  Requires 1 <= N < 2^22. */
+int pcr_fps_f32(const float *xyz, float *temp, int *idx, int B, int N, int M, pcr_stream_t stream);
+
+/* furthest_point_sampling_with_dist_wrapper (furthest_point_sample.cpp:45-57, kernel .cu:213-331).
+ * dist (B,N,N) pairwise distance matrix instead of coordinates. */
+int pcr_fps_dist_f32(const float *dist, float *temp, int *idx, int B, int N, int M,
+                     pcr_stream_t stream);
+
+/* ball_query_wrapper (ops/ball_query/src/ball_query.cpp:30-43, kernel ball_query_cuda.cu:11-54).
+ * centres (B,M,3), xyz (B,N,3) -> idx (B,M,K): the first K indices k (ascending) with
+ * d2 == 0 || (min_r^2 <= d2 < max_r^2), padded with the first hit; rows with no hit are written
+ * as zeros (the reference leaves its pre-zeroed buffer untouched; the result is the same). */
+int pcr_ball_query_f32(const float *centres, const float *xyz, int *idx, int B, int N, int M,
+                       float min_r, float max_r, int K, pcr_stream_t stream);
+
+/* knn_wrapper (ops/knn/src/knn.cpp:28-41, kernel knn_cuda.cu:58-94).  xyz (B,N,3), centres (B,M,3)
+ * -> idx (B,M,K) int32 and dist2 (B,M,K), ascending, produced by the same max-heap + heap-sort
+ * sequence as the reference (so equal distances come out in the reference's order).
+ * 1 <= K <= 100.  (knn.py:62 transposes idx to (B,K,M) on the Python side.) */
+int pcr_knn_f32(const float *xyz, const float *centres, int *idx, float *dist2, int B, int N, int M,
+                int K, pcr_stream_t stream);
+
+/* gather_points_wrapper / gather_points_grad_wrapper (ops/gather_points/src/gather_points.cpp:28-52,
+ * kernels gather_points_cuda.cu:8-26, :51-70).  feat (B,C,N), idx (B,M) -> out (B,C,M);
+ * backward ACCUMULATES into grad_feat (B,C,N), which the caller zero-fills (gather_points.py:43). */
+int pcr_gather_fwd_f32(const float *feat, const int *idx, float *out, int B, int C, int N, int M,
+                       pcr_stream_t stream);
+int pcr_gather_bwd_f32(const float *grad_out, const int *idx, float *grad_feat, int B, int C, int N,
+                       int M, pcr_stream_t stream);
+
+/* group_points forward / backward (ops/group_points/src/group_points.cpp:31-58, kernels
+ * group_points_cuda.cu:56-79, :10-31).  feat (B,C,N), idx (B,S,K) -> out (B,C,S,K);
+ * backward accumulates into the caller-zeroed grad_feat (B,C,N). */
+int pcr_group_fwd_f32(const float *feat, const int *idx, float *out, int B, int C, int N, int S,
+                      int K, pcr_stream_t stream);
+int pcr_group_bwd_f32(const float *grad_out, const int *idx, float *grad_feat, int B, int C, int N,
+                      int S, int K, pcr_stream_t stream);
+
+/* three_nn_wrapper (ops/interpolate/src/interpolate.cpp:46-58, kernel three_nn_cuda.cu:11-65).
+ * unknown (B,N,3), known (B,M,3) -> dist2 (B,N,3) SQUARED distances (three_nn.py:41 takes the
+ * sqrt), idx (B,N,3).  Running bests are kept in double and compared with the float distance, as
+ * in the reference. */
+int pcr_three_nn_f32(const float *unknown, const float *known, float *dist2, int *idx, int B, int N,
+                     int M, pcr_stream_t stream);
+
+/* three_interpolate_wrapper / _grad_wrapper (interpolate.cpp:60-86, kernels
+ * three_interpolate_cuda.cu:11-35, :61-84).  feat (B,C,M), idx/weight (B,N,3) -> out (B,C,N);
+ * backward accumulates into the caller-zeroed grad_feat (B,C,M). */
+int pcr_three_interp_fwd_f32(const float *feat, const int *idx, const float *weight, float *out,
+                             int B, int C, int M, int N, pcr_stream_t stream);
+int pcr_three_interp_bwd_f32(const float *grad_out, const int *idx, const float *weight,
+                             float *grad_feat, int B, int C, int N, int M, pcr_stream_t stream);
+
+/* ------------------------------------------------- B. fused model kernels ------------ */
+
+/* Neighbour search of the "Point-Transformer" set-abstraction layers: centres are the first S
+ * points of each cloud (random_point_sample, models/pointnet2_utils.py:139-149) and the K nearest
+ * of all N points are selected (knn_point, :205-216).  The reference ranks an expanded-matmul
+ * distance with an unstable argsort; this kernel selects by the direct squared distance
+ * (dx*dx+dy*dy)+dz*dz with ties to the lower index and writes idx (B,S,K) in (distance, index)
+ * order.  The consumer is a max over K, so only the K-SET matters (hard part 1).
+ * xyz (B,N,3).  K <= N, K <= 64, N <= 16384. */
+int pcr_knn_prefix_f32(const float *xyz, int *idx, int B, int N, int S, int K, pcr_stream_t stream);
+
+/* Packed weight image of one dense layer out = W x (W is (cout, cin) row-major as in
+ * nn.Linear / 1x1 conv).  Returns the number of floats of the packed image for (cout, cin);
+ * pcr_pack_weight_f32 writes it on the HOST (plain C, no GPU) so that a model can be packed at
+ * load time and uploaded once.  The image is what the MFMA A-operand loads of every fused kernel
+ * below read with one 16-byte load per lane. */
+long pcr_packed_weight_floats(int cout, int cin);
+int pcr_pack_weight_f32(const float *w, int cout, int cin, float *packed);
+
+/* Grouped set-abstraction MLP: gather + edge/relative features + 3 x (1x1 conv -> per-channel
+ * affine (folded eval-mode BatchNorm) -> ReLU) + max over the K neighbours, one pass, nothing but
+ * the (B,C3,S) result written.
+ *   mode 0 ("edge", PointNetSetAbstractionEdgeSA, models/pointnet2_utils.py:242-288, 333-357):
+ *          rows = [xyz[idx]-centre (3), feat[centre] (D), feat[idx]-feat[centre] (D)], centre =
+ *          point s (prefix sampling);
+ *   mode 1 ("query-and-group", ops/group_points/group_points.py:94-118 with use_xyz=True, as used
+ *          by PointSAModule, ops/pointnet_modules/point_sa_module.py:166-216):
+ *          rows = [xyz[idx]-centre_xyz (3), feat[idx] (D)], centres given by centre_idx (B,S).
+ * xyz (B,N,3); feat (B,D,N) or NULL when D == 0; idx (B,S,K); centre_idx (B,S) or NULL (=> s).
+ * wp[l]: packed weights of layer l; scale[l]/shift[l]: (C_l) affine applied after the matmul
+ * (conv bias and BatchNorm folded by the host).  out (B,C3,S). */
+typedef struct pcr_sa_params {
+  int mode, B, N, S, K, D;
+  int c1, c2, c3;
+  const float *xyz, *feat;
+  const int *idx, *centre_idx;
+  const float *wp[3], *scale[3], *shift[3];
+  float *out;
+} pcr_sa_params;
+int pcr_sa_mlp_f32(const pcr_sa_params *p, pcr_stream_t stream);
+
+/* Linear-attention block shared by Self_Attention (models/pointnet2_utils.py:90-114), FP_SA
+ * (:407-437) and corss_attention (models/attention.py:192-219), in two kernels.
+ *
+ * pcr_attn_kv_f32: per key-side cloud, kp = [pos_mlp(xyz_k) +] feat_k; K = elu(Wk x)+1 with
+ *   x = kp if k_pos else feat_k; V = Wv kp; writes kv (B, d+?) = the block-diagonal (per head)
+ *   sum_s K V^T / Sk already in packed-weight form plus ksum (B,d) = sum_s K.
+ * pcr_attn_apply_f32: per query token, Q = elu(Wq x)+1 (x = feat_q [+ pos_mlp(xyz_q)] if q_pos),
+ *   msg = (Q . KV) / (Q . ksum + 1e-6) * Sk, merge, LayerNorm, feed-forward on [feat_q, msg],
+ *   LayerNorm, optional residual; cloud b reads the kv of cloud kv_index[b] (NULL => b), which is
+ *   how the siamese matching head pairs clouds without copying (ReIDNet.xcorr_eff,
+ *   models/ReIDNet.py:231-247).  Optional fused trailing 1x1 conv (Pointnet_Backbone.cov_final,
+ *   models/backbone_net.py:89,124). */
+typedef struct pcr_attn_params {
+  int B, Lq, Sk;             /* clouds, query tokens per cloud, key tokens per cloud */
+  int c1, c2, d, cout;       /* query feature dim, key feature dim, d_model, output dim */
+  int nhead;
+  int q_pos, k_pos, residual;
+  const float *feat_q, *xyz_q; /* (B,c1,Lq), (B,Lq,3) */
+  const float *feat_k, *xyz_k; /* (B,c2,Sk), (B,Sk,3) */
+  const int *kv_index;         /* (B) or NULL */
+  /* packed weights */
+  const float *pos0_w, *pos0_b, *pos2_w, *pos2_b; /* 3->d ; d->c2 (key side) */
+  const float *wq, *wk, *wv, *wmerge, *wmlp0, *wmlp2;
+  const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+  const float *wfinal, *bfinal; int cfinal;       /* optional trailing conv (NULL/0 = none) */
+  float *kv;    /* workspace (B, pcr_attn_kv_floats(d)) */
+  float *out;   /* (B, cfinal ? cfinal : cout, Lq) */
+} pcr_attn_params;
+long pcr_attn_kv_floats(int d);
+int pcr_attn_kv_f32(const pcr_attn_params *p, pcr_stream_t stream);
+int pcr_attn_apply_f32(const pcr_attn_params *p, pcr_stream_t stream);
+
+/* Matching head tail: pool 'both' over the point-concatenated pair (get_pooled_feats,
+ * models/ReIDNet.py:526-534: [max over 2L points, mean over 2L points]) followed by
+ * LinearRes(2C,2C,GroupNorm) + Linear(2C,1) (models/lanegcn_nets.py:228-241, ReIDNet.py:455-457).
+ * o (2P, C, L): cloud p and cloud p+P form pair p.  logits (P); pooled (P,2C) optional (may be NULL). */
+typedef struct pcr_head_params {
+  int P, C, L, groups;
+  const float *o;
+  const float *w1, *w2;            /* (2C,2C) row-major, NOT packed */
+  const float *gn1_g, *gn1_b, *gn2_g, *gn2_b;
+  const float *w_out, *b_out;      /* (1,2C), (1) */
+  float *pooled, *logits;
+} pcr_head_params;
+int pcr_pool_head_f32(const pcr_head_params *p, pcr_stream_t stream);
+
+/* get_pooled_feats with pool_type='both' on its own (models/ReIDNet.py:529-532):
+ * x (B,C,L) -> out (B,2C) = [max over L, mean over L]. */
+int pcr_pool_both_f32(const float *x, float *out, int B, int C, int L, pcr_stream_t stream);
+
+/* Generic per-point dense layer y = act(scale * (W x) + shift) on channel-major tensors
+ * x (B,cin,L) -> y (B,cout,L): 1x1 Conv1d / Linear (+ folded BatchNorm) of the PointNet encoder
+ * (models/pointnet.py:27-45, 67-85, 103-127).  act: 0 none, 1 ReLU.  wp packed. */
+int pcr_dense_f32(const float *x, const float *wp, const float *scale, const float *shift, float *y,
+                  int B, int cin, int cout, int L, int act, pcr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCR_H_ */

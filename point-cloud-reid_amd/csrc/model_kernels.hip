@@ -1,0 +1,674 @@
+// Fused model kernels of the siamese ReID hot path for gfx950 (MI355X).
+//
+// Data layout everywhere: channel-major feature tensors (B, C, L) exactly as the reference's
+// model path carries them ([B,C,N] tensors, models/backbone_net.py:96-124), so a tile of 32*TB
+// consecutive tokens of one cloud is C contiguous runs in HBM and lands in LDS as [C][RP]
+// (RP = tokens + 1, odd => every access pattern used below is bank-conflict free).
+//
+// All matmuls run on the f32-input matrix core (v_mfma_f32_32x32x2_f32: exact fp32 fmaf chain,
+// 64 FLOP/clk/SIMD) with the WEIGHTS as the A operand, read straight from a host-packed image
+// (one 16-byte load per lane covers four k-steps), and the LDS-resident activations as the B
+// operand (token = lane => conflict-free ds_read_b32, token-contiguous epilogue stores).
+#include <math.h>
+
+#include "pcr_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__host__ __device__ inline int ceil8(int x) { return (x + 7) & ~7; }
+__host__ __device__ inline int ceil32(int x) { return (x + 31) & ~31; }
+
+constexpr int kThreads = 256;
+constexpr int kMaxDynLds = 160 * 1024;
+
+// out[o][t] = epi(sum_k W[o][k] * in[k][t], o, t) for o < OP (multiple of 32), t < 32*TB.
+//   in : LDS [CP][RP], CP multiple of 8, rows >= real cin must be ZERO
+//   wp : packed image [CP/8][OP][2][4]  (pcr_pack_weight_f32)
+// The (cout-block, token-block) tiles are dealt round-robin to the waves, cout-block major, so
+// that the waves of a workgroup share weight lines in L1.
+template <class Epi>
+__device__ __forceinline__ void tile_dense(const float *__restrict__ in, int CP, int RP, int TB,
+                                           const float *__restrict__ wp, int OP, Epi epi) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int nItems = (OP >> 5) * TB;
+  const int KB = CP >> 3;
+  const size_t wstride = (size_t)OP * 2;  // f32x4 units per k-block
+  for (int item = wave; item < nItems; item += nwaves) {
+    const int cb = item / TB, tb = item - cb * TB;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    const f32x4 *wv = reinterpret_cast<const f32x4 *>(wp) + (size_t)(cb * 32 + l31) * 2 + h;
+    const float *bp = in + h * RP + tb * 32 + l31;
+#pragma unroll 2
+    for (int kb = 0; kb < KB; kb++) {
+      const f32x4 a = wv[(size_t)kb * wstride];
+      const float *b0 = bp + (kb * 8) * RP;
+      const float x0 = b0[0], x1 = b0[2 * RP], x2 = b0[4 * RP], x3 = b0[6 * RP];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], x0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], x1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], x2, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], x3, acc, 0, 0, 0);
+    }
+    const int t = tb * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int o = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      epi(acc[r], o, t);
+    }
+  }
+}
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x + 1.0f : (expf(x) - 1.0f) + 1.0f; }
+
+// LayerNorm over the channel rows [0,C) of buf ([C][RP]) for each of the T token columns, in
+// place; part = tid / T handles channels part, part+np, ...; partial sums meet in `red`
+// ([2][np][T] floats).  Two passes (mean, then centred variance), eps inside the sqrt, affine.
+__device__ __forceinline__ void tile_layernorm(float *buf, int C, int RP, int T, const float *g,
+                                               const float *bta, float *red) {
+  const int tid = threadIdx.x;
+  const int np = blockDim.x / T;  // T is 32 or 64 => np = 8 or 4
+  const int t = tid % T, part = tid / T;
+  float s = 0.f;
+  if (part < np)
+    for (int c = part; c < C; c += np) s += buf[c * RP + t];
+  if (part < np) red[part * T + t] = s;
+  __syncthreads();
+  float mean = 0.f;
+  for (int p = 0; p < np; p++) mean += red[p * T + t];
+  mean /= (float)C;
+  float v = 0.f;
+  if (part < np)
+    for (int c = part; c < C; c += np) {
+      float d = buf[c * RP + t] - mean;
+      v += d * d;
+    }
+  if (part < np) red[(np + part) * T + t] = v;
+  __syncthreads();
+  float var = 0.f;
+  for (int p = 0; p < np; p++) var += red[(np + p) * T + t];
+  var /= (float)C;
+  const float inv = 1.0f / sqrtf(var + 1e-5f);
+  if (part < np)
+    for (int c = part; c < C; c += np) buf[c * RP + t] = (buf[c * RP + t] - mean) * inv * g[c] + bta[c];
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------- grouped SA MLP ----
+struct SaArgs {
+  pcr_sa_params p;
+  int C0, C0P, RP, TB, CPW, rowsA, rowsB;
+};
+
+__global__ __launch_bounds__(kThreads) void sa_mlp_kernel(SaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const pcr_sa_params &p = a.p;
+  float *bufA = smem;
+  float *bufB = smem + a.rowsA * a.RP;
+  int *sidx = reinterpret_cast<int *>(bufB + a.rowsB * a.RP);
+  const int tid = threadIdx.x;
+  const size_t b = blockIdx.y;
+  const int c0 = blockIdx.x * a.CPW;
+  const int nc = (p.S - c0 < a.CPW) ? p.S - c0 : a.CPW;
+  const int rows = nc * p.K, ROWS = 32 * a.TB, RP = a.RP;
+  const int K = p.K, D = p.D, N = p.N;
+
+  for (int r = tid; r < ROWS; r += kThreads)
+    sidx[r] = r < rows ? p.idx[(b * p.S + c0) * K + r] : -1;
+  __syncthreads();
+
+  // gather + relative / edge features -> bufA [C0P][RP]
+  const float *xyz = p.xyz + b * N * 3;
+  const float *feat = D ? p.feat + b * D * N : nullptr;
+  for (int e = tid; e < a.C0P * ROWS; e += kThreads) {
+    const int ch = e / ROWS, r = e - ch * ROWS;
+    float v = 0.f;
+    if (ch < a.C0 && r < rows) {
+      const int s = c0 + r / K;
+      const int ci = p.centre_idx ? p.centre_idx[b * p.S + s] : s;
+      const int i = sidx[r];
+      if (ch < 3) {
+        v = xyz[i * 3 + ch] - xyz[ci * 3 + ch];
+      } else if (p.mode == 0) {
+        const int f = ch - 3;
+        if (f < D) v = feat[(size_t)f * N + ci];
+        else v = feat[(size_t)(f - D) * N + i] - feat[(size_t)(f - D) * N + ci];
+      } else {
+        v = feat[(size_t)(ch - 3) * N + i];
+      }
+    }
+    bufA[ch * RP + r] = v;
+  }
+  __syncthreads();
+
+  const int c1 = p.c1, c2 = p.c2, c3 = p.c3;
+  {
+    const float *sc = p.scale[0], *sh = p.shift[0];
+    const int lim = ceil8(c1);
+    tile_dense(bufA, a.C0P, RP, a.TB, p.wp[0], ceil32(c1), [&](float v, int o, int t) {
+      if (o < lim) bufB[o * RP + t] = o < c1 ? fmaxf(v * sc[o] + sh[o], 0.f) : 0.f;
+    });
+  }
+  __syncthreads();
+  {
+    const float *sc = p.scale[1], *sh = p.shift[1];
+    const int lim = ceil8(c2);
+    tile_dense(bufB, ceil8(c1), RP, a.TB, p.wp[1], ceil32(c2), [&](float v, int o, int t) {
+      if (o < lim) bufA[o * RP + t] = o < c2 ? fmaxf(v * sc[o] + sh[o], 0.f) : 0.f;
+    });
+  }
+  __syncthreads();
+  {
+    const float *sc = p.scale[2], *sh = p.shift[2];
+    tile_dense(bufA, ceil8(c2), RP, a.TB, p.wp[2], ceil32(c3), [&](float v, int o, int t) {
+      if (o < c3) bufB[o * RP + t] = fmaxf(v * sc[o] + sh[o], 0.f);
+    });
+  }
+  __syncthreads();
+  // max over the K neighbours of each centre
+  for (int e = tid; e < c3 * nc; e += kThreads) {
+    const int c = e / c3, o = e - c * c3;
+    const float *row = bufB + o * RP + c * K;
+    float m = row[0];
+    for (int k = 1; k < K; k++) m = fmaxf(m, row[k]);
+    p.out[(b * c3 + o) * p.S + c0 + c] = m;
+  }
+}
+
+// -------------------------------------------------------------- linear attention ----
+struct AttnArgs {
+  pcr_attn_params p;
+  int TB, RP;
+};
+
+// loads a [C][T] tile of a (B,C,L) tensor into LDS rows [0,CP), zero beyond C or beyond L
+__device__ __forceinline__ void load_tile(float *dst, int RP, const float *src, int C, int CP, int L,
+                                          int t0, int T) {
+  for (int e = threadIdx.x; e < CP * T; e += blockDim.x) {
+    const int c = e / T, t = e - c * T;
+    dst[c * RP + t] = (c < C && t0 + t < L) ? src[(size_t)c * L + t0 + t] : 0.f;
+  }
+}
+
+// xyz (L,3) rows t0.. -> LDS [8][RP] (rows 3..7 zero)
+__device__ __forceinline__ void load_xyz_tile(float *dst, int RP, const float *xyz, int L, int t0, int T) {
+  for (int e = threadIdx.x; e < 8 * T; e += blockDim.x) {
+    const int c = e / T, t = e - c * T;
+    dst[c * RP + t] = (c < 3 && t0 + t < L) ? xyz[(size_t)(t0 + t) * 3 + c] : 0.f;
+  }
+}
+
+// One workgroup per key-side cloud.  kv image per cloud: packed [d x d] matrix W'[v][dd] =
+// sum_s K[s][dd] V[s][v] / Sk for dd, v in the same head (zero elsewhere), followed by ksum[d].
+__global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const pcr_attn_params &p = a.p;
+  const int RP = a.RP, TB = a.TB, T = 32 * TB;
+  const int d = p.d, c2 = p.c2, c2P = ceil8(c2);
+  float *X = smem;                 // [c2P][RP]   key features
+  float *XP = X + c2P * RP;        // [c2P][RP]   + position encoding
+  float *P = XP + c2P * RP;        // [8][RP]     xyz
+  float *H = P + 8 * RP;           // [d][RP]     pos hidden / later K
+  float *Vb = H + d * RP;          // [d][RP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const size_t b = blockIdx.x;
+  const float *feat = p.feat_k + b * c2 * p.Sk;
+  const float *xyz = p.xyz_k + b * p.Sk * 3;
+  const int nT = (d >> 5) * (d >> 5);
+  const int dh = d / p.nhead;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+  float ksum = 0.f;
+
+  for (int t0 = 0; t0 < p.Sk; t0 += T) {
+    load_tile(X, RP, feat, c2, c2P, p.Sk, t0, T);
+    load_xyz_tile(P, RP, xyz, p.Sk, t0, T);
+    __syncthreads();
+    {  // pos hidden = relu(W0 xyz + b0)
+      const float *bb = p.pos0_b;
+      tile_dense(P, 8, RP, TB, p.pos0_w, d, [&](float v, int o, int t) { H[o * RP + t] = fmaxf(v + bb[o], 0.f); });
+    }
+    __syncthreads();
+    {  // XP = X + W2 hidden + b2
+      const float *bb = p.pos2_b;
+      tile_dense(H, d, RP, TB, p.pos2_w, ceil32(c2), [&](float v, int o, int t) {
+        if (o < c2P) XP[o * RP + t] = o < c2 ? X[o * RP + t] + (v + bb[o]) : 0.f;
+      });
+    }
+    __syncthreads();
+    {  // K = elu(Wk x)+1 (zero on padded tokens), V = Wv xp / Sk
+      const float *kin = p.k_pos ? XP : X;
+      const int valid = p.Sk - t0;
+      tile_dense(kin, c2P, RP, TB, p.wk, d, [&](float v, int o, int t) { H[o * RP + t] = t < valid ? elu1(v) : 0.f; });
+      const float invs = (float)p.Sk;
+      tile_dense(XP, c2P, RP, TB, p.wv, d, [&](float v, int o, int t) { Vb[o * RP + t] = t < valid ? v / invs : 0.f; });
+    }
+    __syncthreads();
+    if (tid < d) {
+      const float *row = H + tid * RP;
+      float s = 0.f;
+      for (int t = 0; t < T; t++) s += row[t];
+      ksum += s;
+    }
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int item = wave + 4 * it;
+      if (item < nT) {
+        const int ib = item / (d >> 5), jb = item - ib * (d >> 5);
+        const float *ap = H + (ib * 32 + l31) * RP + h;
+        const float *bp = Vb + (jb * 32 + l31) * RP + h;
+        for (int ks = 0; ks < T / 2; ks++)
+          acc[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc[it], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  float *kv = p.kv + b * ((size_t)d * d + d);
+#pragma unroll
+  for (int it = 0; it < 4; it++) {
+    const int item = wave + 4 * it;
+    if (item < nT) {
+      const int ib = item / (d >> 5), jb = item - ib * (d >> 5);
+      const int v = jb * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int dd = ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float val = (dd / dh == v / dh) ? acc[it][r] : 0.f;
+        const int kb = dd >> 3, rem = dd & 7;
+        kv[(((size_t)kb * d + v) * 2 + (rem & 1)) * 4 + (rem >> 1)] = val;
+      }
+    }
+  }
+  if (tid < d) kv[(size_t)d * d + tid] = ksum;
+}
+
+// One workgroup per (query cloud, tile of 32*TB query tokens).
+__global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const pcr_attn_params &p = a.p;
+  const int RP = a.RP, TB = a.TB, T = 32 * TB;
+  const int d = p.d, c1 = p.c1, cout = p.cout;
+  const int catC = c1 + d, catP = ceil8(catC);
+  const int rowsA = d > cout ? (d > p.cfinal ? d : p.cfinal) : (cout > p.cfinal ? cout : p.cfinal);
+  float *CAT = smem;                  // [catP][RP]  rows [0,c1) query feats, [c1,c1+d) message
+  float *A = CAT + catP * RP;         // [rowsA][RP]
+  float *Bf = A + rowsA * RP;         // [2d][RP]
+  float *P = Bf + 2 * d * RP;         // [8][RP]
+  float *zs = P + 8 * RP;             // [nhead][RP]
+  float *red = zs + p.nhead * RP;     // [16][T]
+  const int tid = threadIdx.x;
+  const size_t b = blockIdx.y;
+  const int t0 = blockIdx.x * T;
+  const float *feat = p.feat_q + b * c1 * p.Lq;
+  const size_t kb_ = p.kv_index ? (size_t)p.kv_index[b] : b;
+  const float *kv = p.kv + kb_ * ((size_t)d * d + d);
+  const float *ksum = kv + (size_t)d * d;
+  const int dh = d / p.nhead;
+
+  load_tile(CAT, RP, feat, c1, c1, p.Lq, t0, T);
+  for (int e = tid; e < (catP - c1) * T; e += kThreads) {  // zero message + pad rows
+    const int c = e / T, t = e - c * T;
+    CAT[(c1 + c) * RP + t] = 0.f;
+  }
+  if (p.q_pos) load_xyz_tile(P, RP, p.xyz_q + b * p.Lq * 3, p.Lq, t0, T);
+  __syncthreads();
+
+  const float *qin = CAT;
+  int qinP = ceil8(c1);
+  if (p.q_pos) {  // Self_Attention: q (and k,v) use feat + pos_mlp(xyz); requires c1 == c2
+    const float *b0 = p.pos0_b, *b2 = p.pos2_b;
+    tile_dense(P, 8, RP, TB, p.pos0_w, d, [&](float v, int o, int t) { Bf[o * RP + t] = fmaxf(v + b0[o], 0.f); });
+    __syncthreads();
+    tile_dense(Bf, d, RP, TB, p.pos2_w, ceil32(c1), [&](float v, int o, int t) {
+      if (o < c1) A[o * RP + t] = CAT[o * RP + t] + (v + b2[o]);
+    });
+    __syncthreads();
+    qin = A;
+    qinP = c1;  // c1 == d, multiple of 32
+  }
+  // the message rows of CAT double as zero padding of the query features when c1 % 8 != 0
+  tile_dense(qin, qinP, RP, TB, p.wq, d, [&](float v, int o, int t) { Bf[o * RP + t] = elu1(v); });
+  __syncthreads();
+  for (int e = tid; e < p.nhead * T; e += kThreads) {
+    const int hd = e / T, t = e - hd * T;
+    float z = 0.f;
+    for (int c = 0; c < dh; c++) z += Bf[(hd * dh + c) * RP + t] * ksum[hd * dh + c];
+    zs[hd * RP + t] = 1.0f / (z + 1e-6f);
+  }
+  __syncthreads();
+  {
+    const float sk = (float)p.Sk;
+    tile_dense(Bf, d, RP, TB, kv, d, [&](float v, int o, int t) { A[o * RP + t] = v * zs[(o / dh) * RP + t] * sk; });
+  }
+  __syncthreads();
+  tile_dense(A, d, RP, TB, p.wmerge, d, [&](float v, int o, int t) { CAT[(c1 + o) * RP + t] = v; });
+  __syncthreads();
+  tile_layernorm(CAT + c1 * RP, d, RP, T, p.ln1_g, p.ln1_b, red);
+  tile_dense(CAT, catP, RP, TB, p.wmlp0, 2 * d, [&](float v, int o, int t) { Bf[o * RP + t] = fmaxf(v, 0.f); });
+  __syncthreads();
+  tile_dense(Bf, 2 * d, RP, TB, p.wmlp2, ceil32(cout), [&](float v, int o, int t) {
+    if (o < cout) A[o * RP + t] = v;
+  });
+  __syncthreads();
+  tile_layernorm(A, cout, RP, T, p.ln2_g, p.ln2_b, red);
+  if (p.residual) {
+    for (int e = tid; e < cout * T; e += kThreads) {
+      const int c = e / T, t = e - c * T;
+      A[c * RP + t] = CAT[c * RP + t] + A[c * RP + t];
+    }
+    __syncthreads();
+  }
+  const float *res = A;
+  int cres = cout;
+  if (p.cfinal) {  // trailing 1x1 conv with bias (cov_final); needs cout % 8 == 0
+    const float *bf = p.bfinal;
+    const int cf = p.cfinal;
+    tile_dense(A, ceil8(cout), RP, TB, p.wfinal, ceil32(cf), [&](float v, int o, int t) {
+      if (o < cf) Bf[o * RP + t] = v + bf[o];
+    });
+    __syncthreads();
+    res = Bf;
+    cres = cf;
+  }
+  float *out = p.out + b * cres * p.Lq;
+  for (int e = tid; e < cres * T; e += kThreads) {
+    const int c = e / T, t = e - c * T;
+    if (t0 + t < p.Lq) out[(size_t)c * p.Lq + t0 + t] = res[c * RP + t];
+  }
+}
+
+// ------------------------------------------------------------------ pool + head ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+
+// GroupNorm of a length-n vector in LDS (one sample), groups of n/g channels; in place.
+__device__ __forceinline__ void vec_groupnorm(float *v, int n, int g, const float *gamma, const float *beta) {
+  const int gs = n / g;
+  const int tid = threadIdx.x;
+  float out = 0.f;
+  if (tid < n) {
+    const int g0 = (tid / gs) * gs;
+    float m = 0.f;
+    for (int i = 0; i < gs; i++) m += v[g0 + i];
+    m /= (float)gs;
+    float var = 0.f;
+    for (int i = 0; i < gs; i++) { float dd = v[g0 + i] - m; var += dd * dd; }
+    var /= (float)gs;
+    out = (v[tid] - m) * (1.0f / sqrtf(var + 1e-5f)) * gamma[tid] + beta[tid];
+  }
+  __syncthreads();
+  if (tid < n) v[tid] = out;
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kThreads) void pool_head_kernel(pcr_head_params p) {
+  __shared__ float x[256], y[256], z[256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t pr = blockIdx.x;
+  const int C = p.C, L = p.L, n = 2 * C;
+  const float *o1 = p.o + pr * C * L;
+  const float *o2 = p.o + (pr + p.P) * C * L;
+  for (int c = wave; c < C; c += kThreads / 64) {
+    float mx = -INFINITY, sm = 0.f;
+    for (int i = lane; i < L; i += 64) {
+      const float a = o1[(size_t)c * L + i], bq = o2[(size_t)c * L + i];
+      mx = fmaxf(mx, fmaxf(a, bq));
+      sm += a + bq;
+    }
+    mx = wave_max(mx);
+    sm = wave_sum(sm);
+    if (lane == 0) { x[c] = mx; x[C + c] = sm / (float)(2 * L); }
+  }
+  __syncthreads();
+  if (p.pooled && tid < n) p.pooled[pr * n + tid] = x[tid];
+  if (tid < n) {
+    const float *w = p.w1 + (size_t)tid * n;
+    float s = 0.f;
+    for (int i = 0; i < n; i++) s += w[i] * x[i];
+    y[tid] = s;
+  }
+  __syncthreads();
+  vec_groupnorm(y, n, p.groups, p.gn1_g, p.gn1_b);
+  if (tid < n) y[tid] = fmaxf(y[tid], 0.f);
+  __syncthreads();
+  if (tid < n) {
+    const float *w = p.w2 + (size_t)tid * n;
+    float s = 0.f;
+    for (int i = 0; i < n; i++) s += w[i] * y[i];
+    z[tid] = s;
+  }
+  __syncthreads();
+  vec_groupnorm(z, n, p.groups, p.gn2_g, p.gn2_b);
+  float part = 0.f;
+  if (tid < n) part = fmaxf(z[tid] + x[tid], 0.f) * p.w_out[tid];
+  part = wave_sum(part);
+  if (lane == 0) y[wave] = part;  // y is free after the second matvec
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.f;
+    for (int w = 0; w < kThreads / 64; w++) s += y[w];
+    p.logits[pr] = s + p.b_out[0];
+  }
+}
+
+// pool 'both' of a (B,C,L) tensor: out (B,2C) = [max over L, mean over L]
+__global__ __launch_bounds__(kThreads) void pool_both_kernel(const float *__restrict__ x,
+                                                             float *__restrict__ out, int C, int L) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t b = blockIdx.x;
+  const float *xb = x + b * C * L;
+  for (int c = wave; c < C; c += kThreads / 64) {
+    float mx = -INFINITY, sm = 0.f;
+    for (int i = lane; i < L; i += 64) {
+      const float a = xb[(size_t)c * L + i];
+      mx = fmaxf(mx, a);
+      sm += a;
+    }
+    mx = wave_max(mx);
+    sm = wave_sum(sm);
+    if (lane == 0) { out[b * 2 * C + c] = mx; out[b * 2 * C + C + c] = sm / (float)L; }
+  }
+}
+
+// ------------------------------------------------------------------- generic dense ----
+struct DenseArgs {
+  const float *x, *wp, *scale, *shift;
+  float *y;
+  int cin, cout, L, act, TB, RP;
+};
+
+__global__ __launch_bounds__(kThreads) void dense_kernel(DenseArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int RP = a.RP, T = 32 * a.TB;
+  const int cinP = ceil8(a.cin), coutP = ceil32(a.cout);
+  float *X = smem;
+  float *Y = smem + cinP * RP;
+  const size_t b = blockIdx.y;
+  const int t0 = blockIdx.x * T;
+  load_tile(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
+  __syncthreads();
+  const float *sc = a.scale, *sh = a.shift;
+  const int cout = a.cout, act = a.act;
+  tile_dense(X, cinP, RP, a.TB, a.wp, coutP, [&](float v, int o, int t) {
+    if (o < cout) {
+      float r = v * (sc ? sc[o] : 1.0f) + (sh ? sh[o] : 0.0f);
+      Y[o * RP + t] = act ? fmaxf(r, 0.f) : r;
+    }
+  });
+  __syncthreads();
+  float *out = a.y + b * a.cout * a.L;
+  for (int e = threadIdx.x; e < a.cout * T; e += kThreads) {
+    const int c = e / T, t = e - c * T;
+    if (t0 + t < a.L) out[(size_t)c * a.L + t0 + t] = Y[c * RP + t];
+  }
+}
+
+template <class Kern>
+bool allow_big_lds(Kern k) {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             kMaxDynLds) == hipSuccess;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------ C ABI ----
+PCR_EXPORT long pcr_packed_weight_floats(int cout, int cin) {
+  if (cout < 1 || cin < 1) return 0;
+  return (long)ceil8(cin) * ceil32(cout);
+}
+
+PCR_EXPORT int pcr_pack_weight_f32(const float *w, int cout, int cin, float *packed) {
+  if (!w || !packed || cout < 1 || cin < 1) return PCR_ERR_INVALID;
+  const int CP = ceil8(cin), OP = ceil32(cout);
+  for (int kb = 0; kb < CP / 8; kb++)
+    for (int o = 0; o < OP; o++)
+      for (int h = 0; h < 2; h++)
+        for (int j = 0; j < 4; j++) {
+          const int k = kb * 8 + j * 2 + h;
+          packed[(((size_t)kb * OP + o) * 2 + h) * 4 + j] = (o < cout && k < cin) ? w[(size_t)o * cin + k] : 0.f;
+        }
+  return PCR_OK;
+}
+
+PCR_EXPORT long pcr_attn_kv_floats(int d) { return (long)d * d + d; }
+
+PCR_EXPORT int pcr_sa_mlp_f32(const pcr_sa_params *pp, pcr_stream_t stream) {
+  if (!pp) return PCR_ERR_INVALID;
+  const pcr_sa_params &p = *pp;
+  if (p.B < 0 || p.N < 1 || p.S < 0 || p.K < 1 || p.D < 0 || p.c1 < 1 || p.c2 < 1 || p.c3 < 1 ||
+      !p.xyz || !p.idx || !p.out || (p.D && !p.feat) || (p.mode != 0 && p.mode != 1))
+    return PCR_ERR_INVALID;
+  for (int l = 0; l < 3; l++)
+    if (!p.wp[l] || !p.scale[l] || !p.shift[l]) return PCR_ERR_INVALID;
+  if (p.B == 0 || p.S == 0) return PCR_OK;
+  if (p.B > 65535) return PCR_ERR_INVALID;
+  SaArgs a;
+  a.p = p;
+  a.C0 = 3 + (p.mode == 0 ? 2 * p.D : p.D);
+  a.C0P = ceil8(a.C0);
+  a.rowsA = a.C0P > ceil8(p.c2) ? a.C0P : ceil8(p.c2);
+  a.rowsB = ceil8(p.c1) > p.c3 ? ceil8(p.c1) : p.c3;
+  // centres per workgroup: as many as keep rows <= 128 (at least one) and LDS <= 150 KiB
+  int cpw = 128 / p.K;
+  if (cpw < 1) cpw = 1;
+  size_t lds = 0;
+  for (;; cpw--) {
+    a.CPW = cpw;
+    a.TB = (cpw * p.K + 31) / 32;
+    a.RP = 32 * a.TB + 1;
+    lds = ((size_t)(a.rowsA + a.rowsB) * a.RP + 32 * a.TB) * sizeof(float);
+    if (lds <= 150 * 1024 || cpw == 1) break;
+  }
+  if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
+  static bool ok = allow_big_lds(sa_mlp_kernel);
+  (void)ok;
+  hipLaunchKernelGGL(sa_mlp_kernel, dim3((p.S + a.CPW - 1) / a.CPW, p.B), dim3(kThreads), lds,
+                     pcr_s(stream), a);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+static int attn_check(const pcr_attn_params &p) {
+  if (p.B < 0 || p.Lq < 1 || p.Sk < 1 || p.c1 < 1 || p.c2 < 1 || p.cout < 1 || p.nhead < 1) return 1;
+  if (p.d < 32 || p.d > 128 || (p.d & 31) || p.d % p.nhead) return 1;  // d_model in {32,64,96,128}
+  if (!p.feat_q || !p.feat_k || !p.xyz_k || !p.kv || !p.pos0_w || !p.pos0_b || !p.pos2_w || !p.pos2_b ||
+      !p.wq || !p.wk || !p.wv || !p.wmerge || !p.wmlp0 || !p.wmlp2 || !p.ln1_g || !p.ln1_b || !p.ln2_g ||
+      !p.ln2_b)
+    return 1;
+  if (p.q_pos && (!p.xyz_q || p.c1 != p.c2 || p.c1 != p.d)) return 1;
+  if (p.residual && p.cout != p.c1) return 1;
+  if (p.cfinal && (!p.wfinal || !p.bfinal || (p.cout & 7))) return 1;
+  return 0;
+}
+
+PCR_EXPORT int pcr_attn_kv_f32(const pcr_attn_params *pp, pcr_stream_t stream) {
+  if (!pp || attn_check(*pp)) return PCR_ERR_INVALID;
+  if (pp->B == 0) return PCR_OK;
+  AttnArgs a;
+  a.p = *pp;
+  a.TB = 1;
+  a.RP = 32 * a.TB + 1;
+  const int c2P = ceil8(pp->c2);
+  size_t lds = ((size_t)(2 * c2P + 8 + 2 * pp->d) * a.RP) * sizeof(float);
+  if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
+  static bool ok = allow_big_lds(attn_kv_kernel);
+  (void)ok;
+  hipLaunchKernelGGL(attn_kv_kernel, dim3(pp->B), dim3(kThreads), lds, pcr_s(stream), a);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_attn_apply_f32(const pcr_attn_params *pp, pcr_stream_t stream) {
+  if (!pp || attn_check(*pp) || !pp->out) return PCR_ERR_INVALID;
+  if (pp->B == 0) return PCR_OK;
+  if (pp->B > 65535) return PCR_ERR_INVALID;
+  const pcr_attn_params &p = *pp;
+  AttnArgs a;
+  a.p = p;
+  a.TB = 1;
+  a.RP = 32 * a.TB + 1;
+  const int T = 32 * a.TB;
+  const int catP = ceil8(p.c1 + p.d);
+  int rowsA = p.d > p.cout ? p.d : p.cout;
+  if (p.cfinal > rowsA) rowsA = p.cfinal;
+  size_t lds = ((size_t)(catP + rowsA + 2 * p.d + 8 + p.nhead) * a.RP + 16 * T) * sizeof(float);
+  if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
+  static bool ok = allow_big_lds(attn_apply_kernel);
+  (void)ok;
+  hipLaunchKernelGGL(attn_apply_kernel, dim3((p.Lq + T - 1) / T, p.B), dim3(kThreads), lds,
+                     pcr_s(stream), a);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_pool_head_f32(const pcr_head_params *pp, pcr_stream_t stream) {
+  if (!pp) return PCR_ERR_INVALID;
+  const pcr_head_params &p = *pp;
+  if (p.P < 0 || p.C < 1 || 2 * p.C > 256 || p.L < 1 || p.groups < 1 || (2 * p.C) % p.groups || !p.o ||
+      !p.w1 || !p.w2 || !p.gn1_g || !p.gn1_b || !p.gn2_g || !p.gn2_b || !p.w_out || !p.b_out || !p.logits)
+    return PCR_ERR_INVALID;
+  if (p.P == 0) return PCR_OK;
+  hipLaunchKernelGGL(pool_head_kernel, dim3(p.P), dim3(kThreads), 0, pcr_s(stream), p);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_pool_both_f32(const float *x, float *out, int B, int C, int L, pcr_stream_t stream) {
+  if (!x || !out || B < 0 || C < 1 || L < 1) return PCR_ERR_INVALID;
+  if (B == 0) return PCR_OK;
+  hipLaunchKernelGGL(pool_both_kernel, dim3(B), dim3(kThreads), 0, pcr_s(stream), x, out, C, L);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_dense_f32(const float *x, const float *wp, const float *scale, const float *shift,
+                             float *y, int B, int cin, int cout, int L, int act, pcr_stream_t stream) {
+  if (!x || !wp || !y || B < 0 || cin < 1 || cout < 1 || L < 1) return PCR_ERR_INVALID;
+  if (B == 0) return PCR_OK;
+  if (B > 65535) return PCR_ERR_INVALID;
+  DenseArgs a{x, wp, scale, shift, y, cin, cout, L, act, 1, 33};
+  size_t lds = ((size_t)(ceil8(cin) + cout) * a.RP) * sizeof(float);
+  if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
+  static bool ok = allow_big_lds(dense_kernel);
+  (void)ok;
+  hipLaunchKernelGGL(dense_kernel, dim3((L + 31) / 32, B), dim3(kThreads), lds, pcr_s(stream), a);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}

@@ -1,0 +1,581 @@
+// Point ops of the ReID hot path for gfx950: FPS, ball query, heap kNN, gather / group,
+// three-NN and three-interpolate.  Semantics (and every index output, bit for bit) follow the
+// reference's dormant CUDA ops under mmdet3d/ops (cited in include/pcr.h); the kernels
+// themselves are designed for CDNA4: 64-wide waves, cloud-resident LDS tiles with broadcast
+// reads, one barrier per FPS step, register-resident running distances.
+//
+// Build with -ffp-contract=off (distance expressions must not be fused; see pcr_common.h).
+#include "pcr_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------- FPS ----
+// One workgroup per cloud.  Thread tid owns the candidates k = tid, tid+block, ... exactly as
+// in the reference (furthest_point_sample_cuda.cu:56-71) so its per-thread candidate (first
+// maximum in increasing k, initial best=-1/besti=0) is identical; the cross-thread merge is a
+// max over a packed 64-bit key that encodes the total order of the reference's halving tree
+// (__update, :17-23): larger value wins, ties go to the slot that survives the tree, which is
+// the tid with the smallest BIT-REVERSED value (stride-s step keeps tid over tid+s).
+constexpr int kFpsPpt = 4;        // candidates per thread held in registers (N <= 4*block)
+constexpr int kFpsLdsPts = 4096;  // clouds up to this size are staged in LDS (48 KiB)
+
+template <bool DIST, bool REG>
+__global__ void fps_kernel(const float *__restrict__ data, float *__restrict__ temp,
+                           int *__restrict__ idxs, int n, int m, int block, int logb,
+                           int stage_xyz) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned long long *skey = reinterpret_cast<unsigned long long *>(smem_raw);  // [2][16]
+  float *sx = reinterpret_cast<float *>(smem_raw + 256);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  const size_t cloud = blockIdx.x;
+  data += DIST ? cloud * n * n : cloud * n * 3;
+  temp += cloud * n;
+  idxs += cloud * m;
+  if (m <= 0) return;
+
+  if (!DIST && stage_xyz)
+    for (int i = tid; i < 3 * n; i += blockDim.x) sx[i] = data[i];
+
+  float px[kFpsPpt], py[kFpsPpt], pz[kFpsPpt], t[kFpsPpt];
+  if (REG) {
+#pragma unroll
+    for (int p = 0; p < kFpsPpt; p++) {
+      int k = tid + p * block;
+      bool ok = tid < block && k < n;
+      t[p] = ok ? temp[k] : 0.f;
+      px[p] = py[p] = pz[p] = 0.f;
+      if (!DIST && ok) { px[p] = data[k * 3]; py[p] = data[k * 3 + 1]; pz[p] = data[k * 3 + 2]; }
+    }
+  }
+  __syncthreads();
+
+  const uint32_t rev = logb ? (__brev((uint32_t)tid) >> (32 - logb)) : 0u;
+  const uint32_t tie = (uint32_t)(block - 1) - rev;  // larger = preferred by the merge tree
+  int old = 0;
+  if (tid == 0) idxs[0] = 0;
+
+  for (int j = 1; j < m; j++) {
+    float x1 = 0.f, y1 = 0.f, z1 = 0.f;
+    if (!DIST) {
+      if (stage_xyz) { x1 = sx[old * 3]; y1 = sx[old * 3 + 1]; z1 = sx[old * 3 + 2]; }
+      else { x1 = data[old * 3]; y1 = data[old * 3 + 1]; z1 = data[old * 3 + 2]; }
+    }
+    float best = -1.f;
+    int besti = 0;
+    if (tid < block) {
+      if (REG) {
+#pragma unroll
+        for (int p = 0; p < kFpsPpt; p++) {
+          int k = tid + p * block;
+          if (k < n) {
+            float d = DIST ? data[(size_t)old * n + k] : pcr_sqdist3(x1, y1, z1, px[p], py[p], pz[p]);
+            float d2 = fminf(d, t[p]);
+            t[p] = d2;
+            besti = d2 > best ? k : besti;
+            best = d2 > best ? d2 : best;
+          }
+        }
+      } else {
+        for (int k = tid; k < n; k += block) {
+          float d;
+          if (DIST) d = data[(size_t)old * n + k];
+          else if (stage_xyz) d = pcr_sqdist3(x1, y1, z1, sx[k * 3], sx[k * 3 + 1], sx[k * 3 + 2]);
+          else d = pcr_sqdist3(x1, y1, z1, data[k * 3], data[k * 3 + 1], data[k * 3 + 2]);
+          float d2 = fminf(d, temp[k]);
+          temp[k] = d2;
+          besti = d2 > best ? k : besti;
+          best = d2 > best ? d2 : best;
+        }
+      }
+    }
+    unsigned long long key = 0ull;
+    if (tid < block)
+      key = ((unsigned long long)pcr_orderable(best + 0.0f) << 32) |
+            (unsigned long long)((tie << 22) | (uint32_t)besti);
+    key = pcr_wave_max_u64(key);
+    if (nw > 1) {
+      unsigned long long *slot = skey + (j & 1) * 16;
+      if (lane == 0) slot[wave] = key;
+      __syncthreads();
+      int w = lane & 15;
+      key = w < nw ? slot[w] : 0ull;
+#pragma unroll
+      for (int s = 8; s >= 1; s >>= 1) {
+        unsigned long long o = __shfl_xor(key, s, 64);
+        key = o > key ? o : key;
+      }
+    }
+    old = (int)(key & 0x3FFFFFull);
+    if (tid == 0) idxs[j] = old;
+  }
+
+  if (REG) {
+#pragma unroll
+    for (int p = 0; p < kFpsPpt; p++) {
+      int k = tid + p * block;
+      if (tid < block && k < n) temp[k] = t[p];
+    }
+  }
+}
+
+int fps_launch(bool dist, const float *data, float *temp, int *idx, int B, int N, int M,
+               hipStream_t st) {
+  if (!data || !temp || !idx || B < 0 || N < 1 || N >= (1 << 22) || M < 0) return PCR_ERR_INVALID;
+  if (B == 0 || M == 0) return PCR_OK;
+  int logb = 0;
+  while ((2 << logb) <= N && logb < 10) logb++;  // block = min(1024, 2^floor(log2 N))
+  int block = 1 << logb;
+  int threads = block < 64 ? 64 : block;
+  bool reg = N <= kFpsPpt * block;
+  int stage = (!dist && N <= kFpsLdsPts) ? 1 : 0;
+  size_t lds = 256 + (stage ? (size_t)3 * N * sizeof(float) : 0);
+  dim3 g(B), b(threads);
+  if (dist) {
+    if (reg) hipLaunchKernelGGL((fps_kernel<true, true>), g, b, lds, st, data, temp, idx, N, M, block, logb, stage);
+    else hipLaunchKernelGGL((fps_kernel<true, false>), g, b, lds, st, data, temp, idx, N, M, block, logb, stage);
+  } else {
+    if (reg) hipLaunchKernelGGL((fps_kernel<false, true>), g, b, lds, st, data, temp, idx, N, M, block, logb, stage);
+    else hipLaunchKernelGGL((fps_kernel<false, false>), g, b, lds, st, data, temp, idx, N, M, block, logb, stage);
+  }
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+// ------------------------------------------------------------------------ ball query ----
+// One thread per centre; the cloud streams through a 1024-point LDS tile that every lane reads
+// at the same address (broadcast, conflict-free), instead of N uncoalesced AoS global loads per
+// thread as in ball_query_cuda.cu:38-52.  Hits are written straight to the output row, the
+// padding (first hit) once at the end.
+constexpr int kBqTile = 1024;
+
+__global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict__ centres,
+                                                         const float *__restrict__ xyz,
+                                                         int *__restrict__ idx, int n, int m,
+                                                         float min_r2, float max_r2, int K) {
+  __shared__ float tile[3 * kBqTile];
+  const int tid = threadIdx.x;
+  const size_t b = blockIdx.y;
+  const int p = blockIdx.x * 256 + tid;
+  const bool valid = p < m;
+  float cx = 0.f, cy = 0.f, cz = 0.f;
+  if (valid) {
+    const float *c = centres + (b * m + p) * 3;
+    cx = c[0]; cy = c[1]; cz = c[2];
+  }
+  int *out = idx + (b * m + (valid ? p : 0)) * K;
+  const float *cloud = xyz + b * n * 3;
+  int cnt = 0, first = 0;
+  bool done = !valid;
+  for (int base = 0; base < n; base += kBqTile) {
+    int tn = n - base < kBqTile ? n - base : kBqTile;
+    __syncthreads();
+    for (int i = tid; i < 3 * tn; i += 256) tile[i] = cloud[(size_t)base * 3 + i];
+    __syncthreads();
+    if (!done) {
+      for (int k = 0; k < tn; k++) {
+        float d2 = pcr_sqdist3(tile[3 * k], tile[3 * k + 1], tile[3 * k + 2], cx, cy, cz);
+        if (d2 == 0.f || (d2 >= min_r2 && d2 < max_r2)) {
+          if (cnt == 0) first = base + k;
+          out[cnt] = base + k;
+          if (++cnt >= K) { done = true; break; }
+        }
+      }
+    }
+    if (__syncthreads_and(done ? 1 : 0)) break;
+  }
+  if (valid)
+    for (int l = cnt; l < K; l++) out[l] = first;  // first == 0 when nothing was hit
+}
+
+// --------------------------------------------------------------------------- heap kNN ----
+// Same max-heap insertion and heap-sort sequence as knn_cuda.cu:27-94, so equal distances leave
+// in the reference's order.  The per-thread heaps live in LDS as [slot][thread] (bank =
+// thread, conflict-free whatever slot each lane touches) instead of 800 B of scratch per thread.
+constexpr int kKnnTile = 256;
+
+__global__ __launch_bounds__(64) void knn_heap_kernel(const float *__restrict__ xyz,
+                                                      const float *__restrict__ centres,
+                                                      int *__restrict__ idx,
+                                                      float *__restrict__ dist2, int n, int m,
+                                                      int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float *hd = reinterpret_cast<float *>(smem_raw);
+  int *hi = reinterpret_cast<int *>(smem_raw) + K * 64;
+  float *tile = reinterpret_cast<float *>(smem_raw) + 2 * K * 64;
+  const int tid = threadIdx.x;
+  const size_t b = blockIdx.y;
+  const int p = blockIdx.x * 64 + tid;
+  const bool valid = p < m;
+#define HD(i) hd[(i) * 64 + tid]
+#define HI(i) hi[(i) * 64 + tid]
+  float cx = 0.f, cy = 0.f, cz = 0.f;
+  if (valid) {
+    const float *c = centres + (b * m + p) * 3;
+    cx = c[0]; cy = c[1]; cz = c[2];
+  }
+  for (int i = 0; i < K; i++) { HD(i) = 1e10f; HI(i) = 0; }
+  const float *cloud = xyz + b * n * 3;
+
+  auto reheap = [&](int k) {
+    int root = 0, child = 1;
+    while (child < k) {
+      if (child + 1 < k && HD(child + 1) > HD(child)) child++;
+      float dr = HD(root), dc = HD(child);
+      if (dr > dc) return;
+      int ir = HI(root), ic = HI(child);
+      HD(root) = dc; HD(child) = dr;
+      HI(root) = ic; HI(child) = ir;
+      root = child;
+      child = root * 2 + 1;
+    }
+  };
+
+  for (int base = 0; base < n; base += kKnnTile) {
+    int tn = n - base < kKnnTile ? n - base : kKnnTile;
+    __syncthreads();
+    for (int i = tid; i < 3 * tn; i += 64) tile[i] = cloud[(size_t)base * 3 + i];
+    __syncthreads();
+    if (valid) {
+      for (int k = 0; k < tn; k++) {
+        float d2 = pcr_sqdist3(tile[3 * k], tile[3 * k + 1], tile[3 * k + 2], cx, cy, cz);
+        if (d2 < HD(0)) {
+          HD(0) = d2;
+          HI(0) = base + k;
+          reheap(K);
+        }
+      }
+    }
+  }
+  if (valid) {
+    for (int i = K - 1; i > 0; i--) {
+      float d0 = HD(0), di = HD(i);
+      int i0 = HI(0), ii = HI(i);
+      HD(0) = di; HD(i) = d0;
+      HI(0) = ii; HI(i) = i0;
+      reheap(i);
+    }
+    int *oi = idx + (b * m + p) * K;
+    float *od = dist2 + (b * m + p) * K;
+    for (int i = 0; i < K; i++) { oi[i] = HI(i); od[i] = HD(i); }
+  }
+#undef HD
+#undef HI
+}
+
+// ------------------------------------------------------------------- gather / group ----
+// Elementwise over the OUTPUT (coalesced stores along the last axis; the gathered reads hit
+// one (b,c) row of at most 4N bytes that stays in L2).
+__global__ void gather_fwd_kernel(const float *__restrict__ feat, const int *__restrict__ idx,
+                                  float *__restrict__ out, int C, int N, int M, size_t total) {
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x) {
+    size_t bc = e / M;
+    int p = (int)(e - bc * M);
+    size_t b = bc / C;
+    out[e] = feat[bc * N + idx[b * M + p]];
+  }
+}
+
+// Scatter-add, float atomics as in gather_points_cuda.cu:69 / group_points_cuda.cu:30 (the
+// summation order is unspecified there too).  M here is the flattened S*K for grouping.
+__global__ void gather_bwd_kernel(const float *__restrict__ grad_out, const int *__restrict__ idx,
+                                  float *__restrict__ grad_feat, int C, int N, int M,
+                                  size_t total) {
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x) {
+    size_t bc = e / M;
+    int p = (int)(e - bc * M);
+    size_t b = bc / C;
+    atomicAdd(grad_feat + bc * N + idx[b * M + p], grad_out[e]);
+  }
+}
+
+int gather_launch(bool bwd, const float *a, const int *idx, float *o, int B, int C, int N, int M,
+                  hipStream_t st) {
+  if (!a || !idx || !o || B < 0 || C < 0 || N < 1 || M < 0) return PCR_ERR_INVALID;
+  size_t total = (size_t)B * C * M;
+  if (total == 0) return PCR_OK;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (bwd) hipLaunchKernelGGL(gather_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, idx, o, C, N, M, total);
+  else hipLaunchKernelGGL(gather_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, idx, o, C, N, M, total);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+// ------------------------------------------------------------------------- three NN ----
+constexpr int kNnTile = 1024;
+
+__global__ __launch_bounds__(256) void three_nn_kernel(const float *__restrict__ unknown,
+                                                       const float *__restrict__ known,
+                                                       float *__restrict__ dist2,
+                                                       int *__restrict__ idx, int n, int m) {
+  __shared__ float tile[3 * kNnTile];
+  const int tid = threadIdx.x;
+  const size_t b = blockIdx.y;
+  const int p = blockIdx.x * 256 + tid;
+  const bool valid = p < n;
+  float ux = 0.f, uy = 0.f, uz = 0.f;
+  if (valid) {
+    const float *u = unknown + (b * n + p) * 3;
+    ux = u[0]; uy = u[1]; uz = u[2];
+  }
+  double best1 = 1e40, best2 = 1e40, best3 = 1e40;
+  int i1 = 0, i2 = 0, i3 = 0;
+  const float *cloud = known + b * m * 3;
+  for (int base = 0; base < m; base += kNnTile) {
+    int tn = m - base < kNnTile ? m - base : kNnTile;
+    __syncthreads();
+    for (int i = tid; i < 3 * tn; i += 256) tile[i] = cloud[(size_t)base * 3 + i];
+    __syncthreads();
+    if (valid) {
+      for (int k = 0; k < tn; k++) {
+        float d = pcr_sqdist3(tile[3 * k], tile[3 * k + 1], tile[3 * k + 2], ux, uy, uz);
+        if (d < best1) {
+          best3 = best2; i3 = i2; best2 = best1; i2 = i1; best1 = d; i1 = base + k;
+        } else if (d < best2) {
+          best3 = best2; i3 = i2; best2 = d; i2 = base + k;
+        } else if (d < best3) {
+          best3 = d; i3 = base + k;
+        }
+      }
+    }
+  }
+  if (valid) {
+    float *o = dist2 + (b * n + p) * 3;
+    int *oi = idx + (b * n + p) * 3;
+    o[0] = (float)best1; o[1] = (float)best2; o[2] = (float)best3;
+    oi[0] = i1; oi[1] = i2; oi[2] = i3;
+  }
+}
+
+__global__ void three_interp_fwd_kernel(const float *__restrict__ feat,
+                                        const int *__restrict__ idx,
+                                        const float *__restrict__ w, float *__restrict__ out,
+                                        int C, int M, int N, size_t total) {
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x) {
+    size_t bc = e / N;
+    int p = (int)(e - bc * N);
+    size_t b = bc / C;
+    const int *i = idx + (b * N + p) * 3;
+    const float *ww = w + (b * N + p) * 3;
+    const float *f = feat + bc * M;
+    float a0 = ww[0] * f[i[0]];
+    float a1 = ww[1] * f[i[1]];
+    float a2 = ww[2] * f[i[2]];
+    float s = a0 + a1;
+    out[e] = s + a2;
+  }
+}
+
+__global__ void three_interp_bwd_kernel(const float *__restrict__ grad_out,
+                                        const int *__restrict__ idx,
+                                        const float *__restrict__ w,
+                                        float *__restrict__ grad_feat, int C, int N, int M,
+                                        size_t total) {
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x) {
+    size_t bc = e / N;
+    int p = (int)(e - bc * N);
+    size_t b = bc / C;
+    const int *i = idx + (b * N + p) * 3;
+    const float *ww = w + (b * N + p) * 3;
+    float *g = grad_feat + bc * M;
+    float go = grad_out[e];
+    atomicAdd(g + i[0], go * ww[0]);
+    atomicAdd(g + i[1], go * ww[1]);
+    atomicAdd(g + i[2], go * ww[2]);
+  }
+}
+
+constexpr int kKnnPThreads = 256;
+// -------------------------------------------------------------- PT neighbour search ----
+// One wave per query; lane l holds the distances to points l, l+64, ... in registers; K rounds
+// of (local argmin, wave argmin on a packed (distance,index) key, knock-out).  The cloud is
+// staged once per workgroup as SoA in LDS (broadcast reads of the query, stride-1 reads of the
+// candidates).  Output order: (distance, index) ascending.
+template <int T>
+__global__ __launch_bounds__(kKnnPThreads) void knn_prefix_kernel(const float *__restrict__ xyz,
+                                                              int *__restrict__ idx, int n, int S,
+                                                              int K, int qpw) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *sx = smem, *sy = smem + n, *sz = smem + 2 * n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t b = blockIdx.y;
+  const float *cloud = xyz + b * n * 3;
+  for (int i = tid; i < n; i += kKnnPThreads) {
+    sx[i] = cloud[3 * i];
+    sy[i] = cloud[3 * i + 1];
+    sz[i] = cloud[3 * i + 2];
+  }
+  __syncthreads();
+  const int q0 = blockIdx.x * qpw;
+  const int q1 = (q0 + qpw < S) ? q0 + qpw : S;
+  for (int q = q0 + wave; q < q1; q += kKnnPThreads / 64) {
+    const float qx = sx[q], qy = sy[q], qz = sz[q];
+    float d[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+      int i = lane + 64 * t;
+      d[t] = i < n ? pcr_sqdist3(qx, qy, qz, sx[i], sy[i], sz[i]) : INFINITY;
+    }
+    int mine = 0;
+    for (int k = 0; k < K; k++) {
+      float bd = d[0];
+      int bt = 0;
+#pragma unroll
+      for (int t = 1; t < T; t++)
+        if (d[t] < bd) { bd = d[t]; bt = t; }
+      unsigned long long key = ((unsigned long long)pcr_orderable(bd) << 32) | (unsigned)(lane + 64 * bt);
+      key = pcr_wave_min_u64(key);
+      const int win = (int)(key & 0xFFFFFFFFull);
+      if (lane == k) mine = win;
+      if (lane == (win & 63)) {
+        const int wt = win >> 6;
+#pragma unroll
+        for (int t = 0; t < T; t++) d[t] = (t == wt) ? INFINITY : d[t];
+      }
+    }
+    if (lane < K) idx[(b * S + q) * K + lane] = mine;
+  }
+}
+
+
+}  // namespace
+
+// ------------------------------------------------------------------------------ C ABI ----
+PCR_EXPORT int pcr_abi_version(void) { return 1; }
+
+PCR_EXPORT const char *pcr_status_string(int status) {
+  switch (status) {
+    case PCR_OK: return "ok";
+    case PCR_ERR_INVALID: return "invalid argument or unsupported configuration";
+    case PCR_ERR_LAUNCH: return "kernel launch failed";
+    default: return "unknown status";
+  }
+}
+
+PCR_EXPORT int pcr_fps_f32(const float *xyz, float *temp, int *idx, int B, int N, int M,
+                           pcr_stream_t stream) {
+  return fps_launch(false, xyz, temp, idx, B, N, M, pcr_s(stream));
+}
+
+PCR_EXPORT int pcr_fps_dist_f32(const float *dist, float *temp, int *idx, int B, int N, int M,
+                                pcr_stream_t stream) {
+  return fps_launch(true, dist, temp, idx, B, N, M, pcr_s(stream));
+}
+
+PCR_EXPORT int pcr_ball_query_f32(const float *centres, const float *xyz, int *idx, int B, int N,
+                                  int M, float min_r, float max_r, int K, pcr_stream_t stream) {
+  if (!centres || !xyz || !idx || B < 0 || N < 1 || M < 0 || K < 1) return PCR_ERR_INVALID;
+  if (B == 0 || M == 0) return PCR_OK;
+  if (B > 65535) return PCR_ERR_INVALID;
+  float max_r2 = max_r * max_r, min_r2 = min_r * min_r;
+  hipLaunchKernelGGL(ball_query_kernel, dim3((M + 255) / 256, B), dim3(256), 0, pcr_s(stream),
+                     centres, xyz, idx, N, M, min_r2, max_r2, K);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_knn_f32(const float *xyz, const float *centres, int *idx, float *dist2, int B,
+                           int N, int M, int K, pcr_stream_t stream) {
+  if (!xyz || !centres || !idx || !dist2 || B < 0 || N < 1 || M < 0 || K < 1 || K > 100)
+    return PCR_ERR_INVALID;
+  if (B == 0 || M == 0) return PCR_OK;
+  if (B > 65535) return PCR_ERR_INVALID;
+  size_t lds = (size_t)2 * K * 64 * 4 + 3 * kKnnTile * 4;
+  hipLaunchKernelGGL(knn_heap_kernel, dim3((M + 63) / 64, B), dim3(64), lds, pcr_s(stream), xyz,
+                     centres, idx, dist2, N, M, K);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_gather_fwd_f32(const float *feat, const int *idx, float *out, int B, int C,
+                                  int N, int M, pcr_stream_t stream) {
+  return gather_launch(false, feat, idx, out, B, C, N, M, pcr_s(stream));
+}
+
+PCR_EXPORT int pcr_gather_bwd_f32(const float *grad_out, const int *idx, float *grad_feat, int B,
+                                  int C, int N, int M, pcr_stream_t stream) {
+  return gather_launch(true, grad_out, idx, grad_feat, B, C, N, M, pcr_s(stream));
+}
+
+PCR_EXPORT int pcr_group_fwd_f32(const float *feat, const int *idx, float *out, int B, int C,
+                                 int N, int S, int K, pcr_stream_t stream) {
+  if (S < 0 || K < 0) return PCR_ERR_INVALID;
+  return gather_launch(false, feat, idx, out, B, C, N, S * K, pcr_s(stream));
+}
+
+PCR_EXPORT int pcr_group_bwd_f32(const float *grad_out, const int *idx, float *grad_feat, int B,
+                                 int C, int N, int S, int K, pcr_stream_t stream) {
+  if (S < 0 || K < 0) return PCR_ERR_INVALID;
+  return gather_launch(true, grad_out, idx, grad_feat, B, C, N, S * K, pcr_s(stream));
+}
+
+PCR_EXPORT int pcr_three_nn_f32(const float *unknown, const float *known, float *dist2, int *idx,
+                                int B, int N, int M, pcr_stream_t stream) {
+  if (!unknown || !known || !dist2 || !idx || B < 0 || N < 0 || M < 1) return PCR_ERR_INVALID;
+  if (B == 0 || N == 0) return PCR_OK;
+  if (B > 65535) return PCR_ERR_INVALID;
+  hipLaunchKernelGGL(three_nn_kernel, dim3((N + 255) / 256, B), dim3(256), 0, pcr_s(stream),
+                     unknown, known, dist2, idx, N, M);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_three_interp_fwd_f32(const float *feat, const int *idx, const float *weight,
+                                        float *out, int B, int C, int M, int N,
+                                        pcr_stream_t stream) {
+  if (!feat || !idx || !weight || !out || B < 0 || C < 0 || M < 1 || N < 0) return PCR_ERR_INVALID;
+  size_t total = (size_t)B * C * N;
+  if (total == 0) return PCR_OK;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(three_interp_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, pcr_s(stream),
+                     feat, idx, weight, out, C, M, N, total);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_three_interp_bwd_f32(const float *grad_out, const int *idx, const float *weight,
+                                        float *grad_feat, int B, int C, int N, int M,
+                                        pcr_stream_t stream) {
+  if (!grad_out || !idx || !weight || !grad_feat || B < 0 || C < 0 || M < 1 || N < 0)
+    return PCR_ERR_INVALID;
+  size_t total = (size_t)B * C * N;
+  if (total == 0) return PCR_OK;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(three_interp_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, pcr_s(stream),
+                     grad_out, idx, weight, grad_feat, C, N, M, total);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_knn_prefix_f32(const float *xyz, int *idx, int B, int N, int S, int K,
+                                  pcr_stream_t stream) {
+  if (!xyz || !idx || B < 0 || N < 1 || S < 0 || S > N || K < 1 || K > 64 || K > N || N > 4096)
+    return PCR_ERR_INVALID;
+  if (B == 0 || S == 0) return PCR_OK;
+  if (B > 65535) return PCR_ERR_INVALID;
+  const int qpw = 32;
+  dim3 g((S + qpw - 1) / qpw, B), blk(kKnnPThreads);
+  size_t lds = (size_t)3 * N * sizeof(float);
+  hipStream_t st = pcr_s(stream);
+#define PCR_KNN_CASE(T) hipLaunchKernelGGL((knn_prefix_kernel<T>), g, blk, lds, st, xyz, idx, N, S, K, qpw)
+  if (N <= 64) PCR_KNN_CASE(1);
+  else if (N <= 128) PCR_KNN_CASE(2);
+  else if (N <= 256) PCR_KNN_CASE(4);
+  else if (N <= 512) PCR_KNN_CASE(8);
+  else if (N <= 1024) PCR_KNN_CASE(16);
+  else if (N <= 2048) PCR_KNN_CASE(32);
+  else PCR_KNN_CASE(64);
+#undef PCR_KNN_CASE
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+

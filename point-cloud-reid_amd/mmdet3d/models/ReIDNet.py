@@ -1,0 +1,366 @@
+"""`ReIDNet`: siamese point-cloud re-identification model with the reference's model-level plugin
+API (bentherien/point-cloud-reid, mmdet3d/models/ReIDNet.py:40-96 module_obj/build_module,
+:111-776 ReIDNet), so that configs_reid/* build unchanged through FUSIONMODELS / build_model.
+
+What runs where: both clouds of every pair go through the backbone in one batch
+(siamese_forward, ref :311-332); the two-stage bidirectional cross-attention (xcorr_eff, ref
+:231-247) runs on all 2B clouds at once with a partner index instead of four separate calls;
+'point-cat' + pool 'both' + match head (ref :526-534, :444-462) is a single launch.  All of it
+is libpcr_hip.so; this file only owns parameters, shapes and the mmdet-style entry points.
+"""
+import copy
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from pcr_amd import engine
+from pcr_amd import _lib as L
+from .attention import corss_attention, cross_lin_attn, local_self_attention
+from .backbone_net import Pointnet_Backbone
+from .builder import FUSIONMODELS
+from .lanegcn_nets import LinearRes
+from .pointnet import PointNet
+
+
+class _OutOfScope(nn.Module):
+    def __init__(self, *a, **k):
+        super().__init__()
+        raise NotImplementedError("%s is outside the siamese point-cloud hot path rebuilt here "
+                                  "(SURVEY.md section 8f)" % type(self).__name__)
+
+
+class PostRes(_OutOfScope):
+    pass
+
+
+class DGCNN(_OutOfScope):
+    pass
+
+
+# type names a config may use (reference ReIDNet.py:40-75)
+module_obj = {
+    "Linear": nn.Linear,
+    "ReLU": nn.ReLU,
+    "LSTM": nn.LSTM,
+    "GroupNorm": nn.GroupNorm,
+    "Embedding": nn.Embedding,
+    "LayerNorm": nn.LayerNorm,
+    "PostRes": PostRes,
+    "LinearRes": LinearRes,
+    "Pointnet_Backbone": Pointnet_Backbone,
+    "corss_attention": corss_attention,
+    "local_self_attention": local_self_attention,
+    "Conv1d": nn.Conv1d,
+    "Conv2d": nn.Conv2d,
+    "BatchNorm1d": nn.BatchNorm1d,
+    "Sigmoid": nn.Sigmoid,
+    "cross_lin_attn": cross_lin_attn,
+    "dgcnn": DGCNN,
+    "PointNet": PointNet,
+}
+
+
+def build_module(cfg):
+    """None / {} -> None, list -> nn.Sequential, dict -> module_obj[type](**rest).
+    Like the reference (:77-96) this consumes the 'type' key of the dict it is given."""
+    if cfg is None or cfg == {}:
+        return None
+    if isinstance(cfg, list):
+        return build_sequential(cfg)
+    cls_ = module_obj[cfg["type"]]
+    del cfg["type"]
+    return cls_(**cfg)
+
+
+def build_sequential(module_list):
+    if module_list is None or module_list == {}:
+        return None
+    return nn.Sequential(*[build_module(cfg) for cfg in module_list])
+
+
+def get_accuracy(y_true, y_prob):
+    assert y_true.ndim == 1 and y_true.size() == y_prob.size()
+    y_prob = y_prob > 0.5
+    return (y_true == y_prob).sum().item() / y_true.size(0)
+
+
+@FUSIONMODELS.register_module()
+class ReIDNet(nn.Module):
+    def __init__(self, hidden_size, backbone, cls_head, match_head, shape_head, fp_head, downsample,
+                 cross_stage1, local_stage1, cross_stage2, local_stage2, match_type="xcorr", pool_type="max",
+                 combine="cat", compute_summary=True, train_cfg=None, test_cfg=None,
+                 backbone_list=[512, 256, 128], use_dgcnn=False,
+                 losses_to_use=dict(kl=True, match=True, cls=True, shape=True, fp=True, dense=False),
+                 output_sequence_size=32, alpha=dict(kl=1, match=1, cls=1, shape=1, fp=1, triplet=1, dense=1),
+                 triplet_sample_num=5, triplet_loss=dict(margin=0.2, p=2), eval_only=False, use_o=False,
+                 eval_flip=False):
+        super().__init__()
+        self.eval_only = eval_only
+        self.hidden_size = hidden_size
+        self.match_type = match_type
+        self.backbone = build_module(backbone)
+        self.cls_head = build_module(cls_head)
+        self.match_head = build_module(match_head)
+        self.shape_head = build_module(shape_head)
+        self.fp_head = build_module(fp_head)
+        self.downsample = build_module(downsample)
+        self.cross_stage1 = build_module(cross_stage1)
+        self.local_stage1 = build_module(local_stage1)
+        self.cross_stage2 = build_module(cross_stage2)
+        self.local_stage2 = build_module(local_stage2)
+
+        self.losses_to_use = dict(kl=False, match=True, cls=False, shape=False, fp=False, dense=False)
+        self.losses_to_use.update(losses_to_use)
+        self.backbone_list = backbone_list
+        self.output_sequence_size = output_sequence_size
+        self.pool_type = pool_type
+        self.bce = nn.BCEWithLogitsLoss()
+        self.alpha = alpha
+        self.use_o = use_o
+        self.eval_flip = eval_flip
+        self.verbose = False
+        self.sampling = None
+        self.compute_summary = compute_summary
+        self.use_dgcnn = use_dgcnn
+        self.combine = combine
+        self.triplet_sample_num = triplet_sample_num
+        self._head_plan = None
+        self._head_key = None
+
+    # ------------------------------------------------------------------ inputs
+    @staticmethod
+    def _stack(*lists):
+        return [torch.stack(x, dim=0) for x in lists]
+
+    @staticmethod
+    def _cat(*lists):
+        return [torch.cat(x, dim=0) for x in lists]
+
+    def preprocess_inputs(self, sparse_1, sparse_2, dense_1, dense_2, label_1, label_2, id_1, id_2):
+        sparse_1, sparse_2, dense_1, dense_2 = self._stack(sparse_1, sparse_2, dense_1, dense_2)
+        label_1, label_2, id_1, id_2 = self._cat(label_1, label_2, id_1, id_2)
+        if self.eval_flip:
+            return sparse_2, sparse_1, dense_2, dense_1, label_2, label_1, id_2, id_1
+        return sparse_1, sparse_2, dense_1, dense_2, label_1, label_2, id_1, id_2
+
+    def preprocess_inputs_size(self, sparse_1, sparse_2, dense_1, dense_2, label_1, label_2, id_1, id_2,
+                               size_1, size_2):
+        sparse_1, sparse_2, dense_1, dense_2 = self._stack(sparse_1, sparse_2, dense_1, dense_2)
+        return (sparse_1, sparse_2, dense_1, dense_2,
+                *self._cat(label_1, label_2, id_1, id_2, size_1, size_2))
+
+    def preprocess_inputs_size_vis(self, sparse_1, sparse_2, dense_1, dense_2, label_1, label_2, id_1, id_2,
+                                   size_1, size_2, vis_1, vis_2):
+        sparse_1, sparse_2, dense_1, dense_2 = self._stack(sparse_1, sparse_2, dense_1, dense_2)
+        return (sparse_1, sparse_2, dense_1, dense_2,
+                *self._cat(label_1, label_2, id_1, id_2, size_1, size_2, vis_1, vis_2))
+
+    # ------------------------------------------------------------------ encoder
+    def forward_inference(self, pts_batched):
+        with torch.no_grad():
+            return self.backbone(pts_batched, self.backbone_list)
+
+    def siamese_forward(self, sparse_1, sparse_2):
+        """(B,N,3) x 2 -> xyz1, xyz2 (B,N,3), h1, h2 (B,C,N); one backbone pass over 2B clouds"""
+        assert sparse_1.shape == sparse_2.shape
+        b, num_points, _ = sparse_1.shape
+        both = torch.cat([sparse_1, sparse_2], dim=0)
+        if self.use_dgcnn or isinstance(self.backbone, PointNet):
+            # per-point 1024-d encoder features, reduced per point by `downsample` (ref :316-324)
+            xyz, h = self.backbone(both.permute(0, 2, 1).contiguous(), self.backbone_list)
+            if self.downsample is not None:
+                from pcr_amd import rows
+                h = rows.downsample_points(self.downsample, h)
+            xyz = xyz.permute(0, 2, 1)
+            return xyz[:b], xyz[b:], h[:b], h[b:]
+        xyz, h = self.backbone(both, self.backbone_list)
+        return xyz[:b], xyz[b:], h[:b], h[b:]
+
+    # ------------------------------------------------------------------ matching
+    @staticmethod
+    def _pair_batch(a1, a2):
+        """two halves -> one (2B, ...) tensor, without a copy when they already are adjacent views"""
+        if (a1.is_contiguous() and a2.is_contiguous() and a1.untyped_storage().data_ptr() == a2.untyped_storage().data_ptr()
+                and a2.storage_offset() == a1.storage_offset() + a1.numel()):
+            return a1.as_strided((2 * a1.shape[0],) + tuple(a1.shape[1:]), a1.stride(), a1.storage_offset())
+        return torch.cat([a1, a2], dim=0)
+
+    def _xcorr_eff_batched(self, h1, xyz1, h2, xyz2):
+        b = h1.shape[0]
+        feats = self._pair_batch(h1, h2).contiguous()
+        xyz = self._pair_batch(xyz1, xyz2).contiguous()
+        partner = torch.cat([torch.arange(b, 2 * b), torch.arange(0, b)]).to(device=feats.device, dtype=torch.int32)
+        s1 = self.cross_stage1.forward_paired(feats, xyz, partner)
+        return self.cross_stage2.forward_paired(s1, xyz, partner)     # (2B,C,N): [o1; o2]
+
+    def xcorr_eff(self, o1, xyz1, o2, xyz2, combine="add"):
+        b = o1.shape[0]
+        o = self._xcorr_eff_batched(o1, xyz1, o2, xyz2)
+        o1, o2 = o[:b], o[b:]
+        if self.combine == "add":
+            out = o1 + o2
+        elif self.combine == "minus":
+            out = o1 - o2
+        elif self.combine == "cat":
+            out = torch.cat([o1, o2], dim=1)
+        elif self.combine == "point-cat":
+            out = torch.cat([o1, o2], dim=2)
+        else:
+            raise NotImplementedError(self.combine)
+        return out, o1, o2
+
+    def _head(self, device):
+        if not (isinstance(self.match_head, nn.Sequential) and len(self.match_head) == 2
+                and isinstance(self.match_head[0], LinearRes) and isinstance(self.match_head[1], nn.Linear)):
+            raise L.PcrError("fused match head expects [LinearRes, Linear] as in every ReID config")
+        key = (str(device), engine.param_version(self.match_head))
+        if self._head_key != key:
+            self._head_plan = engine.HeadPlan(self.match_head[0], self.match_head[1], device)
+            self._head_key = key
+        return self._head_plan
+
+    def get_pooled_feats(self, h_cat):
+        if self.pool_type == "both":
+            from pcr_amd import rows
+            return rows.pool_both(h_cat)
+        raise NotImplementedError("pool_type=%r: only 'both' is used by the point-cat ReID configs" % self.pool_type)
+
+    def _match_logits(self, h1, h2, xyz1, xyz2):
+        if self.match_type != "xcorr_eff" or self.combine != "point-cat" or self.pool_type != "both":
+            raise NotImplementedError("fused matching covers match_type='xcorr_eff', combine='point-cat', "
+                                      "pool_type='both' (all point ReID configs); got %s/%s/%s"
+                                      % (self.match_type, self.combine, self.pool_type))
+        o = self._xcorr_eff_batched(h1, xyz1, h2, xyz2)
+        return self._head(o.device).run(o), o
+
+    def match_forward_inference(self, h1, h2, xyz1, xyz2):
+        return self._match_logits(h1, h2, xyz1, xyz2)[0]
+
+    def get_match_supervision(self, h1, h2, xyz1, xyz2, id_1, id_2):
+        return h1, h2, xyz1, xyz2, (id_1 == id_2).float()
+
+    def match_forward(self, h1, h2, xyz1, xyz2, match, log_vars, device, prefix=""):
+        if not self.losses_to_use["match"]:
+            return None, torch.tensor(0.0, requires_grad=True, device=device), (None, None)
+        b = h1.shape[0]
+        match_preds, o = self._match_logits(h1, h2, xyz1, xyz2)
+        match_loss = self.bce(match_preds, match) * self.alpha["match"]
+        if self.compute_summary and log_vars is not None:
+            pred = (torch.sigmoid(match_preds) > 0.5)
+            log_vars[prefix + "match_loss"] = match_loss.item()
+            log_vars[prefix + "match_acc"] = pred.float().eq(match).float().mean().item()
+            gt_bins = torch.bincount(match.long())
+            log_vars[prefix + "num_preds_0"] = gt_bins[0].item()
+            log_vars[prefix + "num_preds_1"] = gt_bins[1].item() if len(gt_bins) > 1 else 0
+            pred_bins = torch.bincount(pred.long())
+            log_vars[prefix + "num_gt_0"] = pred_bins[0].item()
+            log_vars[prefix + "num_gt_1"] = pred_bins[1].item() if len(pred_bins) > 1 else 0
+        return match_preds, match_loss, (o[:b], o[b:])
+
+    def _check_losses(self):
+        # the constructor default enables every auxiliary loss (as in the reference), but every ReID
+        # config switches them off and builds no heads for them; only the match loss is on the hot path
+        for k in ("kl", "cls", "shape", "fp", "dense", "triplet"):
+            if self.losses_to_use.get(k, False):
+                raise NotImplementedError("loss '%s' is not part of the siamese matching hot path; the ReID "
+                                          "configs train/evaluate with match only (SURVEY.md section 8)" % k)
+
+    # ------------------------------------------------------------------ mmdet-style entry points
+    def forward(self, return_loss=True, **kwargs):
+        if return_loss:
+            return self.forward_train(**kwargs)
+        return self.forward_test(**kwargs)
+
+    def forward_train(self, sparse_1, sparse_2, dense_1, dense_2, label_1, label_2, id_1, id_2):
+        if self.eval_only:
+            exit(0)     # reference behaviour: testing configs stop at the first training iteration (:587-588)
+        self._check_losses()
+        log_vars, losses = {}, {}
+        sparse_1, sparse_2, dense_1, dense_2, label_1, label_2, id_1, id_2 = self.preprocess_inputs(
+            sparse_1, sparse_2, dense_1, dense_2, label_1, label_2, id_1, id_2)
+        device = sparse_1.device
+        xyz1, xyz2, h1, h2 = self.siamese_forward(sparse_1, sparse_2)
+        h1, h2, xyz1, xyz2, match = self.get_match_supervision(h1, h2, xyz1, xyz2, id_1, id_2)
+        _, match_loss, _ = self.match_forward(h1, h2, xyz1, xyz2, match, log_vars, device)
+        losses["reid_loss"] = match_loss
+        return losses, log_vars
+
+    def forward_test(self, sparse_1, sparse_2, dense_1, dense_2, label_1, label_2, id_1, id_2, size_1, size_2,
+                     vis_1, vis_2, *args, **kwargs):
+        self._check_losses()
+        (sparse_1, sparse_2, dense_1, dense_2, label_1, label_2, id_1, id_2, size_1, size_2, vis_1,
+         vis_2) = self.preprocess_inputs_size_vis(sparse_1, sparse_2, dense_1, dense_2, label_1, label_2, id_1,
+                                                  id_2, size_1, size_2, vis_1, vis_2)
+        device = sparse_1.device
+        xyz1, xyz2, h1, h2 = self.siamese_forward(sparse_1, sparse_2)
+        h1, h2, xyz1, xyz2, match = self.get_match_supervision(h1, h2, xyz1, xyz2, id_1, id_2)
+        match_preds, match_loss, _ = self.match_forward(h1, h2, xyz1, xyz2, match, None, device)
+        labels = torch.cat([label_1, label_2], dim=0)
+        zero = torch.tensor([0.0])
+        results = OrderedDict()
+        results["val_dense_loss"] = zero.clone()
+        results["val_fp_loss"] = zero.clone()
+        results["val_match_loss"] = torch.tensor([match_loss])
+        results["val_shape_loss"] = zero.clone()
+        results["val_cls_loss"] = zero.clone()
+        results["val_kl_loss"] = zero.clone()
+        results["val_match_preds"] = match_preds
+        results["val_match_gt"] = match
+        results["val_cls_preds"] = None
+        results["val_cls_gt"] = labels
+        results["val_fp_preds"] = None
+        results["val_fp_gt"] = (labels > 9).float()
+        results["match_classes"] = torch.cat([label_1.unsqueeze(1), label_2.unsqueeze(1)], dim=1)
+        results["is_fp"] = torch.logical_or(label_1 > 9, label_2 > 9)
+        results["num_points"] = torch.cat([size_1.unsqueeze(1), size_2.unsqueeze(1)], dim=1)
+        results["val_vis_gt_all"] = torch.cat([vis_1.unsqueeze(1), vis_2.unsqueeze(1)], dim=1)
+        return [results]
+
+    @staticmethod
+    def _parse_losses(losses):
+        """mmdet BaseDetector._parse_losses: mean every entry, sum those whose key contains 'loss',
+        all-reduce the logged scalars across ranks when torch.distributed is initialised."""
+        log_vars = OrderedDict()
+        for name, value in losses.items():
+            if isinstance(value, torch.Tensor):
+                log_vars[name] = value.mean()
+            elif isinstance(value, list):
+                log_vars[name] = sum(v.mean() for v in value)
+            else:
+                raise TypeError("%s is not a tensor or list of tensors" % name)
+        loss = sum(v for k, v in log_vars.items() if "loss" in k)
+        log_vars["loss"] = loss
+        import torch.distributed as dist
+        for name, value in log_vars.items():
+            if dist.is_available() and dist.is_initialized():
+                value = value.data.clone()
+                dist.all_reduce(value.div_(dist.get_world_size()))
+            log_vars[name] = value.item()
+        return loss, log_vars
+
+    def train_step(self, data, optimizer):
+        losses, log_vars_train = self(**data)
+        loss, log_vars = self._parse_losses(losses)
+        log_vars.update(log_vars_train)
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data["sparse_1"]))
+
+    def val_step(self, data, optimizer=None):
+        losses, _ = self(**data)
+        loss, log_vars = self._parse_losses(losses)
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data["sparse_1"]))
+
+    def extract_feat(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def show_result(self):
+        raise NotImplementedError
+
+    def aug_test(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def simple_test(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def init_weights(self):
+        pass

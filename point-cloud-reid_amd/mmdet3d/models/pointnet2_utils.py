@@ -1,0 +1,146 @@
+"""Set-abstraction and feature-propagation layers of the reference's "Point-Transformer"
+backbone (STNet-style PointNet++ with linear attention), re-implemented as thin parameter
+holders over the fused gfx950 kernels.
+
+Reference: mmdet3d/models/pointnet2_utils.py -- Self_Attention :55-114, sample_and_group_edge
+:242-288, PointNetSetAbstractionEdgeSA :309-360, FP_SA :362-437, PointNetFeaturePropagationSA
+:439-473.  Parameter names/shapes are identical so reference checkpoints load unchanged
+(SURVEY.md Appendix A), including the FP layers' never-used mlp_convs / mlp_bns.
+
+Forward = three launches per SA layer (pcr_knn_prefix_f32, pcr_sa_mlp_f32, pcr_attn_kv/apply)
+and two per FP layer; the unfused chain of the reference (distance matrix, argsort, gathers,
+cat, conv/bn/relu, max, einsum attention) never materialises.
+"""
+import torch
+import torch.nn as nn
+
+from pcr_amd import engine
+from pcr_amd import _lib as L
+
+
+class _Planned(nn.Module):
+    """caches the packed weight image of a module; rebuilt when a parameter changes or moves"""
+
+    def _plan(self, device, build):
+        key = (str(device), engine.param_version(self))
+        if getattr(self, "_plan_key", None) != key:
+            if self.training:
+                raise L.PcrError(
+                    "%s: the fused HIP path implements eval-mode inference (BatchNorm folded from running "
+                    "statistics); call .eval() -- training kernels are listed as next work in DESIGN.md"
+                    % type(self).__name__)
+            object.__setattr__(self, "_plan_obj", build(device))
+            object.__setattr__(self, "_plan_key", key)
+        return self._plan_obj
+
+
+def _attn_holder(m, pos_name, d_model, c_q, c_k, c_pos_out, c_ff_in, out_dim):
+    setattr(m, pos_name, nn.Sequential(nn.Linear(3, d_model), nn.ReLU(), nn.Linear(d_model, c_pos_out)))
+    m.q_proj = nn.Linear(c_q, d_model, bias=False)
+    m.k_proj = nn.Linear(c_k, d_model, bias=False)
+    m.v_proj = nn.Linear(c_k, d_model, bias=False)
+    m.merge = nn.Linear(d_model, d_model, bias=False)
+    m.mlp = nn.Sequential(nn.Linear(c_ff_in, d_model * 2, bias=False), nn.ReLU(True),
+                          nn.Linear(d_model * 2, out_dim, bias=False))
+    m.norm1 = nn.LayerNorm(d_model)
+    m.norm2 = nn.LayerNorm(out_dim)
+
+
+class Self_Attention(_Planned):
+    """feat (B,C,N), xyz (B,N,3) -> (B,C,N): linear self-attention with xyz position encoding on
+    q, k and v, LayerNorm, feed-forward on [feat, msg], LayerNorm, residual."""
+
+    def __init__(self, d_model, nhead, attention="linear"):
+        super().__init__()
+        self.dim = d_model // nhead
+        self.nhead = nhead
+        _attn_holder(self, "pos_mlp", d_model, d_model, d_model, d_model, d_model * 2, d_model)
+
+    def forward(self, feat, xyz, mask=None):
+        assert mask is None, "masks are never passed by the ReID model path"
+        plan = self._plan(feat.device, lambda dev: engine.AttnPlan(self, "pos_mlp", dev, self.nhead,
+                                                                   q_pos=True, k_pos=True, residual=True))
+        feat = feat.contiguous()
+        xyz = xyz.contiguous()
+        return plan.run(feat, xyz, feat, xyz)
+
+
+class PointNetSetAbstractionEdgeSA(_Planned):
+    def __init__(self, npoint, radius, nsample, mlp, sampling, use_xyz=True, group_all=False, use_knn=False):
+        super().__init__()
+        if group_all or sampling != "RANDOM" or not use_knn:
+            raise NotImplementedError("the ReID backbone only builds sampling='RANDOM', use_knn=True SA layers "
+                                      "(backbone_net.py:50-81)")
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+        self.use_xyz, self.sampling, self.use_knn, self.group_all = use_xyz, sampling, use_knn, group_all
+        mlp = list(mlp)
+        if use_xyz:
+            mlp[0] += 3
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last = mlp[0]
+        for out_channel in mlp[1:]:
+            self.mlp_convs.append(nn.Conv2d(last, out_channel, 1))
+            self.mlp_bns.append(nn.BatchNorm2d(out_channel))
+            last = out_channel
+        self.self_attention = Self_Attention(last, 2, "linear")
+
+    def forward(self, xyz, points, numpoints):
+        """xyz (B,N,3); points (B,D,N) or None -> (new_xyz (B,S,3), (B,D',S)); S = numpoints"""
+        plan = self._plan(xyz.device, lambda dev: engine.SaPlan(list(self.mlp_convs), list(self.mlp_bns), dev, mode=0))
+        xyz = xyz.contiguous()
+        idx = engine.knn_prefix(xyz, numpoints, self.nsample)
+        pooled = plan.run(xyz, None if points is None else points.contiguous(), idx)
+        new_xyz = xyz[:, :numpoints].contiguous()
+        return new_xyz, self.self_attention(pooled, new_xyz)
+
+
+class FP_SA(_Planned):
+    """fine <- coarse linear cross-attention (keys without, values with position encoding), no residual"""
+
+    def __init__(self, last_channel, feat1_dim, feat2_dim, d_model, out_dim, nhead, attention="linear"):
+        super().__init__()
+        self.dim = d_model // nhead
+        self.nhead = nhead
+        _attn_holder(self, "pos_mlp2", d_model, feat1_dim, feat2_dim, feat2_dim, feat1_dim + d_model, out_dim)
+        self._final = None
+
+    def fuse_final_conv(self, conv):
+        """let the trailing 1x1 Conv1d (Pointnet_Backbone.cov_final) run inside the same launch"""
+        object.__setattr__(self, "_final", conv)
+        object.__setattr__(self, "_plan_key", None)
+
+    def forward(self, feat1, xyz1, feat2, xyz2, mask=None):
+        assert mask is None
+        plan = self._plan(feat1.device, lambda dev: engine.AttnPlan(self, "pos_mlp2", dev, self.nhead, q_pos=False,
+                                                                    k_pos=False, residual=False, final=self._final))
+        return plan.run(feat1.contiguous(), xyz1.contiguous(), feat2.contiguous(), xyz2.contiguous())
+
+    def _plan(self, device, build):
+        key = (str(device), engine.param_version(self),
+               None if self._final is None else engine.param_version(self._final))
+        if getattr(self, "_plan_key", None) != key:
+            if self.training:
+                raise L.PcrError("FP_SA: the fused HIP path implements eval-mode inference; call .eval()")
+            object.__setattr__(self, "_plan_obj", build(device))
+            object.__setattr__(self, "_plan_key", key)
+        return self._plan_obj
+
+
+class PointNetFeaturePropagationSA(nn.Module):
+    def __init__(self, mlp, mlp_inte):
+        super().__init__()
+        # constructed but never used by forward, exactly as in the reference (:442-449): they exist
+        # only so that checkpoints (and DDP's unused-parameter handling) see the same tensors
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last = mlp[0]
+        for out_channel in mlp[1:]:
+            self.mlp_convs.append(nn.Conv1d(last, out_channel, 1))
+            self.mlp_bns.append(nn.BatchNorm1d(out_channel))
+            last = out_channel
+        self.interpolation = FP_SA(last_channel=mlp_inte[0], feat1_dim=mlp_inte[1], feat2_dim=mlp_inte[2],
+                                   d_model=mlp_inte[3], out_dim=mlp_inte[4], nhead=2, attention="linear")
+
+    def forward(self, xyz1, xyz2, points1, points2):
+        return self.interpolation(points1, xyz1, points2, xyz2)

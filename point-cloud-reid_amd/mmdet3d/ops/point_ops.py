@@ -1,0 +1,216 @@
+"""`mmdet3d.ops` point-op functions with the reference's names, argument meaning and error
+behaviour, as torch.autograd.Functions over the C ABI in include/pcr.h.
+
+Reference wrappers mirrored (bentherien/point-cloud-reid, mmdet3d/ops/...):
+  furthest_point_sample/furthest_point_sample.py:7-78, ball_query/ball_query.py:7-54,
+  knn/knn.py:7-71, gather_points/gather_points.py:7-50, group_points/group_points.py:169-220,
+  interpolate/three_nn.py:8-45, interpolate/three_interpolate.py:8-59.
+Index outputs are int32 and non-differentiable; index ops return None gradients.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from pcr_amd import _lib as L
+
+
+def _i32(*shape, device):
+    return torch.empty(shape, dtype=torch.int32, device=device)
+
+
+def _f32(*shape, device):
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
+class FurthestPointSampling(Function):
+    @staticmethod
+    def forward(ctx, points_xyz, num_points):
+        assert points_xyz.is_contiguous()
+        L.require_cuda(points_xyz)
+        B, N = points_xyz.size()[:2]
+        out = _i32(B, num_points, device=points_xyz.device)
+        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=points_xyz.device)
+        L.check(L.load().pcr_fps_f32(L.ptr(points_xyz), L.ptr(temp), L.ptr(out), B, N, num_points,
+                                     L.stream_ptr()), "pcr_fps_f32")
+        ctx.mark_non_differentiable(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None
+
+
+class FurthestPointSamplingWithDist(Function):
+    @staticmethod
+    def forward(ctx, points_dist, num_points):
+        assert points_dist.is_contiguous()
+        L.require_cuda(points_dist)
+        B, N, _ = points_dist.size()
+        out = _i32(B, num_points, device=points_dist.device)
+        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=points_dist.device)
+        L.check(L.load().pcr_fps_dist_f32(L.ptr(points_dist), L.ptr(temp), L.ptr(out), B, N, num_points,
+                                          L.stream_ptr()), "pcr_fps_dist_f32")
+        ctx.mark_non_differentiable(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None
+
+
+class BallQuery(Function):
+    @staticmethod
+    def forward(ctx, min_radius, max_radius, sample_num, xyz, center_xyz):
+        assert center_xyz.is_contiguous()
+        assert xyz.is_contiguous()
+        assert min_radius < max_radius
+        L.require_cuda(xyz, center_xyz)
+        B, N, _ = xyz.size()
+        npoint = center_xyz.size(1)
+        idx = _i32(B, npoint, sample_num, device=xyz.device)
+        L.check(L.load().pcr_ball_query_f32(L.ptr(center_xyz), L.ptr(xyz), L.ptr(idx), B, N, npoint,
+                                            ctypes.c_float(min_radius), ctypes.c_float(max_radius),
+                                            sample_num, L.stream_ptr()), "pcr_ball_query_f32")
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None, None, None
+
+
+class KNN(Function):
+    @staticmethod
+    def forward(ctx, k, xyz, center_xyz=None, transposed=False):
+        assert k > 0
+        if center_xyz is None:
+            center_xyz = xyz
+        if transposed:
+            xyz = xyz.transpose(2, 1).contiguous()
+            center_xyz = center_xyz.transpose(2, 1).contiguous()
+        assert xyz.is_contiguous()
+        assert center_xyz.is_contiguous()
+        assert center_xyz.device == xyz.device, "center_xyz and xyz should be put on the same device"
+        L.require_cuda(xyz)
+        B, npoint, _ = center_xyz.shape
+        N = xyz.shape[1]
+        idx = _i32(B, npoint, k, device=xyz.device)
+        dist2 = _f32(B, npoint, k, device=xyz.device)
+        with torch.cuda.device(xyz.device):
+            L.check(L.load().pcr_knn_f32(L.ptr(xyz), L.ptr(center_xyz), L.ptr(idx), L.ptr(dist2), B, N,
+                                         npoint, k, L.stream_ptr()), "pcr_knn_f32")
+        idx = idx.transpose(2, 1).contiguous()      # (B, k, npoint) as in knn.py:62
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None, None
+
+
+class GatherPoints(Function):
+    @staticmethod
+    def forward(ctx, features, indices):
+        assert features.is_contiguous()
+        assert indices.is_contiguous()
+        L.require_cuda(features, indices)
+        B, npoint = indices.size()
+        _, C, N = features.size()
+        out = _f32(B, C, npoint, device=features.device)
+        L.check(L.load().pcr_gather_fwd_f32(L.ptr(features), L.ptr(indices), L.ptr(out), B, C, N, npoint,
+                                            L.stream_ptr()), "pcr_gather_fwd_f32")
+        ctx.for_backwards = (indices, C, N)
+        ctx.mark_non_differentiable(indices)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, C, N = ctx.for_backwards
+        B, npoint = idx.size()
+        grad_features = torch.zeros(B, C, N, dtype=torch.float32, device=grad_out.device)
+        g = grad_out.data.contiguous()
+        L.check(L.load().pcr_gather_bwd_f32(L.ptr(g), L.ptr(idx), L.ptr(grad_features), B, C, N, npoint,
+                                            L.stream_ptr()), "pcr_gather_bwd_f32")
+        return grad_features, None
+
+
+class GroupingOperation(Function):
+    @staticmethod
+    def forward(ctx, features, indices):
+        assert features.is_contiguous()
+        assert indices.is_contiguous()
+        L.require_cuda(features, indices)
+        B, nfeatures, nsample = indices.size()
+        _, C, N = features.size()
+        out = _f32(B, C, nfeatures, nsample, device=features.device)
+        L.check(L.load().pcr_group_fwd_f32(L.ptr(features), L.ptr(indices), L.ptr(out), B, C, N, nfeatures,
+                                           nsample, L.stream_ptr()), "pcr_group_fwd_f32")
+        ctx.for_backwards = (indices, N)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, N = ctx.for_backwards
+        B, C, npoint, nsample = grad_out.size()
+        grad_features = torch.zeros(B, C, N, dtype=torch.float32, device=grad_out.device)
+        g = grad_out.data.contiguous()
+        L.check(L.load().pcr_group_bwd_f32(L.ptr(g), L.ptr(idx), L.ptr(grad_features), B, C, N, npoint,
+                                           nsample, L.stream_ptr()), "pcr_group_bwd_f32")
+        return grad_features, None
+
+
+class ThreeNN(Function):
+    @staticmethod
+    def forward(ctx, target, source):
+        assert target.is_contiguous()
+        assert source.is_contiguous()
+        L.require_cuda(target, source)
+        B, N, _ = target.size()
+        m = source.size(1)
+        dist2 = _f32(B, N, 3, device=target.device)
+        idx = _i32(B, N, 3, device=target.device)
+        L.check(L.load().pcr_three_nn_f32(L.ptr(target), L.ptr(source), L.ptr(dist2), L.ptr(idx), B, N, m,
+                                          L.stream_ptr()), "pcr_three_nn_f32")
+        ctx.mark_non_differentiable(idx)
+        return torch.sqrt(dist2), idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None
+
+
+class ThreeInterpolate(Function):
+    @staticmethod
+    def forward(ctx, features, indices, weight):
+        assert features.is_contiguous()
+        assert indices.is_contiguous()
+        assert weight.is_contiguous()
+        L.require_cuda(features, indices, weight)
+        B, c, m = features.size()
+        n = indices.size(1)
+        ctx.three_interpolate_for_backward = (indices, weight, m)
+        out = _f32(B, c, n, device=features.device)
+        L.check(L.load().pcr_three_interp_fwd_f32(L.ptr(features), L.ptr(indices), L.ptr(weight), L.ptr(out),
+                                                  B, c, m, n, L.stream_ptr()), "pcr_three_interp_fwd_f32")
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight, m = ctx.three_interpolate_for_backward
+        B, c, n = grad_out.size()
+        grad_features = torch.zeros(B, c, m, dtype=torch.float32, device=grad_out.device)
+        g = grad_out.data.contiguous()
+        L.check(L.load().pcr_three_interp_bwd_f32(L.ptr(g), L.ptr(idx), L.ptr(weight), L.ptr(grad_features),
+                                                  B, c, n, m, L.stream_ptr()), "pcr_three_interp_bwd_f32")
+        return grad_features, None, None
+
+
+furthest_point_sample = FurthestPointSampling.apply
+furthest_point_sample_with_dist = FurthestPointSamplingWithDist.apply
+ball_query = BallQuery.apply
+knn = KNN.apply
+gather_points = GatherPoints.apply
+grouping_operation = GroupingOperation.apply
+three_nn = ThreeNN.apply
+three_interpolate = ThreeInterpolate.apply

@@ -1,0 +1,55 @@
+"""ctypes binding of libpcr_hip.so (include/pcr.h).  There is NO fallback: if the library is
+missing or a call fails, a RuntimeError is raised."""
+import ctypes
+import os
+
+import torch  # must be imported before the library so that libamdhip64.so.7 resolves to torch's copy
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "lib", "libpcr_hip.so")
+_lib = None
+
+ABI_VERSION = 1
+
+
+class PcrError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise PcrError(
+                "libpcr_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `python point-cloud-reid_amd/pcr_amd/build.py`; there is no CPU fallback." % SO_PATH)
+        lib = ctypes.CDLL(SO_PATH)
+        lib.pcr_status_string.restype = ctypes.c_char_p
+        lib.pcr_packed_weight_floats.restype = ctypes.c_long
+        lib.pcr_attn_kv_floats.restype = ctypes.c_long
+        if lib.pcr_abi_version() != ABI_VERSION:
+            raise PcrError("libpcr_hip.so ABI %d != binding %d: rebuild" % (lib.pcr_abi_version(), ABI_VERSION))
+        _lib = lib
+    return _lib
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def check(status, what):
+    if status != 0:
+        raise PcrError("%s failed: %s" % (what, load().pcr_status_string(status).decode()))
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise PcrError("pcr_amd ops run only on an MI355X device tensor (got %s); there is no CPU "
+                           "fallback in the product path" % t.device)

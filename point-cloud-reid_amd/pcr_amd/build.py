@@ -1,0 +1,65 @@
+"""Builds libpcr_hip.so (every HIP source under csrc/) for gfx950 with hipcc, in-tree."""
+import glob
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(PKG))
+CSRC = os.path.join(os.path.dirname(PKG), "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+SO = os.path.join(LIBDIR, "libpcr_hip.so")
+
+# point_ops.hip must not contract a*b+c into fma (bit-exact index outputs); the MFMA model
+# kernels keep the default.
+FLAGS = {
+    "point_ops.hip": ["-ffp-contract=off"],
+}
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found (need ROCm at /opt/rocm)")
+    return exe
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def needs_build():
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(ROOT, "include", "pcr.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return SO
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    common = ["--offload-arch=gfx950", "-O3", "-fPIC", "-fvisibility=hidden", "-std=c++17",
+              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    objs = []
+    procs = []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        cmd = [hipcc()] + common + FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode()))
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,220 @@
+"""Host side of the fused model kernels (include/pcr.h, section B): weight packing, eval-mode
+BatchNorm folding, parameter structs and launches.  PyTorch only supplies device memory and the
+current HIP stream.  Every entry point requires device tensors and raises if libpcr_hip.so is
+missing -- there is no CPU path here (the CPU restatement lives under oracle/ and is test-only).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+c_float_p = ctypes.c_void_p
+c_int_p = ctypes.c_void_p
+
+
+class SaParams(ctypes.Structure):
+    _fields_ = [("mode", ctypes.c_int), ("B", ctypes.c_int), ("N", ctypes.c_int), ("S", ctypes.c_int),
+                ("K", ctypes.c_int), ("D", ctypes.c_int),
+                ("c1", ctypes.c_int), ("c2", ctypes.c_int), ("c3", ctypes.c_int),
+                ("xyz", c_float_p), ("feat", c_float_p), ("idx", c_int_p), ("centre_idx", c_int_p),
+                ("wp", c_float_p * 3), ("scale", c_float_p * 3), ("shift", c_float_p * 3),
+                ("out", c_float_p)]
+
+
+class AttnParams(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int), ("Lq", ctypes.c_int), ("Sk", ctypes.c_int),
+                ("c1", ctypes.c_int), ("c2", ctypes.c_int), ("d", ctypes.c_int), ("cout", ctypes.c_int),
+                ("nhead", ctypes.c_int),
+                ("q_pos", ctypes.c_int), ("k_pos", ctypes.c_int), ("residual", ctypes.c_int),
+                ("feat_q", c_float_p), ("xyz_q", c_float_p), ("feat_k", c_float_p), ("xyz_k", c_float_p),
+                ("kv_index", c_int_p),
+                ("pos0_w", c_float_p), ("pos0_b", c_float_p), ("pos2_w", c_float_p), ("pos2_b", c_float_p),
+                ("wq", c_float_p), ("wk", c_float_p), ("wv", c_float_p), ("wmerge", c_float_p),
+                ("wmlp0", c_float_p), ("wmlp2", c_float_p),
+                ("ln1_g", c_float_p), ("ln1_b", c_float_p), ("ln2_g", c_float_p), ("ln2_b", c_float_p),
+                ("wfinal", c_float_p), ("bfinal", c_float_p), ("cfinal", ctypes.c_int),
+                ("kv", c_float_p), ("out", c_float_p)]
+
+
+class HeadParams(ctypes.Structure):
+    _fields_ = [("P", ctypes.c_int), ("C", ctypes.c_int), ("L", ctypes.c_int), ("groups", ctypes.c_int),
+                ("o", c_float_p), ("w1", c_float_p), ("w2", c_float_p),
+                ("gn1_g", c_float_p), ("gn1_b", c_float_p), ("gn2_g", c_float_p), ("gn2_b", c_float_p),
+                ("w_out", c_float_p), ("b_out", c_float_p),
+                ("pooled", c_float_p), ("logits", c_float_p)]
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _dev32(t, device):
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def pack_weight(w, device):
+    """(cout, cin[, 1[, 1]]) weight -> packed MFMA A-operand image on `device` (host-side pack)."""
+    w2 = w.detach().reshape(w.shape[0], -1).to("cpu", torch.float32).contiguous().numpy()
+    cout, cin = w2.shape
+    lib = L.load()
+    n = lib.pcr_packed_weight_floats(cout, cin)
+    out = np.empty(n, np.float32)
+    L.check(lib.pcr_pack_weight_f32(w2.ctypes.data_as(ctypes.c_void_p), cout, cin,
+                                    out.ctypes.data_as(ctypes.c_void_p)), "pcr_pack_weight_f32")
+    return torch.from_numpy(out).to(device)
+
+
+def fold_bn(bn, conv_bias, device):
+    """eval-mode BatchNorm after a conv with bias -> per-channel (scale, shift) applied to W x."""
+    scale = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+    bias = conv_bias.detach().double() if conv_bias is not None else 0.0
+    shift = (bias - bn.running_mean.detach().double()) * scale + bn.bias.detach().double()
+    return _dev32(scale.float(), device), _dev32(shift.float(), device)
+
+
+def param_version(module):
+    """cheap fingerprint of a module's parameters/buffers: re-pack when anything was updated"""
+    return tuple((t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers()))
+
+
+# ------------------------------------------------------------------------------ launches --
+def knn_prefix(xyz, S, K):
+    """xyz (B,N,3) device -> idx (B,S,K) int32: K nearest of all N for the first S points."""
+    L.require_cuda(xyz)
+    assert xyz.is_contiguous() and xyz.dtype == torch.float32
+    B, N, _ = xyz.shape
+    idx = torch.empty((B, S, K), dtype=torch.int32, device=xyz.device)
+    L.check(L.load().pcr_knn_prefix_f32(L.ptr(xyz), L.ptr(idx), B, N, S, K, L.stream_ptr()),
+            "pcr_knn_prefix_f32")
+    return idx
+
+
+class SaPlan:
+    """packed 3-layer grouped MLP (conv+BN(eval)+ReLU x3 + max over K)"""
+
+    def __init__(self, convs, bns, device, mode):
+        assert len(convs) == 3 and len(bns) == 3, "the fused SA kernel covers 3-layer MLPs"
+        self.mode = mode
+        self.cin = convs[0].weight.shape[1]
+        self.couts = [c.weight.shape[0] for c in convs]
+        self.wp = [pack_weight(c.weight, device) for c in convs]
+        folded = [fold_bn(b, c.bias, device) for c, b in zip(convs, bns)]
+        self.scale = [f[0] for f in folded]
+        self.shift = [f[1] for f in folded]
+
+    def run(self, xyz, feat, idx, centre_idx=None):
+        L.require_cuda(xyz, idx)
+        B, N, _ = xyz.shape
+        _, S, K = idx.shape
+        D = 0 if feat is None else feat.shape[1]
+        want = 3 + (2 * D if self.mode == 0 else D)
+        assert want == self.cin, "feature width %d does not match the first conv (%d)" % (want, self.cin)
+        assert xyz.is_contiguous() and idx.is_contiguous() and (feat is None or feat.is_contiguous())
+        out = torch.empty((B, self.couts[2], S), dtype=torch.float32, device=xyz.device)
+        p = SaParams()
+        p.mode, p.B, p.N, p.S, p.K, p.D = self.mode, B, N, S, K, D
+        p.c1, p.c2, p.c3 = self.couts
+        p.xyz, p.feat, p.idx, p.centre_idx = _p(xyz), _p(feat), _p(idx), _p(centre_idx)
+        for i in range(3):
+            p.wp[i], p.scale[i], p.shift[i] = _p(self.wp[i]), _p(self.scale[i]), _p(self.shift[i])
+        p.out = _p(out)
+        L.check(L.load().pcr_sa_mlp_f32(ctypes.byref(p), L.stream_ptr()), "pcr_sa_mlp_f32")
+        return out
+
+
+class AttnPlan:
+    """packed linear-attention block.  `m` exposes pos-MLP (name given), q/k/v/merge projections,
+    mlp.{0,2}, norm1/norm2 as in the reference's Self_Attention / FP_SA / corss_attention."""
+
+    def __init__(self, m, pos_name, device, nhead, q_pos, k_pos, residual, final=None):
+        pos = getattr(m, pos_name)
+        self.device = device
+        self.nhead, self.q_pos, self.k_pos, self.residual = nhead, int(q_pos), int(k_pos), int(residual)
+        self.d = m.q_proj.weight.shape[0]
+        self.c1 = m.q_proj.weight.shape[1]
+        self.c2 = m.k_proj.weight.shape[1]
+        self.cout = m.mlp[2].weight.shape[0]
+        self.t = dict(
+            pos0_w=pack_weight(pos[0].weight, device), pos0_b=_dev32(pos[0].bias, device),
+            pos2_w=pack_weight(pos[2].weight, device), pos2_b=_dev32(pos[2].bias, device),
+            wq=pack_weight(m.q_proj.weight, device), wk=pack_weight(m.k_proj.weight, device),
+            wv=pack_weight(m.v_proj.weight, device), wmerge=pack_weight(m.merge.weight, device),
+            wmlp0=pack_weight(m.mlp[0].weight, device), wmlp2=pack_weight(m.mlp[2].weight, device),
+            ln1_g=_dev32(m.norm1.weight, device), ln1_b=_dev32(m.norm1.bias, device),
+            ln2_g=_dev32(m.norm2.weight, device), ln2_b=_dev32(m.norm2.bias, device))
+        self.cfinal = 0
+        if final is not None:
+            self.t["wfinal"] = pack_weight(final.weight, device)
+            self.t["bfinal"] = _dev32(final.bias, device)
+            self.cfinal = final.weight.shape[0]
+
+    def run(self, feat_q, xyz_q, feat_k, xyz_k, kv_index=None):
+        """feat_q (B,c1,Lq), feat_k (B,c2,Sk), xyz (B,L,3) -> (B, cfinal or cout, Lq)"""
+        L.require_cuda(feat_q, feat_k, xyz_k)
+        for t in (feat_q, xyz_q, feat_k, xyz_k):
+            assert t is None or (t.is_contiguous() and t.dtype == torch.float32)
+        B, c1, Lq = feat_q.shape
+        _, c2, Sk = feat_k.shape
+        assert c1 == self.c1 and c2 == self.c2 and feat_k.shape[0] == B
+        lib = L.load()
+        kv = torch.empty((B, lib.pcr_attn_kv_floats(self.d)), dtype=torch.float32, device=feat_q.device)
+        out = torch.empty((B, self.cfinal or self.cout, Lq), dtype=torch.float32, device=feat_q.device)
+        p = AttnParams()
+        p.B, p.Lq, p.Sk = B, Lq, Sk
+        p.c1, p.c2, p.d, p.cout, p.nhead = c1, c2, self.d, self.cout, self.nhead
+        p.q_pos, p.k_pos, p.residual = self.q_pos, self.k_pos, self.residual
+        p.feat_q, p.xyz_q, p.feat_k, p.xyz_k = _p(feat_q), _p(xyz_q), _p(feat_k), _p(xyz_k)
+        p.kv_index = _p(kv_index)
+        for k, v in self.t.items():
+            setattr(p, k, _p(v))
+        p.cfinal = self.cfinal
+        p.kv, p.out = _p(kv), _p(out)
+        st = L.stream_ptr()
+        L.check(lib.pcr_attn_kv_f32(ctypes.byref(p), st), "pcr_attn_kv_f32")
+        L.check(lib.pcr_attn_apply_f32(ctypes.byref(p), st), "pcr_attn_apply_f32")
+        return out
+
+
+class HeadPlan:
+    """pool 'both' over point-concatenated pairs + LinearRes(GN) + Linear(.,1)"""
+
+    def __init__(self, linres, out_linear, device):
+        if getattr(linres, "transform", None) is not None:
+            raise L.PcrError("pcr_pool_head_f32 covers LinearRes with n_in == n_out only")
+        self.n = linres.linear1.weight.shape[0]
+        self.groups = linres.norm1.num_groups
+        self.t = dict(w1=_dev32(linres.linear1.weight, device), w2=_dev32(linres.linear2.weight, device),
+                      gn1_g=_dev32(linres.norm1.weight, device), gn1_b=_dev32(linres.norm1.bias, device),
+                      gn2_g=_dev32(linres.norm2.weight, device), gn2_b=_dev32(linres.norm2.bias, device),
+                      w_out=_dev32(out_linear.weight, device), b_out=_dev32(out_linear.bias, device))
+
+    def run(self, o, want_pooled=False):
+        """o (2P, C, L): clouds p and p+P are pair p -> logits (P) [, pooled (P,2C)]"""
+        L.require_cuda(o)
+        assert o.is_contiguous() and o.dtype == torch.float32
+        twoP, C, Lp = o.shape
+        P = twoP // 2
+        assert 2 * C == self.n, "pooled width %d != match head width %d" % (2 * C, self.n)
+        logits = torch.empty((P,), dtype=torch.float32, device=o.device)
+        pooled = torch.empty((P, 2 * C), dtype=torch.float32, device=o.device) if want_pooled else None
+        p = HeadParams()
+        p.P, p.C, p.L, p.groups = P, C, Lp, self.groups
+        p.o = _p(o)
+        for k, v in self.t.items():
+            setattr(p, k, _p(v))
+        p.pooled, p.logits = _p(pooled), _p(logits)
+        L.check(L.load().pcr_pool_head_f32(ctypes.byref(p), L.stream_ptr()), "pcr_pool_head_f32")
+        return (logits, pooled) if want_pooled else logits
+
+
+def dense(x, wp, cout, scale=None, shift=None, act=0):
+    """x (B,cin,L) -> (B,cout,L) through pcr_dense_f32 (wp packed)."""
+    L.require_cuda(x)
+    assert x.is_contiguous() and x.dtype == torch.float32
+    B, cin, Ln = x.shape
+    y = torch.empty((B, cout, Ln), dtype=torch.float32, device=x.device)
+    L.check(L.load().pcr_dense_f32(L.ptr(x), L.ptr(wp), L.ptr(scale), L.ptr(shift), L.ptr(y), B, cin, cout,
+                                   Ln, act, L.stream_ptr()), "pcr_dense_f32")
+    return y

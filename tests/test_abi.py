@@ -1,0 +1,74 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/pcr.h
+declares (no compute calls without a GPU); host-side weight packing round-trips."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pcr_amd import build, _lib
+    build.build()
+    return _lib.load()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pcr.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pcr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), "libpcr_hip.so does not export %s" % s
+    assert lib.pcr_abi_version() == 1
+    assert lib.pcr_status_string(0) == b"ok"
+
+
+def test_weight_packing_layout(lib):
+    g = np.random.default_rng(0)
+    for cout, cin in ((32, 3), (64, 67), (128, 131), (9, 256), (1, 1)):
+        w = g.standard_normal((cout, cin)).astype(np.float32)
+        n = lib.pcr_packed_weight_floats(cout, cin)
+        cp, op = (cin + 7) // 8 * 8, (cout + 31) // 32 * 32
+        assert n == cp * op
+        out = np.full(n, np.nan, np.float32)
+        assert lib.pcr_pack_weight_f32(w.ctypes.data_as(ctypes.c_void_p), cout, cin, out.ctypes.data_as(ctypes.c_void_p)) == 0
+        img = out.reshape(cp // 8, op, 2, 4)
+        full = np.zeros((op, cp), np.float32)
+        full[:cout, :cin] = w
+        # element (kb, o, h, j) holds W[o][kb*8 + 2*j + h]
+        back = img.transpose(1, 0, 3, 2).reshape(op, cp)
+        assert np.array_equal(back, full)
+
+
+def test_invalid_arguments_return_status_not_crash(lib):
+    assert lib.pcr_fps_f32(None, None, None, 1, 8, 4, None) == 1
+    assert lib.pcr_knn_f32(None, None, None, None, 1, 8, 4, 101, None) == 1
+    assert lib.pcr_pack_weight_f32(None, 4, 4, None) == 1
+    assert lib.pcr_sa_mlp_f32(None, None) == 1
+
+
+def test_product_path_has_no_cpu_fallback():
+    import torch
+    from mmdet3d import ops
+    from pcr_amd._lib import PcrError
+    with pytest.raises(PcrError):
+        ops.furthest_point_sample(torch.zeros(1, 8, 3), 4)
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "point-cloud-reid_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(d, f)).read()
+                assert "model_oracle" not in src and "point_ops as P" not in src and "import oracle" not in src, f
+                assert "pcr_oracle" not in src, f

@@ -1,0 +1,161 @@
+"""GPU parity of the Point-Transformer ReIDNet (HIP path through mmdet3d.models -> engine ->
+C ABI) against (a) the golden vectors recorded from the imported reference and (b) the torch
+CPU restatement (oracle/model_oracle.py) at larger seeded sizes.
+
+Tolerance: north_star asks for embeddings/logits within 1e-4 (fp32) on identical inputs."""
+import copy
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+from pcr_amd import testing as T
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+PT_MODEL = dict(
+    type="ReIDNet", hidden_size=128, combine="point-cat", match_type="xcorr_eff", pool_type="both",
+    backbone_list=[128, 64, 32], output_sequence_size=64,
+    backbone=dict(type="Pointnet_Backbone", input_channels=0, use_xyz=True, conv_out=64),
+    match_head=[dict(type="LinearRes", n_in=128, n_out=128, norm="GN", ng=8),
+                dict(type="Linear", in_features=128, out_features=1)],
+    downsample=None, cls_head=None, fp_head=None, shape_head=None,
+    cross_stage1=dict(type="corss_attention", d_model=64, nhead=2, attention="linear"),
+    cross_stage2=dict(type="corss_attention", d_model=64, nhead=2, attention="linear"),
+    local_stage1=dict(), local_stage2=dict(),
+    losses_to_use=dict(kl=False, match=True, cls=False, shape=False, fp=False, triplet=False))
+
+
+def build_pt(backbone_list):
+    from mmdet3d.models import build_model
+    cfg = copy.deepcopy(PT_MODEL)
+    cfg["backbone_list"] = list(backbone_list)
+    m = build_model(cfg)
+    sd = T.seeded_state_dict(T.load_manifest(os.path.join(GOLDEN, "pt_manifest.json")), 0)
+    m.load_state_dict(sd, strict=True)
+    return m.cuda().eval(), sd
+
+
+def run_stages(m, s1, s2, fused_final=True):
+    st = {}
+    hooks = []
+    bb = m.backbone
+    if not fused_final:
+        bb.FP_modules[0].interpolation.fuse_final_conv(None)
+    for i, sa in enumerate(bb.SA_modules):
+        hooks.append(sa.self_attention.register_forward_pre_hook(
+            lambda mod, args, i=i: st.__setitem__(f"sa{i}_mlp", args[0].cpu().numpy())))
+        hooks.append(sa.register_forward_hook(
+            lambda mod, args, out, i=i: st.__setitem__(f"sa{i}_out", out[1].cpu().numpy())))
+    for j, fp in enumerate(bb.FP_modules):
+        hooks.append(fp.register_forward_hook(
+            lambda mod, args, out, j=j: st.__setitem__(f"fp{j}_out", out.cpu().numpy())))
+    with torch.no_grad():
+        xyz1, xyz2, h1, h2 = m.siamese_forward(s1.cuda(), s2.cuda())
+        out, o1, o2 = m.xcorr_eff(h1, xyz1, h2, xyz2)
+        pooled = m.get_pooled_feats(out)
+        logits = m.match_forward_inference(h1, h2, xyz1, xyz2)
+    torch.cuda.synchronize()
+    for h in hooks:
+        h.remove()
+    if not fused_final:
+        bb.FP_modules[0].interpolation.fuse_final_conv(bb.cov_final)
+    st.update(h1=h1.cpu().numpy(), h2=h2.cpu().numpy(), x2_o1=o1.cpu().numpy(), x2_o2=o2.cpu().numpy(),
+              pooled=pooled.cpu().numpy(), logits=logits.cpu().numpy())
+    return st
+
+
+def _report(st, ref, keys):
+    worst = {}
+    for k in keys:
+        if k in st and k in ref:
+            worst[k] = float(np.abs(st[k] - np.asarray(ref[k])).max())
+    return worst
+
+
+@pytest.mark.parametrize("case", ["pt_n128_randn", "pt_n128_dup", "pt_n256_box", "pt_n1024_randn"])
+def test_pt_matches_reference_golden(case):
+    g = load_golden(case)
+    meta = g["meta"]
+    m, _ = build_pt(meta["backbone_list"])
+    s1, s2 = T.synthetic_pairs(meta["pairs"], meta["n"], meta["input_seed"], meta["kind"])
+    st = run_stages(m, s1, s2, fused_final=False)
+    keys = [k for k in g if k not in ("meta",) and not k.endswith("knn_sorted")]
+    worst = _report(st, g, keys)
+    print(case, json.dumps(worst))
+    assert worst, "no stage compared"
+    bad = {k: v for k, v in worst.items() if not v < TOL}
+    assert not bad, bad
+    # fused cov_final must give the same h
+    st2 = run_stages(m, s1, s2, fused_final=True)
+    assert np.abs(st2["h1"] - g["h1"]).max() < TOL and np.abs(st2["logits"] - g["logits"]).max() < TOL
+
+
+def test_pt_knn_sets_match_reference_golden():
+    from pcr_amd import engine
+    for case in ("pt_n128_randn", "pt_n256_box", "pt_n1024_randn"):
+        g = load_golden(case)
+        meta = g["meta"]
+        s1, s2 = T.synthetic_pairs(meta["pairs"], meta["n"], meta["input_seed"], meta["kind"])
+        xyz = torch.cat([s1, s2], 0).cuda()
+        bl = meta["backbone_list"]
+        idx = engine.knn_prefix(xyz, bl[0], 32).cpu().numpy()
+        assert (np.sort(idx, -1) == g["sa0_knn_sorted"]).all()
+        idx = engine.knn_prefix(xyz[:, :bl[0]].contiguous(), bl[1], 48).cpu().numpy()
+        assert (np.sort(idx, -1) == g["sa1_knn_sorted"]).all()
+        idx = engine.knn_prefix(xyz[:, :bl[1]].contiguous(), bl[2], 48).cpu().numpy()
+        assert (np.sort(idx, -1) == g["sa2_knn_sorted"]).all()
+
+
+@pytest.mark.parametrize("pairs,n,bl,kind", [(5, 200, [200, 100, 50], "box"), (3, 512, [512, 256, 128], "dup"),
+                                             (2, 1000, [1000, 500, 250], "randn")])
+def test_pt_matches_cpu_oracle(pairs, n, bl, kind):
+    """sizes with ragged tiles (N not a multiple of 32/64) against the torch restatement"""
+    import model_oracle as MO
+    m, sd = build_pt(bl)
+    s1, s2 = T.synthetic_pairs(pairs, n, seed=77, kind=kind)
+    ref = {}
+    with torch.no_grad():
+        MO.pt_pairs(sd, s1, s2, bl, stages=ref)
+    ref = {k: v.numpy() for k, v in ref.items()}
+    st = run_stages(m, s1, s2)
+    worst = _report(st, ref, ["sa0_mlp", "sa0_out", "sa1_mlp", "sa1_out", "sa2_mlp", "sa2_out", "fp2_out", "fp1_out",
+                              "h1", "h2", "x2_o1", "x2_o2", "pooled", "logits"])
+    print(json.dumps(worst))
+    bad = {k: v for k, v in worst.items() if not v < TOL}
+    assert not bad, bad
+
+
+def test_forward_test_api_and_decisions():
+    """mmdet-style call: lists of per-sample tensors in, [dict] out (ReIDNet.forward_test)"""
+    g = load_golden("pt_n128_randn")
+    m, _ = build_pt([128, 64, 32])
+    s1, s2 = T.synthetic_pairs(2, 128, 1, "randn")
+    dev = "cuda"
+    data = dict(sparse_1=list(s1.to(dev)), sparse_2=list(s2.to(dev)), dense_1=list(s1.to(dev)), dense_2=list(s2.to(dev)),
+                label_1=[torch.zeros(1, dtype=torch.long, device=dev)] * 2, label_2=[torch.zeros(1, dtype=torch.long, device=dev)] * 2,
+                id_1=[torch.tensor([3], device=dev), torch.tensor([4], device=dev)],
+                id_2=[torch.tensor([3], device=dev), torch.tensor([5], device=dev)],
+                size_1=[torch.tensor([128], device=dev)] * 2, size_2=[torch.tensor([128], device=dev)] * 2,
+                vis_1=[torch.tensor([1], device=dev)] * 2, vis_2=[torch.tensor([1], device=dev)] * 2)
+    with torch.no_grad():
+        res = m(return_loss=False, rescale=True, **data)
+    assert isinstance(res, list) and len(res) == 1
+    r = res[0]
+    assert np.abs(r["val_match_preds"].cpu().numpy() - g["logits"]).max() < TOL
+    assert r["val_match_gt"].cpu().tolist() == [1.0, 0.0]
+    assert r["match_classes"].shape == (2, 2) and r["num_points"].shape == (2, 2)
+    assert ((torch.sigmoid(r["val_match_preds"]) > 0.5).cpu().numpy() == (1 / (1 + np.exp(-g["logits"])) > 0.5)).all()
+
+
+def test_training_mode_fails_loudly():
+    from pcr_amd._lib import PcrError
+    m, _ = build_pt([128, 64, 32])
+    m.train()
+    s1, s2 = T.synthetic_pairs(1, 128, 1, "randn")
+    with pytest.raises(PcrError):
+        m.siamese_forward(s1.cuda(), s2.cuda())

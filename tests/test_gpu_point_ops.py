@@ -1,0 +1,127 @@
+"""GPU parity: every point op of libpcr_hip.so (through the mmdet3d.ops API -> ctypes -> C ABI)
+against the C oracle on the same seeded inputs.  Index outputs must be bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from pcr_amd import testing as T
+import point_ops as P
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mmdet3d import ops as O
+    return O
+
+
+@pytest.mark.parametrize("n,m,kind", [(64, 16, "randn"), (100, 40, "box"), (128, 64, "dup"), (256, 256, "dup"),
+                                      (1024, 512, "randn"), (1024, 128, "dup"), (3000, 64, "box"),
+                                      (4096, 256, "dup"), (5000, 33, "randn"), (17, 17, "randn"), (1, 1, "randn")])
+def test_fps_bit_exact(ops, n, m, kind):
+    xyz = T.synthetic_clouds(3, n, seed=n + m, kind=kind).numpy()
+    want = P.fps(xyz, m)
+    got = ops.furthest_point_sample(dev(xyz), m).cpu().numpy()
+    assert got.dtype == np.int32 and (got == want).all()
+
+
+def test_fps_with_dist_bit_exact(ops):
+    g = np.random.default_rng(3)
+    for n, m in ((96, 32), (300, 77), (1500, 20)):
+        f = g.standard_normal((2, n, 8)).astype(np.float32)
+        d = ((f[:, :, None] - f[:, None]) ** 2).sum(-1).astype(np.float32)
+        d[0, :, : n // 3] = np.round(d[0, :, : n // 3], 1)        # force exact ties
+        want = P.fps_dist(d, m)
+        got = ops.furthest_point_sample_with_dist(dev(d), m).cpu().numpy()
+        assert (got == want).all()
+
+
+@pytest.mark.parametrize("n,m,k,r0,r1,kind", [(1024, 512, 32, 0.0, 0.2, "box"), (1024, 512, 32, 0.0, 0.6, "randn"),
+                                              (2500, 300, 64, 0.1, 0.5, "dup"), (50, 50, 8, 0.0, 0.01, "randn"),
+                                              (128, 128, 16, 0.0, 100.0, "dup")])
+def test_ball_query_bit_exact(ops, n, m, k, r0, r1, kind):
+    xyz = T.synthetic_clouds(2, n, seed=5, kind=kind).numpy()
+    c = xyz[:, :m].copy()
+    c[:, ::7] += 0.05
+    want = P.ball_query(r0, r1, k, xyz, c)
+    got = ops.ball_query(r0, r1, k, dev(xyz), dev(c)).cpu().numpy()
+    assert (got == want).all()
+
+
+@pytest.mark.parametrize("n,m,k,kind", [(256, 100, 16, "randn"), (1000, 70, 100, "dup"), (128, 128, 1, "box"),
+                                        (64, 64, 64, "dup")])
+def test_knn_heap_bit_exact(ops, n, m, k, kind):
+    xyz = T.synthetic_clouds(2, n, seed=9, kind=kind).numpy()
+    c = xyz[:, :m].copy()
+    want, _ = P.knn(k, xyz, c)
+    got = ops.knn(k, dev(xyz), dev(c), False).cpu().numpy()       # (B,k,m)
+    assert got.shape == (2, k, m)
+    assert (got.transpose(0, 2, 1) == want).all()
+    got_t = ops.knn(k, dev(xyz.transpose(0, 2, 1).copy()), dev(c.transpose(0, 2, 1).copy()), True).cpu().numpy()
+    assert (got_t == got).all()
+    with pytest.raises(RuntimeError):
+        ops.knn(101, dev(xyz), dev(c), False)
+
+
+@pytest.mark.parametrize("n,s,k,kind", [(128, 128, 32, "randn"), (128, 64, 48, "dup"), (512, 256, 48, "box"),
+                                        (1024, 1024, 32, "dup"), (4096, 100, 48, "randn"), (70, 70, 64, "dup"),
+                                        (2048, 33, 5, "box")])
+def test_knn_prefix_bit_exact(n, s, k, kind):
+    from pcr_amd import engine
+    xyz = T.synthetic_clouds(3, n, seed=21, kind=kind).numpy()
+    want = P.knn_prefix(xyz, s, k)
+    got = engine.knn_prefix(dev(xyz), s, k).cpu().numpy()
+    assert (got == want).all()
+
+
+def test_gather_group_fwd_bwd(ops):
+    g = np.random.default_rng(0)
+    feat = g.standard_normal((3, 19, 257)).astype(np.float32)
+    idx = g.integers(0, 257, (3, 100)).astype(np.int32)
+    f = dev(feat).requires_grad_(True)
+    out = ops.gather_points(f, dev(idx))
+    assert (out.detach().cpu().numpy() == P.gather_fwd(feat, idx)).all()
+    go = g.standard_normal(out.shape).astype(np.float32)
+    out.backward(dev(go))
+    assert np.allclose(f.grad.cpu().numpy(), P.gather_bwd(go, idx, 257), atol=1e-5)
+
+    gi = g.integers(0, 257, (3, 40, 12)).astype(np.int32)
+    f = dev(feat).requires_grad_(True)
+    out = ops.grouping_operation(f, dev(gi))
+    assert (out.detach().cpu().numpy() == P.group_fwd(feat, gi)).all()
+    go = g.standard_normal(out.shape).astype(np.float32)
+    out.backward(dev(go))
+    assert np.allclose(f.grad.cpu().numpy(), P.group_bwd(go, gi, 257), atol=1e-4)
+
+
+def test_three_nn_and_interpolate(ops):
+    g = np.random.default_rng(1)
+    unk = T.synthetic_clouds(2, 700, seed=3, kind="dup").numpy()
+    kn = unk[:, :90].copy()
+    d2, i3 = P.three_nn(unk, kn)
+    dist, idx = ops.three_nn(dev(unk), dev(kn))
+    assert (idx.cpu().numpy() == i3).all()
+    assert np.allclose(dist.cpu().numpy(), np.sqrt(d2), rtol=1e-6, atol=0)
+    w = g.uniform(size=(2, 700, 3)).astype(np.float32)
+    feat = g.standard_normal((2, 13, 90)).astype(np.float32)
+    f = dev(feat).requires_grad_(True)
+    out = ops.three_interpolate(f, idx, dev(w))
+    assert (out.detach().cpu().numpy() == P.three_interp_fwd(feat, i3, w)).all()
+    go = g.standard_normal(out.shape).astype(np.float32)
+    out.backward(dev(go))
+    assert np.allclose(f.grad.cpu().numpy(), P.three_interp_bwd(go, i3, w, 90), atol=1e-4)
+
+
+def test_errors_are_python_exceptions(ops):
+    x = torch.zeros(2, 8, 3)
+    with pytest.raises(RuntimeError):
+        ops.furthest_point_sample(x, 4)                 # CPU tensor: no fallback
+    with pytest.raises(AssertionError):
+        ops.furthest_point_sample(torch.zeros(2, 3, 8).cuda().transpose(1, 2), 4)   # non-contiguous
+    with pytest.raises(AssertionError):
+        ops.ball_query(0.5, 0.2, 4, x.cuda(), x.cuda())  # min_radius >= max_radius
