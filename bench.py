@@ -1,0 +1,215 @@
+"""Throughput bench of the siamese point-cloud ReID hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--pairs B]
+
+One step = one pass of the hot path (siamese_forward + match_forward_inference)
+over one batch of B synthetic pairs that is already resident in HBM.  Every rank (one process
+per GPU, RCCL only for the barrier / max-reduce of the timing) runs its own independent shard of
+pairs -- the path has no data-path collective -- so scaling is weak and `value` is the whole-job
+pairs/s.  Prints ONE JSON line on rank 0 (see the task contract) carrying `roofline` for the
+dominant kernel and, at N=1, `cpu_baseline` (the torch restatement oracle/model_oracle.py, which
+is pinned to the reference by tests/golden, timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "point-cloud-reid_amd"), os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+PT_MODEL = dict(
+    type="ReIDNet", hidden_size=128, combine="point-cat", match_type="xcorr_eff", pool_type="both",
+    backbone_list=[128, 64, 32], output_sequence_size=64,
+    backbone=dict(type="Pointnet_Backbone", input_channels=0, use_xyz=True, conv_out=64),
+    match_head=[dict(type="LinearRes", n_in=128, n_out=128, norm="GN", ng=8),
+                dict(type="Linear", in_features=128, out_features=1)],
+    downsample=None, cls_head=None, fp_head=None, shape_head=None,
+    cross_stage1=dict(type="corss_attention", d_model=64, nhead=2, attention="linear"),
+    cross_stage2=dict(type="corss_attention", d_model=64, nhead=2, attention="linear"),
+    local_stage1=dict(), local_stage2=dict(),
+    losses_to_use=dict(kl=False, match=True, cls=False, shape=False, fp=False, triplet=False))
+
+# name -> (description, model kind, points, backbone_list, default pairs per GPU per step)
+WORKLOADS = {
+    "pt1024": ("Point-Transformer ReIDNet (configs_reid/reid_nuscenes_pts/num_point_ablation_test/"
+               "pts_point-transformer_r_nus_det_400e_1024pts.py), 1024-pt synthetic pairs, eval", "pt", 1024,
+               [1024, 512, 256], 512),
+    "pt128": ("Point-Transformer ReIDNet (reid_nuscenes_pts/testing_pts_point-transformer_r_nus_det_500e.py), "
+              "128-pt synthetic pairs, eval", "pt", 128, [128, 64, 32], 512),
+    "pt4096": ("Point-Transformer ReIDNet, 4096-pt Waymo-shape synthetic pairs, eval", "pt", 4096,
+               [4096, 2048, 1024], 256),
+}
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3    # f32-input MFMA dense peak
+
+
+def build_pt_model(backbone_list, device="cuda"):
+    from mmdet3d.models import build_model
+    from pcr_amd import testing as T
+    cfg = copy.deepcopy(PT_MODEL)
+    cfg["backbone_list"] = list(backbone_list)
+    model = build_model(cfg)
+    man = T.load_manifest(os.path.join(ROOT, "tests", "golden", "pt_manifest.json"))
+    sd = T.seeded_state_dict(man, 0)
+    model.load_state_dict(sd, strict=True)
+    return model.to(device).eval(), sd
+
+
+def hot_path(model, s1, s2):
+    xyz1, xyz2, h1, h2 = model.siamese_forward(s1, s2)
+    return model.match_forward_inference(h1, h2, xyz1, xyz2)
+
+
+def profile_kernels(model, s1, s2, reps=3):
+    """per-launch device time with events on the launch stream; returns the dominant launch"""
+    from pcr_amd import engine
+    best = None
+    for _ in range(reps):
+        engine.PROFILE = []
+        with torch.no_grad():
+            hot_path(model, s1, s2)
+        torch.cuda.synchronize()
+        rec = engine.PROFILE
+        engine.PROFILE = None
+        tot = {}
+        for name, e0, e1, flops, nbytes in rec:
+            ms = e0.elapsed_time(e1)
+            t = tot.setdefault(name, [0.0, 0, 0.0, 0.0])
+            t[0] += ms
+            t[1] += 1
+            t[2] += flops
+            t[3] += nbytes
+        if best is None or sum(v[0] for v in tot.values()) < sum(v[0] for v in best.values()):
+            best = tot
+    return best
+
+
+def cpu_baseline(workload, sd, budget_s=20.0):
+    import model_oracle as MO
+    from pcr_amd import testing as T
+    _, kind, n, bl, _ = WORKLOADS[workload]
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    pairs = 8 if n >= 1024 else 32
+    s1, s2 = T.synthetic_pairs(pairs, n, seed=1234, kind="randn")
+    best, best_threads, runs = None, 1, 0
+    t_start = time.time()
+    # torch's intra-op pool does not scale to hundreds of threads on these small per-cloud ops:
+    # try a few pool sizes up to the cores we may use and report the fastest
+    candidates = sorted({min(avail, c) for c in (8, 16, 32, avail)})
+    with torch.no_grad():
+        for threads in candidates:
+            torch.set_num_threads(threads)
+            for _ in range(2):
+                if time.time() - t_start > budget_s and runs >= 2:
+                    break
+                t0 = time.time()
+                MO.pt_pairs(sd, s1, s2, bl)
+                dt = time.time() - t0
+                runs += 1
+                if best is None or dt < best:
+                    best, best_threads = dt, threads
+    return dict(value=pairs / best, unit="pairs/s", cores=best_threads, kind="port",
+                sample="%d pairs x %d pts, best of %d runs over thread counts %s (%d usable cores), torch %s eager "
+                       "fp32 restatement of the reference graph (oracle/model_oracle.py)"
+                       % (pairs, n, runs, candidates, avail, torch.__version__))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="pt1024", choices=sorted(WORKLOADS))
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (default: per workload)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from pcr_amd import testing as T
+    desc, kind, n, bl, dpairs = WORKLOADS[args.workload]
+    pairs = args.pairs or dpairs
+    model, sd = build_pt_model(bl)
+    s1, s2 = T.synthetic_pairs(pairs, n, seed=1234 + rank, kind="randn")
+    s1, s2 = s1.cuda(), s2.cuda()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = hot_path(model, s1, s2)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = hot_path(model, s1, s2)
+        barrier()
+        dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    line = None
+    if rank == 0:
+        prof = profile_kernels(model, s1, s2)
+        dom = max(prof, key=lambda k: prof[k][0])
+        ms, cnt, flops, nbytes = prof[dom]
+        step_ms_kern = sum(v[0] for v in prof.values())
+        roof = dict(kernel=dom, bound="mfma", achieved=flops / (ms * 1e-3) / 1e12, peak=MFMA_F32_PEAK_TF,
+                    unit="TFLOP/s", launches_per_step=cnt, avg_launch_ms=ms / cnt, traffic=None,
+                    share_of_step=ms / step_ms_kern,
+                    per_kernel_ms={k: round(v[0], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])})
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        line = {
+            "metric": "siamese pair-comparisons/sec @%d pts" % n,
+            "value": world * pairs * args.steps / dt,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (randn clouds, seeded random-init weights with non-trivial BN statistics)",
+            "config": {"workload": "%s: %s" % (args.workload, desc), "pairs_per_gpu_per_step": pairs,
+                       "points": n, "backbone_list": bl, "parallelism": "independent pair shards x%d" % world},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload, sd)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,28 @@ from . import _lib as L
 c_float_p = ctypes.c_void_p
 c_int_p = ctypes.c_void_p
 
+# bench.py sets this to a list to collect (kernel, start_event, end_event, algorithmic flops,
+# algorithmic bytes) per launch; events are recorded on the stream the kernels are launched on.
+PROFILE = None
+
+
+class _prof:
+    def __init__(self, name, flops=0.0, nbytes=0.0):
+        self.name, self.flops, self.nbytes = name, flops, nbytes
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.e1.record()
+            PROFILE.append((self.name, self.e0, self.e1, self.flops, self.nbytes))
+        return False
+
 
 class SaParams(ctypes.Structure):
     _fields_ = [("mode", ctypes.c_int), ("B", ctypes.c_int), ("N", ctypes.c_int), ("S", ctypes.c_int),
@@ -86,8 +108,9 @@ def knn_prefix(xyz, S, K):
     assert xyz.is_contiguous() and xyz.dtype == torch.float32
     B, N, _ = xyz.shape
     idx = torch.empty((B, S, K), dtype=torch.int32, device=xyz.device)
-    L.check(L.load().pcr_knn_prefix_f32(L.ptr(xyz), L.ptr(idx), B, N, S, K, L.stream_ptr()),
-            "pcr_knn_prefix_f32")
+    with _prof("knn_prefix", 8.0 * B * S * N, 12.0 * B * N + 4.0 * B * S * K):
+        L.check(L.load().pcr_knn_prefix_f32(L.ptr(xyz), L.ptr(idx), B, N, S, K, L.stream_ptr()),
+                "pcr_knn_prefix_f32")
     return idx
 
 
@@ -120,7 +143,11 @@ class SaPlan:
         for i in range(3):
             p.wp[i], p.scale[i], p.shift[i] = _p(self.wp[i]), _p(self.scale[i]), _p(self.shift[i])
         p.out = _p(out)
-        L.check(L.load().pcr_sa_mlp_f32(ctypes.byref(p), L.stream_ptr()), "pcr_sa_mlp_f32")
+        c1, c2, c3 = self.couts
+        flops = 2.0 * B * S * K * (self.cin * c1 + c1 * c2 + c2 * c3)
+        nbytes = 4.0 * B * (3 * N + D * N + S * K + c3 * S)
+        with _prof("sa_mlp", flops, nbytes):
+            L.check(L.load().pcr_sa_mlp_f32(ctypes.byref(p), L.stream_ptr()), "pcr_sa_mlp_f32")
         return out
 
 
@@ -172,8 +199,14 @@ class AttnPlan:
         p.cfinal = self.cfinal
         p.kv, p.out = _p(kv), _p(out)
         st = L.stream_ptr()
-        L.check(lib.pcr_attn_kv_f32(ctypes.byref(p), st), "pcr_attn_kv_f32")
-        L.check(lib.pcr_attn_apply_f32(ctypes.byref(p), st), "pcr_attn_apply_f32")
+        d = self.d
+        kv_flops = 2.0 * B * Sk * (3 * d + d * c2 + 2 * c2 * d + d * d / self.nhead)
+        ap_flops = 2.0 * B * Lq * (c1 * d + d * d / self.nhead + d * d + (c1 + d) * 2 * d + 2 * d * self.cout
+                                   + self.cout * self.cfinal + (self.q_pos * (3 * d + d * c1)))
+        with _prof("attn_kv", kv_flops, 4.0 * B * (c2 * Sk + 3 * Sk + d * d + d)):
+            L.check(lib.pcr_attn_kv_f32(ctypes.byref(p), st), "pcr_attn_kv_f32")
+        with _prof("attn_apply", ap_flops, 4.0 * B * (c1 * Lq + d * d + d + (self.cfinal or self.cout) * Lq)):
+            L.check(lib.pcr_attn_apply_f32(ctypes.byref(p), st), "pcr_attn_apply_f32")
         return out
 
 
@@ -205,7 +238,8 @@ class HeadPlan:
         for k, v in self.t.items():
             setattr(p, k, _p(v))
         p.pooled, p.logits = _p(pooled), _p(logits)
-        L.check(L.load().pcr_pool_head_f32(ctypes.byref(p), L.stream_ptr()), "pcr_pool_head_f32")
+        with _prof("pool_head", 4.0 * P * (2 * C) ** 2, 4.0 * twoP * C * Lp):
+            L.check(L.load().pcr_pool_head_f32(ctypes.byref(p), L.stream_ptr()), "pcr_pool_head_f32")
         return (logits, pooled) if want_pooled else logits
 
 
