@@ -132,6 +132,14 @@ typedef struct pcr_sa_params {
   const float *xyz, *feat;
   const int *idx, *centre_idx;
   const float *wp[3], *scale[3], *shift[3];
+  /* Optional decomposed first layer (fast path).  Layer 1 is linear in its input row, so
+   *   W1 row = Wa dxyz + P[i] + Q[c],  P = Wf f (per point), Q = (Wc - Wf) f (edge mode only),
+   * with Wa = W1[:, 0:3]; edge mode: Wc = W1[:, 3:3+D], Wf = W1[:, 3+D:3+2D]; query-and-group:
+   * Wf = W1[:, 3:3+D], no Q.  wa is (c1,3) row-major; wpq is the PACKED image of the stacked
+   * matrix [Wf ; Wc - Wf] ((2*c1, D), edge) or Wf ((c1, D), query-and-group); pq_ws is a caller
+   * workspace of B*N*(2*c1 or c1) floats.  Leave wa NULL to force the generic kernel (wp[0]). */
+  const float *wa, *wpq;
+  float *pq_ws;
   float *out;
 } pcr_sa_params;
 int pcr_sa_mlp_f32(const pcr_sa_params *p, pcr_stream_t stream);

@@ -63,6 +63,87 @@ __device__ __forceinline__ void tile_dense(const float *__restrict__ in, int CP,
   }
 }
 
+// Second-generation dense tile: compile-time token tile (RP immediate offsets), each wave OWNS
+// cout blocks and sweeps the token blocks with the weight fragment held in registers (one 16-byte
+// weight load feeds 4*TB MFMAs), weight fragments prefetched one k-block ahead, and an optional
+// barrier between the k-loop and the epilogue so that the output may overwrite the input buffer.
+//   nCB = OP/32 >= 3 : wave w owns cout blocks w, w+4 (NR rounds), all TB token blocks
+//   nCB == 2         : wave w owns cout block w&1 and token blocks (w>>1), (w>>1)+2, ...
+//   nCB == 1         : wave w owns token blocks w, w+4, ...
+template <int TB, int NR, class Epi>
+__device__ __forceinline__ void tile_dense2(const float *__restrict__ in, int CP,
+                                            const float *__restrict__ wp, int OP, bool sync_epi, Epi epi) {
+  constexpr int RP = 32 * TB + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int nCB = OP >> 5, KB = CP >> 3;
+  int cb0, tb0, tbstep;
+  if (nCB >= 3) { cb0 = wave; tb0 = 0; tbstep = 1; }
+  else if (nCB == 2) { cb0 = wave & 1; tb0 = wave >> 1; tbstep = 2; }
+  else { cb0 = 0; tb0 = wave; tbstep = 4; }
+  f32x16 acc[NR][TB];
+#pragma unroll
+  for (int nr = 0; nr < NR; nr++)
+#pragma unroll
+    for (int j = 0; j < TB; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[nr][j][r] = 0.f;
+  const f32x4 *wbase = reinterpret_cast<const f32x4 *>(wp) + (size_t)l31 * 2 + h;
+  const size_t wstride = (size_t)OP * 2;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 a_cur[NR];
+#pragma unroll
+  for (int nr = 0; nr < NR; nr++) {
+    const int cb = cb0 + 4 * nr;
+    a_cur[nr] = (cb < nCB && KB > 0) ? wbase[(size_t)cb * 64] : zero4;
+  }
+  const float *bbase = in + h * RP + l31;
+  for (int kb = 0; kb < KB; kb++) {
+    f32x4 a_nxt[NR];
+#pragma unroll
+    for (int nr = 0; nr < NR; nr++) {
+      const int cb = cb0 + 4 * nr;
+      a_nxt[nr] = (cb < nCB && kb + 1 < KB) ? wbase[(size_t)(kb + 1) * wstride + (size_t)cb * 64] : zero4;
+    }
+    const float *b0 = bbase + kb * 8 * RP;
+#pragma unroll
+    for (int j = 0; j < TB; j++) {
+      const int tb = tb0 + j * tbstep;
+      if (tb < TB) {
+        const float *bt = b0 + tb * 32;
+        const float x0 = bt[0], x1 = bt[2 * RP], x2 = bt[4 * RP], x3 = bt[6 * RP];
+#pragma unroll
+        for (int nr = 0; nr < NR; nr++) {
+          if (cb0 + 4 * nr < nCB) {
+            acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nr][0], x0, acc[nr][j], 0, 0, 0);
+            acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nr][1], x1, acc[nr][j], 0, 0, 0);
+            acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nr][2], x2, acc[nr][j], 0, 0, 0);
+            acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nr][3], x3, acc[nr][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int nr = 0; nr < NR; nr++) a_cur[nr] = a_nxt[nr];
+  }
+  if (sync_epi) __syncthreads();
+#pragma unroll
+  for (int nr = 0; nr < NR; nr++) {
+    const int cb = cb0 + 4 * nr;
+    if (cb < nCB) {
+#pragma unroll
+      for (int j = 0; j < TB; j++) {
+        const int tb = tb0 + j * tbstep;
+        if (tb < TB) {
+          const int t = tb * 32 + l31;
+#pragma unroll
+          for (int r = 0; r < 16; r++) epi(acc[nr][j][r], cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, t);
+        }
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x + 1.0f : (expf(x) - 1.0f) + 1.0f; }
 
 // LayerNorm over the channel rows [0,C) of buf ([C][RP]) for each of the T token columns, in
@@ -176,6 +257,138 @@ __global__ __launch_bounds__(kThreads) void sa_mlp_kernel(SaArgs a) {
     float m = row[0];
     for (int k = 1; k < K; k++) m = fmaxf(m, row[k]);
     p.out[(b * c3 + o) * p.S + c0 + c] = m;
+  }
+}
+
+// ------------------------------------------------- grouped SA MLP, second generation ----
+// Layer 1 is linear in its input rows [dxyz, f_c, f_i - f_c] (edge) or [dxyz, f_i] (query-and-
+// group), so  W1 row = Wa dxyz + P[i] + Q[c]  with the per-POINT tables P = Wf f, Q = (Wc - Wf) f
+// computed once per cloud by dense_pm_kernel (K times fewer FLOPs than per (centre,neighbour)
+// row).  The kernel gathers P rows (16-byte loads) straight into the layer-1 activation tile,
+// then runs layers 2 and 3 on the matrix core IN PLACE in one LDS buffer and reduces max over K.
+struct Sa2Args {
+  int B, N, S, K, c1, c2, c3, CPW;
+  const float *xyz;
+  const int *idx, *centre_idx;
+  const float *wa;          // (c1,3) row-major
+  const float *pq;          // (B,N,pqw) point-major or null (no features)
+  int pqw, qoff;            // row width; offset of Q inside a row, -1 = no Q term
+  const float *wp2, *wp3;
+  const float *sc1, *sh1, *sc2, *sh2, *sc3, *sh3;
+  float *out;
+};
+
+template <int TB, int NR>
+__global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
+  constexpr int ROWS = 32 * TB, RP = ROWS + 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int c1 = a.c1, c2 = a.c2, c3 = a.c3, K = a.K;
+  int rowsC = c1 > c3 ? c1 : c3;
+  if (ceil8(c2) > rowsC) rowsC = ceil8(c2);
+  float *buf = smem;                                        // [rowsC][RP]
+  float *sdx = buf + rowsC * RP;                            // [3][ROWS]
+  int *sidx = reinterpret_cast<int *>(sdx + 3 * ROWS);      // [ROWS] neighbour, [ROWS] centre point
+  int *scen = sidx + ROWS;
+  const int tid = threadIdx.x;
+  const size_t b = blockIdx.y;
+  const int c0 = blockIdx.x * a.CPW;
+  const int nc = (a.S - c0 < a.CPW) ? a.S - c0 : a.CPW;
+  const int rows = nc * K;
+  const float *xyz = a.xyz + b * a.N * 3;
+
+  for (int r = tid; r < ROWS; r += kThreads) {
+    int i = -1, ci = -1;
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (r < rows) {
+      const int s = c0 + r / K;
+      ci = a.centre_idx ? a.centre_idx[b * a.S + s] : s;
+      i = a.idx[(b * a.S + c0) * K + r];
+      dx = xyz[i * 3] - xyz[ci * 3];
+      dy = xyz[i * 3 + 1] - xyz[ci * 3 + 1];
+      dz = xyz[i * 3 + 2] - xyz[ci * 3 + 2];
+    }
+    sidx[r] = i;
+    scen[r] = ci;
+    sdx[r] = dx;
+    sdx[ROWS + r] = dy;
+    sdx[2 * ROWS + r] = dz;
+  }
+  __syncthreads();
+
+  // layer 1 (VALU + gathers): four output channels per item, rows fastest across lanes
+  const float *pq = a.pq ? a.pq + b * a.N * (size_t)a.pqw : nullptr;
+  for (int e = tid; e < ROWS * (c1 >> 2); e += kThreads) {
+    const int r = e % ROWS, o = (e / ROWS) << 2;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows) {
+      const float dx = sdx[r], dy = sdx[ROWS + r], dz = sdx[2 * ROWS + r];
+      const float *w = a.wa + o * 3;
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] = w[3 * j] * dx + w[3 * j + 1] * dy + w[3 * j + 2] * dz;
+      if (pq) {
+        const f32x4 p4 = *reinterpret_cast<const f32x4 *>(pq + (size_t)sidx[r] * a.pqw + o);
+        v += p4;
+        if (a.qoff >= 0) v += *reinterpret_cast<const f32x4 *>(pq + (size_t)scen[r] * a.pqw + a.qoff + o);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] = fmaxf(v[j] * a.sc1[o + j] + a.sh1[o + j], 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) buf[(o + j) * RP + r] = v[j];
+  }
+  __syncthreads();
+  {
+    const float *sc = a.sc2, *sh = a.sh2;
+    const int lim = ceil8(c2);
+    tile_dense2<TB, NR>(buf, c1, a.wp2, ceil32(c2), true, [&](float v, int o, int t) {
+      if (o < lim) buf[o * RP + t] = o < c2 ? fmaxf(v * sc[o] + sh[o], 0.f) : 0.f;
+    });
+  }
+  __syncthreads();
+  {
+    const float *sc = a.sc3, *sh = a.sh3;
+    tile_dense2<TB, NR>(buf, ceil8(c2), a.wp3, ceil32(c3), true, [&](float v, int o, int t) {
+      if (o < c3) buf[o * RP + t] = fmaxf(v * sc[o] + sh[o], 0.f);
+    });
+  }
+  __syncthreads();
+  for (int e = tid; e < c3 * nc; e += kThreads) {
+    const int c = e / c3, o = e - c * c3;
+    const float *row = buf + o * RP + c * K;
+    float m = row[0];
+    for (int k = 1; k < K; k++) m = fmaxf(m, row[k]);
+    a.out[(b * c3 + o) * a.S + c0 + c] = m;
+  }
+}
+
+// y (B,L,cout) POINT-major = W x for x (B,cin,L) channel-major; cout <= 256, no activation.
+struct DensePmArgs {
+  const float *x, *wp;
+  float *y;
+  int cin, cout, L;
+};
+
+__global__ __launch_bounds__(kThreads) void dense_pm_kernel(DensePmArgs a) {
+  constexpr int TB = 2, T = 64, RP = 65;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int cinP = ceil8(a.cin), cout = a.cout;
+  float *X = smem;
+  float *Y = smem + cinP * RP;
+  const size_t b = blockIdx.y;
+  const int t0 = blockIdx.x * T;
+  for (int e = threadIdx.x; e < cinP * T; e += kThreads) {
+    const int c = e / T, t = e - c * T;
+    X[c * RP + t] = (c < a.cin && t0 + t < a.L) ? a.x[(b * a.cin + c) * a.L + t0 + t] : 0.f;
+  }
+  __syncthreads();
+  tile_dense2<TB, 2>(X, cinP, a.wp, ceil32(cout), false, [&](float v, int o, int t) {
+    if (o < cout) Y[o * RP + t] = v;
+  });
+  __syncthreads();
+  float *out = a.y + (b * a.L + t0) * (size_t)cout;
+  for (int e = threadIdx.x; e < cout * T; e += kThreads) {
+    const int t = e / cout, c = e - t * cout;
+    if (t0 + t < a.L) out[(size_t)t * cout + c] = Y[c * RP + t];
   }
 }
 
@@ -549,6 +762,80 @@ PCR_EXPORT int pcr_pack_weight_f32(const float *w, int cout, int cin, float *pac
 
 PCR_EXPORT long pcr_attn_kv_floats(int d) { return (long)d * d + d; }
 
+template <int TB>
+static int sa2_launch_tb(const Sa2Args &a, int nr, size_t lds, hipStream_t st, dim3 grid) {
+  if (nr == 1) {
+    static bool ok = allow_big_lds(sa_fused_kernel<TB, 1>);
+    (void)ok;
+    hipLaunchKernelGGL((sa_fused_kernel<TB, 1>), grid, dim3(kThreads), lds, st, a);
+  } else {
+    static bool ok = allow_big_lds(sa_fused_kernel<TB, 2>);
+    (void)ok;
+    hipLaunchKernelGGL((sa_fused_kernel<TB, 2>), grid, dim3(kThreads), lds, st, a);
+  }
+  return 0;
+}
+
+// fast path; returns -1 when the configuration is not covered (caller falls back to sa_mlp_kernel)
+static int sa2_try(const pcr_sa_params &p, hipStream_t st) {
+  if (!p.wa || (p.D && (!p.wpq || !p.pq_ws))) return -1;
+  if ((p.c1 & 7) || p.c1 > 256 || p.c2 > 256 || p.c3 > 256) return -1;
+  const int pqw = p.mode == 0 ? 2 * p.c1 : p.c1;
+  if (p.D && pqw > 256) return -1;
+  int rowsC = p.c1 > p.c3 ? p.c1 : p.c3;
+  if (ceil8(p.c2) > rowsC) rowsC = ceil8(p.c2);
+  const int n2 = ceil32(p.c2) >> 5, n3 = ceil32(p.c3) >> 5;
+  const int nmin = n2 < n3 ? n2 : n3;
+  const int ways = nmin >= 3 ? 1 : (nmin == 2 ? 2 : 4);
+  const int nr = (n2 > 4 || n3 > 4) ? 2 : 1;
+  int best_cpw = 0, best_tb = 0;
+  for (int pass = 0; pass < 2 && !best_cpw; pass++) {
+    // pass 0: token-block count divisible among the waves and >= 3 workgroups per CU; pass 1: anything that fits
+    for (int cpw = 192 / p.K > 0 ? 192 / p.K : 1; cpw >= 1; cpw--) {
+      const int tb = (cpw * p.K + 31) / 32;
+      if (tb > 6) continue;
+      const size_t lds = ((size_t)rowsC * (32 * tb + 1) + 5 * 32 * tb) * sizeof(float);
+      if (pass == 0 && (tb % ways || lds > 52 * 1024)) continue;
+      if (lds > 150 * 1024) continue;
+      best_cpw = cpw;
+      best_tb = tb;
+      break;
+    }
+  }
+  if (!best_cpw) return -1;
+  if (p.D) {
+    DensePmArgs d{p.feat, p.wpq, p.pq_ws, p.D, pqw, p.N};
+    size_t lds = ((size_t)(ceil8(p.D) + pqw) * 65) * sizeof(float);
+    if (lds > (size_t)kMaxDynLds) return -1;
+    static bool ok = allow_big_lds(dense_pm_kernel);
+    (void)ok;
+    hipLaunchKernelGGL(dense_pm_kernel, dim3((p.N + 63) / 64, p.B), dim3(kThreads), lds, st, d);
+    if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
+  }
+  Sa2Args a;
+  a.B = p.B; a.N = p.N; a.S = p.S; a.K = p.K; a.c1 = p.c1; a.c2 = p.c2; a.c3 = p.c3; a.CPW = best_cpw;
+  a.xyz = p.xyz; a.idx = p.idx; a.centre_idx = p.centre_idx; a.wa = p.wa;
+  a.pq = p.D ? p.pq_ws : nullptr;
+  a.pqw = pqw;
+  a.qoff = p.mode == 0 ? p.c1 : -1;
+  a.wp2 = p.wp[1]; a.wp3 = p.wp[2];
+  a.sc1 = p.scale[0]; a.sh1 = p.shift[0]; a.sc2 = p.scale[1]; a.sh2 = p.shift[1];
+  a.sc3 = p.scale[2]; a.sh3 = p.shift[2];
+  a.out = p.out;
+  const size_t lds = ((size_t)rowsC * (32 * best_tb + 1) + 5 * 32 * best_tb) * sizeof(float);
+  dim3 grid((p.S + best_cpw - 1) / best_cpw, p.B);
+  switch (best_tb) {
+    case 1: sa2_launch_tb<1>(a, nr, lds, st, grid); break;
+    case 2: sa2_launch_tb<2>(a, nr, lds, st, grid); break;
+    case 3: sa2_launch_tb<3>(a, nr, lds, st, grid); break;
+    case 4: sa2_launch_tb<4>(a, nr, lds, st, grid); break;
+    case 5: sa2_launch_tb<5>(a, nr, lds, st, grid); break;
+    default: sa2_launch_tb<6>(a, nr, lds, st, grid); break;
+  }
+  if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
+  return PCR_OK;
+}
+
 PCR_EXPORT int pcr_sa_mlp_f32(const pcr_sa_params *pp, pcr_stream_t stream) {
   if (!pp) return PCR_ERR_INVALID;
   const pcr_sa_params &p = *pp;
@@ -559,6 +846,8 @@ PCR_EXPORT int pcr_sa_mlp_f32(const pcr_sa_params *pp, pcr_stream_t stream) {
     if (!p.wp[l] || !p.scale[l] || !p.shift[l]) return PCR_ERR_INVALID;
   if (p.B == 0 || p.S == 0) return PCR_OK;
   if (p.B > 65535) return PCR_ERR_INVALID;
+  const int fast = sa2_try(p, pcr_s(stream));
+  if (fast >= 0) return fast;
   SaArgs a;
   a.p = p;
   a.C0 = 3 + (p.mode == 0 ? 2 * p.D : p.D);

@@ -42,6 +42,7 @@ class SaParams(ctypes.Structure):
                 ("c1", ctypes.c_int), ("c2", ctypes.c_int), ("c3", ctypes.c_int),
                 ("xyz", c_float_p), ("feat", c_float_p), ("idx", c_int_p), ("centre_idx", c_int_p),
                 ("wp", c_float_p * 3), ("scale", c_float_p * 3), ("shift", c_float_p * 3),
+                ("wa", c_float_p), ("wpq", c_float_p), ("pq_ws", c_float_p),
                 ("out", c_float_p)]
 
 
@@ -117,7 +118,7 @@ def knn_prefix(xyz, S, K):
 class SaPlan:
     """packed 3-layer grouped MLP (conv+BN(eval)+ReLU x3 + max over K)"""
 
-    def __init__(self, convs, bns, device, mode):
+    def __init__(self, convs, bns, device, mode, fast=True):
         assert len(convs) == 3 and len(bns) == 3, "the fused SA kernel covers 3-layer MLPs"
         self.mode = mode
         self.cin = convs[0].weight.shape[1]
@@ -126,6 +127,20 @@ class SaPlan:
         folded = [fold_bn(b, c.bias, device) for c, b in zip(convs, bns)]
         self.scale = [f[0] for f in folded]
         self.shift = [f[1] for f in folded]
+        # decomposed first layer (include/pcr.h, pcr_sa_params): W1 = [Wa | Wc | Wf] (edge) or [Wa | Wf]
+        w1 = convs[0].weight.detach().reshape(self.couts[0], -1).double()
+        D = (self.cin - 3) // 2 if mode == 0 else self.cin - 3
+        self.D = D
+        self.wa = _dev32(w1[:, :3].float(), device)
+        self.wpq = None
+        self.fast = fast
+        if D > 0:
+            if mode == 0:
+                wc, wf = w1[:, 3:3 + D], w1[:, 3 + D:3 + 2 * D]
+                stacked = torch.cat([wf, wc - wf], dim=0)
+            else:
+                stacked = w1[:, 3:3 + D]
+            self.wpq = pack_weight(stacked.float(), device)
 
     def run(self, xyz, feat, idx, centre_idx=None):
         L.require_cuda(xyz, idx)
@@ -143,6 +158,12 @@ class SaPlan:
         for i in range(3):
             p.wp[i], p.scale[i], p.shift[i] = _p(self.wp[i]), _p(self.scale[i]), _p(self.shift[i])
         p.out = _p(out)
+        if self.fast:
+            p.wa = _p(self.wa)
+            if D:
+                pqw = (2 if self.mode == 0 else 1) * self.couts[0]
+                ws = torch.empty((B, N, pqw), dtype=torch.float32, device=xyz.device)
+                p.wpq, p.pq_ws = _p(self.wpq), _p(ws)
         c1, c2, c3 = self.couts
         flops = 2.0 * B * S * K * (self.cin * c1 + c1 * c2 + c2 * c3)
         nbytes = 4.0 * B * (3 * N + D * N + S * K + c3 * S)

@@ -159,3 +159,60 @@ def test_training_mode_fails_loudly():
     s1, s2 = T.synthetic_pairs(1, 128, 1, "randn")
     with pytest.raises(PcrError):
         m.siamese_forward(s1.cuda(), s2.cuda())
+
+
+@pytest.mark.parametrize("mode,D,K,S,N,widths", [(0, 0, 32, 100, 128, (32, 32, 32)), (0, 32, 48, 70, 150, (64, 64, 64)),
+                                                 (0, 64, 48, 33, 96, (128, 128, 128)), (1, 16, 64, 40, 300, (128, 128, 256)),
+                                                 (1, 5, 20, 17, 64, (24, 40, 72)), (0, 8, 16, 50, 50, (32, 64, 128))])
+def test_sa_fast_and_generic_paths_agree_with_torch(mode, D, K, S, N, widths):
+    """fused SA kernel (decomposed layer 1, in-place LDS) vs the generic kernel vs plain torch fp32"""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from pcr_amd import engine
+    g = torch.Generator().manual_seed(5)
+    cin = 3 + (2 * D if mode == 0 else D)
+    convs, bns = [], []
+    last = cin
+    for w in widths:
+        c = nn.Conv2d(last, w, 1)
+        b = nn.BatchNorm2d(w)
+        with torch.no_grad():
+            b.running_mean.copy_(torch.randn(w, generator=g) * 0.1)
+            b.running_var.copy_(torch.rand(w, generator=g) + 0.5)
+            b.weight.copy_(1 + 0.1 * torch.randn(w, generator=g))
+            b.bias.copy_(0.1 * torch.randn(w, generator=g))
+        convs.append(c)
+        bns.append(b.eval())
+        last = w
+    xyz = T.synthetic_clouds(3, N, seed=8, kind="box")
+    feat = torch.randn(3, D, N, generator=g) if D else None
+    idx = torch.randint(0, N, (3, S, K), generator=g, dtype=torch.int32)
+    cidx = torch.randint(0, N, (3, S), generator=g, dtype=torch.int32) if mode == 1 else None
+    # torch reference
+    with torch.no_grad():
+        ci = cidx.long() if cidx is not None else torch.arange(S).expand(3, S)
+        gather = lambda t, ix: torch.gather(t, 1, ix.reshape(3, -1, 1).expand(-1, -1, t.shape[-1])).view(*ix.shape, t.shape[-1])
+        centre_xyz = gather(xyz, ci)
+        rel = gather(xyz, idx.long()) - centre_xyz.unsqueeze(2)
+        rows = rel
+        if D:
+            pts = feat.permute(0, 2, 1)
+            nb = gather(pts, idx.long())
+            if mode == 0:
+                cf = gather(pts, ci).unsqueeze(2)
+                rows = torch.cat([rel, cf.expand(-1, -1, K, -1), nb - cf], -1)
+            else:
+                rows = torch.cat([rel, nb], -1)
+        x = rows.permute(0, 3, 1, 2)
+        for c, b in zip(convs, bns):
+            x = F.relu(b(c(x)))
+        want = x.max(dim=3)[0].numpy()
+    outs = {}
+    for fast in (True, False):
+        plan = engine.SaPlan(convs, bns, "cuda", mode, fast=fast)
+        if not fast:
+            assert plan.fast is False
+        out = plan.run(xyz.cuda(), None if feat is None else feat.cuda(), idx.cuda(),
+                       None if cidx is None else cidx.cuda())
+        outs[fast] = out.cpu().numpy()
+        assert np.abs(outs[fast] - want).max() < 2e-5, (fast, np.abs(outs[fast] - want).max())
