@@ -68,7 +68,7 @@ def hot_path(model, s1, s2):
     return model.match_forward_inference(h1, h2, xyz1, xyz2)
 
 
-def profile_kernels(model, s1, s2, reps=3):
+def profile_kernels(model, s1, s2, reps=3, detail=False):
     """per-launch device time with events on the launch stream; returns the dominant launch"""
     from pcr_amd import engine
     best = None
@@ -82,6 +82,8 @@ def profile_kernels(model, s1, s2, reps=3):
         tot = {}
         for name, e0, e1, flops, nbytes in rec:
             ms = e0.elapsed_time(e1)
+            if not detail:
+                name = name.split("[")[0]
             t = tot.setdefault(name, [0.0, 0, 0.0, 0.0])
             t[0] += ms
             t[1] += 1
@@ -133,6 +135,7 @@ def main():
     ap.add_argument("--workload", default="pt1024", choices=sorted(WORKLOADS))
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (default: per workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--detail", action="store_true", help="also print per-launch device times (stderr)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -203,6 +206,11 @@ def main():
                        "points": n, "backbone_list": bl, "parallelism": "independent pair shards x%d" % world},
             "roofline": roof,
         }
+        if args.detail:
+            det = profile_kernels(model, s1, s2, detail=True)
+            for k, v in sorted(det.items(), key=lambda kv: -kv[1][0]):
+                print("%-52s %8.3f ms x%d  %7.2f TFLOP/s  %7.1f GB/s(alg)" % (
+                    k, v[0], v[1], v[2] / (v[0] * 1e-3) / 1e12, v[3] / (v[0] * 1e-3) / 1e9), file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, sd)
         print(json.dumps(line), flush=True)

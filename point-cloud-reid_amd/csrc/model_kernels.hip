@@ -395,7 +395,6 @@ __global__ __launch_bounds__(kThreads) void dense_pm_kernel(DensePmArgs a) {
 // -------------------------------------------------------------- linear attention ----
 struct AttnArgs {
   pcr_attn_params p;
-  int TB, RP;
 };
 
 // loads a [C][T] tile of a (B,C,L) tensor into LDS rows [0,CP), zero beyond C or beyond L
@@ -415,24 +414,29 @@ __device__ __forceinline__ void load_xyz_tile(float *dst, int RP, const float *x
   }
 }
 
+// Token tile of the attention kernels: T = 32*TB tokens with TB = 4 / 2 / 1 for d_model 32 / 64 /
+// 128, so that every dense layer has at least four (cout-block, token-block) tiles -- one per wave
+// -- and the LDS image stays ~70 KiB (two workgroups per CU).
+
 // One workgroup per key-side cloud.  kv image per cloud: packed [d x d] matrix W'[v][dd] =
 // sum_s K[s][dd] V[s][v] / Sk for dd, v in the same head (zero elsewhere), followed by ksum[d].
+// LDS: X [c2P] key features (later K), XP [max(c2P,d)] pos hidden -> features+pos -> V, P [8] xyz.
+template <int TB>
 __global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
+  constexpr int T = 32 * TB, RP = T + 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const pcr_attn_params &p = a.p;
-  const int RP = a.RP, TB = a.TB, T = 32 * TB;
   const int d = p.d, c2 = p.c2, c2P = ceil8(c2);
-  float *X = smem;                 // [c2P][RP]   key features
-  float *XP = X + c2P * RP;        // [c2P][RP]   + position encoding
-  float *P = XP + c2P * RP;        // [8][RP]     xyz
-  float *H = P + 8 * RP;           // [d][RP]     pos hidden / later K
-  float *Vb = H + d * RP;          // [d][RP]
+  const int rowsXP = c2P > d ? c2P : d;
+  float *X = smem;
+  float *XP = X + (c2P > d ? c2P : d) * RP;
+  float *P = XP + rowsXP * RP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const size_t b = blockIdx.x;
   const float *feat = p.feat_k + b * c2 * p.Sk;
   const float *xyz = p.xyz_k + b * p.Sk * 3;
-  const int nT = (d >> 5) * (d >> 5);
+  const int nb = d >> 5, nT = nb * nb;
   const int dh = d / p.nhead;
 
   f32x16 acc[4];
@@ -443,31 +447,34 @@ __global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
   float ksum = 0.f;
 
   for (int t0 = 0; t0 < p.Sk; t0 += T) {
+    const int valid = p.Sk - t0;
     load_tile(X, RP, feat, c2, c2P, p.Sk, t0, T);
     load_xyz_tile(P, RP, xyz, p.Sk, t0, T);
     __syncthreads();
-    {  // pos hidden = relu(W0 xyz + b0)
+    {  // pos hidden = relu(W0 xyz + b0) -> XP rows [0,d)
       const float *bb = p.pos0_b;
-      tile_dense(P, 8, RP, TB, p.pos0_w, d, [&](float v, int o, int t) { H[o * RP + t] = fmaxf(v + bb[o], 0.f); });
+      tile_dense2<TB, 2>(P, 8, p.pos0_w, d, false, [&](float v, int o, int t) { XP[o * RP + t] = fmaxf(v + bb[o], 0.f); });
     }
     __syncthreads();
-    {  // XP = X + W2 hidden + b2
+    {  // XP = X + W2 hidden + b2, in place over the hidden rows
       const float *bb = p.pos2_b;
-      tile_dense(H, d, RP, TB, p.pos2_w, ceil32(c2), [&](float v, int o, int t) {
+      tile_dense2<TB, 2>(XP, d, p.pos2_w, ceil32(c2), true, [&](float v, int o, int t) {
         if (o < c2P) XP[o * RP + t] = o < c2 ? X[o * RP + t] + (v + bb[o]) : 0.f;
       });
     }
     __syncthreads();
-    {  // K = elu(Wk x)+1 (zero on padded tokens), V = Wv xp / Sk
-      const float *kin = p.k_pos ? XP : X;
-      const int valid = p.Sk - t0;
-      tile_dense(kin, c2P, RP, TB, p.wk, d, [&](float v, int o, int t) { H[o * RP + t] = t < valid ? elu1(v) : 0.f; });
-      const float invs = (float)p.Sk;
-      tile_dense(XP, c2P, RP, TB, p.wv, d, [&](float v, int o, int t) { Vb[o * RP + t] = t < valid ? v / invs : 0.f; });
+    // K = elu(Wk x)+1 (zero on padded tokens) -> X rows [0,d); in place when keys carry no position
+    tile_dense2<TB, 2>(p.k_pos ? XP : X, c2P, p.wk, d, true, [&](float v, int o, int t) {
+      X[o * RP + t] = t < valid ? elu1(v) : 0.f;
+    });
+    __syncthreads();
+    {  // V = Wv xp / Sk -> XP rows [0,d), in place
+      const float sk = (float)p.Sk;
+      tile_dense2<TB, 2>(XP, c2P, p.wv, d, true, [&](float v, int o, int t) { XP[o * RP + t] = t < valid ? v / sk : 0.f; });
     }
     __syncthreads();
     if (tid < d) {
-      const float *row = H + tid * RP;
+      const float *row = X + tid * RP;
       float s = 0.f;
       for (int t = 0; t < T; t++) s += row[t];
       ksum += s;
@@ -476,9 +483,10 @@ __global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
     for (int it = 0; it < 4; it++) {
       const int item = wave + 4 * it;
       if (item < nT) {
-        const int ib = item / (d >> 5), jb = item - ib * (d >> 5);
-        const float *ap = H + (ib * 32 + l31) * RP + h;
-        const float *bp = Vb + (jb * 32 + l31) * RP + h;
+        const int ib = item / nb, jb = item - ib * nb;
+        const float *ap = X + (ib * 32 + l31) * RP + h;
+        const float *bp = XP + (jb * 32 + l31) * RP + h;
+#pragma unroll 4
         for (int ks = 0; ks < T / 2; ks++)
           acc[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc[it], 0, 0, 0);
       }
@@ -490,7 +498,7 @@ __global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
   for (int it = 0; it < 4; it++) {
     const int item = wave + 4 * it;
     if (item < nT) {
-      const int ib = item / (d >> 5), jb = item - ib * (d >> 5);
+      const int ib = item / nb, jb = item - ib * nb;
       const int v = jb * 32 + l31;
 #pragma unroll
       for (int r = 0; r < 16; r++) {
@@ -504,20 +512,24 @@ __global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
   if (tid < d) kv[(size_t)d * d + tid] = ksum;
 }
 
-// One workgroup per (query cloud, tile of 32*TB query tokens).
+// One workgroup per (query cloud, tile of T query tokens).
+// LDS: CAT [c1+d (pad 8)] rows [0,c1) query features, [c1,c1+d) message; W [max(2d,cout,cfinal)]
+// working buffer (every dense layer but the cat feed-forward runs in place in it); P [8]; zs; red.
+template <int TB>
 __global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
+  constexpr int T = 32 * TB, RP = T + 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const pcr_attn_params &p = a.p;
-  const int RP = a.RP, TB = a.TB, T = 32 * TB;
   const int d = p.d, c1 = p.c1, cout = p.cout;
   const int catC = c1 + d, catP = ceil8(catC);
-  const int rowsA = d > cout ? (d > p.cfinal ? d : p.cfinal) : (cout > p.cfinal ? cout : p.cfinal);
-  float *CAT = smem;                  // [catP][RP]  rows [0,c1) query feats, [c1,c1+d) message
-  float *A = CAT + catP * RP;         // [rowsA][RP]
-  float *Bf = A + rowsA * RP;         // [2d][RP]
-  float *P = Bf + 2 * d * RP;         // [8][RP]
-  float *zs = P + 8 * RP;             // [nhead][RP]
-  float *red = zs + p.nhead * RP;     // [16][T]
+  int rowsW = 2 * d;
+  if (cout > rowsW) rowsW = cout;
+  if (p.cfinal > rowsW) rowsW = p.cfinal;
+  float *CAT = smem;
+  float *W = CAT + catP * RP;
+  float *P = W + rowsW * RP;
+  float *zs = P + 8 * RP;
+  float *red = zs + p.nhead * RP;  // [2 * (256/T)][T]
   const int tid = threadIdx.x;
   const size_t b = blockIdx.y;
   const int t0 = blockIdx.x * T;
@@ -535,67 +547,63 @@ __global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
   if (p.q_pos) load_xyz_tile(P, RP, p.xyz_q + b * p.Lq * 3, p.Lq, t0, T);
   __syncthreads();
 
-  const float *qin = CAT;
-  int qinP = ceil8(c1);
-  if (p.q_pos) {  // Self_Attention: q (and k,v) use feat + pos_mlp(xyz); requires c1 == c2
+  if (p.q_pos) {  // Self_Attention: q uses feat + pos_mlp(xyz); c1 == c2 == d
     const float *b0 = p.pos0_b, *b2 = p.pos2_b;
-    tile_dense(P, 8, RP, TB, p.pos0_w, d, [&](float v, int o, int t) { Bf[o * RP + t] = fmaxf(v + b0[o], 0.f); });
+    tile_dense2<TB, 2>(P, 8, p.pos0_w, d, false, [&](float v, int o, int t) { W[o * RP + t] = fmaxf(v + b0[o], 0.f); });
     __syncthreads();
-    tile_dense(Bf, d, RP, TB, p.pos2_w, ceil32(c1), [&](float v, int o, int t) {
-      if (o < c1) A[o * RP + t] = CAT[o * RP + t] + (v + b2[o]);
+    tile_dense2<TB, 2>(W, d, p.pos2_w, ceil32(c1), true, [&](float v, int o, int t) {
+      if (o < c1) W[o * RP + t] = CAT[o * RP + t] + (v + b2[o]);
     });
     __syncthreads();
-    qin = A;
-    qinP = c1;  // c1 == d, multiple of 32
+    tile_dense2<TB, 2>(W, c1, p.wq, d, true, [&](float v, int o, int t) { W[o * RP + t] = elu1(v); });
+  } else {
+    // the (still zero) message rows of CAT double as zero padding of the query features
+    tile_dense2<TB, 2>(CAT, ceil8(c1), p.wq, d, false, [&](float v, int o, int t) { W[o * RP + t] = elu1(v); });
   }
-  // the message rows of CAT double as zero padding of the query features when c1 % 8 != 0
-  tile_dense(qin, qinP, RP, TB, p.wq, d, [&](float v, int o, int t) { Bf[o * RP + t] = elu1(v); });
   __syncthreads();
   for (int e = tid; e < p.nhead * T; e += kThreads) {
     const int hd = e / T, t = e - hd * T;
     float z = 0.f;
-    for (int c = 0; c < dh; c++) z += Bf[(hd * dh + c) * RP + t] * ksum[hd * dh + c];
+    for (int c = 0; c < dh; c++) z += W[(hd * dh + c) * RP + t] * ksum[hd * dh + c];
     zs[hd * RP + t] = 1.0f / (z + 1e-6f);
   }
   __syncthreads();
   {
     const float sk = (float)p.Sk;
-    tile_dense(Bf, d, RP, TB, kv, d, [&](float v, int o, int t) { A[o * RP + t] = v * zs[(o / dh) * RP + t] * sk; });
+    tile_dense2<TB, 2>(W, d, kv, d, true, [&](float v, int o, int t) { W[o * RP + t] = v * zs[(o / dh) * RP + t] * sk; });
   }
   __syncthreads();
-  tile_dense(A, d, RP, TB, p.wmerge, d, [&](float v, int o, int t) { CAT[(c1 + o) * RP + t] = v; });
+  tile_dense2<TB, 2>(W, d, p.wmerge, d, false, [&](float v, int o, int t) { CAT[(c1 + o) * RP + t] = v; });
   __syncthreads();
   tile_layernorm(CAT + c1 * RP, d, RP, T, p.ln1_g, p.ln1_b, red);
-  tile_dense(CAT, catP, RP, TB, p.wmlp0, 2 * d, [&](float v, int o, int t) { Bf[o * RP + t] = fmaxf(v, 0.f); });
+  tile_dense2<TB, 2>(CAT, catP, p.wmlp0, 2 * d, false, [&](float v, int o, int t) { W[o * RP + t] = fmaxf(v, 0.f); });
   __syncthreads();
-  tile_dense(Bf, 2 * d, RP, TB, p.wmlp2, ceil32(cout), [&](float v, int o, int t) {
-    if (o < cout) A[o * RP + t] = v;
+  tile_dense2<TB, 2>(W, 2 * d, p.wmlp2, ceil32(cout), true, [&](float v, int o, int t) {
+    if (o < cout) W[o * RP + t] = v;
   });
   __syncthreads();
-  tile_layernorm(A, cout, RP, T, p.ln2_g, p.ln2_b, red);
+  tile_layernorm(W, cout, RP, T, p.ln2_g, p.ln2_b, red);
   if (p.residual) {
     for (int e = tid; e < cout * T; e += kThreads) {
       const int c = e / T, t = e - c * T;
-      A[c * RP + t] = CAT[c * RP + t] + A[c * RP + t];
+      W[c * RP + t] = CAT[c * RP + t] + W[c * RP + t];
     }
     __syncthreads();
   }
-  const float *res = A;
   int cres = cout;
   if (p.cfinal) {  // trailing 1x1 conv with bias (cov_final); needs cout % 8 == 0
     const float *bf = p.bfinal;
     const int cf = p.cfinal;
-    tile_dense(A, ceil8(cout), RP, TB, p.wfinal, ceil32(cf), [&](float v, int o, int t) {
-      if (o < cf) Bf[o * RP + t] = v + bf[o];
+    tile_dense2<TB, 2>(W, cout, p.wfinal, ceil32(cf), true, [&](float v, int o, int t) {
+      if (o < cf) W[o * RP + t] = v + bf[o];
     });
     __syncthreads();
-    res = Bf;
     cres = cf;
   }
   float *out = p.out + b * cres * p.Lq;
   for (int e = tid; e < cres * T; e += kThreads) {
     const int c = e / T, t = e - c * T;
-    if (t0 + t < p.Lq) out[(size_t)c * p.Lq + t0 + t] = res[c * RP + t];
+    if (t0 + t < p.Lq) out[(size_t)c * p.Lq + t0 + t] = W[c * RP + t];
   }
 }
 
@@ -887,19 +895,26 @@ static int attn_check(const pcr_attn_params &p) {
   return 0;
 }
 
+static int attn_tb(int d) { return d <= 32 ? 4 : (d <= 64 ? 2 : 1); }
+
 PCR_EXPORT int pcr_attn_kv_f32(const pcr_attn_params *pp, pcr_stream_t stream) {
   if (!pp || attn_check(*pp)) return PCR_ERR_INVALID;
   if (pp->B == 0) return PCR_OK;
   AttnArgs a;
   a.p = *pp;
-  a.TB = 1;
-  a.RP = 32 * a.TB + 1;
+  const int tb = attn_tb(pp->d), RP = 32 * tb + 1;
   const int c2P = ceil8(pp->c2);
-  size_t lds = ((size_t)(2 * c2P + 8 + 2 * pp->d) * a.RP) * sizeof(float);
+  const int rowsX = c2P > pp->d ? c2P : pp->d;
+  size_t lds = ((size_t)(2 * rowsX + 8) * RP) * sizeof(float);
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
-  static bool ok = allow_big_lds(attn_kv_kernel);
+  static bool ok = allow_big_lds(attn_kv_kernel<1>) && allow_big_lds(attn_kv_kernel<2>) &&
+                   allow_big_lds(attn_kv_kernel<4>);
   (void)ok;
-  hipLaunchKernelGGL(attn_kv_kernel, dim3(pp->B), dim3(kThreads), lds, pcr_s(stream), a);
+  dim3 g(pp->B), blk(kThreads);
+  hipStream_t st = pcr_s(stream);
+  if (tb == 4) hipLaunchKernelGGL(attn_kv_kernel<4>, g, blk, lds, st, a);
+  else if (tb == 2) hipLaunchKernelGGL(attn_kv_kernel<2>, g, blk, lds, st, a);
+  else hipLaunchKernelGGL(attn_kv_kernel<1>, g, blk, lds, st, a);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }
@@ -911,18 +926,21 @@ PCR_EXPORT int pcr_attn_apply_f32(const pcr_attn_params *pp, pcr_stream_t stream
   const pcr_attn_params &p = *pp;
   AttnArgs a;
   a.p = p;
-  a.TB = 1;
-  a.RP = 32 * a.TB + 1;
-  const int T = 32 * a.TB;
+  const int tb = attn_tb(p.d), T = 32 * tb, RP = T + 1;
   const int catP = ceil8(p.c1 + p.d);
-  int rowsA = p.d > p.cout ? p.d : p.cout;
-  if (p.cfinal > rowsA) rowsA = p.cfinal;
-  size_t lds = ((size_t)(catP + rowsA + 2 * p.d + 8 + p.nhead) * a.RP + 16 * T) * sizeof(float);
+  int rowsW = 2 * p.d;
+  if (p.cout > rowsW) rowsW = p.cout;
+  if (p.cfinal > rowsW) rowsW = p.cfinal;
+  size_t lds = ((size_t)(catP + rowsW + 8 + p.nhead) * RP + 2 * (kThreads / T) * T) * sizeof(float);
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
-  static bool ok = allow_big_lds(attn_apply_kernel);
+  static bool ok = allow_big_lds(attn_apply_kernel<1>) && allow_big_lds(attn_apply_kernel<2>) &&
+                   allow_big_lds(attn_apply_kernel<4>);
   (void)ok;
-  hipLaunchKernelGGL(attn_apply_kernel, dim3((p.Lq + T - 1) / T, p.B), dim3(kThreads), lds,
-                     pcr_s(stream), a);
+  dim3 g((p.Lq + T - 1) / T, p.B), blk(kThreads);
+  hipStream_t st = pcr_s(stream);
+  if (tb == 4) hipLaunchKernelGGL(attn_apply_kernel<4>, g, blk, lds, st, a);
+  else if (tb == 2) hipLaunchKernelGGL(attn_apply_kernel<2>, g, blk, lds, st, a);
+  else hipLaunchKernelGGL(attn_apply_kernel<1>, g, blk, lds, st, a);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }

@@ -393,11 +393,19 @@ __global__ void three_interp_bwd_kernel(const float *__restrict__ grad_out,
 }
 
 constexpr int kKnnPThreads = 256;
+constexpr int kKnnCap = 256;  // candidates per query the fast path can rank (4 per lane)
 // -------------------------------------------------------------- PT neighbour search ----
-// One wave per query; lane l holds the distances to points l, l+64, ... in registers; K rounds
-// of (local argmin, wave argmin on a packed (distance,index) key, knock-out).  The cloud is
-// staged once per workgroup as SoA in LDS (broadcast reads of the query, stride-1 reads of the
-// candidates).  Output order: (distance, index) ascending.
+// One wave per query; lane l holds the distances to points l, l+64, ... in registers.  The cloud
+// is staged once per workgroup as SoA in LDS (broadcast reads of the query, stride-1 reads of the
+// candidates).  Selection without sorting N values:
+//   1. tau = K-th smallest of the 64 per-lane minima: an upper bound of the K-th smallest distance
+//      (those minima are 64 distinct points), found by rank counting with v_readlane broadcasts;
+//   2. every point with d <= tau (typically 1-3 K of them) is compacted into LDS as a packed
+//      (distance, index) key;
+//   3. each candidate's rank among the candidates is counted with broadcast LDS reads; ranks < K
+//      are the answer, already in (distance, index) order.
+// If more than kKnnCap points pass (heavily duplicated clouds) the wave falls back to K rounds of
+// (local argmin, wave argmin, knock-out) over all points.  Both paths give the same output.
 template <int T>
 __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_kernel(const float *__restrict__ xyz,
                                                               int *__restrict__ idx, int n, int S,
@@ -405,6 +413,8 @@ __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_kernel(const float *_
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *sx = smem, *sy = smem + n, *sz = smem + 2 * n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long *cand =
+      reinterpret_cast<unsigned long long *>(smem + 3 * n + (n & 1)) + wave * kKnnCap;
   const size_t b = blockIdx.y;
   const float *cloud = xyz + b * n * 3;
   for (int i = tid; i < n; i += kKnnPThreads) {
@@ -418,32 +428,80 @@ __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_kernel(const float *_
   for (int q = q0 + wave; q < q1; q += kKnnPThreads / 64) {
     const float qx = sx[q], qy = sy[q], qz = sz[q];
     float d[T];
+    float m = INFINITY;
 #pragma unroll
     for (int t = 0; t < T; t++) {
       int i = lane + 64 * t;
       d[t] = i < n ? pcr_sqdist3(qx, qy, qz, sx[i], sy[i], sz[i]) : INFINITY;
+      m = fminf(m, d[t]);
     }
-    int mine = 0;
-    for (int k = 0; k < K; k++) {
-      float bd = d[0];
-      int bt = 0;
+    // 1. K-th smallest lane minimum (ties ordered by lane)
+    int rank = 0;
+    for (int j = 0; j < 64; j++) {
+      const float vj = __shfl(m, j, 64);
+      rank += (vj < m || (vj == m && j < lane)) ? 1 : 0;
+    }
+    const unsigned long long hit = __ballot(rank == K - 1);
+    const float tau = __shfl(m, hit ? __ffsll((long long)hit) - 1 : 0, 64);
+    // 2. candidates d <= tau
+    int cnt = 0;
 #pragma unroll
-      for (int t = 1; t < T; t++)
-        if (d[t] < bd) { bd = d[t]; bt = t; }
-      unsigned long long key = ((unsigned long long)pcr_orderable(bd) << 32) | (unsigned)(lane + 64 * bt);
-      key = pcr_wave_min_u64(key);
-      const int win = (int)(key & 0xFFFFFFFFull);
-      if (lane == k) mine = win;
-      if (lane == (win & 63)) {
-        const int wt = win >> 6;
+    for (int t = 0; t < T; t++) cnt += d[t] <= tau ? 1 : 0;
+    int incl = cnt;
 #pragma unroll
-        for (int t = 0; t < T; t++) d[t] = (t == wt) ? INFINITY : d[t];
+    for (int s = 1; s < 64; s <<= 1) {
+      const int o = __shfl_up(incl, s, 64);
+      if (lane >= s) incl += o;
+    }
+    const int total = __shfl(incl, 63, 64);
+    int *out = idx + (b * S + q) * K;
+    if (hit != 0ull && total <= kKnnCap) {
+      int off = incl - cnt;
+#pragma unroll
+      for (int t = 0; t < T; t++)
+        if (d[t] <= tau)
+          cand[off++] = ((unsigned long long)pcr_orderable(d[t]) << 32) | (unsigned)(lane + 64 * t);
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      // 3. rank among candidates (each lane owns candidates lane, lane+64, ...)
+      unsigned long long own[kKnnCap / 64];
+      int rk[kKnnCap / 64];
+#pragma unroll
+      for (int u = 0; u < kKnnCap / 64; u++) {
+        own[u] = lane + 64 * u < total ? cand[lane + 64 * u] : ~0ull;
+        rk[u] = 0;
       }
+      for (int j = 0; j < total; j++) {
+        const unsigned long long cj = cand[j];
+#pragma unroll
+        for (int u = 0; u < kKnnCap / 64; u++) rk[u] += cj < own[u] ? 1 : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < kKnnCap / 64; u++)
+        if (lane + 64 * u < total && rk[u] < K) out[rk[u]] = (int)(own[u] & 0xFFFFFFFFull);
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      int mine = 0;
+      for (int k = 0; k < K; k++) {
+        float bd = d[0];
+        int bt = 0;
+#pragma unroll
+        for (int t = 1; t < T; t++)
+          if (d[t] < bd) { bd = d[t]; bt = t; }
+        unsigned long long key = ((unsigned long long)pcr_orderable(bd) << 32) | (unsigned)(lane + 64 * bt);
+        key = pcr_wave_min_u64(key);
+        const int win = (int)(key & 0xFFFFFFFFull);
+        if (lane == k) mine = win;
+        if (lane == (win & 63)) {
+          const int wt = win >> 6;
+#pragma unroll
+          for (int t = 0; t < T; t++) d[t] = (t == wt) ? INFINITY : d[t];
+        }
+      }
+      if (lane < K) out[lane] = mine;
     }
-    if (lane < K) idx[(b * S + q) * K + lane] = mine;
   }
 }
-
 
 }  // namespace
 
@@ -564,7 +622,7 @@ PCR_EXPORT int pcr_knn_prefix_f32(const float *xyz, int *idx, int B, int N, int 
   if (B > 65535) return PCR_ERR_INVALID;
   const int qpw = 32;
   dim3 g((S + qpw - 1) / qpw, B), blk(kKnnPThreads);
-  size_t lds = (size_t)3 * N * sizeof(float);
+  size_t lds = (size_t)(3 * N + (N & 1)) * sizeof(float) + (size_t)4 * kKnnCap * 8;
   hipStream_t st = pcr_s(stream);
 #define PCR_KNN_CASE(T) hipLaunchKernelGGL((knn_prefix_kernel<T>), g, blk, lds, st, xyz, idx, N, S, K, qpw)
   if (N <= 64) PCR_KNN_CASE(1);

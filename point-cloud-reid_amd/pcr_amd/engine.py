@@ -109,7 +109,7 @@ def knn_prefix(xyz, S, K):
     assert xyz.is_contiguous() and xyz.dtype == torch.float32
     B, N, _ = xyz.shape
     idx = torch.empty((B, S, K), dtype=torch.int32, device=xyz.device)
-    with _prof("knn_prefix", 8.0 * B * S * N, 12.0 * B * N + 4.0 * B * S * K):
+    with _prof("knn_prefix[N=%d,S=%d,K=%d]" % (N, S, K), 8.0 * B * S * N, 12.0 * B * N + 4.0 * B * S * K):
         L.check(L.load().pcr_knn_prefix_f32(L.ptr(xyz), L.ptr(idx), B, N, S, K, L.stream_ptr()),
                 "pcr_knn_prefix_f32")
     return idx
@@ -167,7 +167,7 @@ class SaPlan:
         c1, c2, c3 = self.couts
         flops = 2.0 * B * S * K * (self.cin * c1 + c1 * c2 + c2 * c3)
         nbytes = 4.0 * B * (3 * N + D * N + S * K + c3 * S)
-        with _prof("sa_mlp", flops, nbytes):
+        with _prof("sa_mlp[D=%d,c=%d/%d/%d,N=%d,S=%d,K=%d]" % (D, c1, c2, c3, N, S, K), flops, nbytes):
             L.check(L.load().pcr_sa_mlp_f32(ctypes.byref(p), L.stream_ptr()), "pcr_sa_mlp_f32")
         return out
 
@@ -224,9 +224,9 @@ class AttnPlan:
         kv_flops = 2.0 * B * Sk * (3 * d + d * c2 + 2 * c2 * d + d * d / self.nhead)
         ap_flops = 2.0 * B * Lq * (c1 * d + d * d / self.nhead + d * d + (c1 + d) * 2 * d + 2 * d * self.cout
                                    + self.cout * self.cfinal + (self.q_pos * (3 * d + d * c1)))
-        with _prof("attn_kv", kv_flops, 4.0 * B * (c2 * Sk + 3 * Sk + d * d + d)):
+        with _prof("attn_kv[d=%d,c2=%d,Sk=%d]" % (d, c2, Sk), kv_flops, 4.0 * B * (c2 * Sk + 3 * Sk + d * d + d)):
             L.check(lib.pcr_attn_kv_f32(ctypes.byref(p), st), "pcr_attn_kv_f32")
-        with _prof("attn_apply", ap_flops, 4.0 * B * (c1 * Lq + d * d + d + (self.cfinal or self.cout) * Lq)):
+        with _prof("attn_apply[d=%d,c1=%d,out=%d,Lq=%d]" % (d, c1, self.cfinal or self.cout, Lq), ap_flops, 4.0 * B * (c1 * Lq + d * d + d + (self.cfinal or self.cout) * Lq)):
             L.check(lib.pcr_attn_apply_f32(ctypes.byref(p), st), "pcr_attn_apply_f32")
         return out
 
