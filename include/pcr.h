@@ -147,28 +147,37 @@ int pcr_sa_mlp_f32(const pcr_sa_params *p, pcr_stream_t stream);
 /* Linear-attention block shared by Self_Attention (models/pointnet2_utils.py:90-114), FP_SA
  * (:407-437) and corss_attention (models/attention.py:192-219), in two kernels.
  *
- * pcr_attn_kv_f32: per key-side cloud, kp = [pos_mlp(xyz_k) +] feat_k; K = elu(Wk x)+1 with
- *   x = kp if k_pos else feat_k; V = Wv kp; writes kv (B, d+?) = the block-diagonal (per head)
- *   sum_s K V^T / Sk already in packed-weight form plus ksum (B,d) = sum_s K.
- * pcr_attn_apply_f32: per query token, Q = elu(Wq x)+1 (x = feat_q [+ pos_mlp(xyz_q)] if q_pos),
- *   msg = (Q . KV) / (Q . ksum + 1e-6) * Sk, merge, LayerNorm, feed-forward on [feat_q, msg],
- *   LayerNorm, optional residual; cloud b reads the kv of cloud kv_index[b] (NULL => b), which is
- *   how the siamese matching head pairs clouds without copying (ReIDNet.xcorr_eff,
- *   models/ReIDNet.py:231-247).  Optional fused trailing 1x1 conv (Pointnet_Backbone.cov_final,
- *   models/backbone_net.py:89,124). */
+ * With h = relu(W0 xyz + b0) the reference's position encoding is pos = W2 h + b2; the HOST folds
+ * W2/b2 into the projections (all products formed in fp64, rounded once to fp32):
+ *   wq  = packed [Wq | Wq W2] (d, c1+d)  if q_pos  else packed Wq (d, c1);   bq = Wq b2 or 0
+ *   wkv = packed [[Wk | kpos Wk W2] ; [Wv | Wv W2]] (2d, c2+d);   bkv = [kpos Wk b2 ; Wv b2]
+ * where kpos = 1 for Self_Attention (keys carry the position encoding) and 0 otherwise.
+ *
+ * pcr_attn_kv_f32: per key-side cloud, K = elu(.)+1, V = (.)/Sk from one fused projection of
+ *   [feat_k ; h]; accumulates KV_head = sum_s K V^T and ksum = sum_s K, folds the merge projection
+ *   (wmerge (d,d) row-major) into KV and writes, per cloud, the packed (d,d) matrix
+ *   M[o][dd] = sum_{v in head(dd)} Wm[o][v] KV[dd][v] followed by ksum (d).
+ * pcr_attn_apply_f32: per query token, Q = elu(wq [x ; h] + bq)+1, Q' = Q Sk / (Q.ksum + 1e-6)
+ *   per head, msg = LayerNorm(M Q'), feed-forward mlp2(relu(mlp0 [x ; msg])), LayerNorm, optional
+ *   residual; cloud b reads the kv image of cloud kv_index[b] (NULL => b), which is how the siamese
+ *   matching head pairs clouds without copying (ReIDNet.xcorr_eff, models/ReIDNet.py:231-247).
+ *   Optional fused trailing 1x1 conv (Pointnet_Backbone.cov_final, models/backbone_net.py:89,124).
+ * d_model in {32,64,96,128}; c2 % 8 == 0; q_pos requires c1 == c2 == d; residual requires cout == c1. */
 typedef struct pcr_attn_params {
   int B, Lq, Sk;             /* clouds, query tokens per cloud, key tokens per cloud */
   int c1, c2, d, cout;       /* query feature dim, key feature dim, d_model, output dim */
   int nhead;
-  int q_pos, k_pos, residual;
-  const float *feat_q, *xyz_q; /* (B,c1,Lq), (B,Lq,3) */
+  int q_pos, residual;
+  const float *feat_q, *xyz_q; /* (B,c1,Lq), (B,Lq,3) (xyz_q only read when q_pos) */
   const float *feat_k, *xyz_k; /* (B,c2,Sk), (B,Sk,3) */
   const int *kv_index;         /* (B) or NULL */
-  /* packed weights */
-  const float *pos0_w, *pos0_b, *pos2_w, *pos2_b; /* 3->d ; d->c2 (key side) */
-  const float *wq, *wk, *wv, *wmerge, *wmlp0, *wmlp2;
+  const float *pos0_w, *pos0_b;   /* (d,3) row-major, (d) */
+  const float *wq, *bq;           /* packed fused query projection, (d) */
+  const float *wkv, *bkv;         /* packed fused key/value projection, (2d) */
+  const float *wmerge;            /* (d,d) row-major */
+  const float *wmlp0, *wmlp2;     /* packed (2d, c1+d), packed (cout, 2d) */
   const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
-  const float *wfinal, *bfinal; int cfinal;       /* optional trailing conv (NULL/0 = none) */
+  const float *wfinal, *bfinal; int cfinal;       /* optional trailing conv: packed (cfinal,cout), (cfinal) */
   float *kv;    /* workspace (B, pcr_attn_kv_floats(d)) */
   float *out;   /* (B, cfinal ? cfinal : cout, Lq) */
 } pcr_attn_params;

@@ -289,6 +289,7 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
   float *sdx = buf + rowsC * RP;                            // [3][ROWS]
   int *sidx = reinterpret_cast<int *>(sdx + 3 * ROWS);      // [ROWS] neighbour, [ROWS] centre point
   int *scen = sidx + ROWS;
+  float *sq = reinterpret_cast<float *>(scen + ROWS);     // [CPW][c1] per-centre Q rows
   const int tid = threadIdx.x;
   const size_t b = blockIdx.y;
   const int c0 = blockIdx.x * a.CPW;
@@ -315,26 +316,52 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
   }
   __syncthreads();
 
-  // layer 1 (VALU + gathers): four output channels per item, rows fastest across lanes
+  // layer 1 (VALU + gathers): four output channels per item, rows fastest across lanes; the
+  // 16-byte P-row gathers of four items are issued before any of them is consumed, and the
+  // per-centre Q rows are staged once in LDS
   const float *pq = a.pq ? a.pq + b * a.N * (size_t)a.pqw : nullptr;
-  for (int e = tid; e < ROWS * (c1 >> 2); e += kThreads) {
-    const int r = e % ROWS, o = (e / ROWS) << 2;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (r < rows) {
-      const float dx = sdx[r], dy = sdx[ROWS + r], dz = sdx[2 * ROWS + r];
-      const float *w = a.wa + o * 3;
+  const bool has_q = pq && a.qoff >= 0;
+  if (has_q) {
+    for (int e = tid; e < nc * c1; e += kThreads) {
+      const int c = e / c1, o = e - c * c1;
+      sq[e] = pq[(size_t)scen[c * K] * a.pqw + a.qoff + o];
+    }
+    __syncthreads();
+  }
+  const int total = ROWS * (c1 >> 2);
+  for (int e0 = tid; e0 < total; e0 += 4 * kThreads) {
+    f32x4 p4[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) v[j] = w[3 * j] * dx + w[3 * j + 1] * dy + w[3 * j + 2] * dz;
-      if (pq) {
-        const f32x4 p4 = *reinterpret_cast<const f32x4 *>(pq + (size_t)sidx[r] * a.pqw + o);
-        v += p4;
-        if (a.qoff >= 0) v += *reinterpret_cast<const f32x4 *>(pq + (size_t)scen[r] * a.pqw + a.qoff + o);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++) v[j] = fmaxf(v[j] * a.sc1[o + j] + a.sh1[o + j], 0.f);
+    for (int u = 0; u < 4; u++) {
+      const int e = e0 + u * kThreads;
+      const int r = e % ROWS, o = (e / ROWS) << 2;
+      p4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (pq && e < total && r < rows) p4[u] = *reinterpret_cast<const f32x4 *>(pq + (size_t)sidx[r] * a.pqw + o);
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) buf[(o + j) * RP + r] = v[j];
+    for (int u = 0; u < 4; u++) {
+      const int e = e0 + u * kThreads;
+      if (e < total) {
+        const int r = e % ROWS, o = (e / ROWS) << 2;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < rows) {
+          const float dx = sdx[r], dy = sdx[ROWS + r], dz = sdx[2 * ROWS + r];
+          const float *w = a.wa + o * 3;
+#pragma unroll
+          for (int j = 0; j < 4; j++) v[j] = w[3 * j] * dx + w[3 * j + 1] * dy + w[3 * j + 2] * dz;
+          v += p4[u];
+          if (has_q) {
+            const float *qr = sq + (r / K) * c1 + o;
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] += qr[j];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; j++) v[j] = fmaxf(v[j] * a.sc1[o + j] + a.sh1[o + j], 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) buf[(o + j) * RP + r] = v[j];
+      }
+    }
   }
   __syncthreads();
   {
@@ -414,23 +441,45 @@ __device__ __forceinline__ void load_xyz_tile(float *dst, int RP, const float *x
   }
 }
 
-// Token tile of the attention kernels: T = 32*TB tokens with TB = 4 / 2 / 1 for d_model 32 / 64 /
-// 128, so that every dense layer has at least four (cout-block, token-block) tiles -- one per wave
-// -- and the LDS image stays ~70 KiB (two workgroups per CU).
+// Algebra used by both kernels (the host folds it into the weights, see AttnPlan in
+// pcr_amd/engine.py): with h = relu(W0 xyz + b0) the position encoding is W2 h + b2, so
+//   Wq (x + W2 h + b2) = [Wq | Wq W2] [x ; h] + Wq b2        (one dense instead of three)
+//   [K ; V] pre-activation = [[Wk | kpos Wk W2] ; [Wv | Wv W2]] [x ; h] + [kpos Wk b2 ; Wv b2]
+// and the merge projection is folded into the per-cloud KV matrix by the kv kernel:
+//   merge(msg)[o] = sum_dd M[o][dd] Q'[dd],  M[o][dd] = sum_{v in head(dd)} Wm[o][v] KV[dd][v],
+//   Q'[dd] = Q[dd] * Sk / (Q_head . ksum_head + 1e-6).
 
-// One workgroup per key-side cloud.  kv image per cloud: packed [d x d] matrix W'[v][dd] =
-// sum_s K[s][dd] V[s][v] / Sk for dd, v in the same head (zero elsewhere), followed by ksum[d].
-// LDS: X [c2P] key features (later K), XP [max(c2P,d)] pos hidden -> features+pos -> V, P [8] xyz.
+// hidden = relu(W0 xyz + b0) for the T tokens of a tile -> dst rows [0,d) ([d][RP]); zero xyz beyond L
+__device__ __forceinline__ void pos_hidden(float *dst, int RP, const float *P, const float *w0,
+                                           const float *b0, int d, int T) {
+  for (int e = threadIdx.x; e < d * T; e += blockDim.x) {
+    const int o = e / T, t = e - o * T;
+    const float v = w0[o * 3] * P[t] + w0[o * 3 + 1] * P[RP + t] + w0[o * 3 + 2] * P[2 * RP + t] + b0[o];
+    dst[o * RP + t] = fmaxf(v, 0.f);
+  }
+}
+
+__device__ __forceinline__ void load_xyz3(float *P, int RP, const float *xyz, int L, int t0, int T) {
+  for (int e = threadIdx.x; e < 3 * T; e += blockDim.x) {
+    const int c = e / T, t = e - c * T;
+    P[c * RP + t] = t0 + t < L ? xyz[(size_t)(t0 + t) * 3 + c] : 0.f;
+  }
+}
+
+// One workgroup per key-side cloud, token tiles of T = 32*TB (TB = 2 for d = 32, else 1: the fused
+// K/V projection has 2d/32 >= 4 cout blocks, one per wave).
+// kv image per cloud: packed (d x d) matrix M (merge folded in, see above) followed by ksum[d].
+// LDS: XH [c2 + d] key features ; hidden, KB [d], VB [d], P [3]; after the loop KVl [d][d+1].
 template <int TB>
 __global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
   constexpr int T = 32 * TB, RP = T + 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const pcr_attn_params &p = a.p;
-  const int d = p.d, c2 = p.c2, c2P = ceil8(c2);
-  const int rowsXP = c2P > d ? c2P : d;
-  float *X = smem;
-  float *XP = X + (c2P > d ? c2P : d) * RP;
-  float *P = XP + rowsXP * RP;
+  const int d = p.d, c2 = p.c2;
+  float *XH = smem;
+  float *KB = XH + (c2 + d) * RP;
+  float *VB = KB + d * RP;
+  float *P = VB + d * RP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const size_t b = blockIdx.x;
@@ -438,6 +487,8 @@ __global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
   const float *xyz = p.xyz_k + b * p.Sk * 3;
   const int nb = d >> 5, nT = nb * nb;
   const int dh = d / p.nhead;
+  const float sk = (float)p.Sk;
+  const float *bkv = p.bkv;
 
   f32x16 acc[4];
 #pragma unroll
@@ -448,33 +499,18 @@ __global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
 
   for (int t0 = 0; t0 < p.Sk; t0 += T) {
     const int valid = p.Sk - t0;
-    load_tile(X, RP, feat, c2, c2P, p.Sk, t0, T);
-    load_xyz_tile(P, RP, xyz, p.Sk, t0, T);
+    load_tile(XH, RP, feat, c2, c2, p.Sk, t0, T);
+    load_xyz3(P, RP, xyz, p.Sk, t0, T);
     __syncthreads();
-    {  // pos hidden = relu(W0 xyz + b0) -> XP rows [0,d)
-      const float *bb = p.pos0_b;
-      tile_dense2<TB, 2>(P, 8, p.pos0_w, d, false, [&](float v, int o, int t) { XP[o * RP + t] = fmaxf(v + bb[o], 0.f); });
-    }
+    pos_hidden(XH + c2 * RP, RP, P, p.pos0_w, p.pos0_b, d, T);
     __syncthreads();
-    {  // XP = X + W2 hidden + b2, in place over the hidden rows
-      const float *bb = p.pos2_b;
-      tile_dense2<TB, 2>(XP, d, p.pos2_w, ceil32(c2), true, [&](float v, int o, int t) {
-        if (o < c2P) XP[o * RP + t] = o < c2 ? X[o * RP + t] + (v + bb[o]) : 0.f;
-      });
-    }
-    __syncthreads();
-    // K = elu(Wk x)+1 (zero on padded tokens) -> X rows [0,d); in place when keys carry no position
-    tile_dense2<TB, 2>(p.k_pos ? XP : X, c2P, p.wk, d, true, [&](float v, int o, int t) {
-      X[o * RP + t] = t < valid ? elu1(v) : 0.f;
+    tile_dense2<TB, 2>(XH, c2 + d, p.wkv, 2 * d, false, [&](float v, int o, int t) {
+      if (o < d) KB[o * RP + t] = t < valid ? elu1(v + bkv[o]) : 0.f;
+      else VB[(o - d) * RP + t] = t < valid ? (v + bkv[o]) / sk : 0.f;
     });
     __syncthreads();
-    {  // V = Wv xp / Sk -> XP rows [0,d), in place
-      const float sk = (float)p.Sk;
-      tile_dense2<TB, 2>(XP, c2P, p.wv, d, true, [&](float v, int o, int t) { XP[o * RP + t] = t < valid ? v / sk : 0.f; });
-    }
-    __syncthreads();
     if (tid < d) {
-      const float *row = X + tid * RP;
+      const float *row = KB + tid * RP;
       float s = 0.f;
       for (int t = 0; t < T; t++) s += row[t];
       ksum += s;
@@ -484,16 +520,19 @@ __global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
       const int item = wave + 4 * it;
       if (item < nT) {
         const int ib = item / nb, jb = item - ib * nb;
-        const float *ap = X + (ib * 32 + l31) * RP + h;
-        const float *bp = XP + (jb * 32 + l31) * RP + h;
+        const float *ap = KB + (ib * 32 + l31) * RP + h;
+        const float *bp = VB + (jb * 32 + l31) * RP + h;
 #pragma unroll 4
         for (int ks = 0; ks < T / 2; ks++)
           acc[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc[it], 0, 0, 0);
       }
     }
-    __syncthreads();
+    // no barrier here: the next tile only rewrites XH/P before its first barrier, KB/VB after it
   }
-  float *kv = p.kv + b * ((size_t)d * d + d);
+  __syncthreads();
+  // KV (head-masked) -> LDS [dd][d+1], then fold the merge projection and write the packed image
+  float *KVl = smem;
+  const int ld = d + 1;
 #pragma unroll
   for (int it = 0; it < 4; it++) {
     const int item = wave + 4 * it;
@@ -503,18 +542,28 @@ __global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int dd = ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float val = (dd / dh == v / dh) ? acc[it][r] : 0.f;
-        const int kb = dd >> 3, rem = dd & 7;
-        kv[(((size_t)kb * d + v) * 2 + (rem & 1)) * 4 + (rem >> 1)] = val;
+        KVl[dd * ld + v] = (dd / dh == v / dh) ? acc[it][r] : 0.f;
       }
     }
+  }
+  __syncthreads();
+  float *kv = p.kv + b * ((size_t)d * d + d);
+  for (int e = tid; e < d * d; e += kThreads) {
+    const int o = e / d, dd = e - o * d;
+    const int v0 = (dd / dh) * dh;
+    const float *wm = p.wmerge + (size_t)o * d + v0;
+    const float *kr = KVl + dd * ld + v0;
+    float m = 0.f;
+    for (int v = 0; v < dh; v++) m += wm[v] * kr[v];
+    const int kb = dd >> 3, rem = dd & 7;
+    kv[(((size_t)kb * d + o) * 2 + (rem & 1)) * 4 + (rem >> 1)] = m;
   }
   if (tid < d) kv[(size_t)d * d + tid] = ksum;
 }
 
-// One workgroup per (query cloud, tile of T query tokens).
-// LDS: CAT [c1+d (pad 8)] rows [0,c1) query features, [c1,c1+d) message; W [max(2d,cout,cfinal)]
-// working buffer (every dense layer but the cat feed-forward runs in place in it); P [8]; zs; red.
+// One workgroup per (query cloud, tile of T query tokens), T = 128 / 64 / 32 for d = 32 / 64 / 128.
+// LDS: CAT [c1 + d (pad 8)]: rows [0,c1) query features, rows [c1,c1+d) position hidden -> later
+// the merged message; W [max(2d,cout,cfinal)] working buffer; P [3]; zs [nhead]; red.
 template <int TB>
 __global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
   constexpr int T = 32 * TB, RP = T + 1;
@@ -528,7 +577,7 @@ __global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
   float *CAT = smem;
   float *W = CAT + catP * RP;
   float *P = W + rowsW * RP;
-  float *zs = P + 8 * RP;
+  float *zs = P + 3 * RP;
   float *red = zs + p.nhead * RP;  // [2 * (256/T)][T]
   const int tid = threadIdx.x;
   const size_t b = blockIdx.y;
@@ -540,40 +589,34 @@ __global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
   const int dh = d / p.nhead;
 
   load_tile(CAT, RP, feat, c1, c1, p.Lq, t0, T);
-  for (int e = tid; e < (catP - c1) * T; e += kThreads) {  // zero message + pad rows
-    const int c = e / T, t = e - c * T;
-    CAT[(c1 + c) * RP + t] = 0.f;
-  }
-  if (p.q_pos) load_xyz_tile(P, RP, p.xyz_q + b * p.Lq * 3, p.Lq, t0, T);
-  __syncthreads();
-
-  if (p.q_pos) {  // Self_Attention: q uses feat + pos_mlp(xyz); c1 == c2 == d
-    const float *b0 = p.pos0_b, *b2 = p.pos2_b;
-    tile_dense2<TB, 2>(P, 8, p.pos0_w, d, false, [&](float v, int o, int t) { W[o * RP + t] = fmaxf(v + b0[o], 0.f); });
+  if (p.q_pos) {
+    load_xyz3(P, RP, p.xyz_q + b * p.Lq * 3, p.Lq, t0, T);
     __syncthreads();
-    tile_dense2<TB, 2>(W, d, p.pos2_w, ceil32(c1), true, [&](float v, int o, int t) {
-      if (o < c1) W[o * RP + t] = CAT[o * RP + t] + (v + b2[o]);
-    });
-    __syncthreads();
-    tile_dense2<TB, 2>(W, c1, p.wq, d, true, [&](float v, int o, int t) { W[o * RP + t] = elu1(v); });
+    pos_hidden(CAT + c1 * RP, RP, P, p.pos0_w, p.pos0_b, d, T);
+    for (int e = tid; e < (catP - catC) * T; e += kThreads) CAT[(catC + e / T) * RP + e % T] = 0.f;
   } else {
-    // the (still zero) message rows of CAT double as zero padding of the query features
-    tile_dense2<TB, 2>(CAT, ceil8(c1), p.wq, d, false, [&](float v, int o, int t) { W[o * RP + t] = elu1(v); });
+    for (int e = tid; e < (catP - c1) * T; e += kThreads) CAT[(c1 + e / T) * RP + e % T] = 0.f;
+  }
+  __syncthreads();
+  {  // Q = elu(Wq' [x ; h] + bq) + 1
+    const float *bq = p.bq;
+    tile_dense2<TB, 2>(CAT, p.q_pos ? catP : ceil8(c1), p.wq, d, false,
+                       [&](float v, int o, int t) { W[o * RP + t] = elu1(v + bq[o]); });
   }
   __syncthreads();
   for (int e = tid; e < p.nhead * T; e += kThreads) {
     const int hd = e / T, t = e - hd * T;
     float z = 0.f;
     for (int c = 0; c < dh; c++) z += W[(hd * dh + c) * RP + t] * ksum[hd * dh + c];
-    zs[hd * RP + t] = 1.0f / (z + 1e-6f);
+    zs[hd * RP + t] = (1.0f / (z + 1e-6f)) * (float)p.Sk;
   }
   __syncthreads();
-  {
-    const float sk = (float)p.Sk;
-    tile_dense2<TB, 2>(W, d, kv, d, true, [&](float v, int o, int t) { W[o * RP + t] = v * zs[(o / dh) * RP + t] * sk; });
+  for (int e = tid; e < d * T; e += kThreads) {
+    const int o = e / T, t = e - o * T;
+    W[o * RP + t] *= zs[(o / dh) * RP + t];
   }
   __syncthreads();
-  tile_dense2<TB, 2>(W, d, p.wmerge, d, false, [&](float v, int o, int t) { CAT[(c1 + o) * RP + t] = v; });
+  tile_dense2<TB, 2>(W, d, kv, d, false, [&](float v, int o, int t) { CAT[(c1 + o) * RP + t] = v; });
   __syncthreads();
   tile_layernorm(CAT + c1 * RP, d, RP, T, p.ln1_g, p.ln1_b, red);
   tile_dense2<TB, 2>(CAT, catP, p.wmlp0, 2 * d, false, [&](float v, int o, int t) { W[o * RP + t] = fmaxf(v, 0.f); });
@@ -798,12 +841,12 @@ static int sa2_try(const pcr_sa_params &p, hipStream_t st) {
   const int nr = (n2 > 4 || n3 > 4) ? 2 : 1;
   int best_cpw = 0, best_tb = 0;
   for (int pass = 0; pass < 2 && !best_cpw; pass++) {
-    // pass 0: token-block count divisible among the waves and >= 3 workgroups per CU; pass 1: anything that fits
+    // pass 0: token-block count divisible among the waves and >= 2 workgroups per CU; pass 1: anything that fits
     for (int cpw = 192 / p.K > 0 ? 192 / p.K : 1; cpw >= 1; cpw--) {
       const int tb = (cpw * p.K + 31) / 32;
       if (tb > 6) continue;
-      const size_t lds = ((size_t)rowsC * (32 * tb + 1) + 5 * 32 * tb) * sizeof(float);
-      if (pass == 0 && (tb % ways || lds > 52 * 1024)) continue;
+      const size_t lds = ((size_t)rowsC * (32 * tb + 1) + 5 * 32 * tb + (size_t)cpw * p.c1) * sizeof(float);
+      if (pass == 0 && (tb % ways || lds > 80 * 1024)) continue;
       if (lds > 150 * 1024) continue;
       best_cpw = cpw;
       best_tb = tb;
@@ -830,7 +873,7 @@ static int sa2_try(const pcr_sa_params &p, hipStream_t st) {
   a.sc1 = p.scale[0]; a.sh1 = p.shift[0]; a.sc2 = p.scale[1]; a.sh2 = p.shift[1];
   a.sc3 = p.scale[2]; a.sh3 = p.shift[2];
   a.out = p.out;
-  const size_t lds = ((size_t)rowsC * (32 * best_tb + 1) + 5 * 32 * best_tb) * sizeof(float);
+  const size_t lds = ((size_t)rowsC * (32 * best_tb + 1) + 5 * 32 * best_tb + (size_t)best_cpw * p.c1) * sizeof(float);
   dim3 grid((p.S + best_cpw - 1) / best_cpw, p.B);
   switch (best_tb) {
     case 1: sa2_launch_tb<1>(a, nr, lds, st, grid); break;
@@ -885,9 +928,9 @@ PCR_EXPORT int pcr_sa_mlp_f32(const pcr_sa_params *pp, pcr_stream_t stream) {
 static int attn_check(const pcr_attn_params &p) {
   if (p.B < 0 || p.Lq < 1 || p.Sk < 1 || p.c1 < 1 || p.c2 < 1 || p.cout < 1 || p.nhead < 1) return 1;
   if (p.d < 32 || p.d > 128 || (p.d & 31) || p.d % p.nhead) return 1;  // d_model in {32,64,96,128}
-  if (!p.feat_q || !p.feat_k || !p.xyz_k || !p.kv || !p.pos0_w || !p.pos0_b || !p.pos2_w || !p.pos2_b ||
-      !p.wq || !p.wk || !p.wv || !p.wmerge || !p.wmlp0 || !p.wmlp2 || !p.ln1_g || !p.ln1_b || !p.ln2_g ||
-      !p.ln2_b)
+  if ((p.c2 & 7) || p.cout > 256 || p.cfinal > 256) return 1;
+  if (!p.feat_q || !p.feat_k || !p.xyz_k || !p.kv || !p.pos0_w || !p.pos0_b || !p.wq || !p.bq || !p.wkv ||
+      !p.bkv || !p.wmerge || !p.wmlp0 || !p.wmlp2 || !p.ln1_g || !p.ln1_b || !p.ln2_g || !p.ln2_b)
     return 1;
   if (p.q_pos && (!p.xyz_q || p.c1 != p.c2 || p.c1 != p.d)) return 1;
   if (p.residual && p.cout != p.c1) return 1;
@@ -895,25 +938,22 @@ static int attn_check(const pcr_attn_params &p) {
   return 0;
 }
 
-static int attn_tb(int d) { return d <= 32 ? 4 : (d <= 64 ? 2 : 1); }
-
 PCR_EXPORT int pcr_attn_kv_f32(const pcr_attn_params *pp, pcr_stream_t stream) {
   if (!pp || attn_check(*pp)) return PCR_ERR_INVALID;
   if (pp->B == 0) return PCR_OK;
   AttnArgs a;
   a.p = *pp;
-  const int tb = attn_tb(pp->d), RP = 32 * tb + 1;
-  const int c2P = ceil8(pp->c2);
-  const int rowsX = c2P > pp->d ? c2P : pp->d;
-  size_t lds = ((size_t)(2 * rowsX + 8) * RP) * sizeof(float);
+  const int d = pp->d;
+  const int tb = d <= 32 ? 2 : 1, RP = 32 * tb + 1;
+  size_t lds = ((size_t)(pp->c2 + 3 * d + 3) * RP) * sizeof(float);
+  const size_t lds2 = (size_t)d * (d + 1) * sizeof(float);
+  if (lds2 > lds) lds = lds2;
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
-  static bool ok = allow_big_lds(attn_kv_kernel<1>) && allow_big_lds(attn_kv_kernel<2>) &&
-                   allow_big_lds(attn_kv_kernel<4>);
+  static bool ok = allow_big_lds(attn_kv_kernel<1>) && allow_big_lds(attn_kv_kernel<2>);
   (void)ok;
   dim3 g(pp->B), blk(kThreads);
   hipStream_t st = pcr_s(stream);
-  if (tb == 4) hipLaunchKernelGGL(attn_kv_kernel<4>, g, blk, lds, st, a);
-  else if (tb == 2) hipLaunchKernelGGL(attn_kv_kernel<2>, g, blk, lds, st, a);
+  if (tb == 2) hipLaunchKernelGGL(attn_kv_kernel<2>, g, blk, lds, st, a);
   else hipLaunchKernelGGL(attn_kv_kernel<1>, g, blk, lds, st, a);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
@@ -926,12 +966,12 @@ PCR_EXPORT int pcr_attn_apply_f32(const pcr_attn_params *pp, pcr_stream_t stream
   const pcr_attn_params &p = *pp;
   AttnArgs a;
   a.p = p;
-  const int tb = attn_tb(p.d), T = 32 * tb, RP = T + 1;
+  const int tb = p.d <= 32 ? 4 : (p.d <= 64 ? 2 : 1), T = 32 * tb, RP = T + 1;
   const int catP = ceil8(p.c1 + p.d);
   int rowsW = 2 * p.d;
   if (p.cout > rowsW) rowsW = p.cout;
   if (p.cfinal > rowsW) rowsW = p.cfinal;
-  size_t lds = ((size_t)(catP + rowsW + 8 + p.nhead) * RP + 2 * (kThreads / T) * T) * sizeof(float);
+  size_t lds = ((size_t)(catP + rowsW + 3 + p.nhead) * RP + 2 * (kThreads / T) * T) * sizeof(float);
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
   static bool ok = allow_big_lds(attn_apply_kernel<1>) && allow_big_lds(attn_apply_kernel<2>) &&
                    allow_big_lds(attn_apply_kernel<4>);

@@ -49,13 +49,12 @@ class SaParams(ctypes.Structure):
 class AttnParams(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int), ("Lq", ctypes.c_int), ("Sk", ctypes.c_int),
                 ("c1", ctypes.c_int), ("c2", ctypes.c_int), ("d", ctypes.c_int), ("cout", ctypes.c_int),
-                ("nhead", ctypes.c_int),
-                ("q_pos", ctypes.c_int), ("k_pos", ctypes.c_int), ("residual", ctypes.c_int),
+                ("nhead", ctypes.c_int), ("q_pos", ctypes.c_int), ("residual", ctypes.c_int),
                 ("feat_q", c_float_p), ("xyz_q", c_float_p), ("feat_k", c_float_p), ("xyz_k", c_float_p),
                 ("kv_index", c_int_p),
-                ("pos0_w", c_float_p), ("pos0_b", c_float_p), ("pos2_w", c_float_p), ("pos2_b", c_float_p),
-                ("wq", c_float_p), ("wk", c_float_p), ("wv", c_float_p), ("wmerge", c_float_p),
-                ("wmlp0", c_float_p), ("wmlp2", c_float_p),
+                ("pos0_w", c_float_p), ("pos0_b", c_float_p),
+                ("wq", c_float_p), ("bq", c_float_p), ("wkv", c_float_p), ("bkv", c_float_p),
+                ("wmerge", c_float_p), ("wmlp0", c_float_p), ("wmlp2", c_float_p),
                 ("ln1_g", c_float_p), ("ln1_b", c_float_p), ("ln2_g", c_float_p), ("ln2_b", c_float_p),
                 ("wfinal", c_float_p), ("bfinal", c_float_p), ("cfinal", ctypes.c_int),
                 ("kv", c_float_p), ("out", c_float_p)]
@@ -180,15 +179,27 @@ class AttnPlan:
         pos = getattr(m, pos_name)
         self.device = device
         self.nhead, self.q_pos, self.k_pos, self.residual = nhead, int(q_pos), int(k_pos), int(residual)
-        self.d = m.q_proj.weight.shape[0]
+        self.d = d = m.q_proj.weight.shape[0]
         self.c1 = m.q_proj.weight.shape[1]
         self.c2 = m.k_proj.weight.shape[1]
         self.cout = m.mlp[2].weight.shape[0]
+        # fold the second pos-MLP Linear (W2, b2) into the projections, in fp64 (include/pcr.h)
+        f64 = lambda x: x.detach().double().cpu()
+        W2, b2 = f64(pos[2].weight), f64(pos[2].bias)                 # (c2, d), (c2)
+        Wq, Wk, Wv = f64(m.q_proj.weight), f64(m.k_proj.weight), f64(m.v_proj.weight)
+        if q_pos:
+            wq = torch.cat([Wq, Wq @ W2], dim=1)
+            bq = Wq @ b2
+        else:
+            wq, bq = Wq, torch.zeros(d, dtype=torch.float64)
+        kz = (Wk @ W2) if k_pos else torch.zeros(d, d, dtype=torch.float64)
+        wkv = torch.cat([torch.cat([Wk, kz], dim=1), torch.cat([Wv, Wv @ W2], dim=1)], dim=0)
+        bkv = torch.cat([(Wk @ b2) if k_pos else torch.zeros(d, dtype=torch.float64), Wv @ b2])
         self.t = dict(
-            pos0_w=pack_weight(pos[0].weight, device), pos0_b=_dev32(pos[0].bias, device),
-            pos2_w=pack_weight(pos[2].weight, device), pos2_b=_dev32(pos[2].bias, device),
-            wq=pack_weight(m.q_proj.weight, device), wk=pack_weight(m.k_proj.weight, device),
-            wv=pack_weight(m.v_proj.weight, device), wmerge=pack_weight(m.merge.weight, device),
+            pos0_w=_dev32(pos[0].weight, device), pos0_b=_dev32(pos[0].bias, device),
+            wq=pack_weight(wq.float(), device), bq=_dev32(bq.float(), device),
+            wkv=pack_weight(wkv.float(), device), bkv=_dev32(bkv.float(), device),
+            wmerge=_dev32(m.merge.weight, device),
             wmlp0=pack_weight(m.mlp[0].weight, device), wmlp2=pack_weight(m.mlp[2].weight, device),
             ln1_g=_dev32(m.norm1.weight, device), ln1_b=_dev32(m.norm1.bias, device),
             ln2_g=_dev32(m.norm2.weight, device), ln2_b=_dev32(m.norm2.bias, device))
@@ -212,7 +223,7 @@ class AttnPlan:
         p = AttnParams()
         p.B, p.Lq, p.Sk = B, Lq, Sk
         p.c1, p.c2, p.d, p.cout, p.nhead = c1, c2, self.d, self.cout, self.nhead
-        p.q_pos, p.k_pos, p.residual = self.q_pos, self.k_pos, self.residual
+        p.q_pos, p.residual = self.q_pos, self.residual
         p.feat_q, p.xyz_q, p.feat_k, p.xyz_k = _p(feat_q), _p(xyz_q), _p(feat_k), _p(xyz_k)
         p.kv_index = _p(kv_index)
         for k, v in self.t.items():
@@ -221,7 +232,7 @@ class AttnPlan:
         p.kv, p.out = _p(kv), _p(out)
         st = L.stream_ptr()
         d = self.d
-        kv_flops = 2.0 * B * Sk * (3 * d + d * c2 + 2 * c2 * d + d * d / self.nhead)
+        kv_flops = 2.0 * B * Sk * (3 * d + d * c2 + 2 * c2 * d + d * d / self.nhead)   # reference's op count
         ap_flops = 2.0 * B * Lq * (c1 * d + d * d / self.nhead + d * d + (c1 + d) * 2 * d + 2 * d * self.cout
                                    + self.cout * self.cfinal + (self.q_pos * (3 * d + d * c1)))
         with _prof("attn_kv[d=%d,c2=%d,Sk=%d]" % (d, c2, Sk), kv_flops, 4.0 * B * (c2 * Sk + 3 * Sk + d * d + d)):
