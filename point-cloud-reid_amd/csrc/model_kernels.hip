@@ -70,61 +70,77 @@ __device__ __forceinline__ void tile_dense(const float *__restrict__ in, int CP,
 //   nCB = OP/32 >= 3 : wave w owns cout blocks w, w+4 (NR rounds), all TB token blocks
 //   nCB == 2         : wave w owns cout block w&1 and token blocks (w>>1), (w>>1)+2, ...
 //   nCB == 1         : wave w owns token blocks w, w+4, ...
-template <int TB, int NR, class Epi>
-__device__ __forceinline__ void tile_dense2(const float *__restrict__ in, int CP,
-                                            const float *__restrict__ wp, int OP, bool sync_epi, Epi epi) {
+template <int TB, int NR, int WAYS, class Epi>
+__device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, int CP,
+                                                const float *__restrict__ wp, int OP, bool sync_epi,
+                                                Epi epi) {
   constexpr int RP = 32 * TB + 1;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int TBW = (TB + WAYS - 1) / WAYS;  // token blocks per wave
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l31 = lane & 31, h = lane >> 5;
   const int nCB = OP >> 5, KB = CP >> 3;
-  int cb0, tb0, tbstep;
-  if (nCB >= 3) { cb0 = wave; tb0 = 0; tbstep = 1; }
-  else if (nCB == 2) { cb0 = wave & 1; tb0 = wave >> 1; tbstep = 2; }
-  else { cb0 = 0; tb0 = wave; tbstep = 4; }
-  f32x16 acc[NR][TB];
+  const int cb0 = WAYS == 1 ? wave : (WAYS == 2 ? (wave & 1) : 0);
+  const int tb0 = WAYS == 1 ? 0 : (WAYS == 2 ? (wave >> 1) : wave);
+  // The k-loop is branch-free: a tile the wave does not own (cb >= nCB or tb >= TB, which only
+  // happens for shapes that do not divide evenly) is computed on clamped addresses and dropped in
+  // the epilogue, so the accumulators stay pinned in AGPRs.
+  f32x16 acc[NR][TBW];
 #pragma unroll
   for (int nr = 0; nr < NR; nr++)
 #pragma unroll
-    for (int j = 0; j < TB; j++)
+    for (int j = 0; j < TBW; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[nr][j][r] = 0.f;
-  const f32x4 *wbase = reinterpret_cast<const f32x4 *>(wp) + (size_t)l31 * 2 + h;
   const size_t wstride = (size_t)OP * 2;
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 a_cur[NR];
+  const f32x4 *wrow[NR];
 #pragma unroll
   for (int nr = 0; nr < NR; nr++) {
-    const int cb = cb0 + 4 * nr;
-    a_cur[nr] = (cb < nCB && KB > 0) ? wbase[(size_t)cb * 64] : zero4;
+    int cb = cb0 + 4 * nr;
+    cb = cb < nCB ? cb : nCB - 1;
+    wrow[nr] = reinterpret_cast<const f32x4 *>(wp) + (size_t)cb * 64 + (size_t)l31 * 2 + h;
   }
-  const float *bbase = in + h * RP + l31;
-  for (int kb = 0; kb < KB; kb++) {
-    f32x4 a_nxt[NR];
+  const float *brow[TBW];
 #pragma unroll
-    for (int nr = 0; nr < NR; nr++) {
-      const int cb = cb0 + 4 * nr;
-      a_nxt[nr] = (cb < nCB && kb + 1 < KB) ? wbase[(size_t)(kb + 1) * wstride + (size_t)cb * 64] : zero4;
-    }
-    const float *b0 = bbase + kb * 8 * RP;
+  for (int j = 0; j < TBW; j++) {
+    int tb = tb0 + j * WAYS;
+    tb = tb < TB ? tb : TB - 1;
+    brow[j] = in + h * RP + tb * 32 + l31;
+  }
+  // two weight-fragment register sets in ping-pong: the 16-byte load for k-block kb+2 is issued
+  // right after the last use of set (kb & 1) and has a full block of MFMAs to land
+  auto step = [&](const f32x4 (&aw)[NR], int kb) {
 #pragma unroll
-    for (int j = 0; j < TB; j++) {
-      const int tb = tb0 + j * tbstep;
-      if (tb < TB) {
-        const float *bt = b0 + tb * 32;
-        const float x0 = bt[0], x1 = bt[2 * RP], x2 = bt[4 * RP], x3 = bt[6 * RP];
+    for (int j = 0; j < TBW; j++) {
+      const float *bt = brow[j] + kb * 8 * RP;
+      const float x0 = bt[0], x1 = bt[2 * RP], x2 = bt[4 * RP], x3 = bt[6 * RP];
 #pragma unroll
-        for (int nr = 0; nr < NR; nr++) {
-          if (cb0 + 4 * nr < nCB) {
-            acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nr][0], x0, acc[nr][j], 0, 0, 0);
-            acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nr][1], x1, acc[nr][j], 0, 0, 0);
-            acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nr][2], x2, acc[nr][j], 0, 0, 0);
-            acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nr][3], x3, acc[nr][j], 0, 0, 0);
-          }
-        }
+      for (int nr = 0; nr < NR; nr++) {
+        acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[nr][0], x0, acc[nr][j], 0, 0, 0);
+        acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[nr][1], x1, acc[nr][j], 0, 0, 0);
+        acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[nr][2], x2, acc[nr][j], 0, 0, 0);
+        acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[nr][3], x3, acc[nr][j], 0, 0, 0);
       }
     }
+  };
+  f32x4 a0[NR], a1[NR];
+  const int k1 = KB > 1 ? 1 : 0;
 #pragma unroll
-    for (int nr = 0; nr < NR; nr++) a_cur[nr] = a_nxt[nr];
+  for (int nr = 0; nr < NR; nr++) {
+    a0[nr] = wrow[nr][0];
+    a1[nr] = wrow[nr][(size_t)k1 * wstride];
+  }
+  for (int kb = 0; kb < KB; kb += 2) {
+    step(a0, kb);
+    const int kn0 = kb + 2 < KB ? kb + 2 : KB - 1;
+#pragma unroll
+    for (int nr = 0; nr < NR; nr++) a0[nr] = wrow[nr][(size_t)kn0 * wstride];
+    if (kb + 1 < KB) {
+      step(a1, kb + 1);
+      const int kn1 = kb + 3 < KB ? kb + 3 : KB - 1;
+#pragma unroll
+      for (int nr = 0; nr < NR; nr++) a1[nr] = wrow[nr][(size_t)kn1 * wstride];
+    }
   }
   if (sync_epi) __syncthreads();
 #pragma unroll
@@ -132,8 +148,8 @@ __device__ __forceinline__ void tile_dense2(const float *__restrict__ in, int CP
     const int cb = cb0 + 4 * nr;
     if (cb < nCB) {
 #pragma unroll
-      for (int j = 0; j < TB; j++) {
-        const int tb = tb0 + j * tbstep;
+      for (int j = 0; j < TBW; j++) {
+        const int tb = tb0 + j * WAYS;
         if (tb < TB) {
           const int t = tb * 32 + l31;
 #pragma unroll
@@ -142,6 +158,15 @@ __device__ __forceinline__ void tile_dense2(const float *__restrict__ in, int CP
       }
     }
   }
+}
+
+template <int TB, int NR, class Epi>
+__device__ __forceinline__ void tile_dense2(const float *__restrict__ in, int CP,
+                                            const float *__restrict__ wp, int OP, bool sync_epi, Epi epi) {
+  const int nCB = OP >> 5;
+  if (nCB >= 3) tile_dense_impl<TB, NR, 1>(in, CP, wp, OP, sync_epi, epi);
+  else if (nCB == 2) tile_dense_impl<TB, 1, 2>(in, CP, wp, OP, sync_epi, epi);
+  else tile_dense_impl<TB, 1, 4>(in, CP, wp, OP, sync_epi, epi);
 }
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x + 1.0f : (expf(x) - 1.0f) + 1.0f; }
