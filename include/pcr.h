@@ -137,7 +137,9 @@ typedef struct pcr_sa_params {
    * with Wa = W1[:, 0:3]; edge mode: Wc = W1[:, 3:3+D], Wf = W1[:, 3+D:3+2D]; query-and-group:
    * Wf = W1[:, 3:3+D], no Q.  wa is (c1,3) row-major; wpq is the PACKED image of the stacked
    * matrix [Wf ; Wc - Wf] ((2*c1, D), edge) or Wf ((c1, D), query-and-group); pq_ws is a caller
-   * workspace of B*N*(2*c1 or c1) floats.  Leave wa NULL to force the generic kernel (wp[0]). */
+   * workspace of B*N*(2*c1 or c1) floats.  Leave wa NULL to force the generic kernel (wp[0]).
+   * wa and wpq must be PRE-SCALED by scale[0] (row o times scale[0][o]); the fast path then
+   * evaluates layer 1 as relu(wa dxyz + P[i] + Q[c] + shift[0]) and never reads scale[0]. */
   const float *wa, *wpq;
   float *pq_ws;
   float *out;

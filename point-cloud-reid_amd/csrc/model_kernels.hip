@@ -10,6 +10,7 @@
 // (one 16-byte load per lane covers four k-steps), and the LDS-resident activations as the B
 // operand (token = lane => conflict-free ds_read_b32, token-contiguous epilogue stores).
 #include <math.h>
+#include <stdlib.h>
 
 #include "pcr_common.h"
 
@@ -298,6 +299,9 @@ struct Sa2Args {
   const float *wa;          // (c1,3) row-major
   const float *pq;          // (B,N,pqw) point-major or null (no features)
   int pqw, qoff;            // row width; offset of Q inside a row, -1 = no Q term
+  int dbg;                  // PCR_SA_DBG ablation mask (diagnostics only; 0 in production)
+  int skew_div;
+  int skew;                 // start-up stagger of the first generation of workgroups, in s_sleep(127) units
   const float *wp2, *wp3;
   const float *sc1, *sh1, *sc2, *sh2, *sc3, *sh3;
   float *out;
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
   float *sdx = buf + rowsC * RP;                            // [3][ROWS]
   int *sidx = reinterpret_cast<int *>(sdx + 3 * ROWS);      // [ROWS] neighbour, [ROWS] centre point
   int *scen = sidx + ROWS;
-  float *sq = reinterpret_cast<float *>(scen + ROWS);     // [CPW][c1] per-centre Q rows
+  float *sq = reinterpret_cast<float *>(scen + ROWS);     // [CPW][c1] per-centre Q rows + shift
   const int tid = threadIdx.x;
   const size_t b = blockIdx.y;
   const int c0 = blockIdx.x * a.CPW;
@@ -322,6 +326,17 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
   const int rows = nc * K;
   const float *xyz = a.xyz + b * a.N * 3;
 
+  if (a.skew) {
+    // Identical workgroups started together run their phases in lockstep (all gathering, then all
+    // on the matrix core).  Delaying the co-resident workgroups of the FIRST generation by a
+    // fraction of a workgroup's lifetime de-phases every later generation too, because each CU slot
+    // runs its workgroups back to back.  Pure scheduling heuristic: results do not depend on it.
+    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+    if (lin < 256u * 3u) {
+      const int n = (int)((lin / (unsigned)a.skew_div) % 3u) * a.skew;
+      for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(127);
+    }
+  }
   for (int r = tid; r < ROWS; r += kThreads) {
     int i = -1, ci = -1;
     float dx = 0.f, dy = 0.f, dz = 0.f;
@@ -340,55 +355,56 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
     sdx[2 * ROWS + r] = dz;
   }
   __syncthreads();
-
+  if (!(a.dbg & 1)) {
   // layer 1 (VALU + gathers): four output channels per item, rows fastest across lanes; the
-  // 16-byte P-row gathers of four items are issued before any of them is consumed, and the
-  // per-centre Q rows are staged once in LDS
+  // 16-byte P-row gathers of four items are issued before any of them is consumed; the per-centre
+  // Q rows (+ folded BatchNorm shift) and the dxyz weights are staged once in LDS.  The host has
+  // folded the BatchNorm scale into wa / P / Q, so the layer is  relu(wa dxyz + P[i] + Q[c]).
   const float *pq = a.pq ? a.pq + b * a.N * (size_t)a.pqw : nullptr;
   const bool has_q = pq && a.qoff >= 0;
-  if (has_q) {
-    for (int e = tid; e < nc * c1; e += kThreads) {
-      const int c = e / c1, o = e - c * c1;
-      sq[e] = pq[(size_t)scen[c * K] * a.pqw + a.qoff + o];
-    }
-    __syncthreads();
+  for (int e = tid; e < nc * c1; e += kThreads) {
+    const int c = e / c1, o = e - c * c1;
+    sq[e] = a.sh1[o] + (has_q ? pq[(size_t)scen[c * K] * a.pqw + a.qoff + o] : 0.f);
   }
+  __syncthreads();
   const int total = ROWS * (c1 >> 2);
+  constexpr int dR = kThreads % ROWS, dO = kThreads / ROWS;
+  int r = tid % ROWS, oq = tid / ROWS;
   for (int e0 = tid; e0 < total; e0 += 4 * kThreads) {
     f32x4 p4[4];
+    int rr[4], oo[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      const int e = e0 + u * kThreads;
-      const int r = e % ROWS, o = (e / ROWS) << 2;
+      rr[u] = r;
+      oo[u] = oq << 2;
       p4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (pq && e < total && r < rows) p4[u] = *reinterpret_cast<const f32x4 *>(pq + (size_t)sidx[r] * a.pqw + o);
+      if (pq && e0 + u * kThreads < total && r < rows)
+        p4[u] = *reinterpret_cast<const f32x4 *>(pq + (size_t)sidx[r] * a.pqw + oo[u]);
+      r += dR;
+      oq += dO;
+      if (r >= ROWS) { r -= ROWS; oq++; }
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      const int e = e0 + u * kThreads;
-      if (e < total) {
-        const int r = e % ROWS, o = (e / ROWS) << 2;
+      if (e0 + u * kThreads < total) {
+        const int rw = rr[u], o = oo[u];
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r < rows) {
-          const float dx = sdx[r], dy = sdx[ROWS + r], dz = sdx[2 * ROWS + r];
+        if (rw < rows) {
+          const float dx = sdx[rw], dy = sdx[ROWS + rw], dz = sdx[2 * ROWS + rw];
           const float *w = a.wa + o * 3;
+          const float *qr = sq + (rw / K) * c1 + o;
 #pragma unroll
-          for (int j = 0; j < 4; j++) v[j] = w[3 * j] * dx + w[3 * j + 1] * dy + w[3 * j + 2] * dz;
-          v += p4[u];
-          if (has_q) {
-            const float *qr = sq + (r / K) * c1 + o;
-#pragma unroll
-            for (int j = 0; j < 4; j++) v[j] += qr[j];
-          }
-#pragma unroll
-          for (int j = 0; j < 4; j++) v[j] = fmaxf(v[j] * a.sc1[o + j] + a.sh1[o + j], 0.f);
+          for (int j = 0; j < 4; j++)
+            v[j] = fmaxf(w[3 * j] * dx + w[3 * j + 1] * dy + w[3 * j + 2] * dz + p4[u][j] + qr[j], 0.f);
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) buf[(o + j) * RP + r] = v[j];
+        for (int j = 0; j < 4; j++) buf[(o + j) * RP + rw] = v[j];
       }
     }
   }
+  }
   __syncthreads();
+  if (!(a.dbg & 2)) {
   {
     const float *sc = a.sc2, *sh = a.sh2;
     const int lim = ceil8(c2);
@@ -403,7 +419,9 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
       if (o < c3) buf[o * RP + t] = fmaxf(v * sc[o] + sh[o], 0.f);
     });
   }
+  }
   __syncthreads();
+  if (a.dbg & 4) return;
   for (int e = tid; e < c3 * nc; e += kThreads) {
     const int c = e / c3, o = e - c * c3;
     const float *row = buf + o * RP + c * K;
@@ -894,6 +912,12 @@ static int sa2_try(const pcr_sa_params &p, hipStream_t st) {
   a.pq = p.D ? p.pq_ws : nullptr;
   a.pqw = pqw;
   a.qoff = p.mode == 0 ? p.c1 : -1;
+  static const int dbg = getenv("PCR_SA_DBG") ? atoi(getenv("PCR_SA_DBG")) : 0;
+  a.dbg = dbg;
+  static const int skew = getenv("PCR_SA_SKEW") ? atoi(getenv("PCR_SA_SKEW")) : 0;
+  a.skew = skew;
+  static const int skew_div = getenv("PCR_SA_SKEW_DIV") ? atoi(getenv("PCR_SA_SKEW_DIV")) : 256;
+  a.skew_div = skew_div > 0 ? skew_div : 256;
   a.wp2 = p.wp[1]; a.wp3 = p.wp[2];
   a.sc1 = p.scale[0]; a.sh1 = p.shift[0]; a.sc2 = p.scale[1]; a.sh2 = p.shift[1];
   a.sc3 = p.scale[2]; a.sh3 = p.shift[2];

@@ -127,18 +127,19 @@ class SaPlan:
         self.scale = [f[0] for f in folded]
         self.shift = [f[1] for f in folded]
         # decomposed first layer (include/pcr.h, pcr_sa_params): W1 = [Wa | Wc | Wf] (edge) or [Wa | Wf]
-        w1 = convs[0].weight.detach().reshape(self.couts[0], -1).double()
+        w1 = convs[0].weight.detach().reshape(self.couts[0], -1).double().cpu()
         D = (self.cin - 3) // 2 if mode == 0 else self.cin - 3
         self.D = D
-        self.wa = _dev32(w1[:, :3].float(), device)
+        sc1 = self.scale[0].detach().double().cpu().unsqueeze(1)      # fast path wants scale[0] folded in
+        self.wa = _dev32((w1[:, :3] * sc1).float(), device)
         self.wpq = None
         self.fast = fast
         if D > 0:
             if mode == 0:
                 wc, wf = w1[:, 3:3 + D], w1[:, 3 + D:3 + 2 * D]
-                stacked = torch.cat([wf, wc - wf], dim=0)
+                stacked = torch.cat([wf * sc1, (wc - wf) * sc1], dim=0)
             else:
-                stacked = w1[:, 3:3 + D]
+                stacked = w1[:, 3:3 + D] * sc1
             self.wpq = pack_weight(stacked.float(), device)
 
     def run(self, xyz, feat, idx, centre_idx=None):
