@@ -1,0 +1,388 @@
+// Grouped set-abstraction MLP kernels (pcr_sa_mlp_f32).
+#include "tile_dense.h"
+
+namespace {
+// ---------------------------------------------------------------- grouped SA MLP ----
+struct SaArgs {
+  pcr_sa_params p;
+  int C0, C0P, RP, TB, CPW, rowsA, rowsB;
+};
+
+__global__ __launch_bounds__(kThreads) void sa_mlp_kernel(SaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const pcr_sa_params &p = a.p;
+  float *bufA = smem;
+  float *bufB = smem + a.rowsA * a.RP;
+  int *sidx = reinterpret_cast<int *>(bufB + a.rowsB * a.RP);
+  const int tid = threadIdx.x;
+  const size_t b = blockIdx.y;
+  const int c0 = blockIdx.x * a.CPW;
+  const int nc = (p.S - c0 < a.CPW) ? p.S - c0 : a.CPW;
+  const int rows = nc * p.K, ROWS = 32 * a.TB, RP = a.RP;
+  const int K = p.K, D = p.D, N = p.N;
+
+  for (int r = tid; r < ROWS; r += kThreads)
+    sidx[r] = r < rows ? p.idx[(b * p.S + c0) * K + r] : -1;
+  __syncthreads();
+
+  // gather + relative / edge features -> bufA [C0P][RP]
+  const float *xyz = p.xyz + b * N * 3;
+  const float *feat = D ? p.feat + b * D * N : nullptr;
+  for (int e = tid; e < a.C0P * ROWS; e += kThreads) {
+    const int ch = e / ROWS, r = e - ch * ROWS;
+    float v = 0.f;
+    if (ch < a.C0 && r < rows) {
+      const int s = c0 + r / K;
+      const int ci = p.centre_idx ? p.centre_idx[b * p.S + s] : s;
+      const int i = sidx[r];
+      if (ch < 3) {
+        v = xyz[i * 3 + ch] - xyz[ci * 3 + ch];
+      } else if (p.mode == 0) {
+        const int f = ch - 3;
+        if (f < D) v = feat[(size_t)f * N + ci];
+        else v = feat[(size_t)(f - D) * N + i] - feat[(size_t)(f - D) * N + ci];
+      } else {
+        v = feat[(size_t)(ch - 3) * N + i];
+      }
+    }
+    bufA[ch * RP + r] = v;
+  }
+  __syncthreads();
+
+  const int c1 = p.c1, c2 = p.c2, c3 = p.c3;
+  {
+    const float *sc = p.scale[0], *sh = p.shift[0];
+    const int lim = ceil8(c1);
+    tile_dense(bufA, a.C0P, RP, a.TB, p.wp[0], ceil32(c1), [&](float v, int o, int t) {
+      if (o < lim) bufB[o * RP + t] = o < c1 ? fmaxf(v * sc[o] + sh[o], 0.f) : 0.f;
+    });
+  }
+  __syncthreads();
+  {
+    const float *sc = p.scale[1], *sh = p.shift[1];
+    const int lim = ceil8(c2);
+    tile_dense(bufB, ceil8(c1), RP, a.TB, p.wp[1], ceil32(c2), [&](float v, int o, int t) {
+      if (o < lim) bufA[o * RP + t] = o < c2 ? fmaxf(v * sc[o] + sh[o], 0.f) : 0.f;
+    });
+  }
+  __syncthreads();
+  {
+    const float *sc = p.scale[2], *sh = p.shift[2];
+    tile_dense(bufA, ceil8(c2), RP, a.TB, p.wp[2], ceil32(c3), [&](float v, int o, int t) {
+      if (o < c3) bufB[o * RP + t] = fmaxf(v * sc[o] + sh[o], 0.f);
+    });
+  }
+  __syncthreads();
+  // max over the K neighbours of each centre
+  for (int e = tid; e < c3 * nc; e += kThreads) {
+    const int c = e / c3, o = e - c * c3;
+    const float *row = bufB + o * RP + c * K;
+    float m = row[0];
+    for (int k = 1; k < K; k++) m = fmaxf(m, row[k]);
+    p.out[(b * c3 + o) * p.S + c0 + c] = m;
+  }
+}
+
+// ------------------------------------------------- grouped SA MLP, second generation ----
+// Layer 1 is linear in its input rows [dxyz, f_c, f_i - f_c] (edge) or [dxyz, f_i] (query-and-
+// group), so  W1 row = Wa dxyz + P[i] + Q[c]  with the per-POINT tables P = Wf f, Q = (Wc - Wf) f
+// computed once per cloud by dense_pm_kernel (K times fewer FLOPs than per (centre,neighbour)
+// row).  The kernel gathers P rows (16-byte loads) straight into the layer-1 activation tile,
+// then runs layers 2 and 3 on the matrix core IN PLACE in one LDS buffer and reduces max over K.
+struct Sa2Args {
+  int B, N, S, K, c1, c2, c3, CPW;
+  const float *xyz;
+  const int *idx, *centre_idx;
+  const float *wa;          // (c1,3) row-major
+  const float *pq;          // (B,N,pqw) point-major or null (no features)
+  int pqw, qoff;            // row width; offset of Q inside a row, -1 = no Q term
+  int dbg;                  // PCR_SA_DBG ablation mask (diagnostics only; 0 in production)
+  int skew_div;
+  int skew;                 // start-up stagger of the first generation of workgroups, in s_sleep(127) units
+  const float *wp2, *wp3;
+  const float *sc1, *sh1, *sc2, *sh2, *sc3, *sh3;
+  float *out;
+};
+
+template <int TB, int NR, int W2, int W3>
+__global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
+  constexpr int ROWS = 32 * TB, RP = ROWS + 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int c1 = a.c1, c2 = a.c2, c3 = a.c3, K = a.K;
+  int rowsC = c1 > c3 ? c1 : c3;
+  if (ceil8(c2) > rowsC) rowsC = ceil8(c2);
+  float *buf = smem;                                        // [rowsC][RP]
+  float *sdx = buf + rowsC * RP;                            // [3][ROWS]
+  int *sidx = reinterpret_cast<int *>(sdx + 3 * ROWS);      // [ROWS] neighbour, [ROWS] centre point
+  int *scen = sidx + ROWS;
+  float *sq = reinterpret_cast<float *>(scen + ROWS);     // [CPW][c1] per-centre Q rows + shift
+  const int tid = threadIdx.x;
+  const size_t b = blockIdx.y;
+  const int c0 = blockIdx.x * a.CPW;
+  const int nc = (a.S - c0 < a.CPW) ? a.S - c0 : a.CPW;
+  const int rows = nc * K;
+  const float *xyz = a.xyz + b * a.N * 3;
+
+  if (a.skew) {
+    // Identical workgroups started together run their phases in lockstep (all gathering, then all
+    // on the matrix core).  Delaying the co-resident workgroups of the FIRST generation by a
+    // fraction of a workgroup's lifetime de-phases every later generation too, because each CU slot
+    // runs its workgroups back to back.  Pure scheduling heuristic: results do not depend on it.
+    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+    if (lin < 256u * 3u) {
+      const int n = (int)((lin / (unsigned)a.skew_div) % 3u) * a.skew;
+      for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(127);
+    }
+  }
+  for (int r = tid; r < ROWS; r += kThreads) {
+    int i = -1, ci = -1;
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (r < rows) {
+      const int s = c0 + r / K;
+      ci = a.centre_idx ? a.centre_idx[b * a.S + s] : s;
+      i = a.idx[(b * a.S + c0) * K + r];
+      dx = xyz[i * 3] - xyz[ci * 3];
+      dy = xyz[i * 3 + 1] - xyz[ci * 3 + 1];
+      dz = xyz[i * 3 + 2] - xyz[ci * 3 + 2];
+    }
+    sidx[r] = i;
+    scen[r] = ci;
+    sdx[r] = dx;
+    sdx[ROWS + r] = dy;
+    sdx[2 * ROWS + r] = dz;
+  }
+  __syncthreads();
+  if (!(a.dbg & 1)) {
+  // layer 1 (VALU + gathers): four output channels per item, rows fastest across lanes; the
+  // 16-byte P-row gathers of four items are issued before any of them is consumed; the per-centre
+  // Q rows (+ folded BatchNorm shift) and the dxyz weights are staged once in LDS.  The host has
+  // folded the BatchNorm scale into wa / P / Q, so the layer is  relu(wa dxyz + P[i] + Q[c]).
+  const float *pq = a.pq ? a.pq + b * a.N * (size_t)a.pqw : nullptr;
+  const bool has_q = pq && a.qoff >= 0;
+  for (int e = tid; e < nc * c1; e += kThreads) {
+    const int c = e / c1, o = e - c * c1;
+    sq[e] = a.sh1[o] + (has_q ? pq[(size_t)scen[c * K] * a.pqw + a.qoff + o] : 0.f);
+  }
+  __syncthreads();
+  const int total = ROWS * (c1 >> 2);
+  constexpr int dR = kThreads % ROWS, dO = kThreads / ROWS;
+  int r = tid % ROWS, oq = tid / ROWS;
+  for (int e0 = tid; e0 < total; e0 += 4 * kThreads) {
+    f32x4 p4[4];
+    int rr[4], oo[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      rr[u] = r;
+      oo[u] = oq << 2;
+      p4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (pq && e0 + u * kThreads < total && r < rows)
+        p4[u] = *reinterpret_cast<const f32x4 *>(pq + (size_t)sidx[r] * a.pqw + oo[u]);
+      r += dR;
+      oq += dO;
+      if (r >= ROWS) { r -= ROWS; oq++; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (e0 + u * kThreads < total) {
+        const int rw = rr[u], o = oo[u];
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (rw < rows) {
+          const float dx = sdx[rw], dy = sdx[ROWS + rw], dz = sdx[2 * ROWS + rw];
+          const float *w = a.wa + o * 3;
+          const float *qr = sq + (rw / K) * c1 + o;
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            v[j] = fmaxf(w[3 * j] * dx + w[3 * j + 1] * dy + w[3 * j + 2] * dz + p4[u][j] + qr[j], 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) buf[(o + j) * RP + rw] = v[j];
+      }
+    }
+  }
+  }
+  __syncthreads();
+  if (!(a.dbg & 2)) {
+  {
+    const float *sc = a.sc2, *sh = a.sh2;
+    const int lim = ceil8(c2);
+    tile_dense2<TB, NR, W2>(buf, c1, a.wp2, ceil32(c2), true, [&](float v, int o, int t) {
+      if (o < lim) buf[o * RP + t] = o < c2 ? fmaxf(v * sc[o] + sh[o], 0.f) : 0.f;
+    });
+  }
+  __syncthreads();
+  {
+    const float *sc = a.sc3, *sh = a.sh3;
+    tile_dense2<TB, NR, W3>(buf, ceil8(c2), a.wp3, ceil32(c3), true, [&](float v, int o, int t) {
+      if (o < c3) buf[o * RP + t] = fmaxf(v * sc[o] + sh[o], 0.f);
+    });
+  }
+  }
+  __syncthreads();
+  if (a.dbg & 4) return;
+  for (int e = tid; e < c3 * nc; e += kThreads) {
+    const int c = e / c3, o = e - c * c3;
+    const float *row = buf + o * RP + c * K;
+    float m = row[0];
+    for (int k = 1; k < K; k++) m = fmaxf(m, row[k]);
+    a.out[(b * c3 + o) * a.S + c0 + c] = m;
+  }
+}
+
+// y (B,L,cout) POINT-major = W x for x (B,cin,L) channel-major; cout <= 256, no activation.
+struct DensePmArgs {
+  const float *x, *wp;
+  float *y;
+  int cin, cout, L;
+};
+
+__global__ __launch_bounds__(kThreads) void dense_pm_kernel(DensePmArgs a) {
+  constexpr int TB = 2, T = 64, RP = 65;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int cinP = ceil8(a.cin), cout = a.cout;
+  float *X = smem;
+  float *Y = smem + cinP * RP;
+  const size_t b = blockIdx.y;
+  const int t0 = blockIdx.x * T;
+  for (int e = threadIdx.x; e < cinP * T; e += kThreads) {
+    const int c = e / T, t = e - c * T;
+    X[c * RP + t] = (c < a.cin && t0 + t < a.L) ? a.x[(b * a.cin + c) * a.L + t0 + t] : 0.f;
+  }
+  __syncthreads();
+  tile_dense2<TB, 2>(X, cinP, a.wp, ceil32(cout), false, [&](float v, int o, int t) {
+    if (o < cout) Y[o * RP + t] = v;
+  });
+  __syncthreads();
+  float *out = a.y + (b * a.L + t0) * (size_t)cout;
+  for (int e = threadIdx.x; e < cout * T; e += kThreads) {
+    const int t = e / cout, c = e - t * cout;
+    if (t0 + t < a.L) out[(size_t)t * cout + c] = Y[c * RP + t];
+  }
+}
+
+}  // namespace
+
+template <int TB, int NR, int W2, int W3>
+static void sa2_launch_one(const Sa2Args &a, size_t lds, hipStream_t st, dim3 grid) {
+  static bool ok = allow_big_lds(sa_fused_kernel<TB, NR, W2, W3>);
+  (void)ok;
+  hipLaunchKernelGGL((sa_fused_kernel<TB, NR, W2, W3>), grid, dim3(kThreads), lds, st, a);
+}
+
+// wsel: 1 / 2 / 4 when both MFMA layers have the same cout class (specialised bodies), else 0
+template <int TB>
+static int sa2_launch_tb(const Sa2Args &a, int nr, int wsel, size_t lds, hipStream_t st, dim3 grid) {
+  if (wsel == 4) sa2_launch_one<TB, 1, 4, 4>(a, lds, st, grid);
+  else if (wsel == 2) sa2_launch_one<TB, 1, 2, 2>(a, lds, st, grid);
+  else if (wsel == 1 && nr == 1) sa2_launch_one<TB, 1, 1, 1>(a, lds, st, grid);
+  else if (wsel == 1) sa2_launch_one<TB, 2, 1, 1>(a, lds, st, grid);
+  else if (nr == 1) sa2_launch_one<TB, 1, 0, 0>(a, lds, st, grid);
+  else sa2_launch_one<TB, 2, 0, 0>(a, lds, st, grid);
+  return 0;
+}
+
+// fast path; returns -1 when the configuration is not covered (caller falls back to sa_mlp_kernel)
+static int sa2_try(const pcr_sa_params &p, hipStream_t st) {
+  if (!p.wa || (p.D && (!p.wpq || !p.pq_ws))) return -1;
+  if ((p.c1 & 7) || p.c1 > 256 || p.c2 > 256 || p.c3 > 256) return -1;
+  const int pqw = p.mode == 0 ? 2 * p.c1 : p.c1;
+  if (p.D && pqw > 256) return -1;
+  int rowsC = p.c1 > p.c3 ? p.c1 : p.c3;
+  if (ceil8(p.c2) > rowsC) rowsC = ceil8(p.c2);
+  const int n2 = ceil32(p.c2) >> 5, n3 = ceil32(p.c3) >> 5;
+  const int nmin = n2 < n3 ? n2 : n3;
+  const int ways = nmin >= 3 ? 1 : (nmin == 2 ? 2 : 4);
+  const int nr = (n2 > 4 || n3 > 4) ? 2 : 1;
+  int best_cpw = 0, best_tb = 0;
+  for (int pass = 0; pass < 2 && !best_cpw; pass++) {
+    // pass 0: token-block count divisible among the waves and >= 2 workgroups per CU; pass 1: anything that fits
+    for (int cpw = 192 / p.K > 0 ? 192 / p.K : 1; cpw >= 1; cpw--) {
+      const int tb = (cpw * p.K + 31) / 32;
+      if (tb > 6) continue;
+      const size_t lds = ((size_t)rowsC * (32 * tb + 1) + 5 * 32 * tb + (size_t)cpw * p.c1) * sizeof(float);
+      if (pass == 0 && (tb % ways || lds > 80 * 1024)) continue;
+      if (lds > 150 * 1024) continue;
+      best_cpw = cpw;
+      best_tb = tb;
+      break;
+    }
+  }
+  if (!best_cpw) return -1;
+  if (p.D) {
+    DensePmArgs d{p.feat, p.wpq, p.pq_ws, p.D, pqw, p.N};
+    size_t lds = ((size_t)(ceil8(p.D) + pqw) * 65) * sizeof(float);
+    if (lds > (size_t)kMaxDynLds) return -1;
+    static bool ok = allow_big_lds(dense_pm_kernel);
+    (void)ok;
+    hipLaunchKernelGGL(dense_pm_kernel, dim3((p.N + 63) / 64, p.B), dim3(kThreads), lds, st, d);
+    if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
+  }
+  Sa2Args a;
+  a.B = p.B; a.N = p.N; a.S = p.S; a.K = p.K; a.c1 = p.c1; a.c2 = p.c2; a.c3 = p.c3; a.CPW = best_cpw;
+  a.xyz = p.xyz; a.idx = p.idx; a.centre_idx = p.centre_idx; a.wa = p.wa;
+  a.pq = p.D ? p.pq_ws : nullptr;
+  a.pqw = pqw;
+  a.qoff = p.mode == 0 ? p.c1 : -1;
+  static const int dbg = getenv("PCR_SA_DBG") ? atoi(getenv("PCR_SA_DBG")) : 0;
+  a.dbg = dbg;
+  static const int skew = getenv("PCR_SA_SKEW") ? atoi(getenv("PCR_SA_SKEW")) : 0;
+  a.skew = skew;
+  static const int skew_div = getenv("PCR_SA_SKEW_DIV") ? atoi(getenv("PCR_SA_SKEW_DIV")) : 256;
+  a.skew_div = skew_div > 0 ? skew_div : 256;
+  a.wp2 = p.wp[1]; a.wp3 = p.wp[2];
+  a.sc1 = p.scale[0]; a.sh1 = p.shift[0]; a.sc2 = p.scale[1]; a.sh2 = p.shift[1];
+  a.sc3 = p.scale[2]; a.sh3 = p.shift[2];
+  a.out = p.out;
+  const size_t lds = ((size_t)rowsC * (32 * best_tb + 1) + 5 * 32 * best_tb + (size_t)best_cpw * p.c1) * sizeof(float);
+  dim3 grid((p.S + best_cpw - 1) / best_cpw, p.B);
+  const int w2 = n2 >= 3 ? 1 : (n2 == 2 ? 2 : 4), w3 = n3 >= 3 ? 1 : (n3 == 2 ? 2 : 4);
+  const int wsel = w2 == w3 ? w2 : 0;
+  switch (best_tb) {
+    case 1: sa2_launch_tb<1>(a, nr, wsel, lds, st, grid); break;
+    case 2: sa2_launch_tb<2>(a, nr, wsel, lds, st, grid); break;
+    case 3: sa2_launch_tb<3>(a, nr, wsel, lds, st, grid); break;
+    case 4: sa2_launch_tb<4>(a, nr, wsel, lds, st, grid); break;
+    case 5: sa2_launch_tb<5>(a, nr, wsel, lds, st, grid); break;
+    default: sa2_launch_tb<6>(a, nr, wsel, lds, st, grid); break;
+  }
+  if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_sa_mlp_f32(const pcr_sa_params *pp, pcr_stream_t stream) {
+  if (!pp) return PCR_ERR_INVALID;
+  const pcr_sa_params &p = *pp;
+  if (p.B < 0 || p.N < 1 || p.S < 0 || p.K < 1 || p.D < 0 || p.c1 < 1 || p.c2 < 1 || p.c3 < 1 ||
+      !p.xyz || !p.idx || !p.out || (p.D && !p.feat) || (p.mode != 0 && p.mode != 1))
+    return PCR_ERR_INVALID;
+  for (int l = 0; l < 3; l++)
+    if (!p.wp[l] || !p.scale[l] || !p.shift[l]) return PCR_ERR_INVALID;
+  if (p.B == 0 || p.S == 0) return PCR_OK;
+  if (p.B > 65535) return PCR_ERR_INVALID;
+  const int fast = sa2_try(p, pcr_s(stream));
+  if (fast >= 0) return fast;
+  SaArgs a;
+  a.p = p;
+  a.C0 = 3 + (p.mode == 0 ? 2 * p.D : p.D);
+  a.C0P = ceil8(a.C0);
+  a.rowsA = a.C0P > ceil8(p.c2) ? a.C0P : ceil8(p.c2);
+  a.rowsB = ceil8(p.c1) > p.c3 ? ceil8(p.c1) : p.c3;
+  // centres per workgroup: as many as keep rows <= 128 (at least one) and LDS <= 150 KiB
+  int cpw = 128 / p.K;
+  if (cpw < 1) cpw = 1;
+  size_t lds = 0;
+  for (;; cpw--) {
+    a.CPW = cpw;
+    a.TB = (cpw * p.K + 31) / 32;
+    a.RP = 32 * a.TB + 1;
+    lds = ((size_t)(a.rowsA + a.rowsB) * a.RP + 32 * a.TB) * sizeof(float);
+    if (lds <= 150 * 1024 || cpw == 1) break;
+  }
+  if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
+  static bool ok = allow_big_lds(sa_mlp_kernel);
+  (void)ok;
+  hipLaunchKernelGGL(sa_mlp_kernel, dim3((p.S + a.CPW - 1) / a.CPW, p.B), dim3(kThreads), lds,
+                     pcr_s(stream), a);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+

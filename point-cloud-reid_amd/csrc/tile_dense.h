@@ -1,0 +1,245 @@
+// Shared device helpers of the fused model kernels (included by sa_kernels.hip, attn_kernels.hip,
+// model_kernels.hip): the MFMA dense tile, LayerNorm over an LDS tile, small utilities.
+#pragma once
+// Fused model kernels of the siamese ReID hot path for gfx950 (MI355X).
+//
+// Data layout everywhere: channel-major feature tensors (B, C, L) exactly as the reference's
+// model path carries them ([B,C,N] tensors, models/backbone_net.py:96-124), so a tile of 32*TB
+// consecutive tokens of one cloud is C contiguous runs in HBM and lands in LDS as [C][RP]
+// (RP = tokens + 1, odd => every access pattern used below is bank-conflict free).
+//
+// All matmuls run on the f32-input matrix core (v_mfma_f32_32x32x2_f32: exact fp32 fmaf chain,
+// 64 FLOP/clk/SIMD) with the WEIGHTS as the A operand, read straight from a host-packed image
+// (one 16-byte load per lane covers four k-steps), and the LDS-resident activations as the B
+// operand (token = lane => conflict-free ds_read_b32, token-contiguous epilogue stores).
+#include <math.h>
+#include <stdlib.h>
+
+#include "pcr_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__host__ __device__ inline int ceil8(int x) { return (x + 7) & ~7; }
+__host__ __device__ inline int ceil32(int x) { return (x + 31) & ~31; }
+
+constexpr int kThreads = 256;
+constexpr int kMaxDynLds = 160 * 1024;
+
+// out[o][t] = epi(sum_k W[o][k] * in[k][t], o, t) for o < OP (multiple of 32), t < 32*TB.
+//   in : LDS [CP][RP], CP multiple of 8, rows >= real cin must be ZERO
+//   wp : packed image [CP/8][OP][2][4]  (pcr_pack_weight_f32)
+// The (cout-block, token-block) tiles are dealt round-robin to the waves, cout-block major, so
+// that the waves of a workgroup share weight lines in L1.
+template <class Epi>
+__device__ __forceinline__ void tile_dense(const float *__restrict__ in, int CP, int RP, int TB,
+                                           const float *__restrict__ wp, int OP, Epi epi) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int nItems = (OP >> 5) * TB;
+  const int KB = CP >> 3;
+  const size_t wstride = (size_t)OP * 2;  // f32x4 units per k-block
+  for (int item = wave; item < nItems; item += nwaves) {
+    const int cb = item / TB, tb = item - cb * TB;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    const f32x4 *wv = reinterpret_cast<const f32x4 *>(wp) + (size_t)(cb * 32 + l31) * 2 + h;
+    const float *bp = in + h * RP + tb * 32 + l31;
+#pragma unroll 2
+    for (int kb = 0; kb < KB; kb++) {
+      const f32x4 a = wv[(size_t)kb * wstride];
+      const float *b0 = bp + (kb * 8) * RP;
+      const float x0 = b0[0], x1 = b0[2 * RP], x2 = b0[4 * RP], x3 = b0[6 * RP];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], x0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], x1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], x2, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], x3, acc, 0, 0, 0);
+    }
+    const int t = tb * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int o = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      epi(acc[r], o, t);
+    }
+  }
+}
+
+// Second-generation dense tile: compile-time token tile (RP immediate offsets), each wave OWNS
+// cout blocks and sweeps the token blocks with the weight fragment held in registers (one 16-byte
+// weight load feeds 4*TB MFMAs), weight fragments prefetched one k-block ahead, and an optional
+// barrier between the k-loop and the epilogue so that the output may overwrite the input buffer.
+//   nCB = OP/32 >= 3 : wave w owns cout blocks w, w+4 (NR rounds), all TB token blocks
+//   nCB == 2         : wave w owns cout block w&1 and token blocks (w>>1), (w>>1)+2, ...
+//   nCB == 1         : wave w owns token blocks w, w+4, ...
+template <int TB, int NR, int WAYS, class Epi>
+__device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, int CP,
+                                                const float *__restrict__ wp, int OP, bool sync_epi,
+                                                Epi epi) {
+  constexpr int RP = 32 * TB + 1;
+  constexpr int TBW = (TB + WAYS - 1) / WAYS;  // token blocks per wave
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int nCB = OP >> 5, KB = CP >> 3;
+  const int cb0 = WAYS == 1 ? wave : (WAYS == 2 ? (wave & 1) : 0);
+  const int tb0 = WAYS == 1 ? 0 : (WAYS == 2 ? (wave >> 1) : wave);
+  // The k-loop is branch-free: a tile the wave does not own (cb >= nCB or tb >= TB, which only
+  // happens for shapes that do not divide evenly) is computed on clamped addresses and dropped in
+  // the epilogue, so the accumulators stay pinned in AGPRs.
+  f32x16 acc[NR][TBW];
+#pragma unroll
+  for (int nr = 0; nr < NR; nr++)
+#pragma unroll
+    for (int j = 0; j < TBW; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[nr][j][r] = 0.f;
+  const size_t wstride = (size_t)OP * 2;
+  const f32x4 *wrow[NR];
+#pragma unroll
+  for (int nr = 0; nr < NR; nr++) {
+    int cb = cb0 + 4 * nr;
+    cb = cb < nCB ? cb : nCB - 1;
+    wrow[nr] = reinterpret_cast<const f32x4 *>(wp) + (size_t)cb * 64 + (size_t)l31 * 2 + h;
+  }
+  const float *brow[TBW];
+#pragma unroll
+  for (int j = 0; j < TBW; j++) {
+    int tb = tb0 + j * WAYS;
+    tb = tb < TB ? tb : TB - 1;
+    brow[j] = in + h * RP + tb * 32 + l31;
+  }
+  // two weight-fragment register sets in ping-pong: the 16-byte load for k-block kb+2 is issued
+  // right after the last use of set (kb & 1) and has a full block of MFMAs to land
+  auto step = [&](const f32x4 (&aw)[NR], int kb) {
+#pragma unroll
+    for (int j = 0; j < TBW; j++) {
+      const float *bt = brow[j] + kb * 8 * RP;
+      const float x0 = bt[0], x1 = bt[2 * RP], x2 = bt[4 * RP], x3 = bt[6 * RP];
+#pragma unroll
+      for (int nr = 0; nr < NR; nr++) {
+        acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[nr][0], x0, acc[nr][j], 0, 0, 0);
+        acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[nr][1], x1, acc[nr][j], 0, 0, 0);
+        acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[nr][2], x2, acc[nr][j], 0, 0, 0);
+        acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[nr][3], x3, acc[nr][j], 0, 0, 0);
+      }
+    }
+  };
+  f32x4 a0[NR], a1[NR];
+  const int k1 = KB > 1 ? 1 : 0;
+#pragma unroll
+  for (int nr = 0; nr < NR; nr++) {
+    a0[nr] = wrow[nr][0];
+    a1[nr] = wrow[nr][(size_t)k1 * wstride];
+  }
+  for (int kb = 0; kb < KB; kb += 2) {
+    step(a0, kb);
+    const int kn0 = kb + 2 < KB ? kb + 2 : KB - 1;
+#pragma unroll
+    for (int nr = 0; nr < NR; nr++) a0[nr] = wrow[nr][(size_t)kn0 * wstride];
+    if (kb + 1 < KB) {
+      step(a1, kb + 1);
+      const int kn1 = kb + 3 < KB ? kb + 3 : KB - 1;
+#pragma unroll
+      for (int nr = 0; nr < NR; nr++) a1[nr] = wrow[nr][(size_t)kn1 * wstride];
+    }
+  }
+  if (sync_epi) __syncthreads();
+#pragma unroll
+  for (int nr = 0; nr < NR; nr++) {
+    const int cb = cb0 + 4 * nr;
+    if (cb < nCB) {
+#pragma unroll
+      for (int j = 0; j < TBW; j++) {
+        const int tb = tb0 + j * WAYS;
+        if (tb < TB) {
+          const int t = tb * 32 + l31;
+#pragma unroll
+          for (int r = 0; r < 16; r++) epi(acc[nr][j][r], cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, t);
+        }
+      }
+    }
+  }
+}
+
+// WSEL = 0: pick the wave/tile split from OP at run time (all three bodies are compiled in and the
+// register allocation is their maximum); WSEL = 1 / 2 / 4: the caller guarantees OP/32 >= 3 / == 2 /
+// == 1 and only that body is compiled (fewer registers => more waves per SIMD).
+template <int TB, int NR, int WSEL = 0, class Epi>
+__device__ __forceinline__ void tile_dense2(const float *__restrict__ in, int CP,
+                                            const float *__restrict__ wp, int OP, bool sync_epi, Epi epi) {
+  if constexpr (WSEL == 1) {
+    tile_dense_impl<TB, NR, 1>(in, CP, wp, OP, sync_epi, epi);
+  } else if constexpr (WSEL == 2) {
+    tile_dense_impl<TB, 1, 2>(in, CP, wp, OP, sync_epi, epi);
+  } else if constexpr (WSEL == 4) {
+    tile_dense_impl<TB, 1, 4>(in, CP, wp, OP, sync_epi, epi);
+  } else {
+    const int nCB = OP >> 5;
+    if (nCB >= 3) tile_dense_impl<TB, NR, 1>(in, CP, wp, OP, sync_epi, epi);
+    else if (nCB == 2) tile_dense_impl<TB, 1, 2>(in, CP, wp, OP, sync_epi, epi);
+    else tile_dense_impl<TB, 1, 4>(in, CP, wp, OP, sync_epi, epi);
+  }
+}
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x + 1.0f : (expf(x) - 1.0f) + 1.0f; }
+
+// LayerNorm over the channel rows [0,C) of buf ([C][RP]) for each of the T token columns, in
+// place; part = tid / T handles channels part, part+np, ...; partial sums meet in `red`
+// ([2][np][T] floats).  Two passes (mean, then centred variance), eps inside the sqrt, affine.
+__device__ __forceinline__ void tile_layernorm(float *buf, int C, int RP, int T, const float *g,
+                                               const float *bta, float *red) {
+  const int tid = threadIdx.x;
+  const int np = blockDim.x / T;  // T is 32 or 64 => np = 8 or 4
+  const int t = tid % T, part = tid / T;
+  float s = 0.f;
+  if (part < np)
+    for (int c = part; c < C; c += np) s += buf[c * RP + t];
+  if (part < np) red[part * T + t] = s;
+  __syncthreads();
+  float mean = 0.f;
+  for (int p = 0; p < np; p++) mean += red[p * T + t];
+  mean /= (float)C;
+  float v = 0.f;
+  if (part < np)
+    for (int c = part; c < C; c += np) {
+      float d = buf[c * RP + t] - mean;
+      v += d * d;
+    }
+  if (part < np) red[(np + part) * T + t] = v;
+  __syncthreads();
+  float var = 0.f;
+  for (int p = 0; p < np; p++) var += red[(np + p) * T + t];
+  var /= (float)C;
+  const float inv = 1.0f / sqrtf(var + 1e-5f);
+  if (part < np)
+    for (int c = part; c < C; c += np) buf[c * RP + t] = (buf[c * RP + t] - mean) * inv * g[c] + bta[c];
+  __syncthreads();
+}
+
+// loads a [C][T] tile of a (B,C,L) tensor into LDS rows [0,CP), zero beyond C or beyond L
+__device__ __forceinline__ void load_tile(float *dst, int RP, const float *src, int C, int CP, int L,
+                                          int t0, int T) {
+  for (int e = threadIdx.x; e < CP * T; e += blockDim.x) {
+    const int c = e / T, t = e - c * T;
+    dst[c * RP + t] = (c < C && t0 + t < L) ? src[(size_t)c * L + t0 + t] : 0.f;
+  }
+}
+
+// xyz (L,3) rows t0.. -> LDS [8][RP] (rows 3..7 zero)
+__device__ __forceinline__ void load_xyz_tile(float *dst, int RP, const float *xyz, int L, int t0, int T) {
+  for (int e = threadIdx.x; e < 8 * T; e += blockDim.x) {
+    const int c = e / T, t = e - c * T;
+    dst[c * RP + t] = (c < 3 && t0 + t < L) ? xyz[(size_t)(t0 + t) * 3 + c] : 0.f;
+  }
+}
+
+template <class Kern>
+bool allow_big_lds(Kern k) {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             kMaxDynLds) == hipSuccess;
+}
+
+}  // namespace
