@@ -142,9 +142,16 @@ typedef struct pcr_sa_params {
    * evaluates layer 1 as relu(wa dxyz + P[i] + Q[c] + shift[0]) and never reads scale[0]. */
   const float *wa, *wpq;
   float *pq_ws;
+  int pq_ready; /* nonzero: pq_ws already holds the tables (caller ran pcr_dense_pm_f32 itself) */
   float *out;
 } pcr_sa_params;
 int pcr_sa_mlp_f32(const pcr_sa_params *p, pcr_stream_t stream);
+
+/* Per-point linear map with POINT-major output: x (B,cin,L) channel-major -> y (B,L,cout) = W x,
+ * wp packed (cout,cin), cout <= 256.  This is the table builder of the decomposed first SA layer
+ * (pcr_sa_mlp_f32 runs it itself unless pq_ready is set). */
+int pcr_dense_pm_f32(const float *x, const float *wp, float *y, int B, int cin, int cout, int L,
+                     pcr_stream_t stream);
 
 /* Linear-attention block shared by Self_Attention (models/pointnet2_utils.py:90-114), FP_SA
  * (:407-437) and corss_attention (models/attention.py:192-219), in two kernels.

@@ -280,8 +280,11 @@ static int sa2_launch_tb(const Sa2Args &a, int nr, int wsel, size_t lds, hipStre
   return 0;
 }
 
+extern "C" int pcr_dense_pm_f32(const float *, const float *, float *, int, int, int, int, pcr_stream_t);
+
 // fast path; returns -1 when the configuration is not covered (caller falls back to sa_mlp_kernel)
-static int sa2_try(const pcr_sa_params &p, hipStream_t st) {
+static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
+  hipStream_t st = pcr_s(st_);
   if (!p.wa || (p.D && (!p.wpq || !p.pq_ws))) return -1;
   if ((p.c1 & 7) || p.c1 > 256 || p.c2 > 256 || p.c3 > 256) return -1;
   const int pqw = p.mode == 0 ? 2 * p.c1 : p.c1;
@@ -307,14 +310,9 @@ static int sa2_try(const pcr_sa_params &p, hipStream_t st) {
     }
   }
   if (!best_cpw) return -1;
-  if (p.D) {
-    DensePmArgs d{p.feat, p.wpq, p.pq_ws, p.D, pqw, p.N};
-    size_t lds = ((size_t)(ceil8(p.D) + pqw) * 65) * sizeof(float);
-    if (lds > (size_t)kMaxDynLds) return -1;
-    static bool ok = allow_big_lds(dense_pm_kernel);
-    (void)ok;
-    hipLaunchKernelGGL(dense_pm_kernel, dim3((p.N + 63) / 64, p.B), dim3(kThreads), lds, st, d);
-    if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
+  if (p.D && !p.pq_ready) {
+    const int rc = pcr_dense_pm_f32(p.feat, p.wpq, p.pq_ws, p.B, p.D, pqw, p.N, st_);
+    if (rc != PCR_OK) return rc == PCR_ERR_INVALID ? -1 : rc;
   }
   Sa2Args a;
   a.B = p.B; a.N = p.N; a.S = p.S; a.K = p.K; a.c1 = p.c1; a.c2 = p.c2; a.c3 = p.c3; a.CPW = best_cpw;
@@ -348,6 +346,21 @@ static int sa2_try(const pcr_sa_params &p, hipStream_t st) {
   return PCR_OK;
 }
 
+PCR_EXPORT int pcr_dense_pm_f32(const float *x, const float *wp, float *y, int B, int cin, int cout, int L,
+                                pcr_stream_t stream) {
+  if (!x || !wp || !y || B < 0 || cin < 1 || cout < 1 || cout > 256 || L < 1) return PCR_ERR_INVALID;
+  if (B == 0) return PCR_OK;
+  if (B > 65535) return PCR_ERR_INVALID;
+  DensePmArgs d{x, wp, y, cin, cout, L};
+  size_t lds = ((size_t)(ceil8(cin) + cout) * 65) * sizeof(float);
+  if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
+  static bool ok = allow_big_lds(dense_pm_kernel);
+  (void)ok;
+  hipLaunchKernelGGL(dense_pm_kernel, dim3((L + 63) / 64, B), dim3(kThreads), lds, pcr_s(stream), d);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
 PCR_EXPORT int pcr_sa_mlp_f32(const pcr_sa_params *pp, pcr_stream_t stream) {
   if (!pp) return PCR_ERR_INVALID;
   const pcr_sa_params &p = *pp;
@@ -358,7 +371,7 @@ PCR_EXPORT int pcr_sa_mlp_f32(const pcr_sa_params *pp, pcr_stream_t stream) {
     if (!p.wp[l] || !p.scale[l] || !p.shift[l]) return PCR_ERR_INVALID;
   if (p.B == 0 || p.S == 0) return PCR_OK;
   if (p.B > 65535) return PCR_ERR_INVALID;
-  const int fast = sa2_try(p, pcr_s(stream));
+  const int fast = sa2_try(p, stream);
   if (fast >= 0) return fast;
   SaArgs a;
   a.p = p;

@@ -42,7 +42,7 @@ class SaParams(ctypes.Structure):
                 ("c1", ctypes.c_int), ("c2", ctypes.c_int), ("c3", ctypes.c_int),
                 ("xyz", c_float_p), ("feat", c_float_p), ("idx", c_int_p), ("centre_idx", c_int_p),
                 ("wp", c_float_p * 3), ("scale", c_float_p * 3), ("shift", c_float_p * 3),
-                ("wa", c_float_p), ("wpq", c_float_p), ("pq_ws", c_float_p),
+                ("wa", c_float_p), ("wpq", c_float_p), ("pq_ws", c_float_p), ("pq_ready", ctypes.c_int),
                 ("out", c_float_p)]
 
 
@@ -164,10 +164,16 @@ class SaPlan:
                 pqw = (2 if self.mode == 0 else 1) * self.couts[0]
                 ws = torch.empty((B, N, pqw), dtype=torch.float32, device=xyz.device)
                 p.wpq, p.pq_ws = _p(self.wpq), _p(ws)
+                # the per-point tables of the decomposed first layer, as its own (profiled) launch
+                with _prof("sa_tables[D=%d,out=%d,N=%d]" % (D, pqw, N), 2.0 * B * N * D * pqw,
+                           4.0 * B * N * (D + pqw)):
+                    L.check(L.load().pcr_dense_pm_f32(L.ptr(feat), _p(self.wpq), _p(ws), B, D, pqw, N,
+                                                      L.stream_ptr()), "pcr_dense_pm_f32")
+                p.pq_ready = 1
         c1, c2, c3 = self.couts
         flops = 2.0 * B * S * K * (self.cin * c1 + c1 * c2 + c2 * c3)
         nbytes = 4.0 * B * (3 * N + D * N + S * K + c3 * S)
-        with _prof("sa_mlp[D=%d,c=%d/%d/%d,N=%d,S=%d,K=%d]" % (D, c1, c2, c3, N, S, K), flops, nbytes):
+        with _prof("sa_fused[D=%d,c=%d/%d/%d,N=%d,S=%d,K=%d]" % (D, c1, c2, c3, N, S, K), flops, nbytes):
             L.check(L.load().pcr_sa_mlp_f32(ctypes.byref(p), L.stream_ptr()), "pcr_sa_mlp_f32")
         return out
 
