@@ -43,6 +43,8 @@ WORKLOADS = {
                [1024, 512, 256], 512),
     "pt128": ("Point-Transformer ReIDNet (reid_nuscenes_pts/testing_pts_point-transformer_r_nus_det_500e.py), "
               "128-pt synthetic pairs, eval", "pt", 128, [128, 64, 32], 512),
+    "ssg1024": ("PointNet++ SSG siamese (BASELINE config 2; SA(512,r.2,K32,[64,64,128]) -> SA(128,r.4,K64,[128,128,256]) "
+                "-> Conv1d 64; D-FPS + ball query), 1024-pt synthetic pairs, eval", "ssg", 1024, None, 512),
     "pt4096": ("Point-Transformer ReIDNet, 4096-pt Waymo-shape synthetic pairs, eval", "pt", 4096,
                [4096, 2048, 1024], 256),
 }
@@ -59,6 +61,23 @@ def build_pt_model(backbone_list, device="cuda"):
     model = build_model(cfg)
     man = T.load_manifest(os.path.join(ROOT, "tests", "golden", "pt_manifest.json"))
     sd = T.seeded_state_dict(man, 0)
+    model.load_state_dict(sd, strict=True)
+    return model.to(device).eval(), sd
+
+
+SSG_MODEL = copy.deepcopy(PT_MODEL)
+SSG_MODEL["backbone"] = dict(type="PointNet2SSG", num_points=(512, 128), radii=(0.2, 0.4), num_samples=(32, 64),
+                             sa_channels=((64, 64, 128), (128, 128, 256)), conv_out=64)
+
+
+def build_model(kind, backbone_list, device="cuda"):
+    """kind 'pt' (reference Point-Transformer config) or 'ssg' (BASELINE config 2 composition); seeded weights"""
+    if kind == "pt":
+        return build_pt_model(backbone_list, device)
+    from mmdet3d.models import build_model as _build
+    from pcr_amd import testing as T
+    model = _build(copy.deepcopy(SSG_MODEL))
+    sd = T.seeded_state_dict(T.manifest_of(model), 0)
     model.load_state_dict(sd, strict=True)
     return model.to(device).eval(), sd
 
@@ -103,7 +122,8 @@ def cpu_baseline(workload, sd, budget_s=20.0):
     except AttributeError:
         avail = os.cpu_count() or 1
     pairs = 8 if n >= 1024 else 32
-    s1, s2 = T.synthetic_pairs(pairs, n, seed=1234, kind="randn")
+    s1, s2 = T.synthetic_pairs(pairs, n, seed=1234, kind="box" if kind == "ssg" else "randn")
+    run = (lambda: MO.ssg_pairs(sd, s1, s2)) if kind == "ssg" else (lambda: MO.pt_pairs(sd, s1, s2, bl))
     best, best_threads, runs = None, 1, 0
     t_start = time.time()
     # torch's intra-op pool does not scale to hundreds of threads on these small per-cloud ops:
@@ -116,7 +136,7 @@ def cpu_baseline(workload, sd, budget_s=20.0):
                 if time.time() - t_start > budget_s and runs >= 2:
                     break
                 t0 = time.time()
-                MO.pt_pairs(sd, s1, s2, bl)
+                run()
                 dt = time.time() - t0
                 runs += 1
                 if best is None or dt < best:
@@ -148,9 +168,10 @@ def main():
 
     desc, kind, n, bl, dpairs = WORKLOADS[args.workload]
     pairs = args.pairs or dpairs
-    model, sd = build_pt_model(bl)
+    model, sd = build_model(kind, bl)
     # weak scaling: every rank owns `pairs` independent pairs (its own seed), already resident in HBM
-    s1, s2 = T.synthetic_pairs(pairs, n, seed=1234 + rank, kind="randn")
+    cloud_kind = "box" if kind == "ssg" else "randn"     # ball-query radii are metric: vehicle-sized box crops
+    s1, s2 = T.synthetic_pairs(pairs, n, seed=1234 + rank, kind=cloud_kind)
     s1, s2 = s1.cuda(), s2.cuda()
 
     with torch.no_grad():
@@ -186,7 +207,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (randn clouds, seeded random-init weights with non-trivial BN statistics)",
+            "data": "synthetic (%s clouds, seeded random-init weights with non-trivial BN statistics)" % cloud_kind,
             "config": {"workload": "%s: %s" % (args.workload, desc), "pairs_per_gpu_per_step": pairs,
                        "points": n, "backbone_list": bl, "parallelism": "independent pair shards x%d" % world},
             "roofline": roof,

@@ -259,3 +259,47 @@ def pointnet_pairs(sd, s1, s2, stages=None):
     if stages is not None:
         stages.update(h1=h[:b], h2=h[b:], enc_max=f.max(dim=2)[0], enc_mean=f.mean(dim=2))
     return match(sd, h[:b], xyz[:b], h[b:], xyz[b:], stages)
+
+
+# ---- PointNet++ SSG encoder (BASELINE config 2; build-defined composition) ---------
+# Semantics restated from the reference's mmdet3d ops: Points_Sampler D-FPS (points_sampler.py:107-119),
+# gather_points, QueryAndGroup with ball query and use_xyz (group_points.py:94-118), ConvModule stack
+# (1x1 Conv2d bias-free + BN2d + ReLU, point_sa_module.py:289-299), max pool (:166-182).  FPS and ball
+# query indices come from the C oracle (oracle/pcr_oracle.c), which replays the CUDA kernels' rules.
+def ssg_sa_layer(p, xyz, feats, npoint, radius, nsample, stages=None, tag=""):
+    import numpy as np
+    import point_ops as P
+    x = xyz.numpy()
+    fps = P.fps(x, npoint)
+    new_xyz = torch.from_numpy(np.take_along_axis(x, fps[..., None].astype(np.int64).repeat(3, -1), 1))
+    idx = torch.from_numpy(P.ball_query(0.0, radius, nsample, x, new_xyz.numpy())).long()
+    g = _gather_rows(xyz, idx) - new_xyz.unsqueeze(2)
+    if feats is not None:
+        g = torch.cat([g, _gather_rows(feats.permute(0, 2, 1), idx)], dim=-1)
+    h = g.permute(0, 3, 1, 2)
+    for i in range(3):
+        h = F.conv2d(h, p[f"mlps.0.layer{i}.conv.weight"])
+        h = F.relu(_bn(h, p, f"mlps.0.layer{i}.bn", 4))
+    out = h.max(dim=3)[0]
+    if stages is not None:
+        stages[tag + "_fps"] = torch.from_numpy(fps)
+        stages[tag + "_ball"] = idx
+        stages[tag + "_out"] = out
+    return new_xyz, out
+
+
+def ssg_backbone(p, pc, num_points=(512, 128), radii=(0.2, 0.4), num_samples=(32, 64), stages=None):
+    xyz = pc[..., :3].contiguous()
+    feats = None
+    for i in range(len(num_points)):
+        xyz, feats = ssg_sa_layer(_sub(p, f"SA_modules.{i}."), xyz, feats, num_points[i], radii[i], num_samples[i],
+                                  stages, f"sa{i}")
+    return xyz, F.conv1d(feats, p["cov_final.weight"], p["cov_final.bias"])
+
+
+def ssg_pairs(sd, s1, s2, stages=None, **kw):
+    b = s1.shape[0]
+    xyz, h = ssg_backbone(_sub(sd, "backbone."), torch.cat([s1, s2], 0), stages=stages, **kw)
+    if stages is not None:
+        stages.update(h1=h[:b], h2=h[b:])
+    return match(sd, h[:b], xyz[:b], h[b:], xyz[b:], stages)

@@ -21,6 +21,7 @@ from .backbone_net import Pointnet_Backbone
 from .builder import FUSIONMODELS
 from .lanegcn_nets import LinearRes
 from .pointnet import PointNet
+from .pointnet2_ssg import PointNet2SSG
 
 
 class _OutOfScope(nn.Module):
@@ -58,6 +59,8 @@ module_obj = {
     "cross_lin_attn": cross_lin_attn,
     "dgcnn": DGCNN,
     "PointNet": PointNet,
+    # not in the reference table: BASELINE config 2's build-defined PointNet++ SSG encoder
+    "PointNet2SSG": PointNet2SSG,
 }
 
 

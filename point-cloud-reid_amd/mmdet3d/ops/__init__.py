@@ -6,5 +6,9 @@ from .point_ops import (FurthestPointSampling, FurthestPointSamplingWithDist, Ba
                         furthest_point_sample_with_dist, ball_query, knn, gather_points, grouping_operation,
                         three_nn, three_interpolate)
 
-__all__ = ["furthest_point_sample", "furthest_point_sample_with_dist", "ball_query", "knn", "gather_points",
+from .pointnet_modules import (SA_MODULES, GroupAll, PointFPModule, PointSAModule, PointSAModuleMSG, Points_Sampler,
+                               QueryAndGroup, build_sa_module, calc_square_dist)
+
+__all__ = ["SA_MODULES", "GroupAll", "PointFPModule", "PointSAModule", "PointSAModuleMSG", "Points_Sampler",
+           "QueryAndGroup", "build_sa_module", "furthest_point_sample", "furthest_point_sample_with_dist", "ball_query", "knn", "gather_points",
            "grouping_operation", "three_nn", "three_interpolate"]

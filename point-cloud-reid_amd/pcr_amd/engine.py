@@ -167,7 +167,7 @@ class SaPlan:
                 # the per-point tables of the decomposed first layer, as its own (profiled) launch
                 with _prof("sa_tables[D=%d,out=%d,N=%d]" % (D, pqw, N), 2.0 * B * N * D * pqw,
                            4.0 * B * N * (D + pqw)):
-                    L.check(L.load().pcr_dense_pm_f32(L.ptr(feat), _p(self.wpq), _p(ws), B, D, pqw, N,
+                    L.check(L.load().pcr_dense_pm_f32(L.ptr(feat), L.ptr(self.wpq), L.ptr(ws), B, D, pqw, N,
                                                       L.stream_ptr()), "pcr_dense_pm_f32")
                 p.pq_ready = 1
         c1, c2, c3 = self.couts

@@ -1,0 +1,100 @@
+"""GPU parity of the mmdet3d-style PointNet++ modules (PointSAModule / PointFPModule / Points_Sampler /
+QueryAndGroup) and of the PointNet2SSG siamese model (BASELINE config 2) against the oracles."""
+import copy
+import json
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from pcr_amd import testing as T
+import point_ops as P
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def ssg_model():
+    import bench
+    return bench.build_model("ssg", None)
+
+
+@pytest.mark.parametrize("pairs,n,kind", [(3, 1024, "box"), (2, 1024, "dup"), (2, 700, "randn")])
+def test_ssg_pairs_match_oracle(pairs, n, kind):
+    import model_oracle as MO
+    model, sd = ssg_model()
+    s1, s2 = T.synthetic_pairs(pairs, n, seed=5, kind=kind)
+    ref = {}
+    with torch.no_grad():
+        want = MO.ssg_pairs(sd, s1, s2, stages=ref)
+        xyz1, xyz2, h1, h2 = model.siamese_forward(s1.cuda(), s2.cuda())
+        logits = model.match_forward_inference(h1, h2, xyz1, xyz2)
+    assert xyz1.shape == (pairs, 128, 3) and h1.shape == (pairs, 64, 128)
+    worst = dict(h1=float((h1.cpu() - ref["h1"]).abs().max()), h2=float((h2.cpu() - ref["h2"]).abs().max()),
+                 logits=float((logits.cpu() - want).abs().max()))
+    print(json.dumps(worst))
+    assert max(worst.values()) < TOL, worst
+
+
+def test_point_sa_module_stages_bit_exact_indices():
+    from mmdet3d.ops import PointSAModule
+    import model_oracle as MO
+    torch.manual_seed(0)
+    sa = PointSAModule(mlp_channels=[6, 32, 32, 64], num_point=96, radius=0.5, num_sample=16)
+    sd = T.seeded_state_dict(T.manifest_of(sa), 3)
+    sa.load_state_dict(sd)
+    sa = sa.cuda().eval()
+    xyz = T.synthetic_clouds(2, 300, seed=2, kind="dup")
+    feats = torch.randn(2, 6, 300)
+    new_xyz, out, idx = sa(xyz.cuda(), feats.cuda())
+    st = {}
+    with torch.no_grad():
+        rx, ro = MO.ssg_sa_layer(sd, xyz, feats, 96, 0.5, 16, st, "s")
+    assert (idx.cpu().numpy() == st["s_fps"].numpy()).all()
+    assert torch.equal(new_xyz.cpu(), rx)
+    assert float((out.cpu() - ro).abs().max()) < 2e-5
+    # stand-alone grouper = same indices as the C oracle
+    from mmdet3d.ops import QueryAndGroup
+    grouped, gidx = QueryAndGroup(0.5, 16, return_grouped_idx=True)(xyz.cuda(), new_xyz, feats.cuda())
+    assert (gidx.cpu().numpy() == st["s_ball"].numpy()).all()
+    assert grouped.shape == (2, 9, 96, 16)
+    with pytest.raises(RuntimeError):
+        sa.train()
+        sa(xyz.cuda(), feats.cuda())
+
+
+def test_point_fp_module_matches_torch():
+    from mmdet3d.ops import PointFPModule
+    fp = PointFPModule(mlp_channels=[24 + 10, 48, 32])
+    sd = T.seeded_state_dict(T.manifest_of(fp), 4)
+    fp.load_state_dict(sd)
+    fp = fp.cuda().eval()
+    target = T.synthetic_clouds(2, 257, seed=3, kind="box")
+    source = target[:, :40].contiguous()
+    tf, sf = torch.randn(2, 10, 257), torch.randn(2, 24, 40)
+    out = fp(target.cuda(), source.cuda(), tf.cuda(), sf.cuda()).cpu()
+    d2, i3 = P.three_nn(target.numpy(), source.numpy())
+    dist = torch.from_numpy(np.sqrt(d2))
+    w = 1.0 / (dist + 1e-8)
+    w = w / w.sum(dim=2, keepdim=True)
+    interp = torch.from_numpy(P.three_interp_fwd(sf.numpy(), i3, w.numpy()))
+    x = torch.cat([interp, tf], dim=1).unsqueeze(-1)
+    with torch.no_grad():
+        for i in range(2):
+            x = F.conv2d(x, sd[f"mlps.layer{i}.conv.weight"])
+            x = F.relu(F.batch_norm(x, sd[f"mlps.layer{i}.bn.running_mean"], sd[f"mlps.layer{i}.bn.running_var"],
+                                    sd[f"mlps.layer{i}.bn.weight"], sd[f"mlps.layer{i}.bn.bias"], False, 0.0, 1e-5))
+    assert float((out - x.squeeze(-1)).abs().max()) < 2e-5
+
+
+def test_points_sampler_modes():
+    from mmdet3d.ops import Points_Sampler
+    xyz = T.synthetic_clouds(2, 256, seed=9, kind="randn")
+    feats = torch.randn(2, 8, 256)
+    idx = Points_Sampler([64], ["D-FPS"], [-1])(xyz.cuda(), feats.cuda()).cpu().numpy()
+    assert (idx == P.fps(xyz.numpy(), 64)).all()
+    idx = Points_Sampler([32], ["F-FPS"], [-1])(xyz.cuda(), feats.cuda())
+    assert idx.shape == (2, 32) and idx.dtype == torch.int32 and int(idx.max()) < 256
+    idx = Points_Sampler([16], ["FS"], [-1])(xyz.cuda(), feats.cuda())
+    assert idx.shape == (2, 32)
