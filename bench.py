@@ -152,7 +152,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="pt1024", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="ssg1024", choices=sorted(WORKLOADS),
+                    help="default = BASELINE.json configs[1] (PointNet++ SSG siamese @1024); pt1024 = configs[2]")
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (default: per workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--detail", action="store_true", help="also print per-launch device times (stderr)")

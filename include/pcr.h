@@ -218,6 +218,25 @@ int pcr_pool_both_f32(const float *x, float *out, int B, int C, int L, pcr_strea
 int pcr_dense_f32(const float *x, const float *wp, const float *scale, const float *shift, float *y,
                   int B, int cin, int cout, int L, int act, pcr_stream_t stream);
 
+/* ---- PointNet encoder pieces (models/pointnet.py:10-127) and LinearRes rows (lanegcn_nets.py:228-241) ---- */
+
+/* (B,C,L) -> out (C,B) with out[c*B + b] = max over L: the global max pool of STN3d/STNkd
+ * (pointnet.py:31,71), written channel-major with the clouds as tokens so that the fc layers that
+ * follow are plain pcr_dense_f32 calls on a (1,C,B) tensor. */
+int pcr_max_over_l_f32(const float *x, float *out, int B, int C, int L, pcr_stream_t stream);
+
+/* t (1,k*k,B) = the fc3 output of an STN (+identity), entry [c*k + c2][b] = T_b[c][c2] -> per-cloud packed
+ * weight images (B, packed(k,k)) of W_b = T_b^T; pcr_dense_bmm_f32(x, images) then equals
+ * torch.bmm(x^T, T)^T (pointnet.py:110,118). */
+int pcr_pack_bmm_f32(const float *t, float *wp_per_cloud, int B, int k, pcr_stream_t stream);
+int pcr_dense_bmm_f32(const float *x, const float *wp_per_cloud, float *y, int B, int cin, int cout, int L,
+                      pcr_stream_t stream);
+
+/* GroupNorm over channel groups of every token of x (B,C,L) (nn.GroupNorm on (M,C) rows in the reference's
+ * LinearRes, with M = B*L tokens), optional residual add, optional ReLU: y = [relu](GN(x) [+ res]). */
+int pcr_groupnorm_f32(const float *x, const float *gamma, const float *beta, const float *res, float *y, int B,
+                      int C, int L, int groups, int relu, pcr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,35 +104,102 @@ __global__ __launch_bounds__(kThreads) void pool_both_kernel(const float *__rest
 }
 
 // ------------------------------------------------------------------- generic dense ----
+// y (B,cout,L) = act(scale * (W x) + shift) for x (B,cin,L); the whole cin extent of a token tile
+// sits in LDS, each workgroup produces one chunk of up to 256 output channels (grid.z) and stores
+// it straight from the accumulators.  w_bstride != 0: per-cloud weights (PointNet's learned 3x3 /
+// 64x64 transforms, i.e. torch.bmm), packed image of cloud b at wp + b * w_bstride.
 struct DenseArgs {
   const float *x, *wp, *scale, *shift;
   float *y;
-  int cin, cout, L, act, TB, RP;
+  int cin, cout, L, act;
+  long w_bstride;
 };
 
+template <int TB>
 __global__ __launch_bounds__(kThreads) void dense_kernel(DenseArgs a) {
+  constexpr int T = 32 * TB, RP = T + 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int RP = a.RP, T = 32 * a.TB;
   const int cinP = ceil8(a.cin), coutP = ceil32(a.cout);
   float *X = smem;
-  float *Y = smem + cinP * RP;
   const size_t b = blockIdx.y;
   const int t0 = blockIdx.x * T;
+  const int chunk0 = blockIdx.z * 256;
+  const int chunkP = coutP - chunk0 < 256 ? coutP - chunk0 : 256;
   load_tile(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
   __syncthreads();
   const float *sc = a.scale, *sh = a.shift;
-  const int cout = a.cout, act = a.act;
-  tile_dense(X, cinP, RP, a.TB, a.wp, coutP, [&](float v, int o, int t) {
-    if (o < cout) {
-      float r = v * (sc ? sc[o] : 1.0f) + (sh ? sh[o] : 0.0f);
-      Y[o * RP + t] = act ? fmaxf(r, 0.f) : r;
+  const int cout = a.cout, act = a.act, L = a.L;
+  float *out = a.y + b * a.cout * a.L;
+  // packed image rows [chunk0, chunk0+chunkP) of every k-block: offset chunk0*8 floats, stride coutP
+  const float *wp = a.wp + b * a.w_bstride + (size_t)chunk0 * 8;
+  tile_dense_strided<TB, 2>(X, cinP, wp, chunkP, coutP, [&](float v, int o, int t) {
+    const int oc = chunk0 + o;
+    if (oc < cout && t0 + t < L) {
+      float r = v * (sc ? sc[oc] : 1.0f) + (sh ? sh[oc] : 0.0f);
+      out[(size_t)oc * L + t0 + t] = act ? fmaxf(r, 0.f) : r;
     }
   });
-  __syncthreads();
-  float *out = a.y + b * a.cout * a.L;
-  for (int e = threadIdx.x; e < a.cout * T; e += kThreads) {
-    const int c = e / T, t = e - c * T;
-    if (t0 + t < a.L) out[(size_t)c * a.L + t0 + t] = Y[c * RP + t];
+}
+
+// (B,C,L) -> out[c * B + b] = max over L   (channel-major with the clouds as tokens: (1,C,B))
+__global__ __launch_bounds__(kThreads) void max_over_l_kernel(const float *__restrict__ x,
+                                                              float *__restrict__ out, int B, int C, int L) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t row = (size_t)blockIdx.x * (kThreads / 64) + wave;  // (b, c) row
+  if (row >= (size_t)B * C) return;
+  const float *p = x + row * L;
+  float m = -INFINITY;
+  for (int i = lane; i < L; i += 64) m = fmaxf(m, p[i]);
+  m = wave_max(m);
+  if (lane == 0) out[(row % C) * B + row / C] = m;
+}
+
+// GroupNorm over channel groups of every token of x (B,C,L), optional residual add and ReLU:
+//   y = [relu]( GN(x) [+ res] ).  One thread per (group, token); two passes over C/groups channels.
+struct GnArgs {
+  const float *x, *gamma, *beta, *res;
+  float *y;
+  int C, L, groups, relu;
+};
+
+__global__ __launch_bounds__(kThreads) void groupnorm_kernel(GnArgs a) {
+  const size_t b = blockIdx.z;
+  const int g = blockIdx.y;
+  const int t = blockIdx.x * kThreads + threadIdx.x;
+  if (t >= a.L) return;
+  const int gs = a.C / a.groups;
+  const size_t base = (b * a.C + (size_t)g * gs) * a.L + t;
+  float mean = 0.f;
+  for (int i = 0; i < gs; i++) mean += a.x[base + (size_t)i * a.L];
+  mean /= (float)gs;
+  float var = 0.f;
+  for (int i = 0; i < gs; i++) {
+    const float d = a.x[base + (size_t)i * a.L] - mean;
+    var += d * d;
+  }
+  var /= (float)gs;
+  const float inv = 1.0f / sqrtf(var + 1e-5f);
+  for (int i = 0; i < gs; i++) {
+    const int c = g * gs + i;
+    float v = (a.x[base + (size_t)i * a.L] - mean) * inv * a.gamma[c] + a.beta[c];
+    if (a.res) v += a.res[base + (size_t)i * a.L];
+    a.y[base + (size_t)i * a.L] = a.relu ? fmaxf(v, 0.f) : v;
+  }
+}
+
+// t (1, k*k, B) (entry [c*k + c2][b] = T_b[c][c2], the fc3 output of an STN) -> per-cloud PACKED
+// weight images of W_b[c2][c] = T_b[c][c2], so that dense(x_b, W_b) = (x_b^T T_b)^T = torch.bmm.
+__global__ void pack_bmm_kernel(const float *__restrict__ t, float *__restrict__ wp, int B, int k) {
+  const int CP = ceil8(k), OP = ceil32(k);
+  const size_t per = (size_t)CP * OP;
+  const size_t total = per * B;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = e / per;
+    const int r = (int)(e - b * per);
+    const int j = r & 3, h = (r >> 2) & 1, o = (r >> 3) % OP, kb = (r >> 3) / OP;
+    const int c = kb * 8 + j * 2 + h;  // input channel (contraction index)
+    wp[e] = (o < k && c < k) ? t[((size_t)c * k + o) * B + b] : 0.f;
   }
 }
 
@@ -180,18 +247,66 @@ PCR_EXPORT int pcr_pool_both_f32(const float *x, float *out, int B, int C, int L
   return PCR_OK;
 }
 
-PCR_EXPORT int pcr_dense_f32(const float *x, const float *wp, const float *scale, const float *shift,
-                             float *y, int B, int cin, int cout, int L, int act, pcr_stream_t stream) {
+static int dense_launch(const float *x, const float *wp, long w_bstride, const float *scale, const float *shift,
+                        float *y, int B, int cin, int cout, int L, int act, pcr_stream_t stream) {
   if (!x || !wp || !y || B < 0 || cin < 1 || cout < 1 || L < 1) return PCR_ERR_INVALID;
   if (B == 0) return PCR_OK;
   if (B > 65535) return PCR_ERR_INVALID;
-  DenseArgs a{x, wp, scale, shift, y, cin, cout, L, act, 1, 33};
-  size_t lds = ((size_t)(ceil8(cin) + cout) * a.RP) * sizeof(float);
+  DenseArgs a{x, wp, scale, shift, y, cin, cout, L, act, w_bstride};
+  const int cinP = ceil8(cin);
+  const int tb = ((size_t)cinP * 65 * 4 <= 72 * 1024 && L > 32) ? 2 : 1;
+  size_t lds = (size_t)cinP * (32 * tb + 1) * sizeof(float);
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
-  static bool ok = allow_big_lds(dense_kernel);
+  static bool ok = allow_big_lds(dense_kernel<1>) && allow_big_lds(dense_kernel<2>);
   (void)ok;
-  hipLaunchKernelGGL(dense_kernel, dim3((L + 31) / 32, B), dim3(kThreads), lds, pcr_s(stream), a);
+  dim3 g((L + 32 * tb - 1) / (32 * tb), B, (ceil32(cout) + 255) / 256);
+  if (tb == 2) hipLaunchKernelGGL(dense_kernel<2>, g, dim3(kThreads), lds, pcr_s(stream), a);
+  else hipLaunchKernelGGL(dense_kernel<1>, g, dim3(kThreads), lds, pcr_s(stream), a);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }
 
+PCR_EXPORT int pcr_dense_f32(const float *x, const float *wp, const float *scale, const float *shift,
+                             float *y, int B, int cin, int cout, int L, int act, pcr_stream_t stream) {
+  return dense_launch(x, wp, 0, scale, shift, y, B, cin, cout, L, act, stream);
+}
+
+PCR_EXPORT int pcr_dense_bmm_f32(const float *x, const float *wp_per_cloud, float *y, int B, int cin, int cout,
+                                 int L, pcr_stream_t stream) {
+  return dense_launch(x, wp_per_cloud, (long)ceil8(cin) * ceil32(cout), nullptr, nullptr, y, B, cin, cout, L, 0,
+                      stream);
+}
+
+PCR_EXPORT int pcr_pack_bmm_f32(const float *t, float *wp_per_cloud, int B, int k, pcr_stream_t stream) {
+  if (!t || !wp_per_cloud || B < 0 || k < 1) return PCR_ERR_INVALID;
+  if (B == 0) return PCR_OK;
+  size_t total = (size_t)ceil8(k) * ceil32(k) * B;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(pack_bmm_kernel, dim3((unsigned)blocks), dim3(256), 0, pcr_s(stream), t, wp_per_cloud, B, k);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_max_over_l_f32(const float *x, float *out, int B, int C, int L, pcr_stream_t stream) {
+  if (!x || !out || B < 0 || C < 1 || L < 1) return PCR_ERR_INVALID;
+  if (B == 0) return PCR_OK;
+  size_t rows = (size_t)B * C;
+  hipLaunchKernelGGL(max_over_l_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(kThreads), 0, pcr_s(stream), x, out,
+                     B, C, L);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_groupnorm_f32(const float *x, const float *gamma, const float *beta, const float *res, float *y,
+                                 int B, int C, int L, int groups, int relu, pcr_stream_t stream) {
+  if (!x || !gamma || !beta || !y || B < 0 || C < 1 || L < 1 || groups < 1 || C % groups || groups > 65535)
+    return PCR_ERR_INVALID;
+  if (B == 0) return PCR_OK;
+  if (B > 65535) return PCR_ERR_INVALID;
+  GnArgs a{x, gamma, beta, res, y, C, L, groups, relu};
+  hipLaunchKernelGGL(groupnorm_kernel, dim3((L + kThreads - 1) / kThreads, groups, B), dim3(kThreads), 0,
+                     pcr_s(stream), a);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}

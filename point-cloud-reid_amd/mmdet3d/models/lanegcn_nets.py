@@ -9,9 +9,9 @@ import torch.nn as nn
 class LinearRes(nn.Module):
     """relu(GN(W2 relu(GN(W1 x))) + shortcut(x)); shortcut = Linear+GN when n_in != n_out.
 
-    Parameter names match the reference (linear1, linear2, norm1, norm2, transform.{0,1}).  The
-    arithmetic runs in the fused HIP head kernel when the module sits in ReIDNet.match_head
-    (pcr_pool_head_f32); the module itself only owns parameters."""
+    Parameter names match the reference (linear1, linear2, norm1, norm2, transform.{0,1}).  Inside
+    ReIDNet.match_head the arithmetic runs in the fused head kernel (pcr_pool_head_f32); called on its
+    own (or from the PointNet `downsample` stack) it runs as dense + GroupNorm launches (pcr_amd/rows.py)."""
 
     def __init__(self, n_in, n_out, norm="GN", ng=32, activation="ReLU"):
         super().__init__()

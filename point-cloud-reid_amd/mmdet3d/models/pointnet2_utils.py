@@ -22,13 +22,13 @@ class _Planned(nn.Module):
     """caches the packed weight image of a module; rebuilt when a parameter changes or moves"""
 
     def _plan(self, device, build):
+        if self.training:
+            raise L.PcrError(
+                "%s: the fused HIP path implements eval-mode inference (BatchNorm folded from running "
+                "statistics); call .eval() -- training kernels are listed as next work in DESIGN.md"
+                % type(self).__name__)
         key = (str(device), engine.param_version(self))
         if getattr(self, "_plan_key", None) != key:
-            if self.training:
-                raise L.PcrError(
-                    "%s: the fused HIP path implements eval-mode inference (BatchNorm folded from running "
-                    "statistics); call .eval() -- training kernels are listed as next work in DESIGN.md"
-                    % type(self).__name__)
             object.__setattr__(self, "_plan_obj", build(device))
             object.__setattr__(self, "_plan_key", key)
         return self._plan_obj
@@ -119,9 +119,9 @@ class FP_SA(_Planned):
     def _plan(self, device, build):
         key = (str(device), engine.param_version(self),
                None if self._final is None else engine.param_version(self._final))
+        if self.training:
+            raise L.PcrError("FP_SA: the fused HIP path implements eval-mode inference; call .eval()")
         if getattr(self, "_plan_key", None) != key:
-            if self.training:
-                raise L.PcrError("FP_SA: the fused HIP path implements eval-mode inference; call .eval()")
             object.__setattr__(self, "_plan_obj", build(device))
             object.__setattr__(self, "_plan_key", key)
         return self._plan_obj

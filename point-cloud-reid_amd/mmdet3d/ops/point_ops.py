@@ -13,6 +13,7 @@ import torch
 from torch.autograd import Function
 
 from pcr_amd import _lib as L
+from pcr_amd.engine import _prof
 
 
 def _i32(*shape, device):
@@ -31,8 +32,9 @@ class FurthestPointSampling(Function):
         B, N = points_xyz.size()[:2]
         out = _i32(B, num_points, device=points_xyz.device)
         temp = torch.full((B, N), 1e10, dtype=torch.float32, device=points_xyz.device)
-        L.check(L.load().pcr_fps_f32(L.ptr(points_xyz), L.ptr(temp), L.ptr(out), B, N, num_points,
-                                     L.stream_ptr()), "pcr_fps_f32")
+        with _prof("fps[N=%d,M=%d]" % (N, num_points), 8.0 * B * N * num_points, 4.0 * B * (3 * N + num_points)):
+            L.check(L.load().pcr_fps_f32(L.ptr(points_xyz), L.ptr(temp), L.ptr(out), B, N, num_points,
+                                         L.stream_ptr()), "pcr_fps_f32")
         ctx.mark_non_differentiable(out)
         return out
 
@@ -69,9 +71,11 @@ class BallQuery(Function):
         B, N, _ = xyz.size()
         npoint = center_xyz.size(1)
         idx = _i32(B, npoint, sample_num, device=xyz.device)
-        L.check(L.load().pcr_ball_query_f32(L.ptr(center_xyz), L.ptr(xyz), L.ptr(idx), B, N, npoint,
-                                            ctypes.c_float(min_radius), ctypes.c_float(max_radius),
-                                            sample_num, L.stream_ptr()), "pcr_ball_query_f32")
+        with _prof("ball_query[N=%d,M=%d,K=%d]" % (N, npoint, sample_num), 8.0 * B * N * npoint,
+                   4.0 * B * (3 * N + 3 * npoint + npoint * sample_num)):
+            L.check(L.load().pcr_ball_query_f32(L.ptr(center_xyz), L.ptr(xyz), L.ptr(idx), B, N, npoint,
+                                                ctypes.c_float(min_radius), ctypes.c_float(max_radius),
+                                                sample_num, L.stream_ptr()), "pcr_ball_query_f32")
         ctx.mark_non_differentiable(idx)
         return idx
 

@@ -214,10 +214,10 @@ class BasePointSAModule(nn.Module):
 
     def _plan(self, i, device):
         mlp = self.mlps[i]
+        if self.training:
+            raise L.PcrError("PointSAModule: the fused HIP path implements eval-mode inference; call .eval()")
         key = (str(device), engine.param_version(mlp))
         if self._plans.get(i, (None,))[0] != key:
-            if self.training:
-                raise L.PcrError("PointSAModule: the fused HIP path implements eval-mode inference; call .eval()")
             layers = list(mlp.children())
             if len(layers) != 3 or self.pool_mod != "max" or self.normalize_xyz or not self.use_xyz:
                 raise L.PcrError("fused SA launch covers 3-layer MLPs with use_xyz, max pooling and un-normalised "
@@ -285,10 +285,10 @@ class PointFPModule(nn.Module):
         self._plan = None
 
     def _packed(self, device):
+        if self.training:
+            raise L.PcrError("PointFPModule: the HIP path implements eval-mode inference; call .eval()")
         key = (str(device), engine.param_version(self.mlps))
         if self._plan_key != key:
-            if self.training:
-                raise L.PcrError("PointFPModule: the HIP path implements eval-mode inference; call .eval()")
             plan = []
             for layer in self.mlps.children():
                 scale, shift = engine.fold_bn(layer.bn, layer.conv.bias, device)

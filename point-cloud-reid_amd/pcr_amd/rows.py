@@ -12,3 +12,75 @@ def pool_both(x):
     out = torch.empty((B, 2 * C), dtype=torch.float32, device=x.device)
     L.check(L.load().pcr_pool_both_f32(L.ptr(x), L.ptr(out), B, C, Ln, L.stream_ptr()), "pcr_pool_both_f32")
     return out
+
+
+# ---- LinearRes on channel-major token tensors --------------------------------------------------
+from . import engine as _E
+
+
+def groupnorm(x, gn, res=None, relu=False):
+    """x (B,C,L): GroupNorm over channel groups per token [+ res] [relu]"""
+    L.require_cuda(x)
+    x = x.contiguous()
+    B, C, Ln = x.shape
+    y = torch.empty_like(x)
+    g = gn.weight.detach().to(x.device).float().contiguous()
+    b = gn.bias.detach().to(x.device).float().contiguous()
+    L.check(L.load().pcr_groupnorm_f32(L.ptr(x), L.ptr(g), L.ptr(b), L.ptr(res), L.ptr(y), B, C, Ln, gn.num_groups,
+                                       1 if relu else 0, L.stream_ptr()), "pcr_groupnorm_f32")
+    return y
+
+
+class _LinResPlan:
+    def __init__(self, m, device):
+        self.w1 = _E.pack_weight(m.linear1.weight, device)
+        self.w2 = _E.pack_weight(m.linear2.weight, device)
+        self.wt = _E.pack_weight(m.transform[0].weight, device) if m.transform is not None else None
+        self.n_out = m.linear1.weight.shape[0]
+
+
+def _linres_plan(m, device):
+    key = (str(device), _E.param_version(m))
+    if getattr(m, "_pcr_key", None) != key:
+        object.__setattr__(m, "_pcr_plan", _LinResPlan(m, device))
+        object.__setattr__(m, "_pcr_key", key)
+    return m._pcr_plan
+
+
+def linear_res_cm(m, x):
+    """LinearRes on a channel-major tensor x (B,n_in,L) -> (B,n_out,L) (lanegcn_nets.py:228-241)"""
+    p = _linres_plan(m, x.device)
+    out = groupnorm(_E.dense(x, p.w1, p.n_out), m.norm1, relu=True)
+    out = _E.dense(out, p.w2, p.n_out)
+    if p.wt is not None:
+        short = groupnorm(_E.dense(x, p.wt, p.n_out), m.transform[1])
+    else:
+        short = x
+    return groupnorm(out, m.norm2, res=short, relu=True)
+
+
+def linear_res(m, x):
+    """module-style call on (M,n_in) rows"""
+    L.require_cuda(x)
+    return linear_res_cm(m, x.t().contiguous().unsqueeze(0)).squeeze(0).t().contiguous()
+
+
+def downsample_points(seq, h):
+    """ReIDNet.downsample ([LinearRes, LinearRes, Linear]) applied per point to h (B,C,N) -> (B,C',N)
+    (reference: ReIDNet.siamese_forward :316-324 reshapes to (B*N,C) rows; per-token GroupNorm makes the
+    channel-major evaluation identical)"""
+    from mmdet3d.models.lanegcn_nets import LinearRes
+    x = h.contiguous()
+    for m in seq:
+        if isinstance(m, LinearRes):
+            x = linear_res_cm(m, x)
+        elif isinstance(m, torch.nn.Linear):
+            key = (str(x.device), _E.param_version(m))
+            if getattr(m, "_pcr_key", None) != key:
+                object.__setattr__(m, "_pcr_w", _E.pack_weight(m.weight, x.device))
+                object.__setattr__(m, "_pcr_b", None if m.bias is None else m.bias.detach().to(x.device).float().contiguous())
+                object.__setattr__(m, "_pcr_key", key)
+            x = _E.dense(x, m._pcr_w, m.weight.shape[0], None, m._pcr_b, 0)
+        else:
+            raise L.PcrError("downsample stack may contain LinearRes and Linear only (got %s)" % type(m).__name__)
+    return x

@@ -1,0 +1,71 @@
+"""GPU parity of the PointNet ReIDNet (BASELINE config 1 shape: N=256, batch of pairs) against the golden
+vectors recorded from the imported reference, and of stand-alone LinearRes rows."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+from pcr_amd import testing as T
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+PN_MODEL = dict(
+    type="ReIDNet", hidden_size=128, pool_type="both", combine="point-cat", match_type="xcorr_eff",
+    output_sequence_size=64, use_dgcnn=True, backbone_list=[128, 64, 32],
+    backbone=dict(type="PointNet", k=40, normal_channel=False),
+    match_head=[dict(type="LinearRes", n_in=128, n_out=128, norm="GN", ng=8),
+                dict(type="Linear", in_features=128, out_features=1)],
+    cls_head=None, fp_head=None, shape_head=None,
+    downsample=[dict(type="LinearRes", n_in=1024, n_out=512, norm="GN", ng=64),
+                dict(type="LinearRes", n_in=512, n_out=128, norm="GN", ng=16),
+                dict(type="Linear", in_features=128, out_features=64)],
+    cross_stage1=dict(type="corss_attention", d_model=64, nhead=2, attention="linear"),
+    cross_stage2=dict(type="corss_attention", d_model=64, nhead=2, attention="linear"),
+    local_stage1=dict(), local_stage2=dict(),
+    losses_to_use=dict(kl=False, match=True, cls=False, shape=False, fp=False, triplet=False))
+
+
+def build():
+    import copy
+    from mmdet3d.models import build_model
+    m = build_model(copy.deepcopy(PN_MODEL))
+    man = T.load_manifest(os.path.join(GOLDEN, "pointnet_manifest.json"))
+    assert T.manifest_of(m) == man
+    sd = T.seeded_state_dict(man, 0)
+    m.load_state_dict(sd, strict=True)
+    return m.cuda().eval(), sd
+
+
+def test_pointnet_pairs_match_reference_golden():
+    g = load_golden("pointnet_n256_randn")
+    meta = g["meta"]
+    m, _ = build()
+    s1, s2 = T.synthetic_pairs(meta["pairs"], meta["n"], meta["input_seed"], meta["kind"])
+    with torch.no_grad():
+        xyz, feat = m.backbone(torch.cat([s1, s2], 0).permute(0, 2, 1).contiguous().cuda(), m.backbone_list)
+        xyz1, xyz2, h1, h2 = m.siamese_forward(s1.cuda(), s2.cuda())
+        logits = m.match_forward_inference(h1, h2, xyz1, xyz2)
+    scale = np.abs(g["enc_max"]).max()
+    assert np.abs(feat.max(dim=2)[0].cpu().numpy() - g["enc_max"]).max() < TOL * max(1.0, scale)
+    assert np.abs(feat.mean(dim=2).cpu().numpy() - g["enc_mean"]).max() < TOL
+    assert np.abs(h1.cpu().numpy() - g["h1"]).max() < TOL and np.abs(h2.cpu().numpy() - g["h2"]).max() < TOL
+    assert np.abs(logits.cpu().numpy() - g["logits"]).max() < TOL
+
+
+def test_linear_res_rows_standalone():
+    import model_oracle as MO
+    from mmdet3d.models import LinearRes
+    for n_in, n_out, ng in ((96, 64, 16), (64, 64, 8)):
+        m = LinearRes(n_in, n_out, norm="GN", ng=ng)
+        sd = T.seeded_state_dict(T.manifest_of(m), 7)
+        m.load_state_dict(sd)
+        x = torch.randn(37, n_in)
+        p = dict(sd)
+        p["__groups__"] = m.norm1.num_groups
+        with torch.no_grad():
+            want = MO.linear_res(p, x)
+        got = m.cuda().eval()(x.cuda()).cpu()
+        assert float((got - want).abs().max()) < 2e-5
