@@ -45,6 +45,8 @@ WORKLOADS = {
               "128-pt synthetic pairs, eval", "pt", 128, [128, 64, 32], 512),
     "ssg1024": ("PointNet++ SSG siamese (BASELINE config 2; SA(512,r.2,K32,[64,64,128]) -> SA(128,r.4,K64,[128,128,256]) "
                 "-> Conv1d 64; D-FPS + ball query), 1024-pt synthetic pairs, eval", "ssg", 1024, None, 512),
+    "pointnet256": ("PointNet ReIDNet (configs_reid/_base_/reidentifiers/reid_pts_pointnet_point-cat.py), 256-pt "
+                    "synthetic pairs, eval (BASELINE config 1 shape)", "pointnet", 256, None, 256),
     "pt4096": ("Point-Transformer ReIDNet, 4096-pt Waymo-shape synthetic pairs, eval", "pt", 4096,
                [4096, 2048, 1024], 256),
 }
@@ -70,13 +72,21 @@ SSG_MODEL["backbone"] = dict(type="PointNet2SSG", num_points=(512, 128), radii=(
                              sa_channels=((64, 64, 128), (128, 128, 256)), conv_out=64)
 
 
+PN_MODEL = copy.deepcopy(PT_MODEL)
+PN_MODEL.update(use_dgcnn=True, backbone=dict(type="PointNet", k=40, normal_channel=False),
+                downsample=[dict(type="LinearRes", n_in=1024, n_out=512, norm="GN", ng=64),
+                            dict(type="LinearRes", n_in=512, n_out=128, norm="GN", ng=16),
+                            dict(type="Linear", in_features=128, out_features=64)])
+
+
 def build_model(kind, backbone_list, device="cuda"):
-    """kind 'pt' (reference Point-Transformer config) or 'ssg' (BASELINE config 2 composition); seeded weights"""
+    """kind 'pt' (reference Point-Transformer config), 'pointnet' (reference PointNet config) or 'ssg'
+    (BASELINE config 2 composition); seeded weights"""
     if kind == "pt":
         return build_pt_model(backbone_list, device)
     from mmdet3d.models import build_model as _build
     from pcr_amd import testing as T
-    model = _build(copy.deepcopy(SSG_MODEL))
+    model = _build(copy.deepcopy(SSG_MODEL if kind == "ssg" else PN_MODEL))
     sd = T.seeded_state_dict(T.manifest_of(model), 0)
     model.load_state_dict(sd, strict=True)
     return model.to(device).eval(), sd
@@ -123,7 +133,8 @@ def cpu_baseline(workload, sd, budget_s=20.0):
         avail = os.cpu_count() or 1
     pairs = 8 if n >= 1024 else 32
     s1, s2 = T.synthetic_pairs(pairs, n, seed=1234, kind="box" if kind == "ssg" else "randn")
-    run = (lambda: MO.ssg_pairs(sd, s1, s2)) if kind == "ssg" else (lambda: MO.pt_pairs(sd, s1, s2, bl))
+    run = {"ssg": lambda: MO.ssg_pairs(sd, s1, s2), "pointnet": lambda: MO.pointnet_pairs(sd, s1, s2),
+           "pt": lambda: MO.pt_pairs(sd, s1, s2, bl)}[kind]
     best, best_threads, runs = None, 1, 0
     t_start = time.time()
     # torch's intra-op pool does not scale to hundreds of threads on these small per-cloud ops:

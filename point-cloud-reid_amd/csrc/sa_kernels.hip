@@ -89,6 +89,12 @@ __global__ __launch_bounds__(kThreads) void sa_mlp_kernel(SaArgs a) {
 // computed once per cloud by dense_pm_kernel (K times fewer FLOPs than per (centre,neighbour)
 // row).  The kernel gathers P rows (16-byte loads) straight into the layer-1 activation tile,
 // then runs layers 2 and 3 on the matrix core IN PLACE in one LDS buffer and reduces max over K.
+// in-register cross-lane move inside a 16-lane row (VALU DPP modifier, no LDS traffic)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
 struct Sa2Args {
   int B, N, S, K, c1, c2, c3, CPW;
   const float *xyz;
@@ -104,18 +110,21 @@ struct Sa2Args {
   float *out;
 };
 
-template <int TB, int NR, int W2, int W3>
+template <int TB, int NR, int W2, int W3, bool MAXE>
 __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
   constexpr int ROWS = 32 * TB, RP = ROWS + 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int c1 = a.c1, c2 = a.c2, c3 = a.c3, K = a.K;
-  int rowsC = c1 > c3 ? c1 : c3;
-  if (ceil8(c2) > rowsC) rowsC = ceil8(c2);
+  // MAXE (K % 16 == 0): the max over K is taken from the layer-3 accumulators (16-lane DPP groups ->
+  // gmax[c3][ROWS/16]) and the (c3 x rows) layer-3 output is never materialised in LDS
+  int rowsC = c1 > ceil8(c2) ? c1 : ceil8(c2);
+  if (!MAXE && c3 > rowsC) rowsC = c3;
   float *buf = smem;                                        // [rowsC][RP]
   float *sdx = buf + rowsC * RP;                            // [3][ROWS]
   int *sidx = reinterpret_cast<int *>(sdx + 3 * ROWS);      // [ROWS] neighbour, [ROWS] centre point
   int *scen = sidx + ROWS;
   float *sq = reinterpret_cast<float *>(scen + ROWS);     // [CPW][c1] per-centre Q rows + shift
+  float *gmax = sdx;   // [c3][2*TB] (MAXE only): reuses the staging arrays, all dead once layer 1 is built
   const int tid = threadIdx.x;
   const size_t b = blockIdx.y;
   const int c0 = blockIdx.x * a.CPW;
@@ -202,29 +211,56 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
   }
   __syncthreads();
   if (!(a.dbg & 2)) {
-  {
-    const float *sc = a.sc2, *sh = a.sh2;
-    const int lim = ceil8(c2);
-    tile_dense2<TB, NR, W2>(buf, c1, a.wp2, ceil32(c2), true, [&](float v, int o, int t) {
-      if (o < lim) buf[o * RP + t] = o < c2 ? fmaxf(v * sc[o] + sh[o], 0.f) : 0.f;
-    });
-  }
-  __syncthreads();
-  {
+    {
+      const float *sc = a.sc2, *sh = a.sh2;
+      const int lim = ceil8(c2);
+      tile_dense2<TB, NR, W2>(buf, c1, a.wp2, ceil32(c2), true, [&](float v, int o, int t) {
+        if (o < lim) buf[o * RP + t] = o < c2 ? fmaxf(v * sc[o] + sh[o], 0.f) : 0.f;
+      });
+    }
+    __syncthreads();
     const float *sc = a.sc3, *sh = a.sh3;
-    tile_dense2<TB, NR, W3>(buf, ceil8(c2), a.wp3, ceil32(c3), true, [&](float v, int o, int t) {
-      if (o < c3) buf[o * RP + t] = fmaxf(v * sc[o] + sh[o], 0.f);
-    });
-  }
+    if constexpr (MAXE) {
+      constexpr int NG = 2 * TB;
+      tile_dense2<TB, NR, W3, true>(buf, ceil8(c2), a.wp3, ceil32(c3), false,
+                                    [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int o = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          float v = o < c3 ? fmaxf(acc[r] * sc[o] + sh[o], 0.f) : 0.f;
+          v = fmaxf(v, dpp_f32<0xB1>(v));    // quad_perm [1,0,3,2]  : lane ^ 1
+          v = fmaxf(v, dpp_f32<0x4E>(v));    // quad_perm [2,3,0,1]  : lane ^ 2
+          v = fmaxf(v, dpp_f32<0x141>(v));   // row_half_mirror      : other quad of the 8-lane half
+          v = fmaxf(v, dpp_f32<0x140>(v));   // row_mirror           : other half of the 16-lane row
+          if ((l31 & 15) == 0 && o < c3) gmax[o * NG + tb * 2 + (l31 >> 4)] = v;
+        }
+      });
+    } else {
+      tile_dense2<TB, NR, W3>(buf, ceil8(c2), a.wp3, ceil32(c3), true, [&](float v, int o, int t) {
+        if (o < c3) buf[o * RP + t] = fmaxf(v * sc[o] + sh[o], 0.f);
+      });
+    }
   }
   __syncthreads();
   if (a.dbg & 4) return;
-  for (int e = tid; e < c3 * nc; e += kThreads) {
-    const int c = e / c3, o = e - c * c3;
-    const float *row = buf + o * RP + c * K;
-    float m = row[0];
-    for (int k = 1; k < K; k++) m = fmaxf(m, row[k]);
-    a.out[(b * c3 + o) * a.S + c0 + c] = m;
+  if constexpr (MAXE) {
+    constexpr int NG = 2 * TB;
+    const int gpc = K >> 4;  // 16-row groups per centre
+    for (int e = tid; e < c3 * nc; e += kThreads) {
+      const int c = e / c3, o = e - c * c3;
+      const float *g = gmax + o * NG + c * gpc;
+      float m = g[0];
+      for (int k = 1; k < gpc; k++) m = fmaxf(m, g[k]);
+      a.out[(b * c3 + o) * a.S + c0 + c] = m;
+    }
+  } else {
+    for (int e = tid; e < c3 * nc; e += kThreads) {
+      const int c = e / c3, o = e - c * c3;
+      const float *row = buf + o * RP + c * K;
+      float m = row[0];
+      for (int k = 1; k < K; k++) m = fmaxf(m, row[k]);
+      a.out[(b * c3 + o) * a.S + c0 + c] = m;
+    }
   }
 }
 
@@ -262,21 +298,27 @@ __global__ __launch_bounds__(kThreads) void dense_pm_kernel(DensePmArgs a) {
 }  // namespace
 
 template <int TB, int NR, int W2, int W3>
-static void sa2_launch_one(const Sa2Args &a, size_t lds, hipStream_t st, dim3 grid) {
-  static bool ok = allow_big_lds(sa_fused_kernel<TB, NR, W2, W3>);
-  (void)ok;
-  hipLaunchKernelGGL((sa_fused_kernel<TB, NR, W2, W3>), grid, dim3(kThreads), lds, st, a);
+static void sa2_launch_one(const Sa2Args &a, bool maxe, size_t lds, hipStream_t st, dim3 grid) {
+  if (maxe) {
+    static bool ok = allow_big_lds(sa_fused_kernel<TB, NR, W2, W3, true>);
+    (void)ok;
+    hipLaunchKernelGGL((sa_fused_kernel<TB, NR, W2, W3, true>), grid, dim3(kThreads), lds, st, a);
+  } else {
+    static bool ok = allow_big_lds(sa_fused_kernel<TB, NR, W2, W3, false>);
+    (void)ok;
+    hipLaunchKernelGGL((sa_fused_kernel<TB, NR, W2, W3, false>), grid, dim3(kThreads), lds, st, a);
+  }
 }
 
 // wsel: 1 / 2 / 4 when both MFMA layers have the same cout class (specialised bodies), else 0
 template <int TB>
-static int sa2_launch_tb(const Sa2Args &a, int nr, int wsel, size_t lds, hipStream_t st, dim3 grid) {
-  if (wsel == 4) sa2_launch_one<TB, 1, 4, 4>(a, lds, st, grid);
-  else if (wsel == 2) sa2_launch_one<TB, 1, 2, 2>(a, lds, st, grid);
-  else if (wsel == 1 && nr == 1) sa2_launch_one<TB, 1, 1, 1>(a, lds, st, grid);
-  else if (wsel == 1) sa2_launch_one<TB, 2, 1, 1>(a, lds, st, grid);
-  else if (nr == 1) sa2_launch_one<TB, 1, 0, 0>(a, lds, st, grid);
-  else sa2_launch_one<TB, 2, 0, 0>(a, lds, st, grid);
+static int sa2_launch_tb(const Sa2Args &a, int nr, int wsel, bool maxe, size_t lds, hipStream_t st, dim3 grid) {
+  if (wsel == 4) sa2_launch_one<TB, 1, 4, 4>(a, maxe, lds, st, grid);
+  else if (wsel == 2) sa2_launch_one<TB, 1, 2, 2>(a, maxe, lds, st, grid);
+  else if (wsel == 1 && nr == 1) sa2_launch_one<TB, 1, 1, 1>(a, maxe, lds, st, grid);
+  else if (wsel == 1) sa2_launch_one<TB, 2, 1, 1>(a, maxe, lds, st, grid);
+  else if (nr == 1) sa2_launch_one<TB, 1, 0, 0>(a, maxe, lds, st, grid);
+  else sa2_launch_one<TB, 2, 0, 0>(a, maxe, lds, st, grid);
   return 0;
 }
 
@@ -289,8 +331,15 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   if ((p.c1 & 7) || p.c1 > 256 || p.c2 > 256 || p.c3 > 256) return -1;
   const int pqw = p.mode == 0 ? 2 * p.c1 : p.c1;
   if (p.D && pqw > 256) return -1;
-  int rowsC = p.c1 > p.c3 ? p.c1 : p.c3;
-  if (ceil8(p.c2) > rowsC) rowsC = ceil8(p.c2);
+  const bool maxe = (p.K & 15) == 0;
+  int rowsC = p.c1 > ceil8(p.c2) ? p.c1 : ceil8(p.c2);
+  if (!maxe && p.c3 > rowsC) rowsC = p.c3;
+  auto lds_bytes = [&](int tb, int cpw) {
+    size_t stage = (size_t)5 * 32 * tb + (size_t)cpw * p.c1;
+    const size_t gm = maxe ? (size_t)p.c3 * 2 * tb : 0;
+    if (gm > stage) stage = gm;
+    return ((size_t)rowsC * (32 * tb + 1) + stage) * sizeof(float);
+  };
   const int n2 = ceil32(p.c2) >> 5, n3 = ceil32(p.c3) >> 5;
   const int nmin = n2 < n3 ? n2 : n3;
   const int ways = nmin >= 3 ? 1 : (nmin == 2 ? 2 : 4);
@@ -301,7 +350,8 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
     for (int cpw = 192 / p.K > 0 ? 192 / p.K : 1; cpw >= 1; cpw--) {
       const int tb = (cpw * p.K + 31) / 32;
       if (tb > 6) continue;
-      const size_t lds = ((size_t)rowsC * (32 * tb + 1) + 5 * 32 * tb + (size_t)cpw * p.c1) * sizeof(float);
+      if (nr == 2 && tb > (pass == 0 ? 2 : 3)) continue;   // 2 rounds x tb accumulator tiles: keep >= 2 waves/SIMD
+      const size_t lds = lds_bytes(tb, cpw);
       if (pass == 0 && (tb % ways || lds > 80 * 1024)) continue;
       if (lds > 150 * 1024) continue;
       best_cpw = cpw;
@@ -330,17 +380,17 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   a.sc1 = p.scale[0]; a.sh1 = p.shift[0]; a.sc2 = p.scale[1]; a.sh2 = p.shift[1];
   a.sc3 = p.scale[2]; a.sh3 = p.shift[2];
   a.out = p.out;
-  const size_t lds = ((size_t)rowsC * (32 * best_tb + 1) + 5 * 32 * best_tb + (size_t)best_cpw * p.c1) * sizeof(float);
+  const size_t lds = lds_bytes(best_tb, best_cpw);
   dim3 grid((p.S + best_cpw - 1) / best_cpw, p.B);
   const int w2 = n2 >= 3 ? 1 : (n2 == 2 ? 2 : 4), w3 = n3 >= 3 ? 1 : (n3 == 2 ? 2 : 4);
   const int wsel = w2 == w3 ? w2 : 0;
   switch (best_tb) {
-    case 1: sa2_launch_tb<1>(a, nr, wsel, lds, st, grid); break;
-    case 2: sa2_launch_tb<2>(a, nr, wsel, lds, st, grid); break;
-    case 3: sa2_launch_tb<3>(a, nr, wsel, lds, st, grid); break;
-    case 4: sa2_launch_tb<4>(a, nr, wsel, lds, st, grid); break;
-    case 5: sa2_launch_tb<5>(a, nr, wsel, lds, st, grid); break;
-    default: sa2_launch_tb<6>(a, nr, wsel, lds, st, grid); break;
+    case 1: sa2_launch_tb<1>(a, nr, wsel, maxe, lds, st, grid); break;
+    case 2: sa2_launch_tb<2>(a, nr, wsel, maxe, lds, st, grid); break;
+    case 3: sa2_launch_tb<3>(a, nr, wsel, maxe, lds, st, grid); break;
+    case 4: sa2_launch_tb<4>(a, nr, wsel, maxe, lds, st, grid); break;
+    case 5: sa2_launch_tb<5>(a, nr, wsel, maxe, lds, st, grid); break;
+    default: sa2_launch_tb<6>(a, nr, wsel, maxe, lds, st, grid); break;
   }
   if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
   return PCR_OK;

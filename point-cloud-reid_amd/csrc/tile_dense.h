@@ -74,7 +74,7 @@ __device__ __forceinline__ void tile_dense(const float *__restrict__ in, int CP,
 //   nCB = OP/32 >= 3 : wave w owns cout blocks w, w+4 (NR rounds), all TB token blocks
 //   nCB == 2         : wave w owns cout block w&1 and token blocks (w>>1), (w>>1)+2, ...
 //   nCB == 1         : wave w owns token blocks w, w+4, ...
-template <int TB, int NR, int WAYS, class Epi>
+template <int TB, int NR, int WAYS, bool TILE, class Epi>
 __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, int CP,
                                                 const float *__restrict__ wp, int OP, bool sync_epi,
                                                 Epi epi) {
@@ -155,9 +155,13 @@ __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, in
       for (int j = 0; j < TBW; j++) {
         const int tb = tb0 + j * WAYS;
         if (tb < TB) {
-          const int t = tb * 32 + l31;
+          if constexpr (TILE) {
+            epi(acc[nr][j], cb, tb, l31, h);   // whole 32x32 tile: lane = token l31 of block tb, 16 couts in regs
+          } else {
+            const int t = tb * 32 + l31;
 #pragma unroll
-          for (int r = 0; r < 16; r++) epi(acc[nr][j][r], cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, t);
+            for (int r = 0; r < 16; r++) epi(acc[nr][j][r], cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, t);
+          }
         }
       }
     }
@@ -167,20 +171,20 @@ __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, in
 // WSEL = 0: pick the wave/tile split from OP at run time (all three bodies are compiled in and the
 // register allocation is their maximum); WSEL = 1 / 2 / 4: the caller guarantees OP/32 >= 3 / == 2 /
 // == 1 and only that body is compiled (fewer registers => more waves per SIMD).
-template <int TB, int NR, int WSEL = 0, class Epi>
+template <int TB, int NR, int WSEL = 0, bool TILE = false, class Epi>
 __device__ __forceinline__ void tile_dense2(const float *__restrict__ in, int CP,
                                             const float *__restrict__ wp, int OP, bool sync_epi, Epi epi) {
   if constexpr (WSEL == 1) {
-    tile_dense_impl<TB, NR, 1>(in, CP, wp, OP, sync_epi, epi);
+    tile_dense_impl<TB, NR, 1, TILE>(in, CP, wp, OP, sync_epi, epi);
   } else if constexpr (WSEL == 2) {
-    tile_dense_impl<TB, 1, 2>(in, CP, wp, OP, sync_epi, epi);
+    tile_dense_impl<TB, 1, 2, TILE>(in, CP, wp, OP, sync_epi, epi);
   } else if constexpr (WSEL == 4) {
-    tile_dense_impl<TB, 1, 4>(in, CP, wp, OP, sync_epi, epi);
+    tile_dense_impl<TB, 1, 4, TILE>(in, CP, wp, OP, sync_epi, epi);
   } else {
     const int nCB = OP >> 5;
-    if (nCB >= 3) tile_dense_impl<TB, NR, 1>(in, CP, wp, OP, sync_epi, epi);
-    else if (nCB == 2) tile_dense_impl<TB, 1, 2>(in, CP, wp, OP, sync_epi, epi);
-    else tile_dense_impl<TB, 1, 4>(in, CP, wp, OP, sync_epi, epi);
+    if (nCB >= 3) tile_dense_impl<TB, NR, 1, TILE>(in, CP, wp, OP, sync_epi, epi);
+    else if (nCB == 2) tile_dense_impl<TB, 1, 2, TILE>(in, CP, wp, OP, sync_epi, epi);
+    else tile_dense_impl<TB, 1, 4, TILE>(in, CP, wp, OP, sync_epi, epi);
   }
 }
 

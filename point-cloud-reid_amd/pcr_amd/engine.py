@@ -288,6 +288,7 @@ def dense(x, wp, cout, scale=None, shift=None, act=0):
     assert x.is_contiguous() and x.dtype == torch.float32
     B, cin, Ln = x.shape
     y = torch.empty((B, cout, Ln), dtype=torch.float32, device=x.device)
-    L.check(L.load().pcr_dense_f32(L.ptr(x), L.ptr(wp), L.ptr(scale), L.ptr(shift), L.ptr(y), B, cin, cout,
-                                   Ln, act, L.stream_ptr()), "pcr_dense_f32")
+    with _prof("dense[cin=%d,cout=%d,L=%d]" % (cin, cout, Ln), 2.0 * B * Ln * cin * cout, 4.0 * B * Ln * (cin + cout)):
+        L.check(L.load().pcr_dense_f32(L.ptr(x), L.ptr(wp), L.ptr(scale), L.ptr(shift), L.ptr(y), B, cin, cout,
+                                       Ln, act, L.stream_ptr()), "pcr_dense_f32")
     return y
