@@ -344,20 +344,34 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   const int nmin = n2 < n3 ? n2 : n3;
   const int ways = nmin >= 3 ? 1 : (nmin == 2 ? 2 : 4);
   const int nr = (n2 > 4 || n3 > 4) ? 2 : 1;
+  // Tile choice.  Measured on MI355X: time per row ~ padding x wave imbalance x
+  // (1 + 2.5 / resident workgroups per CU); residency is bounded by LDS (160 KiB, 2 KiB granules),
+  // by registers (accumulator tiles + ~70 VGPRs against 512 per SIMD lane) and by 8 workgroups.
   int best_cpw = 0, best_tb = 0;
-  for (int pass = 0; pass < 2 && !best_cpw; pass++) {
-    // pass 0: token-block count divisible among the waves and >= 2 workgroups per CU; pass 1: anything that fits
-    for (int cpw = 192 / p.K > 0 ? 192 / p.K : 1; cpw >= 1; cpw--) {
-      const int tb = (cpw * p.K + 31) / 32;
-      if (tb > 6) continue;
-      if (nr == 2 && tb > (pass == 0 ? 2 : 3)) continue;   // 2 rounds x tb accumulator tiles: keep >= 2 waves/SIMD
-      const size_t lds = lds_bytes(tb, cpw);
-      if (pass == 0 && (tb % ways || lds > 80 * 1024)) continue;
-      if (lds > 150 * 1024) continue;
-      best_cpw = cpw;
-      best_tb = tb;
-      break;
-    }
+  double best_cost = 1e30;
+  const int cpw_max = 192 / p.K > 0 ? 192 / p.K : 1;
+  for (int cpw = 1; cpw <= cpw_max; cpw++) {
+    const int tb = (cpw * p.K + 31) / 32;
+    if (tb > 6) continue;
+    const size_t lds = lds_bytes(tb, cpw);
+    if (lds > 150 * 1024) continue;
+    const int tbw = (tb + ways - 1) / ways;
+    const int regs = nr * tbw * 16 + 70;
+    if (regs > 250) continue;
+    int wgs = (int)((160 * 1024) / ((lds + 2047) / 2048 * 2048));
+    const int by_regs = 512 / ((regs + 7) / 8 * 8);
+    if (by_regs < wgs) wgs = by_regs;
+    if (wgs > 8) wgs = 8;
+    if (wgs < 1) continue;
+    const double pad = (double)(32 * tb) / (double)(cpw * p.K);
+    const double imb = (double)(tbw * ways) / (double)tb;
+    const double cost = pad * imb * (1.0 + 2.5 / wgs);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best_cpw = cpw; best_tb = tb; }
+  }
+  static const int force_cpw = getenv("PCR_SA_CPW") ? atoi(getenv("PCR_SA_CPW")) : 0;   // tuning aid
+  if (force_cpw > 0) {
+    const int tb = (force_cpw * p.K + 31) / 32;
+    if (tb <= 6 && lds_bytes(tb, force_cpw) <= 150 * 1024) { best_cpw = force_cpw; best_tb = tb; }
   }
   if (!best_cpw) return -1;
   if (p.D && !p.pq_ready) {
