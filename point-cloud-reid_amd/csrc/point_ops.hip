@@ -121,6 +121,98 @@ __global__ void fps_kernel(const float *__restrict__ data, float *__restrict__ t
   }
 }
 
+// Fast D-FPS for N <= 4096: 256 threads per cloud, PPT points per thread in registers, the cloud SoA
+// in LDS for the broadcast read of the last pick, one barrier per step.  Same result as fps_kernel:
+// the reference's outcome is the maximum of the total order (distance, merge-tree preference of
+// k mod block, smaller k); each point carries that order in a packed 64-bit key, reduced with
+// in-register DPP moves inside 16-lane rows, v_readlane across rows and a 4-entry LDS slot across
+// waves.  (Only for coordinates: there d2 >= 0 > -1, so the reference's "best = -1" start never
+// matters; the distance-matrix variant keeps the literal per-thread scan of fps_kernel.)
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+
+template <int PPT>
+__global__ __launch_bounds__(256) void fps_fast_kernel(const float *__restrict__ xyz, float *__restrict__ temp,
+                                                       int *__restrict__ idxs, int n, int m, int block,
+                                                       int logb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned long long *skey = reinterpret_cast<unsigned long long *>(smem_raw);  // [2][4]
+  float *sx = reinterpret_cast<float *>(smem_raw + 64);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t cloud = blockIdx.x;
+  xyz += cloud * n * 3;
+  temp += cloud * n;
+  idxs += cloud * m;
+  for (int i = tid; i < 3 * n; i += 256) sx[i] = xyz[i];
+  __syncthreads();
+  float px[PPT], py[PPT], pz[PPT], t[PPT];
+  uint32_t low[PPT];
+#pragma unroll
+  for (int p = 0; p < PPT; p++) {
+    const int k = tid + 256 * p;
+    const bool ok = k < n;
+    px[p] = ok ? sx[3 * k] : 0.f;
+    py[p] = ok ? sx[3 * k + 1] : 0.f;
+    pz[p] = ok ? sx[3 * k + 2] : 0.f;
+    t[p] = ok ? temp[k] : 0.f;
+    const uint32_t tr = (uint32_t)k & (uint32_t)(block - 1);
+    const uint32_t rev = logb ? (__brev(tr) >> (32 - logb)) : 0u;
+    low[p] = ok ? ((((uint32_t)(block - 1) - rev) << 22) | (0x3FFFFFu - (uint32_t)k)) : 0u;
+  }
+  int old = 0;
+  if (tid == 0) idxs[0] = 0;
+  for (int j = 1; j < m; j++) {
+    const float x1 = sx[3 * old], y1 = sx[3 * old + 1], z1 = sx[3 * old + 2];
+    uint32_t hi = 0u, lo = 0u;
+#pragma unroll
+    for (int p = 0; p < PPT; p++) {
+      const float d = pcr_sqdist3(x1, y1, z1, px[p], py[p], pz[p]);
+      const float d2 = fminf(d, t[p]);
+      t[p] = d2;
+      const uint32_t h2 = low[p] ? pcr_orderable(d2 + 0.0f) : 0u;   // points beyond n never win
+      const bool take = h2 > hi || (h2 == hi && low[p] > lo);
+      hi = take ? h2 : hi;
+      lo = take ? low[p] : lo;
+    }
+#define PCR_FPS_STEP(CTRL)                                         \
+    {                                                              \
+      const uint32_t oh = dpp_u32<CTRL>(hi), ol = dpp_u32<CTRL>(lo); \
+      const bool take = oh > hi || (oh == hi && ol > lo);          \
+      hi = take ? oh : hi;                                         \
+      lo = take ? ol : lo;                                         \
+    }
+    PCR_FPS_STEP(0xB1)   // lane ^ 1
+    PCR_FPS_STEP(0x4E)   // lane ^ 2
+    PCR_FPS_STEP(0x141)  // row_half_mirror
+    PCR_FPS_STEP(0x140)  // row_mirror: every lane of a 16-lane row now holds the row maximum
+#undef PCR_FPS_STEP
+    unsigned long long key = 0ull;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const unsigned long long kr = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)hi, 16 * r) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readlane((int)lo, 16 * r);
+      key = kr > key ? kr : key;
+    }
+    unsigned long long *slot = skey + (j & 1) * 4;
+    if (lane == 0) slot[wave] = key;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const unsigned long long kw = slot[w];
+      key = kw > key ? kw : key;
+    }
+    old = (int)(0x3FFFFFu - (uint32_t)(key & 0x3FFFFFull));
+    if (tid == 0) idxs[j] = old;
+  }
+#pragma unroll
+  for (int p = 0; p < PPT; p++) {
+    const int k = tid + 256 * p;
+    if (k < n) temp[k] = t[p];
+  }
+}
+
 int fps_launch(bool dist, const float *data, float *temp, int *idx, int B, int N, int M,
                hipStream_t st) {
   if (!data || !temp || !idx || B < 0 || N < 1 || N >= (1 << 22) || M < 0) return PCR_ERR_INVALID;
@@ -128,6 +220,19 @@ int fps_launch(bool dist, const float *data, float *temp, int *idx, int B, int N
   int logb = 0;
   while ((2 << logb) <= N && logb < 10) logb++;  // block = min(1024, 2^floor(log2 N))
   int block = 1 << logb;
+  if (!dist && N <= 4096 && M > 1) {
+    const size_t lds_fast = 64 + (size_t)3 * N * sizeof(float);
+    dim3 gf(B), bf(256);
+#define PCR_FPS_FAST(P) hipLaunchKernelGGL((fps_fast_kernel<P>), gf, bf, lds_fast, st, data, temp, idx, N, M, block, logb)
+    if (N <= 256) PCR_FPS_FAST(1);
+    else if (N <= 512) PCR_FPS_FAST(2);
+    else if (N <= 1024) PCR_FPS_FAST(4);
+    else if (N <= 2048) PCR_FPS_FAST(8);
+    else PCR_FPS_FAST(16);
+#undef PCR_FPS_FAST
+    PCR_CHECK_LAUNCH();
+    return PCR_OK;
+  }
   int threads = block < 64 ? 64 : block;
   bool reg = N <= kFpsPpt * block;
   int stage = (!dist && N <= kFpsLdsPts) ? 1 : 0;
