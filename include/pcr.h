@@ -139,8 +139,12 @@ typedef struct pcr_sa_params {
    * matrix [Wf ; Wc - Wf] ((2*c1, D), edge) or Wf ((c1, D), query-and-group); pq_ws is a caller
    * workspace of B*N*(2*c1 or c1) floats.  Leave wa NULL to force the generic kernel (wp[0]).
    * wa and wpq must be PRE-SCALED by scale[0] (row o times scale[0][o]); the fast path then
-   * evaluates layer 1 as relu(wa dxyz + P[i] + Q[c] + shift[0]) and never reads scale[0]. */
+   * evaluates layer 1 as relu(wa dxyz + P[i] + Q[c] + shift[0]) and never reads scale[0].
+   * Likewise wps[0], wps[1] are the packed images of diag(scale[1]) W2 and diag(scale[2]) W3, and
+   * shift_pad[0], shift_pad[1] are shift[1], shift[2] zero-padded to a multiple of 32 floats: the
+   * fast path seeds the MFMA accumulators with the shift and its epilogue is a bare ReLU. */
   const float *wa, *wpq;
+  const float *wps[2], *shift_pad[2];
   float *pq_ws;
   int pq_ready; /* nonzero: pq_ws already holds the tables (caller ran pcr_dense_pm_f32 itself) */
   float *out;
@@ -186,7 +190,7 @@ typedef struct pcr_attn_params {
   const float *wmerge;            /* (d,d) row-major */
   const float *wmlp0, *wmlp2;     /* packed (2d, c1+d), packed (cout, 2d) */
   const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
-  const float *wfinal, *bfinal; int cfinal;       /* optional trailing conv: packed (cfinal,cout), (cfinal) */
+  const float *wfinal, *bfinal; int cfinal;       /* optional trailing conv: packed (cfinal,cout); bias zero-padded to a multiple of 32 */
   float *kv;    /* workspace (B, pcr_attn_kv_floats(d)) */
   float *out;   /* (B, cfinal ? cfinal : cout, Lq) */
 } pcr_attn_params;

@@ -71,9 +71,9 @@ __global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
     pos_hidden(XH + c2 * RP, RP, P, p.pos0_w, p.pos0_b, d, T);
     __syncthreads();
     tile_dense2<TB, NR>(XH, c2 + d, p.wkv, 2 * d, false, [&](float v, int o, int t) {
-      if (o < d) KB[o * RP + t] = t < valid ? elu1(v + bkv[o]) : 0.f;
-      else VB[(o - d) * RP + t] = t < valid ? (v + bkv[o]) / sk : 0.f;
-    });
+      if (o < d) KB[o * RP + t] = t < valid ? elu1(v) : 0.f;
+      else VB[(o - d) * RP + t] = t < valid ? v / sk : 0.f;
+    }, bkv);   // biases seed the accumulators
     __syncthreads();
     if (tid < d) {
       const float *row = KB + tid * RP;
@@ -165,9 +165,8 @@ __global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
   }
   __syncthreads();
   {  // Q = elu(Wq' [x ; h] + bq) + 1
-    const float *bq = p.bq;
     tile_dense2<TB, NR>(CAT, p.q_pos ? catP : ceil8(c1), p.wq, d, false,
-                       [&](float v, int o, int t) { W[o * RP + t] = elu1(v + bq[o]); });
+                       [&](float v, int o, int t) { W[o * RP + t] = elu1(v); }, p.bq);
   }
   __syncthreads();
   for (int e = tid; e < p.nhead * T; e += kThreads) {
@@ -201,11 +200,10 @@ __global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
   }
   int cres = cout;
   if (p.cfinal) {  // trailing 1x1 conv with bias (cov_final); needs cout % 8 == 0
-    const float *bf = p.bfinal;
     const int cf = p.cfinal;
     tile_dense2<TB, NR>(W, cout, p.wfinal, ceil32(cf), true, [&](float v, int o, int t) {
-      if (o < cf) W[o * RP + t] = v + bf[o];
-    });
+      if (o < cf) W[o * RP + t] = v;
+    }, p.bfinal);   // bfinal is zero-padded to a multiple of 32 by the host
     __syncthreads();
     cres = cf;
   }

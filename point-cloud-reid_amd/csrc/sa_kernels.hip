@@ -106,7 +106,7 @@ struct Sa2Args {
   int skew_div;
   int skew;                 // start-up stagger of the first generation of workgroups, in s_sleep(127) units
   const float *wp2, *wp3;
-  const float *sc1, *sh1, *sc2, *sh2, *sc3, *sh3;
+  const float *sh1, *sh2, *sh3;   // folded BatchNorm shifts (sh2/sh3 zero-padded to a multiple of 32)
   float *out;
 };
 
@@ -210,16 +210,17 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
   }
   }
   __syncthreads();
+  for (int rep = 0; rep < ((a.dbg & 8) ? 4 : 1); rep++) {   // dbg bit 8: 4x the matrix work (diagnostic)
+  if (rep) __syncthreads();
   if (!(a.dbg & 2)) {
     {
-      const float *sc = a.sc2, *sh = a.sh2;
+      // BatchNorm scale is folded into wp2/wp3 by the host, the shift seeds the accumulators
       const int lim = ceil8(c2);
       tile_dense2<TB, NR, W2>(buf, c1, a.wp2, ceil32(c2), true, [&](float v, int o, int t) {
-        if (o < lim) buf[o * RP + t] = o < c2 ? fmaxf(v * sc[o] + sh[o], 0.f) : 0.f;
-      });
+        if (o < lim) buf[o * RP + t] = fmaxf(v, 0.f);     // rows [c2, lim) see zero weights and zero init
+      }, a.sh2);
     }
     __syncthreads();
-    const float *sc = a.sc3, *sh = a.sh3;
     if constexpr (MAXE) {
       constexpr int NG = 2 * TB;
       tile_dense2<TB, NR, W3, true>(buf, ceil8(c2), a.wp3, ceil32(c3), false,
@@ -227,19 +228,20 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int o = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          float v = o < c3 ? fmaxf(acc[r] * sc[o] + sh[o], 0.f) : 0.f;
+          float v = fmaxf(acc[r], 0.f);
           v = fmaxf(v, dpp_f32<0xB1>(v));    // quad_perm [1,0,3,2]  : lane ^ 1
           v = fmaxf(v, dpp_f32<0x4E>(v));    // quad_perm [2,3,0,1]  : lane ^ 2
           v = fmaxf(v, dpp_f32<0x141>(v));   // row_half_mirror      : other quad of the 8-lane half
           v = fmaxf(v, dpp_f32<0x140>(v));   // row_mirror           : other half of the 16-lane row
           if ((l31 & 15) == 0 && o < c3) gmax[o * NG + tb * 2 + (l31 >> 4)] = v;
         }
-      });
+      }, a.sh3);
     } else {
       tile_dense2<TB, NR, W3>(buf, ceil8(c2), a.wp3, ceil32(c3), true, [&](float v, int o, int t) {
-        if (o < c3) buf[o * RP + t] = fmaxf(v * sc[o] + sh[o], 0.f);
-      });
+        if (o < c3) buf[o * RP + t] = fmaxf(v, 0.f);
+      }, a.sh3);
     }
+  }
   }
   __syncthreads();
   if (a.dbg & 4) return;
@@ -327,7 +329,8 @@ extern "C" int pcr_dense_pm_f32(const float *, const float *, float *, int, int,
 // fast path; returns -1 when the configuration is not covered (caller falls back to sa_mlp_kernel)
 static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   hipStream_t st = pcr_s(st_);
-  if (!p.wa || (p.D && (!p.wpq || !p.pq_ws))) return -1;
+  if (!p.wa || !p.wps[0] || !p.wps[1] || !p.shift_pad[0] || !p.shift_pad[1] || (p.D && (!p.wpq || !p.pq_ws)))
+    return -1;
   if ((p.c1 & 7) || p.c1 > 256 || p.c2 > 256 || p.c3 > 256) return -1;
   const int pqw = p.mode == 0 ? 2 * p.c1 : p.c1;
   if (p.D && pqw > 256) return -1;
@@ -390,9 +393,8 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   a.skew = skew;
   static const int skew_div = getenv("PCR_SA_SKEW_DIV") ? atoi(getenv("PCR_SA_SKEW_DIV")) : 256;
   a.skew_div = skew_div > 0 ? skew_div : 256;
-  a.wp2 = p.wp[1]; a.wp3 = p.wp[2];
-  a.sc1 = p.scale[0]; a.sh1 = p.shift[0]; a.sc2 = p.scale[1]; a.sh2 = p.shift[1];
-  a.sc3 = p.scale[2]; a.sh3 = p.shift[2];
+  a.wp2 = p.wps[0]; a.wp3 = p.wps[1];
+  a.sh1 = p.shift[0]; a.sh2 = p.shift_pad[0]; a.sh3 = p.shift_pad[1];
   a.out = p.out;
   const size_t lds = lds_bytes(best_tb, best_cpw);
   dim3 grid((p.S + best_cpw - 1) / best_cpw, p.B);

@@ -77,7 +77,7 @@ __device__ __forceinline__ void tile_dense(const float *__restrict__ in, int CP,
 template <int TB, int NR, int WAYS, bool TILE, class Epi>
 __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, int CP,
                                                 const float *__restrict__ wp, int OP, bool sync_epi,
-                                                Epi epi) {
+                                                Epi epi, const float *__restrict__ init = nullptr) {
   constexpr int RP = 32 * TB + 1;
   constexpr int TBW = (TB + WAYS - 1) / WAYS;  // token blocks per wave
   const int lane = threadIdx.x & 63;
@@ -89,13 +89,21 @@ __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, in
   // The k-loop is branch-free: a tile the wave does not own (cb >= nCB or tb >= TB, which only
   // happens for shapes that do not divide evenly) is computed on clamped addresses and dropped in
   // the epilogue, so the accumulators stay pinned in AGPRs.
+  // `init` (OP floats, zero-padded) seeds the accumulators with the per-cout bias / folded BatchNorm
+  // shift, so the epilogue needs no per-element constant loads (they used to cost two global loads per
+  // output value right where the wave has nothing else to do).
   f32x16 acc[NR][TBW];
 #pragma unroll
-  for (int nr = 0; nr < NR; nr++)
+  for (int nr = 0; nr < NR; nr++) {
+    int cbi = cb0 + 4 * nr;
+    cbi = cbi < nCB ? cbi : nCB - 1;
 #pragma unroll
-    for (int j = 0; j < TBW; j++)
+    for (int r = 0; r < 16; r++) {
+      const float v0 = init ? init[cbi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[nr][j][r] = 0.f;
+      for (int j = 0; j < TBW; j++) acc[nr][j][r] = v0;
+    }
+  }
   const size_t wstride = (size_t)OP * 2;
   const f32x4 *wrow[NR];
 #pragma unroll
@@ -173,18 +181,19 @@ __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, in
 // == 1 and only that body is compiled (fewer registers => more waves per SIMD).
 template <int TB, int NR, int WSEL = 0, bool TILE = false, class Epi>
 __device__ __forceinline__ void tile_dense2(const float *__restrict__ in, int CP,
-                                            const float *__restrict__ wp, int OP, bool sync_epi, Epi epi) {
+                                            const float *__restrict__ wp, int OP, bool sync_epi, Epi epi,
+                                            const float *__restrict__ init = nullptr) {
   if constexpr (WSEL == 1) {
-    tile_dense_impl<TB, NR, 1, TILE>(in, CP, wp, OP, sync_epi, epi);
+    tile_dense_impl<TB, NR, 1, TILE>(in, CP, wp, OP, sync_epi, epi, init);
   } else if constexpr (WSEL == 2) {
-    tile_dense_impl<TB, 1, 2, TILE>(in, CP, wp, OP, sync_epi, epi);
+    tile_dense_impl<TB, 1, 2, TILE>(in, CP, wp, OP, sync_epi, epi, init);
   } else if constexpr (WSEL == 4) {
-    tile_dense_impl<TB, 1, 4, TILE>(in, CP, wp, OP, sync_epi, epi);
+    tile_dense_impl<TB, 1, 4, TILE>(in, CP, wp, OP, sync_epi, epi, init);
   } else {
     const int nCB = OP >> 5;
-    if (nCB >= 3) tile_dense_impl<TB, NR, 1, TILE>(in, CP, wp, OP, sync_epi, epi);
-    else if (nCB == 2) tile_dense_impl<TB, 1, 2, TILE>(in, CP, wp, OP, sync_epi, epi);
-    else tile_dense_impl<TB, 1, 4, TILE>(in, CP, wp, OP, sync_epi, epi);
+    if (nCB >= 3) tile_dense_impl<TB, NR, 1, TILE>(in, CP, wp, OP, sync_epi, epi, init);
+    else if (nCB == 2) tile_dense_impl<TB, 1, 2, TILE>(in, CP, wp, OP, sync_epi, epi, init);
+    else tile_dense_impl<TB, 1, 4, TILE>(in, CP, wp, OP, sync_epi, epi, init);
   }
 }
 

@@ -19,8 +19,11 @@ PROFILE = None
 
 
 class _prof:
-    def __init__(self, name, flops=0.0, nbytes=0.0):
+    def __init__(self, name, flops=0.0, nbytes=0.0, exec_flops=None):
+        # flops: the reference's op count for this piece of work (what "achieved" is quoted against);
+        # exec_flops: what the launch really issues on the matrix core, where the two differ
         self.name, self.flops, self.nbytes = name, flops, nbytes
+        self.exec_flops = flops if exec_flops is None else exec_flops
 
     def __enter__(self):
         if PROFILE is not None:
@@ -32,7 +35,7 @@ class _prof:
     def __exit__(self, *exc):
         if PROFILE is not None:
             self.e1.record()
-            PROFILE.append((self.name, self.e0, self.e1, self.flops, self.nbytes))
+            PROFILE.append((self.name, self.e0, self.e1, self.flops, self.nbytes, self.exec_flops))
         return False
 
 
@@ -42,7 +45,8 @@ class SaParams(ctypes.Structure):
                 ("c1", ctypes.c_int), ("c2", ctypes.c_int), ("c3", ctypes.c_int),
                 ("xyz", c_float_p), ("feat", c_float_p), ("idx", c_int_p), ("centre_idx", c_int_p),
                 ("wp", c_float_p * 3), ("scale", c_float_p * 3), ("shift", c_float_p * 3),
-                ("wa", c_float_p), ("wpq", c_float_p), ("pq_ws", c_float_p), ("pq_ready", ctypes.c_int),
+                ("wa", c_float_p), ("wpq", c_float_p), ("wps", c_float_p * 2), ("shift_pad", c_float_p * 2),
+                ("pq_ws", c_float_p), ("pq_ready", ctypes.c_int),
                 ("out", c_float_p)]
 
 
@@ -134,6 +138,15 @@ class SaPlan:
         self.wa = _dev32((w1[:, :3] * sc1).float(), device)
         self.wpq = None
         self.fast = fast
+        # layers 2, 3 with the BatchNorm scale folded into the weights and the shift padded to 32
+        self.wps, self.shift_pad = [], []
+        for l in (1, 2):
+            w = convs[l].weight.detach().reshape(self.couts[l], -1).double().cpu()
+            sc = self.scale[l].detach().double().cpu().unsqueeze(1)
+            self.wps.append(pack_weight((w * sc).float(), device))
+            pad = torch.zeros((self.couts[l] + 31) // 32 * 32, dtype=torch.float32, device=device)
+            pad[:self.couts[l]] = self.shift[l]
+            self.shift_pad.append(pad)
         if D > 0:
             if mode == 0:
                 wc, wf = w1[:, 3:3 + D], w1[:, 3 + D:3 + 2 * D]
@@ -160,6 +173,8 @@ class SaPlan:
         p.out = _p(out)
         if self.fast:
             p.wa = _p(self.wa)
+            for i in range(2):
+                p.wps[i], p.shift_pad[i] = _p(self.wps[i]), _p(self.shift_pad[i])
             if D:
                 pqw = (2 if self.mode == 0 else 1) * self.couts[0]
                 ws = torch.empty((B, N, pqw), dtype=torch.float32, device=xyz.device)
@@ -173,7 +188,8 @@ class SaPlan:
         c1, c2, c3 = self.couts
         flops = 2.0 * B * S * K * (self.cin * c1 + c1 * c2 + c2 * c3)
         nbytes = 4.0 * B * (3 * N + D * N + S * K + c3 * S)
-        with _prof("sa_fused[D=%d,c=%d/%d/%d,N=%d,S=%d,K=%d]" % (D, c1, c2, c3, N, S, K), flops, nbytes):
+        exec_flops = 2.0 * B * S * K * (c1 * c2 + c2 * c3) if self.fast else flops
+        with _prof("sa_fused[D=%d,c=%d/%d/%d,N=%d,S=%d,K=%d]" % (D, c1, c2, c3, N, S, K), flops, nbytes, exec_flops):
             L.check(L.load().pcr_sa_mlp_f32(ctypes.byref(p), L.stream_ptr()), "pcr_sa_mlp_f32")
         return out
 
@@ -213,8 +229,10 @@ class AttnPlan:
         self.cfinal = 0
         if final is not None:
             self.t["wfinal"] = pack_weight(final.weight, device)
-            self.t["bfinal"] = _dev32(final.bias, device)
             self.cfinal = final.weight.shape[0]
+            bpad = torch.zeros((self.cfinal + 31) // 32 * 32, dtype=torch.float32, device=device)
+            bpad[:self.cfinal] = final.bias.detach().to(device).float()
+            self.t["bfinal"] = bpad
 
     def run(self, feat_q, xyz_q, feat_k, xyz_k, kv_index=None):
         """feat_q (B,c1,Lq), feat_k (B,c2,Sk), xyz (B,L,3) -> (B, cfinal or cout, Lq)"""
