@@ -46,9 +46,12 @@ __global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
   float *KB = XH + (c2 + d) * RP;
   float *VB = KB + d * RP;
   float *P = VB + d * RP;
+  float *s_w0 = P + 3 * RP, *s_b0 = s_w0 + 3 * d;   // staged pos-MLP first layer
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const size_t b = blockIdx.x;
+  for (int e = tid; e < 3 * d; e += kThreads) s_w0[e] = p.pos0_w[e];
+  for (int e = tid; e < d; e += kThreads) s_b0[e] = p.pos0_b[e];
   const float *feat = p.feat_k + b * c2 * p.Sk;
   const float *xyz = p.xyz_k + b * p.Sk * 3;
   const int nb = d >> 5, nT = nb * nb;
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
     load_tile(XH, RP, feat, c2, c2, p.Sk, t0, T);
     load_xyz3(P, RP, xyz, p.Sk, t0, T);
     __syncthreads();
-    pos_hidden(XH + c2 * RP, RP, P, p.pos0_w, p.pos0_b, d, T);
+    pos_hidden(XH + c2 * RP, RP, P, s_w0, s_b0, d, T);
     __syncthreads();
     tile_dense2<TB, NR>(XH, c2 + d, p.wkv, 2 * d, false, [&](float v, int o, int t) {
       if (o < d) KB[o * RP + t] = t < valid ? elu1(v) : 0.f;
@@ -145,20 +148,40 @@ __global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
   float *P = W + rowsW * RP;
   float *zs = P + 3 * RP;
   float *red = zs + p.nhead * RP;  // [2 * (256/T)][T]
+  // small constant vectors, staged once: reading them from global inside the per-element loops costs a
+  // vector-memory instruction per use
+  float *cst = red + 2 * (kThreads / T) * T;
+  float *s_ksum = cst, *s_ln1g = cst + d, *s_ln1b = cst + 2 * d, *s_ln2g = cst + 3 * d, *s_ln2b = s_ln2g + cout;
+  float *s_w0 = s_ln2b + cout, *s_b0 = s_w0 + 3 * d;
   const int tid = threadIdx.x;
   const size_t b = blockIdx.y;
   const int t0 = blockIdx.x * T;
   const float *feat = p.feat_q + b * c1 * p.Lq;
   const size_t kb_ = p.kv_index ? (size_t)p.kv_index[b] : b;
   const float *kv = p.kv + kb_ * ((size_t)d * d + d);
-  const float *ksum = kv + (size_t)d * d;
   const int dh = d / p.nhead;
+  for (int e = tid; e < d; e += kThreads) {
+    s_ksum[e] = kv[(size_t)d * d + e];
+    s_ln1g[e] = p.ln1_g[e];
+    s_ln1b[e] = p.ln1_b[e];
+    if (p.q_pos) {
+      s_w0[3 * e] = p.pos0_w[3 * e];
+      s_w0[3 * e + 1] = p.pos0_w[3 * e + 1];
+      s_w0[3 * e + 2] = p.pos0_w[3 * e + 2];
+      s_b0[e] = p.pos0_b[e];
+    }
+  }
+  for (int e = tid; e < cout; e += kThreads) {
+    s_ln2g[e] = p.ln2_g[e];
+    s_ln2b[e] = p.ln2_b[e];
+  }
+  const float *ksum = s_ksum;
 
   load_tile(CAT, RP, feat, c1, c1, p.Lq, t0, T);
   if (p.q_pos) {
     load_xyz3(P, RP, p.xyz_q + b * p.Lq * 3, p.Lq, t0, T);
     __syncthreads();
-    pos_hidden(CAT + c1 * RP, RP, P, p.pos0_w, p.pos0_b, d, T);
+    pos_hidden(CAT + c1 * RP, RP, P, s_w0, s_b0, d, T);
     for (int e = tid; e < (catP - catC) * T; e += kThreads) CAT[(catC + e / T) * RP + e % T] = 0.f;
   } else {
     for (int e = tid; e < (catP - c1) * T; e += kThreads) CAT[(c1 + e / T) * RP + e % T] = 0.f;
@@ -183,14 +206,14 @@ __global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
   __syncthreads();
   tile_dense2<TB, NR>(W, d, kv, d, false, [&](float v, int o, int t) { CAT[(c1 + o) * RP + t] = v; });
   __syncthreads();
-  tile_layernorm(CAT + c1 * RP, d, RP, T, p.ln1_g, p.ln1_b, red);
+  tile_layernorm(CAT + c1 * RP, d, RP, T, s_ln1g, s_ln1b, red);
   tile_dense2<TB, NR>(CAT, catP, p.wmlp0, 2 * d, false, [&](float v, int o, int t) { W[o * RP + t] = fmaxf(v, 0.f); });
   __syncthreads();
   tile_dense2<TB, NR>(W, 2 * d, p.wmlp2, ceil32(cout), true, [&](float v, int o, int t) {
     if (o < cout) W[o * RP + t] = v;
   });
   __syncthreads();
-  tile_layernorm(W, cout, RP, T, p.ln2_g, p.ln2_b, red);
+  tile_layernorm(W, cout, RP, T, s_ln2g, s_ln2b, red);
   if (p.residual) {
     for (int e = tid; e < cout * T; e += kThreads) {
       const int c = e / T, t = e - c * T;
@@ -236,7 +259,7 @@ PCR_EXPORT int pcr_attn_kv_f32(const pcr_attn_params *pp, pcr_stream_t stream) {
   a.p = *pp;
   const int d = pp->d;
   const int tb = d <= 32 ? 2 : 1, RP = 32 * tb + 1;
-  size_t lds = ((size_t)(pp->c2 + 3 * d + 3) * RP) * sizeof(float);
+  size_t lds = ((size_t)(pp->c2 + 3 * d + 3) * RP + 4 * d) * sizeof(float);
   const size_t lds2 = (size_t)d * (d + 1) * sizeof(float);
   if (lds2 > lds) lds = lds2;
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
@@ -265,7 +288,8 @@ PCR_EXPORT int pcr_attn_apply_f32(const pcr_attn_params *pp, pcr_stream_t stream
   int rowsW = 2 * p.d;
   if (p.cout > rowsW) rowsW = p.cout;
   if (p.cfinal > rowsW) rowsW = p.cfinal;
-  size_t lds = ((size_t)(catP + rowsW + 3 + p.nhead) * RP + 2 * (kThreads / T) * T) * sizeof(float);
+  size_t lds = ((size_t)(catP + rowsW + 3 + p.nhead) * RP + 2 * (kThreads / T) * T + 7 * p.d + 2 * p.cout) *
+               sizeof(float);
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
   static bool ok = allow_big_lds(attn_apply_kernel<1, 2>) && allow_big_lds(attn_apply_kernel<2, 1>) &&
                    allow_big_lds(attn_apply_kernel<2, 2>) && allow_big_lds(attn_apply_kernel<4, 1>) &&
