@@ -183,7 +183,9 @@ typedef struct pcr_attn_params {
   int q_pos, residual;
   const float *feat_q, *xyz_q; /* (B,c1,Lq), (B,Lq,3) (xyz_q only read when q_pos) */
   const float *feat_k, *xyz_k; /* (B,c2,Sk), (B,Sk,3) */
-  const int *kv_index;         /* (B) or NULL */
+  const int *kv_index;         /* (B) or NULL: apply: cloud b reads the kv image of cloud kv_index[b] */
+  const int *q_index;          /* (B) or NULL: apply: cloud b takes its query tokens from cloud q_index[b]
+                                  (gallery matching: B = number of (query, template) combinations) */
   const float *pos0_w, *pos0_b;   /* (d,3) row-major, (d) */
   const float *wq, *bq;           /* packed fused query projection, (d) */
   const float *wkv, *bkv;         /* packed fused key/value projection, (2d) */

@@ -156,7 +156,8 @@ __global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
   const int tid = threadIdx.x;
   const size_t b = blockIdx.y;
   const int t0 = blockIdx.x * T;
-  const float *feat = p.feat_q + b * c1 * p.Lq;
+  const size_t bq_ = p.q_index ? (size_t)p.q_index[b] : b;    // which cloud supplies the query tokens
+  const float *feat = p.feat_q + bq_ * c1 * p.Lq;
   const size_t kb_ = p.kv_index ? (size_t)p.kv_index[b] : b;
   const float *kv = p.kv + kb_ * ((size_t)d * d + d);
   const int dh = d / p.nhead;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
 
   load_tile(CAT, RP, feat, c1, c1, p.Lq, t0, T);
   if (p.q_pos) {
-    load_xyz3(P, RP, p.xyz_q + b * p.Lq * 3, p.Lq, t0, T);
+    load_xyz3(P, RP, p.xyz_q + bq_ * p.Lq * 3, p.Lq, t0, T);
     __syncthreads();
     pos_hidden(CAT + c1 * RP, RP, P, s_w0, s_b0, d, T);
     for (int e = tid; e < (catP - catC) * T; e += kThreads) CAT[(catC + e / T) * RP + e % T] = 0.f;

@@ -240,6 +240,29 @@ class ReIDNet(nn.Module):
     def match_forward_inference(self, h1, h2, xyz1, xyz2):
         return self._match_logits(h1, h2, xyz1, xyz2)[0]
 
+    def match_gallery(self, h, xyz, pairs):
+        """Amortised matching (the reference's tracker use-case of forward_inference +
+        match_forward_inference, ReIDNet.py:189-191, 444-462): every object is encoded ONCE, then any list
+        of (i, j) combinations is scored.  h (M,C,N), xyz (M,N,3) from forward_inference / siamese_forward;
+        pairs (P,2) integer tensor -> logits (P), identical to match_forward_inference(h[i], h[j], ...).
+        Stage-1 key/value state is computed once per object and shared by all its pairs."""
+        if self.match_type != "xcorr_eff" or self.combine != "point-cat" or self.pool_type != "both":
+            raise NotImplementedError("match_gallery covers the xcorr_eff / point-cat / both matching head")
+        h, xyz = h.contiguous(), xyz.contiguous()
+        n_pairs, n_pts = pairs.shape[0], h.shape[2]
+        i = pairs[:, 0].to(device=h.device, dtype=torch.int32)
+        j = pairs[:, 1].to(device=h.device, dtype=torch.int32)
+        q_idx = torch.cat([i, j]).contiguous()            # virtual cloud b < P: object i queries object j ...
+        k_idx = torch.cat([j, i]).contiguous()            # ... and b >= P: object j queries object i
+        p1 = self.cross_stage1.plan(h.device)
+        s1 = p1.apply(h, None, p1.kv(h, xyz), n_pts, kv_index=k_idx, q_index=q_idx, n_out=2 * n_pairs)
+        xyz_v = xyz.index_select(0, q_idx.long()).contiguous()
+        partner = torch.cat([torch.arange(n_pairs, 2 * n_pairs), torch.arange(0, n_pairs)]).to(
+            device=h.device, dtype=torch.int32)
+        p2 = self.cross_stage2.plan(h.device)
+        o = p2.apply(s1, None, p2.kv(s1, xyz_v), n_pts, kv_index=partner)
+        return self._head(o.device).run(o)
+
     def get_match_supervision(self, h1, h2, xyz1, xyz2, id_1, id_2):
         return h1, h2, xyz1, xyz2, (id_1 == id_2).float()
 

@@ -55,7 +55,7 @@ class AttnParams(ctypes.Structure):
                 ("c1", ctypes.c_int), ("c2", ctypes.c_int), ("d", ctypes.c_int), ("cout", ctypes.c_int),
                 ("nhead", ctypes.c_int), ("q_pos", ctypes.c_int), ("residual", ctypes.c_int),
                 ("feat_q", c_float_p), ("xyz_q", c_float_p), ("feat_k", c_float_p), ("xyz_k", c_float_p),
-                ("kv_index", c_int_p),
+                ("kv_index", c_int_p), ("q_index", c_int_p),
                 ("pos0_w", c_float_p), ("pos0_b", c_float_p),
                 ("wq", c_float_p), ("bq", c_float_p), ("wkv", c_float_p), ("bkv", c_float_p),
                 ("wmerge", c_float_p), ("wmlp0", c_float_p), ("wmlp2", c_float_p),
@@ -234,37 +234,58 @@ class AttnPlan:
             bpad[:self.cfinal] = final.bias.detach().to(device).float()
             self.t["bfinal"] = bpad
 
-    def run(self, feat_q, xyz_q, feat_k, xyz_k, kv_index=None):
-        """feat_q (B,c1,Lq), feat_k (B,c2,Sk), xyz (B,L,3) -> (B, cfinal or cout, Lq)"""
-        L.require_cuda(feat_q, feat_k, xyz_k)
-        for t in (feat_q, xyz_q, feat_k, xyz_k):
-            assert t is None or (t.is_contiguous() and t.dtype == torch.float32)
-        B, c1, Lq = feat_q.shape
-        _, c2, Sk = feat_k.shape
-        assert c1 == self.c1 and c2 == self.c2 and feat_k.shape[0] == B
-        lib = L.load()
-        kv = torch.empty((B, lib.pcr_attn_kv_floats(self.d)), dtype=torch.float32, device=feat_q.device)
-        out = torch.empty((B, self.cfinal or self.cout, Lq), dtype=torch.float32, device=feat_q.device)
+    def _params(self, B, Lq, Sk, feat_q, xyz_q, feat_k, xyz_k, kv, out, kv_index=None, q_index=None):
         p = AttnParams()
         p.B, p.Lq, p.Sk = B, Lq, Sk
-        p.c1, p.c2, p.d, p.cout, p.nhead = c1, c2, self.d, self.cout, self.nhead
+        p.c1, p.c2, p.d, p.cout, p.nhead = self.c1, self.c2, self.d, self.cout, self.nhead
         p.q_pos, p.residual = self.q_pos, self.residual
         p.feat_q, p.xyz_q, p.feat_k, p.xyz_k = _p(feat_q), _p(xyz_q), _p(feat_k), _p(xyz_k)
-        p.kv_index = _p(kv_index)
+        p.kv_index, p.q_index = _p(kv_index), _p(q_index)
         for k, v in self.t.items():
             setattr(p, k, _p(v))
         p.cfinal = self.cfinal
         p.kv, p.out = _p(kv), _p(out)
-        st = L.stream_ptr()
+        return p
+
+    def kv(self, feat_k, xyz_k):
+        """key-side state of every cloud: (B, d*d + d) per-cloud images (reusable across many queries)"""
+        L.require_cuda(feat_k, xyz_k)
+        assert feat_k.is_contiguous() and xyz_k.is_contiguous() and feat_k.dtype == torch.float32
+        B, c2, Sk = feat_k.shape
+        assert c2 == self.c2
+        lib = L.load()
+        kv = torch.empty((B, lib.pcr_attn_kv_floats(self.d)), dtype=torch.float32, device=feat_k.device)
+        p = self._params(B, 1, Sk, feat_k, xyz_k, feat_k, xyz_k, kv, kv)
         d = self.d
         kv_flops = 2.0 * B * Sk * (3 * d + d * c2 + 2 * c2 * d + d * d / self.nhead)   # reference's op count
+        with _prof("attn_kv[d=%d,c2=%d,Sk=%d]" % (d, c2, Sk), kv_flops, 4.0 * B * (c2 * Sk + 3 * Sk + d * d + d)):
+            L.check(lib.pcr_attn_kv_f32(ctypes.byref(p), L.stream_ptr()), "pcr_attn_kv_f32")
+        return kv
+
+    def apply(self, feat_q, xyz_q, kv, Sk, kv_index=None, q_index=None, n_out=None):
+        """query side: n_out virtual clouds (default: one per query cloud); virtual cloud b takes its tokens
+        from cloud q_index[b] (default b) and the key-side state kv[kv_index[b]] (default b)"""
+        L.require_cuda(feat_q, kv)
+        assert feat_q.is_contiguous() and feat_q.dtype == torch.float32 and (xyz_q is None or xyz_q.is_contiguous())
+        Bq, c1, Lq = feat_q.shape
+        assert c1 == self.c1
+        B = n_out if n_out is not None else Bq
+        out = torch.empty((B, self.cfinal or self.cout, Lq), dtype=torch.float32, device=feat_q.device)
+        p = self._params(B, Lq, Sk, feat_q, xyz_q, feat_q, xyz_q if xyz_q is not None else feat_q, kv, out,
+                         kv_index, q_index)
+        d = self.d
         ap_flops = 2.0 * B * Lq * (c1 * d + d * d / self.nhead + d * d + (c1 + d) * 2 * d + 2 * d * self.cout
                                    + self.cout * self.cfinal + (self.q_pos * (3 * d + d * c1)))
-        with _prof("attn_kv[d=%d,c2=%d,Sk=%d]" % (d, c2, Sk), kv_flops, 4.0 * B * (c2 * Sk + 3 * Sk + d * d + d)):
-            L.check(lib.pcr_attn_kv_f32(ctypes.byref(p), st), "pcr_attn_kv_f32")
-        with _prof("attn_apply[d=%d,c1=%d,out=%d,Lq=%d]" % (d, c1, self.cfinal or self.cout, Lq), ap_flops, 4.0 * B * (c1 * Lq + d * d + d + (self.cfinal or self.cout) * Lq)):
-            L.check(lib.pcr_attn_apply_f32(ctypes.byref(p), st), "pcr_attn_apply_f32")
+        with _prof("attn_apply[d=%d,c1=%d,out=%d,Lq=%d]" % (d, c1, self.cfinal or self.cout, Lq), ap_flops,
+                   4.0 * B * (c1 * Lq + d * d + d + (self.cfinal or self.cout) * Lq)):
+            L.check(L.load().pcr_attn_apply_f32(ctypes.byref(p), L.stream_ptr()), "pcr_attn_apply_f32")
         return out
+
+    def run(self, feat_q, xyz_q, feat_k, xyz_k, kv_index=None):
+        """feat_q (B,c1,Lq), feat_k (B,c2,Sk), xyz (B,L,3) -> (B, cfinal or cout, Lq)"""
+        assert feat_k.shape[0] == feat_q.shape[0]
+        kv = self.kv(feat_k, xyz_k)
+        return self.apply(feat_q, xyz_q, kv, feat_k.shape[2], kv_index=kv_index)
 
 
 class HeadPlan:

@@ -216,3 +216,20 @@ def test_sa_fast_and_generic_paths_agree_with_torch(mode, D, K, S, N, widths):
                        None if cidx is None else cidx.cuda())
         outs[fast] = out.cpu().numpy()
         assert np.abs(outs[fast] - want).max() < 2e-5, (fast, np.abs(outs[fast] - want).max())
+
+
+def test_match_gallery_equals_pairwise_matching():
+    """encode once, score arbitrary (i, j) combinations"""
+    import model_oracle as MO
+    m, sd = build_pt([128, 64, 32])
+    clouds = T.synthetic_clouds(6, 128, seed=11, kind="box")
+    pairs = torch.tensor([[0, 1], [1, 0], [2, 5], [3, 3], [4, 0], [5, 2], [0, 4]])
+    with torch.no_grad():
+        xyz, h = m.forward_inference(clouds.cuda())
+        got = m.match_gallery(h, xyz, pairs).cpu()
+        direct = m.match_forward_inference(h[pairs[:, 0]].contiguous(), h[pairs[:, 1]].contiguous(),
+                                           xyz[pairs[:, 0]].contiguous(), xyz[pairs[:, 1]].contiguous()).cpu()
+        _, href = MO.pt_backbone(MO._sub(sd, "backbone."), clouds, [128, 64, 32])
+        want = MO.match(sd, href[pairs[:, 0]], clouds[pairs[:, 0]], href[pairs[:, 1]], clouds[pairs[:, 1]])
+    assert float((got - direct).abs().max()) < 1e-5
+    assert float((got - want).abs().max()) < TOL
