@@ -185,19 +185,26 @@ def gen_python_twins():
 
 
 def gen_eval_metric():
+    """val_match_acc (reidentification_base.py:104) and the reference's own MatchingEval.f1_precision_recall
+    (datasets/utils.py:254-277) on a seeded (logits, gt) sample"""
     g = np.random.default_rng(5)
     logits = g.standard_normal(64).astype(np.float32)
     gt = (g.uniform(size=64) > 0.5).astype(np.float32)
-    pred = (1.0 / (1.0 + np.exp(-logits)) > 0.5).astype(np.float32)
-    # reidentification_base.py:104  val_match_acc = mean((sigmoid(logit) > 0.5) == gt)
-    acc = torch.tensor((torch.sigmoid(torch.from_numpy(logits)) > 0.5).float().eq(torch.from_numpy(gt)).float().mean())
-    assert abs(float(acc) - float((pred == gt).mean())) < 1e-7
-    np.savez_compressed(os.path.join(GOLD, "eval_metric.npz"), logits=logits, gt=gt, val_match_acc=np.float32(acc))
+    tl, tg = torch.from_numpy(logits), torch.from_numpy(gt)
+    acc = (torch.sigmoid(tl) > 0.5).float().eq(tg).float().mean()
+    me = ref_loader.load_dataset_utils().MatchingEval()
+    f1 = me.f1_precision_recall((torch.sigmoid(tl) > 0.5).float(), tg)
+    np.savez_compressed(os.path.join(GOLD, "eval_metric.npz"), logits=logits, gt=gt, val_match_acc=np.float32(acc),
+                        **{k: np.float32(v) for k, v in f1.items()})
+    print("eval metric", float(acc), f1)
 
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
+    if "--only-metric" in sys.argv:
+        gen_eval_metric()
+        sys.exit(0)
     if "--only-small" not in sys.argv:
         gen_pt()
         gen_pointnet()

@@ -157,3 +157,31 @@ def build_ref_reidnet(relpath="configs_reid/_base_/reidentifiers/reid_pts_point-
     with contextlib.redirect_stdout(io.StringIO()):
         model = ref.ReIDNet.ReIDNet(**cfg)
     return model
+
+
+def load_dataset_utils():
+    """mmdet3d/datasets/utils.py of the reference (MatchingEval, subsamplePC, ...) with inert stand-ins for
+    its absent third-party imports (mmcv, torch_cluster); only the pure-torch metric code is exercised."""
+    full = _PKG + ".datasets_utils"
+    if full in sys.modules:
+        return sys.modules[full]
+
+    def mk(name, **attrs):
+        if name in sys.modules:
+            return sys.modules[name]
+        m = types.ModuleType(name)
+        m.__path__ = []
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    mk("mmcv", Config=object)
+    mk("mmcv.runner", get_dist_info=lambda: (0, 1))
+    mk("torch_cluster", fps=None, knn=None)
+    path = os.path.join(REF_ROOT, "mmdet3d", "datasets", "utils.py")
+    spec = importlib.util.spec_from_file_location(full, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[full] = mod
+    spec.loader.exec_module(mod)
+    return mod

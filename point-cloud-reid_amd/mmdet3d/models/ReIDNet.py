@@ -229,13 +229,36 @@ class ReIDNet(nn.Module):
             return rows.pool_both(h_cat)
         raise NotImplementedError("pool_type=%r: only 'both' is used by the point-cat ReID configs" % self.pool_type)
 
+    def _fused_matching(self):
+        return self.match_type == "xcorr_eff" and self.combine == "point-cat" and self.pool_type == "both"
+
+    def _head_rows(self, pooled):
+        """match_head ([LinearRes..., Linear]) on pooled rows (B,F) through the row kernels (pcr_amd/rows.py)"""
+        from pcr_amd import rows
+        x = pooled.t().contiguous().unsqueeze(0)                 # (1,F,B): channel-major, samples as tokens
+        return rows.downsample_points(self.match_head, x).reshape(-1)
+
+    def xcorr_baseline(self, search_feat, search_xyz, template_feat, template_xyz):
+        a = self.cross_stage1(search_feat, search_xyz, template_feat, template_xyz)
+        return self.cross_stage2(a, search_xyz, template_feat, template_xyz)
+
     def _match_logits(self, h1, h2, xyz1, xyz2):
-        if self.match_type != "xcorr_eff" or self.combine != "point-cat" or self.pool_type != "both":
-            raise NotImplementedError("fused matching covers match_type='xcorr_eff', combine='point-cat', "
-                                      "pool_type='both' (all point ReID configs); got %s/%s/%s"
-                                      % (self.match_type, self.combine, self.pool_type))
-        o = self._xcorr_eff_batched(h1, xyz1, h2, xyz2)
-        return self._head(o.device).run(o), o
+        """logits (B) and the stage-2 features; fused single-launch tail for the configuration every point
+        ReID config uses, generic composition (reference ReIDNet.py:387-462) for the other variants"""
+        if self._fused_matching():
+            o = self._xcorr_eff_batched(h1, xyz1, h2, xyz2)
+            return self._head(o.device).run(o), o
+        if self.match_type == "xcorr_eff":
+            match_in, o1, o2 = self.xcorr_eff(h1, xyz1, h2, xyz2, self.combine)
+            return self._head_rows(self.get_pooled_feats(match_in)), torch.cat([o1, o2], dim=0)
+        if self.match_type == "xcorr-baseline":
+            match_in = self.xcorr_baseline(h1, xyz1, h2, xyz2)
+            return self._head_rows(self.get_pooled_feats(match_in)), None
+        if self.match_type == "concat":
+            cat = torch.cat([self.get_pooled_feats(h1), self.get_pooled_feats(h2)], dim=1)
+            return self._head_rows(cat), None
+        raise NotImplementedError("match_type=%r ('xcorr' needs local_self_attention, SURVEY.md 8f rank 3)"
+                                  % self.match_type)
 
     def match_forward_inference(self, h1, h2, xyz1, xyz2):
         return self._match_logits(h1, h2, xyz1, xyz2)[0]
@@ -272,6 +295,8 @@ class ReIDNet(nn.Module):
         b = h1.shape[0]
         match_preds, o = self._match_logits(h1, h2, xyz1, xyz2)
         match_loss = self.bce(match_preds, match) * self.alpha["match"]
+        if o is None:
+            o = [None] * (2 * b)
         if self.compute_summary and log_vars is not None:
             pred = (torch.sigmoid(match_preds) > 0.5)
             log_vars[prefix + "match_loss"] = match_loss.item()

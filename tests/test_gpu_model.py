@@ -233,3 +233,40 @@ def test_match_gallery_equals_pairwise_matching():
         want = MO.match(sd, href[pairs[:, 0]], clouds[pairs[:, 0]], href[pairs[:, 1]], clouds[pairs[:, 1]])
     assert float((got - direct).abs().max()) < 1e-5
     assert float((got - want).abs().max()) < TOL
+
+
+@pytest.mark.parametrize("match_type,combine", [("xcorr_eff", "add"), ("xcorr_eff", "minus"), ("xcorr-baseline", "cat"),
+                                                ("concat", "cat")])
+def test_match_variants_generic_path(match_type, combine):
+    """the other match_type / combine variants of ReIDNet.match_forward (ReIDNet.py:387-462) run as a
+    composition of the same launches + row kernels; checked against the torch restatement"""
+    import model_oracle as MO
+    import torch.nn.functional as F
+    from mmdet3d.models import build_model
+    cfg = copy.deepcopy(PT_MODEL)
+    cfg.update(match_type=match_type, combine=combine)
+    width = 64 * 2 if (match_type, combine) != ("concat", "cat") else 64 * 4
+    cfg["match_head"] = [dict(type="LinearRes", n_in=width, n_out=width, norm="GN", ng=8),
+                         dict(type="Linear", in_features=width, out_features=1)]
+    m = build_model(cfg)
+    sd = T.seeded_state_dict(T.manifest_of(m), 0)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    s1, s2 = T.synthetic_pairs(3, 128, seed=4, kind="box")
+    with torch.no_grad():
+        xyz1, xyz2, h1, h2 = m.siamese_forward(s1.cuda(), s2.cuda())
+        got = m.match_forward_inference(h1, h2, xyz1, xyz2).cpu()
+        xr, hr = MO.pt_backbone(MO._sub(sd, "backbone."), torch.cat([s1, s2]), [128, 64, 32])
+        a1, a2, x1, x2 = hr[:3], hr[3:], xr[:3], xr[3:]
+        c1, c2 = MO._sub(sd, "cross_stage1."), MO._sub(sd, "cross_stage2.")
+        if match_type == "xcorr_eff":
+            p1, p2 = MO.cross_attention(c1, a1, x1, a2, x2), MO.cross_attention(c1, a2, x2, a1, x1)
+            o1, o2 = MO.cross_attention(c2, p1, x1, p2, x2), MO.cross_attention(c2, p2, x2, p1, x1)
+            pooled = MO.pool_both(o1 + o2 if combine == "add" else o1 - o2)
+        elif match_type == "xcorr-baseline":
+            pooled = MO.pool_both(MO.cross_attention(c2, MO.cross_attention(c1, a1, x1, a2, x2), x1, a2, x2))
+        else:
+            pooled = torch.cat([MO.pool_both(a1), MO.pool_both(a2)], dim=1)
+        x = MO.linear_res(MO._linres_params(sd, "match_head.0.", 8), pooled)
+        want = F.linear(x, sd["match_head.1.weight"], sd["match_head.1.bias"]).squeeze(1)
+    assert float((got - want).abs().max()) < TOL

@@ -51,6 +51,15 @@ def test_pointnet_oracle_matches_reference_golden():
 
 
 def test_eval_metric_fixture():
+    """pcr_amd.metrics against values recorded from the reference's own MatchingEval / accuracy definition"""
+    from pcr_amd import metrics
     g = load_golden("eval_metric")
-    acc = ((torch.sigmoid(torch.from_numpy(g["logits"])) > 0.5).float() == torch.from_numpy(g["gt"])).float().mean()
-    assert abs(float(acc) - float(g["val_match_acc"])) < 1e-7
+    logits, gt = torch.from_numpy(g["logits"]), torch.from_numpy(g["gt"])
+    assert abs(metrics.match_accuracy(logits, gt) - float(g["val_match_acc"])) < 1e-7
+    f1 = metrics.f1_precision_recall(metrics.decisions(logits), gt)
+    for k, v in f1.items():
+        assert abs(v - float(g[k])) < 1e-6, k
+    res = [dict(val_match_preds=logits[:40], val_match_gt=gt[:40], num_points=torch.randint(1, 300, (40, 2)), skip=None),
+           dict(val_match_preds=logits[40:], val_match_gt=gt[40:], num_points=torch.randint(1, 300, (24, 2)), skip=None)]
+    out = metrics.evaluate(res)
+    assert abs(out["val_match_acc"] - float(g["val_match_acc"])) < 1e-7 and "val_match_acc_both_ge_1_pts" in out
