@@ -246,6 +246,9 @@ class ReIDNet(nn.Module):
         """logits (B) and the stage-2 features; fused single-launch tail for the configuration every point
         ReID config uses, generic composition (reference ReIDNet.py:387-462) for the other variants"""
         if self._fused_matching():
+            if self.training:
+                from pcr_amd import train_graph
+                return train_graph.match_logits(self, h1, xyz1, h2, xyz2)
             o = self._xcorr_eff_batched(h1, xyz1, h2, xyz2)
             return self._head(o.device).run(o), o
         if self.match_type == "xcorr_eff":

@@ -32,6 +32,11 @@ class Pointnet_Backbone(nn.Module):
 
     def forward(self, pointcloud, numpoints):
         """pointcloud (B,N,3+C) -> (xyz (B,N,3), features (B,conv_out,N))"""
+        if self.training:
+            # differentiable graph with BatchNorm batch statistics (pcr_amd/train_graph.py); eval mode below is
+            # the fused HIP path
+            from pcr_amd import train_graph
+            return train_graph.backbone(self, pointcloud, numpoints)
         xyz, features = self._break_up_pc(pointcloud)
         l_xyz, l_features = [xyz], [features]
         for i, sa in enumerate(self.SA_modules):

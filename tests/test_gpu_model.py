@@ -152,13 +152,43 @@ def test_forward_test_api_and_decisions():
     assert ((torch.sigmoid(r["val_match_preds"]) > 0.5).cpu().numpy() == (1 / (1 + np.exp(-g["logits"])) > 0.5)).all()
 
 
-def test_training_mode_fails_loudly():
+def test_train_step_matches_reference_loss_and_grads():
+    """ReIDNet.train_step in training mode (HIP kNN + HIP grouping fwd/bwd + torch autograd for the dense
+    math, pcr_amd/train_graph.py) against loss and gradients recorded from the reference's own train_step"""
+    g = load_golden("pt_train_step_n128")
+    m, _ = build_pt([128, 64, 32])
+    m.train()
+    s1, s2 = T.synthetic_pairs(8, 128, seed=2, kind="randn")
+    dev = "cuda"
+    ids1 = torch.arange(8)
+    ids2 = torch.tensor([0, 1, 2, 3, 9, 9, 9, 9])
+    data = dict(sparse_1=list(s1.to(dev)), sparse_2=list(s2.to(dev)), dense_1=list(s1.to(dev)), dense_2=list(s2.to(dev)),
+                label_1=[torch.zeros(1, dtype=torch.long, device=dev)] * 8,
+                label_2=[torch.zeros(1, dtype=torch.long, device=dev)] * 8,
+                id_1=[i.view(1).to(dev) for i in ids1], id_2=[i.view(1).to(dev) for i in ids2])
+    out = m.train_step(data, None)
+    assert set(out) == {"loss", "log_vars", "num_samples"} and out["num_samples"] == 8
+    assert abs(float(out["loss"]) - float(g["loss"])) < 1e-4
+    assert abs(out["log_vars"]["match_acc"] - float(g["match_acc"])) < 1e-6
+    out["loss"].backward()
+    params = dict(m.named_parameters())
+    for k in g:
+        if k.startswith("grad:"):
+            got = params[k[5:]].grad.cpu().numpy()
+            scale = max(1e-3, float(np.abs(g[k]).max()))
+            assert np.abs(got - g[k]).max() < 2e-3 * scale, (k, np.abs(got - g[k]).max(), scale)
+    no_grad = sorted(k for k, p in params.items() if p.grad is None)
+    assert no_grad == sorted(json.loads(str(g["no_grad_params"])))      # the 24 never-used FP tensors
+
+
+def test_submodules_refuse_training_mode_on_the_fused_path():
     from pcr_amd._lib import PcrError
     m, _ = build_pt([128, 64, 32])
     m.train()
-    s1, s2 = T.synthetic_pairs(1, 128, 1, "randn")
+    x = torch.randn(2, 64, 128).cuda()
+    xyz = torch.randn(2, 128, 3).cuda()
     with pytest.raises(PcrError):
-        m.siamese_forward(s1.cuda(), s2.cuda())
+        m.cross_stage1(x, xyz, x, xyz)          # stand-alone fused modules are eval-only
 
 
 @pytest.mark.parametrize("mode,D,K,S,N,widths", [(0, 0, 32, 100, 128, (32, 32, 32)), (0, 32, 48, 70, 150, (64, 64, 64)),
