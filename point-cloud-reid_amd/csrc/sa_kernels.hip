@@ -248,8 +248,10 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
   if constexpr (MAXE) {
     constexpr int NG = 2 * TB;
     const int gpc = K >> 4;  // 16-row groups per centre
+    // centre fastest across lanes: the nc outputs of one channel are adjacent in (B,c3,S), so a wave
+    // store touches 64/nc lines instead of 64 (the store is still nc*4 bytes per line: see DESIGN.md 4.1)
     for (int e = tid; e < c3 * nc; e += kThreads) {
-      const int c = e / c3, o = e - c * c3;
+      const int o = e / nc, c = e - o * nc;
       const float *g = gmax + o * NG + c * gpc;
       float m = g[0];
       for (int k = 1; k < gpc; k++) m = fmaxf(m, g[k]);
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
     }
   } else {
     for (int e = tid; e < c3 * nc; e += kThreads) {
-      const int c = e / c3, o = e - c * c3;
+      const int o = e / nc, c = e - o * nc;
       const float *row = buf + o * RP + c * K;
       float m = row[0];
       for (int k = 1; k < K; k++) m = fmaxf(m, row[k]);
