@@ -212,6 +212,18 @@ def main():
                     share_of_step=ms / step_ms_kern,
                     per_kernel_ms={k: round(v, 4) for k, v in sorted(groups.items(), key=lambda kv: -kv[1])})
         roof["frac"] = roof["achieved"] / roof["peak"]
+        # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (profiles/*_pmc.json:
+        # FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 correction 2*FETCH_SIZE + WRITE_SIZE), scaled to
+        # this batch size; null when no profile of this workload is committed
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01f_%s_pmc.json" % args.workload)) as f:
+                pmc = json.load(f)
+            kern = pmc["_launch_to_kernel"][dom]
+            roof["traffic"] = pmc[kern]["hbm_bytes_corrected"] * pairs / pmc["_pairs_per_step"]
+            roof["traffic_source"] = "profiles/r01f_%s_pmc.json (%s); write side is a lower bound, see _write_size_caveat" % (args.workload, kern)
+            roof["mfma_pipe_busy_pmc"] = pmc[kern]["mfma_pipe_busy"]
+        except (OSError, KeyError, TypeError):
+            pass
         line = {
             "metric": "siamese pair-comparisons/sec @%d pts" % n,
             "value": world * pairs * args.steps / dt,
