@@ -117,8 +117,8 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
   const int c1 = a.c1, c2 = a.c2, c3 = a.c3, K = a.K;
   // MAXE (K % 16 == 0): the max over K is taken from the layer-3 accumulators (16-lane DPP groups ->
   // gmax[c3][ROWS/16]) and the (c3 x rows) layer-3 output is never materialised in LDS
-  int rowsC = c1 > ceil8(c2) ? c1 : ceil8(c2);
-  if (!MAXE && c3 > rowsC) rowsC = c3;
+  int rowsC = c1 > ceil32(c2) ? c1 : ceil32(c2);
+  if (!MAXE && ceil32(c3) > rowsC) rowsC = ceil32(c3);
   float *buf = smem;                                        // [rowsC][RP]
   float *sdx = buf + rowsC * RP;                            // [3][ROWS]
   int *sidx = reinterpret_cast<int *>(sdx + 3 * ROWS);      // [ROWS] neighbour, [ROWS] centre point
@@ -215,9 +215,10 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
   if (!(a.dbg & 2)) {
     {
       // BatchNorm scale is folded into wp2/wp3 by the host, the shift seeds the accumulators
-      const int lim = ceil8(c2);
+      // the buffer has ceil32(c2) rows, so every accumulator row is stored unconditionally (rows past c2
+      // see zero weights and a zero seed -> relu(0) = 0, which is the zero padding layer 3 wants)
       tile_dense2<TB, NR, W2>(buf, c1, a.wp2, ceil32(c2), true, [&](float v, int o, int t) {
-        if (o < lim) buf[o * RP + t] = fmaxf(v, 0.f);     // rows [c2, lim) see zero weights and zero init
+        buf[o * RP + t] = fmaxf(v, 0.f);
       }, a.sh2);
     }
     __syncthreads();
@@ -233,12 +234,12 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
           v = fmaxf(v, dpp_f32<0x4E>(v));    // quad_perm [2,3,0,1]  : lane ^ 2
           v = fmaxf(v, dpp_f32<0x141>(v));   // row_half_mirror      : other quad of the 8-lane half
           v = fmaxf(v, dpp_f32<0x140>(v));   // row_mirror           : other half of the 16-lane row
-          if ((l31 & 15) == 0 && o < c3) gmax[o * NG + tb * 2 + (l31 >> 4)] = v;
+          if ((l31 & 15) == 0) gmax[o * NG + tb * 2 + (l31 >> 4)] = v;      // gmax has ceil32(c3) rows
         }
       }, a.sh3);
     } else {
       tile_dense2<TB, NR, W3>(buf, ceil8(c2), a.wp3, ceil32(c3), true, [&](float v, int o, int t) {
-        if (o < c3) buf[o * RP + t] = fmaxf(v, 0.f);
+        buf[o * RP + t] = fmaxf(v, 0.f);
       }, a.sh3);
     }
   }
@@ -337,11 +338,11 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   const int pqw = p.mode == 0 ? 2 * p.c1 : p.c1;
   if (p.D && pqw > 256) return -1;
   const bool maxe = (p.K & 15) == 0;
-  int rowsC = p.c1 > ceil8(p.c2) ? p.c1 : ceil8(p.c2);
-  if (!maxe && p.c3 > rowsC) rowsC = p.c3;
+  int rowsC = p.c1 > ceil32(p.c2) ? p.c1 : ceil32(p.c2);
+  if (!maxe && ceil32(p.c3) > rowsC) rowsC = ceil32(p.c3);
   auto lds_bytes = [&](int tb, int cpw) {
     size_t stage = (size_t)5 * 32 * tb + (size_t)cpw * p.c1;
-    const size_t gm = maxe ? (size_t)p.c3 * 2 * tb : 0;
+    const size_t gm = maxe ? (size_t)ceil32(p.c3) * 2 * tb : 0;
     if (gm > stage) stage = gm;
     return ((size_t)rowsC * (32 * tb + 1) + stage) * sizeof(float);
   };

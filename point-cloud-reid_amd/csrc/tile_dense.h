@@ -90,18 +90,29 @@ __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, in
   // happens for shapes that do not divide evenly) is computed on clamped addresses and dropped in
   // the epilogue, so the accumulators stay pinned in AGPRs.
   // `init` (OP floats, zero-padded) seeds the accumulators with the per-cout bias / folded BatchNorm
-  // shift, so the epilogue needs no per-element constant loads (they used to cost two global loads per
-  // output value right where the wave has nothing else to do).
+  // shift, so the epilogue needs no per-element constant loads.  The 16 accumulator rows of a lane are
+  // four runs of four consecutive couts (8g + 4h .. +3), i.e. four 16-byte loads, issued together
+  // with the first weight fragments.
   f32x16 acc[NR][TBW];
 #pragma unroll
   for (int nr = 0; nr < NR; nr++) {
     int cbi = cb0 + 4 * nr;
     cbi = cbi < nCB ? cbi : nCB - 1;
+    if (init != nullptr) {
+      const f32x4 *ip = reinterpret_cast<const f32x4 *>(init + cbi * 32 + 4 * h);
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const float v0 = init ? init[cbi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
+      for (int g = 0; g < 4; g++) {
+        const f32x4 v4 = ip[2 * g];
 #pragma unroll
-      for (int j = 0; j < TBW; j++) acc[nr][j][r] = v0;
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+          for (int j = 0; j < TBW; j++) acc[nr][j][4 * g + q] = v4[q];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+#pragma unroll
+        for (int j = 0; j < TBW; j++) acc[nr][j][r] = 0.f;
     }
   }
   const size_t wstride = (size_t)OP * 2;
