@@ -89,6 +89,29 @@ __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, in
   // The k-loop is branch-free: a tile the wave does not own (cb >= nCB or tb >= TB, which only
   // happens for shapes that do not divide evenly) is computed on clamped addresses and dropped in
   // the epilogue, so the accumulators stay pinned in AGPRs.
+  const size_t wstride = (size_t)OP * 2;
+  const f32x4 *wrow[NR];
+#pragma unroll
+  for (int nr = 0; nr < NR; nr++) {
+    int cb = cb0 + 4 * nr;
+    cb = cb < nCB ? cb : nCB - 1;
+    wrow[nr] = reinterpret_cast<const f32x4 *>(wp) + (size_t)cb * 64 + (size_t)l31 * 2 + h;
+  }
+  const float *brow[TBW];
+#pragma unroll
+  for (int j = 0; j < TBW; j++) {
+    int tb = tb0 + j * WAYS;
+    tb = tb < TB ? tb : TB - 1;
+    brow[j] = in + h * RP + tb * 32 + l31;
+  }
+  // first two weight fragments, requested BEFORE the accumulator seeds so that both round trips overlap
+  f32x4 a0[NR], a1[NR];
+  const int k1 = KB > 1 ? 1 : 0;
+#pragma unroll
+  for (int nr = 0; nr < NR; nr++) {
+    a0[nr] = wrow[nr][0];
+    a1[nr] = wrow[nr][(size_t)k1 * wstride];
+  }
   // `init` (OP floats, zero-padded) seeds the accumulators with the per-cout bias / folded BatchNorm
   // shift, so the epilogue needs no per-element constant loads.  The 16 accumulator rows of a lane are
   // four runs of four consecutive couts (8g + 4h .. +3), i.e. four 16-byte loads, issued together
@@ -115,21 +138,6 @@ __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, in
         for (int j = 0; j < TBW; j++) acc[nr][j][r] = 0.f;
     }
   }
-  const size_t wstride = (size_t)OP * 2;
-  const f32x4 *wrow[NR];
-#pragma unroll
-  for (int nr = 0; nr < NR; nr++) {
-    int cb = cb0 + 4 * nr;
-    cb = cb < nCB ? cb : nCB - 1;
-    wrow[nr] = reinterpret_cast<const f32x4 *>(wp) + (size_t)cb * 64 + (size_t)l31 * 2 + h;
-  }
-  const float *brow[TBW];
-#pragma unroll
-  for (int j = 0; j < TBW; j++) {
-    int tb = tb0 + j * WAYS;
-    tb = tb < TB ? tb : TB - 1;
-    brow[j] = in + h * RP + tb * 32 + l31;
-  }
   // two weight-fragment register sets in ping-pong: the 16-byte load for k-block kb+2 is issued
   // right after the last use of set (kb & 1) and has a full block of MFMAs to land
   auto step = [&](const f32x4 (&aw)[NR], int kb) {
@@ -146,13 +154,6 @@ __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, in
       }
     }
   };
-  f32x4 a0[NR], a1[NR];
-  const int k1 = KB > 1 ? 1 : 0;
-#pragma unroll
-  for (int nr = 0; nr < NR; nr++) {
-    a0[nr] = wrow[nr][0];
-    a1[nr] = wrow[nr][(size_t)k1 * wstride];
-  }
   for (int kb = 0; kb < KB; kb += 2) {
     step(a0, kb);
     const int kn0 = kb + 2 < KB ? kb + 2 : KB - 1;
