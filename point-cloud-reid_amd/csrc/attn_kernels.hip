@@ -141,8 +141,8 @@ __global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
   const int d = p.d, c1 = p.c1, cout = p.cout;
   const int catC = c1 + d, catP = ceil8(catC);
   int rowsW = 2 * d;
-  if (cout > rowsW) rowsW = cout;
-  if (p.cfinal > rowsW) rowsW = p.cfinal;
+  if (ceil32(cout) > rowsW) rowsW = ceil32(cout);
+  if (ceil32(p.cfinal) > rowsW) rowsW = ceil32(p.cfinal);
   float *CAT = smem;
   float *W = CAT + catP * RP;
   float *P = W + rowsW * RP;
@@ -210,9 +210,7 @@ __global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
   tile_layernorm(CAT + c1 * RP, d, RP, T, s_ln1g, s_ln1b, red);
   tile_dense2<TB, NR>(CAT, catP, p.wmlp0, 2 * d, false, [&](float v, int o, int t) { W[o * RP + t] = fmaxf(v, 0.f); });
   __syncthreads();
-  tile_dense2<TB, NR>(W, 2 * d, p.wmlp2, ceil32(cout), true, [&](float v, int o, int t) {
-    if (o < cout) W[o * RP + t] = v;
-  });
+  tile_dense2<TB, NR>(W, 2 * d, p.wmlp2, ceil32(cout), true, [&](float v, int o, int t) { W[o * RP + t] = v; });
   __syncthreads();
   tile_layernorm(W, cout, RP, T, s_ln2g, s_ln2b, red);
   if (p.residual) {
@@ -225,9 +223,8 @@ __global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
   int cres = cout;
   if (p.cfinal) {  // trailing 1x1 conv with bias (cov_final); needs cout % 8 == 0
     const int cf = p.cfinal;
-    tile_dense2<TB, NR>(W, cout, p.wfinal, ceil32(cf), true, [&](float v, int o, int t) {
-      if (o < cf) W[o * RP + t] = v;
-    }, p.bfinal);   // bfinal is zero-padded to a multiple of 32 by the host
+    tile_dense2<TB, NR>(W, cout, p.wfinal, ceil32(cf), true, [&](float v, int o, int t) { W[o * RP + t] = v; },
+                        p.bfinal);   // bfinal is zero-padded to a multiple of 32 by the host
     __syncthreads();
     cres = cf;
   }
@@ -287,8 +284,8 @@ PCR_EXPORT int pcr_attn_apply_f32(const pcr_attn_params *pp, pcr_stream_t stream
   const int tb = p.d <= 32 ? 4 : (p.d <= 64 ? 2 : 1), T = 32 * tb, RP = T + 1;
   const int catP = ceil8(p.c1 + p.d);
   int rowsW = 2 * p.d;
-  if (p.cout > rowsW) rowsW = p.cout;
-  if (p.cfinal > rowsW) rowsW = p.cfinal;
+  if (ceil32(p.cout) > rowsW) rowsW = ceil32(p.cout);
+  if (ceil32(p.cfinal) > rowsW) rowsW = ceil32(p.cfinal);
   size_t lds = ((size_t)(catP + rowsW + 3 + p.nhead) * RP + 2 * (kThreads / T) * T + 7 * p.d + 2 * p.cout) *
                sizeof(float);
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;

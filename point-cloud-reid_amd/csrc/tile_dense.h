@@ -246,7 +246,9 @@ __device__ __forceinline__ void tile_dense_strided(const float *__restrict__ in,
   }
 }
 
-__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x + 1.0f : (expf(x) - 1.0f) + 1.0f; }
+// elu(x) + 1 = x + 1 (x > 0) | exp(x) (x <= 0); hardware exp2 (v_exp_f32, ~1 ulp) instead of the libm
+// expansion: this runs once per projected Q/K element and was a third of the attention kernels' VALU time
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x + 1.0f : __expf(x); }
 
 // LayerNorm over the channel rows [0,C) of buf ([C][RP]) for each of the T token columns, in
 // place; part = tid / T handles channels part, part+np, ...; partial sums meet in `red`
