@@ -57,6 +57,10 @@ int pcr_fps_dist_f32(const float *dist, float *temp, int *idx, int B, int N, int
 int pcr_ball_query_f32(const float *centres, const float *xyz, int *idx, int B, int N, int M,
                        float min_r, float max_r, int K, pcr_stream_t stream);
 
+/* pcr_ball_query_f32 that also returns cnt (B,M): the number of genuine hits (<= K) of every row. */
+int pcr_ball_query_cnt_f32(const float *centres, const float *xyz, int *idx, int *cnt, int B, int N, int M,
+                           float min_r, float max_r, int K, pcr_stream_t stream);
+
 /* knn_wrapper (ops/knn/src/knn.cpp:28-41, kernel knn_cuda.cu:58-94).  xyz (B,N,3), centres (B,M,3)
  * -> idx (B,M,K) int32 and dist2 (B,M,K), ascending, produced by the same max-heap + heap-sort
  * sequence as the reference (so equal distances come out in the reference's order).
@@ -145,6 +149,12 @@ typedef struct pcr_sa_params {
    * fast path seeds the MFMA accumulators with the shift and its epilogue is a bare ReLU. */
   const float *wa, *wpq;
   const float *wps[2], *shift_pad[2];
+  /* Optional duplicate-free evaluation for ball-query groups (mode 1): cnt (B,S) = number of genuine hits
+   * of each row of idx as returned by pcr_ball_query_cnt_f32 (entries [cnt,K) of a row repeat entry 0, and
+   * a max over K ignores repeats), tile_ws = caller workspace of B*(2*S+1) ints.  The kernel then runs the
+   * MLP on ceil4(max(cnt,1)) rows per centre; the result is bit-identical to the K-row evaluation. */
+  const int *cnt;
+  int *tile_ws;
   float *pq_ws;
   int pq_ready; /* nonzero: pq_ws already holds the tables (caller ran pcr_dense_pm_f32 itself) */
   float *out;

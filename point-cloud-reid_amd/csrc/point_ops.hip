@@ -259,7 +259,8 @@ constexpr int kBqTile = 1024;
 __global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict__ centres,
                                                          const float *__restrict__ xyz,
                                                          int *__restrict__ idx, int n, int m,
-                                                         float min_r2, float max_r2, int K) {
+                                                         float min_r2, float max_r2, int K,
+                                                         int *__restrict__ cnt_out) {
   __shared__ float tile[3 * kBqTile];
   const int tid = threadIdx.x;
   const size_t b = blockIdx.y;
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict
   }
   if (valid)
     for (int l = cnt; l < K; l++) out[l] = first;  // first == 0 when nothing was hit
+  if (valid && cnt_out) cnt_out[b * m + p] = cnt;  // number of genuine hits; rows [cnt,K) are copies of row 0
 }
 
 // --------------------------------------------------------------------------- heap kNN ----
@@ -639,7 +641,19 @@ PCR_EXPORT int pcr_ball_query_f32(const float *centres, const float *xyz, int *i
   if (B > 65535) return PCR_ERR_INVALID;
   float max_r2 = max_r * max_r, min_r2 = min_r * min_r;
   hipLaunchKernelGGL(ball_query_kernel, dim3((M + 255) / 256, B), dim3(256), 0, pcr_s(stream),
-                     centres, xyz, idx, N, M, min_r2, max_r2, K);
+                     centres, xyz, idx, N, M, min_r2, max_r2, K, (int *)nullptr);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_ball_query_cnt_f32(const float *centres, const float *xyz, int *idx, int *cnt, int B, int N,
+                                      int M, float min_r, float max_r, int K, pcr_stream_t stream) {
+  if (!centres || !xyz || !idx || !cnt || B < 0 || N < 1 || M < 0 || K < 1) return PCR_ERR_INVALID;
+  if (B == 0 || M == 0) return PCR_OK;
+  if (B > 65535) return PCR_ERR_INVALID;
+  float max_r2 = max_r * max_r, min_r2 = min_r * min_r;
+  hipLaunchKernelGGL(ball_query_kernel, dim3((M + 255) / 256, B), dim3(256), 0, pcr_s(stream),
+                     centres, xyz, idx, N, M, min_r2, max_r2, K, cnt);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }

@@ -269,6 +269,157 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
   }
 }
 
+// ------------------------------------------------- ragged SA MLP (ball-query duplicates) ----
+// A ball-query row holds only cnt genuine neighbours; entries [cnt, K) repeat the first one
+// (ball_query_cuda.cu:43-47), and a max over K does not care about repeats.  This variant runs the MLP
+// on ceil4(max(cnt,1)) rows per centre instead of K: sa_rag_plan_kernel packs whole centres into tiles
+// of 32*TB rows (one thread per cloud, a serial walk over S counts), sa_rag_kernel is sa_fused_kernel on
+// such a tile with a 4-lane (quad DPP) max.  Output is bit-identical to the dense kernel's.
+struct RagArgs {
+  int B, N, S, K, c1, c2, c3, maxT;
+  const float *xyz;
+  const int *idx, *cnt, *centre_idx;
+  int *tiles;               // (B, 1 + 2*maxT): [ntiles, (first centre, n centres) x maxT]
+  const float *wa, *pq;
+  int pqw;
+  const float *wp2, *wp3, *sh1, *sh2, *sh3;
+  float *out;
+};
+
+__global__ void sa_rag_plan_kernel(RagArgs a, int rows_per_tile) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const int *cnt = a.cnt + (size_t)b * a.S;
+  int *tl = a.tiles + (size_t)b * (1 + 2 * a.maxT);
+  int t = 0, used = 0, first = 0;
+  for (int s = 0; s < a.S; s++) {
+    int c = cnt[s];
+    c = c < 1 ? 1 : (c > a.K ? a.K : c);
+    const int g = (c + 3) & ~3;
+    if (used + g > rows_per_tile) {
+      tl[1 + 2 * t] = first;
+      tl[2 + 2 * t] = s - first;
+      t++;
+      first = s;
+      used = 0;
+    }
+    used += g;
+  }
+  tl[1 + 2 * t] = first;
+  tl[2 + 2 * t] = a.S - first;
+  tl[0] = t + 1;
+}
+
+template <int TB, int NR>
+__global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
+  constexpr int ROWS = 32 * TB, RP = ROWS + 1, MAXC = ROWS / 4, NG = ROWS / 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int c1 = a.c1, c2 = a.c2, c3 = a.c3, K = a.K;
+  const size_t b = blockIdx.y;
+  const int *tl = a.tiles + b * (1 + 2 * a.maxT);
+  if ((int)blockIdx.x >= tl[0]) return;
+  const int first = tl[1 + 2 * blockIdx.x], nc = tl[2 + 2 * blockIdx.x];
+  const int rowsC = c1 > ceil32(c2) ? c1 : ceil32(c2);
+  float *buf = smem;                                   // [rowsC][RP]
+  float *sdx = buf + rowsC * RP;                       // [3][ROWS]
+  int *sidx = reinterpret_cast<int *>(sdx + 3 * ROWS); // [ROWS] neighbour point (-1: filler row)
+  int *coff = sidx + ROWS;                             // [MAXC + 1] first row of each centre
+  int *ccnt = coff + MAXC + 1;                         // [MAXC] genuine rows of each centre
+  float *gmax = reinterpret_cast<float *>(ccnt + MAXC);  // [ceil32(c3)][NG]
+  const int tid = threadIdx.x;
+  const float *xyz = a.xyz + b * a.N * 3;
+
+  if (tid == 0) {
+    int off = 0;
+    for (int c = 0; c < nc; c++) {
+      int n = a.cnt[b * a.S + first + c];
+      n = n < 1 ? 1 : (n > K ? K : n);
+      coff[c] = off;
+      ccnt[c] = n;
+      off += (n + 3) & ~3;
+    }
+    coff[nc] = off;
+  }
+  for (int r = tid; r < ROWS; r += kThreads) sidx[r] = -1;
+  __syncthreads();
+  // one thread per (centre, row-in-centre): neighbour index and dxyz; padding rows repeat the first
+  for (int e = tid; e < nc * K; e += kThreads) {
+    const int c = e / K, k = e - c * K;
+    const int g = coff[c + 1] - coff[c];
+    if (k < g) {
+      const int s = first + c;
+      const int ci = a.centre_idx ? a.centre_idx[b * a.S + s] : s;
+      const int i = a.idx[(b * a.S + s) * K + (k < ccnt[c] ? k : 0)];
+      const int r = coff[c] + k;
+      sidx[r] = i;
+      sdx[r] = xyz[i * 3] - xyz[ci * 3];
+      sdx[ROWS + r] = xyz[i * 3 + 1] - xyz[ci * 3 + 1];
+      sdx[2 * ROWS + r] = xyz[i * 3 + 2] - xyz[ci * 3 + 2];
+    }
+  }
+  __syncthreads();
+  {  // layer 1 (BatchNorm scale folded into wa / P, shift added here)
+    const float *pq = a.pq ? a.pq + b * a.N * (size_t)a.pqw : nullptr;
+    const int total = ROWS * (c1 >> 2);
+    constexpr int dR = kThreads % ROWS, dO = kThreads / ROWS;
+    int r = tid % ROWS, oq = tid / ROWS;
+    for (int e0 = tid; e0 < total; e0 += 4 * kThreads) {
+      f32x4 p4[4];
+      int rr[4], oo[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        rr[u] = r;
+        oo[u] = oq << 2;
+        p4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (pq && e0 + u * kThreads < total && sidx[r] >= 0)
+          p4[u] = *reinterpret_cast<const f32x4 *>(pq + (size_t)sidx[r] * a.pqw + oo[u]);
+        r += dR;
+        oq += dO;
+        if (r >= ROWS) { r -= ROWS; oq++; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (e0 + u * kThreads < total) {
+          const int rw = rr[u], o = oo[u];
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (sidx[rw] >= 0) {
+            const float dx = sdx[rw], dy = sdx[ROWS + rw], dz = sdx[2 * ROWS + rw];
+            const float *w = a.wa + o * 3;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+              v[j] = fmaxf(w[3 * j] * dx + w[3 * j + 1] * dy + w[3 * j + 2] * dz + p4[u][j] + a.sh1[o + j], 0.f);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; j++) buf[(o + j) * RP + rw] = v[j];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  tile_dense2<TB, NR>(buf, c1, a.wp2, ceil32(c2), true, [&](float v, int o, int t) { buf[o * RP + t] = fmaxf(v, 0.f); },
+                      a.sh2);
+  __syncthreads();
+  tile_dense2<TB, NR, 0, true>(buf, ceil8(c2), a.wp3, ceil32(c3), false,
+                               [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int o = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      float v = fmaxf(acc[r], 0.f);
+      v = fmaxf(v, dpp_f32<0xB1>(v));    // lane ^ 1
+      v = fmaxf(v, dpp_f32<0x4E>(v));    // lane ^ 2: quad maximum
+      if ((l31 & 3) == 0) gmax[o * NG + tb * 8 + (l31 >> 2)] = v;
+    }
+  }, a.sh3);
+  __syncthreads();
+  for (int e = tid; e < c3 * nc; e += kThreads) {
+    const int o = e / nc, c = e - o * nc;
+    const float *g = gmax + o * NG;
+    float m = g[coff[c] >> 2];
+    for (int q = (coff[c] >> 2) + 1; q < (coff[c + 1] >> 2); q++) m = fmaxf(m, g[q]);
+    a.out[(b * c3 + o) * a.S + first + c] = m;
+  }
+}
+
 // y (B,L,cout) POINT-major = W x for x (B,cin,L) channel-major; cout <= 256, no activation.
 struct DensePmArgs {
   const float *x, *wp;
@@ -337,6 +488,45 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   if ((p.c1 & 7) || p.c1 > 256 || p.c2 > 256 || p.c3 > 256) return -1;
   const int pqw = p.mode == 0 ? 2 * p.c1 : p.c1;
   if (p.D && pqw > 256) return -1;
+  if (p.cnt && p.tile_ws && p.mode == 1) {   // duplicate-free path for ball-query groups
+    const int n2r = ceil32(p.c2) >> 5, n3r = ceil32(p.c3) >> 5;
+    const int nrr = (n2r > 4 || n3r > 4) ? 2 : 1;
+    const int tb = nrr == 2 ? 2 : 4;
+    const int ROWS = 32 * tb;
+    if (p.K <= ROWS) {
+      const int per_tile = ROWS / ((p.K + 3) & ~3);            // whole centres a tile holds in the worst case
+      RagArgs r;
+      r.B = p.B; r.N = p.N; r.S = p.S; r.K = p.K; r.c1 = p.c1; r.c2 = p.c2; r.c3 = p.c3;
+      r.maxT = (p.S + per_tile - 1) / per_tile;
+      r.xyz = p.xyz; r.idx = p.idx; r.cnt = p.cnt; r.centre_idx = p.centre_idx; r.tiles = p.tile_ws;
+      r.wa = p.wa; r.pq = p.D ? p.pq_ws : nullptr; r.pqw = p.c1;
+      r.wp2 = p.wps[0]; r.wp3 = p.wps[1]; r.sh1 = p.shift[0]; r.sh2 = p.shift_pad[0]; r.sh3 = p.shift_pad[1];
+      r.out = p.out;
+      const int rowsCr = p.c1 > ceil32(p.c2) ? p.c1 : ceil32(p.c2);
+      const size_t lds = ((size_t)rowsCr * (ROWS + 1) + 3 * ROWS + ROWS + 2 * (ROWS / 4) + 2 +
+                          (size_t)ceil32(p.c3) * (ROWS / 4)) * sizeof(float);
+      if (lds <= 150 * 1024) {
+        if (p.D && !p.pq_ready) {
+          const int rc = pcr_dense_pm_f32(p.feat, p.wpq, p.pq_ws, p.B, p.D, p.c1, p.N, st_);
+          if (rc != PCR_OK) return rc == PCR_ERR_INVALID ? -1 : rc;
+        }
+        hipLaunchKernelGGL(sa_rag_plan_kernel, dim3((p.B + 63) / 64), dim3(64), 0, st, r, ROWS);
+        if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
+        dim3 grid(r.maxT, p.B);
+        if (tb == 2) {
+          static bool ok = allow_big_lds(sa_rag_kernel<2, 2>);
+          (void)ok;
+          hipLaunchKernelGGL((sa_rag_kernel<2, 2>), grid, dim3(kThreads), lds, st, r);
+        } else {
+          static bool ok = allow_big_lds(sa_rag_kernel<4, 1>);
+          (void)ok;
+          hipLaunchKernelGGL((sa_rag_kernel<4, 1>), grid, dim3(kThreads), lds, st, r);
+        }
+        if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
+        return PCR_OK;
+      }
+    }
+  }
   const bool maxe = (p.K & 15) == 0;
   int rowsC = p.c1 > ceil32(p.c2) ? p.c1 : ceil32(p.c2);
   if (!maxe && ceil32(p.c3) > rowsC) rowsC = ceil32(p.c3);

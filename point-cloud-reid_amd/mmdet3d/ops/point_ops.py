@@ -84,6 +84,33 @@ class BallQuery(Function):
         return None, None, None, None, None
 
 
+class BallQueryCnt(Function):
+    """ball_query that also returns the number of genuine hits of every row (entries past it repeat the
+    first hit, ball_query_cuda.cu:43-47); lets the fused SA kernel skip the repeated rows"""
+
+    @staticmethod
+    def forward(ctx, min_radius, max_radius, sample_num, xyz, center_xyz):
+        assert center_xyz.is_contiguous()
+        assert xyz.is_contiguous()
+        assert min_radius < max_radius
+        L.require_cuda(xyz, center_xyz)
+        B, N, _ = xyz.size()
+        npoint = center_xyz.size(1)
+        idx = _i32(B, npoint, sample_num, device=xyz.device)
+        cnt = _i32(B, npoint, device=xyz.device)
+        with _prof("ball_query[N=%d,M=%d,K=%d]" % (N, npoint, sample_num), 8.0 * B * N * npoint,
+                   4.0 * B * (3 * N + 3 * npoint + npoint * sample_num)):
+            L.check(L.load().pcr_ball_query_cnt_f32(L.ptr(center_xyz), L.ptr(xyz), L.ptr(idx), L.ptr(cnt), B, N,
+                                                    npoint, ctypes.c_float(min_radius), ctypes.c_float(max_radius),
+                                                    sample_num, L.stream_ptr()), "pcr_ball_query_cnt_f32")
+        ctx.mark_non_differentiable(idx, cnt)
+        return idx, cnt
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None, None, None, None
+
+
 class KNN(Function):
     @staticmethod
     def forward(ctx, k, xyz, center_xyz=None, transposed=False):
@@ -213,6 +240,7 @@ class ThreeInterpolate(Function):
 furthest_point_sample = FurthestPointSampling.apply
 furthest_point_sample_with_dist = FurthestPointSamplingWithDist.apply
 ball_query = BallQuery.apply
+ball_query_cnt = BallQueryCnt.apply
 knn = KNN.apply
 gather_points = GatherPoints.apply
 grouping_operation = GroupingOperation.apply

@@ -21,7 +21,7 @@ from torch import nn as nn
 from pcr_amd import engine
 from pcr_amd import _lib as L
 from ..models.builder import Registry
-from .point_ops import (ball_query, furthest_point_sample, furthest_point_sample_with_dist, gather_points,
+from .point_ops import (ball_query, ball_query_cnt, furthest_point_sample, furthest_point_sample_with_dist, gather_points,
                         grouping_operation, knn, three_interpolate, three_nn)
 
 SA_MODULES = Registry("point_sa_module")
@@ -129,6 +129,12 @@ class QueryAndGroup(nn.Module):
             return knn(self.sample_num, points_xyz, center_xyz, False).transpose(1, 2).contiguous()
         return ball_query(self.min_radius, self.max_radius, self.sample_num, points_xyz, center_xyz)
 
+    def query_cnt(self, points_xyz, center_xyz):
+        """(idx, cnt): cnt = genuine hits per row for ball queries, None for kNN (no repeated rows)"""
+        if self.max_radius is None:
+            return self.query(points_xyz, center_xyz), None
+        return ball_query_cnt(self.min_radius, self.max_radius, self.sample_num, points_xyz, center_xyz)
+
     def forward(self, points_xyz, center_xyz, features=None):
         idx = self.query(points_xyz, center_xyz)
         xyz_trans = points_xyz.transpose(1, 2).contiguous()
@@ -189,6 +195,8 @@ class BasePointSAModule(nn.Module):
         self.fps_mod_list = fps_mod
         self.fps_sample_range_list = fps_sample_range_list
         self.points_sampler = Points_Sampler(self.num_point, self.fps_mod_list, self.fps_sample_range_list)
+        # evaluate the shared MLP only on the distinct rows of a ball-query group (identical output)
+        self.skip_repeats = True
         for i in range(len(radii)):
             if num_point is not None:
                 min_radius = radii[i - 1] if dilated_group and i != 0 else 0
@@ -235,9 +243,10 @@ class BasePointSAModule(nn.Module):
         for i, grouper in enumerate(self.groupers):
             if not isinstance(grouper, QueryAndGroup):
                 raise L.PcrError("GroupAll scales are not on the ReID path")
-            idx = grouper.query(points_xyz, new_xyz)
+            idx, cnt = grouper.query_cnt(points_xyz, new_xyz)
             feats = None if features is None else features.contiguous()
-            outs.append(self._plan(i, points_xyz.device).run(points_xyz, feats, idx, centre_idx=indices.contiguous()))
+            outs.append(self._plan(i, points_xyz.device).run(points_xyz, feats, idx, centre_idx=indices.contiguous(),
+                                                             cnt=cnt if self.skip_repeats else None))
         return new_xyz, torch.cat(outs, dim=1) if len(outs) > 1 else outs[0], indices
 
 

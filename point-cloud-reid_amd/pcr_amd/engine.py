@@ -46,6 +46,7 @@ class SaParams(ctypes.Structure):
                 ("xyz", c_float_p), ("feat", c_float_p), ("idx", c_int_p), ("centre_idx", c_int_p),
                 ("wp", c_float_p * 3), ("scale", c_float_p * 3), ("shift", c_float_p * 3),
                 ("wa", c_float_p), ("wpq", c_float_p), ("wps", c_float_p * 2), ("shift_pad", c_float_p * 2),
+                ("cnt", c_int_p), ("tile_ws", c_int_p),
                 ("pq_ws", c_float_p), ("pq_ready", ctypes.c_int),
                 ("out", c_float_p)]
 
@@ -155,7 +156,9 @@ class SaPlan:
                 stacked = w1[:, 3:3 + D] * sc1
             self.wpq = pack_weight(stacked.float(), device)
 
-    def run(self, xyz, feat, idx, centre_idx=None):
+    def run(self, xyz, feat, idx, centre_idx=None, cnt=None):
+        """cnt (B,S) int32: genuine-hit counts of a ball query (ops.ball_query_cnt); when given (mode 1) the
+        MLP runs only on the distinct rows of every group -- same result, K/cnt times less work"""
         L.require_cuda(xyz, idx)
         B, N, _ = xyz.shape
         _, S, K = idx.shape
@@ -171,6 +174,11 @@ class SaPlan:
         for i in range(3):
             p.wp[i], p.scale[i], p.shift[i] = _p(self.wp[i]), _p(self.scale[i]), _p(self.shift[i])
         p.out = _p(out)
+        ragged = cnt is not None and self.fast and self.mode == 1
+        if ragged:
+            assert cnt.is_contiguous() and cnt.dtype == torch.int32 and cnt.shape == (B, S)
+            tile_ws = torch.empty((B * (2 * S + 1),), dtype=torch.int32, device=xyz.device)
+            p.cnt, p.tile_ws = _p(cnt), _p(tile_ws)
         if self.fast:
             p.wa = _p(self.wa)
             for i in range(2):
@@ -189,7 +197,11 @@ class SaPlan:
         flops = 2.0 * B * S * K * (self.cin * c1 + c1 * c2 + c2 * c3)
         nbytes = 4.0 * B * (3 * N + D * N + S * K + c3 * S)
         exec_flops = 2.0 * B * S * K * (c1 * c2 + c2 * c3) if self.fast else flops
-        with _prof("sa_fused[D=%d,c=%d/%d/%d,N=%d,S=%d,K=%d]" % (D, c1, c2, c3, N, S, K), flops, nbytes, exec_flops):
+        if ragged:   # rows really evaluated: ceil4(max(cnt,1)) per centre (only computed while profiling)
+            rows = float(((cnt.clamp(1, K) + 3) // 4 * 4).sum().item()) if PROFILE is not None else 0.0
+            exec_flops = 2.0 * rows * (c1 * c2 + c2 * c3)
+        name = "sa_ragged" if ragged else "sa_fused"
+        with _prof("%s[D=%d,c=%d/%d/%d,N=%d,S=%d,K=%d]" % (name, D, c1, c2, c3, N, S, K), flops, nbytes, exec_flops):
             L.check(L.load().pcr_sa_mlp_f32(ctypes.byref(p), L.stream_ptr()), "pcr_sa_mlp_f32")
         return out
 

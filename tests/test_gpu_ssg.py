@@ -98,3 +98,30 @@ def test_points_sampler_modes():
     assert idx.shape == (2, 32) and idx.dtype == torch.int32 and int(idx.max()) < 256
     idx = Points_Sampler([16], ["FS"], [-1])(xyz.cuda(), feats.cuda())
     assert idx.shape == (2, 32)
+
+
+@pytest.mark.parametrize("n,npoint,radius,k,chans,kind", [(1024, 512, 0.2, 32, [0, 64, 64, 128], "box"),
+                                                          (512, 128, 0.4, 64, [16, 128, 128, 256], "dup"),
+                                                          (300, 77, 5.0, 16, [6, 32, 32, 64], "randn"),
+                                                          (200, 50, 0.05, 24, [3, 32, 64, 32], "box")])
+def test_repeat_skipping_is_exact(n, npoint, radius, k, chans, kind):
+    """the duplicate-free evaluation (ball-query hit counts) gives bit-identical features to the K-row one,
+    from groups that are all padding (tiny radius) to groups that are completely full (huge radius)"""
+    from mmdet3d.ops import PointSAModule, ball_query_cnt
+    sa = PointSAModule(mlp_channels=list(chans), num_point=npoint, radius=radius, num_sample=k)
+    sa.load_state_dict(T.seeded_state_dict(T.manifest_of(sa), 5))
+    sa = sa.cuda().eval()
+    xyz = T.synthetic_clouds(3, n, seed=6, kind=kind).cuda()
+    feats = torch.randn(3, chans[0], n).cuda() if chans[0] else None
+    sa.skip_repeats = False
+    _, dense, idx = sa(xyz, feats)
+    sa.skip_repeats = True
+    new_xyz, ragged, idx2 = sa(xyz, feats)
+    assert torch.equal(idx, idx2)
+    assert torch.equal(dense, ragged)
+    bq, cnt = ball_query_cnt(0.0, radius, k, xyz, new_xyz)
+    want = P.ball_query(0.0, radius, k, xyz.cpu().numpy(), new_xyz.cpu().numpy())
+    assert (bq.cpu().numpy() == want).all()
+    uniq = np.array([[len(np.unique(r)) for r in b] for b in want])
+    c = cnt.cpu().numpy()
+    assert ((c == uniq) | ((c == 0) & (uniq == 1))).all()      # cnt = 0: no hit at all (row of zeros)
