@@ -203,12 +203,14 @@ def main():
         groups = {}
         for k, v in prof.items():
             groups[k.split("[")[0]] = groups.get(k.split("[")[0], 0.0) + v[0]
-        roof = dict(kernel=dom, bound="mfma", achieved=(flops / cnt) / (ms / cnt * 1e-3) / 1e12, peak=MFMA_F32_PEAK_TF,
-                    unit="TFLOP/s", avg_launch_ms=ms / cnt, launches_per_step=cnt, traffic=None,
-                    algorithmic_gflop_per_launch=flops / cnt / 1e9,
-                    mfma_issued_tflops=exec_flops / (ms * 1e-3) / 1e12, mfma_issued_frac=exec_flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
-                    note="achieved = reference op count of this layer / launch time; the kernel evaluates the first "
-                         "MLP layer through per-point tables, so mfma_issued_* is what the matrix core really executes",
+        # achieved = FLOPs the launch really issues on the matrix core / its duration (the kernel skips work the
+        # reference does: the first MLP layer via per-point tables, repeated ball-query rows); the reference's op
+        # count for the same layer over the same time is reported beside it as reference_op_tflops
+        roof = dict(kernel=dom, bound="mfma", achieved=(exec_flops / cnt) / (ms / cnt * 1e-3) / 1e12,
+                    peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", avg_launch_ms=ms / cnt, launches_per_step=cnt, traffic=None,
+                    issued_gflop_per_launch=exec_flops / cnt / 1e9,
+                    reference_op_gflop_per_launch=flops / cnt / 1e9,
+                    reference_op_tflops=(flops / cnt) / (ms / cnt * 1e-3) / 1e12,
                     share_of_step=ms / step_ms_kern,
                     per_kernel_ms={k: round(v, 4) for k, v in sorted(groups.items(), key=lambda kv: -kv[1])})
         roof["frac"] = roof["achieved"] / roof["peak"]

@@ -310,7 +310,7 @@ __global__ void sa_rag_plan_kernel(RagArgs a, int rows_per_tile) {
   tl[0] = t + 1;
 }
 
-template <int TB, int NR>
+template <int TB, int NR, int W2, int W3>
 __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   constexpr int ROWS = 32 * TB, RP = ROWS + 1, MAXC = ROWS / 4, NG = ROWS / 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -329,18 +329,20 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   const int tid = threadIdx.x;
   const float *xyz = a.xyz + b * a.N * 3;
 
+  if (tid < nc) {   // nc <= ROWS/4 <= 64: one lane per centre fetches its count, then a serial LDS prefix
+    int n = a.cnt[b * a.S + first + tid];
+    ccnt[tid] = n < 1 ? 1 : (n > K ? K : n);
+  }
+  for (int r = tid; r < ROWS; r += kThreads) sidx[r] = -1;
+  __syncthreads();
   if (tid == 0) {
     int off = 0;
     for (int c = 0; c < nc; c++) {
-      int n = a.cnt[b * a.S + first + c];
-      n = n < 1 ? 1 : (n > K ? K : n);
       coff[c] = off;
-      ccnt[c] = n;
-      off += (n + 3) & ~3;
+      off += (ccnt[c] + 3) & ~3;
     }
     coff[nc] = off;
   }
-  for (int r = tid; r < ROWS; r += kThreads) sidx[r] = -1;
   __syncthreads();
   // one thread per (centre, row-in-centre): neighbour index and dxyz; padding rows repeat the first
   for (int e = tid; e < nc * K; e += kThreads) {
@@ -396,10 +398,10 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
     }
   }
   __syncthreads();
-  tile_dense2<TB, NR>(buf, c1, a.wp2, ceil32(c2), true, [&](float v, int o, int t) { buf[o * RP + t] = fmaxf(v, 0.f); },
-                      a.sh2);
+  tile_dense2<TB, NR, W2>(buf, c1, a.wp2, ceil32(c2), true,
+                          [&](float v, int o, int t) { buf[o * RP + t] = fmaxf(v, 0.f); }, a.sh2);
   __syncthreads();
-  tile_dense2<TB, NR, 0, true>(buf, ceil8(c2), a.wp3, ceil32(c3), false,
+  tile_dense2<TB, NR, W3, true>(buf, ceil8(c2), a.wp3, ceil32(c3), false,
                                [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
 #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -513,15 +515,23 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
         hipLaunchKernelGGL(sa_rag_plan_kernel, dim3((p.B + 63) / 64), dim3(64), 0, st, r, ROWS);
         if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
         dim3 grid(r.maxT, p.B);
+        const int w2 = n2r >= 3 ? 1 : (n2r == 2 ? 2 : 4), w3 = n3r >= 3 ? 1 : (n3r == 2 ? 2 : 4);
+#define PCR_RAG(TBv, NRv, A2, A3)                                                         \
+  do {                                                                                    \
+    static bool ok = allow_big_lds(sa_rag_kernel<TBv, NRv, A2, A3>);                      \
+    (void)ok;                                                                             \
+    hipLaunchKernelGGL((sa_rag_kernel<TBv, NRv, A2, A3>), grid, dim3(kThreads), lds, st, r); \
+  } while (0)
         if (tb == 2) {
-          static bool ok = allow_big_lds(sa_rag_kernel<2, 2>);
-          (void)ok;
-          hipLaunchKernelGGL((sa_rag_kernel<2, 2>), grid, dim3(kThreads), lds, st, r);
+          if (w2 == 1 && w3 == 1) PCR_RAG(2, 2, 1, 1);
+          else PCR_RAG(2, 2, 0, 0);
         } else {
-          static bool ok = allow_big_lds(sa_rag_kernel<4, 1>);
-          (void)ok;
-          hipLaunchKernelGGL((sa_rag_kernel<4, 1>), grid, dim3(kThreads), lds, st, r);
+          if (w2 == 1 && w3 == 1) PCR_RAG(4, 1, 1, 1);
+          else if (w2 == 2 && w3 == 1) PCR_RAG(4, 1, 2, 1);
+          else if (w2 == 2 && w3 == 2) PCR_RAG(4, 1, 2, 2);
+          else PCR_RAG(4, 1, 0, 0);
         }
+#undef PCR_RAG
         if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
         return PCR_OK;
       }
