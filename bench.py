@@ -218,13 +218,15 @@ def main():
         # FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 correction 2*FETCH_SIZE + WRITE_SIZE), scaled to
         # this batch size; null when no profile of this workload is committed
         try:
-            with open(os.path.join(ROOT, "profiles", "r01f_%s_pmc.json" % args.workload)) as f:
+            import glob
+            path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc.json" % args.workload)))[-1]
+            with open(path) as f:
                 pmc = json.load(f)
             kern = pmc["_launch_to_kernel"][dom]
             roof["traffic"] = pmc[kern]["hbm_bytes_corrected"] * pairs / pmc["_pairs_per_step"]
-            roof["traffic_source"] = "profiles/r01f_%s_pmc.json (%s); write side is a lower bound, see _write_size_caveat" % (args.workload, kern)
+            roof["traffic_source"] = "%s (%s)" % (os.path.relpath(path, ROOT), kern)
             roof["mfma_pipe_busy_pmc"] = pmc[kern]["mfma_pipe_busy"]
-        except (OSError, KeyError, TypeError):
+        except (OSError, KeyError, TypeError, IndexError):
             pass
         line = {
             "metric": "siamese pair-comparisons/sec @%d pts" % n,

@@ -133,8 +133,8 @@ __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
 
-template <int PPT>
-__global__ __launch_bounds__(256) void fps_fast_kernel(const float *__restrict__ xyz, float *__restrict__ temp,
+template <int PPT, int NT>
+__global__ __launch_bounds__(NT) void fps_fast_kernel(const float *__restrict__ xyz, float *__restrict__ temp,
                                                        int *__restrict__ idxs, int n, int m, int block,
                                                        int logb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -145,13 +145,13 @@ __global__ __launch_bounds__(256) void fps_fast_kernel(const float *__restrict__
   xyz += cloud * n * 3;
   temp += cloud * n;
   idxs += cloud * m;
-  for (int i = tid; i < 3 * n; i += 256) sx[i] = xyz[i];
+  for (int i = tid; i < 3 * n; i += NT) sx[i] = xyz[i];
   __syncthreads();
   float px[PPT], py[PPT], pz[PPT], t[PPT];
   uint32_t low[PPT];
 #pragma unroll
   for (int p = 0; p < PPT; p++) {
-    const int k = tid + 256 * p;
+    const int k = tid + NT * p;
     const bool ok = k < n;
     px[p] = ok ? sx[3 * k] : 0.f;
     py[p] = ok ? sx[3 * k + 1] : 0.f;
@@ -195,20 +195,22 @@ __global__ __launch_bounds__(256) void fps_fast_kernel(const float *__restrict__
                                     (uint32_t)__builtin_amdgcn_readlane((int)lo, 16 * r);
       key = kr > key ? kr : key;
     }
-    unsigned long long *slot = skey + (j & 1) * 4;
-    if (lane == 0) slot[wave] = key;
-    __syncthreads();
+    if (NT > 64) {   // single-wave workgroups (NT == 64) need no exchange and no barrier at all
+      unsigned long long *slot = skey + (j & 1) * 4;
+      if (lane == 0) slot[wave] = key;
+      __syncthreads();
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
-      const unsigned long long kw = slot[w];
-      key = kw > key ? kw : key;
+      for (int w = 0; w < NT / 64; w++) {
+        const unsigned long long kw = slot[w];
+        key = kw > key ? kw : key;
+      }
     }
     old = (int)(0x3FFFFFu - (uint32_t)(key & 0x3FFFFFull));
     if (tid == 0) idxs[j] = old;
   }
 #pragma unroll
   for (int p = 0; p < PPT; p++) {
-    const int k = tid + 256 * p;
+    const int k = tid + NT * p;
     if (k < n) temp[k] = t[p];
   }
 }
@@ -222,13 +224,21 @@ int fps_launch(bool dist, const float *data, float *temp, int *idx, int B, int N
   int block = 1 << logb;
   if (!dist && N <= 4096 && M > 1) {
     const size_t lds_fast = 64 + (size_t)3 * N * sizeof(float);
-    dim3 gf(B), bf(256);
-#define PCR_FPS_FAST(P) hipLaunchKernelGGL((fps_fast_kernel<P>), gf, bf, lds_fast, st, data, temp, idx, N, M, block, logb)
-    if (N <= 256) PCR_FPS_FAST(1);
-    else if (N <= 512) PCR_FPS_FAST(2);
-    else if (N <= 1024) PCR_FPS_FAST(4);
-    else if (N <= 2048) PCR_FPS_FAST(8);
-    else PCR_FPS_FAST(16);
+    dim3 gf(B);
+#define PCR_FPS_FAST(P, T) hipLaunchKernelGGL((fps_fast_kernel<P, T>), gf, dim3(T), lds_fast, st, data, temp, idx, N, M, block, logb)
+    // up to ~8 clouds per CU: one wave per cloud (16 points per lane, no barrier in the serial loop);
+    // beyond that the 4-wave form fills the machine better
+    if (N <= 1024 && B <= 2048) {
+      if (N <= 64) PCR_FPS_FAST(1, 64);
+      else if (N <= 128) PCR_FPS_FAST(2, 64);
+      else if (N <= 256) PCR_FPS_FAST(4, 64);
+      else if (N <= 512) PCR_FPS_FAST(8, 64);
+      else PCR_FPS_FAST(16, 64);
+    } else if (N <= 256) PCR_FPS_FAST(1, 256);
+    else if (N <= 512) PCR_FPS_FAST(2, 256);
+    else if (N <= 1024) PCR_FPS_FAST(4, 256);
+    else if (N <= 2048) PCR_FPS_FAST(8, 256);
+    else PCR_FPS_FAST(16, 256);
 #undef PCR_FPS_FAST
     PCR_CHECK_LAUNCH();
     return PCR_OK;
