@@ -151,7 +151,7 @@ typedef struct pcr_sa_params {
   const float *wps[2], *shift_pad[2];
   /* Optional duplicate-free evaluation for ball-query groups (mode 1): cnt (B,S) = number of genuine hits
    * of each row of idx as returned by pcr_ball_query_cnt_f32 (entries [cnt,K) of a row repeat entry 0, and
-   * a max over K ignores repeats), tile_ws = caller workspace of B*(2*S+1) ints.  The kernel then runs the
+   * a max over K ignores repeats), tile_ws = caller workspace of B*(6*S+1)+4 ints.  The kernel then runs the
    * MLP on ceil4(max(cnt,1)) rows per centre; the result is bit-identical to the K-row evaluation. */
   const int *cnt;
   int *tile_ws;

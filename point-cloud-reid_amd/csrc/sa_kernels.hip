@@ -110,7 +110,8 @@ struct Sa2Args {
   float *out;
 };
 
-template <int TB, int NR, int W2, int W3, bool MAXE>
+// NR / NR2: cout-block rounds per wave of layer 3 / layer 2 (2 when the layer has more than 4 x 32 couts)
+template <int TB, int NR, int W2, int W3, bool MAXE, int NR2 = NR>
 __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
   constexpr int ROWS = 32 * TB, RP = ROWS + 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
       // BatchNorm scale is folded into wp2/wp3 by the host, the shift seeds the accumulators
       // the buffer has ceil32(c2) rows, so every accumulator row is stored unconditionally (rows past c2
       // see zero weights and a zero seed -> relu(0) = 0, which is the zero padding layer 3 wants)
-      tile_dense2<TB, NR, W2>(buf, c1, a.wp2, ceil32(c2), true, [&](float v, int o, int t) {
+      tile_dense2<TB, NR2, W2>(buf, c1, a.wp2, ceil32(c2), true, [&](float v, int o, int t) {
         buf[o * RP + t] = fmaxf(v, 0.f);
       }, a.sh2);
     }
@@ -272,53 +273,93 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
 // ------------------------------------------------- ragged SA MLP (ball-query duplicates) ----
 // A ball-query row holds only cnt genuine neighbours; entries [cnt, K) repeat the first one
 // (ball_query_cuda.cu:43-47), and a max over K does not care about repeats.  This variant runs the MLP
-// on ceil4(max(cnt,1)) rows per centre instead of K: sa_rag_plan_kernel packs whole centres into tiles
-// of 32*TB rows (one thread per cloud, a serial walk over S counts), sa_rag_kernel is sa_fused_kernel on
-// such a tile with a 4-lane (quad DPP) max.  Output is bit-identical to the dense kernel's.
+// on ceil4(max(cnt,1)) rows per centre instead of K:
+//   sa_rag_plan_kernel  one thread per cloud walks the S counts and packs whole centres into tiles of
+//                       32*TB rows -> per-cloud tile descriptors + tile count;
+//   sa_rag_scan_kernel  one workgroup: exclusive scan of the tile counts over the clouds, then the
+//                       descriptors are copied into ONE flat list (cloud, first centre, n centres);
+//   sa_rag_kernel       persistent: CUs x residency workgroups stride over the flat list (a grid of
+//                       B x worst-case tiles would be 5/6 empty workgroups, which cost the chip a fifth of
+//                       its workgroup slots); each tile is sa_fused_kernel's pipeline with a 4-lane
+//                       (quad DPP) max.  Output is bit-identical to the dense kernel's.
+// Workspace (ints): nt[B] | total | desc[B][2*maxT] | pad to 4 | flat[B*maxT][4]
 struct RagArgs {
   int B, N, S, K, c1, c2, c3, maxT;
   const float *xyz;
   const int *idx, *cnt, *centre_idx;
-  int *tiles;               // (B, 1 + 2*maxT): [ntiles, (first centre, n centres) x maxT]
+  int *ws;
   const float *wa, *pq;
   int pqw;
+  int dbg;                  // PCR_SA_DBG ablation mask (diagnostics only; 0 in production)
   const float *wp2, *wp3, *sh1, *sh2, *sh3;
   float *out;
 };
+
+__host__ __device__ inline size_t rag_desc_off(int B) { return (size_t)B + 1; }
+__host__ __device__ inline size_t rag_flat_off(int B, int maxT) {
+  return (rag_desc_off(B) + (size_t)B * 2 * maxT + 3) & ~(size_t)3;
+}
 
 __global__ void sa_rag_plan_kernel(RagArgs a, int rows_per_tile) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.B) return;
   const int *cnt = a.cnt + (size_t)b * a.S;
-  int *tl = a.tiles + (size_t)b * (1 + 2 * a.maxT);
+  int *tl = a.ws + rag_desc_off(a.B) + (size_t)b * 2 * a.maxT;
   int t = 0, used = 0, first = 0;
   for (int s = 0; s < a.S; s++) {
     int c = cnt[s];
     c = c < 1 ? 1 : (c > a.K ? a.K : c);
     const int g = (c + 3) & ~3;
     if (used + g > rows_per_tile) {
-      tl[1 + 2 * t] = first;
-      tl[2 + 2 * t] = s - first;
+      tl[2 * t] = first;
+      tl[2 * t + 1] = s - first;
       t++;
       first = s;
       used = 0;
     }
     used += g;
   }
-  tl[1 + 2 * t] = first;
-  tl[2 + 2 * t] = a.S - first;
-  tl[0] = t + 1;
+  tl[2 * t] = first;
+  tl[2 * t + 1] = a.S - first;
+  a.ws[b] = t + 1;
 }
 
-template <int TB, int NR, int W2, int W3>
+__global__ __launch_bounds__(1024) void sa_rag_scan_kernel(int B, int maxT, int *ws) {
+  __shared__ int part[1024];
+  __shared__ int carry;
+  const int tid = threadIdx.x;
+  const int *desc = ws + rag_desc_off(B);
+  int4 *flat = reinterpret_cast<int4 *>(ws + rag_flat_off(B, maxT));
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < B; base += 1024) {
+    const int b = base + tid;
+    const int v = b < B ? ws[b] : 0;
+    part[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int t = tid >= off ? part[tid - off] : 0;
+      __syncthreads();
+      part[tid] += t;
+      __syncthreads();
+    }
+    const int excl = part[tid] - v + carry;
+    for (int j = 0; j < v; j++)
+      flat[excl + j] = make_int4(b, desc[(size_t)b * 2 * maxT + 2 * j], desc[(size_t)b * 2 * maxT + 2 * j + 1], 0);
+    __syncthreads();
+    if (tid == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (tid == 0) ws[B] = carry;
+}
+
+template <int TB, int NR, int W2, int W3, int NR2 = NR>
 __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   constexpr int ROWS = 32 * TB, RP = ROWS + 1, MAXC = ROWS / 4, NG = ROWS / 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int c1 = a.c1, c2 = a.c2, c3 = a.c3, K = a.K;
-  const size_t b = blockIdx.y;
-  const int *tl = a.tiles + b * (1 + 2 * a.maxT);
-  if ((int)blockIdx.x >= tl[0]) return;
-  const int first = tl[1 + 2 * blockIdx.x], nc = tl[2 + 2 * blockIdx.x];
+  const int total = a.ws[a.B];
+  const int4 *flat = reinterpret_cast<const int4 *>(a.ws + rag_flat_off(a.B, a.maxT));
   const int rowsC = c1 > ceil32(c2) ? c1 : ceil32(c2);
   float *buf = smem;                                   // [rowsC][RP]
   float *sdx = buf + rowsC * RP;                       // [3][ROWS]
@@ -327,6 +368,10 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   int *ccnt = coff + MAXC + 1;                         // [MAXC] genuine rows of each centre
   float *gmax = reinterpret_cast<float *>(ccnt + MAXC);  // [ceil32(c3)][NG]
   const int tid = threadIdx.x;
+  for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+  const int4 td = flat[tile];
+  const size_t b = (size_t)td.x;
+  const int first = td.y, nc = td.z;
   const float *xyz = a.xyz + b * a.N * 3;
 
   if (tid < nc) {   // nc <= ROWS/4 <= 64: one lane per centre fetches its count, then a serial LDS prefix
@@ -360,7 +405,7 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
     }
   }
   __syncthreads();
-  {  // layer 1 (BatchNorm scale folded into wa / P, shift added here)
+  if (!(a.dbg & 1)) {  // layer 1 (BatchNorm scale folded into wa / P, shift added here)
     const float *pq = a.pq ? a.pq + b * a.N * (size_t)a.pqw : nullptr;
     const int total = ROWS * (c1 >> 2);
     constexpr int dR = kThreads % ROWS, dO = kThreads / ROWS;
@@ -398,9 +443,11 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
     }
   }
   __syncthreads();
-  tile_dense2<TB, NR, W2>(buf, c1, a.wp2, ceil32(c2), true,
-                          [&](float v, int o, int t) { buf[o * RP + t] = fmaxf(v, 0.f); }, a.sh2);
+  if (!(a.dbg & 2))
+  tile_dense2<TB, NR2, W2>(buf, c1, a.wp2, ceil32(c2), true,
+                           [&](float v, int o, int t) { buf[o * RP + t] = fmaxf(v, 0.f); }, a.sh2);
   __syncthreads();
+  if (!(a.dbg & 4))
   tile_dense2<TB, NR, W3, true>(buf, ceil8(c2), a.wp3, ceil32(c3), false,
                                [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
 #pragma unroll
@@ -413,12 +460,15 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
     }
   }, a.sh3);
   __syncthreads();
+  if (!(a.dbg & 8))
   for (int e = tid; e < c3 * nc; e += kThreads) {
     const int o = e / nc, c = e - o * nc;
     const float *g = gmax + o * NG;
     float m = g[coff[c] >> 2];
     for (int q = (coff[c] >> 2) + 1; q < (coff[c + 1] >> 2); q++) m = fmaxf(m, g[q]);
     a.out[(b * c3 + o) * a.S + first + c] = m;
+  }
+  __syncthreads();   // the next tile re-uses every staging array
   }
 }
 
@@ -455,27 +505,31 @@ __global__ __launch_bounds__(kThreads) void dense_pm_kernel(DensePmArgs a) {
 
 }  // namespace
 
-template <int TB, int NR, int W2, int W3>
+template <int TB, int NR, int W2, int W3, int NR2 = NR>
 static void sa2_launch_one(const Sa2Args &a, bool maxe, size_t lds, hipStream_t st, dim3 grid) {
   if (maxe) {
-    static bool ok = allow_big_lds(sa_fused_kernel<TB, NR, W2, W3, true>);
+    static bool ok = allow_big_lds(sa_fused_kernel<TB, NR, W2, W3, true, NR2>);
     (void)ok;
-    hipLaunchKernelGGL((sa_fused_kernel<TB, NR, W2, W3, true>), grid, dim3(kThreads), lds, st, a);
+    hipLaunchKernelGGL((sa_fused_kernel<TB, NR, W2, W3, true, NR2>), grid, dim3(kThreads), lds, st, a);
   } else {
-    static bool ok = allow_big_lds(sa_fused_kernel<TB, NR, W2, W3, false>);
+    static bool ok = allow_big_lds(sa_fused_kernel<TB, NR, W2, W3, false, NR2>);
     (void)ok;
-    hipLaunchKernelGGL((sa_fused_kernel<TB, NR, W2, W3, false>), grid, dim3(kThreads), lds, st, a);
+    hipLaunchKernelGGL((sa_fused_kernel<TB, NR, W2, W3, false, NR2>), grid, dim3(kThreads), lds, st, a);
   }
 }
 
 // wsel: 1 / 2 / 4 when both MFMA layers have the same cout class (specialised bodies), else 0
+// nr2 / nr: cout-block rounds of layer 2 / of the wider of the two layers
 template <int TB>
-static int sa2_launch_tb(const Sa2Args &a, int nr, int wsel, bool maxe, size_t lds, hipStream_t st, dim3 grid) {
+static int sa2_launch_tb(const Sa2Args &a, int nr, int nr2, int wsel, bool maxe, size_t lds, hipStream_t st,
+                         dim3 grid) {
   if (wsel == 4) sa2_launch_one<TB, 1, 4, 4>(a, maxe, lds, st, grid);
   else if (wsel == 2) sa2_launch_one<TB, 1, 2, 2>(a, maxe, lds, st, grid);
   else if (wsel == 1 && nr == 1) sa2_launch_one<TB, 1, 1, 1>(a, maxe, lds, st, grid);
+  else if (wsel == 1 && nr2 == 1) sa2_launch_one<TB, 2, 1, 1, 1>(a, maxe, lds, st, grid);
   else if (wsel == 1) sa2_launch_one<TB, 2, 1, 1>(a, maxe, lds, st, grid);
   else if (nr == 1) sa2_launch_one<TB, 1, 0, 0>(a, maxe, lds, st, grid);
+  else if (nr2 == 1) sa2_launch_one<TB, 2, 0, 0, 1>(a, maxe, lds, st, grid);
   else sa2_launch_one<TB, 2, 0, 0>(a, maxe, lds, st, grid);
   return 0;
 }
@@ -500,9 +554,11 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
       RagArgs r;
       r.B = p.B; r.N = p.N; r.S = p.S; r.K = p.K; r.c1 = p.c1; r.c2 = p.c2; r.c3 = p.c3;
       r.maxT = (p.S + per_tile - 1) / per_tile;
-      r.xyz = p.xyz; r.idx = p.idx; r.cnt = p.cnt; r.centre_idx = p.centre_idx; r.tiles = p.tile_ws;
+      r.xyz = p.xyz; r.idx = p.idx; r.cnt = p.cnt; r.centre_idx = p.centre_idx; r.ws = p.tile_ws;
       r.wa = p.wa; r.pq = p.D ? p.pq_ws : nullptr; r.pqw = p.c1;
       r.wp2 = p.wps[0]; r.wp3 = p.wps[1]; r.sh1 = p.shift[0]; r.sh2 = p.shift_pad[0]; r.sh3 = p.shift_pad[1];
+      static const int rdbg = getenv("PCR_SA_DBG") ? atoi(getenv("PCR_SA_DBG")) : 0;
+      r.dbg = rdbg;
       r.out = p.out;
       const int rowsCr = p.c1 > ceil32(p.c2) ? p.c1 : ceil32(p.c2);
       const size_t lds = ((size_t)rowsCr * (ROWS + 1) + 3 * ROWS + ROWS + 2 * (ROWS / 4) + 2 +
@@ -513,17 +569,41 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
           if (rc != PCR_OK) return rc == PCR_ERR_INVALID ? -1 : rc;
         }
         hipLaunchKernelGGL(sa_rag_plan_kernel, dim3((p.B + 63) / 64), dim3(64), 0, st, r, ROWS);
+        hipLaunchKernelGGL(sa_rag_scan_kernel, dim3(1), dim3(1024), 0, st, p.B, r.maxT, r.ws);
         if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
-        dim3 grid(r.maxT, p.B);
+        static const int n_cu = [] {
+          int dev = 0, n = 0;
+          if (hipGetDevice(&dev) != hipSuccess ||
+              hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+            n = 256;
+          return n;
+        }();
+        const long long max_tiles = (long long)p.B * r.maxT;
         const int w2 = n2r >= 3 ? 1 : (n2r == 2 ? 2 : 4), w3 = n3r >= 3 ? 1 : (n3r == 2 ? 2 : 4);
-#define PCR_RAG(TBv, NRv, A2, A3)                                                         \
-  do {                                                                                    \
-    static bool ok = allow_big_lds(sa_rag_kernel<TBv, NRv, A2, A3>);                      \
-    (void)ok;                                                                             \
-    hipLaunchKernelGGL((sa_rag_kernel<TBv, NRv, A2, A3>), grid, dim3(kThreads), lds, st, r); \
+#define PCR_RAG(TBv, NRv, A2, A3, ...)                                                                   \
+  do {                                                                                                   \
+    auto kern = sa_rag_kernel<TBv, NRv, A2, A3 __VA_ARGS__>;                                             \
+    static bool ok = allow_big_lds(kern);                                                                \
+    (void)ok;                                                                                            \
+    static size_t occ_lds = 0;                                                                           \
+    static int occ = 0;   /* resident workgroups per CU for this LDS size (registers and LDS) */          \
+    if (occ_lds != lds) {                                                                                \
+      int n = 0;                                                                                         \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, kThreads, lds) != hipSuccess || n < 1)  \
+        n = 1;                                                                                           \
+      occ = n;                                                                                           \
+      occ_lds = lds;                                                                                     \
+    }                                                                                                    \
+    long long want = (long long)n_cu * occ;                                                              \
+    if (want > max_tiles) want = max_tiles;                                                              \
+    hipLaunchKernelGGL(kern, dim3((unsigned)want), dim3(kThreads), lds, st, r);                          \
   } while (0)
+#define PCR_COMMA_ONE , 1
         if (tb == 2) {
-          if (w2 == 1 && w3 == 1) PCR_RAG(2, 2, 1, 1);
+          const bool narrow2 = n2r <= 4;   // layer 2 needs one cout-block round only
+          if (w2 == 1 && w3 == 1 && narrow2) PCR_RAG(2, 2, 1, 1, PCR_COMMA_ONE);
+          else if (w2 == 1 && w3 == 1) PCR_RAG(2, 2, 1, 1);
+          else if (narrow2) PCR_RAG(2, 2, 0, 0, PCR_COMMA_ONE);
           else PCR_RAG(2, 2, 0, 0);
         } else {
           if (w2 == 1 && w3 == 1) PCR_RAG(4, 1, 1, 1);
@@ -532,6 +612,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
           else PCR_RAG(4, 1, 0, 0);
         }
 #undef PCR_RAG
+#undef PCR_COMMA_ONE
         if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
         return PCR_OK;
       }
@@ -549,7 +630,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   const int n2 = ceil32(p.c2) >> 5, n3 = ceil32(p.c3) >> 5;
   const int nmin = n2 < n3 ? n2 : n3;
   const int ways = nmin >= 3 ? 1 : (nmin == 2 ? 2 : 4);
-  const int nr = (n2 > 4 || n3 > 4) ? 2 : 1;
+  const int nr = (n2 > 4 || n3 > 4) ? 2 : 1, nr2 = n2 > 4 ? 2 : 1;
   // Tile choice.  Measured on MI355X: time per row ~ padding x wave imbalance x
   // (1 + 2.5 / resident workgroups per CU); residency is bounded by LDS (160 KiB, 2 KiB granules),
   // by registers (accumulator tiles + ~70 VGPRs against 512 per SIMD lane) and by 8 workgroups.
@@ -604,12 +685,12 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   const int w2 = n2 >= 3 ? 1 : (n2 == 2 ? 2 : 4), w3 = n3 >= 3 ? 1 : (n3 == 2 ? 2 : 4);
   const int wsel = w2 == w3 ? w2 : 0;
   switch (best_tb) {
-    case 1: sa2_launch_tb<1>(a, nr, wsel, maxe, lds, st, grid); break;
-    case 2: sa2_launch_tb<2>(a, nr, wsel, maxe, lds, st, grid); break;
-    case 3: sa2_launch_tb<3>(a, nr, wsel, maxe, lds, st, grid); break;
-    case 4: sa2_launch_tb<4>(a, nr, wsel, maxe, lds, st, grid); break;
-    case 5: sa2_launch_tb<5>(a, nr, wsel, maxe, lds, st, grid); break;
-    default: sa2_launch_tb<6>(a, nr, wsel, maxe, lds, st, grid); break;
+    case 1: sa2_launch_tb<1>(a, nr, nr2, wsel, maxe, lds, st, grid); break;
+    case 2: sa2_launch_tb<2>(a, nr, nr2, wsel, maxe, lds, st, grid); break;
+    case 3: sa2_launch_tb<3>(a, nr, nr2, wsel, maxe, lds, st, grid); break;
+    case 4: sa2_launch_tb<4>(a, nr, nr2, wsel, maxe, lds, st, grid); break;
+    case 5: sa2_launch_tb<5>(a, nr, nr2, wsel, maxe, lds, st, grid); break;
+    default: sa2_launch_tb<6>(a, nr, nr2, wsel, maxe, lds, st, grid); break;
   }
   if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
   return PCR_OK;

@@ -26,6 +26,9 @@ __host__ __device__ inline int ceil8(int x) { return (x + 7) & ~7; }
 __host__ __device__ inline int ceil32(int x) { return (x + 31) & ~31; }
 
 constexpr int kThreads = 256;
+#ifndef PCR_PF
+#define PCR_PF 4
+#endif
 constexpr int kMaxDynLds = 160 * 1024;
 
 // out[o][t] = epi(sum_k W[o][k] * in[k][t], o, t) for o < OP (multiple of 32), t < 32*TB.
@@ -74,7 +77,8 @@ __device__ __forceinline__ void tile_dense(const float *__restrict__ in, int CP,
 //   nCB = OP/32 >= 3 : wave w owns cout blocks w, w+4 (NR rounds), all TB token blocks
 //   nCB == 2         : wave w owns cout block w&1 and token blocks (w>>1), (w>>1)+2, ...
 //   nCB == 1         : wave w owns token blocks w, w+4, ...
-template <int TB, int NR, int WAYS, bool TILE, class Epi>
+template <int TB, int NR, int WAYS, bool TILE, class Epi, int PF = PCR_PF>
+// PF must be even (the B-operand double buffer alternates per k-block)
 __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, int CP,
                                                 const float *__restrict__ wp, int OP, bool sync_epi,
                                                 Epi epi, const float *__restrict__ init = nullptr) {
@@ -89,7 +93,11 @@ __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, in
   // The k-loop is branch-free: a tile the wave does not own (cb >= nCB or tb >= TB, which only
   // happens for shapes that do not divide evenly) is computed on clamped addresses and dropped in
   // the epilogue, so the accumulators stay pinned in AGPRs.
+#ifdef PCR_DIAG_WSTRIDE0
+  const size_t wstride = 0;   // diagnostic build only: every k-block re-reads the first one (L1 hits)
+#else
   const size_t wstride = (size_t)OP * 2;
+#endif
   const f32x4 *wrow[NR];
 #pragma unroll
   for (int nr = 0; nr < NR; nr++) {
@@ -104,13 +112,13 @@ __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, in
     tb = tb < TB ? tb : TB - 1;
     brow[j] = in + h * RP + tb * 32 + l31;
   }
-  // first two weight fragments, requested BEFORE the accumulator seeds so that both round trips overlap
-  f32x4 a0[NR], a1[NR];
-  const int k1 = KB > 1 ? 1 : 0;
+  // first PF weight fragments, requested BEFORE the accumulator seeds so that all round trips overlap
+  f32x4 aw[PF][NR];
 #pragma unroll
-  for (int nr = 0; nr < NR; nr++) {
-    a0[nr] = wrow[nr][0];
-    a1[nr] = wrow[nr][(size_t)k1 * wstride];
+  for (int i = 0; i < PF; i++) {
+    const int ki = i < KB ? i : KB - 1;
+#pragma unroll
+    for (int nr = 0; nr < NR; nr++) aw[i][nr] = wrow[nr][(size_t)ki * wstride];
   }
   // `init` (OP floats, zero-padded) seeds the accumulators with the per-cout bias / folded BatchNorm
   // shift, so the epilogue needs no per-element constant loads.  The 16 accumulator rows of a lane are
@@ -138,33 +146,55 @@ __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, in
         for (int j = 0; j < TBW; j++) acc[nr][j][r] = 0.f;
     }
   }
-  // two weight-fragment register sets in ping-pong: the 16-byte load for k-block kb+2 is issued
-  // right after the last use of set (kb & 1) and has a full block of MFMAs to land
-  auto step = [&](const f32x4 (&aw)[NR], int kb) {
+  // PF weight-fragment register sets in a ring: the 16-byte load for k-block kb+PF is issued right
+  // after the last use of set (kb % PF) and has PF-1 blocks of MFMAs to land; the B operands (LDS) of
+  // block kb+1 are requested before the MFMAs of block kb.  The scheduling barriers pin that order
+  // (left alone, hipcc sinks every weight load to the end of the unrolled body, where its latency is
+  // fully exposed, and issues each ds_read right before its first use).
+  float xb[2][TBW][4];
+  auto load_x = [&](float (&x)[TBW][4], int kb) {
 #pragma unroll
     for (int j = 0; j < TBW; j++) {
       const float *bt = brow[j] + kb * 8 * RP;
-      const float x0 = bt[0], x1 = bt[2 * RP], x2 = bt[4 * RP], x3 = bt[6 * RP];
-#pragma unroll
-      for (int nr = 0; nr < NR; nr++) {
-        acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[nr][0], x0, acc[nr][j], 0, 0, 0);
-        acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[nr][1], x1, acc[nr][j], 0, 0, 0);
-        acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[nr][2], x2, acc[nr][j], 0, 0, 0);
-        acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[nr][3], x3, acc[nr][j], 0, 0, 0);
-      }
+      x[j][0] = bt[0];
+      x[j][1] = bt[2 * RP];
+      x[j][2] = bt[4 * RP];
+      x[j][3] = bt[6 * RP];
     }
   };
-  for (int kb = 0; kb < KB; kb += 2) {
-    step(a0, kb);
-    const int kn0 = kb + 2 < KB ? kb + 2 : KB - 1;
+  auto mma = [&](const f32x4 (&a)[NR], const float (&x)[TBW][4]) {
 #pragma unroll
-    for (int nr = 0; nr < NR; nr++) a0[nr] = wrow[nr][(size_t)kn0 * wstride];
-    if (kb + 1 < KB) {
-      step(a1, kb + 1);
-      const int kn1 = kb + 3 < KB ? kb + 3 : KB - 1;
+    for (int q = 0; q < 4; q++)
 #pragma unroll
-      for (int nr = 0; nr < NR; nr++) a1[nr] = wrow[nr][(size_t)kn1 * wstride];
+      for (int j = 0; j < TBW; j++)
+#pragma unroll
+        for (int nr = 0; nr < NR; nr++)
+          acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nr][q], x[j][q], acc[nr][j], 0, 0, 0);
+  };
+  load_x(xb[0], 0);
+  int kb = 0;
+  for (; kb + PF <= KB; kb += PF) {
+#pragma unroll
+    for (int i = 0; i < PF; i++) {
+      const int kx = kb + i + 1 < KB ? kb + i + 1 : KB - 1;
+      load_x(xb[(i + 1) & 1], kx);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(aw[i], xb[i & 1]);
+      const int kn = kb + i + PF < KB ? kb + i + PF : KB - 1;
+#pragma unroll
+      for (int nr = 0; nr < NR; nr++) aw[i][nr] = wrow[nr][(size_t)kn * wstride];
+      __builtin_amdgcn_sched_barrier(0);
     }
+  }
+  {
+    const int rem = KB - kb;   // < PF; aw[i] already holds k-block kb + i, xb[0] the operands of block kb
+#pragma unroll
+    for (int i = 0; i + 1 < PF; i++)
+      if (i < rem) {
+        const int kx = kb + i + 1 < KB ? kb + i + 1 : KB - 1;
+        load_x(xb[(i + 1) & 1], kx);
+        mma(aw[i], xb[i & 1]);
+      }
   }
   if (sync_epi) __syncthreads();
 #pragma unroll

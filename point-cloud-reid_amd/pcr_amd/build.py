@@ -44,6 +44,7 @@ def build(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     common = ["--offload-arch=gfx950", "-O3", "-fPIC", "-fvisibility=hidden", "-std=c++17",
               "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    common += os.environ.get("PCR_EXTRA_HIPCC_FLAGS", "").split()      # diagnostic builds only
     objs = []
     procs = []
     for src in sources():

@@ -177,7 +177,7 @@ class SaPlan:
         ragged = cnt is not None and self.fast and self.mode == 1
         if ragged:
             assert cnt.is_contiguous() and cnt.dtype == torch.int32 and cnt.shape == (B, S)
-            tile_ws = torch.empty((B * (2 * S + 1),), dtype=torch.int32, device=xyz.device)
+            tile_ws = torch.empty((B * (6 * S + 1) + 4,), dtype=torch.int32, device=xyz.device)
             p.cnt, p.tile_ws = _p(cnt), _p(tile_ws)
         if self.fast:
             p.wa = _p(self.wa)
