@@ -151,7 +151,7 @@ typedef struct pcr_sa_params {
   const float *wps[2], *shift_pad[2];
   /* Optional duplicate-free evaluation for ball-query groups (mode 1): cnt (B,S) = number of genuine hits
    * of each row of idx as returned by pcr_ball_query_cnt_f32 (entries [cnt,K) of a row repeat entry 0, and
-   * a max over K ignores repeats), tile_ws = caller workspace of B*(6*S+1)+4 ints.  The kernel then runs the
+   * a max over K ignores repeats), tile_ws = caller workspace of pcr_sa_tile_ws_ints(B,S,K,c2,c3) ints.  The kernel then runs the
    * MLP on ceil4(max(cnt,1)) rows per centre; the result is bit-identical to the K-row evaluation. */
   const int *cnt;
   int *tile_ws;
@@ -160,6 +160,8 @@ typedef struct pcr_sa_params {
   float *out;
 } pcr_sa_params;
 int pcr_sa_mlp_f32(const pcr_sa_params *p, pcr_stream_t stream);
+/* ints of pcr_sa_params.tile_ws for the duplicate-free evaluation (tile lists + per-tile row tables) */
+long pcr_sa_tile_ws_ints(int B, int S, int K, int c2, int c3);
 
 /* Per-point linear map with POINT-major output: x (B,cin,L) channel-major -> y (B,L,cout) = W x,
  * wp packed (cout,cin), cout <= 256.  This is the table builder of the decomposed first SA layer

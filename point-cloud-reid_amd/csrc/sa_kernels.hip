@@ -278,11 +278,16 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
 //                       32*TB rows -> per-cloud tile descriptors + tile count;
 //   sa_rag_scan_kernel  one workgroup: exclusive scan of the tile counts over the clouds, then the
 //                       descriptors are copied into ONE flat list (cloud, first centre, n centres);
+//   sa_rag_rows_kernel  one wave per tile: the row table {neighbour index, dxyz} of the tile and the
+//                       first row of each of its centres (the cnt -> prefix -> idx -> xyz chain of four
+//                       dependent global loads, taken off the matrix kernel's critical path);
 //   sa_rag_kernel       persistent: CUs x residency workgroups stride over the flat list (a grid of
 //                       B x worst-case tiles would be 5/6 empty workgroups, which cost the chip a fifth of
 //                       its workgroup slots); each tile is sa_fused_kernel's pipeline with a 4-lane
-//                       (quad DPP) max.  Output is bit-identical to the dense kernel's.
-// Workspace (ints): nt[B] | total | desc[B][2*maxT] | pad to 4 | flat[B*maxT][4]
+//                       (quad DPP) max; the row table of the NEXT tile is fetched during the matrix
+//                       phases.  Output is bit-identical to the dense kernel's.
+// Workspace (ints): nt[B] | total | desc[B][2*maxT] | pad4 | flat[B*maxT][4] | ctab[B*maxT][ROWS/4+4]
+//                   | rowtab[B*maxT][ROWS][4]
 struct RagArgs {
   int B, N, S, K, c1, c2, c3, maxT;
   const float *xyz;
@@ -298,6 +303,15 @@ struct RagArgs {
 __host__ __device__ inline size_t rag_desc_off(int B) { return (size_t)B + 1; }
 __host__ __device__ inline size_t rag_flat_off(int B, int maxT) {
   return (rag_desc_off(B) + (size_t)B * 2 * maxT + 3) & ~(size_t)3;
+}
+__host__ __device__ inline size_t rag_ctab_off(int B, int maxT) {
+  return rag_flat_off(B, maxT) + (size_t)B * maxT * 4;
+}
+__host__ __device__ inline size_t rag_rowtab_off(int B, int maxT, int rows) {
+  return rag_ctab_off(B, maxT) + (size_t)B * maxT * (rows / 4 + 4);
+}
+__host__ __device__ inline size_t rag_ws_ints(int B, int maxT, int rows) {
+  return rag_rowtab_off(B, maxT, rows) + (size_t)B * maxT * rows * 4;
 }
 
 __global__ void sa_rag_plan_kernel(RagArgs a, int rows_per_tile) {
@@ -353,64 +367,117 @@ __global__ __launch_bounds__(1024) void sa_rag_scan_kernel(int B, int maxT, int 
   if (tid == 0) ws[B] = carry;
 }
 
-template <int TB, int NR, int W2, int W3, int NR2 = NR>
-__global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
-  constexpr int ROWS = 32 * TB, RP = ROWS + 1, MAXC = ROWS / 4, NG = ROWS / 4;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int c1 = a.c1, c2 = a.c2, c3 = a.c3, K = a.K;
+// one wave per tile (4 tiles per workgroup), grid-stride over the flat list
+template <int ROWS>
+__global__ __launch_bounds__(256) void sa_rag_rows_kernel(RagArgs a) {
+  constexpr int MAXC = ROWS / 4, CT = MAXC + 4;
+  __shared__ int s_off[4][MAXC + 1], s_cnt[4][MAXC];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int total = a.ws[a.B];
   const int4 *flat = reinterpret_cast<const int4 *>(a.ws + rag_flat_off(a.B, a.maxT));
+  int *ctab = a.ws + rag_ctab_off(a.B, a.maxT);
+  f32x4 *rowtab = reinterpret_cast<f32x4 *>(a.ws + rag_rowtab_off(a.B, a.maxT, ROWS));
+  for (int tile = blockIdx.x * 4 + w; tile < total; tile += gridDim.x * 4) {
+    const int4 td = flat[tile];
+    const size_t b = (size_t)td.x;
+    const int first = td.y, nc = td.z;      // nc <= MAXC <= 32 < 64 lanes
+    int n = 1;
+    if (lane < nc) {
+      n = a.cnt[b * a.S + first + lane];
+      n = n < 1 ? 1 : (n > a.K ? a.K : n);
+    }
+    const int g = lane < nc ? (n + 3) & ~3 : 0;
+    int incl = g;                            // inclusive prefix over the lanes of the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane < nc) {
+      s_off[w][lane] = incl - g;
+      s_cnt[w][lane] = n;
+      ctab[(size_t)tile * CT + lane] = incl - g;
+    }
+    if (lane == nc) {
+      s_off[w][nc] = incl;                   // lanes >= nc carry the total
+      ctab[(size_t)tile * CT + nc] = incl;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the wave's own LDS writes have landed
+    const int used = s_off[w][nc];
+    const float *xyz = a.xyz + b * a.N * 3;
+    for (int r = lane; r < ROWS; r += 64) {
+      f32x4 v = {__int_as_float(-1), 0.f, 0.f, 0.f};
+      if (r < used) {
+        int lo = 0, hi = nc - 1;             // last centre whose first row is <= r
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (s_off[w][mid] <= r) lo = mid; else hi = mid - 1;
+        }
+        const int c = lo, k = r - s_off[w][c];
+        const int s = first + c;
+        const int ci = a.centre_idx ? a.centre_idx[b * a.S + s] : s;
+        const int i = a.idx[(b * a.S + s) * a.K + (k < s_cnt[w][c] ? k : 0)];
+        v[0] = __int_as_float(i);
+        v[1] = xyz[i * 3] - xyz[ci * 3];
+        v[2] = xyz[i * 3 + 1] - xyz[ci * 3 + 1];
+        v[3] = xyz[i * 3 + 2] - xyz[ci * 3 + 2];
+      }
+      rowtab[(size_t)tile * ROWS + r] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int TB, int NR, int W2, int W3, int NR2 = NR>
+__global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
+  constexpr int ROWS = 32 * TB, RP = ROWS + 1, MAXC = ROWS / 4, NG = ROWS / 4, CT = MAXC + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int c1 = a.c1, c2 = a.c2, c3 = a.c3;
+  const int total = a.ws[a.B];
+  const int4 *flat = reinterpret_cast<const int4 *>(a.ws + rag_flat_off(a.B, a.maxT));
+  const int *ctab = a.ws + rag_ctab_off(a.B, a.maxT);
+  const f32x4 *rowtab = reinterpret_cast<const f32x4 *>(a.ws + rag_rowtab_off(a.B, a.maxT, ROWS));
   const int rowsC = c1 > ceil32(c2) ? c1 : ceil32(c2);
-  float *buf = smem;                                   // [rowsC][RP]
-  float *sdx = buf + rowsC * RP;                       // [3][ROWS]
-  int *sidx = reinterpret_cast<int *>(sdx + 3 * ROWS); // [ROWS] neighbour point (-1: filler row)
-  int *coff = sidx + ROWS;                             // [MAXC + 1] first row of each centre
-  int *ccnt = coff + MAXC + 1;                         // [MAXC] genuine rows of each centre
-  float *gmax = reinterpret_cast<float *>(ccnt + MAXC);  // [ceil32(c3)][NG]
+  float *buf = smem;                                     // [rowsC][RP]
+  float *sdx = buf + rowsC * RP;                         // [3][ROWS]
+  int *sidx = reinterpret_cast<int *>(sdx + 3 * ROWS);   // [ROWS] neighbour point (-1: filler row)
+  int *coff2 = sidx + ROWS;                              // [2][CT] first row of each centre, double-buffered
+  float *gmax = reinterpret_cast<float *>(coff2 + 2 * CT);   // [ceil32(c3)][NG]
   const int tid = threadIdx.x;
-  for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+  // row table / centre offsets of a tile: one 16-byte entry per thread r < ROWS, one int per thread < CT
+  f32x4 rv = {__int_as_float(-1), 0.f, 0.f, 0.f};
+  int cv = 0;
+  auto fetch = [&](int tile) {
+    if (tile < total) {
+      if (tid < ROWS) rv = rowtab[(size_t)tile * ROWS + tid];
+      if (tid < MAXC + 1) cv = ctab[(size_t)tile * CT + tid];
+    }
+  };
+  auto stash = [&](int par) {
+    if (tid < ROWS) {
+      sidx[tid] = __float_as_int(rv[0]);
+      sdx[tid] = rv[1];
+      sdx[ROWS + tid] = rv[2];
+      sdx[2 * ROWS + tid] = rv[3];
+    }
+    if (tid < MAXC + 1) coff2[par * CT + tid] = cv;
+  };
+  int par = 0;
+  fetch(blockIdx.x);
+  stash(0);
+  __syncthreads();
+  for (int tile = blockIdx.x; tile < total; tile += gridDim.x, par ^= 1) {
   const int4 td = flat[tile];
   const size_t b = (size_t)td.x;
   const int first = td.y, nc = td.z;
-  const float *xyz = a.xyz + b * a.N * 3;
-
-  if (tid < nc) {   // nc <= ROWS/4 <= 64: one lane per centre fetches its count, then a serial LDS prefix
-    int n = a.cnt[b * a.S + first + tid];
-    ccnt[tid] = n < 1 ? 1 : (n > K ? K : n);
-  }
-  for (int r = tid; r < ROWS; r += kThreads) sidx[r] = -1;
-  __syncthreads();
-  if (tid == 0) {
-    int off = 0;
-    for (int c = 0; c < nc; c++) {
-      coff[c] = off;
-      off += (ccnt[c] + 3) & ~3;
-    }
-    coff[nc] = off;
-  }
-  __syncthreads();
-  // one thread per (centre, row-in-centre): neighbour index and dxyz; padding rows repeat the first
-  for (int e = tid; e < nc * K; e += kThreads) {
-    const int c = e / K, k = e - c * K;
-    const int g = coff[c + 1] - coff[c];
-    if (k < g) {
-      const int s = first + c;
-      const int ci = a.centre_idx ? a.centre_idx[b * a.S + s] : s;
-      const int i = a.idx[(b * a.S + s) * K + (k < ccnt[c] ? k : 0)];
-      const int r = coff[c] + k;
-      sidx[r] = i;
-      sdx[r] = xyz[i * 3] - xyz[ci * 3];
-      sdx[ROWS + r] = xyz[i * 3 + 1] - xyz[ci * 3 + 1];
-      sdx[2 * ROWS + r] = xyz[i * 3 + 2] - xyz[ci * 3 + 2];
-    }
-  }
-  __syncthreads();
+  const int *coff = coff2 + par * CT;
   if (!(a.dbg & 1)) {  // layer 1 (BatchNorm scale folded into wa / P, shift added here)
     const float *pq = a.pq ? a.pq + b * a.N * (size_t)a.pqw : nullptr;
-    const int total = ROWS * (c1 >> 2);
+    const int total1 = ROWS * (c1 >> 2);
     constexpr int dR = kThreads % ROWS, dO = kThreads / ROWS;
     int r = tid % ROWS, oq = tid / ROWS;
-    for (int e0 = tid; e0 < total; e0 += 4 * kThreads) {
+    for (int e0 = tid; e0 < total1; e0 += 4 * kThreads) {
       f32x4 p4[4];
       int rr[4], oo[4];
 #pragma unroll
@@ -418,7 +485,7 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
         rr[u] = r;
         oo[u] = oq << 2;
         p4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (pq && e0 + u * kThreads < total && sidx[r] >= 0)
+        if (pq && e0 + u * kThreads < total1 && sidx[r] >= 0)
           p4[u] = *reinterpret_cast<const f32x4 *>(pq + (size_t)sidx[r] * a.pqw + oo[u]);
         r += dR;
         oq += dO;
@@ -426,7 +493,7 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        if (e0 + u * kThreads < total) {
+        if (e0 + u * kThreads < total1) {
           const int rw = rr[u], o = oo[u];
           f32x4 v = {0.f, 0.f, 0.f, 0.f};
           if (sidx[rw] >= 0) {
@@ -443,6 +510,7 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
     }
   }
   __syncthreads();
+  fetch(tile + gridDim.x);   // lands during the matrix phases; sidx / sdx are dead from here on
   if (!(a.dbg & 2))
   tile_dense2<TB, NR2, W2>(buf, c1, a.wp2, ceil32(c2), true,
                            [&](float v, int o, int t) { buf[o * RP + t] = fmaxf(v, 0.f); }, a.sh2);
@@ -459,6 +527,7 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
       if ((l31 & 3) == 0) gmax[o * NG + tb * 8 + (l31 >> 2)] = v;
     }
   }, a.sh3);
+  stash(par ^ 1);            // next tile's rows (the other coff buffer: this tile's is read below)
   __syncthreads();
   if (!(a.dbg & 8))
   for (int e = tid; e < c3 * nc; e += kThreads) {
@@ -468,7 +537,8 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
     for (int q = (coff[c] >> 2) + 1; q < (coff[c + 1] >> 2); q++) m = fmaxf(m, g[q]);
     a.out[(b * c3 + o) * a.S + first + c] = m;
   }
-  __syncthreads();   // the next tile re-uses every staging array
+  // no barrier needed here: the next tile's layer 1 writes buf (dead since layer 3), its layer 3 writes gmax
+  // only after two more barriers, and coff / sidx / sdx of the next tile were stashed before the last one
   }
 }
 
@@ -561,7 +631,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
       r.dbg = rdbg;
       r.out = p.out;
       const int rowsCr = p.c1 > ceil32(p.c2) ? p.c1 : ceil32(p.c2);
-      const size_t lds = ((size_t)rowsCr * (ROWS + 1) + 3 * ROWS + ROWS + 2 * (ROWS / 4) + 2 +
+      const size_t lds = ((size_t)rowsCr * (ROWS + 1) + 3 * ROWS + ROWS + 2 * (ROWS / 4 + 4) +
                           (size_t)ceil32(p.c3) * (ROWS / 4)) * sizeof(float);
       if (lds <= 150 * 1024) {
         if (p.D && !p.pq_ready) {
@@ -570,6 +640,12 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
         }
         hipLaunchKernelGGL(sa_rag_plan_kernel, dim3((p.B + 63) / 64), dim3(64), 0, st, r, ROWS);
         hipLaunchKernelGGL(sa_rag_scan_kernel, dim3(1), dim3(1024), 0, st, p.B, r.maxT, r.ws);
+        {
+          long long wgs = ((long long)p.B * r.maxT + 3) / 4;
+          if (wgs > 4096) wgs = 4096;
+          if (tb == 2) hipLaunchKernelGGL(sa_rag_rows_kernel<64>, dim3((unsigned)wgs), dim3(256), 0, st, r);
+          else hipLaunchKernelGGL(sa_rag_rows_kernel<128>, dim3((unsigned)wgs), dim3(256), 0, st, r);
+        }
         if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
         static const int n_cu = [] {
           int dev = 0, n = 0;
@@ -694,6 +770,15 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   }
   if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
   return PCR_OK;
+}
+
+PCR_EXPORT long pcr_sa_tile_ws_ints(int B, int S, int K, int c2, int c3) {
+  if (B < 1 || S < 1 || K < 1 || c2 < 1 || c3 < 1) return 0;
+  const int rows = (ceil32(c2) > 128 || ceil32(c3) > 128) ? 64 : 128;   // sa2_try's tile choice
+  if (K > rows) return 0;
+  const int per_tile = rows / ((K + 3) & ~3);
+  const int maxT = (S + per_tile - 1) / per_tile;
+  return (long)rag_ws_ints(B, maxT, rows);
 }
 
 PCR_EXPORT int pcr_dense_pm_f32(const float *x, const float *wp, float *y, int B, int cin, int cout, int L,

@@ -177,7 +177,8 @@ class SaPlan:
         ragged = cnt is not None and self.fast and self.mode == 1
         if ragged:
             assert cnt.is_contiguous() and cnt.dtype == torch.int32 and cnt.shape == (B, S)
-            tile_ws = torch.empty((B * (6 * S + 1) + 4,), dtype=torch.int32, device=xyz.device)
+            n_ws = L.load().pcr_sa_tile_ws_ints(B, S, K, self.couts[1], self.couts[2])
+            tile_ws = torch.empty((max(n_ws, 1),), dtype=torch.int32, device=xyz.device)
             p.cnt, p.tile_ws = _p(cnt), _p(tile_ws)
         if self.fast:
             p.wa = _p(self.wa)
