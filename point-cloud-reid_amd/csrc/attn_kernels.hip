@@ -123,7 +123,8 @@ __global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
     const float *wm = p.wmerge + (size_t)o * d + v0;
     const float *kr = KVl + dd * ld + v0;
     float m = 0.f;
-    for (int v = 0; v < dh; v++) m += wm[v] * kr[v];
+#pragma unroll 8
+    for (int v = 0; v < dh; v++) m += wm[v] * kr[v];   // (unrolled: batches of independent loads)
     const int kb = dd >> 3, rem = dd & 7;
     kv[(((size_t)kb * d + o) * 2 + (rem & 1)) * 4 + (rem >> 1)] = m;
   }

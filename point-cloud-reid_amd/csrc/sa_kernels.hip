@@ -549,27 +549,24 @@ struct DensePmArgs {
   int cin, cout, L;
 };
 
+// NR: cout-block rounds per wave (2 when cout > 128).  X and Y share one LDS buffer (barrier between the
+// k-loop and the epilogue), so a 128 -> 128 table needs 33 KB and four workgroups fit a CU.
+template <int NR>
 __global__ __launch_bounds__(kThreads) void dense_pm_kernel(DensePmArgs a) {
   constexpr int TB = 2, T = 64, RP = 65;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int cinP = ceil8(a.cin), cout = a.cout;
-  float *X = smem;
-  float *Y = smem + cinP * RP;
+  float *X = smem;   // [max(cinP, ceil32(cout))][RP]
   const size_t b = blockIdx.y;
   const int t0 = blockIdx.x * T;
-  for (int e = threadIdx.x; e < cinP * T; e += kThreads) {
-    const int c = e / T, t = e - c * T;
-    X[c * RP + t] = (c < a.cin && t0 + t < a.L) ? a.x[(b * a.cin + c) * a.L + t0 + t] : 0.f;
-  }
+  load_tile(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
   __syncthreads();
-  tile_dense2<TB, 2>(X, cinP, a.wp, ceil32(cout), false, [&](float v, int o, int t) {
-    if (o < cout) Y[o * RP + t] = v;
-  });
+  tile_dense2<TB, NR>(X, cinP, a.wp, ceil32(cout), true, [&](float v, int o, int t) { X[o * RP + t] = v; });
   __syncthreads();
   float *out = a.y + (b * a.L + t0) * (size_t)cout;
   for (int e = threadIdx.x; e < cout * T; e += kThreads) {
     const int t = e / cout, c = e - t * cout;
-    if (t0 + t < a.L) out[(size_t)t * cout + c] = Y[c * RP + t];
+    if (t0 + t < a.L) out[(size_t)t * cout + c] = X[c * RP + t];
   }
 }
 
@@ -787,11 +784,19 @@ PCR_EXPORT int pcr_dense_pm_f32(const float *x, const float *wp, float *y, int B
   if (B == 0) return PCR_OK;
   if (B > 65535) return PCR_ERR_INVALID;
   DensePmArgs d{x, wp, y, cin, cout, L};
-  size_t lds = ((size_t)(ceil8(cin) + cout) * 65) * sizeof(float);
+  const int rows = ceil8(cin) > ceil32(cout) ? ceil8(cin) : ceil32(cout);
+  size_t lds = (size_t)rows * 65 * sizeof(float);
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
-  static bool ok = allow_big_lds(dense_pm_kernel);
-  (void)ok;
-  hipLaunchKernelGGL(dense_pm_kernel, dim3((L + 63) / 64, B), dim3(kThreads), lds, pcr_s(stream), d);
+  const dim3 grid((L + 63) / 64, B);
+  if (cout > 128) {
+    static bool ok = allow_big_lds(dense_pm_kernel<2>);
+    (void)ok;
+    hipLaunchKernelGGL(dense_pm_kernel<2>, grid, dim3(kThreads), lds, pcr_s(stream), d);
+  } else {
+    static bool ok = allow_big_lds(dense_pm_kernel<1>);
+    (void)ok;
+    hipLaunchKernelGGL(dense_pm_kernel<1>, grid, dim3(kThreads), lds, pcr_s(stream), d);
+  }
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }

@@ -233,7 +233,8 @@ __device__ __forceinline__ void tile_dense2(const float *__restrict__ in, int CP
     tile_dense_impl<TB, 1, 4, TILE>(in, CP, wp, OP, sync_epi, epi, init);
   } else {
     const int nCB = OP >> 5;
-    if (nCB >= 3) tile_dense_impl<TB, NR, 1, TILE>(in, CP, wp, OP, sync_epi, epi, init);
+    if (nCB > 4) tile_dense_impl<TB, NR, 1, TILE>(in, CP, wp, OP, sync_epi, epi, init);
+    else if (nCB >= 3) tile_dense_impl<TB, 1, 1, TILE>(in, CP, wp, OP, sync_epi, epi, init);   // one round is enough
     else if (nCB == 2) tile_dense_impl<TB, 1, 2, TILE>(in, CP, wp, OP, sync_epi, epi, init);
     else tile_dense_impl<TB, 1, 4, TILE>(in, CP, wp, OP, sync_epi, epi, init);
   }
@@ -313,12 +314,60 @@ __device__ __forceinline__ void tile_layernorm(float *buf, int C, int RP, int T,
   __syncthreads();
 }
 
-// loads a [C][T] tile of a (B,C,L) tensor into LDS rows [0,CP), zero beyond C or beyond L
+// loads a [C][T] tile of a (B,C,L) tensor into LDS rows [0,CP), zero beyond C or beyond L.
+// Every thread issues a BATCH of independent loads from clamped (always valid) addresses and selects
+// afterwards: a plain `dst = ok ? src[..] : 0` loop compiles to one load + s_waitcnt vmcnt(0) per
+// element, i.e. CP*T/256 serial memory round trips per workgroup.  16-byte loads when the tile is whole
+// and aligned (t0 is a multiple of 32 in every caller).
 __device__ __forceinline__ void load_tile(float *dst, int RP, const float *src, int C, int CP, int L,
                                           int t0, int T) {
-  for (int e = threadIdx.x; e < CP * T; e += blockDim.x) {
-    const int c = e / T, t = e - c * T;
-    dst[c * RP + t] = (c < C && t0 + t < L) ? src[(size_t)c * L + t0 + t] : 0.f;
+  const bool vec = ((L & 3) == 0) && (t0 + T <= L) && ((reinterpret_cast<size_t>(src) & 15) == 0);
+  if (vec) {
+    const int Q = T >> 2, totq = CP * Q;
+    for (int e0 = threadIdx.x; e0 < totq; e0 += 4 * kThreads) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = e0 + u * kThreads;
+        const int c = e / Q, q = e - c * Q;
+        const bool ok = e < totq && c < C;
+        const f32x4 x = *reinterpret_cast<const f32x4 *>(src + (size_t)(ok ? c : 0) * L + t0 + 4 * q);
+        v[u] = ok ? x : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = e0 + u * kThreads;
+        if (e < totq) {
+          const int c = e / Q, q = e - c * Q;
+          float *d = dst + c * RP + 4 * q;
+          d[0] = v[u][0];
+          d[1] = v[u][1];
+          d[2] = v[u][2];
+          d[3] = v[u][3];
+        }
+      }
+    }
+  } else {
+    const int total = CP * T;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 8 * kThreads) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int e = e0 + u * kThreads;
+        const int c = e / T, t = e - c * T;
+        const bool ok = e < total && c < C && t0 + t < L;
+        const float x = src[ok ? (size_t)c * L + t0 + t : 0];
+        v[u] = ok ? x : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int e = e0 + u * kThreads;
+        if (e < total) {
+          const int c = e / T, t = e - c * T;
+          dst[c * RP + t] = v[u];
+        }
+      }
+    }
   }
 }
 
