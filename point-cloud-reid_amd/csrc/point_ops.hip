@@ -215,6 +215,95 @@ __global__ __launch_bounds__(NT) void fps_fast_kernel(const float *__restrict__ 
   }
 }
 
+// One WAVE per cloud, up to 1024 points, no barrier and no cross-wave exchange: lane l keeps points
+// l, l+64, ... in registers as pairs (packed f32 subtract / multiply / add: same IEEE operations as
+// pcr_sqdist3, two points per instruction), the running maximum of the updated distances comes from a
+// v_max3 chain, and the reference's tie order (see fps_fast_kernel) is only evaluated among the points
+// that ATTAIN the wave maximum.  Coordinates must be finite (as everywhere in this file).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t dpp_max_u32(uint32_t v) {
+  uint32_t o;
+  o = dpp_u32<0xB1>(v); v = o > v ? o : v;
+  o = dpp_u32<0x4E>(v); v = o > v ? o : v;
+  o = dpp_u32<0x141>(v); v = o > v ? o : v;
+  o = dpp_u32<0x140>(v); v = o > v ? o : v;
+  const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+  const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+  const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
+}
+
+template <int PP>   // point PAIRS per lane: n <= 128 * PP
+__global__ __launch_bounds__(64) void fps_wave_kernel(const float *__restrict__ xyz, float *__restrict__ temp,
+                                                      int *__restrict__ idxs, int n, int m, int block, int logb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  f32x4 *sp = reinterpret_cast<f32x4 *>(smem_raw);   // [n] {x, y, z, -}: one 16-byte broadcast read per pick
+  const int lane = threadIdx.x;
+  const size_t cloud = blockIdx.x;
+  xyz += cloud * n * 3;
+  temp += cloud * n;
+  idxs += cloud * m;
+  // the running minimum distances are kept as BITS: for floats >= +0 the unsigned order of the bit
+  // patterns is the float order, and integer min / max need no NaN canonicalisation instructions
+  f32x2 px[PP], py[PP], pz[PP];
+  uint32_t t[2 * PP], low[2 * PP];
+#pragma unroll
+  for (int p = 0; p < 2 * PP; p++) {
+    const int k = lane + 64 * p;
+    const bool ok = k < n;
+    const float *q = xyz + (size_t)(ok ? k : 0) * 3;
+    const float x = q[0], y = q[1], z = q[2], tk = temp[ok ? k : 0];
+    px[p >> 1][p & 1] = ok ? x : 0.f;
+    py[p >> 1][p & 1] = ok ? y : 0.f;
+    pz[p >> 1][p & 1] = ok ? z : 0.f;
+    t[p] = ok ? __float_as_uint(tk) : 0u;   // min(d, 0) = 0: a point beyond n never beats a real one (low = 0)
+    if (ok) sp[k] = f32x4{x, y, z, 0.f};
+    const uint32_t tr = (uint32_t)k & (uint32_t)(block - 1);
+    const uint32_t rev = logb ? (__brev(tr) >> (32 - logb)) : 0u;
+    low[p] = ok ? ((((uint32_t)(block - 1) - rev) << 22) | (0x3FFFFFu - (uint32_t)k)) : 0u;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // this wave's LDS writes (lgkmcnt(0)); there is no other wave
+  __builtin_amdgcn_wave_barrier();
+  int old = 0;
+  if (lane == 0) idxs[0] = 0;
+  for (int j = 1; j < m; j++) {
+    const f32x4 o = sp[old];
+    const f32x2 x1 = {o[0], o[0]}, y1 = {o[1], o[1]}, z1 = {o[2], o[2]};
+    uint32_t mx = 0u;
+#pragma unroll
+    for (int p = 0; p < PP; p++) {
+      const f32x2 dx = px[p] - x1, dy = py[p] - y1, dz = pz[p] - z1;
+      const f32x2 a = dx * dx;
+      const f32x2 b = dy * dy;
+      const f32x2 c = dz * dz;
+      const f32x2 s = a + b;
+      const f32x2 d = s + c;
+      const uint32_t d0 = __float_as_uint(d[0]), d1 = __float_as_uint(d[1]);
+      t[2 * p] = d0 < t[2 * p] ? d0 : t[2 * p];
+      t[2 * p + 1] = d1 < t[2 * p + 1] ? d1 : t[2 * p + 1];
+      const uint32_t m01 = t[2 * p] > t[2 * p + 1] ? t[2 * p] : t[2 * p + 1];
+      mx = m01 > mx ? m01 : mx;
+    }
+    const uint32_t best = dpp_max_u32(mx);
+    uint32_t lo = 0u;
+#pragma unroll
+    for (int p = 0; p < 2 * PP; p++) {
+      const uint32_t l = t[p] == best ? low[p] : 0u;
+      lo = l > lo ? l : lo;
+    }
+    lo = dpp_max_u32(lo);
+    old = (int)(0x3FFFFFu - (lo & 0x3FFFFFu));
+    if (lane == 0) idxs[j] = old;
+  }
+#pragma unroll
+  for (int p = 0; p < 2 * PP; p++) {
+    const int k = lane + 64 * p;
+    if (k < n) temp[k] = __uint_as_float(t[p]);
+  }
+}
+
 int fps_launch(bool dist, const float *data, float *temp, int *idx, int B, int N, int M,
                hipStream_t st) {
   if (!data || !temp || !idx || B < 0 || N < 1 || N >= (1 << 22) || M < 0) return PCR_ERR_INVALID;
@@ -222,14 +311,23 @@ int fps_launch(bool dist, const float *data, float *temp, int *idx, int B, int N
   int logb = 0;
   while ((2 << logb) <= N && logb < 10) logb++;  // block = min(1024, 2^floor(log2 N))
   int block = 1 << logb;
+  if (!dist && N <= 1024 && M > 1) {
+    const size_t lds_wave = (size_t)N * 16;
+    dim3 gw(B), bw(64);
+#define PCR_FPS_WAVE(PPv) hipLaunchKernelGGL((fps_wave_kernel<PPv>), gw, bw, lds_wave, st, data, temp, idx, N, M, block, logb)
+    if (N <= 128) PCR_FPS_WAVE(1);
+    else if (N <= 256) PCR_FPS_WAVE(2);
+    else if (N <= 512) PCR_FPS_WAVE(4);
+    else PCR_FPS_WAVE(8);
+#undef PCR_FPS_WAVE
+    PCR_CHECK_LAUNCH();
+    return PCR_OK;
+  }
   if (!dist && N <= 4096 && M > 1) {
     const size_t lds_fast = 64 + (size_t)3 * N * sizeof(float);
     dim3 gf(B);
 #define PCR_FPS_FAST(P, T) hipLaunchKernelGGL((fps_fast_kernel<P, T>), gf, dim3(T), lds_fast, st, data, temp, idx, N, M, block, logb)
-    // (a one-wave-per-cloud form, NT = 64 with 16 points per lane and no barrier, measured 35 % slower at
-    // 1024 clouds x 1024 points: the serial chain per step is longer than the barrier it saves)
-    if (false) {
-    } else if (N <= 256) PCR_FPS_FAST(1, 256);
+    if (N <= 256) PCR_FPS_FAST(1, 256);
     else if (N <= 512) PCR_FPS_FAST(2, 256);
     else if (N <= 1024) PCR_FPS_FAST(4, 256);
     else if (N <= 2048) PCR_FPS_FAST(8, 256);
@@ -300,6 +398,77 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict
   if (valid)
     for (int l = cnt; l < K; l++) out[l] = first;  // first == 0 when nothing was hit
   if (valid && cnt_out) cnt_out[b * m + p] = cnt;  // number of genuine hits; rows [cnt,K) are copies of row 0
+}
+
+// Register-resident variant for clouds of up to 1024 points: a WAVE owns a run of centres and keeps the
+// whole cloud in registers (lane l holds points l, l+64, ...), so a centre costs PPL distance
+// evaluations per lane instead of N serial LDS round trips per thread; hits are rare (a few per 1024
+// points), so the ordered compaction (ballot + prefix popcount) sits behind a wave-uniform branch.
+// Same hit predicate, same "first K in index order, pad with the first hit" result as above.
+template <int PPL>
+__global__ __launch_bounds__(256) void ball_query_reg_kernel(const float *__restrict__ centres,
+                                                             const float *__restrict__ xyz,
+                                                             int *__restrict__ idx, int n, int m,
+                                                             float min_r2, float max_r2, int K,
+                                                             int *__restrict__ cnt_out, int cpw) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t b = blockIdx.y;
+  const float *cloud = xyz + b * n * 3;
+  float px[PPL], py[PPL], pz[PPL];
+#pragma unroll
+  for (int j = 0; j < PPL; j++) {
+    const int i = j * 64 + lane;
+    const bool ok = i < n;
+    const float *q = cloud + (size_t)(ok ? i : 0) * 3;
+    const float x = q[0], y = q[1], z = q[2];
+    px[j] = ok ? x : INFINITY;   // a point at infinity is never inside a ball
+    py[j] = ok ? y : INFINITY;
+    pz[j] = ok ? z : INFINITY;
+  }
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int c0 = (blockIdx.x * 4 + wave) * cpw;
+  const int c1 = c0 + cpw < m ? c0 + cpw : m;
+  for (int c = c0; c < c1; c++) {
+    const float *cc = centres + (b * m + c) * 3;
+    const float cx = cc[0], cy = cc[1], cz = cc[2];
+    int *out = idx + (b * m + c) * (size_t)K;
+    int cnt = 0, first = 0;
+#pragma unroll
+    for (int j = 0; j < PPL; j++) {
+      if (cnt < K) {   // wave-uniform
+        const float d2 = pcr_sqdist3(px[j], py[j], pz[j], cx, cy, cz);
+        const bool hit = d2 == 0.f || (d2 >= min_r2 && d2 < max_r2);
+        const unsigned long long mask = __ballot(hit);
+        if (mask) {
+          const int pos = cnt + __popcll(mask & lt);
+          if (hit && pos < K) out[pos] = j * 64 + lane;
+          if (cnt == 0) first = j * 64 + (int)__builtin_ctzll(mask);
+          cnt += __popcll(mask);
+        }
+      }
+    }
+    if (cnt > K) cnt = K;
+    for (int l = cnt + lane; l < K; l += 64) out[l] = first;   // first == 0 when nothing was hit
+    if (cnt_out && lane == 0) cnt_out[b * m + c] = cnt;
+  }
+}
+
+static void ball_query_launch(const float *centres, const float *xyz, int *idx, int *cnt, int B, int N, int M,
+                              float min_r2, float max_r2, int K, hipStream_t st) {
+  if (N <= 1024) {
+    const int cpw = 16;                                  // centres per wave
+    const dim3 grid((M + 4 * cpw - 1) / (4 * cpw), B), blk(256);
+    if (N <= 256)
+      hipLaunchKernelGGL(ball_query_reg_kernel<4>, grid, blk, 0, st, centres, xyz, idx, N, M, min_r2, max_r2, K, cnt, cpw);
+    else if (N <= 512)
+      hipLaunchKernelGGL(ball_query_reg_kernel<8>, grid, blk, 0, st, centres, xyz, idx, N, M, min_r2, max_r2, K, cnt, cpw);
+    else
+      hipLaunchKernelGGL(ball_query_reg_kernel<16>, grid, blk, 0, st, centres, xyz, idx, N, M, min_r2, max_r2, K, cnt, cpw);
+  } else {
+    hipLaunchKernelGGL(ball_query_kernel, dim3((M + 255) / 256, B), dim3(256), 0, st, centres, xyz, idx, N, M,
+                       min_r2, max_r2, K, cnt);
+  }
 }
 
 // --------------------------------------------------------------------------- heap kNN ----
@@ -645,8 +814,7 @@ PCR_EXPORT int pcr_ball_query_f32(const float *centres, const float *xyz, int *i
   if (B == 0 || M == 0) return PCR_OK;
   if (B > 65535) return PCR_ERR_INVALID;
   float max_r2 = max_r * max_r, min_r2 = min_r * min_r;
-  hipLaunchKernelGGL(ball_query_kernel, dim3((M + 255) / 256, B), dim3(256), 0, pcr_s(stream),
-                     centres, xyz, idx, N, M, min_r2, max_r2, K, (int *)nullptr);
+  ball_query_launch(centres, xyz, idx, nullptr, B, N, M, min_r2, max_r2, K, pcr_s(stream));
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }
@@ -657,8 +825,7 @@ PCR_EXPORT int pcr_ball_query_cnt_f32(const float *centres, const float *xyz, in
   if (B == 0 || M == 0) return PCR_OK;
   if (B > 65535) return PCR_ERR_INVALID;
   float max_r2 = max_r * max_r, min_r2 = min_r * min_r;
-  hipLaunchKernelGGL(ball_query_kernel, dim3((M + 255) / 256, B), dim3(256), 0, pcr_s(stream),
-                     centres, xyz, idx, N, M, min_r2, max_r2, K, cnt);
+  ball_query_launch(centres, xyz, idx, cnt, B, N, M, min_r2, max_r2, K, pcr_s(stream));
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }

@@ -43,7 +43,8 @@ def test_fps_with_dist_bit_exact(ops):
 
 @pytest.mark.parametrize("n,m,k,r0,r1,kind", [(1024, 512, 32, 0.0, 0.2, "box"), (1024, 512, 32, 0.0, 0.6, "randn"),
                                               (2500, 300, 64, 0.1, 0.5, "dup"), (50, 50, 8, 0.0, 0.01, "randn"),
-                                              (128, 128, 16, 0.0, 100.0, "dup")])
+                                              (128, 128, 16, 0.0, 100.0, "dup"), (300, 77, 20, 0.0, 0.8, "randn"),
+                                              (512, 128, 64, 0.0, 0.4, "box"), (1000, 130, 70, 0.05, 0.9, "dup")])
 def test_ball_query_bit_exact(ops, n, m, k, r0, r1, kind):
     xyz = T.synthetic_clouds(2, n, seed=5, kind=kind).numpy()
     c = xyz[:, :m].copy()
@@ -51,6 +52,21 @@ def test_ball_query_bit_exact(ops, n, m, k, r0, r1, kind):
     want = P.ball_query(r0, r1, k, xyz, c)
     got = ops.ball_query(r0, r1, k, dev(xyz), dev(c)).cpu().numpy()
     assert (got == want).all()
+
+
+@pytest.mark.parametrize("n,m,k,r1,kind", [(1024, 512, 32, 0.2, "box"), (300, 77, 20, 0.8, "randn"),
+                                           (1500, 64, 16, 0.3, "dup")])
+def test_ball_query_cnt_counts_genuine_hits(ops, n, m, k, r1, kind):
+    from mmdet3d.ops import ball_query_cnt
+    xyz = T.synthetic_clouds(2, n, seed=6, kind=kind).numpy()
+    c = xyz[:, :m].copy()
+    c[:, ::5] += 0.03
+    idx, cnt = ball_query_cnt(0.0, r1, k, dev(xyz), dev(c))
+    assert (idx.cpu().numpy() == P.ball_query(0.0, r1, k, xyz, c)).all()
+    d = c[:, :, None, :] - xyz[:, None, :, :]                      # float32, same operation order as the kernel
+    d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    want = np.minimum(((d2 == 0) | (d2 < np.float32(r1) * np.float32(r1))).sum(-1), k)
+    assert (cnt.cpu().numpy() == want).all()
 
 
 @pytest.mark.parametrize("n,m,k,kind", [(256, 100, 16, "randn"), (1000, 70, 100, "dup"), (128, 128, 1, "box"),
