@@ -157,17 +157,21 @@ typedef struct pcr_sa_params {
   int *tile_ws;
   float *pq_ws;
   int pq_ready; /* nonzero: pq_ws already holds the tables (caller ran pcr_dense_pm_f32 itself) */
+  /* Layouts.  feat_point_major: feat is (B,N,D) instead of (B,D,N).  out_point_major: out is (B,S,c3) instead
+   * of (B,c3,S): a centre's c3 channels are then one contiguous run (full-line stores; the (B,c3,S) form writes
+   * 4-byte pieces S floats apart).  Both are pure layout choices; values are identical. */
+  int feat_point_major, out_point_major;
   float *out;
 } pcr_sa_params;
 int pcr_sa_mlp_f32(const pcr_sa_params *p, pcr_stream_t stream);
 /* ints of pcr_sa_params.tile_ws for the duplicate-free evaluation (tile lists + per-tile row tables) */
 long pcr_sa_tile_ws_ints(int B, int S, int K, int c2, int c3);
 
-/* Per-point linear map with POINT-major output: x (B,cin,L) channel-major -> y (B,L,cout) = W x,
- * wp packed (cout,cin), cout <= 256.  This is the table builder of the decomposed first SA layer
- * (pcr_sa_mlp_f32 runs it itself unless pq_ready is set). */
+/* Per-point linear map with POINT-major output: x (B,cin,L) channel-major (or (B,L,cin) when x_point_major)
+ * -> y (B,L,cout) = W x, wp packed (cout,cin), cout <= 256.  This is the table builder of the decomposed first
+ * SA layer (pcr_sa_mlp_f32 runs it itself unless pq_ready is set). */
 int pcr_dense_pm_f32(const float *x, const float *wp, float *y, int B, int cin, int cout, int L,
-                     pcr_stream_t stream);
+                     int x_point_major, pcr_stream_t stream);
 
 /* Linear-attention block shared by Self_Attention (models/pointnet2_utils.py:90-114), FP_SA
  * (:407-437) and corss_attention (models/attention.py:192-219), in two kernels.
@@ -235,6 +239,9 @@ int pcr_pool_both_f32(const float *x, float *out, int B, int C, int L, pcr_strea
  * (models/pointnet.py:27-45, 67-85, 103-127).  act: 0 none, 1 ReLU.  wp packed. */
 int pcr_dense_f32(const float *x, const float *wp, const float *scale, const float *shift, float *y,
                   int B, int cin, int cout, int L, int act, pcr_stream_t stream);
+/* the same with x given point-major, (B,L,cin) */
+int pcr_dense_xpm_f32(const float *x, const float *wp, const float *scale, const float *shift, float *y,
+                      int B, int cin, int cout, int L, int act, pcr_stream_t stream);
 
 /* ---- PointNet encoder pieces (models/pointnet.py:10-127) and LinearRes rows (lanegcn_nets.py:228-241) ---- */
 

@@ -113,6 +113,7 @@ struct DenseArgs {
   float *y;
   int cin, cout, L, act;
   long w_bstride;
+  int x_pm;   // x is (B,L,cin)
 };
 
 template <int TB>
@@ -125,7 +126,8 @@ __global__ __launch_bounds__(kThreads) void dense_kernel(DenseArgs a) {
   const int t0 = blockIdx.x * T;
   const int chunk0 = blockIdx.z * 256;
   const int chunkP = coutP - chunk0 < 256 ? coutP - chunk0 : 256;
-  load_tile(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
+  if (a.x_pm) load_tile_pm(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
+  else load_tile(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
   __syncthreads();
   const float *sc = a.scale, *sh = a.shift;
   const int cout = a.cout, act = a.act, L = a.L;
@@ -248,11 +250,11 @@ PCR_EXPORT int pcr_pool_both_f32(const float *x, float *out, int B, int C, int L
 }
 
 static int dense_launch(const float *x, const float *wp, long w_bstride, const float *scale, const float *shift,
-                        float *y, int B, int cin, int cout, int L, int act, pcr_stream_t stream) {
+                        float *y, int B, int cin, int cout, int L, int act, pcr_stream_t stream, int x_pm = 0) {
   if (!x || !wp || !y || B < 0 || cin < 1 || cout < 1 || L < 1) return PCR_ERR_INVALID;
   if (B == 0) return PCR_OK;
   if (B > 65535) return PCR_ERR_INVALID;
-  DenseArgs a{x, wp, scale, shift, y, cin, cout, L, act, w_bstride};
+  DenseArgs a{x, wp, scale, shift, y, cin, cout, L, act, w_bstride, x_pm};
   const int cinP = ceil8(cin);
   const int tb = ((size_t)cinP * 65 * 4 <= 72 * 1024 && L > 32) ? 2 : 1;
   size_t lds = (size_t)cinP * (32 * tb + 1) * sizeof(float);
@@ -269,6 +271,11 @@ static int dense_launch(const float *x, const float *wp, long w_bstride, const f
 PCR_EXPORT int pcr_dense_f32(const float *x, const float *wp, const float *scale, const float *shift,
                              float *y, int B, int cin, int cout, int L, int act, pcr_stream_t stream) {
   return dense_launch(x, wp, 0, scale, shift, y, B, cin, cout, L, act, stream);
+}
+
+PCR_EXPORT int pcr_dense_xpm_f32(const float *x, const float *wp, const float *scale, const float *shift,
+                                 float *y, int B, int cin, int cout, int L, int act, pcr_stream_t stream) {
+  return dense_launch(x, wp, 0, scale, shift, y, B, cin, cout, L, act, stream, 1);
 }
 
 PCR_EXPORT int pcr_dense_bmm_f32(const float *x, const float *wp_per_cloud, float *y, int B, int cin, int cout,

@@ -787,7 +787,7 @@ __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_kernel(const float *_
 }  // namespace
 
 // ------------------------------------------------------------------------------ C ABI ----
-PCR_EXPORT int pcr_abi_version(void) { return 1; }
+PCR_EXPORT int pcr_abi_version(void) { return 2; }
 
 PCR_EXPORT const char *pcr_status_string(int status) {
   switch (status) {

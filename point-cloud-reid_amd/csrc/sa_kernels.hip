@@ -1,4 +1,8 @@
 // Grouped set-abstraction MLP kernels (pcr_sa_mlp_f32).
+#include <stdio.h>
+
+#include <vector>
+
 #include "tile_dense.h"
 
 namespace {
@@ -28,6 +32,7 @@ __global__ __launch_bounds__(kThreads) void sa_mlp_kernel(SaArgs a) {
   // gather + relative / edge features -> bufA [C0P][RP]
   const float *xyz = p.xyz + b * N * 3;
   const float *feat = D ? p.feat + b * D * N : nullptr;
+  const size_t fs_c = p.feat_point_major ? 1 : (size_t)N, fs_n = p.feat_point_major ? (size_t)D : 1;
   for (int e = tid; e < a.C0P * ROWS; e += kThreads) {
     const int ch = e / ROWS, r = e - ch * ROWS;
     float v = 0.f;
@@ -39,10 +44,10 @@ __global__ __launch_bounds__(kThreads) void sa_mlp_kernel(SaArgs a) {
         v = xyz[i * 3 + ch] - xyz[ci * 3 + ch];
       } else if (p.mode == 0) {
         const int f = ch - 3;
-        if (f < D) v = feat[(size_t)f * N + ci];
-        else v = feat[(size_t)(f - D) * N + i] - feat[(size_t)(f - D) * N + ci];
+        if (f < D) v = feat[fs_c * f + fs_n * ci];
+        else v = feat[fs_c * (f - D) + fs_n * i] - feat[fs_c * (f - D) + fs_n * ci];
       } else {
-        v = feat[(size_t)(ch - 3) * N + i];
+        v = feat[fs_c * (ch - 3) + fs_n * i];
       }
     }
     bufA[ch * RP + r] = v;
@@ -79,7 +84,8 @@ __global__ __launch_bounds__(kThreads) void sa_mlp_kernel(SaArgs a) {
     const float *row = bufB + o * RP + c * K;
     float m = row[0];
     for (int k = 1; k < K; k++) m = fmaxf(m, row[k]);
-    p.out[(b * c3 + o) * p.S + c0 + c] = m;
+    if (p.out_point_major) p.out[(b * p.S + c0 + c) * c3 + o] = m;
+    else p.out[(b * c3 + o) * p.S + c0 + c] = m;
   }
 }
 
@@ -107,6 +113,7 @@ struct Sa2Args {
   int skew;                 // start-up stagger of the first generation of workgroups, in s_sleep(127) units
   const float *wp2, *wp3;
   const float *sh1, *sh2, *sh3;   // folded BatchNorm shifts (sh2/sh3 zero-padded to a multiple of 32)
+  int out_pm;               // out is (B,S,c3)
   float *out;
 };
 
@@ -253,19 +260,21 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
     // centre fastest across lanes: the nc outputs of one channel are adjacent in (B,c3,S), so a wave
     // store touches 64/nc lines instead of 64 (the store is still nc*4 bytes per line: see DESIGN.md 4.1)
     for (int e = tid; e < c3 * nc; e += kThreads) {
-      const int o = e / nc, c = e - o * nc;
+      const int o = a.out_pm ? e % c3 : e / nc, c = a.out_pm ? e / c3 : e - o * nc;
       const float *g = gmax + o * NG + c * gpc;
       float m = g[0];
       for (int k = 1; k < gpc; k++) m = fmaxf(m, g[k]);
-      a.out[(b * c3 + o) * a.S + c0 + c] = m;
+      if (a.out_pm) a.out[(b * a.S + c0 + c) * c3 + o] = m;
+      else a.out[(b * c3 + o) * a.S + c0 + c] = m;
     }
   } else {
     for (int e = tid; e < c3 * nc; e += kThreads) {
-      const int o = e / nc, c = e - o * nc;
+      const int o = a.out_pm ? e % c3 : e / nc, c = a.out_pm ? e / c3 : e - o * nc;
       const float *row = buf + o * RP + c * K;
       float m = row[0];
       for (int k = 1; k < K; k++) m = fmaxf(m, row[k]);
-      a.out[(b * c3 + o) * a.S + c0 + c] = m;
+      if (a.out_pm) a.out[(b * a.S + c0 + c) * c3 + o] = m;
+      else a.out[(b * c3 + o) * a.S + c0 + c] = m;
     }
   }
 }
@@ -296,6 +305,7 @@ struct RagArgs {
   const float *wa, *pq;
   int pqw;
   int dbg;                  // PCR_SA_DBG ablation mask (diagnostics only; 0 in production)
+  int out_pm;               // out is (B,S,c3)
   const float *wp2, *wp3, *sh1, *sh2, *sh3;
   float *out;
 };
@@ -314,28 +324,39 @@ __host__ __device__ inline size_t rag_ws_ints(int B, int maxT, int rows) {
   return rag_rowtab_off(B, maxT, rows) + (size_t)B * maxT * rows * 4;
 }
 
-__global__ void sa_rag_plan_kernel(RagArgs a, int rows_per_tile) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// one WAVE per cloud: the counts arrive 64 at a time with one coalesced load, the greedy walk itself runs
+// on the scalar unit (v_readlane with a uniform lane index), lane 0 stores the descriptors
+__global__ __launch_bounds__(256) void sa_rag_plan_kernel(RagArgs a, int rows_per_tile) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= a.B) return;
   const int *cnt = a.cnt + (size_t)b * a.S;
   int *tl = a.ws + rag_desc_off(a.B) + (size_t)b * 2 * a.maxT;
   int t = 0, used = 0, first = 0;
-  for (int s = 0; s < a.S; s++) {
-    int c = cnt[s];
+  for (int base = 0; base < a.S; base += 64) {
+    int c = base + lane < a.S ? cnt[base + lane] : 1;
     c = c < 1 ? 1 : (c > a.K ? a.K : c);
     const int g = (c + 3) & ~3;
-    if (used + g > rows_per_tile) {
-      tl[2 * t] = first;
-      tl[2 * t + 1] = s - first;
-      t++;
-      first = s;
-      used = 0;
+    const int nv = a.S - base < 64 ? a.S - base : 64;
+    for (int l = 0; l < nv; l++) {
+      const int gl = __builtin_amdgcn_readlane(g, l);
+      if (used + gl > rows_per_tile) {
+        if (lane == 0) {
+          tl[2 * t] = first;
+          tl[2 * t + 1] = base + l - first;
+        }
+        t++;
+        first = base + l;
+        used = 0;
+      }
+      used += gl;
     }
-    used += g;
   }
-  tl[2 * t] = first;
-  tl[2 * t + 1] = a.S - first;
-  a.ws[b] = t + 1;
+  if (lane == 0) {
+    tl[2 * t] = first;
+    tl[2 * t + 1] = a.S - first;
+    a.ws[b] = t + 1;
+  }
 }
 
 __global__ __launch_bounds__(1024) void sa_rag_scan_kernel(int B, int maxT, int *ws) {
@@ -429,9 +450,28 @@ __global__ __launch_bounds__(256) void sa_rag_rows_kernel(RagArgs a) {
   }
 }
 
+// PCR_SA_TRACE=<file> (diagnostics only): wave 0 of every workgroup stamps the shader clock at the phase
+// boundaries of its first kTraceTiles tiles; the host dumps the buffer after the launch
+constexpr int kTraceWgs = 1024, kTraceTiles = 24, kTraceMarks = 8;
+__device__ unsigned long long g_rag_trace[kTraceWgs * (2 + kTraceTiles * kTraceMarks)];
+
 template <int TB, int NR, int W2, int W3, int NR2 = NR>
 __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   constexpr int ROWS = 32 * TB, RP = ROWS + 1, MAXC = ROWS / 4, NG = ROWS / 4, CT = MAXC + 4;
+  const int C3P = ceil32(a.c3);           // gmax is [NG quads][C3P]
+  constexpr int QS = kThreads / ROWS;     // channel quads advance by QS per item: a thread keeps ONE row
+  constexpr int NI = 8;                   // 16-byte table pieces a thread holds in registers
+  const bool tracing = (a.dbg & 256) && threadIdx.x == 0 && blockIdx.x < kTraceWgs;
+  unsigned long long *trace = g_rag_trace + (size_t)blockIdx.x * (2 + kTraceTiles * kTraceMarks);
+  int trace_it = 0;
+  if (tracing) {
+    trace[0] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID, 32 bits
+    trace[1] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+  }
+#define PCR_MARK(m)                                                                                    \
+  do {                                                                                                 \
+    if (tracing && trace_it < kTraceTiles) trace[2 + trace_it * kTraceMarks + (m)] = __builtin_readcyclecounter(); \
+  } while (0)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int c1 = a.c1, c2 = a.c2, c3 = a.c3;
   const int total = a.ws[a.B];
@@ -439,106 +479,128 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   const int *ctab = a.ws + rag_ctab_off(a.B, a.maxT);
   const f32x4 *rowtab = reinterpret_cast<const f32x4 *>(a.ws + rag_rowtab_off(a.B, a.maxT, ROWS));
   const int rowsC = c1 > ceil32(c2) ? c1 : ceil32(c2);
-  float *buf = smem;                                     // [rowsC][RP]
-  float *sdx = buf + rowsC * RP;                         // [3][ROWS]
-  int *sidx = reinterpret_cast<int *>(sdx + 3 * ROWS);   // [ROWS] neighbour point (-1: filler row)
-  int *coff2 = sidx + ROWS;                              // [2][CT] first row of each centre, double-buffered
-  float *gmax = reinterpret_cast<float *>(coff2 + 2 * CT);   // [ceil32(c3)][NG]
+  float *buf = smem;                                          // [rowsC][RP]
+  int *coff2 = reinterpret_cast<int *>(buf + rowsC * RP);     // [2][CT] first row of each centre, double-buffered
+  float *gmax = reinterpret_cast<float *>(coff2 + 2 * CT);    // [NG][ceil32(c3)], 16-byte aligned
   const int tid = threadIdx.x;
-  // row table / centre offsets of a tile: one 16-byte entry per thread r < ROWS, one int per thread < CT
+  const int r = tid % ROWS, q0 = tid / ROWS;   // this thread's row of every tile, its first channel quad
+  const int nq = c1 >> 2;                      // channel quads of layer 1
+  const int ni = (nq - q0 + QS - 1) / QS;      // items of this thread: quads q0, q0 + QS, ...
+  // PREF: the whole layer-1 gather of the NEXT tile (<= NI pieces per thread) is in flight during layer 3
+  const bool pref = a.pq && ni <= NI;
+  // per-tile state in registers: the thread's row entry {neighbour index, dxyz}, its table pieces, one
+  // centre offset (threads < MAXC + 1)
   f32x4 rv = {__int_as_float(-1), 0.f, 0.f, 0.f};
+  f32x4 p4[NI];
   int cv = 0;
-  auto fetch = [&](int tile) {
+  auto fetch_row = [&](int tile) {
     if (tile < total) {
-      if (tid < ROWS) rv = rowtab[(size_t)tile * ROWS + tid];
+      rv = rowtab[(size_t)tile * ROWS + r];
       if (tid < MAXC + 1) cv = ctab[(size_t)tile * CT + tid];
     }
   };
-  auto stash = [&](int par) {
-    if (tid < ROWS) {
-      sidx[tid] = __float_as_int(rv[0]);
-      sdx[tid] = rv[1];
-      sdx[ROWS + tid] = rv[2];
-      sdx[2 * ROWS + tid] = rv[3];
+  auto gather = [&](int tile) {   // table pieces of the row held in rv (tile's cloud from the flat list)
+    if (tile < total) {
+      const size_t bt = (size_t)flat[tile].x;
+      const float *prow = a.pq + (bt * a.N + (size_t)(__float_as_int(rv[0]) < 0 ? 0 : __float_as_int(rv[0]))) * a.pqw;
+#pragma unroll
+      for (int u = 0; u < NI; u++) {
+        const int oq = q0 + u * QS;
+        p4[u] = *reinterpret_cast<const f32x4 *>(prow + 4 * (oq < nq ? oq : 0));
+      }
     }
-    if (tid < MAXC + 1) coff2[par * CT + tid] = cv;
   };
   int par = 0;
-  fetch(blockIdx.x);
-  stash(0);
+  fetch_row(blockIdx.x);
+  if (tid < MAXC + 1) coff2[tid] = cv;
+  if (pref) gather(blockIdx.x);
   __syncthreads();
   for (int tile = blockIdx.x; tile < total; tile += gridDim.x, par ^= 1) {
   const int4 td = flat[tile];
   const size_t b = (size_t)td.x;
   const int first = td.y, nc = td.z;
   const int *coff = coff2 + par * CT;
-  if (!(a.dbg & 1)) {  // layer 1 (BatchNorm scale folded into wa / P, shift added here)
-    const float *pq = a.pq ? a.pq + b * a.N * (size_t)a.pqw : nullptr;
-    const int total1 = ROWS * (c1 >> 2);
-    constexpr int dR = kThreads % ROWS, dO = kThreads / ROWS;
-    int r = tid % ROWS, oq = tid / ROWS;
-    for (int e0 = tid; e0 < total1; e0 += 4 * kThreads) {
-      f32x4 p4[4];
-      int rr[4], oo[4];
+  PCR_MARK(0);
+  if (!(a.dbg & 1)) {  // layer 1 (BatchNorm scale folded into wa / P, shift added here): row r, quads q0 + u QS
+    const bool live = __float_as_int(rv[0]) >= 0;
+    const float dx = rv[1], dy = rv[2], dz = rv[3];
+    const float *prow = a.pq ? a.pq + (b * a.N + (size_t)(live ? __float_as_int(rv[0]) : 0)) * a.pqw : nullptr;
+    for (int u0 = 0; u0 < ni; u0 += NI) {
+      if (!pref && prow) {
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        rr[u] = r;
-        oo[u] = oq << 2;
-        p4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (pq && e0 + u * kThreads < total1 && sidx[r] >= 0)
-          p4[u] = *reinterpret_cast<const f32x4 *>(pq + (size_t)sidx[r] * a.pqw + oo[u]);
-        r += dR;
-        oq += dO;
-        if (r >= ROWS) { r -= ROWS; oq++; }
+        for (int u = 0; u < NI; u++) {
+          const int oq = q0 + (u0 + u) * QS;
+          p4[u] = *reinterpret_cast<const f32x4 *>(prow + 4 * (oq < nq ? oq : 0));
+        }
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        if (e0 + u * kThreads < total1) {
-          const int rw = rr[u], o = oo[u];
+      for (int u = 0; u < NI; u++) {
+        const int oq = q0 + (u0 + u) * QS;
+        if (oq < nq) {
+          const int o = oq << 2;
+          const float *w = a.wa + o * 3;
           f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (sidx[rw] >= 0) {
-            const float dx = sdx[rw], dy = sdx[ROWS + rw], dz = sdx[2 * ROWS + rw];
-            const float *w = a.wa + o * 3;
+          if (live) {
 #pragma unroll
             for (int j = 0; j < 4; j++)
-              v[j] = fmaxf(w[3 * j] * dx + w[3 * j + 1] * dy + w[3 * j + 2] * dz + p4[u][j] + a.sh1[o + j], 0.f);
+              v[j] = fmaxf(w[3 * j] * dx + w[3 * j + 1] * dy + w[3 * j + 2] * dz + (prow ? p4[u][j] : 0.f) + a.sh1[o + j], 0.f);
           }
 #pragma unroll
-          for (int j = 0; j < 4; j++) buf[(o + j) * RP + rw] = v[j];
+          for (int j = 0; j < 4; j++) buf[(o + j) * RP + r] = v[j];
         }
       }
     }
   }
+  PCR_MARK(1);
   __syncthreads();
-  fetch(tile + gridDim.x);   // lands during the matrix phases; sidx / sdx are dead from here on
+  PCR_MARK(2);
+  fetch_row(tile + gridDim.x);   // next tile's row entry: lands during layer 2
   if (!(a.dbg & 2))
   tile_dense2<TB, NR2, W2>(buf, c1, a.wp2, ceil32(c2), true,
                            [&](float v, int o, int t) { buf[o * RP + t] = fmaxf(v, 0.f); }, a.sh2);
+  PCR_MARK(3);
+  if (pref) gather(tile + gridDim.x);   // next tile's table pieces: land during layer 3
   __syncthreads();
+  PCR_MARK(4);
   if (!(a.dbg & 4))
   tile_dense2<TB, NR, W3, true>(buf, ceil8(c2), a.wp3, ceil32(c3), false,
                                [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
+    // quad maxima -> gmax[quad][cout]: the 16 accumulator rows of a lane are four runs of four consecutive
+    // couts, so the first lane of every quad stores four 16-byte pieces
+    f32x4 g4[4];
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int o = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      float v = fmaxf(acc[r], 0.f);
+    for (int rr = 0; rr < 16; rr++) {
+      float v = fmaxf(acc[rr], 0.f);
       v = fmaxf(v, dpp_f32<0xB1>(v));    // lane ^ 1
       v = fmaxf(v, dpp_f32<0x4E>(v));    // lane ^ 2: quad maximum
-      if ((l31 & 3) == 0) gmax[o * NG + tb * 8 + (l31 >> 2)] = v;
+      g4[rr >> 2][rr & 3] = v;
+    }
+    if ((l31 & 3) == 0) {
+      float *gq = gmax + (tb * 8 + (l31 >> 2)) * C3P + cb * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; g++) *reinterpret_cast<f32x4 *>(gq + 8 * g) = g4[g];
     }
   }, a.sh3);
-  stash(par ^ 1);            // next tile's rows (the other coff buffer: this tile's is read below)
+  PCR_MARK(5);
+  if (tid < MAXC + 1) coff2[(par ^ 1) * CT + tid] = cv;   // next tile's offsets (this tile's are read below)
   __syncthreads();
+  PCR_MARK(6);
   if (!(a.dbg & 8))
-  for (int e = tid; e < c3 * nc; e += kThreads) {
-    const int o = e / nc, c = e - o * nc;
-    const float *g = gmax + o * NG;
-    float m = g[coff[c] >> 2];
-    for (int q = (coff[c] >> 2) + 1; q < (coff[c + 1] >> 2); q++) m = fmaxf(m, g[q]);
-    a.out[(b * c3 + o) * a.S + first + c] = m;
+  for (int o = tid; o < c3; o += kThreads) {   // one cout per thread: LDS reads and (point-major) stores coalesce
+    const float *g = gmax + o;
+    int q = 0;
+    for (int c = 0; c < nc; c++) {
+      const int qe = coff[c + 1] >> 2;
+      float m = g[q * C3P];
+      for (q++; q < qe; q++) m = fmaxf(m, g[q * C3P]);
+      if (a.out_pm) a.out[(b * a.S + first + c) * c3 + o] = m;
+      else a.out[(b * c3 + o) * a.S + first + c] = m;
+    }
   }
+  PCR_MARK(7);
+  trace_it++;
   // no barrier needed here: the next tile's layer 1 writes buf (dead since layer 3), its layer 3 writes gmax
-  // only after two more barriers, and coff / sidx / sdx of the next tile were stashed before the last one
+  // only after two more barriers, and the next tile's coff buffer was written before the last one
   }
 }
 
@@ -546,7 +608,7 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
 struct DensePmArgs {
   const float *x, *wp;
   float *y;
-  int cin, cout, L;
+  int cin, cout, L, x_pm;
 };
 
 // NR: cout-block rounds per wave (2 when cout > 128).  X and Y share one LDS buffer (barrier between the
@@ -559,7 +621,8 @@ __global__ __launch_bounds__(kThreads) void dense_pm_kernel(DensePmArgs a) {
   float *X = smem;   // [max(cinP, ceil32(cout))][RP]
   const size_t b = blockIdx.y;
   const int t0 = blockIdx.x * T;
-  load_tile(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
+  if (a.x_pm) load_tile_pm(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
+  else load_tile(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
   __syncthreads();
   tile_dense2<TB, NR>(X, cinP, a.wp, ceil32(cout), true, [&](float v, int o, int t) { X[o * RP + t] = v; });
   __syncthreads();
@@ -601,7 +664,28 @@ static int sa2_launch_tb(const Sa2Args &a, int nr, int nr2, int wsel, bool maxe,
   return 0;
 }
 
-extern "C" int pcr_dense_pm_f32(const float *, const float *, float *, int, int, int, int, pcr_stream_t);
+extern "C" int pcr_dense_pm_f32(const float *, const float *, float *, int, int, int, int, int, pcr_stream_t);
+
+// diagnostics only (PCR_SA_TRACE): synchronises, appends one launch's phase stamps to the file
+static void rag_dump_trace(const char *path, const char *tag, int wgs) {
+  static int launches = 0;
+  if (launches++ >= 8) return;   // the first few launches are enough
+  static std::vector<unsigned long long> host(kTraceWgs * (2 + kTraceTiles * kTraceMarks));
+  if (hipDeviceSynchronize() != hipSuccess) return;
+  if (hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(g_rag_trace), host.size() * sizeof(unsigned long long)) != hipSuccess)
+    return;
+  FILE *f = fopen(path, "a");
+  if (!f) return;
+  const int n = wgs < kTraceWgs ? wgs : kTraceWgs;
+  fprintf(f, "launch %d kernel %s wgs %d\n", launches, tag, wgs);
+  for (int w = 0; w < n; w++) {
+    const unsigned long long *t = host.data() + (size_t)w * (2 + kTraceTiles * kTraceMarks);
+    fprintf(f, "wg %d hwid %llu xcc %llu", w, t[0], t[1]);
+    for (int i = 0; i < kTraceTiles * kTraceMarks; i++) fprintf(f, " %llu", t[2 + i]);
+    fprintf(f, "\n");
+  }
+  fclose(f);
+}
 
 // fast path; returns -1 when the configuration is not covered (caller falls back to sa_mlp_kernel)
 static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
@@ -625,17 +709,19 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
       r.wa = p.wa; r.pq = p.D ? p.pq_ws : nullptr; r.pqw = p.c1;
       r.wp2 = p.wps[0]; r.wp3 = p.wps[1]; r.sh1 = p.shift[0]; r.sh2 = p.shift_pad[0]; r.sh3 = p.shift_pad[1];
       static const int rdbg = getenv("PCR_SA_DBG") ? atoi(getenv("PCR_SA_DBG")) : 0;
-      r.dbg = rdbg;
+      static const char *rtrace = getenv("PCR_SA_TRACE");
+      r.dbg = rdbg | (rtrace ? 256 : 0);
       r.out = p.out;
+      r.out_pm = p.out_point_major;
       const int rowsCr = p.c1 > ceil32(p.c2) ? p.c1 : ceil32(p.c2);
-      const size_t lds = ((size_t)rowsCr * (ROWS + 1) + 3 * ROWS + ROWS + 2 * (ROWS / 4 + 4) +
+      const size_t lds = ((size_t)rowsCr * (ROWS + 1) + 2 * (ROWS / 4 + 4) +
                           (size_t)ceil32(p.c3) * (ROWS / 4)) * sizeof(float);
       if (lds <= 150 * 1024) {
         if (p.D && !p.pq_ready) {
-          const int rc = pcr_dense_pm_f32(p.feat, p.wpq, p.pq_ws, p.B, p.D, p.c1, p.N, st_);
+          const int rc = pcr_dense_pm_f32(p.feat, p.wpq, p.pq_ws, p.B, p.D, p.c1, p.N, p.feat_point_major, st_);
           if (rc != PCR_OK) return rc == PCR_ERR_INVALID ? -1 : rc;
         }
-        hipLaunchKernelGGL(sa_rag_plan_kernel, dim3((p.B + 63) / 64), dim3(64), 0, st, r, ROWS);
+        hipLaunchKernelGGL(sa_rag_plan_kernel, dim3((p.B + 3) / 4), dim3(256), 0, st, r, ROWS);
         hipLaunchKernelGGL(sa_rag_scan_kernel, dim3(1), dim3(1024), 0, st, p.B, r.maxT, r.ws);
         {
           long long wgs = ((long long)p.B * r.maxT + 3) / 4;
@@ -670,6 +756,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
     long long want = (long long)n_cu * occ;                                                              \
     if (want > max_tiles) want = max_tiles;                                                              \
     hipLaunchKernelGGL(kern, dim3((unsigned)want), dim3(kThreads), lds, st, r);                          \
+    if (rtrace) rag_dump_trace(rtrace, #TBv "," #NRv, (int)want);                                        \
   } while (0)
 #define PCR_COMMA_ONE , 1
         if (tb == 2) {
@@ -735,7 +822,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   }
   if (!best_cpw) return -1;
   if (p.D && !p.pq_ready) {
-    const int rc = pcr_dense_pm_f32(p.feat, p.wpq, p.pq_ws, p.B, p.D, pqw, p.N, st_);
+    const int rc = pcr_dense_pm_f32(p.feat, p.wpq, p.pq_ws, p.B, p.D, pqw, p.N, p.feat_point_major, st_);
     if (rc != PCR_OK) return rc == PCR_ERR_INVALID ? -1 : rc;
   }
   Sa2Args a;
@@ -753,6 +840,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   a.wp2 = p.wps[0]; a.wp3 = p.wps[1];
   a.sh1 = p.shift[0]; a.sh2 = p.shift_pad[0]; a.sh3 = p.shift_pad[1];
   a.out = p.out;
+  a.out_pm = p.out_point_major;
   const size_t lds = lds_bytes(best_tb, best_cpw);
   dim3 grid((p.S + best_cpw - 1) / best_cpw, p.B);
   const int w2 = n2 >= 3 ? 1 : (n2 == 2 ? 2 : 4), w3 = n3 >= 3 ? 1 : (n3 == 2 ? 2 : 4);
@@ -779,11 +867,11 @@ PCR_EXPORT long pcr_sa_tile_ws_ints(int B, int S, int K, int c2, int c3) {
 }
 
 PCR_EXPORT int pcr_dense_pm_f32(const float *x, const float *wp, float *y, int B, int cin, int cout, int L,
-                                pcr_stream_t stream) {
+                                int x_point_major, pcr_stream_t stream) {
   if (!x || !wp || !y || B < 0 || cin < 1 || cout < 1 || cout > 256 || L < 1) return PCR_ERR_INVALID;
   if (B == 0) return PCR_OK;
   if (B > 65535) return PCR_ERR_INVALID;
-  DensePmArgs d{x, wp, y, cin, cout, L};
+  DensePmArgs d{x, wp, y, cin, cout, L, x_point_major};
   const int rows = ceil8(cin) > ceil32(cout) ? ceil8(cin) : ceil32(cout);
   size_t lds = (size_t)rows * 65 * sizeof(float);
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;

@@ -371,6 +371,58 @@ __device__ __forceinline__ void load_tile(float *dst, int RP, const float *src, 
   }
 }
 
+// the same tile from a POINT-major tensor: src (L,C) of one cloud, element (c,t) = src[(t0+t)*C + c]
+__device__ __forceinline__ void load_tile_pm(float *dst, int RP, const float *src, int C, int CP, int L,
+                                             int t0, int T) {
+  if ((C & 3) == 0 && (reinterpret_cast<size_t>(src) & 15) == 0) {
+    const int Q = CP >> 2, totq = T * Q;    // CP is a multiple of 8
+    for (int e0 = threadIdx.x; e0 < totq; e0 += 4 * kThreads) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = e0 + u * kThreads;
+        const int t = e / Q, q = e - t * Q;
+        const bool ok = e < totq && 4 * q < C && t0 + t < L;
+        const f32x4 x = *reinterpret_cast<const f32x4 *>(src + (ok ? (size_t)(t0 + t) * C + 4 * q : 0));
+        v[u] = ok ? x : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = e0 + u * kThreads;
+        if (e < totq) {
+          const int t = e / Q, q = e - t * Q;
+          float *d = dst + 4 * q * RP + t;
+          d[0] = v[u][0];
+          d[RP] = v[u][1];
+          d[2 * RP] = v[u][2];
+          d[3 * RP] = v[u][3];
+        }
+      }
+    }
+  } else {
+    const int total = T * CP;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 8 * kThreads) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int e = e0 + u * kThreads;
+        const int t = e / CP, c = e - t * CP;
+        const bool ok = e < total && c < C && t0 + t < L;
+        const float x = src[ok ? (size_t)(t0 + t) * C + c : 0];
+        v[u] = ok ? x : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int e = e0 + u * kThreads;
+        if (e < total) {
+          const int t = e / CP, c = e - t * CP;
+          dst[c * RP + t] = v[u];
+        }
+      }
+    }
+  }
+}
+
 // xyz (L,3) rows t0.. -> LDS [8][RP] (rows 3..7 zero)
 __device__ __forceinline__ void load_xyz_tile(float *dst, int RP, const float *xyz, int L, int t0, int T) {
   for (int e = threadIdx.x; e < 8 * T; e += blockDim.x) {

@@ -37,4 +37,4 @@ class PointNet2SSG(nn.Module):
             object.__setattr__(self, "_cf_w", engine.pack_weight(self.cov_final.weight, feats.device))
             object.__setattr__(self, "_cf_b", self.cov_final.bias.detach().to(feats.device).float().contiguous())
             object.__setattr__(self, "_cf_key", key)
-        return xyz, engine.dense(feats.contiguous(), self._cf_w, self.cov_final.weight.shape[0], None, self._cf_b, 0)
+        return xyz, engine.dense(feats, self._cf_w, self.cov_final.weight.shape[0], None, self._cf_b, 0)

@@ -244,9 +244,12 @@ class BasePointSAModule(nn.Module):
             if not isinstance(grouper, QueryAndGroup):
                 raise L.PcrError("GroupAll scales are not on the ReID path")
             idx, cnt = grouper.query_cnt(points_xyz, new_xyz)
-            feats = None if features is None else features.contiguous()
-            outs.append(self._plan(i, points_xyz.device).run(points_xyz, feats, idx, centre_idx=indices.contiguous(),
-                                                             cnt=cnt if self.skip_repeats else None))
+            # single-scale modules hand out the (B,C,S) view of a point-major buffer (a centre's channels are
+            # stored as one run); SaPlan / engine.dense read either layout, anyone else may call .contiguous()
+            outs.append(self._plan(i, points_xyz.device).run(points_xyz, features, idx,
+                                                             centre_idx=indices.contiguous(),
+                                                             cnt=cnt if self.skip_repeats else None,
+                                                             out_point_major=len(self.groupers) == 1))
         return new_xyz, torch.cat(outs, dim=1) if len(outs) > 1 else outs[0], indices
 
 

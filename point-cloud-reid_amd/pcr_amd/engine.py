@@ -48,6 +48,7 @@ class SaParams(ctypes.Structure):
                 ("wa", c_float_p), ("wpq", c_float_p), ("wps", c_float_p * 2), ("shift_pad", c_float_p * 2),
                 ("cnt", c_int_p), ("tile_ws", c_int_p),
                 ("pq_ws", c_float_p), ("pq_ready", ctypes.c_int),
+                ("feat_point_major", ctypes.c_int), ("out_point_major", ctypes.c_int),
                 ("out", c_float_p)]
 
 
@@ -156,17 +157,22 @@ class SaPlan:
                 stacked = w1[:, 3:3 + D] * sc1
             self.wpq = pack_weight(stacked.float(), device)
 
-    def run(self, xyz, feat, idx, centre_idx=None, cnt=None):
+    def run(self, xyz, feat, idx, centre_idx=None, cnt=None, out_point_major=False):
         """cnt (B,S) int32: genuine-hit counts of a ball query (ops.ball_query_cnt); when given (mode 1) the
-        MLP runs only on the distinct rows of every group -- same result, K/cnt times less work"""
+        MLP runs only on the distinct rows of every group -- same result, K/cnt times less work.
+        feat (B,D,N) may be contiguous or the transposed view of a contiguous (B,N,D) tensor (point-major);
+        out_point_major: the result is the (B,c3,S) VIEW of a contiguous (B,S,c3) tensor (a centre's channels
+        are written as one run; our own consumers read that layout directly)."""
         L.require_cuda(xyz, idx)
         B, N, _ = xyz.shape
         _, S, K = idx.shape
         D = 0 if feat is None else feat.shape[1]
         want = 3 + (2 * D if self.mode == 0 else D)
         assert want == self.cin, "feature width %d does not match the first conv (%d)" % (want, self.cin)
-        assert xyz.is_contiguous() and idx.is_contiguous() and (feat is None or feat.is_contiguous())
-        out = torch.empty((B, self.couts[2], S), dtype=torch.float32, device=xyz.device)
+        feat, feat_pm = as_cm_or_pm(feat)
+        assert xyz.is_contiguous() and idx.is_contiguous()
+        out = torch.empty((B, S, self.couts[2]) if out_point_major else (B, self.couts[2], S),
+                          dtype=torch.float32, device=xyz.device)
         p = SaParams()
         p.mode, p.B, p.N, p.S, p.K, p.D = self.mode, B, N, S, K, D
         p.c1, p.c2, p.c3 = self.couts
@@ -174,6 +180,7 @@ class SaPlan:
         for i in range(3):
             p.wp[i], p.scale[i], p.shift[i] = _p(self.wp[i]), _p(self.scale[i]), _p(self.shift[i])
         p.out = _p(out)
+        p.feat_point_major, p.out_point_major = int(feat_pm), int(bool(out_point_major))
         ragged = cnt is not None and self.fast and self.mode == 1
         if ragged:
             assert cnt.is_contiguous() and cnt.dtype == torch.int32 and cnt.shape == (B, S)
@@ -192,7 +199,7 @@ class SaPlan:
                 with _prof("sa_tables[D=%d,out=%d,N=%d]" % (D, pqw, N), 2.0 * B * N * D * pqw,
                            4.0 * B * N * (D + pqw)):
                     L.check(L.load().pcr_dense_pm_f32(L.ptr(feat), L.ptr(self.wpq), L.ptr(ws), B, D, pqw, N,
-                                                      L.stream_ptr()), "pcr_dense_pm_f32")
+                                                      int(feat_pm), L.stream_ptr()), "pcr_dense_pm_f32")
                 p.pq_ready = 1
         c1, c2, c3 = self.couts
         flops = 2.0 * B * S * K * (self.cin * c1 + c1 * c2 + c2 * c3)
@@ -204,7 +211,7 @@ class SaPlan:
         name = "sa_ragged" if ragged else "sa_fused"
         with _prof("%s[D=%d,c=%d/%d/%d,N=%d,S=%d,K=%d]" % (name, D, c1, c2, c3, N, S, K), flops, nbytes, exec_flops):
             L.check(L.load().pcr_sa_mlp_f32(ctypes.byref(p), L.stream_ptr()), "pcr_sa_mlp_f32")
-        return out
+        return out.transpose(1, 2) if out_point_major else out
 
 
 class AttnPlan:
@@ -334,13 +341,27 @@ class HeadPlan:
         return (logits, pooled) if want_pooled else logits
 
 
+def as_cm_or_pm(x):
+    """(tensor the kernels can read, is_point_major) for a (B,C,L) feature tensor: contiguous = channel-major;
+    the transposed view of a contiguous (B,L,C) tensor = point-major, passed through as it is; anything else is
+    made contiguous."""
+    if x is None or x.is_contiguous():
+        return x, False
+    if x.dim() == 3 and x.transpose(1, 2).is_contiguous():
+        return x, True
+    return x.contiguous(), False
+
+
 def dense(x, wp, cout, scale=None, shift=None, act=0):
-    """x (B,cin,L) -> (B,cout,L) through pcr_dense_f32 (wp packed)."""
+    """x (B,cin,L) (channel-major, or the transposed view of a point-major tensor) -> (B,cout,L) through
+    pcr_dense_f32 / pcr_dense_xpm_f32 (wp packed)."""
     L.require_cuda(x)
-    assert x.is_contiguous() and x.dtype == torch.float32
+    assert x.dtype == torch.float32
+    x, x_pm = as_cm_or_pm(x)
     B, cin, Ln = x.shape
     y = torch.empty((B, cout, Ln), dtype=torch.float32, device=x.device)
+    fn = L.load().pcr_dense_xpm_f32 if x_pm else L.load().pcr_dense_f32
     with _prof("dense[cin=%d,cout=%d,L=%d]" % (cin, cout, Ln), 2.0 * B * Ln * cin * cout, 4.0 * B * Ln * (cin + cout)):
-        L.check(L.load().pcr_dense_f32(L.ptr(x), L.ptr(wp), L.ptr(scale), L.ptr(shift), L.ptr(y), B, cin, cout,
-                                       Ln, act, L.stream_ptr()), "pcr_dense_f32")
+        L.check(fn(L.ptr(x), L.ptr(wp), L.ptr(scale), L.ptr(shift), L.ptr(y), B, cin, cout, Ln, act, L.stream_ptr()),
+                "pcr_dense_f32")
     return y
