@@ -423,6 +423,16 @@ __global__ __launch_bounds__(256) void sa_rag_rows_kernel(RagArgs a) {
       s_off[w][nc] = incl;                   // lanes >= nc carry the total
       ctab[(size_t)tile * CT + nc] = incl;
     }
+    {  // bit q of `ends`: quad q is the last quad of its centre (what the max-pool epilogue scans)
+      unsigned my = lane < nc ? 1u << ((incl >> 2) - 1) : 0u;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) my |= __shfl_xor(my, off, 64);
+      const int nquads = __shfl(incl, nc, 64) >> 2;
+      if (lane == 0) {
+        ctab[(size_t)tile * CT + MAXC + 1] = (int)my;
+        ctab[(size_t)tile * CT + MAXC + 2] = nquads;
+      }
+    }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the wave's own LDS writes have landed
     const int used = s_off[w][nc];
@@ -482,7 +492,11 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   float *buf = smem;                                          // [rowsC][RP]
   int *coff2 = reinterpret_cast<int *>(buf + rowsC * RP);     // [2][CT] first row of each centre, double-buffered
   float *gmax = reinterpret_cast<float *>(coff2 + 2 * CT);    // [NG][ceil32(c3)], 16-byte aligned
+  float *s_wa = gmax + NG * C3P;                              // [c1][3] dxyz weights and [c1] shift of layer 1,
+  float *s_sh1 = s_wa + 3 * c1;                               //   staged once per (persistent) workgroup
   const int tid = threadIdx.x;
+  for (int e = tid; e < 3 * c1; e += kThreads) s_wa[e] = a.wa[e];
+  for (int e = tid; e < c1; e += kThreads) s_sh1[e] = a.sh1[e];
   const int r = tid % ROWS, q0 = tid / ROWS;   // this thread's row of every tile, its first channel quad
   const int nq = c1 >> 2;                      // channel quads of layer 1
   const int ni = (nq - q0 + QS - 1) / QS;      // items of this thread: quads q0, q0 + QS, ...
@@ -496,7 +510,7 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   auto fetch_row = [&](int tile) {
     if (tile < total) {
       rv = rowtab[(size_t)tile * ROWS + r];
-      if (tid < MAXC + 1) cv = ctab[(size_t)tile * CT + tid];
+      if (tid < MAXC + 3) cv = ctab[(size_t)tile * CT + tid];   // offsets, then the `ends` mask and the quad count
     }
   };
   auto gather = [&](int tile) {   // table pieces of the row held in rv (tile's cloud from the flat list)
@@ -512,7 +526,7 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   };
   int par = 0;
   fetch_row(blockIdx.x);
-  if (tid < MAXC + 1) coff2[tid] = cv;
+  if (tid < MAXC + 3) coff2[tid] = cv;
   if (pref) gather(blockIdx.x);
   __syncthreads();
   for (int tile = blockIdx.x; tile < total; tile += gridDim.x, par ^= 1) {
@@ -538,12 +552,12 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
         const int oq = q0 + (u0 + u) * QS;
         if (oq < nq) {
           const int o = oq << 2;
-          const float *w = a.wa + o * 3;
+          const float *w = s_wa + o * 3;
           f32x4 v = {0.f, 0.f, 0.f, 0.f};
           if (live) {
 #pragma unroll
             for (int j = 0; j < 4; j++)
-              v[j] = fmaxf(w[3 * j] * dx + w[3 * j + 1] * dy + w[3 * j + 2] * dz + (prow ? p4[u][j] : 0.f) + a.sh1[o + j], 0.f);
+              v[j] = fmaxf(w[3 * j] * dx + w[3 * j + 1] * dy + w[3 * j + 2] * dz + (prow ? p4[u][j] : 0.f) + s_sh1[o + j], 0.f);
           }
 #pragma unroll
           for (int j = 0; j < 4; j++) buf[(o + j) * RP + r] = v[j];
@@ -582,19 +596,36 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
     }
   }, a.sh3);
   PCR_MARK(5);
-  if (tid < MAXC + 1) coff2[(par ^ 1) * CT + tid] = cv;   // next tile's offsets (this tile's are read below)
+  if (tid < MAXC + 3) coff2[(par ^ 1) * CT + tid] = cv;   // next tile's offsets (this tile's are read below)
   __syncthreads();
   PCR_MARK(6);
-  if (!(a.dbg & 8))
-  for (int o = tid; o < c3; o += kThreads) {   // one cout per thread: LDS reads and (point-major) stores coalesce
-    const float *g = gmax + o;
-    int q = 0;
-    for (int c = 0; c < nc; c++) {
-      const int qe = coff[c + 1] >> 2;
-      float m = g[q * C3P];
-      for (q++; q < qe; q++) m = fmaxf(m, g[q * C3P]);
-      if (a.out_pm) a.out[(b * a.S + first + c) * c3 + o] = m;
-      else a.out[(b * c3 + o) * a.S + first + c] = m;
+  if (!(a.dbg & 8)) {
+    // one cout per thread; all quad maxima of the tile are read first (independent, conflict-free LDS reads),
+    // then scanned with the wave-uniform `ends` mask: values are >= 0 after the ReLU, so 0 starts a segment
+    const unsigned ends = (unsigned)__builtin_amdgcn_readfirstlane(coff[MAXC + 1]);
+    if (tid < c3) {   // c3 <= 256 = kThreads
+      const int o = tid;
+      float gv[NG];
+      const float *g = gmax + o;
+#pragma unroll
+      for (int q = 0; q < NG; q++) gv[q] = g[q * C3P];
+      // a wave issues one instruction every few cycles whatever its kind: the per-step work is kept to a max,
+      // a bit test and (at a centre's last quad) one store through a running 32-bit offset.  `ends` has no bit
+      // beyond the tile's last quad, so whatever the unused quads hold is never stored.
+      float *base = a.out_pm ? a.out + (b * a.S + first) * c3 : a.out + b * c3 * a.S + first;
+      unsigned off = a.out_pm ? (unsigned)o : (unsigned)o * (unsigned)a.S;
+      const unsigned step = a.out_pm ? (unsigned)c3 : 1u;
+      unsigned m = 0u;   // the maxima are >= +0 after the ReLU: their unsigned bit patterns order like the floats
+#pragma unroll
+      for (int q = 0; q < NG; q++) {
+        const unsigned gq = __float_as_uint(gv[q]);
+        m = gq > m ? gq : m;
+        if ((ends >> q) & 1u) {
+          base[off] = __uint_as_float(m);
+          off += step;
+          m = 0u;
+        }
+      }
     }
   }
   PCR_MARK(7);
@@ -715,7 +746,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
       r.out_pm = p.out_point_major;
       const int rowsCr = p.c1 > ceil32(p.c2) ? p.c1 : ceil32(p.c2);
       const size_t lds = ((size_t)rowsCr * (ROWS + 1) + 2 * (ROWS / 4 + 4) +
-                          (size_t)ceil32(p.c3) * (ROWS / 4)) * sizeof(float);
+                          (size_t)ceil32(p.c3) * (ROWS / 4) + 4 * (size_t)p.c1) * sizeof(float);
       if (lds <= 150 * 1024) {
         if (p.D && !p.pq_ready) {
           const int rc = pcr_dense_pm_f32(p.feat, p.wpq, p.pq_ws, p.B, p.D, p.c1, p.N, p.feat_point_major, st_);
