@@ -5,6 +5,12 @@
 
 #include "tile_dense.h"
 
+// 1: the first weight fragments of layers 2 AND 3 are requested one phase early; 2: layer 3 only (layer 2's
+// would stay live across the gather / max-pool phases and push the kernel over 192 VGPRs = one workgroup per CU)
+#ifndef PCR_RING
+#define PCR_RING 2
+#endif
+
 namespace {
 // ---------------------------------------------------------------- grouped SA MLP ----
 struct SaArgs {
@@ -100,6 +106,19 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
+
+// ReLU / max on the BIT patterns (signed integer max): exact for every finite input -- a float >= +0 has a
+// non-negative pattern that orders like the float, any negative float has a negative pattern -- as long as the
+// result is only ever used through max(., 0); one VALU instruction, no NaN-canonicalisation prefix.
+__device__ __forceinline__ float relu_bits(float v) {
+  const int b = __float_as_int(v);
+  return __int_as_float(b > 0 ? b : 0);
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
 struct Sa2Args {
   int B, N, S, K, c1, c2, c3, CPW;
@@ -478,10 +497,14 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
     trace[0] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID, 32 bits
     trace[1] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
   }
+#ifdef PCR_SA_TRACE_BUILD   // diagnostic builds only (the stamps cost registers in the hot kernel)
 #define PCR_MARK(m)                                                                                    \
   do {                                                                                                 \
     if (tracing && trace_it < kTraceTiles) trace[2 + trace_it * kTraceMarks + (m)] = __builtin_readcyclecounter(); \
   } while (0)
+#else
+#define PCR_MARK(m) do { (void)tracing; (void)trace; } while (0)
+#endif
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int c1 = a.c1, c2 = a.c2, c3 = a.c3;
   const int total = a.ws[a.B];
@@ -494,9 +517,24 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   float *gmax = reinterpret_cast<float *>(coff2 + 2 * CT);    // [NG][ceil32(c3)], 16-byte aligned
   float *s_wa = gmax + NG * C3P;                              // [c1][3] dxyz weights and [c1] shift of layer 1,
   float *s_sh1 = s_wa + 3 * c1;                               //   staged once per (persistent) workgroup
+  float *s_sh2 = s_sh1 + c1;                                  // accumulator seeds of layers 2 / 3 (zero-padded)
+  float *s_sh3 = s_sh2 + ceil32(c2);
   const int tid = threadIdx.x;
   for (int e = tid; e < 3 * c1; e += kThreads) s_wa[e] = a.wa[e];
   for (int e = tid; e < c1; e += kThreads) s_sh1[e] = a.sh1[e];
+  for (int e = tid; e < ceil32(c2); e += kThreads) s_sh2[e] = a.sh2[e];
+  for (int e = tid; e < C3P; e += kThreads) s_sh3[e] = a.sh3[e];
+  // weight fragments of the NEXT dense call, requested as soon as the previous call's k-loop is over (explicit
+  // shapes only): the L2 round trip then never sits between a barrier and the first MFMA
+  constexpr bool kRing = PCR_RING && W2 != 0 && W3 != 0;
+  f32x4 ring2[PCR_PF][DenseShape<NR2, W2>::nr], ring3[PCR_PF][DenseShape<NR, W3>::nr];
+  auto load_ring2 = [&]() {
+    if constexpr (kRing && PCR_RING == 1) tile_dense_ring_load<DenseShape<NR2, W2>::nr, DenseShape<NR2, W2>::ways>(a.wp2, c1, ceil32(c2), ring2);
+  };
+  auto load_ring3 = [&]() {
+    if constexpr (kRing) tile_dense_ring_load<DenseShape<NR, W3>::nr, DenseShape<NR, W3>::ways>(a.wp3, ceil8(c2), C3P, ring3);
+  };
+  load_ring2();
   const int r = tid % ROWS, q0 = tid / ROWS;   // this thread's row of every tile, its first channel quad
   const int nq = c1 >> 2;                      // channel quads of layer 1
   const int ni = (nq - q0 + QS - 1) / QS;      // items of this thread: quads q0, q0 + QS, ...
@@ -571,7 +609,8 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   fetch_row(tile + gridDim.x);   // next tile's row entry: lands during layer 2
   if (!(a.dbg & 2))
   tile_dense2<TB, NR2, W2>(buf, c1, a.wp2, ceil32(c2), true,
-                           [&](float v, int o, int t) { buf[o * RP + t] = fmaxf(v, 0.f); }, a.sh2);
+                           [&](float v, int o, int t) { buf[o * RP + t] = relu_bits(v); }, s_sh2,
+                           kRing && PCR_RING == 1 ? ring2 : nullptr, load_ring3);
   PCR_MARK(3);
   if (pref) gather(tile + gridDim.x);   // next tile's table pieces: land during layer 3
   __syncthreads();
@@ -581,20 +620,21 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
                                [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
     // quad maxima -> gmax[quad][cout]: the 16 accumulator rows of a lane are four runs of four consecutive
     // couts, so the first lane of every quad stores four 16-byte pieces
+    // (signed maxima of the bit patterns; the ReLU is the scan's max with 0: see relu_bits)
     f32x4 g4[4];
 #pragma unroll
     for (int rr = 0; rr < 16; rr++) {
-      float v = fmaxf(acc[rr], 0.f);
-      v = fmaxf(v, dpp_f32<0xB1>(v));    // lane ^ 1
-      v = fmaxf(v, dpp_f32<0x4E>(v));    // lane ^ 2: quad maximum
-      g4[rr >> 2][rr & 3] = v;
+      int v = __float_as_int(acc[rr]);
+      v = imax(v, dpp_i32<0xB1>(v));    // lane ^ 1
+      v = imax(v, dpp_i32<0x4E>(v));    // lane ^ 2: quad maximum
+      g4[rr >> 2][rr & 3] = __int_as_float(v);
     }
     if ((l31 & 3) == 0) {
       float *gq = gmax + (tb * 8 + (l31 >> 2)) * C3P + cb * 32 + 4 * h;
 #pragma unroll
       for (int g = 0; g < 4; g++) *reinterpret_cast<f32x4 *>(gq + 8 * g) = g4[g];
     }
-  }, a.sh3);
+  }, s_sh3, kRing ? ring3 : nullptr, load_ring2);
   PCR_MARK(5);
   if (tid < MAXC + 3) coff2[(par ^ 1) * CT + tid] = cv;   // next tile's offsets (this tile's are read below)
   __syncthreads();
@@ -615,15 +655,14 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
       float *base = a.out_pm ? a.out + (b * a.S + first) * c3 : a.out + b * c3 * a.S + first;
       unsigned off = a.out_pm ? (unsigned)o : (unsigned)o * (unsigned)a.S;
       const unsigned step = a.out_pm ? (unsigned)c3 : 1u;
-      unsigned m = 0u;   // the maxima are >= +0 after the ReLU: their unsigned bit patterns order like the floats
+      int m = 0;   // signed max of the bit patterns starting from +0 = max over the quads, then ReLU (relu_bits)
 #pragma unroll
       for (int q = 0; q < NG; q++) {
-        const unsigned gq = __float_as_uint(gv[q]);
-        m = gq > m ? gq : m;
+        m = imax(m, __float_as_int(gv[q]));
         if ((ends >> q) & 1u) {
-          base[off] = __uint_as_float(m);
+          base[off] = __int_as_float(m);
           off += step;
-          m = 0u;
+          m = 0;
         }
       }
     }
@@ -746,7 +785,8 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
       r.out_pm = p.out_point_major;
       const int rowsCr = p.c1 > ceil32(p.c2) ? p.c1 : ceil32(p.c2);
       const size_t lds = ((size_t)rowsCr * (ROWS + 1) + 2 * (ROWS / 4 + 4) +
-                          (size_t)ceil32(p.c3) * (ROWS / 4) + 4 * (size_t)p.c1) * sizeof(float);
+                          (size_t)ceil32(p.c3) * (ROWS / 4) + 4 * (size_t)p.c1 + ceil32(p.c2) + ceil32(p.c3)) *
+                         sizeof(float);
       if (lds <= 150 * 1024) {
         if (p.D && !p.pq_ready) {
           const int rc = pcr_dense_pm_f32(p.feat, p.wpq, p.pq_ws, p.B, p.D, p.c1, p.N, p.feat_point_major, st_);

@@ -27,7 +27,7 @@ __host__ __device__ inline int ceil32(int x) { return (x + 31) & ~31; }
 
 constexpr int kThreads = 256;
 #ifndef PCR_PF
-#define PCR_PF 4
+#define PCR_PF 2
 #endif
 constexpr int kMaxDynLds = 160 * 1024;
 
@@ -77,11 +77,40 @@ __device__ __forceinline__ void tile_dense(const float *__restrict__ in, int CP,
 //   nCB = OP/32 >= 3 : wave w owns cout blocks w, w+4 (NR rounds), all TB token blocks
 //   nCB == 2         : wave w owns cout block w&1 and token blocks (w>>1), (w>>1)+2, ...
 //   nCB == 1         : wave w owns token blocks w, w+4, ...
-template <int TB, int NR, int WAYS, bool TILE, class Epi, int PF = PCR_PF>
+struct DenseNoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+// The first PF weight fragments of a dense call (what tile_dense_impl would load in its prologue), for
+// callers that request them EARLY -- e.g. right after the k-loop of the previous layer, so that the L2
+// round trip is over before the call starts -- and pass them in as `ring`.
+template <int NR, int WAYS, int PF = PCR_PF>
+__device__ __forceinline__ void tile_dense_ring_load(const float *__restrict__ wp, int CP, int OP,
+                                                     f32x4 (&ring)[PF][NR]) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int nCB = OP >> 5, KB = CP >> 3;
+  const int cb0 = WAYS == 1 ? wave : (WAYS == 2 ? (wave & 1) : 0);
+  const size_t wstride = (size_t)OP * 2;
+#pragma unroll
+  for (int nr = 0; nr < NR; nr++) {
+    int cb = cb0 + 4 * nr;
+    cb = cb < nCB ? cb : nCB - 1;
+    const f32x4 *wrow = reinterpret_cast<const f32x4 *>(wp) + (size_t)cb * 64 + (size_t)l31 * 2 + h;
+#pragma unroll
+    for (int i = 0; i < PF; i++) ring[i][nr] = wrow[(size_t)(i < KB ? i : KB - 1) * wstride];
+  }
+}
+
+// ring: nullptr, or the fragments tile_dense_ring_load fetched for THIS call.  after_k(): called once between
+// the k-loop and the epilogue (before the sync_epi barrier): the place to request the next call's ring.
+template <int TB, int NR, int WAYS, bool TILE, class Epi, int PF = PCR_PF, class AfterK = DenseNoHook>
 // PF must be even (the B-operand double buffer alternates per k-block)
 __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, int CP,
                                                 const float *__restrict__ wp, int OP, bool sync_epi,
-                                                Epi epi, const float *__restrict__ init = nullptr) {
+                                                Epi epi, const float *__restrict__ init = nullptr,
+                                                f32x4 (*ring)[NR] = nullptr, AfterK after_k = AfterK()) {
   constexpr int RP = 32 * TB + 1;
   constexpr int TBW = (TB + WAYS - 1) / WAYS;  // token blocks per wave
   const int lane = threadIdx.x & 63;
@@ -118,7 +147,7 @@ __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, in
   for (int i = 0; i < PF; i++) {
     const int ki = i < KB ? i : KB - 1;
 #pragma unroll
-    for (int nr = 0; nr < NR; nr++) aw[i][nr] = wrow[nr][(size_t)ki * wstride];
+    for (int nr = 0; nr < NR; nr++) aw[i][nr] = ring ? ring[i][nr] : wrow[nr][(size_t)ki * wstride];
   }
   // `init` (OP floats, zero-padded) seeds the accumulators with the per-cout bias / folded BatchNorm
   // shift, so the epilogue needs no per-element constant loads.  The 16 accumulator rows of a lane are
@@ -173,18 +202,34 @@ __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, in
   };
   load_x(xb[0], 0);
   int kb = 0;
-  for (; kb + PF <= KB; kb += PF) {
+  // main groups: every prefetch address is inside the image (no clamps: plain pointer increments)
+  for (; kb + 2 * PF <= KB; kb += PF) {
+#pragma unroll
+    for (int i = 0; i < PF; i++) {
+      load_x(xb[(i + 1) & 1], kb + i + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(aw[i], xb[i & 1]);
+#pragma unroll
+      for (int nr = 0; nr < NR; nr++) aw[i][nr] = wrow[nr][(size_t)(kb + i + PF) * wstride];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // last whole group: the ring is drained, partial prefetch only for the tail blocks
+  if (kb + PF <= KB) {
 #pragma unroll
     for (int i = 0; i < PF; i++) {
       const int kx = kb + i + 1 < KB ? kb + i + 1 : KB - 1;
       load_x(xb[(i + 1) & 1], kx);
       __builtin_amdgcn_sched_barrier(0);
       mma(aw[i], xb[i & 1]);
-      const int kn = kb + i + PF < KB ? kb + i + PF : KB - 1;
+      if (i + 1 < PF) {   // only PF - 1 tail blocks can exist
+        const int kn = kb + i + PF < KB ? kb + i + PF : KB - 1;
 #pragma unroll
-      for (int nr = 0; nr < NR; nr++) aw[i][nr] = wrow[nr][(size_t)kn * wstride];
+        for (int nr = 0; nr < NR; nr++) aw[i][nr] = wrow[nr][(size_t)kn * wstride];
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
+    kb += PF;
   }
   {
     const int rem = KB - kb;   // < PF; aw[i] already holds k-block kb + i, xb[0] the operands of block kb
@@ -196,6 +241,7 @@ __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, in
         mma(aw[i], xb[i & 1]);
       }
   }
+  after_k();
   if (sync_epi) __syncthreads();
 #pragma unroll
   for (int nr = 0; nr < NR; nr++) {
@@ -221,17 +267,27 @@ __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, in
 // WSEL = 0: pick the wave/tile split from OP at run time (all three bodies are compiled in and the
 // register allocation is their maximum); WSEL = 1 / 2 / 4: the caller guarantees OP/32 >= 3 / == 2 /
 // == 1 and only that body is compiled (fewer registers => more waves per SIMD).
-template <int TB, int NR, int WSEL = 0, bool TILE = false, class Epi>
+// rounds / ways of the explicit variants (what a caller's ring must be dimensioned with)
+template <int NR, int WSEL>
+struct DenseShape {
+  static constexpr int ways = WSEL == 0 ? 1 : WSEL;
+  static constexpr int nr = WSEL == 1 ? NR : 1;
+};
+
+template <int TB, int NR, int WSEL = 0, bool TILE = false, class Epi, class AfterK = DenseNoHook>
 __device__ __forceinline__ void tile_dense2(const float *__restrict__ in, int CP,
                                             const float *__restrict__ wp, int OP, bool sync_epi, Epi epi,
-                                            const float *__restrict__ init = nullptr) {
+                                            const float *__restrict__ init = nullptr,
+                                            f32x4 (*ring)[DenseShape<NR, WSEL>::nr] = nullptr,
+                                            AfterK after_k = AfterK()) {
   if constexpr (WSEL == 1) {
-    tile_dense_impl<TB, NR, 1, TILE>(in, CP, wp, OP, sync_epi, epi, init);
+    tile_dense_impl<TB, NR, 1, TILE, Epi, PCR_PF, AfterK>(in, CP, wp, OP, sync_epi, epi, init, ring, after_k);
   } else if constexpr (WSEL == 2) {
-    tile_dense_impl<TB, 1, 2, TILE>(in, CP, wp, OP, sync_epi, epi, init);
+    tile_dense_impl<TB, 1, 2, TILE, Epi, PCR_PF, AfterK>(in, CP, wp, OP, sync_epi, epi, init, ring, after_k);
   } else if constexpr (WSEL == 4) {
-    tile_dense_impl<TB, 1, 4, TILE>(in, CP, wp, OP, sync_epi, epi, init);
+    tile_dense_impl<TB, 1, 4, TILE, Epi, PCR_PF, AfterK>(in, CP, wp, OP, sync_epi, epi, init, ring, after_k);
   } else {
+    after_k();   // (generic shape: no early ring, the hook still runs once)
     const int nCB = OP >> 5;
     if (nCB > 4) tile_dense_impl<TB, NR, 1, TILE>(in, CP, wp, OP, sync_epi, epi, init);
     else if (nCB >= 3) tile_dense_impl<TB, 1, 1, TILE>(in, CP, wp, OP, sync_epi, epi, init);   // one round is enough
