@@ -125,3 +125,50 @@ def test_repeat_skipping_is_exact(n, npoint, radius, k, chans, kind):
     uniq = np.array([[len(np.unique(r)) for r in b] for b in want])
     c = cnt.cpu().numpy()
     assert ((c == uniq) | ((c == 0) & (uniq == 1))).all()      # cnt = 0: no hit at all (row of zeros)
+
+
+def test_point_major_layouts_change_nothing():
+    """features may travel between SA layers as the (B,C,S) view of a point-major buffer: every consumer reads
+    both layouts and gives identical results; the channel-major output form of the ragged kernel agrees too"""
+    from mmdet3d.ops import PointSAModule
+    from mmdet3d.ops.point_ops import ball_query_cnt, furthest_point_sample, gather_points
+    from pcr_amd import engine
+    sa1 = PointSAModule(mlp_channels=[0, 32, 32, 64], num_point=128, radius=0.3, num_sample=16)
+    sa2 = PointSAModule(mlp_channels=[64, 64, 64, 128], num_point=32, radius=0.6, num_sample=32)
+    for i, m in enumerate((sa1, sa2)):
+        m.load_state_dict(T.seeded_state_dict(T.manifest_of(m), 11 + i))
+        m.cuda().eval()
+    xyz = T.synthetic_clouds(3, 500, seed=8, kind="box").cuda()
+    x1, f1, _ = sa1(xyz, None)
+    assert f1.shape == (3, 64, 128) and not f1.is_contiguous() and f1.transpose(1, 2).is_contiguous()
+    _, f2_pm, _ = sa2(x1, f1)                      # point-major view in
+    _, f2_cm, _ = sa2(x1, f1.contiguous())         # channel-major copy in
+    assert torch.equal(f2_pm, f2_cm)
+    # the plan itself, channel-major output against point-major output
+    idx1 = furthest_point_sample(x1, 32)
+    c = gather_points(x1.transpose(1, 2).contiguous(), idx1).transpose(1, 2).contiguous()
+    bq, cnt = ball_query_cnt(0.0, 0.6, 32, x1, c)
+    plan = sa2._plan(0, xyz.device)
+    o_cm = plan.run(x1, f1, bq, centre_idx=idx1, cnt=cnt, out_point_major=False)
+    o_pm = plan.run(x1, f1, bq, centre_idx=idx1, cnt=cnt, out_point_major=True)
+    o_k = plan.run(x1, f1.contiguous(), bq, centre_idx=idx1, cnt=None, out_point_major=True)   # K-row kernel
+    assert o_cm.is_contiguous() and torch.equal(o_cm, o_pm) and torch.equal(o_cm, o_k) and torch.equal(o_cm, f2_pm)
+    # generic dense layer on either layout
+    w = torch.randn(48, 128, device="cuda")
+    wp = engine.pack_weight(w, xyz.device)
+    assert torch.equal(engine.dense(f2_pm, wp, 48), engine.dense(f2_pm.contiguous(), wp, 48))
+
+
+@pytest.mark.parametrize("B,n,npoint,k,radius", [(1, 64, 1, 8, 0.5), (2, 70, 33, 4, 0.2), (5, 1024, 512, 32, 0.05)])
+def test_ragged_path_small_and_degenerate_shapes(B, n, npoint, k, radius):
+    """one centre, odd sizes, (almost) empty balls: the tile lists and row tables of the ragged path hold up"""
+    from mmdet3d.ops import PointSAModule
+    sa = PointSAModule(mlp_channels=[0, 16, 32, 64], num_point=npoint, radius=radius, num_sample=k)
+    sa.load_state_dict(T.seeded_state_dict(T.manifest_of(sa), 3))
+    sa = sa.cuda().eval()
+    xyz = T.synthetic_clouds(B, n, seed=2, kind="box").cuda()
+    sa.skip_repeats = False
+    _, dense, _ = sa(xyz, None)
+    sa.skip_repeats = True
+    _, ragged, _ = sa(xyz, None)
+    assert torch.equal(dense, ragged)
