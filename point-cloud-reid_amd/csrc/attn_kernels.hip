@@ -32,21 +32,27 @@ __device__ __forceinline__ void load_xyz3(float *P, int RP, const float *xyz, in
   }
 }
 
-// One workgroup per key-side cloud, token tiles of T = 32*TB (TB = 2 for d = 32, else 1: the fused
-// K/V projection has 2d/32 >= 4 cout blocks, one per wave).
+// One workgroup per key-side cloud, token tiles of T = 32*TB (TB = 2 for d <= 64, 1 for d = 128).
 // kv image per cloud: packed (d x d) matrix M (merge folded in, see above) followed by ksum[d].
-// LDS: XH [c2 + d] key features ; hidden, KB [d], VB [d], P [3]; after the loop KVl [d][d+1].
-template <int TB, int NR>
+// LDS: XH [c2 + d] key features ; hidden -- the fused K/V projection (2d <= c2 + d rows) is written IN PLACE over
+// it (barrier between k-loop and epilogue) -- and P [3]; after the loop KVl [d][d+1].  34 KB at d = c2 = 64, so four
+// workgroups share a CU; the next tile's features are fetched into registers while this tile is on the matrix core.
+//   WSEL: dense shape of the 2d-row projection (2 / 1 / 1 for d = 32 / 64 / 128), NTW: KV tiles per wave (1 / 1 / 4)
+template <int TB, int NR, int WSEL, int NTW>
 __global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
   constexpr int T = 32 * TB, RP = T + 1;
+  constexpr int NPF = 4;   // 16-byte feature pieces per thread and tile held in registers (c2 * T / 4 / 256 <= NPF)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const pcr_attn_params &p = a.p;
   const int d = p.d, c2 = p.c2;
   float *XH = smem;
-  float *KB = XH + (c2 + d) * RP;
-  float *VB = KB + d * RP;
-  float *P = VB + d * RP;
+  float *KB = XH;             // rows [0,d) after the projection
+  float *VB = XH + d * RP;    // rows [d,2d)
+  float *P = XH + (c2 + d) * RP;
   float *s_w0 = P + 3 * RP, *s_b0 = s_w0 + 3 * d;   // staged pos-MLP first layer
+  // [256] partial key sums, beyond both the loop's buffers and the KVl / total-sum overlay used after it
+  const int tail_a = (c2 + d + 3) * RP + 4 * d, tail_b = d * (d + 1) + d;
+  float *s_ks = smem + (tail_a > tail_b ? tail_a : tail_b);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const size_t b = blockIdx.x;
@@ -59,33 +65,78 @@ __global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
   const float sk = (float)p.Sk;
   const float *bkv = p.bkv;
 
-  f32x16 acc[4];
+  f32x16 acc[NTW];
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < NTW; i++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+  // key sums: thread (row = tid % d, part = tid / d) adds up its share of the tokens of every tile
+  const int krow = tid % d, kpart = tid / d, kparts = kThreads / d;
   float ksum = 0.f;
 
+  // feature tile prefetch (whole, aligned tiles: one 16-byte piece per (row, 4 tokens); others go the plain way)
+  const int Q = T >> 2, npieces = c2 * Q;
+  const bool vec_ok = ((p.Sk & 3) == 0) && ((reinterpret_cast<size_t>(feat) & 15) == 0) && npieces <= NPF * kThreads;
+  f32x4 pf[NPF];
+  auto fetch = [&](int t0) {
+#pragma unroll
+    for (int u = 0; u < NPF; u++) {
+      const int e = tid + u * kThreads;
+      const int c = e / Q, q = e - c * Q;
+      const bool ok = e < npieces;
+      pf[u] = *reinterpret_cast<const f32x4 *>(feat + (size_t)(ok ? c : 0) * p.Sk + t0 + 4 * (ok ? q : 0));
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int u = 0; u < NPF; u++) {
+      const int e = tid + u * kThreads;
+      if (e < npieces) {
+        const int c = e / Q, q = e - c * Q;
+        float *dst = XH + c * RP + 4 * q;
+        dst[0] = pf[u][0];
+        dst[1] = pf[u][1];
+        dst[2] = pf[u][2];
+        dst[3] = pf[u][3];
+      }
+    }
+  };
+  bool have = false;   // the registers hold the tile about to be processed
+  if (vec_ok && T <= p.Sk) {
+    fetch(0);
+    have = true;
+  }
   for (int t0 = 0; t0 < p.Sk; t0 += T) {
     const int valid = p.Sk - t0;
-    load_tile(XH, RP, feat, c2, c2, p.Sk, t0, T);
+    if (have) stash();
+    else load_tile(XH, RP, feat, c2, c2, p.Sk, t0, T);
     load_xyz3(P, RP, xyz, p.Sk, t0, T);
     __syncthreads();
+    have = vec_ok && t0 + 2 * T <= p.Sk;   // the next tile is whole: request it now, store it after this tile's MFMAs
+    if (have) fetch(t0 + T);
     pos_hidden(XH + c2 * RP, RP, P, s_w0, s_b0, d, T);
     __syncthreads();
-    tile_dense2<TB, NR>(XH, c2 + d, p.wkv, 2 * d, false, [&](float v, int o, int t) {
-      if (o < d) KB[o * RP + t] = t < valid ? elu1(v) : 0.f;
-      else VB[(o - d) * RP + t] = t < valid ? v / sk : 0.f;
+    // (whole-tile epilogue: a 32-cout block is all K or all V, so the branch is wave-uniform)
+    tile_dense2<TB, NR, WSEL, true>(XH, c2 + d, p.wkv, 2 * d, true,
+                                    [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
+      const int t = tb * 32 + l31;
+      float *dst = XH + (cb * 32 + 4 * h) * RP + t;
+      const bool live = t < valid;
+      if (cb * 32 < d) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) dst[((r & 3) + 8 * (r >> 2)) * RP] = live ? elu1(acc[r]) : 0.f;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) dst[((r & 3) + 8 * (r >> 2)) * RP] = live ? acc[r] / sk : 0.f;
+      }
     }, bkv);   // biases seed the accumulators
     __syncthreads();
-    if (tid < d) {
-      const float *row = KB + tid * RP;
-      float s = 0.f;
-      for (int t = 0; t < T; t++) s += row[t];
-      ksum += s;
+    {
+      const float *row = KB + krow * RP;
+      for (int t = kpart; t < T; t += kparts) ksum += row[t];
     }
 #pragma unroll
-    for (int it = 0; it < 4; it++) {
+    for (int it = 0; it < NTW; it++) {
       const int item = wave + 4 * it;
       if (item < nT) {
         const int ib = item / nb, jb = item - ib * nb;
@@ -96,14 +147,15 @@ __global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
           acc[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc[it], 0, 0, 0);
       }
     }
-    // no barrier here: the next tile only rewrites XH/P before its first barrier, KB/VB after it
+    __syncthreads();   // K / V live in XH: the next tile may only be written once every wave is done with them
   }
-  __syncthreads();
   // KV (head-masked) -> LDS [dd][d+1], then fold the merge projection and write the packed image
   float *KVl = smem;
   const int ld = d + 1;
+  float *s_kt = smem + d * ld;   // [d] total key sums
+  s_ks[tid] = ksum;
 #pragma unroll
-  for (int it = 0; it < 4; it++) {
+  for (int it = 0; it < NTW; it++) {
     const int item = wave + 4 * it;
     if (item < nT) {
       const int ib = item / nb, jb = item - ib * nb;
@@ -116,6 +168,11 @@ __global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
     }
   }
   __syncthreads();
+  if (tid < d) {
+    float s = 0.f;
+    for (int pp = 0; pp < kparts; pp++) s += s_ks[pp * d + tid];
+    s_kt[tid] = s;
+  }
   float *kv = p.kv + b * ((size_t)d * d + d);
   for (int e = tid; e < d * d; e += kThreads) {
     const int o = e / d, dd = e - o * d;
@@ -128,12 +185,16 @@ __global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
     const int kb = dd >> 3, rem = dd & 7;
     kv[(((size_t)kb * d + o) * 2 + (rem & 1)) * 4 + (rem >> 1)] = m;
   }
-  if (tid < d) kv[(size_t)d * d + tid] = ksum;
+  __syncthreads();
+  if (tid < d) kv[(size_t)d * d + tid] = s_kt[tid];
 }
 
 // One workgroup per (query cloud, tile of T query tokens), T = 128 / 64 / 32 for d = 32 / 64 / 128.
-// LDS: CAT [c1 + d (pad 8)]: rows [0,c1) query features, rows [c1,c1+d) position hidden -> later
-// the merged message; W [max(2d,cout,cfinal)] working buffer; P [3]; zs [nhead]; red.
+// ONE LDS buffer U of max(c1 + d, 2d, cout, cfinal) rows, every dense phase in place (barrier between its
+// k-loop and its epilogue), so a d = 64 tile is 33 KB and four workgroups share a CU:
+//   rows [0,c1) query features x, rows [c1,c1+d) position hidden h  --Q-->  rows [c1,c1+d) = elu(.)+1
+//   --scale by Sk/(Q.ksum)--> --M (kv image)--> message --LayerNorm--> [x ; msg] --FFN0--> 2d rows --FFN1-->
+//   cout rows --LayerNorm--> (+ x, re-read from global: it was overwritten by FFN0) --cov_final--> store.
 template <int TB, int NR>
 __global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
   constexpr int T = 32 * TB, RP = T + 1;
@@ -141,12 +202,11 @@ __global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
   const pcr_attn_params &p = a.p;
   const int d = p.d, c1 = p.c1, cout = p.cout;
   const int catC = c1 + d, catP = ceil8(catC);
-  int rowsW = 2 * d;
-  if (ceil32(cout) > rowsW) rowsW = ceil32(cout);
-  if (ceil32(p.cfinal) > rowsW) rowsW = ceil32(p.cfinal);
-  float *CAT = smem;
-  float *W = CAT + catP * RP;
-  float *P = W + rowsW * RP;
+  int rowsU = catP > 2 * d ? catP : 2 * d;
+  if (ceil32(cout) > rowsU) rowsU = ceil32(cout);
+  if (ceil32(p.cfinal) > rowsU) rowsU = ceil32(p.cfinal);
+  float *U = smem;
+  float *P = U + rowsU * RP;
   float *zs = P + 3 * RP;
   float *red = zs + p.nhead * RP;  // [2 * (256/T)][T]
   // small constant vectors, staged once: reading them from global inside the per-element loops costs a
@@ -178,53 +238,53 @@ __global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
     s_ln2b[e] = p.ln2_b[e];
   }
   const float *ksum = s_ksum;
+  float *MSG = U + c1 * RP;   // rows [c1, c1+d): hidden -> Q -> message
 
-  load_tile(CAT, RP, feat, c1, c1, p.Lq, t0, T);
+  load_tile(U, RP, feat, c1, c1, p.Lq, t0, T);
   if (p.q_pos) {
     load_xyz3(P, RP, p.xyz_q + bq_ * p.Lq * 3, p.Lq, t0, T);
     __syncthreads();
-    pos_hidden(CAT + c1 * RP, RP, P, s_w0, s_b0, d, T);
-    for (int e = tid; e < (catP - catC) * T; e += kThreads) CAT[(catC + e / T) * RP + e % T] = 0.f;
+    pos_hidden(MSG, RP, P, s_w0, s_b0, d, T);
+    for (int e = tid; e < (catP - catC) * T; e += kThreads) U[(catC + e / T) * RP + e % T] = 0.f;
   } else {
-    for (int e = tid; e < (catP - c1) * T; e += kThreads) CAT[(c1 + e / T) * RP + e % T] = 0.f;
+    for (int e = tid; e < (catP - c1) * T; e += kThreads) U[(c1 + e / T) * RP + e % T] = 0.f;
   }
   __syncthreads();
-  {  // Q = elu(Wq' [x ; h] + bq) + 1
-    tile_dense2<TB, NR>(CAT, p.q_pos ? catP : ceil8(c1), p.wq, d, false,
-                       [&](float v, int o, int t) { W[o * RP + t] = elu1(v); }, p.bq);
-  }
+  // Q = elu(Wq' [x ; h] + bq) + 1, written over h
+  tile_dense2<TB, NR>(U, p.q_pos ? catP : ceil8(c1), p.wq, d, true,
+                      [&](float v, int o, int t) { MSG[o * RP + t] = elu1(v); }, p.bq);
   __syncthreads();
   for (int e = tid; e < p.nhead * T; e += kThreads) {
     const int hd = e / T, t = e - hd * T;
     float z = 0.f;
-    for (int c = 0; c < dh; c++) z += W[(hd * dh + c) * RP + t] * ksum[hd * dh + c];
+    for (int c = 0; c < dh; c++) z += MSG[(hd * dh + c) * RP + t] * ksum[hd * dh + c];
     zs[hd * RP + t] = (1.0f / (z + 1e-6f)) * (float)p.Sk;
   }
   __syncthreads();
   for (int e = tid; e < d * T; e += kThreads) {
     const int o = e / T, t = e - o * T;
-    W[o * RP + t] *= zs[(o / dh) * RP + t];
+    MSG[o * RP + t] *= zs[(o / dh) * RP + t];
   }
   __syncthreads();
-  tile_dense2<TB, NR>(W, d, kv, d, false, [&](float v, int o, int t) { CAT[(c1 + o) * RP + t] = v; });
+  tile_dense2<TB, NR>(MSG, d, kv, d, true, [&](float v, int o, int t) { MSG[o * RP + t] = v; });
   __syncthreads();
-  tile_layernorm(CAT + c1 * RP, d, RP, T, s_ln1g, s_ln1b, red);
-  tile_dense2<TB, NR>(CAT, catP, p.wmlp0, 2 * d, false, [&](float v, int o, int t) { W[o * RP + t] = fmaxf(v, 0.f); });
+  tile_layernorm(MSG, d, RP, T, s_ln1g, s_ln1b, red);
+  tile_dense2<TB, NR>(U, catP, p.wmlp0, 2 * d, true, [&](float v, int o, int t) { U[o * RP + t] = fmaxf(v, 0.f); });
   __syncthreads();
-  tile_dense2<TB, NR>(W, 2 * d, p.wmlp2, ceil32(cout), true, [&](float v, int o, int t) { W[o * RP + t] = v; });
+  tile_dense2<TB, NR>(U, 2 * d, p.wmlp2, ceil32(cout), true, [&](float v, int o, int t) { U[o * RP + t] = v; });
   __syncthreads();
-  tile_layernorm(W, cout, RP, T, s_ln2g, s_ln2b, red);
-  if (p.residual) {
+  tile_layernorm(U, cout, RP, T, s_ln2g, s_ln2b, red);
+  if (p.residual) {   // cout == c1: add the query features back (re-read: FFN0 has overwritten them)
     for (int e = tid; e < cout * T; e += kThreads) {
       const int c = e / T, t = e - c * T;
-      W[c * RP + t] = CAT[c * RP + t] + W[c * RP + t];
+      if (t0 + t < p.Lq) U[c * RP + t] += feat[(size_t)c * p.Lq + t0 + t];
     }
     __syncthreads();
   }
   int cres = cout;
   if (p.cfinal) {  // trailing 1x1 conv with bias (cov_final); needs cout % 8 == 0
     const int cf = p.cfinal;
-    tile_dense2<TB, NR>(W, cout, p.wfinal, ceil32(cf), true, [&](float v, int o, int t) { W[o * RP + t] = v; },
+    tile_dense2<TB, NR>(U, cout, p.wfinal, ceil32(cf), true, [&](float v, int o, int t) { U[o * RP + t] = v; },
                         p.bfinal);   // bfinal is zero-padded to a multiple of 32 by the host
     __syncthreads();
     cres = cf;
@@ -232,7 +292,7 @@ __global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
   float *out = p.out + b * cres * p.Lq;
   for (int e = tid; e < cres * T; e += kThreads) {
     const int c = e / T, t = e - c * T;
-    if (t0 + t < p.Lq) out[(size_t)c * p.Lq + t0 + t] = W[c * RP + t];
+    if (t0 + t < p.Lq) out[(size_t)c * p.Lq + t0 + t] = U[c * RP + t];
   }
 }
 
@@ -254,23 +314,25 @@ static int attn_check(const pcr_attn_params &p) {
 PCR_EXPORT int pcr_attn_kv_f32(const pcr_attn_params *pp, pcr_stream_t stream) {
   if (!pp || attn_check(*pp)) return PCR_ERR_INVALID;
   if (pp->B == 0) return PCR_OK;
+  if (pp->c2 < pp->d) return PCR_ERR_INVALID;   // the in-place K/V projection needs 2d <= c2 + d rows
   AttnArgs a;
   a.p = *pp;
   const int d = pp->d;
-  const int tb = d <= 32 ? 2 : 1, RP = 32 * tb + 1;
-  size_t lds = ((size_t)(pp->c2 + 3 * d + 3) * RP + 4 * d) * sizeof(float);
-  const size_t lds2 = (size_t)d * (d + 1) * sizeof(float);
+  const int tb = d <= 64 ? 2 : 1, RP = 32 * tb + 1;
+  size_t lds = (size_t)(pp->c2 + d + 3) * RP + 4 * d;
+  const size_t lds2 = (size_t)d * (d + 1) + d;
   if (lds2 > lds) lds = lds2;
+  lds = (lds + kThreads) * sizeof(float);
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
-  static bool ok = allow_big_lds(attn_kv_kernel<1, 1>) && allow_big_lds(attn_kv_kernel<1, 2>) &&
-                   allow_big_lds(attn_kv_kernel<2, 1>);
+  static bool ok = allow_big_lds(attn_kv_kernel<2, 1, 2, 1>) && allow_big_lds(attn_kv_kernel<2, 1, 1, 1>) &&
+                   allow_big_lds(attn_kv_kernel<1, 2, 1, 4>) && allow_big_lds(attn_kv_kernel<2, 1, 0, 1>);
   (void)ok;
   dim3 g(pp->B), blk(kThreads);
   hipStream_t st = pcr_s(stream);
-  // NR = 2 only when the fused K/V projection has more than four cout blocks (2d > 128)
-  if (tb == 2) hipLaunchKernelGGL((attn_kv_kernel<2, 1>), g, blk, lds, st, a);
-  else if (2 * d > 128) hipLaunchKernelGGL((attn_kv_kernel<1, 2>), g, blk, lds, st, a);
-  else hipLaunchKernelGGL((attn_kv_kernel<1, 1>), g, blk, lds, st, a);
+  if (d == 32) hipLaunchKernelGGL((attn_kv_kernel<2, 1, 2, 1>), g, blk, lds, st, a);        // 2d = 64: two cout blocks
+  else if (d == 64) hipLaunchKernelGGL((attn_kv_kernel<2, 1, 1, 1>), g, blk, lds, st, a);   // four, one per wave
+  else if (d == 128) hipLaunchKernelGGL((attn_kv_kernel<1, 2, 1, 4>), g, blk, lds, st, a);  // eight, two rounds
+  else hipLaunchKernelGGL((attn_kv_kernel<1, 2, 0, 4>), g, blk, lds, st, a);                // d = 96: generic shape
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }
@@ -284,10 +346,10 @@ PCR_EXPORT int pcr_attn_apply_f32(const pcr_attn_params *pp, pcr_stream_t stream
   a.p = p;
   const int tb = p.d <= 32 ? 4 : (p.d <= 64 ? 2 : 1), T = 32 * tb, RP = T + 1;
   const int catP = ceil8(p.c1 + p.d);
-  int rowsW = 2 * p.d;
-  if (ceil32(p.cout) > rowsW) rowsW = ceil32(p.cout);
-  if (ceil32(p.cfinal) > rowsW) rowsW = ceil32(p.cfinal);
-  size_t lds = ((size_t)(catP + rowsW + 3 + p.nhead) * RP + 2 * (kThreads / T) * T + 7 * p.d + 2 * p.cout) *
+  int rowsU = catP > 2 * p.d ? catP : 2 * p.d;
+  if (ceil32(p.cout) > rowsU) rowsU = ceil32(p.cout);
+  if (ceil32(p.cfinal) > rowsU) rowsU = ceil32(p.cfinal);
+  size_t lds = ((size_t)(rowsU + 3 + p.nhead) * RP + 2 * (kThreads / T) * T + 7 * p.d + 2 * p.cout) *
                sizeof(float);
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
   static bool ok = allow_big_lds(attn_apply_kernel<1, 2>) && allow_big_lds(attn_apply_kernel<2, 1>) &&
