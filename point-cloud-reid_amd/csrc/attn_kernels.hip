@@ -76,7 +76,10 @@ __global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
 
   // feature tile prefetch (whole, aligned tiles: one 16-byte piece per (row, 4 tokens); others go the plain way)
   const int Q = T >> 2, npieces = c2 * Q;
-  const bool vec_ok = ((p.Sk & 3) == 0) && ((reinterpret_cast<size_t>(feat) & 15) == 0) && npieces <= NPF * kThreads;
+#ifndef PCR_KV_PREFETCH
+#define PCR_KV_PREFETCH 1
+#endif
+  const bool vec_ok = PCR_KV_PREFETCH && ((p.Sk & 3) == 0) && ((reinterpret_cast<size_t>(feat) & 15) == 0) && npieces <= NPF * kThreads;
   f32x4 pf[NPF];
   auto fetch = [&](int t0) {
 #pragma unroll

@@ -137,11 +137,21 @@ struct Sa2Args {
 };
 
 // NR / NR2: cout-block rounds per wave of layer 3 / layer 2 (2 when the layer has more than 4 x 32 couts)
-template <int TB, int NR, int W2, int W3, bool MAXE, int NR2 = NR>
+// RKB > 0 (narrow layers: c1, c2 <= 8 RKB): ALL weight fragments of layers 2 and 3 are fetched into registers at
+// the top of the kernel, behind the index staging and the gathers; the two dense calls then run without a single
+// weight load (their 4- or 8-block k-loops were mostly L2 latency)
+template <int TB, int NR, int W2, int W3, bool MAXE, int NR2 = NR, int RKB = 0>
 __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
   constexpr int ROWS = 32 * TB, RP = ROWS + 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int c1 = a.c1, c2 = a.c2, c3 = a.c3, K = a.K;
+  constexpr bool kRes = RKB > 0;
+  constexpr int RK = kRes ? RKB : 2;
+  f32x4 wres2[RK][DenseShape<NR2, W2>::nr], wres3[RK][DenseShape<NR, W3>::nr];
+  if constexpr (kRes) {
+    tile_dense_ring_load<DenseShape<NR2, W2>::nr, DenseShape<NR2, W2>::ways, RK>(a.wp2, c1, ceil32(c2), wres2);
+    tile_dense_ring_load<DenseShape<NR, W3>::nr, DenseShape<NR, W3>::ways, RK>(a.wp3, ceil8(c2), ceil32(c3), wres3);
+  }
   // MAXE (K % 16 == 0): the max over K is taken from the layer-3 accumulators (16-lane DPP groups ->
   // gmax[c3][ROWS/16]) and the (c3 x rows) layer-3 output is never materialised in LDS
   int rowsC = c1 > ceil32(c2) ? c1 : ceil32(c2);
@@ -244,26 +254,34 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
       // BatchNorm scale is folded into wp2/wp3 by the host, the shift seeds the accumulators
       // the buffer has ceil32(c2) rows, so every accumulator row is stored unconditionally (rows past c2
       // see zero weights and a zero seed -> relu(0) = 0, which is the zero padding layer 3 wants)
-      tile_dense2<TB, NR2, W2>(buf, c1, a.wp2, ceil32(c2), true, [&](float v, int o, int t) {
-        buf[o * RP + t] = fmaxf(v, 0.f);
-      }, a.sh2);
+      auto epi2 = [&](float v, int o, int t) { buf[o * RP + t] = relu_bits(v); };
+      if constexpr (kRes)
+        tile_dense2<TB, NR2, W2, false, decltype(epi2), DenseNoHook, RK, true>(buf, c1, a.wp2, ceil32(c2), true, epi2,
+                                                                               a.sh2, wres2);
+      else
+        tile_dense2<TB, NR2, W2>(buf, c1, a.wp2, ceil32(c2), true, epi2, a.sh2);
     }
     __syncthreads();
     if constexpr (MAXE) {
       constexpr int NG = 2 * TB;
-      tile_dense2<TB, NR, W3, true>(buf, ceil8(c2), a.wp3, ceil32(c3), false,
-                                    [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
+      // (signed maxima of the bit patterns, ReLU at the end: see relu_bits)
+      auto epi3 = [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int o = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          float v = fmaxf(acc[r], 0.f);
-          v = fmaxf(v, dpp_f32<0xB1>(v));    // quad_perm [1,0,3,2]  : lane ^ 1
-          v = fmaxf(v, dpp_f32<0x4E>(v));    // quad_perm [2,3,0,1]  : lane ^ 2
-          v = fmaxf(v, dpp_f32<0x141>(v));   // row_half_mirror      : other quad of the 8-lane half
-          v = fmaxf(v, dpp_f32<0x140>(v));   // row_mirror           : other half of the 16-lane row
-          if ((l31 & 15) == 0) gmax[o * NG + tb * 2 + (l31 >> 4)] = v;      // gmax has ceil32(c3) rows
+          int v = __float_as_int(acc[r]);
+          v = imax(v, dpp_i32<0xB1>(v));    // quad_perm [1,0,3,2]  : lane ^ 1
+          v = imax(v, dpp_i32<0x4E>(v));    // quad_perm [2,3,0,1]  : lane ^ 2
+          v = imax(v, dpp_i32<0x141>(v));   // row_half_mirror      : other quad of the 8-lane half
+          v = imax(v, dpp_i32<0x140>(v));   // row_mirror           : other half of the 16-lane row
+          if ((l31 & 15) == 0) gmax[o * NG + tb * 2 + (l31 >> 4)] = __int_as_float(imax(v, 0));   // ceil32(c3) rows
         }
-      }, a.sh3);
+      };
+      if constexpr (kRes)
+        tile_dense2<TB, NR, W3, true, decltype(epi3), DenseNoHook, RK, true>(buf, ceil8(c2), a.wp3, ceil32(c3), false,
+                                                                             epi3, a.sh3, wres3);
+      else
+        tile_dense2<TB, NR, W3, true>(buf, ceil8(c2), a.wp3, ceil32(c3), false, epi3, a.sh3);
     } else {
       tile_dense2<TB, NR, W3>(buf, ceil8(c2), a.wp3, ceil32(c3), true, [&](float v, int o, int t) {
         buf[o * RP + t] = fmaxf(v, 0.f);
@@ -705,16 +723,16 @@ __global__ __launch_bounds__(kThreads) void dense_pm_kernel(DensePmArgs a) {
 
 }  // namespace
 
-template <int TB, int NR, int W2, int W3, int NR2 = NR>
+template <int TB, int NR, int W2, int W3, int NR2 = NR, int RKB = 0>
 static void sa2_launch_one(const Sa2Args &a, bool maxe, size_t lds, hipStream_t st, dim3 grid) {
   if (maxe) {
-    static bool ok = allow_big_lds(sa_fused_kernel<TB, NR, W2, W3, true, NR2>);
+    static bool ok = allow_big_lds(sa_fused_kernel<TB, NR, W2, W3, true, NR2, RKB>);
     (void)ok;
-    hipLaunchKernelGGL((sa_fused_kernel<TB, NR, W2, W3, true, NR2>), grid, dim3(kThreads), lds, st, a);
+    hipLaunchKernelGGL((sa_fused_kernel<TB, NR, W2, W3, true, NR2, RKB>), grid, dim3(kThreads), lds, st, a);
   } else {
-    static bool ok = allow_big_lds(sa_fused_kernel<TB, NR, W2, W3, false, NR2>);
+    static bool ok = allow_big_lds(sa_fused_kernel<TB, NR, W2, W3, false, NR2, RKB>);
     (void)ok;
-    hipLaunchKernelGGL((sa_fused_kernel<TB, NR, W2, W3, false, NR2>), grid, dim3(kThreads), lds, st, a);
+    hipLaunchKernelGGL((sa_fused_kernel<TB, NR, W2, W3, false, NR2, RKB>), grid, dim3(kThreads), lds, st, a);
   }
 }
 
@@ -723,7 +741,11 @@ static void sa2_launch_one(const Sa2Args &a, bool maxe, size_t lds, hipStream_t 
 template <int TB>
 static int sa2_launch_tb(const Sa2Args &a, int nr, int nr2, int wsel, bool maxe, size_t lds, hipStream_t st,
                          dim3 grid) {
-  if (wsel == 4) sa2_launch_one<TB, 1, 4, 4>(a, maxe, lds, st, grid);
+  // resident weight fragments for 32-channel layers (2 x 16 VGPRs).  For 64-channel layers the 2 x 32 VGPRs cost
+  // more residency than the saved L2 round trips are worth (measured: 6.4 -> 7.9 ms on the 64/64/64 layer).
+  const bool narrow4 = a.c1 <= 32 && a.c2 <= 32;
+  if (wsel == 4 && narrow4) sa2_launch_one<TB, 1, 4, 4, 1, 4>(a, maxe, lds, st, grid);
+  else if (wsel == 4) sa2_launch_one<TB, 1, 4, 4>(a, maxe, lds, st, grid);
   else if (wsel == 2) sa2_launch_one<TB, 1, 2, 2>(a, maxe, lds, st, grid);
   else if (wsel == 1 && nr == 1) sa2_launch_one<TB, 1, 1, 1>(a, maxe, lds, st, grid);
   else if (wsel == 1 && nr2 == 1) sa2_launch_one<TB, 2, 1, 1, 1>(a, maxe, lds, st, grid);
@@ -862,8 +884,8 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   const int nmin = n2 < n3 ? n2 : n3;
   const int ways = nmin >= 3 ? 1 : (nmin == 2 ? 2 : 4);
   const int nr = (n2 > 4 || n3 > 4) ? 2 : 1, nr2 = n2 > 4 ? 2 : 1;
-  // Tile choice.  Measured on MI355X: time per row ~ padding x wave imbalance x
-  // (1 + 2.5 / resident workgroups per CU); residency is bounded by LDS (160 KiB, 2 KiB granules),
+  // Tile choice.  Measured on MI355X (re-fitted after the epilogue / k-loop work, which halved what
+  // a low residency costs): time per row ~ padding x wave imbalance x (1 + 1.0 / resident workgroups per CU); residency is bounded by LDS (160 KiB, 2 KiB granules),
   // by registers (accumulator tiles + ~70 VGPRs against 512 per SIMD lane) and by 8 workgroups.
   int best_cpw = 0, best_tb = 0;
   double best_cost = 1e30;
@@ -883,7 +905,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
     if (wgs < 1) continue;
     const double pad = (double)(32 * tb) / (double)(cpw * p.K);
     const double imb = (double)(tbw * ways) / (double)tb;
-    const double cost = pad * imb * (1.0 + 2.5 / wgs);
+    const double cost = pad * imb * (1.0 + 1.0 / wgs);
     if (cost < best_cost - 1e-9) { best_cost = cost; best_cpw = cpw; best_tb = tb; }
   }
   static const int force_cpw = getenv("PCR_SA_CPW") ? atoi(getenv("PCR_SA_CPW")) : 0;   // tuning aid

@@ -105,7 +105,10 @@ __device__ __forceinline__ void tile_dense_ring_load(const float *__restrict__ w
 
 // ring: nullptr, or the fragments tile_dense_ring_load fetched for THIS call.  after_k(): called once between
 // the k-loop and the epilogue (before the sync_epi barrier): the place to request the next call's ring.
-template <int TB, int NR, int WAYS, bool TILE, class Epi, int PF = PCR_PF, class AfterK = DenseNoHook>
+// RES (resident weights): `ring` holds ALL k-blocks of the call (KB <= PF, narrow layers): no weight load inside
+// the call at all -- a caller that runs the same layer on many tiles fetches the ring once.
+template <int TB, int NR, int WAYS, bool TILE, class Epi, int PF = PCR_PF, class AfterK = DenseNoHook,
+          bool RES = false>
 // PF must be even (the B-operand double buffer alternates per k-block)
 __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, int CP,
                                                 const float *__restrict__ wp, int OP, bool sync_epi,
@@ -202,6 +205,17 @@ __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, in
   };
   load_x(xb[0], 0);
   int kb = 0;
+  if constexpr (RES) {
+#pragma unroll
+    for (int i = 0; i < PF; i++)
+      if (i < KB) {
+        load_x(xb[(i + 1) & 1], i + 1 < KB ? i + 1 : KB - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(aw[i], xb[i & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    kb = KB;
+  }
   // main groups: every prefetch address is inside the image (no clamps: plain pointer increments)
   for (; kb + 2 * PF <= KB; kb += PF) {
 #pragma unroll
@@ -274,18 +288,19 @@ struct DenseShape {
   static constexpr int nr = WSEL == 1 ? NR : 1;
 };
 
-template <int TB, int NR, int WSEL = 0, bool TILE = false, class Epi, class AfterK = DenseNoHook>
+template <int TB, int NR, int WSEL = 0, bool TILE = false, class Epi, class AfterK = DenseNoHook, int PFv = PCR_PF,
+          bool RES = false>
 __device__ __forceinline__ void tile_dense2(const float *__restrict__ in, int CP,
                                             const float *__restrict__ wp, int OP, bool sync_epi, Epi epi,
                                             const float *__restrict__ init = nullptr,
                                             f32x4 (*ring)[DenseShape<NR, WSEL>::nr] = nullptr,
                                             AfterK after_k = AfterK()) {
   if constexpr (WSEL == 1) {
-    tile_dense_impl<TB, NR, 1, TILE, Epi, PCR_PF, AfterK>(in, CP, wp, OP, sync_epi, epi, init, ring, after_k);
+    tile_dense_impl<TB, NR, 1, TILE, Epi, PFv, AfterK, RES>(in, CP, wp, OP, sync_epi, epi, init, ring, after_k);
   } else if constexpr (WSEL == 2) {
-    tile_dense_impl<TB, 1, 2, TILE, Epi, PCR_PF, AfterK>(in, CP, wp, OP, sync_epi, epi, init, ring, after_k);
+    tile_dense_impl<TB, 1, 2, TILE, Epi, PFv, AfterK, RES>(in, CP, wp, OP, sync_epi, epi, init, ring, after_k);
   } else if constexpr (WSEL == 4) {
-    tile_dense_impl<TB, 1, 4, TILE, Epi, PCR_PF, AfterK>(in, CP, wp, OP, sync_epi, epi, init, ring, after_k);
+    tile_dense_impl<TB, 1, 4, TILE, Epi, PFv, AfterK, RES>(in, CP, wp, OP, sync_epi, epi, init, ring, after_k);
   } else {
     after_k();   // (generic shape: no early ring, the hook still runs once)
     const int nCB = OP >> 5;
