@@ -122,25 +122,44 @@ __global__ __launch_bounds__(kThreads) void dense_kernel(DenseArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int cinP = ceil8(a.cin), coutP = ceil32(a.cout);
   float *X = smem;
+  float *s_sc = X + cinP * RP;   // [256] scale and [256] shift of this workgroup's cout chunk (1 / 0 when absent)
+  float *s_sh = s_sc + 256;
   const size_t b = blockIdx.y;
   const int t0 = blockIdx.x * T;
   const int chunk0 = blockIdx.z * 256;
   const int chunkP = coutP - chunk0 < 256 ? coutP - chunk0 : 256;
+  {
+    const int oc = chunk0 + threadIdx.x;   // kThreads == 256
+    s_sc[threadIdx.x] = (a.scale && oc < a.cout) ? a.scale[oc] : 1.0f;
+    s_sh[threadIdx.x] = (a.shift && oc < a.cout) ? a.shift[oc] : 0.0f;
+  }
   if (a.x_pm) load_tile_pm(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
   else load_tile(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
   __syncthreads();
-  const float *sc = a.scale, *sh = a.shift;
   const int cout = a.cout, act = a.act, L = a.L;
   float *out = a.y + b * a.cout * a.L;
-  // packed image rows [chunk0, chunk0+chunkP) of every k-block: offset chunk0*8 floats, stride coutP
+  // packed image rows [chunk0, chunk0+chunkP) of every k-block: offset chunk0*8 floats, stride coutP.
+  // Pipelined dense tile (weights through a register ring, B operands one k-block ahead); the epilogue takes a
+  // whole 32x32 tile: the lane's 16 couts are four runs of four, so scale / shift are eight 16-byte LDS reads.
   const float *wp = a.wp + b * a.w_bstride + (size_t)chunk0 * 8;
-  tile_dense_strided<TB, 2>(X, cinP, wp, chunkP, coutP, [&](float v, int o, int t) {
-    const int oc = chunk0 + o;
-    if (oc < cout && t0 + t < L) {
-      float r = v * (sc ? sc[oc] : 1.0f) + (sh ? sh[oc] : 0.0f);
-      out[(size_t)oc * L + t0 + t] = act ? fmaxf(r, 0.f) : r;
+  tile_dense2<TB, 2, 0, true>(X, cinP, wp, chunkP, false, [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
+    const int t = tb * 32 + l31;
+    if (t0 + t < L) {
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int o = cb * 32 + 8 * g + 4 * h;
+        const f32x4 s4 = *reinterpret_cast<const f32x4 *>(s_sc + o), b4 = *reinterpret_cast<const f32x4 *>(s_sh + o);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int oc = chunk0 + o + q;
+          if (oc < cout) {
+            const float r = acc[4 * g + q] * s4[q] + b4[q];
+            out[(size_t)oc * L + t0 + t] = act ? fmaxf(r, 0.f) : r;
+          }
+        }
+      }
     }
-  });
+  }, nullptr, nullptr, DenseNoHook(), coutP);
 }
 
 // (B,C,L) -> out[c * B + b] = max over L   (channel-major with the clouds as tokens: (1,C,B))
@@ -257,7 +276,7 @@ static int dense_launch(const float *x, const float *wp, long w_bstride, const f
   DenseArgs a{x, wp, scale, shift, y, cin, cout, L, act, w_bstride, x_pm};
   const int cinP = ceil8(cin);
   const int tb = ((size_t)cinP * 65 * 4 <= 72 * 1024 && L > 32) ? 2 : 1;
-  size_t lds = (size_t)cinP * (32 * tb + 1) * sizeof(float);
+  size_t lds = ((size_t)cinP * (32 * tb + 1) + 512) * sizeof(float);
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
   static bool ok = allow_big_lds(dense_kernel<1>) && allow_big_lds(dense_kernel<2>);
   (void)ok;

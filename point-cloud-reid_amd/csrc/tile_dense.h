@@ -113,7 +113,8 @@ template <int TB, int NR, int WAYS, bool TILE, class Epi, int PF = PCR_PF, class
 __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, int CP,
                                                 const float *__restrict__ wp, int OP, bool sync_epi,
                                                 Epi epi, const float *__restrict__ init = nullptr,
-                                                f32x4 (*ring)[NR] = nullptr, AfterK after_k = AfterK()) {
+                                                f32x4 (*ring)[NR] = nullptr, AfterK after_k = AfterK(),
+                                                int opfull = 0) {
   constexpr int RP = 32 * TB + 1;
   constexpr int TBW = (TB + WAYS - 1) / WAYS;  // token blocks per wave
   const int lane = threadIdx.x & 63;
@@ -128,7 +129,8 @@ __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, in
 #ifdef PCR_DIAG_WSTRIDE0
   const size_t wstride = 0;   // diagnostic build only: every k-block re-reads the first one (L1 hits)
 #else
-  const size_t wstride = (size_t)OP * 2;
+  // opfull: `wp` points at a WINDOW of OP cout rows inside a wider packed image of opfull padded couts
+  const size_t wstride = (size_t)(opfull ? opfull : OP) * 2;
 #endif
   const f32x4 *wrow[NR];
 #pragma unroll
@@ -294,20 +296,21 @@ __device__ __forceinline__ void tile_dense2(const float *__restrict__ in, int CP
                                             const float *__restrict__ wp, int OP, bool sync_epi, Epi epi,
                                             const float *__restrict__ init = nullptr,
                                             f32x4 (*ring)[DenseShape<NR, WSEL>::nr] = nullptr,
-                                            AfterK after_k = AfterK()) {
+                                            AfterK after_k = AfterK(), int opfull = 0) {
   if constexpr (WSEL == 1) {
-    tile_dense_impl<TB, NR, 1, TILE, Epi, PFv, AfterK, RES>(in, CP, wp, OP, sync_epi, epi, init, ring, after_k);
+    tile_dense_impl<TB, NR, 1, TILE, Epi, PFv, AfterK, RES>(in, CP, wp, OP, sync_epi, epi, init, ring, after_k, opfull);
   } else if constexpr (WSEL == 2) {
-    tile_dense_impl<TB, 1, 2, TILE, Epi, PFv, AfterK, RES>(in, CP, wp, OP, sync_epi, epi, init, ring, after_k);
+    tile_dense_impl<TB, 1, 2, TILE, Epi, PFv, AfterK, RES>(in, CP, wp, OP, sync_epi, epi, init, ring, after_k, opfull);
   } else if constexpr (WSEL == 4) {
-    tile_dense_impl<TB, 1, 4, TILE, Epi, PFv, AfterK, RES>(in, CP, wp, OP, sync_epi, epi, init, ring, after_k);
+    tile_dense_impl<TB, 1, 4, TILE, Epi, PFv, AfterK, RES>(in, CP, wp, OP, sync_epi, epi, init, ring, after_k, opfull);
   } else {
     after_k();   // (generic shape: no early ring, the hook still runs once)
     const int nCB = OP >> 5;
-    if (nCB > 4) tile_dense_impl<TB, NR, 1, TILE>(in, CP, wp, OP, sync_epi, epi, init);
-    else if (nCB >= 3) tile_dense_impl<TB, 1, 1, TILE>(in, CP, wp, OP, sync_epi, epi, init);   // one round is enough
-    else if (nCB == 2) tile_dense_impl<TB, 1, 2, TILE>(in, CP, wp, OP, sync_epi, epi, init);
-    else tile_dense_impl<TB, 1, 4, TILE>(in, CP, wp, OP, sync_epi, epi, init);
+    const DenseNoHook nh;
+    if (nCB > 4) tile_dense_impl<TB, NR, 1, TILE>(in, CP, wp, OP, sync_epi, epi, init, nullptr, nh, opfull);
+    else if (nCB >= 3) tile_dense_impl<TB, 1, 1, TILE>(in, CP, wp, OP, sync_epi, epi, init, nullptr, nh, opfull);   // one round
+    else if (nCB == 2) tile_dense_impl<TB, 1, 2, TILE>(in, CP, wp, OP, sync_epi, epi, init, nullptr, nh, opfull);
+    else tile_dense_impl<TB, 1, 4, TILE>(in, CP, wp, OP, sync_epi, epi, init, nullptr, nh, opfull);
   }
 }
 
