@@ -784,6 +784,147 @@ __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_kernel(const float *_
   }
 }
 
+// Second generation (clouds of up to 2048 points): the wave keeps the whole cloud in REGISTERS as packed
+// pairs (no LDS reads per query; packed f32 subtract / multiply / add = pcr_sqdist3's operations, two points per
+// instruction), and every ranking step is a count over v_readlane broadcasts -- three instructions per
+// comparand -- on keys whose order is the required one:
+//   tau : lane minima as 32-bit keys (distance bits with the low 6 bits replaced by the lane: unique, and
+//         monotone up to 64 ulps); the lane of rank K-1 gives tau = its distance with those 6 bits SET, still an
+//         upper bound of the K-th smallest distance (K lanes have a minimum <= tau);
+//   rank: the candidates d <= tau (a few more than K) are compacted one per lane and ranked by their exact
+//         64-bit (distance, index) keys; ranks < K are the answer in (distance, index) order.
+// More than 64 candidates (duplicate-heavy clouds) go through the LDS path of the first generation, more than
+// kKnnCap through the K-round fallback; all paths produce the same output.
+template <int TP>   // point PAIRS per lane: n <= 128 * TP
+__global__ __launch_bounds__(kKnnPThreads) void knn_prefix_reg_kernel(const float *__restrict__ xyz,
+                                                                  int *__restrict__ idx, int n, int S,
+                                                                  int K, int qpw) {
+  constexpr int T = 2 * TP;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *sx = smem, *sy = smem + n, *sz = smem + 2 * n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long *cand =
+      reinterpret_cast<unsigned long long *>(smem + 3 * n + (n & 1)) + wave * kKnnCap;
+  const size_t b = blockIdx.y;
+  const float *cloud = xyz + b * n * 3;
+  for (int i = tid; i < n; i += kKnnPThreads) {
+    sx[i] = cloud[3 * i];
+    sy[i] = cloud[3 * i + 1];
+    sz[i] = cloud[3 * i + 2];
+  }
+  __syncthreads();
+  f32x2 px[TP], py[TP], pz[TP];
+#pragma unroll
+  for (int t = 0; t < T; t++) {
+    const int i = lane + 64 * t;
+    const bool ok = i < n;
+    px[t >> 1][t & 1] = ok ? sx[i] : INFINITY;   // a point at infinity is never among the K nearest (K <= n)
+    py[t >> 1][t & 1] = ok ? sy[i] : INFINITY;
+    pz[t >> 1][t & 1] = ok ? sz[i] : INFINITY;
+  }
+  const int q0 = blockIdx.x * qpw;
+  const int q1 = (q0 + qpw < S) ? q0 + qpw : S;
+  for (int q = q0 + wave; q < q1; q += kKnnPThreads / 64) {
+    const float qx = sx[q], qy = sy[q], qz = sz[q];
+    const f32x2 x1 = {qx, qx}, y1 = {qy, qy}, z1 = {qz, qz};
+    uint32_t d[T];   // distances as BITS (>= +0: unsigned order = float order; +inf = 0x7f800000 sorts last)
+    uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+    for (int t = 0; t < TP; t++) {
+      const f32x2 dx = px[t] - x1, dy = py[t] - y1, dz = pz[t] - z1;   // pcr_sqdist3(q, p): p - q
+      const f32x2 a = dx * dx;
+      const f32x2 bb = dy * dy;
+      const f32x2 c = dz * dz;
+      const f32x2 sab = a + bb;
+      const f32x2 dd = sab + c;
+      d[2 * t] = __float_as_uint(dd[0]);
+      d[2 * t + 1] = __float_as_uint(dd[1]);
+      const uint32_t m01 = d[2 * t] < d[2 * t + 1] ? d[2 * t] : d[2 * t + 1];
+      m = m01 < m ? m01 : m;
+    }
+    // 1. the lane whose (truncated, lane-tagged) minimum has rank K-1
+    const uint32_t mkey = (m & ~63u) | (uint32_t)lane;
+    int rank = 0;
+#pragma unroll 8
+    for (int j = 0; j < 64; j++) {
+      const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)mkey, j);
+      rank += kj < mkey ? 1 : 0;
+    }
+    const unsigned long long hit = __ballot(rank == K - 1);    // exactly one lane: the keys are distinct
+    const uint32_t tau = (uint32_t)__builtin_amdgcn_readlane((int)mkey, (int)__builtin_ctzll(hit)) | 63u;
+    // 2. candidates d <= tau
+    int cnt = 0;
+#pragma unroll
+    for (int t = 0; t < T; t++) cnt += d[t] <= tau ? 1 : 0;
+    int incl = cnt;
+#pragma unroll
+    for (int s2 = 1; s2 < 64; s2 <<= 1) {
+      const int o = __shfl_up(incl, s2, 64);
+      if (lane >= s2) incl += o;
+    }
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    int *out = idx + (b * S + q) * K;
+    if (total <= kKnnCap) {
+      int off = incl - cnt;
+#pragma unroll
+      for (int t = 0; t < T; t++)
+        if (d[t] <= tau) cand[off++] = ((unsigned long long)(d[t] | 0x80000000u) << 32) | (unsigned)(lane + 64 * t);
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (total <= 64) {
+        // 3a. one candidate per lane, ranked over readlane broadcasts of the two key halves
+        const unsigned long long own = lane < total ? cand[lane] : ~0ull;
+        const uint32_t ohi = (uint32_t)(own >> 32), olo = (uint32_t)own;
+        int rk = 0;
+        for (int j = 0; j < total; j++) {
+          const uint32_t jhi = (uint32_t)__builtin_amdgcn_readlane((int)ohi, j);
+          const uint32_t jlo = (uint32_t)__builtin_amdgcn_readlane((int)olo, j);
+          const unsigned long long cj = ((unsigned long long)jhi << 32) | jlo;
+          rk += cj < own ? 1 : 0;
+        }
+        if (lane < total && rk < K) out[rk] = (int)olo;
+      } else {
+        // 3b. up to kKnnCap candidates: four per lane, broadcast LDS reads
+        unsigned long long own[kKnnCap / 64];
+        int rk[kKnnCap / 64];
+#pragma unroll
+        for (int u = 0; u < kKnnCap / 64; u++) {
+          own[u] = lane + 64 * u < total ? cand[lane + 64 * u] : ~0ull;
+          rk[u] = 0;
+        }
+        for (int j = 0; j < total; j++) {
+          const unsigned long long cj = cand[j];
+#pragma unroll
+          for (int u = 0; u < kKnnCap / 64; u++) rk[u] += cj < own[u] ? 1 : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kKnnCap / 64; u++)
+          if (lane + 64 * u < total && rk[u] < K) out[rk[u]] = (int)(own[u] & 0xFFFFFFFFull);
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      int mine = 0;
+      for (int k = 0; k < K; k++) {
+        uint32_t bd = d[0];
+        int bt = 0;
+#pragma unroll
+        for (int t = 1; t < T; t++)
+          if (d[t] < bd) { bd = d[t]; bt = t; }
+        unsigned long long key = ((unsigned long long)(bd | 0x80000000u) << 32) | (unsigned)(lane + 64 * bt);
+        key = pcr_wave_min_u64(key);
+        const int win = (int)(key & 0xFFFFFFFFull);
+        if (lane == k) mine = win;
+        if (lane == (win & 63)) {
+          const int wt = win >> 6;
+#pragma unroll
+          for (int t = 0; t < T; t++) d[t] = (t == wt) ? 0xFFFFFFFFu : d[t];
+        }
+      }
+      if (lane < K) out[lane] = mine;
+    }
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------ C ABI ----
@@ -916,13 +1057,14 @@ PCR_EXPORT int pcr_knn_prefix_f32(const float *xyz, int *idx, int B, int N, int 
   size_t lds = (size_t)(3 * N + (N & 1)) * sizeof(float) + (size_t)4 * kKnnCap * 8;
   hipStream_t st = pcr_s(stream);
 #define PCR_KNN_CASE(T) hipLaunchKernelGGL((knn_prefix_kernel<T>), g, blk, lds, st, xyz, idx, N, S, K, qpw)
-  if (N <= 64) PCR_KNN_CASE(1);
-  else if (N <= 128) PCR_KNN_CASE(2);
-  else if (N <= 256) PCR_KNN_CASE(4);
-  else if (N <= 512) PCR_KNN_CASE(8);
-  else if (N <= 1024) PCR_KNN_CASE(16);
-  else if (N <= 2048) PCR_KNN_CASE(32);
+#define PCR_KNN_REG(TP) hipLaunchKernelGGL((knn_prefix_reg_kernel<TP>), g, blk, lds, st, xyz, idx, N, S, K, qpw)
+  if (N <= 128) PCR_KNN_REG(1);
+  else if (N <= 256) PCR_KNN_REG(2);
+  else if (N <= 512) PCR_KNN_REG(4);
+  else if (N <= 1024) PCR_KNN_REG(8);
+  else if (N <= 2048) PCR_KNN_REG(16);
   else PCR_KNN_CASE(64);
+#undef PCR_KNN_REG
 #undef PCR_KNN_CASE
   PCR_CHECK_LAUNCH();
   return PCR_OK;
