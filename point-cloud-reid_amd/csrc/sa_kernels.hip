@@ -367,11 +367,11 @@ __global__ __launch_bounds__(256) void sa_rag_plan_kernel(RagArgs a, int rows_pe
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= a.B) return;
-  const int *cnt = a.cnt + (size_t)b * a.S;
+  const int *cnt = a.cnt ? a.cnt + (size_t)b * a.S : nullptr;   // no counts: every row of idx is genuine (kNN groups)
   int *tl = a.ws + rag_desc_off(a.B) + (size_t)b * 2 * a.maxT;
   int t = 0, used = 0, first = 0;
   for (int base = 0; base < a.S; base += 64) {
-    int c = base + lane < a.S ? cnt[base + lane] : 1;
+    int c = (cnt && base + lane < a.S) ? cnt[base + lane] : (cnt ? 1 : a.K);
     c = c < 1 ? 1 : (c > a.K ? a.K : c);
     const int g = (c + 3) & ~3;
     const int nv = a.S - base < 64 ? a.S - base : 64;
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void sa_rag_rows_kernel(RagArgs a) {
     const int first = td.y, nc = td.z;      // nc <= MAXC <= 32 < 64 lanes
     int n = 1;
     if (lane < nc) {
-      n = a.cnt[b * a.S + first + lane];
+      n = a.cnt ? a.cnt[b * a.S + first + lane] : a.K;
       n = n < 1 ? 1 : (n > a.K ? a.K : n);
     }
     const int g = lane < nc ? (n + 3) & ~3 : 0;
@@ -787,7 +787,10 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   if ((p.c1 & 7) || p.c1 > 256 || p.c2 > 256 || p.c3 > 256) return -1;
   const int pqw = p.mode == 0 ? 2 * p.c1 : p.c1;
   if (p.D && pqw > 256) return -1;
-  if (p.cnt && p.tile_ws && p.mode == 1) {   // duplicate-free path for ball-query groups
+  // the persistent, register-pipelined kernel: ball-query groups with hit counts (only the distinct rows are
+  // evaluated).  (It also runs count-less featureless layers -- all K rows -- but the K-row kernel with resident
+  // weights is faster there: 2.2 vs 2.9 ms on the 32-channel kNN layer, its row tables are 0.5 GB of extra traffic.)
+  if (p.tile_ws && p.cnt && p.mode == 1) {
     const int n2r = ceil32(p.c2) >> 5, n3r = ceil32(p.c3) >> 5;
     const int nrr = (n2r > 4 || n3r > 4) ? 2 : 1;
     const int tb = nrr == 2 ? 2 : 4;
@@ -862,6 +865,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
           if (w2 == 1 && w3 == 1) PCR_RAG(4, 1, 1, 1);
           else if (w2 == 2 && w3 == 1) PCR_RAG(4, 1, 2, 1);
           else if (w2 == 2 && w3 == 2) PCR_RAG(4, 1, 2, 2);
+          else if (w2 == 4 && w3 == 4) PCR_RAG(4, 1, 4, 4);
           else PCR_RAG(4, 1, 0, 0);
         }
 #undef PCR_RAG

@@ -182,11 +182,16 @@ class SaPlan:
         p.out = _p(out)
         p.feat_point_major, p.out_point_major = int(feat_pm), int(bool(out_point_major))
         ragged = cnt is not None and self.fast and self.mode == 1
-        if ragged:
+        if cnt is not None:
             assert cnt.is_contiguous() and cnt.dtype == torch.int32 and cnt.shape == (B, S)
+        if ragged:
+            # the persistent tile-list kernel (distinct rows only)
             n_ws = L.load().pcr_sa_tile_ws_ints(B, S, K, self.couts[1], self.couts[2])
-            tile_ws = torch.empty((max(n_ws, 1),), dtype=torch.int32, device=xyz.device)
-            p.cnt, p.tile_ws = _p(cnt), _p(tile_ws)
+            if n_ws > 0:
+                tile_ws = torch.empty((n_ws,), dtype=torch.int32, device=xyz.device)
+                p.tile_ws = _p(tile_ws)
+            if ragged:
+                p.cnt = _p(cnt)
         if self.fast:
             p.wa = _p(self.wa)
             for i in range(2):
