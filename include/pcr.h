@@ -162,6 +162,9 @@ typedef struct pcr_sa_params {
    * 4-byte pieces S floats apart).  Both are pure layout choices; values are identical. */
   int feat_point_major, out_point_major;
   float *out;
+  /* optional: (c1,3) dxyz weights of layer 1 (BatchNorm scale folded in, like wa) as a PACKED image
+   * (pcr_pack_weight_f32 of the (c1,3) matrix): lets the persistent kernel run layer 1 on the matrix core too */
+  const float *wa_packed;
 } pcr_sa_params;
 int pcr_sa_mlp_f32(const pcr_sa_params *p, pcr_stream_t stream);
 /* ints of pcr_sa_params.tile_ws for the duplicate-free evaluation (tile lists + per-tile row tables) */

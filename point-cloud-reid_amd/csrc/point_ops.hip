@@ -928,7 +928,7 @@ __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_reg_kernel(const floa
 }  // namespace
 
 // ------------------------------------------------------------------------------ C ABI ----
-PCR_EXPORT int pcr_abi_version(void) { return 2; }
+PCR_EXPORT int pcr_abi_version(void) { return 3; }
 
 PCR_EXPORT const char *pcr_status_string(int status) {
   switch (status) {

@@ -237,8 +237,12 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
           const float *w = a.wa + o * 3;
           const float *qr = sq + (rw / K) * c1 + o;
 #pragma unroll
-          for (int j = 0; j < 4; j++)
-            v[j] = fmaxf(w[3 * j] * dx + w[3 * j + 1] * dy + w[3 * j + 2] * dz + p4[u][j] + qr[j], 0.f);
+          for (int j = 0; j < 4; j++) {
+            // the order of the matrix-core form of this layer (sa_rag_kernel, W1): an fma chain over dx, dy, dz
+            // seeded with shift (+ Q), then the table piece -- both kernels give the same bits
+            const float t = fmaf(w[3 * j + 2], dz, fmaf(w[3 * j + 1], dy, fmaf(w[3 * j], dx, qr[j])));
+            v[j] = relu_bits(t + p4[u][j]);
+          }
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) buf[(o + j) * RP + rw] = v[j];
@@ -340,6 +344,7 @@ struct RagArgs {
   const int *idx, *cnt, *centre_idx;
   int *ws;
   const float *wa, *pq;
+  const float *wap;         // packed (c1, 3) image of wa (layer 1 on the matrix core), or null
   int pqw;
   int dbg;                  // PCR_SA_DBG ablation mask (diagnostics only; 0 in production)
   int out_pm;               // out is (B,S,c3)
@@ -502,9 +507,14 @@ __global__ __launch_bounds__(256) void sa_rag_rows_kernel(RagArgs a) {
 constexpr int kTraceWgs = 1024, kTraceTiles = 24, kTraceMarks = 8;
 __device__ unsigned long long g_rag_trace[kTraceWgs * (2 + kTraceTiles * kTraceMarks)];
 
-template <int TB, int NR, int W2, int W3, int NR2 = NR>
+// W1 != 0: layer 1 on the matrix core as well.  relu(Wa dxyz + P[i] + shift) is a one-k-block dense call on the
+// [dx;dy;dz;0..] rows of the tile (seeded with the shift) whose epilogue adds the table pieces, which each lane
+// gathers directly in the accumulator layout (token = lane, four runs of four couts): ~100 instructions per tile
+// instead of ~500 of VALU / LDS work.  (Host picks it when c1 has at most four cout blocks and, with a table, TB = 2.)
+template <int TB, int NR, int W2, int W3, int NR2 = NR, int W1 = 0>
 __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   constexpr int ROWS = 32 * TB, RP = ROWS + 1, MAXC = ROWS / 4, NG = ROWS / 4, CT = MAXC + 4;
+  constexpr bool kL1M = W1 != 0;
   const int C3P = ceil32(a.c3);           // gmax is [NG quads][C3P]
   constexpr int QS = kThreads / ROWS;     // channel quads advance by QS per item: a thread keeps ONE row
   constexpr int NI = 8;                   // 16-byte table pieces a thread holds in registers
@@ -533,13 +543,16 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   float *buf = smem;                                          // [rowsC][RP]
   int *coff2 = reinterpret_cast<int *>(buf + rowsC * RP);     // [2][CT] first row of each centre, double-buffered
   float *gmax = reinterpret_cast<float *>(coff2 + 2 * CT);    // [NG][ceil32(c3)], 16-byte aligned
-  float *s_wa = gmax + NG * C3P;                              // [c1][3] dxyz weights and [c1] shift of layer 1,
-  float *s_sh1 = s_wa + 3 * c1;                               //   staged once per (persistent) workgroup
-  float *s_sh2 = s_sh1 + c1;                                  // accumulator seeds of layers 2 / 3 (zero-padded)
+  float *s_wa = gmax + NG * C3P;                              // [c1][3] dxyz weights and [ceil32(c1)] shift of
+  float *s_sh1 = s_wa + 3 * c1;                               //   layer 1, staged once per (persistent) workgroup
+  float *s_sh2 = s_sh1 + ceil32(c1);                          // accumulator seeds of layers 2 / 3 (zero-padded)
   float *s_sh3 = s_sh2 + ceil32(c2);
+  float *sdx8 = s_sh3 + C3P;                                  // [8][RP] (kL1M): dx, dy, dz of the tile's rows, 5 zero rows
   const int tid = threadIdx.x;
   for (int e = tid; e < 3 * c1; e += kThreads) s_wa[e] = a.wa[e];
-  for (int e = tid; e < c1; e += kThreads) s_sh1[e] = a.sh1[e];
+  for (int e = tid; e < ceil32(c1); e += kThreads) s_sh1[e] = e < c1 ? a.sh1[e] : 0.f;
+  if constexpr (kL1M)
+    for (int e = tid; e < 8 * RP; e += kThreads) sdx8[e] = 0.f;
   for (int e = tid; e < ceil32(c2); e += kThreads) s_sh2[e] = a.sh2[e];
   for (int e = tid; e < C3P; e += kThreads) s_sh3[e] = a.sh3[e];
   // weight fragments of the NEXT dense call, requested as soon as the previous call's k-loop is over (explicit
@@ -569,21 +582,46 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
       if (tid < MAXC + 3) cv = ctab[(size_t)tile * CT + tid];   // offsets, then the `ends` mask and the quad count
     }
   };
+  const int lane = tid & 63, wv = tid >> 6;
   auto gather = [&](int tile) {   // table pieces of the row held in rv (tile's cloud from the flat list)
     if (tile < total) {
       const size_t bt = (size_t)flat[tile].x;
-      const float *prow = a.pq + (bt * a.N + (size_t)(__float_as_int(rv[0]) < 0 ? 0 : __float_as_int(rv[0]))) * a.pqw;
+      if constexpr (kL1M) {
+        // accumulator layout (TB = 2, one cout block per wave): tokens l31 and 32 + l31 (their row entries are
+        // this lane's and lane ^ 32's), couts 32 wave + 8 g + 4 h .. + 3
+        const int own = __float_as_int(rv[0]), other = __shfl_xor(own, 32, 64);
+        const int h = lane >> 5;
+        const int i0 = h ? other : own, i1 = h ? own : other;
+        const float *pr0 = a.pq + (bt * a.N + (size_t)(i0 < 0 ? 0 : i0)) * a.pqw + wv * 32 + 4 * h;
+        const float *pr1 = a.pq + (bt * a.N + (size_t)(i1 < 0 ? 0 : i1)) * a.pqw + wv * 32 + 4 * h;
 #pragma unroll
-      for (int u = 0; u < NI; u++) {
-        const int oq = q0 + u * QS;
-        p4[u] = *reinterpret_cast<const f32x4 *>(prow + 4 * (oq < nq ? oq : 0));
+        for (int g = 0; g < 4; g++) {
+          p4[g] = *reinterpret_cast<const f32x4 *>(pr0 + 8 * g);
+          p4[4 + g] = *reinterpret_cast<const f32x4 *>(pr1 + 8 * g);
+        }
+      } else {
+        const float *prow = a.pq + (bt * a.N + (size_t)(__float_as_int(rv[0]) < 0 ? 0 : __float_as_int(rv[0]))) * a.pqw;
+#pragma unroll
+        for (int u = 0; u < NI; u++) {
+          const int oq = q0 + u * QS;
+          p4[u] = *reinterpret_cast<const f32x4 *>(prow + 4 * (oq < nq ? oq : 0));
+        }
       }
     }
   };
+  auto stash_dxyz = [&]() {   // (kL1M) the row entry in rv -> B operand rows of layer 1
+    if (q0 == 0) {
+      sdx8[r] = rv[1];
+      sdx8[RP + r] = rv[2];
+      sdx8[2 * RP + r] = rv[3];
+    }
+  };
   int par = 0;
+  __syncthreads();            // (sdx8 zeroed)
   fetch_row(blockIdx.x);
   if (tid < MAXC + 3) coff2[tid] = cv;
-  if (pref) gather(blockIdx.x);
+  if constexpr (kL1M) stash_dxyz();
+  if (pref || (kL1M && a.pq)) gather(blockIdx.x);
   __syncthreads();
   for (int tile = blockIdx.x; tile < total; tile += gridDim.x, par ^= 1) {
   const int4 td = flat[tile];
@@ -591,6 +629,19 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   const int first = td.y, nc = td.z;
   const int *coff = coff2 + par * CT;
   PCR_MARK(0);
+  if constexpr (kL1M) {
+    const bool hasp = a.pq != nullptr;
+    tile_dense2<TB, 1, W1, true>(sdx8, 8, a.wap, ceil32(c1), false,
+                                 [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
+      float *dst = buf + (cb * 32 + 4 * h) * RP + tb * 32 + l31;
+#pragma unroll
+      for (int rr = 0; rr < 16; rr++) {
+        float v = acc[rr];
+        if (hasp) v += (tb == 0 ? p4[rr >> 2] : p4[4 + (rr >> 2)])[rr & 3];   // (TB = 2 whenever there is a table)
+        dst[((rr & 3) + 8 * (rr >> 2)) * RP] = relu_bits(v);
+      }
+    }, s_sh1);
+  } else
   if (!(a.dbg & 1)) {  // layer 1 (BatchNorm scale folded into wa / P, shift added here): row r, quads q0 + u QS
     const bool live = __float_as_int(rv[0]) >= 0;
     const float dx = rv[1], dy = rv[2], dz = rv[3];
@@ -612,8 +663,10 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
           f32x4 v = {0.f, 0.f, 0.f, 0.f};
           if (live) {
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-              v[j] = fmaxf(w[3 * j] * dx + w[3 * j + 1] * dy + w[3 * j + 2] * dz + (prow ? p4[u][j] : 0.f) + s_sh1[o + j], 0.f);
+            for (int j = 0; j < 4; j++) {
+              const float t = fmaf(w[3 * j + 2], dz, fmaf(w[3 * j + 1], dy, fmaf(w[3 * j], dx, s_sh1[o + j])));
+              v[j] = relu_bits(prow ? t + p4[u][j] : t);
+            }
           }
 #pragma unroll
           for (int j = 0; j < 4; j++) buf[(o + j) * RP + r] = v[j];
@@ -630,7 +683,7 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
                            [&](float v, int o, int t) { buf[o * RP + t] = relu_bits(v); }, s_sh2,
                            kRing && PCR_RING == 1 ? ring2 : nullptr, load_ring3);
   PCR_MARK(3);
-  if (pref) gather(tile + gridDim.x);   // next tile's table pieces: land during layer 3
+  if (pref || (kL1M && a.pq)) gather(tile + gridDim.x);   // next tile's table pieces: land during layer 3
   __syncthreads();
   PCR_MARK(4);
   if (!(a.dbg & 4))
@@ -655,6 +708,7 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   }, s_sh3, kRing ? ring3 : nullptr, load_ring2);
   PCR_MARK(5);
   if (tid < MAXC + 3) coff2[(par ^ 1) * CT + tid] = cv;   // next tile's offsets (this tile's are read below)
+  if constexpr (kL1M) stash_dxyz();                       // and its dxyz rows (layer 1 of this tile is long done)
   __syncthreads();
   PCR_MARK(6);
   if (!(a.dbg & 8)) {
@@ -802,6 +856,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
       r.maxT = (p.S + per_tile - 1) / per_tile;
       r.xyz = p.xyz; r.idx = p.idx; r.cnt = p.cnt; r.centre_idx = p.centre_idx; r.ws = p.tile_ws;
       r.wa = p.wa; r.pq = p.D ? p.pq_ws : nullptr; r.pqw = p.c1;
+      r.wap = p.wa_packed;
       r.wp2 = p.wps[0]; r.wp3 = p.wps[1]; r.sh1 = p.shift[0]; r.sh2 = p.shift_pad[0]; r.sh3 = p.shift_pad[1];
       static const int rdbg = getenv("PCR_SA_DBG") ? atoi(getenv("PCR_SA_DBG")) : 0;
       static const char *rtrace = getenv("PCR_SA_TRACE");
@@ -810,7 +865,8 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
       r.out_pm = p.out_point_major;
       const int rowsCr = p.c1 > ceil32(p.c2) ? p.c1 : ceil32(p.c2);
       const size_t lds = ((size_t)rowsCr * (ROWS + 1) + 2 * (ROWS / 4 + 4) +
-                          (size_t)ceil32(p.c3) * (ROWS / 4) + 4 * (size_t)p.c1 + ceil32(p.c2) + ceil32(p.c3)) *
+                          (size_t)ceil32(p.c3) * (ROWS / 4) + 3 * (size_t)p.c1 + ceil32(p.c1) + ceil32(p.c2) +
+                          ceil32(p.c3) + 8 * (ROWS + 1)) *
                          sizeof(float);
       if (lds <= 150 * 1024) {
         if (p.D && !p.pq_ready) {
@@ -855,14 +911,21 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
     if (rtrace) rag_dump_trace(rtrace, #TBv "," #NRv, (int)want);                                        \
   } while (0)
 #define PCR_COMMA_ONE , 1
+#define PCR_COMMA_ONE_ONE , 1, 1
+#define PCR_COMMA_ONE_TWO , 1, 2
+        const int n1r = ceil32(p.c1) >> 5;
+        const int w1 = n1r >= 3 ? 1 : (n1r == 2 ? 2 : 4);
+        const bool l1m = p.wa_packed && n1r <= 4;   // layer 1 on the matrix core
         if (tb == 2) {
           const bool narrow2 = n2r <= 4;   // layer 2 needs one cout-block round only
-          if (w2 == 1 && w3 == 1 && narrow2) PCR_RAG(2, 2, 1, 1, PCR_COMMA_ONE);
+          if (w2 == 1 && w3 == 1 && narrow2 && l1m && w1 == 1) PCR_RAG(2, 2, 1, 1, PCR_COMMA_ONE_ONE);
+          else if (w2 == 1 && w3 == 1 && narrow2) PCR_RAG(2, 2, 1, 1, PCR_COMMA_ONE);
           else if (w2 == 1 && w3 == 1) PCR_RAG(2, 2, 1, 1);
           else if (narrow2) PCR_RAG(2, 2, 0, 0, PCR_COMMA_ONE);
           else PCR_RAG(2, 2, 0, 0);
         } else {
           if (w2 == 1 && w3 == 1) PCR_RAG(4, 1, 1, 1);
+          else if (w2 == 2 && w3 == 1 && l1m && w1 == 2 && !p.D) PCR_RAG(4, 1, 2, 1, PCR_COMMA_ONE_TWO);
           else if (w2 == 2 && w3 == 1) PCR_RAG(4, 1, 2, 1);
           else if (w2 == 2 && w3 == 2) PCR_RAG(4, 1, 2, 2);
           else if (w2 == 4 && w3 == 4) PCR_RAG(4, 1, 4, 4);
@@ -870,6 +933,8 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
         }
 #undef PCR_RAG
 #undef PCR_COMMA_ONE
+#undef PCR_COMMA_ONE_ONE
+#undef PCR_COMMA_ONE_TWO
         if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
         return PCR_OK;
       }

@@ -49,7 +49,7 @@ class SaParams(ctypes.Structure):
                 ("cnt", c_int_p), ("tile_ws", c_int_p),
                 ("pq_ws", c_float_p), ("pq_ready", ctypes.c_int),
                 ("feat_point_major", ctypes.c_int), ("out_point_major", ctypes.c_int),
-                ("out", c_float_p)]
+                ("out", c_float_p), ("wa_packed", c_float_p)]
 
 
 class AttnParams(ctypes.Structure):
@@ -138,6 +138,7 @@ class SaPlan:
         self.D = D
         sc1 = self.scale[0].detach().double().cpu().unsqueeze(1)      # fast path wants scale[0] folded in
         self.wa = _dev32((w1[:, :3] * sc1).float(), device)
+        self.wa_packed = pack_weight((w1[:, :3] * sc1).float(), device)    # the same (c1,3) matrix as an MFMA operand
         self.wpq = None
         self.fast = fast
         # layers 2, 3 with the BatchNorm scale folded into the weights and the shift padded to 32
@@ -194,6 +195,7 @@ class SaPlan:
                 p.cnt = _p(cnt)
         if self.fast:
             p.wa = _p(self.wa)
+            p.wa_packed = _p(self.wa_packed)
             for i in range(2):
                 p.wps[i], p.shift_pad[i] = _p(self.wps[i]), _p(self.shift_pad[i])
             if D:
