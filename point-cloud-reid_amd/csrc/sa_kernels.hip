@@ -352,7 +352,7 @@ struct RagArgs {
   float *out;
 };
 
-__host__ __device__ inline size_t rag_desc_off(int B) { return (size_t)B + 1; }
+__host__ __device__ inline size_t rag_desc_off(int B) { return ((size_t)B + 2) & ~(size_t)1; }   // (8-byte aligned pairs)
 __host__ __device__ inline size_t rag_flat_off(int B, int maxT) {
   return (rag_desc_off(B) + (size_t)B * 2 * maxT + 3) & ~(size_t)3;
 }
@@ -403,8 +403,9 @@ __global__ __launch_bounds__(256) void sa_rag_plan_kernel(RagArgs a, int rows_pe
 
 __global__ __launch_bounds__(1024) void sa_rag_scan_kernel(int B, int maxT, int *ws) {
   __shared__ int part[1024];
+  __shared__ int wtot[16];
   __shared__ int carry;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int *desc = ws + rag_desc_off(B);
   int4 *flat = reinterpret_cast<int4 *>(ws + rag_flat_off(B, maxT));
   if (tid == 0) carry = 0;
@@ -412,17 +413,36 @@ __global__ __launch_bounds__(1024) void sa_rag_scan_kernel(int B, int maxT, int 
   for (int base = 0; base < B; base += 1024) {
     const int b = base + tid;
     const int v = b < B ? ws[b] : 0;
-    part[tid] = v;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-      const int t = tid >= off ? part[tid - off] : 0;
-      __syncthreads();
-      part[tid] += t;
-      __syncthreads();
+    int incl = v;                            // wave scans, then one scan over the 16 wave totals: two barriers
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
     }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+      int w = lane < 16 ? wtot[lane] : 0;
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) {
+        const int t = __shfl_up(w, off, 64);
+        if (lane >= off) w += t;
+      }
+      if (lane < 16) wtot[lane] = w;         // inclusive totals
+    }
+    __syncthreads();
+    part[tid] = incl + (wave ? wtot[wave - 1] : 0);
     const int excl = part[tid] - v + carry;
-    for (int j = 0; j < v; j++)
-      flat[excl + j] = make_int4(b, desc[(size_t)b * 2 * maxT + 2 * j], desc[(size_t)b * 2 * maxT + 2 * j + 1], 0);
+    // (batches of independent loads: a plain load / store loop is one memory round trip per descriptor)
+    const int2 *dsrc = reinterpret_cast<const int2 *>(desc + (size_t)(b < B ? b : 0) * 2 * maxT);
+    for (int j0 = 0; j0 < v; j0 += 8) {
+      int2 dd[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) dd[u] = dsrc[j0 + u < v ? j0 + u : 0];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (j0 + u < v) flat[excl + j0 + u] = make_int4(b, dd[u].x, dd[u].y, 0);
+    }
     __syncthreads();
     if (tid == 1023) carry += part[1023];
     __syncthreads();
