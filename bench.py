@@ -44,7 +44,7 @@ WORKLOADS = {
     "pt128": ("Point-Transformer ReIDNet (reid_nuscenes_pts/testing_pts_point-transformer_r_nus_det_500e.py), "
               "128-pt synthetic pairs, eval", "pt", 128, [128, 64, 32], 512),
     "ssg1024": ("PointNet++ SSG siamese (BASELINE config 2; SA(512,r.2,K32,[64,64,128]) -> SA(128,r.4,K64,[128,128,256]) "
-                "-> Conv1d 64; D-FPS + ball query), 1024-pt synthetic pairs, eval", "ssg", 1024, None, 512),
+                "-> Conv1d 64; D-FPS + ball query), 1024-pt synthetic pairs, eval", "ssg", 1024, None, 2048),
     "pointnet256": ("PointNet ReIDNet (configs_reid/_base_/reidentifiers/reid_pts_pointnet_point-cat.py), 256-pt "
                     "synthetic pairs, eval (BASELINE config 1 shape)", "pointnet", 256, None, 256),
     "pt4096": ("Point-Transformer ReIDNet, 4096-pt Waymo-shape synthetic pairs, eval", "pt", 4096,
