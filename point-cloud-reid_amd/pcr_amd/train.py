@@ -1,0 +1,156 @@
+"""mmcv-free training loop pieces for the ReID path (SURVEY.md 8e "Training", 8f row 2).
+
+What the reference gets from mmcv / mmdet and this module restates (formulas as documented by mmcv 1.x; the
+reference pins no version and has no tests at this boundary -- parity "unpinned", values fixed by this build's own
+fixtures in tests/test_train_loop.py):
+
+* optimizer  AdamW(lr, weight_decay) over every parameter (configs_reid/_base_/schedules/cyclic_*.py:7);
+* OptimizerHook: grad-norm clipping (max_norm 35 or 1), optional GradientCumulativeOptimizerHook (loss / k,
+  step every k iterations) (cyclic_*_accum*.py:9-11);
+* CyclicLrUpdaterHook / CyclicMomentumUpdaterHook, by iteration, cosine annealing, two phases per cycle:
+  [0, up) from 1 to target_ratio[0], [up, end) from target_ratio[0] to target_ratio[1]; the momentum hook drives
+  AdamW's beta1 (cyclic_*.py:10-21);
+* MMDistributedDataParallel(broadcast_buffers=False): one gradient exchange per step.  Here that is ONE flat
+  bucket holding every gradient that exists (the reference's 24 never-used FP-module tensors have none and are
+  left out), summed with a single all-reduce (RCCL over xGMI on the GPU box: 2.3 MB, direct rather than ring:
+  SURVEY.md 5.8) and divided by the world size; BatchNorm statistics stay per rank, and are broadcast from rank 0
+  before evaluation (shard.broadcast_buffers, eval_hook.py:102-108);
+* checkpoints in mmcv's layout: {'meta': {...,'epoch','iter'}, 'state_dict': ..., 'optimizer': ...}.
+
+The model's forward/backward is whatever `model.train_step(data, optimizer)` builds (ReIDNet: HIP neighbour search
+and grouping with their HIP backward, torch autograd for the dense math today -- pcr_amd/train_graph.py); nothing
+here touches kernels.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import shard
+
+
+def annealing_cos(start, end, factor):
+    """mmcv.runner.hooks.lr_updater.annealing_cos: start -> end as factor goes 0 -> 1"""
+    return end + 0.5 * (start - end) * (math.cos(math.pi * factor) + 1.0)
+
+
+def cyclic_value(base, it, max_iters, target_ratio=(10.0, 1e-4), cyclic_times=1, step_ratio_up=0.4):
+    """value at iteration `it` of mmcv's by-iteration cyclic policy (lr or momentum) around `base`"""
+    per_phase = max_iters // cyclic_times
+    up = int(step_ratio_up * per_phase)
+    phases = ((0, up, 1.0, target_ratio[0]), (up, per_phase, target_ratio[0], target_ratio[1]))
+    cur = it % per_phase
+    for start, end, r0, r1 in phases:
+        if start <= cur < end:
+            return annealing_cos(base * r0, base * r1, (cur - start) / float(end - start))
+    return base * target_ratio[1]
+
+
+class GradBucket:
+    """every existing gradient of `params` in one flat fp32 buffer: pack -> one all-reduce (sum) -> / world -> unpack"""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        self.live = None
+        self.flat = None
+
+    def _layout(self):
+        live = [p for p in self.params if p.grad is not None]
+        if self.live is None or len(live) != len(self.live) or any(a is not b for a, b in zip(live, self.live)):
+            self.live = live
+            n = sum(p.numel() for p in live)
+            dev = live[0].device if live else torch.device("cpu")
+            self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        return self.live
+
+    def nbytes(self):
+        return 0 if self.flat is None else self.flat.numel() * 4
+
+    def all_reduce_mean(self):
+        live = self._layout()
+        if not live or not shard.is_dist():
+            return
+        off = 0
+        for p in live:
+            n = p.numel()
+            self.flat[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self.flat.div_(dist.get_world_size())
+        off = 0
+        for p in live:
+            n = p.numel()
+            p.grad.copy_(self.flat[off:off + n].view_as(p.grad))
+            off += n
+
+
+class Trainer:
+    """AdamW + cyclic lr / beta1 + gradient clipping + accumulation + one-bucket data-parallel exchange"""
+
+    def __init__(self, model, max_iters, lr=3e-4, weight_decay=0.01, betas=(0.9, 0.999), grad_clip=35.0,
+                 cumulative_iters=1, lr_target_ratio=(10.0, 1e-4), momentum_target_ratio=(0.85 / 0.95, 1.0),
+                 cyclic_times=1, step_ratio_up=0.4):
+        self.model = model
+        self.max_iters = int(max_iters)
+        self.base_lr, self.base_beta1 = float(lr), float(betas[0])
+        self.grad_clip, self.cumulative_iters = grad_clip, int(cumulative_iters)
+        self.lr_ratio, self.mom_ratio = tuple(lr_target_ratio), tuple(momentum_target_ratio)
+        self.cyclic_times, self.step_ratio_up = cyclic_times, step_ratio_up
+        self.optimizer = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay, betas=betas)
+        self.bucket = GradBucket(list(model.parameters()))
+        self.iter = 0
+        self.epoch = 0
+
+    def current_lr(self):
+        return cyclic_value(self.base_lr, self.iter, self.max_iters, self.lr_ratio, self.cyclic_times, self.step_ratio_up)
+
+    def current_beta1(self):
+        return cyclic_value(self.base_beta1, self.iter, self.max_iters, self.mom_ratio, self.cyclic_times,
+                            self.step_ratio_up)
+
+    def _set_hyper(self):
+        lr, b1 = self.current_lr(), self.current_beta1()
+        for g in self.optimizer.param_groups:
+            g["lr"] = lr
+            g["betas"] = (b1, g["betas"][1])
+        return lr, b1
+
+    def step(self, data):
+        """one iteration: forward + backward of model.train_step(data, optimizer); every `cumulative_iters`
+        iterations exchange gradients, clip, and apply AdamW.  Returns the outputs dict (+ lr, grad_norm)."""
+        lr, b1 = self._set_hyper()
+        if self.iter % self.cumulative_iters == 0:
+            self.optimizer.zero_grad(set_to_none=True)
+        out = self.model.train_step(data, self.optimizer)
+        (out["loss"] / self.cumulative_iters).backward()
+        out["lr"], out["beta1"] = lr, b1
+        if (self.iter + 1) % self.cumulative_iters == 0:
+            self.bucket.all_reduce_mean()
+            if self.grad_clip is not None:
+                params = [p for p in self.model.parameters() if p.grad is not None]
+                out["grad_norm"] = float(torch.nn.utils.clip_grad_norm_(params, self.grad_clip, norm_type=2))
+            self.optimizer.step()
+        self.iter += 1
+        return out
+
+    # ---- checkpoints (mmcv layout) ----
+    def state(self):
+        return {"meta": {"epoch": self.epoch, "iter": self.iter, "pcr_amd": True},
+                "state_dict": {k: v.detach().cpu() for k, v in self.model.state_dict().items()},
+                "optimizer": self.optimizer.state_dict()}
+
+    def save(self, path):
+        if shard.env_world()[0] == 0:
+            torch.save(self.state(), path)
+        shard.barrier()
+
+    def load(self, path, strict=True, map_location="cpu"):
+        ckpt = torch.load(path, map_location=map_location, weights_only=False)
+        sd = ckpt.get("state_dict", ckpt)
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+        self.model.load_state_dict(sd, strict=strict)
+        if "optimizer" in ckpt:
+            self.optimizer.load_state_dict(ckpt["optimizer"])
+        meta = ckpt.get("meta", {})
+        self.epoch, self.iter = int(meta.get("epoch", 0)), int(meta.get("iter", 0))
+        return meta

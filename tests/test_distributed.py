@@ -53,7 +53,7 @@ WORKER = textwrap.dedent("""
     assert float(bn.running_mean[0]) == 1.0 and float(bn.running_var[0]) == 10.0
     dist.barrier()
     dist.destroy_process_group()
-    print("rank", rank, "ok")
+    sys.stdout.write("rank %%d ok\\n" %% rank); sys.stdout.flush()
 """)
 
 
