@@ -220,7 +220,24 @@ __global__ __launch_bounds__(NT) void fps_fast_kernel(const float *__restrict__ 
 // pcr_sqdist3, two points per instruction), the running maximum of the updated distances comes from a
 // v_max3 chain, and the reference's tie order (see fps_fast_kernel) is only evaluated among the points
 // that ATTAIN the wave maximum.  Coordinates must be finite (as everywhere in this file).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+// Two points side by side.  PCR_POINT_PACKED=1 maps the arithmetic onto v_pk_{add,mul}_f32; 0 keeps plain scalar
+// instructions (same IEEE operations either way; which is faster is a measurement)
+#ifndef PCR_POINT_PACKED
+#define PCR_POINT_PACKED 1
+#endif
+#if PCR_POINT_PACKED
+typedef f32x2v f32x2;
+#else
+struct f32x2 {
+  float a, b;
+  __device__ __forceinline__ float &operator[](int i) { return i ? b : a; }
+  __device__ __forceinline__ float operator[](int i) const { return i ? b : a; }
+};
+__device__ __forceinline__ f32x2 operator-(const f32x2 &x, const f32x2 &y) { return f32x2{x.a - y.a, x.b - y.b}; }
+__device__ __forceinline__ f32x2 operator+(const f32x2 &x, const f32x2 &y) { return f32x2{x.a + y.a, x.b + y.b}; }
+__device__ __forceinline__ f32x2 operator*(const f32x2 &x, const f32x2 &y) { return f32x2{x.a * y.a, x.b * y.b}; }
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t dpp_max_u32(uint32_t v) {

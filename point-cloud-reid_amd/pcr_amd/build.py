@@ -13,7 +13,7 @@ SO = os.path.join(LIBDIR, "libpcr_hip.so")
 # point_ops.hip must not contract a*b+c into fma (bit-exact index outputs); the MFMA model
 # kernels keep the default.
 FLAGS = {
-    "point_ops.hip": ["-ffp-contract=off"],
+    "point_ops.hip": ["-ffp-contract=off"] + os.environ.get("PCR_POINT_FLAGS", "").split(),
 }
 
 
