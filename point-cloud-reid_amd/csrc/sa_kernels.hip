@@ -128,8 +128,6 @@ struct Sa2Args {
   const float *pq;          // (B,N,pqw) point-major or null (no features)
   int pqw, qoff;            // row width; offset of Q inside a row, -1 = no Q term
   int dbg;                  // PCR_SA_DBG ablation mask (diagnostics only; 0 in production)
-  int skew_div;
-  int skew;                 // start-up stagger of the first generation of workgroups, in s_sleep(127) units
   const float *wp2, *wp3;
   const float *sh1, *sh2, *sh3;   // folded BatchNorm shifts (sh2/sh3 zero-padded to a multiple of 32)
   int out_pm;               // out is (B,S,c3)
@@ -169,17 +167,6 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
   const int rows = nc * K;
   const float *xyz = a.xyz + b * a.N * 3;
 
-  if (a.skew) {
-    // Identical workgroups started together run their phases in lockstep (all gathering, then all
-    // on the matrix core).  Delaying the co-resident workgroups of the FIRST generation by a
-    // fraction of a workgroup's lifetime de-phases every later generation too, because each CU slot
-    // runs its workgroups back to back.  Pure scheduling heuristic: results do not depend on it.
-    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
-    if (lin < 256u * 3u) {
-      const int n = (int)((lin / (unsigned)a.skew_div) % 3u) * a.skew;
-      for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(127);
-    }
-  }
   for (int r = tid; r < ROWS; r += kThreads) {
     int i = -1, ci = -1;
     float dx = 0.f, dy = 0.f, dz = 0.f;
@@ -1015,10 +1002,6 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   a.qoff = p.mode == 0 ? p.c1 : -1;
   static const int dbg = getenv("PCR_SA_DBG") ? atoi(getenv("PCR_SA_DBG")) : 0;
   a.dbg = dbg;
-  static const int skew = getenv("PCR_SA_SKEW") ? atoi(getenv("PCR_SA_SKEW")) : 0;
-  a.skew = skew;
-  static const int skew_div = getenv("PCR_SA_SKEW_DIV") ? atoi(getenv("PCR_SA_SKEW_DIV")) : 256;
-  a.skew_div = skew_div > 0 ? skew_div : 256;
   a.wp2 = p.wps[0]; a.wp3 = p.wps[1];
   a.sh1 = p.shift[0]; a.sh2 = p.shift_pad[0]; a.sh3 = p.shift_pad[1];
   a.out = p.out;
