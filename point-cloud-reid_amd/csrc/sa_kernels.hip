@@ -131,6 +131,8 @@ struct Sa2Args {
   const float *wp2, *wp3;
   const float *sh1, *sh2, *sh3;   // folded BatchNorm shifts (sh2/sh3 zero-padded to a multiple of 32)
   int out_pm;               // out is (B,S,c3)
+  const float *wap;         // packed (c1,3) image of wa, or null
+  int l1m;                  // layer 1 on the matrix core (wap given and c1 in layer 2's cout-block class)
   float *out;
 };
 
@@ -155,8 +157,8 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
   int rowsC = c1 > ceil32(c2) ? c1 : ceil32(c2);
   if (!MAXE && ceil32(c3) > rowsC) rowsC = ceil32(c3);
   float *buf = smem;                                        // [rowsC][RP]
-  float *sdx = buf + rowsC * RP;                            // [3][ROWS]
-  int *sidx = reinterpret_cast<int *>(sdx + 3 * ROWS);      // [ROWS] neighbour, [ROWS] centre point
+  float *sdx = buf + rowsC * RP;                            // [4][ROWS]: dx, dy, dz and a zero row (MFMA k = 3)
+  int *sidx = reinterpret_cast<int *>(sdx + 4 * ROWS);      // [ROWS] neighbour, [ROWS] centre point
   int *scen = sidx + ROWS;
   float *sq = reinterpret_cast<float *>(scen + ROWS);     // [CPW][c1] per-centre Q rows + shift
   float *gmax = sdx;   // [c3][2*TB] (MAXE only): reuses the staging arrays, all dead once layer 1 is built
@@ -183,6 +185,7 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
     sdx[r] = dx;
     sdx[ROWS + r] = dy;
     sdx[2 * ROWS + r] = dz;
+    sdx[3 * ROWS + r] = 0.f;
   }
   __syncthreads();
   if (!(a.dbg & 1)) {
@@ -197,6 +200,58 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
     sq[e] = a.sh1[o] + (has_q ? pq[(size_t)scen[c * K] * a.pqw + a.qoff + o] : 0.f);
   }
   __syncthreads();
+  if (a.l1m) {
+    // Layer 1 on the matrix core: relu(Wa dxyz + (shift + Q[c]) + P[i]) per 32 x 32 tile is two MFMAs (k = dx, dy |
+    // dz, 0) on accumulators SEEDED with the centre's shift + Q row, plus the table piece in the epilogue -- the fma
+    // order of the VALU form below, so the bits are the same.  A lane gathers its token's pieces in the accumulator
+    // layout (four runs of four couts), one tile ahead.  Tiles are dealt to the waves like layer 2's.
+    constexpr int WAYS = DenseShape<NR2, W2>::ways;
+    constexpr int TBW = (TB + WAYS - 1) / WAYS;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nCB = ceil32(c1) >> 5;
+    const int cb = WAYS == 1 ? wave : (WAYS == 2 ? (wave & 1) : 0);
+    const int tb0 = WAYS == 1 ? 0 : (WAYS == 2 ? (wave >> 1) : wave);
+    if (cb < nCB) {
+      const f32x4 av = reinterpret_cast<const f32x4 *>(a.wap)[(size_t)cb * 64 + l31 * 2 + h];   // k = h, 2+h, (4+h, 6+h)
+      f32x4 pc[4], pn[4];
+      auto gather = [&](f32x4 (&p)[4], int tb) {
+        const int i = sidx[tb * 32 + l31];
+        const float *pr = pq + (size_t)(i < 0 ? 0 : i) * a.pqw + cb * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; g++) p[g] = *reinterpret_cast<const f32x4 *>(pr + 8 * g);
+      };
+      if (pq && tb0 < TB) gather(pc, tb0);
+#pragma unroll
+      for (int j = 0; j < TBW; j++) {
+        const int tb = tb0 + j * WAYS;
+        if (tb < TB) {
+          const int t = tb * 32 + l31;
+          if (pq && tb + WAYS < TB) gather(pn, tb + WAYS);
+          int c = t / K;
+          c = c < nc ? c : nc - 1;
+          const float *sr = sq + c * c1 + cb * 32 + 4 * h;
+          f32x16 acc;
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            const f32x4 s4 = *reinterpret_cast<const f32x4 *>(sr + 8 * g);
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc[4 * g + q] = s4[q];
+          }
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], sdx[h * ROWS + t], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], sdx[(2 + h) * ROWS + t], acc, 0, 0, 0);
+          float *dst = buf + (cb * 32 + 4 * h) * RP + t;
+#pragma unroll
+          for (int rr = 0; rr < 16; rr++) {
+            const float v = pq ? acc[rr] + pc[rr >> 2][rr & 3] : acc[rr];
+            dst[((rr & 3) + 8 * (rr >> 2)) * RP] = relu_bits(v);
+          }
+#pragma unroll
+          for (int g = 0; g < 4; g++) pc[g] = pn[g];
+        }
+      }
+    }
+  } else {
   const int total = ROWS * (c1 >> 2);
   constexpr int dR = kThreads % ROWS, dO = kThreads / ROWS;
   int r = tid % ROWS, oq = tid / ROWS;
@@ -235,6 +290,7 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
         for (int j = 0; j < 4; j++) buf[(o + j) * RP + rw] = v[j];
       }
     }
+  }
   }
   }
   __syncthreads();
@@ -951,7 +1007,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   int rowsC = p.c1 > ceil32(p.c2) ? p.c1 : ceil32(p.c2);
   if (!maxe && ceil32(p.c3) > rowsC) rowsC = ceil32(p.c3);
   auto lds_bytes = [&](int tb, int cpw) {
-    size_t stage = (size_t)5 * 32 * tb + (size_t)cpw * p.c1;
+    size_t stage = (size_t)6 * 32 * tb + (size_t)cpw * p.c1 + 32;   // (sq read in 16-byte pieces up to ceil32(c1))
     const size_t gm = maxe ? (size_t)ceil32(p.c3) * 2 * tb : 0;
     if (gm > stage) stage = gm;
     return ((size_t)rowsC * (32 * tb + 1) + stage) * sizeof(float);
@@ -1006,6 +1062,15 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   a.sh1 = p.shift[0]; a.sh2 = p.shift_pad[0]; a.sh3 = p.shift_pad[1];
   a.out = p.out;
   a.out_pm = p.out_point_major;
+  a.wap = p.wa_packed;
+  {
+    static const int no_l1m = getenv("PCR_SA_NO_L1M") ? atoi(getenv("PCR_SA_NO_L1M")) : 0;   // diagnostics
+    const int n1 = ceil32(p.c1) >> 5;
+    const int w1 = n1 >= 3 ? 1 : (n1 == 2 ? 2 : 4);
+    const int w2c = n2 >= 3 ? 1 : (n2 == 2 ? 2 : 4), w3c = n3 >= 3 ? 1 : (n3 == 2 ? 2 : 4);
+    // (the kernel deals layer 1's tiles with layer 2's compile-time shape: explicit shapes only, same class)
+    a.l1m = (!no_l1m && p.wa_packed && n1 <= 4 && n2 <= 4 && w1 == w2c && w2c == w3c && (p.c1 & 3) == 0) ? 1 : 0;
+  }
   const size_t lds = lds_bytes(best_tb, best_cpw);
   dim3 grid((p.S + best_cpw - 1) / best_cpw, p.B);
   const int w2 = n2 >= 3 ? 1 : (n2 == 2 ? 2 : 4), w3 = n3 >= 3 ? 1 : (n3 == 2 ? 2 : 4);
