@@ -214,6 +214,12 @@ def main():
                     share_of_step=ms / step_ms_kern,
                     per_kernel_ms={k: round(v, 4) for k, v in sorted(groups.items(), key=lambda kv: -kv[1])})
         roof["frac"] = roof["achieved"] / roof["peak"]
+        if dom.split("[")[0] in ("knn_prefix", "fps", "ball_query", "pool_head", "gather"):
+            # neighbour search / sampling / pooling launches move bytes, they do not multiply: price them against
+            # HBM with their ALGORITHMIC bytes (read xyz, write indices) -- their real limiter today is
+            # instruction issue, which this fraction makes plain
+            roof.update(bound="hbm", achieved=(nbytes / cnt) / (ms / cnt * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+            roof["frac"] = roof["achieved"] / roof["peak"]
         # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (profiles/*_pmc.json:
         # FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 correction 2*FETCH_SIZE + WRITE_SIZE), scaled to
         # this batch size; null when no profile of this workload is committed
