@@ -693,115 +693,13 @@ __global__ void three_interp_bwd_kernel(const float *__restrict__ grad_out,
 constexpr int kKnnPThreads = 256;
 constexpr int kKnnCap = 256;  // candidates per query the fast path can rank (4 per lane)
 // -------------------------------------------------------------- PT neighbour search ----
-// One wave per query; lane l holds the distances to points l, l+64, ... in registers.  The cloud
-// is staged once per workgroup as SoA in LDS (broadcast reads of the query, stride-1 reads of the
-// candidates).  Selection without sorting N values:
-//   1. tau = K-th smallest of the 64 per-lane minima: an upper bound of the K-th smallest distance
-//      (those minima are 64 distinct points), found by rank counting with v_readlane broadcasts;
-//   2. every point with d <= tau (typically 1-3 K of them) is compacted into LDS as a packed
-//      (distance, index) key;
-//   3. each candidate's rank among the candidates is counted with broadcast LDS reads; ranks < K
-//      are the answer, already in (distance, index) order.
-// If more than kKnnCap points pass (heavily duplicated clouds) the wave falls back to K rounds of
-// (local argmin, wave argmin, knock-out) over all points.  Both paths give the same output.
-template <int T>
-__global__ __launch_bounds__(kKnnPThreads) void knn_prefix_kernel(const float *__restrict__ xyz,
-                                                              int *__restrict__ idx, int n, int S,
-                                                              int K, int qpw) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *sx = smem, *sy = smem + n, *sz = smem + 2 * n;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  unsigned long long *cand =
-      reinterpret_cast<unsigned long long *>(smem + 3 * n + (n & 1)) + wave * kKnnCap;
-  const size_t b = blockIdx.y;
-  const float *cloud = xyz + b * n * 3;
-  for (int i = tid; i < n; i += kKnnPThreads) {
-    sx[i] = cloud[3 * i];
-    sy[i] = cloud[3 * i + 1];
-    sz[i] = cloud[3 * i + 2];
-  }
-  __syncthreads();
-  const int q0 = blockIdx.x * qpw;
-  const int q1 = (q0 + qpw < S) ? q0 + qpw : S;
-  for (int q = q0 + wave; q < q1; q += kKnnPThreads / 64) {
-    const float qx = sx[q], qy = sy[q], qz = sz[q];
-    float d[T];
-    float m = INFINITY;
-#pragma unroll
-    for (int t = 0; t < T; t++) {
-      int i = lane + 64 * t;
-      d[t] = i < n ? pcr_sqdist3(qx, qy, qz, sx[i], sy[i], sz[i]) : INFINITY;
-      m = fminf(m, d[t]);
-    }
-    // 1. K-th smallest lane minimum (ties ordered by lane)
-    int rank = 0;
-    for (int j = 0; j < 64; j++) {
-      const float vj = __shfl(m, j, 64);
-      rank += (vj < m || (vj == m && j < lane)) ? 1 : 0;
-    }
-    const unsigned long long hit = __ballot(rank == K - 1);
-    const float tau = __shfl(m, hit ? __ffsll((long long)hit) - 1 : 0, 64);
-    // 2. candidates d <= tau
-    int cnt = 0;
-#pragma unroll
-    for (int t = 0; t < T; t++) cnt += d[t] <= tau ? 1 : 0;
-    int incl = cnt;
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-      const int o = __shfl_up(incl, s, 64);
-      if (lane >= s) incl += o;
-    }
-    const int total = __shfl(incl, 63, 64);
-    int *out = idx + (b * S + q) * K;
-    if (hit != 0ull && total <= kKnnCap) {
-      int off = incl - cnt;
-#pragma unroll
-      for (int t = 0; t < T; t++)
-        if (d[t] <= tau)
-          cand[off++] = ((unsigned long long)pcr_orderable(d[t]) << 32) | (unsigned)(lane + 64 * t);
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      // 3. rank among candidates (each lane owns candidates lane, lane+64, ...)
-      unsigned long long own[kKnnCap / 64];
-      int rk[kKnnCap / 64];
-#pragma unroll
-      for (int u = 0; u < kKnnCap / 64; u++) {
-        own[u] = lane + 64 * u < total ? cand[lane + 64 * u] : ~0ull;
-        rk[u] = 0;
-      }
-      for (int j = 0; j < total; j++) {
-        const unsigned long long cj = cand[j];
-#pragma unroll
-        for (int u = 0; u < kKnnCap / 64; u++) rk[u] += cj < own[u] ? 1 : 0;
-      }
-#pragma unroll
-      for (int u = 0; u < kKnnCap / 64; u++)
-        if (lane + 64 * u < total && rk[u] < K) out[rk[u]] = (int)(own[u] & 0xFFFFFFFFull);
-      __builtin_amdgcn_wave_barrier();
-    } else {
-      int mine = 0;
-      for (int k = 0; k < K; k++) {
-        float bd = d[0];
-        int bt = 0;
-#pragma unroll
-        for (int t = 1; t < T; t++)
-          if (d[t] < bd) { bd = d[t]; bt = t; }
-        unsigned long long key = ((unsigned long long)pcr_orderable(bd) << 32) | (unsigned)(lane + 64 * bt);
-        key = pcr_wave_min_u64(key);
-        const int win = (int)(key & 0xFFFFFFFFull);
-        if (lane == k) mine = win;
-        if (lane == (win & 63)) {
-          const int wt = win >> 6;
-#pragma unroll
-          for (int t = 0; t < T; t++) d[t] = (t == wt) ? INFINITY : d[t];
-        }
-      }
-      if (lane < K) out[lane] = mine;
-    }
-  }
-}
-
-// Second generation (clouds of up to 2048 points): the wave keeps the whole cloud in REGISTERS as packed
+// knn_point(K, xyz, xyz[:, :S]) of the Point-Transformer (pointnet2_utils.py:205-216): for each of the first S
+// points its K nearest points in (distance, index) order, distance = pcr_sqdist3.  One wave per query; selection
+// without sorting N values:
+//   1. tau = an upper bound of the K-th smallest distance from the 64 per-lane minima (64 distinct points);
+//   2. every point with d <= tau (typically 1.3-1.5 K of them) becomes a packed (distance, index) key;
+//   3. each candidate's rank among the candidates is counted; ranks < K are the answer, already ordered.
+// Clouds of up to 1024 points: the wave keeps the whole cloud in REGISTERS as packed
 // pairs (no LDS reads per query; packed f32 subtract / multiply / add = pcr_sqdist3's operations, two points per
 // instruction), and every ranking step is a count over v_readlane broadcasts -- three instructions per
 // comparand -- on keys whose order is the required one:
@@ -810,8 +708,8 @@ __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_kernel(const float *_
 //         upper bound of the K-th smallest distance (K lanes have a minimum <= tau);
 //   rank: the candidates d <= tau (a few more than K) are compacted one per lane and ranked by their exact
 //         64-bit (distance, index) keys; ranks < K are the answer in (distance, index) order.
-// More than 64 candidates (duplicate-heavy clouds) go through the LDS path of the first generation, more than
-// kKnnCap through the K-round fallback; all paths produce the same output.
+// More than 64 candidates (duplicate-heavy clouds) are ranked four per lane over broadcast LDS reads, more than
+// kKnnCap go through a K-round argmin fallback; all paths produce the same output.
 template <int TP>   // point PAIRS per lane: n <= 128 * TP
 __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_reg_kernel(const float *__restrict__ xyz,
                                                                   int *__restrict__ idx, int n, int S,
@@ -939,6 +837,111 @@ __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_reg_kernel(const floa
       }
       if (lane < K) out[lane] = mine;
     }
+  }
+}
+
+// Larger clouds (1024 < n <= 4096): 32-64 points per lane do not fit in registers next to their distances, so the
+// cloud sits in LDS as {x,y,z,-} (one 16-byte read per point) and the distances are computed TWICE instead of
+// stored: pass 1 keeps only the lane minimum (-> tau as above), pass 2 recomputes them and compacts the candidates
+// d <= tau chunk by chunk (ballot + prefix popcount, in index order).  Ranking as in the register kernel; if more
+// than kKnnCap points pass (heavily duplicated clouds) the K nearest are emitted one per round as "the smallest
+// (distance, index) key above the previous one", which needs no per-point state either.
+template <int T, int NT>   // points per lane: n <= 64 * T; NT threads (NT / 64 waves share the cloud in LDS)
+__global__ __launch_bounds__(NT) void knn_prefix_lds_kernel(const float *__restrict__ xyz,
+                                                                  int *__restrict__ idx, int n, int S,
+                                                                  int K, int qpw) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  f32x4 *pts = reinterpret_cast<f32x4 *>(smem);   // [64 * T], padded with points at infinity
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long *cand = reinterpret_cast<unsigned long long *>(pts + 64 * T) + wave * kKnnCap;
+  const size_t b = blockIdx.y;
+  const float *cloud = xyz + b * n * 3;
+  for (int i = tid; i < 64 * T; i += NT) {
+    const bool ok = i < n;
+    const float *q = cloud + (size_t)(ok ? i : 0) * 3;
+    const float x = q[0], y = q[1], z = q[2];
+    pts[i] = ok ? f32x4{x, y, z, 0.f} : f32x4{INFINITY, INFINITY, INFINITY, 0.f};
+  }
+  __syncthreads();
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int q0 = blockIdx.x * qpw;
+  const int q1 = (q0 + qpw < S) ? q0 + qpw : S;
+  for (int q = q0 + wave; q < q1; q += NT / 64) {
+    const f32x4 qp = pts[q];
+    auto dist_bits = [&](int t) {   // pcr_sqdist3(query, point) as bits (>= +0; +inf sorts last)
+      const f32x4 pp = pts[lane + 64 * t];
+      return __float_as_uint(pcr_sqdist3(qp[0], qp[1], qp[2], pp[0], pp[1], pp[2]));
+    };
+    uint32_t m = 0xFFFFFFFFu;
+#pragma unroll 8
+    for (int t = 0; t < T; t++) {
+      const uint32_t d = dist_bits(t);
+      m = d < m ? d : m;
+    }
+    const uint32_t mkey = (m & ~63u) | (uint32_t)lane;
+    int rank = 0;
+#pragma unroll 8
+    for (int j = 0; j < 64; j++) {
+      const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)mkey, j);
+      rank += kj < mkey ? 1 : 0;
+    }
+    const unsigned long long hit = __ballot(rank == K - 1);
+    const uint32_t tau = (uint32_t)__builtin_amdgcn_readlane((int)mkey, (int)__builtin_ctzll(hit)) | 63u;
+    int total = 0;
+#pragma unroll 4
+    for (int t = 0; t < T; t++) {
+      const uint32_t d = dist_bits(t);
+      const bool in = d <= tau;
+      const unsigned long long mask = __ballot(in);
+      if (mask) {
+        const int pos = total + __popcll(mask & lt);
+        if (in && pos < kKnnCap) cand[pos] = ((unsigned long long)(d | 0x80000000u) << 32) | (unsigned)(lane + 64 * t);
+        total += __popcll(mask);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    int *out = idx + (b * S + q) * K;
+    if (total <= 64) {
+      const unsigned long long own = lane < total ? cand[lane] : ~0ull;
+      const uint32_t ohi = (uint32_t)(own >> 32), olo = (uint32_t)own;
+      int rk = 0;
+      for (int j = 0; j < total; j++) {
+        const uint32_t jhi = (uint32_t)__builtin_amdgcn_readlane((int)ohi, j);
+        const uint32_t jlo = (uint32_t)__builtin_amdgcn_readlane((int)olo, j);
+        rk += (((unsigned long long)jhi << 32) | jlo) < own ? 1 : 0;
+      }
+      if (lane < total && rk < K) out[rk] = (int)olo;
+    } else if (total <= kKnnCap) {
+      unsigned long long own[kKnnCap / 64];
+      int rk[kKnnCap / 64];
+#pragma unroll
+      for (int u = 0; u < kKnnCap / 64; u++) {
+        own[u] = lane + 64 * u < total ? cand[lane + 64 * u] : ~0ull;
+        rk[u] = 0;
+      }
+      for (int j = 0; j < total; j++) {
+        const unsigned long long cj = cand[j];
+#pragma unroll
+        for (int u = 0; u < kKnnCap / 64; u++) rk[u] += cj < own[u] ? 1 : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < kKnnCap / 64; u++)
+        if (lane + 64 * u < total && rk[u] < K) out[rk[u]] = (int)(own[u] & 0xFFFFFFFFull);
+    } else {
+      unsigned long long last = 0ull;   // every real key has bit 63 set
+      for (int k = 0; k < K; k++) {
+        unsigned long long best = ~0ull;
+        for (int t = 0; t < T; t++) {
+          const unsigned long long key = ((unsigned long long)(dist_bits(t) | 0x80000000u) << 32) | (unsigned)(lane + 64 * t);
+          best = (key > last && key < best) ? key : best;
+        }
+        best = pcr_wave_min_u64(best);
+        if (lane == 0) out[k] = (int)(best & 0xFFFFFFFFull);
+        last = best;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -1073,16 +1076,32 @@ PCR_EXPORT int pcr_knn_prefix_f32(const float *xyz, int *idx, int B, int N, int 
   dim3 g((S + qpw - 1) / qpw, B), blk(kKnnPThreads);
   size_t lds = (size_t)(3 * N + (N & 1)) * sizeof(float) + (size_t)4 * kKnnCap * 8;
   hipStream_t st = pcr_s(stream);
-#define PCR_KNN_CASE(T) hipLaunchKernelGGL((knn_prefix_kernel<T>), g, blk, lds, st, xyz, idx, N, S, K, qpw)
 #define PCR_KNN_REG(TP) hipLaunchKernelGGL((knn_prefix_reg_kernel<TP>), g, blk, lds, st, xyz, idx, N, S, K, qpw)
   if (N <= 128) PCR_KNN_REG(1);
   else if (N <= 256) PCR_KNN_REG(2);
   else if (N <= 512) PCR_KNN_REG(4);
-  else if (N <= 1024) PCR_KNN_REG(8);
-  else if (N <= 2048) PCR_KNN_REG(16);
-  else PCR_KNN_CASE(64);
+  else {
+    // sixteen waves share one copy of the cloud in LDS (4 waves per SIMD already at one workgroup per CU)
+    constexpr int NT = 1024;
+    const int qpw_l = 128;
+    const dim3 gl((S + qpw_l - 1) / qpw_l, B);
+    if (N <= 1024) {
+      PCR_KNN_REG(8);   // (the two-pass LDS form measures 1.79 ms against 1.60 here: registers win while they fit)
+    } else if (N <= 2048) {
+      lds = (size_t)64 * 32 * 16 + (size_t)(NT / 64) * kKnnCap * 8;
+      static bool big = hipFuncSetAttribute(reinterpret_cast<const void *>(knn_prefix_lds_kernel<32, NT>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+      (void)big;
+      hipLaunchKernelGGL((knn_prefix_lds_kernel<32, NT>), gl, dim3(NT), lds, st, xyz, idx, N, S, K, qpw_l);
+    } else {
+      lds = (size_t)64 * 64 * 16 + (size_t)(NT / 64) * kKnnCap * 8;
+      static bool big = hipFuncSetAttribute(reinterpret_cast<const void *>(knn_prefix_lds_kernel<64, NT>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+      (void)big;
+      hipLaunchKernelGGL((knn_prefix_lds_kernel<64, NT>), gl, dim3(NT), lds, st, xyz, idx, N, S, K, qpw_l);
+    }
+  }
 #undef PCR_KNN_REG
-#undef PCR_KNN_CASE
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }

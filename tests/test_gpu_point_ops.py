@@ -86,7 +86,8 @@ def test_knn_heap_bit_exact(ops, n, m, k, kind):
 
 @pytest.mark.parametrize("n,s,k,kind", [(128, 128, 32, "randn"), (128, 64, 48, "dup"), (512, 256, 48, "box"),
                                         (1024, 1024, 32, "dup"), (4096, 100, 48, "randn"), (70, 70, 64, "dup"),
-                                        (2048, 33, 5, "box")])
+                                        (2048, 33, 5, "box"), (4096, 64, 32, "dup"), (3000, 50, 16, "box"),
+                                        (2500, 40, 64, "dup")])
 def test_knn_prefix_bit_exact(n, s, k, kind):
     from pcr_amd import engine
     xyz = T.synthetic_clouds(3, n, seed=21, kind=kind).numpy()
