@@ -1,0 +1,51 @@
+"""BASELINE sizes on the GPU, through properties that do not need the (slow) CPU oracle at that size:
+  * a pair's logit does not depend on what else is in the batch (every pair is an independent unit: SURVEY 8e) --
+    the bench batch against the same pairs run in small groups, bit for bit;
+  * the duplicate-free (ragged) SA evaluation equals the K-row evaluation bit for bit at full size;
+  * the matching head is symmetric in the two clouds of a pair (point-concatenation + pooling), so swapping them
+    changes the logit only by summation order;
+  * the small-group logits themselves are pinned to the oracle by the other test files."""
+import numpy as np
+import pytest
+import torch
+
+import bench
+from pcr_amd import testing as T
+
+pytestmark = pytest.mark.gpu
+
+
+def _logits(model, s1, s2):
+    with torch.no_grad():
+        return bench.hot_path(model, s1, s2)
+
+
+@pytest.mark.parametrize("workload,pairs,group", [("ssg1024", 2048, 64), ("pt1024", 512, 32), ("pointnet256", 256, 16)])
+def test_bench_batch_equals_small_groups(workload, pairs, group):
+    desc, kind, n, bl, _ = bench.WORKLOADS[workload]
+    model, _ = bench.build_model(kind, bl)
+    data_kind = "box" if kind == "ssg" else "randn"
+    s1, s2 = T.synthetic_pairs(pairs, n, seed=21, kind=data_kind)
+    s1, s2 = s1.cuda(), s2.cuda()
+    full = _logits(model, s1, s2)
+    assert full.shape == (pairs,) and bool(torch.isfinite(full).all())
+    for lo in (0, pairs // 2 - group // 2, pairs - group):            # first, middle and last group
+        part = _logits(model, s1[lo:lo + group].contiguous(), s2[lo:lo + group].contiguous())
+        assert torch.equal(part, full[lo:lo + group]), (workload, lo, float((part - full[lo:lo + group]).abs().max()))
+    swapped = _logits(model, s2, s1)
+    assert float((swapped - full).abs().max()) < 1e-4
+
+
+def test_ragged_equals_k_row_at_bench_size():
+    from mmdet3d.ops.pointnet_modules import PointSAModule
+    desc, kind, n, bl, _ = bench.WORKLOADS["ssg1024"]
+    model, _ = bench.build_model(kind, bl)
+    s1, s2 = T.synthetic_pairs(256, n, seed=22, kind="box")
+    s1, s2 = s1.cuda(), s2.cuda()
+    a = _logits(model, s1, s2)
+    sas = [m for m in model.modules() if isinstance(m, PointSAModule)]
+    assert len(sas) == 2
+    for m in sas:
+        m.skip_repeats = False
+    b = _logits(model, s1, s2)
+    assert torch.equal(a, b)
