@@ -5,6 +5,8 @@
 // reads, one barrier per FPS step, register-resident running distances.
 //
 // Build with -ffp-contract=off (distance expressions must not be fused; see pcr_common.h).
+#include <type_traits>
+
 #include "pcr_common.h"
 
 namespace {
@@ -444,6 +446,7 @@ __global__ __launch_bounds__(256) void ball_query_reg_kernel(const float *__rest
     pz[j] = ok ? z : INFINITY;
   }
   const unsigned long long lt = (1ull << lane) - 1ull;
+  const bool simple = min_r2 == 0.f && max_r2 > 0.f;
   const int c0 = (blockIdx.x * 4 + wave) * cpw;
   const int c1 = c0 + cpw < m ? c0 + cpw : m;
   for (int c = c0; c < c1; c++) {
@@ -451,20 +454,27 @@ __global__ __launch_bounds__(256) void ball_query_reg_kernel(const float *__rest
     const float cx = cc[0], cy = cc[1], cz = cc[2];
     int *out = idx + (b * m + c) * (size_t)K;
     int cnt = 0, first = 0;
+    auto scan = [&](auto simple_tag) {
+      constexpr bool kSimple = decltype(simple_tag)::value;
 #pragma unroll
-    for (int j = 0; j < PPL; j++) {
-      if (cnt < K) {   // wave-uniform
-        const float d2 = pcr_sqdist3(px[j], py[j], pz[j], cx, cy, cz);
-        const bool hit = d2 == 0.f || (d2 >= min_r2 && d2 < max_r2);
-        const unsigned long long mask = __ballot(hit);
-        if (mask) {
-          const int pos = cnt + __popcll(mask & lt);
-          if (hit && pos < K) out[pos] = j * 64 + lane;
-          if (cnt == 0) first = j * 64 + (int)__builtin_ctzll(mask);
-          cnt += __popcll(mask);
+      for (int j = 0; j < PPL; j++) {
+        if (cnt < K) {   // wave-uniform
+          const float d2 = pcr_sqdist3(px[j], py[j], pz[j], cx, cy, cz);
+          // min_radius = 0 (every configuration in the reference): d2 >= 0 always holds and d2 == 0 implies
+          // d2 < max_r2, so the predicate is a single compare
+          const bool hit = kSimple ? d2 < max_r2 : (d2 == 0.f || (d2 >= min_r2 && d2 < max_r2));
+          const unsigned long long mask = __ballot(hit);
+          if (mask) {
+            const int pos = cnt + __popcll(mask & lt);
+            if (hit && pos < K) out[pos] = j * 64 + lane;
+            if (cnt == 0) first = j * 64 + (int)__builtin_ctzll(mask);
+            cnt += __popcll(mask);
+          }
         }
       }
-    }
+    };
+    if (simple) scan(std::true_type{});
+    else scan(std::false_type{});
     if (cnt > K) cnt = K;
     for (int l = cnt + lane; l < K; l += 64) out[l] = first;   // first == 0 when nothing was hit
     if (cnt_out && lane == 0) cnt_out[b * m + c] = cnt;
