@@ -152,7 +152,7 @@ typedef struct pcr_sa_params {
   /* Optional duplicate-free evaluation for ball-query groups (mode 1): cnt (B,S) = number of genuine hits
    * of each row of idx as returned by pcr_ball_query_cnt_f32 (entries [cnt,K) of a row repeat entry 0, and
    * a max over K ignores repeats), tile_ws = caller workspace of pcr_sa_tile_ws_ints(B,S,K,c2,c3) ints.  The kernel then runs the
-   * MLP on ceil4(max(cnt,1)) rows per centre; the result is bit-identical to the K-row evaluation. */
+   * MLP on ceil2(max(cnt,1)) rows per centre; the result is bit-identical to the K-row evaluation. */
   const int *cnt;
   int *tile_ws;
   float *pq_ws;

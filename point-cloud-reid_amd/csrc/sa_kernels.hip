@@ -395,6 +395,13 @@ struct RagArgs {
   float *out;
 };
 
+// rows of a centre are padded to a multiple of kRagG (the max over a centre's rows starts with a DPP max inside
+// groups of kRagG lanes): 2 instead of 4 costs twice the LDS for the group maxima and saves a quarter of the rows
+// of sparsely populated balls (mean 2.9 hits: 4.5 -> 3.4 rows per centre)
+constexpr int kRagG = 2;
+__host__ __device__ inline int rag_ceil(int x) { return (x + kRagG - 1) & ~(kRagG - 1); }
+constexpr int kRagCT = 4;   // ints per tile in ctab: ends mask (2 x 32 bits), group count, pad
+
 __host__ __device__ inline size_t rag_desc_off(int B) { return ((size_t)B + 2) & ~(size_t)1; }   // (8-byte aligned pairs)
 __host__ __device__ inline size_t rag_flat_off(int B, int maxT) {
   return (rag_desc_off(B) + (size_t)B * 2 * maxT + 3) & ~(size_t)3;
@@ -403,7 +410,8 @@ __host__ __device__ inline size_t rag_ctab_off(int B, int maxT) {
   return rag_flat_off(B, maxT) + (size_t)B * maxT * 4;
 }
 __host__ __device__ inline size_t rag_rowtab_off(int B, int maxT, int rows) {
-  return rag_ctab_off(B, maxT) + (size_t)B * maxT * (rows / 4 + 4);
+  (void)rows;
+  return rag_ctab_off(B, maxT) + (size_t)B * maxT * kRagCT;
 }
 __host__ __device__ inline size_t rag_ws_ints(int B, int maxT, int rows) {
   return rag_rowtab_off(B, maxT, rows) + (size_t)B * maxT * rows * 4;
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(256) void sa_rag_plan_kernel(RagArgs a, int rows_pe
   for (int base = 0; base < a.S; base += 64) {
     int c = (cnt && base + lane < a.S) ? cnt[base + lane] : (cnt ? 1 : a.K);
     c = c < 1 ? 1 : (c > a.K ? a.K : c);
-    const int g = (c + 3) & ~3;
+    const int g = rag_ceil(c);
     const int nv = a.S - base < 64 ? a.S - base : 64;
     for (int l = 0; l < nv; l++) {
       const int gl = __builtin_amdgcn_readlane(g, l);
@@ -496,7 +504,7 @@ __global__ __launch_bounds__(1024) void sa_rag_scan_kernel(int B, int maxT, int 
 // one wave per tile (4 tiles per workgroup), grid-stride over the flat list
 template <int ROWS>
 __global__ __launch_bounds__(256) void sa_rag_rows_kernel(RagArgs a) {
-  constexpr int MAXC = ROWS / 4, CT = MAXC + 4;
+  constexpr int MAXC = ROWS / kRagG, CT = kRagCT;   // MAXC <= 64: one lane per centre
   __shared__ int s_off[4][MAXC + 1], s_cnt[4][MAXC];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int total = a.ws[a.B];
@@ -506,13 +514,13 @@ __global__ __launch_bounds__(256) void sa_rag_rows_kernel(RagArgs a) {
   for (int tile = blockIdx.x * 4 + w; tile < total; tile += gridDim.x * 4) {
     const int4 td = flat[tile];
     const size_t b = (size_t)td.x;
-    const int first = td.y, nc = td.z;      // nc <= MAXC <= 32 < 64 lanes
+    const int first = td.y, nc = td.z;      // 1 <= nc <= MAXC <= 64 lanes
     int n = 1;
     if (lane < nc) {
       n = a.cnt ? a.cnt[b * a.S + first + lane] : a.K;
       n = n < 1 ? 1 : (n > a.K ? a.K : n);
     }
-    const int g = lane < nc ? (n + 3) & ~3 : 0;
+    const int g = lane < nc ? rag_ceil(n) : 0;
     int incl = g;                            // inclusive prefix over the lanes of the wave
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -522,20 +530,22 @@ __global__ __launch_bounds__(256) void sa_rag_rows_kernel(RagArgs a) {
     if (lane < nc) {
       s_off[w][lane] = incl - g;
       s_cnt[w][lane] = n;
-      ctab[(size_t)tile * CT + lane] = incl - g;
     }
-    if (lane == nc) {
-      s_off[w][nc] = incl;                   // lanes >= nc carry the total
-      ctab[(size_t)tile * CT + nc] = incl;
-    }
-    {  // bit q of `ends`: quad q is the last quad of its centre (what the max-pool epilogue scans)
-      unsigned my = lane < nc ? 1u << ((incl >> 2) - 1) : 0u;
+    const int used_rows = __shfl(incl, nc - 1, 64);
+    if (lane == 0) s_off[w][nc] = used_rows;
+    {  // bit q of `ends`: row group q is the last group of its centre (what the max-pool epilogue scans)
+      const int last = (incl / kRagG) - 1;
+      unsigned lo32 = (lane < nc && last < 32) ? 1u << last : 0u;
+      unsigned hi32 = (lane < nc && last >= 32) ? 1u << (last - 32) : 0u;
 #pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) my |= __shfl_xor(my, off, 64);
-      const int nquads = __shfl(incl, nc, 64) >> 2;
+      for (int off = 32; off >= 1; off >>= 1) {
+        lo32 |= __shfl_xor(lo32, off, 64);
+        hi32 |= __shfl_xor(hi32, off, 64);
+      }
       if (lane == 0) {
-        ctab[(size_t)tile * CT + MAXC + 1] = (int)my;
-        ctab[(size_t)tile * CT + MAXC + 2] = nquads;
+        ctab[(size_t)tile * CT] = (int)lo32;
+        ctab[(size_t)tile * CT + 1] = (int)hi32;
+        ctab[(size_t)tile * CT + 2] = used_rows / kRagG;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -576,9 +586,9 @@ __device__ unsigned long long g_rag_trace[kTraceWgs * (2 + kTraceTiles * kTraceM
 // instead of ~500 of VALU / LDS work.  (Host picks it when c1 has at most four cout blocks and, with a table, TB = 2.)
 template <int TB, int NR, int W2, int W3, int NR2 = NR, int W1 = 0>
 __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
-  constexpr int ROWS = 32 * TB, RP = ROWS + 1, MAXC = ROWS / 4, NG = ROWS / 4, CT = MAXC + 4;
+  constexpr int ROWS = 32 * TB, RP = ROWS + 1, NG = ROWS / kRagG, CT = kRagCT;
   constexpr bool kL1M = W1 != 0;
-  const int C3P = ceil32(a.c3);           // gmax is [NG quads][C3P]
+  const int C3P = ceil32(a.c3);           // gmax is [NG row groups][C3P]
   constexpr int QS = kThreads / ROWS;     // channel quads advance by QS per item: a thread keeps ONE row
   constexpr int NI = 8;                   // 16-byte table pieces a thread holds in registers
   const bool tracing = (a.dbg & 256) && threadIdx.x == 0 && blockIdx.x < kTraceWgs;
@@ -604,8 +614,7 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   const f32x4 *rowtab = reinterpret_cast<const f32x4 *>(a.ws + rag_rowtab_off(a.B, a.maxT, ROWS));
   const int rowsC = c1 > ceil32(c2) ? c1 : ceil32(c2);
   float *buf = smem;                                          // [rowsC][RP]
-  int *coff2 = reinterpret_cast<int *>(buf + rowsC * RP);     // [2][CT] first row of each centre, double-buffered
-  float *gmax = reinterpret_cast<float *>(coff2 + 2 * CT);    // [NG][ceil32(c3)], 16-byte aligned
+  float *gmax = buf + rowsC * RP;                             // [NG][ceil32(c3)], 16-byte aligned
   float *s_wa = gmax + NG * C3P;                              // [c1][3] dxyz weights and [ceil32(c1)] shift of
   float *s_sh1 = s_wa + 3 * c1;                               //   layer 1, staged once per (persistent) workgroup
   float *s_sh2 = s_sh1 + ceil32(c1);                          // accumulator seeds of layers 2 / 3 (zero-padded)
@@ -634,15 +643,16 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   const int ni = (nq - q0 + QS - 1) / QS;      // items of this thread: quads q0, q0 + QS, ...
   // PREF: the whole layer-1 gather of the NEXT tile (<= NI pieces per thread) is in flight during layer 3
   const bool pref = a.pq && ni <= NI;
-  // per-tile state in registers: the thread's row entry {neighbour index, dxyz}, its table pieces, one
-  // centre offset (threads < MAXC + 1)
+  // per-tile state in registers: the thread's row entry {neighbour index, dxyz}, its table pieces, the tile's
+  // segment mask (bit q: row group q closes a centre; wave-uniform)
   f32x4 rv = {__int_as_float(-1), 0.f, 0.f, 0.f};
   f32x4 p4[NI];
-  int cv = 0;
+  unsigned ends_lo = 0u, ends_hi = 0u, nxt_lo = 0u, nxt_hi = 0u;
   auto fetch_row = [&](int tile) {
     if (tile < total) {
       rv = rowtab[(size_t)tile * ROWS + r];
-      if (tid < MAXC + 3) cv = ctab[(size_t)tile * CT + tid];   // offsets, then the `ends` mask and the quad count
+      nxt_lo = (unsigned)ctab[(size_t)tile * CT];
+      nxt_hi = (unsigned)ctab[(size_t)tile * CT + 1];
     }
   };
   const int lane = tid & 63, wv = tid >> 6;
@@ -682,15 +692,15 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   int par = 0;
   __syncthreads();            // (sdx8 zeroed)
   fetch_row(blockIdx.x);
-  if (tid < MAXC + 3) coff2[tid] = cv;
+  ends_lo = nxt_lo;
+  ends_hi = nxt_hi;
   if constexpr (kL1M) stash_dxyz();
   if (pref || (kL1M && a.pq)) gather(blockIdx.x);
   __syncthreads();
   for (int tile = blockIdx.x; tile < total; tile += gridDim.x, par ^= 1) {
   const int4 td = flat[tile];
   const size_t b = (size_t)td.x;
-  const int first = td.y, nc = td.z;
-  const int *coff = coff2 + par * CT;
+  const int first = td.y;
   PCR_MARK(0);
   if constexpr (kL1M) {
     const bool hasp = a.pq != nullptr;
@@ -752,60 +762,64 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   if (!(a.dbg & 4))
   tile_dense2<TB, NR, W3, true>(buf, ceil8(c2), a.wp3, ceil32(c3), false,
                                [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
-    // quad maxima -> gmax[quad][cout]: the 16 accumulator rows of a lane are four runs of four consecutive
-    // couts, so the first lane of every quad stores four 16-byte pieces
+    // row-pair maxima -> gmax[group][cout]: the 16 accumulator rows of a lane are four runs of four consecutive
+    // couts, so the first lane of every pair stores four 16-byte pieces
     // (signed maxima of the bit patterns; the ReLU is the scan's max with 0: see relu_bits)
+    static_assert(kRagG == 2, "the DPP step below pairs lanes l and l ^ 1");
     f32x4 g4[4];
 #pragma unroll
     for (int rr = 0; rr < 16; rr++) {
       int v = __float_as_int(acc[rr]);
       v = imax(v, dpp_i32<0xB1>(v));    // lane ^ 1
-      v = imax(v, dpp_i32<0x4E>(v));    // lane ^ 2: quad maximum
       g4[rr >> 2][rr & 3] = __int_as_float(v);
     }
-    if ((l31 & 3) == 0) {
-      float *gq = gmax + (tb * 8 + (l31 >> 2)) * C3P + cb * 32 + 4 * h;
+    if ((l31 & 1) == 0) {
+      float *gq = gmax + (tb * 16 + (l31 >> 1)) * C3P + cb * 32 + 4 * h;
 #pragma unroll
       for (int g = 0; g < 4; g++) *reinterpret_cast<f32x4 *>(gq + 8 * g) = g4[g];
     }
   }, s_sh3, kRing ? ring3 : nullptr, load_ring2);
   PCR_MARK(5);
-  if (tid < MAXC + 3) coff2[(par ^ 1) * CT + tid] = cv;   // next tile's offsets (this tile's are read below)
-  if constexpr (kL1M) stash_dxyz();                       // and its dxyz rows (layer 1 of this tile is long done)
+  if constexpr (kL1M) stash_dxyz();   // next tile's dxyz rows (layer 1 of this tile is long done)
   __syncthreads();
   PCR_MARK(6);
   if (!(a.dbg & 8)) {
     // one cout per thread; all quad maxima of the tile are read first (independent, conflict-free LDS reads),
     // then scanned with the wave-uniform `ends` mask: values are >= 0 after the ReLU, so 0 starts a segment
-    const unsigned ends = (unsigned)__builtin_amdgcn_readfirstlane(coff[MAXC + 1]);
     if (tid < c3) {   // c3 <= 256 = kThreads
       const int o = tid;
-      float gv[NG];
       const float *g = gmax + o;
-#pragma unroll
-      for (int q = 0; q < NG; q++) gv[q] = g[q * C3P];
       // a wave issues one instruction every few cycles whatever its kind: the per-step work is kept to a max,
-      // a bit test and (at a centre's last quad) one store through a running 32-bit offset.  `ends` has no bit
-      // beyond the tile's last quad, so whatever the unused quads hold is never stored.
+      // a bit test and (at a centre's last group) one store through a running 32-bit offset.  The mask has no bit
+      // beyond the tile's last group, so whatever the unused groups hold is never stored.
       float *base = a.out_pm ? a.out + (b * a.S + first) * c3 : a.out + b * c3 * a.S + first;
       unsigned off = a.out_pm ? (unsigned)o : (unsigned)o * (unsigned)a.S;
       const unsigned step = a.out_pm ? (unsigned)c3 : 1u;
-      int m = 0;   // signed max of the bit patterns starting from +0 = max over the quads, then ReLU (relu_bits)
+      int m = 0;   // signed max of the bit patterns starting from +0 = max over the groups, then ReLU (relu_bits)
 #pragma unroll
-      for (int q = 0; q < NG; q++) {
-        m = imax(m, __float_as_int(gv[q]));
-        if ((ends >> q) & 1u) {
-          base[off] = __int_as_float(m);
-          off += step;
-          m = 0;
+      for (int half = 0; half < NG / 32; half++) {
+        const unsigned ends = (unsigned)__builtin_amdgcn_readfirstlane((int)(half ? ends_hi : ends_lo));
+        float gv[32];
+#pragma unroll
+        for (int q = 0; q < 32; q++) gv[q] = g[(half * 32 + q) * C3P];
+#pragma unroll
+        for (int q = 0; q < 32; q++) {
+          m = imax(m, __float_as_int(gv[q]));
+          if ((ends >> q) & 1u) {
+            base[off] = __int_as_float(m);
+            off += step;
+            m = 0;
+          }
         }
       }
     }
   }
+  ends_lo = nxt_lo;
+  ends_hi = nxt_hi;
   PCR_MARK(7);
   trace_it++;
   // no barrier needed here: the next tile's layer 1 writes buf (dead since layer 3), its layer 3 writes gmax
-  // only after two more barriers, and the next tile's coff buffer was written before the last one
+  // only after two more barriers
   }
 }
 
@@ -913,7 +927,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
     const int tb = nrr == 2 ? 2 : 4;
     const int ROWS = 32 * tb;
     if (p.K <= ROWS) {
-      const int per_tile = ROWS / ((p.K + 3) & ~3);            // whole centres a tile holds in the worst case
+      const int per_tile = ROWS / rag_ceil(p.K);               // whole centres a tile holds in the worst case
       RagArgs r;
       r.B = p.B; r.N = p.N; r.S = p.S; r.K = p.K; r.c1 = p.c1; r.c2 = p.c2; r.c3 = p.c3;
       r.maxT = (p.S + per_tile - 1) / per_tile;
@@ -927,8 +941,8 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
       r.out = p.out;
       r.out_pm = p.out_point_major;
       const int rowsCr = p.c1 > ceil32(p.c2) ? p.c1 : ceil32(p.c2);
-      const size_t lds = ((size_t)rowsCr * (ROWS + 1) + 2 * (ROWS / 4 + 4) +
-                          (size_t)ceil32(p.c3) * (ROWS / 4) + 3 * (size_t)p.c1 + ceil32(p.c1) + ceil32(p.c2) +
+      const size_t lds = ((size_t)rowsCr * (ROWS + 1) +
+                          (size_t)ceil32(p.c3) * (ROWS / kRagG) + 3 * (size_t)p.c1 + ceil32(p.c1) + ceil32(p.c2) +
                           ceil32(p.c3) + 8 * (ROWS + 1)) *
                          sizeof(float);
       if (lds <= 150 * 1024) {
@@ -1091,7 +1105,7 @@ PCR_EXPORT long pcr_sa_tile_ws_ints(int B, int S, int K, int c2, int c3) {
   if (B < 1 || S < 1 || K < 1 || c2 < 1 || c3 < 1) return 0;
   const int rows = (ceil32(c2) > 128 || ceil32(c3) > 128) ? 64 : 128;   // sa2_try's tile choice
   if (K > rows) return 0;
-  const int per_tile = rows / ((K + 3) & ~3);
+  const int per_tile = rows / rag_ceil(K);
   const int maxT = (S + per_tile - 1) / per_tile;
   return (long)rag_ws_ints(B, maxT, rows);
 }

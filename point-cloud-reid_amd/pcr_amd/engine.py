@@ -212,8 +212,8 @@ class SaPlan:
         flops = 2.0 * B * S * K * (self.cin * c1 + c1 * c2 + c2 * c3)
         nbytes = 4.0 * B * (3 * N + D * N + S * K + c3 * S)
         exec_flops = 2.0 * B * S * K * (c1 * c2 + c2 * c3) if self.fast else flops
-        if ragged:   # rows really evaluated: ceil4(max(cnt,1)) per centre (only computed while profiling)
-            rows = float(((cnt.clamp(1, K) + 3) // 4 * 4).sum().item()) if PROFILE is not None else 0.0
+        if ragged:   # rows really evaluated: ceil2(max(cnt,1)) per centre (only computed while profiling)
+            rows = float(((cnt.clamp(1, K) + 1) // 2 * 2).sum().item()) if PROFILE is not None else 0.0
             exec_flops = 2.0 * rows * (c1 * c2 + c2 * c3)
         name = "sa_ragged" if ragged else "sa_fused"
         with _prof("%s[D=%d,c=%d/%d/%d,N=%d,S=%d,K=%d]" % (name, D, c1, c2, c3, N, S, K), flops, nbytes, exec_flops):
