@@ -366,11 +366,11 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
 // ------------------------------------------------- ragged SA MLP (ball-query duplicates) ----
 // A ball-query row holds only cnt genuine neighbours; entries [cnt, K) repeat the first one
 // (ball_query_cuda.cu:43-47), and a max over K does not care about repeats.  This variant runs the MLP
-// on ceil4(max(cnt,1)) rows per centre instead of K:
+// on ceil2(max(cnt,1)) rows per centre instead of K:
 //   sa_rag_plan_kernel  one thread per cloud walks the S counts and packs whole centres into tiles of
 //                       32*TB rows -> per-cloud tile descriptors + tile count;
-//   sa_rag_scan_kernel  one workgroup: exclusive scan of the tile counts over the clouds, then the
-//                       descriptors are copied into ONE flat list (cloud, first centre, n centres);
+//   sa_rag_scan_kernel  one workgroup: exclusive scan of the tile counts over the clouds;
+//   sa_rag_flatten_kernel  one wave per cloud copies its descriptors into ONE flat list (cloud, first centre, n);
 //   sa_rag_rows_kernel  one wave per tile: the row table {neighbour index, dxyz} of the tile and the
 //                       first row of each of its centres (the cnt -> prefix -> idx -> xyz chain of four
 //                       dependent global loads, taken off the matrix kernel's critical path);
@@ -452,19 +452,24 @@ __global__ __launch_bounds__(256) void sa_rag_plan_kernel(RagArgs a, int rows_pe
   }
 }
 
-__global__ __launch_bounds__(1024) void sa_rag_scan_kernel(int B, int maxT, int *ws) {
-  __shared__ int part[1024];
+// exclusive scan of the per-cloud tile counts (one workgroup; four clouds per thread and iteration), in place:
+// ws[b] <- first flat index of cloud b, ws[B] <- total
+__global__ __launch_bounds__(1024) void sa_rag_scan_kernel(int B, int *ws) {
   __shared__ int wtot[16];
   __shared__ int carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int *desc = ws + rag_desc_off(B);
-  int4 *flat = reinterpret_cast<int4 *>(ws + rag_flat_off(B, maxT));
   if (tid == 0) carry = 0;
   __syncthreads();
-  for (int base = 0; base < B; base += 1024) {
-    const int b = base + tid;
-    const int v = b < B ? ws[b] : 0;
-    int incl = v;                            // wave scans, then one scan over the 16 wave totals: two barriers
+  for (int base = 0; base < B; base += 4096) {
+    int v[4];
+    int sum = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int b = base + tid * 4 + u;
+      v[u] = b < B ? ws[b] : 0;
+      sum += v[u];
+    }
+    int incl = sum;                          // wave scans, then one scan over the 16 wave totals: two barriers
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const int t = __shfl_up(incl, off, 64);
@@ -482,23 +487,32 @@ __global__ __launch_bounds__(1024) void sa_rag_scan_kernel(int B, int maxT, int 
       if (lane < 16) wtot[lane] = w;         // inclusive totals
     }
     __syncthreads();
-    part[tid] = incl + (wave ? wtot[wave - 1] : 0);
-    const int excl = part[tid] - v + carry;
-    // (batches of independent loads: a plain load / store loop is one memory round trip per descriptor)
-    const int2 *dsrc = reinterpret_cast<const int2 *>(desc + (size_t)(b < B ? b : 0) * 2 * maxT);
-    for (int j0 = 0; j0 < v; j0 += 8) {
-      int2 dd[8];
+    int excl = incl - sum + (wave ? wtot[wave - 1] : 0) + carry;
 #pragma unroll
-      for (int u = 0; u < 8; u++) dd[u] = dsrc[j0 + u < v ? j0 + u : 0];
-#pragma unroll
-      for (int u = 0; u < 8; u++)
-        if (j0 + u < v) flat[excl + j0 + u] = make_int4(b, dd[u].x, dd[u].y, 0);
+    for (int u = 0; u < 4; u++) {
+      const int b = base + tid * 4 + u;
+      if (b < B) ws[b] = excl;
+      excl += v[u];
     }
     __syncthreads();
-    if (tid == 1023) carry += part[1023];
+    if (tid == 1023) carry = excl;
     __syncthreads();
   }
   if (tid == 0) ws[B] = carry;
+}
+
+// one wave per cloud: its descriptors (first centre, n centres) -> the flat list entries (cloud, first, n, -)
+__global__ __launch_bounds__(256) void sa_rag_flatten_kernel(int B, int maxT, int *ws) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int lo = ws[b], hi = b + 1 < B ? ws[b + 1] : ws[B];
+  const int2 *dsrc = reinterpret_cast<const int2 *>(ws + rag_desc_off(B) + (size_t)b * 2 * maxT);
+  int4 *flat = reinterpret_cast<int4 *>(ws + rag_flat_off(B, maxT));
+  for (int j = lane; j < hi - lo; j += 64) {
+    const int2 d = dsrc[j];
+    flat[lo + j] = make_int4(b, d.x, d.y, 0);
+  }
 }
 
 // one wave per tile (4 tiles per workgroup), grid-stride over the flat list
@@ -951,7 +965,8 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
           if (rc != PCR_OK) return rc == PCR_ERR_INVALID ? -1 : rc;
         }
         hipLaunchKernelGGL(sa_rag_plan_kernel, dim3((p.B + 3) / 4), dim3(256), 0, st, r, ROWS);
-        hipLaunchKernelGGL(sa_rag_scan_kernel, dim3(1), dim3(1024), 0, st, p.B, r.maxT, r.ws);
+        hipLaunchKernelGGL(sa_rag_scan_kernel, dim3(1), dim3(1024), 0, st, p.B, r.ws);
+        hipLaunchKernelGGL(sa_rag_flatten_kernel, dim3((p.B + 3) / 4), dim3(256), 0, st, p.B, r.maxT, r.ws);
         {
           long long wgs = ((long long)p.B * r.maxT + 3) / 4;
           if (wgs > 4096) wgs = 4096;
