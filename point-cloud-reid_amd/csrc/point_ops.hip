@@ -282,6 +282,7 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(const float *__restrict__ 
     const uint32_t tr = (uint32_t)k & (uint32_t)(block - 1);
     const uint32_t rev = logb ? (__brev(tr) >> (32 - logb)) : 0u;
     low[p] = ok ? ((((uint32_t)(block - 1) - rev) << 22) | (0x3FFFFFu - (uint32_t)k)) : 0u;
+    asm volatile("" : "+v"(low[p]));   // keep the value in a register (else it is re-derived from masks every step)
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);   // this wave's LDS writes (lgkmcnt(0)); there is no other wave
   __builtin_amdgcn_wave_barrier();
@@ -308,9 +309,11 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(const float *__restrict__ 
     const uint32_t best = dpp_max_u32(mx);
     uint32_t lo = 0u;
 #pragma unroll
-    for (int p = 0; p < 2 * PP; p++) {
-      const uint32_t l = t[p] == best ? low[p] : 0u;
-      lo = l > lo ? l : lo;
+    for (int p = 0; p < PP; p++) {   // (pairs: the two selects feed one three-way max)
+      const uint32_t l0 = t[2 * p] == best ? low[2 * p] : 0u;
+      const uint32_t l1 = t[2 * p + 1] == best ? low[2 * p + 1] : 0u;
+      const uint32_t l01 = l0 > l1 ? l0 : l1;
+      lo = l01 > lo ? l01 : lo;
     }
     lo = dpp_max_u32(lo);
     old = (int)(0x3FFFFFu - (lo & 0x3FFFFFu));
