@@ -101,11 +101,6 @@ __global__ __launch_bounds__(kThreads) void sa_mlp_kernel(SaArgs a) {
 // computed once per cloud by dense_pm_kernel (K times fewer FLOPs than per (centre,neighbour)
 // row).  The kernel gathers P rows (16-byte loads) straight into the layer-1 activation tile,
 // then runs layers 2 and 3 on the matrix core IN PLACE in one LDS buffer and reduces max over K.
-// in-register cross-lane move inside a 16-lane row (VALU DPP modifier, no LDS traffic)
-template <int CTRL>
-__device__ __forceinline__ float dpp_f32(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
 
 // ReLU / max on the BIT patterns (signed integer max): exact for every finite input -- a float >= +0 has a
 // non-negative pattern that orders like the float, any negative float has a negative pattern -- as long as the

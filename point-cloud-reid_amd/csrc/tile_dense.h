@@ -314,43 +314,6 @@ __device__ __forceinline__ void tile_dense2(const float *__restrict__ in, int CP
   }
 }
 
-// tile_dense2 over a WINDOW of cout rows of a wider packed image: `wp` already points at the first
-// row of the window, OP is the window height (multiple of 32) and OPfull the image's padded cout
-// (the k-block stride).  Used by dense_kernel to split wide layers over workgroups.
-template <int TB, int NR, class Epi>
-__device__ __forceinline__ void tile_dense_strided(const float *__restrict__ in, int CP,
-                                                   const float *__restrict__ wp, int OP, int OPfull, Epi epi) {
-  constexpr int RP = 32 * TB + 1;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int l31 = lane & 31, h = lane >> 5;
-  const int nCB = OP >> 5, KB = CP >> 3;
-  const size_t wstride = (size_t)OPfull * 2;
-  for (int item = wave; item < nCB * TB; item += kThreads / 64) {
-    const int cb = item / TB, tb = item - cb * TB;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = 0.f;
-    const f32x4 *wv = reinterpret_cast<const f32x4 *>(wp) + (size_t)(cb * 32 + l31) * 2 + h;
-    const float *bp = in + h * RP + tb * 32 + l31;
-    f32x4 a = wv[0];
-    for (int kb = 0; kb < KB; kb++) {
-      const int kn = kb + 1 < KB ? kb + 1 : kb;
-      const f32x4 an = wv[(size_t)kn * wstride];
-      const float *b0 = bp + (kb * 8) * RP;
-      const float x0 = b0[0], x1 = b0[2 * RP], x2 = b0[4 * RP], x3 = b0[6 * RP];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], x0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], x1, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], x2, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], x3, acc, 0, 0, 0);
-      a = an;
-    }
-    const int t = tb * 32 + l31;
-#pragma unroll
-    for (int r = 0; r < 16; r++) epi(acc[r], cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, t);
-  }
-}
-
 // elu(x) + 1 = x + 1 (x > 0) | exp(x) (x <= 0); hardware exp2 (v_exp_f32, ~1 ulp) instead of the libm
 // expansion: this runs once per projected Q/K element and was a third of the attention kernels' VALU time
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x + 1.0f : __expf(x); }
@@ -494,14 +457,6 @@ __device__ __forceinline__ void load_tile_pm(float *dst, int RP, const float *sr
         }
       }
     }
-  }
-}
-
-// xyz (L,3) rows t0.. -> LDS [8][RP] (rows 3..7 zero)
-__device__ __forceinline__ void load_xyz_tile(float *dst, int RP, const float *xyz, int L, int t0, int T) {
-  for (int e = threadIdx.x; e < 8 * T; e += blockDim.x) {
-    const int c = e / T, t = e - c * T;
-    dst[c * RP + t] = (c < 3 && t0 + t < L) ? xyz[(size_t)(t0 + t) * 3 + c] : 0.f;
   }
 }
 
