@@ -39,7 +39,7 @@ __device__ __forceinline__ void load_xyz3(float *P, int RP, const float *xyz, in
 // workgroups share a CU; the next tile's features are fetched into registers while this tile is on the matrix core.
 //   WSEL: dense shape of the 2d-row projection (2 / 1 / 1 for d = 32 / 64 / 128), NTW: KV tiles per wave (1 / 1 / 4)
 template <int TB, int NR, int WSEL, int NTW>
-__global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
+__device__ __forceinline__ void attn_kv_body(const AttnArgs &a) {
   constexpr int T = 32 * TB, RP = T + 1;
   constexpr int NPF = 4;   // 16-byte feature pieces per thread and tile held in registers (c2 * T / 4 / 256 <= NPF)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -192,6 +192,17 @@ __global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
   if (tid < d) kv[(size_t)d * d + tid] = s_kt[tid];
 }
 
+template <int TB, int NR, int WSEL, int NTW>
+__global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
+  attn_kv_body<TB, NR, WSEL, NTW>(a);
+}
+// the same body held to a third of the register file (three workgroups per CU): worth 5-15 % for d = 64 / 128 even
+// where it costs a few spilled registers, not for d = 32 (already three per CU on its own)
+template <int TB, int NR, int WSEL, int NTW>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_kv_kernel_o3(AttnArgs a) {
+  attn_kv_body<TB, NR, WSEL, NTW>(a);
+}
+
 // One workgroup per (query cloud, tile of T query tokens), T = 128 / 64 / 32 for d = 32 / 64 / 128.
 // ONE LDS buffer U of max(c1 + d, 2d, cout, cfinal) rows, every dense phase in place (barrier between its
 // k-loop and its epilogue), so a d = 64 tile is 33 KB and four workgroups share a CU:
@@ -327,14 +338,14 @@ PCR_EXPORT int pcr_attn_kv_f32(const pcr_attn_params *pp, pcr_stream_t stream) {
   if (lds2 > lds) lds = lds2;
   lds = (lds + kThreads) * sizeof(float);
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
-  static bool ok = allow_big_lds(attn_kv_kernel<2, 1, 2, 1>) && allow_big_lds(attn_kv_kernel<2, 1, 1, 1>) &&
-                   allow_big_lds(attn_kv_kernel<1, 2, 1, 4>) && allow_big_lds(attn_kv_kernel<2, 1, 0, 1>);
+  static bool ok = allow_big_lds(attn_kv_kernel<2, 1, 2, 1>) && allow_big_lds(attn_kv_kernel_o3<2, 1, 1, 1>) &&
+                   allow_big_lds(attn_kv_kernel_o3<1, 2, 1, 4>) && allow_big_lds(attn_kv_kernel<1, 2, 0, 4>);
   (void)ok;
   dim3 g(pp->B), blk(kThreads);
   hipStream_t st = pcr_s(stream);
   if (d == 32) hipLaunchKernelGGL((attn_kv_kernel<2, 1, 2, 1>), g, blk, lds, st, a);        // 2d = 64: two cout blocks
-  else if (d == 64) hipLaunchKernelGGL((attn_kv_kernel<2, 1, 1, 1>), g, blk, lds, st, a);   // four, one per wave
-  else if (d == 128) hipLaunchKernelGGL((attn_kv_kernel<1, 2, 1, 4>), g, blk, lds, st, a);  // eight, two rounds
+  else if (d == 64) hipLaunchKernelGGL((attn_kv_kernel_o3<2, 1, 1, 1>), g, blk, lds, st, a);   // four, one per wave
+  else if (d == 128) hipLaunchKernelGGL((attn_kv_kernel_o3<1, 2, 1, 4>), g, blk, lds, st, a);  // eight, two rounds
   else hipLaunchKernelGGL((attn_kv_kernel<1, 2, 0, 4>), g, blk, lds, st, a);                // d = 96: generic shape
   PCR_CHECK_LAUNCH();
   return PCR_OK;
