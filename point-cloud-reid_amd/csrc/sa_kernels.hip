@@ -855,9 +855,25 @@ __global__ __launch_bounds__(kThreads) void dense_pm_kernel(DensePmArgs a) {
   tile_dense2<TB, NR>(X, cinP, a.wp, ceil32(cout), true, [&](float v, int o, int t) { X[o * RP + t] = v; });
   __syncthreads();
   float *out = a.y + (b * a.L + t0) * (size_t)cout;
-  for (int e = threadIdx.x; e < cout * T; e += kThreads) {
-    const int t = e / cout, c = e - t * cout;
-    if (t0 + t < a.L) out[(size_t)t * cout + c] = X[c * RP + t];
+  if ((cout & 3) == 0) {
+    // 16-byte stores; item e = (token e / Q, cout quad e % Q) advances by kThreads: one division, then increments
+    const int Q = cout >> 2, total = Q * T;
+    const int dt = kThreads / Q, dq = kThreads - dt * Q;
+    int t = threadIdx.x / Q, q = threadIdx.x - t * Q;
+    for (int e = threadIdx.x; e < total; e += kThreads) {
+      if (t0 + t < a.L) {
+        const float *xs = X + 4 * q * RP + t;
+        *reinterpret_cast<f32x4 *>(out + (size_t)t * cout + 4 * q) = f32x4{xs[0], xs[RP], xs[2 * RP], xs[3 * RP]};
+      }
+      t += dt;
+      q += dq;
+      if (q >= Q) { q -= Q; t++; }
+    }
+  } else {
+    for (int e = threadIdx.x; e < cout * T; e += kThreads) {
+      const int t = e / cout, c = e - t * cout;
+      if (t0 + t < a.L) out[(size_t)t * cout + c] = X[c * RP + t];
+    }
   }
 }
 

@@ -413,22 +413,28 @@ __device__ __forceinline__ void load_tile_pm(float *dst, int RP, const float *sr
                                              int t0, int T) {
   if ((C & 3) == 0 && (reinterpret_cast<size_t>(src) & 15) == 0) {
     const int Q = CP >> 2, totq = T * Q;    // CP is a multiple of 8
+    // piece e = (token e / Q, channel quad e % Q); e advances by kThreads per piece: ONE division per thread, then
+    // increments (a runtime division is ~20 instructions, and there would be one per piece and pass)
+    const int dt = kThreads / Q, dq = kThreads - dt * Q;
+    int t = threadIdx.x / Q, q = threadIdx.x - t * Q;
     for (int e0 = threadIdx.x; e0 < totq; e0 += 4 * kThreads) {
       f32x4 v[4];
+      int tt[4], qq[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int e = e0 + u * kThreads;
-        const int t = e / Q, q = e - t * Q;
-        const bool ok = e < totq && 4 * q < C && t0 + t < L;
+        tt[u] = t;
+        qq[u] = q;
+        const bool ok = e0 + u * kThreads < totq && 4 * q < C && t0 + t < L;
         const f32x4 x = *reinterpret_cast<const f32x4 *>(src + (ok ? (size_t)(t0 + t) * C + 4 * q : 0));
         v[u] = ok ? x : f32x4{0.f, 0.f, 0.f, 0.f};
+        t += dt;
+        q += dq;
+        if (q >= Q) { q -= Q; t++; }
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int e = e0 + u * kThreads;
-        if (e < totq) {
-          const int t = e / Q, q = e - t * Q;
-          float *d = dst + 4 * q * RP + t;
+        if (e0 + u * kThreads < totq) {
+          float *d = dst + 4 * qq[u] * RP + tt[u];
           d[0] = v[u][0];
           d[RP] = v[u][1];
           d[2 * RP] = v[u][2];
