@@ -177,9 +177,17 @@ __device__ __forceinline__ void attn_kv_body(const AttnArgs &a) {
     s_kt[tid] = s;
   }
   float *kv = p.kv + b * ((size_t)d * d + d);
-  for (int e = tid; e < d * d; e += kThreads) {
-    const int o = e / d, dd = e - o * d;
-    const int v0 = (dd / dh) * dh;
+  // e = (o = e / d, dd = e % d) advances by kThreads: one division per thread, then increments; the head of dd is
+  // re-derived only when dd changes (never for d = 32 / 64 / 128, where kThreads % d == 0)
+  const int d_o = kThreads / d, d_dd = kThreads - d_o * d;
+  int o = tid / d, dd = tid - o * d;
+  int v0 = (dd / dh) * dh;
+  for (int e = tid; e < d * d; e += kThreads, o += d_o, dd += d_dd) {
+    if (dd >= d) {
+      dd -= d;
+      o++;
+    }
+    if (d_dd) v0 = (dd / dh) * dh;
     const float *wm = p.wmerge + (size_t)o * d + v0;
     const float *kr = KVl + dd * ld + v0;
     float m = 0.f;
