@@ -70,6 +70,9 @@ __device__ __forceinline__ void attn_kv_body(const AttnArgs &a) {
   for (int i = 0; i < NTW; i++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+  int tile_ib[NTW];   // KV tile (ib, jb) of this wave's it-th item: the division is done once, not per token tile
+#pragma unroll
+  for (int it = 0; it < NTW; it++) tile_ib[it] = (wave + 4 * it) / nb;
   // key sums: thread (row = tid % d, part = tid / d) adds up its share of the tokens of every tile
   const int krow = tid % d, kpart = tid / d, kparts = kThreads / d;
   float ksum = 0.f;
@@ -142,7 +145,7 @@ __device__ __forceinline__ void attn_kv_body(const AttnArgs &a) {
     for (int it = 0; it < NTW; it++) {
       const int item = wave + 4 * it;
       if (item < nT) {
-        const int ib = item / nb, jb = item - ib * nb;
+        const int ib = tile_ib[it], jb = item - ib * nb;
         const float *ap = KB + (ib * 32 + l31) * RP + h;
         const float *bp = VB + (jb * 32 + l31) * RP + h;
 #pragma unroll 4
@@ -161,12 +164,16 @@ __device__ __forceinline__ void attn_kv_body(const AttnArgs &a) {
   for (int it = 0; it < NTW; it++) {
     const int item = wave + 4 * it;
     if (item < nT) {
-      const int ib = item / nb, jb = item - ib * nb;
+      const int ib = tile_ib[it], jb = item - ib * nb;
       const int v = jb * 32 + l31;
+      const int hv = v / dh;
+      const bool aligned = (dh & 31) == 0;           // heads made of whole 32-blocks: one test per tile
+      const bool same_blk = (ib * 32) / dh == hv;
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int dd = ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        KVl[dd * ld + v] = (dd / dh == v / dh) ? acc[it][r] : 0.f;
+        const bool same = aligned ? same_blk : (dd / dh == hv);
+        KVl[dd * ld + v] = same ? acc[it][r] : 0.f;
       }
     }
   }
@@ -283,10 +290,11 @@ __global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
     zs[hd * RP + t] = (1.0f / (z + 1e-6f)) * (float)p.Sk;
   }
   __syncthreads();
-  for (int e = tid; e < d * T; e += kThreads) {
-    const int o = e / T, t = e - o * T;
-    MSG[o * RP + t] *= zs[(o / dh) * RP + t];
-  }
+  for (int hd = 0; hd < p.nhead; hd++)   // (head-major: no runtime division per element)
+    for (int e = tid; e < dh * T; e += kThreads) {
+      const int o = hd * dh + e / T, t = e % T;
+      MSG[o * RP + t] *= zs[hd * RP + t];
+    }
   __syncthreads();
   tile_dense2<TB, NR>(MSG, d, kv, d, true, [&](float v, int o, int t) { MSG[o * RP + t] = v; });
   __syncthreads();
