@@ -239,7 +239,8 @@ int pcr_pool_both_f32(const float *x, float *out, int B, int C, int L, pcr_strea
 
 /* Generic per-point dense layer y = act(scale * (W x) + shift) on channel-major tensors
  * x (B,cin,L) -> y (B,cout,L): 1x1 Conv1d / Linear (+ folded BatchNorm) of the PointNet encoder
- * (models/pointnet.py:27-45, 67-85, 103-127).  act: 0 none, 1 ReLU.  wp packed. */
+ * (models/pointnet.py:27-45, 67-85, 103-127).  act: 0 none, 1 ReLU, 2 LeakyReLU(0.2) (dgcnn_orig.py:112-114).
+ * wp packed. */
 int pcr_dense_f32(const float *x, const float *wp, const float *scale, const float *shift, float *y,
                   int B, int cin, int cout, int L, int act, pcr_stream_t stream);
 /* the same with x given point-major, (B,L,cin) */
@@ -264,6 +265,28 @@ int pcr_dense_bmm_f32(const float *x, const float *wp_per_cloud, float *y, int B
  * LinearRes, with M = B*L tokens), optional residual add, optional ReLU: y = [relu](GN(x) [+ res]). */
 int pcr_groupnorm_f32(const float *x, const float *gamma, const float *beta, const float *res, float *y, int B,
                       int C, int L, int groups, int relu, pcr_stream_t stream);
+
+/* ---- DGCNN EdgeConv (models/dgcnn_orig.py: knn :22-29, get_graph_feature :32-56, DGCNN.forward :127-152) ---- */
+
+/* Feature-space kNN of every point among the points of its own cloud (replaces dgcnn_orig.knn, :22-29):
+ * x (B,C,N) channel-major with batch stride x_bstride floats (0 = C*N), xx_ws = caller workspace of B*N floats
+ * -> idx (B,N,K) int32, the K largest pd_ij = (2 <x_i,x_j> - |x_i|^2) - |x_j|^2 of row i, largest first, ties by
+ * the lower index.  The reference leaves the order of summation of its matmul to the BLAS; this library fixes
+ * <.,.> = fmaf chain over channels 0..C-1 and |.|^2 = left-to-right sum of rounded squares
+ * (oracle/pcr_oracle.c:pcr_oracle_knn_feat).  K <= 64, K <= N <= 2048, C <= 512 (and the LDS budget: see
+ * csrc/edge_kernels.hip). */
+int pcr_knn_feat_f32(const float *x, float *xx_ws, int *idx, int B, int C, int N, int K, long x_bstride,
+                     pcr_stream_t stream);
+
+/* The gather + max + BatchNorm shift + LeakyReLU tail of one EdgeConv layer (dgcnn_orig.py:129-131 and the
+ * like): ta, tb (B,N,Co) point-major tables A = (s.W1) f and Bt = (s.(W2-W1)) f built with pcr_dense_pm_f32
+ * (s = folded BatchNorm scale, W = [W1 | W2] the (Co,2C) conv weight), idx (B,N,K) ->
+ * out[b][c][i] = leaky_slope(max_j ta[b][idx[b][i][j]][c] + tb[b][i][c] + shift[c]), channel-major with batch
+ * stride out_bstride floats (0 = Co*N); out2 (optional, may be NULL) receives the same values with its own
+ * batch stride (the x1..x4 slices of the concatenated conv5 input, dgcnn_orig.py:145).  Co <= 256, K <= 64. */
+int pcr_edge_max_f32(const float *ta, const float *tb, const int *idx, const float *shift, float slope, float *out,
+                     long out_bstride, float *out2, long out2_bstride, int B, int N, int Co, int K,
+                     pcr_stream_t stream);
 
 #ifdef __cplusplus
 }

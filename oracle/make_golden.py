@@ -131,6 +131,54 @@ def gen_pointnet():
     print("pointnet", rec["logits"])
 
 
+DG_CFG = "configs_reid/_base_/reidentifiers/reid_pts_dgcnn_point-cat.py"
+
+
+class _CpuTorch:
+    """dgcnn_orig.get_graph_feature hard-codes torch.device('cuda') (dgcnn_orig.py:38); there is no GPU in the
+    development container, so for fixture generation that module sees a torch whose device() answers 'cpu'."""
+
+    def __getattr__(self, name):
+        return getattr(torch, name)
+
+    @staticmethod
+    def device(*a, **k):
+        return torch.device("cpu")
+
+
+def gen_dgcnn():
+    ref = ref_loader.load_reference()
+    ref.dgcnn_orig.torch = _CpuTorch()
+    model, manifest = build(DG_CFG, seed=0)
+    s1, s2 = T.synthetic_pairs(2, 256, seed=1, kind="randn")
+    knns = []
+    orig_knn = ref.dgcnn_orig.knn
+
+    def spy(x, k):
+        idx = orig_knn(x, k)
+        knns.append(_np(idx).astype(np.int16))
+        return idx
+
+    ref.dgcnn_orig.knn = spy
+    try:
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            xyz1, xyz2, h1, h2 = model.siamese_forward(s1, s2)
+            logits = model.match_forward_inference(h1, h2, xyz1, xyz2)
+            knns_fwd = list(knns)
+            _, feat = model.backbone(torch.cat([s1, s2], 0).permute(0, 2, 1), model.backbone_list)
+    finally:
+        ref.dgcnn_orig.knn = orig_knn
+    rec = dict(h1=_np(h1), h2=_np(h2), logits=_np(logits),
+               enc_max=_np(feat.max(dim=2)[0]), enc_mean=_np(feat.mean(dim=2)),
+               meta=np.array(json.dumps(dict(pairs=2, n=256, kind="randn", input_seed=1, weight_seed=0, k=20))))
+    for i, kk in enumerate(knns_fwd[:4]):
+        rec["knn%d" % (i + 1)] = kk
+    np.savez_compressed(os.path.join(GOLD, "dgcnn_n256_randn.npz"), **rec)
+    with open(os.path.join(GOLD, "dgcnn_manifest.json"), "w") as f:
+        json.dump(manifest, f)
+    print("dgcnn", rec["logits"])
+
+
 def gen_train_step():
     """reference train_step loss + a few gradients (training rows are 'next')."""
     ref_loader.load_reference()
@@ -205,7 +253,11 @@ if __name__ == "__main__":
     if "--only-metric" in sys.argv:
         gen_eval_metric()
         sys.exit(0)
+    if "--only-dgcnn" in sys.argv:
+        gen_dgcnn()
+        sys.exit(0)
     if "--only-small" not in sys.argv:
+        gen_dgcnn()
         gen_pt()
         gen_pointnet()
     gen_train_step()

@@ -221,15 +221,16 @@ def pool_both(x):
     return torch.cat([x.max(dim=2)[0], x.mean(dim=2)], dim=1)
 
 
-def match(sd, h1, xyz1, h2, xyz2, stages=None):
-    """xcorr_eff + point-cat + pool 'both' + match head (ReIDNet.py:231-247, 444-462)"""
+def match(sd, h1, xyz1, h2, xyz2, stages=None, head_ng=8):
+    """xcorr_eff + point-cat + pool 'both' + match head (ReIDNet.py:231-247, 444-462); head_ng = the match head's
+    GroupNorm `ng` (8 in the Point-Transformer / PointNet configs, 16 in reid_pts_dgcnn_point-cat.py:33)"""
     c1, c2 = _sub(sd, "cross_stage1."), _sub(sd, "cross_stage2.")
     a1 = cross_attention(c1, h1, xyz1, h2, xyz2)
     a2 = cross_attention(c1, h2, xyz2, h1, xyz1)
     o1 = cross_attention(c2, a1, xyz1, a2, xyz2)
     o2 = cross_attention(c2, a2, xyz2, a1, xyz1)
     pooled = pool_both(torch.cat([o1, o2], dim=2))
-    x = linear_res(_linres_params(sd, "match_head.0.", 8), pooled)
+    x = linear_res(_linres_params(sd, "match_head.0.", head_ng), pooled)
     logits = F.linear(x, sd["match_head.1.weight"], sd["match_head.1.bias"]).squeeze(1)
     if stages is not None:
         stages.update(x1_o1=a1, x1_o2=a2, x2_o1=o1, x2_o2=o2, pooled=pooled, logits=logits)
@@ -259,6 +260,73 @@ def pointnet_pairs(sd, s1, s2, stages=None):
     if stages is not None:
         stages.update(h1=h[:b], h2=h[b:], enc_max=f.max(dim=2)[0], enc_mean=f.mean(dim=2))
     return match(sd, h[:b], xyz[:b], h[b:], xyz[b:], stages)
+
+
+# ---- DGCNN backbone (mmdet3d/models/dgcnn_orig.py: knn :22-29, get_graph_feature :32-56, DGCNN :89-152) ------
+# The graph feature is materialised exactly as the reference does: cat[f_j - f_i, f_i] -> 1x1 Conv2d (no bias) ->
+# BatchNorm2d -> LeakyReLU(0.2) -> max over the k neighbours; x1..x4 concatenated -> Conv1d 512 -> emb_dims + BN +
+# LeakyReLU.  bn{i} and conv{i}.1 are ONE module registered twice (dgcnn_orig.py:94-104): a state_dict carries both
+# names, load_state_dict writes conv{i}.1 last, so that is the name read here.  The neighbour SETS come from oracle/pcr_oracle.c:pcr_oracle_knn_feat, which fixes the summation order
+# the reference leaves to its BLAS (`knn_fn` lets the tests substitute the reference's own torch formula).
+def knn_feat_torch(x, k):
+    """the reference's formula verbatim in torch (order of summation = whatever ATen picks)"""
+    inner = -2 * torch.matmul(x.transpose(2, 1), x)
+    xx = torch.sum(x ** 2, dim=1, keepdim=True)
+    pd = -xx - inner - xx.transpose(2, 1)
+    return pd.topk(k=k, dim=-1)[1]
+
+
+def knn_feat_oracle(x, k):
+    import point_ops
+    return torch.from_numpy(point_ops.knn_feat(x.detach().cpu().numpy(), k)).long()
+
+
+def graph_feature(x, idx):
+    """x (B,C,N), idx (B,N,k) -> (B,2C,N,k) = cat[f_j - f_i, f_i]"""
+    B, C, N = x.shape
+    k = idx.shape[-1]
+    xt = x.transpose(2, 1)                                          # (B,N,C)
+    nb = torch.gather(xt.unsqueeze(1).expand(B, N, N, C), 2, idx.unsqueeze(-1).expand(B, N, k, C))
+    ctr = xt.unsqueeze(2).expand(B, N, k, C)
+    return torch.cat((nb - ctr, ctr), dim=3).permute(0, 3, 1, 2).contiguous()
+
+
+def dgcnn_backbone(p, x, k=20, stages=None, knn_fn=None):
+    """x (B,3,N) -> (xyz (B,3,N), feats (B,emb_dims,N))"""
+    knn_fn = knn_fn or knn_feat_oracle
+    outs = []
+    f = x
+    for i in (1, 2, 3, 4):
+        idx = knn_fn(f, k)
+        if stages is not None:
+            stages["knn%d" % i] = idx
+        e = graph_feature(f, idx)
+        e = F.conv2d(e, p["conv%d.0.weight" % i])
+        e = F.leaky_relu(_bn(e, p, "conv%d.1" % i, 4), 0.2)
+        f = e.max(dim=-1)[0]
+        if stages is not None:
+            stages["x%d" % i] = f
+        outs.append(f)
+    c = torch.cat(outs, dim=1)
+    y = F.conv1d(c, p["conv5.0.weight"])
+    y = F.leaky_relu(_bn(y, p, "conv5.1", 3), 0.2)
+    return x, y
+
+
+def dgcnn_pairs(sd, s1, s2, k=20, stages=None, knn_fn=None):
+    """DGCNN ReIDNet (use_dgcnn branch of siamese_forward, ReIDNet.py:316-324; downsample ng = 64, 16)."""
+    b, n, _ = s1.shape
+    x = torch.cat([s1, s2], 0).permute(0, 2, 1).contiguous()
+    xyz, f = dgcnn_backbone(_sub(sd, "backbone."), x, k, stages, knn_fn)
+    t = f.permute(0, 2, 1).reshape(-1, f.shape[1])
+    t = linear_res(_linres_params(sd, "downsample.0.", 64), t)
+    t = linear_res(_linres_params(sd, "downsample.1.", 16), t)
+    t = F.linear(t, sd["downsample.2.weight"], sd["downsample.2.bias"])
+    h = t.reshape(2 * b, n, -1).permute(0, 2, 1)
+    xyz = xyz.permute(0, 2, 1)
+    if stages is not None:
+        stages.update(h1=h[:b], h2=h[b:], enc_max=f.max(dim=2)[0], enc_mean=f.mean(dim=2))
+    return match(sd, h[:b], xyz[:b], h[b:], xyz[b:], stages, head_ng=16)
 
 
 # ---- PointNet++ SSG encoder (BASELINE config 2; build-defined composition, SURVEY.md 8d) ---------

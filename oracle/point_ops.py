@@ -100,6 +100,15 @@ def knn_prefix(xyz, s, k):
     return idx
 
 
+def knn_feat(x, k):
+    """x (B,C,N) -> idx (B,N,k): DGCNN feature-space kNN in this build's pinned arithmetic order"""
+    x = _f32(x)
+    B, C, N = x.shape
+    idx = np.zeros((B, N, k), np.int32)
+    lib().pcr_oracle_knn_feat(_fp(x), _ip(idx), B, C, N, k)
+    return idx
+
+
 def gather_fwd(feat, idx):
     feat, idx = _f32(feat), _i32(idx)
     B, C, N = feat.shape

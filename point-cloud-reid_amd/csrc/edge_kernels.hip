@@ -1,0 +1,318 @@
+// DGCNN EdgeConv path for gfx950 (reference: mmdet3d/models/dgcnn_orig.py -- knn :22-29, get_graph_feature
+// :32-56, DGCNN.forward :127-152).  Built with -ffp-contract=off: the neighbour indices are bit-exact against
+// oracle/pcr_oracle.c:pcr_oracle_knn_feat.
+//
+// The reference materialises a (B,2C,N,k) edge tensor cat[f_j - f_i, f_i] and runs a 1x1 Conv2d + BatchNorm +
+// LeakyReLU + max over k on it.  Here one EdgeConv layer is three launches and the edge tensor never exists:
+//   1. pcr_knn_feat_f32   feature-space kNN: 32 queries x N distances per workgroup on the matrix core
+//                         (v_mfma_f32_32x32x2_f32, exact fmaf chain over channels), staged in LDS as sortable keys,
+//                         then one wave per query selects the k largest (same threshold + rank scheme as the xyz kNN);
+//   2. pcr_dense_pm_f32   (twice) per-point tables  A = (s.W1) f  and  Bt = (s.(W2 - W1)) f,  point-major, with the
+//                         BatchNorm scale s folded into the weights:  s.W [f_j - f_i; f_i] = A_j + Bt_i;
+//   3. pcr_edge_max_f32   out_i = leaky(max_j A_j + Bt_i + shift): fl(a + b) is monotone in a and LeakyReLU is
+//                         increasing, so the max over the k neighbours commutes with everything after the gather --
+//                         k times fewer matrix flops than the reference's layout and a gather of k contiguous rows.
+#include <math.h>
+
+#include "pcr_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kEdgeThreads = 256;
+constexpr int kSelCap = 256;   // candidates per query the fast ranking path takes (4 per lane)
+
+// xx[b][i] = ((x0^2 + x1^2) + x2^2) + ...  (separately rounded squares, channel order)
+__global__ __launch_bounds__(256) void feat_sqnorm_kernel(const float *__restrict__ x, float *__restrict__ xx, int C,
+                                                          int N, long bstride) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const float *f = x + (size_t)blockIdx.y * bstride + i;
+  float s = 0.f;
+  for (int c = 0; c < C; c++) {
+    const float v = f[(size_t)c * N];
+    const float sq = v * v;
+    s = c == 0 ? sq : s + sq;
+  }
+  xx[(size_t)blockIdx.y * N + i] = s;
+}
+
+// keys: smaller key = larger pd (so "k largest" is the same "k smallest keys" selection as the xyz kNN)
+__device__ __forceinline__ uint32_t desc_key(float pd) { return ~pcr_orderable(pd + 0.f); }
+
+// One wave: the K smallest (key, index) pairs of d[t] <-> index lane + 64 t, written in (key, index) order.
+template <int T>
+__device__ __forceinline__ void select_k(uint32_t (&d)[T], int lane, int K, unsigned long long *cand,
+                                         int *__restrict__ out) {
+  uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+  for (int t = 0; t < T; t++) m = d[t] < m ? d[t] : m;
+  // 1. the lane whose (truncated, lane-tagged) minimum has rank K-1 gives a threshold with >= K keys under it
+  const uint32_t mkey = (m & ~63u) | (uint32_t)lane;
+  int rank = 0;
+#pragma unroll 8
+  for (int j = 0; j < 64; j++) {
+    const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)mkey, j);
+    rank += kj < mkey ? 1 : 0;
+  }
+  const unsigned long long hit = __ballot(rank == K - 1);
+  const uint32_t tau = (uint32_t)__builtin_amdgcn_readlane((int)mkey, (int)__builtin_ctzll(hit)) | 63u;
+  // 2. candidates d <= tau, compacted in index order
+  int cnt = 0;
+#pragma unroll
+  for (int t = 0; t < T; t++) cnt += d[t] <= tau ? 1 : 0;
+  int incl = cnt;
+#pragma unroll
+  for (int s2 = 1; s2 < 64; s2 <<= 1) {
+    const int o = __shfl_up(incl, s2, 64);
+    if (lane >= s2) incl += o;
+  }
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  if (total <= kSelCap) {
+    int off = incl - cnt;
+#pragma unroll
+    for (int t = 0; t < T; t++)
+      if (d[t] <= tau) cand[off++] = ((unsigned long long)d[t] << 32) | (unsigned)(lane + 64 * t);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (total <= 64) {
+      const unsigned long long own = lane < total ? cand[lane] : ~0ull;
+      const uint32_t ohi = (uint32_t)(own >> 32), olo = (uint32_t)own;
+      int rk = 0;
+      for (int j = 0; j < total; j++) {
+        const uint32_t jhi = (uint32_t)__builtin_amdgcn_readlane((int)ohi, j);
+        const uint32_t jlo = (uint32_t)__builtin_amdgcn_readlane((int)olo, j);
+        const unsigned long long cj = ((unsigned long long)jhi << 32) | jlo;
+        rk += cj < own ? 1 : 0;
+      }
+      if (lane < total && rk < K) out[rk] = (int)olo;
+    } else {
+      unsigned long long own[kSelCap / 64];
+      int rk[kSelCap / 64];
+#pragma unroll
+      for (int u = 0; u < kSelCap / 64; u++) {
+        own[u] = lane + 64 * u < total ? cand[lane + 64 * u] : ~0ull;
+        rk[u] = 0;
+      }
+      for (int j = 0; j < total; j++) {
+        const unsigned long long cj = cand[j];
+#pragma unroll
+        for (int u = 0; u < kSelCap / 64; u++) rk[u] += cj < own[u] ? 1 : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < kSelCap / 64; u++)
+        if (lane + 64 * u < total && rk[u] < K) out[rk[u]] = (int)(own[u] & 0xFFFFFFFFull);
+    }
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    // heavily tied rows: K rounds of wave-wide argmin over (key, index)
+    int mine = 0;
+    for (int k = 0; k < K; k++) {
+      uint32_t bd = d[0];
+      int bt = 0;
+#pragma unroll
+      for (int t = 1; t < T; t++)
+        if (d[t] < bd) { bd = d[t]; bt = t; }
+      unsigned long long key = ((unsigned long long)bd << 32) | (unsigned)(lane + 64 * bt);
+      key = pcr_wave_min_u64(key);
+      const int win = (int)(key & 0xFFFFFFFFull);
+      if (lane == k) mine = win;
+      if (lane == (win & 63)) {
+        const int wt = win >> 6;
+#pragma unroll
+        for (int t = 0; t < T; t++) d[t] = (t == wt) ? 0xFFFFFFFFu : d[t];
+      }
+    }
+    if (lane < K) out[lane] = mine;
+  }
+}
+
+// x (B,C,N) channel-major (batch stride bstride floats), xx (B,N) -> idx (B,N,K).
+// Workgroup = QT queries (rows of a 32-row MFMA tile; QT = 16 wastes half of it but halves the key tile so that
+// N = 2048 fits in LDS) x all N points.  LDS: sA [C2*2][32] query operands | sxq [32] | keys [QT][NP] | cand.
+template <int T>   // NP = 64 T >= N
+__global__ __launch_bounds__(kEdgeThreads) void knn_feat_kernel(const float *__restrict__ x,
+                                                                 const float *__restrict__ xx,
+                                                                 int *__restrict__ idx, int C, int N, int K, int QT,
+                                                                 long bstride) {
+  constexpr int NP = 64 * T;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int C2 = (C + 1) >> 1;
+  float *sA = smem;                         // [2*C2][32]
+  float *sxq = sA + 2 * C2 * 32;            // [32]
+  uint32_t *keys = reinterpret_cast<uint32_t *>(sxq + 32);   // [QT][NP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  unsigned long long *cand = reinterpret_cast<unsigned long long *>(keys + (size_t)QT * NP) + wave * kSelCap;
+  const size_t b = blockIdx.y;
+  const float *f = x + b * bstride;
+  const float *xxb = xx + b * N;
+  const int q0 = blockIdx.x * QT;
+  for (int e = tid; e < 2 * C2 * 32; e += kEdgeThreads) {
+    const int c = e >> 5, r = e & 31;
+    const int q = q0 + r < N ? q0 + r : N - 1;
+    sA[e] = c < C ? f[(size_t)c * N + q] : 0.f;
+  }
+  if (tid < 32) sxq[tid] = xxb[q0 + tid < N ? q0 + tid : N - 1];
+  __syncthreads();
+  const int nblk = (N + 31) >> 5;
+  for (int jb = wave; jb < nblk; jb += kEdgeThreads / 64) {
+    const int j = jb * 32 + l31;
+    const int jc = j < N ? j : N - 1;
+    const float *bp = f + jc;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    int kk = 0;
+    for (; kk + 8 <= C2; kk += 8) {   // 8 loads in flight, then 8 MFMAs (all channels < C except maybe the last)
+      float bv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int c = 2 * (kk + u) + h;
+        const int cc = c < C ? c : C - 1;
+        const float v = bp[(size_t)cc * N];
+        bv[u] = c < C ? v : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[(2 * (kk + u) + h) * 32 + l31], bv[u], acc, 0, 0, 0);
+    }
+    for (; kk < C2; kk++) {
+      const int c = 2 * kk + h;
+      const int cc = c < C ? c : C - 1;
+      const float v = bp[(size_t)cc * N];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[c * 32 + l31], c < C ? v : 0.f, acc, 0, 0, 0);
+    }
+    const float xj = xxb[jc];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < QT) {
+        const float t2 = 2.f * acc[r] - sxq[row];
+        const float pd = t2 - xj;
+        keys[(size_t)row * NP + j] = j < N ? desc_key(pd) : 0xFFFFFFFFu;
+      }
+    }
+  }
+  // columns [nblk*32, NP) were not touched by the loop
+  for (int e = tid; e < QT * (NP - nblk * 32); e += kEdgeThreads) {
+    const int w = NP - nblk * 32;
+    const int row = e / w, col = nblk * 32 + e - row * w;
+    keys[(size_t)row * NP + col] = 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  for (int row = wave; row < QT; row += kEdgeThreads / 64) {
+    const int q = q0 + row;
+    if (q >= N) break;
+    uint32_t d[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) d[t] = keys[(size_t)row * NP + lane + 64 * t];
+    select_k<T>(d, lane, K, cand, idx + (b * N + q) * K);
+  }
+}
+
+// out[b][c][i] = leaky(max_j ta[b][idx[b][i][j]][c] + tb[b][i][c] + shift[c]); ta, tb (B,N,Co) point-major;
+// out / out2 channel-major with their own batch strides (out2 optional: the slice of the concatenated buffer).
+struct EdgeMaxArgs {
+  const float *ta, *tb, *shift;
+  const int *idx;
+  float *out, *out2;
+  long out_bs, out2_bs;
+  int N, Co, K;
+  float slope;
+};
+
+__global__ __launch_bounds__(kEdgeThreads) void edge_max_kernel(const EdgeMaxArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int N = a.N, Co = a.Co, K = a.K;
+  int *sidx = reinterpret_cast<int *>(smem);   // [32][K]
+  float *so = smem + 32 * K;                   // [Co][33]
+  const int tid = threadIdx.x;
+  const size_t b = blockIdx.y;
+  const int p0 = blockIdx.x * 32;
+  const int np = N - p0 < 32 ? N - p0 : 32;
+  const int *ib = a.idx + (b * N + p0) * K;
+  for (int e = tid; e < np * K; e += kEdgeThreads) sidx[e] = ib[e];
+  __syncthreads();
+  const float *ta = a.ta + b * N * Co;
+  const float *tb = a.tb + (b * N + p0) * Co;
+  int p = tid / Co, c = tid - p * Co;
+  const int dp = kEdgeThreads / Co, dc = kEdgeThreads - dp * Co;   // e += 256 without a division per element
+  for (; p < np; ) {
+    const int *nb = sidx + p * K;
+    float m = -INFINITY;
+    int k = 0;
+    for (; k + 4 <= K; k += 4) {
+      const float v0 = ta[(size_t)nb[k] * Co + c], v1 = ta[(size_t)nb[k + 1] * Co + c];
+      const float v2 = ta[(size_t)nb[k + 2] * Co + c], v3 = ta[(size_t)nb[k + 3] * Co + c];
+      m = fmaxf(fmaxf(m, fmaxf(v0, v1)), fmaxf(v2, v3));
+    }
+    for (; k < K; k++) m = fmaxf(m, ta[(size_t)nb[k] * Co + c]);
+    const float s = m + tb[(size_t)p * Co + c];
+    const float y = s + a.shift[c];
+    so[c * 33 + p] = y > 0.f ? y : y * a.slope;
+    p += dp;
+    c += dc;
+    if (c >= Co) { c -= Co; p++; }
+  }
+  __syncthreads();
+  for (int e = tid; e < Co * 32; e += kEdgeThreads) {
+    const int cc = e >> 5, pp = e & 31;
+    if (pp < np) {
+      const float v = so[cc * 33 + pp];
+      a.out[b * a.out_bs + (size_t)cc * N + p0 + pp] = v;
+      if (a.out2) a.out2[b * a.out2_bs + (size_t)cc * N + p0 + pp] = v;
+    }
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------ C ABI ----
+PCR_EXPORT int pcr_knn_feat_f32(const float *x, float *xx_ws, int *idx, int B, int C, int N, int K, long x_bstride,
+                                pcr_stream_t stream) {
+  if (!x || !xx_ws || !idx) return PCR_ERR_INVALID;
+  if (B <= 0 || C <= 0 || N <= 0 || K <= 0 || K > N || K > 64 || N > 2048 || C > 512 || B > 65535)
+    return PCR_ERR_INVALID;
+  if (x_bstride <= 0) x_bstride = (long)C * N;
+  hipStream_t st = pcr_s(stream);
+  hipLaunchKernelGGL(feat_sqnorm_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, x, xx_ws, C, N, x_bstride);
+  const int T = N <= 64 ? 1 : N <= 128 ? 2 : N <= 256 ? 4 : N <= 512 ? 8 : N <= 1024 ? 16 : 32;
+  const int QT = N <= 1024 ? 32 : 16;
+  const int C2 = (C + 1) / 2;
+  const size_t lds = (size_t)(2 * C2 * 32 + 32) * 4 + (size_t)QT * 64 * T * 4 + (size_t)4 * kSelCap * 8;
+  if (lds > 160 * 1024) return PCR_ERR_INVALID;
+  const dim3 g((N + QT - 1) / QT, B), blk(kEdgeThreads);
+#define PCR_KNNF(TT)                                                                                              \
+  do {                                                                                                            \
+    static bool big = hipFuncSetAttribute(reinterpret_cast<const void *>(knn_feat_kernel<TT>),                    \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;  \
+    (void)big;                                                                                                    \
+    hipLaunchKernelGGL((knn_feat_kernel<TT>), g, blk, lds, st, x, (const float *)xx_ws, idx, C, N, K, QT,         \
+                       x_bstride);                                                                                \
+  } while (0)
+  switch (T) {
+    case 1: PCR_KNNF(1); break;
+    case 2: PCR_KNNF(2); break;
+    case 4: PCR_KNNF(4); break;
+    case 8: PCR_KNNF(8); break;
+    case 16: PCR_KNNF(16); break;
+    default: PCR_KNNF(32); break;
+  }
+#undef PCR_KNNF
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_edge_max_f32(const float *ta, const float *tb, const int *idx, const float *shift, float slope,
+                                float *out, long out_bstride, float *out2, long out2_bstride, int B, int N, int Co,
+                                int K, pcr_stream_t stream) {
+  if (!ta || !tb || !idx || !shift || !out) return PCR_ERR_INVALID;
+  if (B <= 0 || N <= 0 || Co <= 0 || Co > 256 || K <= 0 || K > 64 || B > 65535) return PCR_ERR_INVALID;
+  EdgeMaxArgs a{ta, tb, shift, idx, out, out2, out_bstride > 0 ? out_bstride : (long)Co * N,
+                out2_bstride > 0 ? out2_bstride : (long)Co * N, N, Co, K, slope};
+  const size_t lds = (size_t)(32 * K + Co * 33) * 4;
+  hipLaunchKernelGGL(edge_max_kernel, dim3((N + 31) / 32, B), dim3(kEdgeThreads), lds, pcr_s(stream), a);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}

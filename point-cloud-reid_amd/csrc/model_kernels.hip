@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kThreads) void dense_kernel(DenseArgs a) {
           const int oc = chunk0 + o + q;
           if (oc < cout) {
             const float r = acc[4 * g + q] * s4[q] + b4[q];
-            out[(size_t)oc * L + t0 + t] = act ? fmaxf(r, 0.f) : r;
+            out[(size_t)oc * L + t0 + t] = act == 1 ? fmaxf(r, 0.f) : (act == 2 && r < 0.f) ? r * 0.2f : r;
           }
         }
       }

@@ -18,6 +18,7 @@ from pcr_amd import engine
 from pcr_amd import _lib as L
 from .attention import corss_attention, cross_lin_attn, local_self_attention
 from .backbone_net import Pointnet_Backbone
+from .dgcnn_orig import DGCNN
 from .builder import FUSIONMODELS
 from .lanegcn_nets import LinearRes
 from .pointnet import PointNet
@@ -32,10 +33,6 @@ class _OutOfScope(nn.Module):
 
 
 class PostRes(_OutOfScope):
-    pass
-
-
-class DGCNN(_OutOfScope):
     pass
 
 

@@ -14,6 +14,7 @@ SO = os.path.join(LIBDIR, "libpcr_hip.so")
 # kernels keep the default.
 FLAGS = {
     "point_ops.hip": ["-ffp-contract=off"] + os.environ.get("PCR_POINT_FLAGS", "").split(),
+    "edge_kernels.hip": ["-ffp-contract=off"],
 }
 
 

@@ -1,0 +1,85 @@
+"""DGCNN forward (reference: mmdet3d/models/dgcnn_orig.py:127-152) as libpcr_hip.so launches.  One EdgeConv layer =
+pcr_knn_feat_f32 (feature-space kNN on the matrix core + wave selection) -> 2 x pcr_dense_pm_f32 (per-point tables
+of the decomposed conv: s.W [f_j - f_i; f_i] = (s.W1) f_j + (s.(W2 - W1)) f_i) -> pcr_edge_max_f32 (gather, max over
+the k neighbours, BatchNorm shift, LeakyReLU).  The (B,2C,N,k) edge tensor of the reference is never built; the four
+layer outputs are written straight into their slices of the (B,512,N) conv5 input."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from . import engine as E
+
+
+class _Plan:
+    def __init__(self, net, device):
+        self.k = int(net.k)
+        self.layers = []
+        for conv in (net.conv1, net.conv2, net.conv3, net.conv4):
+            w = conv[0].weight.detach().double().reshape(conv[0].weight.shape[0], -1)     # (Co, 2C)
+            co, c2 = w.shape
+            c = c2 // 2
+            sc, sh = E.fold_bn(conv[1], None, device)
+            s = sc.double().cpu().unsqueeze(1)
+            w1, w2 = w[:, :c].cpu(), w[:, c:].cpu()
+            wa = E.pack_weight((s * w1).float(), device)
+            wb = E.pack_weight((s * (w2 - w1)).float(), device)
+            self.layers.append((c, co, wa, wb, sh))
+        sc5, sh5 = E.fold_bn(net.conv5[1], None, device)
+        self.w5 = E.pack_weight(net.conv5[0].weight, device)
+        self.c5 = net.conv5[0].weight.shape[0]
+        self.sc5, self.sh5 = sc5, sh5
+        self.cat = sum(l[1] for l in self.layers)
+
+
+def knn_feat(x, k, bstride=0):
+    """x (B,C,N) fp32 device tensor (or a channel slice with batch stride `bstride` floats) -> idx (B,N,k) int32"""
+    L.require_cuda(x)
+    B, C, N = x.shape
+    xx = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    idx = torch.empty((B, N, k), dtype=torch.int32, device=x.device)
+    with E._prof("knn_feat[C=%d,N=%d]" % (C, N), 2.0 * B * N * N * C, 4.0 * B * N * (C + k)):
+        L.check(L.load().pcr_knn_feat_f32(L.ptr(x), L.ptr(xx), L.ptr(idx), B, C, N, k, ctypes.c_long(bstride),
+                                          L.stream_ptr()), "pcr_knn_feat_f32")
+    return idx
+
+
+def _table(x, wp, co):
+    B, cin, N = x.shape
+    y = torch.empty((B, N, co), dtype=torch.float32, device=x.device)
+    with E._prof("edge_tables", 2.0 * B * N * cin * co, 4.0 * B * N * (cin + co)):
+        L.check(L.load().pcr_dense_pm_f32(L.ptr(x), L.ptr(wp), L.ptr(y), B, cin, co, N, 0, L.stream_ptr()),
+                "pcr_dense_pm_f32")
+    return y
+
+
+def forward(net, xyz):
+    """xyz (B,3,N) -> (xyz, per-point features (B,emb_dims,N)); eval mode only"""
+    L.require_cuda(xyz)
+    if net.training:
+        raise L.PcrError("DGCNN: the HIP path implements eval-mode inference; call .eval()")
+    key = (str(xyz.device), E.param_version(net))
+    if getattr(net, "_pcr_key", None) != key:
+        object.__setattr__(net, "_pcr_plan", _Plan(net, xyz.device))
+        object.__setattr__(net, "_pcr_key", key)
+    p = net._pcr_plan
+    x = xyz.contiguous().float()
+    B, _, N = x.shape
+    if p.k > N:
+        raise L.PcrError("DGCNN: k=%d neighbours need at least that many points (N=%d)" % (p.k, N))
+    cat = torch.empty((B, p.cat, N), dtype=torch.float32, device=x.device)
+    lib = L.load()
+    off = 0
+    f = x
+    for c, co, wa, wb, sh in p.layers:
+        idx = knn_feat(f, p.k)
+        ta, tb = _table(f, wa, co), _table(f, wb, co)
+        out = torch.empty((B, co, N), dtype=torch.float32, device=x.device)
+        with E._prof("edge_max", 0.0, 4.0 * B * N * (co * (p.k + 3) + p.k)):
+            L.check(lib.pcr_edge_max_f32(L.ptr(ta), L.ptr(tb), L.ptr(idx), L.ptr(sh), ctypes.c_float(0.2),
+                                         L.ptr(out), ctypes.c_long(0), L.ptr(cat[:, off:off + co]),
+                                         ctypes.c_long(p.cat * N), B, N, co, p.k, L.stream_ptr()), "pcr_edge_max_f32")
+        off += co
+        f = out
+    y = E.dense(cat, p.w5, p.c5, p.sc5, p.sh5, act=2)
+    return xyz, y

@@ -50,6 +50,24 @@ def test_pointnet_oracle_matches_reference_golden():
     assert np.abs(logits.numpy() - g["logits"]).max() < TOL
 
 
+@pytest.mark.parametrize("knn", ["pinned_order", "reference_formula"])
+def test_dgcnn_oracle_matches_reference_golden(knn):
+    """DGCNN: the reference's matmul-based kNN leaves the summation order to the BLAS; the oracle pins one order
+    (oracle/pcr_oracle.c:pcr_oracle_knn_feat).  On this fixture both give the reference's neighbour sets exactly."""
+    g = load_golden("dgcnn_n256_randn")
+    m = g["meta"]
+    s1, s2 = T.synthetic_pairs(m["pairs"], m["n"], m["input_seed"], m["kind"])
+    st = {}
+    with torch.no_grad():
+        logits = MO.dgcnn_pairs(_sd("dgcnn"), s1, s2, k=m["k"], stages=st,
+                                knn_fn=MO.knn_feat_torch if knn == "reference_formula" else None)
+    for i in (1, 2, 3, 4):
+        assert (np.sort(st["knn%d" % i].numpy(), -1) == np.sort(g["knn%d" % i].astype(np.int64), -1)).all(), i
+    for k in ("h1", "h2", "enc_max", "enc_mean"):
+        assert np.abs(st[k].numpy() - g[k]).max() < 5e-5, k
+    assert np.abs(logits.numpy() - g["logits"]).max() < TOL
+
+
 def test_eval_metric_fixture():
     """pcr_amd.metrics against values recorded from the reference's own MatchingEval / accuracy definition"""
     from pcr_amd import metrics
