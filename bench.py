@@ -47,6 +47,10 @@ WORKLOADS = {
                 "-> Conv1d 64; D-FPS + ball query), 1024-pt synthetic pairs, eval", "ssg", 1024, None, 2048),
     "pointnet256": ("PointNet ReIDNet (configs_reid/_base_/reidentifiers/reid_pts_pointnet_point-cat.py), 256-pt "
                     "synthetic pairs, eval (BASELINE config 1 shape)", "pointnet", 256, None, 256),
+    "dgcnn256": ("DGCNN ReIDNet (configs_reid/_base_/reidentifiers/reid_pts_dgcnn_point-cat.py, k=20, emb 1024), "
+                 "256-pt synthetic pairs, eval", "dgcnn", 256, None, 512),
+    "dgcnn1024": ("DGCNN ReIDNet (reid_waymo_pts/num_point_ablation_test/pts_dgcnn_r_waymo_det_400e_1024pts.py), "
+                  "1024-pt synthetic pairs, eval", "dgcnn", 1024, None, 128),
     "pt4096": ("Point-Transformer ReIDNet, 4096-pt Waymo-shape synthetic pairs, eval", "pt", 4096,
                [4096, 2048, 1024], 256),
 }
@@ -79,6 +83,12 @@ PN_MODEL.update(use_dgcnn=True, backbone=dict(type="PointNet", k=40, normal_chan
                             dict(type="Linear", in_features=128, out_features=64)])
 
 
+DG_MODEL = copy.deepcopy(PN_MODEL)
+DG_MODEL.update(backbone=dict(type="dgcnn", dropout=0.5, emb_dims=1024, k=20, output_channels=40))
+DG_MODEL["match_head"] = [dict(type="LinearRes", n_in=128, n_out=128, norm="GN", ng=16),
+                          dict(type="Linear", in_features=128, out_features=1)]
+
+
 def build_model(kind, backbone_list, device="cuda"):
     """kind 'pt' (reference Point-Transformer config), 'pointnet' (reference PointNet config) or 'ssg'
     (BASELINE config 2 composition); seeded weights"""
@@ -86,7 +96,7 @@ def build_model(kind, backbone_list, device="cuda"):
         return build_pt_model(backbone_list, device)
     from mmdet3d.models import build_model as _build
     from pcr_amd import testing as T
-    model = _build(copy.deepcopy(SSG_MODEL if kind == "ssg" else PN_MODEL))
+    model = _build(copy.deepcopy({"ssg": SSG_MODEL, "dgcnn": DG_MODEL}.get(kind, PN_MODEL)))
     sd = T.seeded_state_dict(T.manifest_of(model), 0)
     model.load_state_dict(sd, strict=True)
     return model.to(device).eval(), sd
@@ -135,7 +145,7 @@ def cpu_baseline(workload, sd, budget_s=20.0):
     pairs = 8 if n >= 1024 else 32
     s1, s2 = T.synthetic_pairs(pairs, n, seed=1234, kind="box" if kind == "ssg" else "randn")
     run = {"ssg": lambda: MO.ssg_pairs(sd, s1, s2), "pointnet": lambda: MO.pointnet_pairs(sd, s1, s2),
-           "pt": lambda: MO.pt_pairs(sd, s1, s2, bl)}[kind]
+           "pt": lambda: MO.pt_pairs(sd, s1, s2, bl), "dgcnn": lambda: MO.dgcnn_pairs(sd, s1, s2)}[kind]
     best, best_threads, runs = None, 1, 0
     t_start = time.time()
     # torch's intra-op pool does not scale to hundreds of threads on these small per-cloud ops:
@@ -214,7 +224,7 @@ def main():
                     share_of_step=ms / step_ms_kern,
                     per_kernel_ms={k: round(v, 4) for k, v in sorted(groups.items(), key=lambda kv: -kv[1])})
         roof["frac"] = roof["achieved"] / roof["peak"]
-        if dom.split("[")[0] in ("knn_prefix", "fps", "ball_query", "pool_head", "gather"):
+        if dom.split("[")[0] in ("knn_prefix", "fps", "ball_query", "pool_head", "gather", "edge_max"):
             # neighbour search / sampling / pooling launches move bytes, they do not multiply: price them against
             # HBM with their ALGORITHMIC bytes (read xyz, write indices) -- their real limiter today is
             # instruction issue, which this fraction makes plain

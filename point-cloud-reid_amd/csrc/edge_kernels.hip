@@ -21,7 +21,9 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kEdgeThreads = 256;
-constexpr int kSelCap = 256;   // candidates per query the fast ranking path takes (4 per lane)
+constexpr int kKnnThreads = 512;   // 8 waves: at N = 1024 the key tile leaves room for ONE workgroup per CU
+constexpr int kSelCap = 128;       // candidates per query the fast ranking path takes (2 per lane)
+constexpr int kKB = 16;            // B-operand values (k-blocks) fetched per batch, one batch ahead of the MFMAs
 
 // xx[b][i] = ((x0^2 + x1^2) + x2^2) + ...  (separately rounded squares, channel order)
 __global__ __launch_bounds__(256) void feat_sqnorm_kernel(const float *__restrict__ x, float *__restrict__ xx, int C,
@@ -132,11 +134,12 @@ __device__ __forceinline__ void select_k(uint32_t (&d)[T], int lane, int K, unsi
 // Workgroup = QT queries (rows of a 32-row MFMA tile; QT = 16 wastes half of it but halves the key tile so that
 // N = 2048 fits in LDS) x all N points.  LDS: sA [C2*2][32] query operands | sxq [32] | keys [QT][NP] | cand.
 template <int T>   // NP = 64 T >= N
-__global__ __launch_bounds__(kEdgeThreads) void knn_feat_kernel(const float *__restrict__ x,
-                                                                 const float *__restrict__ xx,
-                                                                 int *__restrict__ idx, int C, int N, int K, int QT,
-                                                                 long bstride) {
+__global__ __launch_bounds__(kKnnThreads) void knn_feat_kernel(const float *__restrict__ x,
+                                                                const float *__restrict__ xx,
+                                                                int *__restrict__ idx, int C, int N, int K, int QT,
+                                                                long bstride) {
   constexpr int NP = 64 * T;
+  constexpr int NW = kKnnThreads / 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int C2 = (C + 1) >> 1;
   float *sA = smem;                         // [2*C2][32]
@@ -148,60 +151,74 @@ __global__ __launch_bounds__(kEdgeThreads) void knn_feat_kernel(const float *__r
   const float *f = x + b * bstride;
   const float *xxb = xx + b * N;
   const int q0 = blockIdx.x * QT;
-  for (int e = tid; e < 2 * C2 * 32; e += kEdgeThreads) {
+  for (int e = tid; e < 2 * C2 * 32; e += kKnnThreads) {
     const int c = e >> 5, r = e & 31;
     const int q = q0 + r < N ? q0 + r : N - 1;
     sA[e] = c < C ? f[(size_t)c * N + q] : 0.f;
   }
   if (tid < 32) sxq[tid] = xxb[q0 + tid < N ? q0 + tid : N - 1];
-  __syncthreads();
   const int nblk = (N + 31) >> 5;
-  for (int jb = wave; jb < nblk; jb += kEdgeThreads / 64) {
-    const int j = jb * 32 + l31;
-    const int jc = j < N ? j : N - 1;
-    const float *bp = f + jc;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = 0.f;
-    int kk = 0;
-    for (; kk + 8 <= C2; kk += 8) {   // 8 loads in flight, then 8 MFMAs (all channels < C except maybe the last)
-      float bv[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int c = 2 * (kk + u) + h;
-        const int cc = c < C ? c : C - 1;
-        const float v = bp[(size_t)cc * N];
-        bv[u] = c < C ? v : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[(2 * (kk + u) + h) * 32 + l31], bv[u], acc, 0, 0, 0);
-    }
-    for (; kk < C2; kk++) {
-      const int c = 2 * kk + h;
-      const int cc = c < C ? c : C - 1;
-      const float v = bp[(size_t)cc * N];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[c * 32 + l31], c < C ? v : 0.f, acc, 0, 0, 0);
-    }
-    const float xj = xxb[jc];
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (row < QT) {
-        const float t2 = 2.f * acc[r] - sxq[row];
-        const float pd = t2 - xj;
-        keys[(size_t)row * NP + j] = j < N ? desc_key(pd) : 0xFFFFFFFFu;
-      }
-    }
-  }
-  // columns [nblk*32, NP) were not touched by the loop
-  for (int e = tid; e < QT * (NP - nblk * 32); e += kEdgeThreads) {
+  // columns [nblk*32, NP) are not touched by the MFMA loop
+  for (int e = tid; e < QT * (NP - nblk * 32); e += kKnnThreads) {
     const int w = NP - nblk * 32;
     const int row = e / w, col = nblk * 32 + e - row * w;
     keys[(size_t)row * NP + col] = 0xFFFFFFFFu;
   }
   __syncthreads();
-  for (int row = wave; row < QT; row += kEdgeThreads / 64) {
+  // One flat sequence of batches (column block jb, k-blocks [kk, kk + kKB)): the B values of batch i+1 are
+  // requested before the MFMAs of batch i, across column-block boundaries too.
+  auto fetch = [&](float (&v)[kKB], int jb, int kk) {
+    const int j = jb * 32 + l31;
+    const float *bp = f + (j < N ? j : N - 1);
+#pragma unroll
+    for (int u = 0; u < kKB; u++) {
+      const int c = 2 * (kk + u) + h;
+      const int cc = c < C ? c : C - 1;
+      const float t = bp[(size_t)cc * N];
+      v[u] = c < C ? t : 0.f;
+    }
+  };
+  float cur[kKB], nxt[kKB];
+  int jb = wave, kk = 0;
+  if (jb < nblk) fetch(cur, jb, 0);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] = 0.f;
+  while (jb < nblk) {
+    int njb = jb, nkk = kk + kKB;
+    if (nkk >= C2) { njb = jb + NW; nkk = 0; }
+    if (njb < nblk) fetch(nxt, njb, nkk);
+    const int lim = C2 - kk < kKB ? C2 - kk : kKB;
+    const float *ap = sA + (2 * kk + h) * 32 + l31;
+    if (lim == kKB) {
+#pragma unroll
+      for (int u = 0; u < kKB; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[u * 64], cur[u], acc, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int u = 0; u < kKB; u++)
+        if (u < lim) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[u * 64], cur[u], acc, 0, 0, 0);
+    }
+    if (nkk == 0) {   // last batch of column block jb: keys out, accumulator reset
+      const int j = jb * 32 + l31;
+      const float xj = xxb[j < N ? j : N - 1];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < QT) {
+          const float t2 = 2.f * acc[r] - sxq[row];
+          const float pd = t2 - xj;
+          keys[(size_t)row * NP + j] = j < N ? desc_key(pd) : 0xFFFFFFFFu;
+        }
+        acc[r] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kKB; u++) cur[u] = nxt[u];
+    jb = njb;
+    kk = nkk;
+  }
+  __syncthreads();
+  for (int row = wave; row < QT; row += NW) {
     const int q = q0 + row;
     if (q >= N) break;
     uint32_t d[T];
@@ -280,9 +297,9 @@ PCR_EXPORT int pcr_knn_feat_f32(const float *x, float *xx_ws, int *idx, int B, i
   const int T = N <= 64 ? 1 : N <= 128 ? 2 : N <= 256 ? 4 : N <= 512 ? 8 : N <= 1024 ? 16 : 32;
   const int QT = N <= 1024 ? 32 : 16;
   const int C2 = (C + 1) / 2;
-  const size_t lds = (size_t)(2 * C2 * 32 + 32) * 4 + (size_t)QT * 64 * T * 4 + (size_t)4 * kSelCap * 8;
+  const size_t lds = (size_t)(2 * C2 * 32 + 32) * 4 + (size_t)QT * 64 * T * 4 + (size_t)(kKnnThreads / 64) * kSelCap * 8;
   if (lds > 160 * 1024) return PCR_ERR_INVALID;
-  const dim3 g((N + QT - 1) / QT, B), blk(kEdgeThreads);
+  const dim3 g((N + QT - 1) / QT, B), blk(kKnnThreads);
 #define PCR_KNNF(TT)                                                                                              \
   do {                                                                                                            \
     static bool big = hipFuncSetAttribute(reinterpret_cast<const void *>(knn_feat_kernel<TT>),                    \
