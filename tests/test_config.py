@@ -51,6 +51,10 @@ def test_reference_configs_load_unchanged_and_build():
     cfg = Config.fromfile(os.path.join(REF, "reid_nuscenes_pts/testing_pts_pointnet_r_nus_det_500e.py"))
     model = build_model(cfg.model)
     assert T.manifest_of(model) == T.load_manifest(os.path.join(GOLDEN, "pointnet_manifest.json"))
+    cfg = Config.fromfile(os.path.join(REF, "reid_waymo_pts/testing_pts_dgcnn_r_waymo_det_400e.py"))
+    assert cfg.model.backbone.type == "dgcnn" and cfg.model.use_dgcnn is True
+    model = build_model(cfg.model)
+    assert T.manifest_of(model) == T.load_manifest(os.path.join(GOLDEN, "dgcnn_manifest.json"))
     # every point-cloud ReID config of the reference parses
     n, broken = 0, []
     for sub in ("reid_nuscenes_pts", "reid_waymo_pts"):
