@@ -247,6 +247,14 @@ int pcr_dense_f32(const float *x, const float *wp, const float *scale, const flo
 int pcr_dense_xpm_f32(const float *x, const float *wp, const float *scale, const float *shift, float *y,
                       int B, int cin, int cout, int L, int act, pcr_stream_t stream);
 
+/* Linear (no bias) -> GroupNorm [-> + res] [-> ReLU] in one launch: the three steps LinearRes repeats
+ * (lanegcn_nets.py:228-241) on channel-major token tensors, y (B,cout,L) = [relu](GN(W x) * gamma + beta [+ res]).
+ * GroupNorm is per token over groups of cout/groups consecutive channels (4, 8, 16 or 32 per group; anything else
+ * returns PCR_ERR_INVALID and the caller runs pcr_dense_f32 + pcr_groupnorm_f32), biased variance, eps 1e-5;
+ * res (optional) is (B,cout,L). */
+int pcr_dense_gn_f32(const float *x, const float *wp, const float *gamma, const float *beta, const float *res,
+                     float *y, int B, int cin, int cout, int L, int groups, int relu, pcr_stream_t stream);
+
 /* ---- PointNet encoder pieces (models/pointnet.py:10-127) and LinearRes rows (lanegcn_nets.py:228-241) ---- */
 
 /* (B,C,L) -> out (C,B) with out[c*B + b] = max over L: the global max pool of STN3d/STNkd

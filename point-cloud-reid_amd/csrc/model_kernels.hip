@@ -114,9 +114,39 @@ struct DenseArgs {
   int cin, cout, L, act;
   long w_bstride;
   int x_pm;   // x is (B,L,cin)
+  int gn_gs;  // GN kernels only: channels per GroupNorm group (4, 8, 16 or 32); scale / shift are gamma / beta
+  const float *res;   // GN kernels only: optional residual (B,cout,L) added after the normalisation
 };
 
-template <int TB>
+// GroupNorm of one 32-cout x 32-token accumulator tile over groups of GS consecutive channels of each token (nn.GroupNorm
+// on (M,C) rows, lanegcn_nets.py:228-241): a lane holds couts 8g + 4h + {0..3} (g = 0..3) of token l31, so a group of
+// 8 / 16 / 32 channels is 1 / 2 / 4 bands of this lane plus the same bands of lane ^ 32; groups of 4 are lane-local.
+// Two-pass mean / biased variance, eps 1e-5.  Every lane of the wave must call it (cross-lane exchange).
+template <int GS>
+__device__ __forceinline__ void gn_tile(const f32x16 &acc, float (&y)[16]) {
+  constexpr int NB = GS >= 8 ? GS / 8 : 1;
+  constexpr bool kCross = GS >= 8;
+#pragma unroll
+  for (int g0 = 0; g0 < 4; g0 += NB) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 4 * g0; i < 4 * (g0 + NB); i++) s += acc[i];
+    if (kCross) s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / (float)GS);
+    float v = 0.f;
+#pragma unroll
+    for (int i = 4 * g0; i < 4 * (g0 + NB); i++) {
+      const float d = acc[i] - mean;
+      v += d * d;
+    }
+    if (kCross) v += __shfl_xor(v, 32, 64);
+    const float inv = 1.0f / sqrtf(v * (1.0f / (float)GS) + 1e-5f);
+#pragma unroll
+    for (int i = 4 * g0; i < 4 * (g0 + NB); i++) y[i] = (acc[i] - mean) * inv;
+  }
+}
+
+template <int TB, bool GN = false>
 __global__ __launch_bounds__(kThreads) void dense_kernel(DenseArgs a) {
   constexpr int T = 32 * TB, RP = T + 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -144,6 +174,34 @@ __global__ __launch_bounds__(kThreads) void dense_kernel(DenseArgs a) {
   const float *wp = a.wp + b * a.w_bstride + (size_t)chunk0 * 8;
   tile_dense2<TB, 2, 0, true>(X, cinP, wp, chunkP, false, [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
     const int t = tb * 32 + l31;
+    if constexpr (GN) {
+      // y = act(GN(W x) * gamma + beta [+ res]): the Linear -> GroupNorm [-> + shortcut] [-> ReLU] steps of LinearRes
+      float nrm[16];
+      switch (a.gn_gs) {
+        case 4: gn_tile<4>(acc, nrm); break;
+        case 8: gn_tile<8>(acc, nrm); break;
+        case 16: gn_tile<16>(acc, nrm); break;
+        default: gn_tile<32>(acc, nrm); break;
+      }
+      if (t0 + t < L) {
+        const float *res = a.res ? a.res + b * a.cout * a.L : nullptr;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int o = cb * 32 + 8 * g + 4 * h;
+          const f32x4 s4 = *reinterpret_cast<const f32x4 *>(s_sc + o), b4 = *reinterpret_cast<const f32x4 *>(s_sh + o);
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int oc = chunk0 + o + q;
+            if (oc < cout) {
+              float r = nrm[4 * g + q] * s4[q] + b4[q];
+              if (res) r += res[(size_t)oc * L + t0 + t];
+              out[(size_t)oc * L + t0 + t] = act == 1 ? fmaxf(r, 0.f) : r;
+            }
+          }
+        }
+      }
+      return;
+    }
     if (t0 + t < L) {
 #pragma unroll
       for (int g = 0; g < 4; g++) {
@@ -269,22 +327,37 @@ PCR_EXPORT int pcr_pool_both_f32(const float *x, float *out, int B, int C, int L
 }
 
 static int dense_launch(const float *x, const float *wp, long w_bstride, const float *scale, const float *shift,
-                        float *y, int B, int cin, int cout, int L, int act, pcr_stream_t stream, int x_pm = 0) {
+                        float *y, int B, int cin, int cout, int L, int act, pcr_stream_t stream, int x_pm = 0,
+                        int gn_gs = 0, const float *res = nullptr) {
   if (!x || !wp || !y || B < 0 || cin < 1 || cout < 1 || L < 1) return PCR_ERR_INVALID;
   if (B == 0) return PCR_OK;
   if (B > 65535) return PCR_ERR_INVALID;
-  DenseArgs a{x, wp, scale, shift, y, cin, cout, L, act, w_bstride, x_pm};
+  DenseArgs a{x, wp, scale, shift, y, cin, cout, L, act, w_bstride, x_pm, gn_gs, res};
   const int cinP = ceil8(cin);
   const int tb = ((size_t)cinP * 65 * 4 <= 72 * 1024 && L > 32) ? 2 : 1;
   size_t lds = ((size_t)cinP * (32 * tb + 1) + 512) * sizeof(float);
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
-  static bool ok = allow_big_lds(dense_kernel<1>) && allow_big_lds(dense_kernel<2>);
+  static bool ok = allow_big_lds(dense_kernel<1, false>) && allow_big_lds(dense_kernel<2, false>);
   (void)ok;
   dim3 g((L + 32 * tb - 1) / (32 * tb), B, (ceil32(cout) + 255) / 256);
-  if (tb == 2) hipLaunchKernelGGL(dense_kernel<2>, g, dim3(kThreads), lds, pcr_s(stream), a);
-  else hipLaunchKernelGGL(dense_kernel<1>, g, dim3(kThreads), lds, pcr_s(stream), a);
+  if (gn_gs) {
+    static bool okg = allow_big_lds(dense_kernel<1, true>) && allow_big_lds(dense_kernel<2, true>);
+    (void)okg;
+    if (tb == 2) hipLaunchKernelGGL((dense_kernel<2, true>), g, dim3(kThreads), lds, pcr_s(stream), a);
+    else hipLaunchKernelGGL((dense_kernel<1, true>), g, dim3(kThreads), lds, pcr_s(stream), a);
+  } else if (tb == 2) hipLaunchKernelGGL((dense_kernel<2, false>), g, dim3(kThreads), lds, pcr_s(stream), a);
+  else hipLaunchKernelGGL((dense_kernel<1, false>), g, dim3(kThreads), lds, pcr_s(stream), a);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
+}
+
+PCR_EXPORT int pcr_dense_gn_f32(const float *x, const float *wp, const float *gamma, const float *beta,
+                                const float *res, float *y, int B, int cin, int cout, int L, int groups, int relu,
+                                pcr_stream_t stream) {
+  if (!gamma || !beta || groups < 1 || cout % groups) return PCR_ERR_INVALID;
+  const int gs = cout / groups;
+  if (gs != 4 && gs != 8 && gs != 16 && gs != 32) return PCR_ERR_INVALID;
+  return dense_launch(x, wp, 0, gamma, beta, y, B, cin, cout, L, relu ? 1 : 0, stream, 0, gs, res);
 }
 
 PCR_EXPORT int pcr_dense_f32(const float *x, const float *wp, const float *scale, const float *shift,

@@ -47,16 +47,32 @@ def _linres_plan(m, device):
     return m._pcr_plan
 
 
+def dense_gn(x, wp, cout, gn, res=None, relu=False):
+    """[relu](GroupNorm(W x) [+ res]) on a channel-major tensor: one launch (pcr_dense_gn_f32) when the group size is
+    4 / 8 / 16 / 32 channels, pcr_dense_f32 + pcr_groupnorm_f32 otherwise"""
+    L.require_cuda(x)
+    if cout // gn.num_groups not in (4, 8, 16, 32) or gn.eps != 1e-5:
+        return groupnorm(_E.dense(x, wp, cout), gn, res=res, relu=relu)
+    x = x.contiguous()
+    B, cin, Ln = x.shape
+    y = torch.empty((B, cout, Ln), dtype=torch.float32, device=x.device)
+    g = gn.weight.detach().to(x.device).float().contiguous()
+    b = gn.bias.detach().to(x.device).float().contiguous()
+    if res is not None:
+        res = res.contiguous()
+    with _E._prof("dense_gn[cin=%d,cout=%d,L=%d]" % (cin, cout, Ln), 2.0 * B * Ln * cin * cout,
+                  4.0 * B * Ln * (cin + cout * (2 if res is not None else 1))):
+        L.check(L.load().pcr_dense_gn_f32(L.ptr(x), L.ptr(wp), L.ptr(g), L.ptr(b), L.ptr(res), L.ptr(y), B, cin, cout,
+                                          Ln, gn.num_groups, 1 if relu else 0, L.stream_ptr()), "pcr_dense_gn_f32")
+    return y
+
+
 def linear_res_cm(m, x):
     """LinearRes on a channel-major tensor x (B,n_in,L) -> (B,n_out,L) (lanegcn_nets.py:228-241)"""
     p = _linres_plan(m, x.device)
-    out = groupnorm(_E.dense(x, p.w1, p.n_out), m.norm1, relu=True)
-    out = _E.dense(out, p.w2, p.n_out)
-    if p.wt is not None:
-        short = groupnorm(_E.dense(x, p.wt, p.n_out), m.transform[1])
-    else:
-        short = x
-    return groupnorm(out, m.norm2, res=short, relu=True)
+    out = dense_gn(x, p.w1, p.n_out, m.norm1, relu=True)
+    short = dense_gn(x, p.wt, p.n_out, m.transform[1]) if p.wt is not None else x
+    return dense_gn(out, p.w2, p.n_out, m.norm2, res=short, relu=True)
 
 
 def linear_res(m, x):
