@@ -47,6 +47,8 @@ WORKLOADS = {
                 "-> Conv1d 64; D-FPS + ball query), 1024-pt synthetic pairs, eval", "ssg", 1024, None, 2048),
     "pointnet256": ("PointNet ReIDNet (configs_reid/_base_/reidentifiers/reid_pts_pointnet_point-cat.py), 256-pt "
                     "synthetic pairs, eval (BASELINE config 1 shape)", "pointnet", 256, None, 256),
+    "dgcnn128": ("DGCNN ReIDNet (reid_waymo_pts/testing_pts_dgcnn_r_waymo_det_400e.py: 128-pt crops, 512 pairs per "
+                 "GPU), synthetic pairs, eval", "dgcnn", 128, None, 512),
     "dgcnn256": ("DGCNN ReIDNet (configs_reid/_base_/reidentifiers/reid_pts_dgcnn_point-cat.py, k=20, emb 1024), "
                  "256-pt synthetic pairs, eval", "dgcnn", 256, None, 512),
     "dgcnn1024": ("DGCNN ReIDNet (reid_waymo_pts/num_point_ablation_test/pts_dgcnn_r_waymo_det_400e_1024pts.py), "

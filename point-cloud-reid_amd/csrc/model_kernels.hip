@@ -1,4 +1,6 @@
 // Pooling + match head, generic dense layer, host-side weight packing.
+#include <stdlib.h>
+
 #include "tile_dense.h"
 
 namespace {
@@ -146,11 +148,17 @@ __device__ __forceinline__ void gn_tile(const f32x16 &acc, float (&y)[16]) {
   }
 }
 
-template <int TB, bool GN = false>
+// CH (chunked contraction, cin and cout multiples of 256): only kChunk input channels of the token tile sit in LDS at
+// a time and the accumulators are carried across chunks, so a 1024-channel layer keeps a 64-token tile in 67 KB (two
+// workgroups per CU) where the whole-extent form needs 135 KB for 32 tokens -- and every weight byte streamed from L2
+// now feeds twice the tokens (at 32 tokens per tile the 1024 -> 512 layers asked L2 for ~10 TB/s of weights).
+constexpr int kChunk = 256;
+
+template <int TB, bool GN = false, bool CH = false>
 __global__ __launch_bounds__(kThreads) void dense_kernel(DenseArgs a) {
   constexpr int T = 32 * TB, RP = T + 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int cinP = ceil8(a.cin), coutP = ceil32(a.cout);
+  const int cinP = CH ? kChunk : ceil8(a.cin), coutP = ceil32(a.cout);
   float *X = smem;
   float *s_sc = X + cinP * RP;   // [256] scale and [256] shift of this workgroup's cout chunk (1 / 0 when absent)
   float *s_sh = s_sc + 256;
@@ -163,16 +171,18 @@ __global__ __launch_bounds__(kThreads) void dense_kernel(DenseArgs a) {
     s_sc[threadIdx.x] = (a.scale && oc < a.cout) ? a.scale[oc] : 1.0f;
     s_sh[threadIdx.x] = (a.shift && oc < a.cout) ? a.shift[oc] : 0.0f;
   }
-  if (a.x_pm) load_tile_pm(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
-  else load_tile(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
-  __syncthreads();
+  if constexpr (!CH) {
+    if (a.x_pm) load_tile_pm(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
+    else load_tile(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
+    __syncthreads();
+  }
   const int cout = a.cout, act = a.act, L = a.L;
   float *out = a.y + b * a.cout * a.L;
   // packed image rows [chunk0, chunk0+chunkP) of every k-block: offset chunk0*8 floats, stride coutP.
   // Pipelined dense tile (weights through a register ring, B operands one k-block ahead); the epilogue takes a
   // whole 32x32 tile: the lane's 16 couts are four runs of four, so scale / shift are eight 16-byte LDS reads.
   const float *wp = a.wp + b * a.w_bstride + (size_t)chunk0 * 8;
-  tile_dense2<TB, 2, 0, true>(X, cinP, wp, chunkP, false, [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
+  auto epi = [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
     const int t = tb * 32 + l31;
     if constexpr (GN) {
       // y = act(GN(W x) * gamma + beta [+ res]): the Linear -> GroupNorm [-> + shortcut] [-> ReLU] steps of LinearRes
@@ -217,7 +227,35 @@ __global__ __launch_bounds__(kThreads) void dense_kernel(DenseArgs a) {
         }
       }
     }
-  }, nullptr, nullptr, DenseNoHook(), coutP);
+  };
+  if constexpr (CH) {
+    // chunkP == 256: eight cout blocks, two rounds per wave; accumulators carried over the cin chunks
+    f32x16 carry[2][TB];
+#pragma unroll
+    for (int nr = 0; nr < 2; nr++)
+#pragma unroll
+      for (int j = 0; j < TB; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) carry[nr][j][r] = 0.f;
+    const float *xb = a.x + b * a.cin * a.L;
+    const int nch = a.cin / kChunk;
+    const size_t wchunk = (size_t)(kChunk / 8) * coutP * 8;   // floats of kChunk input channels in the packed image
+    const DenseNoHook nh;
+    for (int c = 0; c < nch; c++) {
+      if (c) __syncthreads();   // everyone is done with the previous chunk's operands
+      load_tile(X, RP, xb + (size_t)c * kChunk * a.L, kChunk, kChunk, a.L, t0, T);
+      __syncthreads();
+      tile_dense_impl<TB, 2, 1, true, decltype(epi), PCR_PF, DenseNoHook, false, true, true>(
+          X, kChunk, wp + c * wchunk, 256, false, epi, nullptr, nullptr, nh, coutP, carry);
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+#pragma unroll
+    for (int nr = 0; nr < 2; nr++)
+#pragma unroll
+      for (int j = 0; j < TB; j++) epi(carry[nr][j], wave + 4 * nr, j, lane & 31, lane >> 5);
+  } else {
+    tile_dense2<TB, 2, 0, true>(X, cinP, wp, chunkP, false, epi, nullptr, nullptr, DenseNoHook(), coutP);
+  }
 }
 
 // (B,C,L) -> out[c * B + b] = max over L   (channel-major with the clouds as tokens: (1,C,B))
@@ -334,6 +372,17 @@ static int dense_launch(const float *x, const float *wp, long w_bstride, const f
   if (B > 65535) return PCR_ERR_INVALID;
   DenseArgs a{x, wp, scale, shift, y, cin, cout, L, act, w_bstride, x_pm, gn_gs, res};
   const int cinP = ceil8(cin);
+  if (cin >= 2 * kChunk && cin % kChunk == 0 && cout % 256 == 0 && !x_pm && !w_bstride && L > 32 &&
+      !getenv("PCR_DENSE_NO_CHUNK")) {
+    const size_t ldsc = ((size_t)kChunk * 65 + 512) * sizeof(float);
+    static bool okc = allow_big_lds(dense_kernel<2, true, true>) && allow_big_lds(dense_kernel<2, false, true>);
+    (void)okc;
+    const dim3 gc((L + 63) / 64, B, cout / 256);
+    if (gn_gs) hipLaunchKernelGGL((dense_kernel<2, true, true>), gc, dim3(kThreads), ldsc, pcr_s(stream), a);
+    else hipLaunchKernelGGL((dense_kernel<2, false, true>), gc, dim3(kThreads), ldsc, pcr_s(stream), a);
+    PCR_CHECK_LAUNCH();
+    return PCR_OK;
+  }
   const int tb = ((size_t)cinP * 65 * 4 <= 72 * 1024 && L > 32) ? 2 : 1;
   size_t lds = ((size_t)cinP * (32 * tb + 1) + 512) * sizeof(float);
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;

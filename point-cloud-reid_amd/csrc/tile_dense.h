@@ -107,14 +107,17 @@ __device__ __forceinline__ void tile_dense_ring_load(const float *__restrict__ w
 // the k-loop and the epilogue (before the sync_epi barrier): the place to request the next call's ring.
 // RES (resident weights): `ring` holds ALL k-blocks of the call (KB <= PF, narrow layers): no weight load inside
 // the call at all -- a caller that runs the same layer on many tiles fetches the ring once.
+// CIN / COUT (split contraction): the accumulators come from / go back to `carry` instead of the seeds / the
+// epilogue, so a caller can walk a long cin extent chunk by chunk through a small LDS buffer.
 template <int TB, int NR, int WAYS, bool TILE, class Epi, int PF = PCR_PF, class AfterK = DenseNoHook,
-          bool RES = false>
+          bool RES = false, bool CIN = false, bool COUT = false>
 // PF must be even (the B-operand double buffer alternates per k-block)
 __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, int CP,
                                                 const float *__restrict__ wp, int OP, bool sync_epi,
                                                 Epi epi, const float *__restrict__ init = nullptr,
                                                 f32x4 (*ring)[NR] = nullptr, AfterK after_k = AfterK(),
-                                                int opfull = 0) {
+                                                int opfull = 0,
+                                                f32x16 (*carry)[(TB + WAYS - 1) / WAYS] = nullptr) {
   constexpr int RP = 32 * TB + 1;
   constexpr int TBW = (TB + WAYS - 1) / WAYS;  // token blocks per wave
   const int lane = threadIdx.x & 63;
@@ -163,7 +166,10 @@ __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, in
   for (int nr = 0; nr < NR; nr++) {
     int cbi = cb0 + 4 * nr;
     cbi = cbi < nCB ? cbi : nCB - 1;
-    if (init != nullptr) {
+    if constexpr (CIN) {
+#pragma unroll
+      for (int j = 0; j < TBW; j++) acc[nr][j] = carry[nr][j];
+    } else if (init != nullptr) {
       const f32x4 *ip = reinterpret_cast<const f32x4 *>(init + cbi * 32 + 4 * h);
 #pragma unroll
       for (int g = 0; g < 4; g++) {
@@ -256,6 +262,13 @@ __device__ __forceinline__ void tile_dense_impl(const float *__restrict__ in, in
         load_x(xb[(i + 1) & 1], kx);
         mma(aw[i], xb[i & 1]);
       }
+  }
+  if constexpr (COUT) {
+#pragma unroll
+    for (int nr = 0; nr < NR; nr++)
+#pragma unroll
+      for (int j = 0; j < TBW; j++) carry[nr][j] = acc[nr][j];
+    return;
   }
   after_k();
   if (sync_epi) __syncthreads();
