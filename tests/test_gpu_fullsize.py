@@ -20,7 +20,8 @@ def _logits(model, s1, s2):
         return bench.hot_path(model, s1, s2)
 
 
-@pytest.mark.parametrize("workload,pairs,group", [("ssg1024", 2048, 64), ("pt1024", 512, 32), ("pointnet256", 256, 16)])
+@pytest.mark.parametrize("workload,pairs,group", [("ssg1024", 2048, 64), ("pt1024", 512, 32), ("pointnet256", 256, 16),
+                                                  ("dgcnn128", 512, 32), ("dgcnn1024", 128, 8)])
 def test_bench_batch_equals_small_groups(workload, pairs, group):
     desc, kind, n, bl, _ = bench.WORKLOADS[workload]
     model, _ = bench.build_model(kind, bl)
@@ -49,3 +50,25 @@ def test_ragged_equals_k_row_at_bench_size():
         m.skip_repeats = False
     b = _logits(model, s1, s2)
     assert torch.equal(a, b)
+
+
+def test_dgcnn_knn_properties_at_bench_size():
+    """feature-space kNN at the bench shape (1024 clouds x 256 pts x 64 ch): every row starts with the query itself
+    (distance 0 is the largest pd unless an exact duplicate with a lower index exists -- none in randn features), has
+    k distinct members, and its pd values, recomputed in float64, are non-increasing up to fp32 rounding and all
+    above every non-member's."""
+    from pcr_amd import dgcnn_engine as DE
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(1024, 64, 256, generator=g).cuda()
+    idx = DE.knn_feat(x, 20).long()
+    assert bool((idx[:, :, 0] == torch.arange(256, device="cuda")[None, :]).all())
+    srt = idx.sort(dim=-1)[0]
+    assert bool((srt[:, :, 1:] != srt[:, :, :-1]).all())
+    xd = x[:64].double()
+    pd = 2 * xd.transpose(1, 2) @ xd - (xd * xd).sum(1)[:, :, None] - (xd * xd).sum(1)[:, None, :]
+    sel = torch.gather(pd, 2, idx[:64])
+    assert bool((sel[:, :, 1:] <= sel[:, :, :-1] + 1e-3).all())
+    mask = torch.ones_like(pd, dtype=torch.bool).scatter_(2, idx[:64], False)
+    worst_in = sel.min(dim=-1)[0]
+    best_out = pd.masked_fill(~mask, -1e30).max(dim=-1)[0]
+    assert bool((best_out <= worst_in + 1e-3).all())
