@@ -296,6 +296,14 @@ int pcr_edge_max_f32(const float *ta, const float *tb, const int *idx, const flo
                      long out_bstride, float *out2, long out2_bstride, int B, int N, int Co, int K,
                      pcr_stream_t stream);
 
+/* The attention step of local_self_attention (models/attention.py:262-289): every point is ONE query token over its
+ * K feature-space neighbours.  qkv (B,N,3C) point-major rows [q | k | v] = the three projections of
+ * feat + pos_mlp(xyz) (built with pcr_dense_pm_f32), idx (B,N,K) from pcr_knn_feat_f32 ->
+ * msg (B,C,N) channel-major, msg_i = sum_j a_ij v_j / (sum_j a_ij + eps), a_ij = <elu(q_i)+1, elu(k_j)+1> per head
+ * (identical to the reference's LinearAttention with L = 1, S = K).  C <= 64, C / nhead a power of two. */
+int pcr_local_attn_f32(const float *qkv, const int *idx, float *msg, int B, int N, int C, int K, int nhead, float eps,
+                       pcr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -179,6 +179,44 @@ def gen_dgcnn():
     print("dgcnn", rec["logits"])
 
 
+LOCAL = dict(type="local_self_attention", d_model=64, nhead=2, attention="linear", knum=48, pos_size=64)
+
+
+def gen_xcorr():
+    """Point-Transformer with the 'baseline-orig' matching (cross -> local_self_attention -> cross -> local;
+    configs_reid/_base_/reidentifiers/reid_pts_point-transformer_baseline_orig.py), 4 pairs of 128 points"""
+    ref = ref_loader.load_reference()
+    ref.attention.torch = _CpuTorch()        # attention.get_graph_feature hard-codes torch.device('cuda') (:114)
+    model, manifest = build(PT_CFG, seed=0, match_type="xcorr", local_stage1=dict(LOCAL), local_stage2=dict(LOCAL),
+                            backbone_list=[128, 64, 32])
+    s1, s2 = T.synthetic_pairs(4, 128, seed=1, kind="randn")
+    knns = []
+    orig_knn = ref.attention.knn
+
+    def spy(x, k):
+        idx = orig_knn(x, k)
+        knns.append(_np(idx).astype(np.int16))
+        return idx
+
+    ref.attention.knn = spy
+    try:
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            xyz1, xyz2, h1, h2 = model.siamese_forward(s1, s2)
+            a = model.cross_stage1(h1, xyz1, h2, xyz2)
+            b = model.local_stage1(a, xyz1)
+            knn_b = knns[-1]
+            logits = model.match_forward_inference(h1, h2, xyz1, xyz2)
+    finally:
+        ref.attention.knn = orig_knn
+    rec = dict(h1=_np(h1), h2=_np(h2), xc_a=_np(a), xc_b=_np(b), knn_local1=knn_b, logits=_np(logits),
+               meta=np.array(json.dumps(dict(pairs=4, n=128, kind="randn", input_seed=1, weight_seed=0, knum=48,
+                                             backbone_list=[128, 64, 32]))))
+    np.savez_compressed(os.path.join(GOLD, "pt_xcorr_n128_randn.npz"), **rec)
+    with open(os.path.join(GOLD, "pt_xcorr_manifest.json"), "w") as f:
+        json.dump(manifest, f)
+    print("xcorr", rec["logits"])
+
+
 def gen_train_step():
     """reference train_step loss + a few gradients (training rows are 'next')."""
     ref_loader.load_reference()
@@ -253,11 +291,15 @@ if __name__ == "__main__":
     if "--only-metric" in sys.argv:
         gen_eval_metric()
         sys.exit(0)
+    if "--only-xcorr" in sys.argv:
+        gen_xcorr()
+        sys.exit(0)
     if "--only-dgcnn" in sys.argv:
         gen_dgcnn()
         sys.exit(0)
     if "--only-small" not in sys.argv:
         gen_dgcnn()
+        gen_xcorr()
         gen_pt()
         gen_pointnet()
     gen_train_step()

@@ -105,6 +105,53 @@ def cross_attention(p, search, search_xyz, template, template_xyz, nhead=2):
     return attention_block(p, s, t, tp, s, nhead, True).permute(0, 2, 1)
 
 
+def local_self_attention(p, feat, xyz, nhead=2, knum=48, knn_fn=None):
+    """attention.py:262-296: every point attends (linear attention, one query token) to its knum feature-space
+    neighbours; parameter names carry the reference's `_knn` suffix.  feat (B,C,N), xyz (B,N,3) -> (B,C,N)."""
+    knn_fn = knn_fn or knn_feat_oracle
+    B, C, N = feat.shape
+    idx = knn_fn(feat, knum)                                            # (B,N,K)
+    ft = feat.permute(0, 2, 1)                                          # (B,N,C)
+    gi = idx.reshape(B, N * knum)
+    fea_knn = torch.gather(ft, 1, gi.unsqueeze(-1).expand(B, N * knum, C)).reshape(B * N, knum, C)
+    xyz_knn = torch.gather(xyz, 1, gi.unsqueeze(-1).expand(B, N * knum, 3)).reshape(B * N, knum, 3)
+    sf = ft.reshape(B * N, 1, C)
+    q_in = sf + _pos_mlp(p, "pos_mlp_knn", xyz.reshape(B * N, 1, 3))
+    kv_in = fea_knn + _pos_mlp(p, "pos_mlp_knn", xyz_knn)
+    d = C // nhead
+    q = F.linear(q_in, p["q_proj_knn.weight"]).view(B * N, 1, nhead, d)
+    k = F.linear(kv_in, p["k_proj_knn.weight"]).view(B * N, knum, nhead, d)
+    v = F.linear(kv_in, p["v_proj_knn.weight"]).view(B * N, knum, nhead, d)
+    msg = linear_attention(q, k, v).reshape(B * N, 1, C)
+    msg = F.layer_norm(F.linear(msg, p["merge_knn.weight"]), (C,), p["norm1_knn.weight"], p["norm1_knn.bias"], LN_EPS)
+    msg = F.linear(torch.cat([sf, msg], dim=2), p["mlp_knn.0.weight"])
+    msg = F.linear(F.relu(msg), p["mlp_knn.2.weight"])
+    msg = F.layer_norm(msg, (C,), p["norm2_knn.weight"], p["norm2_knn.bias"], LN_EPS)
+    return (sf + msg).view(B, N, C).permute(0, 2, 1)
+
+
+def match_xcorr(sd, h1, xyz1, h2, xyz2, knum=48, stages=None, knn_fn=None, head_ng=8):
+    """match_type='xcorr' (ReIDNet.py:250-256, 445-449): cross -> local -> cross -> local on the search branch only,
+    pool 'both', match head"""
+    a = cross_attention(_sub(sd, "cross_stage1."), h1, xyz1, h2, xyz2)
+    b = local_self_attention(_sub(sd, "local_stage1."), a, xyz1, 2, knum, knn_fn)
+    c = cross_attention(_sub(sd, "cross_stage2."), b, xyz1, h2, xyz2)
+    d = local_self_attention(_sub(sd, "local_stage2."), c, xyz1, 2, knum, knn_fn)
+    pooled = pool_both(d)
+    x = linear_res(_linres_params(sd, "match_head.0.", head_ng), pooled)
+    logits = F.linear(x, sd["match_head.1.weight"], sd["match_head.1.bias"]).squeeze(1)
+    if stages is not None:
+        stages.update(xc_a=a, xc_b=b, xc_c=c, xc_d=d, pooled=pooled, logits=logits)
+    return logits
+
+
+def pt_pairs_xcorr(sd, s1, s2, backbone_list, nsample=(32, 48, 48), knum=48, stages=None, knn_fn=None):
+    """Point-Transformer backbone + the 'baseline-orig' matching (reid_pts_point-transformer_baseline_orig.py)"""
+    b = s1.shape[0]
+    xyz, h = pt_backbone(_sub(sd, "backbone."), torch.cat([s1, s2], 0), backbone_list, nsample, stages)
+    return match_xcorr(sd, h[:b], xyz[:b], h[b:], xyz[b:], knum, stages, knn_fn)
+
+
 def square_distance(src, dst):
     d = -2 * torch.matmul(src, dst.permute(0, 2, 1))
     d += torch.sum(src ** 2, -1).unsqueeze(-1)

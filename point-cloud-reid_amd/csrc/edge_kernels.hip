@@ -283,9 +283,84 @@ __global__ __launch_bounds__(kEdgeThreads) void edge_max_kernel(const EdgeMaxArg
   }
 }
 
+// local_self_attention's message (reference attention.py:262-289): for point i with neighbours j in idx[i],
+//   a_j = <elu(q_i)+1, elu(k_j)+1>_head,  msg_i = sum_j a_j v_j / (sum_j a_j + eps)
+// (the reference's LinearAttention with ONE query token: Q.(sum_j K_j (x) v_j / K) / (Q.sum_j K_j + eps) * K).
+// qkv (B,N,3C) point-major rows [q | k | v]; one wave per point, lane = channel (C <= 64, heads of dh = C / nhead
+// lanes, dh a power of two); the output tile is transposed through LDS into channel-major msg (B,C,N).
+__device__ __forceinline__ float edge_elu1(float x) { return x > 0.f ? x + 1.0f : __expf(x); }
+
+__global__ __launch_bounds__(kEdgeThreads) void local_attn_kernel(const float *__restrict__ qkv,
+                                                                   const int *__restrict__ idx,
+                                                                   float *__restrict__ msg, int N, int C, int K, int dh,
+                                                                   float eps) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *so = smem;   // [C][33]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t b = blockIdx.y;
+  const int p0 = blockIdx.x * 32;
+  const int np = N - p0 < 32 ? N - p0 : 32;
+  const float *rows = qkv + b * N * 3 * C;
+  const int cl = lane < C ? lane : C - 1;
+  for (int p = wave; p < np; p += kEdgeThreads / 64) {
+    const int i = p0 + p;
+    const float Q = edge_elu1(rows[(size_t)i * 3 * C + cl]);
+    const int *nb = idx + (b * N + i) * K;
+    float num = 0.f, den = 0.f;
+    int k = 0;
+    for (; k + 4 <= K; k += 4) {
+      float kf[4], vv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const float *r = rows + (size_t)nb[k + u] * 3 * C;
+        kf[u] = r[C + cl];
+        vv[u] = r[2 * C + cl];
+      }
+      float a[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) a[u] = Q * edge_elu1(kf[u]);
+      for (int m = 1; m < dh; m <<= 1) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) a[u] += __shfl_xor(a[u], m, 64);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        den += a[u];
+        num = fmaf(a[u], vv[u], num);
+      }
+    }
+    for (; k < K; k++) {
+      const float *r = rows + (size_t)nb[k] * 3 * C;
+      float a = Q * edge_elu1(r[C + cl]);
+      const float v = r[2 * C + cl];
+      for (int m = 1; m < dh; m <<= 1) a += __shfl_xor(a, m, 64);
+      den += a;
+      num = fmaf(a, v, num);
+    }
+    if (lane < C) so[lane * 33 + p] = num / (den + eps);
+  }
+  __syncthreads();
+  for (int e = tid; e < C * 32; e += kEdgeThreads) {
+    const int c = e >> 5, pp = e & 31;
+    if (pp < np) msg[(b * C + c) * N + p0 + pp] = so[c * 33 + pp];
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------ C ABI ----
+PCR_EXPORT int pcr_local_attn_f32(const float *qkv, const int *idx, float *msg, int B, int N, int C, int K, int nhead,
+                                  float eps, pcr_stream_t stream) {
+  if (!qkv || !idx || !msg) return PCR_ERR_INVALID;
+  if (B <= 0 || N <= 0 || K <= 0 || C <= 0 || C > 64 || nhead <= 0 || C % nhead || B > 65535) return PCR_ERR_INVALID;
+  const int dh = C / nhead;
+  if (dh & (dh - 1)) return PCR_ERR_INVALID;
+  hipLaunchKernelGGL(local_attn_kernel, dim3((N + 31) / 32, B), dim3(kEdgeThreads), (size_t)C * 33 * 4, pcr_s(stream),
+                     qkv, idx, msg, N, C, K, dh, eps);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
 PCR_EXPORT int pcr_knn_feat_f32(const float *x, float *xx_ws, int *idx, int B, int C, int N, int K, long x_bstride,
                                 pcr_stream_t stream) {
   if (!x || !xx_ws || !idx) return PCR_ERR_INVALID;

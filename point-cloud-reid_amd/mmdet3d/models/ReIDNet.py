@@ -235,6 +235,13 @@ class ReIDNet(nn.Module):
         x = pooled.t().contiguous().unsqueeze(0)                 # (1,F,B): channel-major, samples as tokens
         return rows.downsample_points(self.match_head, x).reshape(-1)
 
+    def xcorr(self, search_feat, search_xyz, template_feat, template_xyz):
+        """cross -> local -> cross -> local on the search branch (reference ReIDNet.py:250-256)"""
+        a = self.cross_stage1(search_feat, search_xyz, template_feat, template_xyz)
+        b = self.local_stage1(a, search_xyz)
+        c = self.cross_stage2(b, search_xyz, template_feat, template_xyz)
+        return self.local_stage2(c, search_xyz)
+
     def xcorr_baseline(self, search_feat, search_xyz, template_feat, template_xyz):
         a = self.cross_stage1(search_feat, search_xyz, template_feat, template_xyz)
         return self.cross_stage2(a, search_xyz, template_feat, template_xyz)
@@ -251,14 +258,18 @@ class ReIDNet(nn.Module):
         if self.match_type == "xcorr_eff":
             match_in, o1, o2 = self.xcorr_eff(h1, xyz1, h2, xyz2, self.combine)
             return self._head_rows(self.get_pooled_feats(match_in)), torch.cat([o1, o2], dim=0)
+        if self.match_type == "xcorr":
+            if self.local_stage1 is None or self.local_stage2 is None:
+                raise L.PcrError("match_type='xcorr' needs local_stage1 / local_stage2 (local_self_attention)")
+            match_in = self.xcorr(h1, xyz1, h2, xyz2)
+            return self._head_rows(self.get_pooled_feats(match_in)), None
         if self.match_type == "xcorr-baseline":
             match_in = self.xcorr_baseline(h1, xyz1, h2, xyz2)
             return self._head_rows(self.get_pooled_feats(match_in)), None
         if self.match_type == "concat":
             cat = torch.cat([self.get_pooled_feats(h1), self.get_pooled_feats(h2)], dim=1)
             return self._head_rows(cat), None
-        raise NotImplementedError("match_type=%r ('xcorr' needs local_self_attention, SURVEY.md 8f rank 3)"
-                                  % self.match_type)
+        raise NotImplementedError("match_type=%r" % self.match_type)
 
     def match_forward_inference(self, h1, h2, xyz1, xyz2):
         return self._match_logits(h1, h2, xyz1, xyz2)[0]

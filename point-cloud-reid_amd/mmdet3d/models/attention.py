@@ -41,8 +41,28 @@ class _OutOfScope(nn.Module):
                                   "(SURVEY.md section 8f)" % self.what)
 
 
-class local_self_attention(_OutOfScope):
-    what = "local_self_attention (feature-kNN local attention, only used by the baseline_orig config)"
+class local_self_attention(nn.Module):
+    """Every point attends to its `knum` feature-space neighbours (attention.py:221-296; the `baseline_orig`
+    matching, match_type='xcorr').  Parameter names are the reference's.  search_feat (B,C,N), search_xyz (B,N,3)
+    -> (B,C,N)."""
+
+    def __init__(self, d_model, nhead, attention="linear", knum=32, pos_size=16):
+        super().__init__()
+        self.d_model, self.dim, self.nhead, self.knum = d_model, d_model // nhead, nhead, knum
+        self.pos_mlp_knn = nn.Sequential(nn.Linear(3, pos_size), nn.ReLU(True), nn.Linear(pos_size, pos_size))
+        self.q_proj_knn = nn.Linear(d_model, d_model, bias=False)
+        self.k_proj_knn = nn.Linear(d_model, d_model, bias=False)
+        self.v_proj_knn = nn.Linear(d_model, d_model, bias=False)
+        self.merge_knn = nn.Linear(d_model, d_model, bias=False)
+        self.mlp_knn = nn.Sequential(nn.Linear(d_model * 2, d_model * 2, bias=False), nn.ReLU(True),
+                                     nn.Linear(d_model * 2, d_model, bias=False))
+        self.norm1_knn = nn.LayerNorm(d_model)
+        self.norm2_knn = nn.LayerNorm(d_model)
+
+    def forward(self, search_feat, search_xyz, mask=None):
+        assert mask is None
+        from pcr_amd import local_attn_engine
+        return local_attn_engine.forward(self, search_feat, search_xyz)
 
 
 class cross_lin_attn(_OutOfScope):

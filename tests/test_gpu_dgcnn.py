@@ -159,3 +159,51 @@ def test_edge_layer_matches_materialised_edge_formulation():
                                       L.ptr(out), ctypes.c_long(0), None, ctypes.c_long(0), B, N, Co, K,
                                       L.stream_ptr()), "pcr_edge_max_f32")
     assert float((out.cpu() - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+
+
+# ---- local_self_attention / match_type='xcorr' (attention.py:221-296, ReIDNet.py:250-256) -------------------------
+LOCAL = dict(type="local_self_attention", d_model=64, nhead=2, attention="linear", knum=48, pos_size=64)
+
+
+def build_xcorr():
+    import bench
+    from mmdet3d.models import build_model
+    cfg = copy.deepcopy(bench.PT_MODEL)
+    cfg.update(match_type="xcorr", local_stage1=dict(LOCAL), local_stage2=dict(LOCAL), backbone_list=[128, 64, 32])
+    m = build_model(cfg)
+    man = T.load_manifest(os.path.join(GOLDEN, "pt_xcorr_manifest.json"))
+    assert T.manifest_of(m) == man
+    sd = T.seeded_state_dict(man, 0)
+    m.load_state_dict(sd, strict=True)
+    return m.cuda().eval(), sd
+
+
+def test_xcorr_pairs_match_reference_golden():
+    g = load_golden("pt_xcorr_n128_randn")
+    meta = g["meta"]
+    m, _ = build_xcorr()
+    s1, s2 = T.synthetic_pairs(meta["pairs"], meta["n"], meta["input_seed"], meta["kind"])
+    with torch.no_grad():
+        xyz1, xyz2, h1, h2 = m.siamese_forward(s1.cuda(), s2.cuda())
+        a = m.cross_stage1(h1, xyz1, h2, xyz2)
+        b = m.local_stage1(a, xyz1)
+        logits = m.match_forward_inference(h1, h2, xyz1, xyz2)
+    assert np.abs(a.cpu().numpy() - g["xc_a"]).max() < TOL
+    assert np.abs(b.cpu().numpy() - g["xc_b"]).max() < TOL
+    assert np.abs(logits.cpu().numpy() - g["logits"]).max() < TOL
+
+
+@pytest.mark.parametrize("n,knum", [(100, 48), (64, 32), (257, 20)])
+def test_local_self_attention_matches_oracle(n, knum):
+    import model_oracle as MO
+    from mmdet3d.models.attention import local_self_attention
+    m = local_self_attention(64, 2, knum=knum, pos_size=64)
+    sd = T.seeded_state_dict(T.manifest_of(m), 13)
+    m.load_state_dict(sd)
+    g = torch.Generator().manual_seed(n)
+    feat = torch.randn(3, 64, n, generator=g)
+    xyz = torch.randn(3, n, 3, generator=g)
+    with torch.no_grad():
+        want = MO.local_self_attention(sd, feat, xyz, 2, knum)
+        got = m.cuda().eval()(feat.cuda(), xyz.cuda()).cpu()
+    assert float((got - want).abs().max()) < TOL

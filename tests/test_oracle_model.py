@@ -68,6 +68,21 @@ def test_dgcnn_oracle_matches_reference_golden(knn):
     assert np.abs(logits.numpy() - g["logits"]).max() < TOL
 
 
+@pytest.mark.parametrize("knn", ["pinned_order", "reference_formula"])
+def test_xcorr_local_attention_oracle_matches_reference_golden(knn):
+    """match_type='xcorr' (cross -> local_self_attention -> cross -> local), recorded from the imported reference"""
+    g = load_golden("pt_xcorr_n128_randn")
+    m = g["meta"]
+    s1, s2 = T.synthetic_pairs(m["pairs"], m["n"], m["input_seed"], m["kind"])
+    st = {}
+    with torch.no_grad():
+        logits = MO.pt_pairs_xcorr(_sd("pt_xcorr"), s1, s2, m["backbone_list"], knum=m["knum"], stages=st,
+                                   knn_fn=MO.knn_feat_torch if knn == "reference_formula" else None)
+    for k in ("xc_a", "xc_b"):
+        assert np.abs(st[k].numpy() - g[k]).max() < TOL, k
+    assert np.abs(logits.numpy() - g["logits"]).max() < TOL
+
+
 def test_eval_metric_fixture():
     """pcr_amd.metrics against values recorded from the reference's own MatchingEval / accuracy definition"""
     from pcr_amd import metrics
