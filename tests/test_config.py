@@ -55,6 +55,11 @@ def test_reference_configs_load_unchanged_and_build():
     assert cfg.model.backbone.type == "dgcnn" and cfg.model.use_dgcnn is True
     model = build_model(cfg.model)
     assert T.manifest_of(model) == T.load_manifest(os.path.join(GOLDEN, "dgcnn_manifest.json"))
+    cfg = Config.fromfile(os.path.join(
+        REF, "reid_waymo_pts/testing_pts_point-transformer_baseline-orig_r_waymo_det_400e.py"))
+    assert cfg.model.match_type == "xcorr" and cfg.model.local_stage1.type == "local_self_attention"
+    model = build_model(cfg.model)
+    assert T.manifest_of(model) == T.load_manifest(os.path.join(GOLDEN, "pt_xcorr_manifest.json"))
     # every point-cloud ReID config of the reference parses
     n, broken = 0, []
     for sub in ("reid_nuscenes_pts", "reid_waymo_pts"):
