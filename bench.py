@@ -47,6 +47,9 @@ WORKLOADS = {
                 "-> Conv1d 64; D-FPS + ball query), 1024-pt synthetic pairs, eval", "ssg", 1024, None, 2048),
     "pointnet256": ("PointNet ReIDNet (configs_reid/_base_/reidentifiers/reid_pts_pointnet_point-cat.py), 256-pt "
                     "synthetic pairs, eval (BASELINE config 1 shape)", "pointnet", 256, None, 256),
+    "ptxcorr128": ("Point-Transformer with the baseline-orig matching (match_type='xcorr': cross -> local_self_attention "
+                   "-> cross -> local; reid_waymo_pts/testing_pts_point-transformer_baseline-orig_r_waymo_det_400e.py), "
+                   "128-pt synthetic pairs, eval", "ptx", 128, [128, 64, 32], 512),
     "dgcnn128": ("DGCNN ReIDNet (reid_waymo_pts/testing_pts_dgcnn_r_waymo_det_400e.py: 128-pt crops, 512 pairs per "
                  "GPU), synthetic pairs, eval", "dgcnn", 128, None, 512),
     "dgcnn256": ("DGCNN ReIDNet (configs_reid/_base_/reidentifiers/reid_pts_dgcnn_point-cat.py, k=20, emb 1024), "
@@ -91,11 +94,24 @@ DG_MODEL["match_head"] = [dict(type="LinearRes", n_in=128, n_out=128, norm="GN",
                           dict(type="Linear", in_features=128, out_features=1)]
 
 
+LOCAL_STAGE = dict(type="local_self_attention", d_model=64, nhead=2, attention="linear", knum=48, pos_size=64)
+
+
 def build_model(kind, backbone_list, device="cuda"):
-    """kind 'pt' (reference Point-Transformer config), 'pointnet' (reference PointNet config) or 'ssg'
-    (BASELINE config 2 composition); seeded weights"""
+    """kind 'pt' (reference Point-Transformer config), 'ptx' (the same with the baseline-orig matching), 'pointnet',
+    'dgcnn' (reference configs) or 'ssg' (BASELINE config 2 composition); seeded weights"""
     if kind == "pt":
         return build_pt_model(backbone_list, device)
+    if kind == "ptx":
+        from mmdet3d.models import build_model as _build
+        from pcr_amd import testing as T
+        cfg = copy.deepcopy(PT_MODEL)
+        cfg.update(match_type="xcorr", local_stage1=dict(LOCAL_STAGE), local_stage2=dict(LOCAL_STAGE),
+                   backbone_list=list(backbone_list))
+        model = _build(cfg)
+        sd = T.seeded_state_dict(T.manifest_of(model), 0)
+        model.load_state_dict(sd, strict=True)
+        return model.to(device).eval(), sd
     from mmdet3d.models import build_model as _build
     from pcr_amd import testing as T
     model = _build(copy.deepcopy({"ssg": SSG_MODEL, "dgcnn": DG_MODEL}.get(kind, PN_MODEL)))
@@ -147,7 +163,8 @@ def cpu_baseline(workload, sd, budget_s=20.0):
     pairs = 8 if n >= 1024 else 32
     s1, s2 = T.synthetic_pairs(pairs, n, seed=1234, kind="box" if kind == "ssg" else "randn")
     run = {"ssg": lambda: MO.ssg_pairs(sd, s1, s2), "pointnet": lambda: MO.pointnet_pairs(sd, s1, s2),
-           "pt": lambda: MO.pt_pairs(sd, s1, s2, bl), "dgcnn": lambda: MO.dgcnn_pairs(sd, s1, s2)}[kind]
+           "pt": lambda: MO.pt_pairs(sd, s1, s2, bl), "dgcnn": lambda: MO.dgcnn_pairs(sd, s1, s2),
+           "ptx": lambda: MO.pt_pairs_xcorr(sd, s1, s2, bl)}[kind]
     best, best_threads, runs = None, 1, 0
     t_start = time.time()
     # torch's intra-op pool does not scale to hundreds of threads on these small per-cloud ops:
