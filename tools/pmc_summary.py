@@ -54,7 +54,12 @@ def main():
                   "fetch_size_kb": f_kb, "write_size_kb": w_kb,
                   "hbm_bytes_corrected": (2.0 * f_kb + w_kb) * 1024.0}
     res["_pairs_per_step"] = pairs
-    res["_launch_to_kernel"] = {}
+    # bench.py's launch names -> kernel symbols (ssg1024: the launches whose roofline object quotes PMC figures)
+    known = {"sa_ragged[D=128,c=128/128/256,N=512,S=128,K=64]": "sa_rag_kernel<2, 2, 1, 1, 1, 1>",
+             "sa_ragged[D=0,c=64/64/128,N=1024,S=512,K=32]": "sa_rag_kernel<4, 1, 2, 1, 1, 2>",
+             "sa_tables[D=128,out=128,N=512]": "dense_pm_kernel<1>", "fps[N=1024,M=512]": "fps_wave_kernel<8>",
+             "ball_query[N=1024,M=512,K=32]": "ball_query_reg_kernel<16>"}
+    res["_launch_to_kernel"] = {k: v for k, v in known.items() if v in res}
     json.dump(res, open(out, "w"), indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["launch_us"] if isinstance(kv[1], dict) and "launch_us" in kv[1] else 0):
         if isinstance(v, dict) and "launch_us" in v:
