@@ -47,6 +47,10 @@ WORKLOADS = {
                 "-> Conv1d 64; D-FPS + ball query), 1024-pt synthetic pairs, eval", "ssg", 1024, None, 2048),
     "pointnet256": ("PointNet ReIDNet (configs_reid/_base_/reidentifiers/reid_pts_pointnet_point-cat.py), 256-pt "
                     "synthetic pairs, eval (BASELINE config 1 shape)", "pointnet", 256, None, 256),
+    "pt128_train": ("Point-Transformer siamese TRAINING step (BASELINE config 4 shape: nuScenes-ReID 128-pt crops, 256 pairs "
+                    "per GPU): forward + backward + one-bucket gradient all-reduce + clip + AdamW (cyclic lr/beta1). HIP "
+                    "kNN / grouping forward+backward, dense math through torch autograd (DESIGN.md 9.4)", "pt_train", 128,
+                    [128, 64, 32], 256),
     "ptxcorr128": ("Point-Transformer with the baseline-orig matching (match_type='xcorr': cross -> local_self_attention "
                    "-> cross -> local; reid_waymo_pts/testing_pts_point-transformer_baseline-orig_r_waymo_det_400e.py), "
                    "128-pt synthetic pairs, eval", "ptx", 128, [128, 64, 32], 512),
@@ -188,6 +192,45 @@ def cpu_baseline(workload, sd, budget_s=20.0):
                        % (pairs, n, runs, candidates, avail, torch.__version__))
 
 
+def train_bench(args, desc, n, bl, pairs, rank, world):
+    """training throughput (reported separately from the inference metric): pairs/s of
+    Trainer.step = ReIDNet.train_step forward + backward, ONE flat-bucket gradient all-reduce over RCCL, gradient
+    clipping and AdamW with the cyclic schedule, on a fixed synthetic batch already resident in HBM"""
+    from pcr_amd import shard, train
+    from pcr_amd import testing as T
+    model, _ = build_pt_model(bl)
+    model.train()
+    s1, s2 = T.synthetic_pairs(pairs, n, seed=4321 + rank, kind="randn")
+    dev = "cuda"
+    g = torch.Generator().manual_seed(99 + rank)
+    ids1 = torch.arange(pairs)
+    ids2 = torch.where(torch.rand(pairs, generator=g) < 0.5, ids1, ids1 + pairs)      # half of the pairs match
+    zero = torch.zeros(1, dtype=torch.long, device=dev)
+    data = dict(sparse_1=list(s1.to(dev)), sparse_2=list(s2.to(dev)), dense_1=list(s1.to(dev)), dense_2=list(s2.to(dev)),
+                label_1=[zero] * pairs, label_2=[zero] * pairs,
+                id_1=[i.view(1).to(dev) for i in ids1], id_2=[i.view(1).to(dev) for i in ids2])
+    tr = train.Trainer(model, max_iters=args.steps + args.warmup + 1, lr=3e-4, grad_clip=1.0)
+    dt, out = shard.timed(lambda: tr.step(data)["loss"].detach(), args.steps, args.warmup,
+                          sync=torch.cuda.synchronize, device="cuda")
+    assert torch.isfinite(out).all()
+    if rank == 0:
+        tr.bucket._layout()
+        print(json.dumps({
+            "metric": "siamese training pairs/sec @%d pts" % n, "value": world * pairs * args.steps / dt,
+            "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (randn clouds, seeded random-init weights)",
+            "config": {"workload": "%s: %s" % (args.workload, desc), "pairs_per_gpu_per_step": pairs, "points": n,
+                       "backbone_list": bl, "parallelism": "data parallel x%d, one %d-byte gradient bucket per step"
+                       % (world, tr.bucket.nbytes())},
+            "roofline": None, "note": "training is not the headline metric; no per-kernel roofline is claimed for the "
+                                      "torch-autograd dense math"}), flush=True)
+    if shard.is_dist():
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,6 +253,8 @@ def main():
 
     desc, kind, n, bl, dpairs = WORKLOADS[args.workload]
     pairs = args.pairs or dpairs
+    if kind == "pt_train":
+        return train_bench(args, desc, n, bl, pairs, rank, world)
     model, sd = build_model(kind, bl)
     # weak scaling: every rank owns `pairs` independent pairs (its own seed), already resident in HBM
     cloud_kind = "box" if kind == "ssg" else "randn"     # ball-query radii are metric: vehicle-sized box crops
