@@ -69,3 +69,38 @@ def test_linear_res_rows_standalone():
             want = MO.linear_res(p, x)
         got = m.cuda().eval()(x.cuda()).cpu()
         assert float((got - want).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("cin,cout,L,B", [(512, 256, 100, 3), (1024, 512, 77, 2), (768, 256, 64, 1), (512, 512, 33, 2),
+                                          (1024, 256, 200, 1)])
+def test_chunked_dense_ragged_token_counts(cin, cout, L, B):
+    """the chunked-contraction dense kernel (cin >= 512, multiples of 256) on token counts that are not multiples of
+    its 64-token tile, plain and with the fused GroupNorm (+ residual, ReLU) epilogue, against torch fp32"""
+    import torch.nn.functional as F
+    from pcr_amd import engine as E, rows
+    g = torch.Generator().manual_seed(cin + L)
+    x = torch.randn(B, cin, L, generator=g)
+    w = torch.randn(cout, cin, generator=g) / cin ** 0.5
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    wp = E.pack_weight(w, "cuda")
+    for act in (0, 1, 2):
+        want = torch.einsum("oc,bcl->bol", w, x) * sc.view(1, -1, 1) + sh.view(1, -1, 1)
+        want = F.relu(want) if act == 1 else F.leaky_relu(want, 0.2) if act == 2 else want
+        got = E.dense(x.cuda(), wp, cout, sc.cuda(), sh.cuda(), act=act).cpu()
+        assert float((got - want).abs().max()) < 2e-4 * max(1.0, float(want.abs().max())), (act,)
+    gn = torch.nn.GroupNorm(cout // 8, cout)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(cout, generator=g))
+        gn.bias.copy_(torch.randn(cout, generator=g))
+    res = torch.randn(B, cout, L, generator=g)
+    with torch.no_grad():
+        y = torch.einsum("oc,bcl->bol", w, x)
+        want = F.relu(gn(y.permute(0, 2, 1).reshape(-1, cout)).reshape(B, L, cout).permute(0, 2, 1) + res)
+    got = rows.dense_gn(x.cuda(), wp, cout, gn, res=res.cuda(), relu=True).cpu()
+    assert float((got - want).abs().max()) < 2e-4
+    for groups in (cout // 4, cout // 16, cout // 32, 1):           # group sizes 4 / 16 / 32 fused, 1 group unfused
+        gn2 = torch.nn.GroupNorm(groups, cout)
+        with torch.no_grad():
+            want = gn2(y.permute(0, 2, 1).reshape(-1, cout)).reshape(B, L, cout).permute(0, 2, 1)
+        got = rows.dense_gn(x.cuda(), wp, cout, gn2).cpu()
+        assert float((got - want).abs().max()) < 2e-4, groups
