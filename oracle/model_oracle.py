@@ -338,6 +338,13 @@ def graph_feature(x, idx):
     return torch.cat((nb - ctr, ctr), dim=3).permute(0, 3, 1, 2).contiguous()
 
 
+def dgcnn_edge_layer(p, f, i, k=20, knn_fn=None):
+    """EdgeConv layer i (1..4) on its own: f (B,C,N) -> (B,Co,N)"""
+    idx = (knn_fn or knn_feat_oracle)(f, k)
+    e = F.conv2d(graph_feature(f, idx), p["conv%d.0.weight" % i])
+    return F.leaky_relu(_bn(e, p, "conv%d.1" % i, 4), 0.2).max(dim=-1)[0]
+
+
 def dgcnn_backbone(p, x, k=20, stages=None, knn_fn=None):
     """x (B,3,N) -> (xyz (B,3,N), feats (B,emb_dims,N))"""
     knn_fn = knn_fn or knn_feat_oracle

@@ -53,8 +53,9 @@ def _table(x, wp, co):
     return y
 
 
-def forward(net, xyz):
-    """xyz (B,3,N) -> (xyz, per-point features (B,emb_dims,N)); eval mode only"""
+def forward(net, xyz, stages=None):
+    """xyz (B,3,N) -> (xyz, per-point features (B,emb_dims,N)); eval mode only.  stages (optional dict) receives
+    the layer outputs x1..x4 and neighbour indices knn1..knn4 (for stage-wise parity checks)"""
     L.require_cuda(xyz)
     if net.training:
         raise L.PcrError("DGCNN: the HIP path implements eval-mode inference; call .eval()")
@@ -81,5 +82,8 @@ def forward(net, xyz):
                                          ctypes.c_long(p.cat * N), B, N, co, p.k, L.stream_ptr()), "pcr_edge_max_f32")
         off += co
         f = out
+        if stages is not None:
+            stages["knn%d" % (len(stages) // 2 + 1)] = idx
+            stages["x%d" % (len(stages) // 2 + 1)] = out
     y = E.dense(cat, p.w5, p.c5, p.sc5, p.sh5, act=2)
     return xyz, y
