@@ -13,12 +13,14 @@
 //                         increasing, so the max over the k neighbours commutes with everything after the gather --
 //                         k times fewer matrix flops than the reference's layout and a gather of k contiguous rows.
 #include <math.h>
+#include <stdlib.h>
 
 #include "pcr_common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kEdgeThreads = 256;
 constexpr int kKnnThreads = 512;   // 8 waves: at N = 1024 the key tile leaves room for ONE workgroup per CU
@@ -283,6 +285,74 @@ __global__ __launch_bounds__(kEdgeThreads) void edge_max_kernel(const EdgeMaxArg
   }
 }
 
+// The same for small clouds: a workgroup owns (cloud, slice of CS channels) and keeps the slice of the A table,
+// [N][CS] floats, in LDS -- every table row is read from L2 ONCE (coalesced) instead of k times through gathers, and
+// the k-fold gather runs at LDS bandwidth.  N * CS * 4 <= 64 KB (CS = 64 up to 256 points, 32 up to 512).
+template <int CS>
+__global__ __launch_bounds__(kEdgeThreads) void edge_max_lds_kernel(const EdgeMaxArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int PG = kEdgeThreads / CS;   // points in flight per pass
+  const int N = a.N, Co = a.Co, K = a.K;
+  float *tab = smem;                 // [N][CS]
+  float *so = smem + (size_t)N * CS;   // [CS][33]
+  int *sidx = reinterpret_cast<int *>(so + CS * 33);   // [32][K]: neighbour indices of the current 32-point tile
+  const int tid = threadIdx.x;
+  const size_t b = blockIdx.y;
+  const int c0 = blockIdx.x * CS;
+  const int cw = Co - c0 < CS ? Co - c0 : CS;          // channels of this slice that exist
+  const float *ta = a.ta + b * N * Co + c0;
+  for (int e = tid; e < N * (CS / 4); e += kEdgeThreads) {
+    const int p = e / (CS / 4), q = (e - p * (CS / 4)) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (q + 3 < cw && (Co & 3) == 0) v = *reinterpret_cast<const f32x4 *>(ta + (size_t)p * Co + q);
+    else
+      for (int u = 0; u < 4; u++)
+        if (q + u < cw) v[u] = ta[(size_t)p * Co + q + u];
+    *reinterpret_cast<f32x4 *>(tab + (size_t)p * CS + q) = v;
+  }
+  __syncthreads();
+  const int c = tid % CS, pg = tid / CS;
+  const bool live = c < cw;
+  const float sh = live ? a.shift[c0 + c] : 0.f;
+  const float *tb = a.tb + b * N * Co + c0 + (live ? c : 0);
+  const int *ib = a.idx + b * N * K;
+  for (int t0 = 0; t0 < N; t0 += 32) {
+    {
+      const int np = N - t0 < 32 ? N - t0 : 32;
+      for (int e = tid; e < np * K; e += kEdgeThreads) sidx[e] = ib[(size_t)t0 * K + e];
+    }
+    __syncthreads();
+    for (int pp = pg; pp < 32; pp += PG) {
+      const int p = t0 + pp;
+      if (p < N) {
+        const int *nb = sidx + pp * K;
+        const float tbv = tb[(size_t)p * Co];
+        float m = -INFINITY;
+        int k = 0;
+        for (; k + 4 <= K; k += 4) {
+          const int j0 = nb[k], j1 = nb[k + 1], j2 = nb[k + 2], j3 = nb[k + 3];
+          const float v0 = tab[j0 * CS + c], v1 = tab[j1 * CS + c], v2 = tab[j2 * CS + c], v3 = tab[j3 * CS + c];
+          m = fmaxf(fmaxf(m, fmaxf(v0, v1)), fmaxf(v2, v3));
+        }
+        for (; k < K; k++) m = fmaxf(m, tab[nb[k] * CS + c]);
+        const float s = m + tbv;
+        const float y = s + sh;
+        so[c * 33 + pp] = y > 0.f ? y : y * a.slope;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < CS * 32; e += kEdgeThreads) {
+      const int cc = e >> 5, pp = e & 31;
+      if (cc < cw && t0 + pp < N) {
+        const float v = so[cc * 33 + pp];
+        a.out[b * a.out_bs + (size_t)(c0 + cc) * N + t0 + pp] = v;
+        if (a.out2) a.out2[b * a.out2_bs + (size_t)(c0 + cc) * N + t0 + pp] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // local_self_attention's message (reference attention.py:262-289): for point i with neighbours j in idx[i],
 //   a_j = <elu(q_i)+1, elu(k_j)+1>_head,  msg_i = sum_j a_j v_j / (sum_j a_j + eps)
 // (the reference's LinearAttention with ONE query token: Q.(sum_j K_j (x) v_j / K) / (Q.sum_j K_j + eps) * K).
@@ -403,6 +473,27 @@ PCR_EXPORT int pcr_edge_max_f32(const float *ta, const float *tb, const int *idx
   if (B <= 0 || N <= 0 || Co <= 0 || Co > 256 || K <= 0 || K > 64 || B > 65535) return PCR_ERR_INVALID;
   EdgeMaxArgs a{ta, tb, shift, idx, out, out2, out_bstride > 0 ? out_bstride : (long)Co * N,
                 out2_bstride > 0 ? out2_bstride : (long)Co * N, N, Co, K, slope};
+  if (N <= 512 && !getenv("PCR_EDGE_NO_LDS")) {
+    // channel-slice width: narrower slices = more, smaller workgroups.  Measured (512 pairs/step, ms for the four
+    // layers, CS = 64 / 32 / 16): N = 128: 0.46 / 0.35 / 0.36; N = 256: 1.11 / 0.83 / 0.76; the L2-gather kernel
+    // below: 0.72 and 1.55, but 1.52 against 1.69 at N = 1024, where it stays.
+    static const int cs_env = getenv("PCR_EDGE_CS") ? atoi(getenv("PCR_EDGE_CS")) : 0;
+    const int cs = cs_env ? cs_env : (N <= 128 ? 32 : 16);
+#define PCR_EDGE_LDS(CS_)                                                                                         \
+  do {                                                                                                            \
+    static bool big = hipFuncSetAttribute(reinterpret_cast<const void *>(edge_max_lds_kernel<CS_>),               \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;  \
+    (void)big;                                                                                                    \
+    hipLaunchKernelGGL(edge_max_lds_kernel<CS_>, dim3((Co + CS_ - 1) / CS_, B), dim3(kEdgeThreads),               \
+                       (size_t)(N * CS_ + CS_ * 33 + 32 * K) * 4, pcr_s(stream), a);                              \
+  } while (0)
+    if (cs == 64 && N <= 512) PCR_EDGE_LDS(64);
+    else if (cs == 16 || N > 512) PCR_EDGE_LDS(16);
+    else PCR_EDGE_LDS(32);
+#undef PCR_EDGE_LDS
+    PCR_CHECK_LAUNCH();
+    return PCR_OK;
+  }
   const size_t lds = (size_t)(32 * K + Co * 33) * 4;
   hipLaunchKernelGGL(edge_max_kernel, dim3((N + 31) / 32, B), dim3(kEdgeThreads), lds, pcr_s(stream), a);
   PCR_CHECK_LAUNCH();
