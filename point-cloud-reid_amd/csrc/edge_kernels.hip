@@ -360,6 +360,29 @@ __global__ __launch_bounds__(kEdgeThreads) void edge_max_lds_kernel(const EdgeMa
 // lanes, dh a power of two); the output tile is transposed through LDS into channel-major msg (B,C,N).
 __device__ __forceinline__ float edge_elu1(float x) { return x > 0.f ? x + 1.0f : __expf(x); }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// sum over the DH lanes of a head, every lane gets the total.  DH = 16 / 32: DPP adds inside the 16-lane row
+// (lane ^ 1, lane ^ 2, other quad of the half, other half of the row -- the same pairings as the xor butterfly, so
+// the result is bit-identical) + one ds_swizzle across the two rows; the generic form is five ds_bpermute round
+// trips per value, which is what this kernel spent its time on.
+template <int DH>
+__device__ __forceinline__ float head_sum(float a, int dh) {
+  if constexpr (DH == 16 || DH == 32) {
+    a += dpp_f32<0xB1>(a);
+    a += dpp_f32<0x4E>(a);
+    a += dpp_f32<0x141>(a);
+    a += dpp_f32<0x140>(a);
+    if constexpr (DH == 32) a += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(a), 0x401F));   // lane ^ 16
+  } else {
+    for (int m = 1; m < dh; m <<= 1) a += __shfl_xor(a, m, 64);
+  }
+  return a;
+}
+
+template <int DH>
 __global__ __launch_bounds__(kEdgeThreads) void local_attn_kernel(const float *__restrict__ qkv,
                                                                    const int *__restrict__ idx,
                                                                    float *__restrict__ msg, int N, int C, int K, int dh,
@@ -389,10 +412,8 @@ __global__ __launch_bounds__(kEdgeThreads) void local_attn_kernel(const float *_
       float a[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) a[u] = Q * edge_elu1(kf[u]);
-      for (int m = 1; m < dh; m <<= 1) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) a[u] += __shfl_xor(a[u], m, 64);
-      }
+      for (int u = 0; u < 4; u++) a[u] = head_sum<DH>(a[u], dh);
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         den += a[u];
@@ -403,7 +424,7 @@ __global__ __launch_bounds__(kEdgeThreads) void local_attn_kernel(const float *_
       const float *r = rows + (size_t)nb[k] * 3 * C;
       float a = Q * edge_elu1(r[C + cl]);
       const float v = r[2 * C + cl];
-      for (int m = 1; m < dh; m <<= 1) a += __shfl_xor(a, m, 64);
+      a = head_sum<DH>(a, dh);
       den += a;
       num = fmaf(a, v, num);
     }
@@ -425,8 +446,11 @@ PCR_EXPORT int pcr_local_attn_f32(const float *qkv, const int *idx, float *msg, 
   if (B <= 0 || N <= 0 || K <= 0 || C <= 0 || C > 64 || nhead <= 0 || C % nhead || B > 65535) return PCR_ERR_INVALID;
   const int dh = C / nhead;
   if (dh & (dh - 1)) return PCR_ERR_INVALID;
-  hipLaunchKernelGGL(local_attn_kernel, dim3((N + 31) / 32, B), dim3(kEdgeThreads), (size_t)C * 33 * 4, pcr_s(stream),
-                     qkv, idx, msg, N, C, K, dh, eps);
+  const dim3 g((N + 31) / 32, B), blk(kEdgeThreads);
+  const size_t lds = (size_t)C * 33 * 4;
+  if (dh == 32) hipLaunchKernelGGL(local_attn_kernel<32>, g, blk, lds, pcr_s(stream), qkv, idx, msg, N, C, K, dh, eps);
+  else if (dh == 16) hipLaunchKernelGGL(local_attn_kernel<16>, g, blk, lds, pcr_s(stream), qkv, idx, msg, N, C, K, dh, eps);
+  else hipLaunchKernelGGL(local_attn_kernel<0>, g, blk, lds, pcr_s(stream), qkv, idx, msg, N, C, K, dh, eps);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }
