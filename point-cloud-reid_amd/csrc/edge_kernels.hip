@@ -437,6 +437,75 @@ __global__ __launch_bounds__(kEdgeThreads) void local_attn_kernel(const float *_
   }
 }
 
+// The same with one workgroup per (cloud, head) and that head's elu(k)+1 | v columns of the whole cloud resident in
+// LDS ([N][DH] each): the table is read from L2 once and the K-fold neighbour gather runs from LDS (with the DPP
+// reduction above the LDS pipe is free for it).  Same operation order as local_attn_kernel: bit-identical output.
+template <int DH>
+__global__ __launch_bounds__(kEdgeThreads) void local_attn_lds_kernel(const float *__restrict__ qkv,
+                                                                       const int *__restrict__ idx,
+                                                                       float *__restrict__ msg, int N, int C, int K,
+                                                                       float eps) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int PG = kEdgeThreads / DH;
+  float *tk = smem;                       // [N][DH] elu(k)+1
+  float *tv = tk + (size_t)N * DH;        // [N][DH]
+  float *so = tv + (size_t)N * DH;        // [DH][33]
+  int *sidx = reinterpret_cast<int *>(so + DH * 33);   // [32][K]
+  const int tid = threadIdx.x;
+  const size_t b = blockIdx.y;
+  const int c0 = blockIdx.x * DH;
+  const float *rows = qkv + b * N * 3 * C;
+  for (int e = tid; e < N * DH; e += kEdgeThreads) {
+    const int p = e / DH, c = e - p * DH;
+    const float *r = rows + (size_t)p * 3 * C + c0 + c;
+    tk[e] = edge_elu1(r[C]);
+    tv[e] = r[2 * C];
+  }
+  const int c = tid % DH, pg = tid / DH;
+  const int *ib = idx + b * N * K;
+  for (int t0 = 0; t0 < N; t0 += 32) {
+    const int np = N - t0 < 32 ? N - t0 : 32;
+    for (int e = tid; e < np * K; e += kEdgeThreads) sidx[e] = ib[(size_t)t0 * K + e];
+    __syncthreads();   // (also orders the table fill before its first use)
+    for (int pp = pg; pp < 32; pp += PG) {
+      const int pc = pp < np ? pp : np - 1;            // clamped: every lane takes part in the reductions
+      const float Q = edge_elu1(rows[(size_t)(t0 + pc) * 3 * C + c0 + c]);
+      const int *nb = sidx + pc * K;
+      float num = 0.f, den = 0.f;
+      int k = 0;
+      for (; k + 4 <= K; k += 4) {
+        float a[4], vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int j = nb[k + u];
+          a[u] = Q * tk[j * DH + c];
+          vv[u] = tv[j * DH + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) a[u] = head_sum<DH>(a[u], DH);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          den += a[u];
+          num = fmaf(a[u], vv[u], num);
+        }
+      }
+      for (; k < K; k++) {
+        const int j = nb[k];
+        float a = head_sum<DH>(Q * tk[j * DH + c], DH);
+        den += a;
+        num = fmaf(a, tv[j * DH + c], num);
+      }
+      if (pp < np) so[c * 33 + pp] = num / (den + eps);
+    }
+    __syncthreads();
+    for (int e = tid; e < DH * 32; e += kEdgeThreads) {
+      const int cc = e >> 5, pp = e & 31;
+      if (pp < np) msg[(b * C + c0 + cc) * N + t0 + pp] = so[cc * 33 + pp];
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------ C ABI ----
@@ -446,6 +515,16 @@ PCR_EXPORT int pcr_local_attn_f32(const float *qkv, const int *idx, float *msg, 
   if (B <= 0 || N <= 0 || K <= 0 || C <= 0 || C > 64 || nhead <= 0 || C % nhead || B > 65535) return PCR_ERR_INVALID;
   const int dh = C / nhead;
   if (dh & (dh - 1)) return PCR_ERR_INVALID;
+  const size_t lds32 = ((size_t)N * 32 * 2 + 32 * 33 + 32 * K) * 4;
+  if (dh == 32 && lds32 <= 72 * 1024 && !getenv("PCR_LOCAL_NO_LDS")) {
+    static bool big = hipFuncSetAttribute(reinterpret_cast<const void *>(local_attn_lds_kernel<32>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    (void)big;
+    hipLaunchKernelGGL(local_attn_lds_kernel<32>, dim3(nhead, B), dim3(kEdgeThreads), lds32, pcr_s(stream), qkv, idx,
+                       msg, N, C, K, eps);
+    PCR_CHECK_LAUNCH();
+    return PCR_OK;
+  }
   const dim3 g((N + 31) / 32, B), blk(kEdgeThreads);
   const size_t lds = (size_t)C * 33 * 4;
   if (dh == 32) hipLaunchKernelGGL(local_attn_kernel<32>, g, blk, lds, pcr_s(stream), qkv, idx, msg, N, C, K, dh, eps);
