@@ -222,9 +222,196 @@ def train_bench(args, desc, n, bl, pairs, rank, world):
             "dtype": "f32", "data": "synthetic (randn clouds, seeded random-init weights)",
             "config": {"workload": "%s: %s" % (args.workload, desc), "pairs_per_gpu_per_step": pairs, "points": n,
                        "backbone_list": bl, "parallelism": "data parallel x%d, one %d-byte gradient bucket per step"
-                       % (world, tr.bucket.nbytes())},
+                       % (world, tr.bucket.nbytes()), "rccl_ranks": world},
             "roofline": None, "note": "training is not the headline metric; no per-kernel roofline is claimed for the "
                                       "torch-autograd dense math"}), flush=True)
+    if shard.is_dist():
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def clock_probe(iters=20000):
+    """GHz the matrix core sustains with every CU busy on f32 MFMAs (pcr_clock_probe), measured right after the
+    timed region (warm chip).  Two readings: 16-MFMA rounds counted against the constant-rate wall clock (the one
+    reported), and the shader-clock counter against the same wall clock (a cross-check)."""
+    import ctypes
+    from pcr_amd import _lib as L
+    lib = L.load()
+    n_cu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    ticks = torch.zeros((n_cu, 2), dtype=torch.int64, device="cuda")
+    khz = lib.pcr_wall_clock_khz()
+    if khz <= 0:
+        return None
+    for _ in range(2):    # first call: code load
+        L.check(lib.pcr_clock_probe(L.ptr(ticks), n_cu, iters, L.stream_ptr()), "pcr_clock_probe")
+    torch.cuda.synchronize()
+    t = ticks.cpu().double()
+    wall_s = t[:, 1] / (khz * 1e3)
+    by_mfma = (iters * 16 * 64) / wall_s / 1e9
+    by_counter = t[:, 0] / wall_s / 1e9
+    return dict(clock_ghz=float(by_mfma.median()), shader_counter_ghz=float(by_counter.median()),
+                wall_clock_khz=khz)
+
+
+def ssg_fill(model, s1):
+    """mean genuine ball-query hits / K of every SA layer on these clouds (how much of the reference's K-row work
+    the duplicate-free SA evaluation really has to do)"""
+    from mmdet3d.ops.point_ops import ball_query_cnt, furthest_point_sample, gather_points
+    xyz = s1.contiguous()
+    fill = {}
+    with torch.no_grad():
+        for i, sa in enumerate(model.backbone.SA_modules):
+            idx = furthest_point_sample(xyz, sa.num_point[0])
+            new_xyz = gather_points(xyz.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+            g = sa.groupers[0]
+            _, cnt = ball_query_cnt(g.min_radius, g.max_radius, g.sample_num, xyz, new_xyz)
+            fill["sa%d" % (i + 1)] = dict(K=g.sample_num, radius=g.max_radius,
+                                          mean_hits=float(cnt.float().mean()),
+                                          fill=float(cnt.float().mean()) / g.sample_num)
+            xyz = new_xyz
+    return fill
+
+
+def roofline_of(model, s1, s2, workload, pairs):
+    """per-launch device times (events on the launch stream); the roofline object describes the single most
+    expensive LAUNCH"""
+    prof = profile_kernels(model, s1, s2, detail=True)
+    dom = max(prof, key=lambda k: prof[k][0] / prof[k][1])
+    ms, cnt, flops, nbytes, exec_flops = prof[dom]
+    step_ms_kern = sum(v[0] for v in prof.values())
+    groups = {}
+    for k, v in prof.items():
+        groups[k.split("[")[0]] = groups.get(k.split("[")[0], 0.0) + v[0]
+    # achieved = FLOPs the launch really issues on the matrix core / its duration (the kernel skips work the
+    # reference does: the first MLP layer via per-point tables, repeated ball-query rows); the reference's op
+    # count for the same layer over the same time is reported beside it as reference_op_tflops
+    roof = dict(kernel=dom, bound="mfma", achieved=(exec_flops / cnt) / (ms / cnt * 1e-3) / 1e12,
+                peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", avg_launch_ms=ms / cnt, launches_per_step=cnt, traffic=None,
+                issued_gflop_per_launch=exec_flops / cnt / 1e9,
+                reference_op_gflop_per_launch=flops / cnt / 1e9,
+                reference_op_tflops=(flops / cnt) / (ms / cnt * 1e-3) / 1e12,
+                share_of_step=ms / step_ms_kern,
+                per_kernel_ms={k: round(v, 4) for k, v in sorted(groups.items(), key=lambda kv: -kv[1])})
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    if dom.split("[")[0] in ("knn_prefix", "fps", "ball_query", "pool_head", "gather", "edge_max"):
+        # neighbour search / sampling / pooling launches move bytes, they do not multiply: price them against
+        # HBM with their ALGORITHMIC bytes (SURVEY 8d: read xyz, write indices) -- their real limiter today is
+        # instruction issue (DESIGN.md 4.3), which this fraction makes plain
+        roof.update(bound="hbm", achieved=(nbytes / cnt) / (ms / cnt * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+        roof["frac"] = roof["achieved"] / roof["peak"]
+    # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (profiles/*_pmc.json:
+    # FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 correction 2*FETCH_SIZE + WRITE_SIZE), scaled to
+    # this batch size; null when no profile of this workload is committed
+    try:
+        import glob
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc.json" % workload)))[-1]
+        with open(path) as f:
+            pmc = json.load(f)
+        kern = pmc["_launch_to_kernel"][dom]
+        roof["traffic"] = pmc[kern]["hbm_bytes_corrected"] * pairs / pmc["_pairs_per_step"]
+        roof["traffic_source"] = "%s (%s)" % (os.path.relpath(path, ROOT), kern)
+        roof["mfma_pipe_busy_pmc"] = pmc[kern]["mfma_pipe_busy"]
+    except (OSError, KeyError, TypeError, IndexError):
+        pass
+    return roof, prof
+
+
+def add_clock(roof, clk):
+    """the clock beside frac: the spec peak assumes 2.4 GHz; under sustained MFMA load the chip runs lower"""
+    if clk is None:
+        return
+    roof["clock_ghz"] = clk["clock_ghz"]
+    roof["clock_source"] = ("pcr_clock_probe: sustained v_mfma_f32_32x32x2_f32 on all CUs right after the timed "
+                            "region, MFMA count / wall clock (shader counter cross-check %.3f GHz)"
+                            % clk["shader_counter_ghz"])
+    if roof["bound"] == "mfma":
+        roof["peak_at_clock"] = roof["peak"] * clk["clock_ghz"] / 2.4
+        roof["frac_at_clock"] = roof["achieved"] / roof["peak_at_clock"]
+
+
+def measure(workload, args, rank, world, pairs=None, cloud_kind=None, skip_repeats=True, steps=None, warmup=None):
+    """one workload: timed region + (rank 0) roofline of its dominant launch; returns (record, state_dict)"""
+    from pcr_amd import shard
+    from pcr_amd import testing as T
+    desc, kind, n, bl, dpairs = WORKLOADS[workload]
+    pairs = pairs or dpairs
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
+    model, sd = build_model(kind, bl)
+    if kind == "ssg":
+        for sa in model.backbone.SA_modules:
+            sa.skip_repeats = skip_repeats
+    # weak scaling: every rank owns `pairs` independent pairs (its own seed), already resident in HBM
+    cloud_kind = cloud_kind or ("box" if kind == "ssg" else "randn")   # ball-query radii are metric: box crops
+    s1, s2 = T.synthetic_pairs(pairs, n, seed=1234 + rank, kind=cloud_kind)
+    s1, s2 = s1.cuda(), s2.cuda()
+    with torch.no_grad():
+        dt, out = shard.timed(lambda: hot_path(model, s1, s2), steps, warmup,
+                              sync=torch.cuda.synchronize, device="cuda")
+    assert torch.isfinite(out).all()
+    rec = None
+    if rank == 0:
+        clk = clock_probe()
+        roof, _ = roofline_of(model, s1, s2, workload, pairs)
+        add_clock(roof, clk)
+        rec = dict(value=world * pairs * steps / dt, unit="pairs/s", steps=steps, warmup=warmup,
+                   ms_per_step=dt / steps * 1e3,
+                   data="synthetic (%s clouds, seeded random-init weights with non-trivial BN statistics)" % cloud_kind,
+                   config={"workload": "%s: %s" % (workload, desc), "pairs_per_gpu_per_step": pairs, "points": n,
+                           "backbone_list": bl, "parallelism": "independent pair shards x%d" % world,
+                           "rccl_ranks": world},
+                   roofline=roof)
+        if kind == "ssg":
+            rec["config"]["fill"] = ssg_fill(model, s1)
+            rec["config"]["skip_repeats"] = bool(skip_repeats)
+        else:
+            rec["config"]["fill"] = "kNN groups: every one of the K rows is a genuine neighbour (fill 1.0)"
+        if args.detail:
+            det = profile_kernels(model, s1, s2, detail=True)
+            for k, v in sorted(det.items(), key=lambda kv: -kv[1][0]):
+                print("%-52s %8.3f ms x%d  %7.2f TFLOP/s  %7.1f GB/s(alg)" % (
+                    k, v[0], v[1], v[2] / (v[0] * 1e-3) / 1e12, v[3] / (v[0] * 1e-3) / 1e9), file=sys.stderr)
+    del model, s1, s2
+    torch.cuda.empty_cache()
+    return rec, sd
+
+
+def launch_ranks(args, argv):
+    """`--gpus N` without a torchrun environment: this process has not touched the GPU (nothing here calls into HIP
+    before this point) and never will -- it starts N fresh ranks with torch.distributed.run as CHILD processes,
+    relays their output (rank 0 prints the JSON line) and exits with their status.  (Reference counterpart:
+    `torchpack dist-run -np N`, launcher_training.py:65 / tools/train.py:26.)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for ln in proc.stdout:
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    raise SystemExit(proc.wait())
+
+
+def dry_run(args):
+    """CPU / gloo rehearsal of the launch + timing protocol (tests/test_distributed.py): same rendezvous, barrier
+    bracket, max-reduce and JSON line; the step is a stand-in, no throughput is claimed."""
+    from pcr_amd import shard
+    rank, local, world = shard.init(backend="gloo")
+    x = torch.ones(64, 64)
+    dt, out = shard.timed(lambda: (x @ x).sum(), args.steps, args.warmup)
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run (no GPU work)", "value": 0.0, "unit": "pairs/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "none", "config": {"workload": "dry-run", "rccl_ranks": world,
+                                                     "backend": "gloo"}}), flush=True)
     if shard.is_dist():
         import torch.distributed as dist
         dist.barrier()
@@ -239,97 +426,68 @@ def main():
     ap.add_argument("--workload", default="ssg1024", choices=sorted(WORKLOADS),
                     help="default = BASELINE.json configs[1] (PointNet++ SSG siamese @1024); pt1024 = configs[2]")
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (default: per workload)")
+    ap.add_argument("--clouds", default=None, choices=["box", "dup", "randn"], help="synthetic cloud distribution")
+    ap.add_argument("--full-groups", action="store_true",
+                    help="SSG: evaluate all K rows of every ball-query group (no duplicate-row skipping)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the companion measurements of the default run")
     ap.add_argument("--detail", action="store_true", help="also print per-launch device times (stderr)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU/gloo rehearsal of the launch + timing protocol")
     args = ap.parse_args()
+
+    # ---- rank launch: BEFORE anything touches the GPU (torch.cuda.is_available() would) ----
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            return launch_ranks(args, sys.argv[1:])
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks"
+                         % (args.gpus, os.environ["WORLD_SIZE"]))
+    if args.dry_run:
+        return dry_run(args)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     from pcr_amd import shard
-    from pcr_amd import testing as T
     rank, local, world = shard.env_world()
     torch.cuda.set_device(local)
     shard.init(backend="nccl", device=torch.device("cuda", local))       # "nccl" is RCCL on ROCm
+    if shard.is_dist():
+        import torch.distributed as dist
+        assert dist.get_world_size() == args.gpus
 
     desc, kind, n, bl, dpairs = WORKLOADS[args.workload]
-    pairs = args.pairs or dpairs
     if kind == "pt_train":
-        return train_bench(args, desc, n, bl, pairs, rank, world)
-    model, sd = build_model(kind, bl)
-    # weak scaling: every rank owns `pairs` independent pairs (its own seed), already resident in HBM
-    cloud_kind = "box" if kind == "ssg" else "randn"     # ball-query radii are metric: vehicle-sized box crops
-    s1, s2 = T.synthetic_pairs(pairs, n, seed=1234 + rank, kind=cloud_kind)
-    s1, s2 = s1.cuda(), s2.cuda()
+        return train_bench(args, desc, n, bl, args.pairs or dpairs, rank, world)
 
-    with torch.no_grad():
-        dt, out = shard.timed(lambda: hot_path(model, s1, s2), args.steps, args.warmup,
-                              sync=torch.cuda.synchronize, device="cuda")
-    assert torch.isfinite(out).all()
-
-    line = None
+    rec, sd = measure(args.workload, args, rank, world, pairs=args.pairs or None, cloud_kind=args.clouds,
+                      skip_repeats=not args.full_groups)
+    default_run = (args.workload == "ssg1024" and not args.pairs and not args.clouds and not args.full_groups)
+    also = []
+    if default_run and world == 1 and not args.no_also:
+        # The headline workload's uniform box clouds leave the ball-query groups nearly empty (config.fill), and
+        # the ragged SA kernel skips the repeated rows.  Beside it, in the same run: the same model on clouds
+        # with 50 % duplicated points (what subsamplePC's sampling with replacement produces: fuller groups), the
+        # same model evaluating all K rows of every group, and the reference's own 1024-pt Point-Transformer
+        # config (BASELINE configs[2]; kNN groups, always full).
+        for name, wl, kw in (("ssg1024_dup", "ssg1024", dict(cloud_kind="dup")),
+                             ("ssg1024_full", "ssg1024", dict(skip_repeats=False, steps=max(4, args.steps // 4))),
+                             ("pt1024", "pt1024", dict())):
+            try:
+                r, _ = measure(wl, args, rank, world, **kw)
+                r["metric"] = "siamese pair-comparisons/sec @%d pts" % WORKLOADS[wl][2]
+            except Exception as e:      # a companion must never cost the headline line
+                r = {"error": "%s: %s" % (type(e).__name__, e)}
+            r["name"] = name
+            also.append(r)
     if rank == 0:
-        # per-launch device times (events on the launch stream); the roofline object describes the single
-        # most expensive LAUNCH; its "achieved" uses the reference's op count for that layer
-        prof = profile_kernels(model, s1, s2, detail=True)
-        dom = max(prof, key=lambda k: prof[k][0] / prof[k][1])
-        ms, cnt, flops, nbytes, exec_flops = prof[dom]
-        step_ms_kern = sum(v[0] for v in prof.values())
-        groups = {}
-        for k, v in prof.items():
-            groups[k.split("[")[0]] = groups.get(k.split("[")[0], 0.0) + v[0]
-        # achieved = FLOPs the launch really issues on the matrix core / its duration (the kernel skips work the
-        # reference does: the first MLP layer via per-point tables, repeated ball-query rows); the reference's op
-        # count for the same layer over the same time is reported beside it as reference_op_tflops
-        roof = dict(kernel=dom, bound="mfma", achieved=(exec_flops / cnt) / (ms / cnt * 1e-3) / 1e12,
-                    peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", avg_launch_ms=ms / cnt, launches_per_step=cnt, traffic=None,
-                    issued_gflop_per_launch=exec_flops / cnt / 1e9,
-                    reference_op_gflop_per_launch=flops / cnt / 1e9,
-                    reference_op_tflops=(flops / cnt) / (ms / cnt * 1e-3) / 1e12,
-                    share_of_step=ms / step_ms_kern,
-                    per_kernel_ms={k: round(v, 4) for k, v in sorted(groups.items(), key=lambda kv: -kv[1])})
-        roof["frac"] = roof["achieved"] / roof["peak"]
-        if dom.split("[")[0] in ("knn_prefix", "fps", "ball_query", "pool_head", "gather", "edge_max"):
-            # neighbour search / sampling / pooling launches move bytes, they do not multiply: price them against
-            # HBM with their ALGORITHMIC bytes (read xyz, write indices) -- their real limiter today is
-            # instruction issue, which this fraction makes plain
-            roof.update(bound="hbm", achieved=(nbytes / cnt) / (ms / cnt * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
-            roof["frac"] = roof["achieved"] / roof["peak"]
-        # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (profiles/*_pmc.json:
-        # FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 correction 2*FETCH_SIZE + WRITE_SIZE), scaled to
-        # this batch size; null when no profile of this workload is committed
-        try:
-            import glob
-            path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc.json" % args.workload)))[-1]
-            with open(path) as f:
-                pmc = json.load(f)
-            kern = pmc["_launch_to_kernel"][dom]
-            roof["traffic"] = pmc[kern]["hbm_bytes_corrected"] * pairs / pmc["_pairs_per_step"]
-            roof["traffic_source"] = "%s (%s)" % (os.path.relpath(path, ROOT), kern)
-            roof["mfma_pipe_busy_pmc"] = pmc[kern]["mfma_pipe_busy"]
-        except (OSError, KeyError, TypeError, IndexError):
-            pass
         line = {
             "metric": "siamese pair-comparisons/sec @%d pts" % n,
-            "value": world * pairs * args.steps / dt,
-            "unit": "pairs/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic (%s clouds, seeded random-init weights with non-trivial BN statistics)" % cloud_kind,
-            "config": {"workload": "%s: %s" % (args.workload, desc), "pairs_per_gpu_per_step": pairs,
-                       "points": n, "backbone_list": bl, "parallelism": "independent pair shards x%d" % world},
-            "roofline": roof,
+            "value": rec["value"], "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": rec["data"], "config": rec["config"], "roofline": rec["roofline"],
         }
-        if args.detail:
-            det = profile_kernels(model, s1, s2, detail=True)
-            for k, v in sorted(det.items(), key=lambda kv: -kv[1][0]):
-                print("%-52s %8.3f ms x%d  %7.2f TFLOP/s  %7.1f GB/s(alg)" % (
-                    k, v[0], v[1], v[2] / (v[0] * 1e-3) / 1e12, v[3] / (v[0] * 1e-3) / 1e9), file=sys.stderr)
+        if also:
+            line["also"] = also
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, sd)
         print(json.dumps(line), flush=True)

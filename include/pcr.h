@@ -304,6 +304,15 @@ int pcr_edge_max_f32(const float *ta, const float *tb, const int *idx, const flo
 int pcr_local_attn_f32(const float *qkv, const int *idx, float *msg, int B, int N, int C, int K, int nhead, float eps,
                        pcr_stream_t stream);
 
+/* ---- measurement aid (bench.py; not on the hot path) ---- */
+
+/* Sustained f32-MFMA probe: n_wg workgroups (one per CU: pass the CU count) each run iters * 16
+ * v_mfma_f32_32x32x2_f32 per wave (= iters * 1024 matrix-pipe cycles) and write ticks[2 wg] = shader-clock ticks,
+ * ticks[2 wg + 1] = constant-rate wall-clock ticks (pcr_wall_clock_khz) spent on them.  The clock the matrix core
+ * ran at is iters * 1024 / (wall ticks / rate): what `roofline.clock_ghz` in the bench line reports. */
+int pcr_wall_clock_khz(void);
+int pcr_clock_probe(unsigned long long *ticks, int n_wg, int iters, pcr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

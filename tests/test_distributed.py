@@ -70,3 +70,30 @@ def test_two_rank_gloo(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+def _run_bench(*argv, env=None):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + list(argv)
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env or dict(os.environ))
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` (no torchrun environment) starts 2 ranks itself -- here over gloo with the
+    --dry-run step -- and relays rank 0's single JSON line"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = _run_bench("--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1", env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["rccl_ranks"] == 2 and rec["steps"] == 3
+    # N = 1 stays a single process
+    r = _run_bench("--gpus", "1", "--dry-run", "--steps", "2", "--warmup", "0", env=env)
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_bench_rejects_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = _run_bench("--gpus", "4", "--dry-run", env=env)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stdout + r.stderr)
