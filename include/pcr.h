@@ -61,6 +61,20 @@ int pcr_ball_query_f32(const float *centres, const float *xyz, int *idx, int B, 
 int pcr_ball_query_cnt_f32(const float *centres, const float *xyz, int *idx, int *cnt, int B, int N, int M,
                            float min_r, float max_r, int K, pcr_stream_t stream);
 
+/* The model path's own (dormant) Python samplers / groupers, semantics of the PYTHON code rather than of the CUDA ops:
+ *
+ * farthest_point_sample (models/pointnet2_utils.py:116-137): first pick = start[b] (the reference draws it with
+ * torch.randint; NULL = 0), running distance min(.), next pick = the maximum with ties to the LOWEST index
+ * (torch.max), distance (dx^2+dy^2)+dz^2.  temp (B,N) is filled with 1e10 by the caller.  idx (B,M) int32.
+ *
+ * query_ball_point (:218-240): distances by square_distance's expanded form (-2<c,p> + |c|^2) + |p|^2 (:169-188),
+ * a point is kept unless d > radius^2 (i.e. d <= r^2, where the CUDA op uses d < r^2), first K kept indices in index
+ * order, padded with the first; a row without a hit is filled with N, as the reference's sort leaves it. */
+int pcr_fps_py_f32(const float *xyz, float *temp, const int *start, int *idx, int B, int N, int M,
+                   pcr_stream_t stream);
+int pcr_query_ball_point_f32(const float *centres, const float *xyz, int *idx, int B, int N, int M, float radius,
+                             int K, pcr_stream_t stream);
+
 /* knn_wrapper (ops/knn/src/knn.cpp:28-41, kernel knn_cuda.cu:58-94).  xyz (B,N,3), centres (B,M,3)
  * -> idx (B,M,K) int32 and dist2 (B,M,K), ascending, produced by the same max-heap + heap-sort
  * sequence as the reference (so equal distances come out in the reference's order).
@@ -171,7 +185,7 @@ int pcr_sa_mlp_f32(const pcr_sa_params *p, pcr_stream_t stream);
 long pcr_sa_tile_ws_ints(int B, int S, int K, int c2, int c3);
 
 /* Per-point linear map with POINT-major output: x (B,cin,L) channel-major (or (B,L,cin) when x_point_major)
- * -> y (B,L,cout) = W x, wp packed (cout,cin), cout <= 256.  This is the table builder of the decomposed first
+ * -> y (B,L,cout) = W x, wp packed (cout,cin), cout <= 1024 (a multiple of 4 beyond 256).  This is the table builder of the decomposed first
  * SA layer (pcr_sa_mlp_f32 runs it itself unless pq_ready is set). */
 int pcr_dense_pm_f32(const float *x, const float *wp, float *y, int B, int cin, int cout, int L,
                      int x_point_major, pcr_stream_t stream);
@@ -194,7 +208,7 @@ int pcr_dense_pm_f32(const float *x, const float *wp, float *y, int B, int cin, 
  *   residual; cloud b reads the kv image of cloud kv_index[b] (NULL => b), which is how the siamese
  *   matching head pairs clouds without copying (ReIDNet.xcorr_eff, models/ReIDNet.py:231-247).
  *   Optional fused trailing 1x1 conv (Pointnet_Backbone.cov_final, models/backbone_net.py:89,124).
- * d_model in {32,64,96,128}; c2 % 8 == 0; q_pos requires c1 == c2 == d; residual requires cout == c1. */
+ * d_model in {32,64,96,128,256,512}; c2 % 8 == 0; q_pos requires c1 == c2 == d; residual requires cout == c1. */
 typedef struct pcr_attn_params {
   int B, Lq, Sk;             /* clouds, query tokens per cloud, key tokens per cloud */
   int c1, c2, d, cout;       /* query feature dim, key feature dim, d_model, output dim */
@@ -212,6 +226,12 @@ typedef struct pcr_attn_params {
   const float *wmlp0, *wmlp2;     /* packed (2d, c1+d), packed (cout, 2d) */
   const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
   const float *wfinal, *bfinal; int cfinal;       /* optional trailing conv: packed (cfinal,cout); bias zero-padded to a multiple of 32 */
+  /* d_model 256 / 512 only (d % 64 == 0, head width a multiple of 64 and <= 256; the mul = 2 / 4 Point-Transformer
+   * configs): the kv kernel splits a cloud over d/64 workgroups, band g owning rows [64g, 64g+64) of KV.
+   * wkv_wide: d/64 packed images, image g = pcr_pack_weight_f32 of the (64 + dh, c2 + d) matrix made of rows
+   * [64g, 64g+64) (K band) and [d + hd dh, d + (hd+1) dh) (V rows of the band's head hd) of the fused projection wkv;
+   * bkv_wide: the same rows of bkv, (d/64, 64 + dh); wmerge_packed: packed image of wmerge (d,d).  NULL otherwise. */
+  const float *wkv_wide, *bkv_wide, *wmerge_packed;
   float *kv;    /* workspace (B, pcr_attn_kv_floats(d)) */
   float *out;   /* (B, cfinal ? cfinal : cout, Lq) */
 } pcr_attn_params;
@@ -236,6 +256,11 @@ int pcr_pool_head_f32(const pcr_head_params *p, pcr_stream_t stream);
 /* get_pooled_feats with pool_type='both' on its own (models/ReIDNet.py:529-532):
  * x (B,C,L) -> out (B,2C) = [max over L, mean over L]. */
 int pcr_pool_both_f32(const float *x, float *out, int B, int C, int L, pcr_stream_t stream);
+
+/* get_pooled_feats with pool_type='max' (models/ReIDNet.py:145,526-528; reid_pts_point-transformer_baseline.py):
+ * nn.MaxPool1d(window) on the permuted (B,L,C) tensor = max over windows of `window` consecutive channels of every
+ * point, floor mode.  x (B,C,L) -> out (B,L,C/window). */
+int pcr_channel_max_f32(const float *x, float *out, int B, int C, int L, int window, pcr_stream_t stream);
 
 /* Generic per-point dense layer y = act(scale * (W x) + shift) on channel-major tensors
  * x (B,cin,L) -> y (B,cout,L): 1x1 Conv1d / Linear (+ folded BatchNorm) of the PointNet encoder

@@ -115,6 +115,51 @@ def gen_pt():
         json.dump(manifest, f)
 
 
+BASE_CFG = "configs_reid/_base_/reidentifiers/reid_pts_point-transformer_baseline.py"
+MUL_CFGS = (("pt15m", "configs_reid/_base_/reidentifiers/reid_pts_point-transformer-1.5M_point-cat.py"),
+            ("pt7m", "configs_reid/_base_/reidentifiers/reid_pts_point-transformer-7M_point-cat.py"))
+
+
+def gen_baseline():
+    """reid_pts_point-transformer_baseline.py: match_type='concat', pool_type='max' (a max over the 64 CHANNELS of
+    every point, ReIDNet.py:145,526-528), LinearRes(256) head.  The config's shape_head (105 M parameters, never
+    evaluated: losses_to_use.shape is off) is left out of the fixture model."""
+    model, manifest = build(BASE_CFG, seed=0, shape_head=None)
+    s1, s2 = T.synthetic_pairs(4, 128, seed=1, kind="randn")
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        xyz1, xyz2, h1, h2 = model.siamese_forward(s1, s2)
+        pooled1 = model.get_pooled_feats(h1)
+        logits = model.match_forward_inference(h1, h2, xyz1, xyz2)
+        # the training / forward_test entry point pools through get_pooled_feats (:412-416): same numbers here
+        preds, _, _ = model.match_forward(h1, h2, xyz1, xyz2, torch.zeros(4), None, "cpu")
+    assert torch.equal(preds, logits)
+    rec = dict(h1=_np(h1), h2=_np(h2), pooled1=_np(pooled1), logits=_np(logits),
+               meta=np.array(json.dumps(dict(pairs=4, n=128, kind="randn", input_seed=1, weight_seed=0,
+                                             backbone_list=[128, 64, 32]))))
+    np.savez_compressed(os.path.join(GOLD, "pt_baseline_n128_randn.npz"), **rec)
+    with open(os.path.join(GOLD, "pt_baseline_manifest.json"), "w") as f:
+        json.dump(manifest, f)
+    print("baseline", rec["logits"], rec["pooled1"].shape)
+
+
+def gen_pt_mul():
+    """the 1.5M (mul=2) and 7M (mul=4) Point-Transformer configs (backbone_net.py:43-46,84-86: SA widths 64/128/256
+    and 128/256/512, attention d_model up to 512), 2 pairs of 128 points"""
+    for tag, cfg in MUL_CFGS:
+        model, manifest = build(cfg, seed=0)
+        s1, s2 = T.synthetic_pairs(2, 128, seed=1, kind="randn")
+        rec = record_pt(model, s1, s2)
+        keep = ("sa0_knn_sorted", "sa1_knn_sorted", "sa2_knn_sorted", "sa0_mlp", "sa0_out", "sa1_out", "sa2_mlp",
+                "sa2_out", "fp2_out", "fp1_out", "fp0_out", "h1", "h2", "x2_o1", "pooled", "logits")
+        rec = {k: v for k, v in rec.items() if k in keep}
+        rec["meta"] = np.array(json.dumps(dict(pairs=2, n=128, backbone_list=[128, 64, 32], kind="randn",
+                                               input_seed=1, weight_seed=0)))
+        np.savez_compressed(os.path.join(GOLD, tag + "_n128_randn.npz"), **rec)
+        with open(os.path.join(GOLD, tag + "_manifest.json"), "w") as f:
+            json.dump(manifest, f)
+        print(tag, "params", sum(int(np.prod(m[1])) for m in manifest), "logits", rec["logits"])
+
+
 def gen_pointnet():
     model, manifest = build(PN_CFG, seed=0)
     s1, s2 = T.synthetic_pairs(2, 256, seed=1, kind="randn")
@@ -297,7 +342,15 @@ if __name__ == "__main__":
     if "--only-dgcnn" in sys.argv:
         gen_dgcnn()
         sys.exit(0)
+    if "--only-baseline" in sys.argv:
+        gen_baseline()
+        sys.exit(0)
+    if "--only-mul" in sys.argv:
+        gen_pt_mul()
+        sys.exit(0)
     if "--only-small" not in sys.argv:
+        gen_baseline()
+        gen_pt_mul()
         gen_dgcnn()
         gen_xcorr()
         gen_pt()

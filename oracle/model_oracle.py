@@ -159,6 +159,37 @@ def square_distance(src, dst):
     return d
 
 
+def farthest_point_sample_py(xyz, npoint, start):
+    """farthest_point_sample (pointnet2_utils.py:116-137) with the reference's torch.randint start replaced by `start`"""
+    B, N, _ = xyz.shape
+    centroids = torch.zeros(B, npoint, dtype=torch.long)
+    distance = torch.ones(B, N) * 1e10
+    farthest = start.long().clone()
+    batch = torch.arange(B)
+    for i in range(npoint):
+        centroids[:, i] = farthest
+        centroid = xyz[batch, farthest, :].view(B, 1, 3)
+        dist = torch.sum((xyz - centroid) ** 2, -1)
+        mask = dist < distance
+        distance[mask] = dist[mask]
+        farthest = torch.max(distance, -1)[1]
+    return centroids
+
+
+def query_ball_point_py(radius, nsample, xyz, new_xyz, return_dist=False):
+    """query_ball_point (pointnet2_utils.py:218-240)"""
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    group_idx = torch.arange(N).view(1, 1, N).repeat(B, S, 1)
+    sqrdists = square_distance(new_xyz, xyz)
+    group_idx[sqrdists > radius ** 2] = N
+    group_idx = group_idx.sort(dim=-1)[0][:, :, :nsample]
+    first = group_idx[:, :, 0].view(B, S, 1).repeat(1, 1, nsample)
+    mask = group_idx == N
+    group_idx[mask] = first[mask]
+    return (group_idx, sqrdists) if return_dist else group_idx
+
+
 def knn_prefix(xyz, s, k):
     """first-s centres, k nearest of all N by full argsort (pointnet2_utils.py:190-216)"""
     d = square_distance(xyz[:, :s], xyz)
@@ -173,15 +204,18 @@ def _gather_rows(points, idx):
     return torch.gather(points, 1, flat).view(B, S, K, C)
 
 
-def sa_edge_layer(p, xyz, feats, s, k, stages=None, tag=""):
+def sa_edge_layer(p, xyz, feats, s, k, stages=None, tag="", centre_idx=None, group_idx=None):
     """One PointNetSetAbstractionEdgeSA (pointnet2_utils.py:333-360) with RANDOM (prefix)
-    sampling and kNN grouping.  xyz [B,N,3]; feats [B,D,N] or None -> (new_xyz, [B,D',S])"""
-    idx = knn_prefix(xyz, s, k)
-    new_xyz = xyz[:, :s]
+    sampling and kNN grouping (or, for the dormant branches of sample_and_group_edge :262-272, the given centre
+    indices [B,S] and group indices [B,S,K]).  xyz [B,N,3]; feats [B,D,N] or None -> (new_xyz, [B,D',S])"""
+    idx = knn_prefix(xyz, s, k) if group_idx is None else group_idx
+    if centre_idx is None:
+        centre_idx = torch.arange(s).repeat(xyz.shape[0], 1)
+    new_xyz = torch.gather(xyz, 1, centre_idx.unsqueeze(-1).expand(-1, -1, 3))
     g = _gather_rows(xyz, idx) - new_xyz.unsqueeze(2)
     if feats is not None:
         pts = feats.permute(0, 2, 1)
-        centre = pts[:, :s].unsqueeze(2)
+        centre = torch.gather(pts, 1, centre_idx.unsqueeze(-1).expand(-1, -1, pts.shape[-1])).unsqueeze(2)
         nb = _gather_rows(pts, idx)
         g = torch.cat([g, centre.expand(-1, -1, k, -1), nb - centre], dim=-1)
     x = g.permute(0, 3, 1, 2)
@@ -266,6 +300,24 @@ def pointnet_encoder(p, x):
 def pool_both(x):
     """get_pooled_feats, pool_type='both' (ReIDNet.py:529-532). x [B,C,L] -> [B,2C]"""
     return torch.cat([x.max(dim=2)[0], x.mean(dim=2)], dim=1)
+
+
+def pool_channel_max(x, window):
+    """get_pooled_feats, pool_type='max' (ReIDNet.py:145,526-528): nn.MaxPool1d(window) on the permuted [B,N,C]
+    tensor, i.e. a max over windows of `window` channels of every point.  x [B,C,N] -> [B,N] when C == window"""
+    return F.max_pool1d(x.permute(0, 2, 1), window).squeeze(-1)
+
+
+def pt_pairs_concat(sd, s1, s2, backbone_list, window=64, head_ng=32, stages=None):
+    """reid_pts_point-transformer_baseline.py: match_type='concat' + pool_type='max' (ReIDNet.py:415-419, 455-457)"""
+    b = s1.shape[0]
+    xyz, h = pt_backbone(_sub(sd, "backbone."), torch.cat([s1, s2], 0), backbone_list)
+    cat = torch.cat([pool_channel_max(h[:b], window), pool_channel_max(h[b:], window)], dim=1)
+    x = linear_res(_linres_params(sd, "match_head.0.", head_ng), cat)
+    logits = F.linear(x, sd["match_head.1.weight"], sd["match_head.1.bias"]).squeeze(1)
+    if stages is not None:
+        stages.update(h1=h[:b], h2=h[b:], pooled1=cat[:, :cat.shape[1] // 2], logits=logits)
+    return logits
 
 
 def match(sd, h1, xyz1, h2, xyz2, stages=None, head_ng=8):

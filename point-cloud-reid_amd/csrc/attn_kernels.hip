@@ -218,7 +218,111 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))
   attn_kv_body<TB, NR, WSEL, NTW>(a);
 }
 
-// One workgroup per (query cloud, tile of T query tokens), T = 128 / 64 / 32 for d = 32 / 64 / 128.
+// d_model 256 / 512 (the 1.5M / 7M Point-Transformer configs, backbone_net.py:43-46,84-86): the per-cloud KV matrix
+// no longer fits one workgroup's accumulators, so a cloud is split over d / 64 workgroups.  Workgroup (band g, cloud b)
+// owns the rows dd in [64 g, 64 g + 64) of KV -- one head, since the head width is a multiple of 64 -- and therefore
+// needs the K rows of its band and the V rows of its head: the host gathers exactly those rows of the fused K/V
+// projection into one packed image per band (wkv_wide, 64 + dh couts), so the projection is one in-place dense call
+// as in the narrow kernel.  With a whole head's V columns at hand the merge fold M[:, band] = Wm[:, head] KV_band^T
+// is complete inside the workgroup (no cross-workgroup reduction) and runs on the matrix core as well.
+//   NRW: cout-block rounds of the 64 + dh row projection (2 for dh = 128, 3 for dh = 256)
+template <int NRW>
+__global__ __launch_bounds__(kThreads) void attn_kv_wide_kernel(AttnArgs a) {
+  constexpr int TB = 1, T = 32, RP = 33, BAND = 64, RPK = BAND + 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const pcr_attn_params &p = a.p;
+  const int d = p.d, c2 = p.c2, dh = d / p.nhead;
+  const int g = blockIdx.x, hd = (g * BAND) / dh;
+  const int OPW = BAND + dh;                 // couts of this band's projection (multiple of 32)
+  float *XH = smem;                          // [c2 + d][RP]: key features ; hidden -> rows [0,64) K band, [64,64+dh) V head
+  float *KB = XH, *VB = XH + BAND * RP;
+  float *P = XH + (c2 + d) * RP;
+  float *s_w0 = P + 3 * RP, *s_b0 = s_w0 + 3 * d;
+  float *s_ks = s_b0 + d;                    // [256] partial key sums
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const size_t b = blockIdx.y;
+  for (int e = tid; e < 3 * d; e += kThreads) s_w0[e] = p.pos0_w[e];
+  for (int e = tid; e < d; e += kThreads) s_b0[e] = p.pos0_b[e];
+  const float *feat = p.feat_k + b * c2 * p.Sk;
+  const float *xyz = p.xyz_k + b * p.Sk * 3;
+  const float sk = (float)p.Sk;
+  const float *wband = p.wkv_wide + (size_t)g * ((size_t)ceil8(c2 + d) * OPW);
+  const float *bband = p.bkv_wide + (size_t)g * OPW;
+  const int nj = dh >> 5, nT = 2 * nj;       // KV tiles (ib in {0,1}) x (jb < dh/32): 8 or 16, up to 4 per wave
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+  const int krow = tid & (BAND - 1), kpart = tid >> 6;   // four partial sums per K row
+  float ksum = 0.f;
+  for (int t0 = 0; t0 < p.Sk; t0 += T) {
+    const int valid = p.Sk - t0;
+    load_tile(XH, RP, feat, c2, c2, p.Sk, t0, T);
+    load_xyz3(P, RP, xyz, p.Sk, t0, T);
+    __syncthreads();
+    pos_hidden(XH + c2 * RP, RP, P, s_w0, s_b0, d, T);
+    __syncthreads();
+    tile_dense2<TB, NRW, 0, true>(XH, c2 + d, wband, OPW, true,
+                                  [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
+      const int t = tb * 32 + l31;
+      float *dst = XH + (cb * 32 + 4 * h) * RP + t;
+      const bool live = t < valid;
+      if (cb * 32 < BAND) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) dst[((r & 3) + 8 * (r >> 2)) * RP] = live ? elu1(acc[r]) : 0.f;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) dst[((r & 3) + 8 * (r >> 2)) * RP] = live ? acc[r] / sk : 0.f;
+      }
+    }, bband);
+    __syncthreads();
+    {
+      const float *row = KB + krow * RP;
+      for (int t = kpart; t < T; t += 4) ksum += row[t];
+    }
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int item = wave + 4 * it;
+      if (item < nT) {
+        const int ib = item / nj, jb = item - ib * nj;
+        const float *ap = KB + (ib * 32 + l31) * RP + h;
+        const float *bp = VB + (jb * 32 + l31) * RP + h;
+#pragma unroll 4
+        for (int ks = 0; ks < T / 2; ks++)
+          acc[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc[it], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // KV band, transposed: KVt [v (dh)][dd (64) + 1] = the B operand (k = v, token = dd) of the merge fold
+  float *KVt = smem;
+  s_ks[tid] = ksum;
+#pragma unroll
+  for (int it = 0; it < 4; it++) {
+    const int item = wave + 4 * it;
+    if (item < nT) {
+      const int ib = item / nj, jb = item - ib * nj;
+      const int v = jb * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; r++) KVt[v * RPK + ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = acc[it][r];
+    }
+  }
+  __syncthreads();
+  float *kv = p.kv + b * ((size_t)d * d + d);
+  if (tid < BAND) kv[(size_t)d * d + g * BAND + tid] = s_ks[tid] + s_ks[64 + tid] + s_ks[128 + tid] + s_ks[192 + tid];
+  // M[o][dd] = sum_{v < dh} Wm[o][hd dh + v] KV[dd][v]: dense over k = v with the k-blocks [hd dh / 8, +dh / 8) of the
+  // packed merge weights; stored in the packed (d,d) layout the apply kernel reads as an A operand
+  const float *wm = p.wmerge_packed + (size_t)(hd * dh / 8) * d * 8;
+  tile_dense(KVt, dh, RPK, 2, wm, d, [&](float m, int o, int t) {
+    const int dd = g * BAND + t;
+    const int kb = dd >> 3, rem = dd & 7;
+    kv[(((size_t)kb * d + o) * 2 + (rem & 1)) * 4 + (rem >> 1)] = m;
+  });
+}
+
+// One workgroup per (query cloud, tile of T query tokens), T = 128 / 64 / 32 for d = 32 / 64 / 128 (32 beyond).
 // ONE LDS buffer U of max(c1 + d, 2d, cout, cfinal) rows, every dense phase in place (barrier between its
 // k-loop and its epilogue), so a d = 64 tile is 33 KB and four workgroups share a CU:
 //   rows [0,c1) query features x, rows [c1,c1+d) position hidden h  --Q-->  rows [c1,c1+d) = elu(.)+1
@@ -330,8 +434,9 @@ __global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
 
 static int attn_check(const pcr_attn_params &p) {
   if (p.B < 0 || p.Lq < 1 || p.Sk < 1 || p.c1 < 1 || p.c2 < 1 || p.cout < 1 || p.nhead < 1) return 1;
-  if (p.d < 32 || p.d > 128 || (p.d & 31) || p.d % p.nhead) return 1;  // d_model in {32,64,96,128}
-  if ((p.c2 & 7) || p.cout > 256 || p.cfinal > 256) return 1;
+  if (p.d < 32 || p.d > 512 || (p.d & 31) || p.d % p.nhead) return 1;  // d_model in {32,64,96,128} or wide (below)
+  if (p.d > 128 && ((p.d & 63) || ((p.d / p.nhead) & 63) || p.d / p.nhead > 256)) return 1;   // wide: heads of 64 n <= 256
+  if ((p.c2 & 7) || p.cout > 512 || p.cfinal > 512) return 1;
   if (!p.feat_q || !p.feat_k || !p.xyz_k || !p.kv || !p.pos0_w || !p.pos0_b || !p.wq || !p.bq || !p.wkv ||
       !p.bkv || !p.wmerge || !p.wmlp0 || !p.wmlp2 || !p.ln1_g || !p.ln1_b || !p.ln2_g || !p.ln2_b)
     return 1;
@@ -344,10 +449,25 @@ static int attn_check(const pcr_attn_params &p) {
 PCR_EXPORT int pcr_attn_kv_f32(const pcr_attn_params *pp, pcr_stream_t stream) {
   if (!pp || attn_check(*pp)) return PCR_ERR_INVALID;
   if (pp->B == 0) return PCR_OK;
-  if (pp->c2 < pp->d) return PCR_ERR_INVALID;   // the in-place K/V projection needs 2d <= c2 + d rows
   AttnArgs a;
   a.p = *pp;
   const int d = pp->d;
+  if (d > 128) {   // wide: d / 64 workgroups per cloud (attn_kv_wide_kernel)
+    if (!pp->wkv_wide || !pp->bkv_wide || !pp->wmerge_packed || pp->B > 65535) return PCR_ERR_INVALID;
+    const int dh = d / pp->nhead;
+    size_t lds = ((size_t)(pp->c2 + d + 3) * 33 + 4 * d + kThreads) * sizeof(float);
+    const size_t lds2 = (size_t)dh * 65 * sizeof(float);
+    if (lds2 > lds) lds = lds2;
+    if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
+    static bool okw = allow_big_lds(attn_kv_wide_kernel<2>) && allow_big_lds(attn_kv_wide_kernel<3>);
+    (void)okw;
+    dim3 g(d / 64, pp->B), blk(kThreads);
+    if (64 + dh <= 256) hipLaunchKernelGGL((attn_kv_wide_kernel<2>), g, blk, lds, pcr_s(stream), a);
+    else hipLaunchKernelGGL((attn_kv_wide_kernel<3>), g, blk, lds, pcr_s(stream), a);
+    PCR_CHECK_LAUNCH();
+    return PCR_OK;
+  }
+  if (pp->c2 < pp->d) return PCR_ERR_INVALID;   // the in-place K/V projection needs 2d <= c2 + d rows
   const int tb = d <= 64 ? 2 : 1, RP = 32 * tb + 1;
   size_t lds = (size_t)(pp->c2 + d + 3) * RP + 4 * d;
   const size_t lds2 = (size_t)d * (d + 1) + d;
@@ -384,7 +504,8 @@ PCR_EXPORT int pcr_attn_apply_f32(const pcr_attn_params *pp, pcr_stream_t stream
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
   static bool ok = allow_big_lds(attn_apply_kernel<1, 2>) && allow_big_lds(attn_apply_kernel<2, 1>) &&
                    allow_big_lds(attn_apply_kernel<2, 2>) && allow_big_lds(attn_apply_kernel<4, 1>) &&
-                   allow_big_lds(attn_apply_kernel<4, 2>);
+                   allow_big_lds(attn_apply_kernel<4, 2>) && allow_big_lds(attn_apply_kernel<1, 4>) &&
+                   allow_big_lds(attn_apply_kernel<1, 8>);
   (void)ok;
   dim3 g((p.Lq + T - 1) / T, p.B), blk(kThreads);
   hipStream_t st = pcr_s(stream);
@@ -396,7 +517,12 @@ PCR_EXPORT int pcr_attn_apply_f32(const pcr_attn_params *pp, pcr_stream_t stream
     if (wide) hipLaunchKernelGGL((attn_apply_kernel<2, 2>), g, blk, lds, st, a);
     else hipLaunchKernelGGL((attn_apply_kernel<2, 1>), g, blk, lds, st, a);
   } else {
-    hipLaunchKernelGGL((attn_apply_kernel<1, 2>), g, blk, lds, st, a);
+    // cout blocks of the widest layer: up to 8 -> two rounds per wave, up to 16 -> four, up to 32 (d_model 512) -> eight
+    int widest = 2 * p.d > p.cout ? 2 * p.d : p.cout;
+    if (p.cfinal > widest) widest = p.cfinal;
+    if (widest > 512) hipLaunchKernelGGL((attn_apply_kernel<1, 8>), g, blk, lds, st, a);
+    else if (widest > 256) hipLaunchKernelGGL((attn_apply_kernel<1, 4>), g, blk, lds, st, a);
+    else hipLaunchKernelGGL((attn_apply_kernel<1, 2>), g, blk, lds, st, a);
   }
   PCR_CHECK_LAUNCH();
   return PCR_OK;

@@ -105,6 +105,23 @@ __global__ __launch_bounds__(kThreads) void pool_both_kernel(const float *__rest
   }
 }
 
+// get_pooled_feats with pool_type='max' (models/ReIDNet.py:145,526-528): nn.MaxPool1d(window) applied to the PERMUTED
+// (B,L,C) tensor, i.e. a max over windows of `window` consecutive CHANNELS of every point (floor mode: a trailing
+// partial window is dropped).  x (B,C,L) channel-major -> out (B,L,G), G = C / window.  Thread = point: the loads of a
+// wave are 256 contiguous bytes per channel.
+__global__ __launch_bounds__(kThreads) void channel_max_kernel(const float *__restrict__ x, float *__restrict__ out,
+                                                               int C, int L, int window, int G) {
+  const size_t b = blockIdx.y;
+  const int l = blockIdx.x * kThreads + threadIdx.x;
+  if (l >= L) return;
+  const float *xp = x + b * C * L + l;
+  for (int g = 0; g < G; g++) {
+    float m = -INFINITY;
+    for (int c = g * window; c < (g + 1) * window; c++) m = fmaxf(m, xp[(size_t)c * L]);
+    out[(b * L + l) * G + g] = m;
+  }
+}
+
 // ------------------------------------------------------------------- generic dense ----
 // y (B,cout,L) = act(scale * (W x) + shift) for x (B,cin,L); the whole cin extent of a token tile
 // sits in LDS, each workgroup produces one chunk of up to 256 output channels (grid.z) and stores
@@ -432,6 +449,16 @@ PCR_EXPORT int pcr_pack_bmm_f32(const float *t, float *wp_per_cloud, int B, int 
   size_t blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(pack_bmm_kernel, dim3((unsigned)blocks), dim3(256), 0, pcr_s(stream), t, wp_per_cloud, B, k);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_channel_max_f32(const float *x, float *out, int B, int C, int L, int window, pcr_stream_t stream) {
+  if (!x || !out || B < 0 || C < 1 || L < 1 || window < 1 || window > C) return PCR_ERR_INVALID;
+  if (B == 0) return PCR_OK;
+  if (B > 65535) return PCR_ERR_INVALID;
+  hipLaunchKernelGGL(channel_max_kernel, dim3((L + kThreads - 1) / kThreads, B), dim3(kThreads), 0, pcr_s(stream), x, out,
+                     C, L, window, C / window);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }

@@ -21,10 +21,12 @@ namespace {
 constexpr int kFpsPpt = 4;        // candidates per thread held in registers (N <= 4*block)
 constexpr int kFpsLdsPts = 4096;  // clouds up to this size are staged in LDS (48 KiB)
 
+// `start` / `pytie`: the Python twin of the model path (models/pointnet2_utils.py:116-137): the first pick is start[cloud]
+// (the reference draws it with torch.randint) and equal distances go to the LOWEST index (torch.max).
 template <bool DIST, bool REG>
 __global__ void fps_kernel(const float *__restrict__ data, float *__restrict__ temp,
                            int *__restrict__ idxs, int n, int m, int block, int logb,
-                           int stage_xyz) {
+                           int stage_xyz, const int *__restrict__ start, int pytie) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned long long *skey = reinterpret_cast<unsigned long long *>(smem_raw);  // [2][16]
   float *sx = reinterpret_cast<float *>(smem_raw + 256);
@@ -55,9 +57,9 @@ __global__ void fps_kernel(const float *__restrict__ data, float *__restrict__ t
   __syncthreads();
 
   const uint32_t rev = logb ? (__brev((uint32_t)tid) >> (32 - logb)) : 0u;
-  const uint32_t tie = (uint32_t)(block - 1) - rev;  // larger = preferred by the merge tree
-  int old = 0;
-  if (tid == 0) idxs[0] = 0;
+  const uint32_t tie = pytie ? 0u : (uint32_t)(block - 1) - rev;  // larger = preferred by the merge tree
+  int old = start ? start[cloud] : 0;
+  if (tid == 0) idxs[0] = old;
 
   for (int j = 1; j < m; j++) {
     float x1 = 0.f, y1 = 0.f, z1 = 0.f;
@@ -96,7 +98,7 @@ __global__ void fps_kernel(const float *__restrict__ data, float *__restrict__ t
     unsigned long long key = 0ull;
     if (tid < block)
       key = ((unsigned long long)pcr_orderable(best + 0.0f) << 32) |
-            (unsigned long long)((tie << 22) | (uint32_t)besti);
+            (unsigned long long)((tie << 22) | (pytie ? 0x3FFFFFu - (uint32_t)besti : (uint32_t)besti));
     key = pcr_wave_max_u64(key);
     if (nw > 1) {
       unsigned long long *slot = skey + (j & 1) * 16;
@@ -111,6 +113,7 @@ __global__ void fps_kernel(const float *__restrict__ data, float *__restrict__ t
       }
     }
     old = (int)(key & 0x3FFFFFull);
+    if (pytie) old = 0x3FFFFF - old;
     if (tid == 0) idxs[j] = old;
   }
 
@@ -364,11 +367,11 @@ int fps_launch(bool dist, const float *data, float *temp, int *idx, int B, int N
   size_t lds = 256 + (stage ? (size_t)3 * N * sizeof(float) : 0);
   dim3 g(B), b(threads);
   if (dist) {
-    if (reg) hipLaunchKernelGGL((fps_kernel<true, true>), g, b, lds, st, data, temp, idx, N, M, block, logb, stage);
-    else hipLaunchKernelGGL((fps_kernel<true, false>), g, b, lds, st, data, temp, idx, N, M, block, logb, stage);
+    if (reg) hipLaunchKernelGGL((fps_kernel<true, true>), g, b, lds, st, data, temp, idx, N, M, block, logb, stage, (const int *)nullptr, 0);
+    else hipLaunchKernelGGL((fps_kernel<true, false>), g, b, lds, st, data, temp, idx, N, M, block, logb, stage, (const int *)nullptr, 0);
   } else {
-    if (reg) hipLaunchKernelGGL((fps_kernel<false, true>), g, b, lds, st, data, temp, idx, N, M, block, logb, stage);
-    else hipLaunchKernelGGL((fps_kernel<false, false>), g, b, lds, st, data, temp, idx, N, M, block, logb, stage);
+    if (reg) hipLaunchKernelGGL((fps_kernel<false, true>), g, b, lds, st, data, temp, idx, N, M, block, logb, stage, (const int *)nullptr, 0);
+    else hipLaunchKernelGGL((fps_kernel<false, false>), g, b, lds, st, data, temp, idx, N, M, block, logb, stage, (const int *)nullptr, 0);
   }
   PCR_CHECK_LAUNCH();
   return PCR_OK;
@@ -381,6 +384,10 @@ int fps_launch(bool dist, const float *data, float *temp, int *idx, int B, int N
 // padding (first hit) once at the end.
 constexpr int kBqTile = 1024;
 
+// PY: the Python twin query_ball_point (models/pointnet2_utils.py:218-240): square_distance's expanded form
+// (-2 <c,p> + |c|^2) + |p|^2 (:169-188; the dot product is summed left to right here, the reference leaves that order
+// to its matmul), a point is kept unless d > r^2, and a row without any hit is filled with N as in the reference.
+template <bool PY>
 __global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict__ centres,
                                                          const float *__restrict__ xyz,
                                                          int *__restrict__ idx, int n, int m,
@@ -398,7 +405,13 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict
   }
   int *out = idx + (b * m + (valid ? p : 0)) * K;
   const float *cloud = xyz + b * n * 3;
-  int cnt = 0, first = 0;
+  int cnt = 0, first = PY ? n : 0;
+  float cc = 0.f;
+  if (PY) {
+    const float a2 = cx * cx, b2 = cy * cy, c2 = cz * cz;
+    const float s2 = a2 + b2;
+    cc = s2 + c2;
+  }
   bool done = !valid;
   for (int base = 0; base < n; base += kBqTile) {
     int tn = n - base < kBqTile ? n - base : kBqTile;
@@ -407,8 +420,24 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict
     __syncthreads();
     if (!done) {
       for (int k = 0; k < tn; k++) {
-        float d2 = pcr_sqdist3(tile[3 * k], tile[3 * k + 1], tile[3 * k + 2], cx, cy, cz);
-        if (d2 == 0.f || (d2 >= min_r2 && d2 < max_r2)) {
+        bool hit;
+        if (PY) {
+          const float x = tile[3 * k], y = tile[3 * k + 1], z = tile[3 * k + 2];
+          const float m0 = cx * x, m1 = cy * y, m2 = cz * z;
+          const float dot0 = m0 + m1;
+          const float dot = dot0 + m2;
+          const float x2 = x * x, y2 = y * y, z2 = z * z;
+          const float p0 = x2 + y2;
+          const float pp = p0 + z2;
+          const float t0 = -2.0f * dot;
+          const float t1 = t0 + cc;
+          const float d = t1 + pp;
+          hit = !(d > max_r2);
+        } else {
+          const float d2 = pcr_sqdist3(tile[3 * k], tile[3 * k + 1], tile[3 * k + 2], cx, cy, cz);
+          hit = d2 == 0.f || (d2 >= min_r2 && d2 < max_r2);
+        }
+        if (hit) {
           if (cnt == 0) first = base + k;
           out[cnt] = base + k;
           if (++cnt >= K) { done = true; break; }
@@ -496,7 +525,7 @@ static void ball_query_launch(const float *centres, const float *xyz, int *idx, 
     else
       hipLaunchKernelGGL(ball_query_reg_kernel<16>, grid, blk, 0, st, centres, xyz, idx, N, M, min_r2, max_r2, K, cnt, cpw);
   } else {
-    hipLaunchKernelGGL(ball_query_kernel, dim3((M + 255) / 256, B), dim3(256), 0, st, centres, xyz, idx, N, M,
+    hipLaunchKernelGGL(ball_query_kernel<false>, dim3((M + 255) / 256, B), dim3(256), 0, st, centres, xyz, idx, N, M,
                        min_r2, max_r2, K, cnt);
   }
 }
@@ -961,7 +990,7 @@ __global__ __launch_bounds__(NT) void knn_prefix_lds_kernel(const float *__restr
 }  // namespace
 
 // ------------------------------------------------------------------------------ C ABI ----
-PCR_EXPORT int pcr_abi_version(void) { return 4; }
+PCR_EXPORT int pcr_abi_version(void) { return 5; }
 
 PCR_EXPORT const char *pcr_status_string(int status) {
   switch (status) {
@@ -980,6 +1009,36 @@ PCR_EXPORT int pcr_fps_f32(const float *xyz, float *temp, int *idx, int B, int N
 PCR_EXPORT int pcr_fps_dist_f32(const float *dist, float *temp, int *idx, int B, int N, int M,
                                 pcr_stream_t stream) {
   return fps_launch(true, dist, temp, idx, B, N, M, pcr_s(stream));
+}
+
+PCR_EXPORT int pcr_fps_py_f32(const float *xyz, float *temp, const int *start, int *idx, int B, int N, int M,
+                              pcr_stream_t stream) {
+  if (!xyz || !temp || !idx || B < 0 || N < 1 || N >= (1 << 22) || M < 0) return PCR_ERR_INVALID;
+  if (B == 0 || M == 0) return PCR_OK;
+  int logb = 0;
+  while ((2 << logb) <= N && logb < 10) logb++;
+  const int block = 1 << logb;
+  const int threads = block < 64 ? 64 : block;
+  const bool reg = N <= kFpsPpt * block;
+  const int stage = N <= kFpsLdsPts ? 1 : 0;
+  const size_t lds = 256 + (stage ? (size_t)3 * N * sizeof(float) : 0);
+  if (reg) hipLaunchKernelGGL((fps_kernel<false, true>), dim3(B), dim3(threads), lds, pcr_s(stream), xyz, temp, idx, N, M,
+                              block, logb, stage, start, 1);
+  else hipLaunchKernelGGL((fps_kernel<false, false>), dim3(B), dim3(threads), lds, pcr_s(stream), xyz, temp, idx, N, M,
+                          block, logb, stage, start, 1);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_query_ball_point_f32(const float *centres, const float *xyz, int *idx, int B, int N, int M,
+                                        float radius, int K, pcr_stream_t stream) {
+  if (!centres || !xyz || !idx || B < 0 || N < 1 || M < 0 || K < 1) return PCR_ERR_INVALID;
+  if (B == 0 || M == 0) return PCR_OK;
+  if (B > 65535) return PCR_ERR_INVALID;
+  hipLaunchKernelGGL(ball_query_kernel<true>, dim3((M + 255) / 256, B), dim3(256), 0, pcr_s(stream), centres, xyz, idx,
+                     N, M, 0.f, radius * radius, K, (int *)nullptr);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
 }
 
 PCR_EXPORT int pcr_ball_query_f32(const float *centres, const float *xyz, int *idx, int B, int N,

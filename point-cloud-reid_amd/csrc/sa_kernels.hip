@@ -845,19 +845,24 @@ template <int NR>
 __global__ __launch_bounds__(kThreads) void dense_pm_kernel(DensePmArgs a) {
   constexpr int TB = 2, T = 64, RP = 65;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // couts beyond 256 (the tables of 256- / 512-channel SA layers) go in windows of 256 along grid.z: the window's rows
+  // of the packed image start 8 floats per cout further in, the k-block stride stays that of the whole image
   const int cinP = ceil8(a.cin), cout = a.cout;
-  float *X = smem;   // [max(cinP, ceil32(cout))][RP]
+  const int w0 = blockIdx.z * 256;
+  const int wc = cout - w0 < 256 ? cout - w0 : 256;
+  float *X = smem;   // [max(cinP, ceil32(wc))][RP]
   const size_t b = blockIdx.y;
   const int t0 = blockIdx.x * T;
   if (a.x_pm) load_tile_pm(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
   else load_tile(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
   __syncthreads();
-  tile_dense2<TB, NR>(X, cinP, a.wp, ceil32(cout), true, [&](float v, int o, int t) { X[o * RP + t] = v; });
+  tile_dense2<TB, NR>(X, cinP, a.wp + (size_t)w0 * 8, ceil32(wc), true, [&](float v, int o, int t) { X[o * RP + t] = v; },
+                      nullptr, nullptr, DenseNoHook(), ceil32(cout));
   __syncthreads();
-  float *out = a.y + (b * a.L + t0) * (size_t)cout;
+  float *out = a.y + (b * a.L + t0) * (size_t)cout + w0;
   if ((cout & 3) == 0) {
     // 16-byte stores; item e = (token e / Q, cout quad e % Q) advances by kThreads: one division, then increments
-    const int Q = cout >> 2, total = Q * T;
+    const int Q = wc >> 2, total = Q * T;
     const int dt = kThreads / Q, dq = kThreads - dt * Q;
     int t = threadIdx.x / Q, q = threadIdx.x - t * Q;
     for (int e = threadIdx.x; e < total; e += kThreads) {
@@ -870,8 +875,8 @@ __global__ __launch_bounds__(kThreads) void dense_pm_kernel(DensePmArgs a) {
       if (q >= Q) { q -= Q; t++; }
     }
   } else {
-    for (int e = threadIdx.x; e < cout * T; e += kThreads) {
-      const int t = e / cout, c = e - t * cout;
+    for (int e = threadIdx.x; e < wc * T; e += kThreads) {
+      const int t = e / wc, c = e - t * wc;
       if (t0 + t < a.L) out[(size_t)t * cout + c] = X[c * RP + t];
     }
   }
@@ -900,7 +905,10 @@ static int sa2_launch_tb(const Sa2Args &a, int nr, int nr2, int wsel, bool maxe,
   // resident weight fragments for 32-channel layers (2 x 16 VGPRs).  For 64-channel layers the 2 x 32 VGPRs cost
   // more residency than the saved L2 round trips are worth (measured: 6.4 -> 7.9 ms on the 64/64/64 layer).
   const bool narrow4 = a.c1 <= 32 && a.c2 <= 32;
-  if (wsel == 4 && narrow4) sa2_launch_one<TB, 1, 4, 4, 1, 4>(a, maxe, lds, st, grid);
+  if (nr == 4) {
+    if constexpr (TB <= 2) sa2_launch_one<TB, 4, 1, 1, 4>(a, maxe, lds, st, grid);
+    else return -1;
+  } else if (wsel == 4 && narrow4) sa2_launch_one<TB, 1, 4, 4, 1, 4>(a, maxe, lds, st, grid);
   else if (wsel == 4) sa2_launch_one<TB, 1, 4, 4>(a, maxe, lds, st, grid);
   else if (wsel == 2) sa2_launch_one<TB, 1, 2, 2>(a, maxe, lds, st, grid);
   else if (wsel == 1 && nr == 1) sa2_launch_one<TB, 1, 1, 1>(a, maxe, lds, st, grid);
@@ -940,13 +948,13 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   hipStream_t st = pcr_s(st_);
   if (!p.wa || !p.wps[0] || !p.wps[1] || !p.shift_pad[0] || !p.shift_pad[1] || (p.D && (!p.wpq || !p.pq_ws)))
     return -1;
-  if ((p.c1 & 7) || p.c1 > 256 || p.c2 > 256 || p.c3 > 256) return -1;
+  if ((p.c1 & 7) || p.c1 > 512 || p.c2 > 512 || p.c3 > 512) return -1;
   const int pqw = p.mode == 0 ? 2 * p.c1 : p.c1;
-  if (p.D && pqw > 256) return -1;
+  if (p.D && pqw > 1024) return -1;
   // the persistent, register-pipelined kernel: ball-query groups with hit counts (only the distinct rows are
   // evaluated).  (It also runs count-less featureless layers -- all K rows -- but the K-row kernel with resident
   // weights is faster there: 2.2 vs 2.9 ms on the 32-channel kNN layer, its row tables are 0.5 GB of extra traffic.)
-  if (p.tile_ws && p.cnt && p.mode == 1) {
+  if (p.tile_ws && p.cnt && p.mode == 1 && p.c1 <= 256 && p.c2 <= 256 && p.c3 <= 256) {
     const int n2r = ceil32(p.c2) >> 5, n3r = ceil32(p.c3) >> 5;
     const int nrr = (n2r > 4 || n3r > 4) ? 2 : 1;
     const int tb = nrr == 2 ? 2 : 4;
@@ -1055,7 +1063,10 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   const int n2 = ceil32(p.c2) >> 5, n3 = ceil32(p.c3) >> 5;
   const int nmin = n2 < n3 ? n2 : n3;
   const int ways = nmin >= 3 ? 1 : (nmin == 2 ? 2 : 4);
-  const int nr = (n2 > 4 || n3 > 4) ? 2 : 1, nr2 = n2 > 4 ? 2 : 1;
+  // cout-block rounds per wave: 2 for 129-256 couts, 4 for 257-512 (the 1.5M / 7M Point-Transformer configs'
+  // 256- / 512-channel layers, backbone_net.py:43-46); the four-round form is instantiated for both layers together
+  const int nr = (n2 > 8 || n3 > 8) ? 4 : ((n2 > 4 || n3 > 4) ? 2 : 1);
+  const int nr2 = nr == 4 ? 4 : (n2 > 4 ? 2 : 1);
   // Tile choice.  Measured on MI355X (re-fitted after the epilogue / k-loop work, which halved what
   // a low residency costs): time per row ~ padding x wave imbalance x (1 + 1.0 / resident workgroups per CU); residency is bounded by LDS (160 KiB, 2 KiB granules),
   // by registers (accumulator tiles + ~70 VGPRs against 512 per SIMD lane) and by 8 workgroups.
@@ -1064,7 +1075,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   const int cpw_max = 192 / p.K > 0 ? 192 / p.K : 1;
   for (int cpw = 1; cpw <= cpw_max; cpw++) {
     const int tb = (cpw * p.K + 31) / 32;
-    if (tb > 6) continue;
+    if (tb > 6 || (nr == 4 && tb > 2)) continue;
     const size_t lds = lds_bytes(tb, cpw);
     if (lds > 150 * 1024) continue;
     const int tbw = (tb + ways - 1) / ways;
@@ -1083,7 +1094,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   static const int force_cpw = getenv("PCR_SA_CPW") ? atoi(getenv("PCR_SA_CPW")) : 0;   // tuning aid
   if (force_cpw > 0) {
     const int tb = (force_cpw * p.K + 31) / 32;
-    if (tb <= 6 && lds_bytes(tb, force_cpw) <= 150 * 1024) { best_cpw = force_cpw; best_tb = tb; }
+    if (tb <= (nr == 4 ? 2 : 6) && lds_bytes(tb, force_cpw) <= 150 * 1024) { best_cpw = force_cpw; best_tb = tb; }
   }
   if (!best_cpw) return -1;
   if (p.D && !p.pq_ready) {
@@ -1138,14 +1149,16 @@ PCR_EXPORT long pcr_sa_tile_ws_ints(int B, int S, int K, int c2, int c3) {
 
 PCR_EXPORT int pcr_dense_pm_f32(const float *x, const float *wp, float *y, int B, int cin, int cout, int L,
                                 int x_point_major, pcr_stream_t stream) {
-  if (!x || !wp || !y || B < 0 || cin < 1 || cout < 1 || cout > 256 || L < 1) return PCR_ERR_INVALID;
+  if (!x || !wp || !y || B < 0 || cin < 1 || cout < 1 || cout > 1024 || L < 1) return PCR_ERR_INVALID;
+  if (cout > 256 && (cout & 3)) return PCR_ERR_INVALID;   // windows of 256 couts keep the 16-byte store path
   if (B == 0) return PCR_OK;
   if (B > 65535) return PCR_ERR_INVALID;
   DensePmArgs d{x, wp, y, cin, cout, L, x_point_major};
-  const int rows = ceil8(cin) > ceil32(cout) ? ceil8(cin) : ceil32(cout);
+  const int wmax = cout < 256 ? cout : 256;
+  const int rows = ceil8(cin) > ceil32(wmax) ? ceil8(cin) : ceil32(wmax);
   size_t lds = (size_t)rows * 65 * sizeof(float);
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
-  const dim3 grid((L + 63) / 64, B);
+  const dim3 grid((L + 63) / 64, B, (cout + 255) / 256);
   if (cout > 128) {
     static bool ok = allow_big_lds(dense_pm_kernel<2>);
     (void)ok;

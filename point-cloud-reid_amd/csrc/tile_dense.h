@@ -320,7 +320,21 @@ __device__ __forceinline__ void tile_dense2(const float *__restrict__ in, int CP
     after_k();   // (generic shape: no early ring, the hook still runs once)
     const int nCB = OP >> 5;
     const DenseNoHook nh;
-    if (nCB > 4) tile_dense_impl<TB, NR, 1, TILE>(in, CP, wp, OP, sync_epi, epi, init, nullptr, nh, opfull);
+    // rounds per wave for the layer at hand: NR of the caller, except that callers instantiated for the 512- / 1024-row
+    // layers of the wide attention blocks (NR = 4 / 8) run their narrower layers with fewer rounds
+    if constexpr (NR >= 8) {
+      if (nCB > 16) {
+        tile_dense_impl<TB, 8, 1, TILE>(in, CP, wp, OP, sync_epi, epi, init, nullptr, nh, opfull);
+        return;
+      }
+    }
+    if constexpr (NR >= 4) {
+      if (nCB > 8) {
+        tile_dense_impl<TB, 4, 1, TILE>(in, CP, wp, OP, sync_epi, epi, init, nullptr, nh, opfull);
+        return;
+      }
+    }
+    if (nCB > 4) tile_dense_impl<TB, (NR >= 4 ? 2 : NR), 1, TILE>(in, CP, wp, OP, sync_epi, epi, init, nullptr, nh, opfull);
     else if (nCB >= 3) tile_dense_impl<TB, 1, 1, TILE>(in, CP, wp, OP, sync_epi, epi, init, nullptr, nh, opfull);   // one round
     else if (nCB == 2) tile_dense_impl<TB, 1, 2, TILE>(in, CP, wp, OP, sync_epi, epi, init, nullptr, nh, opfull);
     else tile_dense_impl<TB, 1, 4, TILE>(in, CP, wp, OP, sync_epi, epi, init, nullptr, nh, opfull);

@@ -221,10 +221,14 @@ class ReIDNet(nn.Module):
         return self._head_plan
 
     def get_pooled_feats(self, h_cat):
+        from pcr_amd import rows
+        if self.pool_type == "max":
+            # nn.MaxPool1d(output_sequence_size) on the permuted (B,N,C) tensor: a max over channel windows (reference
+            # :145, :526-528) -- (B,N) when C == output_sequence_size, as in reid_pts_point-transformer_baseline.py
+            return rows.pool_channel_max(h_cat, self.output_sequence_size)
         if self.pool_type == "both":
-            from pcr_amd import rows
             return rows.pool_both(h_cat)
-        raise NotImplementedError("pool_type=%r: only 'both' is used by the point-cat ReID configs" % self.pool_type)
+        raise NotImplementedError("pool_type=%r" % self.pool_type)
 
     def _fused_matching(self):
         return self.match_type == "xcorr_eff" and self.combine == "point-cat" and self.pool_type == "both"
@@ -246,7 +250,7 @@ class ReIDNet(nn.Module):
         a = self.cross_stage1(search_feat, search_xyz, template_feat, template_xyz)
         return self.cross_stage2(a, search_xyz, template_feat, template_xyz)
 
-    def _match_logits(self, h1, h2, xyz1, xyz2):
+    def _match_logits(self, h1, h2, xyz1, xyz2, inference=False):
         """logits (B) and the stage-2 features; fused single-launch tail for the configuration every point
         ReID config uses, generic composition (reference ReIDNet.py:387-462) for the other variants"""
         if self._fused_matching():
@@ -267,12 +271,17 @@ class ReIDNet(nn.Module):
             match_in = self.xcorr_baseline(h1, xyz1, h2, xyz2)
             return self._head_rows(self.get_pooled_feats(match_in)), None
         if self.match_type == "concat":
-            cat = torch.cat([self.get_pooled_feats(h1), self.get_pooled_feats(h2)], dim=1)
+            if inference:     # the reference's inference entry point pools with self.maxpool whatever pool_type (:455-457)
+                from pcr_amd import rows
+                pool = lambda h: rows.pool_channel_max(h, self.output_sequence_size)
+            else:
+                pool = self.get_pooled_feats
+            cat = torch.cat([pool(h1), pool(h2)], dim=1)
             return self._head_rows(cat), None
         raise NotImplementedError("match_type=%r" % self.match_type)
 
     def match_forward_inference(self, h1, h2, xyz1, xyz2):
-        return self._match_logits(h1, h2, xyz1, xyz2)[0]
+        return self._match_logits(h1, h2, xyz1, xyz2, inference=True)[0]
 
     def match_gallery(self, h, xyz, pairs):
         """Amortised matching (the reference's tracker use-case of forward_inference +

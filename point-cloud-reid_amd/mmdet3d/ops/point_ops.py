@@ -16,6 +16,20 @@ from pcr_amd import _lib as L
 from pcr_amd.engine import _prof
 
 
+def _on_device(fn):
+    """run a Function's forward / backward with the tensors' device current (a tensor may live on another GPU than
+    the caller's current one; the reference's KNN wrapper does the same with torch.cuda.device_of, knn.py:47)"""
+    def wrapped(ctx, *args):
+        dev = next((a.device for a in args if isinstance(a, torch.Tensor) and a.is_cuda), None)
+        if dev is None:
+            return fn(ctx, *args)
+        with torch.cuda.device(dev):
+            return fn(ctx, *args)
+    wrapped.__name__ = fn.__name__
+    wrapped.__doc__ = fn.__doc__
+    return staticmethod(wrapped)
+
+
 def _i32(*shape, device):
     return torch.empty(shape, dtype=torch.int32, device=device)
 
@@ -25,10 +39,11 @@ def _f32(*shape, device):
 
 
 class FurthestPointSampling(Function):
-    @staticmethod
+    @_on_device
     def forward(ctx, points_xyz, num_points):
         assert points_xyz.is_contiguous()
         L.require_cuda(points_xyz)
+        L.require_f32(points_xyz)
         B, N = points_xyz.size()[:2]
         out = _i32(B, num_points, device=points_xyz.device)
         temp = torch.full((B, N), 1e10, dtype=torch.float32, device=points_xyz.device)
@@ -38,16 +53,17 @@ class FurthestPointSampling(Function):
         ctx.mark_non_differentiable(out)
         return out
 
-    @staticmethod
+    @_on_device
     def backward(ctx, a=None):
         return None, None
 
 
 class FurthestPointSamplingWithDist(Function):
-    @staticmethod
+    @_on_device
     def forward(ctx, points_dist, num_points):
         assert points_dist.is_contiguous()
         L.require_cuda(points_dist)
+        L.require_f32(points_dist)
         B, N, _ = points_dist.size()
         out = _i32(B, num_points, device=points_dist.device)
         temp = torch.full((B, N), 1e10, dtype=torch.float32, device=points_dist.device)
@@ -56,18 +72,19 @@ class FurthestPointSamplingWithDist(Function):
         ctx.mark_non_differentiable(out)
         return out
 
-    @staticmethod
+    @_on_device
     def backward(ctx, a=None):
         return None, None
 
 
 class BallQuery(Function):
-    @staticmethod
+    @_on_device
     def forward(ctx, min_radius, max_radius, sample_num, xyz, center_xyz):
         assert center_xyz.is_contiguous()
         assert xyz.is_contiguous()
         assert min_radius < max_radius
         L.require_cuda(xyz, center_xyz)
+        L.require_f32(xyz, center_xyz)
         B, N, _ = xyz.size()
         npoint = center_xyz.size(1)
         idx = _i32(B, npoint, sample_num, device=xyz.device)
@@ -79,7 +96,7 @@ class BallQuery(Function):
         ctx.mark_non_differentiable(idx)
         return idx
 
-    @staticmethod
+    @_on_device
     def backward(ctx, a=None):
         return None, None, None, None, None
 
@@ -88,12 +105,13 @@ class BallQueryCnt(Function):
     """ball_query that also returns the number of genuine hits of every row (entries past it repeat the
     first hit, ball_query_cuda.cu:43-47); lets the fused SA kernel skip the repeated rows"""
 
-    @staticmethod
+    @_on_device
     def forward(ctx, min_radius, max_radius, sample_num, xyz, center_xyz):
         assert center_xyz.is_contiguous()
         assert xyz.is_contiguous()
         assert min_radius < max_radius
         L.require_cuda(xyz, center_xyz)
+        L.require_f32(xyz, center_xyz)
         B, N, _ = xyz.size()
         npoint = center_xyz.size(1)
         idx = _i32(B, npoint, sample_num, device=xyz.device)
@@ -106,13 +124,13 @@ class BallQueryCnt(Function):
         ctx.mark_non_differentiable(idx, cnt)
         return idx, cnt
 
-    @staticmethod
+    @_on_device
     def backward(ctx, a=None, b=None):
         return None, None, None, None, None
 
 
 class KNN(Function):
-    @staticmethod
+    @_on_device
     def forward(ctx, k, xyz, center_xyz=None, transposed=False):
         assert k > 0
         if center_xyz is None:
@@ -124,28 +142,30 @@ class KNN(Function):
         assert center_xyz.is_contiguous()
         assert center_xyz.device == xyz.device, "center_xyz and xyz should be put on the same device"
         L.require_cuda(xyz)
+        L.require_f32(xyz, center_xyz)
         B, npoint, _ = center_xyz.shape
         N = xyz.shape[1]
         idx = _i32(B, npoint, k, device=xyz.device)
         dist2 = _f32(B, npoint, k, device=xyz.device)
-        with torch.cuda.device(xyz.device):
-            L.check(L.load().pcr_knn_f32(L.ptr(xyz), L.ptr(center_xyz), L.ptr(idx), L.ptr(dist2), B, N,
-                                         npoint, k, L.stream_ptr()), "pcr_knn_f32")
+        L.check(L.load().pcr_knn_f32(L.ptr(xyz), L.ptr(center_xyz), L.ptr(idx), L.ptr(dist2), B, N,
+                                     npoint, k, L.stream_ptr()), "pcr_knn_f32")
         idx = idx.transpose(2, 1).contiguous()      # (B, k, npoint) as in knn.py:62
         ctx.mark_non_differentiable(idx)
         return idx
 
-    @staticmethod
+    @_on_device
     def backward(ctx, a=None):
         return None, None, None, None
 
 
 class GatherPoints(Function):
-    @staticmethod
+    @_on_device
     def forward(ctx, features, indices):
         assert features.is_contiguous()
         assert indices.is_contiguous()
         L.require_cuda(features, indices)
+        L.require_f32(features)
+        L.require_i32(indices)
         B, npoint = indices.size()
         _, C, N = features.size()
         out = _f32(B, C, npoint, device=features.device)
@@ -155,23 +175,25 @@ class GatherPoints(Function):
         ctx.mark_non_differentiable(indices)
         return out
 
-    @staticmethod
+    @_on_device
     def backward(ctx, grad_out):
         idx, C, N = ctx.for_backwards
         B, npoint = idx.size()
         grad_features = torch.zeros(B, C, N, dtype=torch.float32, device=grad_out.device)
-        g = grad_out.data.contiguous()
+        g = grad_out.data.float().contiguous()
         L.check(L.load().pcr_gather_bwd_f32(L.ptr(g), L.ptr(idx), L.ptr(grad_features), B, C, N, npoint,
                                             L.stream_ptr()), "pcr_gather_bwd_f32")
         return grad_features, None
 
 
 class GroupingOperation(Function):
-    @staticmethod
+    @_on_device
     def forward(ctx, features, indices):
         assert features.is_contiguous()
         assert indices.is_contiguous()
         L.require_cuda(features, indices)
+        L.require_f32(features)
+        L.require_i32(indices)
         B, nfeatures, nsample = indices.size()
         _, C, N = features.size()
         out = _f32(B, C, nfeatures, nsample, device=features.device)
@@ -180,23 +202,24 @@ class GroupingOperation(Function):
         ctx.for_backwards = (indices, N)
         return out
 
-    @staticmethod
+    @_on_device
     def backward(ctx, grad_out):
         idx, N = ctx.for_backwards
         B, C, npoint, nsample = grad_out.size()
         grad_features = torch.zeros(B, C, N, dtype=torch.float32, device=grad_out.device)
-        g = grad_out.data.contiguous()
+        g = grad_out.data.float().contiguous()
         L.check(L.load().pcr_group_bwd_f32(L.ptr(g), L.ptr(idx), L.ptr(grad_features), B, C, N, npoint,
                                            nsample, L.stream_ptr()), "pcr_group_bwd_f32")
         return grad_features, None
 
 
 class ThreeNN(Function):
-    @staticmethod
+    @_on_device
     def forward(ctx, target, source):
         assert target.is_contiguous()
         assert source.is_contiguous()
         L.require_cuda(target, source)
+        L.require_f32(target, source)
         B, N, _ = target.size()
         m = source.size(1)
         dist2 = _f32(B, N, 3, device=target.device)
@@ -206,18 +229,20 @@ class ThreeNN(Function):
         ctx.mark_non_differentiable(idx)
         return torch.sqrt(dist2), idx
 
-    @staticmethod
+    @_on_device
     def backward(ctx, a=None, b=None):
         return None, None
 
 
 class ThreeInterpolate(Function):
-    @staticmethod
+    @_on_device
     def forward(ctx, features, indices, weight):
         assert features.is_contiguous()
         assert indices.is_contiguous()
         assert weight.is_contiguous()
         L.require_cuda(features, indices, weight)
+        L.require_f32(features, weight)
+        L.require_i32(indices)
         B, c, m = features.size()
         n = indices.size(1)
         ctx.three_interpolate_for_backward = (indices, weight, m)
@@ -226,12 +251,12 @@ class ThreeInterpolate(Function):
                                                   B, c, m, n, L.stream_ptr()), "pcr_three_interp_fwd_f32")
         return out
 
-    @staticmethod
+    @_on_device
     def backward(ctx, grad_out):
         idx, weight, m = ctx.three_interpolate_for_backward
         B, c, n = grad_out.size()
         grad_features = torch.zeros(B, c, m, dtype=torch.float32, device=grad_out.device)
-        g = grad_out.data.contiguous()
+        g = grad_out.data.float().contiguous()
         L.check(L.load().pcr_three_interp_bwd_f32(L.ptr(g), L.ptr(idx), L.ptr(weight), L.ptr(grad_features),
                                                   B, c, n, m, L.stream_ptr()), "pcr_three_interp_bwd_f32")
         return grad_features, None, None

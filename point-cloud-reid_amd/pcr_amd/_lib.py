@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libpcr_hip.so")
 _lib = None
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class PcrError(RuntimeError):
@@ -50,7 +50,36 @@ def check(status, what):
 
 
 def require_cuda(*tensors):
+    """device tensors only (no CPU fallback), all on the CURRENT device: the launch goes to the current device's
+    stream (mmdet3d.ops switches to the tensor's device first, as the reference's KNN wrapper does)"""
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise PcrError("pcr_amd ops run only on an MI355X device tensor (got %s); there is no CPU "
                            "fallback in the product path" % t.device)
+        if t.device.index != torch.cuda.current_device():
+            raise PcrError("tensor on %s but the current device is cuda:%d: call torch.cuda.set_device / "
+                           "torch.cuda.device(...) first" % (t.device, torch.cuda.current_device()))
+
+
+def require_f32(*tensors):
+    for t in tensors:
+        if t is not None and t.dtype != torch.float32:
+            raise PcrError("expected a float32 tensor, got %s (the kernels read raw binary32)" % t.dtype)
+
+
+def require_i32(*tensors):
+    """the reference's wrappers read indices through data_ptr<int>() and raise on int64; so do we"""
+    for t in tensors:
+        if t is not None and t.dtype != torch.int32:
+            raise PcrError("expected an int32 index tensor, got %s" % t.dtype)
+
+
+def require_default_eps(*norms):
+    """GroupNorm / LayerNorm kernels use eps = 1e-5 (every norm layer of the ReID configs): anything else is refused
+    rather than silently computed with the wrong constant"""
+    for n in norms:
+        eps = getattr(n, "eps", 1e-5)
+        if abs(eps - 1e-5) > 1e-12:
+            raise PcrError("%s with eps=%g: the HIP kernels implement eps = 1e-5 only" % (type(n).__name__, eps))

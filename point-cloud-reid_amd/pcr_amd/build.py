@@ -48,9 +48,13 @@ def build(force=False, verbose=False):
     common += os.environ.get("PCR_EXTRA_HIPCC_FLAGS", "").split()      # diagnostic builds only
     objs = []
     procs = []
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(ROOT, "include", "pcr.h"), os.path.abspath(__file__)]
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
+        if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in [src] + hdrs) \
+                and not os.environ.get("PCR_EXTRA_HIPCC_FLAGS") and not os.environ.get("PCR_POINT_FLAGS"):
+            continue        # incremental: this object is newer than its source and every header
         cmd = [hipcc()] + common + FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
@@ -64,4 +68,5 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force="--force" in sys.argv, verbose=True))

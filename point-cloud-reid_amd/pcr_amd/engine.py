@@ -63,6 +63,7 @@ class AttnParams(ctypes.Structure):
                 ("wmerge", c_float_p), ("wmlp0", c_float_p), ("wmlp2", c_float_p),
                 ("ln1_g", c_float_p), ("ln1_b", c_float_p), ("ln2_g", c_float_p), ("ln2_b", c_float_p),
                 ("wfinal", c_float_p), ("bfinal", c_float_p), ("cfinal", ctypes.c_int),
+                ("wkv_wide", c_float_p), ("bkv_wide", c_float_p), ("wmerge_packed", c_float_p),
                 ("kv", c_float_p), ("out", c_float_p)]
 
 
@@ -227,6 +228,7 @@ class AttnPlan:
 
     def __init__(self, m, pos_name, device, nhead, q_pos, k_pos, residual, final=None):
         pos = getattr(m, pos_name)
+        L.require_default_eps(m.norm1, m.norm2)
         self.device = device
         self.nhead, self.q_pos, self.k_pos, self.residual = nhead, int(q_pos), int(k_pos), int(residual)
         self.d = d = m.q_proj.weight.shape[0]
@@ -253,6 +255,21 @@ class AttnPlan:
             wmlp0=pack_weight(m.mlp[0].weight, device), wmlp2=pack_weight(m.mlp[2].weight, device),
             ln1_g=_dev32(m.norm1.weight, device), ln1_b=_dev32(m.norm1.bias, device),
             ln2_g=_dev32(m.norm2.weight, device), ln2_b=_dev32(m.norm2.bias, device))
+        if d > 128:
+            # d_model 256 / 512 (mul = 2 / 4 configs): the kv kernel splits a cloud over d/64 workgroups; band g needs
+            # the K rows [64g, 64g+64) and the V rows of its head of the fused projection (include/pcr.h)
+            dh = d // nhead
+            if d % 64 or dh % 64 or dh > 256:
+                raise L.PcrError("attention with d_model %d, %d heads is not covered (heads of 64..256 channels)" % (d, nhead))
+            imgs, biases = [], []
+            for g in range(d // 64):
+                hd = (64 * g) // dh
+                rows = torch.cat([torch.arange(64 * g, 64 * g + 64), torch.arange(d + hd * dh, d + (hd + 1) * dh)])
+                imgs.append(pack_weight(wkv[rows].float(), device))
+                biases.append(bkv[rows].float())
+            self.t["wkv_wide"] = torch.cat(imgs).contiguous()
+            self.t["bkv_wide"] = _dev32(torch.cat(biases), device)
+            self.t["wmerge_packed"] = pack_weight(m.merge.weight, device)
         self.cfinal = 0
         if final is not None:
             self.t["wfinal"] = pack_weight(final.weight, device)
@@ -321,6 +338,7 @@ class HeadPlan:
     def __init__(self, linres, out_linear, device):
         if getattr(linres, "transform", None) is not None:
             raise L.PcrError("pcr_pool_head_f32 covers LinearRes with n_in == n_out only")
+        L.require_default_eps(linres.norm1, linres.norm2)
         self.n = linres.linear1.weight.shape[0]
         self.groups = linres.norm1.num_groups
         self.t = dict(w1=_dev32(linres.linear1.weight, device), w2=_dev32(linres.linear2.weight, device),

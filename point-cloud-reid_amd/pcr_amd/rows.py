@@ -14,6 +14,20 @@ def pool_both(x):
     return out
 
 
+def pool_channel_max(x, window):
+    """(B,C,L) -> (B,L) (or (B,L,C//window) when C > window): ReIDNet.get_pooled_feats with pool_type='max', i.e.
+    nn.MaxPool1d(window) over the channels of the permuted tensor followed by squeeze(-1) (ReIDNet.py:145,526-528)"""
+    L.require_cuda(x)
+    x = x.contiguous()
+    B, C, Ln = x.shape
+    if window > C:
+        raise L.PcrError("MaxPool1d(%d) over %d channels has no output" % (window, C))
+    G = C // window
+    out = torch.empty((B, Ln, G), dtype=torch.float32, device=x.device)
+    L.check(L.load().pcr_channel_max_f32(L.ptr(x), L.ptr(out), B, C, Ln, window, L.stream_ptr()), "pcr_channel_max_f32")
+    return out.squeeze(-1)
+
+
 # ---- LinearRes on channel-major token tensors --------------------------------------------------
 from . import engine as _E
 
@@ -21,6 +35,7 @@ from . import engine as _E
 def groupnorm(x, gn, res=None, relu=False):
     """x (B,C,L): GroupNorm over channel groups per token [+ res] [relu]"""
     L.require_cuda(x)
+    L.require_default_eps(gn)
     x = x.contiguous()
     B, C, Ln = x.shape
     y = torch.empty_like(x)
@@ -51,7 +66,8 @@ def dense_gn(x, wp, cout, gn, res=None, relu=False):
     """[relu](GroupNorm(W x) [+ res]) on a channel-major tensor: one launch (pcr_dense_gn_f32) when the group size is
     4 / 8 / 16 / 32 channels, pcr_dense_f32 + pcr_groupnorm_f32 otherwise"""
     L.require_cuda(x)
-    if cout // gn.num_groups not in (4, 8, 16, 32) or gn.eps != 1e-5:
+    L.require_default_eps(gn)
+    if cout // gn.num_groups not in (4, 8, 16, 32):
         return groupnorm(_E.dense(x, wp, cout), gn, res=res, relu=relu)
     x = x.contiguous()
     B, cin, Ln = x.shape

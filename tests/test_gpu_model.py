@@ -324,3 +324,40 @@ def test_match_variants_generic_path(match_type, combine):
         x = MO.linear_res(MO._linres_params(sd, "match_head.0.", 8), pooled)
         want = F.linear(x, sd["match_head.1.weight"], sd["match_head.1.bias"]).squeeze(1)
     assert float((got - want).abs().max()) < TOL
+
+
+@pytest.mark.parametrize("sampling,use_knn", [("FPS", True), ("FPS", False), ("RANDOM", False)])
+def test_sa_layer_dormant_sampling_and_grouping_branches(sampling, use_knn):
+    """PointNetSetAbstractionEdgeSA with FPS centres and / or ball-query groups (the branches sample_and_group_edge
+    keeps behind hard-coded flags, pointnet2_utils.py:262-272): HIP twins + the fused SA launch with explicit centre
+    indices against the oracle fed with the same indices"""
+    import model_oracle as MO
+    from mmdet3d.models import pointnet2_utils as U
+    sa = U.PointNetSetAbstractionEdgeSA(npoint=None, radius=0.9, nsample=16, mlp=[32, 32, 32, 64], sampling=sampling,
+                                        use_xyz=True, use_knn=use_knn)
+    # edge features: 3 + 2 D input channels for D = 16 point features
+    sa.mlp_convs[0] = torch.nn.Conv2d(3 + 2 * 16, 32, 1)
+    sd = T.seeded_state_dict(T.manifest_of(sa), 7)
+    sa.load_state_dict(sd)
+    sa = sa.cuda().eval()
+    xyz = T.synthetic_clouds(3, 200, seed=31, kind="randn")
+    feats = torch.randn(3, 16, 200, generator=torch.Generator().manual_seed(1))
+    S = 50
+    torch.manual_seed(5)
+    new_xyz, out = sa(xyz.cuda(), feats.cuda(), S)
+    # recover the centres the module drew (FPS start is random) from new_xyz, then replay the oracle with them
+    d = (new_xyz.cpu().unsqueeze(2) - xyz.unsqueeze(1)).abs().sum(-1)
+    centre = d.argmin(dim=-1)
+    assert float(d.min(dim=-1)[0].max()) == 0.0
+    if sampling == "FPS":
+        assert torch.equal(centre, MO.farthest_point_sample_py(xyz, S, centre[:, 0]))
+    else:
+        assert torch.equal(centre, torch.arange(S).repeat(3, 1))
+    cx = torch.gather(xyz, 1, centre.unsqueeze(-1).expand(-1, -1, 3))
+    if use_knn:
+        gidx = torch.argsort(MO.square_distance(cx, xyz), dim=-1)[:, :, :16]
+    else:
+        gidx = MO.query_ball_point_py(0.9, 16, xyz, cx)
+    with torch.no_grad():
+        _, want = MO.sa_edge_layer(sd, xyz, feats, S, 16, centre_idx=centre, group_idx=gidx)
+    assert float((out.cpu() - want).abs().max()) < TOL

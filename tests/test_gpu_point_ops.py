@@ -142,3 +142,51 @@ def test_errors_are_python_exceptions(ops):
         ops.furthest_point_sample(torch.zeros(2, 3, 8).cuda().transpose(1, 2), 4)   # non-contiguous
     with pytest.raises(AssertionError):
         ops.ball_query(0.5, 0.2, 4, x.cuda(), x.cuda())  # min_radius >= max_radius
+
+
+# ---- Python-semantic twins of the model path (pointnet2_utils.py:116-137, 218-240) ----
+def test_python_twins_match_reference_golden():
+    """farthest_point_sample (start index 0) and query_ball_point recorded from the imported reference"""
+    from conftest import load_golden
+    from mmdet3d.models import pointnet2_utils as U
+    g = load_golden("ops_python_twins")
+    m = g["meta"]
+    xyz = T.synthetic_clouds(m["clouds"], m["n"], seed=m["seed"], kind=m["kind"]).cuda()
+    fps = U.farthest_point_sample(xyz, m["m"], start=torch.zeros(m["clouds"], dtype=torch.long))
+    assert fps.dtype == torch.int64 and (fps.cpu().numpy() == g["fps"]).all()
+    centres = U.index_points(xyz, fps)
+    ball = U.query_ball_point(m["radius"], m["nsample"], xyz, centres)
+    assert (ball.cpu().numpy() == g["ball"]).all()
+    knn = U.knn_point(m["nsample"], xyz, centres)
+    assert (np.sort(knn.cpu().numpy(), -1) == g["knn_sorted"]).all()
+    assert torch.equal(U.random_point_sample(xyz, 7).cpu(), torch.arange(7).repeat(m["clouds"], 1))
+
+
+@pytest.mark.parametrize("B,N,M,kind", [(3, 300, 77, "box"), (2, 1024, 256, "randn"), (4, 128, 128, "dup"), (2, 5000, 64, "box")])
+def test_python_fps_twin_matches_oracle_with_random_starts(B, N, M, kind):
+    import model_oracle as MO
+    from mmdet3d.models import pointnet2_utils as U
+    xyz = T.synthetic_clouds(B, N, seed=21, kind=kind)
+    start = torch.randint(0, N, (B,), generator=torch.Generator().manual_seed(4))
+    got = U.farthest_point_sample(xyz.cuda(), M, start=start).cpu()
+    want = MO.farthest_point_sample_py(xyz, M, start)
+    assert torch.equal(got, want)
+    # without `start` the first pick is drawn at random, as in the reference: valid indices, first column varies
+    r = U.farthest_point_sample(xyz.cuda(), 4)
+    assert r.shape == (B, 4) and int(r.min()) >= 0 and int(r.max()) < N
+
+
+@pytest.mark.parametrize("B,N,S,K,radius,kind", [(2, 400, 100, 16, 0.5, "box"), (3, 256, 64, 32, 0.8, "randn"),
+                                                  (2, 1500, 200, 8, 0.3, "dup"), (1, 64, 64, 64, 100.0, "box")])
+def test_python_ball_query_twin_matches_oracle(B, N, S, K, radius, kind):
+    """rows whose decision could flip with the summation order of the reference's matmul (a distance within 1e-5 of
+    r^2) are left out of the comparison; everything else must be identical"""
+    import model_oracle as MO
+    from mmdet3d.models import pointnet2_utils as U
+    xyz = T.synthetic_clouds(B, N, seed=22, kind=kind)
+    new_xyz = xyz[:, :S].contiguous()
+    got = U.query_ball_point(radius, K, xyz.cuda(), new_xyz.cuda()).cpu()
+    want, d = MO.query_ball_point_py(radius, K, xyz, new_xyz, return_dist=True)
+    safe = ((d - radius ** 2).abs() > 1e-5 * max(1.0, radius ** 2)).all(dim=-1)
+    assert safe.float().mean() > 0.9
+    assert torch.equal(got[safe], want[safe])

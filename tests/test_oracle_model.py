@@ -38,6 +38,43 @@ def test_pt_oracle_matches_reference_golden(case):
             assert np.abs(got - v).max() < TOL, (k, np.abs(got - v).max())
 
 
+@pytest.mark.parametrize("tag,head_ng", [("pt15m", 8), ("pt7m", 16)])
+def test_pt_mul_oracle_matches_reference_golden(tag, head_ng):
+    """the 1.5M (mul=2) / 7M (mul=4) Point-Transformer configs, recorded from the imported reference"""
+    g = load_golden(tag + "_n128_randn")
+    m = g["meta"]
+    s1, s2 = T.synthetic_pairs(m["pairs"], m["n"], m["input_seed"], m["kind"])
+    st = {}
+    sd = _sd(tag)
+    with torch.no_grad():
+        b = s1.shape[0]
+        xyz, h = MO.pt_backbone(MO._sub(sd, "backbone."), torch.cat([s1, s2], 0), m["backbone_list"], stages=st)
+        st.update(h1=h[:b], h2=h[b:])
+        logits = MO.match(sd, h[:b], xyz[:b], h[b:], xyz[b:], st, head_ng=head_ng)
+    assert np.abs(logits.numpy() - g["logits"]).max() < TOL
+    for k, v in g.items():
+        if k in ("meta", "logits"):
+            continue
+        got = st[k].numpy()
+        if k.endswith("knn_sorted"):
+            assert (got == v).all(), k
+        else:
+            assert np.abs(got - v).max() < TOL, (k, np.abs(got - v).max())
+
+
+def test_pt_baseline_concat_oracle_matches_reference_golden():
+    """match_type='concat' + pool_type='max' (reid_pts_point-transformer_baseline.py)"""
+    g = load_golden("pt_baseline_n128_randn")
+    m = g["meta"]
+    s1, s2 = T.synthetic_pairs(m["pairs"], m["n"], m["input_seed"], m["kind"])
+    st = {}
+    with torch.no_grad():
+        logits = MO.pt_pairs_concat(_sd("pt_baseline"), s1, s2, m["backbone_list"], stages=st)
+    for k in ("h1", "h2", "pooled1"):
+        assert np.abs(st[k].numpy() - g[k]).max() < TOL, k
+    assert np.abs(logits.numpy() - g["logits"]).max() < TOL
+
+
 def test_pointnet_oracle_matches_reference_golden():
     g = load_golden("pointnet_n256_randn")
     m = g["meta"]
