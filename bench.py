@@ -426,7 +426,7 @@ def main():
     ap.add_argument("--workload", default="ssg1024", choices=sorted(WORKLOADS),
                     help="default = BASELINE.json configs[1] (PointNet++ SSG siamese @1024); pt1024 = configs[2]")
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (default: per workload)")
-    ap.add_argument("--clouds", default=None, choices=["box", "dup", "randn"], help="synthetic cloud distribution")
+    ap.add_argument("--clouds", default=None, choices=["box", "dup", "crop", "randn"], help="synthetic cloud distribution")
     ap.add_argument("--full-groups", action="store_true",
                     help="SSG: evaluate all K rows of every ball-query group (no duplicate-row skipping)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -466,10 +466,11 @@ def main():
     if default_run and world == 1 and not args.no_also:
         # The headline workload's uniform box clouds leave the ball-query groups nearly empty (config.fill), and
         # the ragged SA kernel skips the repeated rows.  Beside it, in the same run: the same model on clouds
-        # with 50 % duplicated points (what subsamplePC's sampling with replacement produces: fuller groups), the
-        # same model evaluating all K rows of every group, and the reference's own 1024-pt Point-Transformer
+        # with 50 % duplicated points, on crops of 32..512 surface returns resampled to 1024 WITH replacement (what the
+        # reference's subsamplePC hands the model: fuller groups), the same model evaluating all K rows of every group, and the reference's own 1024-pt Point-Transformer
         # config (BASELINE configs[2]; kNN groups, always full).
         for name, wl, kw in (("ssg1024_dup", "ssg1024", dict(cloud_kind="dup")),
+                             ("ssg1024_crop", "ssg1024", dict(cloud_kind="crop")),
                              ("ssg1024_full", "ssg1024", dict(skip_repeats=False, steps=max(4, args.steps // 4))),
                              ("pt1024", "pt1024", dict())):
             try:

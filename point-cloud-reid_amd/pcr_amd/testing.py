@@ -64,10 +64,24 @@ def synthetic_clouds(n_clouds, n_points, seed, kind="randn"):
     dup   : box, but half of the points are copies of other points of the same cloud
             (the reference resamples crops *with replacement*, datasets/utils.py:606-621,
             so exact duplicates -- exact distance ties -- are the normal case)
+    crop  : what the reference's loader really hands the model: a crop of 32..512 DISTINCT returns on the faces of
+            the 4 x 2 x 1.5 m box (a LiDAR sees surfaces), resampled to n_points WITH replacement exactly as
+            subsamplePC does (np.random.randint indices) -- every point has ~2..32 exact copies
     """
     g = np.random.default_rng([0x5EED, seed])
     if kind == "randn":
         a = g.standard_normal((n_clouds, n_points, 3))
+    elif kind == "crop":
+        ext = np.array([4.0, 2.0, 1.5])
+        area = np.array([ext[1] * ext[2], ext[0] * ext[2], ext[0] * ext[1]])      # faces normal to x, y, z
+        a = np.empty((n_clouds, n_points, 3))
+        for c in range(n_clouds):
+            n_src = int(g.integers(32, 513))
+            src = g.uniform(-0.5, 0.5, (n_src, 3)) * ext
+            axis = g.choice(3, size=n_src, p=area / area.sum())
+            side = g.integers(0, 2, n_src) - 0.5
+            src[np.arange(n_src), axis] = side * ext[axis]
+            a[c] = src[g.integers(0, n_src, n_points)]
     else:
         a = g.uniform(-0.5, 0.5, (n_clouds, n_points, 3)) * np.array([4.0, 2.0, 1.5])
         if kind == "dup":

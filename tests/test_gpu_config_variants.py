@@ -84,12 +84,14 @@ def test_pt_mul_matches_reference_golden(tag, mul, oss, ng):
     meta = g["meta"]
     m, sd = _build(_pt_mul(mul, oss, ng), tag)
     s1, s2 = T.synthetic_pairs(meta["pairs"], meta["n"], meta["input_seed"], meta["kind"])
-    st = run_stages(m, s1, s2)
+    st = run_stages(m, s1, s2, fused_final=False)      # (fp0_out is the tensor BEFORE cov_final)
     keys = [k for k in g if k not in ("meta",) and not k.endswith("knn_sorted")]
     worst = {k: float(np.abs(st[k] - g[k]).max()) for k in keys if k in st}
     print(json.dumps(worst))
-    assert "logits" in worst and "h1" in worst and "sa2_out" in worst
+    assert "logits" in worst and "h1" in worst and "sa2_out" in worst and "fp0_out" in worst
     assert max(worst.values()) < TOL, worst
+    st2 = run_stages(m, s1, s2, fused_final=True)      # cov_final inside the last FP launch: same h, same logits
+    assert np.abs(st2["h1"] - g["h1"]).max() < TOL and np.abs(st2["logits"] - g["logits"]).max() < TOL
 
 
 @pytest.mark.parametrize("mul,oss,ng,pairs,n,bl", [(2, 64, 8, 3, 200, [200, 100, 50]), (4, 128, 16, 2, 256, [256, 128, 64])])

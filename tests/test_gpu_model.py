@@ -309,7 +309,12 @@ def test_match_variants_generic_path(match_type, combine):
     s1, s2 = T.synthetic_pairs(3, 128, seed=4, kind="box")
     with torch.no_grad():
         xyz1, xyz2, h1, h2 = m.siamese_forward(s1.cuda(), s2.cuda())
-        got = m.match_forward_inference(h1, h2, xyz1, xyz2).cpu()
+        if match_type == "concat":
+            # forward_test / forward_train pool through get_pooled_feats (reference :415-419); the reference's
+            # match_forward_inference pools 'concat' inputs with self.maxpool whatever pool_type says (:455-457)
+            got = m.match_forward(h1, h2, xyz1, xyz2, torch.zeros(3, device="cuda"), None, "cuda")[0].cpu()
+        else:
+            got = m.match_forward_inference(h1, h2, xyz1, xyz2).cpu()
         xr, hr = MO.pt_backbone(MO._sub(sd, "backbone."), torch.cat([s1, s2]), [128, 64, 32])
         a1, a2, x1, x2 = hr[:3], hr[3:], xr[:3], xr[3:]
         c1, c2 = MO._sub(sd, "cross_stage1."), MO._sub(sd, "cross_stage2.")
