@@ -50,6 +50,12 @@ int pcr_fps_f32(const float *xyz, float *temp, int *idx, int B, int N, int M, pc
 int pcr_fps_dist_f32(const float *dist, float *temp, int *idx, int B, int N, int M,
                      pcr_stream_t stream);
 
+/* calc_square_dist (ops/furthest_point_sample/utils.py:4-32): the (B,N,M) matrix the F-FPS / FS samplers hand to
+ * pcr_fps_dist_f32 (points_sampler.py:121-157).  a (B,N,C), b (B,M,C) -> out[i][j] = (|a_i|^2 + |b_j|^2) - 2 <a_i,b_j>,
+ * sums left to right over the channels, no fma (the reference leaves the order to its matmul); norm: sqrt(.)/C. */
+int pcr_pairwise_sqdist_f32(const float *a, const float *b, float *out, int B, int N, int M, int C, int norm,
+                            pcr_stream_t stream);
+
 /* ball_query_wrapper (ops/ball_query/src/ball_query.cpp:30-43, kernel ball_query_cuda.cu:11-54).
  * centres (B,M,3), xyz (B,N,3) -> idx (B,M,K): the first K indices k (ascending) with
  * d2 == 0 || (min_r^2 <= d2 < max_r^2), padded with the first hit; rows with no hit are written

@@ -69,6 +69,15 @@ def fps_dist(dist, m):
     return idx
 
 
+def pairwise_sqdist(a, b, norm=False):
+    a, b = _f32(a), _f32(b)
+    B, N, C = a.shape
+    M = b.shape[1]
+    out = np.zeros((B, N, M), np.float32)
+    lib().pcr_oracle_pairwise_sqdist(_fp(a), _fp(b), _fp(out), B, N, M, C, int(bool(norm)))
+    return out
+
+
 def ball_query(min_r, max_r, k, xyz, centres):
     xyz, centres = _f32(xyz), _f32(centres)
     B, N, _ = xyz.shape

@@ -377,6 +377,33 @@ int fps_launch(bool dist, const float *data, float *temp, int *idx, int B, int N
   return PCR_OK;
 }
 
+// ------------------------------------------------------------------ pairwise distances ----
+// calc_square_dist (ops/furthest_point_sample/utils.py:4-32): (|a_i|^2 + |b_j|^2) - 2 <a_i, b_j> with every sum taken
+// left to right over the channels and no fma (the order oracle/pcr_oracle.c:pcr_oracle_pairwise_sqdist restates).
+// One thread per (i, j); the a row is a wave-uniform broadcast, b rows are C floats apart (C is 3 + a few features).
+__global__ __launch_bounds__(256) void pairwise_sqdist_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                              float *__restrict__ out, int N, int M, int C, int norm) {
+  const size_t bb = blockIdx.z;
+  const int i = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= M) return;
+  const float *ai = a + (bb * N + i) * C;
+  const float *bj = b + (bb * M + j) * C;
+  float a2 = 0.f, b2 = 0.f, dot = 0.f;
+  for (int c = 0; c < C; c++) {
+    const float x = ai[c], y = bj[c];
+    const float sa = x * x, sb = y * y, sd = x * y;
+    a2 = a2 + sa;
+    b2 = b2 + sb;
+    dot = dot + sd;
+  }
+  const float t = a2 + b2;
+  const float u = 2.0f * dot;
+  float d = t - u;
+  if (norm) d = sqrtf(d) / (float)C;
+  out[(bb * N + i) * M + j] = d;
+}
+
 // ------------------------------------------------------------------------ ball query ----
 // One thread per centre; the cloud streams through a 1024-point LDS tile that every lane reads
 // at the same address (broadcast, conflict-free), instead of N uncoalesced AoS global loads per
@@ -1009,6 +1036,17 @@ PCR_EXPORT int pcr_fps_f32(const float *xyz, float *temp, int *idx, int B, int N
 PCR_EXPORT int pcr_fps_dist_f32(const float *dist, float *temp, int *idx, int B, int N, int M,
                                 pcr_stream_t stream) {
   return fps_launch(true, dist, temp, idx, B, N, M, pcr_s(stream));
+}
+
+PCR_EXPORT int pcr_pairwise_sqdist_f32(const float *a, const float *b, float *out, int B, int N, int M, int C, int norm,
+                                       pcr_stream_t stream) {
+  if (!a || !b || !out || B < 0 || N < 0 || M < 0 || C < 1) return PCR_ERR_INVALID;
+  if (B == 0 || N == 0 || M == 0) return PCR_OK;
+  if (B > 65535 || N > 65535) return PCR_ERR_INVALID;
+  hipLaunchKernelGGL(pairwise_sqdist_kernel, dim3((M + 255) / 256, N, B), dim3(256), 0, pcr_s(stream), a, b, out, N, M, C,
+                     norm);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
 }
 
 PCR_EXPORT int pcr_fps_py_f32(const float *xyz, float *temp, const int *start, int *idx, int B, int N, int M,

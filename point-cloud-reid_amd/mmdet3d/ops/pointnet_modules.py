@@ -44,14 +44,16 @@ class ConvModule(nn.Module):
 
 
 def calc_square_dist(point_feat_a, point_feat_b, norm=True):
-    """(B,N,C),(B,M,C) -> (B,N,M) squared distances by the expanded form, as the reference's F-FPS does"""
-    num_channel = point_feat_a.shape[-1]
-    a_square = torch.sum(point_feat_a.unsqueeze(dim=2).pow(2), dim=-1)
-    b_square = torch.sum(point_feat_b.unsqueeze(dim=1).pow(2), dim=-1)
-    coor = torch.matmul(point_feat_a, point_feat_b.transpose(1, 2))
-    dist = a_square + b_square - 2 * coor
-    if norm:
-        dist = torch.sqrt(dist) / num_channel
+    """(B,N,C),(B,M,C) -> (B,N,M) squared distances by the expanded form, as the reference's F-FPS does
+    (furthest_point_sample/utils.py:4-32); one HIP launch with a fixed summation order (pcr_pairwise_sqdist_f32)"""
+    L.require_cuda(point_feat_a, point_feat_b)
+    L.require_f32(point_feat_a, point_feat_b)
+    a, b = point_feat_a.contiguous(), point_feat_b.contiguous()
+    B, N, C = a.shape
+    M = b.shape[1]
+    dist = torch.empty((B, N, M), dtype=torch.float32, device=a.device)
+    L.check(L.load().pcr_pairwise_sqdist_f32(L.ptr(a), L.ptr(b), L.ptr(dist), B, N, M, C, int(bool(norm)), L.stream_ptr()),
+            "pcr_pairwise_sqdist_f32")
     return dist
 
 

@@ -21,7 +21,8 @@ def _logits(model, s1, s2):
 
 
 @pytest.mark.parametrize("workload,pairs,group", [("ssg1024", 2048, 64), ("pt1024", 512, 32), ("pointnet256", 256, 16),
-                                                  ("dgcnn128", 512, 32), ("dgcnn1024", 128, 8)])
+                                                  ("dgcnn128", 512, 32), ("dgcnn1024", 128, 8),
+                                                  ("pt4096", 256, 8)])      # BASELINE config 5: 256 pairs/GPU @4096
 def test_bench_batch_equals_small_groups(workload, pairs, group):
     desc, kind, n, bl, _ = bench.WORKLOADS[workload]
     model, _ = bench.build_model(kind, bl)
@@ -72,3 +73,22 @@ def test_dgcnn_knn_properties_at_bench_size():
     worst_in = sel.min(dim=-1)[0]
     best_out = pd.masked_fill(~mask, -1e30).max(dim=-1)[0]
     assert bool((best_out <= worst_in + 1e-3).all())
+
+
+def test_pt4096_pair_matches_cpu_oracle():
+    """BASELINE config 5's shape ([4096, 2048, 1024], K = 32/48/48) on ONE pair against the torch restatement (the
+    CPU oracle needs ~10 s for it): embeddings and logit within the north-star's 1e-4; the rest of the 256-pair batch
+    is tied to this through test_bench_batch_equals_small_groups[pt4096]"""
+    import model_oracle as MO
+    desc, kind, n, bl, _ = bench.WORKLOADS["pt4096"]
+    model, sd = bench.build_model(kind, bl)
+    s1, s2 = T.synthetic_pairs(1, n, seed=23, kind="box")
+    st = {}
+    with torch.no_grad():
+        want = MO.pt_pairs(sd, s1, s2, bl, stages=st)
+        xyz1, xyz2, h1, h2 = model.siamese_forward(s1.cuda(), s2.cuda())
+        got = model.match_forward_inference(h1, h2, xyz1, xyz2).cpu()
+    worst = dict(h1=float((h1.cpu() - st["h1"]).abs().max()), h2=float((h2.cpu() - st["h2"]).abs().max()),
+                 logits=float((got - want).abs().max()))
+    print(worst)
+    assert max(worst.values()) < 1e-4, worst

@@ -88,16 +88,78 @@ def test_point_fp_module_matches_torch():
     assert float((out - x.squeeze(-1)).abs().max()) < 2e-5
 
 
-def test_points_sampler_modes():
-    from mmdet3d.ops import Points_Sampler
+def test_points_sampler_modes_match_oracle():
+    """D-FPS, F-FPS (feature-space FPS over the calc_square_dist matrix) and FS (both, concatenated), and a two-range
+    sampler list (points_sampler.py:66-157): every index against the C oracle"""
+    from mmdet3d.ops import Points_Sampler, calc_square_dist
     xyz = T.synthetic_clouds(2, 256, seed=9, kind="randn")
-    feats = torch.randn(2, 8, 256)
+    feats = torch.randn(2, 8, 256, generator=torch.Generator().manual_seed(3))
+    f = np.concatenate([xyz.numpy(), feats.numpy().transpose(0, 2, 1)], axis=2)
+    dmat = P.pairwise_sqdist(f, f)
+    got = calc_square_dist(torch.from_numpy(f).cuda(), torch.from_numpy(f).cuda(), norm=False).cpu().numpy()
+    assert np.array_equal(got, dmat)
+    gotn = calc_square_dist(torch.from_numpy(f).cuda(), torch.from_numpy(f[:, :40]).cuda(), norm=True).cpu().numpy()
+    assert np.array_equal(gotn, P.pairwise_sqdist(f, f[:, :40], norm=True), equal_nan=True)
     idx = Points_Sampler([64], ["D-FPS"], [-1])(xyz.cuda(), feats.cuda()).cpu().numpy()
     assert (idx == P.fps(xyz.numpy(), 64)).all()
     idx = Points_Sampler([32], ["F-FPS"], [-1])(xyz.cuda(), feats.cuda())
-    assert idx.shape == (2, 32) and idx.dtype == torch.int32 and int(idx.max()) < 256
-    idx = Points_Sampler([16], ["FS"], [-1])(xyz.cuda(), feats.cuda())
-    assert idx.shape == (2, 32)
+    assert idx.dtype == torch.int32 and (idx.cpu().numpy() == P.fps_dist(dmat, 32)).all()
+    idx = Points_Sampler([16], ["FS"], [-1])(xyz.cuda(), feats.cuda()).cpu().numpy()
+    assert (idx == np.concatenate([P.fps_dist(dmat, 16), P.fps(xyz.numpy(), 16)], axis=1)).all()
+    # two ranges: F-FPS on points [0,100), D-FPS on the rest; indices of the second range are offset by 100
+    idx = Points_Sampler([8, 24], ["F-FPS", "D-FPS"], [100, -1])(xyz.cuda(), feats.cuda()).cpu().numpy()
+    f0 = f[:, :100]
+    want = np.concatenate([P.fps_dist(P.pairwise_sqdist(f0, f0), 8), P.fps(xyz.numpy()[:, 100:], 24) + 100], axis=1)
+    assert (idx == want).all()
+
+
+def test_point_sa_module_msg_two_scales_match_oracle():
+    """PointSAModuleMSG (point_sa_module.py:219-299): one FPS, one ball query + shared MLP per radius (the second
+    one dilated: min_radius = the first radius), outputs concatenated along the channels"""
+    from mmdet3d.ops import PointSAModuleMSG
+    import model_oracle as MO
+    for dilated in (False, True):
+        sa = PointSAModuleMSG(num_point=64, radii=[0.3, 0.6], sample_nums=[16, 32],
+                              mlp_channels=[[6, 16, 16, 32], [6, 32, 32, 64]], dilated_group=dilated)
+        sd = T.seeded_state_dict(T.manifest_of(sa), 9)
+        sa.load_state_dict(sd)
+        sa = sa.cuda().eval()
+        xyz = T.synthetic_clouds(2, 400, seed=12, kind="dup")
+        feats = torch.randn(2, 6, 400, generator=torch.Generator().manual_seed(2))
+        new_xyz, out, idx = sa(xyz.cuda(), feats.cuda())
+        x = xyz.numpy()
+        fps = P.fps(x, 64)
+        assert (idx.cpu().numpy() == fps).all()
+        cx = np.take_along_axis(x, fps[..., None].astype(np.int64).repeat(3, -1), 1)
+        assert np.array_equal(new_xyz.cpu().numpy(), cx)
+        outs = []
+        with torch.no_grad():
+            for i, (r, k) in enumerate(((0.3, 16), (0.6, 32))):
+                bq = torch.from_numpy(P.ball_query(0.3 if (dilated and i) else 0.0, r, k, x, cx)).long()
+                g = MO._gather_rows(xyz, bq) - torch.from_numpy(cx).unsqueeze(2)
+                h = torch.cat([g, MO._gather_rows(feats.permute(0, 2, 1), bq)], dim=-1).permute(0, 3, 1, 2)
+                for l in range(3):
+                    h = F.conv2d(h, sd[f"mlps.{i}.layer{l}.conv.weight"])
+                    h = F.relu(MO._bn(h, sd, f"mlps.{i}.layer{l}.bn", 4))
+                outs.append(h.max(dim=3)[0])
+        want = torch.cat(outs, dim=1)
+        assert out.shape == (2, 96, 64)
+        assert float((out.cpu() - want).abs().max()) < 2e-5, dilated
+
+
+def test_group_all_and_base_module_contract():
+    """GroupAll (group_points.py:132-166): [xyz ; features] as one group of all N points; a BasePointSAModule cannot
+    be built with num_point=None (point_sa_module.py:74-79 raises) in the reference either"""
+    from mmdet3d.ops import GroupAll, PointSAModuleMSG
+    xyz = T.synthetic_clouds(2, 50, seed=1, kind="box").cuda()
+    feats = torch.randn(2, 5, 50, device="cuda")
+    g = GroupAll(use_xyz=True)(xyz, None, feats)
+    assert g.shape == (2, 8, 1, 50)
+    assert torch.equal(g[:, :3, 0], xyz.transpose(1, 2)) and torch.equal(g[:, 3:, 0], feats)
+    assert torch.equal(GroupAll(use_xyz=False)(xyz, None, feats), feats.unsqueeze(2))
+    assert torch.equal(GroupAll()(xyz, None, None), xyz.transpose(1, 2).unsqueeze(2))
+    with pytest.raises(NotImplementedError):
+        PointSAModuleMSG(num_point=None, radii=[0.3], sample_nums=[8], mlp_channels=[[3, 8, 8, 8]])
 
 
 @pytest.mark.parametrize("n,npoint,radius,k,chans,kind", [(1024, 512, 0.2, 32, [0, 64, 64, 128], "box"),

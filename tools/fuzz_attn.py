@@ -16,18 +16,23 @@ from mmdet3d.models.pointnet2_utils import FP_SA, Self_Attention         # noqa:
 from pcr_amd import testing as T   # noqa: E402
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+def main(budget=None, seed=None, max_cases=None):
+    """budget seconds / seed from the command line when not given; max_cases bounds the sweep for the pytest slice
+    (tests/test_gpu_fuzz.py: fixed seeds, fixed case counts)"""
+    if budget is None:
+        budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    rng = np.random.default_rng(seed if seed is not None else (int(sys.argv[2]) if len(sys.argv) > 2 else 0))
     t0, n, worst, kinds = time.time(), 0, 0.0, {}
     tt = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))     # noqa: E731
-    while time.time() - t0 < budget:
+    while time.time() - t0 < budget and (max_cases is None or n < max_cases):
         case = ["self", "fp", "cross"][rng.integers(0, 3)]
         B = int(rng.integers(1, 5))
         Lq, Sk = int(rng.integers(1, 700)), int(rng.integers(1, 700))
         seed = int(rng.integers(0, 1000))
         if case == "self":
-            d = int(rng.choice([32, 64, 128]))
+            d = int(rng.choice([32, 64, 128, 256, 512]))
+            if d > 128:
+                Lq = min(Lq, 200)
             m = Self_Attention(d, 2)
             sd = T.seeded_state_dict(T.manifest_of(m), seed)
             m.load_state_dict(sd)
@@ -37,7 +42,10 @@ def main():
                 got = m.cuda().eval()(feat.cuda(), xyz.cuda()).cpu()
         elif case == "fp":
             c1, c2, d, out = [(64, 128, 64, 128), (32, 128, 64, 64), (3, 64, 64, 32), (16, 64, 64, 64),
-                              (64, 64, 32, 32), (128, 128, 128, 64)][rng.integers(0, 6)]
+                              (64, 64, 32, 32), (128, 128, 128, 64), (128, 256, 128, 256), (64, 256, 128, 128),
+                              (3, 128, 128, 64), (256, 512, 256, 512), (128, 512, 256, 256), (3, 256, 256, 128)][rng.integers(0, 12)]
+            if d > 128:
+                Lq, Sk = min(Lq, 200), min(Sk, 200)
             m = FP_SA(0, c1, c2, d, out, 2)
             sd = T.seeded_state_dict(T.manifest_of(m), seed)
             m.load_state_dict(sd)
@@ -61,6 +69,7 @@ def main():
         n += 1
     print("attention fuzz ok: %d blocks in %.0f s %s, worst |d| %.1e" % (n, time.time() - t0, kinds, worst))
 
+    return n, worst
 
 if __name__ == "__main__":
     main()

@@ -16,12 +16,15 @@ from mmdet3d.models.attention import local_self_attention   # noqa: E402
 from pcr_amd import dgcnn_engine as DE, engine as E, testing as T   # noqa: E402
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+def main(budget=None, seed=None, max_cases=None):
+    """budget seconds / seed from the command line when not given; max_cases bounds the sweep for the pytest slice
+    (tests/test_gpu_fuzz.py: fixed seeds, fixed case counts)"""
+    if budget is None:
+        budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    rng = np.random.default_rng(seed if seed is not None else (int(sys.argv[2]) if len(sys.argv) > 2 else 0))
     t0, n = time.time(), 0
     counts = {}
-    while time.time() - t0 < budget:
+    while time.time() - t0 < budget and (max_cases is None or n < max_cases):
         case = rng.integers(0, 5)
         kind = ["randn", "box", "dup"][rng.integers(0, 3)]
         if case == 0:      # feature kNN
@@ -75,6 +78,7 @@ def main():
         n += 1
     print("fuzz ok: %d cases in %.0f s, by kind %s" % (n, time.time() - t0, counts))
 
+    return n, counts
 
 if __name__ == "__main__":
     main()

@@ -16,11 +16,14 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "point-cloud-reid_amd")]
 from pcr_amd import engine, testing as T   # noqa: E402
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+def main(budget=None, seed=None, max_cases=None):
+    """budget seconds / seed from the command line when not given; max_cases bounds the sweep for the pytest slice
+    (tests/test_gpu_fuzz.py: fixed seeds, fixed case counts)"""
+    if budget is None:
+        budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    rng = np.random.default_rng(seed if seed is not None else (int(sys.argv[2]) if len(sys.argv) > 2 else 0))
     t0, n, worst, kinds = time.time(), 0, 0.0, {}
-    while time.time() - t0 < budget:
+    while time.time() - t0 < budget and (max_cases is None or n < max_cases):
         g = torch.Generator().manual_seed(int(rng.integers(0, 1 << 30)))
         mode = int(rng.integers(0, 2))
         D = int(rng.choice([0, 3, 8, 16, 32, 64, 128]))
@@ -28,7 +31,9 @@ def main():
         N = int(rng.integers(max(K, 8), 600))
         S = int(rng.integers(1, N + 1)) if mode == 1 else int(rng.integers(1, N + 1))
         widths = [(32, 32, 32), (64, 64, 64), (128, 128, 128), (64, 64, 128), (128, 128, 256), (24, 40, 72),
-                  (32, 64, 128)][rng.integers(0, 7)]
+                  (32, 64, 128), (256, 256, 256), (512, 512, 512), (128, 320, 384)][rng.integers(0, 10)]
+        if max(widths) > 256 or (widths[0] > 128 and mode == 0):     # the wide (mul = 2 / 4) layers: 64 rows at most per tile
+            D = int(rng.choice([0, 64, 128, 256]))
         B = int(rng.integers(1, 4))
         cin = 3 + (2 * D if mode == 0 else D)
         convs, bns, last = [], [], cin
@@ -86,6 +91,7 @@ def main():
         n += 1
     print("sa fuzz ok: %d layers in %.0f s %s, worst |d| %.1e" % (n, time.time() - t0, kinds, worst))
 
+    return n, worst
 
 if __name__ == "__main__":
     main()
