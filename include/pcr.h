@@ -335,6 +335,106 @@ int pcr_edge_max_f32(const float *ta, const float *tb, const int *idx, const flo
 int pcr_local_attn_f32(const float *qkv, const int *idx, float *msg, int B, int N, int C, int K, int nhead, float eps,
                        pcr_stream_t stream);
 
+/* ------------------------------------------------- C. training-mode kernels ------------ */
+/* Forward with BatchNorm batch statistics and backward of the same path (the reference trains it with autograd over
+ * unfused ATen ops: models/ReIDNet.py:586-634,694-738; pointnet2_utils.py:333-360; group_points_cuda.cu:10-31).
+ * All tensors are (B, C, L) channel-major fp32; every reduction is two-stage in a fixed order (per-workgroup partials
+ * + a reduce / finalize launch): no float atomics, gradients are bit-reproducible.  csrc/train_kernels.hip. */
+
+/* device-side pcr_pack_weight_f32 (weights change every iteration): W (rows x cols, leading dimension ld) -> packed
+ * image of W (transpose = 0) or of W^T (transpose = 1); packed holds pcr_packed_weight_floats(cout, cin) floats */
+int pcr_pack_weight_dev_f32(const float *w, int rows, int cols, int ld, int transpose, float *packed, pcr_stream_t stream);
+
+/* workgroups per cloud the train-dense launches use for (B, L): the partial buffers below have B * this many entries */
+int pcr_train_groups(int B, int L);
+
+/* y = [relu](W f([x ; x2]) + bias [+ res]),  f(x) = [relu](isc x + ish) on the cin1 channels of x (the previous
+ * layer's BatchNorm + ReLU, applied while the tile is loaded; isc NULL = identity).  stats (optional): partials
+ * [B * groups][2][ceil32(cout)] of sum y and sum y^2 (before res / relu) for pcr_bn_fwd_finalize_f32.  cout <= 256. */
+typedef struct pcr_tdense_fwd {
+  int B, cin1, cin2, cout, L;
+  const float *x, *x2;
+  const float *isc, *ish;
+  int in_relu;
+  const float *wp, *bias;      /* packed (cout, cin1+cin2); bias zero-padded to ceil32(cout) or NULL */
+  const float *res;
+  int out_relu;
+  float *y;
+  float *stats;
+} pcr_tdense_fwd;
+int pcr_tdense_fwd_f32(const pcr_tdense_fwd *p, pcr_stream_t stream);
+
+/* Backward of that layer.  dy is formed while the tiles are loaded: dy_mode 0: dy = g; 1: dy = ka g + kb y + kc
+ * (BatchNorm backward, constants from pcr_bn_bwd_finalize_f32; y = the layer's stored raw output); 2: dy = g [y > 0]
+ * (layer stored after its ReLU); 3: as 1 with g = the gradient gp (B,cout,S) of the max-pooled output routed to row
+ * argmax (B,cout,S) of every centre where pooled (B,cout,S) > 0 (L = S K).
+ * Outputs (each optional): dx / dx2 = W^T dy masked by f(x) > 0 when in_relu (wpT = packed W^T); dstats = partials
+ * [B * groups][2][ceil32(cin1)] of sum dx and sum dx * (raw x) for the next BatchNorm backward (iinv = 1 / isc);
+ * dwp = partials [B * groups][ceil32(cout)][ceil32(cin)] of dy f(x)^T, dbp = partials [B * groups][ceil32(cout)] of sum dy
+ * (reduce with pcr_reduce_parts_f32).  cout <= 256, cin1 + cin2 <= 288. */
+typedef struct pcr_tdense_bwd {
+  int B, cin1, cin2, cout, L;
+  const float *g, *y;
+  int dy_mode;
+  const float *ka, *kb, *kc;
+  const int *argmax;
+  const float *pooled;
+  int K, S;
+  const float *x, *x2;
+  const float *isc, *ish, *iinv;
+  int in_relu;
+  const float *wpT;
+  float *dx, *dx2, *dstats, *dwp, *dbp;
+} pcr_tdense_bwd;
+int pcr_tdense_bwd_f32(const pcr_tdense_bwd *p, pcr_stream_t stream);
+
+/* out[r][c] = sum over p < nparts (increasing p) of part[p * stride + r * ld + c] */
+int pcr_reduce_parts_f32(const float *part, int nparts, long stride, int rows, int cols, int ld, float *out,
+                         pcr_stream_t stream);
+
+/* BatchNorm (training) from the statistics partials [nparts][2][ceil32(C)] over R rows: mean, biased variance ->
+ * scale = gamma invstd, shift = beta - mean scale, inv_scale = 1 / scale; running statistics updated in place
+ * (momentum, unbiased variance) when given.  nn.BatchNorm2d semantics (pointnet2_utils.py:353-355). */
+typedef struct pcr_bn_fwd_fin {
+  const float *part;
+  int nparts, C;
+  double R;
+  const float *gamma, *beta;
+  float eps, momentum;
+  float *running_mean, *running_var;
+  float *scale, *shift, *inv_scale, *mean, *invstd;
+} pcr_bn_fwd_fin;
+int pcr_bn_fwd_finalize_f32(const pcr_bn_fwd_fin *p, pcr_stream_t stream);
+
+/* BatchNorm backward constants from partials [nparts][2][ceil32(C)] of S1 = sum dyhat, S2 = sum dyhat * y:
+ * dbeta = S1, dgamma = invstd (S2 - mean S1), and ka, kb, kc with dy = ka dyhat + kb y + kc */
+typedef struct pcr_bn_bwd_fin {
+  const float *part;
+  int nparts, C;
+  double R;
+  const float *gamma, *mean, *invstd;
+  float *ka, *kb, *kc, *dgamma, *dbeta;
+} pcr_bn_bwd_fin;
+int pcr_bn_bwd_finalize_f32(const pcr_bn_bwd_fin *p, pcr_stream_t stream);
+
+/* First layer of the grouped edge MLP from per-point tables (training; csrc/train_sa_kernels.hip):
+ * y[b][c][s K + k] = wa[c] . (xyz[idx] - xyz[s]) + bias[c] + tab[b][c][idx] + tab[b][c1 + c][s]   (tab NULL: no
+ * point features), stats = partials [B][2][ceil32(c1)] of sum y, sum y^2.  Centres are the first S points. */
+int pcr_sa_l1_fwd_f32(const float *xyz, const int *idx, const float *tab, const float *wa, const float *bias,
+                      float *y, float *stats, int B, int N, int S, int K, int c1, pcr_stream_t stream);
+/* its backward: dy = ka g + kb y + kc; dtab (B,2 c1,N) = [sum of dy over the rows that gathered each point ; sum over
+ * the K rows of each centre (zero beyond S)], dwa = partials [B][c1][4] of (d wa, d bias).  No atomics: every
+ * accumulator has one owner that adds in row order. */
+int pcr_sa_l1_bwd_f32(const float *xyz, const int *idx, const float *g, const float *y, const float *ka,
+                      const float *kb, const float *kc, float *dtab, float *dwa, int B, int N, int S, int K, int c1,
+                      pcr_stream_t stream);
+/* pooled[b][c][s] = max_k relu(scale[c] y[b][c][s K + k] + shift[c]), argmax = the first k attaining it */
+int pcr_sa_pool_fwd_f32(const float *y, const float *scale, const float *shift, float *pooled, int *argmax, int B,
+                        int C, int S, int K, pcr_stream_t stream);
+/* partials [B][2][ceil32(C)] of S1 = sum gp [pooled > 0], S2 = sum gp [pooled > 0] y[argmax] for pcr_bn_bwd_finalize_f32 */
+int pcr_sa_pool_bwd_stats_f32(const float *gp, const float *pooled, const int *argmax, const float *y, float *part,
+                              int B, int C, int S, int K, pcr_stream_t stream);
+
 /* ---- measurement aid (bench.py; not on the hot path) ---- */
 
 /* Sustained f32-MFMA probe: n_wg workgroups (one per CU: pass the CU count) each run iters * 16

@@ -1,0 +1,652 @@
+// Training-mode kernels of the siamese ReID hot path (forward with BatchNorm batch statistics + backward).
+//
+// The reference trains this path with unfused autograd ops over materialised (B,C,S,K) tensors
+// (models/ReIDNet.py:586-634,694-738; models/pointnet2_utils.py:333-360 with BatchNorm2d in batch-statistics mode).
+// Here every dense layer is ONE launch forward and ONE launch backward, on the same (B, C, L) channel-major tensors
+// the inference kernels use (L = S*K rows for the grouped MLPs):
+//   forward  y = W f(x) + b            f = the previous layer's BatchNorm affine + ReLU, applied WHILE the tile is
+//                                      loaded (the normalised activation never exists in HBM); per-channel sum and
+//                                      sum of squares of y leave the kernel as per-workgroup partials;
+//   backward dy = BN-backward(g, y)    formed while the tiles are loaded (BatchNorm's backward is linear in the
+//                                      incoming gradient and the stored pre-activation: dy = ka g + kb y + kc);
+//            dW += dy f(x)^T           on the matrix core (contraction over the tokens of the tile), accumulated
+//                                      in registers over the workgroup's tiles;
+//            dx  = (W^T dy) [f(x) > 0] on the matrix core, with the sums the NEXT BatchNorm backward needs.
+// What a layer keeps for its backward is its raw output y (needed anyway: BatchNorm statistics are global, so the
+// layer below cannot be normalised before the whole layer above it exists).  All reductions are two-stage with a
+// fixed order (per-workgroup partials, then a reduce kernel): no float atomics, bit-reproducible gradients.
+#include "tile_dense.h"
+
+namespace {
+
+constexpr int kTT = 64, kTRP = 65;   // tokens per tile (TB = 2), LDS row pitch
+
+// dst[c][t] = f(c, t0 + t) for c < C, zero for rows [C, CP) and tokens beyond L.  F4(c, tg) -> four tokens
+// tg .. tg+3 (whole, aligned tiles only), F1(c, tg) -> one.  Loads are issued in batches from clamped addresses.
+template <class F4, class F1>
+__device__ __forceinline__ void tile_fill(float *dst, int C, int CP, int L, int t0, bool vec, F4 f4, F1 f1) {
+  constexpr int T = kTT, RP = kTRP, Q = T / 4;
+  if (vec && t0 + T <= L) {
+    const int totq = CP * Q;
+    for (int e0 = threadIdx.x; e0 < totq; e0 += 4 * kThreads) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = e0 + u * kThreads;
+        const int c = e / Q, q = e - c * Q;
+        const bool ok = e < totq && c < C;
+        const f32x4 x = f4(ok ? c : 0, t0 + 4 * (ok ? q : 0));
+        v[u] = ok ? x : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = e0 + u * kThreads;
+        if (e < totq) {
+          const int c = e / Q, q = e - c * Q;
+          float *d = dst + c * RP + 4 * q;
+          d[0] = v[u][0];
+          d[1] = v[u][1];
+          d[2] = v[u][2];
+          d[3] = v[u][3];
+        }
+      }
+    }
+  } else {
+    const int total = CP * T;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 4 * kThreads) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = e0 + u * kThreads;
+        const int c = e / T, t = e - c * T;
+        const bool ok = e < total && c < C && t0 + t < L;
+        const float x = f1(ok ? c : 0, ok ? t0 + t : 0);
+        v[u] = ok ? x : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = e0 + u * kThreads;
+        if (e < total) {
+          const int c = e / T, t = e - c * T;
+          dst[c * RP + t] = v[u];
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+
+// ---------------------------------------------------------------------------------- forward ----
+struct TFwd {
+  const float *x, *x2;              // (B,cin1,L), (B,cin2,L) or null: the layer's input is [x ; x2] along the channels
+  int cin1, cin2;
+  const float *isc, *ish;           // (cin1) input affine of x (previous BatchNorm), null = none
+  int in_relu;
+  const float *wp, *bias;           // packed (cout, cin1+cin2); bias zero-padded to ceil32(cout), or null
+  const float *res;                 // (B,cout,L) added to the output, or null
+  int out_relu;
+  float *y;
+  int cout, L, tpw;                 // tiles per workgroup
+  float *stats;                     // partials [workgroups][2][ceil32(cout)] (sum, sum of squares of y), or null
+};
+
+template <int NR>
+__global__ __launch_bounds__(kThreads) void tdense_fwd_kernel(TFwd a) {
+  constexpr int TB = 2, T = kTT, RP = kTRP;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int cin = a.cin1 + a.cin2, cinP = ceil8(cin), coutP = ceil32(a.cout), L = a.L;
+  const int rows = cinP > coutP ? cinP : coutP;
+  float *X = smem;
+  float *s_isc = X + rows * RP, *s_ish = s_isc + a.cin1;
+  const int tid = threadIdx.x;
+  const size_t b = blockIdx.y;
+  const bool aff = a.isc != nullptr;
+  if (aff)
+    for (int e = tid; e < a.cin1; e += kThreads) {
+      s_isc[e] = a.isc[e];
+      s_ish[e] = a.ish[e];
+    }
+  const float *xb = a.x + b * a.cin1 * L;
+  const float *x2b = a.x2 ? a.x2 + b * a.cin2 * L : xb;
+  const float *resb = a.res ? a.res + b * a.cout * L : nullptr;
+  float *yb = a.y + b * a.cout * L;
+  const bool vec = (L & 3) == 0;
+  const int cin1 = a.cin1, in_relu = a.in_relu;
+  float ssum = 0.f, ssq = 0.f;
+  __syncthreads();
+  auto f4 = [&](int c, int tg) {
+    const bool first = c < cin1;
+    f32x4 v = ld4((first ? xb + (size_t)c * L : x2b + (size_t)(c - cin1) * L) + tg);
+    if (aff && first) {
+      const float sc = s_isc[c], sh = s_ish[c];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        v[j] = v[j] * sc + sh;
+        if (in_relu) v[j] = fmaxf(v[j], 0.f);
+      }
+    }
+    return v;
+  };
+  auto f1 = [&](int c, int tg) {
+    const bool first = c < cin1;
+    float v = (first ? xb + (size_t)c * L : x2b + (size_t)(c - cin1) * L)[tg];
+    if (aff && first) {
+      v = v * s_isc[c] + s_ish[c];
+      if (in_relu) v = fmaxf(v, 0.f);
+    }
+    return v;
+  };
+  for (int ti = 0; ti < a.tpw; ti++) {
+    const int t0 = (blockIdx.x * a.tpw + ti) * T;
+    if (t0 >= L) break;
+    if (ti) __syncthreads();
+    tile_fill(X, cin, cinP, L, t0, vec, f4, f1);
+    __syncthreads();
+    tile_dense2<TB, NR>(X, cinP, a.wp, coutP, true, [&](float v, int o, int t) { X[o * RP + t] = v; }, a.bias);
+    __syncthreads();
+    const int valid = L - t0 < T ? L - t0 : T;
+    if (a.stats && tid < coutP) {   // BatchNorm statistics of the raw output (bias included)
+      const float *row = X + tid * RP;
+      for (int t = 0; t < valid; t++) {
+        const float v = row[t];
+        ssum += v;
+        ssq += v * v;
+      }
+    }
+    if (vec && valid == T) {
+      constexpr int Q = T / 4;
+      for (int e = tid; e < a.cout * Q; e += kThreads) {
+        const int o = e / Q, q = e - o * Q;
+        const float *xs = X + o * RP + 4 * q;
+        f32x4 v = {xs[0], xs[1], xs[2], xs[3]};
+        if (resb) {
+          const f32x4 r = ld4(resb + (size_t)o * L + t0 + 4 * q);
+          v += r;
+        }
+        if (a.out_relu) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) v[j] = fmaxf(v[j], 0.f);
+        }
+        *reinterpret_cast<f32x4 *>(yb + (size_t)o * L + t0 + 4 * q) = v;
+      }
+    } else {
+      for (int e = tid; e < a.cout * T; e += kThreads) {
+        const int o = e / T, t = e - o * T;
+        if (t < valid) {
+          float v = X[o * RP + t];
+          if (resb) v += resb[(size_t)o * L + t0 + t];
+          if (a.out_relu) v = fmaxf(v, 0.f);
+          yb[(size_t)o * L + t0 + t] = v;
+        }
+      }
+    }
+  }
+  if (a.stats && tid < coutP) {
+    float *sp = a.stats + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * coutP;
+    sp[tid] = ssum;
+    sp[coutP + tid] = ssq;
+  }
+}
+
+// --------------------------------------------------------------------------------- backward ----
+// dy_mode: 0 dy = g | 1 dy = ka g + kb y + kc (BatchNorm backward) | 2 dy = g [y > 0] (ReLU output layer)
+//          3 g is the gradient of the max-pooled output: g_eff[c][s K + k] = gp[c][s] if k == argmax[c][s] and
+//            pooled[c][s] > 0, else 0; then as mode 1
+struct TBwd {
+  const float *g, *y;
+  int dy_mode;
+  const float *ka, *kb, *kc;
+  const int *argmax;
+  const float *pooled;
+  int K, S;
+  const float *x, *x2;              // the layer's forward input, as in TFwd
+  int cin1, cin2;
+  const float *isc, *ish, *iinv;    // input affine (+ 1 / isc: recovers the raw input for the next BN backward)
+  int in_relu;
+  const float *wpT;                 // packed (cin, cout) = W^T, or null: no input gradient wanted
+  float *dx, *dx2;
+  float *dstats;                    // partials [workgroups][2][ceil32(cin1)]: sum dxm, sum dxm * raw x (dxm = masked dx)
+  float *dwp, *dbp;                 // partials [workgroups][ceil32(cout)][ceil32(cin)], [workgroups][ceil32(cout)]
+  int cout, L, tpw;
+};
+
+template <int NRX, int NTW>
+__global__ __launch_bounds__(kThreads) void tdense_bwd_kernel(TBwd a) {
+  constexpr int TB = 2, T = kTT, RP = kTRP;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int cin = a.cin1 + a.cin2, cinP = ceil32(cin), coutP = ceil32(a.cout), L = a.L;
+  const int rowsY = coutP > cinP ? coutP : cinP;
+  float *DY = smem;                 // [rowsY][RP]: dy, then (in place) W^T dy
+  float *AT = DY + rowsY * RP;      // [cinP][RP]: the forward input f(x)
+  float *s_k = AT + cinP * RP;      // ka | kb | kc (cout each), isc | ish | iinv (cin1 each)
+  float *s_ka = s_k, *s_kb = s_k + a.cout, *s_kc = s_k + 2 * a.cout;
+  float *s_isc = s_k + 3 * a.cout, *s_ish = s_isc + a.cin1, *s_iinv = s_ish + a.cin1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const size_t b = blockIdx.y;
+  const int z = blockIdx.z;
+  const bool bn = a.dy_mode == 1 || a.dy_mode == 3;
+  const bool aff = a.isc != nullptr;
+  for (int e = tid; e < a.cout; e += kThreads) {
+    s_ka[e] = bn ? a.ka[e] : 1.f;
+    s_kb[e] = bn ? a.kb[e] : 0.f;
+    s_kc[e] = bn ? a.kc[e] : 0.f;
+  }
+  for (int e = tid; e < a.cin1; e += kThreads) {
+    s_isc[e] = aff ? a.isc[e] : 1.f;
+    s_ish[e] = aff ? a.ish[e] : 0.f;
+    s_iinv[e] = (aff && a.iinv) ? a.iinv[e] : 1.f;
+  }
+  const int mode = a.dy_mode, K = a.K, S = a.S;
+  const float *gb = mode == 3 ? a.g + b * a.cout * S : a.g + b * a.cout * L;
+  const float *yb = a.y ? a.y + b * a.cout * L : gb;
+  const int *amb = mode == 3 ? a.argmax + b * a.cout * S : nullptr;
+  const float *plb = mode == 3 ? a.pooled + b * a.cout * S : nullptr;
+  const float *xb = a.x + b * a.cin1 * L;
+  const float *x2b = a.x2 ? a.x2 + b * a.cin2 * L : xb;
+  const bool vec = (L & 3) == 0;
+  const int cin1 = a.cin1, in_relu = a.in_relu;
+  // the gradient tile: one fetch per element whatever the mode (mode 3 reads the small pooled tensors instead of g)
+  auto g1 = [&](int c, int tg) {
+    if (mode != 3) return gb[(size_t)c * L + tg];
+    const int s = tg / K, k = tg - s * K;
+    const size_t o = (size_t)c * S + s;
+    return (amb[o] == k && plb[o] > 0.f) ? gb[o] : 0.f;
+  };
+  auto dy4 = [&](int c, int tg) {
+    f32x4 g;
+    if (mode != 3) g = ld4(gb + (size_t)c * L + tg);
+    else {
+#pragma unroll
+      for (int j = 0; j < 4; j++) g[j] = g1(c, tg + j);
+    }
+    if (mode == 0) return g;
+    const f32x4 yv = ld4(yb + (size_t)c * L + tg);
+    f32x4 r;
+    if (mode == 2) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) r[j] = yv[j] > 0.f ? g[j] : 0.f;
+    } else {
+      const float ka = s_ka[c], kb = s_kb[c], kc = s_kc[c];
+#pragma unroll
+      for (int j = 0; j < 4; j++) r[j] = ka * g[j] + kb * yv[j] + kc;
+    }
+    return r;
+  };
+  auto dy1 = [&](int c, int tg) {
+    const float g = g1(c, tg);
+    if (mode == 0) return g;
+    const float yv = yb[(size_t)c * L + tg];
+    if (mode == 2) return yv > 0.f ? g : 0.f;
+    return s_ka[c] * g + s_kb[c] * yv + s_kc[c];
+  };
+  auto a4 = [&](int c, int tg) {
+    const bool first = c < cin1;
+    f32x4 v = ld4((first ? xb + (size_t)c * L : x2b + (size_t)(c - cin1) * L) + tg);
+    if (aff && first) {
+      const float sc = s_isc[c], sh = s_ish[c];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        v[j] = v[j] * sc + sh;
+        if (in_relu) v[j] = fmaxf(v[j], 0.f);
+      }
+    }
+    return v;
+  };
+  auto a1 = [&](int c, int tg) {
+    const bool first = c < cin1;
+    float v = (first ? xb + (size_t)c * L : x2b + (size_t)(c - cin1) * L)[tg];
+    if (aff && first) {
+      v = v * s_isc[c] + s_ish[c];
+      if (in_relu) v = fmaxf(v, 0.f);
+    }
+    return v;
+  };
+  // dW tiles of this workgroup: items [z 4 NTW, (z + 1) 4 NTW) of the (cout block, cin block) grid
+  const int nIB = cinP >> 5, items = (coutP >> 5) * nIB;
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+  float dbsum = 0.f, s1 = 0.f, s2 = 0.f;
+  const bool want_dx = a.wpT != nullptr && z == 0;
+  __syncthreads();
+  for (int ti = 0; ti < a.tpw; ti++) {
+    const int t0 = (blockIdx.x * a.tpw + ti) * T;
+    if (t0 >= L) break;
+    if (ti) __syncthreads();
+    tile_fill(DY, a.cout, rowsY, L, t0, vec, dy4, dy1);
+    tile_fill(AT, cin, cinP, L, t0, vec, a4, a1);
+    __syncthreads();
+    const int valid = L - t0 < T ? L - t0 : T;
+    // (tile_fill leaves the padding tokens of a ragged tile zero, also where BatchNorm's backward adds a constant)
+    if (a.dbp && z == 0 && tid < coutP) {
+      const float *row = DY + tid * RP;
+      float s = 0.f;
+      for (int t = 0; t < T; t++) s += row[t];
+      dbsum += s;
+    }
+    if (a.dwp) {
+#pragma unroll
+      for (int it = 0; it < NTW; it++) {
+        const int item = z * 4 * NTW + wave + 4 * it;
+        if (item < items) {
+          const int ob = item / nIB, ib = item - ob * nIB;
+          const float *ap = DY + (ob * 32 + l31) * RP + h;
+          const float *bp = AT + (ib * 32 + l31) * RP + h;
+#pragma unroll 8
+          for (int ks = 0; ks < T / 2; ks++)
+            acc[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc[it], 0, 0, 0);
+        }
+      }
+    }
+    if (want_dx) {
+      // (the barrier between this call's k-loop and its epilogue also orders the dW reads of DY above before the
+      // in-place overwrite)
+      tile_dense2<TB, NRX>(DY, ceil8(a.cout), a.wpT, cinP, true, [&](float v, int o, int t) { DY[o * RP + t] = v; });
+      __syncthreads();
+      if (a.dstats && tid < cin1) {
+        const float *dr = DY + tid * RP, *ar = AT + tid * RP;
+        const float sh = s_ish[tid], inv = s_iinv[tid];
+        for (int t = 0; t < valid; t++) {
+          const float av = ar[t];
+          const float v = (!in_relu || av > 0.f) ? dr[t] : 0.f;
+          s1 += v;
+          s2 += v * ((av - sh) * inv);
+        }
+      }
+      for (int e = tid; e < cin * T; e += kThreads) {
+        const int c = e / T, t = e - c * T;
+        if (t < valid) {
+          float v = DY[c * RP + t];
+          if (c < cin1) {
+            if (in_relu && !(AT[c * RP + t] > 0.f)) v = 0.f;
+            a.dx[(b * cin1 + c) * L + t0 + t] = v;
+          } else {
+            a.dx2[(b * a.cin2 + (c - cin1)) * L + t0 + t] = v;
+          }
+        }
+      }
+    }
+  }
+  const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  if (a.dwp) {
+    float *dw = a.dwp + wg * (size_t)coutP * cinP;
+#pragma unroll
+    for (int it = 0; it < NTW; it++) {
+      const int item = z * 4 * NTW + wave + 4 * it;
+      if (item < items) {
+        const int ob = item / nIB, ib = item - ob * nIB;
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          dw[(size_t)(ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * cinP + ib * 32 + l31] = acc[it][r];
+      }
+    }
+  }
+  if (a.dbp && z == 0 && tid < coutP) a.dbp[wg * coutP + tid] = dbsum;
+  if (a.dstats && want_dx) {
+    const int c1P = ceil32(cin1);
+    float *sp = a.dstats + wg * 2 * (size_t)c1P;
+    if (tid < c1P) {
+      sp[tid] = tid < cin1 ? s1 : 0.f;
+      sp[c1P + tid] = tid < cin1 ? s2 : 0.f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------- reductions / finalisers ----
+// out[e] = sum over p of part[p][e], p in increasing order (fixed order => reproducible); optional row gather:
+// element e = (row r, col c) of a (rows x cols) result reads part[p][r * ld + c]
+__global__ void reduce_parts_kernel(const float *__restrict__ part, int nparts, size_t stride, int rows, int cols,
+                                    int ld, float *__restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * cols) return;
+  const int r = e / cols, c = e - r * cols;
+  const float *p = part + (size_t)r * ld + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four interleaved chains (fixed association), then a fixed combine
+  int q = 0;
+  for (; q + 4 <= nparts; q += 4) {
+    s0 += p[(size_t)q * stride];
+    s1 += p[(size_t)(q + 1) * stride];
+    s2 += p[(size_t)(q + 2) * stride];
+    s3 += p[(size_t)(q + 3) * stride];
+  }
+  for (; q < nparts; q++) s0 += p[(size_t)q * stride];
+  out[e] = (s0 + s1) + (s2 + s3);
+}
+
+// partial sums [nparts][2][CP] -> per-channel totals in double.  Block = 32 channels x 8 part lanes.
+__device__ __forceinline__ void sum_parts2(const float *part, int nparts, int CP, int c, double &t0, double &t1,
+                                           double (*red)[8][32]) {
+  const int cl = threadIdx.x & 31, pg = threadIdx.x >> 5;
+  double a0 = 0.0, a1 = 0.0;
+  for (int p = pg; p < nparts; p += 8) {
+    a0 += (double)part[((size_t)p * 2) * CP + c];
+    a1 += (double)part[((size_t)p * 2 + 1) * CP + c];
+  }
+  red[0][pg][cl] = a0;
+  red[1][pg][cl] = a1;
+  __syncthreads();
+  t0 = 0.0;
+  t1 = 0.0;
+  for (int i = 0; i < 8; i++) {
+    t0 += red[0][i][cl];
+    t1 += red[1][i][cl];
+  }
+}
+
+struct BnFwdFin {
+  const float *part;
+  int nparts, CP, C;
+  double R;
+  const float *gamma, *beta;
+  float eps, momentum;
+  float *running_mean, *running_var;    // updated in place (may be null)
+  float *scale, *shift, *inv_scale, *mean, *invstd;
+};
+
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(BnFwdFin a) {
+  __shared__ double red[2][8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  double s, sq;
+  sum_parts2(a.part, a.nparts, a.CP, c < a.CP ? c : 0, s, sq, red);
+  if ((threadIdx.x >> 5) != 0 || c >= a.C) return;
+  const double mean = s / a.R;
+  double var = sq / a.R - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)a.eps);
+  const double sc = (double)a.gamma[c] * invstd;
+  a.scale[c] = (float)sc;
+  a.shift[c] = (float)((double)a.beta[c] - mean * sc);
+  a.inv_scale[c] = sc != 0.0 ? (float)(1.0 / sc) : 0.f;
+  a.mean[c] = (float)mean;
+  a.invstd[c] = (float)invstd;
+  if (a.running_mean) {
+    const double m = a.momentum;
+    a.running_mean[c] = (float)((1.0 - m) * (double)a.running_mean[c] + m * mean);
+    const double unb = a.R > 1.0 ? var * a.R / (a.R - 1.0) : var;
+    a.running_var[c] = (float)((1.0 - m) * (double)a.running_var[c] + m * unb);
+  }
+}
+
+// BatchNorm backward constants from S1 = sum dyhat, S2 = sum dyhat * y (y = the raw pre-activation):
+//   dbeta = S1, dgamma = invstd (S2 - mean S1), dy = ka dyhat + kb y + kc with
+//   ka = gamma invstd, kb = -ka dgamma invstd / R, kc = ka (dgamma invstd mean - dbeta) / R
+struct BnBwdFin {
+  const float *part;
+  int nparts, CP, C;
+  double R;
+  const float *gamma, *mean, *invstd;
+  float *ka, *kb, *kc, *dgamma, *dbeta;
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdFin a) {
+  __shared__ double red[2][8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  double s1, s2;
+  sum_parts2(a.part, a.nparts, a.CP, c < a.CP ? c : 0, s1, s2, red);
+  if ((threadIdx.x >> 5) != 0 || c >= a.C) return;
+  const double mean = a.mean[c], invstd = a.invstd[c], gamma = a.gamma[c];
+  const double dgamma = invstd * (s2 - mean * s1);
+  const double ka = gamma * invstd;
+  a.dgamma[c] = (float)dgamma;
+  a.dbeta[c] = (float)s1;
+  a.ka[c] = (float)ka;
+  a.kb[c] = (float)(-ka * dgamma * invstd / a.R);
+  a.kc[c] = (float)(ka * (dgamma * invstd * mean - s1) / a.R);
+}
+
+// W (rows x cols, row-major, leading dimension ld) -> packed MFMA A-operand image of W (transpose = 0: cout = rows,
+// cin = cols) or of W^T (transpose = 1: cout = cols, cin = rows): element (kb, o, h, j) = M[o][kb*8 + 2*j + h]
+__global__ void pack_weight_kernel(const float *__restrict__ w, int rows, int cols, int ld, int transpose,
+                                   float *__restrict__ packed) {
+  const int cout = transpose ? cols : rows, cin = transpose ? rows : cols;
+  const int CP = ceil8(cin), OP = ceil32(cout);
+  const int total = CP * OP;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int j = e & 3, hh = (e >> 2) & 1, o = (e >> 3) % OP, kb = (e >> 3) / OP;
+    const int k = kb * 8 + 2 * j + hh;
+    float v = 0.f;
+    if (o < cout && k < cin) v = transpose ? w[(size_t)k * ld + o] : w[(size_t)o * ld + k];
+    packed[e] = v;
+  }
+}
+
+template <class K>
+static bool big_lds(K k) {
+  return allow_big_lds(k);
+}
+
+}  // namespace
+
+static int wg_groups(int B, int ntiles) {
+  // workgroups per cloud: enough to fill the chip a few times over, few enough that the per-workgroup partials
+  // (dW images, statistics) stay small: ~2048 workgroups per launch
+  int g = (2048 + B - 1) / (B > 0 ? B : 1);
+  if (g < 1) g = 1;
+  if (g > ntiles) g = ntiles;
+  return g;
+}
+
+PCR_EXPORT int pcr_train_groups(int B, int L) {
+  const int ntiles = (L + kTT - 1) / kTT;
+  const int g = wg_groups(B, ntiles);
+  const int tpw = (ntiles + g - 1) / g;
+  return (ntiles + tpw - 1) / tpw;   // workgroups per cloud actually launched
+}
+
+PCR_EXPORT int pcr_pack_weight_dev_f32(const float *w, int rows, int cols, int ld, int transpose, float *packed,
+                                       pcr_stream_t stream) {
+  if (!w || !packed || rows < 1 || cols < 1 || ld < cols) return PCR_ERR_INVALID;
+  const int cout = transpose ? cols : rows, cin = transpose ? rows : cols;
+  const int total = ceil8(cin) * ceil32(cout);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0,
+                     pcr_s(stream), w, rows, cols, ld, transpose, packed);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_tdense_fwd_f32(const pcr_tdense_fwd *p, pcr_stream_t stream) {
+  if (!p || !p->x || !p->wp || !p->y || p->B < 0 || p->cin1 < 1 || p->cin2 < 0 || p->cout < 1 || p->cout > 256 ||
+      p->L < 1 || (p->cin2 && !p->x2) || (p->isc && !p->ish))
+    return PCR_ERR_INVALID;
+  if (p->B == 0) return PCR_OK;
+  if (p->B > 65535) return PCR_ERR_INVALID;
+  TFwd a;
+  a.x = p->x; a.x2 = p->cin2 ? p->x2 : nullptr; a.cin1 = p->cin1; a.cin2 = p->cin2;
+  a.isc = p->isc; a.ish = p->ish; a.in_relu = p->in_relu;
+  a.wp = p->wp; a.bias = p->bias; a.res = p->res; a.out_relu = p->out_relu;
+  a.y = p->y; a.cout = p->cout; a.L = p->L; a.stats = p->stats;
+  const int ntiles = (p->L + kTT - 1) / kTT;
+  const int g = wg_groups(p->B, ntiles);
+  a.tpw = (ntiles + g - 1) / g;
+  const int gx = (ntiles + a.tpw - 1) / a.tpw;
+  const int cinP = ceil8(p->cin1 + p->cin2), coutP = ceil32(p->cout);
+  const size_t lds = ((size_t)(cinP > coutP ? cinP : coutP) * kTRP + 2 * (size_t)p->cin1) * sizeof(float);
+  if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
+  static bool ok = big_lds(tdense_fwd_kernel<1>) && big_lds(tdense_fwd_kernel<2>);
+  (void)ok;
+  if (coutP > 128) hipLaunchKernelGGL(tdense_fwd_kernel<2>, dim3(gx, p->B), dim3(kThreads), lds, pcr_s(stream), a);
+  else hipLaunchKernelGGL(tdense_fwd_kernel<1>, dim3(gx, p->B), dim3(kThreads), lds, pcr_s(stream), a);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_tdense_bwd_f32(const pcr_tdense_bwd *p, pcr_stream_t stream) {
+  if (!p || !p->g || !p->x || p->B < 0 || p->cin1 < 1 || p->cin2 < 0 || p->cout < 1 || p->cout > 256 || p->L < 1 ||
+      p->cin1 + p->cin2 > 288 || (p->cin2 && !p->x2) || p->dy_mode < 0 || p->dy_mode > 3)
+    return PCR_ERR_INVALID;
+  if ((p->dy_mode == 1 || p->dy_mode == 3) && (!p->ka || !p->kb || !p->kc || !p->y)) return PCR_ERR_INVALID;
+  if (p->dy_mode == 2 && !p->y) return PCR_ERR_INVALID;
+  if (p->dy_mode == 3 && (!p->argmax || !p->pooled || p->K < 1 || p->S < 1 || p->S * p->K != p->L)) return PCR_ERR_INVALID;
+  if (p->wpT && (!p->dx || (p->cin2 && !p->dx2))) return PCR_ERR_INVALID;
+  if (p->dwp && !p->dbp) return PCR_ERR_INVALID;
+  if (p->B == 0) return PCR_OK;
+  if (p->B > 65535) return PCR_ERR_INVALID;
+  TBwd a;
+  a.g = p->g; a.y = p->y; a.dy_mode = p->dy_mode; a.ka = p->ka; a.kb = p->kb; a.kc = p->kc;
+  a.argmax = p->argmax; a.pooled = p->pooled; a.K = p->K; a.S = p->S;
+  a.x = p->x; a.x2 = p->cin2 ? p->x2 : nullptr; a.cin1 = p->cin1; a.cin2 = p->cin2;
+  a.isc = p->isc; a.ish = p->ish; a.iinv = p->iinv; a.in_relu = p->in_relu;
+  a.wpT = p->wpT; a.dx = p->dx; a.dx2 = p->dx2; a.dstats = p->dstats; a.dwp = p->dwp; a.dbp = p->dbp;
+  a.cout = p->cout; a.L = p->L;
+  const int ntiles = (p->L + kTT - 1) / kTT;
+  const int g = wg_groups(p->B, ntiles);
+  a.tpw = (ntiles + g - 1) / g;
+  const int gx = (ntiles + a.tpw - 1) / a.tpw;
+  const int cinP = ceil32(p->cin1 + p->cin2), coutP = ceil32(p->cout);
+  const size_t lds = ((size_t)((coutP > cinP ? coutP : cinP) + cinP) * kTRP + 3 * (size_t)p->cout + 3 * (size_t)p->cin1) *
+                     sizeof(float);
+  if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
+  constexpr int NTW = 4;
+  const int items = (coutP >> 5) * (cinP >> 5);
+  const int gz = p->dwp ? (items + 4 * NTW - 1) / (4 * NTW) : 1;
+  static bool ok = big_lds(tdense_bwd_kernel<1, NTW>) && big_lds(tdense_bwd_kernel<2, NTW>) &&
+                   big_lds(tdense_bwd_kernel<3, NTW>);
+  (void)ok;
+  const dim3 grid(gx, p->B, gz);
+  const int nx = cinP >> 5;
+  if (nx > 8) hipLaunchKernelGGL((tdense_bwd_kernel<3, NTW>), grid, dim3(kThreads), lds, pcr_s(stream), a);
+  else if (nx > 4) hipLaunchKernelGGL((tdense_bwd_kernel<2, NTW>), grid, dim3(kThreads), lds, pcr_s(stream), a);
+  else hipLaunchKernelGGL((tdense_bwd_kernel<1, NTW>), grid, dim3(kThreads), lds, pcr_s(stream), a);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_reduce_parts_f32(const float *part, int nparts, long stride, int rows, int cols, int ld, float *out,
+                                    pcr_stream_t stream) {
+  if (!part || !out || nparts < 1 || rows < 1 || cols < 1 || ld < cols) return PCR_ERR_INVALID;
+  const int total = rows * cols;
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((total + 255) / 256), dim3(256), 0, pcr_s(stream), part, nparts,
+                     (size_t)stride, rows, cols, ld, out);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_bn_fwd_finalize_f32(const pcr_bn_fwd_fin *p, pcr_stream_t stream) {
+  if (!p || !p->part || p->nparts < 1 || p->C < 1 || p->R < 1 || !p->gamma || !p->beta || !p->scale || !p->shift ||
+      !p->inv_scale || !p->mean || !p->invstd)
+    return PCR_ERR_INVALID;
+  BnFwdFin a;
+  a.part = p->part; a.nparts = p->nparts; a.CP = ceil32(p->C); a.C = p->C; a.R = p->R;
+  a.gamma = p->gamma; a.beta = p->beta; a.eps = p->eps; a.momentum = p->momentum;
+  a.running_mean = p->running_mean; a.running_var = p->running_var;
+  a.scale = p->scale; a.shift = p->shift; a.inv_scale = p->inv_scale; a.mean = p->mean; a.invstd = p->invstd;
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(a.CP / 32), dim3(256), 0, pcr_s(stream), a);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_bn_bwd_finalize_f32(const pcr_bn_bwd_fin *p, pcr_stream_t stream) {
+  if (!p || !p->part || p->nparts < 1 || p->C < 1 || p->R < 1 || !p->gamma || !p->mean || !p->invstd || !p->ka ||
+      !p->kb || !p->kc || !p->dgamma || !p->dbeta)
+    return PCR_ERR_INVALID;
+  BnBwdFin a;
+  a.part = p->part; a.nparts = p->nparts; a.CP = ceil32(p->C); a.C = p->C; a.R = p->R;
+  a.gamma = p->gamma; a.mean = p->mean; a.invstd = p->invstd;
+  a.ka = p->ka; a.kb = p->kb; a.kc = p->kc; a.dgamma = p->dgamma; a.dbeta = p->dbeta;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.CP / 32), dim3(256), 0, pcr_s(stream), a);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}

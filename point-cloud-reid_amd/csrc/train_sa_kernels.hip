@@ -1,0 +1,361 @@
+// Training-mode pieces of the grouped set-abstraction layer (models/pointnet2_utils.py:242-288, 333-357) that are
+// not plain dense layers: the first MLP layer evaluated from per-point tables (forward and backward) and the max
+// over K with its argmax (forward) / the BatchNorm-backward sums of the pooled gradient.
+//
+// Layer 1 is linear in its input row [dxyz, f_c, f_i - f_c], so y1 = Wa dxyz + P[i] + Q[c] + b with the per-POINT
+// tables P = Wf f, Q = (Wc - Wf) f (one dense layer over the N points of the cloud instead of S*K rows); its
+// backward sends dy1 back to the tables: dP[i] = sum of dy1 over the rows that gathered point i, dQ[c] = sum over
+// the K rows of centre c -- a scatter, done here WITHOUT float atomics: every (channel, point) accumulator has one
+// owner thread that adds its rows in row order, so the gradients are bit-reproducible.
+#include <type_traits>
+
+#include "tile_dense.h"
+
+namespace {
+
+__host__ __device__ inline int l1_chunk(int N, int c1) {   // channels per workgroup: the chunk's table slice (CS x N) lives in LDS
+  int cs = 32;
+  while (cs > 1 && (size_t)cs * N * 4 > 32 * 1024) cs >>= 1;
+  return cs < c1 ? cs : c1;
+}
+
+struct L1Args {
+  const float *xyz;        // (B,N,3)
+  const int *idx;          // (B,S,K)
+  const float *tab;        // (B,2*c1,N): rows [0,c1) = P, rows [c1,2c1) = Q; null when the layer has no point features
+  const float *wa, *bias;  // (c1,3), (c1)
+  float *y;                // (B,c1,S*K)
+  float *stats;            // partials [B * chunks][2][ceil32(CS)]... see l1_fwd: [b][chunk][2][CS]
+  int N, S, K, c1, CS;
+};
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// one workgroup per (cloud, chunk of CS channels); rows r = s*K + k across the lanes (coalesced idx reads / y writes)
+template <int CS>
+__global__ __launch_bounds__(kThreads) void sa_l1_fwd_kernel(L1Args a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int N = a.N, S = a.S, K = a.K, c1 = a.c1, L = S * K;
+  float *Pl = smem;                                   // [CS][N]
+  float *xl = Pl + (a.tab ? CS * N : 0);              // [N][3]
+  float *wl = xl + 3 * N;                             // [CS][4]: wa, bias
+  float *red = wl + 4 * CS;                           // [4 waves][2][CS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t b = blockIdx.y;
+  const int c0 = blockIdx.x * CS;
+  const float *tab = a.tab ? a.tab + b * 2 * c1 * N : nullptr;
+  if (tab)
+    for (int e = tid; e < CS * N; e += kThreads) {
+      const int c = e / N, i = e - c * N;
+      Pl[e] = c0 + c < c1 ? tab[(size_t)(c0 + c) * N + i] : 0.f;
+    }
+  for (int e = tid; e < 3 * N; e += kThreads) xl[e] = a.xyz[b * N * 3 + e];
+  for (int e = tid; e < CS; e += kThreads) {
+    const int c = c0 + e;
+    const bool ok = c < c1;
+    wl[4 * e] = ok ? a.wa[3 * c] : 0.f;
+    wl[4 * e + 1] = ok ? a.wa[3 * c + 1] : 0.f;
+    wl[4 * e + 2] = ok ? a.wa[3 * c + 2] : 0.f;
+    wl[4 * e + 3] = ok && a.bias ? a.bias[c] : 0.f;
+  }
+  __syncthreads();
+  float ssum[CS], ssq[CS];
+#pragma unroll
+  for (int c = 0; c < CS; c++) ssum[c] = ssq[c] = 0.f;
+  const int *idx = a.idx + b * L;
+  float *y = a.y + (b * c1 + c0) * L;
+  const float *Q = tab ? tab + (size_t)(c1 + c0) * N : nullptr;
+  for (int r = tid; r < L; r += kThreads) {
+    const int s = r / K, i = idx[r];
+    const float dx = xl[3 * i] - xl[3 * s], dy = xl[3 * i + 1] - xl[3 * s + 1], dz = xl[3 * i + 2] - xl[3 * s + 2];
+#pragma unroll
+    for (int c = 0; c < CS; c++) {
+      if (c0 + c < c1) {
+        float v = fmaf(wl[4 * c + 2], dz, fmaf(wl[4 * c + 1], dy, fmaf(wl[4 * c], dx, wl[4 * c + 3])));
+        if (tab) v += Pl[c * N + i] + Q[(size_t)c * N + s];
+        y[(size_t)c * L + r] = v;
+        ssum[c] += v;
+        ssq[c] += v * v;
+      }
+    }
+  }
+  if (!a.stats) return;
+#pragma unroll
+  for (int c = 0; c < CS; c++) {
+    const float s = wave_sum_f(ssum[c]), q = wave_sum_f(ssq[c]);
+    if (lane == 0) {
+      red[(wave * 2) * CS + c] = s;
+      red[(wave * 2 + 1) * CS + c] = q;
+    }
+  }
+  __syncthreads();
+  if (tid < 2 * CS) {
+    const int st = tid / CS, c = tid - st * CS;
+    const float v = ((red[(0 * 2 + st) * CS + c] + red[(1 * 2 + st) * CS + c]) + red[(2 * 2 + st) * CS + c]) +
+                    red[(3 * 2 + st) * CS + c];
+    // partial layout [cloud][2][ceil32(c1)]: every chunk of a cloud writes its own channels
+    const int CP = ceil32(c1);
+    if (c0 + c < c1) a.stats[(b * 2 + st) * CP + c0 + c] = v;
+  }
+}
+
+struct L1BwdArgs {
+  const float *xyz;
+  const int *idx;
+  const float *g, *y;          // (B,c1,S*K): masked gradient of the BatchNorm output and the raw layer output
+  const float *ka, *kb, *kc;   // BatchNorm backward: dy = ka g + kb y + kc
+  float *dtab;                 // (B,2*c1,N) or null
+  float *dwa;                  // partials [B][c1][4]: d wa (3), d bias
+  int N, S, K, c1, CS;
+};
+
+// thread (cl = tid % CS, part = tid / CS): owner of channel cl's accumulators for the points / centres / rows
+// congruent to `part` modulo the number of parts; rows are visited in increasing order by every owner
+template <int CS>
+__global__ __launch_bounds__(kThreads) void sa_l1_bwd_kernel(L1BwdArgs a) {
+  constexpr int PARTS = kThreads / CS, TR = 64;   // rows per staged tile
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int N = a.N, S = a.S, K = a.K, c1 = a.c1, L = S * K;
+  float *dP = smem;                            // [CS][N]
+  float *dQ = dP + (a.dtab ? CS * N : 0);      // [CS][S]
+  float *xl = dQ + (a.dtab ? CS * S : 0);      // [N][3]
+  float *dyt = xl + 3 * N;                     // [CS][TR + 1]
+  float *dxt = dyt + CS * (TR + 1);            // [TR][3]
+  int *it = reinterpret_cast<int *>(dxt + 3 * TR);   // [TR] neighbour index, [TR] centre
+  int *st = it + TR;
+  float *comb = reinterpret_cast<float *>(st + TR);  // [PARTS][CS][4]
+  const int tid = threadIdx.x;
+  const int cl = tid % CS, part = tid / CS;
+  const size_t b = blockIdx.y;
+  const int c0 = blockIdx.x * CS;
+  const bool live = c0 + cl < c1;
+  if (a.dtab)
+    for (int e = tid; e < CS * N + CS * S; e += kThreads) dP[e] = 0.f;   // (dQ follows dP)
+  for (int e = tid; e < 3 * N; e += kThreads) xl[e] = a.xyz[b * N * 3 + e];
+  const int *idx = a.idx + b * L;
+  const float *g = a.g + (b * c1 + c0) * L, *y = a.y + (b * c1 + c0) * L;
+  float w0 = 0.f, w1 = 0.f, w2 = 0.f, wb = 0.f;
+  __syncthreads();
+  for (int t0 = 0; t0 < L; t0 += TR) {
+    const int nr = L - t0 < TR ? L - t0 : TR;
+    if (tid < nr) {
+      const int r = t0 + tid, i = idx[r], s = r / K;
+      it[tid] = i;
+      st[tid] = s;
+      dxt[3 * tid] = xl[3 * i] - xl[3 * s];
+      dxt[3 * tid + 1] = xl[3 * i + 1] - xl[3 * s + 1];
+      dxt[3 * tid + 2] = xl[3 * i + 2] - xl[3 * s + 2];
+    }
+    for (int e = tid; e < CS * TR; e += kThreads) {
+      const int c = e / TR, rr = e - c * TR;
+      float v = 0.f;
+      if (rr < nr && c0 + c < c1) {
+        const size_t o = (size_t)c * L + t0 + rr;
+        v = a.ka[c0 + c] * g[o] + a.kb[c0 + c] * y[o] + a.kc[c0 + c];
+      }
+      dyt[c * (TR + 1) + rr] = v;
+    }
+    __syncthreads();
+    if (live) {
+      const float *row = dyt + cl * (TR + 1);
+      for (int rr = 0; rr < nr; rr++) {
+        const float v = row[rr];
+        if ((rr % PARTS) == part) {
+          w0 += v * dxt[3 * rr];
+          w1 += v * dxt[3 * rr + 1];
+          w2 += v * dxt[3 * rr + 2];
+          wb += v;
+        }
+        if (a.dtab) {
+          const int i = it[rr], s = st[rr];
+          if ((i % PARTS) == part) dP[cl * N + i] += v;
+          if ((s % PARTS) == part) dQ[cl * S + s] += v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  comb[(part * CS + cl) * 4] = w0;
+  comb[(part * CS + cl) * 4 + 1] = w1;
+  comb[(part * CS + cl) * 4 + 2] = w2;
+  comb[(part * CS + cl) * 4 + 3] = wb;
+  __syncthreads();
+  if (tid < CS * 4) {
+    const int c = tid >> 2, j = tid & 3;
+    float s = 0.f;
+    for (int p = 0; p < PARTS; p++) s += comb[(p * CS + c) * 4 + j];
+    if (c0 + c < c1) a.dwa[(b * c1 + c0 + c) * 4 + j] = s;
+  }
+  if (a.dtab) {
+    float *dt = a.dtab + b * 2 * c1 * N;
+    for (int e = tid; e < CS * N; e += kThreads) {
+      const int c = e / N, i = e - c * N;
+      if (c0 + c < c1) {
+        dt[(size_t)(c0 + c) * N + i] = dP[e];
+        dt[(size_t)(c1 + c0 + c) * N + i] = i < S ? dQ[c * S + i] : 0.f;
+      }
+    }
+  }
+}
+
+// max over the K rows of every centre of relu(scale * y + shift), with the winning k (first maximum)
+struct PoolArgs {
+  const float *y;              // (B,C,S*K) raw layer-3 output
+  const float *scale, *shift;  // BatchNorm affine of this batch
+  float *pooled;               // (B,C,S)
+  int *argmax;                 // (B,C,S)
+  int C, S, K;
+};
+
+__global__ __launch_bounds__(kThreads) void sa_pool_fwd_kernel(PoolArgs a) {
+  constexpr int CS = 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int C = a.C, S = a.S, K = a.K, L = S * K;
+  const int G = 192 / K > 0 ? 192 / K : 1;     // centres per staged tile
+  const int RP = G * K + 1;
+  float *tile = smem;                           // [CS][RP]
+  const int tid = threadIdx.x, cl = tid & 31, gi = tid >> 5;
+  const size_t b = blockIdx.y;
+  const int c0 = blockIdx.x * CS;
+  const float *y = a.y + (b * C + c0) * L;
+  const float sc = c0 + cl < C ? a.scale[c0 + cl] : 0.f, sh = c0 + cl < C ? a.shift[c0 + cl] : 0.f;
+  for (int s0 = 0; s0 < S; s0 += G) {
+    const int ng = S - s0 < G ? S - s0 : G, nrow = ng * K;
+    if (s0) __syncthreads();
+    for (int e = tid; e < CS * nrow; e += kThreads) {
+      const int c = e / nrow, rr = e - c * nrow;
+      tile[c * RP + rr] = c0 + c < C ? y[(size_t)c * L + (size_t)s0 * K + rr] : 0.f;
+    }
+    __syncthreads();
+    if (c0 + cl < C)
+      for (int gc = gi; gc < ng; gc += kThreads / 32) {   // (up to 192 / K centres per tile, eight lanes of centres)
+        const float *row = tile + cl * RP + gc * K;
+        float best = -INFINITY;
+        int bk = 0;
+        for (int k = 0; k < K; k++) {
+          const float v = fmaxf(row[k] * sc + sh, 0.f);
+          if (v > best) {
+            best = v;
+            bk = k;
+          }
+        }
+        const size_t o = (b * C + c0 + cl) * S + s0 + gc;
+        a.pooled[o] = best;
+        a.argmax[o] = bk;
+      }
+  }
+}
+
+// BatchNorm-backward sums of the pooled gradient: per cloud, S1[c] = sum_s g_eff, S2[c] = sum_s g_eff * y[c][s K + argmax]
+// with g_eff = gp where pooled > 0.  Partials [B][2][ceil32(C)].
+__global__ void sa_pool_bwd_stats_kernel(const float *__restrict__ gp, const float *__restrict__ pooled,
+                                         const int *__restrict__ argmax, const float *__restrict__ y,
+                                         float *__restrict__ part, int C, int S, int K) {
+  const size_t b = blockIdx.x;
+  const int CP = ceil32(C);
+  for (int c = threadIdx.x; c < CP; c += blockDim.x) {
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C) {
+      const size_t o = (b * C + c) * S;
+      const float *yr = y + (b * C + c) * (size_t)S * K;
+      for (int s = 0; s < S; s++) {
+        const float gv = pooled[o + s] > 0.f ? gp[o + s] : 0.f;
+        s1 += gv;
+        s2 += gv * yr[(size_t)s * K + argmax[o + s]];
+      }
+    }
+    part[(b * 2) * CP + c] = s1;
+    part[(b * 2 + 1) * CP + c] = s2;
+  }
+}
+
+}  // namespace
+
+template <class F>
+static void l1_dispatch(int cs, F f) {
+  switch (cs) {
+    case 32: f(std::integral_constant<int, 32>()); break;
+    case 16: f(std::integral_constant<int, 16>()); break;
+    case 8: f(std::integral_constant<int, 8>()); break;
+    case 4: f(std::integral_constant<int, 4>()); break;
+    case 2: f(std::integral_constant<int, 2>()); break;
+    default: f(std::integral_constant<int, 1>()); break;
+  }
+}
+
+static int l1_pow2(int cs) {
+  int p = 1;
+  while (p * 2 <= cs) p *= 2;
+  return p;
+}
+
+PCR_EXPORT int pcr_sa_l1_fwd_f32(const float *xyz, const int *idx, const float *tab, const float *wa, const float *bias,
+                                 float *y, float *stats, int B, int N, int S, int K, int c1, pcr_stream_t stream) {
+  if (!xyz || !idx || !wa || !y || B < 0 || N < 1 || S < 1 || S > N || K < 1 || c1 < 1) return PCR_ERR_INVALID;
+  if (B == 0) return PCR_OK;
+  if (B > 65535) return PCR_ERR_INVALID;
+  const int cs = l1_pow2(l1_chunk(N, c1));
+  L1Args a{xyz, idx, tab, wa, bias, y, stats, N, S, K, c1, cs};
+  const size_t lds = ((tab ? (size_t)cs * N : 0) + 3 * (size_t)N + 4 * cs + 8 * cs) * sizeof(float);
+  if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
+  const dim3 grid((c1 + cs - 1) / cs, B);
+  l1_dispatch(cs, [&](auto tag) {
+    constexpr int CS = decltype(tag)::value;
+    static bool ok = allow_big_lds(sa_l1_fwd_kernel<CS>);
+    (void)ok;
+    hipLaunchKernelGGL(sa_l1_fwd_kernel<CS>, grid, dim3(kThreads), lds, pcr_s(stream), a);
+  });
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_sa_l1_bwd_f32(const float *xyz, const int *idx, const float *g, const float *y, const float *ka,
+                                 const float *kb, const float *kc, float *dtab, float *dwa, int B, int N, int S, int K,
+                                 int c1, pcr_stream_t stream) {
+  if (!xyz || !idx || !g || !y || !ka || !kb || !kc || !dwa || B < 0 || N < 1 || S < 1 || S > N || K < 1 || c1 < 1)
+    return PCR_ERR_INVALID;
+  if (B == 0) return PCR_OK;
+  if (B > 65535) return PCR_ERR_INVALID;
+  int cs = l1_pow2(l1_chunk(N, c1));
+  if (cs > 32) cs = 32;
+  L1BwdArgs a{xyz, idx, g, y, ka, kb, kc, dtab, dwa, N, S, K, c1, cs};
+  const int parts = kThreads / cs;
+  const size_t lds = ((dtab ? (size_t)cs * (N + S) : 0) + 3 * (size_t)N + (size_t)cs * 65 + 3 * 64 + 2 * 64 +
+                      (size_t)parts * cs * 4) * sizeof(float);
+  if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
+  const dim3 grid((c1 + cs - 1) / cs, B);
+  l1_dispatch(cs, [&](auto tag) {
+    constexpr int CS = decltype(tag)::value;
+    static bool ok = allow_big_lds(sa_l1_bwd_kernel<CS>);
+    (void)ok;
+    hipLaunchKernelGGL(sa_l1_bwd_kernel<CS>, grid, dim3(kThreads), lds, pcr_s(stream), a);
+  });
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_sa_pool_fwd_f32(const float *y, const float *scale, const float *shift, float *pooled, int *argmax,
+                                   int B, int C, int S, int K, pcr_stream_t stream) {
+  if (!y || !scale || !shift || !pooled || !argmax || B < 0 || C < 1 || S < 1 || K < 1 || K > 192) return PCR_ERR_INVALID;
+  if (B == 0) return PCR_OK;
+  if (B > 65535) return PCR_ERR_INVALID;
+  PoolArgs a{y, scale, shift, pooled, argmax, C, S, K};
+  const int G = 192 / K > 0 ? 192 / K : 1;
+  const size_t lds = (size_t)32 * (G * K + 1) * sizeof(float);
+  hipLaunchKernelGGL(sa_pool_fwd_kernel, dim3((C + 31) / 32, B), dim3(kThreads), lds, pcr_s(stream), a);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_sa_pool_bwd_stats_f32(const float *gp, const float *pooled, const int *argmax, const float *y,
+                                         float *part, int B, int C, int S, int K, pcr_stream_t stream) {
+  if (!gp || !pooled || !argmax || !y || !part || B < 0 || C < 1 || S < 1 || K < 1) return PCR_ERR_INVALID;
+  if (B == 0) return PCR_OK;
+  hipLaunchKernelGGL(sa_pool_bwd_stats_kernel, dim3(B), dim3(128), 0, pcr_s(stream), gp, pooled, argmax, y, part, C, S, K);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}

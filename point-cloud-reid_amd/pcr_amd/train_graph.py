@@ -56,20 +56,14 @@ def cross_attention(m, search, search_xyz, template, template_xyz):
 
 
 def sa_edge_layer(sa, xyz, feats, s):
-    """PointNetSetAbstractionEdgeSA in training mode: (B,N,3), (B,D,N)|None -> (B,S,3), (B,D',S)"""
+    """PointNetSetAbstractionEdgeSA in training mode: (B,N,3), (B,D,N)|None -> (B,S,3), (B,D',S).  Neighbour search,
+    the per-point tables of layer 1, the three conv + BatchNorm(batch statistics) + ReLU layers, the max over K and
+    all of their backward are HIP launches (pcr_amd/train_ops.py: SaEdgeTrain)."""
+    from . import train_ops
     xyz = xyz.contiguous()
     idx = engine.knn_prefix(xyz.detach(), s, sa.nsample)                      # HIP, (B,S,K) int32
     new_xyz = xyz[:, :s]
-    g = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)            # HIP gather (B,3,S,K)
-    x = g - new_xyz.transpose(1, 2).unsqueeze(-1)
-    if feats is not None:
-        feats = feats.contiguous()
-        centre = feats[:, :, :s].unsqueeze(-1)
-        nb = grouping_operation(feats, idx)                                   # HIP gather + scatter-add backward
-        x = torch.cat([x, centre.expand(-1, -1, -1, sa.nsample), nb - centre], dim=1)
-    for conv, bn in zip(sa.mlp_convs, sa.mlp_bns):
-        x = F.relu(bn(conv(x)))                                               # BatchNorm2d in batch-statistics mode
-    x = x.max(dim=3)[0]
+    x = train_ops.sa_edge_train(sa, xyz.detach(), None if feats is None else feats.contiguous(), idx)
     return new_xyz, self_attention(sa.self_attention, x, new_xyz)
 
 

@@ -1,0 +1,306 @@
+"""Host side of the training-mode kernels (include/pcr.h section C; csrc/train_kernels.hip, train_sa_kernels.hip):
+ctypes parameter blocks, launches, and the torch.autograd.Functions that put them under `loss.backward()`.
+
+What runs where: every dense layer of the training graph -- the grouped set-abstraction MLPs with BatchNorm in
+batch-statistics mode (reference pointnet2_utils.py:333-360), the per-point tables of their first layer, the attention
+projections / feed-forward layers and the match head -- is a HIP launch forward and a HIP launch backward on the
+matrix core; autograd only strings the Functions together.  Nothing here has a CPU path.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+
+c_fp = ctypes.c_void_p
+
+
+def _c32(n):
+    return (n + 31) // 32 * 32
+
+
+def _c8(n):
+    return (n + 7) // 8 * 8
+
+
+class _TFwd(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int), ("cin1", ctypes.c_int), ("cin2", ctypes.c_int), ("cout", ctypes.c_int),
+                ("L", ctypes.c_int), ("x", c_fp), ("x2", c_fp), ("isc", c_fp), ("ish", c_fp), ("in_relu", ctypes.c_int),
+                ("wp", c_fp), ("bias", c_fp), ("res", c_fp), ("out_relu", ctypes.c_int), ("y", c_fp), ("stats", c_fp)]
+
+
+class _TBwd(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int), ("cin1", ctypes.c_int), ("cin2", ctypes.c_int), ("cout", ctypes.c_int),
+                ("L", ctypes.c_int), ("g", c_fp), ("y", c_fp), ("dy_mode", ctypes.c_int),
+                ("ka", c_fp), ("kb", c_fp), ("kc", c_fp), ("argmax", c_fp), ("pooled", c_fp),
+                ("K", ctypes.c_int), ("S", ctypes.c_int), ("x", c_fp), ("x2", c_fp),
+                ("isc", c_fp), ("ish", c_fp), ("iinv", c_fp), ("in_relu", ctypes.c_int), ("wpT", c_fp),
+                ("dx", c_fp), ("dx2", c_fp), ("dstats", c_fp), ("dwp", c_fp), ("dbp", c_fp)]
+
+
+class _BnFwd(ctypes.Structure):
+    _fields_ = [("part", c_fp), ("nparts", ctypes.c_int), ("C", ctypes.c_int), ("R", ctypes.c_double),
+                ("gamma", c_fp), ("beta", c_fp), ("eps", ctypes.c_float), ("momentum", ctypes.c_float),
+                ("running_mean", c_fp), ("running_var", c_fp),
+                ("scale", c_fp), ("shift", c_fp), ("inv_scale", c_fp), ("mean", c_fp), ("invstd", c_fp)]
+
+
+class _BnBwd(ctypes.Structure):
+    _fields_ = [("part", c_fp), ("nparts", ctypes.c_int), ("C", ctypes.c_int), ("R", ctypes.c_double),
+                ("gamma", c_fp), ("mean", c_fp), ("invstd", c_fp),
+                ("ka", c_fp), ("kb", c_fp), ("kc", c_fp), ("dgamma", c_fp), ("dbeta", c_fp)]
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _f32(*shape, device):
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
+def _dev(t):
+    L.require_cuda(t)
+    L.require_f32(t)
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------- launches --
+def pack_dev(w, transpose=False):
+    """(rows, cols) device matrix -> packed MFMA A-operand image of W or W^T (weights change every step, so the
+    pack runs on the device; inference packs once on the host)"""
+    w = _dev(w.detach())
+    rows, cols = w.shape
+    cout, cin = (cols, rows) if transpose else (rows, cols)
+    out = _f32(_c8(cin) * _c32(cout), device=w.device)
+    L.check(L.load().pcr_pack_weight_dev_f32(L.ptr(w), rows, cols, cols, int(transpose), L.ptr(out), L.stream_ptr()),
+            "pcr_pack_weight_dev_f32")
+    return out
+
+
+def pad32(v, n):
+    """(n) vector -> zero-padded to a multiple of 32 (accumulator seeds are read 16 bytes at a time)"""
+    if v is None:
+        return None
+    out = torch.zeros(_c32(n), dtype=torch.float32, device=v.device)
+    out[:n] = v.detach()
+    return out
+
+
+def groups(B, Ln):
+    return L.load().pcr_train_groups(B, Ln)
+
+
+def tdense_fwd(x, wp, cout, x2=None, isc=None, ish=None, in_relu=False, bias=None, res=None, out_relu=False,
+               want_stats=False):
+    x = _dev(x)
+    B, cin1, Ln = x.shape
+    cin2 = 0
+    if x2 is not None:
+        x2 = _dev(x2)
+        cin2 = x2.shape[1]
+    y = _f32(B, cout, Ln, device=x.device)
+    stats = _f32(B * groups(B, Ln), 2, _c32(cout), device=x.device) if want_stats else None
+    p = _TFwd()
+    p.B, p.cin1, p.cin2, p.cout, p.L = B, cin1, cin2, cout, Ln
+    p.x, p.x2, p.isc, p.ish, p.in_relu = _p(x), _p(x2), _p(isc), _p(ish), int(in_relu)
+    p.wp, p.bias, p.res, p.out_relu = _p(wp), _p(pad32(bias, cout)), _p(res), int(out_relu)
+    p.y, p.stats = _p(y), _p(stats)
+    L.check(L.load().pcr_tdense_fwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_tdense_fwd_f32")
+    return y, stats
+
+
+def reduce_parts(part, nparts, stride, rows, cols, ld):
+    out = _f32(rows, cols, device=part.device)
+    L.check(L.load().pcr_reduce_parts_f32(L.ptr(part), nparts, ctypes.c_long(stride), rows, cols, ld, L.ptr(out),
+                                          L.stream_ptr()), "pcr_reduce_parts_f32")
+    return out
+
+
+def tdense_bwd(g, x, cout, dy_mode=0, y=None, k=None, argmax=None, pooled=None, K=0, S=0, x2=None, isc=None, ish=None,
+               iinv=None, in_relu=False, wpT=None, want_dstats=False, want_dw=True):
+    """-> dict(dx, dx2, dstats, dW (cout, cin1+cin2), db (cout)); see pcr_tdense_bwd in include/pcr.h"""
+    x = _dev(x)
+    B, cin1, Ln = x.shape
+    cin2 = 0
+    if x2 is not None:
+        x2 = _dev(x2)
+        cin2 = x2.shape[1]
+    cin = cin1 + cin2
+    dev = x.device
+    nwg = B * groups(B, Ln)
+    out = {}
+    p = _TBwd()
+    p.B, p.cin1, p.cin2, p.cout, p.L = B, cin1, cin2, cout, Ln
+    p.g, p.y, p.dy_mode = _p(g), _p(y), dy_mode
+    if k is not None:
+        p.ka, p.kb, p.kc = _p(k["ka"]), _p(k["kb"]), _p(k["kc"])
+    p.argmax, p.pooled, p.K, p.S = _p(argmax), _p(pooled), K, S
+    p.x, p.x2, p.isc, p.ish, p.iinv, p.in_relu = _p(x), _p(x2), _p(isc), _p(ish), _p(iinv), int(in_relu)
+    if wpT is not None:
+        out["dx"] = _f32(B, cin1, Ln, device=dev)
+        out["dx2"] = _f32(B, cin2, Ln, device=dev) if cin2 else None
+        p.wpT, p.dx, p.dx2 = _p(wpT), _p(out["dx"]), _p(out["dx2"])
+        if want_dstats:
+            out["dstats"] = _f32(nwg, 2, _c32(cin1), device=dev)
+            p.dstats = _p(out["dstats"])
+    coutP, cinP = _c32(cout), _c32(cin)
+    if want_dw:
+        dwp = _f32(nwg, coutP, cinP, device=dev)
+        dbp = _f32(nwg, coutP, device=dev)
+        p.dwp, p.dbp = _p(dwp), _p(dbp)
+    L.check(L.load().pcr_tdense_bwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_tdense_bwd_f32")
+    if want_dw:
+        out["dW"] = reduce_parts(dwp, nwg, coutP * cinP, cout, cin, cinP)
+        out["db"] = reduce_parts(dbp, nwg, coutP, 1, cout, coutP).view(cout)
+    return out
+
+
+def bn_fwd_finalize(part, nparts, C, R, gamma, beta, eps, momentum, running_mean=None, running_var=None):
+    dev = part.device
+    o = {k: _f32(C, device=dev) for k in ("scale", "shift", "inv_scale", "mean", "invstd")}
+    p = _BnFwd()
+    p.part, p.nparts, p.C, p.R = _p(part), nparts, C, float(R)
+    p.gamma, p.beta, p.eps, p.momentum = _p(gamma.detach()), _p(beta.detach()), eps, momentum
+    p.running_mean, p.running_var = _p(running_mean), _p(running_var)
+    for k, v in o.items():
+        setattr(p, k, _p(v))
+    L.check(L.load().pcr_bn_fwd_finalize_f32(ctypes.byref(p), L.stream_ptr()), "pcr_bn_fwd_finalize_f32")
+    return o
+
+
+def bn_bwd_finalize(part, nparts, C, R, gamma, mean, invstd):
+    dev = part.device
+    o = {k: _f32(C, device=dev) for k in ("ka", "kb", "kc", "dgamma", "dbeta")}
+    p = _BnBwd()
+    p.part, p.nparts, p.C, p.R = _p(part), nparts, C, float(R)
+    p.gamma, p.mean, p.invstd = _p(gamma.detach()), _p(mean), _p(invstd)
+    for k, v in o.items():
+        setattr(p, k, _p(v))
+    L.check(L.load().pcr_bn_bwd_finalize_f32(ctypes.byref(p), L.stream_ptr()), "pcr_bn_bwd_finalize_f32")
+    return o
+
+
+# ----------------------------------------------------------------------------------- autograd Functions --
+class TDense(Function):
+    """y = [relu](W [x ; x2] + bias [+ res]) on (B,C,L) tensors; W (cout, cin1+cin2) row-major (nn.Linear / 1x1 conv)"""
+
+    @staticmethod
+    def forward(ctx, x, x2, W, bias, res, out_relu):
+        assert not (out_relu and res is not None)
+        cout = W.shape[0]
+        y, _ = tdense_fwd(x, pack_dev(W), cout, x2=x2, bias=bias, res=res, out_relu=out_relu)
+        ctx.save_for_backward(x, x2, W, y if out_relu else None)
+        ctx.meta = (out_relu, bias is not None, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, x2, W, y = ctx.saved_tensors
+        out_relu, has_bias, has_res = ctx.meta
+        g = g.contiguous()
+        need_dx = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
+        r = tdense_bwd(g, x, W.shape[0], dy_mode=2 if out_relu else 0, y=y, x2=x2,
+                       wpT=pack_dev(W, transpose=True) if need_dx else None,
+                       want_dw=ctx.needs_input_grad[2] or (has_bias and ctx.needs_input_grad[3]))
+        return (r.get("dx"), r.get("dx2"), r.get("dW"), r.get("db") if has_bias else None,
+                g if has_res else None, None)
+
+
+def dense(x, W, bias=None, x2=None, res=None, relu=False):
+    return TDense.apply(x, x2, W, bias, res, relu)
+
+
+class SaEdgeTrain(Function):
+    """Grouped edge MLP of one set-abstraction layer in TRAINING mode: layer 1 from per-point tables, three
+    (conv, BatchNorm over the batch, ReLU) layers, max over K.  Inputs: xyz (B,N,3), idx (B,S,K) int32, tab (B,2c1,N)
+    or None, then per layer (W, b, gamma, beta); `bns` = the three nn.BatchNorm2d modules (running statistics are
+    updated in place, as nn.BatchNorm2d does in training mode).  -> pooled (B,c3,S)."""
+
+    @staticmethod
+    def forward(ctx, xyz, idx, tab, wa, b1, g1, be1, w2, b2, g2, be2, w3, b3, g3, be3, bns):
+        lib = L.load()
+        xyz, idx = _dev(xyz), idx.contiguous()
+        L.require_i32(idx)
+        B, N, _ = xyz.shape
+        _, S, K = idx.shape
+        Ln = S * K
+        R = B * Ln
+        c1, c2, c3 = wa.shape[0], w2.shape[0], w3.shape[0]
+        dev = xyz.device
+        tab = None if tab is None else _dev(tab)
+        y1 = _f32(B, c1, Ln, device=dev)
+        st1 = _f32(B, 2, _c32(c1), device=dev)
+        L.check(lib.pcr_sa_l1_fwd_f32(L.ptr(xyz), L.ptr(idx), L.ptr(tab), L.ptr(_dev(wa.detach())), L.ptr(b1.detach()),
+                                      L.ptr(y1), L.ptr(st1), B, N, S, K, c1, L.stream_ptr()), "pcr_sa_l1_fwd_f32")
+
+        def fin(st, nparts, C, gamma, beta, bn):
+            o = bn_fwd_finalize(st, nparts, C, R, gamma, beta, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
+                                bn.running_mean if bn.track_running_stats else None,
+                                bn.running_var if bn.track_running_stats else None)
+            if bn.track_running_stats and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+            return o
+        n1 = fin(st1, B, c1, g1, be1, bns[0])
+        y2, st2 = tdense_fwd(y1, pack_dev(w2), c2, isc=n1["scale"], ish=n1["shift"], in_relu=True, bias=b2, want_stats=True)
+        n2 = fin(st2, st2.shape[0], c2, g2, be2, bns[1])
+        y3, st3 = tdense_fwd(y2, pack_dev(w3), c3, isc=n2["scale"], ish=n2["shift"], in_relu=True, bias=b3, want_stats=True)
+        n3 = fin(st3, st3.shape[0], c3, g3, be3, bns[2])
+        pooled = _f32(B, c3, S, device=dev)
+        argmax = torch.empty((B, c3, S), dtype=torch.int32, device=dev)
+        L.check(lib.pcr_sa_pool_fwd_f32(L.ptr(y3), L.ptr(n3["scale"]), L.ptr(n3["shift"]), L.ptr(pooled), L.ptr(argmax),
+                                        B, c3, S, K, L.stream_ptr()), "pcr_sa_pool_fwd_f32")
+        ctx.save_for_backward(xyz, idx, y1, y2, y3, pooled, argmax, w2, w3, g1, g2, g3)
+        ctx.norms = (n1, n2, n3)
+        ctx.has_tab = tab is not None
+        ctx.dims = (B, N, S, K, c1, c2, c3)
+        ctx.mark_non_differentiable(argmax)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, gp):
+        lib = L.load()
+        xyz, idx, y1, y2, y3, pooled, argmax, w2, w3, g1, g2, g3 = ctx.saved_tensors
+        n1, n2, n3 = ctx.norms
+        B, N, S, K, c1, c2, c3 = ctx.dims
+        Ln, R, dev = S * K, B * S * K, xyz.device
+        gp = gp.contiguous()
+        part3 = _f32(B, 2, _c32(c3), device=dev)
+        L.check(lib.pcr_sa_pool_bwd_stats_f32(L.ptr(gp), L.ptr(pooled), L.ptr(argmax), L.ptr(y3), L.ptr(part3), B, c3, S,
+                                              K, L.stream_ptr()), "pcr_sa_pool_bwd_stats_f32")
+        k3 = bn_bwd_finalize(part3, B, c3, R, g3, n3["mean"], n3["invstd"])
+        r3 = tdense_bwd(gp, y2, c3, dy_mode=3, y=y3, k=k3, argmax=argmax, pooled=pooled, K=K, S=S,
+                        isc=n2["scale"], ish=n2["shift"], iinv=n2["inv_scale"], in_relu=True,
+                        wpT=pack_dev(w3, transpose=True), want_dstats=True)
+        k2 = bn_bwd_finalize(r3["dstats"], r3["dstats"].shape[0], c2, R, g2, n2["mean"], n2["invstd"])
+        r2 = tdense_bwd(r3["dx"], y1, c2, dy_mode=1, y=y2, k=k2, isc=n1["scale"], ish=n1["shift"], iinv=n1["inv_scale"],
+                        in_relu=True, wpT=pack_dev(w2, transpose=True), want_dstats=True)
+        k1 = bn_bwd_finalize(r2["dstats"], r2["dstats"].shape[0], c1, R, g1, n1["mean"], n1["invstd"])
+        dtab = _f32(B, 2 * c1, N, device=dev) if ctx.has_tab else None
+        dwa_p = _f32(B, c1, 4, device=dev)
+        L.check(lib.pcr_sa_l1_bwd_f32(L.ptr(xyz), L.ptr(idx), L.ptr(r2["dx"]), L.ptr(y1), L.ptr(k1["ka"]), L.ptr(k1["kb"]),
+                                      L.ptr(k1["kc"]), L.ptr(dtab), L.ptr(dwa_p), B, N, S, K, c1, L.stream_ptr()),
+                "pcr_sa_l1_bwd_f32")
+        dwa4 = reduce_parts(dwa_p, B, c1 * 4, c1, 4, 4)
+        return (None, None, dtab, dwa4[:, :3].contiguous(), dwa4[:, 3].contiguous(), k1["dgamma"], k1["dbeta"],
+                r2["dW"], r2["db"], k2["dgamma"], k2["dbeta"], r3["dW"], r3["db"], k3["dgamma"], k3["dbeta"], None)
+
+
+def sa_edge_train(sa, xyz, feats, idx):
+    """PointNetSetAbstractionEdgeSA's grouped MLP + max in training mode: xyz (B,N,3), feats (B,D,N) or None,
+    idx (B,S,K) -> (B,c3,S).  The first conv's weight [Wa | Wc | Wf] is split here; autograd carries the table
+    weights' gradient back into it."""
+    convs, bns = list(sa.mlp_convs), list(sa.mlp_bns)
+    c1 = convs[0].weight.shape[0]
+    w1 = convs[0].weight.view(c1, -1)
+    wa = w1[:, :3]
+    tab = None
+    if feats is not None:
+        D = feats.shape[1]
+        wc, wf = w1[:, 3:3 + D], w1[:, 3 + D:3 + 2 * D]
+        tab = dense(feats, torch.cat([wf, wc - wf], dim=0))          # (B, 2 c1, N): [P ; Q]
+    args = [xyz, idx, tab, wa, convs[0].bias, bns[0].weight, bns[0].bias]
+    for l in (1, 2):
+        args += [convs[l].weight.view(convs[l].weight.shape[0], -1), convs[l].bias, bns[l].weight, bns[l].bias]
+    return SaEdgeTrain.apply(*args, bns)
