@@ -350,7 +350,7 @@ int pcr_train_groups(int B, int L);
 
 /* y = [relu](W f([x ; x2]) + bias [+ res]),  f(x) = [relu](isc x + ish) on the cin1 channels of x (the previous
  * layer's BatchNorm + ReLU, applied while the tile is loaded; isc NULL = identity).  stats (optional): partials
- * [B * groups][2][ceil32(cout)] of sum y and sum y^2 (before res / relu) for pcr_bn_fwd_finalize_f32.  cout <= 256. */
+ * [B * groups][2][ceil32(cout)] of sum y and sum y^2 (before res / relu) for pcr_bn_fwd_finalize_f32.  cout <= 384. */
 typedef struct pcr_tdense_fwd {
   int B, cin1, cin2, cout, L;
   const float *x, *x2;
@@ -371,7 +371,7 @@ int pcr_tdense_fwd_f32(const pcr_tdense_fwd *p, pcr_stream_t stream);
  * Outputs (each optional): dx / dx2 = W^T dy masked by f(x) > 0 when in_relu (wpT = packed W^T); dstats = partials
  * [B * groups][2][ceil32(cin1)] of sum dx and sum dx * (raw x) for the next BatchNorm backward (iinv = 1 / isc);
  * dwp = partials [B * groups][ceil32(cout)][ceil32(cin)] of dy f(x)^T, dbp = partials [B * groups][ceil32(cout)] of sum dy
- * (reduce with pcr_reduce_parts_f32).  cout <= 256, cin1 + cin2 <= 288. */
+ * (reduce with pcr_reduce_parts_f32).  cout <= 384, cin1 + cin2 <= 288. */
 typedef struct pcr_tdense_bwd {
   int B, cin1, cin2, cout, L;
   const float *g, *y;
@@ -434,6 +434,41 @@ int pcr_sa_pool_fwd_f32(const float *y, const float *scale, const float *shift, 
 /* partials [B][2][ceil32(C)] of S1 = sum gp [pooled > 0], S2 = sum gp [pooled > 0] y[argmax] for pcr_bn_bwd_finalize_f32 */
 int pcr_sa_pool_bwd_stats_f32(const float *gp, const float *pooled, const int *argmax, const float *y, float *part,
                               int B, int C, int S, int K, pcr_stream_t stream);
+
+/* LayerNorm / GroupNorm over the channels of every token of x (B,C,L) (G groups of C/G consecutive channels; LayerNorm:
+ * G = 1), y = [relu]((x - mean) rstd gamma + beta [+ res]); mean / rstd (B,G,L) are kept for the backward.  Backward: dx and
+ * partials [B * ceil(L/256)][2][C] of (d gamma, d beta) for pcr_reduce_parts_f32.  csrc/train_attn_kernels.hip. */
+int pcr_tnorm_fwd_f32(const float *x, const float *gamma, const float *beta, const float *res, float *y, float *mean,
+                      float *rstd, int B, int C, int L, int G, float eps, int relu, pcr_stream_t stream);
+/* y_relu: the forward output when relu was set (the gradient is masked by y > 0 first), else NULL; dres (optional): the
+ * masked gradient = gradient of the residual input */
+int pcr_tnorm_bwd_f32(const float *g, const float *x, const float *gamma, const float *mean, const float *rstd,
+                      const float *y_relu, float *dx, float *dres, float *part, int B, int C, int L, int G,
+                      pcr_stream_t stream);
+
+/* Linear-attention core (LinearAttention.forward, models/pointnet2_utils.py:26-47), forward and backward, one workgroup
+ * per (cloud, head): Q' = elu(q)+1, K' = elu(k)+1, V' = v/Sk, A = sum_s K'_s V'_s^T, ks = sum_s K'_s,
+ * out_l = (Q'_l^T A) Sk / (Q'_l . ks + eps).  q / k / v (and dq / dk / dv) are (d, L) channel-major blocks per cloud
+ * addressed with a batch stride, so slices of a fused (B,3d,L) projection need no copies.  d / H in {16, 32, 64}.
+ * A (B,H,dh,dh) and ks (B,H,dh) are written by the forward and read by the backward. */
+typedef struct pcr_linattn {
+  int B, Lq, Sk, d, H;
+  float eps;
+  const float *q, *k, *v;
+  long q_bs, k_bs, v_bs;
+  float *out, *A, *ks;
+  const float *dout;
+  float *dq, *dk, *dv;
+  long dq_bs, dk_bs, dv_bs;
+} pcr_linattn;
+int pcr_linattn_fwd_f32(const pcr_linattn *p, pcr_stream_t stream);
+int pcr_linattn_bwd_f32(const pcr_linattn *p, pcr_stream_t stream);
+
+/* Match-head pooling in training (get_pooled_feats 'both' over the point-concatenated pair, models/ReIDNet.py:529-532):
+ * o (2P,C,L) -> pooled (P,2C) = [max, mean] over the 2L points of pair p (clouds p, p+P), arg (P,C) = position of the
+ * maximum; backward: dout (2P,C,L) from g (P,2C). */
+int pcr_pool_pair_fwd_f32(const float *o, float *pooled, int *arg, int P, int C, int L, pcr_stream_t stream);
+int pcr_pool_pair_bwd_f32(const float *g, const int *arg, float *dout, int P, int C, int L, pcr_stream_t stream);
 
 /* ---- measurement aid (bench.py; not on the hot path) ---- */
 

@@ -1,0 +1,479 @@
+// Training-mode kernels of the attention blocks and the match head that are not dense layers: the linear-attention
+// core (forward + backward), LayerNorm / GroupNorm over the channels of every token (forward + backward) and the
+// pair pooling of the match head (forward + backward).  The dense layers around them are pcr_tdense_{fwd,bwd}_f32.
+//
+// Reference graph: LinearAttention (models/pointnet2_utils.py:14-47), Self_Attention (:90-114), FP_SA (:407-437),
+// corss_attention (models/attention.py:192-219), LinearRes (models/lanegcn_nets.py:228-241), get_pooled_feats
+// 'both' (models/ReIDNet.py:529-532).  All reductions have a fixed order (no float atomics).
+#include <type_traits>
+
+#include "tile_dense.h"
+
+namespace {
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------ token norm (LayerNorm / GroupNorm) ----
+// x (B,C,L): every token is normalised over each of its G groups of C/G consecutive channels (LayerNorm: G = 1),
+// y = (x - mean) rstd gamma + beta [+ res].  One thread per (token, group); mean / rstd are kept for the backward.
+struct TNorm {
+  const float *x, *gamma, *beta, *res;
+  float *y, *mean, *rstd;     // mean / rstd (B,G,L)
+  int C, L, G;
+  float eps;
+  int relu;                   // y = relu(...) (LinearRes, lanegcn_nets.py:233,240)
+};
+
+__global__ __launch_bounds__(256) void tnorm_fwd_kernel(TNorm a) {
+  const size_t b = blockIdx.z;
+  const int g = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= a.L) return;
+  const int gs = a.C / a.G;
+  const size_t base = (b * a.C + (size_t)g * gs) * a.L + t;
+  float m = 0.f;
+  for (int i = 0; i < gs; i++) m += a.x[base + (size_t)i * a.L];
+  m /= (float)gs;
+  float v = 0.f;
+  for (int i = 0; i < gs; i++) {
+    const float d = a.x[base + (size_t)i * a.L] - m;
+    v += d * d;
+  }
+  const float r = 1.0f / sqrtf(v / (float)gs + a.eps);
+  for (int i = 0; i < gs; i++) {
+    const int c = g * gs + i;
+    float o = (a.x[base + (size_t)i * a.L] - m) * r * a.gamma[c] + a.beta[c];
+    if (a.res) o += a.res[base + (size_t)i * a.L];
+    a.y[base + (size_t)i * a.L] = a.relu ? fmaxf(o, 0.f) : o;
+  }
+  a.mean[(b * a.G + g) * a.L + t] = m;
+  a.rstd[(b * a.G + g) * a.L + t] = r;
+}
+
+struct TNormBwd {
+  const float *g, *x, *gamma, *mean, *rstd;
+  float *dx;
+  float *part;     // partials [gridDim.z * gridDim.x][2][C]: d gamma, d beta   (grid.y = groups)
+  int C, L, G;
+  const float *y;  // forward output when it went through a ReLU: the gradient is masked by y > 0 first
+  float *dres;     // optional: the masked gradient (= gradient of the residual input)
+};
+
+__global__ __launch_bounds__(256) void tnorm_bwd_kernel(TNormBwd a) {
+  __shared__ float red[4][2];
+  const size_t b = blockIdx.z;
+  const int g = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool ok = t < a.L;
+  const int gs = a.C / a.G;
+  const size_t base = (b * a.C + (size_t)g * gs) * a.L + (ok ? t : 0);
+  const float m = ok ? a.mean[(b * a.G + g) * a.L + t] : 0.f, r = ok ? a.rstd[(b * a.G + g) * a.L + t] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+  auto grad = [&](int i) {   // incoming gradient of channel i of this group, through the optional ReLU
+    float go = ok ? a.g[base + (size_t)i * a.L] : 0.f;
+    if (a.y && ok && !(a.y[base + (size_t)i * a.L] > 0.f)) go = 0.f;
+    return go;
+  };
+  for (int i = 0; i < gs; i++) {
+    const float gv = grad(i) * a.gamma[g * gs + i];
+    const float xh = ok ? (a.x[base + (size_t)i * a.L] - m) * r : 0.f;
+    s1 += gv;
+    s2 += gv * xh;
+  }
+  const float inv = 1.0f / (float)gs;
+  float *part = a.part + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 2 * a.C;
+  for (int i = 0; i < gs; i++) {
+    const int c = g * gs + i;
+    const float go = grad(i);
+    const float xh = ok ? (a.x[base + (size_t)i * a.L] - m) * r : 0.f;
+    if (ok) a.dx[base + (size_t)i * a.L] = r * (go * a.gamma[c] - s1 * inv - xh * s2 * inv);
+    if (ok && a.dres) a.dres[base + (size_t)i * a.L] = go;
+    // d gamma[c] = sum over tokens of g xhat, d beta[c] = sum of g: wave sums, then the four waves in order
+    const float w1 = wsum(go * xh), w2 = wsum(go);
+    __syncthreads();
+    if (lane == 0) {
+      red[wave][0] = w1;
+      red[wave][1] = w2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      part[c] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+      part[a.C + c] = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------- linear attention core ----
+// Per (cloud, head): Q' = elu(q) + 1, K' = elu(k) + 1, V' = v / S, A = sum_s K'_s V'_s^T (dh x dh), ks = sum_s K'_s,
+// out_l = (Q'_l^T A) S / (Q'_l . ks + eps)   (LinearAttention.forward, pointnet2_utils.py:26-47).
+// q / k / v / out are (B, *, L) channel-major blocks addressed by a batch stride and a channel offset, so a fused
+// (B,3d,L) projection needs no slicing copies.
+struct LinAttn {
+  const float *q, *k, *v;
+  long q_bs, k_bs, v_bs;       // floats between clouds
+  int Lq, Sk, d, H;
+  float eps;
+  float *out;                  // (B,d,Lq)
+  float *A, *ks;               // saved for the backward: (B,H,dh,dh), (B,H,dh)
+  // backward
+  const float *dout;
+  float *dq, *dk, *dv;
+  long dq_bs, dk_bs, dv_bs;
+};
+
+constexpr int kAT = 64;        // tokens per staged chunk
+
+__device__ __forceinline__ float elu1f(float x) { return x > 0.f ? x + 1.0f : __expf(x); }
+
+template <int DH>
+__global__ __launch_bounds__(256) void linattn_fwd_kernel(LinAttn a) {
+  constexpr int RP = kAT + 1, NP = (DH * DH + 255) / 256;
+  __shared__ float Kt[DH * RP], Vt[DH * RP], Al[DH * (DH + 1)], ksl[DH], zl[kAT];
+  const int tid = threadIdx.x;
+  const int h = blockIdx.x;
+  const size_t b = blockIdx.y;
+  const float *q = a.q + b * a.q_bs + (size_t)h * DH * a.Lq;
+  const float *k = a.k + b * a.k_bs + (size_t)h * DH * a.Sk;
+  const float *v = a.v + b * a.v_bs + (size_t)h * DH * a.Sk;
+  const float sk = (float)a.Sk;
+  float acc[NP];
+#pragma unroll
+  for (int p = 0; p < NP; p++) acc[p] = 0.f;
+  float ksum = 0.f;
+  for (int s0 = 0; s0 < a.Sk; s0 += kAT) {
+    const int ns = a.Sk - s0 < kAT ? a.Sk - s0 : kAT;
+    if (s0) __syncthreads();
+    for (int e = tid; e < DH * kAT; e += 256) {
+      const int i = e / kAT, s = e - i * kAT;
+      const bool ok = s < ns;
+      Kt[i * RP + s] = ok ? elu1f(k[(size_t)i * a.Sk + s0 + s]) : 0.f;
+      Vt[i * RP + s] = ok ? v[(size_t)i * a.Sk + s0 + s] / sk : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+      const int e = tid + p * 256;
+      if (e < DH * DH) {
+        const int i = e / DH, j = e - i * DH;
+        const float *kr = Kt + i * RP, *vr = Vt + j * RP;
+        float s = 0.f;
+#pragma unroll 8
+        for (int t = 0; t < kAT; t++) s += kr[t] * vr[t];
+        acc[p] += s;
+      }
+    }
+    if (tid < DH) {
+      const float *kr = Kt + tid * RP;
+      float s = 0.f;
+      for (int t = 0; t < kAT; t++) s += kr[t];
+      ksum += s;
+    }
+  }
+  float *Ag = a.A + (b * a.H + h) * DH * DH;
+#pragma unroll
+  for (int p = 0; p < NP; p++) {
+    const int e = tid + p * 256;
+    if (e < DH * DH) {
+      Al[(e / DH) * (DH + 1) + e % DH] = acc[p];
+      Ag[e] = acc[p];
+    }
+  }
+  if (tid < DH) {
+    ksl[tid] = ksum;
+    a.ks[(b * a.H + h) * DH + tid] = ksum;
+  }
+  float *out = a.out + (b * a.d + (size_t)h * DH) * a.Lq;
+  float *Qt = Kt;     // the key tiles are dead
+  for (int l0 = 0; l0 < a.Lq; l0 += kAT) {
+    const int nl = a.Lq - l0 < kAT ? a.Lq - l0 : kAT;
+    __syncthreads();
+    for (int e = tid; e < DH * kAT; e += 256) {
+      const int i = e / kAT, l = e - i * kAT;
+      Qt[i * RP + l] = l < nl ? elu1f(q[(size_t)i * a.Lq + l0 + l]) : 0.f;
+    }
+    __syncthreads();
+    if (tid < kAT) {
+      float z = 0.f;
+      for (int i = 0; i < DH; i++) z += Qt[i * RP + tid] * ksl[i];
+      zl[tid] = 1.0f / (z + a.eps);
+    }
+    __syncthreads();
+    for (int e = tid; e < DH * kAT; e += 256) {
+      const int vv = e / kAT, l = e - vv * kAT;
+      float s = 0.f;
+#pragma unroll 8
+      for (int i = 0; i < DH; i++) s += Qt[i * RP + l] * Al[i * (DH + 1) + vv];
+      if (l < nl) out[(size_t)vv * a.Lq + l0 + l] = s * zl[l] * sk;
+    }
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void linattn_bwd_kernel(LinAttn a) {
+  constexpr int RP = kAT + 1, NP = (DH * DH + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];    // 83 KB at DH = 64: dynamic
+  float *Qt = smem, *Gt = Qt + DH * RP, *Dn = Gt + DH * RP, *Al = Dn + DH * RP, *dAl = Al + DH * (DH + 1);
+  float *ksl = dAl + DH * (DH + 1), *dksl = ksl + DH, *zl = dksl + DH, *ddl = zl + kAT;
+  const int tid = threadIdx.x;
+  const int h = blockIdx.x;
+  const size_t b = blockIdx.y;
+  const float *q = a.q + b * a.q_bs + (size_t)h * DH * a.Lq;
+  const float *k = a.k + b * a.k_bs + (size_t)h * DH * a.Sk;
+  const float *v = a.v + b * a.v_bs + (size_t)h * DH * a.Sk;
+  const float *go = a.dout + (b * a.d + (size_t)h * DH) * a.Lq;
+  float *dq = a.dq + b * a.dq_bs + (size_t)h * DH * a.Lq;
+  float *dk = a.dk + b * a.dk_bs + (size_t)h * DH * a.Sk;
+  float *dv = a.dv + b * a.dv_bs + (size_t)h * DH * a.Sk;
+  const float sk = (float)a.Sk;
+  const float *Ag = a.A + (b * a.H + h) * DH * DH;
+  for (int e = tid; e < DH * DH; e += 256) Al[(e / DH) * (DH + 1) + e % DH] = Ag[e];
+  if (tid < DH) ksl[tid] = a.ks[(b * a.H + h) * DH + tid];
+  float dA[NP];
+#pragma unroll
+  for (int p = 0; p < NP; p++) dA[p] = 0.f;
+  float dks = 0.f;
+  // ---- pass 1 over the query tokens: dq, and the sums dA = sum_l Q'_l dnum_l^T, dks = sum_l dden_l Q'_l
+  for (int l0 = 0; l0 < a.Lq; l0 += kAT) {
+    const int nl = a.Lq - l0 < kAT ? a.Lq - l0 : kAT;
+    __syncthreads();
+    for (int e = tid; e < DH * kAT; e += 256) {
+      const int i = e / kAT, l = e - i * kAT;
+      const bool ok = l < nl;
+      Qt[i * RP + l] = ok ? elu1f(q[(size_t)i * a.Lq + l0 + l]) : 0.f;
+      Gt[i * RP + l] = ok ? go[(size_t)i * a.Lq + l0 + l] : 0.f;
+    }
+    __syncthreads();
+    if (tid < kAT) {
+      float z = 0.f;
+      for (int i = 0; i < DH; i++) z += Qt[i * RP + tid] * ksl[i];
+      zl[tid] = 1.0f / (z + a.eps);
+    }
+    __syncthreads();
+    // num[v][l] = Q'_l . A[:,v];  dnum = dout z S;  dz_l = sum_v dout num S  (accumulated per token below)
+    for (int e = tid; e < DH * kAT; e += 256) {
+      const int vv = e / kAT, l = e - vv * kAT;
+      float s = 0.f;
+#pragma unroll 8
+      for (int i = 0; i < DH; i++) s += Qt[i * RP + l] * Al[i * (DH + 1) + vv];
+      const float gv = Gt[vv * RP + l];
+      Dn[vv * RP + l] = gv * zl[l] * sk;
+      Gt[vv * RP + l] = gv * s * sk;          // dout * num * S (summed over v next)
+    }
+    __syncthreads();
+    if (tid < kAT) {
+      float dz = 0.f;
+      for (int vv = 0; vv < DH; vv++) dz += Gt[vv * RP + tid];
+      ddl[tid] = -zl[tid] * zl[tid] * dz;      // gradient of the denominator Q'.ks + eps
+    }
+    __syncthreads();
+    for (int e = tid; e < DH * kAT; e += 256) {
+      const int i = e / kAT, l = e - i * kAT;
+      float s = ddl[l] * ksl[i];
+#pragma unroll 8
+      for (int vv = 0; vv < DH; vv++) s += Dn[vv * RP + l] * Al[i * (DH + 1) + vv];
+      const float qp = Qt[i * RP + l];
+      if (l < nl) dq[(size_t)i * a.Lq + l0 + l] = s * (qp > 1.0f ? 1.0f : qp);   // elu'(q) = 1 (q > 0) | exp(q) = Q'
+    }
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+      const int e = tid + p * 256;
+      if (e < DH * DH) {
+        const int i = e / DH, vv = e - i * DH;
+        const float *qr = Qt + i * RP, *dr = Dn + vv * RP;
+        float s = 0.f;
+#pragma unroll 8
+        for (int t = 0; t < kAT; t++) s += qr[t] * dr[t];
+        dA[p] += s;
+      }
+    }
+    if (tid < DH) {
+      const float *qr = Qt + tid * RP;
+      float s = 0.f;
+      for (int t = 0; t < kAT; t++) s += ddl[t] * qr[t];
+      dks += s;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < NP; p++) {
+    const int e = tid + p * 256;
+    if (e < DH * DH) dAl[(e / DH) * (DH + 1) + e % DH] = dA[p];
+  }
+  if (tid < DH) dksl[tid] = dks;
+  // ---- pass 2 over the key tokens: dK' = dA V' + dks, dV' = dA^T K'
+  float *Kt = Qt, *Vt = Gt;
+  for (int s0 = 0; s0 < a.Sk; s0 += kAT) {
+    const int ns = a.Sk - s0 < kAT ? a.Sk - s0 : kAT;
+    __syncthreads();
+    for (int e = tid; e < DH * kAT; e += 256) {
+      const int i = e / kAT, s = e - i * kAT;
+      const bool ok = s < ns;
+      Kt[i * RP + s] = ok ? elu1f(k[(size_t)i * a.Sk + s0 + s]) : 0.f;
+      Vt[i * RP + s] = ok ? v[(size_t)i * a.Sk + s0 + s] / sk : 0.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < DH * kAT; e += 256) {
+      const int i = e / kAT, s = e - i * kAT;
+      float dkp = dksl[i], dvp = 0.f;
+#pragma unroll 8
+      for (int j = 0; j < DH; j++) {
+        dkp += dAl[i * (DH + 1) + j] * Vt[j * RP + s];
+        dvp += Kt[j * RP + s] * dAl[j * (DH + 1) + i];
+      }
+      if (s < ns) {
+        const float kp = Kt[i * RP + s];
+        dk[(size_t)i * a.Sk + s0 + s] = dkp * (kp > 1.0f ? 1.0f : kp);
+        dv[(size_t)i * a.Sk + s0 + s] = dvp / sk;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ pair pooling ----
+// o (2P,C,L): clouds p and p + P are pair p.  pooled (P,2C) = [max over the 2L points, mean over the 2L points];
+// arg (P,C) = position of the maximum in the point-concatenated pair (0 .. 2L-1, first maximum).
+__global__ __launch_bounds__(256) void pool_pair_fwd_kernel(const float *__restrict__ o, float *__restrict__ pooled,
+                                                            int *__restrict__ arg, int P, int C, int L) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t p = blockIdx.x;
+  for (int c = wave; c < C; c += 4) {
+    const float *o1 = o + (p * C + c) * L, *o2 = o + ((p + P) * C + c) * L;
+    float mx = -INFINITY, sm = 0.f;
+    int am = 0;
+    for (int i = lane; i < 2 * L; i += 64) {
+      const float x = i < L ? o1[i] : o2[i - L];
+      if (x > mx) {
+        mx = x;
+        am = i;
+      }
+      sm += x;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const float ox = __shfl_xor(mx, m, 64);
+      const int oa = __shfl_xor(am, m, 64);
+      if (ox > mx || (ox == mx && oa < am)) {
+        mx = ox;
+        am = oa;
+      }
+    }
+    sm = wsum(sm);
+    if (lane == 0) {
+      pooled[p * 2 * C + c] = mx;
+      pooled[p * 2 * C + C + c] = sm / (float)(2 * L);
+      arg[p * C + c] = am;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pool_pair_bwd_kernel(const float *__restrict__ g, const int *__restrict__ arg,
+                                                            float *__restrict__ dout, int P, int C, int L) {
+  const size_t bc = blockIdx.x;                 // (cloud, channel) row of the (2P,C,L) gradient
+  const size_t b = bc / C;
+  const int c = (int)(bc - b * C);
+  const size_t p = b < (size_t)P ? b : b - P;
+  const int half = b < (size_t)P ? 0 : 1;
+  const float gm = g[p * 2 * C + c], ga = g[p * 2 * C + C + c] / (float)(2 * L);
+  const int am = arg[p * C + c] - half * L;
+  for (int l = threadIdx.x; l < L; l += 256) dout[bc * L + l] = ga + (l == am ? gm : 0.f);
+}
+
+template <class F>
+void dh_dispatch(int dh, F f) {
+  switch (dh) {
+    case 16: f(std::integral_constant<int, 16>()); break;
+    case 32: f(std::integral_constant<int, 32>()); break;
+    default: f(std::integral_constant<int, 64>()); break;
+  }
+}
+
+}  // namespace
+
+PCR_EXPORT int pcr_tnorm_fwd_f32(const float *x, const float *gamma, const float *beta, const float *res, float *y,
+                                 float *mean, float *rstd, int B, int C, int L, int G, float eps, int relu,
+                                 pcr_stream_t stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || B < 0 || C < 1 || L < 1 || G < 1 || C % G) return PCR_ERR_INVALID;
+  if (B == 0) return PCR_OK;
+  if (B > 65535 || G > 65535) return PCR_ERR_INVALID;
+  TNorm a{x, gamma, beta, res, y, mean, rstd, C, L, G, eps, relu};
+  hipLaunchKernelGGL(tnorm_fwd_kernel, dim3((L + 255) / 256, G, B), dim3(256), 0, pcr_s(stream), a);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_tnorm_bwd_f32(const float *g, const float *x, const float *gamma, const float *mean, const float *rstd,
+                                 const float *y_relu, float *dx, float *dres, float *part, int B, int C, int L, int G,
+                                 pcr_stream_t stream) {
+  if (!g || !x || !gamma || !mean || !rstd || !dx || !part || B < 0 || C < 1 || L < 1 || G < 1 || C % G)
+    return PCR_ERR_INVALID;
+  if (B == 0) return PCR_OK;
+  if (B > 65535 || G > 65535) return PCR_ERR_INVALID;
+  TNormBwd a{g, x, gamma, mean, rstd, dx, part, C, L, G, y_relu, dres};
+  hipLaunchKernelGGL(tnorm_bwd_kernel, dim3((L + 255) / 256, G, B), dim3(256), 0, pcr_s(stream), a);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+static int linattn_check(const pcr_linattn *p) {
+  if (!p || !p->q || !p->k || !p->v || !p->A || !p->ks || p->B < 0 || p->Lq < 1 || p->Sk < 1 || p->H < 1 || p->d % p->H)
+    return 1;
+  const int dh = p->d / p->H;
+  return !(dh == 16 || dh == 32 || dh == 64);
+}
+
+static LinAttn linattn_args(const pcr_linattn *p) {
+  LinAttn a;
+  a.q = p->q; a.k = p->k; a.v = p->v; a.q_bs = p->q_bs; a.k_bs = p->k_bs; a.v_bs = p->v_bs;
+  a.Lq = p->Lq; a.Sk = p->Sk; a.d = p->d; a.H = p->H; a.eps = p->eps;
+  a.out = p->out; a.A = p->A; a.ks = p->ks; a.dout = p->dout;
+  a.dq = p->dq; a.dk = p->dk; a.dv = p->dv; a.dq_bs = p->dq_bs; a.dk_bs = p->dk_bs; a.dv_bs = p->dv_bs;
+  return a;
+}
+
+PCR_EXPORT int pcr_linattn_fwd_f32(const pcr_linattn *p, pcr_stream_t stream) {
+  if (linattn_check(p) || !p->out) return PCR_ERR_INVALID;
+  if (p->B == 0) return PCR_OK;
+  if (p->B > 65535) return PCR_ERR_INVALID;
+  const LinAttn a = linattn_args(p);
+  dh_dispatch(p->d / p->H, [&](auto tag) {
+    hipLaunchKernelGGL(linattn_fwd_kernel<decltype(tag)::value>, dim3(p->H, p->B), dim3(256), 0, pcr_s(stream), a);
+  });
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_linattn_bwd_f32(const pcr_linattn *p, pcr_stream_t stream) {
+  if (linattn_check(p) || !p->dout || !p->dq || !p->dk || !p->dv) return PCR_ERR_INVALID;
+  if (p->B == 0) return PCR_OK;
+  if (p->B > 65535) return PCR_ERR_INVALID;
+  const LinAttn a = linattn_args(p);
+  dh_dispatch(p->d / p->H, [&](auto tag) {
+    constexpr int DH = decltype(tag)::value;
+    static bool ok = allow_big_lds(linattn_bwd_kernel<DH>);
+    (void)ok;
+    const size_t lds = (3 * (size_t)DH * (kAT + 1) + 2 * (size_t)DH * (DH + 1) + 2 * DH + 2 * kAT) * sizeof(float);
+    hipLaunchKernelGGL(linattn_bwd_kernel<DH>, dim3(p->H, p->B), dim3(256), lds, pcr_s(stream), a);
+  });
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_pool_pair_fwd_f32(const float *o, float *pooled, int *arg, int P, int C, int L, pcr_stream_t stream) {
+  if (!o || !pooled || !arg || P < 0 || C < 1 || L < 1) return PCR_ERR_INVALID;
+  if (P == 0) return PCR_OK;
+  hipLaunchKernelGGL(pool_pair_fwd_kernel, dim3(P), dim3(256), 0, pcr_s(stream), o, pooled, arg, P, C, L);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_pool_pair_bwd_f32(const float *g, const int *arg, float *dout, int P, int C, int L,
+                                     pcr_stream_t stream) {
+  if (!g || !arg || !dout || P < 0 || C < 1 || L < 1) return PCR_ERR_INVALID;
+  if (P == 0) return PCR_OK;
+  hipLaunchKernelGGL(pool_pair_bwd_kernel, dim3(2 * P * C), dim3(256), 0, pcr_s(stream), g, arg, dout, P, C, L);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}

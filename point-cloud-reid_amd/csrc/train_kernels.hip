@@ -148,10 +148,22 @@ __global__ __launch_bounds__(kThreads) void tdense_fwd_kernel(TFwd a) {
     const int valid = L - t0 < T ? L - t0 : T;
     if (a.stats && tid < coutP) {   // BatchNorm statistics of the raw output (bias included)
       const float *row = X + tid * RP;
-      for (int t = 0; t < valid; t++) {
-        const float v = row[t];
-        ssum += v;
-        ssq += v * v;
+      if (valid == T) {   // whole tile: unrolled, four independent chains (the LDS reads overlap)
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; t += 4) {
+          const float v0 = row[t], v1 = row[t + 1], v2 = row[t + 2], v3 = row[t + 3];
+          p0 += v0; p1 += v1; p2 += v2; p3 += v3;
+          q0 += v0 * v0; q1 += v1 * v1; q2 += v2 * v2; q3 += v3 * v3;
+        }
+        ssum += (p0 + p1) + (p2 + p3);
+        ssq += (q0 + q1) + (q2 + q3);
+      } else {
+        for (int t = 0; t < valid; t++) {
+          const float v = row[t];
+          ssum += v;
+          ssq += v * v;
+        }
       }
     }
     if (vec && valid == T) {
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(kThreads) void tdense_bwd_kernel(TBwd a) {
     s_ish[e] = aff ? a.ish[e] : 0.f;
     s_iinv[e] = (aff && a.iinv) ? a.iinv[e] : 1.f;
   }
-  const int mode = a.dy_mode, K = a.K, S = a.S;
+  const int mode = a.dy_mode, K = a.K, S = a.S, cout = a.cout;
   const float *gb = mode == 3 ? a.g + b * a.cout * S : a.g + b * a.cout * L;
   const float *yb = a.y ? a.y + b * a.cout * L : gb;
   const int *amb = mode == 3 ? a.argmax + b * a.cout * S : nullptr;
@@ -256,7 +268,14 @@ __global__ __launch_bounds__(kThreads) void tdense_bwd_kernel(TBwd a) {
   auto dy4 = [&](int c, int tg) {
     f32x4 g;
     if (mode != 3) g = ld4(gb + (size_t)c * L + tg);
-    else {
+    else if ((K & 3) == 0) {   // the four tokens of an aligned piece belong to one centre
+      const int s = tg / K, k = tg - s * K;
+      const size_t o = (size_t)c * S + s;
+      const int am = amb[o] - k;
+      const float gv = plb[o] > 0.f ? gb[o] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; j++) g[j] = am == j ? gv : 0.f;
+    } else {
 #pragma unroll
       for (int j = 0; j < 4; j++) g[j] = g1(c, tg + j);
     }
@@ -309,23 +328,43 @@ __global__ __launch_bounds__(kThreads) void tdense_bwd_kernel(TBwd a) {
   for (int i = 0; i < NTW; i++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
-  float dbsum = 0.f, s1 = 0.f, s2 = 0.f;
+  float dbsum[2] = {0.f, 0.f}, s1 = 0.f, s2 = 0.f;
   const bool want_dx = a.wpT != nullptr && z == 0;
   __syncthreads();
   for (int ti = 0; ti < a.tpw; ti++) {
     const int t0 = (blockIdx.x * a.tpw + ti) * T;
     if (t0 >= L) break;
     if (ti) __syncthreads();
-    tile_fill(DY, a.cout, rowsY, L, t0, vec, dy4, dy1);
-    tile_fill(AT, cin, cinP, L, t0, vec, a4, a1);
+    // ONE fill over both tiles (AT follows DY in LDS): the loads of dy and of the forward input are in flight together
+    tile_fill(DY, rowsY + cinP, rowsY + cinP, L, t0, vec,
+              [&](int c, int tg) {
+                if (c < rowsY) return c < cout ? dy4(c, tg) : f32x4{0.f, 0.f, 0.f, 0.f};
+                return c - rowsY < cin ? a4(c - rowsY, tg) : f32x4{0.f, 0.f, 0.f, 0.f};
+              },
+              [&](int c, int tg) {
+                if (c < rowsY) return c < cout ? dy1(c, tg) : 0.f;
+                return c - rowsY < cin ? a1(c - rowsY, tg) : 0.f;
+              });
     __syncthreads();
     const int valid = L - t0 < T ? L - t0 : T;
     // (tile_fill leaves the padding tokens of a ragged tile zero, also where BatchNorm's backward adds a constant)
-    if (a.dbp && z == 0 && tid < coutP) {
-      const float *row = DY + tid * RP;
-      float s = 0.f;
-      for (int t = 0; t < T; t++) s += row[t];
-      dbsum += s;
+    if (a.dbp && z == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; j++) {      // up to 384 cout rows, 256 threads
+        const int rw = tid + j * kThreads;
+        if (rw < coutP) {
+          const float *row = DY + rw * RP;
+          float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+#pragma unroll
+          for (int t = 0; t < T; t += 4) {
+            p0 += row[t];
+            p1 += row[t + 1];
+            p2 += row[t + 2];
+            p3 += row[t + 3];
+          }
+          dbsum[j] += (p0 + p1) + (p2 + p3);
+        }
+      }
     }
     if (a.dwp) {
 #pragma unroll
@@ -349,22 +388,55 @@ __global__ __launch_bounds__(kThreads) void tdense_bwd_kernel(TBwd a) {
       if (a.dstats && tid < cin1) {
         const float *dr = DY + tid * RP, *ar = AT + tid * RP;
         const float sh = s_ish[tid], inv = s_iinv[tid];
-        for (int t = 0; t < valid; t++) {
-          const float av = ar[t];
-          const float v = (!in_relu || av > 0.f) ? dr[t] : 0.f;
-          s1 += v;
-          s2 += v * ((av - sh) * inv);
+        if (valid == T) {
+          float p0 = 0.f, p1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll
+          for (int t = 0; t < T; t += 2) {
+            const float a0 = ar[t], a1 = ar[t + 1];
+            const float v0 = (!in_relu || a0 > 0.f) ? dr[t] : 0.f, v1 = (!in_relu || a1 > 0.f) ? dr[t + 1] : 0.f;
+            p0 += v0;
+            p1 += v1;
+            q0 += v0 * ((a0 - sh) * inv);
+            q1 += v1 * ((a1 - sh) * inv);
+          }
+          s1 += p0 + p1;
+          s2 += q0 + q1;
+        } else {
+          for (int t = 0; t < valid; t++) {
+            const float av = ar[t];
+            const float v = (!in_relu || av > 0.f) ? dr[t] : 0.f;
+            s1 += v;
+            s2 += v * ((av - sh) * inv);
+          }
         }
       }
-      for (int e = tid; e < cin * T; e += kThreads) {
-        const int c = e / T, t = e - c * T;
-        if (t < valid) {
-          float v = DY[c * RP + t];
+      if (vec && valid == T) {
+        constexpr int Q = T / 4;
+        for (int e = tid; e < cin * Q; e += kThreads) {
+          const int c = e / Q, q = e - c * Q;
+          const float *ds = DY + c * RP + 4 * q, *as = AT + c * RP + 4 * q;
+          f32x4 v = {ds[0], ds[1], ds[2], ds[3]};
           if (c < cin1) {
-            if (in_relu && !(AT[c * RP + t] > 0.f)) v = 0.f;
-            a.dx[(b * cin1 + c) * L + t0 + t] = v;
+            if (in_relu) {
+#pragma unroll
+              for (int j = 0; j < 4; j++) v[j] = as[j] > 0.f ? v[j] : 0.f;
+            }
+            *reinterpret_cast<f32x4 *>(a.dx + (b * cin1 + c) * L + t0 + 4 * q) = v;
           } else {
-            a.dx2[(b * a.cin2 + (c - cin1)) * L + t0 + t] = v;
+            *reinterpret_cast<f32x4 *>(a.dx2 + (b * a.cin2 + (c - cin1)) * L + t0 + 4 * q) = v;
+          }
+        }
+      } else {
+        for (int e = tid; e < cin * T; e += kThreads) {
+          const int c = e / T, t = e - c * T;
+          if (t < valid) {
+            float v = DY[c * RP + t];
+            if (c < cin1) {
+              if (in_relu && !(AT[c * RP + t] > 0.f)) v = 0.f;
+              a.dx[(b * cin1 + c) * L + t0 + t] = v;
+            } else {
+              a.dx2[(b * a.cin2 + (c - cin1)) * L + t0 + t] = v;
+            }
           }
         }
       }
@@ -384,7 +456,10 @@ __global__ __launch_bounds__(kThreads) void tdense_bwd_kernel(TBwd a) {
       }
     }
   }
-  if (a.dbp && z == 0 && tid < coutP) a.dbp[wg * coutP + tid] = dbsum;
+  if (a.dbp && z == 0) {
+    if (tid < coutP) a.dbp[wg * coutP + tid] = dbsum[0];
+    if (tid + kThreads < coutP) a.dbp[wg * coutP + tid + kThreads] = dbsum[1];
+  }
   if (a.dstats && want_dx) {
     const int c1P = ceil32(cin1);
     float *sp = a.dstats + wg * 2 * (size_t)c1P;
@@ -396,32 +471,43 @@ __global__ __launch_bounds__(kThreads) void tdense_bwd_kernel(TBwd a) {
 }
 
 // ------------------------------------------------------------------- reductions / finalisers ----
-// out[e] = sum over p of part[p][e], p in increasing order (fixed order => reproducible); optional row gather:
-// element e = (row r, col c) of a (rows x cols) result reads part[p][r * ld + c]
-__global__ void reduce_parts_kernel(const float *__restrict__ part, int nparts, size_t stride, int rows, int cols,
-                                    int ld, float *__restrict__ out) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= rows * cols) return;
-  const int r = e / cols, c = e - r * cols;
+// out[e] = sum over p of part[p][e] in a FIXED order (reproducible): block = 32 elements x 8 part lanes, lane pl adds
+// parts pl, pl + 8, ... on four interleaved chains, the eight lane totals are combined in lane order.  Optional row
+// gather: element e = (row r, col c) of a (rows x cols) result reads part[p][r * ld + c].
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float *__restrict__ part, int nparts, size_t stride,
+                                                           int rows, int cols, int ld, float *__restrict__ out) {
+  __shared__ float red[8][32];
+  const int el = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + el;
+  const bool ok = e < rows * cols;
+  const int r = ok ? e / cols : 0, c = ok ? e - r * cols : 0;
   const float *p = part + (size_t)r * ld + c;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four interleaved chains (fixed association), then a fixed combine
-  int q = 0;
-  for (; q + 4 <= nparts; q += 4) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int q = pl;
+  for (; q + 24 < nparts; q += 32) {
     s0 += p[(size_t)q * stride];
-    s1 += p[(size_t)(q + 1) * stride];
-    s2 += p[(size_t)(q + 2) * stride];
-    s3 += p[(size_t)(q + 3) * stride];
+    s1 += p[(size_t)(q + 8) * stride];
+    s2 += p[(size_t)(q + 16) * stride];
+    s3 += p[(size_t)(q + 24) * stride];
   }
-  for (; q < nparts; q++) s0 += p[(size_t)q * stride];
-  out[e] = (s0 + s1) + (s2 + s3);
+  for (; q < nparts; q += 8) s0 += p[(size_t)q * stride];
+  red[pl][el] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (pl == 0 && ok) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) t += red[i][el];
+    out[e] = t;
+  }
 }
 
-// partial sums [nparts][2][CP] -> per-channel totals in double.  Block = 32 channels x 8 part lanes.
+// partial sums [nparts][2][CP] -> per-channel totals in double.  Block = 32 channels x 32 part lanes; the lane
+// totals are combined in lane order (fixed => reproducible).
 __device__ __forceinline__ void sum_parts2(const float *part, int nparts, int CP, int c, double &t0, double &t1,
-                                           double (*red)[8][32]) {
+                                           double (*red)[32][32]) {
   const int cl = threadIdx.x & 31, pg = threadIdx.x >> 5;
   double a0 = 0.0, a1 = 0.0;
-  for (int p = pg; p < nparts; p += 8) {
+  for (int p = pg; p < nparts; p += 32) {
     a0 += (double)part[((size_t)p * 2) * CP + c];
     a1 += (double)part[((size_t)p * 2 + 1) * CP + c];
   }
@@ -430,7 +516,7 @@ __device__ __forceinline__ void sum_parts2(const float *part, int nparts, int CP
   __syncthreads();
   t0 = 0.0;
   t1 = 0.0;
-  for (int i = 0; i < 8; i++) {
+  for (int i = 0; i < 32; i++) {
     t0 += red[0][i][cl];
     t1 += red[1][i][cl];
   }
@@ -446,8 +532,8 @@ struct BnFwdFin {
   float *scale, *shift, *inv_scale, *mean, *invstd;
 };
 
-__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(BnFwdFin a) {
-  __shared__ double red[2][8][32];
+__global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(BnFwdFin a) {
+  __shared__ double red[2][32][32];
   const int c = blockIdx.x * 32 + (threadIdx.x & 31);
   double s, sq;
   sum_parts2(a.part, a.nparts, a.CP, c < a.CP ? c : 0, s, sq, red);
@@ -481,8 +567,8 @@ struct BnBwdFin {
   float *ka, *kb, *kc, *dgamma, *dbeta;
 };
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdFin a) {
-  __shared__ double red[2][8][32];
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(BnBwdFin a) {
+  __shared__ double red[2][32][32];
   const int c = blockIdx.x * 32 + (threadIdx.x & 31);
   double s1, s2;
   sum_parts2(a.part, a.nparts, a.CP, c < a.CP ? c : 0, s1, s2, red);
@@ -522,8 +608,8 @@ static bool big_lds(K k) {
 
 static int wg_groups(int B, int ntiles) {
   // workgroups per cloud: enough to fill the chip a few times over, few enough that the per-workgroup partials
-  // (dW images, statistics) stay small: ~2048 workgroups per launch
-  int g = (2048 + B - 1) / (B > 0 ? B : 1);
+  // (dW images, statistics) stay small: ~1024 workgroups per launch
+  int g = (1024 + B - 1) / (B > 0 ? B : 1);
   if (g < 1) g = 1;
   if (g > ntiles) g = ntiles;
   return g;
@@ -548,9 +634,10 @@ PCR_EXPORT int pcr_pack_weight_dev_f32(const float *w, int rows, int cols, int l
 }
 
 PCR_EXPORT int pcr_tdense_fwd_f32(const pcr_tdense_fwd *p, pcr_stream_t stream) {
-  if (!p || !p->x || !p->wp || !p->y || p->B < 0 || p->cin1 < 1 || p->cin2 < 0 || p->cout < 1 || p->cout > 256 ||
+  if (!p || !p->x || !p->wp || !p->y || p->B < 0 || p->cin1 < 1 || p->cin2 < 0 || p->cout < 1 || p->cout > 384 ||
       p->L < 1 || (p->cin2 && !p->x2) || (p->isc && !p->ish))
     return PCR_ERR_INVALID;
+  if (p->stats && p->cout > 256) return PCR_ERR_INVALID;   // (statistics are taken by one thread per cout row)
   if (p->B == 0) return PCR_OK;
   if (p->B > 65535) return PCR_ERR_INVALID;
   TFwd a;
@@ -565,16 +652,17 @@ PCR_EXPORT int pcr_tdense_fwd_f32(const pcr_tdense_fwd *p, pcr_stream_t stream) 
   const int cinP = ceil8(p->cin1 + p->cin2), coutP = ceil32(p->cout);
   const size_t lds = ((size_t)(cinP > coutP ? cinP : coutP) * kTRP + 2 * (size_t)p->cin1) * sizeof(float);
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
-  static bool ok = big_lds(tdense_fwd_kernel<1>) && big_lds(tdense_fwd_kernel<2>);
+  static bool ok = big_lds(tdense_fwd_kernel<1>) && big_lds(tdense_fwd_kernel<2>) && big_lds(tdense_fwd_kernel<3>);
   (void)ok;
-  if (coutP > 128) hipLaunchKernelGGL(tdense_fwd_kernel<2>, dim3(gx, p->B), dim3(kThreads), lds, pcr_s(stream), a);
+  if (coutP > 256) hipLaunchKernelGGL(tdense_fwd_kernel<3>, dim3(gx, p->B), dim3(kThreads), lds, pcr_s(stream), a);
+  else if (coutP > 128) hipLaunchKernelGGL(tdense_fwd_kernel<2>, dim3(gx, p->B), dim3(kThreads), lds, pcr_s(stream), a);
   else hipLaunchKernelGGL(tdense_fwd_kernel<1>, dim3(gx, p->B), dim3(kThreads), lds, pcr_s(stream), a);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }
 
 PCR_EXPORT int pcr_tdense_bwd_f32(const pcr_tdense_bwd *p, pcr_stream_t stream) {
-  if (!p || !p->g || !p->x || p->B < 0 || p->cin1 < 1 || p->cin2 < 0 || p->cout < 1 || p->cout > 256 || p->L < 1 ||
+  if (!p || !p->g || !p->x || p->B < 0 || p->cin1 < 1 || p->cin2 < 0 || p->cout < 1 || p->cout > 384 || p->L < 1 ||
       p->cin1 + p->cin2 > 288 || (p->cin2 && !p->x2) || p->dy_mode < 0 || p->dy_mode > 3)
     return PCR_ERR_INVALID;
   if ((p->dy_mode == 1 || p->dy_mode == 3) && (!p->ka || !p->kb || !p->kc || !p->y)) return PCR_ERR_INVALID;
@@ -618,7 +706,7 @@ PCR_EXPORT int pcr_reduce_parts_f32(const float *part, int nparts, long stride, 
                                     pcr_stream_t stream) {
   if (!part || !out || nparts < 1 || rows < 1 || cols < 1 || ld < cols) return PCR_ERR_INVALID;
   const int total = rows * cols;
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((total + 255) / 256), dim3(256), 0, pcr_s(stream), part, nparts,
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((total + 31) / 32), dim3(256), 0, pcr_s(stream), part, nparts,
                      (size_t)stride, rows, cols, ld, out);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
@@ -633,7 +721,7 @@ PCR_EXPORT int pcr_bn_fwd_finalize_f32(const pcr_bn_fwd_fin *p, pcr_stream_t str
   a.gamma = p->gamma; a.beta = p->beta; a.eps = p->eps; a.momentum = p->momentum;
   a.running_mean = p->running_mean; a.running_var = p->running_var;
   a.scale = p->scale; a.shift = p->shift; a.inv_scale = p->inv_scale; a.mean = p->mean; a.invstd = p->invstd;
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(a.CP / 32), dim3(256), 0, pcr_s(stream), a);
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(a.CP / 32), dim3(1024), 0, pcr_s(stream), a);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }
@@ -646,7 +734,7 @@ PCR_EXPORT int pcr_bn_bwd_finalize_f32(const pcr_bn_bwd_fin *p, pcr_stream_t str
   a.part = p->part; a.nparts = p->nparts; a.CP = ceil32(p->C); a.C = p->C; a.R = p->R;
   a.gamma = p->gamma; a.mean = p->mean; a.invstd = p->invstd;
   a.ka = p->ka; a.kb = p->kb; a.kc = p->kc; a.dgamma = p->dgamma; a.dbeta = p->dbeta;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.CP / 32), dim3(256), 0, pcr_s(stream), a);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.CP / 32), dim3(1024), 0, pcr_s(stream), a);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }

@@ -120,9 +120,10 @@ __global__ __launch_bounds__(kThreads) void sa_l1_bwd_kernel(L1BwdArgs a) {
   constexpr int PARTS = kThreads / CS, TR = 64;   // rows per staged tile
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = a.N, S = a.S, K = a.K, c1 = a.c1, L = S * K;
-  float *dP = smem;                            // [CS][N]
-  float *dQ = dP + (a.dtab ? CS * N : 0);      // [CS][S]
-  float *xl = dQ + (a.dtab ? CS * S : 0);      // [N][3]
+  const int NP = N | 1, SP = S | 1;            // odd pitches: the lanes of a wave differ in cl, not in i / s
+  float *dP = smem;                            // [CS][NP]
+  float *dQ = dP + (a.dtab ? CS * NP : 0);     // [CS][SP]
+  float *xl = dQ + (a.dtab ? CS * SP : 0);     // [N][3]
   float *dyt = xl + 3 * N;                     // [CS][TR + 1]
   float *dxt = dyt + CS * (TR + 1);            // [TR][3]
   int *it = reinterpret_cast<int *>(dxt + 3 * TR);   // [TR] neighbour index, [TR] centre
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(kThreads) void sa_l1_bwd_kernel(L1BwdArgs a) {
   const int c0 = blockIdx.x * CS;
   const bool live = c0 + cl < c1;
   if (a.dtab)
-    for (int e = tid; e < CS * N + CS * S; e += kThreads) dP[e] = 0.f;   // (dQ follows dP)
+    for (int e = tid; e < CS * NP + CS * SP; e += kThreads) dP[e] = 0.f;   // (dQ follows dP)
   for (int e = tid; e < 3 * N; e += kThreads) xl[e] = a.xyz[b * N * 3 + e];
   const int *idx = a.idx + b * L;
   const float *g = a.g + (b * c1 + c0) * L, *y = a.y + (b * c1 + c0) * L;
@@ -172,8 +173,8 @@ __global__ __launch_bounds__(kThreads) void sa_l1_bwd_kernel(L1BwdArgs a) {
         }
         if (a.dtab) {
           const int i = it[rr], s = st[rr];
-          if ((i % PARTS) == part) dP[cl * N + i] += v;
-          if ((s % PARTS) == part) dQ[cl * S + s] += v;
+          if ((i % PARTS) == part) dP[cl * NP + i] += v;
+          if ((s % PARTS) == part) dQ[cl * SP + s] += v;
         }
       }
     }
@@ -195,8 +196,8 @@ __global__ __launch_bounds__(kThreads) void sa_l1_bwd_kernel(L1BwdArgs a) {
     for (int e = tid; e < CS * N; e += kThreads) {
       const int c = e / N, i = e - c * N;
       if (c0 + c < c1) {
-        dt[(size_t)(c0 + c) * N + i] = dP[e];
-        dt[(size_t)(c1 + c0 + c) * N + i] = i < S ? dQ[c * S + i] : 0.f;
+        dt[(size_t)(c0 + c) * N + i] = dP[c * NP + i];
+        dt[(size_t)(c1 + c0 + c) * N + i] = i < S ? dQ[c * SP + i] : 0.f;
       }
     }
   }
@@ -324,7 +325,7 @@ PCR_EXPORT int pcr_sa_l1_bwd_f32(const float *xyz, const int *idx, const float *
   if (cs > 32) cs = 32;
   L1BwdArgs a{xyz, idx, g, y, ka, kb, kc, dtab, dwa, N, S, K, c1, cs};
   const int parts = kThreads / cs;
-  const size_t lds = ((dtab ? (size_t)cs * (N + S) : 0) + 3 * (size_t)N + (size_t)cs * 65 + 3 * 64 + 2 * 64 +
+  const size_t lds = ((dtab ? (size_t)cs * ((N | 1) + (S | 1)) : 0) + 3 * (size_t)N + (size_t)cs * 65 + 3 * 64 + 2 * 64 +
                       (size_t)parts * cs * 4) * sizeof(float);
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
   const dim3 grid((c1 + cs - 1) / cs, B);

@@ -1,98 +1,103 @@
-"""Training-mode forward of the Point-Transformer ReID path as a differentiable graph on the device.
+"""Training-mode forward of the Point-Transformer ReID path as a differentiable graph whose every node is a HIP launch.
 
-STATUS: inference is hand-written HIP end to end; training is NOT yet.  This module
-makes `ReIDNet.train_step` usable today: neighbour search runs on the HIP kernel (pcr_knn_prefix_f32,
-indices carry no gradient), neighbour gathers run on the HIP grouping op with its HIP scatter-add
-backward (pcr_group_fwd/bwd_f32), and the dense math (1x1 convs with BatchNorm in batch-statistics mode,
-linear attention, LayerNorm/GroupNorm, BCE) is expressed with torch autograd ops on the GPU, following the
-reference's graph (mmdet3d/models/pointnet2_utils.py:55-114, 242-288, 333-437; attention.py:192-219;
-lanegcn_nets.py:228-241).  Gradients are pinned to the reference by tests/golden/pt_train_step_n128.npz.
-Fused forward/backward kernels for these layers are the next training milestone; nothing here is used in
-eval mode.
+`ReIDNet.train_step` in training mode runs through here: neighbour search (pcr_knn_prefix_f32, no gradient), the
+grouped set-abstraction MLPs with BatchNorm in batch-statistics mode (train_ops.SaEdgeTrain), the linear-attention
+blocks (dense projections + LinAttn + LayerNorm), the matching stages, pair pooling and the LinearRes + Linear head.
+torch.autograd only strings the Functions of pcr_amd/train_ops.py together and owns the scalar loss
+(BCEWithLogits over B logits); no torch matmul / conv / norm kernel is on this path.  It follows the reference's graph
+(mmdet3d/models/pointnet2_utils.py:55-114, 242-288, 333-437; attention.py:192-219; lanegcn_nets.py:228-241;
+ReIDNet.py:231-247, 526-534) and is pinned to the reference's loss and gradients by tests/golden/pt_train_step_n128.npz.
+Tensors are (B, C, L) channel-major throughout, as in the inference path.  Nothing here is used in eval mode.
 """
 import torch
-import torch.nn.functional as F
 
 from . import engine
-from mmdet3d.ops.point_ops import grouping_operation
+from . import train_ops as TO
+
+ATTN_EPS = 1e-6
 
 
-def linear_attention(q, k, v, eps=1e-6):
-    Q = F.elu(q) + 1
-    K = F.elu(k) + 1
-    s = v.size(1)
-    v = v / s
-    KV = torch.einsum("nshd,nshv->nhdv", K, v)
-    Z = 1 / (torch.einsum("nlhd,nhd->nlh", Q, K.sum(dim=1)) + eps)
-    return torch.einsum("nlhd,nhdv,nlh->nlhv", Q, KV, Z) * s
+def _cm(xyz):
+    """(B,L,3) -> (B,3,L) channel-major coordinates"""
+    return xyz.transpose(1, 2).contiguous()
 
 
-def attention_block(m, q_in, k_in, v_in, res_in, residual):
-    """m: module with q_proj/k_proj/v_proj/merge/mlp/norm1/norm2; inputs (B,L,C) token-major"""
-    B, L, _ = q_in.shape
-    d, h = m.q_proj.weight.shape[0], m.nhead
-    q = m.q_proj(q_in).view(B, L, h, d // h)
-    k = m.k_proj(k_in).view(B, -1, h, d // h)
-    v = m.v_proj(v_in).view(B, -1, h, d // h)
-    msg = m.norm1(m.merge(linear_attention(q, k, v).reshape(B, L, d)))
-    msg = m.norm2(m.mlp(torch.cat([res_in, msg], dim=2)))
-    return res_in + msg if residual else msg
+def _attention(m, pos, q_in, k_in, v_in, res_in, residual, fused_qkv):
+    """shared tail of Self_Attention / FP_SA / corss_attention: projections, linear attention, merge, LayerNorm,
+    feed-forward on [res_in ; msg], LayerNorm (+ residual)"""
+    d, H = m.q_proj.weight.shape[0], m.nhead
+    if fused_qkv:      # q, k, v all project the same tensor: one dense launch, slices feed the attention core
+        qkv = TO.dense(q_in, torch.cat([m.q_proj.weight, m.k_proj.weight, m.v_proj.weight], dim=0))
+        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    else:
+        q, k, v = TO.dense(q_in, m.q_proj.weight), TO.dense(k_in, m.k_proj.weight), TO.dense(v_in, m.v_proj.weight)
+    msg = TO.LinAttn.apply(q, k, v, H, ATTN_EPS)
+    n1 = TO.tnorm(TO.dense(msg, m.merge.weight), m.norm1)
+    f0 = TO.dense(res_in, m.mlp[0].weight, x2=n1, relu=True)
+    return TO.tnorm(TO.dense(f0, m.mlp[2].weight), m.norm2, res=res_in if residual else None)
 
 
-def self_attention(m, feat, xyz):
-    f = feat.permute(0, 2, 1)
-    fp = f + m.pos_mlp(xyz)
-    return attention_block(m, fp, fp, fp, f, True).permute(0, 2, 1)
+def _pos(pos_mlp, xyz_cm, add_to):
+    """add_to + Linear(ReLU(Linear(xyz)))  (the residual add rides in the second dense launch)"""
+    h = TO.dense(xyz_cm, pos_mlp[0].weight, pos_mlp[0].bias, relu=True)
+    return TO.dense(h, pos_mlp[2].weight, pos_mlp[2].bias, res=add_to)
 
 
-def fp_sa(m, feat1, xyz1, feat2, xyz2):
-    f1, f2 = feat1.permute(0, 2, 1), feat2.permute(0, 2, 1)
-    return attention_block(m, f1, f2, f2 + m.pos_mlp2(xyz2), f1, False).permute(0, 2, 1)
+def self_attention(m, feat, xyz_cm):
+    fp = _pos(m.pos_mlp, xyz_cm, feat)
+    return _attention(m, None, fp, fp, fp, feat, True, True)
 
 
-def cross_attention(m, search, search_xyz, template, template_xyz):
-    s, t = search.permute(0, 2, 1), template.permute(0, 2, 1)
-    return attention_block(m, s, t, t + m.pos_mlp(template_xyz), s, True).permute(0, 2, 1)
+def fp_sa(m, feat1, feat2, xyz2_cm):
+    return _attention(m, None, feat1, feat2, _pos(m.pos_mlp2, xyz2_cm, feat2), feat1, False, False)
+
+
+def cross_attention(m, search, template, template_xyz_cm):
+    return _attention(m, None, search, template, _pos(m.pos_mlp, template_xyz_cm, template), search, True, False)
 
 
 def sa_edge_layer(sa, xyz, feats, s):
-    """PointNetSetAbstractionEdgeSA in training mode: (B,N,3), (B,D,N)|None -> (B,S,3), (B,D',S).  Neighbour search,
-    the per-point tables of layer 1, the three conv + BatchNorm(batch statistics) + ReLU layers, the max over K and
-    all of their backward are HIP launches (pcr_amd/train_ops.py: SaEdgeTrain)."""
-    from . import train_ops
+    """PointNetSetAbstractionEdgeSA in training mode: (B,N,3), (B,D,N)|None -> (B,S,3), (B,D',S)"""
     xyz = xyz.contiguous()
-    idx = engine.knn_prefix(xyz.detach(), s, sa.nsample)                      # HIP, (B,S,K) int32
-    new_xyz = xyz[:, :s]
-    x = train_ops.sa_edge_train(sa, xyz.detach(), None if feats is None else feats.contiguous(), idx)
-    return new_xyz, self_attention(sa.self_attention, x, new_xyz)
+    idx = engine.knn_prefix(xyz, s, sa.nsample)                               # HIP, (B,S,K) int32
+    new_xyz = xyz[:, :s].contiguous()
+    x = TO.sa_edge_train(sa, xyz, None if feats is None else feats.contiguous(), idx)
+    return new_xyz, self_attention(sa.self_attention, x, _cm(new_xyz))
 
 
 def backbone(bb, pointcloud, numpoints):
-    xyz = pointcloud[..., 0:3].contiguous()
+    xyz = pointcloud[..., 0:3].detach().contiguous()
     l_xyz, l_feat = [xyz], [None]
     for i, sa in enumerate(bb.SA_modules):
         nx, nf = sa_edge_layer(sa, l_xyz[i], l_feat[i], numpoints[i])
         l_xyz.append(nx)
         l_feat.append(nf)
-    l_feat[0] = xyz.transpose(1, 2).contiguous()
+    l_feat[0] = _cm(xyz)
     for i in (2, 1, 0):
-        l_feat[i] = fp_sa(bb.FP_modules[i].interpolation, l_feat[i], l_xyz[i], l_feat[i + 1], l_xyz[i + 1])
-    return xyz, bb.cov_final(l_feat[0])
+        l_feat[i] = fp_sa(bb.FP_modules[i].interpolation, l_feat[i], l_feat[i + 1], _cm(l_xyz[i + 1]))
+    cf = bb.cov_final
+    return xyz, TO.dense(l_feat[0], cf.weight.view(cf.weight.shape[0], -1), cf.bias)
 
 
-def linear_res(m, x):
-    out = F.relu(m.norm1(m.linear1(x)))
-    out = m.norm2(m.linear2(out))
-    out = out + (m.transform(x) if m.transform is not None else x)
-    return F.relu(out)
+def linear_res_rows(m, x):
+    """LinearRes (lanegcn_nets.py:228-241) on (M, n) rows, evaluated channel-major with the rows as tokens (1, n, M):
+    relu(GN(W1 x)) -> GN(W2 .) + shortcut -> relu, the ReLUs and the shortcut add inside the norm launches"""
+    out = TO.tnorm(TO.dense(x, m.linear1.weight), m.norm1, relu=True)
+    short = x if m.transform is None else TO.tnorm(TO.dense(x, m.transform[0].weight), m.transform[1])
+    return TO.tnorm(TO.dense(out, m.linear2.weight), m.norm2, res=short, relu=True)
 
 
 def match_logits(model, h1, xyz1, h2, xyz2):
-    a1 = cross_attention(model.cross_stage1, h1, xyz1, h2, xyz2)
-    a2 = cross_attention(model.cross_stage1, h2, xyz2, h1, xyz1)
-    o1 = cross_attention(model.cross_stage2, a1, xyz1, a2, xyz2)
-    o2 = cross_attention(model.cross_stage2, a2, xyz2, a1, xyz1)
-    x = torch.cat([o1, o2], dim=2)
-    pooled = torch.cat([x.max(dim=2)[0], x.mean(dim=2)], dim=1)
-    x = linear_res(model.match_head[0], pooled)
-    return model.match_head[1](x).squeeze(1), torch.cat([o1, o2], dim=0)
+    """xcorr_eff + point-cat + pool 'both' + LinearRes + Linear (ReIDNet.py:231-247, 526-534, 455-457); the four
+    cross-attention calls of the reference run as two, over all 2B clouds with the halves swapped as templates"""
+    b = h1.shape[0]
+    feats = torch.cat([h1, h2], dim=0)
+    xyz_cm = _cm(torch.cat([xyz1, xyz2], dim=0))
+    swap = lambda t: torch.cat([t[b:], t[:b]], dim=0)       # noqa: E731
+    a = cross_attention(model.cross_stage1, feats, swap(feats), swap(xyz_cm))
+    o = cross_attention(model.cross_stage2, a, swap(a), swap(xyz_cm))
+    pooled = TO.PoolPair.apply(o)                                          # (B, 2C)
+    x = pooled.t().contiguous().unsqueeze(0)                               # (1, 2C, B): samples as tokens
+    x = linear_res_rows(model.match_head[0], x)
+    logits = TO.dense(x, model.match_head[1].weight, model.match_head[1].bias)   # (1, 1, B)
+    return logits.reshape(-1), o

@@ -304,3 +304,131 @@ def sa_edge_train(sa, xyz, feats, idx):
     for l in (1, 2):
         args += [convs[l].weight.view(convs[l].weight.shape[0], -1), convs[l].bias, bns[l].weight, bns[l].bias]
     return SaEdgeTrain.apply(*args, bns)
+
+
+# ---------------------------------------------------------------- attention / norm / pooling Functions --
+class _LinAttnP(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int), ("Lq", ctypes.c_int), ("Sk", ctypes.c_int), ("d", ctypes.c_int), ("H", ctypes.c_int),
+                ("eps", ctypes.c_float), ("q", c_fp), ("k", c_fp), ("v", c_fp),
+                ("q_bs", ctypes.c_long), ("k_bs", ctypes.c_long), ("v_bs", ctypes.c_long),
+                ("out", c_fp), ("A", c_fp), ("ks", c_fp), ("dout", c_fp), ("dq", c_fp), ("dk", c_fp), ("dv", c_fp),
+                ("dq_bs", ctypes.c_long), ("dk_bs", ctypes.c_long), ("dv_bs", ctypes.c_long)]
+
+
+def _block(t, d):
+    """(pointer, batch stride) of a (B,d,L) channel-major block that may be a channel slice of a wider tensor"""
+    assert t.dim() == 3 and t.shape[1] == d and t.stride(2) == 1 and t.stride(1) == t.shape[2], \
+        "attention operands must be channel slices of contiguous (B,C,L) tensors"
+    return t.data_ptr(), t.stride(0)
+
+
+class LinAttn(Function):
+    """LinearAttention (pointnet2_utils.py:26-47) on channel-major tensors: q (B,d,Lq), k, v (B,d,Sk) -> (B,d,Lq).
+    The operands may be channel slices of one fused projection; their gradients are then written into one buffer."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, H, eps):
+        L.require_cuda(q, k, v)
+        B, d, Lq = q.shape
+        Sk = k.shape[2]
+        dev = q.device
+        out = _f32(B, d, Lq, device=dev)
+        A = _f32(B, H, d // H, d // H, device=dev)
+        ks = _f32(B, H, d // H, device=dev)
+        p = _LinAttnP()
+        p.B, p.Lq, p.Sk, p.d, p.H, p.eps = B, Lq, Sk, d, H, eps
+        (p.q, p.q_bs), (p.k, p.k_bs), (p.v, p.v_bs) = _block(q, d), _block(k, d), _block(v, d)
+        p.out, p.A, p.ks = _p(out), _p(A), _p(ks)
+        L.check(L.load().pcr_linattn_fwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_linattn_fwd_f32")
+        ctx.save_for_backward(q, k, v, A, ks)
+        ctx.meta = (H, eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v, A, ks = ctx.saved_tensors
+        H, eps = ctx.meta
+        B, d, Lq = q.shape
+        Sk = k.shape[2]
+        g = g.contiguous()
+        step = d * Lq * 4
+        fused = (Lq == Sk and q.stride(0) == 3 * d * Lq and k.stride(0) == q.stride(0) and v.stride(0) == q.stride(0)
+                 and k.data_ptr() == q.data_ptr() + step and v.data_ptr() == k.data_ptr() + step)
+        if fused:     # slices [q ; k ; v] of one (B,3d,L) projection: one gradient buffer, returned through its slices
+            buf = _f32(B, 3 * d, Lq, device=q.device)
+            dq, dk, dv = buf[:, :d], buf[:, d:2 * d], buf[:, 2 * d:]
+        else:
+            dq, dk, dv = _f32(B, d, Lq, device=q.device), _f32(B, d, Sk, device=q.device), _f32(B, d, Sk, device=q.device)
+        p = _LinAttnP()
+        p.B, p.Lq, p.Sk, p.d, p.H, p.eps = B, Lq, Sk, d, H, eps
+        (p.q, p.q_bs), (p.k, p.k_bs), (p.v, p.v_bs) = _block(q, d), _block(k, d), _block(v, d)
+        p.A, p.ks, p.dout = _p(A), _p(ks), _p(g)
+        (p.dq, p.dq_bs), (p.dk, p.dk_bs), (p.dv, p.dv_bs) = _block(dq, d), _block(dk, d), _block(dv, d)
+        L.check(L.load().pcr_linattn_bwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_linattn_bwd_f32")
+        return dq, dk, dv, None, None
+
+
+class TNorm(Function):
+    """[relu](LayerNorm (G = 1) / GroupNorm over the channels of every token of (B,C,L) [+ res])"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, G, eps, relu):
+        x = _dev(x)
+        B, C, Ln = x.shape
+        y = torch.empty_like(x)
+        mean, rstd = _f32(B, G, Ln, device=x.device), _f32(B, G, Ln, device=x.device)
+        L.check(L.load().pcr_tnorm_fwd_f32(L.ptr(x), L.ptr(gamma.detach()), L.ptr(beta.detach()),
+                                           L.ptr(None if res is None else _dev(res)), L.ptr(y), L.ptr(mean), L.ptr(rstd),
+                                           B, C, Ln, G, ctypes.c_float(eps), int(relu), L.stream_ptr()), "pcr_tnorm_fwd_f32")
+        ctx.save_for_backward(x, gamma, mean, rstd, y if relu else None)
+        ctx.meta = (G, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, mean, rstd, y = ctx.saved_tensors
+        G, has_res = ctx.meta
+        B, C, Ln = x.shape
+        g = g.contiguous()
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if (has_res and y is not None) else None
+        nparts = B * ((Ln + 255) // 256)
+        part = _f32(nparts, 2, C, device=x.device)
+        L.check(L.load().pcr_tnorm_bwd_f32(L.ptr(g), L.ptr(x), L.ptr(gamma.detach()), L.ptr(mean), L.ptr(rstd), L.ptr(y),
+                                           L.ptr(dx), L.ptr(dres), L.ptr(part), B, C, Ln, G, L.stream_ptr()),
+                "pcr_tnorm_bwd_f32")
+        gb = reduce_parts(part, nparts, 2 * C, 2, C, C)
+        return dx, gb[0], gb[1], (dres if dres is not None else g) if has_res else None, None, None, None
+
+
+def tnorm(x, norm, res=None, relu=False):
+    L.require_default_eps(norm)
+    G = getattr(norm, "num_groups", 1)
+    return TNorm.apply(x, norm.weight, norm.bias, res, G, norm.eps, relu)
+
+
+class PoolPair(Function):
+    """o (2P,C,L) -> (P,2C): [max, mean] over the point-concatenated pair (clouds p and p + P)"""
+
+    @staticmethod
+    def forward(ctx, o):
+        o = _dev(o)
+        twoP, C, Ln = o.shape
+        P = twoP // 2
+        pooled = _f32(P, 2 * C, device=o.device)
+        arg = torch.empty((P, C), dtype=torch.int32, device=o.device)
+        L.check(L.load().pcr_pool_pair_fwd_f32(L.ptr(o), L.ptr(pooled), L.ptr(arg), P, C, Ln, L.stream_ptr()),
+                "pcr_pool_pair_fwd_f32")
+        ctx.save_for_backward(arg)
+        ctx.dims = (P, C, Ln)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, g):
+        arg, = ctx.saved_tensors
+        P, C, Ln = ctx.dims
+        g = g.contiguous()
+        dout = _f32(2 * P, C, Ln, device=g.device)
+        L.check(L.load().pcr_pool_pair_bwd_f32(L.ptr(g), L.ptr(arg), L.ptr(dout), P, C, Ln, L.stream_ptr()),
+                "pcr_pool_pair_bwd_f32")
+        return dout

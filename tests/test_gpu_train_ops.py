@@ -105,3 +105,154 @@ def test_train_dense_and_gradients_are_reproducible():
         for a, r in zip(ours, again):
             if a is not None:
                 assert torch.equal(a, r)          # fixed-order reductions: bit-identical from run to run
+
+
+# ---- attention / norm / pooling Functions against torch autograd on the reference's formulas ----
+def _t_linattn(q, k, v, H, eps=1e-6):
+    """LinearAttention.forward (pointnet2_utils.py:26-47) on (B,d,L) tensors"""
+    B, d, Lq = q.shape
+    qq = q.permute(0, 2, 1).reshape(B, Lq, H, d // H)
+    kk = k.permute(0, 2, 1).reshape(B, -1, H, d // H)
+    vv = v.permute(0, 2, 1).reshape(B, -1, H, d // H)
+    Q, K = F.elu(qq) + 1, F.elu(kk) + 1
+    s = vv.size(1)
+    vv = vv / s
+    KV = torch.einsum("nshd,nshv->nhdv", K, vv)
+    Z = 1 / (torch.einsum("nlhd,nhd->nlh", Q, K.sum(dim=1)) + eps)
+    out = torch.einsum("nlhd,nhdv,nlh->nlhv", Q, KV, Z) * s
+    return out.reshape(B, Lq, d).permute(0, 2, 1)
+
+
+def _grads(fn, tensors, go):
+    for t in tensors:
+        t.grad = None
+    y = fn()
+    (y * go).sum().backward()
+    return [y.detach()] + [t.grad.clone() for t in tensors]
+
+
+@pytest.mark.parametrize("B,d,H,Lq,Sk,fused", [(3, 32, 2, 128, 128, True), (2, 64, 2, 100, 37, False), (4, 128, 2, 32, 32, True),
+                                               (2, 64, 2, 200, 64, False)])
+def test_linear_attention_core_matches_torch(B, d, H, Lq, Sk, fused):
+    from pcr_amd import train_ops as TO
+    g = torch.Generator().manual_seed(4)
+    if fused:
+        qkv = torch.randn(B, 3 * d, Lq, generator=g).cuda().requires_grad_(True)
+        go = torch.randn(B, d, Lq, generator=g).cuda()
+        ours = _grads(lambda: TO.LinAttn.apply(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], H, 1e-6), [qkv], go)
+        want = _grads(lambda: _t_linattn(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], H), [qkv], go)
+    else:
+        q = torch.randn(B, d, Lq, generator=g).cuda().requires_grad_(True)
+        k = torch.randn(B, d, Sk, generator=g).cuda().requires_grad_(True)
+        v = torch.randn(B, d, Sk, generator=g).cuda().requires_grad_(True)
+        go = torch.randn(B, d, Lq, generator=g).cuda()
+        ours = _grads(lambda: TO.LinAttn.apply(q, k, v, H, 1e-6), [q, k, v], go)
+        want = _grads(lambda: _t_linattn(q, k, v, H), [q, k, v], go)
+    for a, r in zip(ours, want):
+        assert _rel(a, r) < 2e-5, _rel(a, r)
+
+
+@pytest.mark.parametrize("B,C,Ln,G,res,relu", [(3, 64, 128, 1, True, False), (2, 128, 33, 1, False, False),
+                                               (1, 128, 256, 8, True, True), (1, 96, 70, 6, False, True)])
+def test_token_norm_matches_torch(B, C, Ln, G, res, relu):
+    from pcr_amd import train_ops as TO
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, Ln, generator=g).cuda().requires_grad_(True)
+    r = torch.randn(B, C, Ln, generator=g).cuda().requires_grad_(True) if res else None
+    norm = (torch.nn.LayerNorm(C) if G == 1 else torch.nn.GroupNorm(G, C)).cuda()
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.1 * torch.randn(C, generator=g))
+        norm.bias.copy_(0.1 * torch.randn(C, generator=g))
+    go = torch.randn(B, C, Ln, generator=g).cuda()
+    ts = [x, norm.weight, norm.bias] + ([r] if res else [])
+    # the torch reference runs on the CPU: torch 2.10+rocm7.0's GPU GroupNorm backward returns wrong d gamma / d beta
+    # for 2-D (256, 128) inputs (checked against the CPU and against direct sums), which is exactly the match head's shape
+    import copy
+    xc = x.detach().cpu().requires_grad_(True)
+    rc = r.detach().cpu().requires_grad_(True) if res else None
+    normc = copy.deepcopy(norm).cpu()
+    tc = [xc, normc.weight, normc.bias] + ([rc] if res else [])
+
+    def torch_fn():
+        rows = xc.permute(0, 2, 1).reshape(B * Ln, C)
+        y = normc(rows).reshape(B, Ln, C).permute(0, 2, 1)
+        if res:
+            y = y + rc
+        return F.relu(y) if relu else y
+    ours = _grads(lambda: TO.tnorm(x, norm, res=r, relu=relu), ts, go)
+    want = _grads(torch_fn, tc, go.cpu())
+    for a, b_ in zip(ours, want):
+        assert _rel(a.cpu(), b_) < 2e-5, _rel(a.cpu(), b_)
+
+
+def test_pair_pooling_matches_torch():
+    from pcr_amd import train_ops as TO
+    g = torch.Generator().manual_seed(6)
+    o = torch.randn(10, 64, 77, generator=g).cuda().requires_grad_(True)
+    go = torch.randn(5, 128, generator=g).cuda()
+
+    def torch_fn():
+        x = torch.cat([o[:5], o[5:]], dim=2)
+        return torch.cat([x.max(dim=2)[0], x.mean(dim=2)], dim=1)
+    ours = _grads(lambda: TO.PoolPair.apply(o), [o], go)
+    want = _grads(torch_fn, [o], go)
+    for a, b_ in zip(ours, want):
+        assert _rel(a, b_) < 1e-6
+
+
+def test_attention_blocks_match_torch_graph():
+    """Self_Attention / FP_SA / corss_attention in training mode (HIP Functions) against the reference's formulas in
+    plain torch (pointnet2_utils.py:90-114, 407-437; attention.py:192-219)"""
+    import copy
+    from mmdet3d.models.pointnet2_utils import Self_Attention, FP_SA
+    from mmdet3d.models.attention import corss_attention
+    from pcr_amd import train_graph as TG
+
+    def t_block(m, q_in, k_in, v_in, res_in, residual):
+        B, Lq, _ = q_in.shape
+        d, h = m.q_proj.weight.shape[0], m.nhead
+        q = m.q_proj(q_in).permute(0, 2, 1)
+        k = m.k_proj(k_in).permute(0, 2, 1)
+        v = m.v_proj(v_in).permute(0, 2, 1)
+        msg = _t_linattn(q, k, v, h).permute(0, 2, 1)
+        msg = m.norm1(m.merge(msg))
+        msg = m.norm2(m.mlp(torch.cat([res_in, msg], dim=2)))
+        return res_in + msg if residual else msg
+    g = torch.Generator().manual_seed(7)
+    rnd = lambda *s: torch.randn(*s, generator=g).cuda()     # noqa: E731
+    cases = []
+    m = Self_Attention(64, 2)
+    cases.append(("self", m, lambda mm, f, x, f2, x2: TG.self_attention(mm, f, TG._cm(x)),
+                  lambda mm, f, x, f2, x2: t_block(mm, f.permute(0, 2, 1) + mm.pos_mlp(x), f.permute(0, 2, 1) + mm.pos_mlp(x),
+                                                   f.permute(0, 2, 1) + mm.pos_mlp(x), f.permute(0, 2, 1), True).permute(0, 2, 1),
+                  (64, 50, 64, 50)))
+    m = FP_SA(0, 32, 128, 64, 64, 2)
+    cases.append(("fp", m, lambda mm, f, x, f2, x2: TG.fp_sa(mm, f, f2, TG._cm(x2)),
+                  lambda mm, f, x, f2, x2: t_block(mm, f.permute(0, 2, 1), f2.permute(0, 2, 1),
+                                                   f2.permute(0, 2, 1) + mm.pos_mlp2(x2), f.permute(0, 2, 1), False).permute(0, 2, 1),
+                  (32, 128, 128, 40)))
+    m = corss_attention(64, 2)
+    cases.append(("cross", m, lambda mm, f, x, f2, x2: TG.cross_attention(mm, f, f2, TG._cm(x2)),
+                  lambda mm, f, x, f2, x2: t_block(mm, f.permute(0, 2, 1), f2.permute(0, 2, 1),
+                                                   f2.permute(0, 2, 1) + mm.pos_mlp(x2), f.permute(0, 2, 1), True).permute(0, 2, 1),
+                  (64, 100, 64, 100)))
+    for name, m, ours_fn, torch_fn, (c1, Lq, c2, Sk) in cases:
+        m.load_state_dict(T.seeded_state_dict(T.manifest_of(m), 9))
+        m = m.cuda().train()
+        ref = copy.deepcopy(m)
+        f, x = rnd(3, c1, Lq).requires_grad_(True), rnd(3, Lq, 3)
+        f2, x2 = rnd(3, c2, Sk).requires_grad_(True), rnd(3, Sk, 3)
+        fr, f2r = f.detach().clone().requires_grad_(True), f2.detach().clone().requires_grad_(True)
+        out = ours_fn(m, f, x, f2, x2)
+        want = torch_fn(ref, fr, x, f2r, x2)
+        assert _rel(out, want) < 2e-5, (name, _rel(out, want))
+        go = rnd(*out.shape)
+        (out * go).sum().backward()
+        (want * go).sum().backward()
+        worst = {"f": _rel(f.grad, fr.grad)}
+        if name != "self":
+            worst["f2"] = _rel(f2.grad, f2r.grad)
+        for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+            if q.grad is not None:
+                worst[k] = _rel(p.grad, q.grad)
+        assert max(worst.values()) < 1e-4, (name, worst)
