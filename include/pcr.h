@@ -342,7 +342,8 @@ int pcr_local_attn_f32(const float *qkv, const int *idx, float *msg, int B, int 
  * + a reduce / finalize launch): no float atomics, gradients are bit-reproducible.  csrc/train_kernels.hip. */
 
 /* device-side pcr_pack_weight_f32 (weights change every iteration): W (rows x cols, leading dimension ld) -> packed
- * image of W (transpose = 0) or of W^T (transpose = 1); packed holds pcr_packed_weight_floats(cout, cin) floats */
+ * image of W (transpose = 0), of W^T (transpose = 1), or both, W first (transpose = 2); packed holds
+ * pcr_packed_weight_floats(cout, cin) floats per image */
 int pcr_pack_weight_dev_f32(const float *w, int rows, int cols, int ld, int transpose, float *packed, pcr_stream_t stream);
 
 /* workgroups per cloud the train-dense launches use for (B, L): the partial buffers below have B * this many entries */
@@ -385,6 +386,7 @@ typedef struct pcr_tdense_bwd {
   int in_relu;
   const float *wpT;
   float *dx, *dx2, *dstats, *dwp, *dbp;
+  long part_stride;   /* floats between consecutive workgroups' dwp / dbp partials; 0 = two dense arrays */
 } pcr_tdense_bwd;
 int pcr_tdense_bwd_f32(const pcr_tdense_bwd *p, pcr_stream_t stream);
 
@@ -437,7 +439,7 @@ int pcr_sa_pool_bwd_stats_f32(const float *gp, const float *pooled, const int *a
 
 /* LayerNorm / GroupNorm over the channels of every token of x (B,C,L) (G groups of C/G consecutive channels; LayerNorm:
  * G = 1), y = [relu]((x - mean) rstd gamma + beta [+ res]); mean / rstd (B,G,L) are kept for the backward.  Backward: dx and
- * partials [B * ceil(L/256)][2][C] of (d gamma, d beta) for pcr_reduce_parts_f32.  csrc/train_attn_kernels.hip. */
+ * partials [ceil(B L / 256) * 4][2][C] (one row per 64-token wave) of (d gamma, d beta) for pcr_reduce_parts_f32.  csrc/train_attn_kernels.hip. */
 int pcr_tnorm_fwd_f32(const float *x, const float *gamma, const float *beta, const float *res, float *y, float *mean,
                       float *rstd, int B, int C, int L, int G, float eps, int relu, pcr_stream_t stream);
 /* y_relu: the forward output when relu was set (the gradient is masked by y > 0 first), else NULL; dres (optional): the

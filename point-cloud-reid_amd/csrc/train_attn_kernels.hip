@@ -11,10 +11,20 @@
 
 namespace {
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 64 lanes of a wave (the same value in every lane): four DPP adds inside the 16-lane rows, then the four
+// row totals through v_readlane -- no LDS traffic (a __shfl_xor butterfly is six ds_bpermute round trips)
 __device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
+  v += dpp_f32<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(v);    // row_half_mirror
+  v += dpp_f32<0x140>(v);    // row_mirror
+  const int b = __float_as_int(v);     // (v_readlane moves 32-bit patterns: the builtin is typed int)
+  return (__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16))) +
+         (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
 }
 
 // ------------------------------------------------------------------ token norm (LayerNorm / GroupNorm) ----
@@ -28,10 +38,13 @@ struct TNorm {
   int relu;                   // y = relu(...) (LinearRes, lanegcn_nets.py:233,240)
 };
 
-__global__ __launch_bounds__(256) void tnorm_fwd_kernel(TNorm a) {
-  const size_t b = blockIdx.z;
-  const int g = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= a.L) return;
+// (tokens are indexed flat over all clouds: ft = b * L + t, so a block is 256 real tokens whatever L is)
+__global__ __launch_bounds__(256) void tnorm_fwd_kernel(TNorm a, int B) {
+  const int g = blockIdx.y;
+  const size_t ft = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (ft >= (size_t)B * a.L) return;
+  const size_t b = ft / a.L;
+  const int t = (int)(ft - b * a.L);
   const int gs = a.C / a.G;
   const size_t base = (b * a.C + (size_t)g * gs) * a.L + t;
   float m = 0.f;
@@ -62,14 +75,15 @@ struct TNormBwd {
   float *dres;     // optional: the masked gradient (= gradient of the residual input)
 };
 
-__global__ __launch_bounds__(256) void tnorm_bwd_kernel(TNormBwd a) {
-  __shared__ float red[4][2];
-  const size_t b = blockIdx.z;
-  const int g = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void tnorm_bwd_kernel(TNormBwd a, int B) {
+  const int g = blockIdx.y;
+  const size_t ft = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool ok = t < a.L;
+  const bool ok = ft < (size_t)B * a.L;
+  const size_t b = ok ? ft / a.L : 0;
+  const int t = ok ? (int)(ft - b * a.L) : 0;
   const int gs = a.C / a.G;
-  const size_t base = (b * a.C + (size_t)g * gs) * a.L + (ok ? t : 0);
+  const size_t base = (b * a.C + (size_t)g * gs) * a.L + t;
   const float m = ok ? a.mean[(b * a.G + g) * a.L + t] : 0.f, r = ok ? a.rstd[(b * a.G + g) * a.L + t] : 0.f;
   float s1 = 0.f, s2 = 0.f;
   auto grad = [&](int i) {   // incoming gradient of channel i of this group, through the optional ReLU
@@ -84,24 +98,18 @@ __global__ __launch_bounds__(256) void tnorm_bwd_kernel(TNormBwd a) {
     s2 += gv * xh;
   }
   const float inv = 1.0f / (float)gs;
-  float *part = a.part + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 2 * a.C;
+  // d gamma / d beta: one partial row per WAVE (64 tokens), no barriers; rows [(blockIdx.x 4 + wave)][2][C]
+  float *part = a.part + ((size_t)blockIdx.x * 4 + wave) * 2 * a.C;
   for (int i = 0; i < gs; i++) {
     const int c = g * gs + i;
     const float go = grad(i);
     const float xh = ok ? (a.x[base + (size_t)i * a.L] - m) * r : 0.f;
     if (ok) a.dx[base + (size_t)i * a.L] = r * (go * a.gamma[c] - s1 * inv - xh * s2 * inv);
     if (ok && a.dres) a.dres[base + (size_t)i * a.L] = go;
-    // d gamma[c] = sum over tokens of g xhat, d beta[c] = sum of g: wave sums, then the four waves in order
     const float w1 = wsum(go * xh), w2 = wsum(go);
-    __syncthreads();
     if (lane == 0) {
-      red[wave][0] = w1;
-      red[wave][1] = w2;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      part[c] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
-      part[a.C + c] = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
+      part[c] = w1;
+      part[a.C + c] = w2;
     }
   }
 }
@@ -397,9 +405,10 @@ PCR_EXPORT int pcr_tnorm_fwd_f32(const float *x, const float *gamma, const float
                                  pcr_stream_t stream) {
   if (!x || !gamma || !beta || !y || !mean || !rstd || B < 0 || C < 1 || L < 1 || G < 1 || C % G) return PCR_ERR_INVALID;
   if (B == 0) return PCR_OK;
-  if (B > 65535 || G > 65535) return PCR_ERR_INVALID;
+  if (G > 65535) return PCR_ERR_INVALID;
   TNorm a{x, gamma, beta, res, y, mean, rstd, C, L, G, eps, relu};
-  hipLaunchKernelGGL(tnorm_fwd_kernel, dim3((L + 255) / 256, G, B), dim3(256), 0, pcr_s(stream), a);
+  const unsigned nb = (unsigned)(((size_t)B * L + 255) / 256);
+  hipLaunchKernelGGL(tnorm_fwd_kernel, dim3(nb, G), dim3(256), 0, pcr_s(stream), a, B);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }
@@ -410,9 +419,10 @@ PCR_EXPORT int pcr_tnorm_bwd_f32(const float *g, const float *x, const float *ga
   if (!g || !x || !gamma || !mean || !rstd || !dx || !part || B < 0 || C < 1 || L < 1 || G < 1 || C % G)
     return PCR_ERR_INVALID;
   if (B == 0) return PCR_OK;
-  if (B > 65535 || G > 65535) return PCR_ERR_INVALID;
+  if (G > 65535) return PCR_ERR_INVALID;
   TNormBwd a{g, x, gamma, mean, rstd, dx, part, C, L, G, y_relu, dres};
-  hipLaunchKernelGGL(tnorm_bwd_kernel, dim3((L + 255) / 256, G, B), dim3(256), 0, pcr_s(stream), a);
+  const unsigned nb = (unsigned)(((size_t)B * L + 255) / 256);
+  hipLaunchKernelGGL(tnorm_bwd_kernel, dim3(nb, G), dim3(256), 0, pcr_s(stream), a, B);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }

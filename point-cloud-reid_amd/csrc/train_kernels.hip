@@ -91,7 +91,10 @@ struct TFwd {
   float *stats;                     // partials [workgroups][2][ceil32(cout)] (sum, sum of squares of y), or null
 };
 
-template <int NR>
+// PFQ > 0: the NEXT tile's raw input (PFQ 16-byte pieces per thread) is requested right after the current tile has been
+// committed to LDS, so its HBM round trip hides behind the matrix phase and the epilogue of the current tile
+// WS / NR: the dense shape (tile_dense2): WS = 4 / 2 / 1 for one / two / >= 3 cout blocks, NR rounds of four blocks per wave
+template <int WS, int NR, int PFQ>
 __global__ __launch_bounds__(kThreads) void tdense_fwd_kernel(TFwd a) {
   constexpr int TB = 2, T = kTT, RP = kTRP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -137,20 +140,67 @@ __global__ __launch_bounds__(kThreads) void tdense_fwd_kernel(TFwd a) {
     }
     return v;
   };
+  constexpr int NPQ = PFQ > 0 ? PFQ : 1;
+  f32x4 pre[NPQ];
+  const int totq = cinP * (T / 4);
+  auto fetch = [&](int t0) {
+#pragma unroll
+    for (int u = 0; u < NPQ; u++) {
+      const int e = tid + u * kThreads;
+      const int c = e >> 4, q = e & 15;
+      const bool ok = e < totq && c < cin;
+      const int cc = ok ? c : 0;
+      pre[u] = ld4((cc < cin1 ? xb + (size_t)cc * L : x2b + (size_t)(cc - cin1) * L) + t0 + 4 * (ok ? q : 0));
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < NPQ; u++) {
+      const int e = tid + u * kThreads;
+      if (e < totq) {
+        const int c = e >> 4, q = e & 15;
+        f32x4 v = pre[u];
+        if (c >= cin) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        else if (aff && c < cin1) {
+          const float sc = s_isc[c], sh = s_ish[c];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            v[j] = v[j] * sc + sh;
+            if (in_relu) v[j] = fmaxf(v[j], 0.f);
+          }
+        }
+        float *d = X + c * RP + 4 * q;
+        d[0] = v[0];
+        d[1] = v[1];
+        d[2] = v[2];
+        d[3] = v[3];
+      }
+    }
+  };
+  auto whole = [&](int t0) { return PFQ > 0 && vec && t0 + T <= L; };
+  const int tfirst = blockIdx.x * a.tpw * T;
+  bool have = false;
+  if (tfirst < L && whole(tfirst)) {
+    fetch(tfirst);
+    have = true;
+  }
   for (int ti = 0; ti < a.tpw; ti++) {
     const int t0 = (blockIdx.x * a.tpw + ti) * T;
     if (t0 >= L) break;
     if (ti) __syncthreads();
-    tile_fill(X, cin, cinP, L, t0, vec, f4, f1);
+    if (have) commit();
+    else tile_fill(X, cin, cinP, L, t0, vec, f4, f1);
     __syncthreads();
-    tile_dense2<TB, NR>(X, cinP, a.wp, coutP, true, [&](float v, int o, int t) { X[o * RP + t] = v; }, a.bias);
+    have = ti + 1 < a.tpw && t0 + T < L && whole(t0 + T);
+    if (have) fetch(t0 + T);
+    tile_dense2<TB, NR, WS>(X, cinP, a.wp, coutP, true, [&](float v, int o, int t) { X[o * RP + t] = v; }, a.bias);
     __syncthreads();
     const int valid = L - t0 < T ? L - t0 : T;
     if (a.stats && tid < coutP) {   // BatchNorm statistics of the raw output (bias included)
       const float *row = X + tid * RP;
       if (valid == T) {   // whole tile: unrolled, four independent chains (the LDS reads overlap)
         float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
-#pragma unroll
+#pragma unroll 4
         for (int t = 0; t < T; t += 4) {
           const float v0 = row[t], v1 = row[t + 1], v2 = row[t + 2], v3 = row[t + 3];
           p0 += v0; p1 += v1; p2 += v2; p3 += v3;
@@ -220,11 +270,14 @@ struct TBwd {
   float *dx, *dx2;
   float *dstats;                    // partials [workgroups][2][ceil32(cin1)]: sum dxm, sum dxm * raw x (dxm = masked dx)
   float *dwp, *dbp;                 // partials [workgroups][ceil32(cout)][ceil32(cin)], [workgroups][ceil32(cout)]
+  long dw_stride, db_stride;        // floats between the workgroups' partials (0 = dense arrays)
   int cout, L, tpw;
 };
 
-template <int NRX, int NTW>
-__global__ __launch_bounds__(kThreads) void tdense_bwd_kernel(TBwd a) {
+// QY / QX > 0: register prefetch of the NEXT tile (QY pieces of g and of y, QX pieces of the forward input per thread),
+// requested once the current tile sits in LDS: the HBM round trip hides behind the two matrix phases
+template <int WSX, int NRX, int NTW, int QY, int QX>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void tdense_bwd_kernel(TBwd a) {
   constexpr int TB = 2, T = kTT, RP = kTRP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int cin = a.cin1 + a.cin2, cinP = ceil32(cin), coutP = ceil32(a.cout), L = a.L;
@@ -331,10 +384,100 @@ __global__ __launch_bounds__(kThreads) void tdense_bwd_kernel(TBwd a) {
   float dbsum[2] = {0.f, 0.f}, s1 = 0.f, s2 = 0.f;
   const bool want_dx = a.wpT != nullptr && z == 0;
   __syncthreads();
+  constexpr bool kPF = QY > 0;
+  constexpr int NQY = kPF ? QY : 1, NQX = kPF ? QX : 1;
+  f32x4 pg[NQY], py[NQY], px[NQX];
+  auto fetch = [&](int t0) {
+#pragma unroll
+    for (int u = 0; u < NQY; u++) {
+      const int e = tid + u * kThreads;
+      const int c = e >> 4, q = e & 15;
+      const bool ok = c < cout;                 // (rows [cout, rowsY) stay zero)
+      const int cc = ok ? c : 0, tg = t0 + 4 * q;
+      if (mode == 3) {
+        const int sc = tg / K, k = tg - sc * K;
+        const size_t o = (size_t)cc * S + sc;
+        pg[u] = f32x4{__int_as_float(amb[o] - k), plb[o], gb[o], 0.f};
+      } else {
+        pg[u] = ld4(gb + (size_t)cc * L + tg);
+      }
+      if (mode != 0) py[u] = ld4(yb + (size_t)cc * L + tg);
+    }
+#pragma unroll
+    for (int u = 0; u < NQX; u++) {
+      const int e = tid + u * kThreads;
+      const int c = e >> 4, q = e & 15;
+      const bool ok = c < cin;
+      const int cc = ok ? c : 0;
+      px[u] = ld4((cc < cin1 ? xb + (size_t)cc * L : x2b + (size_t)(cc - cin1) * L) + t0 + 4 * q);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < NQY; u++) {
+      const int e = tid + u * kThreads;
+      const int c = e >> 4, q = e & 15;
+      f32x4 r = {0.f, 0.f, 0.f, 0.f};
+      if (c < cout) {
+        f32x4 g = pg[u];
+        if (mode == 3) {
+          const int am = __float_as_int(pg[u][0]);
+          const float gv = pg[u][1] > 0.f ? pg[u][2] : 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; j++) g[j] = am == j ? gv : 0.f;
+        }
+        if (mode == 0) r = g;
+        else if (mode == 2) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) r[j] = py[u][j] > 0.f ? g[j] : 0.f;
+        } else {
+          const float ka = s_ka[c], kb = s_kb[c], kc = s_kc[c];
+#pragma unroll
+          for (int j = 0; j < 4; j++) r[j] = ka * g[j] + kb * py[u][j] + kc;
+        }
+      }
+      float *d = DY + c * RP + 4 * q;
+      d[0] = r[0];
+      d[1] = r[1];
+      d[2] = r[2];
+      d[3] = r[3];
+    }
+#pragma unroll
+    for (int u = 0; u < NQX; u++) {
+      const int e = tid + u * kThreads;
+      const int c = e >> 4, q = e & 15;
+      f32x4 v = px[u];
+      if (c >= cin) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      else if (aff && c < cin1) {
+        const float sc = s_isc[c], sh = s_ish[c];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          v[j] = v[j] * sc + sh;
+          if (in_relu) v[j] = fmaxf(v[j], 0.f);
+        }
+      }
+      float *d = AT + c * RP + 4 * q;
+      d[0] = v[0];
+      d[1] = v[1];
+      d[2] = v[2];
+      d[3] = v[3];
+    }
+  };
+  // (the prefetch path covers whole tiles of layers whose tiles are exactly QY / QX pieces per thread)
+  const bool pf_ok = kPF && vec && (mode != 3 || (K & 3) == 0) && rowsY == 16 * QY && cinP == 16 * QX;
+  auto whole = [&](int t0) { return pf_ok && t0 + T <= L; };
+  const int tfirst = blockIdx.x * a.tpw * T;
+  bool have = false;
+  if (tfirst < L && whole(tfirst)) {
+    fetch(tfirst);
+    have = true;
+  }
   for (int ti = 0; ti < a.tpw; ti++) {
     const int t0 = (blockIdx.x * a.tpw + ti) * T;
     if (t0 >= L) break;
     if (ti) __syncthreads();
+    if (have) commit();
+    else
     // ONE fill over both tiles (AT follows DY in LDS): the loads of dy and of the forward input are in flight together
     tile_fill(DY, rowsY + cinP, rowsY + cinP, L, t0, vec,
               [&](int c, int tg) {
@@ -346,6 +489,8 @@ __global__ __launch_bounds__(kThreads) void tdense_bwd_kernel(TBwd a) {
                 return c - rowsY < cin ? a1(c - rowsY, tg) : 0.f;
               });
     __syncthreads();
+    have = ti + 1 < a.tpw && t0 + T < L && whole(t0 + T);
+    if (have) fetch(t0 + T);
     const int valid = L - t0 < T ? L - t0 : T;
     // (tile_fill leaves the padding tokens of a ragged tile zero, also where BatchNorm's backward adds a constant)
     if (a.dbp && z == 0) {
@@ -355,7 +500,7 @@ __global__ __launch_bounds__(kThreads) void tdense_bwd_kernel(TBwd a) {
         if (rw < coutP) {
           const float *row = DY + rw * RP;
           float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-#pragma unroll
+#pragma unroll 4
           for (int t = 0; t < T; t += 4) {
             p0 += row[t];
             p1 += row[t + 1];
@@ -383,14 +528,14 @@ __global__ __launch_bounds__(kThreads) void tdense_bwd_kernel(TBwd a) {
     if (want_dx) {
       // (the barrier between this call's k-loop and its epilogue also orders the dW reads of DY above before the
       // in-place overwrite)
-      tile_dense2<TB, NRX>(DY, ceil8(a.cout), a.wpT, cinP, true, [&](float v, int o, int t) { DY[o * RP + t] = v; });
+      tile_dense2<TB, NRX, WSX>(DY, ceil8(a.cout), a.wpT, cinP, true, [&](float v, int o, int t) { DY[o * RP + t] = v; });
       __syncthreads();
       if (a.dstats && tid < cin1) {
         const float *dr = DY + tid * RP, *ar = AT + tid * RP;
         const float sh = s_ish[tid], inv = s_iinv[tid];
         if (valid == T) {
           float p0 = 0.f, p1 = 0.f, q0 = 0.f, q1 = 0.f;
-#pragma unroll
+#pragma unroll 4
           for (int t = 0; t < T; t += 2) {
             const float a0 = ar[t], a1 = ar[t + 1];
             const float v0 = (!in_relu || a0 > 0.f) ? dr[t] : 0.f, v1 = (!in_relu || a1 > 0.f) ? dr[t + 1] : 0.f;
@@ -444,7 +589,7 @@ __global__ __launch_bounds__(kThreads) void tdense_bwd_kernel(TBwd a) {
   }
   const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
   if (a.dwp) {
-    float *dw = a.dwp + wg * (size_t)coutP * cinP;
+    float *dw = a.dwp + wg * (a.dw_stride ? (size_t)a.dw_stride : (size_t)coutP * cinP);
 #pragma unroll
     for (int it = 0; it < NTW; it++) {
       const int item = z * 4 * NTW + wave + 4 * it;
@@ -457,8 +602,9 @@ __global__ __launch_bounds__(kThreads) void tdense_bwd_kernel(TBwd a) {
     }
   }
   if (a.dbp && z == 0) {
-    if (tid < coutP) a.dbp[wg * coutP + tid] = dbsum[0];
-    if (tid + kThreads < coutP) a.dbp[wg * coutP + tid + kThreads] = dbsum[1];
+    float *db = a.dbp + wg * (a.db_stride ? (size_t)a.db_stride : (size_t)coutP);
+    if (tid < coutP) db[tid] = dbsum[0];
+    if (tid + kThreads < coutP) db[tid + kThreads] = dbsum[1];
   }
   if (a.dstats && want_dx) {
     const int c1P = ceil32(cin1);
@@ -587,15 +733,19 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(BnBwdFin a) {
 // cin = cols) or of W^T (transpose = 1: cout = cols, cin = rows): element (kb, o, h, j) = M[o][kb*8 + 2*j + h]
 __global__ void pack_weight_kernel(const float *__restrict__ w, int rows, int cols, int ld, int transpose,
                                    float *__restrict__ packed) {
-  const int cout = transpose ? cols : rows, cin = transpose ? rows : cols;
-  const int CP = ceil8(cin), OP = ceil32(cout);
-  const int total = CP * OP;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+  // transpose = 2: both images, W first (ceil8(cols) * ceil32(rows) floats), then W^T
+  const int n0 = ceil8(cols) * ceil32(rows), n1 = ceil8(rows) * ceil32(cols);
+  const int total = transpose == 2 ? n0 + n1 : (transpose ? n1 : n0);
+  for (int e0 = blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += gridDim.x * blockDim.x) {
+    const bool tr = transpose == 1 || (transpose == 2 && e0 >= n0);
+    const int e = (transpose == 2 && e0 >= n0) ? e0 - n0 : e0;
+    const int cout = tr ? cols : rows, cin = tr ? rows : cols;
+    const int OP = ceil32(cout);
     const int j = e & 3, hh = (e >> 2) & 1, o = (e >> 3) % OP, kb = (e >> 3) / OP;
     const int k = kb * 8 + 2 * j + hh;
     float v = 0.f;
-    if (o < cout && k < cin) v = transpose ? w[(size_t)k * ld + o] : w[(size_t)o * ld + k];
-    packed[e] = v;
+    if (o < cout && k < cin) v = tr ? w[(size_t)k * ld + o] : w[(size_t)o * ld + k];
+    packed[e0] = v;
   }
 }
 
@@ -624,9 +774,9 @@ PCR_EXPORT int pcr_train_groups(int B, int L) {
 
 PCR_EXPORT int pcr_pack_weight_dev_f32(const float *w, int rows, int cols, int ld, int transpose, float *packed,
                                        pcr_stream_t stream) {
-  if (!w || !packed || rows < 1 || cols < 1 || ld < cols) return PCR_ERR_INVALID;
-  const int cout = transpose ? cols : rows, cin = transpose ? rows : cols;
-  const int total = ceil8(cin) * ceil32(cout);
+  if (!w || !packed || rows < 1 || cols < 1 || ld < cols || transpose < 0 || transpose > 2) return PCR_ERR_INVALID;
+  const int n0 = ceil8(cols) * ceil32(rows), n1 = ceil8(rows) * ceil32(cols);
+  const int total = transpose == 2 ? n0 + n1 : (transpose ? n1 : n0);
   hipLaunchKernelGGL(pack_weight_kernel, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0,
                      pcr_s(stream), w, rows, cols, ld, transpose, packed);
   PCR_CHECK_LAUNCH();
@@ -652,11 +802,31 @@ PCR_EXPORT int pcr_tdense_fwd_f32(const pcr_tdense_fwd *p, pcr_stream_t stream) 
   const int cinP = ceil8(p->cin1 + p->cin2), coutP = ceil32(p->cout);
   const size_t lds = ((size_t)(cinP > coutP ? cinP : coutP) * kTRP + 2 * (size_t)p->cin1) * sizeof(float);
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
-  static bool ok = big_lds(tdense_fwd_kernel<1>) && big_lds(tdense_fwd_kernel<2>) && big_lds(tdense_fwd_kernel<3>);
-  (void)ok;
-  if (coutP > 256) hipLaunchKernelGGL(tdense_fwd_kernel<3>, dim3(gx, p->B), dim3(kThreads), lds, pcr_s(stream), a);
-  else if (coutP > 128) hipLaunchKernelGGL(tdense_fwd_kernel<2>, dim3(gx, p->B), dim3(kThreads), lds, pcr_s(stream), a);
-  else hipLaunchKernelGGL(tdense_fwd_kernel<1>, dim3(gx, p->B), dim3(kThreads), lds, pcr_s(stream), a);
+  const int need = (cinP + 15) / 16;     // 16-byte pieces per thread of one input tile
+  const int pfq = need <= 2 ? 2 : (need <= 4 ? 4 : (need <= 8 ? 8 : 0));
+  const dim3 grid(gx, p->B), blk(kThreads);
+  hipStream_t st = pcr_s(stream);
+#define PCR_TF(WSv, NRv, Qv)                                                        \
+  do {                                                                              \
+    static bool ok = big_lds(tdense_fwd_kernel<WSv, NRv, Qv>);                      \
+    (void)ok;                                                                       \
+    hipLaunchKernelGGL((tdense_fwd_kernel<WSv, NRv, Qv>), grid, blk, lds, st, a);   \
+  } while (0)
+#define PCR_TFQ(WSv, NRv)                                                           \
+  do {                                                                              \
+    if (pfq == 2) PCR_TF(WSv, NRv, 2);                                              \
+    else if (pfq == 4) PCR_TF(WSv, NRv, 4);                                         \
+    else if (pfq == 8) PCR_TF(WSv, NRv, 8);                                         \
+    else PCR_TF(WSv, NRv, 0);                                                       \
+  } while (0)
+  const int nb = coutP >> 5;
+  if (nb == 1) PCR_TFQ(4, 1);
+  else if (nb == 2) PCR_TFQ(2, 1);
+  else if (nb <= 4) PCR_TFQ(1, 1);
+  else if (nb <= 8) PCR_TFQ(1, 2);
+  else PCR_TFQ(1, 3);
+#undef PCR_TFQ
+#undef PCR_TF
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }
@@ -678,6 +848,7 @@ PCR_EXPORT int pcr_tdense_bwd_f32(const pcr_tdense_bwd *p, pcr_stream_t stream) 
   a.x = p->x; a.x2 = p->cin2 ? p->x2 : nullptr; a.cin1 = p->cin1; a.cin2 = p->cin2;
   a.isc = p->isc; a.ish = p->ish; a.iinv = p->iinv; a.in_relu = p->in_relu;
   a.wpT = p->wpT; a.dx = p->dx; a.dx2 = p->dx2; a.dstats = p->dstats; a.dwp = p->dwp; a.dbp = p->dbp;
+  a.dw_stride = p->part_stride; a.db_stride = p->part_stride;
   a.cout = p->cout; a.L = p->L;
   const int ntiles = (p->L + kTT - 1) / kTT;
   const int g = wg_groups(p->B, ntiles);
@@ -690,14 +861,26 @@ PCR_EXPORT int pcr_tdense_bwd_f32(const pcr_tdense_bwd *p, pcr_stream_t stream) 
   constexpr int NTW = 4;
   const int items = (coutP >> 5) * (cinP >> 5);
   const int gz = p->dwp ? (items + 4 * NTW - 1) / (4 * NTW) : 1;
-  static bool ok = big_lds(tdense_bwd_kernel<1, NTW>) && big_lds(tdense_bwd_kernel<2, NTW>) &&
-                   big_lds(tdense_bwd_kernel<3, NTW>);
-  (void)ok;
-  const dim3 grid(gx, p->B, gz);
+  const dim3 grid(gx, p->B, gz), blk(kThreads);
+  hipStream_t st = pcr_s(stream);
   const int nx = cinP >> 5;
-  if (nx > 8) hipLaunchKernelGGL((tdense_bwd_kernel<3, NTW>), grid, dim3(kThreads), lds, pcr_s(stream), a);
-  else if (nx > 4) hipLaunchKernelGGL((tdense_bwd_kernel<2, NTW>), grid, dim3(kThreads), lds, pcr_s(stream), a);
-  else hipLaunchKernelGGL((tdense_bwd_kernel<1, NTW>), grid, dim3(kThreads), lds, pcr_s(stream), a);
+  const int rowsY = coutP > cinP ? coutP : cinP;
+#define PCR_TB(WSv, NRXv, QYv, QXv)                                                              \
+  do {                                                                                           \
+    static bool ok = big_lds(tdense_bwd_kernel<WSv, NRXv, NTW, QYv, QXv>);                       \
+    (void)ok;                                                                                    \
+    hipLaunchKernelGGL((tdense_bwd_kernel<WSv, NRXv, NTW, QYv, QXv>), grid, blk, lds, st, a);    \
+  } while (0)
+  // register-prefetch variants for the 32- / 64-channel square layers of the grouped MLPs (at 128 channels the 24
+  // prefetched pieces per thread spill); everything else (attention projections, tables: small tensors) takes the plain path
+  if (rowsY == 32 && cinP == 32) PCR_TB(4, 1, 2, 2);
+  else if (rowsY == 64 && cinP == 64) PCR_TB(2, 1, 4, 4);
+  else if (nx == 1) PCR_TB(4, 1, 0, 0);
+  else if (nx == 2) PCR_TB(2, 1, 0, 0);
+  else if (nx <= 4) PCR_TB(1, 1, 0, 0);
+  else if (nx <= 8) PCR_TB(1, 2, 0, 0);
+  else PCR_TB(1, 3, 0, 0);
+#undef PCR_TB
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }

@@ -29,10 +29,18 @@ struct L1Args {
   int N, S, K, c1, CS;
 };
 
-__device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_f(float v) {   // four DPP adds inside the 16-lane rows + four v_readlane
+  v += dpp_f32<0xB1>(v);
+  v += dpp_f32<0x4E>(v);
+  v += dpp_f32<0x141>(v);
+  v += dpp_f32<0x140>(v);
+  const int b = __float_as_int(v);     // (v_readlane moves 32-bit patterns: the builtin is typed int)
+  return (__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16))) +
+         (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
 }
 
 // one workgroup per (cloud, chunk of CS channels); rows r = s*K + k across the lanes (coalesced idx reads / y writes)
@@ -140,6 +148,23 @@ __global__ __launch_bounds__(kThreads) void sa_l1_bwd_kernel(L1BwdArgs a) {
   const int *idx = a.idx + b * L;
   const float *g = a.g + (b * c1 + c0) * L, *y = a.y + (b * c1 + c0) * L;
   float w0 = 0.f, w1 = 0.f, w2 = 0.f, wb = 0.f;
+  // the tile's (channel, row) elements of this thread: e = tid + u * 256, u < NE; the NEXT tile's g / y are fetched into
+  // registers before the current tile is scanned, so the global round trip hides behind the scan
+  constexpr int NE = (CS * TR + kThreads - 1) / kThreads;
+  float pg[NE], py[NE];
+  auto fetch = [&](int t0) {
+    const int nr = L - t0 < TR ? L - t0 : TR;
+#pragma unroll
+    for (int u = 0; u < NE; u++) {
+      const int e = tid + u * kThreads;
+      const int c = e / TR, rr = e - c * TR;
+      const bool ok = e < CS * TR && rr < nr && c0 + c < c1;
+      const size_t o = ok ? (size_t)c * L + t0 + rr : 0;
+      pg[u] = g[o];
+      py[u] = y[o];
+    }
+  };
+  if (L > 0) fetch(0);
   __syncthreads();
   for (int t0 = 0; t0 < L; t0 += TR) {
     const int nr = L - t0 < TR ? L - t0 : TR;
@@ -151,16 +176,16 @@ __global__ __launch_bounds__(kThreads) void sa_l1_bwd_kernel(L1BwdArgs a) {
       dxt[3 * tid + 1] = xl[3 * i + 1] - xl[3 * s + 1];
       dxt[3 * tid + 2] = xl[3 * i + 2] - xl[3 * s + 2];
     }
-    for (int e = tid; e < CS * TR; e += kThreads) {
+#pragma unroll
+    for (int u = 0; u < NE; u++) {
+      const int e = tid + u * kThreads;
       const int c = e / TR, rr = e - c * TR;
       float v = 0.f;
-      if (rr < nr && c0 + c < c1) {
-        const size_t o = (size_t)c * L + t0 + rr;
-        v = a.ka[c0 + c] * g[o] + a.kb[c0 + c] * y[o] + a.kc[c0 + c];
-      }
-      dyt[c * (TR + 1) + rr] = v;
+      if (rr < nr && c0 + c < c1) v = a.ka[c0 + c] * pg[u] + a.kb[c0 + c] * py[u] + a.kc[c0 + c];
+      if (e < CS * TR) dyt[c * (TR + 1) + rr] = v;
     }
     __syncthreads();
+    if (t0 + TR < L) fetch(t0 + TR);
     if (live) {
       const float *row = dyt + cl * (TR + 1);
       for (int rr = 0; rr < nr; rr++) {

@@ -36,7 +36,7 @@ class _TBwd(ctypes.Structure):
                 ("ka", c_fp), ("kb", c_fp), ("kc", c_fp), ("argmax", c_fp), ("pooled", c_fp),
                 ("K", ctypes.c_int), ("S", ctypes.c_int), ("x", c_fp), ("x2", c_fp),
                 ("isc", c_fp), ("ish", c_fp), ("iinv", c_fp), ("in_relu", ctypes.c_int), ("wpT", c_fp),
-                ("dx", c_fp), ("dx2", c_fp), ("dstats", c_fp), ("dwp", c_fp), ("dbp", c_fp)]
+                ("dx", c_fp), ("dx2", c_fp), ("dstats", c_fp), ("dwp", c_fp), ("dbp", c_fp), ("part_stride", ctypes.c_long)]
 
 
 class _BnFwd(ctypes.Structure):
@@ -77,6 +77,17 @@ def pack_dev(w, transpose=False):
     L.check(L.load().pcr_pack_weight_dev_f32(L.ptr(w), rows, cols, cols, int(transpose), L.ptr(out), L.stream_ptr()),
             "pcr_pack_weight_dev_f32")
     return out
+
+
+def pack_both(w):
+    """-> (image of W, image of W^T) from ONE launch (forward and backward operands of a layer)"""
+    w = _dev(w.detach())
+    rows, cols = w.shape
+    n0, n1 = _c8(cols) * _c32(rows), _c8(rows) * _c32(cols)
+    out = _f32(n0 + n1, device=w.device)
+    L.check(L.load().pcr_pack_weight_dev_f32(L.ptr(w), rows, cols, cols, 2, L.ptr(out), L.stream_ptr()),
+            "pcr_pack_weight_dev_f32")
+    return out[:n0], out[n0:]
 
 
 def pad32(v, n):
@@ -147,13 +158,15 @@ def tdense_bwd(g, x, cout, dy_mode=0, y=None, k=None, argmax=None, pooled=None, 
             p.dstats = _p(out["dstats"])
     coutP, cinP = _c32(cout), _c32(cin)
     if want_dw:
-        dwp = _f32(nwg, coutP, cinP, device=dev)
-        dbp = _f32(nwg, coutP, device=dev)
-        p.dwp, p.dbp = _p(dwp), _p(dbp)
+        # per workgroup: the dW image (coutP x cinP) followed by db (coutP); ONE reduction over both
+        per = coutP * cinP + coutP
+        parts = _f32(nwg, per, device=dev)
+        p.dwp, p.dbp, p.part_stride = _p(parts), parts.data_ptr() + 4 * coutP * cinP, per
     L.check(L.load().pcr_tdense_bwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_tdense_bwd_f32")
     if want_dw:
-        out["dW"] = reduce_parts(dwp, nwg, coutP * cinP, cout, cin, cinP)
-        out["db"] = reduce_parts(dbp, nwg, coutP, 1, cout, coutP).view(cout)
+        flat = reduce_parts(parts, nwg, per, 1, per, per).view(per)
+        out["dW"] = flat[:coutP * cinP].view(coutP, cinP)[:cout, :cin]
+        out["db"] = flat[coutP * cinP:coutP * cinP + cout]
     return out
 
 
@@ -190,19 +203,23 @@ class TDense(Function):
     def forward(ctx, x, x2, W, bias, res, out_relu):
         assert not (out_relu and res is not None)
         cout = W.shape[0]
-        y, _ = tdense_fwd(x, pack_dev(W), cout, x2=x2, bias=bias, res=res, out_relu=out_relu)
-        ctx.save_for_backward(x, x2, W, y if out_relu else None)
+        need_dx = x.requires_grad or (x2 is not None and x2.requires_grad)
+        wp, wpT = pack_both(W) if need_dx else (pack_dev(W), None)
+        y, _ = tdense_fwd(x, wp, cout, x2=x2, bias=bias, res=res, out_relu=out_relu)
+        ctx.save_for_backward(x, x2, W, y if out_relu else None, wpT)
         ctx.meta = (out_relu, bias is not None, res is not None)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, x2, W, y = ctx.saved_tensors
+        x, x2, W, y, wpT = ctx.saved_tensors
         out_relu, has_bias, has_res = ctx.meta
         g = g.contiguous()
         need_dx = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
+        if need_dx and wpT is None:
+            wpT = pack_dev(W, transpose=True)
         r = tdense_bwd(g, x, W.shape[0], dy_mode=2 if out_relu else 0, y=y, x2=x2,
-                       wpT=pack_dev(W, transpose=True) if need_dx else None,
+                       wpT=wpT if need_dx else None,
                        want_dw=ctx.needs_input_grad[2] or (has_bias and ctx.needs_input_grad[3]))
         return (r.get("dx"), r.get("dx2"), r.get("dW"), r.get("db") if has_bias else None,
                 g if has_res else None, None)
@@ -392,7 +409,7 @@ class TNorm(Function):
         g = g.contiguous()
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if (has_res and y is not None) else None
-        nparts = B * ((Ln + 255) // 256)
+        nparts = ((B * Ln + 255) // 256) * 4        # one partial row per 64-token wave
         part = _f32(nparts, 2, C, device=x.device)
         L.check(L.load().pcr_tnorm_bwd_f32(L.ptr(g), L.ptr(x), L.ptr(gamma.detach()), L.ptr(mean), L.ptr(rstd), L.ptr(y),
                                            L.ptr(dx), L.ptr(dres), L.ptr(part), B, C, Ln, G, L.stream_ptr()),
