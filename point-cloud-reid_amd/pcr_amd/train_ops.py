@@ -12,6 +12,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib as L
+from .engine import _prof
 
 c_fp = ctypes.c_void_p
 
@@ -118,7 +119,10 @@ def tdense_fwd(x, wp, cout, x2=None, isc=None, ish=None, in_relu=False, bias=Non
     p.x, p.x2, p.isc, p.ish, p.in_relu = _p(x), _p(x2), _p(isc), _p(ish), int(in_relu)
     p.wp, p.bias, p.res, p.out_relu = _p(wp), _p(pad32(bias, cout)), _p(res), int(out_relu)
     p.y, p.stats = _p(y), _p(stats)
-    L.check(L.load().pcr_tdense_fwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_tdense_fwd_f32")
+    cin = cin1 + cin2
+    with _prof("tdense_fwd[cin=%d,cout=%d,L=%d]" % (cin, cout, Ln), 2.0 * B * Ln * cin * cout,
+               4.0 * B * Ln * (cin + cout * (2 if res is not None else 1))):
+        L.check(L.load().pcr_tdense_fwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_tdense_fwd_f32")
     return y, stats
 
 
@@ -162,7 +166,13 @@ def tdense_bwd(g, x, cout, dy_mode=0, y=None, k=None, argmax=None, pooled=None, 
         per = coutP * cinP + coutP
         parts = _f32(nwg, per, device=dev)
         p.dwp, p.dbp, p.part_stride = _p(parts), parts.data_ptr() + 4 * coutP * cinP, per
-    L.check(L.load().pcr_tdense_bwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_tdense_bwd_f32")
+    # algorithmic work: dW = dy f(x)^T and dx = W^T dy (2 B L cout cin flops each); bytes: read g (or the small pooled
+    # tensors in mode 3), y (BatchNorm / ReLU modes), x; write dx
+    flops = 2.0 * B * Ln * cout * cin * ((1 if want_dw else 0) + (1 if wpT is not None else 0))
+    nbytes = 4.0 * B * Ln * ((cout if dy_mode != 3 else 0) + (cout if dy_mode != 0 else 0) + cin +
+                             (cin if wpT is not None else 0))
+    with _prof("tdense_bwd[mode=%d,cin=%d,cout=%d,L=%d]" % (dy_mode, cin, cout, Ln), flops, nbytes):
+        L.check(L.load().pcr_tdense_bwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_tdense_bwd_f32")
     if want_dw:
         flat = reduce_parts(parts, nwg, per, 1, per, per).view(per)
         out["dW"] = flat[:coutP * cinP].view(coutP, cinP)[:cout, :cin]
@@ -249,8 +259,9 @@ class SaEdgeTrain(Function):
         tab = None if tab is None else _dev(tab)
         y1 = _f32(B, c1, Ln, device=dev)
         st1 = _f32(B, 2, _c32(c1), device=dev)
-        L.check(lib.pcr_sa_l1_fwd_f32(L.ptr(xyz), L.ptr(idx), L.ptr(tab), L.ptr(_dev(wa.detach())), L.ptr(b1.detach()),
-                                      L.ptr(y1), L.ptr(st1), B, N, S, K, c1, L.stream_ptr()), "pcr_sa_l1_fwd_f32")
+        with _prof("sa_l1_fwd[c1=%d,N=%d,S=%d,K=%d]" % (c1, N, S, K), 8.0 * B * Ln * c1, 4.0 * B * (Ln * (c1 + 1) + 2 * c1 * N)):
+            L.check(lib.pcr_sa_l1_fwd_f32(L.ptr(xyz), L.ptr(idx), L.ptr(tab), L.ptr(_dev(wa.detach())), L.ptr(b1.detach()),
+                                          L.ptr(y1), L.ptr(st1), B, N, S, K, c1, L.stream_ptr()), "pcr_sa_l1_fwd_f32")
 
         def fin(st, nparts, C, gamma, beta, bn):
             o = bn_fwd_finalize(st, nparts, C, R, gamma, beta, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
@@ -266,8 +277,9 @@ class SaEdgeTrain(Function):
         n3 = fin(st3, st3.shape[0], c3, g3, be3, bns[2])
         pooled = _f32(B, c3, S, device=dev)
         argmax = torch.empty((B, c3, S), dtype=torch.int32, device=dev)
-        L.check(lib.pcr_sa_pool_fwd_f32(L.ptr(y3), L.ptr(n3["scale"]), L.ptr(n3["shift"]), L.ptr(pooled), L.ptr(argmax),
-                                        B, c3, S, K, L.stream_ptr()), "pcr_sa_pool_fwd_f32")
+        with _prof("sa_pool_fwd[c=%d,S=%d,K=%d]" % (c3, S, K), 2.0 * B * Ln * c3, 4.0 * B * c3 * (Ln + 2 * S)):
+            L.check(lib.pcr_sa_pool_fwd_f32(L.ptr(y3), L.ptr(n3["scale"]), L.ptr(n3["shift"]), L.ptr(pooled), L.ptr(argmax),
+                                            B, c3, S, K, L.stream_ptr()), "pcr_sa_pool_fwd_f32")
         ctx.save_for_backward(xyz, idx, y1, y2, y3, pooled, argmax, w2, w3, g1, g2, g3)
         ctx.norms = (n1, n2, n3)
         ctx.has_tab = tab is not None
@@ -296,9 +308,10 @@ class SaEdgeTrain(Function):
         k1 = bn_bwd_finalize(r2["dstats"], r2["dstats"].shape[0], c1, R, g1, n1["mean"], n1["invstd"])
         dtab = _f32(B, 2 * c1, N, device=dev) if ctx.has_tab else None
         dwa_p = _f32(B, c1, 4, device=dev)
-        L.check(lib.pcr_sa_l1_bwd_f32(L.ptr(xyz), L.ptr(idx), L.ptr(r2["dx"]), L.ptr(y1), L.ptr(k1["ka"]), L.ptr(k1["kb"]),
-                                      L.ptr(k1["kc"]), L.ptr(dtab), L.ptr(dwa_p), B, N, S, K, c1, L.stream_ptr()),
-                "pcr_sa_l1_bwd_f32")
+        with _prof("sa_l1_bwd[c1=%d,N=%d,S=%d,K=%d]" % (c1, N, S, K), 10.0 * B * Ln * c1, 4.0 * B * (Ln * (2 * c1 + 1) + 2 * c1 * N)):
+            L.check(lib.pcr_sa_l1_bwd_f32(L.ptr(xyz), L.ptr(idx), L.ptr(r2["dx"]), L.ptr(y1), L.ptr(k1["ka"]), L.ptr(k1["kb"]),
+                                          L.ptr(k1["kc"]), L.ptr(dtab), L.ptr(dwa_p), B, N, S, K, c1, L.stream_ptr()),
+                    "pcr_sa_l1_bwd_f32")
         dwa4 = reduce_parts(dwa_p, B, c1 * 4, c1, 4, 4)
         return (None, None, dtab, dwa4[:, :3].contiguous(), dwa4[:, 3].contiguous(), k1["dgamma"], k1["dbeta"],
                 r2["dW"], r2["db"], k2["dgamma"], k2["dbeta"], r3["dW"], r3["db"], k3["dgamma"], k3["dbeta"], None)

@@ -153,8 +153,8 @@ def test_forward_test_api_and_decisions():
 
 
 def test_train_step_matches_reference_loss_and_grads():
-    """ReIDNet.train_step in training mode (HIP kNN + HIP grouping fwd/bwd + torch autograd for the dense
-    math, pcr_amd/train_graph.py) against loss and gradients recorded from the reference's own train_step"""
+    """ReIDNet.train_step in training mode (every forward / backward node a HIP launch: pcr_amd/train_graph.py,
+    train_ops.py) against loss and gradients recorded from the reference's own train_step"""
     g = load_golden("pt_train_step_n128")
     m, _ = build_pt([128, 64, 32])
     m.train()
@@ -172,14 +172,21 @@ def test_train_step_matches_reference_loss_and_grads():
     assert abs(out["log_vars"]["match_acc"] - float(g["match_acc"])) < 1e-6
     out["loss"].backward()
     params = dict(m.named_parameters())
+    worst = {}
     for k in g:
         if k.startswith("grad:"):
             got = params[k[5:]].grad.cpu().numpy()
             scale = max(1e-3, float(np.abs(g[k]).max()))
-            # gradients that reach the encoder pass through max-over-K / ReLU routing and BatchNorm batch
-            # statistics, which amplify fp32 summation-order noise (observed 0.5 % of the tensor's scale)
-            rel = 2e-2 if "SA_modules" in k else 2e-3
-            assert np.abs(got - g[k]).max() < rel * scale, (k, np.abs(got - g[k]).max(), scale)
+            worst[k[5:]] = float(np.abs(got - g[k]).max()) / scale
+    print(json.dumps(worst))
+    # Against the REFERENCE's own backward (CPU): match head, cross attention, cov_final and the SA attention projection
+    # agree to ~6e-7 of the tensor's scale (bound used: 1e-5).  The first SA conv's gradient passes through three
+    # BatchNorm layers in batch-statistics mode and the max-over-K routing, where a near-tie between two rows of a group
+    # resolved differently by the two summation orders moves a whole gradient row: observed 4.5e-3 of the scale here and
+    # 5e-3 with torch's own GPU autograd on the same graph (round 1), i.e. a property of the comparison, not of the
+    # kernels -- tests/test_gpu_train_ops.py pins the same layer to 2e-4 against torch autograd on identical indices.
+    for k, v in worst.items():
+        assert v < (1e-2 if k == "backbone.SA_modules.0.mlp_convs.0.weight" else 1e-5), worst
     no_grad = sorted(k for k, p in params.items() if p.grad is None)
     assert no_grad == sorted(json.loads(str(g["no_grad_params"])))      # the 24 never-used FP tensors
 
