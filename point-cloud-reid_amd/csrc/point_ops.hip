@@ -646,8 +646,8 @@ __global__ void gather_fwd_kernel(const float *__restrict__ feat, const int *__r
   }
 }
 
-// Scatter-add, float atomics as in gather_points_cuda.cu:69 / group_points_cuda.cu:30 (the
-// summation order is unspecified there too).  M here is the flattened S*K for grouping.
+// Scatter-add for clouds too large for the owner-computes kernel below (N > 16384): float atomics as in
+// gather_points_cuda.cu:69 / group_points_cuda.cu:30 (the summation order is unspecified there too).
 __global__ void gather_bwd_kernel(const float *__restrict__ grad_out, const int *__restrict__ idx,
                                   float *__restrict__ grad_feat, int C, int N, int M,
                                   size_t total) {
@@ -660,6 +660,84 @@ __global__ void gather_bwd_kernel(const float *__restrict__ grad_out, const int 
   }
 }
 
+// Deterministic scatter-add (the backward of gather / group / three_interpolate): grad_feat[b][c][idx[b][e]] +=
+// src[b][c][e / DIV] * w[b][e] for e < M.  One workgroup per (cloud, chunk of CS channels); the chunk's accumulators
+// [CS][N] live in LDS and every (channel, point) accumulator has ONE owner thread -- (cl = tid % CS, part = tid / CS)
+// owns the points congruent to `part` -- that adds its entries in increasing e: no atomics, the same bits every run.
+template <int CS>
+__global__ __launch_bounds__(256) void scatter_owner_kernel(const float *__restrict__ src, const int *__restrict__ idx,
+                                                            const float *__restrict__ w, float *__restrict__ grad_feat,
+                                                            int C, int N, int M, int DIV) {
+  constexpr int PARTS = 256 / CS, TR = 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int NP = N | 1;
+  float *acc = smem;                 // [CS][NP]
+  float *st = acc + CS * NP;         // [CS][TR + 1]
+  float *wt = st + CS * (TR + 1);    // [TR]
+  int *it = reinterpret_cast<int *>(wt + TR);
+  const int tid = threadIdx.x, cl = tid % CS, part = tid / CS;
+  const size_t b = blockIdx.y;
+  const int c0 = blockIdx.x * CS;
+  const int Msrc = M / DIV;
+  for (int e = tid; e < CS * NP; e += 256) acc[e] = 0.f;
+  __syncthreads();
+  for (int e0 = 0; e0 < M; e0 += TR) {
+    const int nr = M - e0 < TR ? M - e0 : TR;
+    if (tid < nr) {
+      it[tid] = idx[b * M + e0 + tid];
+      wt[tid] = w ? w[b * M + e0 + tid] : 1.0f;
+    }
+    for (int e = tid; e < CS * TR; e += 256) {
+      const int c = e / TR, rr = e - c * TR;
+      st[c * (TR + 1) + rr] = (rr < nr && c0 + c < C) ? src[(b * C + c0 + c) * Msrc + (e0 + rr) / DIV] : 0.f;
+    }
+    __syncthreads();
+    if (c0 + cl < C) {
+      const float *row = st + cl * (TR + 1);
+      for (int rr = 0; rr < nr; rr++) {
+        const int i = it[rr];
+        if ((i % PARTS) == part) acc[cl * NP + i] += row[rr] * wt[rr];
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < CS * N; e += 256) {
+    const int c = e / N, i = e - c * N;
+    if (c0 + c < C) grad_feat[(b * C + c0 + c) * N + i] += acc[c * NP + i];
+  }
+}
+
+// -> false when the cloud is too large for the LDS accumulators (caller falls back to the atomic kernel)
+static bool scatter_owner_launch(const float *src, const int *idx, const float *w, float *grad_feat, int B, int C, int N,
+                                 int M, int DIV, hipStream_t st) {
+  int cs = 32;
+  while (cs > 1 && (size_t)cs * (N | 1) * 4 > 64 * 1024) cs >>= 1;
+  if ((size_t)cs * (N | 1) * 4 > 96 * 1024 || B > 65535) return false;
+  if (cs > C) {
+    cs = 1;
+    while (cs * 2 <= C) cs *= 2;
+  }
+  const size_t lds = ((size_t)cs * (N | 1) + (size_t)cs * 65 + 64 + 64) * sizeof(float);
+  const dim3 grid((C + cs - 1) / cs, B);
+#define PCR_SC(CSv)                                                                                              \
+  do {                                                                                                           \
+    static bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_owner_kernel<CSv>),              \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;  \
+    (void)ok;                                                                                                    \
+    hipLaunchKernelGGL(scatter_owner_kernel<CSv>, grid, dim3(256), lds, st, src, idx, w, grad_feat, C, N, M, DIV); \
+  } while (0)
+  switch (cs) {
+    case 32: PCR_SC(32); break;
+    case 16: PCR_SC(16); break;
+    case 8: PCR_SC(8); break;
+    case 4: PCR_SC(4); break;
+    case 2: PCR_SC(2); break;
+    default: PCR_SC(1); break;
+  }
+#undef PCR_SC
+  return true;
+}
+
 int gather_launch(bool bwd, const float *a, const int *idx, float *o, int B, int C, int N, int M,
                   hipStream_t st) {
   if (!a || !idx || !o || B < 0 || C < 0 || N < 1 || M < 0) return PCR_ERR_INVALID;
@@ -667,8 +745,10 @@ int gather_launch(bool bwd, const float *a, const int *idx, float *o, int B, int
   if (total == 0) return PCR_OK;
   size_t blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  if (bwd) hipLaunchKernelGGL(gather_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, idx, o, C, N, M, total);
-  else hipLaunchKernelGGL(gather_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, idx, o, C, N, M, total);
+  if (bwd) {
+    if (!scatter_owner_launch(a, idx, nullptr, o, B, C, N, M, 1, st))
+      hipLaunchKernelGGL(gather_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, idx, o, C, N, M, total);
+  } else hipLaunchKernelGGL(gather_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, idx, o, C, N, M, total);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }
@@ -1170,8 +1250,11 @@ PCR_EXPORT int pcr_three_interp_bwd_f32(const float *grad_out, const int *idx, c
   if (total == 0) return PCR_OK;
   size_t blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(three_interp_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, pcr_s(stream),
-                     grad_out, idx, weight, grad_feat, C, N, M, total);
+  // entries e = 3 n + j scatter grad_out[n] * weight[n][j] to idx[n][j]: owner-computes (deterministic) when the
+  // accumulators fit LDS, the atomic kernel otherwise
+  if (!scatter_owner_launch(grad_out, idx, weight, grad_feat, B, C, M, 3 * N, 3, pcr_s(stream)))
+    hipLaunchKernelGGL(three_interp_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, pcr_s(stream),
+                       grad_out, idx, weight, grad_feat, C, N, M, total);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }
