@@ -330,8 +330,43 @@ def gen_eval_metric():
     print("eval metric", float(acc), f1)
 
 
+def gen_eval_tables():
+    """MatchingEval.evaluate_points / evaluate_distance / eval_per_visibility (datasets/utils.py:280-533) of the imported
+    reference on a seeded sample: every table entry, flattened to 'family/key/metric' -> value"""
+    g = np.random.default_rng(9)
+    n = 200
+    logits = torch.from_numpy(g.standard_normal(n).astype(np.float32))
+    gt = torch.from_numpy((g.uniform(size=n) > 0.5).astype(np.float32))
+    num_points = torch.from_numpy(g.integers(1, 700, (n, 2)))
+    vis = torch.from_numpy(g.integers(0, 4, (n, 2)))
+    dist = torch.from_numpy(g.integers(0, 60, (n, 2)))
+    gt_fp = gt.clone()
+    gt_fp[::17] = -1            # false-positive pairs are excluded from the visibility tables
+    me = ref_loader.load_dataset_utils().MatchingEval()
+
+    def flat(t):
+        out = {}
+        for fam, rows in t.items():
+            for key, entry in rows.items():
+                for m, v in entry.items():
+                    out["%s/%s/%s" % (fam, key, m)] = float(v)
+        return out
+    rec = dict(logits=logits.numpy(), gt=gt.numpy(), gt_fp=gt_fp.numpy(), num_points=num_points.numpy(), vis=vis.numpy(),
+               dist=dist.numpy())
+    for name, t in (("points", me.evaluate_points(logits, gt, num_points)), ("distance", me.evaluate_distance(logits, gt, dist)),
+                    ("visibility", me.eval_per_visibility(logits, gt_fp, vis))):
+        f = flat(t)
+        rec[name + "_keys"] = np.array(json.dumps(sorted(f)))
+        rec[name + "_vals"] = np.array([f[k] for k in sorted(f)], dtype=np.float64)
+        print("tables", name, len(f))
+    np.savez_compressed(os.path.join(GOLD, "eval_tables.npz"), **rec)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    if "--only-tables" in sys.argv:
+        gen_eval_tables()
+        sys.exit(0)
     torch.set_num_threads(8)
     if "--only-metric" in sys.argv:
         gen_eval_metric()
@@ -358,3 +393,4 @@ if __name__ == "__main__":
     gen_train_step()
     gen_python_twins()
     gen_eval_metric()
+    gen_eval_tables()

@@ -133,3 +133,27 @@ def test_eval_metric_fixture():
            dict(val_match_preds=logits[40:], val_match_gt=gt[40:], num_points=torch.randint(1, 300, (24, 2)), skip=None)]
     out = metrics.evaluate(res)
     assert abs(out["val_match_acc"] - float(g["val_match_acc"])) < 1e-7 and "val_match_acc_both_ge_1_pts" in out
+
+
+def test_eval_tables_match_reference_fixture():
+    """pcr_amd.metrics.evaluate_points / evaluate_distance / eval_per_visibility: every entry of the three tables
+    against the values the imported reference's MatchingEval produced (tests/golden/eval_tables.npz)"""
+    import json
+    from pcr_amd import metrics
+    g = load_golden("eval_tables")
+    logits, gt, gt_fp = (torch.from_numpy(g[k]) for k in ("logits", "gt", "gt_fp"))
+    got = {"points": metrics.evaluate_points(logits, gt, torch.from_numpy(g["num_points"])),
+           "distance": metrics.evaluate_distance(logits, gt, torch.from_numpy(g["dist"])),
+           "visibility": metrics.eval_per_visibility(logits, gt_fp, torch.from_numpy(g["vis"]))}
+    for name, tables in got.items():
+        flat = metrics.flatten_tables(tables)
+        keys = json.loads(str(g[name + "_keys"]))
+        assert sorted(flat) == keys, name
+        want = g[name + "_vals"]
+        for k, w in zip(keys, want):
+            v = float(flat[k])
+            assert (v != v and w != w) or abs(v - w) < 1e-6, (name, k, v, w)
+    res = [dict(val_match_preds=logits, val_match_gt=gt, num_points=torch.from_numpy(g["num_points"]),
+                val_vis_gt_all=torch.from_numpy(g["vis"]))]
+    t = metrics.evaluate_tables(res)
+    assert set(t) == {"results_per_points", "results_per_distance", "results_per_visibility"}
