@@ -60,6 +60,26 @@ def test_reference_configs_load_unchanged_and_build():
     assert cfg.model.match_type == "xcorr" and cfg.model.local_stage1.type == "local_self_attention"
     model = build_model(cfg.model)
     assert T.manifest_of(model) == T.load_manifest(os.path.join(GOLDEN, "pt_xcorr_manifest.json"))
+    # the wide Point-Transformers (mul = 2 / 4) and the baseline (match_type 'concat', pool_type 'max') configs
+    # (the reference's own testing_pts_{1.5M,7M}_* files name a base file that does not exist in its tree --
+    # reid_1.5M_point-transformer-point-cat-lin-xcorr_fp.py -- so the reidentifier files they mean are loaded directly)
+    for cfg_file, man in (("_base_/reidentifiers/reid_pts_point-transformer-1.5M_point-cat.py", "pt15m"),
+                          ("_base_/reidentifiers/reid_pts_point-transformer-7M_point-cat.py", "pt7m")):
+        cfg = Config.fromfile(os.path.join(REF, cfg_file))
+        with pytest.raises(FileNotFoundError):
+            Config.fromfile(os.path.join(REF, "reid_waymo_pts/testing_pts_1.5M_point-transformer_r_waymo_det_800e.py"))
+        assert cfg.model.backbone.mul in (2, 4)
+        model = build_model(cfg.model)
+        assert T.manifest_of(model) == T.load_manifest(os.path.join(GOLDEN, man + "_manifest.json")), cfg_file
+    cfg = Config.fromfile(os.path.join(REF, "reid_nuscenes_pts/testing_pts_point-transformer_baseline_r_nus_det_500e.py"))
+    assert cfg.model.match_type == "concat" and cfg.model.pool_type == "max"
+    model = build_model(cfg.model)              # (incl. the config's 105 M-parameter shape_head, never evaluated)
+    man = [m for m in T.manifest_of(model) if not m[0].startswith("shape_head.")]
+    assert man == T.load_manifest(os.path.join(GOLDEN, "pt_baseline_manifest.json"))
+    del model
+    cfg = Config.fromfile(os.path.join(REF, "reid_nuscenes_pts/testing_pts_point-transformer_baseline-stnet_r_nus_det_500e.py"))
+    assert cfg.model.match_type == "xcorr-baseline"
+    build_model(cfg.model)
     # every point-cloud ReID config of the reference parses
     n, broken = 0, []
     for sub in ("reid_nuscenes_pts", "reid_waymo_pts"):
