@@ -54,14 +54,7 @@ __device__ __forceinline__ void select_k(uint32_t (&d)[T], int lane, int K, unsi
   for (int t = 0; t < T; t++) m = d[t] < m ? d[t] : m;
   // 1. the lane whose (truncated, lane-tagged) minimum has rank K-1 gives a threshold with >= K keys under it
   const uint32_t mkey = (m & ~63u) | (uint32_t)lane;
-  int rank = 0;
-#pragma unroll 8
-  for (int j = 0; j < 64; j++) {
-    const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)mkey, j);
-    rank += kj < mkey ? 1 : 0;
-  }
-  const unsigned long long hit = __ballot(rank == K - 1);
-  const uint32_t tau = (uint32_t)__builtin_amdgcn_readlane((int)mkey, (int)__builtin_ctzll(hit)) | 63u;
+  const uint32_t tau = (uint32_t)__builtin_amdgcn_readlane((int)pcr_wave_sort_u32(mkey, lane), K - 1) | 63u;   // (pcr_common.h)
   // 2. candidates d <= tau, compacted in index order
   int cnt = 0;
 #pragma unroll
@@ -81,16 +74,8 @@ __device__ __forceinline__ void select_k(uint32_t (&d)[T], int lane, int K, unsi
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (total <= 64) {
-      const unsigned long long own = lane < total ? cand[lane] : ~0ull;
-      const uint32_t ohi = (uint32_t)(own >> 32), olo = (uint32_t)own;
-      int rk = 0;
-      for (int j = 0; j < total; j++) {
-        const uint32_t jhi = (uint32_t)__builtin_amdgcn_readlane((int)ohi, j);
-        const uint32_t jlo = (uint32_t)__builtin_amdgcn_readlane((int)olo, j);
-        const unsigned long long cj = ((unsigned long long)jhi << 32) | jlo;
-        rk += cj < own ? 1 : 0;
-      }
-      if (lane < total && rk < K) out[rk] = (int)olo;
+      const unsigned long long own = pcr_wave_sort_u64(lane < total ? cand[lane] : ~0ull, lane);
+      if (lane < K) out[lane] = (int)(uint32_t)own;
     } else {
       unsigned long long own[kSelCap / 64];
       int rk[kSelCap / 64];

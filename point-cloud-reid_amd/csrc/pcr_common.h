@@ -51,3 +51,75 @@ __device__ __forceinline__ unsigned long long pcr_wave_min_u64(unsigned long lon
   }
   return k;
 }
+
+// ---- sorting network over the 64 lanes of a wave (bitonic, 21 compare-exchange steps) -------------------------
+// Used where a wave ranks <= 64 keys (kNN selection): a rank count over v_readlane broadcasts costs 64 x 3
+// instructions for 32-bit keys and ~64 x 7 for 64-bit keys; the network costs 21 x (exchange + compare + select).
+// Exchanges: xor 1 / 2 and the mirrors inside 4 / 8 / 16 lanes are DPP modifiers (no extra instruction latency),
+// xor 4 / 8 / 16 and the mirror inside 32 lanes are ds_swizzle bit-mode patterns, the one cross-half step uses
+// gfx950's v_permlane32_swap.  Step (K, 0) "flips" a sorted block of K/2 against its mirror neighbour, steps (K, J)
+// are the xor-J merges below it; after the (64, *) group the keys ascend with the lane index.
+template <int CTRL>
+__device__ __forceinline__ uint32_t pcr_dpp_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+
+__device__ __forceinline__ uint32_t pcr_lane_xor32(uint32_t v, bool upper_half) {
+  const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // {lanes 0..31 twice, lanes 32..63 twice}
+  return upper_half ? r[0] : r[1];
+}
+
+template <int K, int J>
+__device__ __forceinline__ uint32_t pcr_sort_partner(uint32_t v, int lane) {
+  if constexpr (J == 0) {
+    if constexpr (K == 2) return pcr_dpp_u32<0xB1>(v);                 // quad_perm [1,0,3,2]
+    else if constexpr (K == 4) return pcr_dpp_u32<0x1B>(v);            // quad_perm [3,2,1,0]
+    else if constexpr (K == 8) return pcr_dpp_u32<0x141>(v);           // row_half_mirror
+    else if constexpr (K == 16) return pcr_dpp_u32<0x140>(v);          // row_mirror
+    else if constexpr (K == 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x7C1F);   // xor 31
+    else return pcr_lane_xor32((uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x7C1F), lane >= 32);   // xor 63
+  } else {
+    if constexpr (J == 1) return pcr_dpp_u32<0xB1>(v);
+    else if constexpr (J == 2) return pcr_dpp_u32<0x4E>(v);            // quad_perm [2,3,0,1]
+    else if constexpr (J == 4) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);
+    else if constexpr (J == 8) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x201F);
+    else return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);
+  }
+}
+
+#define PCR_SORT_NETWORK(STEP)                                                                      \
+  STEP(2, 0, 1)                                                                                     \
+  STEP(4, 0, 2) STEP(4, 1, 1)                                                                       \
+  STEP(8, 0, 4) STEP(8, 2, 2) STEP(8, 1, 1)                                                         \
+  STEP(16, 0, 8) STEP(16, 4, 4) STEP(16, 2, 2) STEP(16, 1, 1)                                       \
+  STEP(32, 0, 16) STEP(32, 8, 8) STEP(32, 4, 4) STEP(32, 2, 2) STEP(32, 1, 1)                       \
+  STEP(64, 0, 32) STEP(64, 16, 16) STEP(64, 8, 8) STEP(64, 4, 4) STEP(64, 2, 2) STEP(64, 1, 1)
+
+// ascending over the lanes; the lower lane of a pair keeps the smaller key
+__device__ __forceinline__ uint32_t pcr_wave_sort_u32(uint32_t v, int lane) {
+#define PCR_STEP32(K, J, BIT)                                   \
+  {                                                             \
+    const uint32_t o = pcr_sort_partner<K, J>(v, lane);         \
+    const bool up = (lane & BIT) != 0;                          \
+    v = ((o < v) != up) ? o : v;                                \
+  }
+  PCR_SORT_NETWORK(PCR_STEP32)
+#undef PCR_STEP32
+  return v;
+}
+
+__device__ __forceinline__ unsigned long long pcr_wave_sort_u64(unsigned long long key, int lane) {
+  uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
+#define PCR_STEP64(K, J, BIT)                                                        \
+  {                                                                                  \
+    const uint32_t ohi = pcr_sort_partner<K, J>(hi, lane), olo = pcr_sort_partner<K, J>(lo, lane); \
+    const bool less = (((unsigned long long)ohi << 32) | olo) < (((unsigned long long)hi << 32) | lo); \
+    const bool up = (lane & BIT) != 0;                                               \
+    const bool take = less != up;                                                    \
+    hi = take ? ohi : hi;                                                            \
+    lo = take ? olo : lo;                                                            \
+  }
+  PCR_SORT_NETWORK(PCR_STEP64)
+#undef PCR_STEP64
+  return ((unsigned long long)hi << 32) | lo;
+}

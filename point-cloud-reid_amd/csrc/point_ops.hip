@@ -906,16 +906,9 @@ __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_reg_kernel(const floa
       const uint32_t m01 = d[2 * t] < d[2 * t + 1] ? d[2 * t] : d[2 * t + 1];
       m = m01 < m ? m01 : m;
     }
-    // 1. the lane whose (truncated, lane-tagged) minimum has rank K-1
+    // 1. the (truncated, lane-tagged) lane minimum of rank K-1: sort the 64 keys across the lanes (21-step network)
     const uint32_t mkey = (m & ~63u) | (uint32_t)lane;
-    int rank = 0;
-#pragma unroll 8
-    for (int j = 0; j < 64; j++) {
-      const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)mkey, j);
-      rank += kj < mkey ? 1 : 0;
-    }
-    const unsigned long long hit = __ballot(rank == K - 1);    // exactly one lane: the keys are distinct
-    const uint32_t tau = (uint32_t)__builtin_amdgcn_readlane((int)mkey, (int)__builtin_ctzll(hit)) | 63u;
+    const uint32_t tau = (uint32_t)__builtin_amdgcn_readlane((int)pcr_wave_sort_u32(mkey, lane), K - 1) | 63u;
     // 2. candidates d <= tau
     int cnt = 0;
 #pragma unroll
@@ -936,17 +929,10 @@ __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_reg_kernel(const floa
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       if (total <= 64) {
-        // 3a. one candidate per lane, ranked over readlane broadcasts of the two key halves
-        const unsigned long long own = lane < total ? cand[lane] : ~0ull;
-        const uint32_t ohi = (uint32_t)(own >> 32), olo = (uint32_t)own;
-        int rk = 0;
-        for (int j = 0; j < total; j++) {
-          const uint32_t jhi = (uint32_t)__builtin_amdgcn_readlane((int)ohi, j);
-          const uint32_t jlo = (uint32_t)__builtin_amdgcn_readlane((int)olo, j);
-          const unsigned long long cj = ((unsigned long long)jhi << 32) | jlo;
-          rk += cj < own ? 1 : 0;
-        }
-        if (lane < total && rk < K) out[rk] = (int)olo;
+        // 3a. one candidate per lane: sort the exact 64-bit (distance, index) keys across the lanes; lanes < K hold
+        // the answer in order (K <= total: tau bounds the K-th smallest distance)
+        const unsigned long long own = pcr_wave_sort_u64(lane < total ? cand[lane] : ~0ull, lane);
+        if (lane < K) out[lane] = (int)(uint32_t)own;
       } else {
         // 3b. up to kKnnCap candidates: four per lane, broadcast LDS reads
         unsigned long long own[kKnnCap / 64];
@@ -1028,14 +1014,7 @@ __global__ __launch_bounds__(NT) void knn_prefix_lds_kernel(const float *__restr
       m = d < m ? d : m;
     }
     const uint32_t mkey = (m & ~63u) | (uint32_t)lane;
-    int rank = 0;
-#pragma unroll 8
-    for (int j = 0; j < 64; j++) {
-      const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)mkey, j);
-      rank += kj < mkey ? 1 : 0;
-    }
-    const unsigned long long hit = __ballot(rank == K - 1);
-    const uint32_t tau = (uint32_t)__builtin_amdgcn_readlane((int)mkey, (int)__builtin_ctzll(hit)) | 63u;
+    const uint32_t tau = (uint32_t)__builtin_amdgcn_readlane((int)pcr_wave_sort_u32(mkey, lane), K - 1) | 63u;
     int total = 0;
 #pragma unroll 4
     for (int t = 0; t < T; t++) {
@@ -1052,15 +1031,8 @@ __global__ __launch_bounds__(NT) void knn_prefix_lds_kernel(const float *__restr
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     int *out = idx + (b * S + q) * K;
     if (total <= 64) {
-      const unsigned long long own = lane < total ? cand[lane] : ~0ull;
-      const uint32_t ohi = (uint32_t)(own >> 32), olo = (uint32_t)own;
-      int rk = 0;
-      for (int j = 0; j < total; j++) {
-        const uint32_t jhi = (uint32_t)__builtin_amdgcn_readlane((int)ohi, j);
-        const uint32_t jlo = (uint32_t)__builtin_amdgcn_readlane((int)olo, j);
-        rk += (((unsigned long long)jhi << 32) | jlo) < own ? 1 : 0;
-      }
-      if (lane < total && rk < K) out[rk] = (int)olo;
+      const unsigned long long own = pcr_wave_sort_u64(lane < total ? cand[lane] : ~0ull, lane);
+      if (lane < K) out[lane] = (int)(uint32_t)own;
     } else if (total <= kKnnCap) {
       unsigned long long own[kKnnCap / 64];
       int rk[kKnnCap / 64];
