@@ -439,7 +439,7 @@ int pcr_sa_pool_bwd_stats_f32(const float *gp, const float *pooled, const int *a
 
 /* LayerNorm / GroupNorm over the channels of every token of x (B,C,L) (G groups of C/G consecutive channels; LayerNorm:
  * G = 1), y = [relu]((x - mean) rstd gamma + beta [+ res]); mean / rstd (B,G,L) are kept for the backward.  Backward: dx and
- * partials [ceil(B L / 256) * 4][2][C] (one row per 64-token wave) of (d gamma, d beta) for pcr_reduce_parts_f32.  csrc/train_attn_kernels.hip. */
+ * partials [ceil(B L / 64)][2][C] (one row per 64-token wave) of (d gamma, d beta) for pcr_reduce_parts_f32.  csrc/train_attn_kernels.hip. */
 int pcr_tnorm_fwd_f32(const float *x, const float *gamma, const float *beta, const float *res, float *y, float *mean,
                       float *rstd, int B, int C, int L, int G, float eps, int relu, pcr_stream_t stream);
 /* y_relu: the forward output when relu was set (the gradient is masked by y > 0 first), else NULL; dres (optional): the

@@ -158,8 +158,19 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
   float *sq = reinterpret_cast<float *>(scen + ROWS);     // [CPW][c1] per-centre Q rows + shift
   float *gmax = sdx;   // [c3][2*TB] (MAXE only): reuses the staging arrays, all dead once layer 1 is built
   const int tid = threadIdx.x;
-  const size_t b = blockIdx.y;
-  const int c0 = blockIdx.x * a.CPW;
+  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so the workgroups of
+  // ONE cloud -- which gather rows of the same table -- would pull that table into eight L2s.  Linear id w is remapped
+  // so that the ids an XCD receives (w % 8 == x) cover whole consecutive clouds (bijective for any grid size).
+  int bsw, xsw;
+  {
+    const unsigned nwg = gridDim.x * gridDim.y, orig = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned xcd = orig & 7u, q = nwg >> 3, rr = nwg & 7u;
+    const unsigned swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
+    bsw = (int)(swz / gridDim.x);
+    xsw = (int)(swz - (unsigned)bsw * gridDim.x);
+  }
+  const size_t b = (size_t)bsw;
+  const int c0 = xsw * a.CPW;
   const int nc = (a.S - c0 < a.CPW) ? a.S - c0 : a.CPW;
   const int rows = nc * K;
   const float *xyz = a.xyz + b * a.N * 3;
@@ -617,7 +628,16 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
 #endif
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int c1 = a.c1, c2 = a.c2, c3 = a.c3;
-  const int total = a.ws[a.B];
+  // XCD-aware tile ranges: workgroup ids are dealt round-robin over the 8 XCDs (own L2 each); the flat tile list is
+  // ordered by cloud, so XCD x (ids = x mod 8) takes the contiguous eighth [t_lo, t_end) of it and its workgroups stride
+  // through that range -- the tiles of one cloud, which gather rows of the same table, then share one L2
+  const int n_all = a.ws[a.B];
+  const bool xaware = gridDim.x >= 8;      // (fewer than eight workgroups: plain striding, every range needs an owner)
+  const int xcd = blockIdx.x & 7;
+  const int t_step = xaware ? ((int)gridDim.x + 7 - xcd) >> 3 : (int)gridDim.x;
+  const int t_lo = xaware ? (int)((long long)n_all * xcd / 8) : 0;
+  const int total = xaware ? (int)((long long)n_all * (xcd + 1) / 8) : n_all;
+  const int t_first = xaware ? t_lo + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int4 *flat = reinterpret_cast<const int4 *>(a.ws + rag_flat_off(a.B, a.maxT));
   const int *ctab = a.ws + rag_ctab_off(a.B, a.maxT);
   const f32x4 *rowtab = reinterpret_cast<const f32x4 *>(a.ws + rag_rowtab_off(a.B, a.maxT, ROWS));
@@ -700,13 +720,13 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   };
   int par = 0;
   __syncthreads();            // (sdx8 zeroed)
-  fetch_row(blockIdx.x);
+  fetch_row(t_first);
   ends_lo = nxt_lo;
   ends_hi = nxt_hi;
   if constexpr (kL1M) stash_dxyz();
-  if (pref || (kL1M && a.pq)) gather(blockIdx.x);
+  if (pref || (kL1M && a.pq)) gather(t_first);
   __syncthreads();
-  for (int tile = blockIdx.x; tile < total; tile += gridDim.x, par ^= 1) {
+  for (int tile = t_first; tile < total; tile += t_step, par ^= 1) {
   const int4 td = flat[tile];
   const size_t b = (size_t)td.x;
   const int first = td.y;
@@ -759,13 +779,13 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   PCR_MARK(1);
   __syncthreads();
   PCR_MARK(2);
-  fetch_row(tile + gridDim.x);   // next tile's row entry: lands during layer 2
+  fetch_row(tile + t_step);   // next tile's row entry: lands during layer 2
   if (!(a.dbg & 2))
   tile_dense2<TB, NR2, W2>(buf, c1, a.wp2, ceil32(c2), true,
                            [&](float v, int o, int t) { buf[o * RP + t] = relu_bits(v); }, s_sh2,
                            kRing && PCR_RING == 1 ? ring2 : nullptr, load_ring3);
   PCR_MARK(3);
-  if (pref || (kL1M && a.pq)) gather(tile + gridDim.x);   // next tile's table pieces: land during layer 3
+  if (pref || (kL1M && a.pq)) gather(tile + t_step);   // next tile's table pieces: land during layer 3
   __syncthreads();
   PCR_MARK(4);
   if (!(a.dbg & 4))

@@ -39,9 +39,9 @@ struct TNorm {
 };
 
 // (tokens are indexed flat over all clouds: ft = b * L + t, so a block is 256 real tokens whatever L is)
-__global__ __launch_bounds__(256) void tnorm_fwd_kernel(TNorm a, int B) {
+__global__ __launch_bounds__(64) void tnorm_fwd_kernel(TNorm a, int B) {
   const int g = blockIdx.y;
-  const size_t ft = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t ft = (size_t)blockIdx.x * 64 + threadIdx.x;   // one wave per block: small tensors need the workgroup count
   if (ft >= (size_t)B * a.L) return;
   const size_t b = ft / a.L;
   const int t = (int)(ft - b * a.L);
@@ -75,10 +75,10 @@ struct TNormBwd {
   float *dres;     // optional: the masked gradient (= gradient of the residual input)
 };
 
-__global__ __launch_bounds__(256) void tnorm_bwd_kernel(TNormBwd a, int B) {
+__global__ __launch_bounds__(64) void tnorm_bwd_kernel(TNormBwd a, int B) {
   const int g = blockIdx.y;
-  const size_t ft = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t ft = (size_t)blockIdx.x * 64 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const bool ok = ft < (size_t)B * a.L;
   const size_t b = ok ? ft / a.L : 0;
   const int t = ok ? (int)(ft - b * a.L) : 0;
@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void tnorm_bwd_kernel(TNormBwd a, int B) {
     s2 += gv * xh;
   }
   const float inv = 1.0f / (float)gs;
-  // d gamma / d beta: one partial row per WAVE (64 tokens), no barriers; rows [(blockIdx.x 4 + wave)][2][C]
-  float *part = a.part + ((size_t)blockIdx.x * 4 + wave) * 2 * a.C;
+  // d gamma / d beta: one partial row per wave = block (64 tokens), no barriers; rows [blockIdx.x][2][C]
+  float *part = a.part + (size_t)blockIdx.x * 2 * a.C;
   for (int i = 0; i < gs; i++) {
     const int c = g * gs + i;
     const float go = grad(i);
@@ -407,8 +407,8 @@ PCR_EXPORT int pcr_tnorm_fwd_f32(const float *x, const float *gamma, const float
   if (B == 0) return PCR_OK;
   if (G > 65535) return PCR_ERR_INVALID;
   TNorm a{x, gamma, beta, res, y, mean, rstd, C, L, G, eps, relu};
-  const unsigned nb = (unsigned)(((size_t)B * L + 255) / 256);
-  hipLaunchKernelGGL(tnorm_fwd_kernel, dim3(nb, G), dim3(256), 0, pcr_s(stream), a, B);
+  const unsigned nb = (unsigned)(((size_t)B * L + 63) / 64);
+  hipLaunchKernelGGL(tnorm_fwd_kernel, dim3(nb, G), dim3(64), 0, pcr_s(stream), a, B);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }
@@ -421,8 +421,8 @@ PCR_EXPORT int pcr_tnorm_bwd_f32(const float *g, const float *x, const float *ga
   if (B == 0) return PCR_OK;
   if (G > 65535) return PCR_ERR_INVALID;
   TNormBwd a{g, x, gamma, mean, rstd, dx, part, C, L, G, y_relu, dres};
-  const unsigned nb = (unsigned)(((size_t)B * L + 255) / 256);
-  hipLaunchKernelGGL(tnorm_bwd_kernel, dim3(nb, G), dim3(256), 0, pcr_s(stream), a, B);
+  const unsigned nb = (unsigned)(((size_t)B * L + 63) / 64);
+  hipLaunchKernelGGL(tnorm_bwd_kernel, dim3(nb, G), dim3(64), 0, pcr_s(stream), a, B);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }

@@ -137,6 +137,8 @@ __global__ __launch_bounds__(kThreads) void sa_l1_bwd_kernel(L1BwdArgs a) {
   int *it = reinterpret_cast<int *>(dxt + 3 * TR);   // [TR] neighbour index, [TR] centre
   int *st = it + TR;
   float *comb = reinterpret_cast<float *>(st + TR);  // [PARTS][CS][4]
+  unsigned long long *msk = reinterpret_cast<unsigned long long *>(      // [PARTS][2] row masks, 8-byte aligned
+      (reinterpret_cast<uintptr_t>(comb + PARTS * CS * 4) + 7) & ~(uintptr_t)7);
   const int tid = threadIdx.x;
   const int cl = tid % CS, part = tid / CS;
   const size_t b = blockIdx.y;
@@ -184,22 +186,42 @@ __global__ __launch_bounds__(kThreads) void sa_l1_bwd_kernel(L1BwdArgs a) {
       if (rr < nr && c0 + c < c1) v = a.ka[c0 + c] * pg[u] + a.kb[c0 + c] * py[u] + a.kc[c0 + c];
       if (e < CS * TR) dyt[c * (TR + 1) + rr] = v;
     }
+    // per owner class p: which rows of this tile gather a point / belong to a centre congruent to p (one ballot each by
+    // wave 0): an owner then visits ITS rows only (~1/PARTS of them), in row order
+    if (tid < 64) {
+      const int iv = tid < nr ? it[tid] : -1, sv = tid < nr ? st[tid] : -1;
+#pragma unroll
+      for (int p = 0; p < PARTS; p++) {
+        const unsigned long long mp = __ballot(iv >= 0 && (iv % PARTS) == p), mq = __ballot(sv >= 0 && (sv % PARTS) == p);
+        if (tid == 0) {
+          msk[2 * p] = mp;
+          msk[2 * p + 1] = mq;
+        }
+      }
+    }
     __syncthreads();
     if (t0 + TR < L) fetch(t0 + TR);
     if (live) {
       const float *row = dyt + cl * (TR + 1);
-      for (int rr = 0; rr < nr; rr++) {
+      for (int rr = part; rr < nr; rr += PARTS) {
         const float v = row[rr];
-        if ((rr % PARTS) == part) {
-          w0 += v * dxt[3 * rr];
-          w1 += v * dxt[3 * rr + 1];
-          w2 += v * dxt[3 * rr + 2];
-          wb += v;
+        w0 += v * dxt[3 * rr];
+        w1 += v * dxt[3 * rr + 1];
+        w2 += v * dxt[3 * rr + 2];
+        wb += v;
+      }
+      if (a.dtab) {
+        unsigned long long m = msk[2 * part];
+        while (m) {
+          const int rr = __builtin_ctzll(m);
+          m &= m - 1;
+          dP[cl * NP + it[rr]] += row[rr];
         }
-        if (a.dtab) {
-          const int i = it[rr], s = st[rr];
-          if ((i % PARTS) == part) dP[cl * NP + i] += v;
-          if ((s % PARTS) == part) dQ[cl * SP + s] += v;
+        m = msk[2 * part + 1];
+        while (m) {
+          const int rr = __builtin_ctzll(m);
+          m &= m - 1;
+          dQ[cl * SP + st[rr]] += row[rr];
         }
       }
     }
@@ -351,7 +373,7 @@ PCR_EXPORT int pcr_sa_l1_bwd_f32(const float *xyz, const int *idx, const float *
   L1BwdArgs a{xyz, idx, g, y, ka, kb, kc, dtab, dwa, N, S, K, c1, cs};
   const int parts = kThreads / cs;
   const size_t lds = ((dtab ? (size_t)cs * ((N | 1) + (S | 1)) : 0) + 3 * (size_t)N + (size_t)cs * 65 + 3 * 64 + 2 * 64 +
-                      (size_t)parts * cs * 4) * sizeof(float);
+                      (size_t)parts * cs * 4 + 4 * (size_t)parts + 2) * sizeof(float);
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
   const dim3 grid((c1 + cs - 1) / cs, B);
   l1_dispatch(cs, [&](auto tag) {

@@ -422,7 +422,7 @@ class TNorm(Function):
         g = g.contiguous()
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if (has_res and y is not None) else None
-        nparts = ((B * Ln + 255) // 256) * 4        # one partial row per 64-token wave
+        nparts = (B * Ln + 63) // 64              # one partial row per 64-token wave
         part = _f32(nparts, 2, C, device=x.device)
         L.check(L.load().pcr_tnorm_bwd_f32(L.ptr(g), L.ptr(x), L.ptr(gamma.detach()), L.ptr(mean), L.ptr(rstd), L.ptr(y),
                                            L.ptr(dx), L.ptr(dres), L.ptr(part), B, C, Ln, G, L.stream_ptr()),
