@@ -346,12 +346,16 @@ int pcr_local_attn_f32(const float *qkv, const int *idx, float *msg, int B, int 
  * pcr_packed_weight_floats(cout, cin) floats per image */
 int pcr_pack_weight_dev_f32(const float *w, int rows, int cols, int ld, int transpose, float *packed, pcr_stream_t stream);
 
-/* workgroups per cloud the train-dense launches use for (B, L): the partial buffers below have B * this many entries */
+/* workgroups a train-dense launch uses for (B, L) (a workgroup strides over tiles AND clouds): the partial buffers
+ * below have this many entries */
 int pcr_train_groups(int B, int L);
+/* ... of a pcr_tdense_bwd_f32 launch that accumulates dW (cout x cin; cout = 0: no dW): wide layers on short clouds use
+ * fewer workgroups, each accumulating over more clouds */
+int pcr_train_groups_bwd(int B, int L, int cout, int cin);
 
 /* y = [relu](W f([x ; x2]) + bias [+ res]),  f(x) = [relu](isc x + ish) on the cin1 channels of x (the previous
  * layer's BatchNorm + ReLU, applied while the tile is loaded; isc NULL = identity).  stats (optional): partials
- * [B * groups][2][ceil32(cout)] of sum y and sum y^2 (before res / relu) for pcr_bn_fwd_finalize_f32.  cout <= 384. */
+ * [groups][2][ceil32(cout)] of sum y and sum y^2 (before res / relu) for pcr_bn_fwd_finalize_f32.  cout <= 384. */
 typedef struct pcr_tdense_fwd {
   int B, cin1, cin2, cout, L;
   const float *x, *x2;
@@ -370,8 +374,8 @@ int pcr_tdense_fwd_f32(const pcr_tdense_fwd *p, pcr_stream_t stream);
  * (layer stored after its ReLU); 3: as 1 with g = the gradient gp (B,cout,S) of the max-pooled output routed to row
  * argmax (B,cout,S) of every centre where pooled (B,cout,S) > 0 (L = S K).
  * Outputs (each optional): dx / dx2 = W^T dy masked by f(x) > 0 when in_relu (wpT = packed W^T); dstats = partials
- * [B * groups][2][ceil32(cin1)] of sum dx and sum dx * (raw x) for the next BatchNorm backward (iinv = 1 / isc);
- * dwp = partials [B * groups][ceil32(cout)][ceil32(cin)] of dy f(x)^T, dbp = partials [B * groups][ceil32(cout)] of sum dy
+ * [groups][2][ceil32(cin1)] of sum dx and sum dx * (raw x) for the next BatchNorm backward (iinv = 1 / isc);
+ * dwp = partials [groups][ceil32(cout)][ceil32(cin)] of dy f(x)^T, dbp = partials [groups][ceil32(cout)] of sum dy
  * (reduce with pcr_reduce_parts_f32).  cout <= 384, cin1 + cin2 <= 288. */
 typedef struct pcr_tdense_bwd {
   int B, cin1, cin2, cout, L;

@@ -87,7 +87,8 @@ struct TFwd {
   const float *res;                 // (B,cout,L) added to the output, or null
   int out_relu;
   float *y;
-  int cout, L, tpw;                 // tiles per workgroup
+  int cout, L, tpw;                 // tiles per workgroup and cloud
+  int B;                            // clouds: workgroup (x, y) takes clouds y, y + gridDim.y, ...
   float *stats;                     // partials [workgroups][2][ceil32(cout)] (sum, sum of squares of y), or null
 };
 
@@ -103,13 +104,14 @@ __global__ __launch_bounds__(kThreads) void tdense_fwd_kernel(TFwd a) {
   float *X = smem;
   float *s_isc = X + rows * RP, *s_ish = s_isc + a.cin1;
   const int tid = threadIdx.x;
-  const size_t b = blockIdx.y;
+  size_t b = blockIdx.y;
   const bool aff = a.isc != nullptr;
   if (aff)
     for (int e = tid; e < a.cin1; e += kThreads) {
       s_isc[e] = a.isc[e];
       s_ish[e] = a.ish[e];
     }
+  // per-cloud bases (the fill / store lambdas below read the current ones)
   const float *xb = a.x + b * a.cin1 * L;
   const float *x2b = a.x2 ? a.x2 + b * a.cin2 * L : xb;
   const float *resb = a.res ? a.res + b * a.cout * L : nullptr;
@@ -179,6 +181,14 @@ __global__ __launch_bounds__(kThreads) void tdense_fwd_kernel(TFwd a) {
   };
   auto whole = [&](int t0) { return PFQ > 0 && vec && t0 + T <= L; };
   const int tfirst = blockIdx.x * a.tpw * T;
+  for (bool first_cloud = true; b < (size_t)a.B; b += gridDim.y, first_cloud = false) {
+  if (!first_cloud) {
+    xb = a.x + b * a.cin1 * L;
+    x2b = a.x2 ? a.x2 + b * a.cin2 * L : xb;
+    resb = a.res ? a.res + b * a.cout * L : nullptr;
+    yb = a.y + b * a.cout * L;
+    __syncthreads();     // the previous cloud's last tile has been stored from X
+  }
   bool have = false;
   if (tfirst < L && whole(tfirst)) {
     fetch(tfirst);
@@ -244,6 +254,7 @@ __global__ __launch_bounds__(kThreads) void tdense_fwd_kernel(TFwd a) {
       }
     }
   }
+  }   // clouds
   if (a.stats && tid < coutP) {
     float *sp = a.stats + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * coutP;
     sp[tid] = ssum;
@@ -272,6 +283,7 @@ struct TBwd {
   float *dwp, *dbp;                 // partials [workgroups][ceil32(cout)][ceil32(cin)], [workgroups][ceil32(cout)]
   long dw_stride, db_stride;        // floats between the workgroups' partials (0 = dense arrays)
   int cout, L, tpw;
+  int B;                            // clouds: workgroup (x, y, z) takes clouds y, y + gridDim.y, ...
 };
 
 // QY / QX > 0: register prefetch of the NEXT tile (QY pieces of g and of y, QX pieces of the forward input per thread),
@@ -288,7 +300,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   float *s_ka = s_k, *s_kb = s_k + a.cout, *s_kc = s_k + 2 * a.cout;
   float *s_isc = s_k + 3 * a.cout, *s_ish = s_isc + a.cin1, *s_iinv = s_ish + a.cin1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-  const size_t b = blockIdx.y;
+  size_t b = blockIdx.y;
   const int z = blockIdx.z;
   const bool bn = a.dy_mode == 1 || a.dy_mode == 3;
   const bool aff = a.isc != nullptr;
@@ -467,6 +479,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   const bool pf_ok = kPF && vec && (mode != 3 || (K & 3) == 0) && rowsY == 16 * QY && cinP == 16 * QX;
   auto whole = [&](int t0) { return pf_ok && t0 + T <= L; };
   const int tfirst = blockIdx.x * a.tpw * T;
+  for (bool first_cloud = true; b < (size_t)a.B; b += gridDim.y, first_cloud = false) {
+  if (!first_cloud) {
+    gb = mode == 3 ? a.g + b * a.cout * S : a.g + b * a.cout * L;
+    yb = a.y ? a.y + b * a.cout * L : gb;
+    amb = mode == 3 ? a.argmax + b * a.cout * S : nullptr;
+    plb = mode == 3 ? a.pooled + b * a.cout * S : nullptr;
+    xb = a.x + b * a.cin1 * L;
+    x2b = a.x2 ? a.x2 + b * a.cin2 * L : xb;
+    __syncthreads();     // the previous cloud's last tile has been consumed
+  }
   bool have = false;
   if (tfirst < L && whole(tfirst)) {
     fetch(tfirst);
@@ -587,6 +609,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
       }
     }
   }
+  }   // clouds
   const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
   if (a.dwp) {
     float *dw = a.dwp + wg * (a.dw_stride ? (size_t)a.dw_stride : (size_t)coutP * cinP);
@@ -756,6 +779,17 @@ static bool big_lds(K k) {
 
 }  // namespace
 
+// grid.y: clouds are strided over at most this many workgroup rows, so that a launch has ~768 workgroups whatever the
+// batch (small tensors: a workgroup then carries its weights, dW accumulators and statistics across several clouds)
+static int wg_cloud_rows(int B, int gx, long part_floats = 0) {
+  // (measured: letting wide layers on short clouds use fewer rows, to shrink their per-workgroup dW partials, costs
+  // more in lost parallelism than the partial traffic it saves -- 0.59 -> 0.70 ms on the 256 x 256, L = 32 layer)
+  (void)part_floats;
+  int r = 768 / (gx > 0 ? gx : 1);
+  if (r < 1) r = 1;
+  return r < B ? r : B;
+}
+
 static int wg_groups(int B, int ntiles) {
   // workgroups per cloud: enough to fill the chip a few times over, few enough that the per-workgroup partials
   // (dW images, statistics) stay small: ~1024 workgroups per launch
@@ -769,7 +803,18 @@ PCR_EXPORT int pcr_train_groups(int B, int L) {
   const int ntiles = (L + kTT - 1) / kTT;
   const int g = wg_groups(B, ntiles);
   const int tpw = (ntiles + g - 1) / g;
-  return (ntiles + tpw - 1) / tpw;   // workgroups per cloud actually launched
+  const int gx = (ntiles + tpw - 1) / tpw;
+  return gx * wg_cloud_rows(B, gx);   // workgroups of a train-dense launch = rows of its partial buffers
+}
+
+// the same for a backward launch that accumulates dW (cout x cin): wide layers use fewer workgroup rows
+PCR_EXPORT int pcr_train_groups_bwd(int B, int L, int cout, int cin) {
+  const int ntiles = (L + kTT - 1) / kTT;
+  const int g = wg_groups(B, ntiles);
+  const int tpw = (ntiles + g - 1) / g;
+  const int gx = (ntiles + tpw - 1) / tpw;
+  const long pf = cout > 0 ? (long)ceil32(cout) * ceil32(cin) + ceil32(cout) : 0;
+  return gx * wg_cloud_rows(B, gx, pf);
 }
 
 PCR_EXPORT int pcr_pack_weight_dev_f32(const float *w, int rows, int cols, int ld, int transpose, float *packed,
@@ -794,7 +839,7 @@ PCR_EXPORT int pcr_tdense_fwd_f32(const pcr_tdense_fwd *p, pcr_stream_t stream) 
   a.x = p->x; a.x2 = p->cin2 ? p->x2 : nullptr; a.cin1 = p->cin1; a.cin2 = p->cin2;
   a.isc = p->isc; a.ish = p->ish; a.in_relu = p->in_relu;
   a.wp = p->wp; a.bias = p->bias; a.res = p->res; a.out_relu = p->out_relu;
-  a.y = p->y; a.cout = p->cout; a.L = p->L; a.stats = p->stats;
+  a.y = p->y; a.cout = p->cout; a.L = p->L; a.stats = p->stats; a.B = p->B;
   const int ntiles = (p->L + kTT - 1) / kTT;
   const int g = wg_groups(p->B, ntiles);
   a.tpw = (ntiles + g - 1) / g;
@@ -804,7 +849,7 @@ PCR_EXPORT int pcr_tdense_fwd_f32(const pcr_tdense_fwd *p, pcr_stream_t stream) 
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
   const int need = (cinP + 15) / 16;     // 16-byte pieces per thread of one input tile
   const int pfq = need <= 2 ? 2 : (need <= 4 ? 4 : (need <= 8 ? 8 : 0));
-  const dim3 grid(gx, p->B), blk(kThreads);
+  const dim3 grid(gx, wg_cloud_rows(p->B, gx)), blk(kThreads);
   hipStream_t st = pcr_s(stream);
 #define PCR_TF(WSv, NRv, Qv)                                                        \
   do {                                                                              \
@@ -849,7 +894,7 @@ PCR_EXPORT int pcr_tdense_bwd_f32(const pcr_tdense_bwd *p, pcr_stream_t stream) 
   a.isc = p->isc; a.ish = p->ish; a.iinv = p->iinv; a.in_relu = p->in_relu;
   a.wpT = p->wpT; a.dx = p->dx; a.dx2 = p->dx2; a.dstats = p->dstats; a.dwp = p->dwp; a.dbp = p->dbp;
   a.dw_stride = p->part_stride; a.db_stride = p->part_stride;
-  a.cout = p->cout; a.L = p->L;
+  a.cout = p->cout; a.L = p->L; a.B = p->B;
   const int ntiles = (p->L + kTT - 1) / kTT;
   const int g = wg_groups(p->B, ntiles);
   a.tpw = (ntiles + g - 1) / g;
@@ -861,7 +906,7 @@ PCR_EXPORT int pcr_tdense_bwd_f32(const pcr_tdense_bwd *p, pcr_stream_t stream) 
   constexpr int NTW = 4;
   const int items = (coutP >> 5) * (cinP >> 5);
   const int gz = p->dwp ? (items + 4 * NTW - 1) / (4 * NTW) : 1;
-  const dim3 grid(gx, p->B, gz), blk(kThreads);
+  const dim3 grid(gx, wg_cloud_rows(p->B, gx, p->dwp ? (long)coutP * cinP + coutP : 0), gz), blk(kThreads);
   hipStream_t st = pcr_s(stream);
   const int nx = cinP >> 5;
   const int rowsY = coutP > cinP ? coutP : cinP;

@@ -113,7 +113,7 @@ def tdense_fwd(x, wp, cout, x2=None, isc=None, ish=None, in_relu=False, bias=Non
         x2 = _dev(x2)
         cin2 = x2.shape[1]
     y = _f32(B, cout, Ln, device=x.device)
-    stats = _f32(B * groups(B, Ln), 2, _c32(cout), device=x.device) if want_stats else None
+    stats = _f32(groups(B, Ln), 2, _c32(cout), device=x.device) if want_stats else None
     p = _TFwd()
     p.B, p.cin1, p.cin2, p.cout, p.L = B, cin1, cin2, cout, Ln
     p.x, p.x2, p.isc, p.ish, p.in_relu = _p(x), _p(x2), _p(isc), _p(ish), int(in_relu)
@@ -144,7 +144,7 @@ def tdense_bwd(g, x, cout, dy_mode=0, y=None, k=None, argmax=None, pooled=None, 
         cin2 = x2.shape[1]
     cin = cin1 + cin2
     dev = x.device
-    nwg = B * groups(B, Ln)
+    nwg = L.load().pcr_train_groups_bwd(B, Ln, cout if want_dw else 0, cin)
     out = {}
     p = _TBwd()
     p.B, p.cin1, p.cin2, p.cout, p.L = B, cin1, cin2, cout, Ln
