@@ -48,14 +48,17 @@ __global__ __launch_bounds__(64) void tnorm_fwd_kernel(TNorm a, int B) {
   const int gs = a.C / a.G;
   const size_t base = (b * a.C + (size_t)g * gs) * a.L + t;
   float m = 0.f;
+#pragma unroll 8
   for (int i = 0; i < gs; i++) m += a.x[base + (size_t)i * a.L];
   m /= (float)gs;
   float v = 0.f;
+#pragma unroll 8
   for (int i = 0; i < gs; i++) {
     const float d = a.x[base + (size_t)i * a.L] - m;
     v += d * d;
   }
   const float r = 1.0f / sqrtf(v / (float)gs + a.eps);
+#pragma unroll 8
   for (int i = 0; i < gs; i++) {
     const int c = g * gs + i;
     float o = (a.x[base + (size_t)i * a.L] - m) * r * a.gamma[c] + a.beta[c];
@@ -91,6 +94,7 @@ __global__ __launch_bounds__(64) void tnorm_bwd_kernel(TNormBwd a, int B) {
     if (a.y && ok && !(a.y[base + (size_t)i * a.L] > 0.f)) go = 0.f;
     return go;
   };
+#pragma unroll 8
   for (int i = 0; i < gs; i++) {
     const float gv = grad(i) * a.gamma[g * gs + i];
     const float xh = ok ? (a.x[base + (size_t)i * a.L] - m) * r : 0.f;
@@ -100,6 +104,7 @@ __global__ __launch_bounds__(64) void tnorm_bwd_kernel(TNormBwd a, int B) {
   const float inv = 1.0f / (float)gs;
   // d gamma / d beta: one partial row per wave = block (64 tokens), no barriers; rows [blockIdx.x][2][C]
   float *part = a.part + (size_t)blockIdx.x * 2 * a.C;
+#pragma unroll 4
   for (int i = 0; i < gs; i++) {
     const int c = g * gs + i;
     const float go = grad(i);

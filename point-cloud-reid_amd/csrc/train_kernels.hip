@@ -77,6 +77,21 @@ __device__ __forceinline__ void tile_fill(float *dst, int C, int CP, int L, int 
 
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 
+// Row sums of an LDS tile use ALL 256 threads: thread t owns the 16-token quarter (t & 3) of rows (t >> 2) + 64 p and keeps
+// its partial sums across the workgroup's tiles; the four quarters of a row meet once, at the end (two DPP adds inside
+// the quad).  (One thread per row -- 64 dependent-ish iterations on a quarter of the threads -- was the longest serial
+// stretch of a tile.)
+constexpr int kRowPasses = 6;   // up to 384 rows
+template <int CTRL>
+__device__ __forceinline__ float tk_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += tk_dpp<0xB1>(v);
+  v += tk_dpp<0x4E>(v);
+  return v;
+}
+
 // ---------------------------------------------------------------------------------- forward ----
 struct TFwd {
   const float *x, *x2;              // (B,cin1,L), (B,cin2,L) or null: the layer's input is [x ; x2] along the channels
@@ -118,7 +133,9 @@ __global__ __launch_bounds__(kThreads) void tdense_fwd_kernel(TFwd a) {
   float *yb = a.y + b * a.cout * L;
   const bool vec = (L & 3) == 0;
   const int cin1 = a.cin1, in_relu = a.in_relu;
-  float ssum = 0.f, ssq = 0.f;
+  float ssum[kRowPasses], ssq[kRowPasses];
+#pragma unroll
+  for (int p = 0; p < kRowPasses; p++) ssum[p] = ssq[p] = 0.f;
   __syncthreads();
   auto f4 = [&](int c, int tg) {
     const bool first = c < cin1;
@@ -206,23 +223,24 @@ __global__ __launch_bounds__(kThreads) void tdense_fwd_kernel(TFwd a) {
     tile_dense2<TB, NR, WS>(X, cinP, a.wp, coutP, true, [&](float v, int o, int t) { X[o * RP + t] = v; }, a.bias);
     __syncthreads();
     const int valid = L - t0 < T ? L - t0 : T;
-    if (a.stats && tid < coutP) {   // BatchNorm statistics of the raw output (bias included)
-      const float *row = X + tid * RP;
-      if (valid == T) {   // whole tile: unrolled, four independent chains (the LDS reads overlap)
-        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
-#pragma unroll 4
-        for (int t = 0; t < T; t += 4) {
-          const float v0 = row[t], v1 = row[t + 1], v2 = row[t + 2], v3 = row[t + 3];
-          p0 += v0; p1 += v1; p2 += v2; p3 += v3;
-          q0 += v0 * v0; q1 += v1 * v1; q2 += v2 * v2; q3 += v3 * v3;
-        }
-        ssum += (p0 + p1) + (p2 + p3);
-        ssq += (q0 + q1) + (q2 + q3);
-      } else {
-        for (int t = 0; t < valid; t++) {
-          const float v = row[t];
-          ssum += v;
-          ssq += v * v;
+    if (a.stats) {   // BatchNorm statistics of the raw output (bias included): quarter-row partial sums
+      const int q16 = 16 * (tid & 3);
+#pragma unroll
+      for (int p = 0; p < kRowPasses; p++) {
+        const int r = (tid >> 2) + 64 * p;
+        if (r < coutP) {
+          const float *row = X + r * RP + q16;
+          float p0 = 0.f, p1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll
+          for (int t = 0; t < 16; t += 2) {
+            const float v0 = q16 + t < valid ? row[t] : 0.f, v1 = q16 + t + 1 < valid ? row[t + 1] : 0.f;
+            p0 += v0;
+            p1 += v1;
+            q0 += v0 * v0;
+            q1 += v1 * v1;
+          }
+          ssum[p] += p0 + p1;
+          ssq[p] += q0 + q1;
         }
       }
     }
@@ -255,10 +273,17 @@ __global__ __launch_bounds__(kThreads) void tdense_fwd_kernel(TFwd a) {
     }
   }
   }   // clouds
-  if (a.stats && tid < coutP) {
+  if (a.stats) {
     float *sp = a.stats + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * coutP;
-    sp[tid] = ssum;
-    sp[coutP + tid] = ssq;
+#pragma unroll
+    for (int p = 0; p < kRowPasses; p++) {
+      const int r = (tid >> 2) + 64 * p;
+      const float s1 = quad_sum(ssum[p]), s2 = quad_sum(ssq[p]);
+      if ((tid & 3) == 0 && r < coutP) {
+        sp[r] = s1;
+        sp[coutP + r] = s2;
+      }
+    }
   }
 }
 
@@ -284,12 +309,13 @@ struct TBwd {
   long dw_stride, db_stride;        // floats between the workgroups' partials (0 = dense arrays)
   int cout, L, tpw;
   int B;                            // clouds: workgroup (x, y, z) takes clouds y, y + gridDim.y, ...
+  int dbg;                          // PCR_TD_DBG ablation mask (diagnostics only; 0 in production)
 };
 
 // QY / QX > 0: register prefetch of the NEXT tile (QY pieces of g and of y, QX pieces of the forward input per thread),
 // requested once the current tile sits in LDS: the HBM round trip hides behind the two matrix phases
 template <int WSX, int NRX, int NTW, int QY, int QX>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void tdense_bwd_kernel(TBwd a) {
+__device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
   constexpr int TB = 2, T = kTT, RP = kTRP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int cin = a.cin1 + a.cin2, cinP = ceil32(cin), coutP = ceil32(a.cout), L = a.L;
@@ -393,7 +419,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   for (int i = 0; i < NTW; i++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
-  float dbsum[2] = {0.f, 0.f}, s1 = 0.f, s2 = 0.f;
+  float dbsum[kRowPasses], s1[kRowPasses], s2[kRowPasses];
+#pragma unroll
+  for (int p = 0; p < kRowPasses; p++) dbsum[p] = s1[p] = s2[p] = 0.f;
   const bool want_dx = a.wpT != nullptr && z == 0;
   __syncthreads();
   constexpr bool kPF = QY > 0;
@@ -498,7 +526,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int t0 = (blockIdx.x * a.tpw + ti) * T;
     if (t0 >= L) break;
     if (ti) __syncthreads();
-    if (have) commit();
+    if (a.dbg & 16) {
+    } else if (have) commit();
     else
     // ONE fill over both tiles (AT follows DY in LDS): the loads of dy and of the forward input are in flight together
     tile_fill(DY, rowsY + cinP, rowsY + cinP, L, t0, vec,
@@ -515,25 +544,24 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (have) fetch(t0 + T);
     const int valid = L - t0 < T ? L - t0 : T;
     // (tile_fill leaves the padding tokens of a ragged tile zero, also where BatchNorm's backward adds a constant)
-    if (a.dbp && z == 0) {
+    if (a.dbp && z == 0 && !(a.dbg & 4)) {   // sum of dy over the tile's tokens (padding tokens are zero), quarter rows
+      const int q16 = 16 * (tid & 3);
 #pragma unroll
-      for (int j = 0; j < 2; j++) {      // up to 384 cout rows, 256 threads
-        const int rw = tid + j * kThreads;
-        if (rw < coutP) {
-          const float *row = DY + rw * RP;
-          float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-#pragma unroll 4
-          for (int t = 0; t < T; t += 4) {
+      for (int p = 0; p < kRowPasses; p++) {
+        const int r = (tid >> 2) + 64 * p;
+        if (r < coutP) {
+          const float *row = DY + r * RP + q16;
+          float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+          for (int t = 0; t < 16; t += 2) {
             p0 += row[t];
             p1 += row[t + 1];
-            p2 += row[t + 2];
-            p3 += row[t + 3];
           }
-          dbsum[j] += (p0 + p1) + (p2 + p3);
+          dbsum[p] += p0 + p1;
         }
       }
     }
-    if (a.dwp) {
+    if (a.dwp && !(a.dbg & 1)) {
 #pragma unroll
       for (int it = 0; it < NTW; it++) {
         const int item = z * 4 * NTW + wave + 4 * it;
@@ -547,37 +575,34 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
       }
     }
-    if (want_dx) {
+    if (want_dx && !(a.dbg & 2)) {
       // (the barrier between this call's k-loop and its epilogue also orders the dW reads of DY above before the
       // in-place overwrite)
       tile_dense2<TB, NRX, WSX>(DY, ceil8(a.cout), a.wpT, cinP, true, [&](float v, int o, int t) { DY[o * RP + t] = v; });
       __syncthreads();
-      if (a.dstats && tid < cin1) {
-        const float *dr = DY + tid * RP, *ar = AT + tid * RP;
-        const float sh = s_ish[tid], inv = s_iinv[tid];
-        if (valid == T) {
-          float p0 = 0.f, p1 = 0.f, q0 = 0.f, q1 = 0.f;
-#pragma unroll 4
-          for (int t = 0; t < T; t += 2) {
-            const float a0 = ar[t], a1 = ar[t + 1];
-            const float v0 = (!in_relu || a0 > 0.f) ? dr[t] : 0.f, v1 = (!in_relu || a1 > 0.f) ? dr[t + 1] : 0.f;
-            p0 += v0;
-            p1 += v1;
-            q0 += v0 * ((a0 - sh) * inv);
-            q1 += v1 * ((a1 - sh) * inv);
-          }
-          s1 += p0 + p1;
-          s2 += q0 + q1;
-        } else {
-          for (int t = 0; t < valid; t++) {
-            const float av = ar[t];
-            const float v = (!in_relu || av > 0.f) ? dr[t] : 0.f;
-            s1 += v;
-            s2 += v * ((av - sh) * inv);
+      if (a.dstats && !(a.dbg & 4)) {   // sums of the masked dx and of dx * (raw input) per input channel, quarter rows
+        const int q16 = 16 * (tid & 3);
+#pragma unroll
+        for (int p = 0; p < kRowPasses; p++) {
+          const int r = (tid >> 2) + 64 * p;
+          if (r < cin1) {
+            const float *dr = DY + r * RP + q16, *ar = AT + r * RP + q16;
+            const float sh = s_ish[r], inv = s_iinv[r];
+            float p0 = 0.f, q0 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+              const float av = ar[t];
+              const float v = (q16 + t < valid && (!in_relu || av > 0.f)) ? dr[t] : 0.f;
+              p0 += v;
+              q0 += v * ((av - sh) * inv);
+            }
+            s1[p] += p0;
+            s2[p] += q0;
           }
         }
       }
-      if (vec && valid == T) {
+      if (a.dbg & 8) {
+      } else if (vec && valid == T) {
         constexpr int Q = T / 4;
         for (int e = tid; e < cin * Q; e += kThreads) {
           const int c = e / Q, q = e - c * Q;
@@ -626,17 +651,38 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
   if (a.dbp && z == 0) {
     float *db = a.dbp + wg * (a.db_stride ? (size_t)a.db_stride : (size_t)coutP);
-    if (tid < coutP) db[tid] = dbsum[0];
-    if (tid + kThreads < coutP) db[tid + kThreads] = dbsum[1];
+#pragma unroll
+    for (int p = 0; p < kRowPasses; p++) {
+      const int r = (tid >> 2) + 64 * p;
+      const float v = quad_sum(dbsum[p]);
+      if ((tid & 3) == 0 && r < coutP) db[r] = v;
+    }
   }
   if (a.dstats && want_dx) {
     const int c1P = ceil32(cin1);
     float *sp = a.dstats + wg * 2 * (size_t)c1P;
-    if (tid < c1P) {
-      sp[tid] = tid < cin1 ? s1 : 0.f;
-      sp[c1P + tid] = tid < cin1 ? s2 : 0.f;
+#pragma unroll
+    for (int p = 0; p < kRowPasses; p++) {
+      const int r = (tid >> 2) + 64 * p;
+      const float v1 = quad_sum(s1[p]), v2 = quad_sum(s2[p]);
+      if ((tid & 3) == 0 && r < c1P) {
+        sp[r] = r < cin1 ? v1 : 0.f;
+        sp[c1P + r] = r < cin1 ? v2 : 0.f;
+      }
     }
   }
+}
+
+template <int WSX, int NRX, int NTW, int QY, int QX>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void tdense_bwd_kernel(TBwd a) {
+  tdense_bwd_body<WSX, NRX, NTW, QY, QX>(a);
+}
+// narrow layers (at most four dW tiles: one accumulator tile per wave): held to a quarter of the register file, so that
+// four workgroups share a CU and the load / LDS-commit / matrix / store phases of different workgroups overlap -- the
+// phases of ONE workgroup are strictly serial (ablation: 0.32 + 0.29 + 0.07 + 0.27 ms add up to the 0.93 ms launch)
+template <int WSX, int NRX>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void tdense_bwd_kernel_o4(TBwd a) {
+  tdense_bwd_body<WSX, NRX, 1, 0, 0>(a);
 }
 
 // ------------------------------------------------------------------- reductions / finalisers ----
@@ -895,6 +941,8 @@ PCR_EXPORT int pcr_tdense_bwd_f32(const pcr_tdense_bwd *p, pcr_stream_t stream) 
   a.wpT = p->wpT; a.dx = p->dx; a.dx2 = p->dx2; a.dstats = p->dstats; a.dwp = p->dwp; a.dbp = p->dbp;
   a.dw_stride = p->part_stride; a.db_stride = p->part_stride;
   a.cout = p->cout; a.L = p->L; a.B = p->B;
+  static const int dbg = getenv("PCR_TD_DBG") ? atoi(getenv("PCR_TD_DBG")) : 0;
+  a.dbg = dbg;
   const int ntiles = (p->L + kTT - 1) / kTT;
   const int g = wg_groups(p->B, ntiles);
   a.tpw = (ntiles + g - 1) / g;
@@ -916,15 +964,28 @@ PCR_EXPORT int pcr_tdense_bwd_f32(const pcr_tdense_bwd *p, pcr_stream_t stream) 
     (void)ok;                                                                                    \
     hipLaunchKernelGGL((tdense_bwd_kernel<WSv, NRXv, NTW, QYv, QXv>), grid, blk, lds, st, a);    \
   } while (0)
-  // register-prefetch variants for the 32- / 64-channel square layers of the grouped MLPs (at 128 channels the 24
-  // prefetched pieces per thread spill); everything else (attention projections, tables: small tensors) takes the plain path
-  if (rowsY == 32 && cinP == 32) PCR_TB(4, 1, 2, 2);
+#define PCR_TB4(WSv, NRXv)                                                              \
+  do {                                                                                  \
+    static bool ok = big_lds(tdense_bwd_kernel_o4<WSv, NRXv>);                          \
+    (void)ok;                                                                           \
+    hipLaunchKernelGGL((tdense_bwd_kernel_o4<WSv, NRXv>), grid, blk, lds, st, a);       \
+  } while (0)
+  static const int variant = getenv("PCR_TD_VARIANT") ? atoi(getenv("PCR_TD_VARIANT")) : 0;   // tuning aid
+  // narrow layers (<= 4 dW tiles, LDS <= 40 KB): four workgroups per CU; wider ones: two per CU (with operand prefetch
+  // for the 64-channel square layers whose pieces fit the registers)
+  // (measured at B = 512: 64 x 64, L = 3072: 0.94 -> 0.72 ms with four workgroups per CU; 32 x 32, L = 4096: 0.56 with
+  // the prefetch variant against 0.59)
+  if (items <= 4 && lds <= 40 * 1024 && variant != 2 && !(rowsY == 32 && cinP == 32)) {
+    if (nx == 1) PCR_TB4(4, 1);
+    else PCR_TB4(2, 1);
+  } else if (rowsY == 32 && cinP == 32) PCR_TB(4, 1, 2, 2);
   else if (rowsY == 64 && cinP == 64) PCR_TB(2, 1, 4, 4);
   else if (nx == 1) PCR_TB(4, 1, 0, 0);
   else if (nx == 2) PCR_TB(2, 1, 0, 0);
   else if (nx <= 4) PCR_TB(1, 1, 0, 0);
   else if (nx <= 8) PCR_TB(1, 2, 0, 0);
   else PCR_TB(1, 3, 0, 0);
+#undef PCR_TB4
 #undef PCR_TB
   PCR_CHECK_LAUNCH();
   return PCR_OK;

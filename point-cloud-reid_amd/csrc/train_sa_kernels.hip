@@ -274,9 +274,11 @@ __global__ __launch_bounds__(kThreads) void sa_pool_fwd_kernel(PoolArgs a) {
   for (int s0 = 0; s0 < S; s0 += G) {
     const int ng = S - s0 < G ? S - s0 : G, nrow = ng * K;
     if (s0) __syncthreads();
-    for (int e = tid; e < CS * nrow; e += kThreads) {
-      const int c = e / nrow, rr = e - c * nrow;
-      tile[c * RP + rr] = c0 + c < C ? y[(size_t)c * L + (size_t)s0 * K + rr] : 0.f;
+    // (wave w stages channels w, w + 4, ...: lanes run along the rows, no index division)
+    for (int c = tid >> 6; c < CS; c += kThreads / 64) {
+      const float *src = y + (size_t)c * L + (size_t)s0 * K;
+      const bool okc = c0 + c < C;
+      for (int rr = tid & 63; rr < nrow; rr += 64) tile[c * RP + rr] = okc ? src[rr] : 0.f;
     }
     __syncthreads();
     if (c0 + cl < C)

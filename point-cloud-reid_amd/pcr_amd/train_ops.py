@@ -91,12 +91,23 @@ def pack_both(w):
     return out[:n0], out[n0:]
 
 
+_PAD_CACHE = {}
+
+
 def pad32(v, n):
-    """(n) vector -> zero-padded to a multiple of 32 (accumulator seeds are read 16 bytes at a time)"""
+    """(n) vector -> zero-padded to a multiple of 32 (accumulator seeds are read 16 bytes at a time); cached per
+    (tensor, version): a bias is padded once per optimizer step, not once per launch"""
     if v is None:
         return None
+    key = (v.data_ptr(), v._version, n)
+    hit = _PAD_CACHE.get(key)
+    if hit is not None:
+        return hit
     out = torch.zeros(_c32(n), dtype=torch.float32, device=v.device)
     out[:n] = v.detach()
+    if len(_PAD_CACHE) > 256:
+        _PAD_CACHE.clear()
+    _PAD_CACHE[key] = out
     return out
 
 
