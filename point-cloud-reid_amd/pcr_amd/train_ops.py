@@ -99,15 +99,16 @@ def pad32(v, n):
     (tensor, version): a bias is padded once per optimizer step, not once per launch"""
     if v is None:
         return None
-    key = (v.data_ptr(), v._version, n)
-    hit = _PAD_CACHE.get(key)
-    if hit is not None:
-        return hit
+    # keyed by the tensor OBJECT (kept alive by the entry, so its id and storage cannot be recycled under the cache: a
+    # (data_ptr, version) key returned another tensor's bias once the allocator had reused the address) and its version
+    hit = _PAD_CACHE.get(id(v))
+    if hit is not None and hit[0] is v and hit[1] == v._version and hit[2].numel() == _c32(n):
+        return hit[2]
     out = torch.zeros(_c32(n), dtype=torch.float32, device=v.device)
     out[:n] = v.detach()
     if len(_PAD_CACHE) > 256:
         _PAD_CACHE.clear()
-    _PAD_CACHE[key] = out
+    _PAD_CACHE[id(v)] = (v, v._version, out)
     return out
 
 
