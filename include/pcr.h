@@ -476,6 +476,31 @@ int pcr_linattn_bwd_f32(const pcr_linattn *p, pcr_stream_t stream);
 int pcr_pool_pair_fwd_f32(const float *o, float *pooled, int *arg, int P, int C, int L, pcr_stream_t stream);
 int pcr_pool_pair_bwd_f32(const float *g, const int *arg, float *dout, int P, int C, int L, pcr_stream_t stream);
 
+/* Parameter update of one iteration over EVERY parameter tensor in two launches: the global gradient norm of mmcv's
+ * OptimizerHook(grad_clip=dict(max_norm, norm_type=2)) = torch.nn.utils.clip_grad_norm_, then torch.optim.AdamW's
+ * step (configs_reid/_base_/schedules/cyclic_200e_lr3e-4.py:7-9; the cyclic lr / beta1 of lines 10-21 arrive as
+ * per-tensor constants).  `tab` (device) lists the tensors; the launch is cut into chunks of pcr_opt_chunk() elements,
+ * chunk i = elements [chunk_first[i], +chunk) of tensor chunk_tensor[i] (both device arrays).  A tensor whose g is
+ * NULL is skipped (no gradient this iteration).  Per element, with g' = g * coef:
+ *   p <- p * decay;  m <- m + one_m_beta1 (g' - m);  v <- beta2 v + one_m_beta2 g'^2;
+ *   p <- p - step_size * m / (sqrt(v) / bc2_sqrt + eps)
+ * where the host sets (in double, then rounds) decay = 1 - lr * weight_decay, step_size = lr / (1 - beta1^step),
+ * bc2_sqrt = sqrt(1 - beta2^step), one_m_beta = 1 - beta.
+ * pcr_grad_sumsq_f32 writes one sum of squares per chunk into part (n_chunks doubles); pcr_adamw_step_f32 with
+ * part != NULL adds them in a fixed order, writes the norm to *grad_norm (optional) and, when max_norm > 0, uses
+ * coef = min(1, max_norm / (norm + 1e-6)) and stores g' back into g; with part == NULL coef = 1.  No atomics: the
+ * update is reproducible bit for bit. */
+typedef struct pcr_opt_tensor {
+  float *p, *g, *m, *v;
+  long n;
+  float step_size, bc2_sqrt, decay, one_m_beta1, beta2, one_m_beta2, eps, pad_;
+} pcr_opt_tensor;
+int pcr_opt_chunk(void);
+int pcr_grad_sumsq_f32(const pcr_opt_tensor *tab, const int *chunk_tensor, const int *chunk_first, int n_chunks,
+                       double *part, pcr_stream_t stream);
+int pcr_adamw_step_f32(const pcr_opt_tensor *tab, const int *chunk_tensor, const int *chunk_first, int n_chunks,
+                       const double *part, float max_norm, float *grad_norm, pcr_stream_t stream);
+
 /* ---- measurement aid (bench.py; not on the hot path) ---- */
 
 /* Sustained f32-MFMA probe: n_wg workgroups (one per CU: pass the CU count) each run iters * 16

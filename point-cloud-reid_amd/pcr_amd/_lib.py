@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libpcr_hip.so")
 _lib = None
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class PcrError(RuntimeError):

@@ -17,9 +17,9 @@ fixtures in tests/test_train_loop.py):
   before evaluation (shard.broadcast_buffers, eval_hook.py:102-108);
 * checkpoints in mmcv's layout: {'meta': {...,'epoch','iter'}, 'state_dict': ..., 'optimizer': ...}.
 
-The model's forward/backward is whatever `model.train_step(data, optimizer)` builds (ReIDNet: HIP neighbour search
-and grouping with their HIP backward, torch autograd for the dense math today -- pcr_amd/train_graph.py); nothing
-here touches kernels.
+The model's forward/backward is whatever `model.train_step(data, optimizer)` builds (ReIDNet: every node a HIP
+launch strung together by autograd Functions -- pcr_amd/train_graph.py); for GPU parameters the update (norm, clip,
+AdamW) is pcr_amd/optim.py's two launches, for host tensors (the CPU tests of this module) torch.optim.AdamW.
 """
 import math
 
@@ -70,18 +70,12 @@ class GradBucket:
         live = self._layout()
         if not live or not shard.is_dist():
             return
-        off = 0
-        for p in live:
-            n = p.numel()
-            self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
+        views = [v.view_as(p.grad) for v, p in zip(self.flat.split([p.numel() for p in live]), live)]
+        grads = [p.grad for p in live]
+        torch._foreach_copy_(views, grads)                 # pack: one multi-tensor launch, not one copy per tensor
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self.flat.div_(dist.get_world_size())
-        off = 0
-        for p in live:
-            n = p.numel()
-            p.grad.copy_(self.flat[off:off + n].view_as(p.grad))
-            off += n
+        torch._foreach_copy_(grads, views)
 
 
 class Trainer:
@@ -96,7 +90,15 @@ class Trainer:
         self.grad_clip, self.cumulative_iters = grad_clip, int(cumulative_iters)
         self.lr_ratio, self.mom_ratio = tuple(lr_target_ratio), tuple(momentum_target_ratio)
         self.cyclic_times, self.step_ratio_up = cyclic_times, step_ratio_up
-        self.optimizer = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay, betas=betas)
+        params = [p for p in model.parameters()]
+        if params and all(p.is_cuda for p in params):
+            # on the GPU: norm + clip + AdamW are two HIP launches over every tensor (pcr_amd/optim.py)
+            from .optim import FusedAdamW
+            self.optimizer = FusedAdamW(params, lr=lr, weight_decay=weight_decay, betas=betas)
+        else:
+            # host tensors (the gloo tests of the exchange / schedule logic): torch's optimizer
+            self.optimizer = torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, betas=betas)
+        self.fused = not isinstance(self.optimizer, torch.optim.AdamW)
         self.bucket = GradBucket(list(model.parameters()))
         self.iter = 0
         self.epoch = 0
@@ -126,10 +128,15 @@ class Trainer:
         out["lr"], out["beta1"] = lr, b1
         if (self.iter + 1) % self.cumulative_iters == 0:
             self.bucket.all_reduce_mean()
-            if self.grad_clip is not None:
-                params = [p for p in self.model.parameters() if p.grad is not None]
-                out["grad_norm"] = float(torch.nn.utils.clip_grad_norm_(params, self.grad_clip, norm_type=2))
-            self.optimizer.step()
+            if self.fused:
+                norm = self.optimizer.step(max_norm=self.grad_clip)     # a device scalar: no host round trip
+                if norm is not None:
+                    out["grad_norm"] = norm
+            else:
+                if self.grad_clip is not None:
+                    params = [p for p in self.model.parameters() if p.grad is not None]
+                    out["grad_norm"] = float(torch.nn.utils.clip_grad_norm_(params, self.grad_clip, norm_type=2))
+                self.optimizer.step()
         self.iter += 1
         return out
 

@@ -256,3 +256,91 @@ def test_attention_blocks_match_torch_graph():
             if q.grad is not None:
                 worst[k] = _rel(p.grad, q.grad)
         assert max(worst.values()) < 1e-4, (name, worst)
+
+
+def _opt_params(seed):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(64, 67), (64,), (128, 128), (1,), (3, 5, 7), (4099,), (300, 33)]
+    return [torch.nn.Parameter(torch.randn(*s, generator=g).cuda()) for s in shapes]
+
+
+@pytest.mark.parametrize("max_norm", [None, 0.5, 1e6])
+def test_fused_adamw_matches_torch_adamw_and_clip(max_norm):
+    """pcr_adamw_step_f32 / pcr_grad_sumsq_f32 against clip_grad_norm_ + torch.optim.AdamW over several iterations with
+    a cyclic lr / beta1, a parameter that gets no gradient on some iterations, and gradients that are views"""
+    from pcr_amd.optim import FusedAdamW
+    pa, pb = _opt_params(5), _opt_params(5)
+    oa = FusedAdamW(pa, lr=3e-4, weight_decay=0.01)
+    ob = torch.optim.AdamW(pb, lr=3e-4, weight_decay=0.01, foreach=False)
+    g = torch.Generator().manual_seed(9)
+    for it in range(6):
+        lr, b1 = 3e-4 * (1 + it), 0.9 - 0.01 * it
+        for o in (oa, ob):
+            for grp in o.param_groups:
+                grp["lr"], grp["betas"] = lr, (b1, 0.999)
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i == 3 and it % 2 == 0:
+                a.grad = b.grad = None          # no gradient this iteration: untouched, its step count stays
+                continue
+            gr = torch.randn(*a.shape, generator=g).cuda() * (10.0 if it == 2 else 1.0)
+            if i == 0:
+                pad = torch.zeros(64, 96, device="cuda")
+                pad[:, :67] = gr
+                a.grad = pad[:, :67]            # a non-contiguous view, as the padded dW images are
+            else:
+                a.grad = gr.clone()
+            b.grad = gr.clone()
+        if max_norm is None:
+            na = oa.step()
+            assert na is None
+        else:
+            na = oa.step(max_norm=max_norm)
+            nb = torch.nn.utils.clip_grad_norm_([p for p in pb if p.grad is not None], max_norm, norm_type=2)
+            assert float(na) == pytest.approx(float(nb), rel=1e-6)
+            for a, b in zip(pa, pb):            # the clipped gradients stay visible in .grad
+                if b.grad is not None:
+                    assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=1e-9)
+        ob.step()
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), (it, float((a - b).abs().max()))
+    # state_dict has torch.optim.AdamW's layout and moves both ways
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert set(sa["state"]) == set(sb["state"])
+    for k in sb["state"]:
+        assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"])
+        assert torch.allclose(sa["state"][k]["exp_avg"], sb["state"][k]["exp_avg"], rtol=1e-5, atol=1e-6)
+        assert torch.allclose(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"], rtol=1e-5, atol=1e-7)
+    pc = _opt_params(5)
+    with torch.no_grad():
+        for c, b in zip(pc, pb):
+            c.copy_(b)
+    oc = FusedAdamW(pc, lr=3e-4, weight_decay=0.01)
+    import copy
+    oc.load_state_dict(copy.deepcopy(sb))       # resume the torch run with the HIP optimizer (own state tensors)
+    for c, b in zip(pc, pb):
+        gr = torch.randn(*b.shape, generator=g).cuda()
+        c.grad, b.grad = gr.clone(), gr.clone()
+    oc.step()
+    ob.step()
+    for c, b in zip(pc, pb):
+        assert torch.allclose(c, b, rtol=1e-6, atol=1e-7)
+
+
+def test_fused_adamw_is_reproducible_and_refuses_host_tensors():
+    from pcr_amd import _lib as L
+    from pcr_amd.optim import FusedAdamW
+    outs = []
+    for _ in range(2):
+        ps = _opt_params(7)
+        o = FusedAdamW(ps, lr=1e-3)
+        g = torch.Generator().manual_seed(1)
+        for _ in range(3):
+            for p in ps:
+                p.grad = torch.randn(*p.shape, generator=g).cuda()
+            n = o.step(max_norm=1.0)
+        outs.append([p.detach().clone() for p in ps] + [n.clone()])
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    cpu = [torch.nn.Parameter(torch.randn(4))]
+    cpu[0].grad = torch.randn(4)
+    with pytest.raises(L.PcrError):
+        FusedAdamW(cpu).step()
