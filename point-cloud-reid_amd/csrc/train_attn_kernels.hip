@@ -119,6 +119,104 @@ __global__ __launch_bounds__(64) void tnorm_bwd_kernel(TNormBwd a, int B) {
   }
 }
 
+// The same two kernels for wide groups (LayerNorm over 32 .. 256 channels): FOUR waves share the 64 tokens of a block,
+// each holding a quarter of the group's channels in registers (NC per thread), and exchange their partial sums through
+// LDS.  One pass over HBM instead of three (two in the backward), and four times the waves in flight: with one wave
+// per 64 tokens a (512, 64, 128) tensor is 1024 waves on 1024 SIMDs, each waiting out its own load latency.
+template <int NC>
+__global__ __launch_bounds__(256) void tnorm_fwd4_kernel(TNorm a, int B) {
+  __shared__ float ex[2][4][64];
+  const int g = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t ft = (size_t)blockIdx.x * 64 + lane;
+  const bool ok = ft < (size_t)B * a.L;
+  const size_t b = ok ? ft / a.L : 0;
+  const int t = ok ? (int)(ft - b * a.L) : 0;
+  const int gs = 4 * NC, c0 = g * gs + w * NC;
+  const size_t base = (b * a.C + c0) * a.L + t;
+  float xv[NC];
+#pragma unroll
+  for (int i = 0; i < NC; i++) xv[i] = ok ? a.x[base + (size_t)i * a.L] : 0.f;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; i++) s += xv[i];
+  ex[0][w][lane] = s;
+  __syncthreads();
+  const float m = ((ex[0][0][lane] + ex[0][1][lane]) + (ex[0][2][lane] + ex[0][3][lane])) / (float)gs;
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; i++) {
+    const float d = xv[i] - m;
+    v += d * d;
+  }
+  ex[1][w][lane] = v;
+  __syncthreads();
+  v = (ex[1][0][lane] + ex[1][1][lane]) + (ex[1][2][lane] + ex[1][3][lane]);
+  const float r = 1.0f / sqrtf(v / (float)gs + a.eps);
+  if (!ok) return;
+  float rv[NC];
+#pragma unroll
+  for (int i = 0; i < NC; i++) rv[i] = a.res ? a.res[base + (size_t)i * a.L] : 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; i++) {
+    const float o = (xv[i] - m) * r * a.gamma[c0 + i] + a.beta[c0 + i] + rv[i];
+    a.y[base + (size_t)i * a.L] = a.relu ? fmaxf(o, 0.f) : o;
+  }
+  if (w == 0) {
+    a.mean[(b * a.G + g) * a.L + t] = m;
+    a.rstd[(b * a.G + g) * a.L + t] = r;
+  }
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void tnorm_bwd4_kernel(TNormBwd a, int B) {
+  __shared__ float ex[2][4][64];
+  const int g = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t ft = (size_t)blockIdx.x * 64 + lane;
+  const bool ok = ft < (size_t)B * a.L;
+  const size_t b = ok ? ft / a.L : 0;
+  const int t = ok ? (int)(ft - b * a.L) : 0;
+  const int gs = 4 * NC, c0 = g * gs + w * NC;
+  const size_t base = (b * a.C + c0) * a.L + t;
+  const float m = ok ? a.mean[(b * a.G + g) * a.L + t] : 0.f, r = ok ? a.rstd[(b * a.G + g) * a.L + t] : 0.f;
+  float go[NC], xh[NC];
+#pragma unroll
+  for (int i = 0; i < NC; i++) {
+    go[i] = ok ? a.g[base + (size_t)i * a.L] : 0.f;
+    xh[i] = ok ? a.x[base + (size_t)i * a.L] : m;
+  }
+  if (a.y) {
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+      if (ok && !(a.y[base + (size_t)i * a.L] > 0.f)) go[i] = 0.f;
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; i++) {
+    xh[i] = (xh[i] - m) * r;
+    const float gv = go[i] * a.gamma[c0 + i];
+    s1 += gv;
+    s2 += gv * xh[i];
+  }
+  ex[0][w][lane] = s1;
+  ex[1][w][lane] = s2;
+  __syncthreads();
+  s1 = (ex[0][0][lane] + ex[0][1][lane]) + (ex[0][2][lane] + ex[0][3][lane]);
+  s2 = (ex[1][0][lane] + ex[1][1][lane]) + (ex[1][2][lane] + ex[1][3][lane]);
+  const float inv = 1.0f / (float)gs;
+  float *part = a.part + (size_t)blockIdx.x * 2 * a.C;
+#pragma unroll
+  for (int i = 0; i < NC; i++) {
+    const int c = c0 + i;
+    if (ok) a.dx[base + (size_t)i * a.L] = r * (go[i] * a.gamma[c] - s1 * inv - xh[i] * s2 * inv);
+    if (ok && a.dres) a.dres[base + (size_t)i * a.L] = go[i];
+    const float w1 = wsum(go[i] * xh[i]), w2 = wsum(go[i]);
+    if (lane == 0) {
+      part[c] = w1;
+      part[a.C + c] = w2;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------- linear attention core ----
 // Per (cloud, head): Q' = elu(q) + 1, K' = elu(k) + 1, V' = v / S, A = sum_s K'_s V'_s^T (dh x dh), ks = sum_s K'_s,
 // out_l = (Q'_l^T A) S / (Q'_l . ks + eps)   (LinearAttention.forward, pointnet2_utils.py:26-47).
@@ -413,7 +511,14 @@ PCR_EXPORT int pcr_tnorm_fwd_f32(const float *x, const float *gamma, const float
   if (G > 65535) return PCR_ERR_INVALID;
   TNorm a{x, gamma, beta, res, y, mean, rstd, C, L, G, eps, relu};
   const unsigned nb = (unsigned)(((size_t)B * L + 63) / 64);
-  hipLaunchKernelGGL(tnorm_fwd_kernel, dim3(nb, G), dim3(64), 0, pcr_s(stream), a, B);
+  const int gs = C / G;
+  switch ((gs & 3) == 0 ? gs / 4 : 0) {
+    case 8: hipLaunchKernelGGL(tnorm_fwd4_kernel<8>, dim3(nb, G), dim3(256), 0, pcr_s(stream), a, B); break;
+    case 16: hipLaunchKernelGGL(tnorm_fwd4_kernel<16>, dim3(nb, G), dim3(256), 0, pcr_s(stream), a, B); break;
+    case 32: hipLaunchKernelGGL(tnorm_fwd4_kernel<32>, dim3(nb, G), dim3(256), 0, pcr_s(stream), a, B); break;
+    case 64: hipLaunchKernelGGL(tnorm_fwd4_kernel<64>, dim3(nb, G), dim3(256), 0, pcr_s(stream), a, B); break;
+    default: hipLaunchKernelGGL(tnorm_fwd_kernel, dim3(nb, G), dim3(64), 0, pcr_s(stream), a, B);
+  }
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }
@@ -427,7 +532,14 @@ PCR_EXPORT int pcr_tnorm_bwd_f32(const float *g, const float *x, const float *ga
   if (G > 65535) return PCR_ERR_INVALID;
   TNormBwd a{g, x, gamma, mean, rstd, dx, part, C, L, G, y_relu, dres};
   const unsigned nb = (unsigned)(((size_t)B * L + 63) / 64);
-  hipLaunchKernelGGL(tnorm_bwd_kernel, dim3(nb, G), dim3(64), 0, pcr_s(stream), a, B);
+  const int gs = C / G;
+  switch ((gs & 3) == 0 ? gs / 4 : 0) {
+    case 8: hipLaunchKernelGGL(tnorm_bwd4_kernel<8>, dim3(nb, G), dim3(256), 0, pcr_s(stream), a, B); break;
+    case 16: hipLaunchKernelGGL(tnorm_bwd4_kernel<16>, dim3(nb, G), dim3(256), 0, pcr_s(stream), a, B); break;
+    case 32: hipLaunchKernelGGL(tnorm_bwd4_kernel<32>, dim3(nb, G), dim3(256), 0, pcr_s(stream), a, B); break;
+    case 64: hipLaunchKernelGGL(tnorm_bwd4_kernel<64>, dim3(nb, G), dim3(256), 0, pcr_s(stream), a, B); break;
+    default: hipLaunchKernelGGL(tnorm_bwd_kernel, dim3(nb, G), dim3(64), 0, pcr_s(stream), a, B);
+  }
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }
