@@ -434,12 +434,13 @@ int pcr_sa_l1_fwd_f32(const float *xyz, const int *idx, const float *tab, const 
 int pcr_sa_l1_bwd_f32(const float *xyz, const int *idx, const float *g, const float *y, const float *ka,
                       const float *kb, const float *kc, float *dtab, float *dwa, int B, int N, int S, int K, int c1,
                       pcr_stream_t stream);
-/* pooled[b][c][s] = max_k relu(scale[c] y[b][c][s K + k] + shift[c]), argmax = the first k attaining it */
-int pcr_sa_pool_fwd_f32(const float *y, const float *scale, const float *shift, float *pooled, int *argmax, int B,
-                        int C, int S, int K, pcr_stream_t stream);
-/* partials [B][2][ceil32(C)] of S1 = sum gp [pooled > 0], S2 = sum gp [pooled > 0] y[argmax] for pcr_bn_bwd_finalize_f32 */
-int pcr_sa_pool_bwd_stats_f32(const float *gp, const float *pooled, const int *argmax, const float *y, float *part,
-                              int B, int C, int S, int K, pcr_stream_t stream);
+/* pooled[b][c][s] = max_k relu(scale[c] y[b][c][s K + k] + shift[c]), argmax = the first k attaining it, ymax (optional)
+ * = the raw y at that row (what the backward's BatchNorm sums need) */
+int pcr_sa_pool_fwd_f32(const float *y, const float *scale, const float *shift, float *pooled, int *argmax, float *ymax,
+                        int B, int C, int S, int K, pcr_stream_t stream);
+/* partials [B][2][ceil32(C)] of S1 = sum gp [pooled > 0], S2 = sum gp [pooled > 0] ymax for pcr_bn_bwd_finalize_f32 */
+int pcr_sa_pool_bwd_stats_f32(const float *gp, const float *pooled, const float *ymax, float *part, int B, int C, int S,
+                              pcr_stream_t stream);
 
 /* LayerNorm / GroupNorm over the channels of every token of x (B,C,L) (G groups of C/G consecutive channels; LayerNorm:
  * G = 1), y = [relu]((x - mean) rstd gamma + beta [+ res]); mean / rstd (B,G,L) are kept for the backward.  Backward: dx and

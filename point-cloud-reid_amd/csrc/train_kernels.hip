@@ -22,24 +22,28 @@ namespace {
 constexpr int kTT = 64, kTRP = 65;   // tokens per tile (TB = 2), LDS row pitch
 
 // dst[c][t] = f(c, t0 + t) for c < C, zero for rows [C, CP) and tokens beyond L.  F4(c, tg) -> four tokens
-// tg .. tg+3 (whole, aligned tiles only), F1(c, tg) -> one.  Loads are issued in batches from clamped addresses.
-template <class F4, class F1>
+// tg .. tg+3 (an aligned piece inside the row; rows of L % 4 == 0 floats: `vec`), F1(c, tg) -> one.  Loads are issued in
+// batches from clamped addresses.  A ragged last tile of a `vec` tensor is still filled by 16-byte pieces (the pieces
+// beyond L are zeros): short clouds (L = 32: every tile is ragged) took 128 dependent scalar batches per thread on the
+// 256-channel layers before, 0.5 ms of latency on a 0.07 ms launch.
+template <int U = 4, class F4, class F1>
 __device__ __forceinline__ void tile_fill(float *dst, int C, int CP, int L, int t0, bool vec, F4 f4, F1 f1) {
   constexpr int T = kTT, RP = kTRP, Q = T / 4;
-  if (vec && t0 + T <= L) {
+  if (vec) {
     const int totq = CP * Q;
-    for (int e0 = threadIdx.x; e0 < totq; e0 += 4 * kThreads) {
-      f32x4 v[4];
+    const int nq = L - t0 >= T ? Q : (L - t0) >> 2;      // valid pieces of a row
+    for (int e0 = threadIdx.x; e0 < totq; e0 += U * kThreads) {
+      f32x4 v[U];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < U; u++) {
         const int e = e0 + u * kThreads;
         const int c = e / Q, q = e - c * Q;
-        const bool ok = e < totq && c < C;
+        const bool ok = e < totq && c < C && q < nq;
         const f32x4 x = f4(ok ? c : 0, t0 + 4 * (ok ? q : 0));
         v[u] = ok ? x : f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < U; u++) {
         const int e = e0 + u * kThreads;
         if (e < totq) {
           const int c = e / Q, q = e - c * Q;
@@ -244,10 +248,12 @@ __global__ __launch_bounds__(kThreads) void tdense_fwd_kernel(TFwd a) {
         }
       }
     }
-    if (vec && valid == T) {
+    if (vec) {
       constexpr int Q = T / 4;
+      const int nq = valid >> 2;
       for (int e = tid; e < a.cout * Q; e += kThreads) {
         const int o = e / Q, q = e - o * Q;
+        if (q >= nq) continue;
         const float *xs = X + o * RP + 4 * q;
         f32x4 v = {xs[0], xs[1], xs[2], xs[3]};
         if (resb) {
@@ -602,10 +608,12 @@ __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
         }
       }
       if (a.dbg & 8) {
-      } else if (vec && valid == T) {
+      } else if (vec) {
         constexpr int Q = T / 4;
+        const int nq = valid >> 2;
         for (int e = tid; e < cin * Q; e += kThreads) {
           const int c = e / Q, q = e - c * Q;
+          if (q >= nq) continue;
           const float *ds = DY + c * RP + 4 * q, *as = AT + c * RP + 4 * q;
           f32x4 v = {ds[0], ds[1], ds[2], ds[3]};
           if (c < cin1) {
@@ -683,6 +691,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 template <int WSX, int NRX>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void tdense_bwd_kernel_o4(TBwd a) {
   tdense_bwd_body<WSX, NRX, 1, 0, 0>(a);
+}
+
+// the same with the register prefetch of the next tile (QY / QX pieces per thread)
+template <int WSX, int NRX, int QY, int QX>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void tdense_bwd_kernel_o4p(TBwd a) {
+  tdense_bwd_body<WSX, NRX, 1, QY, QX>(a);
+}
+template <int WSX, int NRX, int QY, int QX>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void tdense_bwd_kernel_o3p(TBwd a) {
+  tdense_bwd_body<WSX, NRX, 1, QY, QX>(a);
 }
 
 // ------------------------------------------------------------------- reductions / finalisers ----
@@ -975,6 +993,17 @@ PCR_EXPORT int pcr_tdense_bwd_f32(const pcr_tdense_bwd *p, pcr_stream_t stream) 
   // for the 64-channel square layers whose pieces fit the registers)
   // (measured at B = 512: 64 x 64, L = 3072: 0.94 -> 0.72 ms with four workgroups per CU; 32 x 32, L = 4096: 0.56 with
   // the prefetch variant against 0.59)
+#define PCR_TBP(KERN, WSv, NRXv, QYv, QXv)                                              \
+  do {                                                                                  \
+    static bool ok = big_lds(KERN<WSv, NRXv, QYv, QXv>);                                \
+    (void)ok;                                                                           \
+    hipLaunchKernelGGL((KERN<WSv, NRXv, QYv, QXv>), grid, blk, lds, st, a);             \
+  } while (0)
+  if (variant == 3 && rowsY == 32 && cinP == 32) PCR_TBP(tdense_bwd_kernel_o4p, 4, 1, 2, 2);
+  else if (variant == 4 && rowsY == 64 && cinP == 64) PCR_TBP(tdense_bwd_kernel_o3p, 2, 1, 4, 4);
+  else if (variant == 5 && rowsY == 64 && cinP == 64) PCR_TBP(tdense_bwd_kernel_o4p, 2, 1, 4, 4);
+  else if (variant == 6 && rowsY == 32 && cinP == 32) PCR_TBP(tdense_bwd_kernel_o3p, 4, 1, 2, 2);
+  else
   if (items <= 4 && lds <= 40 * 1024 && variant != 2 && !(rowsY == 32 && cinP == 32)) {
     if (nx == 1) PCR_TB4(4, 1);
     else PCR_TB4(2, 1);

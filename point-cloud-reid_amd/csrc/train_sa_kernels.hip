@@ -250,17 +250,23 @@ __global__ __launch_bounds__(kThreads) void sa_l1_bwd_kernel(L1BwdArgs a) {
   }
 }
 
-// max over the K rows of every centre of relu(scale * y + shift), with the winning k (first maximum)
+// max over the K rows of every centre of relu(scale * y + shift), with the winning k (first maximum) and the raw y at
+// that row (the backward's BatchNorm sums need it: a gather of B C S scattered floats otherwise).
+// One workgroup = 32 channels of one cloud, tiles of G = 192 / K centres z, z + gridDim.z, ...: the (32, G K) tile is
+// fetched by 16-byte pieces, all of a thread's loads in flight before the first LDS write, then 32 x G threads each
+// scan the K rows of one (channel, centre).  grid.z spreads a cloud's tiles over enough workgroups to fill the chip
+// (C = 32 is ONE channel block: 512 workgroups of 22 serial tiles before).
 struct PoolArgs {
   const float *y;              // (B,C,S*K) raw layer-3 output
   const float *scale, *shift;  // BatchNorm affine of this batch
   float *pooled;               // (B,C,S)
   int *argmax;                 // (B,C,S)
+  float *ymax;                 // (B,C,S) or null
   int C, S, K;
 };
 
 __global__ __launch_bounds__(kThreads) void sa_pool_fwd_kernel(PoolArgs a) {
-  constexpr int CS = 32;
+  constexpr int CS = 32, kMaxQ = 6;               // 32 channels x <= 48 pieces = 1536 pieces = 6 per thread
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int C = a.C, S = a.S, K = a.K, L = S * K;
   const int G = 192 / K > 0 ? 192 / K : 1;     // centres per staged tile
@@ -271,53 +277,87 @@ __global__ __launch_bounds__(kThreads) void sa_pool_fwd_kernel(PoolArgs a) {
   const int c0 = blockIdx.x * CS;
   const float *y = a.y + (b * C + c0) * L;
   const float sc = c0 + cl < C ? a.scale[c0 + cl] : 0.f, sh = c0 + cl < C ? a.shift[c0 + cl] : 0.f;
-  for (int s0 = 0; s0 < S; s0 += G) {
+  const bool vec = (K & 3) == 0;
+  bool first = true;
+  for (int s0 = blockIdx.z * G; s0 < S; s0 += gridDim.z * G, first = false) {
     const int ng = S - s0 < G ? S - s0 : G, nrow = ng * K;
-    if (s0) __syncthreads();
-    // (wave w stages channels w, w + 4, ...: lanes run along the rows, no index division)
-    for (int c = tid >> 6; c < CS; c += kThreads / 64) {
-      const float *src = y + (size_t)c * L + (size_t)s0 * K;
-      const bool okc = c0 + c < C;
-      for (int rr = tid & 63; rr < nrow; rr += 64) tile[c * RP + rr] = okc ? src[rr] : 0.f;
+    if (!first) __syncthreads();
+    if (vec) {
+      const int npc = nrow >> 2, totq = CS * npc;
+      f32x4 v[kMaxQ];
+#pragma unroll
+      for (int u = 0; u < kMaxQ; u++) {
+        const int e = tid + u * kThreads;
+        const int c = e / npc, q = e - c * npc;
+        const bool ok = e < totq && c0 + c < C;
+        v[u] = ok ? *reinterpret_cast<const f32x4 *>(y + (size_t)c * L + (size_t)s0 * K + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < kMaxQ; u++) {
+        const int e = tid + u * kThreads;
+        if (e < totq) {
+          const int c = e / npc, q = e - c * npc;
+          float *d = tile + c * RP + 4 * q;
+          d[0] = v[u][0];
+          d[1] = v[u][1];
+          d[2] = v[u][2];
+          d[3] = v[u][3];
+        }
+      }
+    } else {
+      // (wave w stages channels w, w + 4, ...: lanes run along the rows, no index division)
+      for (int c = tid >> 6; c < CS; c += kThreads / 64) {
+        const float *src = y + (size_t)c * L + (size_t)s0 * K;
+        const bool okc = c0 + c < C;
+        for (int rr = tid & 63; rr < nrow; rr += 64) tile[c * RP + rr] = okc ? src[rr] : 0.f;
+      }
     }
     __syncthreads();
     if (c0 + cl < C)
       for (int gc = gi; gc < ng; gc += kThreads / 32) {   // (up to 192 / K centres per tile, eight lanes of centres)
         const float *row = tile + cl * RP + gc * K;
-        float best = -INFINITY;
+        float best = -INFINITY, raw = 0.f;
         int bk = 0;
         for (int k = 0; k < K; k++) {
-          const float v = fmaxf(row[k] * sc + sh, 0.f);
+          const float r = row[k];
+          const float v = fmaxf(r * sc + sh, 0.f);
           if (v > best) {
             best = v;
             bk = k;
+            raw = r;
           }
         }
         const size_t o = (b * C + c0 + cl) * S + s0 + gc;
         a.pooled[o] = best;
         a.argmax[o] = bk;
+        if (a.ymax) a.ymax[o] = raw;
       }
   }
 }
 
-// BatchNorm-backward sums of the pooled gradient: per cloud, S1[c] = sum_s g_eff, S2[c] = sum_s g_eff * y[c][s K + argmax]
-// with g_eff = gp where pooled > 0.  Partials [B][2][ceil32(C)].
-__global__ void sa_pool_bwd_stats_kernel(const float *__restrict__ gp, const float *__restrict__ pooled,
-                                         const int *__restrict__ argmax, const float *__restrict__ y,
-                                         float *__restrict__ part, int C, int S, int K) {
-  const size_t b = blockIdx.x;
+// BatchNorm-backward sums of the pooled gradient: per cloud, S1[c] = sum_s g_eff, S2[c] = sum_s g_eff * ymax[c][s]
+// with g_eff = gp where pooled > 0 (ymax = the raw layer-3 output at the winning row, kept by the forward).
+// Partials [B][2][ceil32(C)].  One wave per (cloud, channel): lanes over the centres, fixed-order lane sums.
+__global__ __launch_bounds__(kThreads) void sa_pool_bwd_stats_kernel(const float *__restrict__ gp,
+                                                                     const float *__restrict__ pooled,
+                                                                     const float *__restrict__ ymax,
+                                                                     float *__restrict__ part, int C, int S) {
+  const size_t b = blockIdx.y;
   const int CP = ceil32(C);
-  for (int c = threadIdx.x; c < CP; c += blockDim.x) {
-    float s1 = 0.f, s2 = 0.f;
-    if (c < C) {
-      const size_t o = (b * C + c) * S;
-      const float *yr = y + (b * C + c) * (size_t)S * K;
-      for (int s = 0; s < S; s++) {
-        const float gv = pooled[o + s] > 0.f ? gp[o + s] : 0.f;
-        s1 += gv;
-        s2 += gv * yr[(size_t)s * K + argmax[o + s]];
-      }
+  const int lane = threadIdx.x & 63, c = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  if (c >= CP) return;
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C) {
+    const size_t o = (b * C + c) * S;
+    for (int s = lane; s < S; s += 64) {
+      const float gv = pooled[o + s] > 0.f ? gp[o + s] : 0.f;
+      s1 += gv;
+      s2 += gv * ymax[o + s];
     }
+  }
+  s1 = wave_sum_f(s1);
+  s2 = wave_sum_f(s2);
+  if (lane == 0) {
     part[(b * 2) * CP + c] = s1;
     part[(b * 2 + 1) * CP + c] = s2;
   }
@@ -389,23 +429,29 @@ PCR_EXPORT int pcr_sa_l1_bwd_f32(const float *xyz, const int *idx, const float *
 }
 
 PCR_EXPORT int pcr_sa_pool_fwd_f32(const float *y, const float *scale, const float *shift, float *pooled, int *argmax,
-                                   int B, int C, int S, int K, pcr_stream_t stream) {
+                                   float *ymax, int B, int C, int S, int K, pcr_stream_t stream) {
   if (!y || !scale || !shift || !pooled || !argmax || B < 0 || C < 1 || S < 1 || K < 1 || K > 192) return PCR_ERR_INVALID;
   if (B == 0) return PCR_OK;
   if (B > 65535) return PCR_ERR_INVALID;
-  PoolArgs a{y, scale, shift, pooled, argmax, C, S, K};
+  PoolArgs a{y, scale, shift, pooled, argmax, ymax, C, S, K};
   const int G = 192 / K > 0 ? 192 / K : 1;
   const size_t lds = (size_t)32 * (G * K + 1) * sizeof(float);
-  hipLaunchKernelGGL(sa_pool_fwd_kernel, dim3((C + 31) / 32, B), dim3(kThreads), lds, pcr_s(stream), a);
+  const int cb = (C + 31) / 32, tiles = (S + G - 1) / G;
+  int gz = (2048 + cb * B - 1) / (cb * B);      // ~2048 workgroups
+  gz = gz < 1 ? 1 : (gz > tiles ? tiles : gz);
+  hipLaunchKernelGGL(sa_pool_fwd_kernel, dim3(cb, B, gz), dim3(kThreads), lds, pcr_s(stream), a);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }
 
-PCR_EXPORT int pcr_sa_pool_bwd_stats_f32(const float *gp, const float *pooled, const int *argmax, const float *y,
-                                         float *part, int B, int C, int S, int K, pcr_stream_t stream) {
-  if (!gp || !pooled || !argmax || !y || !part || B < 0 || C < 1 || S < 1 || K < 1) return PCR_ERR_INVALID;
+PCR_EXPORT int pcr_sa_pool_bwd_stats_f32(const float *gp, const float *pooled, const float *ymax, float *part, int B, int C,
+                                         int S, pcr_stream_t stream) {
+  if (!gp || !pooled || !ymax || !part || B < 0 || C < 1 || S < 1) return PCR_ERR_INVALID;
   if (B == 0) return PCR_OK;
-  hipLaunchKernelGGL(sa_pool_bwd_stats_kernel, dim3(B), dim3(128), 0, pcr_s(stream), gp, pooled, argmax, y, part, C, S, K);
+  if (B > 65535) return PCR_ERR_INVALID;
+  const int CP = ceil32(C);
+  hipLaunchKernelGGL(sa_pool_bwd_stats_kernel, dim3(CP / (kThreads / 64), B), dim3(kThreads), 0, pcr_s(stream), gp, pooled,
+                     ymax, part, C, S);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }

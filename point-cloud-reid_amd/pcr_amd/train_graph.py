@@ -28,10 +28,10 @@ def _attention(m, pos, q_in, k_in, v_in, res_in, residual, fused_qkv):
     d, H = m.q_proj.weight.shape[0], m.nhead
     if fused_qkv:      # q, k, v all project the same tensor: one dense launch, slices feed the attention core
         qkv = TO.dense(q_in, torch.cat([m.q_proj.weight, m.k_proj.weight, m.v_proj.weight], dim=0))
-        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        msg = TO.LinAttnQKV.apply(qkv, H, ATTN_EPS)
     else:
         q, k, v = TO.dense(q_in, m.q_proj.weight), TO.dense(k_in, m.k_proj.weight), TO.dense(v_in, m.v_proj.weight)
-    msg = TO.LinAttn.apply(q, k, v, H, ATTN_EPS)
+        msg = TO.LinAttn.apply(q, k, v, H, ATTN_EPS)
     n1 = TO.tnorm(TO.dense(msg, m.merge.weight), m.norm1)
     f0 = TO.dense(res_in, m.mlp[0].weight, x2=n1, relu=True)
     return TO.tnorm(TO.dense(f0, m.mlp[2].weight), m.norm2, res=res_in if residual else None)
@@ -87,13 +87,24 @@ def linear_res_rows(m, x):
     return TO.tnorm(TO.dense(out, m.linear2.weight), m.norm2, res=short, relu=True)
 
 
+def _joined(a1, a2):
+    """[a1 ; a2] along the batch -- the tensor they were sliced from when they are its two halves (siamese_forward
+    returns h[:b], h[b:]): no copy, and no slice / cat nodes between the backbone and the matching stages"""
+    base = a1._base
+    if (base is not None and base is a2._base and base.is_contiguous() and base.shape[0] == 2 * a1.shape[0]
+            and base.shape[1:] == a1.shape[1:] == a2.shape[1:] and a1.is_contiguous() and a2.is_contiguous()
+            and a1.data_ptr() == base.data_ptr() and a2.data_ptr() == base.data_ptr() + a1.numel() * a1.element_size()):
+        return base
+    return torch.cat([a1, a2], dim=0)
+
+
 def match_logits(model, h1, xyz1, h2, xyz2):
     """xcorr_eff + point-cat + pool 'both' + LinearRes + Linear (ReIDNet.py:231-247, 526-534, 455-457); the four
     cross-attention calls of the reference run as two, over all 2B clouds with the halves swapped as templates"""
     b = h1.shape[0]
-    feats = torch.cat([h1, h2], dim=0)
-    xyz_cm = _cm(torch.cat([xyz1, xyz2], dim=0))
-    swap = lambda t: torch.cat([t[b:], t[:b]], dim=0)       # noqa: E731
+    feats = _joined(h1, h2)
+    xyz_cm = _cm(_joined(xyz1, xyz2))
+    swap = lambda t: torch.roll(t, b, 0)                    # noqa: E731  (halves exchanged: one launch each way)
     a = cross_attention(model.cross_stage1, feats, swap(feats), swap(xyz_cm))
     o = cross_attention(model.cross_stage2, a, swap(a), swap(xyz_cm))
     pooled = TO.PoolPair.apply(o)                                          # (B, 2C)

@@ -289,10 +289,11 @@ class SaEdgeTrain(Function):
         n3 = fin(st3, st3.shape[0], c3, g3, be3, bns[2])
         pooled = _f32(B, c3, S, device=dev)
         argmax = torch.empty((B, c3, S), dtype=torch.int32, device=dev)
+        ymax = _f32(B, c3, S, device=dev)
         with _prof("sa_pool_fwd[c=%d,S=%d,K=%d]" % (c3, S, K), 2.0 * B * Ln * c3, 4.0 * B * c3 * (Ln + 2 * S)):
             L.check(lib.pcr_sa_pool_fwd_f32(L.ptr(y3), L.ptr(n3["scale"]), L.ptr(n3["shift"]), L.ptr(pooled), L.ptr(argmax),
-                                            B, c3, S, K, L.stream_ptr()), "pcr_sa_pool_fwd_f32")
-        ctx.save_for_backward(xyz, idx, y1, y2, y3, pooled, argmax, w2, w3, g1, g2, g3)
+                                            L.ptr(ymax), B, c3, S, K, L.stream_ptr()), "pcr_sa_pool_fwd_f32")
+        ctx.save_for_backward(xyz, idx, y1, y2, y3, pooled, argmax, w2, w3, g1, g2, g3, ymax)
         ctx.norms = (n1, n2, n3)
         ctx.has_tab = tab is not None
         ctx.dims = (B, N, S, K, c1, c2, c3)
@@ -302,14 +303,14 @@ class SaEdgeTrain(Function):
     @staticmethod
     def backward(ctx, gp):
         lib = L.load()
-        xyz, idx, y1, y2, y3, pooled, argmax, w2, w3, g1, g2, g3 = ctx.saved_tensors
+        xyz, idx, y1, y2, y3, pooled, argmax, w2, w3, g1, g2, g3, ymax = ctx.saved_tensors
         n1, n2, n3 = ctx.norms
         B, N, S, K, c1, c2, c3 = ctx.dims
         Ln, R, dev = S * K, B * S * K, xyz.device
         gp = gp.contiguous()
         part3 = _f32(B, 2, _c32(c3), device=dev)
-        L.check(lib.pcr_sa_pool_bwd_stats_f32(L.ptr(gp), L.ptr(pooled), L.ptr(argmax), L.ptr(y3), L.ptr(part3), B, c3, S,
-                                              K, L.stream_ptr()), "pcr_sa_pool_bwd_stats_f32")
+        L.check(lib.pcr_sa_pool_bwd_stats_f32(L.ptr(gp), L.ptr(pooled), L.ptr(ymax), L.ptr(part3), B, c3, S,
+                                              L.stream_ptr()), "pcr_sa_pool_bwd_stats_f32")
         k3 = bn_bwd_finalize(part3, B, c3, R, g3, n3["mean"], n3["invstd"])
         r3 = tdense_bwd(gp, y2, c3, dy_mode=3, y=y3, k=k3, argmax=argmax, pooled=pooled, K=K, S=S,
                         isc=n2["scale"], ish=n2["shift"], iinv=n2["inv_scale"], in_relu=True,
@@ -364,24 +365,38 @@ def _block(t, d):
     return t.data_ptr(), t.stride(0)
 
 
+def _linattn_fwd(q, k, v, H, eps):
+    L.require_cuda(q, k, v)
+    B, d, Lq = q.shape
+    Sk = k.shape[2]
+    dev = q.device
+    out = _f32(B, d, Lq, device=dev)
+    A = _f32(B, H, d // H, d // H, device=dev)
+    ks = _f32(B, H, d // H, device=dev)
+    p = _LinAttnP()
+    p.B, p.Lq, p.Sk, p.d, p.H, p.eps = B, Lq, Sk, d, H, eps
+    (p.q, p.q_bs), (p.k, p.k_bs), (p.v, p.v_bs) = _block(q, d), _block(k, d), _block(v, d)
+    p.out, p.A, p.ks = _p(out), _p(A), _p(ks)
+    L.check(L.load().pcr_linattn_fwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_linattn_fwd_f32")
+    return out, A, ks
+
+
+def _linattn_bwd(q, k, v, A, ks, g, dq, dk, dv, H, eps):
+    B, d, Lq = q.shape
+    p = _LinAttnP()
+    p.B, p.Lq, p.Sk, p.d, p.H, p.eps = B, Lq, k.shape[2], d, H, eps
+    (p.q, p.q_bs), (p.k, p.k_bs), (p.v, p.v_bs) = _block(q, d), _block(k, d), _block(v, d)
+    p.A, p.ks, p.dout = _p(A), _p(ks), _p(g)
+    (p.dq, p.dq_bs), (p.dk, p.dk_bs), (p.dv, p.dv_bs) = _block(dq, d), _block(dk, d), _block(dv, d)
+    L.check(L.load().pcr_linattn_bwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_linattn_bwd_f32")
+
+
 class LinAttn(Function):
-    """LinearAttention (pointnet2_utils.py:26-47) on channel-major tensors: q (B,d,Lq), k, v (B,d,Sk) -> (B,d,Lq).
-    The operands may be channel slices of one fused projection; their gradients are then written into one buffer."""
+    """LinearAttention (pointnet2_utils.py:26-47) on channel-major tensors: q (B,d,Lq), k, v (B,d,Sk) -> (B,d,Lq)"""
 
     @staticmethod
     def forward(ctx, q, k, v, H, eps):
-        L.require_cuda(q, k, v)
-        B, d, Lq = q.shape
-        Sk = k.shape[2]
-        dev = q.device
-        out = _f32(B, d, Lq, device=dev)
-        A = _f32(B, H, d // H, d // H, device=dev)
-        ks = _f32(B, H, d // H, device=dev)
-        p = _LinAttnP()
-        p.B, p.Lq, p.Sk, p.d, p.H, p.eps = B, Lq, Sk, d, H, eps
-        (p.q, p.q_bs), (p.k, p.k_bs), (p.v, p.v_bs) = _block(q, d), _block(k, d), _block(v, d)
-        p.out, p.A, p.ks = _p(out), _p(A), _p(ks)
-        L.check(L.load().pcr_linattn_fwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_linattn_fwd_f32")
+        out, A, ks = _linattn_fwd(q, k, v, H, eps)
         ctx.save_for_backward(q, k, v, A, ks)
         ctx.meta = (H, eps)
         return out
@@ -390,24 +405,35 @@ class LinAttn(Function):
     def backward(ctx, g):
         q, k, v, A, ks = ctx.saved_tensors
         H, eps = ctx.meta
-        B, d, Lq = q.shape
-        Sk = k.shape[2]
-        g = g.contiguous()
-        step = d * Lq * 4
-        fused = (Lq == Sk and q.stride(0) == 3 * d * Lq and k.stride(0) == q.stride(0) and v.stride(0) == q.stride(0)
-                 and k.data_ptr() == q.data_ptr() + step and v.data_ptr() == k.data_ptr() + step)
-        if fused:     # slices [q ; k ; v] of one (B,3d,L) projection: one gradient buffer, returned through its slices
-            buf = _f32(B, 3 * d, Lq, device=q.device)
-            dq, dk, dv = buf[:, :d], buf[:, d:2 * d], buf[:, 2 * d:]
-        else:
-            dq, dk, dv = _f32(B, d, Lq, device=q.device), _f32(B, d, Sk, device=q.device), _f32(B, d, Sk, device=q.device)
-        p = _LinAttnP()
-        p.B, p.Lq, p.Sk, p.d, p.H, p.eps = B, Lq, Sk, d, H, eps
-        (p.q, p.q_bs), (p.k, p.k_bs), (p.v, p.v_bs) = _block(q, d), _block(k, d), _block(v, d)
-        p.A, p.ks, p.dout = _p(A), _p(ks), _p(g)
-        (p.dq, p.dq_bs), (p.dk, p.dk_bs), (p.dv, p.dv_bs) = _block(dq, d), _block(dk, d), _block(dv, d)
-        L.check(L.load().pcr_linattn_bwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_linattn_bwd_f32")
+        dq, dk, dv = torch.empty_like(q, memory_format=torch.contiguous_format), \
+            torch.empty_like(k, memory_format=torch.contiguous_format), torch.empty_like(v, memory_format=torch.contiguous_format)
+        _linattn_bwd(q, k, v, A, ks, g.contiguous(), dq, dk, dv, H, eps)
         return dq, dk, dv, None, None
+
+
+class LinAttnQKV(Function):
+    """the same on ONE fused projection qkv (B,3d,L) = [q ; k ; v] (self-attention): the kernels address the three
+    channel blocks by a batch stride, and the gradient comes back as one (B,3d,L) buffer -- no slice / pad / add nodes
+    in the autograd graph"""
+
+    @staticmethod
+    def forward(ctx, qkv, H, eps):
+        qkv = _dev(qkv)
+        d = qkv.shape[1] // 3
+        out, A, ks = _linattn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], H, eps)
+        ctx.save_for_backward(qkv, A, ks)
+        ctx.meta = (H, eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv, A, ks = ctx.saved_tensors
+        H, eps = ctx.meta
+        d = qkv.shape[1] // 3
+        buf = torch.empty_like(qkv)
+        _linattn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], A, ks, g.contiguous(),
+                     buf[:, :d], buf[:, d:2 * d], buf[:, 2 * d:], H, eps)
+        return buf, None, None
 
 
 class TNorm(Function):
