@@ -443,6 +443,229 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(LinAttn a) {
   }
 }
 
+// ---- the same two kernels with the small matrix products on the matrix cores (head widths 32 and 64) ----
+// Every product of the attention core is a (DH x DH) by (DH x 64 tokens) GEMM or a contraction over the 64 tokens of a
+// staged chunk.  As scalar loops each multiply-add costs two LDS reads (no register reuse): 0.40 ms for the ONE
+// dh = 64 launch of a training step (B = 512, two heads, L = 32).  v_mfma_f32_32x32x2_f32 reads the same LDS tiles
+// once per 32 x 32 output tile: acc[m][n] += sum_k A(m,k) B(n,k), one tile per wave.
+template <class AF, class BF>
+__device__ __forceinline__ f32x16 mm_tile(int K, AF af, BF bf, f32x16 acc) {
+  const int l31 = threadIdx.x & 31, h = (threadIdx.x >> 5) & 1;
+#pragma unroll 8
+  for (int ks = 0; ks < K / 2; ks++)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af(l31, 2 * ks + h), bf(l31, 2 * ks + h), acc, 0, 0, 0);
+  return acc;
+}
+template <class F>
+__device__ __forceinline__ void mm_each(const f32x16 &acc, F f) {   // f(m, n, value) over the lane's 16 results
+  const int l31 = threadIdx.x & 31, h = (threadIdx.x >> 5) & 1;
+#pragma unroll
+  for (int r = 0; r < 16; r++) f((r & 3) + 8 * (r >> 2) + 4 * h, l31, acc[r]);
+}
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; r++) z[r] = 0.f;
+  return z;
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void linattn_fwd_mfma_kernel(LinAttn a) {
+  constexpr int RP = kAT + 1, AP = DH + 1, MT = DH / 32, NT = kAT / 32;
+  __shared__ float Kt[DH * RP], Vt[DH * RP], Al[DH * AP], ksl[DH], zl[kAT];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int h = blockIdx.x;
+  const size_t b = blockIdx.y;
+  const float *q = a.q + b * a.q_bs + (size_t)h * DH * a.Lq;
+  const float *k = a.k + b * a.k_bs + (size_t)h * DH * a.Sk;
+  const float *v = a.v + b * a.v_bs + (size_t)h * DH * a.Sk;
+  const float sk = (float)a.Sk;
+  f32x16 accA = zero16();              // tile `wave` of A (MT x MT tiles; DH = 32: wave 0 only)
+  const bool a_owner = wave < MT * MT;
+  const int amt = wave / MT, ant = wave % MT;
+  float ksum = 0.f;
+  for (int s0 = 0; s0 < a.Sk; s0 += kAT) {
+    const int ns = a.Sk - s0 < kAT ? a.Sk - s0 : kAT;
+    if (s0) __syncthreads();
+    for (int e = tid; e < DH * kAT; e += 256) {
+      const int i = e / kAT, s = e - i * kAT;
+      const bool ok = s < ns;
+      Kt[i * RP + s] = ok ? elu1f(k[(size_t)i * a.Sk + s0 + s]) : 0.f;
+      Vt[i * RP + s] = ok ? v[(size_t)i * a.Sk + s0 + s] / sk : 0.f;
+    }
+    __syncthreads();
+    const int KT = ns > 32 ? 64 : 32;      // (the padding tokens are zeros)
+    if (a_owner)
+      accA = mm_tile(KT, [&](int m, int kk) { return Kt[(amt * 32 + m) * RP + kk]; },
+                     [&](int n, int kk) { return Vt[(ant * 32 + n) * RP + kk]; }, accA);
+    if (tid < DH) {
+      const float *kr = Kt + tid * RP;
+      float s = 0.f;
+      for (int t = 0; t < kAT; t++) s += kr[t];
+      ksum += s;
+    }
+  }
+  float *Ag = a.A + (b * a.H + h) * DH * DH;
+  if (a_owner)
+    mm_each(accA, [&](int m, int n, float val) {
+      const int i = amt * 32 + m, j = ant * 32 + n;
+      Al[i * AP + j] = val;
+      Ag[i * DH + j] = val;
+    });
+  if (tid < DH) {
+    ksl[tid] = ksum;
+    a.ks[(b * a.H + h) * DH + tid] = ksum;
+  }
+  float *out = a.out + (b * a.d + (size_t)h * DH) * a.Lq;
+  float *Qt = Kt;     // the key tiles are dead
+  for (int l0 = 0; l0 < a.Lq; l0 += kAT) {
+    const int nl = a.Lq - l0 < kAT ? a.Lq - l0 : kAT;
+    __syncthreads();
+    for (int e = tid; e < DH * kAT; e += 256) {
+      const int i = e / kAT, l = e - i * kAT;
+      Qt[i * RP + l] = l < nl ? elu1f(q[(size_t)i * a.Lq + l0 + l]) : 0.f;
+    }
+    __syncthreads();
+    if (tid < kAT) {
+      float z = 0.f;
+      for (int i = 0; i < DH; i++) z += Qt[i * RP + tid] * ksl[i];
+      zl[tid] = 1.0f / (z + a.eps);
+    }
+    __syncthreads();
+    for (int tile = wave; tile < MT * NT; tile += 4) {      // out[v][l] = sum_i A[i][v] Q'[i][l]
+      const int mt = tile / NT, nt = tile % NT;
+      if (nt * 32 >= nl) continue;
+      const f32x16 acc = mm_tile(DH, [&](int m, int kk) { return Al[kk * AP + mt * 32 + m]; },
+                                 [&](int n, int kk) { return Qt[kk * RP + nt * 32 + n]; }, zero16());
+      mm_each(acc, [&](int m, int n, float val) {
+        const int vv = mt * 32 + m, l = nt * 32 + n;
+        if (l < nl) out[(size_t)vv * a.Lq + l0 + l] = val * zl[l] * sk;
+      });
+    }
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void linattn_bwd_mfma_kernel(LinAttn a) {
+  constexpr int RP = kAT + 1, AP = DH + 1, MT = DH / 32, NT = kAT / 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];    // 83 KB at DH = 64: dynamic
+  float *Qt = smem, *Gt = Qt + DH * RP, *Dn = Gt + DH * RP, *Al = Dn + DH * RP, *dAl = Al + DH * AP;
+  float *ksl = dAl + DH * AP, *dksl = ksl + DH, *zl = dksl + DH, *ddl = zl + kAT;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int h = blockIdx.x;
+  const size_t b = blockIdx.y;
+  const float *q = a.q + b * a.q_bs + (size_t)h * DH * a.Lq;
+  const float *k = a.k + b * a.k_bs + (size_t)h * DH * a.Sk;
+  const float *v = a.v + b * a.v_bs + (size_t)h * DH * a.Sk;
+  const float *go = a.dout + (b * a.d + (size_t)h * DH) * a.Lq;
+  float *dq = a.dq + b * a.dq_bs + (size_t)h * DH * a.Lq;
+  float *dk = a.dk + b * a.dk_bs + (size_t)h * DH * a.Sk;
+  float *dv = a.dv + b * a.dv_bs + (size_t)h * DH * a.Sk;
+  const float sk = (float)a.Sk;
+  const float *Ag = a.A + (b * a.H + h) * DH * DH;
+  for (int e = tid; e < DH * DH; e += 256) Al[(e / DH) * AP + e % DH] = Ag[e];
+  if (tid < DH) ksl[tid] = a.ks[(b * a.H + h) * DH + tid];
+  f32x16 accdA = zero16();             // tile `wave` of dA = sum_l Q'_l dnum_l^T
+  const bool a_owner = wave < MT * MT;
+  const int amt = wave / MT, ant = wave % MT;
+  float dks = 0.f;
+  // ---- pass 1 over the query tokens: dq, and the sums dA, dks = sum_l dden_l Q'_l
+  for (int l0 = 0; l0 < a.Lq; l0 += kAT) {
+    const int nl = a.Lq - l0 < kAT ? a.Lq - l0 : kAT;
+    const int KT = nl > 32 ? 64 : 32;
+    __syncthreads();
+    for (int e = tid; e < DH * kAT; e += 256) {
+      const int i = e / kAT, l = e - i * kAT;
+      const bool ok = l < nl;
+      Qt[i * RP + l] = ok ? elu1f(q[(size_t)i * a.Lq + l0 + l]) : 0.f;
+      Gt[i * RP + l] = ok ? go[(size_t)i * a.Lq + l0 + l] : 0.f;
+    }
+    __syncthreads();
+    if (tid < kAT) {
+      float z = 0.f;
+      for (int i = 0; i < DH; i++) z += Qt[i * RP + tid] * ksl[i];
+      zl[tid] = 1.0f / (z + a.eps);
+    }
+    __syncthreads();
+    // num[v][l] = Q'_l . A[:,v];  dnum = dout z S;  dout * num * S is summed over v into dz below
+    for (int tile = wave; tile < MT * NT; tile += 4) {
+      const int mt = tile / NT, nt = tile % NT;
+      if (nt * 32 >= KT) continue;
+      const f32x16 acc = mm_tile(DH, [&](int m, int kk) { return Al[kk * AP + mt * 32 + m]; },
+                                 [&](int n, int kk) { return Qt[kk * RP + nt * 32 + n]; }, zero16());
+      mm_each(acc, [&](int m, int n, float num) {
+        const int vv = mt * 32 + m, l = nt * 32 + n;
+        const float gv = Gt[vv * RP + l];
+        Dn[vv * RP + l] = gv * zl[l] * sk;
+        Gt[vv * RP + l] = gv * num * sk;
+      });
+    }
+    __syncthreads();
+    if (tid < kAT) {
+      float dz = 0.f;
+      if (tid < KT)
+        for (int vv = 0; vv < DH; vv++) dz += Gt[vv * RP + tid];
+      ddl[tid] = -zl[tid] * zl[tid] * dz;      // gradient of the denominator Q'.ks + eps (zero on padding tokens)
+    }
+    __syncthreads();
+    for (int tile = wave; tile < MT * NT; tile += 4) {      // dq[i][l] = ddl[l] ks[i] + sum_v A[i][v] dnum[v][l]
+      const int mt = tile / NT, nt = tile % NT;
+      if (nt * 32 >= nl) continue;
+      const f32x16 acc = mm_tile(DH, [&](int m, int kk) { return Al[(mt * 32 + m) * AP + kk]; },
+                                 [&](int n, int kk) { return Dn[kk * RP + nt * 32 + n]; }, zero16());
+      mm_each(acc, [&](int m, int n, float val) {
+        const int i = mt * 32 + m, l = nt * 32 + n;
+        const float qp = Qt[i * RP + l];
+        if (l < nl) dq[(size_t)i * a.Lq + l0 + l] = (val + ddl[l] * ksl[i]) * (qp > 1.0f ? 1.0f : qp);   // elu' = 1 | Q'
+      });
+    }
+    if (a_owner)
+      accdA = mm_tile(KT, [&](int m, int kk) { return Qt[(amt * 32 + m) * RP + kk]; },
+                      [&](int n, int kk) { return Dn[(ant * 32 + n) * RP + kk]; }, accdA);
+    if (tid < DH) {
+      const float *qr = Qt + tid * RP;
+      float s = 0.f;
+      for (int t = 0; t < KT; t++) s += ddl[t] * qr[t];
+      dks += s;
+    }
+  }
+  __syncthreads();
+  if (a_owner)
+    mm_each(accdA, [&](int m, int n, float val) { dAl[(amt * 32 + m) * AP + ant * 32 + n] = val; });
+  if (tid < DH) dksl[tid] = dks;
+  // ---- pass 2 over the key tokens: dK' = dA V' + dks, dV' = dA^T K'
+  float *Kt = Qt, *Vt = Gt;
+  for (int s0 = 0; s0 < a.Sk; s0 += kAT) {
+    const int ns = a.Sk - s0 < kAT ? a.Sk - s0 : kAT;
+    __syncthreads();
+    for (int e = tid; e < DH * kAT; e += 256) {
+      const int i = e / kAT, s = e - i * kAT;
+      const bool ok = s < ns;
+      Kt[i * RP + s] = ok ? elu1f(k[(size_t)i * a.Sk + s0 + s]) : 0.f;
+      Vt[i * RP + s] = ok ? v[(size_t)i * a.Sk + s0 + s] / sk : 0.f;
+    }
+    __syncthreads();
+    for (int tile = wave; tile < MT * NT; tile += 4) {
+      const int mt = tile / NT, nt = tile % NT;
+      if (nt * 32 >= ns) continue;
+      const f32x16 ak = mm_tile(DH, [&](int m, int kk) { return dAl[(mt * 32 + m) * AP + kk]; },
+                                [&](int n, int kk) { return Vt[kk * RP + nt * 32 + n]; }, zero16());
+      const f32x16 av = mm_tile(DH, [&](int m, int kk) { return dAl[kk * AP + mt * 32 + m]; },
+                                [&](int n, int kk) { return Kt[kk * RP + nt * 32 + n]; }, zero16());
+      const int l31 = threadIdx.x & 31, hh = (threadIdx.x >> 5) & 1, s = nt * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int i = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (s < ns) {
+          const float kp = Kt[i * RP + s];
+          dk[(size_t)i * a.Sk + s0 + s] = (ak[r] + dksl[i]) * (kp > 1.0f ? 1.0f : kp);
+          dv[(size_t)i * a.Sk + s0 + s] = av[r] / sk;
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ pair pooling ----
 // o (2P,C,L): clouds p and p + P are pair p.  pooled (P,2C) = [max over the 2L points, mean over the 2L points];
 // arg (P,C) = position of the maximum in the point-concatenated pair (0 .. 2L-1, first maximum).
@@ -566,7 +789,11 @@ PCR_EXPORT int pcr_linattn_fwd_f32(const pcr_linattn *p, pcr_stream_t stream) {
   if (p->B > 65535) return PCR_ERR_INVALID;
   const LinAttn a = linattn_args(p);
   dh_dispatch(p->d / p->H, [&](auto tag) {
-    hipLaunchKernelGGL(linattn_fwd_kernel<decltype(tag)::value>, dim3(p->H, p->B), dim3(256), 0, pcr_s(stream), a);
+    constexpr int DH = decltype(tag)::value;
+    if constexpr (DH >= 32)
+      hipLaunchKernelGGL(linattn_fwd_mfma_kernel<DH>, dim3(p->H, p->B), dim3(256), 0, pcr_s(stream), a);
+    else
+      hipLaunchKernelGGL(linattn_fwd_kernel<DH>, dim3(p->H, p->B), dim3(256), 0, pcr_s(stream), a);
   });
   PCR_CHECK_LAUNCH();
   return PCR_OK;
@@ -579,10 +806,16 @@ PCR_EXPORT int pcr_linattn_bwd_f32(const pcr_linattn *p, pcr_stream_t stream) {
   const LinAttn a = linattn_args(p);
   dh_dispatch(p->d / p->H, [&](auto tag) {
     constexpr int DH = decltype(tag)::value;
-    static bool ok = allow_big_lds(linattn_bwd_kernel<DH>);
-    (void)ok;
     const size_t lds = (3 * (size_t)DH * (kAT + 1) + 2 * (size_t)DH * (DH + 1) + 2 * DH + 2 * kAT) * sizeof(float);
-    hipLaunchKernelGGL(linattn_bwd_kernel<DH>, dim3(p->H, p->B), dim3(256), lds, pcr_s(stream), a);
+    if constexpr (DH >= 32) {
+      static bool ok = allow_big_lds(linattn_bwd_mfma_kernel<DH>);
+      (void)ok;
+      hipLaunchKernelGGL(linattn_bwd_mfma_kernel<DH>, dim3(p->H, p->B), dim3(256), lds, pcr_s(stream), a);
+    } else {
+      static bool ok = allow_big_lds(linattn_bwd_kernel<DH>);
+      (void)ok;
+      hipLaunchKernelGGL(linattn_bwd_kernel<DH>, dim3(p->H, p->B), dim3(256), lds, pcr_s(stream), a);
+    }
   });
   PCR_CHECK_LAUNCH();
   return PCR_OK;

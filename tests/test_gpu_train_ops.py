@@ -132,7 +132,8 @@ def _grads(fn, tensors, go):
 
 
 @pytest.mark.parametrize("B,d,H,Lq,Sk,fused", [(3, 32, 2, 128, 128, True), (2, 64, 2, 100, 37, False), (4, 128, 2, 32, 32, True),
-                                               (2, 64, 2, 200, 64, False)])
+                                               (2, 64, 2, 200, 64, False), (2, 128, 2, 96, 96, True),
+                                               (2, 128, 2, 70, 45, False)])
 def test_linear_attention_core_matches_torch(B, d, H, Lq, Sk, fused):
     from pcr_amd import train_ops as TO
     g = torch.Generator().manual_seed(4)
@@ -141,6 +142,8 @@ def test_linear_attention_core_matches_torch(B, d, H, Lq, Sk, fused):
         go = torch.randn(B, d, Lq, generator=g).cuda()
         ours = _grads(lambda: TO.LinAttn.apply(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], H, 1e-6), [qkv], go)
         want = _grads(lambda: _t_linattn(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], H), [qkv], go)
+        one = _grads(lambda: TO.LinAttnQKV.apply(qkv, H, 1e-6), [qkv], go)       # the one-input form of the training graph
+        assert all(torch.equal(a, b) for a, b in zip(one, ours))
     else:
         q = torch.randn(B, d, Lq, generator=g).cuda().requires_grad_(True)
         k = torch.randn(B, d, Sk, generator=g).cuda().requires_grad_(True)
