@@ -693,16 +693,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))
   tdense_bwd_body<WSX, NRX, 1, 0, 0>(a);
 }
 
-// the same with the register prefetch of the next tile (QY / QX pieces per thread)
-template <int WSX, int NRX, int QY, int QX>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void tdense_bwd_kernel_o4p(TBwd a) {
-  tdense_bwd_body<WSX, NRX, 1, QY, QX>(a);
-}
-template <int WSX, int NRX, int QY, int QX>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void tdense_bwd_kernel_o3p(TBwd a) {
-  tdense_bwd_body<WSX, NRX, 1, QY, QX>(a);
-}
-
 // ------------------------------------------------------------------- reductions / finalisers ----
 // out[e] = sum over p of part[p][e] in a FIXED order (reproducible): block = 32 elements x 8 part lanes, lane pl adds
 // parts pl, pl + 8, ... on four interleaved chains, the eight lane totals are combined in lane order.  Optional row
@@ -848,6 +838,7 @@ static bool big_lds(K k) {
 static int wg_cloud_rows(int B, int gx, long part_floats = 0) {
   // (measured: letting wide layers on short clouds use fewer rows, to shrink their per-workgroup dW partials, costs
   // more in lost parallelism than the partial traffic it saves -- 0.59 -> 0.70 ms on the 256 x 256, L = 32 layer)
+  // (re-measured with the vector fill of ragged tiles: 512 .. 2048 rows are all within noise on the whole step)
   (void)part_floats;
   int r = 768 / (gx > 0 ? gx : 1);
   if (r < 1) r = 1;
@@ -993,17 +984,6 @@ PCR_EXPORT int pcr_tdense_bwd_f32(const pcr_tdense_bwd *p, pcr_stream_t stream) 
   // for the 64-channel square layers whose pieces fit the registers)
   // (measured at B = 512: 64 x 64, L = 3072: 0.94 -> 0.72 ms with four workgroups per CU; 32 x 32, L = 4096: 0.56 with
   // the prefetch variant against 0.59)
-#define PCR_TBP(KERN, WSv, NRXv, QYv, QXv)                                              \
-  do {                                                                                  \
-    static bool ok = big_lds(KERN<WSv, NRXv, QYv, QXv>);                                \
-    (void)ok;                                                                           \
-    hipLaunchKernelGGL((KERN<WSv, NRXv, QYv, QXv>), grid, blk, lds, st, a);             \
-  } while (0)
-  if (variant == 3 && rowsY == 32 && cinP == 32) PCR_TBP(tdense_bwd_kernel_o4p, 4, 1, 2, 2);
-  else if (variant == 4 && rowsY == 64 && cinP == 64) PCR_TBP(tdense_bwd_kernel_o3p, 2, 1, 4, 4);
-  else if (variant == 5 && rowsY == 64 && cinP == 64) PCR_TBP(tdense_bwd_kernel_o4p, 2, 1, 4, 4);
-  else if (variant == 6 && rowsY == 32 && cinP == 32) PCR_TBP(tdense_bwd_kernel_o3p, 4, 1, 2, 2);
-  else
   if (items <= 4 && lds <= 40 * 1024 && variant != 2 && !(rowsY == 32 && cinP == 32)) {
     if (nx == 1) PCR_TB4(4, 1);
     else PCR_TB4(2, 1);
