@@ -469,6 +469,30 @@ __device__ __forceinline__ f32x16 zero16() {
   return z;
 }
 
+// Two (DH x 64-token) tiles into LDS, every global load of a thread in flight before its first LDS write (a load ->
+// store loop serialises on the load latency: 8 .. 16 round trips per tile and tensor).
+template <int DH, class FA, class FB>
+__device__ __forceinline__ void stage_pair(float *dA, float *dB, const float *sA, const float *sB, int Lrow, int l0,
+                                           int nl, FA fa, FB fb) {
+  constexpr int RP = kAT + 1, NE = DH * kAT / 256;
+  float va[NE], vb[NE];
+#pragma unroll
+  for (int u = 0; u < NE; u++) {
+    const int e = threadIdx.x + u * 256, i = e / kAT, l = e % kAT;
+    const bool ok = l < nl;
+    const size_t o = (size_t)i * Lrow + l0 + (ok ? l : 0);
+    va[u] = sA[o];
+    vb[u] = sB ? sB[o] : 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < NE; u++) {
+    const int e = threadIdx.x + u * 256, i = e / kAT, l = e % kAT;
+    const bool ok = l < nl;
+    dA[i * RP + l] = ok ? fa(va[u]) : 0.f;
+    if (dB) dB[i * RP + l] = ok ? fb(vb[u]) : 0.f;
+  }
+}
+
 template <int DH>
 __global__ __launch_bounds__(256) void linattn_fwd_mfma_kernel(LinAttn a) {
   constexpr int RP = kAT + 1, AP = DH + 1, MT = DH / 32, NT = kAT / 32;
@@ -487,12 +511,7 @@ __global__ __launch_bounds__(256) void linattn_fwd_mfma_kernel(LinAttn a) {
   for (int s0 = 0; s0 < a.Sk; s0 += kAT) {
     const int ns = a.Sk - s0 < kAT ? a.Sk - s0 : kAT;
     if (s0) __syncthreads();
-    for (int e = tid; e < DH * kAT; e += 256) {
-      const int i = e / kAT, s = e - i * kAT;
-      const bool ok = s < ns;
-      Kt[i * RP + s] = ok ? elu1f(k[(size_t)i * a.Sk + s0 + s]) : 0.f;
-      Vt[i * RP + s] = ok ? v[(size_t)i * a.Sk + s0 + s] / sk : 0.f;
-    }
+    stage_pair<DH>(Kt, Vt, k, v, a.Sk, s0, ns, [](float x) { return elu1f(x); }, [&](float x) { return x / sk; });
     __syncthreads();
     const int KT = ns > 32 ? 64 : 32;      // (the padding tokens are zeros)
     if (a_owner)
@@ -521,10 +540,8 @@ __global__ __launch_bounds__(256) void linattn_fwd_mfma_kernel(LinAttn a) {
   for (int l0 = 0; l0 < a.Lq; l0 += kAT) {
     const int nl = a.Lq - l0 < kAT ? a.Lq - l0 : kAT;
     __syncthreads();
-    for (int e = tid; e < DH * kAT; e += 256) {
-      const int i = e / kAT, l = e - i * kAT;
-      Qt[i * RP + l] = l < nl ? elu1f(q[(size_t)i * a.Lq + l0 + l]) : 0.f;
-    }
+    stage_pair<DH>(Qt, (float *)nullptr, q, (const float *)nullptr, a.Lq, l0, nl, [](float x) { return elu1f(x); },
+                   [](float x) { return x; });
     __syncthreads();
     if (tid < kAT) {
       float z = 0.f;
@@ -563,7 +580,17 @@ __global__ __launch_bounds__(256) void linattn_bwd_mfma_kernel(LinAttn a) {
   float *dv = a.dv + b * a.dv_bs + (size_t)h * DH * a.Sk;
   const float sk = (float)a.Sk;
   const float *Ag = a.A + (b * a.H + h) * DH * DH;
-  for (int e = tid; e < DH * DH; e += 256) Al[(e / DH) * AP + e % DH] = Ag[e];
+  {
+    constexpr int NA = DH * DH / 256;
+    float va[NA];
+#pragma unroll
+    for (int u = 0; u < NA; u++) va[u] = Ag[tid + u * 256];
+#pragma unroll
+    for (int u = 0; u < NA; u++) {
+      const int e = tid + u * 256;
+      Al[(e / DH) * AP + e % DH] = va[u];
+    }
+  }
   if (tid < DH) ksl[tid] = a.ks[(b * a.H + h) * DH + tid];
   f32x16 accdA = zero16();             // tile `wave` of dA = sum_l Q'_l dnum_l^T
   const bool a_owner = wave < MT * MT;
@@ -574,12 +601,7 @@ __global__ __launch_bounds__(256) void linattn_bwd_mfma_kernel(LinAttn a) {
     const int nl = a.Lq - l0 < kAT ? a.Lq - l0 : kAT;
     const int KT = nl > 32 ? 64 : 32;
     __syncthreads();
-    for (int e = tid; e < DH * kAT; e += 256) {
-      const int i = e / kAT, l = e - i * kAT;
-      const bool ok = l < nl;
-      Qt[i * RP + l] = ok ? elu1f(q[(size_t)i * a.Lq + l0 + l]) : 0.f;
-      Gt[i * RP + l] = ok ? go[(size_t)i * a.Lq + l0 + l] : 0.f;
-    }
+    stage_pair<DH>(Qt, Gt, q, go, a.Lq, l0, nl, [](float x) { return elu1f(x); }, [](float x) { return x; });
     __syncthreads();
     if (tid < kAT) {
       float z = 0.f;
@@ -638,12 +660,7 @@ __global__ __launch_bounds__(256) void linattn_bwd_mfma_kernel(LinAttn a) {
   for (int s0 = 0; s0 < a.Sk; s0 += kAT) {
     const int ns = a.Sk - s0 < kAT ? a.Sk - s0 : kAT;
     __syncthreads();
-    for (int e = tid; e < DH * kAT; e += 256) {
-      const int i = e / kAT, s = e - i * kAT;
-      const bool ok = s < ns;
-      Kt[i * RP + s] = ok ? elu1f(k[(size_t)i * a.Sk + s0 + s]) : 0.f;
-      Vt[i * RP + s] = ok ? v[(size_t)i * a.Sk + s0 + s] / sk : 0.f;
-    }
+    stage_pair<DH>(Kt, Vt, k, v, a.Sk, s0, ns, [](float x) { return elu1f(x); }, [&](float x) { return x / sk; });
     __syncthreads();
     for (int tile = wave; tile < MT * NT; tile += 4) {
       const int mt = tile / NT, nt = tile % NT;

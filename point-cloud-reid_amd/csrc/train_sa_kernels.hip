@@ -56,11 +56,23 @@ __global__ __launch_bounds__(kThreads) void sa_l1_fwd_kernel(L1Args a) {
   const size_t b = blockIdx.y;
   const int c0 = blockIdx.x * CS;
   const float *tab = a.tab ? a.tab + b * 2 * c1 * N : nullptr;
-  if (tab)
-    for (int e = tid; e < CS * N; e += kThreads) {
-      const int c = e / N, i = e - c * N;
-      Pl[e] = c0 + c < c1 ? tab[(size_t)(c0 + c) * N + i] : 0.f;
+  if (tab) {   // (batches of eight loads in flight: a load -> LDS-store loop pays the full latency per element)
+    constexpr int U = 8;
+    for (int e0 = tid; e0 < CS * N; e0 += U * kThreads) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int e = e0 + u * kThreads;
+        const int c = e / N, i = e - c * N;
+        v[u] = (e < CS * N && c0 + c < c1) ? tab[(size_t)(c0 + c) * N + i] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int e = e0 + u * kThreads;
+        if (e < CS * N) Pl[e] = v[u];
+      }
     }
+  }
   for (int e = tid; e < 3 * N; e += kThreads) xl[e] = a.xyz[b * N * 3 + e];
   for (int e = tid; e < CS; e += kThreads) {
     const int c = c0 + e;
@@ -77,8 +89,10 @@ __global__ __launch_bounds__(kThreads) void sa_l1_fwd_kernel(L1Args a) {
   const int *idx = a.idx + b * L;
   float *y = a.y + (b * c1 + c0) * L;
   const float *Q = tab ? tab + (size_t)(c1 + c0) * N : nullptr;
+  int inext = tid < L ? idx[tid] : 0;
   for (int r = tid; r < L; r += kThreads) {
-    const int s = r / K, i = idx[r];
+    const int s = r / K, i = inext;
+    if (r + kThreads < L) inext = idx[r + kThreads];   // (the next row's index travels while this row is written)
     const float dx = xl[3 * i] - xl[3 * s], dy = xl[3 * i + 1] - xl[3 * s + 1], dz = xl[3 * i + 2] - xl[3 * s + 2];
 #pragma unroll
     for (int c = 0; c < CS; c++) {
@@ -154,8 +168,10 @@ __global__ __launch_bounds__(kThreads) void sa_l1_bwd_kernel(L1BwdArgs a) {
   // registers before the current tile is scanned, so the global round trip hides behind the scan
   constexpr int NE = (CS * TR + kThreads - 1) / kThreads;
   float pg[NE], py[NE];
+  int pi = 0;
   auto fetch = [&](int t0) {
     const int nr = L - t0 < TR ? L - t0 : TR;
+    if (tid < nr) pi = idx[t0 + tid];
 #pragma unroll
     for (int u = 0; u < NE; u++) {
       const int e = tid + u * kThreads;
@@ -171,7 +187,7 @@ __global__ __launch_bounds__(kThreads) void sa_l1_bwd_kernel(L1BwdArgs a) {
   for (int t0 = 0; t0 < L; t0 += TR) {
     const int nr = L - t0 < TR ? L - t0 : TR;
     if (tid < nr) {
-      const int r = t0 + tid, i = idx[r], s = r / K;
+      const int r = t0 + tid, i = pi, s = r / K;
       it[tid] = i;
       st[tid] = s;
       dxt[3 * tid] = xl[3 * i] - xl[3 * s];
