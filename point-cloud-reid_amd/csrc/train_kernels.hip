@@ -15,6 +15,8 @@
 // What a layer keeps for its backward is its raw output y (needed anyway: BatchNorm statistics are global, so the
 // layer below cannot be normalised before the whole layer above it exists).  All reductions are two-stage with a
 // fixed order (per-workgroup partials, then a reduce kernel): no float atomics, bit-reproducible gradients.
+#include <type_traits>
+
 #include "tile_dense.h"
 
 namespace {
@@ -509,6 +511,111 @@ __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
       d[3] = v[3];
     }
   };
+  // The fill of the variants without prefetch: 16-byte pieces in batches of four per thread, RAW loads first (clamped
+  // addresses, no data-dependent branch between them: all of a batch is in flight at once), transformation and LDS
+  // writes after.  (The lambda-per-element form compiled to one `s_waitcnt vmcnt(0)` per piece inside divergent
+  // branches: 16 serial HBM round trips per 128-channel tile.)
+  auto fill_dy = [&](auto mtag, int t0, int nq) {
+    constexpr int M = decltype(mtag)::value;
+    const int totq = rowsY * 16;
+    for (int e0 = tid; e0 < totq; e0 += 4 * kThreads) {
+      f32x4 gq[4], yq[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = e0 + u * kThreads, c = e >> 4, q = e & 15;
+        const bool ok = e < totq && c < cout && q < nq;
+        const int cc = ok ? c : 0, tg = t0 + 4 * (ok ? q : 0);
+        if constexpr (M == 3) {
+          const int sc = tg / K, k = tg - sc * K;
+          const size_t o = (size_t)cc * S + sc;
+          gq[u] = f32x4{__int_as_float(amb[o] - k), plb[o], gb[o], 0.f};
+        } else {
+          gq[u] = ld4(gb + (size_t)cc * L + tg);
+        }
+        if constexpr (M != 0) yq[u] = ld4(yb + (size_t)cc * L + tg);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = e0 + u * kThreads, c = e >> 4, q = e & 15;
+        const bool ok = e < totq && c < cout && q < nq;
+        const int cc = ok ? c : 0;
+        f32x4 g = gq[u], r;
+        if constexpr (M == 3) {
+          const int am = __float_as_int(gq[u][0]);
+          const float gv = gq[u][1] > 0.f ? gq[u][2] : 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; j++) g[j] = am == j ? gv : 0.f;
+        }
+        if constexpr (M == 0) r = g;
+        else if constexpr (M == 2) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) r[j] = yq[u][j] > 0.f ? g[j] : 0.f;
+        } else {
+          const float ka = s_ka[cc], kb = s_kb[cc], kc = s_kc[cc];
+#pragma unroll
+          for (int j = 0; j < 4; j++) r[j] = ka * g[j] + kb * yq[u][j] + kc;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) r[j] = ok ? r[j] : 0.f;
+        if (e < totq) {
+          float *d = DY + c * RP + 4 * q;
+          d[0] = r[0];
+          d[1] = r[1];
+          d[2] = r[2];
+          d[3] = r[3];
+        }
+      }
+    }
+  };
+  auto fill_x = [&](int t0, int nq) {
+    const int totq = cinP * 16;
+    for (int e0 = tid; e0 < totq; e0 += 4 * kThreads) {
+      f32x4 xq[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = e0 + u * kThreads, c = e >> 4, q = e & 15;
+        const bool ok = e < totq && c < cin && q < nq;
+        const int cc = ok ? c : 0, tg = t0 + 4 * (ok ? q : 0);
+        const float *src = cc < cin1 ? xb + (size_t)cc * L : x2b + (size_t)(cc - cin1) * L;
+        xq[u] = ld4(src + tg);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = e0 + u * kThreads, c = e >> 4, q = e & 15;
+        const bool ok = e < totq && c < cin && q < nq;
+        const int cc = ok ? c : 0;
+        const bool first = cc < cin1;
+        const int ci = first ? cc : 0;
+        const float sc = first ? s_isc[ci] : 1.f, sh = first ? s_ish[ci] : 0.f;
+        const bool rl = in_relu && aff && first;
+        f32x4 v = xq[u];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          float t = (aff && first) ? v[j] * sc + sh : v[j];
+          t = rl ? fmaxf(t, 0.f) : t;
+          v[j] = ok ? t : 0.f;
+        }
+        if (e < totq) {
+          float *d = AT + c * RP + 4 * q;
+          d[0] = v[0];
+          d[1] = v[1];
+          d[2] = v[2];
+          d[3] = v[3];
+        }
+      }
+    }
+  };
+  auto fill_vec = [&](int t0) {
+    const int nq = L - t0 >= T ? 16 : (L - t0) >> 2;
+    // (x first: its loads are independent of the mode switch and travel while the dy rows are formed)
+    fill_x(t0, nq);
+    switch (mode) {
+      case 0: fill_dy(std::integral_constant<int, 0>(), t0, nq); break;
+      case 1: fill_dy(std::integral_constant<int, 1>(), t0, nq); break;
+      case 2: fill_dy(std::integral_constant<int, 2>(), t0, nq); break;
+      default: fill_dy(std::integral_constant<int, 3>(), t0, nq); break;
+    }
+  };
   // (the prefetch path covers whole tiles of layers whose tiles are exactly QY / QX pieces per thread)
   const bool pf_ok = kPF && vec && (mode != 3 || (K & 3) == 0) && rowsY == 16 * QY && cinP == 16 * QX;
   auto whole = [&](int t0) { return pf_ok && t0 + T <= L; };
@@ -534,8 +641,9 @@ __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
     if (ti) __syncthreads();
     if (a.dbg & 16) {
     } else if (have) commit();
+    else if (vec && (mode != 3 || (K & 3) == 0)) fill_vec(t0);
     else
-    // ONE fill over both tiles (AT follows DY in LDS): the loads of dy and of the forward input are in flight together
+    // (rows that are not a multiple of four floats) ONE fill over both tiles (AT follows DY in LDS)
     tile_fill(DY, rowsY + cinP, rowsY + cinP, L, t0, vec,
               [&](int c, int tg) {
                 if (c < rowsY) return c < cout ? dy4(c, tg) : f32x4{0.f, 0.f, 0.f, 0.f};
