@@ -126,7 +126,14 @@ __global__ __launch_bounds__(64) void tnorm_bwd_kernel(TNormBwd a, int B) {
 template <int NC>
 __global__ __launch_bounds__(256) void tnorm_fwd4_kernel(TNorm a, int B) {
   __shared__ float ex[2][4][64];
-  const int g = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // gamma / beta of the group through LDS: read from global inside the store loops, every load waits behind the
+  // previous store (the compiler cannot tell that y does not alias them)
+  __shared__ float sgam[4 * NC], sbet[4 * NC];
+  const int g = blockIdx.y, lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (threadIdx.x < 4 * NC) {
+    sgam[threadIdx.x] = a.gamma[g * 4 * NC + threadIdx.x];
+    sbet[threadIdx.x] = a.beta[g * 4 * NC + threadIdx.x];
+  }
   const size_t ft = (size_t)blockIdx.x * 64 + lane;
   const bool ok = ft < (size_t)B * a.L;
   const size_t b = ok ? ft / a.L : 0;
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(256) void tnorm_fwd4_kernel(TNorm a, int B) {
   for (int i = 0; i < NC; i++) rv[i] = a.res ? a.res[base + (size_t)i * a.L] : 0.f;
 #pragma unroll
   for (int i = 0; i < NC; i++) {
-    const float o = (xv[i] - m) * r * a.gamma[c0 + i] + a.beta[c0 + i] + rv[i];
+    const float o = (xv[i] - m) * r * sgam[w * NC + i] + sbet[w * NC + i] + rv[i];
     a.y[base + (size_t)i * a.L] = a.relu ? fmaxf(o, 0.f) : o;
   }
   if (w == 0) {
@@ -170,7 +177,13 @@ __global__ __launch_bounds__(256) void tnorm_fwd4_kernel(TNorm a, int B) {
 template <int NC>
 __global__ __launch_bounds__(256) void tnorm_bwd4_kernel(TNormBwd a, int B) {
   __shared__ float ex[2][4][64];
-  const int g = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // gamma / beta of the group through LDS: read from global inside the store loops, every load waits behind the
+  // previous store (the compiler cannot tell that y does not alias them)
+  __shared__ float sgam[4 * NC];
+  const int g = blockIdx.y, lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (threadIdx.x < 4 * NC) {
+    sgam[threadIdx.x] = a.gamma[g * 4 * NC + threadIdx.x];
+  }
   const size_t ft = (size_t)blockIdx.x * 64 + lane;
   const bool ok = ft < (size_t)B * a.L;
   const size_t b = ok ? ft / a.L : 0;
@@ -179,21 +192,29 @@ __global__ __launch_bounds__(256) void tnorm_bwd4_kernel(TNormBwd a, int B) {
   const size_t base = (b * a.C + c0) * a.L + t;
   const float m = ok ? a.mean[(b * a.G + g) * a.L + t] : 0.f, r = ok ? a.rstd[(b * a.G + g) * a.L + t] : 0.f;
   float go[NC], xh[NC];
-#pragma unroll
-  for (int i = 0; i < NC; i++) {
-    go[i] = ok ? a.g[base + (size_t)i * a.L] : 0.f;
-    xh[i] = ok ? a.x[base + (size_t)i * a.L] : m;
-  }
+  const size_t base_c = ok ? base : 0;       // (clamped: the loads below are unconditional, so they all go out at once)
   if (a.y) {
 #pragma unroll
-    for (int i = 0; i < NC; i++)
-      if (ok && !(a.y[base + (size_t)i * a.L] > 0.f)) go[i] = 0.f;
+    for (int i = 0; i < NC; i++) {
+      const float gv = a.g[base_c + (size_t)i * a.L], yv = a.y[base_c + (size_t)i * a.L];
+      xh[i] = a.x[base_c + (size_t)i * a.L];
+      go[i] = (ok && yv > 0.f) ? gv : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NC; i++) {
+      const float gv = a.g[base_c + (size_t)i * a.L];
+      xh[i] = a.x[base_c + (size_t)i * a.L];
+      go[i] = ok ? gv : 0.f;
+    }
   }
+#pragma unroll
+  for (int i = 0; i < NC; i++) xh[i] = ok ? xh[i] : m;
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < NC; i++) {
     xh[i] = (xh[i] - m) * r;
-    const float gv = go[i] * a.gamma[c0 + i];
+    const float gv = go[i] * sgam[w * NC + i];
     s1 += gv;
     s2 += gv * xh[i];
   }
@@ -207,7 +228,7 @@ __global__ __launch_bounds__(256) void tnorm_bwd4_kernel(TNormBwd a, int B) {
 #pragma unroll
   for (int i = 0; i < NC; i++) {
     const int c = c0 + i;
-    if (ok) a.dx[base + (size_t)i * a.L] = r * (go[i] * a.gamma[c] - s1 * inv - xh[i] * s2 * inv);
+    if (ok) a.dx[base + (size_t)i * a.L] = r * (go[i] * sgam[w * NC + i] - s1 * inv - xh[i] * s2 * inv);
     if (ok && a.dres) a.dres[base + (size_t)i * a.L] = go[i];
     const float w1 = wsum(go[i] * xh[i]), w2 = wsum(go[i]);
     if (lane == 0) {

@@ -816,10 +816,12 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float *__restri
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int q = pl;
   for (; q + 24 < nparts; q += 32) {
-    s0 += p[(size_t)q * stride];
-    s1 += p[(size_t)(q + 8) * stride];
-    s2 += p[(size_t)(q + 16) * stride];
-    s3 += p[(size_t)(q + 24) * stride];
+    const float v0 = p[(size_t)q * stride], v1 = p[(size_t)(q + 8) * stride], v2 = p[(size_t)(q + 16) * stride],
+                v3 = p[(size_t)(q + 24) * stride];
+    s0 += v0;
+    s1 += v1;
+    s2 += v2;
+    s3 += v3;
   }
   for (; q < nparts; q += 8) s0 += p[(size_t)q * stride];
   red[pl][el] = (s0 + s1) + (s2 + s3);
@@ -847,8 +849,11 @@ __global__ __launch_bounds__(256) void reduce_parts4_kernel(const float *__restr
   for (int j = 0; j < 8; j++) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   int q = pl;
   for (; q + 224 < nparts; q += 256) {
+    f32x4 v[8];     // (all eight loads first: written as `s[j] += load` the compiler waits for each one in turn)
 #pragma unroll
-    for (int j = 0; j < 8; j++) s[j] += ld4(p + (size_t)(q + 32 * j) * stride);
+    for (int j = 0; j < 8; j++) v[j] = ld4(p + (size_t)(q + 32 * j) * stride);
+#pragma unroll
+    for (int j = 0; j < 8; j++) s[j] += v[j];
   }
   for (; q < nparts; q += 32) s[0] += ld4(p + (size_t)q * stride);
   red[pl][ql] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
@@ -1121,8 +1126,8 @@ PCR_EXPORT int pcr_tdense_bwd_f32(const pcr_tdense_bwd *p, pcr_stream_t stream) 
   static const int variant = getenv("PCR_TD_VARIANT") ? atoi(getenv("PCR_TD_VARIANT")) : 0;   // tuning aid
   // narrow layers (<= 4 dW tiles, LDS <= 40 KB): four workgroups per CU; wider ones: two per CU (with operand prefetch
   // for the 64-channel square layers whose pieces fit the registers)
-  // (measured at B = 512: 64 x 64, L = 3072: 0.94 -> 0.72 ms with four workgroups per CU; 32 x 32, L = 4096: 0.56 with
-  // the prefetch variant against 0.59)
+  // (measured at B = 512: 64 x 64, L = 3072: 0.94 -> 0.72 ms with four workgroups per CU, 0.63 with the batched fill;
+  // 32 x 32, L = 4096: 0.59 with the prefetch variant against 0.62)
   if (items <= 4 && lds <= 40 * 1024 && variant != 2 && !(rowsY == 32 && cinP == 32)) {
     if (nx == 1) PCR_TB4(4, 1);
     else PCR_TB4(2, 1);
