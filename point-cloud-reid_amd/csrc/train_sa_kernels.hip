@@ -89,27 +89,35 @@ __global__ __launch_bounds__(kThreads) void sa_l1_fwd_kernel(L1Args a) {
   const int *idx = a.idx + b * L;
   float *y = a.y + (b * c1 + c0) * L;
   const float *Q = tab ? tab + (size_t)(c1 + c0) * N : nullptr;
-  int inext = tid < L ? idx[tid] : 0;
-  for (int r = tid; r < L; r += kThreads) {
-    const int s = r / K, i = inext;
-    if (r + kThreads < L) inext = idx[r + kThreads];   // (the next row's index travels while this row is written)
-    const float dx = xl[3 * i] - xl[3 * s], dy = xl[3 * i + 1] - xl[3 * s + 1], dz = xl[3 * i + 2] - xl[3 * s + 2];
-    // the centre's table column first, all CS loads in flight: read inside the store loop each one waits behind the
-    // previous store to y (the compiler cannot rule out that y aliases the table)
-    float qv[CS];
+  // (two instantiations of the row loop: the table-less first layer must not carry the table's registers and selects)
+  auto rows = [&](auto has_tab) {
+    constexpr bool TAB = decltype(has_tab)::value;
+    int inext = tid < L ? idx[tid] : 0;
+    for (int r = tid; r < L; r += kThreads) {
+      const int s = r / K, i = inext;
+      if (r + kThreads < L) inext = idx[r + kThreads];   // (the next row's index travels while this row is written)
+      const float dx = xl[3 * i] - xl[3 * s], dy = xl[3 * i + 1] - xl[3 * s + 1], dz = xl[3 * i + 2] - xl[3 * s + 2];
+      // the centre's table column first, all CS loads in flight: read inside the store loop each one waits behind the
+      // previous store to y (the compiler cannot rule out that y aliases the table)
+      float qv[TAB ? CS : 1];
+      if constexpr (TAB) {
 #pragma unroll
-    for (int c = 0; c < CS; c++) qv[c] = (tab && c0 + c < c1) ? Q[(size_t)c * N + s] : 0.f;
+        for (int c = 0; c < CS; c++) qv[c] = c0 + c < c1 ? Q[(size_t)c * N + s] : 0.f;
+      }
 #pragma unroll
-    for (int c = 0; c < CS; c++) {
-      if (c0 + c < c1) {
-        float v = fmaf(wl[4 * c + 2], dz, fmaf(wl[4 * c + 1], dy, fmaf(wl[4 * c], dx, wl[4 * c + 3])));
-        if (tab) v += Pl[c * N + i] + qv[c];
-        y[(size_t)c * L + r] = v;
-        ssum[c] += v;
-        ssq[c] += v * v;
+      for (int c = 0; c < CS; c++) {
+        if (c0 + c < c1) {
+          float v = fmaf(wl[4 * c + 2], dz, fmaf(wl[4 * c + 1], dy, fmaf(wl[4 * c], dx, wl[4 * c + 3])));
+          if constexpr (TAB) v += Pl[c * N + i] + qv[c];
+          y[(size_t)c * L + r] = v;
+          ssum[c] += v;
+          ssq[c] += v * v;
+        }
       }
     }
-  }
+  };
+  if (tab) rows(std::true_type());
+  else rows(std::false_type());
   if (!a.stats) return;
 #pragma unroll
   for (int c = 0; c < CS; c++) {
