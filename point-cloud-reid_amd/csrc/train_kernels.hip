@@ -801,6 +801,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))
   tdense_bwd_body<WSX, NRX, 1, 0, 0>(a);
 }
 
+template <int WSX, int NRX>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void tdense_bwd_kernel_o3(TBwd a) {
+  tdense_bwd_body<WSX, NRX, 1, 0, 0>(a);
+}
+
 // ------------------------------------------------------------------- reductions / finalisers ----
 // out[e] = sum over p of part[p][e] in a FIXED order (reproducible): block = 32 elements x 8 part lanes, lane pl adds
 // parts pl, pl + 8, ... on four interleaved chains, the eight lane totals are combined in lane order.  Optional row
@@ -1128,6 +1133,12 @@ PCR_EXPORT int pcr_tdense_bwd_f32(const pcr_tdense_bwd *p, pcr_stream_t stream) 
   // for the 64-channel square layers whose pieces fit the registers)
   // (measured at B = 512: 64 x 64, L = 3072: 0.94 -> 0.72 ms with four workgroups per CU, 0.63 with the batched fill;
   // 32 x 32, L = 4096: 0.59 with the prefetch variant against 0.62)
+  // (64-wide inputs: three workgroups per CU without scratch beat four with 136 B of spills per lane, 0.61 vs 0.63 ms)
+  if (variant != 2 && items <= 4 && lds <= 40 * 1024 && nx == 2) {
+    static bool ok3 = big_lds(tdense_bwd_kernel_o3<2, 1>);
+    (void)ok3;
+    hipLaunchKernelGGL((tdense_bwd_kernel_o3<2, 1>), grid, blk, lds, st, a);
+  } else
   if (items <= 4 && lds <= 40 * 1024 && variant != 2 && !(rowsY == 32 && cinP == 32)) {
     if (nx == 1) PCR_TB4(4, 1);
     else PCR_TB4(2, 1);
