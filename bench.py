@@ -49,7 +49,8 @@ WORKLOADS = {
                     "synthetic pairs, eval (BASELINE config 1 shape)", "pointnet", 256, None, 256),
     "pt128_train": ("Point-Transformer siamese TRAINING step (BASELINE config 4 shape: nuScenes-ReID 128-pt crops, 256 pairs "
                     "per GPU): forward + backward + one-bucket gradient all-reduce + clip + AdamW (cyclic lr/beta1). Forward "
-                    "(BatchNorm batch statistics) and backward are HIP launches end to end (pcr_amd/train_ops.py)", "pt_train", 128,
+                    "(BatchNorm batch statistics), backward and the update (norm + clip + AdamW) are HIP launches end to end "
+                    "(pcr_amd/train_ops.py, optim.py)", "pt_train", 128,
                     [128, 64, 32], 256),
     "ptxcorr128": ("Point-Transformer with the baseline-orig matching (match_type='xcorr': cross -> local_self_attention "
                    "-> cross -> local; reid_waymo_pts/testing_pts_point-transformer_baseline-orig_r_waymo_det_400e.py), "
