@@ -1,0 +1,68 @@
+"""GPU: the data-parallel training pieces with DEVICE tensors -- two ranks (gloo; both on cuda:0, RCCL refuses two ranks
+on one device) run the bucketed gradient exchange (foreach pack / unpack) and the HIP norm + clip + AdamW launches;
+the result must equal one rank on the concatenated batch.  The 8-GPU RCCL run itself is the driver's."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, os.path.join(%r, "point-cloud-reid_amd"))
+    sys.path.insert(0, os.path.join(%r, "tests"))
+    import torch, torch.distributed as dist
+    from pcr_amd import shard, train
+    from pcr_amd.optim import FusedAdamW
+    import test_train_loop as T
+    rank, local, world = shard.init(backend="gloo")
+    torch.cuda.set_device(0)
+
+    def run(sharded):
+        m = T.Toy().cuda()
+        tr = train.Trainer(m, max_iters=4, lr=1e-2, grad_clip=0.5)
+        assert isinstance(tr.optimizer, FusedAdamW) and tr.fused
+        norms = []
+        for b in T._batches():
+            lo, hi = shard.shard_range(8, rank, world) if sharded else (0, 8)
+            out = tr.step(dict(x=b["x"][lo:hi].cuda(), t=b["t"][lo:hi].cuda()))
+            norms.append(float(out["grad_norm"]))
+        return m, tr, norms
+
+    class NoDist:      # the single-rank reference: same process, exchange switched off
+        def __enter__(self):
+            self.f = shard.is_dist
+            shard.is_dist = lambda: False
+        def __exit__(self, *a):
+            shard.is_dist = self.f
+    m, tr, norms = run(True)
+    assert tr.bucket.nbytes() == 4 * (6 * 8 + 8 + 8 + 1) and tr.bucket.flat.is_cuda
+    with NoDist():
+        ref, _, ref_norms = run(False)
+    for p, q in zip(m.parameters(), ref.parameters()):
+        assert torch.allclose(p, q, atol=1e-6), float((p - q).abs().max())
+    assert all(abs(a - b) < 1e-5 * max(1.0, abs(b)) for a, b in zip(norms, ref_norms)), (norms, ref_norms)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.stdout.write("rank %%d ok\\n" %% rank); sys.stdout.flush()
+""")
+
+
+def test_two_ranks_on_device_tensors(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % (ROOT, ROOT))
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
