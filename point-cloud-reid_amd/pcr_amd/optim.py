@@ -142,6 +142,11 @@ class FusedAdamW(torch.optim.Optimizer):
         L.check(lib.pcr_adamw_step_f32(tab_p, L.ptr(plan["chunk_tensor"]), L.ptr(plan["chunk_first"]),
                                        plan["n_chunks"], part, ctypes.c_float(max_norm if max_norm is not None else 0.0),
                                        L.ptr(norm) if norm is not None else None, stream), "pcr_adamw_step_f32")
+        # the kernels write through raw pointers: tell autograd / every cache keyed by Tensor._version (inference launch
+        # plans, padded biases) that these tensors changed, as an in-place torch op would
+        torch.autograd.graph.increment_version([p for i, (_, p) in enumerate(ts) if live[i]])
+        if part is not None and max_norm is not None and max_norm > 0:
+            torch.autograd.graph.increment_version([p.grad for i, (_, p) in enumerate(ts) if live[i]])
         return norm[0] if norm is not None else None
 
     # -------------------------------------------------------------- checkpoints --

@@ -83,7 +83,7 @@ class Trainer:
 
     def __init__(self, model, max_iters, lr=3e-4, weight_decay=0.01, betas=(0.9, 0.999), grad_clip=35.0,
                  cumulative_iters=1, lr_target_ratio=(10.0, 1e-4), momentum_target_ratio=(0.85 / 0.95, 1.0),
-                 cyclic_times=1, step_ratio_up=0.4):
+                 cyclic_times=1, step_ratio_up=0.4, fused=None):
         self.model = model
         self.max_iters = int(max_iters)
         self.base_lr, self.base_beta1 = float(lr), float(betas[0])
@@ -91,7 +91,9 @@ class Trainer:
         self.lr_ratio, self.mom_ratio = tuple(lr_target_ratio), tuple(momentum_target_ratio)
         self.cyclic_times, self.step_ratio_up = cyclic_times, step_ratio_up
         params = [p for p in model.parameters()]
-        if params and all(p.is_cuda for p in params):
+        if fused is None:
+            fused = bool(params) and all(p.is_cuda for p in params)
+        if fused:
             # on the GPU: norm + clip + AdamW are two HIP launches over every tensor (pcr_amd/optim.py)
             from .optim import FusedAdamW
             self.optimizer = FusedAdamW(params, lr=lr, weight_decay=weight_decay, betas=betas)

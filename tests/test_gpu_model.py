@@ -212,6 +212,45 @@ def test_trainer_overfits_a_fixed_batch():
     assert tr.bucket.nbytes() == 4 * 579425          # live gradient payload 2.32 MB
 
 
+def _hx(m, a, b):
+    xyz1, xyz2, h1, h2 = m.siamese_forward(a, b)
+    return h1, h2, xyz1, xyz2
+
+
+def test_training_steps_agree_between_the_hip_and_torch_optimizers():
+    """four Trainer iterations on the same HIP forward / backward graph, once with the HIP norm + clip + AdamW launches
+    and once with clip_grad_norm_ + torch.optim.AdamW: losses and parameters must agree.  (Guards the caches keyed by
+    Tensor._version -- padded biases, inference launch plans -- against an update that does not bump it: with stale
+    biases the two runs part after the first step.)  Then eval mode must see the trained weights."""
+    from pcr_amd import train
+    s1, s2 = T.synthetic_pairs(8, 128, seed=2, kind="randn")
+    dev = "cuda"
+    ids1 = torch.arange(8)
+    ids2 = torch.tensor([0, 1, 2, 3, 9, 9, 9, 9])
+    data = dict(sparse_1=list(s1.to(dev)), sparse_2=list(s2.to(dev)), dense_1=list(s1.to(dev)), dense_2=list(s2.to(dev)),
+                label_1=[torch.zeros(1, dtype=torch.long, device=dev)] * 8,
+                label_2=[torch.zeros(1, dtype=torch.long, device=dev)] * 8,
+                id_1=[i.view(1).to(dev) for i in ids1], id_2=[i.view(1).to(dev) for i in ids2])
+    runs = []
+    for fused in (True, False):
+        m, _ = build_pt([128, 64, 32])
+        m.train()
+        tr = train.Trainer(m, max_iters=8, lr=1e-3, grad_clip=1.0, fused=fused)
+        assert tr.fused == fused
+        losses = [float(tr.step(data)["loss"].detach()) for _ in range(4)]
+        runs.append((m, losses))
+    (ma, la), (mb, lb) = runs
+    assert la == pytest.approx(lb, rel=2e-4, abs=2e-5), (la, lb)
+    # (parameters are not compared one by one: conv biases in front of a BatchNorm have a zero true gradient, and AdamW
+    # turns their rounding noise into +-lr steps -- the FUNCTION is what must agree: losses above, eval logits below)
+    # eval after training: the launch plans are rebuilt from the updated weights
+    ma.eval(); mb.eval()
+    with torch.no_grad():
+        ea = ma.match_forward_inference(*_hx(ma, s1.to(dev), s2.to(dev)))
+        eb = mb.match_forward_inference(*_hx(mb, s1.to(dev), s2.to(dev)))
+    assert float((ea - eb).abs().max()) < 2e-3 * max(1.0, float(eb.abs().max()))
+
+
 def test_submodules_refuse_training_mode_on_the_fused_path():
     from pcr_amd._lib import PcrError
     m, _ = build_pt([128, 64, 32])

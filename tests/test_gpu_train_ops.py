@@ -329,6 +329,25 @@ def test_fused_adamw_matches_torch_adamw_and_clip(max_norm):
         assert torch.allclose(c, b, rtol=1e-6, atol=1e-7)
 
 
+def test_fused_adamw_bumps_versions_so_caches_see_the_update():
+    """the update is written through raw pointers: Tensor._version must still move, or the padded-bias cache of the
+    training launches and the inference launch plans (keyed by data_ptr + version) would keep serving old weights"""
+    from pcr_amd import engine, train_ops as TO
+    from pcr_amd.optim import FusedAdamW
+    lin = torch.nn.Linear(8, 20).cuda()
+    opt = FusedAdamW(lin.parameters(), lr=0.1)
+    v0 = [p._version for p in lin.parameters()]
+    key0 = engine.param_version(lin)
+    pad0 = TO.pad32(lin.bias, 20).clone()
+    for p in lin.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step(max_norm=1.0)
+    assert all(p._version > v for p, v in zip(lin.parameters(), v0))
+    assert engine.param_version(lin) != key0
+    pad1 = TO.pad32(lin.bias, 20)
+    assert torch.equal(pad1[:20], lin.bias.detach()) and not torch.equal(pad1, pad0)
+
+
 def test_fused_adamw_is_reproducible_and_refuses_host_tensors():
     from pcr_amd import _lib as L
     from pcr_amd.optim import FusedAdamW
