@@ -102,7 +102,10 @@ def pad32(v, n):
     # keyed by the tensor OBJECT (kept alive by the entry, so its id and storage cannot be recycled under the cache: a
     # (data_ptr, version) key returned another tensor's bias once the allocator had reused the address) and its version
     hit = _PAD_CACHE.get(id(v))
-    if hit is not None and hit[0] is v and hit[1] == v._version and hit[2].numel() == _c32(n):
+    if hit is not None and hit[0] is v and hit[2].numel() == _c32(n) and hit[2].device == v.device:
+        if hit[1] != v._version:          # updated since (optimizer step): refresh the live part in place, one small copy
+            hit[2][:n].copy_(v.detach())
+            _PAD_CACHE[id(v)] = (v, v._version, hit[2])
         return hit[2]
     out = torch.zeros(_c32(n), dtype=torch.float32, device=v.device)
     out[:n] = v.detach()
@@ -279,8 +282,11 @@ class SaEdgeTrain(Function):
             o = bn_fwd_finalize(st, nparts, C, R, gamma, beta, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
                                 bn.running_mean if bn.track_running_stats else None,
                                 bn.running_var if bn.track_running_stats else None)
-            if bn.track_running_stats and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked += 1
+            if bn.track_running_stats:
+                # (written through raw pointers by the finalize launch: keep Tensor._version honest for the caches)
+                torch.autograd.graph.increment_version([bn.running_mean, bn.running_var])
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked += 1
             return o
         n1 = fin(st1, B, c1, g1, be1, bns[0])
         y2, st2 = tdense_fwd(y1, pack_dev(w2), c2, isc=n1["scale"], ish=n1["shift"], in_relu=True, bias=b2, want_stats=True)
