@@ -291,6 +291,54 @@ def gen_train_step():
     print("train_step loss", rec["loss"], "params without grad:", len(no_grad))
 
 
+def gen_train_loop():
+    """five iterations of the REFERENCE model (its own train_step: forward with BatchNorm batch statistics, autograd
+    backward, running statistics) under torch's clip_grad_norm_ + AdamW with the cyclic lr / beta1 values of the
+    reference's schedule config: the loss trajectory, the eval-mode logits after training and one BatchNorm's running
+    statistics.  Pins the multi-step behaviour (update applied, statistics tracked, caches refreshed), which the
+    one-step fixture cannot see."""
+    from pcr_amd import train as TR
+    ref_loader.load_reference()
+    model, _ = build(PT_CFG, seed=0, backbone_list=[128, 64, 32],
+                     losses_to_use=dict(kl=False, match=True, cls=False, shape=False, fp=False, triplet=False))
+    model.train()
+    s1, s2 = T.synthetic_pairs(8, 128, seed=2, kind="randn")
+    ids1 = torch.arange(8)
+    ids2 = torch.tensor([0, 1, 2, 3, 9, 9, 9, 9])
+    data = dict(sparse_1=list(s1), sparse_2=list(s2), dense_1=list(s1), dense_2=list(s2),
+                label_1=[torch.zeros(1, dtype=torch.long)] * 8, label_2=[torch.zeros(1, dtype=torch.long)] * 8,
+                id_1=[i.view(1) for i in ids1], id_2=[i.view(1) for i in ids2])
+    iters, lr0, clip = 5, 1e-3, 1.0
+    opt = torch.optim.AdamW(model.parameters(), lr=lr0, weight_decay=0.01, betas=(0.9, 0.999))
+    losses, norms = [], []
+    for it in range(iters):
+        lr = TR.cyclic_value(lr0, it, 10)
+        b1 = TR.cyclic_value(0.9, it, 10, target_ratio=(0.85 / 0.95, 1.0))
+        for g in opt.param_groups:
+            g["lr"], g["betas"] = lr, (b1, 0.999)
+        opt.zero_grad(set_to_none=True)
+        with contextlib.redirect_stdout(io.StringIO()):
+            out = model.train_step(data, None)
+        out["loss"].backward()
+        norms.append(float(torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], clip)))
+        opt.step()
+        losses.append(float(out["loss"].item()))
+    model.eval()
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        xyz1, xyz2, h1, h2 = model.siamese_forward(s1, s2)
+        logits = model.match_forward_inference(h1, h2, xyz1, xyz2)
+    rec = dict(losses=np.array(losses, dtype=np.float64), grad_norms=np.array(norms, dtype=np.float64),
+               logits=_np(logits), head_weight=_np(model.match_head[1].weight), iters=np.int32(iters), lr=np.float64(lr0),
+               clip=np.float64(clip), max_iters=np.int32(10))
+    for i, sa in enumerate(model.backbone.SA_modules):
+        for j, bn in enumerate(sa.mlp_bns):
+            rec["bn%d%d_mean" % (i, j)] = _np(bn.running_mean)
+            rec["bn%d%d_var" % (i, j)] = _np(bn.running_var)
+            rec["bn%d%d_n" % (i, j)] = np.int64(int(bn.num_batches_tracked))
+    np.savez_compressed(os.path.join(GOLD, "pt_train_loop_n128.npz"), **rec)
+    print("train loop losses", losses, "norms", norms)
+
+
 def gen_python_twins():
     """Python twins of the dormant CUDA ops (pointnet2_utils.py:116-240) where semantics
     coincide with the .cu kernels: FPS with the start index forced to 0 (power-of-two N <= 1024,
@@ -380,6 +428,9 @@ if __name__ == "__main__":
     if "--only-baseline" in sys.argv:
         gen_baseline()
         sys.exit(0)
+    if "--only-train-loop" in sys.argv:
+        gen_train_loop()
+        sys.exit(0)
     if "--only-mul" in sys.argv:
         gen_pt_mul()
         sys.exit(0)
@@ -391,6 +442,7 @@ if __name__ == "__main__":
         gen_pt()
         gen_pointnet()
     gen_train_step()
+    gen_train_loop()
     gen_python_twins()
     gen_eval_metric()
     gen_eval_tables()
