@@ -50,6 +50,9 @@ def case_dense(rng, g):
     cin2 = int(rng.choice([0, 0, 32, 64])) if cin <= 128 else 0
     cout = int(rng.choice([1, 32, 64, 96, 128, 192, 256, 300, 384]))
     Ln = int(rng.choice([1, 4, 20, 32, 33, 64, 96, 100, 128, 200, 257, 512]))
+    if rng.integers(0, 6) == 0:       # many short clouds: a workgroup then strides over several clouds (carried dW / stats)
+        B, Ln = int(rng.choice([700, 900, 1700])), int(rng.choice([16, 32, 50, 64, 128]))
+        cin, cin2, cout = min(cin, 128), 0, min(cout, 128)
     relu = bool(rng.integers(0, 2))
     has_b = bool(rng.integers(0, 2))
     c32 = lambda v: (v + 31) // 32 * 32      # noqa: E731
@@ -78,6 +81,8 @@ def case_dense(rng, g):
 
 def case_tnorm(rng, g):
     B, Ln = int(rng.integers(1, 5)), int(rng.choice([1, 7, 32, 33, 64, 100, 128, 300]))
+    if rng.integers(0, 8) == 0:
+        B = int(rng.choice([300, 700]))
     C, G = [(32, 1), (64, 1), (128, 1), (256, 1), (96, 1), (128, 32), (256, 32), (96, 6), (40, 1)][int(rng.integers(0, 9))]   # (groups of 2 are degenerate: dx cancels to ~0)
     res, relu = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
     x = torch.randn(B, C, Ln, generator=g).cuda().requires_grad_(True)
@@ -142,7 +147,11 @@ def case_sa(rng, g):
     from mmdet3d.models.pointnet2_utils import PointNetSetAbstractionEdgeSA
     from test_gpu_train_ops import _torch_sa
     B = int(rng.integers(2, 5))
+    if rng.integers(0, 8) == 0:       # more clouds than workgroup rows
+        B = int(rng.choice([200, 400]))
     N = int(rng.choice([48, 64, 100, 128, 150, 256]))
+    if B > 100:
+        N = int(rng.choice([48, 64]))
     S = int(rng.integers(8, N + 1))
     K = int(rng.choice([8, 16, 20, 32, 48]))
     K = min(K, N)
