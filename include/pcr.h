@@ -477,6 +477,17 @@ int pcr_linattn_bwd_f32(const pcr_linattn *p, pcr_stream_t stream);
 int pcr_pool_pair_fwd_f32(const float *o, float *pooled, int *arg, int P, int C, int L, pcr_stream_t stream);
 int pcr_pool_pair_bwd_f32(const float *g, const int *arg, float *dout, int P, int C, int L, pcr_stream_t stream);
 
+/* The packed images of MANY weights in one launch (a training step re-packs every weight after the update: ~76 small
+ * launches otherwise).  descs (device): per tensor the contiguous row-major (rows x cols) matrix w and out, which
+ * receives the image of W (pcr_packed... ceil8(cols) * ceil32(rows) floats) followed by the image of W^T
+ * (ceil8(rows) * ceil32(cols) floats), as pcr_pack_weight_dev_f32(transpose = 2) lays them out. */
+typedef struct pcr_pack_desc {
+  const float *w;
+  float *out;
+  int rows, cols;
+} pcr_pack_desc;
+int pcr_pack_weights_multi_f32(const pcr_pack_desc *descs_dev, int n, pcr_stream_t stream);
+
 /* Parameter update of one iteration over EVERY parameter tensor in two launches: the global gradient norm of mmcv's
  * OptimizerHook(grad_clip=dict(max_norm, norm_type=2)) = torch.nn.utils.clip_grad_norm_, then torch.optim.AdamW's
  * step (configs_reid/_base_/schedules/cyclic_200e_lr3e-4.py:7-9; the cyclic lr / beta1 of lines 10-21 arrive as

@@ -980,6 +980,31 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, int rows, int co
   }
 }
 
+// every weight of a model in ONE launch: blockIdx.y = tensor (descriptor table on the device), both images per tensor
+struct PackDesc {      // = pcr_pack_desc
+  const float *w;
+  float *out;
+  int rows, cols;
+};
+static_assert(sizeof(PackDesc) == sizeof(pcr_pack_desc), "pcr_pack_desc layout");
+
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackDesc *__restrict__ descs) {
+  const PackDesc d = descs[blockIdx.y];
+  const int rows = d.rows, cols = d.cols;
+  const int n0 = ceil8(cols) * ceil32(rows), n1 = ceil8(rows) * ceil32(cols);
+  for (int e0 = blockIdx.x * blockDim.x + threadIdx.x; e0 < n0 + n1; e0 += gridDim.x * blockDim.x) {
+    const bool tr = e0 >= n0;
+    const int e = tr ? e0 - n0 : e0;
+    const int cout = tr ? cols : rows, cin = tr ? rows : cols;
+    const int OP = ceil32(cout);
+    const int j = e & 3, hh = (e >> 2) & 1, o = (e >> 3) % OP, kb = (e >> 3) / OP;
+    const int k = kb * 8 + 2 * j + hh;
+    float v = 0.f;
+    if (o < cout && k < cin) v = tr ? d.w[(size_t)k * cols + o] : d.w[(size_t)o * cols + k];
+    d.out[e0] = v;
+  }
+}
+
 template <class K>
 static bool big_lds(K k) {
   return allow_big_lds(k);
@@ -1033,6 +1058,15 @@ PCR_EXPORT int pcr_pack_weight_dev_f32(const float *w, int rows, int cols, int l
   const int total = transpose == 2 ? n0 + n1 : (transpose ? n1 : n0);
   hipLaunchKernelGGL(pack_weight_kernel, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0,
                      pcr_s(stream), w, rows, cols, ld, transpose, packed);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_pack_weights_multi_f32(const pcr_pack_desc *descs_dev, int n, pcr_stream_t stream) {
+  if (!descs_dev || n < 0 || n > 65535) return PCR_ERR_INVALID;
+  if (n == 0) return PCR_OK;
+  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(8, n), dim3(256), 0, pcr_s(stream),
+                     reinterpret_cast<const PackDesc *>(descs_dev));
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }

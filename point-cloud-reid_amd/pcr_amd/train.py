@@ -125,6 +125,9 @@ class Trainer:
         lr, b1 = self._set_hyper()
         if self.iter % self.cumulative_iters == 0:
             self.optimizer.zero_grad(set_to_none=True)
+        if self.fused:
+            from . import train_ops
+            train_ops.prepack(self.model)      # every weight's packed images in one launch (they changed last step)
         out = self.model.train_step(data, self.optimizer)
         (out["loss"] / self.cumulative_iters).backward()
         out["lr"], out["beta1"] = lr, b1

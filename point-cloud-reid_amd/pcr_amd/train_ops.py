@@ -68,9 +68,69 @@ def _dev(t):
 
 
 # ------------------------------------------------------------------------------------------- launches --
+class _Prepack:
+    """Packed images (W and W^T) of every conv / linear weight of a model, refreshed by ONE launch per optimizer step
+    (`prepack(model)`, called by the Trainer) instead of one small launch per layer.  Looked up by storage address +
+    shape + Tensor._version: a weight that was not registered, or that changed since the refresh, simply misses and is
+    packed on the spot."""
+
+    def __init__(self):
+        self.key = None
+        self.entries = {}          # data_ptr -> [param, rows, cols, version, wp, wpT]
+        self.descs = None
+        self.params = []
+
+    def build(self, params):
+        import numpy as np
+        dev = params[0].device
+        self.params = params
+        self.entries = {}
+        desc = np.zeros(len(params), dtype=np.dtype([("w", "<u8"), ("out", "<u8"), ("rows", "<i4"), ("cols", "<i4")]))
+        for i, p in enumerate(params):
+            rows, cols = p.shape[0], p.numel() // p.shape[0]
+            n0, n1 = _c8(cols) * _c32(rows), _c8(rows) * _c32(cols)
+            out = _f32(n0 + n1, device=dev)
+            desc[i] = (p.data_ptr(), out.data_ptr(), rows, cols)
+            self.entries[p.data_ptr()] = [p, rows, cols, -1, out[:n0], out[n0:]]
+        self.descs = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
+        self.key = tuple(id(p) for p in params)
+
+    def refresh(self, params):
+        params = [p for p in params if p.is_cuda and p.dim() >= 2 and p.dtype == torch.float32 and p.is_contiguous()]
+        if not params:
+            return
+        if self.key != tuple(id(p) for p in params) or any(e[0].data_ptr() != k for k, e in self.entries.items()):
+            self.build(params)
+        L.check(L.load().pcr_pack_weights_multi_f32(ctypes.c_void_p(self.descs.data_ptr()), len(params), L.stream_ptr()),
+                "pcr_pack_weights_multi_f32")
+        for e in self.entries.values():
+            e[3] = e[0]._version
+
+    def lookup(self, w):
+        e = self.entries.get(w.data_ptr())
+        if e is None or e[3] != w._version or w.dim() != 2 or w.shape[0] != e[1] or w.shape[1] != e[2] or \
+                not w.is_contiguous():
+            return None
+        return e[4], e[5]
+
+
+_PREPACK = _Prepack()
+
+
+def prepack(model):
+    """refresh the packed images of every conv / linear weight of `model` in one launch (Trainer.step calls this once
+    per iteration, after the previous update); pack_dev / pack_both then hit the cache"""
+    ws = [m.weight for m in model.modules()
+          if isinstance(m, (torch.nn.Linear, torch.nn.Conv1d, torch.nn.Conv2d)) and m.weight is not None]
+    _PREPACK.refresh(ws)
+
+
 def pack_dev(w, transpose=False):
     """(rows, cols) device matrix -> packed MFMA A-operand image of W or W^T (weights change every step, so the
     pack runs on the device; inference packs once on the host)"""
+    hit = _PREPACK.lookup(w)
+    if hit is not None:
+        return hit[1] if transpose else hit[0]
     w = _dev(w.detach())
     rows, cols = w.shape
     cout, cin = (cols, rows) if transpose else (rows, cols)
@@ -82,6 +142,9 @@ def pack_dev(w, transpose=False):
 
 def pack_both(w):
     """-> (image of W, image of W^T) from ONE launch (forward and backward operands of a layer)"""
+    hit = _PREPACK.lookup(w)
+    if hit is not None:
+        return hit
     w = _dev(w.detach())
     rows, cols = w.shape
     n0, n1 = _c8(cols) * _c32(rows), _c8(rows) * _c32(cols)
