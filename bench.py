@@ -214,14 +214,17 @@ def train_bench(args, desc, n, bl, pairs, rank, world):
     dt, out = shard.timed(lambda: tr.step(data)["loss"].detach(), args.steps, args.warmup,
                           sync=torch.cuda.synchronize, device="cuda")
     assert torch.isfinite(out).all()
+    # per-launch device times of one more step (events on the launch stream): the dominant TRAINING launch.  EVERY rank
+    # runs that step (it contains the gradient all-reduce: rank 0 alone would wait for the others forever); only rank
+    # 0 records it
+    from pcr_amd import engine
+    clk = clock_probe() if rank == 0 else None
+    if rank == 0:
+        engine.PROFILE = []
+    tr.step(data)
+    torch.cuda.synchronize()
     if rank == 0:
         tr.bucket._layout()
-        # per-launch device times of one more step (events on the launch stream): the dominant TRAINING launch
-        from pcr_amd import engine
-        clk = clock_probe()
-        engine.PROFILE = []
-        tr.step(data)
-        torch.cuda.synchronize()
         rec, engine.PROFILE = engine.PROFILE, None
         tot = {}
         for name, e0, e1, flops, nbytes, _ in rec:
@@ -481,8 +484,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     from pcr_amd import shard
     rank, local, world = shard.env_world()
+    # (test hooks, tests/test_gpu_distributed.py: RCCL refuses two ranks on one device, so the multi-rank code path is
+    # exercised on a 1-GPU box with every rank on cuda:0 over gloo; the driver's runs use neither variable)
+    if os.environ.get("PCR_BENCH_TEST_SAME_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
-    shard.init(backend="nccl", device=torch.device("cuda", local))       # "nccl" is RCCL on ROCm
+    shard.init(backend=os.environ.get("PCR_BENCH_TEST_BACKEND", "nccl"),       # "nccl" is RCCL on ROCm
+               device=torch.device("cuda", local))
     if shard.is_dist():
         import torch.distributed as dist
         assert dist.get_world_size() == args.gpus

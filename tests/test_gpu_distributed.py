@@ -66,3 +66,26 @@ def test_two_ranks_on_device_tensors(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+@pytest.mark.parametrize("workload", ["pt128", "pt128_train"])
+def test_bench_runs_two_ranks_on_the_gpu(workload):
+    """bench.py's multi-rank path end to end on the GPU (pair sharding, barriers, max-over-ranks timing, rank 0's JSON
+    line, the gradient bucket under the training workload): two ranks on cuda:0 over gloo through the test hooks"""
+    import json
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PCR_BENCH_TEST_BACKEND="gloo",
+               PCR_BENCH_TEST_SAME_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--steps", "2", "--warmup", "1", "--workload", workload, "--pairs", "32", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and "roofline" in d
+    assert d["config"].get("rccl_ranks", 2) == 2
