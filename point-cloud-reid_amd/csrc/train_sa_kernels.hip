@@ -215,16 +215,15 @@ __global__ __launch_bounds__(kThreads) void sa_l1_bwd_kernel(L1BwdArgs a) {
       if (rr < nr && c0 + c < c1) v = a.ka[c0 + c] * pg[u] + a.kb[c0 + c] * py[u] + a.kc[c0 + c];
       if (e < CS * TR) dyt[c * (TR + 1) + rr] = v;
     }
-    // per owner class p: which rows of this tile gather a point / belong to a centre congruent to p (one ballot each by
-    // wave 0): an owner then visits ITS rows only (~1/PARTS of them), in row order
+    // per owner class p: which rows of this tile gather a point congruent to p (one ballot by wave 0): an owner then
+    // visits ITS rows only (~1/PARTS of them), in row order
     if (tid < 64) {
-      const int iv = tid < nr ? it[tid] : -1, sv = tid < nr ? st[tid] : -1;
+      const int iv = tid < nr ? it[tid] : -1;
 #pragma unroll
       for (int p = 0; p < PARTS; p++) {
-        const unsigned long long mp = __ballot(iv >= 0 && (iv % PARTS) == p), mq = __ballot(sv >= 0 && (sv % PARTS) == p);
+        const unsigned long long mp = __ballot(iv >= 0 && (iv % PARTS) == p);
         if (tid == 0) {
           msk[2 * p] = mp;
-          msk[2 * p + 1] = mq;
         }
       }
     }
@@ -246,11 +245,17 @@ __global__ __launch_bounds__(kThreads) void sa_l1_bwd_kernel(L1BwdArgs a) {
           m &= m - 1;
           dP[cl * NP + it[rr]] += row[rr];
         }
-        m = msk[2 * part + 1];
-        while (m) {
-          const int rr = __builtin_ctzll(m);
-          m &= m - 1;
-          dQ[cl * SP + st[rr]] += row[rr];
+        // centre sums: the rows of a centre are CONTIGUOUS (K per centre), so the tile holds at most 64 / K + 2 segments;
+        // owner class j mod PARTS adds segment j's rows in a register (independent LDS reads) and touches dQ once.
+        // (Scattering them row by row like the points above put all K rows of a centre on ONE owner: a chain of K
+        // dependent LDS read-modify-writes per tile, ~14 k cycles at K = 48, with the other seven owners idle.)
+        const int s_first = st[0], nseg = st[nr - 1] - s_first + 1;
+        for (int j = part; j < nseg; j += PARTS) {
+          const int s = s_first + j;
+          const int lo = s * K - t0 > 0 ? s * K - t0 : 0, hi = (s + 1) * K - t0 < nr ? (s + 1) * K - t0 : nr;
+          float acc = 0.f;
+          for (int rr = lo; rr < hi; rr++) acc += row[rr];
+          dQ[cl * SP + s] += acc;
         }
       }
     }
