@@ -47,6 +47,10 @@ WORKLOADS = {
                 "-> Conv1d 64; D-FPS + ball query), 1024-pt synthetic pairs, eval", "ssg", 1024, None, 2048),
     "pointnet256": ("PointNet ReIDNet (configs_reid/_base_/reidentifiers/reid_pts_pointnet_point-cat.py), 256-pt "
                     "synthetic pairs, eval (BASELINE config 1 shape)", "pointnet", 256, None, 256),
+    "gallery128": ("amortised gallery matching (SURVEY 8f rank 1; forward_inference ReIDNet.py:189-191 + "
+                   "match_forward_inference :444-462, the tracker use-case): G tracks x G detections of 128 pts -- every "
+                   "object is encoded ONCE, then all G*G combinations go through the matching head (match_gallery); "
+                   "`pairs` = G*G comparisons per GPU per step", "gallery", 128, [128, 64, 32], 192 * 192),
     "pt128_train": ("Point-Transformer siamese TRAINING step (BASELINE config 4 shape: nuScenes-ReID 128-pt crops, 256 pairs "
                     "per GPU): forward + backward + one-bucket gradient all-reduce + clip + AdamW (cyclic lr/beta1). Forward "
                     "(BatchNorm batch statistics), backward and the update (norm + clip + AdamW) are HIP launches end to end "
@@ -130,14 +134,17 @@ def hot_path(model, s1, s2):
     return model.match_forward_inference(h1, h2, xyz1, xyz2)
 
 
-def profile_kernels(model, s1, s2, reps=3, detail=False):
+def profile_kernels(model, s1, s2, reps=3, detail=False, fn=None):
     """per-launch device time with events on the launch stream; returns the dominant launch"""
     from pcr_amd import engine
     best = None
     for _ in range(reps):
         engine.PROFILE = []
         with torch.no_grad():
-            hot_path(model, s1, s2)
+            if fn is not None:
+                fn()
+            else:
+                hot_path(model, s1, s2)
         torch.cuda.synchronize()
         rec = engine.PROFILE
         engine.PROFILE = None
@@ -308,10 +315,10 @@ def ssg_fill(model, s1):
     return fill
 
 
-def roofline_of(model, s1, s2, workload, pairs):
+def roofline_of(model, s1, s2, workload, pairs, fn=None):
     """per-launch device times (events on the launch stream); the roofline object describes the single most
     expensive LAUNCH"""
-    prof = profile_kernels(model, s1, s2, detail=True)
+    prof = profile_kernels(model, s1, s2, detail=True, fn=fn)
     dom = max(prof, key=lambda k: prof[k][0] / prof[k][1])
     ms, cnt, flops, nbytes, exec_flops = prof[dom]
     step_ms_kern = sum(v[0] for v in prof.values())
@@ -412,6 +419,72 @@ def measure(workload, args, rank, world, pairs=None, cloud_kind=None, skip_repea
     return rec, sd
 
 
+def gallery_bench(args, desc, n, bl, pairs, rank, world):
+    """G tracks x G detections; encode the 2G objects once, score all G*G combinations"""
+    from pcr_amd import shard
+    from pcr_amd import testing as T
+    G = max(1, int(round(pairs ** 0.5)))
+    P = G * G
+    model, sd = build_pt_model(bl)
+    clouds = T.synthetic_clouds(2 * G, n, seed=1234 + rank, kind="randn").cuda()
+    ii, jj = torch.meshgrid(torch.arange(G), torch.arange(G, 2 * G), indexing="ij")
+    combos = torch.stack([ii.reshape(-1), jj.reshape(-1)], dim=1).cuda()
+
+    def step():
+        xyz, h = model.forward_inference(clouds)
+        return model.match_gallery(h, xyz, combos)
+    with torch.no_grad():
+        dt, out = shard.timed(step, args.steps, args.warmup, sync=torch.cuda.synchronize, device="cuda")
+    assert torch.isfinite(out).all() and out.numel() == P
+    if rank == 0:
+        clk = clock_probe()
+        roof, _ = roofline_of(None, None, None, "gallery128", P, fn=step)
+        add_clock(roof, clk)
+        line = {"metric": "siamese pair-comparisons/sec @%d pts (gallery: every object encoded once)" % n,
+                "value": world * P * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic (randn clouds, seeded random-init weights with non-trivial BN statistics)",
+                "config": {"workload": "gallery128: %s" % desc, "pairs_per_gpu_per_step": P, "objects_per_gpu_per_step": 2 * G,
+                           "points": n, "backbone_list": bl, "parallelism": "independent galleries x%d" % world,
+                           "rccl_ranks": world},
+                "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = gallery_cpu_baseline(sd, n, bl, G)
+        print(json.dumps(line), flush=True)
+    if shard.is_dist():
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def gallery_cpu_baseline(sd, n, bl, G, budget_s=20.0):
+    """the torch restatement on the host: encode 8 objects, match 16 combinations, project to the job's shape
+    (2G encodes + G*G matches) -- the CPU cannot run 36 k comparisons in a bench's time"""
+    import time
+    import model_oracle as MO
+    from pcr_amd import testing as T
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(32, avail))
+    torch.set_num_threads(threads)
+    clouds = T.synthetic_clouds(8, n, seed=1234, kind="randn")
+    pairs = torch.tensor([[i, (i + 1 + k) % 8] for i in range(8) for k in range(2)])
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        _, h = MO.pt_backbone(MO._sub(sd, "backbone."), clouds, bl)
+        t_enc = (time.perf_counter() - t0) / 8
+        t0 = time.perf_counter()
+        MO.match(sd, h[pairs[:, 0]], clouds[pairs[:, 0]], h[pairs[:, 1]], clouds[pairs[:, 1]])
+        t_match = (time.perf_counter() - t0) / len(pairs)
+    P = G * G
+    return {"value": P / (2 * G * t_enc + P * t_match), "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": "8 objects encoded + 16 combinations matched by the torch eager fp32 restatement "
+                      "(oracle/model_oracle.py), projected to 2G = %d encodes + G*G = %d matches per step" % (2 * G, P)}
+
+
 def launch_ranks(args, argv):
     """`--gpus N` without a torchrun environment: this process has not touched the GPU (nothing here calls into HIP
     before this point) and never will -- it starts N fresh ranks with torch.distributed.run as CHILD processes,
@@ -498,6 +571,8 @@ def main():
     desc, kind, n, bl, dpairs = WORKLOADS[args.workload]
     if kind == "pt_train":
         return train_bench(args, desc, n, bl, args.pairs or dpairs, rank, world)
+    if kind == "gallery":
+        return gallery_bench(args, desc, n, bl, args.pairs or dpairs, rank, world)
 
     rec, sd = measure(args.workload, args, rank, world, pairs=args.pairs or None, cloud_kind=args.clouds,
                       skip_repeats=not args.full_groups)

@@ -292,19 +292,27 @@ class ReIDNet(nn.Module):
         if self.match_type != "xcorr_eff" or self.combine != "point-cat" or self.pool_type != "both":
             raise NotImplementedError("match_gallery covers the xcorr_eff / point-cat / both matching head")
         h, xyz = h.contiguous(), xyz.contiguous()
-        n_pairs, n_pts = pairs.shape[0], h.shape[2]
-        i = pairs[:, 0].to(device=h.device, dtype=torch.int32)
-        j = pairs[:, 1].to(device=h.device, dtype=torch.int32)
-        q_idx = torch.cat([i, j]).contiguous()            # virtual cloud b < P: object i queries object j ...
-        k_idx = torch.cat([j, i]).contiguous()            # ... and b >= P: object j queries object i
+        n_pts = h.shape[2]
         p1 = self.cross_stage1.plan(h.device)
-        s1 = p1.apply(h, None, p1.kv(h, xyz), n_pts, kv_index=k_idx, q_index=q_idx, n_out=2 * n_pairs)
-        xyz_v = xyz.index_select(0, q_idx.long()).contiguous()
-        partner = torch.cat([torch.arange(n_pairs, 2 * n_pairs), torch.arange(0, n_pairs)]).to(
-            device=h.device, dtype=torch.int32)
         p2 = self.cross_stage2.plan(h.device)
-        o = p2.apply(s1, None, p2.kv(s1, xyz_v), n_pts, kv_index=partner)
-        return self._head(o.device).run(o)
+        kv1 = p1.kv(h, xyz)                                  # stage-1 key/value state: once per OBJECT
+        out = []
+        # the launches index clouds by a 16-bit grid dimension: at most 32 k pairs (64 k virtual clouds) per pass
+        chunk = 32000
+        for lo in range(0, pairs.shape[0], chunk):
+            pc = pairs[lo:lo + chunk]
+            n_pairs = pc.shape[0]
+            i = pc[:, 0].to(device=h.device, dtype=torch.int32)
+            j = pc[:, 1].to(device=h.device, dtype=torch.int32)
+            q_idx = torch.cat([i, j]).contiguous()        # virtual cloud b < P: object i queries object j ...
+            k_idx = torch.cat([j, i]).contiguous()        # ... and b >= P: object j queries object i
+            s1 = p1.apply(h, None, kv1, n_pts, kv_index=k_idx, q_index=q_idx, n_out=2 * n_pairs)
+            xyz_v = xyz.index_select(0, q_idx.long()).contiguous()
+            partner = torch.cat([torch.arange(n_pairs, 2 * n_pairs), torch.arange(0, n_pairs)]).to(
+                device=h.device, dtype=torch.int32)
+            o = p2.apply(s1, None, p2.kv(s1, xyz_v), n_pts, kv_index=partner)
+            out.append(self._head(o.device).run(o))
+        return out[0] if len(out) == 1 else torch.cat(out, dim=0)
 
     def get_match_supervision(self, h1, h2, xyz1, xyz2, id_1, id_2):
         return h1, h2, xyz1, xyz2, (id_1 == id_2).float()

@@ -381,6 +381,13 @@ def test_match_gallery_equals_pairwise_matching():
         want = MO.match(sd, href[pairs[:, 0]], clouds[pairs[:, 0]], href[pairs[:, 1]], clouds[pairs[:, 1]])
     assert float((got - direct).abs().max()) < 1e-5
     assert float((got - want).abs().max()) < TOL
+    # more combinations than one pass takes (the launches index clouds by a 16-bit grid dimension): chunked, same values
+    many = torch.stack([torch.arange(70000) % 6, (torch.arange(70000) * 7 + 1) % 6], dim=1)
+    with torch.no_grad():
+        big = m.match_gallery(h, xyz, many).cpu()
+        ref = m.match_gallery(h, xyz, many[:36]).cpu()
+    assert big.shape == (70000,) and torch.equal(big[:36], ref)
+    assert torch.equal(big[66006:66042], big[:36])        # (the pattern of combinations repeats every 6 rows: second pass)
 
 
 @pytest.mark.parametrize("match_type,combine", [("xcorr_eff", "add"), ("xcorr_eff", "minus"), ("xcorr-baseline", "cat"),
