@@ -312,6 +312,8 @@ class ReIDNet(nn.Module):
                 device=h.device, dtype=torch.int32)
             o = p2.apply(s1, None, p2.kv(s1, xyz_v), n_pts, kv_index=partner)
             out.append(self._head(o.device).run(o))
+        if not out:
+            return torch.empty(0, dtype=torch.float32, device=h.device)
         return out[0] if len(out) == 1 else torch.cat(out, dim=0)
 
     def get_match_supervision(self, h1, h2, xyz1, xyz2, id_1, id_2):

@@ -428,6 +428,7 @@ def test_match_gallery_equals_pairwise_matching():
     with torch.no_grad():
         big = m.match_gallery(h, xyz, many).cpu()
         ref = m.match_gallery(h, xyz, many[:36]).cpu()
+    assert m.match_gallery(h, xyz, many[:0]).shape == (0,)
     assert big.shape == (70000,) and torch.equal(big[:36], ref)
     assert torch.equal(big[66006:66042], big[:36])        # (the pattern of combinations repeats every 6 rows: second pass)
 
