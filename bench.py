@@ -200,12 +200,14 @@ def cpu_baseline(workload, sd, budget_s=20.0):
                        % (pairs, n, runs, candidates, avail, torch.__version__))
 
 
-def train_bench(args, desc, n, bl, pairs, rank, world):
+def train_bench(args, desc, n, bl, pairs, rank, world, steps=None, warmup=None):
     """training throughput (reported separately from the inference metric): pairs/s of
     Trainer.step = ReIDNet.train_step forward + backward, ONE flat-bucket gradient all-reduce over RCCL, gradient
     clipping and AdamW with the cyclic schedule, on a fixed synthetic batch already resident in HBM"""
     from pcr_amd import shard, train
     from pcr_amd import testing as T
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
     model, _ = build_pt_model(bl)
     model.train()
     s1, s2 = T.synthetic_pairs(pairs, n, seed=4321 + rank, kind="randn")
@@ -217,8 +219,8 @@ def train_bench(args, desc, n, bl, pairs, rank, world):
     data = dict(sparse_1=list(s1.to(dev)), sparse_2=list(s2.to(dev)), dense_1=list(s1.to(dev)), dense_2=list(s2.to(dev)),
                 label_1=[zero] * pairs, label_2=[zero] * pairs,
                 id_1=[i.view(1).to(dev) for i in ids1], id_2=[i.view(1).to(dev) for i in ids2])
-    tr = train.Trainer(model, max_iters=args.steps + args.warmup + 3, lr=3e-4, grad_clip=1.0)
-    dt, out = shard.timed(lambda: tr.step(data)["loss"].detach(), args.steps, args.warmup,
+    tr = train.Trainer(model, max_iters=steps + warmup + 3, lr=3e-4, grad_clip=1.0)
+    dt, out = shard.timed(lambda: tr.step(data)["loss"].detach(), steps, warmup,
                           sync=torch.cuda.synchronize, device="cuda")
     assert torch.isfinite(out).all()
     # per-launch device times of one more step (events on the launch stream): the dominant TRAINING launch.  EVERY rank
@@ -230,6 +232,7 @@ def train_bench(args, desc, n, bl, pairs, rank, world):
         engine.PROFILE = []
     tr.step(data)
     torch.cuda.synchronize()
+    line = None
     if rank == 0:
         tr.bucket._layout()
         rec, engine.PROFILE = engine.PROFILE, None
@@ -258,19 +261,18 @@ def train_bench(args, desc, n, bl, pairs, rank, world):
                          "(events on the launch stream), the rest (norms, attention core, reductions, packing, AdamW) is in "
                          "ms_per_step only")
         add_clock(roof, clk)
-        print(json.dumps({
-            "metric": "siamese training pairs/sec @%d pts" % n, "value": world * pairs * args.steps / dt,
-            "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        line = {
+            "metric": "siamese training pairs/sec @%d pts" % n, "value": world * pairs * steps / dt,
+            "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (randn clouds, seeded random-init weights)",
-            "config": {"workload": "%s: %s" % (args.workload, desc), "pairs_per_gpu_per_step": pairs, "points": n,
+            "config": {"workload": "pt128_train: %s" % desc, "pairs_per_gpu_per_step": pairs, "points": n,
                        "backbone_list": bl, "parallelism": "data parallel x%d, one %d-byte gradient bucket per step"
                        % (world, tr.bucket.nbytes()), "rccl_ranks": world},
-            "roofline": roof}), flush=True)
-    if shard.is_dist():
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+            "roofline": roof}
+    del model, tr, data
+    torch.cuda.empty_cache()
+    return line
 
 
 def clock_probe(iters=20000):
@@ -419,10 +421,12 @@ def measure(workload, args, rank, world, pairs=None, cloud_kind=None, skip_repea
     return rec, sd
 
 
-def gallery_bench(args, desc, n, bl, pairs, rank, world):
+def gallery_bench(args, desc, n, bl, pairs, rank, world, steps=None, warmup=None, cpu=True):
     """G tracks x G detections; encode the 2G objects once, score all G*G combinations"""
     from pcr_amd import shard
     from pcr_amd import testing as T
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
     G = max(1, int(round(pairs ** 0.5)))
     P = G * G
     model, sd = build_pt_model(bl)
@@ -434,23 +438,33 @@ def gallery_bench(args, desc, n, bl, pairs, rank, world):
         xyz, h = model.forward_inference(clouds)
         return model.match_gallery(h, xyz, combos)
     with torch.no_grad():
-        dt, out = shard.timed(step, args.steps, args.warmup, sync=torch.cuda.synchronize, device="cuda")
+        dt, out = shard.timed(step, steps, warmup, sync=torch.cuda.synchronize, device="cuda")
     assert torch.isfinite(out).all() and out.numel() == P
+    line = None
     if rank == 0:
         clk = clock_probe()
         roof, _ = roofline_of(None, None, None, "gallery128", P, fn=step)
         add_clock(roof, clk)
         line = {"metric": "siamese pair-comparisons/sec @%d pts (gallery: every object encoded once)" % n,
-                "value": world * P * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
-                "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+                "value": world * P * steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": steps,
+                "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                 "data": "synthetic (randn clouds, seeded random-init weights with non-trivial BN statistics)",
                 "config": {"workload": "gallery128: %s" % desc, "pairs_per_gpu_per_step": P, "objects_per_gpu_per_step": 2 * G,
                            "points": n, "backbone_list": bl, "parallelism": "independent galleries x%d" % world,
                            "rccl_ranks": world},
                 "roofline": roof}
-        if world == 1 and not args.no_cpu_baseline:
+        if cpu and world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = gallery_cpu_baseline(sd, n, bl, G)
+    del model, clouds, combos
+    torch.cuda.empty_cache()
+    return line
+
+
+def finish(line, rank):
+    """rank 0 prints the ONE JSON line; every rank leaves the process group"""
+    from pcr_amd import shard
+    if rank == 0 and line is not None:
         print(json.dumps(line), flush=True)
     if shard.is_dist():
         import torch.distributed as dist
@@ -570,9 +584,9 @@ def main():
 
     desc, kind, n, bl, dpairs = WORKLOADS[args.workload]
     if kind == "pt_train":
-        return train_bench(args, desc, n, bl, args.pairs or dpairs, rank, world)
+        return finish(train_bench(args, desc, n, bl, args.pairs or dpairs, rank, world), rank)
     if kind == "gallery":
-        return gallery_bench(args, desc, n, bl, args.pairs or dpairs, rank, world)
+        return finish(gallery_bench(args, desc, n, bl, args.pairs or dpairs, rank, world), rank)
 
     rec, sd = measure(args.workload, args, rank, world, pairs=args.pairs or None, cloud_kind=args.clouds,
                       skip_repeats=not args.full_groups)
@@ -592,6 +606,17 @@ def main():
                 r, _ = measure(wl, args, rank, world, **kw)
                 r["metric"] = "siamese pair-comparisons/sec @%d pts" % WORKLOADS[wl][2]
             except Exception as e:      # a companion must never cost the headline line
+                r = {"error": "%s: %s" % (type(e).__name__, e)}
+            r["name"] = name
+            also.append(r)
+        # BASELINE config 4 (the training step: forward + backward + bucket exchange + clip + AdamW) and SURVEY 8f rank 1
+        # (gallery matching), each with the roofline of its own dominant launch
+        for name, fn in (("pt128_train", train_bench), ("gallery128", gallery_bench)):
+            d, _, n_, bl_, p_ = WORKLOADS[name]
+            try:
+                kw = dict(cpu=False) if name == "gallery128" else {}
+                r = fn(args, d, n_, bl_, p_, rank, world, **kw)
+            except Exception as e:
                 r = {"error": "%s: %s" % (type(e).__name__, e)}
             r["name"] = name
             also.append(r)

@@ -297,8 +297,13 @@ __global__ __launch_bounds__(kThreads) void attn_kv_wide_kernel(AttnArgs a) {
     __syncthreads();
   }
   // KV band, transposed: KVt [v (dh)][dd (64) + 1] = the B operand (k = v, token = dd) of the merge fold
+  // (KVt spans dh * 65 floats from the start of the buffer and can reach past s_ks -- d_model 256 with ONE head and
+  // c2 < 214 -- so the four key-sum partials are combined into a register before the first KVt write)
   float *KVt = smem;
   s_ks[tid] = ksum;
+  __syncthreads();
+  const float ks_total = tid < BAND ? s_ks[tid] + s_ks[64 + tid] + s_ks[128 + tid] + s_ks[192 + tid] : 0.f;
+  __syncthreads();
 #pragma unroll
   for (int it = 0; it < 4; it++) {
     const int item = wave + 4 * it;
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(kThreads) void attn_kv_wide_kernel(AttnArgs a) {
   }
   __syncthreads();
   float *kv = p.kv + b * ((size_t)d * d + d);
-  if (tid < BAND) kv[(size_t)d * d + g * BAND + tid] = s_ks[tid] + s_ks[64 + tid] + s_ks[128 + tid] + s_ks[192 + tid];
+  if (tid < BAND) kv[(size_t)d * d + g * BAND + tid] = ks_total;
   // M[o][dd] = sum_{v < dh} Wm[o][hd dh + v] KV[dd][v]: dense over k = v with the k-blocks [hd dh / 8, +dh / 8) of the
   // packed merge weights; stored in the packed (d,d) layout the apply kernel reads as an A operand
   const float *wm = p.wmerge_packed + (size_t)(hd * dh / 8) * d * 8;

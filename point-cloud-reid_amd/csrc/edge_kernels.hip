@@ -501,7 +501,7 @@ PCR_EXPORT int pcr_local_attn_f32(const float *qkv, const int *idx, float *msg, 
   const int dh = C / nhead;
   if (dh & (dh - 1)) return PCR_ERR_INVALID;
   const size_t lds32 = ((size_t)N * 32 * 2 + 32 * 33 + 32 * K) * 4;
-  if (dh == 32 && lds32 <= 72 * 1024 && !getenv("PCR_LOCAL_NO_LDS")) {
+  if (dh == 32 && lds32 <= 72 * 1024 && !pcr_tune_str("PCR_LOCAL_NO_LDS")) {
     static bool big = hipFuncSetAttribute(reinterpret_cast<const void *>(local_attn_lds_kernel<32>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
     (void)big;
@@ -561,11 +561,11 @@ PCR_EXPORT int pcr_edge_max_f32(const float *ta, const float *tb, const int *idx
   if (B <= 0 || N <= 0 || Co <= 0 || Co > 256 || K <= 0 || K > 64 || B > 65535) return PCR_ERR_INVALID;
   EdgeMaxArgs a{ta, tb, shift, idx, out, out2, out_bstride > 0 ? out_bstride : (long)Co * N,
                 out2_bstride > 0 ? out2_bstride : (long)Co * N, N, Co, K, slope};
-  if (N <= 512 && !getenv("PCR_EDGE_NO_LDS")) {
+  if (N <= 512 && !pcr_tune_str("PCR_EDGE_NO_LDS")) {
     // channel-slice width: narrower slices = more, smaller workgroups.  Measured (512 pairs/step, ms for the four
     // layers, CS = 64 / 32 / 16): N = 128: 0.46 / 0.35 / 0.36; N = 256: 1.11 / 0.83 / 0.76; the L2-gather kernel
     // below: 0.72 and 1.55, but 1.52 against 1.69 at N = 1024, where it stays.
-    static const int cs_env = getenv("PCR_EDGE_CS") ? atoi(getenv("PCR_EDGE_CS")) : 0;
+    static const int cs_env = pcr_tune_int("PCR_EDGE_CS");
     const int cs = cs_env ? cs_env : (N <= 128 ? 32 : 16);
 #define PCR_EDGE_LDS(CS_)                                                                                         \
   do {                                                                                                            \

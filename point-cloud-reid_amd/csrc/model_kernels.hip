@@ -390,7 +390,7 @@ static int dense_launch(const float *x, const float *wp, long w_bstride, const f
   DenseArgs a{x, wp, scale, shift, y, cin, cout, L, act, w_bstride, x_pm, gn_gs, res};
   const int cinP = ceil8(cin);
   if (cin >= 2 * kChunk && cin % kChunk == 0 && cout % 256 == 0 && !x_pm && !w_bstride && L > 32 &&
-      !getenv("PCR_DENSE_NO_CHUNK")) {
+      !pcr_tune_str("PCR_DENSE_NO_CHUNK")) {
     const size_t ldsc = ((size_t)kChunk * 65 + 512) * sizeof(float);
     static bool okc = allow_big_lds(dense_kernel<2, true, true>) && allow_big_lds(dense_kernel<2, false, true>);
     (void)okc;

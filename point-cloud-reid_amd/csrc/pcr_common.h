@@ -16,6 +16,18 @@ static inline hipStream_t pcr_s(pcr_stream_t s) { return reinterpret_cast<hipStr
 
 constexpr int kWave = 64;
 
+// Tuning / ablation knobs (PCR_SA_DBG, PCR_TD_VARIANT, ...) are read from the environment ONLY in builds made with
+// -DPCR_TUNING=1 (PCR_EXTRA_HIPCC_FLAGS); the shipped library ignores the environment on its launch paths.
+#ifndef PCR_TUNING
+#define PCR_TUNING 0
+#endif
+#include <stdlib.h>
+static inline const char *pcr_tune_str(const char *name) { return PCR_TUNING ? getenv(name) : nullptr; }
+static inline int pcr_tune_int(const char *name) {
+  const char *v = pcr_tune_str(name);
+  return v ? atoi(v) : 0;
+}
+
 // (x2-x1)^2+(y2-y1)^2+(z2-z1)^2, left to right, never contracted into fma: the file is built
 // with -ffp-contract=off and the products are kept in separate statements.
 __device__ __forceinline__ float pcr_sqdist3(float x1, float y1, float z1, float x2, float y2,

@@ -59,6 +59,7 @@ __global__ void fps_kernel(const float *__restrict__ data, float *__restrict__ t
   const uint32_t rev = logb ? (__brev((uint32_t)tid) >> (32 - logb)) : 0u;
   const uint32_t tie = pytie ? 0u : (uint32_t)(block - 1) - rev;  // larger = preferred by the merge tree
   int old = start ? start[cloud] : 0;
+  old = (unsigned)old < (unsigned)N ? old : 0;   // (a start outside the cloud has no point to begin from: clamped, the wrapper validates)
   if (tid == 0) idxs[0] = old;
 
   for (int j = 1; j < m; j++) {
@@ -696,7 +697,9 @@ __global__ __launch_bounds__(256) void scatter_owner_kernel(const float *__restr
       const float *row = st + cl * (TR + 1);
       for (int rr = 0; rr < nr; rr++) {
         const int i = it[rr];
-        if ((i % PARTS) == part) acc[cl * NP + i] += row[rr] * wt[rr];
+        // (an index outside [0, N) -- e.g. the Python-twin ball query's N sentinel for a row without hits -- has no
+        // accumulator: it is skipped, as the reference's gather would have faulted on it)
+        if ((unsigned)i < (unsigned)N && (i % PARTS) == part) acc[cl * NP + i] += row[rr] * wt[rr];
       }
     }
     __syncthreads();

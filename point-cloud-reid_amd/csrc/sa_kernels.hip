@@ -988,8 +988,8 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
       r.wa = p.wa; r.pq = p.D ? p.pq_ws : nullptr; r.pqw = p.c1;
       r.wap = p.wa_packed;
       r.wp2 = p.wps[0]; r.wp3 = p.wps[1]; r.sh1 = p.shift[0]; r.sh2 = p.shift_pad[0]; r.sh3 = p.shift_pad[1];
-      static const int rdbg = getenv("PCR_SA_DBG") ? atoi(getenv("PCR_SA_DBG")) : 0;
-      static const char *rtrace = getenv("PCR_SA_TRACE");
+      static const int rdbg = pcr_tune_int("PCR_SA_DBG");
+      static const char *rtrace = pcr_tune_str("PCR_SA_TRACE");
       r.dbg = rdbg | (rtrace ? 256 : 0);
       r.out = p.out;
       r.out_pm = p.out_point_major;
@@ -1111,7 +1111,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
     const double cost = pad * imb * (1.0 + 1.0 / wgs);
     if (cost < best_cost - 1e-9) { best_cost = cost; best_cpw = cpw; best_tb = tb; }
   }
-  static const int force_cpw = getenv("PCR_SA_CPW") ? atoi(getenv("PCR_SA_CPW")) : 0;   // tuning aid
+  static const int force_cpw = pcr_tune_int("PCR_SA_CPW");   // tuning aid
   if (force_cpw > 0) {
     const int tb = (force_cpw * p.K + 31) / 32;
     if (tb <= (nr == 4 ? 2 : 6) && lds_bytes(tb, force_cpw) <= 150 * 1024) { best_cpw = force_cpw; best_tb = tb; }
@@ -1127,7 +1127,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   a.pq = p.D ? p.pq_ws : nullptr;
   a.pqw = pqw;
   a.qoff = p.mode == 0 ? p.c1 : -1;
-  static const int dbg = getenv("PCR_SA_DBG") ? atoi(getenv("PCR_SA_DBG")) : 0;
+  static const int dbg = pcr_tune_int("PCR_SA_DBG");
   a.dbg = dbg;
   a.wp2 = p.wps[0]; a.wp3 = p.wps[1];
   a.sh1 = p.shift[0]; a.sh2 = p.shift_pad[0]; a.sh3 = p.shift_pad[1];
@@ -1135,7 +1135,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   a.out_pm = p.out_point_major;
   a.wap = p.wa_packed;
   {
-    static const int no_l1m = getenv("PCR_SA_NO_L1M") ? atoi(getenv("PCR_SA_NO_L1M")) : 0;   // diagnostics
+    static const int no_l1m = pcr_tune_int("PCR_SA_NO_L1M");   // diagnostics
     const int n1 = ceil32(p.c1) >> 5;
     const int w1 = n1 >= 3 ? 1 : (n1 == 2 ? 2 : 4);
     const int w2c = n2 >= 3 ? 1 : (n2 == 2 ? 2 : 4), w3c = n3 >= 3 ? 1 : (n3 == 2 ? 2 : 4);

@@ -1138,7 +1138,7 @@ PCR_EXPORT int pcr_tdense_bwd_f32(const pcr_tdense_bwd *p, pcr_stream_t stream) 
   a.wpT = p->wpT; a.dx = p->dx; a.dx2 = p->dx2; a.dstats = p->dstats; a.dwp = p->dwp; a.dbp = p->dbp;
   a.dw_stride = p->part_stride; a.db_stride = p->part_stride;
   a.cout = p->cout; a.L = p->L; a.B = p->B;
-  static const int dbg = getenv("PCR_TD_DBG") ? atoi(getenv("PCR_TD_DBG")) : 0;
+  static const int dbg = pcr_tune_int("PCR_TD_DBG");
   a.dbg = dbg;
   const int ntiles = (p->L + kTT - 1) / kTT;
   const int g = wg_groups(p->B, ntiles);
@@ -1167,7 +1167,7 @@ PCR_EXPORT int pcr_tdense_bwd_f32(const pcr_tdense_bwd *p, pcr_stream_t stream) 
     (void)ok;                                                                           \
     hipLaunchKernelGGL((tdense_bwd_kernel_o4<WSv, NRXv>), grid, blk, lds, st, a);       \
   } while (0)
-  static const int variant = getenv("PCR_TD_VARIANT") ? atoi(getenv("PCR_TD_VARIANT")) : 0;   // tuning aid
+  static const int variant = pcr_tune_int("PCR_TD_VARIANT");   // tuning aid
   // narrow layers (<= 4 dW tiles, LDS <= 40 KB): four workgroups per CU; wider ones: two per CU (with operand prefetch
   // for the 64-channel square layers whose pieces fit the registers)
   // (measured at B = 512: 64 x 64, L = 3072: 0.94 -> 0.72 ms with four workgroups per CU, 0.63 with the batched fill;

@@ -16,6 +16,7 @@ import torch.nn as nn
 
 from pcr_amd import engine
 from pcr_amd import _lib as L
+from pcr_amd.lazylog import LazyScalars
 from .attention import corss_attention, cross_lin_attn, local_self_attention
 from .backbone_net import Pointnet_Backbone
 from .dgcnn_orig import DGCNN
@@ -328,15 +329,22 @@ class ReIDNet(nn.Module):
         if o is None:
             o = [None] * (2 * b)
         if self.compute_summary and log_vars is not None:
-            pred = (torch.sigmoid(match_preds) > 0.5)
-            log_vars[prefix + "match_loss"] = match_loss.item()
-            log_vars[prefix + "match_acc"] = pred.float().eq(match).float().mean().item()
-            gt_bins = torch.bincount(match.long())
-            log_vars[prefix + "num_preds_0"] = gt_bins[0].item()
-            log_vars[prefix + "num_preds_1"] = gt_bins[1].item() if len(gt_bins) > 1 else 0
-            pred_bins = torch.bincount(pred.long())
-            log_vars[prefix + "num_gt_0"] = pred_bins[0].item()
-            log_vars[prefix + "num_gt_1"] = pred_bins[1].item() if len(pred_bins) > 1 else 0
+            # the reference's six log entries (ReIDNet.py:426-435: `.item()` each), computed on the device as ONE small
+            # tensor and read lazily (pcr_amd/lazylog.py): same keys -- including the reference's swapped
+            # num_preds / num_gt naming -- and same values, no host round trip inside the step
+            pred = match_preds.detach() > 0                      # sigmoid(x) > 0.5
+            m = match.detach()
+            n = float(m.numel())
+            gt1, p1 = m.sum(), pred.float().sum()
+            stats = torch.stack([match_loss.detach().reshape(()), pred.float().eq(m).float().mean(),
+                                 n - gt1, gt1, n - p1, p1])
+            names = [prefix + k for k in ("match_loss", "match_acc", "num_preds_0", "num_preds_1", "num_gt_0", "num_gt_1")]
+            ints = [False, False, True, True, True, True]
+            if isinstance(log_vars, LazyScalars):
+                log_vars.add_device(names, stats, ints)
+            else:
+                for k, i, v in zip(names, ints, stats.tolist()):
+                    log_vars[k] = int(round(v)) if i else v
         return match_preds, match_loss, (o[:b], o[b:])
 
     def _check_losses(self):
@@ -357,7 +365,7 @@ class ReIDNet(nn.Module):
         if self.eval_only:
             exit(0)     # reference behaviour: testing configs stop at the first training iteration (:587-588)
         self._check_losses()
-        log_vars, losses = {}, {}
+        log_vars, losses = LazyScalars(), {}
         sparse_1, sparse_2, dense_1, dense_2, label_1, label_2, id_1, id_2 = self.preprocess_inputs(
             sparse_1, sparse_2, dense_1, dense_2, label_1, label_2, id_1, id_2)
         device = sparse_1.device
@@ -412,12 +420,16 @@ class ReIDNet(nn.Module):
                 raise TypeError("%s is not a tensor or list of tensors" % name)
         loss = sum(v for k, v in log_vars.items() if "loss" in k)
         log_vars["loss"] = loss
+        # mmdet reduces and reads every entry on its own (one all-reduce + one .item() each); here the entries travel as
+        # ONE stacked tensor: one all-reduce, one asynchronous copy, read on first access (pcr_amd/lazylog.py)
         import torch.distributed as dist
-        for name, value in log_vars.items():
-            if dist.is_available() and dist.is_initialized():
-                value = value.data.clone()
-                dist.all_reduce(value.div_(dist.get_world_size()))
-            log_vars[name] = value.item()
+        names = list(log_vars.keys())
+        stacked = torch.stack([log_vars[k].detach().reshape(()).float() for k in names])
+        if dist.is_available() and dist.is_initialized():
+            stacked = stacked.clone()
+            dist.all_reduce(stacked.div_(dist.get_world_size()))
+        log_vars = LazyScalars()
+        log_vars.add_device(names, stacked)
         return loss, log_vars
 
     def train_step(self, data, optimizer):

@@ -33,6 +33,9 @@ def farthest_point_sample(xyz, npoint, start=None):
     B, N, _ = xyz.shape
     if start is None:
         start = torch.randint(0, N, (B,), dtype=torch.long).to(xyz.device)
+    if not start.is_cuda and start.numel() and (int(start.min()) < 0 or int(start.max()) >= N):
+        raise L.PcrError("farthest_point_sample: start index outside [0, %d)" % N)
+    # (a start tensor already on the device is not read back: the kernel clamps an out-of-range entry to point 0)
     start = start.to(device=xyz.device, dtype=torch.int32).contiguous()
     idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
     temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)

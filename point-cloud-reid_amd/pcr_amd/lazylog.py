@@ -1,0 +1,86 @@
+"""log_vars without a host synchronisation per entry.
+
+The reference's `match_forward` (mmdet3d/models/ReIDNet.py:426-435) and mmdet's `BaseDetector._parse_losses` (call
+site ReIDNet.py:728) read every logged scalar with `.item()`: eight-plus device -> host round trips per training
+iteration, each of which drains the launch queue.  Here the scalars of one iteration are stacked on the device,
+copied to pinned host memory asynchronously, and turned into the same Python numbers (same keys, same values, ints
+where the reference logs ints) the first time anybody READS the dict -- a trainer that logs every k iterations pays
+one wait every k iterations, one that never looks pays none.
+"""
+from collections import OrderedDict
+
+import torch
+
+
+class LazyScalars(OrderedDict):
+    """an OrderedDict whose pending entries live in device tensors until the first read"""
+
+    def __init__(self, *a, **kw):
+        self._pending = []          # (names, int_flags, host_tensor, event or None)
+        super().__init__(*a, **kw)
+
+    # ---- producer side ----
+    def add_device(self, names, values, ints=None):
+        """names: list of keys; values: 1-d tensor (same length) on any device; ints: per-key flag -> int(value)"""
+        names = list(names)
+        ints = list(ints) if ints is not None else [False] * len(names)
+        values = values.detach()
+        if values.is_cuda:
+            host = torch.empty(values.shape, dtype=values.dtype).pin_memory()
+            host.copy_(values, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            host, ev = values.clone(), None
+        for n in names:                     # keeps the reference's key order
+            OrderedDict.__setitem__(self, n, None)
+        self._pending.append((names, ints, host, ev))
+
+    # ---- consumer side ----
+    def materialize(self):
+        pend, self._pending = self._pending, []
+        for names, ints, host, ev in pend:
+            if ev is not None:
+                ev.synchronize()
+            vals = host.tolist()
+            for n, i, v in zip(names, ints, vals):
+                if OrderedDict.__contains__(self, n) and OrderedDict.__getitem__(self, n) is None:
+                    OrderedDict.__setitem__(self, n, int(round(v)) if i else v)
+        return self
+
+    def __getitem__(self, k):
+        self.materialize()
+        return OrderedDict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        self.materialize()
+        return OrderedDict.get(self, k, default)
+
+    def items(self):
+        self.materialize()
+        return OrderedDict.items(self)
+
+    def values(self):
+        self.materialize()
+        return OrderedDict.values(self)
+
+    def copy(self):
+        self.materialize()
+        return OrderedDict(OrderedDict.items(self))
+
+    def update(self, other=(), **kw):
+        if isinstance(other, LazyScalars):          # keep the other's entries lazy too
+            pend, other._pending = other._pending, []
+            for n in OrderedDict.keys(other):
+                OrderedDict.__setitem__(self, n, OrderedDict.__getitem__(other, n))
+            self._pending.extend(pend)
+            other = ()
+        OrderedDict.update(self, other, **kw)
+
+    def __repr__(self):
+        self.materialize()
+        return OrderedDict.__repr__(self)
+
+    def __reduce__(self):
+        self.materialize()
+        return (OrderedDict, (list(OrderedDict.items(self)),))

@@ -38,6 +38,9 @@ class FusedAdamW(torch.optim.Optimizer):
         return [(g, p) for g in self.param_groups for p in g["params"] if p.requires_grad]
 
     def _build(self):
+        # a plan is being replaced (add_param_group, a parameter object swapped): the step counts live in the old plan
+        # only -- write them back first, or the new plan would restart bias correction against old moments
+        self._sync_steps()
         ts = self._tensors()
         if not ts:
             raise L.PcrError("FusedAdamW: no parameters")
@@ -154,7 +157,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._plan is None:
             return
         for i, (_, p) in enumerate(self._plan["ts"]):
-            if self._plan["have_state"][i]:
+            if self._plan["have_state"][i] and p in self.state:
                 self.state[p]["step"] = torch.tensor(float(self._plan["steps"][i]), dtype=torch.float32)
 
     def state_dict(self):
@@ -162,5 +165,9 @@ class FusedAdamW(torch.optim.Optimizer):
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
+        for g in state_dict.get("param_groups", []):
+            if g.get("amsgrad", False) or g.get("maximize", False):
+                raise L.PcrError("FusedAdamW: a state_dict with amsgrad / maximize set cannot be honoured "
+                                 "(pcr_adamw_step_f32 implements plain AdamW)")
+        self._plan = None          # (the old plan's step counts must not be written over the loaded ones)
         super().load_state_dict(state_dict)
-        self._plan = None

@@ -121,7 +121,9 @@ class Trainer:
 
     def step(self, data):
         """one iteration: forward + backward of model.train_step(data, optimizer); every `cumulative_iters`
-        iterations exchange gradients, clip, and apply AdamW.  Returns the outputs dict (+ lr, grad_norm)."""
+        iterations exchange gradients, clip, and apply AdamW.  Returns the outputs dict (+ lr, beta1 as floats;
+        grad_norm as a 0-d tensor on the parameters' device in BOTH optimizer paths -- `float()` it at log time, which is
+        the only place it costs a host synchronisation; log_vars is a LazyScalars dict with the same property)."""
         lr, b1 = self._set_hyper()
         if self.iter % self.cumulative_iters == 0:
             self.optimizer.zero_grad(set_to_none=True)
@@ -140,7 +142,7 @@ class Trainer:
             else:
                 if self.grad_clip is not None:
                     params = [p for p in self.model.parameters() if p.grad is not None]
-                    out["grad_norm"] = float(torch.nn.utils.clip_grad_norm_(params, self.grad_clip, norm_type=2))
+                    out["grad_norm"] = torch.nn.utils.clip_grad_norm_(params, self.grad_clip, norm_type=2).detach()
                 self.optimizer.step()
         self.iter += 1
         return out

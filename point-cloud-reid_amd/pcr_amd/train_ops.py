@@ -7,6 +7,7 @@ projections / feed-forward layers and the match head -- is a HIP launch forward 
 matrix core; autograd only strings the Functions together.  Nothing here has a CPU path.
 """
 import ctypes
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -101,6 +102,8 @@ class _Prepack:
             return
         if self.key != tuple(id(p) for p in params) or any(e[0].data_ptr() != k for k, e in self.entries.items()):
             self.build(params)
+        elif all(e[3] == e[0]._version for e in self.entries.values()):
+            return        # nothing changed since the last refresh (micro-steps of a gradient accumulation)
         L.check(L.load().pcr_pack_weights_multi_f32(ctypes.c_void_p(self.descs.data_ptr()), len(params), L.stream_ptr()),
                 "pcr_pack_weights_multi_f32")
         for e in self.entries.values():
@@ -114,21 +117,34 @@ class _Prepack:
         return e[4], e[5]
 
 
-_PREPACK = _Prepack()
+# one table per model, owned by the model (dropped with it); `lookup` below searches the live tables
+_PREPACKS = weakref.WeakKeyDictionary()
+
+
+def _lookup(w):
+    for t in _PREPACKS.values():
+        hit = t.lookup(w)
+        if hit is not None:
+            return hit
+    return None
 
 
 def prepack(model):
     """refresh the packed images of every conv / linear weight of `model` in one launch (Trainer.step calls this once
-    per iteration, after the previous update); pack_dev / pack_both then hit the cache"""
+    per iteration, after the previous update); pack_dev / pack_both then hit the cache.  Note for callers that keep an
+    autograd graph across iterations: the images are overwritten in place by the next refresh."""
     ws = [m.weight for m in model.modules()
           if isinstance(m, (torch.nn.Linear, torch.nn.Conv1d, torch.nn.Conv2d)) and m.weight is not None]
-    _PREPACK.refresh(ws)
+    tab = _PREPACKS.get(model)
+    if tab is None:
+        tab = _PREPACKS[model] = _Prepack()
+    tab.refresh(ws)
 
 
 def pack_dev(w, transpose=False):
     """(rows, cols) device matrix -> packed MFMA A-operand image of W or W^T (weights change every step, so the
     pack runs on the device; inference packs once on the host)"""
-    hit = _PREPACK.lookup(w)
+    hit = _lookup(w)
     if hit is not None:
         return hit[1] if transpose else hit[0]
     w = _dev(w.detach())
@@ -142,7 +158,7 @@ def pack_dev(w, transpose=False):
 
 def pack_both(w):
     """-> (image of W, image of W^T) from ONE launch (forward and backward operands of a layer)"""
-    hit = _PREPACK.lookup(w)
+    hit = _lookup(w)
     if hit is not None:
         return hit
     w = _dev(w.detach())
@@ -342,7 +358,11 @@ class SaEdgeTrain(Function):
                                           L.ptr(y1), L.ptr(st1), B, N, S, K, c1, L.stream_ptr()), "pcr_sa_l1_fwd_f32")
 
         def fin(st, nparts, C, gamma, beta, bn):
-            o = bn_fwd_finalize(st, nparts, C, R, gamma, beta, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
+            if bn.momentum is None:
+                # nn.BatchNorm2d(momentum=None) is the cumulative average 1 / num_batches_tracked (a device counter: a
+                # host read per layer and step); no reference config uses it -- refused rather than approximated
+                raise L.PcrError("BatchNorm with momentum=None (cumulative average) is not supported by the HIP training path")
+            o = bn_fwd_finalize(st, nparts, C, R, gamma, beta, bn.eps, bn.momentum,
                                 bn.running_mean if bn.track_running_stats else None,
                                 bn.running_var if bn.track_running_stats else None)
             if bn.track_running_stats:

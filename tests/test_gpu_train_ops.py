@@ -354,21 +354,29 @@ def test_prepacked_weights_equal_fresh_packs_and_follow_updates():
     from pcr_amd import train_ops as TO
     net = torch.nn.Sequential(torch.nn.Linear(67, 40), torch.nn.Conv1d(40, 96, 1), torch.nn.Conv2d(96, 33, 1)).cuda()
     ws = [net[0].weight, net[1].weight.view(96, 40), net[2].weight.view(33, 96)]
-    TO._PREPACK.entries.clear(); TO._PREPACK.key = None
+    TO._PREPACKS.clear()
     fresh = [tuple(t.clone() for t in TO.pack_both(w)) for w in ws]          # cache empty: per-layer launches
     TO.prepack(net)
     for w, (f0, f1) in zip(ws, fresh):
-        assert TO._PREPACK.lookup(w) is not None
+        assert TO._lookup(w) is not None
         c0, c1 = TO.pack_both(w)
         assert torch.equal(c0, f0) and torch.equal(c1, f1)
         assert torch.equal(TO.pack_dev(w), f0) and torch.equal(TO.pack_dev(w, transpose=True), f1)
     with torch.no_grad():
         net[1].weight.mul_(2.0)                                              # an update: the version moves
-    assert TO._PREPACK.lookup(ws[1]) is None and TO._PREPACK.lookup(ws[0]) is not None
+    assert TO._lookup(ws[1]) is None and TO._lookup(ws[0]) is not None
     assert torch.equal(TO.pack_both(ws[1])[0], 2.0 * fresh[1][0])            # packed on the spot from the new values
     TO.prepack(net)
-    assert torch.equal(TO.pack_both(ws[1])[0], 2.0 * fresh[1][0]) and TO._PREPACK.lookup(ws[1]) is not None
-    TO._PREPACK.entries.clear(); TO._PREPACK.key = None
+    assert torch.equal(TO.pack_both(ws[1])[0], 2.0 * fresh[1][0]) and TO._lookup(ws[1]) is not None
+    # a second model gets its own table (the first one's images stay valid), and a dropped model takes its table along
+    net2 = torch.nn.Sequential(torch.nn.Linear(16, 8)).cuda()
+    TO.prepack(net2)
+    assert TO._lookup(net2[0].weight) is not None and TO._lookup(ws[0]) is not None and len(TO._PREPACKS) == 2
+    del net2
+    import gc
+    gc.collect()
+    assert len(TO._PREPACKS) == 1
+    TO._PREPACKS.clear()
 
 
 def test_fused_adamw_is_reproducible_and_refuses_host_tensors():
