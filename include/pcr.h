@@ -34,6 +34,9 @@ enum pcr_status {
 
 /* ABI version (bumped whenever a signature changes) and human-readable status. */
 int pcr_abi_version(void);
+#define PCR_PREC_F32 0
+#define PCR_PREC_BF16X3 1
+#define PCR_PREC_BF16 2
 const char *pcr_status_string(int status);
 
 /* ---------------------------------------------------------------- A. point ops ------- */
@@ -137,6 +140,13 @@ int pcr_knn_prefix_f32(const float *xyz, int *idx, int B, int N, int S, int K, p
  * below read with one 16-byte load per lane. */
 long pcr_packed_weight_floats(int cout, int cin);
 int pcr_pack_weight_f32(const float *w, int cout, int cin, float *packed);
+/* The same matrix as a bf16 image for the bf16 matrix core (v_mfma_f32_32x32x16_bf16): every weight is stored as
+ * hi = bf16(w) and lo = bf16(w - hi) (round to nearest), laid out [ceil16(cin)/16][ceil32(cout)/32][hi, lo][64 lanes]
+ * [8 bf16] so that a lane's A operand of one 16-channel step is one 16-byte load.  Kernels run in "bf16x3" mode (split
+ * bf16: W x ~= W_hi x_hi + W_hi x_lo + W_lo x_hi, f32 accumulate, ~2^-17 relative per term) read both parts, in plain
+ * "bf16" mode the hi part only.  Size in floats (4-byte units) / host-side pack. */
+long pcr_packed_weight_bf16_floats(int cout, int cin);
+int pcr_pack_weight_bf16x2_f32(const float *w, int cout, int cin, float *packed);
 
 /* Grouped set-abstraction MLP: gather + edge/relative features + 3 x (1x1 conv -> per-channel
  * affine (folded eval-mode BatchNorm) -> ReLU) + max over the K neighbours, one pass, nothing but
@@ -185,6 +195,12 @@ typedef struct pcr_sa_params {
   /* optional: (c1,3) dxyz weights of layer 1 (BatchNorm scale folded in, like wa) as a PACKED image
    * (pcr_pack_weight_f32 of the (c1,3) matrix): lets the persistent kernel run layer 1 on the matrix core too */
   const float *wa_packed;
+  /* arithmetic of layers 2 and 3 (layer 1 and the tables stay f32): PCR_PREC_F32 = f32-input MFMA, exact fmaf chains
+   * (wps); PCR_PREC_BF16X3 = split bf16, three bf16 MFMAs per product with f32 accumulation; PCR_PREC_BF16 = plain bf16
+   * activations and weights, f32 accumulation (BASELINE config 2 as stated).  wps_bf[l]: pcr_pack_weight_bf16x2_f32
+   * images of the matrices wps[l] holds.  Shapes the bf16 kernels do not cover run in f32. */
+  int precision;
+  const float *wps_bf[2];
 } pcr_sa_params;
 int pcr_sa_mlp_f32(const pcr_sa_params *p, pcr_stream_t stream);
 /* ints of pcr_sa_params.tile_ws for the duplicate-free evaluation (tile lists + per-tile row tables) */

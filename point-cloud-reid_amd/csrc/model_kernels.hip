@@ -1,6 +1,8 @@
 // Pooling + match head, generic dense layer, host-side weight packing.
 #include <stdlib.h>
 
+#include <string.h>
+
 #include "tile_dense.h"
 
 namespace {
@@ -355,6 +357,45 @@ PCR_EXPORT int pcr_pack_weight_f32(const float *w, int cout, int cin, float *pac
         for (int j = 0; j < 4; j++) {
           const int k = kb * 8 + j * 2 + h;
           packed[(((size_t)kb * OP + o) * 2 + h) * 4 + j] = (o < cout && k < cin) ? w[(size_t)o * cin + k] : 0.f;
+        }
+  return PCR_OK;
+}
+
+// ---- bf16 images (tile_dense.h, tile_dense_bf_impl): [S = ceil16(cin)/16][OP/32][hi, lo][64 lanes][8 bf16] ----
+static inline unsigned short pcr_bf16_rn(float f) {   // round to nearest even; weights are finite
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7f800000u) == 0x7f800000u) return (unsigned short)(u >> 16);   // inf / nan: truncate
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+static inline float pcr_bf16_to_f32(unsigned short b) {
+  const uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+PCR_EXPORT long pcr_packed_weight_bf16_floats(int cout, int cin) {
+  if (cout < 1 || cin < 1) return 0;
+  return (long)((cin + 15) / 16) * (ceil32(cout) / 32) * 2 * 64 * 4;
+}
+
+PCR_EXPORT int pcr_pack_weight_bf16x2_f32(const float *w, int cout, int cin, float *packed) {
+  if (!w || !packed || cout < 1 || cin < 1) return PCR_ERR_INVALID;
+  const int S = (cin + 15) / 16, nCB = ceil32(cout) / 32;
+  unsigned short *img = reinterpret_cast<unsigned short *>(packed);
+  for (int s = 0; s < S; s++)
+    for (int cb = 0; cb < nCB; cb++)
+      for (int lane = 0; lane < 64; lane++)
+        for (int j = 0; j < 8; j++) {
+          const int o = cb * 32 + (lane & 31), k = 16 * s + 8 * (lane >> 5) + j;
+          const float v = (o < cout && k < cin) ? w[(size_t)o * cin + k] : 0.f;
+          const unsigned short hi = pcr_bf16_rn(v);
+          const unsigned short lo = pcr_bf16_rn(v - pcr_bf16_to_f32(hi));
+          const size_t base = (((size_t)s * nCB + cb) * 2) * 64;
+          img[(base + lane) * 8 + j] = hi;
+          img[(base + 64 + lane) * 8 + j] = lo;
         }
   return PCR_OK;
 }

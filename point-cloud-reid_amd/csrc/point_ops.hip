@@ -59,7 +59,7 @@ __global__ void fps_kernel(const float *__restrict__ data, float *__restrict__ t
   const uint32_t rev = logb ? (__brev((uint32_t)tid) >> (32 - logb)) : 0u;
   const uint32_t tie = pytie ? 0u : (uint32_t)(block - 1) - rev;  // larger = preferred by the merge tree
   int old = start ? start[cloud] : 0;
-  old = (unsigned)old < (unsigned)N ? old : 0;   // (a start outside the cloud has no point to begin from: clamped, the wrapper validates)
+  old = (unsigned)old < (unsigned)n ? old : 0;   // (a start outside the cloud has no point to begin from: clamped, the wrapper validates)
   if (tid == 0) idxs[0] = old;
 
   for (int j = 1; j < m; j++) {
@@ -1072,7 +1072,7 @@ __global__ __launch_bounds__(NT) void knn_prefix_lds_kernel(const float *__restr
 }  // namespace
 
 // ------------------------------------------------------------------------------ C ABI ----
-PCR_EXPORT int pcr_abi_version(void) { return 6; }
+PCR_EXPORT int pcr_abi_version(void) { return 7; }
 
 PCR_EXPORT const char *pcr_status_string(int status) {
   switch (status) {

@@ -1,0 +1,1295 @@
+// Grouped set-abstraction MLP kernels (pcr_sa_mlp_f32).  This file is the body of three translation units:
+//   sa_kernels.hip      PCR_SA_PREC 0  f32-input MFMA (exact fmaf chains), every shape, and the C-ABI entry points
+//   sa_kernels_bf3.hip  PCR_SA_PREC 1  split bf16 (three v_mfma_f32_32x32x16_bf16 per product, ~2e-6 of the f32 result)
+//   sa_kernels_bf1.hip  PCR_SA_PREC 2  plain bf16 activations / weights, f32 accumulate (BASELINE config 2 as stated)
+// The bf16 units instantiate the explicit-shape kernels only and export pcr_sa2_try_bf3 / _bf1 to the first one.
+#pragma once
+#ifndef PCR_SA_PREC
+#define PCR_SA_PREC 0
+#endif
+#include <stdio.h>
+
+#include <vector>
+
+#include "tile_dense.h"
+
+// 1: the first weight fragments of layers 2 AND 3 are requested one phase early; 2: layer 3 only (layer 2's
+// would stay live across the gather / max-pool phases and push the kernel over 192 VGPRs = one workgroup per CU)
+#ifndef PCR_RING
+#define PCR_RING 2
+#endif
+
+namespace {
+constexpr int kPrec = PCR_SA_PREC;
+#if PCR_SA_PREC == 0
+// ---------------------------------------------------------------- grouped SA MLP ----
+struct SaArgs {
+  pcr_sa_params p;
+  int C0, C0P, RP, TB, CPW, rowsA, rowsB;
+};
+
+__global__ __launch_bounds__(kThreads) void sa_mlp_kernel(SaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const pcr_sa_params &p = a.p;
+  float *bufA = smem;
+  float *bufB = smem + a.rowsA * a.RP;
+  int *sidx = reinterpret_cast<int *>(bufB + a.rowsB * a.RP);
+  const int tid = threadIdx.x;
+  const size_t b = blockIdx.y;
+  const int c0 = blockIdx.x * a.CPW;
+  const int nc = (p.S - c0 < a.CPW) ? p.S - c0 : a.CPW;
+  const int rows = nc * p.K, ROWS = 32 * a.TB, RP = a.RP;
+  const int K = p.K, D = p.D, N = p.N;
+
+  for (int r = tid; r < ROWS; r += kThreads)
+    sidx[r] = r < rows ? p.idx[(b * p.S + c0) * K + r] : -1;
+  __syncthreads();
+
+  // gather + relative / edge features -> bufA [C0P][RP]
+  const float *xyz = p.xyz + b * N * 3;
+  const float *feat = D ? p.feat + b * D * N : nullptr;
+  const size_t fs_c = p.feat_point_major ? 1 : (size_t)N, fs_n = p.feat_point_major ? (size_t)D : 1;
+  for (int e = tid; e < a.C0P * ROWS; e += kThreads) {
+    const int ch = e / ROWS, r = e - ch * ROWS;
+    float v = 0.f;
+    if (ch < a.C0 && r < rows) {
+      const int s = c0 + r / K;
+      const int ci = p.centre_idx ? p.centre_idx[b * p.S + s] : s;
+      const int i = sidx[r];
+      if (ch < 3) {
+        v = xyz[i * 3 + ch] - xyz[ci * 3 + ch];
+      } else if (p.mode == 0) {
+        const int f = ch - 3;
+        if (f < D) v = feat[fs_c * f + fs_n * ci];
+        else v = feat[fs_c * (f - D) + fs_n * i] - feat[fs_c * (f - D) + fs_n * ci];
+      } else {
+        v = feat[fs_c * (ch - 3) + fs_n * i];
+      }
+    }
+    bufA[ch * RP + r] = v;
+  }
+  __syncthreads();
+
+  const int c1 = p.c1, c2 = p.c2, c3 = p.c3;
+  {
+    const float *sc = p.scale[0], *sh = p.shift[0];
+    const int lim = ceil8(c1);
+    tile_dense(bufA, a.C0P, RP, a.TB, p.wp[0], ceil32(c1), [&](float v, int o, int t) {
+      if (o < lim) bufB[o * RP + t] = o < c1 ? fmaxf(v * sc[o] + sh[o], 0.f) : 0.f;
+    });
+  }
+  __syncthreads();
+  {
+    const float *sc = p.scale[1], *sh = p.shift[1];
+    const int lim = ceil8(c2);
+    tile_dense(bufB, ceil8(c1), RP, a.TB, p.wp[1], ceil32(c2), [&](float v, int o, int t) {
+      if (o < lim) bufA[o * RP + t] = o < c2 ? fmaxf(v * sc[o] + sh[o], 0.f) : 0.f;
+    });
+  }
+  __syncthreads();
+  {
+    const float *sc = p.scale[2], *sh = p.shift[2];
+    tile_dense(bufA, ceil8(c2), RP, a.TB, p.wp[2], ceil32(c3), [&](float v, int o, int t) {
+      if (o < c3) bufB[o * RP + t] = fmaxf(v * sc[o] + sh[o], 0.f);
+    });
+  }
+  __syncthreads();
+  // max over the K neighbours of each centre
+  for (int e = tid; e < c3 * nc; e += kThreads) {
+    const int c = e / c3, o = e - c * c3;
+    const float *row = bufB + o * RP + c * K;
+    float m = row[0];
+    for (int k = 1; k < K; k++) m = fmaxf(m, row[k]);
+    if (p.out_point_major) p.out[(b * p.S + c0 + c) * c3 + o] = m;
+    else p.out[(b * c3 + o) * p.S + c0 + c] = m;
+  }
+}
+
+#endif   // PCR_SA_PREC == 0 (the generic kernel)
+
+// ------------------------------------------------- grouped SA MLP, second generation ----
+// Layer 1 is linear in its input rows [dxyz, f_c, f_i - f_c] (edge) or [dxyz, f_i] (query-and-
+// group), so  W1 row = Wa dxyz + P[i] + Q[c]  with the per-POINT tables P = Wf f, Q = (Wc - Wf) f
+// computed once per cloud by dense_pm_kernel (K times fewer FLOPs than per (centre,neighbour)
+// row).  The kernel gathers P rows (16-byte loads) straight into the layer-1 activation tile,
+// then runs layers 2 and 3 on the matrix core IN PLACE in one LDS buffer and reduces max over K.
+
+// ReLU / max on the BIT patterns (signed integer max): exact for every finite input -- a float >= +0 has a
+// non-negative pattern that orders like the float, any negative float has a negative pattern -- as long as the
+// result is only ever used through max(., 0); one VALU instruction, no NaN-canonicalisation prefix.
+__device__ __forceinline__ float relu_bits(float v) {
+  const int b = __float_as_int(v);
+  return __int_as_float(b > 0 ? b : 0);
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+
+struct Sa2Args {
+  int B, N, S, K, c1, c2, c3, CPW;
+  const float *xyz;
+  const int *idx, *centre_idx;
+  const float *wa;          // (c1,3) row-major
+  const float *pq;          // (B,N,pqw) point-major or null (no features)
+  int pqw, qoff;            // row width; offset of Q inside a row, -1 = no Q term
+  int dbg;                  // PCR_SA_DBG ablation mask (diagnostics only; 0 in production)
+  const float *wp2, *wp3;
+  const float *sh1, *sh2, *sh3;   // folded BatchNorm shifts (sh2/sh3 zero-padded to a multiple of 32)
+  int out_pm;               // out is (B,S,c3)
+  const float *wap;         // packed (c1,3) image of wa, or null
+  int l1m;                  // layer 1 on the matrix core (wap given and c1 in layer 2's cout-block class)
+  float *out;
+};
+
+// NR / NR2: cout-block rounds per wave of layer 3 / layer 2 (2 when the layer has more than 4 x 32 couts)
+// RKB > 0 (narrow layers: c1, c2 <= 8 RKB): ALL weight fragments of layers 2 and 3 are fetched into registers at
+// the top of the kernel, behind the index staging and the gathers; the two dense calls then run without a single
+// weight load (their 4- or 8-block k-loops were mostly L2 latency)
+template <int TB, int NR, int W2, int W3, bool MAXE, int NR2 = NR, int RKB = 0, int PREC = 0>
+__global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
+  static_assert(PREC == 0 || RKB == 0, "resident f32 weight fragments belong to the f32 form");
+  constexpr int ROWS = 32 * TB, RP = ROWS + 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int c1 = a.c1, c2 = a.c2, c3 = a.c3, K = a.K;
+  constexpr bool kRes = RKB > 0;
+  constexpr int RK = kRes ? RKB : 2;
+  f32x4 wres2[RK][DenseShape<NR2, W2>::nr], wres3[RK][DenseShape<NR, W3>::nr];
+  if constexpr (kRes) {
+    tile_dense_ring_load<DenseShape<NR2, W2>::nr, DenseShape<NR2, W2>::ways, RK>(a.wp2, c1, ceil32(c2), wres2);
+    tile_dense_ring_load<DenseShape<NR, W3>::nr, DenseShape<NR, W3>::ways, RK>(a.wp3, ceil8(c2), ceil32(c3), wres3);
+  }
+  // MAXE (K % 16 == 0): the max over K is taken from the layer-3 accumulators (16-lane DPP groups ->
+  // gmax[c3][ROWS/16]) and the (c3 x rows) layer-3 output is never materialised in LDS
+  int rowsC = c1 > ceil32(c2) ? c1 : ceil32(c2);
+  if (!MAXE && ceil32(c3) > rowsC) rowsC = ceil32(c3);
+  float *buf = smem;                                        // [rowsC][RP]
+  float *sdx = buf + rowsC * RP;                            // [4][ROWS]: dx, dy, dz and a zero row (MFMA k = 3)
+  int *sidx = reinterpret_cast<int *>(sdx + 4 * ROWS);      // [ROWS] neighbour, [ROWS] centre point
+  int *scen = sidx + ROWS;
+  float *sq = reinterpret_cast<float *>(scen + ROWS);     // [CPW][c1] per-centre Q rows + shift
+  float *gmax = sdx;   // [c3][2*TB] (MAXE only): reuses the staging arrays, all dead once layer 1 is built
+  const int tid = threadIdx.x;
+  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so the workgroups of
+  // ONE cloud -- which gather rows of the same table -- would pull that table into eight L2s.  Linear id w is remapped
+  // so that the ids an XCD receives (w % 8 == x) cover whole consecutive clouds (bijective for any grid size).
+  int bsw, xsw;
+  {
+    const unsigned nwg = gridDim.x * gridDim.y, orig = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned xcd = orig & 7u, q = nwg >> 3, rr = nwg & 7u;
+    const unsigned swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
+    bsw = (int)(swz / gridDim.x);
+    xsw = (int)(swz - (unsigned)bsw * gridDim.x);
+  }
+  const size_t b = (size_t)bsw;
+  const int c0 = xsw * a.CPW;
+  const int nc = (a.S - c0 < a.CPW) ? a.S - c0 : a.CPW;
+  const int rows = nc * K;
+  const float *xyz = a.xyz + b * a.N * 3;
+
+  for (int r = tid; r < ROWS; r += kThreads) {
+    int i = -1, ci = -1;
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (r < rows) {
+      const int s = c0 + r / K;
+      ci = a.centre_idx ? a.centre_idx[b * a.S + s] : s;
+      i = a.idx[(b * a.S + c0) * K + r];
+      dx = xyz[i * 3] - xyz[ci * 3];
+      dy = xyz[i * 3 + 1] - xyz[ci * 3 + 1];
+      dz = xyz[i * 3 + 2] - xyz[ci * 3 + 2];
+    }
+    sidx[r] = i;
+    scen[r] = ci;
+    sdx[r] = dx;
+    sdx[ROWS + r] = dy;
+    sdx[2 * ROWS + r] = dz;
+    sdx[3 * ROWS + r] = 0.f;
+  }
+  __syncthreads();
+  if (!(a.dbg & 1)) {
+  // layer 1 (VALU + gathers): four output channels per item, rows fastest across lanes; the
+  // 16-byte P-row gathers of four items are issued before any of them is consumed; the per-centre
+  // Q rows (+ folded BatchNorm shift) and the dxyz weights are staged once in LDS.  The host has
+  // folded the BatchNorm scale into wa / P / Q, so the layer is  relu(wa dxyz + P[i] + Q[c]).
+  const float *pq = a.pq ? a.pq + b * a.N * (size_t)a.pqw : nullptr;
+  const bool has_q = pq && a.qoff >= 0;
+  for (int e = tid; e < nc * c1; e += kThreads) {
+    const int c = e / c1, o = e - c * c1;
+    sq[e] = a.sh1[o] + (has_q ? pq[(size_t)scen[c * K] * a.pqw + a.qoff + o] : 0.f);
+  }
+  __syncthreads();
+  if (a.l1m) {
+    // Layer 1 on the matrix core: relu(Wa dxyz + (shift + Q[c]) + P[i]) per 32 x 32 tile is two MFMAs (k = dx, dy |
+    // dz, 0) on accumulators SEEDED with the centre's shift + Q row, plus the table piece in the epilogue -- the fma
+    // order of the VALU form below, so the bits are the same.  A lane gathers its token's pieces in the accumulator
+    // layout (four runs of four couts), one tile ahead.  Tiles are dealt to the waves like layer 2's.
+    constexpr int WAYS = DenseShape<NR2, W2>::ways;
+    constexpr int TBW = (TB + WAYS - 1) / WAYS;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nCB = ceil32(c1) >> 5;
+    const int cb = WAYS == 1 ? wave : (WAYS == 2 ? (wave & 1) : 0);
+    const int tb0 = WAYS == 1 ? 0 : (WAYS == 2 ? (wave >> 1) : wave);
+    if (cb < nCB) {
+      const f32x4 av = reinterpret_cast<const f32x4 *>(a.wap)[(size_t)cb * 64 + l31 * 2 + h];   // k = h, 2+h, (4+h, 6+h)
+      f32x4 pc[4], pn[4];
+      auto gather = [&](f32x4 (&p)[4], int tb) {
+        const int i = sidx[tb * 32 + l31];
+        const float *pr = pq + (size_t)(i < 0 ? 0 : i) * a.pqw + cb * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; g++) p[g] = *reinterpret_cast<const f32x4 *>(pr + 8 * g);
+      };
+      if (pq && tb0 < TB) gather(pc, tb0);
+#pragma unroll
+      for (int j = 0; j < TBW; j++) {
+        const int tb = tb0 + j * WAYS;
+        if (tb < TB) {
+          const int t = tb * 32 + l31;
+          if (pq && tb + WAYS < TB) gather(pn, tb + WAYS);
+          int c = t / K;
+          c = c < nc ? c : nc - 1;
+          const float *sr = sq + c * c1 + cb * 32 + 4 * h;
+          f32x16 acc;
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            const f32x4 s4 = *reinterpret_cast<const f32x4 *>(sr + 8 * g);
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc[4 * g + q] = s4[q];
+          }
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], sdx[h * ROWS + t], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], sdx[(2 + h) * ROWS + t], acc, 0, 0, 0);
+          float *dst = buf + (cb * 32 + 4 * h) * RP + t;
+#pragma unroll
+          for (int rr = 0; rr < 16; rr++) {
+            const float v = pq ? acc[rr] + pc[rr >> 2][rr & 3] : acc[rr];
+            dst[((rr & 3) + 8 * (rr >> 2)) * RP] = relu_bits(v);
+          }
+#pragma unroll
+          for (int g = 0; g < 4; g++) pc[g] = pn[g];
+        }
+      }
+    }
+  } else {
+  const int total = ROWS * (c1 >> 2);
+  constexpr int dR = kThreads % ROWS, dO = kThreads / ROWS;
+  int r = tid % ROWS, oq = tid / ROWS;
+  for (int e0 = tid; e0 < total; e0 += 4 * kThreads) {
+    f32x4 p4[4];
+    int rr[4], oo[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      rr[u] = r;
+      oo[u] = oq << 2;
+      p4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (pq && e0 + u * kThreads < total && r < rows)
+        p4[u] = *reinterpret_cast<const f32x4 *>(pq + (size_t)sidx[r] * a.pqw + oo[u]);
+      r += dR;
+      oq += dO;
+      if (r >= ROWS) { r -= ROWS; oq++; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (e0 + u * kThreads < total) {
+        const int rw = rr[u], o = oo[u];
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (rw < rows) {
+          const float dx = sdx[rw], dy = sdx[ROWS + rw], dz = sdx[2 * ROWS + rw];
+          const float *w = a.wa + o * 3;
+          const float *qr = sq + (rw / K) * c1 + o;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            // the order of the matrix-core form of this layer (sa_rag_kernel, W1): an fma chain over dx, dy, dz
+            // seeded with shift (+ Q), then the table piece -- both kernels give the same bits
+            const float t = fmaf(w[3 * j + 2], dz, fmaf(w[3 * j + 1], dy, fmaf(w[3 * j], dx, qr[j])));
+            v[j] = relu_bits(t + p4[u][j]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) buf[(o + j) * RP + rw] = v[j];
+      }
+    }
+  }
+  }
+  }
+  __syncthreads();
+  for (int rep = 0; rep < ((a.dbg & 8) ? 4 : 1); rep++) {   // dbg bit 8: 4x the matrix work (diagnostic)
+  if (rep) __syncthreads();
+  if (!(a.dbg & 2)) {
+    {
+      // BatchNorm scale is folded into wp2/wp3 by the host, the shift seeds the accumulators
+      // the buffer has ceil32(c2) rows, so every accumulator row is stored unconditionally (rows past c2
+      // see zero weights and a zero seed -> relu(0) = 0, which is the zero padding layer 3 wants)
+      auto epi2 = [&](float v, int o, int t) { buf[o * RP + t] = relu_bits(v); };
+      if constexpr (kRes)
+        tile_dense2<TB, NR2, W2, false, decltype(epi2), DenseNoHook, RK, true>(buf, c1, a.wp2, ceil32(c2), true, epi2,
+                                                                               a.sh2, wres2);
+      else
+        tile_dense2p<PREC, TB, NR2, W2>(buf, c1, a.wp2, ceil32(c2), true, epi2, a.sh2);
+    }
+    __syncthreads();
+    if constexpr (MAXE) {
+      constexpr int NG = 2 * TB;
+      // (signed maxima of the bit patterns, ReLU at the end: see relu_bits)
+      auto epi3 = [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int o = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          int v = __float_as_int(acc[r]);
+          v = imax(v, dpp_i32<0xB1>(v));    // quad_perm [1,0,3,2]  : lane ^ 1
+          v = imax(v, dpp_i32<0x4E>(v));    // quad_perm [2,3,0,1]  : lane ^ 2
+          v = imax(v, dpp_i32<0x141>(v));   // row_half_mirror      : other quad of the 8-lane half
+          v = imax(v, dpp_i32<0x140>(v));   // row_mirror           : other half of the 16-lane row
+          if ((l31 & 15) == 0) gmax[o * NG + tb * 2 + (l31 >> 4)] = __int_as_float(imax(v, 0));   // ceil32(c3) rows
+        }
+      };
+      if constexpr (kRes)
+        tile_dense2<TB, NR, W3, true, decltype(epi3), DenseNoHook, RK, true>(buf, ceil8(c2), a.wp3, ceil32(c3), false,
+                                                                             epi3, a.sh3, wres3);
+      else
+        tile_dense2p<PREC, TB, NR, W3, true>(buf, ceil8(c2), a.wp3, ceil32(c3), false, epi3, a.sh3);
+    } else {
+      tile_dense2p<PREC, TB, NR, W3>(buf, ceil8(c2), a.wp3, ceil32(c3), true, [&](float v, int o, int t) {
+        buf[o * RP + t] = fmaxf(v, 0.f);
+      }, a.sh3);
+    }
+  }
+  }
+  __syncthreads();
+  if (a.dbg & 4) return;
+  if constexpr (MAXE) {
+    constexpr int NG = 2 * TB;
+    const int gpc = K >> 4;  // 16-row groups per centre
+    // centre fastest across lanes: the nc outputs of one channel are adjacent in (B,c3,S), so a wave
+    // store touches 64/nc lines instead of 64 (the store is still nc*4 bytes per line: see DESIGN.md 4.1)
+    for (int e = tid; e < c3 * nc; e += kThreads) {
+      const int o = a.out_pm ? e % c3 : e / nc, c = a.out_pm ? e / c3 : e - o * nc;
+      const float *g = gmax + o * NG + c * gpc;
+      float m = g[0];
+      for (int k = 1; k < gpc; k++) m = fmaxf(m, g[k]);
+      if (a.out_pm) a.out[(b * a.S + c0 + c) * c3 + o] = m;
+      else a.out[(b * c3 + o) * a.S + c0 + c] = m;
+    }
+  } else {
+    for (int e = tid; e < c3 * nc; e += kThreads) {
+      const int o = a.out_pm ? e % c3 : e / nc, c = a.out_pm ? e / c3 : e - o * nc;
+      const float *row = buf + o * RP + c * K;
+      float m = row[0];
+      for (int k = 1; k < K; k++) m = fmaxf(m, row[k]);
+      if (a.out_pm) a.out[(b * a.S + c0 + c) * c3 + o] = m;
+      else a.out[(b * c3 + o) * a.S + c0 + c] = m;
+    }
+  }
+}
+
+// ------------------------------------------------- ragged SA MLP (ball-query duplicates) ----
+// A ball-query row holds only cnt genuine neighbours; entries [cnt, K) repeat the first one
+// (ball_query_cuda.cu:43-47), and a max over K does not care about repeats.  This variant runs the MLP
+// on ceil2(max(cnt,1)) rows per centre instead of K:
+//   sa_rag_plan_kernel  one thread per cloud walks the S counts and packs whole centres into tiles of
+//                       32*TB rows -> per-cloud tile descriptors + tile count;
+//   sa_rag_scan_kernel  one workgroup: exclusive scan of the tile counts over the clouds;
+//   sa_rag_flatten_kernel  one wave per cloud copies its descriptors into ONE flat list (cloud, first centre, n);
+//   sa_rag_rows_kernel  one wave per tile: the row table {neighbour index, dxyz} of the tile and the
+//                       first row of each of its centres (the cnt -> prefix -> idx -> xyz chain of four
+//                       dependent global loads, taken off the matrix kernel's critical path);
+//   sa_rag_kernel       persistent: CUs x residency workgroups stride over the flat list (a grid of
+//                       B x worst-case tiles would be 5/6 empty workgroups, which cost the chip a fifth of
+//                       its workgroup slots); each tile is sa_fused_kernel's pipeline with a 4-lane
+//                       (quad DPP) max; the row table of the NEXT tile is fetched during the matrix
+//                       phases.  Output is bit-identical to the dense kernel's.
+// Workspace (ints): nt[B] | total | desc[B][2*maxT] | pad4 | flat[B*maxT][4] | ctab[B*maxT][ROWS/4+4]
+//                   | rowtab[B*maxT][ROWS][4]
+struct RagArgs {
+  int B, N, S, K, c1, c2, c3, maxT;
+  const float *xyz;
+  const int *idx, *cnt, *centre_idx;
+  int *ws;
+  const float *wa, *pq;
+  const float *wap;         // packed (c1, 3) image of wa (layer 1 on the matrix core), or null
+  int pqw;
+  int dbg;                  // PCR_SA_DBG ablation mask (diagnostics only; 0 in production)
+  int out_pm;               // out is (B,S,c3)
+  const float *wp2, *wp3, *sh1, *sh2, *sh3;
+  float *out;
+};
+
+// rows of a centre are padded to a multiple of kRagG (the max over a centre's rows starts with a DPP max inside
+// groups of kRagG lanes): 2 instead of 4 costs twice the LDS for the group maxima and saves a quarter of the rows
+// of sparsely populated balls (mean 2.9 hits: 4.5 -> 3.4 rows per centre)
+constexpr int kRagG = 2;
+__host__ __device__ inline int rag_ceil(int x) { return (x + kRagG - 1) & ~(kRagG - 1); }
+constexpr int kRagCT = 4;   // ints per tile in ctab: ends mask (2 x 32 bits), group count, pad
+
+__host__ __device__ inline size_t rag_desc_off(int B) { return ((size_t)B + 2) & ~(size_t)1; }   // (8-byte aligned pairs)
+__host__ __device__ inline size_t rag_flat_off(int B, int maxT) {
+  return (rag_desc_off(B) + (size_t)B * 2 * maxT + 3) & ~(size_t)3;
+}
+__host__ __device__ inline size_t rag_ctab_off(int B, int maxT) {
+  return rag_flat_off(B, maxT) + (size_t)B * maxT * 4;
+}
+__host__ __device__ inline size_t rag_rowtab_off(int B, int maxT, int rows) {
+  (void)rows;
+  return rag_ctab_off(B, maxT) + (size_t)B * maxT * kRagCT;
+}
+__host__ __device__ inline size_t rag_ws_ints(int B, int maxT, int rows) {
+  return rag_rowtab_off(B, maxT, rows) + (size_t)B * maxT * rows * 4;
+}
+
+// one WAVE per cloud: the counts arrive 64 at a time with one coalesced load, the greedy walk itself runs
+// on the scalar unit (v_readlane with a uniform lane index), lane 0 stores the descriptors
+__global__ __launch_bounds__(256) void sa_rag_plan_kernel(RagArgs a, int rows_per_tile) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.B) return;
+  const int *cnt = a.cnt ? a.cnt + (size_t)b * a.S : nullptr;   // no counts: every row of idx is genuine (kNN groups)
+  int *tl = a.ws + rag_desc_off(a.B) + (size_t)b * 2 * a.maxT;
+  int t = 0, used = 0, first = 0;
+  for (int base = 0; base < a.S; base += 64) {
+    int c = (cnt && base + lane < a.S) ? cnt[base + lane] : (cnt ? 1 : a.K);
+    c = c < 1 ? 1 : (c > a.K ? a.K : c);
+    const int g = rag_ceil(c);
+    const int nv = a.S - base < 64 ? a.S - base : 64;
+    for (int l = 0; l < nv; l++) {
+      const int gl = __builtin_amdgcn_readlane(g, l);
+      if (used + gl > rows_per_tile) {
+        if (lane == 0) {
+          tl[2 * t] = first;
+          tl[2 * t + 1] = base + l - first;
+        }
+        t++;
+        first = base + l;
+        used = 0;
+      }
+      used += gl;
+    }
+  }
+  if (lane == 0) {
+    tl[2 * t] = first;
+    tl[2 * t + 1] = a.S - first;
+    a.ws[b] = t + 1;
+  }
+}
+
+// exclusive scan of the per-cloud tile counts (one workgroup; four clouds per thread and iteration), in place:
+// ws[b] <- first flat index of cloud b, ws[B] <- total
+__global__ __launch_bounds__(1024) void sa_rag_scan_kernel(int B, int *ws) {
+  __shared__ int wtot[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < B; base += 4096) {
+    int v[4];
+    int sum = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int b = base + tid * 4 + u;
+      v[u] = b < B ? ws[b] : 0;
+      sum += v[u];
+    }
+    int incl = sum;                          // wave scans, then one scan over the 16 wave totals: two barriers
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+      int w = lane < 16 ? wtot[lane] : 0;
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) {
+        const int t = __shfl_up(w, off, 64);
+        if (lane >= off) w += t;
+      }
+      if (lane < 16) wtot[lane] = w;         // inclusive totals
+    }
+    __syncthreads();
+    int excl = incl - sum + (wave ? wtot[wave - 1] : 0) + carry;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int b = base + tid * 4 + u;
+      if (b < B) ws[b] = excl;
+      excl += v[u];
+    }
+    __syncthreads();
+    if (tid == 1023) carry = excl;
+    __syncthreads();
+  }
+  if (tid == 0) ws[B] = carry;
+}
+
+// one wave per cloud: its descriptors (first centre, n centres) -> the flat list entries (cloud, first, n, -)
+__global__ __launch_bounds__(256) void sa_rag_flatten_kernel(int B, int maxT, int *ws) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int lo = ws[b], hi = b + 1 < B ? ws[b + 1] : ws[B];
+  const int2 *dsrc = reinterpret_cast<const int2 *>(ws + rag_desc_off(B) + (size_t)b * 2 * maxT);
+  int4 *flat = reinterpret_cast<int4 *>(ws + rag_flat_off(B, maxT));
+  for (int j = lane; j < hi - lo; j += 64) {
+    const int2 d = dsrc[j];
+    flat[lo + j] = make_int4(b, d.x, d.y, 0);
+  }
+}
+
+// one wave per tile (4 tiles per workgroup), grid-stride over the flat list
+template <int ROWS>
+__global__ __launch_bounds__(256) void sa_rag_rows_kernel(RagArgs a) {
+  constexpr int MAXC = ROWS / kRagG, CT = kRagCT;   // MAXC <= 64: one lane per centre
+  __shared__ int s_off[4][MAXC + 1], s_cnt[4][MAXC];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int total = a.ws[a.B];
+  const int4 *flat = reinterpret_cast<const int4 *>(a.ws + rag_flat_off(a.B, a.maxT));
+  int *ctab = a.ws + rag_ctab_off(a.B, a.maxT);
+  f32x4 *rowtab = reinterpret_cast<f32x4 *>(a.ws + rag_rowtab_off(a.B, a.maxT, ROWS));
+  for (int tile = blockIdx.x * 4 + w; tile < total; tile += gridDim.x * 4) {
+    const int4 td = flat[tile];
+    const size_t b = (size_t)td.x;
+    const int first = td.y, nc = td.z;      // 1 <= nc <= MAXC <= 64 lanes
+    int n = 1;
+    if (lane < nc) {
+      n = a.cnt ? a.cnt[b * a.S + first + lane] : a.K;
+      n = n < 1 ? 1 : (n > a.K ? a.K : n);
+    }
+    const int g = lane < nc ? rag_ceil(n) : 0;
+    int incl = g;                            // inclusive prefix over the lanes of the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane < nc) {
+      s_off[w][lane] = incl - g;
+      s_cnt[w][lane] = n;
+    }
+    const int used_rows = __shfl(incl, nc - 1, 64);
+    if (lane == 0) s_off[w][nc] = used_rows;
+    {  // bit q of `ends`: row group q is the last group of its centre (what the max-pool epilogue scans)
+      const int last = (incl / kRagG) - 1;
+      unsigned lo32 = (lane < nc && last < 32) ? 1u << last : 0u;
+      unsigned hi32 = (lane < nc && last >= 32) ? 1u << (last - 32) : 0u;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        lo32 |= __shfl_xor(lo32, off, 64);
+        hi32 |= __shfl_xor(hi32, off, 64);
+      }
+      if (lane == 0) {
+        ctab[(size_t)tile * CT] = (int)lo32;
+        ctab[(size_t)tile * CT + 1] = (int)hi32;
+        ctab[(size_t)tile * CT + 2] = used_rows / kRagG;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the wave's own LDS writes have landed
+    const int used = s_off[w][nc];
+    const float *xyz = a.xyz + b * a.N * 3;
+    for (int r = lane; r < ROWS; r += 64) {
+      f32x4 v = {__int_as_float(-1), 0.f, 0.f, 0.f};
+      if (r < used) {
+        int lo = 0, hi = nc - 1;             // last centre whose first row is <= r
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (s_off[w][mid] <= r) lo = mid; else hi = mid - 1;
+        }
+        const int c = lo, k = r - s_off[w][c];
+        const int s = first + c;
+        const int ci = a.centre_idx ? a.centre_idx[b * a.S + s] : s;
+        const int i = a.idx[(b * a.S + s) * a.K + (k < s_cnt[w][c] ? k : 0)];
+        v[0] = __int_as_float(i);
+        v[1] = xyz[i * 3] - xyz[ci * 3];
+        v[2] = xyz[i * 3 + 1] - xyz[ci * 3 + 1];
+        v[3] = xyz[i * 3 + 2] - xyz[ci * 3 + 2];
+      }
+      rowtab[(size_t)tile * ROWS + r] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// PCR_SA_TRACE=<file> (diagnostics only): wave 0 of every workgroup stamps the shader clock at the phase
+// boundaries of its first kTraceTiles tiles; the host dumps the buffer after the launch
+constexpr int kTraceWgs = 1024, kTraceTiles = 24, kTraceMarks = 8;
+__device__ unsigned long long g_rag_trace[kTraceWgs * (2 + kTraceTiles * kTraceMarks)];
+
+// W1 != 0: layer 1 on the matrix core as well.  relu(Wa dxyz + P[i] + shift) is a one-k-block dense call on the
+// [dx;dy;dz;0..] rows of the tile (seeded with the shift) whose epilogue adds the table pieces, which each lane
+// gathers directly in the accumulator layout (token = lane, four runs of four couts): ~100 instructions per tile
+// instead of ~500 of VALU / LDS work.  (Host picks it when c1 has at most four cout blocks and, with a table, TB = 2.)
+template <int TB, int NR, int W2, int W3, int NR2 = NR, int W1 = 0, int PREC = 0>
+__global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
+  constexpr int ROWS = 32 * TB, RP = ROWS + 1, NG = ROWS / kRagG, CT = kRagCT;
+  constexpr bool kL1M = W1 != 0;
+  const int C3P = ceil32(a.c3);           // gmax is [NG row groups][C3P]
+  constexpr int QS = kThreads / ROWS;     // channel quads advance by QS per item: a thread keeps ONE row
+  constexpr int NI = 8;                   // 16-byte table pieces a thread holds in registers
+  const bool tracing = (a.dbg & 256) && threadIdx.x == 0 && blockIdx.x < kTraceWgs;
+  unsigned long long *trace = g_rag_trace + (size_t)blockIdx.x * (2 + kTraceTiles * kTraceMarks);
+  int trace_it = 0;
+  if (tracing) {
+    trace[0] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID, 32 bits
+    trace[1] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+  }
+#ifdef PCR_SA_TRACE_BUILD   // diagnostic builds only (the stamps cost registers in the hot kernel)
+#define PCR_MARK(m)                                                                                    \
+  do {                                                                                                 \
+    if (tracing && trace_it < kTraceTiles) trace[2 + trace_it * kTraceMarks + (m)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define PCR_MARK(m) do { (void)tracing; (void)trace; } while (0)
+#endif
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int c1 = a.c1, c2 = a.c2, c3 = a.c3;
+  // XCD-aware tile ranges: workgroup ids are dealt round-robin over the 8 XCDs (own L2 each); the flat tile list is
+  // ordered by cloud, so XCD x (ids = x mod 8) takes the contiguous eighth [t_lo, t_end) of it and its workgroups stride
+  // through that range -- the tiles of one cloud, which gather rows of the same table, then share one L2
+  const int n_all = a.ws[a.B];
+  const bool xaware = gridDim.x >= 8;      // (fewer than eight workgroups: plain striding, every range needs an owner)
+  const int xcd = blockIdx.x & 7;
+  const int t_step = xaware ? ((int)gridDim.x + 7 - xcd) >> 3 : (int)gridDim.x;
+  const int t_lo = xaware ? (int)((long long)n_all * xcd / 8) : 0;
+  const int total = xaware ? (int)((long long)n_all * (xcd + 1) / 8) : n_all;
+  const int t_first = xaware ? t_lo + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int4 *flat = reinterpret_cast<const int4 *>(a.ws + rag_flat_off(a.B, a.maxT));
+  const int *ctab = a.ws + rag_ctab_off(a.B, a.maxT);
+  const f32x4 *rowtab = reinterpret_cast<const f32x4 *>(a.ws + rag_rowtab_off(a.B, a.maxT, ROWS));
+  const int rowsC = c1 > ceil32(c2) ? c1 : ceil32(c2);
+  float *buf = smem;                                          // [rowsC][RP]
+  float *gmax = buf + rowsC * RP;                             // [NG][ceil32(c3)], 16-byte aligned
+  float *s_wa = gmax + NG * C3P;                              // [c1][3] dxyz weights and [ceil32(c1)] shift of
+  float *s_sh1 = s_wa + 3 * c1;                               //   layer 1, staged once per (persistent) workgroup
+  float *s_sh2 = s_sh1 + ceil32(c1);                          // accumulator seeds of layers 2 / 3 (zero-padded)
+  float *s_sh3 = s_sh2 + ceil32(c2);
+  float *sdx8 = s_sh3 + C3P;                                  // [8][RP] (kL1M): dx, dy, dz of the tile's rows, 5 zero rows
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 3 * c1; e += kThreads) s_wa[e] = a.wa[e];
+  for (int e = tid; e < ceil32(c1); e += kThreads) s_sh1[e] = e < c1 ? a.sh1[e] : 0.f;
+  if constexpr (kL1M)
+    for (int e = tid; e < 8 * RP; e += kThreads) sdx8[e] = 0.f;
+  for (int e = tid; e < ceil32(c2); e += kThreads) s_sh2[e] = a.sh2[e];
+  for (int e = tid; e < C3P; e += kThreads) s_sh3[e] = a.sh3[e];
+  // weight fragments of the NEXT dense call, requested as soon as the previous call's k-loop is over (explicit
+  // shapes only): the L2 round trip then never sits between a barrier and the first MFMA
+  constexpr bool kRing = PCR_RING && W2 != 0 && W3 != 0 && PREC == 0;   // (the bf16 tile streams its own ring)
+  f32x4 ring2[PCR_PF][DenseShape<NR2, W2>::nr], ring3[PCR_PF][DenseShape<NR, W3>::nr];
+  auto load_ring2 = [&]() {
+    if constexpr (kRing && PCR_RING == 1) tile_dense_ring_load<DenseShape<NR2, W2>::nr, DenseShape<NR2, W2>::ways>(a.wp2, c1, ceil32(c2), ring2);
+  };
+  auto load_ring3 = [&]() {
+    if constexpr (kRing) tile_dense_ring_load<DenseShape<NR, W3>::nr, DenseShape<NR, W3>::ways>(a.wp3, ceil8(c2), C3P, ring3);
+  };
+  load_ring2();
+  const int r = tid % ROWS, q0 = tid / ROWS;   // this thread's row of every tile, its first channel quad
+  const int nq = c1 >> 2;                      // channel quads of layer 1
+  const int ni = (nq - q0 + QS - 1) / QS;      // items of this thread: quads q0, q0 + QS, ...
+  // PREF: the whole layer-1 gather of the NEXT tile (<= NI pieces per thread) is in flight during layer 3
+  const bool pref = a.pq && ni <= NI;
+  // per-tile state in registers: the thread's row entry {neighbour index, dxyz}, its table pieces, the tile's
+  // segment mask (bit q: row group q closes a centre; wave-uniform)
+  f32x4 rv = {__int_as_float(-1), 0.f, 0.f, 0.f};
+  f32x4 p4[NI];
+  unsigned ends_lo = 0u, ends_hi = 0u, nxt_lo = 0u, nxt_hi = 0u;
+  auto fetch_row = [&](int tile) {
+    if (tile < total) {
+      rv = rowtab[(size_t)tile * ROWS + r];
+      nxt_lo = (unsigned)ctab[(size_t)tile * CT];
+      nxt_hi = (unsigned)ctab[(size_t)tile * CT + 1];
+    }
+  };
+  const int lane = tid & 63, wv = tid >> 6;
+  auto gather = [&](int tile) {   // table pieces of the row held in rv (tile's cloud from the flat list)
+    if (tile < total) {
+      const size_t bt = (size_t)flat[tile].x;
+      if constexpr (kL1M) {
+        // accumulator layout (TB = 2, one cout block per wave): tokens l31 and 32 + l31 (their row entries are
+        // this lane's and lane ^ 32's), couts 32 wave + 8 g + 4 h .. + 3
+        const int own = __float_as_int(rv[0]), other = __shfl_xor(own, 32, 64);
+        const int h = lane >> 5;
+        const int i0 = h ? other : own, i1 = h ? own : other;
+        const float *pr0 = a.pq + (bt * a.N + (size_t)(i0 < 0 ? 0 : i0)) * a.pqw + wv * 32 + 4 * h;
+        const float *pr1 = a.pq + (bt * a.N + (size_t)(i1 < 0 ? 0 : i1)) * a.pqw + wv * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          p4[g] = *reinterpret_cast<const f32x4 *>(pr0 + 8 * g);
+          p4[4 + g] = *reinterpret_cast<const f32x4 *>(pr1 + 8 * g);
+        }
+      } else {
+        const float *prow = a.pq + (bt * a.N + (size_t)(__float_as_int(rv[0]) < 0 ? 0 : __float_as_int(rv[0]))) * a.pqw;
+#pragma unroll
+        for (int u = 0; u < NI; u++) {
+          const int oq = q0 + u * QS;
+          p4[u] = *reinterpret_cast<const f32x4 *>(prow + 4 * (oq < nq ? oq : 0));
+        }
+      }
+    }
+  };
+  auto stash_dxyz = [&]() {   // (kL1M) the row entry in rv -> B operand rows of layer 1
+    if (q0 == 0) {
+      sdx8[r] = rv[1];
+      sdx8[RP + r] = rv[2];
+      sdx8[2 * RP + r] = rv[3];
+    }
+  };
+  int par = 0;
+  __syncthreads();            // (sdx8 zeroed)
+  fetch_row(t_first);
+  ends_lo = nxt_lo;
+  ends_hi = nxt_hi;
+  if constexpr (kL1M) stash_dxyz();
+  if (pref || (kL1M && a.pq)) gather(t_first);
+  __syncthreads();
+  for (int tile = t_first; tile < total; tile += t_step, par ^= 1) {
+  const int4 td = flat[tile];
+  const size_t b = (size_t)td.x;
+  const int first = td.y;
+  PCR_MARK(0);
+  if constexpr (kL1M) {
+    const bool hasp = a.pq != nullptr;
+    tile_dense2<TB, 1, W1, true>(sdx8, 8, a.wap, ceil32(c1), false,
+                                 [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
+      float *dst = buf + (cb * 32 + 4 * h) * RP + tb * 32 + l31;
+#pragma unroll
+      for (int rr = 0; rr < 16; rr++) {
+        float v = acc[rr];
+        if (hasp) v += (tb == 0 ? p4[rr >> 2] : p4[4 + (rr >> 2)])[rr & 3];   // (TB = 2 whenever there is a table)
+        dst[((rr & 3) + 8 * (rr >> 2)) * RP] = relu_bits(v);
+      }
+    }, s_sh1);
+  } else
+  if (!(a.dbg & 1)) {  // layer 1 (BatchNorm scale folded into wa / P, shift added here): row r, quads q0 + u QS
+    const bool live = __float_as_int(rv[0]) >= 0;
+    const float dx = rv[1], dy = rv[2], dz = rv[3];
+    const float *prow = a.pq ? a.pq + (b * a.N + (size_t)(live ? __float_as_int(rv[0]) : 0)) * a.pqw : nullptr;
+    for (int u0 = 0; u0 < ni; u0 += NI) {
+      if (!pref && prow) {
+#pragma unroll
+        for (int u = 0; u < NI; u++) {
+          const int oq = q0 + (u0 + u) * QS;
+          p4[u] = *reinterpret_cast<const f32x4 *>(prow + 4 * (oq < nq ? oq : 0));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NI; u++) {
+        const int oq = q0 + (u0 + u) * QS;
+        if (oq < nq) {
+          const int o = oq << 2;
+          const float *w = s_wa + o * 3;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (live) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const float t = fmaf(w[3 * j + 2], dz, fmaf(w[3 * j + 1], dy, fmaf(w[3 * j], dx, s_sh1[o + j])));
+              v[j] = relu_bits(prow ? t + p4[u][j] : t);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; j++) buf[(o + j) * RP + r] = v[j];
+        }
+      }
+    }
+  }
+  PCR_MARK(1);
+  __syncthreads();
+  PCR_MARK(2);
+  fetch_row(tile + t_step);   // next tile's row entry: lands during layer 2
+  if (!(a.dbg & 2))
+  tile_dense2p<PREC, TB, NR2, W2>(buf, c1, a.wp2, ceil32(c2), true,
+                                  [&](float v, int o, int t) { buf[o * RP + t] = relu_bits(v); }, s_sh2,
+                                  kRing && PCR_RING == 1 ? ring2 : nullptr, load_ring3);
+  PCR_MARK(3);
+  if (pref || (kL1M && a.pq)) gather(tile + t_step);   // next tile's table pieces: land during layer 3
+  __syncthreads();
+  PCR_MARK(4);
+  if (!(a.dbg & 4))
+  tile_dense2p<PREC, TB, NR, W3, true>(buf, ceil8(c2), a.wp3, ceil32(c3), false,
+                                      [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
+    // row-pair maxima -> gmax[group][cout]: the 16 accumulator rows of a lane are four runs of four consecutive
+    // couts, so the first lane of every pair stores four 16-byte pieces
+    // (signed maxima of the bit patterns; the ReLU is the scan's max with 0: see relu_bits)
+    static_assert(kRagG == 2, "the DPP step below pairs lanes l and l ^ 1");
+    f32x4 g4[4];
+#pragma unroll
+    for (int rr = 0; rr < 16; rr++) {
+      int v = __float_as_int(acc[rr]);
+      v = imax(v, dpp_i32<0xB1>(v));    // lane ^ 1
+      g4[rr >> 2][rr & 3] = __int_as_float(v);
+    }
+    if ((l31 & 1) == 0) {
+      float *gq = gmax + (tb * 16 + (l31 >> 1)) * C3P + cb * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; g++) *reinterpret_cast<f32x4 *>(gq + 8 * g) = g4[g];
+    }
+  }, s_sh3, kRing ? ring3 : nullptr, load_ring2);
+  PCR_MARK(5);
+  if constexpr (kL1M) stash_dxyz();   // next tile's dxyz rows (layer 1 of this tile is long done)
+  __syncthreads();
+  PCR_MARK(6);
+  if (!(a.dbg & 8)) {
+    // one cout per thread; all quad maxima of the tile are read first (independent, conflict-free LDS reads),
+    // then scanned with the wave-uniform `ends` mask: values are >= 0 after the ReLU, so 0 starts a segment
+    if (tid < c3) {   // c3 <= 256 = kThreads
+      const int o = tid;
+      const float *g = gmax + o;
+      // a wave issues one instruction every few cycles whatever its kind: the per-step work is kept to a max,
+      // a bit test and (at a centre's last group) one store through a running 32-bit offset.  The mask has no bit
+      // beyond the tile's last group, so whatever the unused groups hold is never stored.
+      float *base = a.out_pm ? a.out + (b * a.S + first) * c3 : a.out + b * c3 * a.S + first;
+      unsigned off = a.out_pm ? (unsigned)o : (unsigned)o * (unsigned)a.S;
+      const unsigned step = a.out_pm ? (unsigned)c3 : 1u;
+      int m = 0;   // signed max of the bit patterns starting from +0 = max over the groups, then ReLU (relu_bits)
+#pragma unroll
+      for (int half = 0; half < NG / 32; half++) {
+        const unsigned ends = (unsigned)__builtin_amdgcn_readfirstlane((int)(half ? ends_hi : ends_lo));
+        float gv[32];
+#pragma unroll
+        for (int q = 0; q < 32; q++) gv[q] = g[(half * 32 + q) * C3P];
+#pragma unroll
+        for (int q = 0; q < 32; q++) {
+          m = imax(m, __float_as_int(gv[q]));
+          if ((ends >> q) & 1u) {
+            base[off] = __int_as_float(m);
+            off += step;
+            m = 0;
+          }
+        }
+      }
+    }
+  }
+  ends_lo = nxt_lo;
+  ends_hi = nxt_hi;
+  PCR_MARK(7);
+  trace_it++;
+  // no barrier needed here: the next tile's layer 1 writes buf (dead since layer 3), its layer 3 writes gmax
+  // only after two more barriers
+  }
+}
+
+#if PCR_SA_PREC == 0
+// y (B,L,cout) POINT-major = W x for x (B,cin,L) channel-major; cout <= 256, no activation.
+struct DensePmArgs {
+  const float *x, *wp;
+  float *y;
+  int cin, cout, L, x_pm;
+};
+
+// NR: cout-block rounds per wave (2 when cout > 128).  X and Y share one LDS buffer (barrier between the
+// k-loop and the epilogue), so a 128 -> 128 table needs 33 KB and four workgroups fit a CU.
+template <int NR>
+__global__ __launch_bounds__(kThreads) void dense_pm_kernel(DensePmArgs a) {
+  constexpr int TB = 2, T = 64, RP = 65;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // couts beyond 256 (the tables of 256- / 512-channel SA layers) go in windows of 256 along grid.z: the window's rows
+  // of the packed image start 8 floats per cout further in, the k-block stride stays that of the whole image
+  const int cinP = ceil8(a.cin), cout = a.cout;
+  const int w0 = blockIdx.z * 256;
+  const int wc = cout - w0 < 256 ? cout - w0 : 256;
+  float *X = smem;   // [max(cinP, ceil32(wc))][RP]
+  const size_t b = blockIdx.y;
+  const int t0 = blockIdx.x * T;
+  if (a.x_pm) load_tile_pm(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
+  else load_tile(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
+  __syncthreads();
+  tile_dense2<TB, NR>(X, cinP, a.wp + (size_t)w0 * 8, ceil32(wc), true, [&](float v, int o, int t) { X[o * RP + t] = v; },
+                      nullptr, nullptr, DenseNoHook(), ceil32(cout));
+  __syncthreads();
+  float *out = a.y + (b * a.L + t0) * (size_t)cout + w0;
+  if ((cout & 3) == 0) {
+    // 16-byte stores; item e = (token e / Q, cout quad e % Q) advances by kThreads: one division, then increments
+    const int Q = wc >> 2, total = Q * T;
+    const int dt = kThreads / Q, dq = kThreads - dt * Q;
+    int t = threadIdx.x / Q, q = threadIdx.x - t * Q;
+    for (int e = threadIdx.x; e < total; e += kThreads) {
+      if (t0 + t < a.L) {
+        const float *xs = X + 4 * q * RP + t;
+        *reinterpret_cast<f32x4 *>(out + (size_t)t * cout + 4 * q) = f32x4{xs[0], xs[RP], xs[2 * RP], xs[3 * RP]};
+      }
+      t += dt;
+      q += dq;
+      if (q >= Q) { q -= Q; t++; }
+    }
+  } else {
+    for (int e = threadIdx.x; e < wc * T; e += kThreads) {
+      const int t = e / wc, c = e - t * wc;
+      if (t0 + t < a.L) out[(size_t)t * cout + c] = X[c * RP + t];
+    }
+  }
+}
+
+#endif   // PCR_SA_PREC == 0 (table kernel)
+
+}  // namespace
+
+template <int TB, int NR, int W2, int W3, int NR2 = NR, int RKB = 0>
+static void sa2_launch_one(const Sa2Args &a, bool maxe, size_t lds, hipStream_t st, dim3 grid) {
+  if (maxe) {
+    static bool ok = allow_big_lds(sa_fused_kernel<TB, NR, W2, W3, true, NR2, RKB, kPrec>);
+    (void)ok;
+    hipLaunchKernelGGL((sa_fused_kernel<TB, NR, W2, W3, true, NR2, RKB, kPrec>), grid, dim3(kThreads), lds, st, a);
+  } else if constexpr (kPrec == 0) {
+    static bool ok = allow_big_lds(sa_fused_kernel<TB, NR, W2, W3, false, NR2, RKB, kPrec>);
+    (void)ok;
+    hipLaunchKernelGGL((sa_fused_kernel<TB, NR, W2, W3, false, NR2, RKB, kPrec>), grid, dim3(kThreads), lds, st, a);
+  }
+}
+
+// wsel: 1 / 2 / 4 when both MFMA layers have the same cout class (specialised bodies), else 0
+// nr2 / nr: cout-block rounds of layer 2 / of the wider of the two layers
+template <int TB>
+static int sa2_launch_tb(const Sa2Args &a, int nr, int nr2, int w2, int w3, bool maxe, size_t lds, hipStream_t st,
+                         dim3 grid) {
+  const int wsel = kPrec != 0 ? 10 * w2 + w3 : (w2 == w3 ? w2 : 0);
+  // resident weight fragments for 32-channel layers (2 x 16 VGPRs).  For 64-channel layers the 2 x 32 VGPRs cost
+  // more residency than the saved L2 round trips are worth (measured: 6.4 -> 7.9 ms on the 64/64/64 layer).
+  const bool narrow4 = a.c1 <= 32 && a.c2 <= 32;
+  if constexpr (kPrec != 0) {
+    // bf16 forms: explicit shapes, max-from-accumulators epilogue, at most two cout-block rounds (the callers checked);
+    // w23 = 10 * (ways of layer 2) + (ways of layer 3)
+    (void)narrow4;
+    if (!maxe || nr > 2) return -1;
+    if (wsel == 44) sa2_launch_one<TB, 1, 4, 4>(a, maxe, lds, st, grid);
+    else if (wsel == 22) sa2_launch_one<TB, 1, 2, 2>(a, maxe, lds, st, grid);
+    else if (wsel == 21) sa2_launch_one<TB, 1, 2, 1>(a, maxe, lds, st, grid);
+    else if (wsel == 11 && nr == 1) sa2_launch_one<TB, 1, 1, 1>(a, maxe, lds, st, grid);
+    else if (wsel == 11 && nr2 == 1) sa2_launch_one<TB, 2, 1, 1, 1>(a, maxe, lds, st, grid);
+    else if (wsel == 11) sa2_launch_one<TB, 2, 1, 1>(a, maxe, lds, st, grid);
+    else return -1;
+    return 0;
+  } else {
+  if (nr == 4) {
+    if constexpr (TB <= 2) sa2_launch_one<TB, 4, 1, 1, 4>(a, maxe, lds, st, grid);
+    else return -1;
+  } else if (wsel == 4 && narrow4) sa2_launch_one<TB, 1, 4, 4, 1, 4>(a, maxe, lds, st, grid);
+  else if (wsel == 4) sa2_launch_one<TB, 1, 4, 4>(a, maxe, lds, st, grid);
+  else if (wsel == 2) sa2_launch_one<TB, 1, 2, 2>(a, maxe, lds, st, grid);
+  else if (wsel == 1 && nr == 1) sa2_launch_one<TB, 1, 1, 1>(a, maxe, lds, st, grid);
+  else if (wsel == 1 && nr2 == 1) sa2_launch_one<TB, 2, 1, 1, 1>(a, maxe, lds, st, grid);
+  else if (wsel == 1) sa2_launch_one<TB, 2, 1, 1>(a, maxe, lds, st, grid);
+  else if (nr == 1) sa2_launch_one<TB, 1, 0, 0>(a, maxe, lds, st, grid);
+  else if (nr2 == 1) sa2_launch_one<TB, 2, 0, 0, 1>(a, maxe, lds, st, grid);
+  else sa2_launch_one<TB, 2, 0, 0>(a, maxe, lds, st, grid);
+  return 0;
+  }
+}
+
+extern "C" int pcr_dense_pm_f32(const float *, const float *, float *, int, int, int, int, int, pcr_stream_t);
+
+// diagnostics only (PCR_SA_TRACE): synchronises, appends one launch's phase stamps to the file
+static void rag_dump_trace(const char *path, const char *tag, int wgs) {
+  static int launches = 0;
+  if (launches++ >= 8) return;   // the first few launches are enough
+  static std::vector<unsigned long long> host(kTraceWgs * (2 + kTraceTiles * kTraceMarks));
+  if (hipDeviceSynchronize() != hipSuccess) return;
+  if (hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(g_rag_trace), host.size() * sizeof(unsigned long long)) != hipSuccess)
+    return;
+  FILE *f = fopen(path, "a");
+  if (!f) return;
+  const int n = wgs < kTraceWgs ? wgs : kTraceWgs;
+  fprintf(f, "launch %d kernel %s wgs %d\n", launches, tag, wgs);
+  for (int w = 0; w < n; w++) {
+    const unsigned long long *t = host.data() + (size_t)w * (2 + kTraceTiles * kTraceMarks);
+    fprintf(f, "wg %d hwid %llu xcc %llu", w, t[0], t[1]);
+    for (int i = 0; i < kTraceTiles * kTraceMarks; i++) fprintf(f, " %llu", t[2 + i]);
+    fprintf(f, "\n");
+  }
+  fclose(f);
+}
+
+// fast path; returns -1 when the configuration is not covered (caller falls back to sa_mlp_kernel)
+#if PCR_SA_PREC == 0
+int pcr_sa2_try_bf3(const pcr_sa_params *p, pcr_stream_t st);   // sa_kernels_bf3.hip / sa_kernels_bf1.hip
+int pcr_sa2_try_bf1(const pcr_sa_params *p, pcr_stream_t st);
+#endif
+
+static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
+  hipStream_t st = pcr_s(st_);
+  if (!p.wa || !p.wps[0] || !p.wps[1] || !p.shift_pad[0] || !p.shift_pad[1] || (p.D && (!p.wpq || !p.pq_ws)))
+    return -1;
+#if PCR_SA_PREC == 0
+  // precision 1 / 2: layers 2 and 3 on the bf16 matrix core (their own translation units); shapes those units do not
+  // instantiate come back with -1 and run here in f32, which is never less accurate than what was asked for
+  if (p.precision != 0 && p.wps_bf[0] && p.wps_bf[1]) {
+    const int rc = p.precision == 1 ? pcr_sa2_try_bf3(&p, st_) : pcr_sa2_try_bf1(&p, st_);
+    if (rc >= 0) return rc;
+  }
+  const float *const wl2 = p.wps[0], *const wl3 = p.wps[1];
+#else
+  if (!p.wps_bf[0] || !p.wps_bf[1] || (p.c1 & 31) || (p.c2 & 7)) return -1;
+  const float *const wl2 = p.wps_bf[0], *const wl3 = p.wps_bf[1];
+#endif
+  if ((p.c1 & 7) || p.c1 > 512 || p.c2 > 512 || p.c3 > 512) return -1;
+  const int pqw = p.mode == 0 ? 2 * p.c1 : p.c1;
+  if (p.D && pqw > 1024) return -1;
+  // the persistent, register-pipelined kernel: ball-query groups with hit counts (only the distinct rows are
+  // evaluated).  (It also runs count-less featureless layers -- all K rows -- but the K-row kernel with resident
+  // weights is faster there: 2.2 vs 2.9 ms on the 32-channel kNN layer, its row tables are 0.5 GB of extra traffic.)
+  if (p.tile_ws && p.cnt && p.mode == 1 && p.c1 <= 256 && p.c2 <= 256 && p.c3 <= 256) {
+    const int n2r = ceil32(p.c2) >> 5, n3r = ceil32(p.c3) >> 5;
+    const int nrr = (n2r > 4 || n3r > 4) ? 2 : 1;
+    const int tb = nrr == 2 ? 2 : 4;
+    const int ROWS = 32 * tb;
+    bool shape_ok = true;
+    if (kPrec != 0) {   // the bf16 units hold the explicit-shape instantiations only
+      const int v2 = n2r >= 3 ? 1 : (n2r == 2 ? 2 : 4), v3 = n3r >= 3 ? 1 : (n3r == 2 ? 2 : 4);
+      shape_ok = tb == 2 ? (v2 == 1 && v3 == 1)
+                         : ((v2 == 1 && v3 == 1) || (v2 == 2 && v3 == 1) || (v2 == 2 && v3 == 2) || (v2 == 4 && v3 == 4));
+    }
+    if (!shape_ok) return -1;
+    if (p.K <= ROWS) {
+      const int per_tile = ROWS / rag_ceil(p.K);               // whole centres a tile holds in the worst case
+      RagArgs r;
+      r.B = p.B; r.N = p.N; r.S = p.S; r.K = p.K; r.c1 = p.c1; r.c2 = p.c2; r.c3 = p.c3;
+      r.maxT = (p.S + per_tile - 1) / per_tile;
+      r.xyz = p.xyz; r.idx = p.idx; r.cnt = p.cnt; r.centre_idx = p.centre_idx; r.ws = p.tile_ws;
+      r.wa = p.wa; r.pq = p.D ? p.pq_ws : nullptr; r.pqw = p.c1;
+      r.wap = p.wa_packed;
+      r.wp2 = wl2; r.wp3 = wl3; r.sh1 = p.shift[0]; r.sh2 = p.shift_pad[0]; r.sh3 = p.shift_pad[1];
+      static const int rdbg = pcr_tune_int("PCR_SA_DBG");
+      static const char *rtrace = pcr_tune_str("PCR_SA_TRACE");
+      r.dbg = rdbg | (rtrace ? 256 : 0);
+      r.out = p.out;
+      r.out_pm = p.out_point_major;
+      const int rowsCr = p.c1 > ceil32(p.c2) ? p.c1 : ceil32(p.c2);
+      const size_t lds = ((size_t)rowsCr * (ROWS + 1) +
+                          (size_t)ceil32(p.c3) * (ROWS / kRagG) + 3 * (size_t)p.c1 + ceil32(p.c1) + ceil32(p.c2) +
+                          ceil32(p.c3) + 8 * (ROWS + 1)) *
+                         sizeof(float);
+      if (lds <= 150 * 1024) {
+        if (p.D && !p.pq_ready) {
+          const int rc = pcr_dense_pm_f32(p.feat, p.wpq, p.pq_ws, p.B, p.D, p.c1, p.N, p.feat_point_major, st_);
+          if (rc != PCR_OK) return rc == PCR_ERR_INVALID ? -1 : rc;
+        }
+        hipLaunchKernelGGL(sa_rag_plan_kernel, dim3((p.B + 3) / 4), dim3(256), 0, st, r, ROWS);
+        hipLaunchKernelGGL(sa_rag_scan_kernel, dim3(1), dim3(1024), 0, st, p.B, r.ws);
+        hipLaunchKernelGGL(sa_rag_flatten_kernel, dim3((p.B + 3) / 4), dim3(256), 0, st, p.B, r.maxT, r.ws);
+        {
+          long long wgs = ((long long)p.B * r.maxT + 3) / 4;
+          if (wgs > 4096) wgs = 4096;
+          if (tb == 2) hipLaunchKernelGGL(sa_rag_rows_kernel<64>, dim3((unsigned)wgs), dim3(256), 0, st, r);
+          else hipLaunchKernelGGL(sa_rag_rows_kernel<128>, dim3((unsigned)wgs), dim3(256), 0, st, r);
+        }
+        if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
+        static const int n_cu = [] {
+          int dev = 0, n = 0;
+          if (hipGetDevice(&dev) != hipSuccess ||
+              hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+            n = 256;
+          return n;
+        }();
+        const long long max_tiles = (long long)p.B * r.maxT;
+        const int w2 = n2r >= 3 ? 1 : (n2r == 2 ? 2 : 4), w3 = n3r >= 3 ? 1 : (n3r == 2 ? 2 : 4);
+#define PCR_RAG(TBv, NRv, A2, A3, NR2v, W1v)                                                             \
+  do {                                                                                                   \
+    auto kern = sa_rag_kernel<TBv, NRv, A2, A3, NR2v, W1v, kPrec>;                                       \
+    static bool ok = allow_big_lds(kern);                                                                \
+    (void)ok;                                                                                            \
+    static size_t occ_lds = 0;                                                                           \
+    static int occ = 0;   /* resident workgroups per CU for this LDS size (registers and LDS) */          \
+    if (occ_lds != lds) {                                                                                \
+      int n = 0;                                                                                         \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, kThreads, lds) != hipSuccess || n < 1)  \
+        n = 1;                                                                                           \
+      occ = n;                                                                                           \
+      occ_lds = lds;                                                                                     \
+    }                                                                                                    \
+    long long want = (long long)n_cu * occ;                                                              \
+    if (want > max_tiles) want = max_tiles;                                                              \
+    hipLaunchKernelGGL(kern, dim3((unsigned)want), dim3(kThreads), lds, st, r);                          \
+    if (rtrace) rag_dump_trace(rtrace, #TBv "," #NRv, (int)want);                                        \
+  } while (0)
+        const int n1r = ceil32(p.c1) >> 5;
+        const int w1 = n1r >= 3 ? 1 : (n1r == 2 ? 2 : 4);
+        const bool l1m = p.wa_packed && n1r <= 4;   // layer 1 on the matrix core
+        if (tb == 2) {
+          const bool narrow2 = n2r <= 4;   // layer 2 needs one cout-block round only
+          if (w2 == 1 && w3 == 1 && narrow2 && l1m && w1 == 1) PCR_RAG(2, 2, 1, 1, 1, 1);
+          else if (w2 == 1 && w3 == 1 && narrow2) PCR_RAG(2, 2, 1, 1, 1, 0);
+          else if (w2 == 1 && w3 == 1) PCR_RAG(2, 2, 1, 1, 2, 0);
+          else if constexpr (kPrec == 0) {
+            if (narrow2) PCR_RAG(2, 2, 0, 0, 1, 0);
+            else PCR_RAG(2, 2, 0, 0, 2, 0);
+          }
+        } else {
+          if (w2 == 1 && w3 == 1) PCR_RAG(4, 1, 1, 1, 1, 0);
+          else if (w2 == 2 && w3 == 1 && l1m && w1 == 2 && !p.D) PCR_RAG(4, 1, 2, 1, 1, 2);
+          else if (w2 == 2 && w3 == 1) PCR_RAG(4, 1, 2, 1, 1, 0);
+          else if (w2 == 2 && w3 == 2) PCR_RAG(4, 1, 2, 2, 1, 0);
+          else if (w2 == 4 && w3 == 4) PCR_RAG(4, 1, 4, 4, 1, 0);
+          else if constexpr (kPrec == 0) PCR_RAG(4, 1, 0, 0, 1, 0);
+        }
+#undef PCR_RAG
+        if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
+        return PCR_OK;
+      }
+    }
+  }
+  const bool maxe = (p.K & 15) == 0;
+  int rowsC = p.c1 > ceil32(p.c2) ? p.c1 : ceil32(p.c2);
+  if (!maxe && ceil32(p.c3) > rowsC) rowsC = ceil32(p.c3);
+  auto lds_bytes = [&](int tb, int cpw) {
+    size_t stage = (size_t)6 * 32 * tb + (size_t)cpw * p.c1 + 32;   // (sq read in 16-byte pieces up to ceil32(c1))
+    const size_t gm = maxe ? (size_t)ceil32(p.c3) * 2 * tb : 0;
+    if (gm > stage) stage = gm;
+    return ((size_t)rowsC * (32 * tb + 1) + stage) * sizeof(float);
+  };
+  const int n2 = ceil32(p.c2) >> 5, n3 = ceil32(p.c3) >> 5;
+  const int nmin = n2 < n3 ? n2 : n3;
+  const int ways = nmin >= 3 ? 1 : (nmin == 2 ? 2 : 4);
+  // cout-block rounds per wave: 2 for 129-256 couts, 4 for 257-512 (the 1.5M / 7M Point-Transformer configs'
+  // 256- / 512-channel layers, backbone_net.py:43-46); the four-round form is instantiated for both layers together
+  const int nr = (n2 > 8 || n3 > 8) ? 4 : ((n2 > 4 || n3 > 4) ? 2 : 1);
+  const int nr2 = nr == 4 ? 4 : (n2 > 4 ? 2 : 1);
+  if (kPrec != 0) {   // the bf16 units: max-from-accumulators epilogue, explicit shapes, at most two cout-block rounds
+    const int v2 = n2 >= 3 ? 1 : (n2 == 2 ? 2 : 4), v3 = n3 >= 3 ? 1 : (n3 == 2 ? 2 : 4);
+    if (!maxe || nr > 2 || !((v2 == v3) || (v2 == 2 && v3 == 1))) return -1;
+  }
+  // Tile choice.  Measured on MI355X (re-fitted after the epilogue / k-loop work, which halved what
+  // a low residency costs): time per row ~ padding x wave imbalance x (1 + 1.0 / resident workgroups per CU); residency is bounded by LDS (160 KiB, 2 KiB granules),
+  // by registers (accumulator tiles + ~70 VGPRs against 512 per SIMD lane) and by 8 workgroups.
+  int best_cpw = 0, best_tb = 0;
+  double best_cost = 1e30;
+  const int cpw_max = 192 / p.K > 0 ? 192 / p.K : 1;
+  for (int cpw = 1; cpw <= cpw_max; cpw++) {
+    const int tb = (cpw * p.K + 31) / 32;
+    if (tb > 6 || (nr == 4 && tb > 2)) continue;
+    const size_t lds = lds_bytes(tb, cpw);
+    if (lds > 150 * 1024) continue;
+    const int tbw = (tb + ways - 1) / ways;
+    const int regs = nr * tbw * 16 + 70;
+    if (regs > 250) continue;
+    int wgs = (int)((160 * 1024) / ((lds + 2047) / 2048 * 2048));
+    const int by_regs = 512 / ((regs + 7) / 8 * 8);
+    if (by_regs < wgs) wgs = by_regs;
+    if (wgs > 8) wgs = 8;
+    if (wgs < 1) continue;
+    const double pad = (double)(32 * tb) / (double)(cpw * p.K);
+    const double imb = (double)(tbw * ways) / (double)tb;
+    const double cost = pad * imb * (1.0 + 1.0 / wgs);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best_cpw = cpw; best_tb = tb; }
+  }
+  static const int force_cpw = pcr_tune_int("PCR_SA_CPW");   // tuning aid
+  if (force_cpw > 0) {
+    const int tb = (force_cpw * p.K + 31) / 32;
+    if (tb <= (nr == 4 ? 2 : 6) && lds_bytes(tb, force_cpw) <= 150 * 1024) { best_cpw = force_cpw; best_tb = tb; }
+  }
+  if (!best_cpw) return -1;
+  if (p.D && !p.pq_ready) {
+    const int rc = pcr_dense_pm_f32(p.feat, p.wpq, p.pq_ws, p.B, p.D, pqw, p.N, p.feat_point_major, st_);
+    if (rc != PCR_OK) return rc == PCR_ERR_INVALID ? -1 : rc;
+  }
+  Sa2Args a;
+  a.B = p.B; a.N = p.N; a.S = p.S; a.K = p.K; a.c1 = p.c1; a.c2 = p.c2; a.c3 = p.c3; a.CPW = best_cpw;
+  a.xyz = p.xyz; a.idx = p.idx; a.centre_idx = p.centre_idx; a.wa = p.wa;
+  a.pq = p.D ? p.pq_ws : nullptr;
+  a.pqw = pqw;
+  a.qoff = p.mode == 0 ? p.c1 : -1;
+  static const int dbg = pcr_tune_int("PCR_SA_DBG");
+  a.dbg = dbg;
+  a.wp2 = wl2; a.wp3 = wl3;
+  a.sh1 = p.shift[0]; a.sh2 = p.shift_pad[0]; a.sh3 = p.shift_pad[1];
+  a.out = p.out;
+  a.out_pm = p.out_point_major;
+  a.wap = p.wa_packed;
+  {
+    static const int no_l1m = pcr_tune_int("PCR_SA_NO_L1M");   // diagnostics
+    const int n1 = ceil32(p.c1) >> 5;
+    const int w1 = n1 >= 3 ? 1 : (n1 == 2 ? 2 : 4);
+    const int w2c = n2 >= 3 ? 1 : (n2 == 2 ? 2 : 4), w3c = n3 >= 3 ? 1 : (n3 == 2 ? 2 : 4);
+    // (the kernel deals layer 1's tiles with layer 2's compile-time shape: explicit shapes only, same class)
+    a.l1m = (!no_l1m && p.wa_packed && n1 <= 4 && n2 <= 4 && w1 == w2c && w2c == w3c && (p.c1 & 3) == 0) ? 1 : 0;
+  }
+  const size_t lds = lds_bytes(best_tb, best_cpw);
+  dim3 grid((p.S + best_cpw - 1) / best_cpw, p.B);
+  const int w2 = n2 >= 3 ? 1 : (n2 == 2 ? 2 : 4), w3 = n3 >= 3 ? 1 : (n3 == 2 ? 2 : 4);
+  int lrc = 0;
+  switch (best_tb) {
+    case 1: lrc = sa2_launch_tb<1>(a, nr, nr2, w2, w3, maxe, lds, st, grid); break;
+    case 2: lrc = sa2_launch_tb<2>(a, nr, nr2, w2, w3, maxe, lds, st, grid); break;
+    case 3: lrc = sa2_launch_tb<3>(a, nr, nr2, w2, w3, maxe, lds, st, grid); break;
+    case 4: lrc = sa2_launch_tb<4>(a, nr, nr2, w2, w3, maxe, lds, st, grid); break;
+    case 5: lrc = sa2_launch_tb<5>(a, nr, nr2, w2, w3, maxe, lds, st, grid); break;
+    default: lrc = sa2_launch_tb<6>(a, nr, nr2, w2, w3, maxe, lds, st, grid); break;
+  }
+  if (lrc < 0) return -1;
+  if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
+  return PCR_OK;
+}
+
+#if PCR_SA_PREC == 1
+int pcr_sa2_try_bf3(const pcr_sa_params *p, pcr_stream_t st) { return sa2_try(*p, st); }
+#elif PCR_SA_PREC == 2
+int pcr_sa2_try_bf1(const pcr_sa_params *p, pcr_stream_t st) { return sa2_try(*p, st); }
+#else
+
+PCR_EXPORT long pcr_sa_tile_ws_ints(int B, int S, int K, int c2, int c3) {
+  if (B < 1 || S < 1 || K < 1 || c2 < 1 || c3 < 1) return 0;
+  const int rows = (ceil32(c2) > 128 || ceil32(c3) > 128) ? 64 : 128;   // sa2_try's tile choice
+  if (K > rows) return 0;
+  const int per_tile = rows / rag_ceil(K);
+  const int maxT = (S + per_tile - 1) / per_tile;
+  return (long)rag_ws_ints(B, maxT, rows);
+}
+
+PCR_EXPORT int pcr_dense_pm_f32(const float *x, const float *wp, float *y, int B, int cin, int cout, int L,
+                                int x_point_major, pcr_stream_t stream) {
+  if (!x || !wp || !y || B < 0 || cin < 1 || cout < 1 || cout > 1024 || L < 1) return PCR_ERR_INVALID;
+  if (cout > 256 && (cout & 3)) return PCR_ERR_INVALID;   // windows of 256 couts keep the 16-byte store path
+  if (B == 0) return PCR_OK;
+  if (B > 65535) return PCR_ERR_INVALID;
+  DensePmArgs d{x, wp, y, cin, cout, L, x_point_major};
+  const int wmax = cout < 256 ? cout : 256;
+  const int rows = ceil8(cin) > ceil32(wmax) ? ceil8(cin) : ceil32(wmax);
+  size_t lds = (size_t)rows * 65 * sizeof(float);
+  if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
+  const dim3 grid((L + 63) / 64, B, (cout + 255) / 256);
+  if (cout > 128) {
+    static bool ok = allow_big_lds(dense_pm_kernel<2>);
+    (void)ok;
+    hipLaunchKernelGGL(dense_pm_kernel<2>, grid, dim3(kThreads), lds, pcr_s(stream), d);
+  } else {
+    static bool ok = allow_big_lds(dense_pm_kernel<1>);
+    (void)ok;
+    hipLaunchKernelGGL(dense_pm_kernel<1>, grid, dim3(kThreads), lds, pcr_s(stream), d);
+  }
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_sa_mlp_f32(const pcr_sa_params *pp, pcr_stream_t stream) {
+  if (!pp) return PCR_ERR_INVALID;
+  const pcr_sa_params &p = *pp;
+  if (p.B < 0 || p.N < 1 || p.S < 0 || p.K < 1 || p.D < 0 || p.c1 < 1 || p.c2 < 1 || p.c3 < 1 ||
+      !p.xyz || !p.idx || !p.out || (p.D && !p.feat) || (p.mode != 0 && p.mode != 1))
+    return PCR_ERR_INVALID;
+  for (int l = 0; l < 3; l++)
+    if (!p.wp[l] || !p.scale[l] || !p.shift[l]) return PCR_ERR_INVALID;
+  if (p.B == 0 || p.S == 0) return PCR_OK;
+  if (p.B > 65535) return PCR_ERR_INVALID;
+  const int fast = sa2_try(p, stream);
+  if (fast >= 0) return fast;
+  SaArgs a;
+  a.p = p;
+  a.C0 = 3 + (p.mode == 0 ? 2 * p.D : p.D);
+  a.C0P = ceil8(a.C0);
+  a.rowsA = a.C0P > ceil8(p.c2) ? a.C0P : ceil8(p.c2);
+  a.rowsB = ceil8(p.c1) > p.c3 ? ceil8(p.c1) : p.c3;
+  // centres per workgroup: as many as keep rows <= 128 (at least one) and LDS <= 150 KiB
+  int cpw = 128 / p.K;
+  if (cpw < 1) cpw = 1;
+  size_t lds = 0;
+  for (;; cpw--) {
+    a.CPW = cpw;
+    a.TB = (cpw * p.K + 31) / 32;
+    a.RP = 32 * a.TB + 1;
+    lds = ((size_t)(a.rowsA + a.rowsB) * a.RP + 32 * a.TB) * sizeof(float);
+    if (lds <= 150 * 1024 || cpw == 1) break;
+  }
+  if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
+  static bool ok = allow_big_lds(sa_mlp_kernel);
+  (void)ok;
+  hipLaunchKernelGGL(sa_mlp_kernel, dim3((p.S + a.CPW - 1) / a.CPW, p.B), dim3(kThreads), lds,
+                     pcr_s(stream), a);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+#endif   // PCR_SA_PREC == 0 (C-ABI entry points)

@@ -341,6 +341,216 @@ __device__ __forceinline__ void tile_dense2(const float *__restrict__ in, int CP
   }
 }
 
+// ---------------------------------------------------------------- bf16 matrix core (gfx950) ----
+// The same dense tile on v_mfma_f32_32x32x16_bf16 (16x the f32-input MFMA's rate, f32 accumulate).  The LDS tile keeps
+// its f32 [C][RP] layout -- every other phase of the callers (gathers, LayerNorm, pooling, stores) is untouched -- and the
+// B operand is converted where it is consumed: a lane reads the 8 channels k = 16 s + 8 h .. + 7 of its token and forms
+//   NS = 3 ("bf16x3", split bf16):  x = hi + lo + O(2^-18 |x|),  hi = bf16(x), lo = bf16(x - hi)  (round to nearest),
+//            W x ~= W_hi x_hi + W_hi x_lo + W_lo x_hi : three MFMAs per product, relative error ~2^-17 per term
+//            (measured end to end: logits within 2e-6 of the f32 path) at ~5x the f32-input rate;
+//   NS = 1 ("bf16"): x_hi and W_hi only -- BASELINE config 2's "bf16 activations, f32 accumulate" taken literally.
+// Weights: image [S = ceil16(cin)/16][OP/32][hi, lo][64 lanes][8 bf16] (pcr_pack_weight_bf16x2): one 16-byte load per
+// lane, step and part, streamed through a ring of bf_pf(NR) steps.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// ring depth in 16-channel steps: a step is 3 TBW NR MFMAs of 32 cycles, so two cout-block rounds per wave halve the
+// depth an L2 round trip needs (and the 8 registers per step and round are what decides the residency)
+constexpr int bf_pf(int nr) { return nr >= 2 ? 2 : 4; }
+
+__device__ __forceinline__ void bf_split8(const float (&x)[8], bf16x8 &hi, bf16x8 &lo, bool want_lo) {
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const f32x2 v = {x[2 * q], x[2 * q + 1]};
+    const bf16x2 h2 = __builtin_convertvector(v, bf16x2);
+    hi[2 * q] = h2[0];
+    hi[2 * q + 1] = h2[1];
+    if (want_lo) {
+      const f32x2 r = v - __builtin_convertvector(h2, f32x2);
+      const bf16x2 l2 = __builtin_convertvector(r, bf16x2);
+      lo[2 * q] = l2[0];
+      lo[2 * q + 1] = l2[1];
+    }
+  }
+}
+
+template <int TB, int NR, int WAYS, bool TILE, int NS, class Epi, int PF = bf_pf(NR), class AfterK = DenseNoHook>
+__device__ __forceinline__ void tile_dense_bf_impl(const float *__restrict__ in, int CP,
+                                                   const float *__restrict__ wp_, int OP, bool sync_epi, Epi epi,
+                                                   const float *__restrict__ init = nullptr,
+                                                   AfterK after_k = AfterK(), int opfull = 0) {
+  static_assert((PF & 1) == 0, "the B-operand double buffer alternates per step");
+  constexpr int RP = 32 * TB + 1;
+  constexpr int TBW = (TB + WAYS - 1) / WAYS;
+  constexpr bool kLo = NS == 3;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int nCB = OP >> 5, KS = (CP + 15) >> 4;
+  const bool tail = (CP & 8) != 0;          // the last step's upper half (k = 8 .. 15) lies beyond the tile's rows
+  const int cb0 = WAYS == 1 ? wave : (WAYS == 2 ? (wave & 1) : 0);
+  const int tb0 = WAYS == 1 ? 0 : (WAYS == 2 ? (wave >> 1) : wave);
+  const size_t wstride = (size_t)((opfull ? opfull : OP) >> 5) * 128;   // bf16x8 units per step
+  const bf16x8 *wrow[NR];
+#pragma unroll
+  for (int nr = 0; nr < NR; nr++) {
+    int cb = cb0 + 4 * nr;
+    cb = cb < nCB ? cb : nCB - 1;
+    wrow[nr] = reinterpret_cast<const bf16x8 *>(wp_) + (size_t)cb * 128 + lane;
+  }
+  const float *brow[TBW];
+#pragma unroll
+  for (int j = 0; j < TBW; j++) {
+    int tb = tb0 + j * WAYS;
+    tb = tb < TB ? tb : TB - 1;
+    brow[j] = in + 8 * h * RP + tb * 32 + l31;
+  }
+  bf16x8 ah[PF][NR], al[PF][NR];
+#pragma unroll
+  for (int i = 0; i < PF; i++) {
+    const int ki = i < KS ? i : KS - 1;
+#pragma unroll
+    for (int nr = 0; nr < NR; nr++) {
+      ah[i][nr] = wrow[nr][(size_t)ki * wstride];
+      if constexpr (kLo) al[i][nr] = wrow[nr][(size_t)ki * wstride + 64];
+    }
+  }
+  f32x16 acc[NR][TBW];
+#pragma unroll
+  for (int nr = 0; nr < NR; nr++) {
+    int cbi = cb0 + 4 * nr;
+    cbi = cbi < nCB ? cbi : nCB - 1;
+    if (init != nullptr) {
+      const f32x4 *ip = reinterpret_cast<const f32x4 *>(init + cbi * 32 + 4 * h);
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const f32x4 v4 = ip[2 * g];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+          for (int j = 0; j < TBW; j++) acc[nr][j][4 * g + q] = v4[q];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+#pragma unroll
+        for (int j = 0; j < TBW; j++) acc[nr][j][r] = 0.f;
+    }
+  }
+  float xr[2][TBW][8];
+  auto load_x = [&](float (&x)[TBW][8], int s) {
+#pragma unroll
+    for (int j = 0; j < TBW; j++) {
+      const float *bt = brow[j] + s * 16 * RP;
+#pragma unroll
+      for (int q = 0; q < 8; q++) x[j][q] = bt[q * RP];
+    }
+  };
+  auto mma = [&](int i, float (&x)[TBW][8], bool last) {
+    if (last && tail && h) {
+#pragma unroll
+      for (int j = 0; j < TBW; j++)
+#pragma unroll
+        for (int q = 0; q < 8; q++) x[j][q] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < TBW; j++) {
+      bf16x8 bh, bl;
+      bf_split8(x[j], bh, bl, kLo);
+#pragma unroll
+      for (int nr = 0; nr < NR; nr++) {
+        if constexpr (kLo) {
+          acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i][nr], bl, acc[nr][j], 0, 0, 0);
+          acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i][nr], bh, acc[nr][j], 0, 0, 0);
+        }
+        acc[nr][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i][nr], bh, acc[nr][j], 0, 0, 0);
+      }
+    }
+  };
+  auto refill = [&](int i, int ks) {
+#pragma unroll
+    for (int nr = 0; nr < NR; nr++) {
+      ah[i][nr] = wrow[nr][(size_t)ks * wstride];
+      if constexpr (kLo) al[i][nr] = wrow[nr][(size_t)ks * wstride + 64];
+    }
+  };
+  load_x(xr[0], 0);
+  int s = 0;
+  for (; s + 2 * PF <= KS; s += PF) {
+#pragma unroll
+    for (int i = 0; i < PF; i++) {
+      load_x(xr[(i + 1) & 1], s + i + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(i, xr[i & 1], false);
+      refill(i, s + i + PF);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (s + PF <= KS) {
+#pragma unroll
+    for (int i = 0; i < PF; i++) {
+      const int sx = s + i + 1 < KS ? s + i + 1 : KS - 1;
+      load_x(xr[(i + 1) & 1], sx);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(i, xr[i & 1], s + i == KS - 1);
+      if (i + 1 < PF) {
+        const int sn = s + i + PF < KS ? s + i + PF : KS - 1;
+        refill(i, sn);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    s += PF;
+  }
+  {
+    const int rem = KS - s;   // < PF; ring slot i holds step s + i, xr[0] the operands of step s
+#pragma unroll
+    for (int i = 0; i + 1 < PF; i++)
+      if (i < rem) {
+        const int sx = s + i + 1 < KS ? s + i + 1 : KS - 1;
+        load_x(xr[(i + 1) & 1], sx);
+        mma(i, xr[i & 1], s + i == KS - 1);
+      }
+  }
+  after_k();
+  if (sync_epi) __syncthreads();
+#pragma unroll
+  for (int nr = 0; nr < NR; nr++) {
+    const int cb = cb0 + 4 * nr;
+    if (cb < nCB) {
+#pragma unroll
+      for (int j = 0; j < TBW; j++) {
+        const int tb = tb0 + j * WAYS;
+        if (tb < TB) {
+          if constexpr (TILE) {
+            epi(acc[nr][j], cb, tb, l31, h);
+          } else {
+            const int t = tb * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; r++) epi(acc[nr][j][r], cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, t);
+          }
+        }
+      }
+    }
+  }
+}
+
+// PREC 0: f32-input MFMA (exact fmaf chains); 1: split bf16 (three MFMAs per product); 2: plain bf16.  The bf16 forms
+// exist for the explicit wave / tile splits only (WSEL 1 / 2 / 4).
+template <int PREC, int TB, int NR, int WSEL = 0, bool TILE = false, class Epi, class AfterK = DenseNoHook, int PFv = PCR_PF,
+          bool RES = false>
+__device__ __forceinline__ void tile_dense2p(const float *__restrict__ in, int CP, const float *__restrict__ wp, int OP,
+                                             bool sync_epi, Epi epi, const float *__restrict__ init = nullptr,
+                                             f32x4 (*ring)[DenseShape<NR, WSEL>::nr] = nullptr,
+                                             AfterK after_k = AfterK(), int opfull = 0) {
+  if constexpr (PREC == 0) {
+    tile_dense2<TB, NR, WSEL, TILE, Epi, AfterK, PFv, RES>(in, CP, wp, OP, sync_epi, epi, init, ring, after_k, opfull);
+  } else {
+    static_assert(WSEL != 0, "bf16 dense tiles are instantiated for explicit shapes only");
+    tile_dense_bf_impl<TB, DenseShape<NR, WSEL>::nr, DenseShape<NR, WSEL>::ways, TILE, PREC == 1 ? 3 : 1, Epi,
+                       bf_pf(DenseShape<NR, WSEL>::nr), AfterK>(in, CP, wp, OP, sync_epi, epi, init, after_k, opfull);
+  }
+}
+
 // elu(x) + 1 = x + 1 (x > 0) | exp(x) (x <= 0); hardware exp2 (v_exp_f32, ~1 ulp) instead of the libm
 // expansion: this runs once per projected Q/K element and was a third of the attention kernels' VALU time
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x + 1.0f : __expf(x); }

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libpcr_hip.so")
 _lib = None
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class PcrError(RuntimeError):
@@ -26,6 +26,7 @@ def load():
         lib = ctypes.CDLL(SO_PATH)
         lib.pcr_status_string.restype = ctypes.c_char_p
         lib.pcr_packed_weight_floats.restype = ctypes.c_long
+        lib.pcr_packed_weight_bf16_floats.restype = ctypes.c_long
         lib.pcr_attn_kv_floats.restype = ctypes.c_long
         lib.pcr_sa_tile_ws_ints.restype = ctypes.c_long
         if lib.pcr_abi_version() != ABI_VERSION:

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert len(syms) >= 20
     for s in syms:
         assert hasattr(lib, s), "libpcr_hip.so does not export %s" % s
-    assert lib.pcr_abi_version() == 6
+    assert lib.pcr_abi_version() == 7
     assert lib.pcr_status_string(0) == b"ok"
 
 
@@ -47,6 +47,31 @@ def test_weight_packing_layout(lib):
         # element (kb, o, h, j) holds W[o][kb*8 + 2*j + h]
         back = img.transpose(1, 0, 3, 2).reshape(op, cp)
         assert np.array_equal(back, full)
+
+
+def test_bf16_weight_image_layout_and_split(lib):
+    """pcr_pack_weight_bf16x2_f32: element j of lane l of step s, cout block cb, part p holds W[32 cb + l % 32][16 s + 8 (l
+    // 32) + j] as bf16 hi (p = 0) / lo (p = 1); hi + lo reproduces the weight to 2^-17 relative"""
+    lib.pcr_packed_weight_bf16_floats.restype = ctypes.c_long
+    g = np.random.default_rng(1)
+    for cout, cin in ((32, 32), (64, 67), (130, 24), (1, 1)):
+        w = g.standard_normal((cout, cin)).astype(np.float32)
+        n = lib.pcr_packed_weight_bf16_floats(cout, cin)
+        S, ncb = (cin + 15) // 16, (cout + 31) // 32
+        assert n == S * ncb * 2 * 64 * 4
+        out = np.zeros(n, np.float32)
+        assert lib.pcr_pack_weight_bf16x2_f32(w.ctypes.data_as(ctypes.c_void_p), cout, cin,
+                                              out.ctypes.data_as(ctypes.c_void_p)) == 0
+        img = out.view(np.uint16).reshape(S, ncb, 2, 64, 8)
+        as_f32 = (img.astype(np.uint32) << 16).view(np.float32)
+        full = np.zeros((ncb * 32, S * 16), np.float32)
+        full[:cout, :cin] = w
+        # (s, cb, part, lane = 32 h + r, j) -> row 32 cb + r, column 16 s + 8 h + j
+        back = as_f32.reshape(S, ncb, 2, 2, 32, 8).transpose(2, 1, 4, 0, 3, 5).reshape(2, ncb * 32, S * 16)
+        hi, lo = back[0], back[1]
+        assert np.all(np.abs(hi - full) <= np.abs(full) * 2.0 ** -8 + 1e-38)
+        assert np.all(np.abs(hi + lo - full) <= np.abs(full) * 2.0 ** -16)
+    assert lib.pcr_pack_weight_bf16x2_f32(None, 4, 4, None) == 1
 
 
 def test_invalid_arguments_return_status_not_crash(lib):
