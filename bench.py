@@ -71,6 +71,10 @@ WORKLOADS = {
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3    # f32-input MFMA dense peak
+MFMA_BF16_PEAK_TF = 2500.0  # bf16 MFMA dense peak (MI355X_MICROARCH.md: ~2.5 PF dense; 16x the f32-input rate)
+# arithmetic of the grouped-SA matrix layers (pcr_amd/engine.py PRECISION): (dtype label, peak, MFMAs issued per product)
+PREC_INFO = {"f32": ("f32", MFMA_F32_PEAK_TF, 1), "bf16x3": ("bf16x3", MFMA_BF16_PEAK_TF, 3),
+             "bf16": ("bf16", MFMA_BF16_PEAK_TF, 1)}
 
 
 def build_pt_model(backbone_list, device="cuda"):
@@ -330,9 +334,18 @@ def roofline_of(model, s1, s2, workload, pairs, fn=None):
     # achieved = FLOPs the launch really issues on the matrix core / its duration (the kernel skips work the
     # reference does: the first MLP layer via per-point tables, repeated ball-query rows); the reference's op
     # count for the same layer over the same time is reported beside it as reference_op_tflops
-    roof = dict(kernel=dom, bound="mfma", achieved=(exec_flops / cnt) / (ms / cnt * 1e-3) / 1e12,
-                peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", avg_launch_ms=ms / cnt, launches_per_step=cnt, traffic=None,
-                issued_gflop_per_launch=exec_flops / cnt / 1e9,
+    from pcr_amd import engine
+    # the grouped-SA launches follow engine.PRECISION (bf16x3: three bf16 MFMAs per product, priced against the bf16
+    # peak with all three counted; the f32 figure beside it is the same work over the f32-input peak); every other
+    # MFMA launch of this build is f32-input
+    prec = engine.PRECISION if dom.split("[")[0] in ("sa_ragged", "sa_fused") else "f32"
+    _, peak, mult = PREC_INFO[prec]
+    roof = dict(kernel=dom, bound="mfma", achieved=(exec_flops * mult / cnt) / (ms / cnt * 1e-3) / 1e12,
+                peak=peak, unit="TFLOP/s", avg_launch_ms=ms / cnt, launches_per_step=cnt, traffic=None,
+                kernel_arithmetic=prec, mfma_per_product=mult,
+                product_tflops=(exec_flops / cnt) / (ms / cnt * 1e-3) / 1e12,
+                product_frac_of_f32_mfma_peak=(exec_flops / cnt) / (ms / cnt * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
+                issued_gflop_per_launch=exec_flops * mult / cnt / 1e9,
                 reference_op_gflop_per_launch=flops / cnt / 1e9,
                 reference_op_tflops=(flops / cnt) / (ms / cnt * 1e-3) / 1e12,
                 share_of_step=ms / step_ms_kern,
@@ -369,13 +382,18 @@ def add_clock(roof, clk):
     roof["clock_source"] = ("pcr_clock_probe: sustained v_mfma_f32_32x32x2_f32 on all CUs right after the timed "
                             "region, MFMA count / wall clock (shader counter cross-check %.3f GHz)"
                             % clk["shader_counter_ghz"])
-    if roof["bound"] == "mfma":
+    if roof["bound"] == "mfma" and roof.get("kernel_arithmetic", "f32") == "f32":   # (the probe runs f32 MFMAs)
         roof["peak_at_clock"] = roof["peak"] * clk["clock_ghz"] / 2.4
         roof["frac_at_clock"] = roof["achieved"] / roof["peak_at_clock"]
 
 
-def measure(workload, args, rank, world, pairs=None, cloud_kind=None, skip_repeats=True, steps=None, warmup=None):
+def measure(workload, args, rank, world, pairs=None, cloud_kind=None, skip_repeats=True, steps=None, warmup=None,
+            precision=None):
     """one workload: timed region + (rank 0) roofline of its dominant launch; returns (record, state_dict)"""
+    from pcr_amd import engine
+    if precision is not None:
+        with engine.precision(precision):
+            return measure(workload, args, rank, world, pairs, cloud_kind, skip_repeats, steps, warmup)
     from pcr_amd import shard
     from pcr_amd import testing as T
     desc, kind, n, bl, dpairs = WORKLOADS[workload]
@@ -399,12 +417,20 @@ def measure(workload, args, rank, world, pairs=None, cloud_kind=None, skip_repea
         clk = clock_probe()
         roof, _ = roofline_of(model, s1, s2, workload, pairs)
         add_clock(roof, clk)
+        with torch.no_grad(), engine.precision("f32"):
+            ref = hot_path(model, s1, s2)
         rec = dict(value=world * pairs * steps / dt, unit="pairs/s", steps=steps, warmup=warmup,
-                   ms_per_step=dt / steps * 1e3,
+                   ms_per_step=dt / steps * 1e3, dtype=PREC_INFO[engine.PRECISION][0],
+                   max_abs_dlogit_vs_f32_path=float((out - ref).abs().max()),
                    data="synthetic (%s clouds, seeded random-init weights with non-trivial BN statistics)" % cloud_kind,
                    config={"workload": "%s: %s" % (workload, desc), "pairs_per_gpu_per_step": pairs, "points": n,
                            "backbone_list": bl, "parallelism": "independent pair shards x%d" % world,
-                           "rccl_ranks": world},
+                           "rccl_ranks": world,
+                           "precision": "%s: grouped-SA layers 2/3 on the %s; tables, attention, head: f32-input MFMA"
+                           % (engine.PRECISION, {"f32": "f32-input MFMA (exact fmaf chains)",
+                                                 "bf16x3": "bf16 MFMA as split bf16 (3 MFMAs per product, f32 accumulate)",
+                                                 "bf16": "bf16 MFMA (bf16 activations / weights, f32 accumulate)"}
+                              [engine.PRECISION])},
                    roofline=roof)
         if kind == "ssg":
             rec["config"]["fill"] = ssg_fill(model, s1)
@@ -598,7 +624,9 @@ def main():
         # with 50 % duplicated points, on crops of 32..512 surface returns resampled to 1024 WITH replacement (what the
         # reference's subsamplePC hands the model: fuller groups), the same model evaluating all K rows of every group, and the reference's own 1024-pt Point-Transformer
         # config (BASELINE configs[2]; kNN groups, always full).
-        for name, wl, kw in (("ssg1024_dup", "ssg1024", dict(cloud_kind="dup")),
+        for name, wl, kw in (("ssg1024_f32", "ssg1024", dict(precision="f32")),
+                             ("ssg1024_bf16", "ssg1024", dict(precision="bf16")),
+                             ("ssg1024_dup", "ssg1024", dict(cloud_kind="dup")),
                              ("ssg1024_crop", "ssg1024", dict(cloud_kind="crop")),
                              ("ssg1024_full", "ssg1024", dict(skip_repeats=False, steps=max(4, args.steps // 4))),
                              ("pt1024", "pt1024", dict())):
@@ -625,7 +653,8 @@ def main():
             "metric": "siamese pair-comparisons/sec @%d pts" % n,
             "value": rec["value"], "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": rec["data"], "config": rec["config"], "roofline": rec["roofline"],
+            "dtype": rec["dtype"], "max_abs_dlogit_vs_f32_path": rec["max_abs_dlogit_vs_f32_path"],
+            "data": rec["data"], "config": rec["config"], "roofline": rec["roofline"],
         }
         if also:
             line["also"] = also

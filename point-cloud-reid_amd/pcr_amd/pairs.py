@@ -11,8 +11,17 @@ observation (falling to lower buckets while the bucket is empty), so positives a
 matched in sparsity.
 
 PARITY: unpinned.  The reference's dataset classes sit on `lamtk.aggregation.loader.Loader`, which is absent here, so
-no fixture can be recorded from them; this module issues the SAME sequence of numpy global-RNG calls (np.random.seed,
-shuffle, choice) over equivalent tables, which is what makes the sets reproducible under a seed.
+no fixture can be recorded from them; this module makes the same KIND of numpy global-RNG calls (np.random.seed,
+shuffle, choice) in the same order over equivalent tables, which is what makes the sets reproducible under a seed.
+
+One deliberate difference, selectable: the reference passes `taken_idx=x['o1']` -- the positive's first OBSERVATION
+NUMBER -- to `get_random_other_even_val` (reidentification_nuscenes.py:236), which then refuses the object
+`self.obj_tokens[taken_idx]` (reidentification_base.py:392,423): the object whose INDEX happens to equal that
+observation number, not the positive's own object.  So the reference can pair an object with itself as a "negative"
+and needlessly excludes an unrelated one.  `build_val_pairs(..., literal_exclusion=False)` (default) excludes the
+positive's own object, which is what the docstring of the reference function says it does;
+`literal_exclusion=True` reproduces the reference's rule as written (an observation number beyond the object list,
+where the reference would raise IndexError, excludes nothing).  Under one seed the two give different negative sets.
 """
 import itertools
 
@@ -46,7 +55,8 @@ class ObjectTable:
 
 
 def _other_even(table, token, cls, pts):
-    """another object's observation in the bucket of `pts` (or the nearest lower non-empty one); -> (token, cls, frame)"""
+    """an observation in the bucket of `pts` (or the nearest lower non-empty one) of an object other than `token`
+    (None: nothing excluded); -> (token, cls, frame)"""
     b_idx = bucket_of(pts)
     use_tp = np.random.choice([0, 1]) == 1
     pool = table.tp if use_tp else table.fp
@@ -54,7 +64,7 @@ def _other_even(table, token, cls, pts):
     while True:
         cands = pool.get(cls, {}).get(BUCKETS[b_idx])
         # a true-positive bucket holding only the object itself cannot supply a partner: go one bucket down
-        if cands and not (use_tp and len(cands) == 1):
+        if cands and not (use_tp and len(cands) == 1) and not (len(cands) == 1 and cands[0][0] == token):
             break
         b_idx -= 1
         if b_idx < -len(BUCKETS):
@@ -67,8 +77,9 @@ def _other_even(table, token, cls, pts):
     return other, out_cls, int(frame)
 
 
-def build_val_pairs(table, max_combinations, seed=0):
-    """-> (positives, negatives): lists of dict(tok1, o1, tok2, o2, cls1, cls2, match); len(negatives) == len(positives)"""
+def build_val_pairs(table, max_combinations, seed=0, literal_exclusion=False):
+    """-> (positives, negatives): lists of dict(tok1, o1, tok2, o2, cls1, cls2, match); len(negatives) == len(positives)
+    literal_exclusion: see the module docstring"""
     np.random.seed(seed)
     positives = []
     for o in table.objects:
@@ -81,6 +92,9 @@ def build_val_pairs(table, max_combinations, seed=0):
                                   pts2=o["frames"][b], match=1))
     negatives = []
     for p in positives:
-        other, cls2, frame = _other_even(table, p["tok1"], p["cls1"], p["pts2"])
+        excluded = p["tok1"]
+        if literal_exclusion:
+            excluded = table.objects[p["o1"]]["token"] if p["o1"] < len(table.objects) else None
+        other, cls2, frame = _other_even(table, excluded, p["cls1"], p["pts2"])
         negatives.append(dict(tok1=p["tok1"], o1=p["o1"], tok2=other, o2=frame, cls1=p["cls1"], cls2=cls2, match=0))
     return positives, negatives
