@@ -142,7 +142,9 @@ long pcr_packed_weight_floats(int cout, int cin);
 int pcr_pack_weight_f32(const float *w, int cout, int cin, float *packed);
 /* The same matrix as a bf16 image for the bf16 matrix core (v_mfma_f32_32x32x16_bf16): every weight is stored as
  * hi = bf16(w) and lo = bf16(w - hi) (round to nearest), laid out [ceil16(cin)/16][ceil32(cout)/32][hi, lo][64 lanes]
- * [8 bf16] so that a lane's A operand of one 16-channel step is one 16-byte load.  Kernels run in "bf16x3" mode (split
+ * [8 bf16] so that a lane's A operand of one 16-channel step is one 16-byte load; element j of lane l (row l % 32, half
+ * h = l / 32) of step s is column 16 s + 4 h + j (j < 4) | 16 s + 8 + 4 h + (j - 4): the order in which a 32 x 32
+ * accumulator tile holds its rows, so that a layer's output can be stored already converted (csrc/tile_dense.h).  Kernels run in "bf16x3" mode (split
  * bf16: W x ~= W_hi x_hi + W_hi x_lo + W_lo x_hi, f32 accumulate, ~2^-17 relative per term) read both parts, in plain
  * "bf16" mode the hi part only.  Size in floats (4-byte units) / host-side pack. */
 long pcr_packed_weight_bf16_floats(int cout, int cin);
@@ -492,6 +494,15 @@ int pcr_linattn_bwd_f32(const pcr_linattn *p, pcr_stream_t stream);
  * maximum; backward: dout (2P,C,L) from g (P,2C). */
 int pcr_pool_pair_fwd_f32(const float *o, float *pooled, int *arg, int P, int C, int L, pcr_stream_t stream);
 int pcr_pool_pair_bwd_f32(const float *g, const int *arg, float *dout, int P, int C, int L, pcr_stream_t stream);
+/* The same pooling for ONE tensor (match types that pool a single branch: `xcorr-baseline`, models/ReIDNet.py:258-264
+ * with get_pooled_feats 'both' :529-532): o (P,C,L) -> pooled (P,2C) = [max over L, mean over L], arg (P,C); and its
+ * backward dout (P,C,L). */
+int pcr_pool_both_fwd_f32(const float *o, float *pooled, int *arg, int P, int C, int L, pcr_stream_t stream);
+int pcr_pool_both_bwd_f32(const float *g, const int *arg, float *dout, int P, int C, int L, pcr_stream_t stream);
+/* get_pooled_feats 'max' (models/ReIDNet.py:145, 526-528: nn.MaxPool1d(W) on the permuted (B,L,C) tensor) with the
+ * winning channel kept for the backward: x (B,C,L) -> y (B,C/W,L), arg (B,C/W,L); backward dx (B,C,L). */
+int pcr_channel_max_fwd_f32(const float *x, float *y, int *arg, int B, int C, int L, int W, pcr_stream_t stream);
+int pcr_channel_max_bwd_f32(const float *g, const int *arg, float *dx, int B, int C, int L, int W, pcr_stream_t stream);
 
 /* The packed images of MANY weights in one launch (a training step re-packs every weight after the update: ~76 small
  * launches otherwise).  descs (device): per tensor the contiguous row-major (rows x cols) matrix w and out, which

@@ -287,12 +287,104 @@ def gen_train_step():
               "backbone.SA_modules.0.mlp_convs.0.weight", "backbone.SA_modules.2.self_attention.q_proj.weight"):
         rec["grad:" + k] = _np(dict(model.named_parameters())[k].grad)
     rec["no_grad_params"] = np.array(json.dumps(no_grad))
+    # the same step in float64 (see gen_train_variants): the yardstick for the gradients in front of a max-over-K
+    model64, _ = build(PT_CFG, seed=0, backbone_list=[128, 64, 32],
+                       losses_to_use=dict(kl=False, match=True, cls=False, shape=False, fp=False, triplet=False))
+    model64 = model64.double().train()
+    data64 = {k: [t.double() if t.is_floating_point() else t for t in v] for k, v in data.items()}
+    with contextlib.redirect_stdout(io.StringIO()):
+        out64 = model64.train_step(data64, None)
+    out64["loss"].backward()
+    p64 = dict(model64.named_parameters())
+    for k in list(rec):
+        if k.startswith("grad:"):
+            rec["grad64:" + k[5:]] = p64[k[5:]].grad.numpy().astype(np.float32)
     np.savez_compressed(os.path.join(GOLD, "pt_train_step_n128.npz"), **rec)
     print("train_step loss", rec["loss"], "params without grad:", len(no_grad))
 
+STNET_CFG = "configs_reid/_base_/reidentifiers/reid_pts_point-transformer_baseline_stnet.py"
 
-def gen_train_loop():
-    """five iterations of the REFERENCE model (its own train_step: forward with BatchNorm batch statistics, autograd
+
+def _train_data(pairs, n, seed=2):
+    s1, s2 = T.synthetic_pairs(pairs, n, seed=seed, kind="randn")
+    ids1 = torch.arange(pairs)
+    ids2 = torch.where(torch.arange(pairs) < pairs // 2, ids1, ids1 + 100)      # first half of the pairs match
+    zero = torch.zeros(1, dtype=torch.long)
+    return dict(sparse_1=list(s1), sparse_2=list(s2), dense_1=list(s1), dense_2=list(s2),
+                label_1=[zero] * pairs, label_2=[zero] * pairs,
+                id_1=[i.view(1) for i in ids1], id_2=[i.view(1) for i in ids2])
+
+
+def gen_train_variants(only=None):
+    """the reference's own train_step (loss, accuracy, gradients of a spread of parameters, which parameters get none)
+    for the OTHER training configs it ships: the mul = 2 Point-Transformer
+    (reid_waymo_pts/pts_point-transformer_point-cat_waymo_det_4x256_400e_512pts_2.py:25 -> the 1.5M reidentifier), the
+    `concat` + channel-max baseline, the `xcorr-baseline` matching, PointNet and DGCNN; 8 pairs (4 for the wide
+    encoders) of 128 points, seeded weights, BatchNorm in batch-statistics mode"""
+    ref = ref_loader.load_reference()
+    ref.dgcnn_orig.torch = _CpuTorch()
+    losses = dict(kl=False, match=True, cls=False, shape=False, fp=False, triplet=False)
+    cases = (("pt15m", MUL_CFGS[0][1], dict(), 4, 128),
+             ("baseline", BASE_CFG, dict(shape_head=None), 8, 128),
+             # (reid_pts_point-transformer_baseline_stnet.py = the point-cat file + match_type 'xcorr-baseline'; the loader
+             # executes plain config files only, so the `_base_` merge is spelled out)
+             ("stnet", PT_CFG, dict(match_type="xcorr-baseline"), 8, 128),
+             ("pointnet", PN_CFG, dict(), 4, 128),
+             ("dgcnn", DG_CFG, dict(), 4, 128))
+    for tag, cfg, over, pairs, n in cases:
+        if only and tag not in only:
+            continue
+        model, manifest = build(cfg, seed=0, losses_to_use=losses, **over)
+        if "backbone_list" in over or tag in ("pt15m", "baseline", "stnet"):
+            model.backbone_list = [128, 64, 32]
+        model.train()
+        data = _train_data(pairs, n)
+        with contextlib.redirect_stdout(io.StringIO()):
+            out = model.train_step(data, None)
+        out["loss"].backward()
+        params = dict(model.named_parameters())
+        rec = dict(loss=np.float32(out["loss"].item()), match_acc=np.float32(out["log_vars"]["match_acc"]))
+        with_grad = [k for k, p in params.items() if p.grad is not None]
+        # a spread of gradients: first / last tensors with a gradient, every 7th in between, capped in size
+        pick = sorted(set(with_grad[:3] + with_grad[-3:] + with_grad[::7]))
+        for k in pick:
+            g = params[k].grad
+            if g.numel() <= 40000:
+                rec["grad:" + k] = _np(g)
+        rec["no_grad_params"] = np.array(json.dumps([k for k, p in params.items() if p.grad is None]))
+        rec["grad_norm"] = np.float32(float(torch.sqrt(sum((params[k].grad.double() ** 2).sum() for k in with_grad))))
+        # the same step of the same reference model in float64 ("grad64:"): how far the reference's OWN float32
+        # gradients are from the exact ones.  Tensors in front of a max-over-K / BatchNorm batch statistics move by
+        # 1e-3 .. 1e-2 of their scale between float32 and float64 (a near-tie resolved the other way re-routes a whole
+        # gradient row), tensors behind the last max by ~1e-6: the yardstick the GPU test holds the HIP gradients to
+        model64, _ = build(cfg, seed=0, losses_to_use=losses, **over)
+        if tag in ("pt15m", "baseline", "stnet"):
+            model64.backbone_list = [128, 64, 32]
+        model64 = model64.double().train()
+        data64 = {k: [t.double() if t.is_floating_point() else t for t in v] for k, v in data.items()}
+        with contextlib.redirect_stdout(io.StringIO()):
+            out64 = model64.train_step(data64, None)
+        out64["loss"].backward()
+        p64 = dict(model64.named_parameters())
+        rec["loss64"] = np.float64(out64["loss"].item())
+        for k in list(rec):
+            if k.startswith("grad:"):
+                rec["grad64:" + k[5:]] = p64[k[5:]].grad.numpy().astype(np.float32)   # (exact value rounded once)
+        bn = [(k, b) for k, b in model.named_buffers() if k.endswith("running_mean")]
+        for k, b in bn[:2] + bn[-1:]:
+            rec["buf:" + k] = _np(b)
+        rec["meta"] = np.array(json.dumps(dict(pairs=pairs, n=n, input_seed=2, weight_seed=0, cfg=cfg)))
+        np.savez_compressed(os.path.join(GOLD, "train_step_%s_n%d.npz" % (tag, n)), **rec)
+        # (state_dict manifests: the inference fixtures' -- pt15m / pt_baseline / pt / pointnet / dgcnn _manifest.json)
+        print("train variant", tag, "loss", rec["loss"], "grads", len(with_grad), "recorded",
+              sum(1 for k in rec if k.startswith("grad:")), "no grad", len(params) - len(with_grad))
+
+
+def gen_train_loop(frozen_bias=False):
+    """(frozen_bias: the conv biases in front of a BatchNorm -- whose true gradient is zero -- do not train, on both
+    sides: what is left of the disagreement between two float32 runs then shows how much of it was those biases' random
+    walk under AdamW; fixture pt_train_loop_frozen_n128.npz)
+    five iterations of the REFERENCE model (its own train_step: forward with BatchNorm batch statistics, autograd
     backward, running statistics) under torch's clip_grad_norm_ + AdamW with the cyclic lr / beta1 values of the
     reference's schedule config: the loss trajectory, the eval-mode logits after training and one BatchNorm's running
     statistics.  Pins the multi-step behaviour (update applied, statistics tracked, caches refreshed), which the
@@ -309,7 +401,12 @@ def gen_train_loop():
                 label_1=[torch.zeros(1, dtype=torch.long)] * 8, label_2=[torch.zeros(1, dtype=torch.long)] * 8,
                 id_1=[i.view(1) for i in ids1], id_2=[i.view(1) for i in ids2])
     iters, lr0, clip = 5, 1e-3, 1.0
-    opt = torch.optim.AdamW(model.parameters(), lr=lr0, weight_decay=0.01, betas=(0.9, 0.999))
+    if frozen_bias:
+        for k, p in model.named_parameters():
+            if ".mlp_convs." in k and k.endswith(".bias"):
+                p.requires_grad_(False)
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=lr0, weight_decay=0.01,
+                            betas=(0.9, 0.999))
     losses, norms = [], []
     for it in range(iters):
         lr = TR.cyclic_value(lr0, it, 10)
@@ -335,8 +432,9 @@ def gen_train_loop():
             rec["bn%d%d_mean" % (i, j)] = _np(bn.running_mean)
             rec["bn%d%d_var" % (i, j)] = _np(bn.running_var)
             rec["bn%d%d_n" % (i, j)] = np.int64(int(bn.num_batches_tracked))
-    np.savez_compressed(os.path.join(GOLD, "pt_train_loop_n128.npz"), **rec)
-    print("train loop losses", losses, "norms", norms)
+    np.savez_compressed(os.path.join(GOLD, "pt_train_loop_frozen_n128.npz" if frozen_bias else "pt_train_loop_n128.npz"),
+                        **rec)
+    print("train loop%s losses" % (" (frozen pre-BN biases)" if frozen_bias else ""), losses, "norms", norms)
 
 
 def gen_python_twins():
@@ -430,9 +528,16 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--only-train-loop" in sys.argv:
         gen_train_loop()
+        gen_train_loop(frozen_bias=True)
         sys.exit(0)
     if "--only-mul" in sys.argv:
         gen_pt_mul()
+    if "--only-train-step" in sys.argv:
+        gen_train_step()
+        sys.exit(0)
+    if "--only-train-variants" in sys.argv:
+        gen_train_variants([a for a in sys.argv[1:] if not a.startswith("--")] or None)
+        sys.exit(0)
         sys.exit(0)
     if "--only-small" not in sys.argv:
         gen_baseline()
@@ -442,7 +547,9 @@ if __name__ == "__main__":
         gen_pt()
         gen_pointnet()
     gen_train_step()
+    gen_train_variants()
     gen_train_loop()
+    gen_train_loop(frozen_bias=True)
     gen_python_twins()
     gen_eval_metric()
     gen_eval_tables()

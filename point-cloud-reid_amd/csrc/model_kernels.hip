@@ -389,7 +389,7 @@ PCR_EXPORT int pcr_pack_weight_bf16x2_f32(const float *w, int cout, int cin, flo
     for (int cb = 0; cb < nCB; cb++)
       for (int lane = 0; lane < 64; lane++)
         for (int j = 0; j < 8; j++) {
-          const int o = cb * 32 + (lane & 31), k = 16 * s + 8 * (lane >> 5) + j;
+          const int o = cb * 32 + (lane & 31), k = 16 * s + bf_kpos(lane >> 5, j);   // (accumulator order: tile_dense.h)
           const float v = (o < cout && k < cin) ? w[(size_t)o * cin + k] : 0.f;
           const unsigned short hi = pcr_bf16_rn(v);
           const unsigned short lo = pcr_bf16_rn(v - pcr_bf16_to_f32(hi));

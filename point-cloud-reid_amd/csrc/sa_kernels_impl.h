@@ -147,9 +147,13 @@ struct Sa2Args {
 // RKB > 0 (narrow layers: c1, c2 <= 8 RKB): ALL weight fragments of layers 2 and 3 are fetched into registers at
 // the top of the kernel, behind the index staging and the gathers; the two dense calls then run without a single
 // weight load (their 4- or 8-block k-loops were mostly L2 latency)
-template <int TB, int NR, int W2, int W3, bool MAXE, int NR2 = NR, int RKB = 0, int PREC = 0>
+// IMG (bf16 forms with layer 1 on the matrix core): the activations between the layers live in LDS as a bf image
+// (tile_dense.h) written by the producing layer's epilogue, already converted, instead of the f32 tile
+template <int TB, int NR, int W2, int W3, bool MAXE, int NR2 = NR, int RKB = 0, int PREC = 0, bool IMG = false>
 __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
   static_assert(PREC == 0 || RKB == 0, "resident f32 weight fragments belong to the f32 form");
+  static_assert(!IMG || (PREC != 0 && MAXE), "bf images belong to the bf16 forms");
+  constexpr bool kLoImg = PREC == 1;
   constexpr int ROWS = 32 * TB, RP = ROWS + 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int c1 = a.c1, c2 = a.c2, c3 = a.c3, K = a.K;
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
     sq[e] = a.sh1[o] + (has_q ? pq[(size_t)scen[c * K] * a.pqw + a.qoff + o] : 0.f);
   }
   __syncthreads();
-  if (a.l1m) {
+  if (IMG || a.l1m) {
     // Layer 1 on the matrix core: relu(Wa dxyz + (shift + Q[c]) + P[i]) per 32 x 32 tile is two MFMAs (k = dx, dy |
     // dz, 0) on accumulators SEEDED with the centre's shift + Q row, plus the table piece in the epilogue -- the fma
     // order of the VALU form below, so the bits are the same.  A lane gathers its token's pieces in the accumulator
@@ -259,11 +263,19 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
           }
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], sdx[h * ROWS + t], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], sdx[(2 + h) * ROWS + t], acc, 0, 0, 0);
+          if constexpr (IMG) {
+            if (pq) {
+#pragma unroll
+              for (int rr = 0; rr < 16; rr++) acc[rr] += pc[rr >> 2][rr & 3];
+            }
+            bf_store_tile<kLoImg>(buf, ROWS, acc, cb, tb, l31, h);
+          } else {
           float *dst = buf + (cb * 32 + 4 * h) * RP + t;
 #pragma unroll
           for (int rr = 0; rr < 16; rr++) {
             const float v = pq ? acc[rr] + pc[rr >> 2][rr & 3] : acc[rr];
             dst[((rr & 3) + 8 * (rr >> 2)) * RP] = relu_bits(v);
+          }
           }
 #pragma unroll
           for (int g = 0; g < 4; g++) pc[g] = pn[g];
@@ -324,6 +336,11 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
       if constexpr (kRes)
         tile_dense2<TB, NR2, W2, false, decltype(epi2), DenseNoHook, RK, true>(buf, c1, a.wp2, ceil32(c2), true, epi2,
                                                                                a.sh2, wres2);
+      else if constexpr (IMG)
+        tile_dense2p<PREC, TB, NR2, W2, true, true>(buf, c1, a.wp2, ceil32(c2), true,
+                                                    [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
+          bf_store_tile<kLoImg>(buf, ROWS, acc, cb, tb, l31, h);
+        }, a.sh2);
       else
         tile_dense2p<PREC, TB, NR2, W2>(buf, c1, a.wp2, ceil32(c2), true, epi2, a.sh2);
     }
@@ -347,7 +364,7 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
         tile_dense2<TB, NR, W3, true, decltype(epi3), DenseNoHook, RK, true>(buf, ceil8(c2), a.wp3, ceil32(c3), false,
                                                                              epi3, a.sh3, wres3);
       else
-        tile_dense2p<PREC, TB, NR, W3, true>(buf, ceil8(c2), a.wp3, ceil32(c3), false, epi3, a.sh3);
+        tile_dense2p<PREC, TB, NR, W3, true, IMG>(buf, ceil8(c2), a.wp3, ceil32(c3), false, epi3, a.sh3);
     } else {
       tile_dense2p<PREC, TB, NR, W3>(buf, ceil8(c2), a.wp3, ceil32(c3), true, [&](float v, int o, int t) {
         buf[o * RP + t] = fmaxf(v, 0.f);
@@ -621,6 +638,8 @@ template <int TB, int NR, int W2, int W3, int NR2 = NR, int W1 = 0, int PREC = 0
 __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   constexpr int ROWS = 32 * TB, RP = ROWS + 1, NG = ROWS / kRagG, CT = kRagCT;
   constexpr bool kL1M = W1 != 0;
+  constexpr bool kImg = PREC != 0 && kL1M;   // activations between the layers as a bf image (tile_dense.h)
+  constexpr bool kLoImg = PREC == 1;
   const int C3P = ceil32(a.c3);           // gmax is [NG row groups][C3P]
   constexpr int QS = kThreads / ROWS;     // channel quads advance by QS per item: a thread keeps ONE row
   constexpr int NI = 8;                   // 16-byte table pieces a thread holds in registers
@@ -748,12 +767,21 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
     const bool hasp = a.pq != nullptr;
     tile_dense2<TB, 1, W1, true>(sdx8, 8, a.wap, ceil32(c1), false,
                                  [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
+      if constexpr (kImg) {
+        f32x16 v16 = acc;
+        if (hasp) {
+#pragma unroll
+          for (int rr = 0; rr < 16; rr++) v16[rr] += (tb == 0 ? p4[rr >> 2] : p4[4 + (rr >> 2)])[rr & 3];
+        }
+        bf_store_tile<kLoImg>(buf, ROWS, v16, cb, tb, l31, h);
+      } else {
       float *dst = buf + (cb * 32 + 4 * h) * RP + tb * 32 + l31;
 #pragma unroll
       for (int rr = 0; rr < 16; rr++) {
         float v = acc[rr];
         if (hasp) v += (tb == 0 ? p4[rr >> 2] : p4[4 + (rr >> 2)])[rr & 3];   // (TB = 2 whenever there is a table)
         dst[((rr & 3) + 8 * (rr >> 2)) * RP] = relu_bits(v);
+      }
       }
     }, s_sh1);
   } else
@@ -793,17 +821,24 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   __syncthreads();
   PCR_MARK(2);
   fetch_row(tile + t_step);   // next tile's row entry: lands during layer 2
-  if (!(a.dbg & 2))
+  if (!(a.dbg & 2)) {
+  if constexpr (kImg)
+  tile_dense2p<PREC, TB, NR2, W2, true, true>(buf, c1, a.wp2, ceil32(c2), true,
+                                              [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
+    bf_store_tile<kLoImg>(buf, ROWS, acc, cb, tb, l31, h);
+  }, s_sh2, nullptr, load_ring3);
+  else
   tile_dense2p<PREC, TB, NR2, W2>(buf, c1, a.wp2, ceil32(c2), true,
                                   [&](float v, int o, int t) { buf[o * RP + t] = relu_bits(v); }, s_sh2,
                                   kRing && PCR_RING == 1 ? ring2 : nullptr, load_ring3);
+  }
   PCR_MARK(3);
   if (pref || (kL1M && a.pq)) gather(tile + t_step);   // next tile's table pieces: land during layer 3
   __syncthreads();
   PCR_MARK(4);
   if (!(a.dbg & 4))
-  tile_dense2p<PREC, TB, NR, W3, true>(buf, ceil8(c2), a.wp3, ceil32(c3), false,
-                                      [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
+  tile_dense2p<PREC, TB, NR, W3, true, kImg>(buf, ceil8(c2), a.wp3, ceil32(c3), false,
+                                            [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
     // row-pair maxima -> gmax[group][cout]: the 16 accumulator rows of a lane are four runs of four consecutive
     // couts, so the first lane of every pair stores four 16-byte pieces
     // (signed maxima of the bit patterns; the ReLU is the scan's max with 0: see relu_bits)
@@ -922,10 +957,13 @@ __global__ __launch_bounds__(kThreads) void dense_pm_kernel(DensePmArgs a) {
 
 template <int TB, int NR, int W2, int W3, int NR2 = NR, int RKB = 0>
 static void sa2_launch_one(const Sa2Args &a, bool maxe, size_t lds, hipStream_t st, dim3 grid) {
+  // bf16 forms: layers whose first layer runs on the matrix core (NR2 == 1; the launcher has checked a.l1m) keep their
+  // activations as bf images
+  constexpr bool kImgK = kPrec != 0 && NR2 == 1;
   if (maxe) {
-    static bool ok = allow_big_lds(sa_fused_kernel<TB, NR, W2, W3, true, NR2, RKB, kPrec>);
+    static bool ok = allow_big_lds(sa_fused_kernel<TB, NR, W2, W3, true, NR2, RKB, kPrec, kImgK>);
     (void)ok;
-    hipLaunchKernelGGL((sa_fused_kernel<TB, NR, W2, W3, true, NR2, RKB, kPrec>), grid, dim3(kThreads), lds, st, a);
+    hipLaunchKernelGGL((sa_fused_kernel<TB, NR, W2, W3, true, NR2, RKB, kPrec, kImgK>), grid, dim3(kThreads), lds, st, a);
   } else if constexpr (kPrec == 0) {
     static bool ok = allow_big_lds(sa_fused_kernel<TB, NR, W2, W3, false, NR2, RKB, kPrec>);
     (void)ok;
@@ -947,6 +985,7 @@ static int sa2_launch_tb(const Sa2Args &a, int nr, int nr2, int w2, int w3, bool
     // w23 = 10 * (ways of layer 2) + (ways of layer 3)
     (void)narrow4;
     if (!maxe || nr > 2) return -1;
+    if (nr2 == 1 && !a.l1m) return -1;     // (the one-round instantiations are the bf-image ones: layer 1 on the matrix core)
     if (wsel == 44) sa2_launch_one<TB, 1, 4, 4>(a, maxe, lds, st, grid);
     else if (wsel == 22) sa2_launch_one<TB, 1, 2, 2>(a, maxe, lds, st, grid);
     else if (wsel == 21) sa2_launch_one<TB, 1, 2, 1>(a, maxe, lds, st, grid);
@@ -1014,7 +1053,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   }
   const float *const wl2 = p.wps[0], *const wl3 = p.wps[1];
 #else
-  if (!p.wps_bf[0] || !p.wps_bf[1] || (p.c1 & 31) || (p.c2 & 7)) return -1;
+  if (!p.wps_bf[0] || !p.wps_bf[1] || (p.c1 & 31) || (p.c2 & 31)) return -1;
   const float *const wl2 = p.wps_bf[0], *const wl3 = p.wps_bf[1];
 #endif
   if ((p.c1 & 7) || p.c1 > 512 || p.c2 > 512 || p.c3 > 512) return -1;
@@ -1196,7 +1235,8 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
     const int w1 = n1 >= 3 ? 1 : (n1 == 2 ? 2 : 4);
     const int w2c = n2 >= 3 ? 1 : (n2 == 2 ? 2 : 4), w3c = n3 >= 3 ? 1 : (n3 == 2 ? 2 : 4);
     // (the kernel deals layer 1's tiles with layer 2's compile-time shape: explicit shapes only, same class)
-    a.l1m = (!no_l1m && p.wa_packed && n1 <= 4 && n2 <= 4 && w1 == w2c && w2c == w3c && (p.c1 & 3) == 0) ? 1 : 0;
+    // (f32 forms are instantiated for equal classes of layers 2 and 3 only; the bf16 units also hold (2, 1))
+    a.l1m = (!no_l1m && p.wa_packed && n1 <= 4 && n2 <= 4 && w1 == w2c && (kPrec != 0 || w2c == w3c) && (p.c1 & 3) == 0) ? 1 : 0;
   }
   const size_t lds = lds_bytes(best_tb, best_cpw);
   dim3 grid((p.S + best_cpw - 1) / best_cpw, p.B);

@@ -351,12 +351,27 @@ __device__ __forceinline__ void tile_dense2(const float *__restrict__ in, int CP
 //   NS = 1 ("bf16"): x_hi and W_hi only -- BASELINE config 2's "bf16 activations, f32 accumulate" taken literally.
 // Weights: image [S = ceil16(cin)/16][OP/32][hi, lo][64 lanes][8 bf16] (pcr_pack_weight_bf16x2): one 16-byte load per
 // lane, step and part, streamed through a ring of bf_pf(NR) steps.
+// K ORDER inside a 16-channel step: element j of lane half h is channel 16 s + bf_kpos(h, j) = 16 s + 4 h + j (j < 4) |
+// 16 s + 8 + 4 h + (j - 4) -- not 8 h + j.  That is the order in which a 32 x 32 accumulator tile hands its rows to a
+// lane (four runs of four couts, 8 g + 4 h + q), so a producing layer can store its output already converted, as
+// 16-byte bf16 pieces in accumulator order (bf_store_tile -> "bf image", below), and the consuming layer's B operand
+// is one ds_read_b128 per part instead of eight ds_read_b32 and 24 conversion instructions per step, repeated by every
+// wave that owns a cout block.  The f32-tile form (BIMG = false) reads its rows in the same order, so ONE weight image
+// serves both.
+//
+// bf image of a [C][ROWS] activation tile (C a multiple of 32): 16-byte units, unit (2 P + part) ROWS + t holds piece P
+// (8 channels: 32 (P >> 2) + 16 ((P >> 1) & 1) + bf_kpos(P & 1, j)) of token t, part 0 = hi, 1 = lo.  Step s of the
+// consumer reads pieces 2 s (lanes 0..31) and 2 s + 1 (lanes 32..63): 512 contiguous bytes per half, conflict-free; the
+// producer's lane (token l31, half h) writes pieces 4 cb + 2 gp + h, gp = 0, 1: 128 contiguous bytes per 8 lanes.
+// The image takes C ROWS 4 bytes (hi + lo), what the f32 tile takes.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // ring depth in 16-channel steps: a step is 3 TBW NR MFMAs of 32 cycles, so two cout-block rounds per wave halve the
 // depth an L2 round trip needs (and the 8 registers per step and round are what decides the residency)
 constexpr int bf_pf(int nr) { return nr >= 2 ? 2 : 4; }
+
+__host__ __device__ constexpr int bf_kpos(int h, int j) { return j < 4 ? 4 * h + j : 8 + 4 * h + (j - 4); }
 
 __device__ __forceinline__ void bf_split8(const float (&x)[8], bf16x8 &hi, bf16x8 &lo, bool want_lo) {
 #pragma unroll
@@ -374,7 +389,28 @@ __device__ __forceinline__ void bf_split8(const float (&x)[8], bf16x8 &hi, bf16x
   }
 }
 
-template <int TB, int NR, int WAYS, bool TILE, int NS, class Epi, int PF = bf_pf(NR), class AfterK = DenseNoHook>
+// relu(acc) of one 32 x 32 accumulator tile (cout block cb, token block tb; lane = token l31, half h) -> bf image
+template <bool LO>
+__device__ __forceinline__ void bf_store_tile(float *img, int ROWS, const f32x16 &acc, int cb, int tb, int l31, int h) {
+  bf16x8 *u = reinterpret_cast<bf16x8 *>(img);
+#pragma unroll
+  for (int gp = 0; gp < 2; gp++) {
+    float x[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int b = __float_as_int(acc[8 * gp + q]);
+      x[q] = __int_as_float(b > 0 ? b : 0);
+    }
+    bf16x8 hi, lo;
+    bf_split8(x, hi, lo, LO);
+    const int P = 4 * cb + 2 * gp + h;
+    u[(2 * P) * ROWS + tb * 32 + l31] = hi;
+    if constexpr (LO) u[(2 * P + 1) * ROWS + tb * 32 + l31] = lo;
+  }
+}
+
+// BIMG: `in` is a bf image ([CP / 8 pieces][2][32 TB tokens] 16-byte units), not an f32 [CP][RP] tile
+template <int TB, int NR, int WAYS, bool TILE, int NS, class Epi, int PF = bf_pf(NR), class AfterK = DenseNoHook, bool BIMG = false>
 __device__ __forceinline__ void tile_dense_bf_impl(const float *__restrict__ in, int CP,
                                                    const float *__restrict__ wp_, int OP, bool sync_epi, Epi epi,
                                                    const float *__restrict__ init = nullptr,
@@ -399,11 +435,13 @@ __device__ __forceinline__ void tile_dense_bf_impl(const float *__restrict__ in,
     wrow[nr] = reinterpret_cast<const bf16x8 *>(wp_) + (size_t)cb * 128 + lane;
   }
   const float *brow[TBW];
+  const bf16x8 *bimg[TBW];
 #pragma unroll
   for (int j = 0; j < TBW; j++) {
     int tb = tb0 + j * WAYS;
     tb = tb < TB ? tb : TB - 1;
-    brow[j] = in + 8 * h * RP + tb * 32 + l31;
+    brow[j] = in + 4 * h * RP + tb * 32 + l31;                                            // rows bf_kpos(h, .) of a step
+    bimg[j] = reinterpret_cast<const bf16x8 *>(in) + 2 * h * (32 * TB) + tb * 32 + l31;   // piece 2 s + h of a step
   }
   bf16x8 ah[PF][NR], al[PF][NR];
 #pragma unroll
@@ -437,26 +475,44 @@ __device__ __forceinline__ void tile_dense_bf_impl(const float *__restrict__ in,
         for (int j = 0; j < TBW; j++) acc[nr][j][r] = 0.f;
     }
   }
-  float xr[2][TBW][8];
-  auto load_x = [&](float (&x)[TBW][8], int s) {
+  // operands of one step: raw f32 rows (converted in mma) or, from a bf image, the hi / lo pieces themselves
+  struct XB {
+    float r[BIMG ? 1 : 8];
+    bf16x8 hi, lo;
+  };
+  XB xr[2][TBW];
+  auto load_x = [&](XB (&x)[TBW], int s) {
 #pragma unroll
     for (int j = 0; j < TBW; j++) {
-      const float *bt = brow[j] + s * 16 * RP;
+      if constexpr (BIMG) {
+        const bf16x8 *bt = bimg[j] + (size_t)s * (4 * 32 * TB);
+        x[j].hi = bt[0];
+        if constexpr (kLo) x[j].lo = bt[32 * TB];
+      } else {
+        const float *bt = brow[j] + s * 16 * RP;
 #pragma unroll
-      for (int q = 0; q < 8; q++) x[j][q] = bt[q * RP];
+        for (int q = 0; q < 8; q++) x[j].r[q] = bt[(q < 4 ? q : q + 4) * RP];
+      }
     }
   };
-  auto mma = [&](int i, float (&x)[TBW][8], bool last) {
-    if (last && tail && h) {
+  auto mma = [&](int i, XB (&x)[TBW], bool last) {
+    if constexpr (!BIMG) {
+      if (last && tail) {   // channels 16 s + 8 .. + 15 lie beyond the tile: elements 4 .. 7 of both lane halves
 #pragma unroll
-      for (int j = 0; j < TBW; j++)
+        for (int j = 0; j < TBW; j++)
 #pragma unroll
-        for (int q = 0; q < 8; q++) x[j][q] = 0.f;
+          for (int q = 4; q < 8; q++) x[j].r[q] = 0.f;
+      }
     }
 #pragma unroll
     for (int j = 0; j < TBW; j++) {
       bf16x8 bh, bl;
-      bf_split8(x[j], bh, bl, kLo);
+      if constexpr (BIMG) {
+        bh = x[j].hi;
+        bl = x[j].lo;
+      } else {
+        bf_split8(x[j].r, bh, bl, kLo);
+      }
 #pragma unroll
       for (int nr = 0; nr < NR; nr++) {
         if constexpr (kLo) {
@@ -536,18 +592,19 @@ __device__ __forceinline__ void tile_dense_bf_impl(const float *__restrict__ in,
 
 // PREC 0: f32-input MFMA (exact fmaf chains); 1: split bf16 (three MFMAs per product); 2: plain bf16.  The bf16 forms
 // exist for the explicit wave / tile splits only (WSEL 1 / 2 / 4).
-template <int PREC, int TB, int NR, int WSEL = 0, bool TILE = false, class Epi, class AfterK = DenseNoHook, int PFv = PCR_PF,
-          bool RES = false>
+template <int PREC, int TB, int NR, int WSEL = 0, bool TILE = false, bool BIMG = false, class Epi,
+          class AfterK = DenseNoHook, int PFv = PCR_PF, bool RES = false>
 __device__ __forceinline__ void tile_dense2p(const float *__restrict__ in, int CP, const float *__restrict__ wp, int OP,
                                              bool sync_epi, Epi epi, const float *__restrict__ init = nullptr,
                                              f32x4 (*ring)[DenseShape<NR, WSEL>::nr] = nullptr,
                                              AfterK after_k = AfterK(), int opfull = 0) {
   if constexpr (PREC == 0) {
+    static_assert(!BIMG, "bf images feed the bf16 tile only");
     tile_dense2<TB, NR, WSEL, TILE, Epi, AfterK, PFv, RES>(in, CP, wp, OP, sync_epi, epi, init, ring, after_k, opfull);
   } else {
     static_assert(WSEL != 0, "bf16 dense tiles are instantiated for explicit shapes only");
     tile_dense_bf_impl<TB, DenseShape<NR, WSEL>::nr, DenseShape<NR, WSEL>::ways, TILE, PREC == 1 ? 3 : 1, Epi,
-                       bf_pf(DenseShape<NR, WSEL>::nr), AfterK>(in, CP, wp, OP, sync_epi, epi, init, after_k, opfull);
+                       bf_pf(DenseShape<NR, WSEL>::nr), AfterK, BIMG>(in, CP, wp, OP, sync_epi, epi, init, after_k, opfull);
   }
 }
 

@@ -260,10 +260,13 @@ constexpr int kAT = 64;        // tokens per staged chunk
 
 __device__ __forceinline__ float elu1f(float x) { return x > 0.f ? x + 1.0f : __expf(x); }
 
-template <int DH>
+// KAT: tokens per staged chunk (64; 16 for the 128-wide heads of the mul = 2 configs' SA3 attention, whose dh x dh
+// matrices leave that much LDS).  LDS is dynamic: the launch sites compute the byte counts.
+template <int DH, int KAT = kAT>
 __global__ __launch_bounds__(256) void linattn_fwd_kernel(LinAttn a) {
-  constexpr int RP = kAT + 1, NP = (DH * DH + 255) / 256;
-  __shared__ float Kt[DH * RP], Vt[DH * RP], Al[DH * (DH + 1)], ksl[DH], zl[kAT];
+  constexpr int RP = KAT + 1, NP = (DH * DH + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *Kt = smem, *Vt = Kt + DH * RP, *Al = Vt + DH * RP, *ksl = Al + DH * (DH + 1), *zl = ksl + DH;
   const int tid = threadIdx.x;
   const int h = blockIdx.x;
   const size_t b = blockIdx.y;
@@ -275,11 +278,11 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(LinAttn a) {
 #pragma unroll
   for (int p = 0; p < NP; p++) acc[p] = 0.f;
   float ksum = 0.f;
-  for (int s0 = 0; s0 < a.Sk; s0 += kAT) {
-    const int ns = a.Sk - s0 < kAT ? a.Sk - s0 : kAT;
+  for (int s0 = 0; s0 < a.Sk; s0 += KAT) {
+    const int ns = a.Sk - s0 < KAT ? a.Sk - s0 : KAT;
     if (s0) __syncthreads();
-    for (int e = tid; e < DH * kAT; e += 256) {
-      const int i = e / kAT, s = e - i * kAT;
+    for (int e = tid; e < DH * KAT; e += 256) {
+      const int i = e / KAT, s = e - i * KAT;
       const bool ok = s < ns;
       Kt[i * RP + s] = ok ? elu1f(k[(size_t)i * a.Sk + s0 + s]) : 0.f;
       Vt[i * RP + s] = ok ? v[(size_t)i * a.Sk + s0 + s] / sk : 0.f;
@@ -293,14 +296,14 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(LinAttn a) {
         const float *kr = Kt + i * RP, *vr = Vt + j * RP;
         float s = 0.f;
 #pragma unroll 8
-        for (int t = 0; t < kAT; t++) s += kr[t] * vr[t];
+        for (int t = 0; t < KAT; t++) s += kr[t] * vr[t];
         acc[p] += s;
       }
     }
     if (tid < DH) {
       const float *kr = Kt + tid * RP;
       float s = 0.f;
-      for (int t = 0; t < kAT; t++) s += kr[t];
+      for (int t = 0; t < KAT; t++) s += kr[t];
       ksum += s;
     }
   }
@@ -319,22 +322,22 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(LinAttn a) {
   }
   float *out = a.out + (b * a.d + (size_t)h * DH) * a.Lq;
   float *Qt = Kt;     // the key tiles are dead
-  for (int l0 = 0; l0 < a.Lq; l0 += kAT) {
-    const int nl = a.Lq - l0 < kAT ? a.Lq - l0 : kAT;
+  for (int l0 = 0; l0 < a.Lq; l0 += KAT) {
+    const int nl = a.Lq - l0 < KAT ? a.Lq - l0 : KAT;
     __syncthreads();
-    for (int e = tid; e < DH * kAT; e += 256) {
-      const int i = e / kAT, l = e - i * kAT;
+    for (int e = tid; e < DH * KAT; e += 256) {
+      const int i = e / KAT, l = e - i * KAT;
       Qt[i * RP + l] = l < nl ? elu1f(q[(size_t)i * a.Lq + l0 + l]) : 0.f;
     }
     __syncthreads();
-    if (tid < kAT) {
+    if (tid < KAT) {
       float z = 0.f;
       for (int i = 0; i < DH; i++) z += Qt[i * RP + tid] * ksl[i];
       zl[tid] = 1.0f / (z + a.eps);
     }
     __syncthreads();
-    for (int e = tid; e < DH * kAT; e += 256) {
-      const int vv = e / kAT, l = e - vv * kAT;
+    for (int e = tid; e < DH * KAT; e += 256) {
+      const int vv = e / KAT, l = e - vv * KAT;
       float s = 0.f;
 #pragma unroll 8
       for (int i = 0; i < DH; i++) s += Qt[i * RP + l] * Al[i * (DH + 1) + vv];
@@ -343,12 +346,12 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(LinAttn a) {
   }
 }
 
-template <int DH>
+template <int DH, int KAT = kAT>
 __global__ __launch_bounds__(256) void linattn_bwd_kernel(LinAttn a) {
-  constexpr int RP = kAT + 1, NP = (DH * DH + 255) / 256;
+  constexpr int RP = KAT + 1, NP = (DH * DH + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) float smem[];    // 83 KB at DH = 64: dynamic
   float *Qt = smem, *Gt = Qt + DH * RP, *Dn = Gt + DH * RP, *Al = Dn + DH * RP, *dAl = Al + DH * (DH + 1);
-  float *ksl = dAl + DH * (DH + 1), *dksl = ksl + DH, *zl = dksl + DH, *ddl = zl + kAT;
+  float *ksl = dAl + DH * (DH + 1), *dksl = ksl + DH, *zl = dksl + DH, *ddl = zl + KAT;
   const int tid = threadIdx.x;
   const int h = blockIdx.x;
   const size_t b = blockIdx.y;
@@ -368,25 +371,25 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(LinAttn a) {
   for (int p = 0; p < NP; p++) dA[p] = 0.f;
   float dks = 0.f;
   // ---- pass 1 over the query tokens: dq, and the sums dA = sum_l Q'_l dnum_l^T, dks = sum_l dden_l Q'_l
-  for (int l0 = 0; l0 < a.Lq; l0 += kAT) {
-    const int nl = a.Lq - l0 < kAT ? a.Lq - l0 : kAT;
+  for (int l0 = 0; l0 < a.Lq; l0 += KAT) {
+    const int nl = a.Lq - l0 < KAT ? a.Lq - l0 : KAT;
     __syncthreads();
-    for (int e = tid; e < DH * kAT; e += 256) {
-      const int i = e / kAT, l = e - i * kAT;
+    for (int e = tid; e < DH * KAT; e += 256) {
+      const int i = e / KAT, l = e - i * KAT;
       const bool ok = l < nl;
       Qt[i * RP + l] = ok ? elu1f(q[(size_t)i * a.Lq + l0 + l]) : 0.f;
       Gt[i * RP + l] = ok ? go[(size_t)i * a.Lq + l0 + l] : 0.f;
     }
     __syncthreads();
-    if (tid < kAT) {
+    if (tid < KAT) {
       float z = 0.f;
       for (int i = 0; i < DH; i++) z += Qt[i * RP + tid] * ksl[i];
       zl[tid] = 1.0f / (z + a.eps);
     }
     __syncthreads();
     // num[v][l] = Q'_l . A[:,v];  dnum = dout z S;  dz_l = sum_v dout num S  (accumulated per token below)
-    for (int e = tid; e < DH * kAT; e += 256) {
-      const int vv = e / kAT, l = e - vv * kAT;
+    for (int e = tid; e < DH * KAT; e += 256) {
+      const int vv = e / KAT, l = e - vv * KAT;
       float s = 0.f;
 #pragma unroll 8
       for (int i = 0; i < DH; i++) s += Qt[i * RP + l] * Al[i * (DH + 1) + vv];
@@ -395,14 +398,14 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(LinAttn a) {
       Gt[vv * RP + l] = gv * s * sk;          // dout * num * S (summed over v next)
     }
     __syncthreads();
-    if (tid < kAT) {
+    if (tid < KAT) {
       float dz = 0.f;
       for (int vv = 0; vv < DH; vv++) dz += Gt[vv * RP + tid];
       ddl[tid] = -zl[tid] * zl[tid] * dz;      // gradient of the denominator Q'.ks + eps
     }
     __syncthreads();
-    for (int e = tid; e < DH * kAT; e += 256) {
-      const int i = e / kAT, l = e - i * kAT;
+    for (int e = tid; e < DH * KAT; e += 256) {
+      const int i = e / KAT, l = e - i * KAT;
       float s = ddl[l] * ksl[i];
 #pragma unroll 8
       for (int vv = 0; vv < DH; vv++) s += Dn[vv * RP + l] * Al[i * (DH + 1) + vv];
@@ -417,14 +420,14 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(LinAttn a) {
         const float *qr = Qt + i * RP, *dr = Dn + vv * RP;
         float s = 0.f;
 #pragma unroll 8
-        for (int t = 0; t < kAT; t++) s += qr[t] * dr[t];
+        for (int t = 0; t < KAT; t++) s += qr[t] * dr[t];
         dA[p] += s;
       }
     }
     if (tid < DH) {
       const float *qr = Qt + tid * RP;
       float s = 0.f;
-      for (int t = 0; t < kAT; t++) s += ddl[t] * qr[t];
+      for (int t = 0; t < KAT; t++) s += ddl[t] * qr[t];
       dks += s;
     }
   }
@@ -437,18 +440,18 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(LinAttn a) {
   if (tid < DH) dksl[tid] = dks;
   // ---- pass 2 over the key tokens: dK' = dA V' + dks, dV' = dA^T K'
   float *Kt = Qt, *Vt = Gt;
-  for (int s0 = 0; s0 < a.Sk; s0 += kAT) {
-    const int ns = a.Sk - s0 < kAT ? a.Sk - s0 : kAT;
+  for (int s0 = 0; s0 < a.Sk; s0 += KAT) {
+    const int ns = a.Sk - s0 < KAT ? a.Sk - s0 : KAT;
     __syncthreads();
-    for (int e = tid; e < DH * kAT; e += 256) {
-      const int i = e / kAT, s = e - i * kAT;
+    for (int e = tid; e < DH * KAT; e += 256) {
+      const int i = e / KAT, s = e - i * KAT;
       const bool ok = s < ns;
       Kt[i * RP + s] = ok ? elu1f(k[(size_t)i * a.Sk + s0 + s]) : 0.f;
       Vt[i * RP + s] = ok ? v[(size_t)i * a.Sk + s0 + s] / sk : 0.f;
     }
     __syncthreads();
-    for (int e = tid; e < DH * kAT; e += 256) {
-      const int i = e / kAT, s = e - i * kAT;
+    for (int e = tid; e < DH * KAT; e += 256) {
+      const int i = e / KAT, s = e - i * KAT;
       float dkp = dksl[i], dvp = 0.f;
 #pragma unroll 8
       for (int j = 0; j < DH; j++) {
@@ -753,11 +756,97 @@ __global__ __launch_bounds__(256) void pool_pair_bwd_kernel(const float *__restr
   for (int l = threadIdx.x; l < L; l += 256) dout[bc * L + l] = ga + (l == am ? gm : 0.f);
 }
 
+// ---- the same pooling for ONE tensor (match types that pool a single branch: xcorr-baseline, ReIDNet.py:258-264 with
+// get_pooled_feats 'both' :529-532), and the channel-window max of pool_type 'max' (:145, 526-528) ----
+// o (P,C,L) -> pooled (P,2C) = [max over L, mean over L]; arg (P,C)
+__global__ __launch_bounds__(256) void pool_both_fwd_kernel(const float *__restrict__ o, float *__restrict__ pooled,
+                                                            int *__restrict__ arg, int C, int L) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t p = blockIdx.x;
+  for (int c = wave; c < C; c += 4) {
+    const float *row = o + (p * C + c) * L;
+    float mx = -INFINITY, sm = 0.f;
+    int am = 0;
+    for (int i = lane; i < L; i += 64) {
+      const float x = row[i];
+      if (x > mx) {
+        mx = x;
+        am = i;
+      }
+      sm += x;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const float ox = __shfl_xor(mx, m, 64);
+      const int oa = __shfl_xor(am, m, 64);
+      if (ox > mx || (ox == mx && oa < am)) {
+        mx = ox;
+        am = oa;
+      }
+    }
+    sm = wsum(sm);
+    if (lane == 0) {
+      pooled[p * 2 * C + c] = mx;
+      pooled[p * 2 * C + C + c] = sm / (float)L;
+      arg[p * C + c] = am;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pool_both_bwd_kernel(const float *__restrict__ g, const int *__restrict__ arg,
+                                                            float *__restrict__ dout, int C, int L) {
+  const size_t pc = blockIdx.x;                 // (cloud, channel) row
+  const size_t p = pc / C;
+  const int c = (int)(pc - p * C);
+  const float gm = g[p * 2 * C + c], ga = g[p * 2 * C + C + c] / (float)L;
+  const int am = arg[pc];
+  for (int l = threadIdx.x; l < L; l += 256) dout[pc * L + l] = ga + (l == am ? gm : 0.f);
+}
+
+// x (B,C,L) -> y (B,C/W,L) = max over windows of W consecutive channels of every point (nn.MaxPool1d(W) on the
+// permuted (B,L,C) tensor); arg (B,C/W,L) = the winning channel (first maximum)
+__global__ __launch_bounds__(256) void channel_max_idx_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                              int *__restrict__ arg, int C, int L, int W, size_t total) {
+  const int G = C / W;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int l = (int)(e % L);
+    const size_t bg = e / L;
+    const int g = (int)(bg % G);
+    const size_t b = bg / G;
+    const float *src = x + (b * C + (size_t)g * W) * L + l;
+    float mx = src[0];
+    int am = 0;
+    for (int w = 1; w < W; w++) {
+      const float v = src[(size_t)w * L];
+      if (v > mx) {
+        mx = v;
+        am = w;
+      }
+    }
+    y[e] = mx;
+    arg[e] = g * W + am;
+  }
+}
+
+__global__ __launch_bounds__(256) void channel_max_bwd_kernel(const float *__restrict__ g, const int *__restrict__ arg,
+                                                              float *__restrict__ dx, int C, int L, int W, size_t total) {
+  const int G = C / W;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {   // over (B,C,L)
+    const int l = (int)(e % L);
+    const size_t bc = e / L;
+    const int c = (int)(bc % C);
+    const size_t b = bc / C;
+    const size_t o = (b * G + c / W) * L + l;
+    dx[e] = arg[o] == c ? g[o] : 0.f;
+  }
+}
+
 template <class F>
 void dh_dispatch(int dh, F f) {
   switch (dh) {
     case 16: f(std::integral_constant<int, 16>()); break;
     case 32: f(std::integral_constant<int, 32>()); break;
+    case 128: f(std::integral_constant<int, 128>()); break;
     default: f(std::integral_constant<int, 64>()); break;
   }
 }
@@ -809,7 +898,7 @@ static int linattn_check(const pcr_linattn *p) {
   if (!p || !p->q || !p->k || !p->v || !p->A || !p->ks || p->B < 0 || p->Lq < 1 || p->Sk < 1 || p->H < 1 || p->d % p->H)
     return 1;
   const int dh = p->d / p->H;
-  return !(dh == 16 || dh == 32 || dh == 64);
+  return !(dh == 16 || dh == 32 || dh == 64 || dh == 128);
 }
 
 static LinAttn linattn_args(const pcr_linattn *p) {
@@ -828,10 +917,16 @@ PCR_EXPORT int pcr_linattn_fwd_f32(const pcr_linattn *p, pcr_stream_t stream) {
   const LinAttn a = linattn_args(p);
   dh_dispatch(p->d / p->H, [&](auto tag) {
     constexpr int DH = decltype(tag)::value;
-    if constexpr (DH >= 32)
+    if constexpr (DH == 32 || DH == 64) {
       hipLaunchKernelGGL(linattn_fwd_mfma_kernel<DH>, dim3(p->H, p->B), dim3(256), 0, pcr_s(stream), a);
-    else
-      hipLaunchKernelGGL(linattn_fwd_kernel<DH>, dim3(p->H, p->B), dim3(256), 0, pcr_s(stream), a);
+    } else {
+      // scalar form: 16-wide heads, and the 128-wide ones (d_model 256: the mul = 2 configs) with 16-token chunks
+      constexpr int KAT = DH == 128 ? 16 : kAT;
+      const size_t lds = (2 * (size_t)DH * (KAT + 1) + (size_t)DH * (DH + 1) + DH + KAT) * sizeof(float);
+      static bool ok = allow_big_lds(linattn_fwd_kernel<DH, KAT>);
+      (void)ok;
+      hipLaunchKernelGGL((linattn_fwd_kernel<DH, KAT>), dim3(p->H, p->B), dim3(256), lds, pcr_s(stream), a);
+    }
   });
   PCR_CHECK_LAUNCH();
   return PCR_OK;
@@ -844,15 +939,16 @@ PCR_EXPORT int pcr_linattn_bwd_f32(const pcr_linattn *p, pcr_stream_t stream) {
   const LinAttn a = linattn_args(p);
   dh_dispatch(p->d / p->H, [&](auto tag) {
     constexpr int DH = decltype(tag)::value;
-    const size_t lds = (3 * (size_t)DH * (kAT + 1) + 2 * (size_t)DH * (DH + 1) + 2 * DH + 2 * kAT) * sizeof(float);
-    if constexpr (DH >= 32) {
+    constexpr int KAT = DH == 128 ? 16 : kAT;
+    const size_t lds = (3 * (size_t)DH * (KAT + 1) + 2 * (size_t)DH * (DH + 1) + 2 * DH + 2 * KAT) * sizeof(float);
+    if constexpr (DH == 32 || DH == 64) {
       static bool ok = allow_big_lds(linattn_bwd_mfma_kernel<DH>);
       (void)ok;
       hipLaunchKernelGGL(linattn_bwd_mfma_kernel<DH>, dim3(p->H, p->B), dim3(256), lds, pcr_s(stream), a);
     } else {
-      static bool ok = allow_big_lds(linattn_bwd_kernel<DH>);
+      static bool ok = allow_big_lds(linattn_bwd_kernel<DH, KAT>);
       (void)ok;
-      hipLaunchKernelGGL(linattn_bwd_kernel<DH>, dim3(p->H, p->B), dim3(256), lds, pcr_s(stream), a);
+      hipLaunchKernelGGL((linattn_bwd_kernel<DH, KAT>), dim3(p->H, p->B), dim3(256), lds, pcr_s(stream), a);
     }
   });
   PCR_CHECK_LAUNCH();
@@ -872,6 +968,45 @@ PCR_EXPORT int pcr_pool_pair_bwd_f32(const float *g, const int *arg, float *dout
   if (!g || !arg || !dout || P < 0 || C < 1 || L < 1) return PCR_ERR_INVALID;
   if (P == 0) return PCR_OK;
   hipLaunchKernelGGL(pool_pair_bwd_kernel, dim3(2 * P * C), dim3(256), 0, pcr_s(stream), g, arg, dout, P, C, L);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_pool_both_fwd_f32(const float *o, float *pooled, int *arg, int P, int C, int L, pcr_stream_t stream) {
+  if (!o || !pooled || !arg || P < 0 || C < 1 || L < 1) return PCR_ERR_INVALID;
+  if (P == 0) return PCR_OK;
+  hipLaunchKernelGGL(pool_both_fwd_kernel, dim3(P), dim3(256), 0, pcr_s(stream), o, pooled, arg, C, L);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_pool_both_bwd_f32(const float *g, const int *arg, float *dout, int P, int C, int L, pcr_stream_t stream) {
+  if (!g || !arg || !dout || P < 0 || C < 1 || L < 1) return PCR_ERR_INVALID;
+  if (P == 0) return PCR_OK;
+  hipLaunchKernelGGL(pool_both_bwd_kernel, dim3(P * C), dim3(256), 0, pcr_s(stream), g, arg, dout, C, L);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_channel_max_fwd_f32(const float *x, float *y, int *arg, int B, int C, int L, int W, pcr_stream_t stream) {
+  if (!x || !y || !arg || B < 0 || C < 1 || L < 1 || W < 1 || C % W) return PCR_ERR_INVALID;
+  if (B == 0) return PCR_OK;
+  const size_t total = (size_t)B * (C / W) * L;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(channel_max_idx_kernel, dim3((unsigned)blocks), dim3(256), 0, pcr_s(stream), x, y, arg, C, L, W, total);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_channel_max_bwd_f32(const float *g, const int *arg, float *dx, int B, int C, int L, int W,
+                                       pcr_stream_t stream) {
+  if (!g || !arg || !dx || B < 0 || C < 1 || L < 1 || W < 1 || C % W) return PCR_ERR_INVALID;
+  if (B == 0) return PCR_OK;
+  const size_t total = (size_t)B * C * L;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(channel_max_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, pcr_s(stream), g, arg, dx, C, L, W, total);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }

@@ -254,10 +254,12 @@ class ReIDNet(nn.Module):
     def _match_logits(self, h1, h2, xyz1, xyz2, inference=False):
         """logits (B) and the stage-2 features; fused single-launch tail for the configuration every point
         ReID config uses, generic composition (reference ReIDNet.py:387-462) for the other variants"""
+        if self.training:
+            # training mode: the differentiable HIP graph (raises PcrError for the matchings it does not cover -- the
+            # inference compositions below have no backward)
+            from pcr_amd import train_graph
+            return train_graph.match_logits(self, h1, xyz1, h2, xyz2)
         if self._fused_matching():
-            if self.training:
-                from pcr_amd import train_graph
-                return train_graph.match_logits(self, h1, xyz1, h2, xyz2)
             o = self._xcorr_eff_batched(h1, xyz1, h2, xyz2)
             return self._head(o.device).run(o), o
         if self.match_type == "xcorr_eff":

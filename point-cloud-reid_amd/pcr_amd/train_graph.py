@@ -98,17 +98,58 @@ def _joined(a1, a2):
     return torch.cat([a1, a2], dim=0)
 
 
+def _head(model, pooled):
+    """match_head = [LinearRes, Linear] on pooled rows (B,F), samples as tokens"""
+    x = pooled.t().contiguous().unsqueeze(0)                               # (1, F, B)
+    x = linear_res_rows(model.match_head[0], x)
+    return TO.dense(x, model.match_head[1].weight, model.match_head[1].bias).reshape(-1)   # (1, 1, B)
+
+
+def supports(model):
+    """the training graph covers: xcorr_eff + point-cat + pool 'both' (every point-cat config), xcorr-baseline + pool
+    'both' (reid_pts_point-transformer_baseline_stnet.py) and concat + pool 'max'
+    (reid_pts_point-transformer_baseline.py); -> None or the reason it does not"""
+    head = model.match_head
+    if not (isinstance(head, torch.nn.Sequential) and len(head) == 2):
+        return "match_head must be [LinearRes, Linear]"
+    mt, pool = model.match_type, model.pool_type
+    if mt == "xcorr_eff" and model.combine == "point-cat" and pool == "both":
+        return None
+    if mt == "xcorr-baseline" and pool == "both":
+        return None
+    if mt == "concat" and pool == "max":
+        return None
+    return ("match_type=%r / combine=%r / pool_type=%r has no HIP training graph (covered: xcorr_eff + point-cat + both, "
+            "xcorr-baseline + both, concat + max)" % (mt, model.combine, pool))
+
+
 def match_logits(model, h1, xyz1, h2, xyz2):
-    """xcorr_eff + point-cat + pool 'both' + LinearRes + Linear (ReIDNet.py:231-247, 526-534, 455-457); the four
-    cross-attention calls of the reference run as two, over all 2B clouds with the halves swapped as templates"""
+    """matching + pooling + LinearRes + Linear in training mode -> (logits (B), stage-2 features or None)
+    * xcorr_eff + point-cat + pool 'both' (ReIDNet.py:231-247, 526-534, 455-457): the four cross-attention calls of the
+      reference run as two, over all 2B clouds with the halves swapped as templates;
+    * xcorr-baseline (:258-264): the search branch only, two cross-attention stages against the template, pool 'both';
+    * concat + pool 'max' (:415-419, 526-528): channel-window max of each encoding, concatenated."""
+    why = supports(model)
+    if why is not None:
+        from . import _lib as L
+        raise L.PcrError(why)
     b = h1.shape[0]
+    if model.match_type == "concat":
+        w = model.output_sequence_size
+        if h1.shape[1] != w:
+            from . import _lib as L
+            raise L.PcrError("concat + pool 'max' pools one window of %d channels per point; the encoder gives %d"
+                             % (w, h1.shape[1]))
+        pooled = TO.ChannelMax.apply(_joined(h1, h2), w)                   # (2B, 1, N)
+        pooled = pooled.reshape(2 * b, -1)
+        return _head(model, torch.cat([pooled[:b], pooled[b:]], dim=1)), None
+    if model.match_type == "xcorr-baseline":
+        a = cross_attention(model.cross_stage1, h1, h2, _cm(xyz2))
+        o = cross_attention(model.cross_stage2, a, h2, _cm(xyz2))
+        return _head(model, TO.PoolBoth.apply(o)), None
     feats = _joined(h1, h2)
     xyz_cm = _cm(_joined(xyz1, xyz2))
     swap = lambda t: torch.roll(t, b, 0)                    # noqa: E731  (halves exchanged: one launch each way)
     a = cross_attention(model.cross_stage1, feats, swap(feats), swap(xyz_cm))
     o = cross_attention(model.cross_stage2, a, swap(a), swap(xyz_cm))
-    pooled = TO.PoolPair.apply(o)                                          # (B, 2C)
-    x = pooled.t().contiguous().unsqueeze(0)                               # (1, 2C, B): samples as tokens
-    x = linear_res_rows(model.match_head[0], x)
-    logits = TO.dense(x, model.match_head[1].weight, model.match_head[1].bias)   # (1, 1, B)
-    return logits.reshape(-1), o
+    return _head(model, TO.PoolPair.apply(o)), o

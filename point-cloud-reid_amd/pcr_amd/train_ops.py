@@ -305,7 +305,6 @@ class TDense(Function):
 
     @staticmethod
     def forward(ctx, x, x2, W, bias, res, out_relu):
-        assert not (out_relu and res is not None)
         cout = W.shape[0]
         need_dx = x.requires_grad or (x2 is not None and x2.requires_grad)
         wp, wpT = pack_both(W) if need_dx else (pack_dev(W), None)
@@ -325,12 +324,43 @@ class TDense(Function):
         r = tdense_bwd(g, x, W.shape[0], dy_mode=2 if out_relu else 0, y=y, x2=x2,
                        wpT=wpT if need_dx else None,
                        want_dw=ctx.needs_input_grad[2] or (has_bias and ctx.needs_input_grad[3]))
-        return (r.get("dx"), r.get("dx2"), r.get("dW"), r.get("db") if has_bias else None,
-                g if has_res else None, None)
+        g_res = None
+        if has_res and ctx.needs_input_grad[4]:
+            # relu(W x + res): the residual sees the gradient through the same mask (only the wide-layer tiling below
+            # builds this combination; one elementwise select)
+            g_res = torch.where(y > 0, g, torch.zeros((), dtype=g.dtype, device=g.device)) if out_relu else g
+        return (r.get("dx"), r.get("dx2"), r.get("dW"), r.get("db") if has_bias else None, g_res, None)
+
+
+# pcr_tdense_{fwd,bwd}_f32 take up to 384 output rows and 288 input rows per launch (the backward keeps dy and the forward
+# input of a 64-token tile in LDS together).  Wider layers -- the 256-channel attention blocks and 512-row feed-forward /
+# table layers of the mul = 2 Point-Transformer -- run as a grid of launches: output rows in chunks, input rows in chunks
+# chained through the launch's residual input; autograd sees ordinary Functions, so the backward tiles the same way.
+_MAX_COUT, _MAX_CIN, _CHUNK = 384, 288, 256
 
 
 def dense(x, W, bias=None, x2=None, res=None, relu=False):
-    return TDense.apply(x, x2, W, bias, res, relu)
+    cout, cin = W.shape
+    if cout <= _MAX_COUT and cin <= _MAX_CIN and not (relu and res is not None):
+        return TDense.apply(x, x2, W, bias, res, relu)
+    segs = [x] if x2 is None else [x, x2]             # input = the channel concatenation of the segments
+    pieces, c0 = [], 0                                # (tensor, first column of W)
+    for t in segs:
+        for a in range(0, t.shape[1], _CHUNK):
+            b = min(t.shape[1], a + _CHUNK)
+            pieces.append((t if (a == 0 and b == t.shape[1]) else t[:, a:b].contiguous(), c0 + a, c0 + b))
+        c0 += t.shape[1]
+    assert c0 == cin, "dense: input width %d != weight width %d" % (c0, cin)
+    outs = []
+    for o0 in range(0, cout, _CHUNK):
+        o1 = min(cout, o0 + _CHUNK)
+        acc = None if res is None else (res if (o0 == 0 and o1 == cout) else res[:, o0:o1].contiguous())
+        for i, (t, a, b) in enumerate(pieces):
+            last = i == len(pieces) - 1
+            acc = TDense.apply(t, None, W[o0:o1, a:b], bias[o0:o1] if (bias is not None and i == 0) else None, acc,
+                               relu and last)
+        outs.append(acc)
+    return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
 
 
 class SaEdgeTrain(Function):
@@ -589,3 +619,56 @@ class PoolPair(Function):
         L.check(L.load().pcr_pool_pair_bwd_f32(L.ptr(g), L.ptr(arg), L.ptr(dout), P, C, Ln, L.stream_ptr()),
                 "pcr_pool_pair_bwd_f32")
         return dout
+
+
+class PoolBoth(Function):
+    """o (P,C,L) -> (P,2C): [max over L, mean over L] (get_pooled_feats 'both' on one tensor, ReIDNet.py:529-532)"""
+
+    @staticmethod
+    def forward(ctx, o):
+        o = _dev(o)
+        P, C, Ln = o.shape
+        pooled = _f32(P, 2 * C, device=o.device)
+        arg = torch.empty((P, C), dtype=torch.int32, device=o.device)
+        L.check(L.load().pcr_pool_both_fwd_f32(L.ptr(o), L.ptr(pooled), L.ptr(arg), P, C, Ln, L.stream_ptr()),
+                "pcr_pool_both_fwd_f32")
+        ctx.save_for_backward(arg)
+        ctx.dims = (P, C, Ln)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, g):
+        arg, = ctx.saved_tensors
+        P, C, Ln = ctx.dims
+        g = g.contiguous()
+        dout = _f32(P, C, Ln, device=g.device)
+        L.check(L.load().pcr_pool_both_bwd_f32(L.ptr(g), L.ptr(arg), L.ptr(dout), P, C, Ln, L.stream_ptr()),
+                "pcr_pool_both_bwd_f32")
+        return dout
+
+
+class ChannelMax(Function):
+    """x (B,C,L) -> (B,C/W,L): max over windows of W channels of every point (get_pooled_feats 'max', ReIDNet.py:145,
+    526-528: nn.MaxPool1d(W) on the permuted tensor)"""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        x = _dev(x)
+        B, C, Ln = x.shape
+        y = _f32(B, C // W, Ln, device=x.device)
+        arg = torch.empty((B, C // W, Ln), dtype=torch.int32, device=x.device)
+        L.check(L.load().pcr_channel_max_fwd_f32(L.ptr(x), L.ptr(y), L.ptr(arg), B, C, Ln, W, L.stream_ptr()),
+                "pcr_channel_max_fwd_f32")
+        ctx.save_for_backward(arg)
+        ctx.dims = (B, C, Ln, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        arg, = ctx.saved_tensors
+        B, C, Ln, W = ctx.dims
+        g = g.contiguous()
+        dx = _f32(B, C, Ln, device=g.device)
+        L.check(L.load().pcr_channel_max_bwd_f32(L.ptr(g), L.ptr(arg), L.ptr(dx), B, C, Ln, W, L.stream_ptr()),
+                "pcr_channel_max_bwd_f32")
+        return dx, None

@@ -50,8 +50,9 @@ def test_weight_packing_layout(lib):
 
 
 def test_bf16_weight_image_layout_and_split(lib):
-    """pcr_pack_weight_bf16x2_f32: element j of lane l of step s, cout block cb, part p holds W[32 cb + l % 32][16 s + 8 (l
-    // 32) + j] as bf16 hi (p = 0) / lo (p = 1); hi + lo reproduces the weight to 2^-17 relative"""
+    """pcr_pack_weight_bf16x2_f32: element j of lane l (h = l // 32) of step s, cout block cb, part p holds
+    W[32 cb + l % 32][16 s + kpos(h, j)], kpos = 4 h + j (j < 4) | 8 + 4 h + j - 4 (the accumulator order, pcr.h), as
+    bf16 hi (p = 0) / lo (p = 1); hi + lo reproduces the weight to 2^-16 relative"""
     lib.pcr_packed_weight_bf16_floats.restype = ctypes.c_long
     g = np.random.default_rng(1)
     for cout, cin in ((32, 32), (64, 67), (130, 24), (1, 1)):
@@ -66,8 +67,13 @@ def test_bf16_weight_image_layout_and_split(lib):
         as_f32 = (img.astype(np.uint32) << 16).view(np.float32)
         full = np.zeros((ncb * 32, S * 16), np.float32)
         full[:cout, :cin] = w
-        # (s, cb, part, lane = 32 h + r, j) -> row 32 cb + r, column 16 s + 8 h + j
-        back = as_f32.reshape(S, ncb, 2, 2, 32, 8).transpose(2, 1, 4, 0, 3, 5).reshape(2, ncb * 32, S * 16)
+        # (s, cb, part, lane = 32 h + r, j) -> row 32 cb + r, column 16 s + kpos(h, j)
+        a6 = as_f32.reshape(S, ncb, 2, 2, 32, 8)
+        back = np.zeros((2, ncb * 32, S * 16), np.float32)
+        for h in range(2):
+            for j in range(8):
+                col = (4 * h + j) if j < 4 else (8 + 4 * h + j - 4)
+                back[:, :, col::16] = a6[:, :, :, h, :, j].transpose(2, 1, 3, 0).reshape(2, ncb * 32, S)
         hi, lo = back[0], back[1]
         assert np.all(np.abs(hi - full) <= np.abs(full) * 2.0 ** -8 + 1e-38)
         assert np.all(np.abs(hi + lo - full) <= np.abs(full) * 2.0 ** -16)

@@ -172,21 +172,25 @@ def test_train_step_matches_reference_loss_and_grads():
     assert abs(out["log_vars"]["match_acc"] - float(g["match_acc"])) < 1e-6
     out["loss"].backward()
     params = dict(m.named_parameters())
-    worst = {}
+    worst, ref_own, vs64 = {}, {}, {}
     for k in g:
         if k.startswith("grad:"):
             got = params[k[5:]].grad.cpu().numpy()
             scale = max(1e-3, float(np.abs(g[k]).max()))
             worst[k[5:]] = float(np.abs(got - g[k]).max()) / scale
-    print(json.dumps(worst))
-    # Against the REFERENCE's own backward (CPU): match head, cross attention, cov_final and the SA attention projection
-    # agree to ~6e-7 of the tensor's scale (bound used: 1e-5).  The first SA conv's gradient passes through three
+            ref_own[k[5:]] = float(np.abs(g[k] - g["grad64:" + k[5:]]).max()) / scale
+            vs64[k[5:]] = float(np.abs(got - g["grad64:" + k[5:]]).max()) / scale
+    print(json.dumps(dict(vs_ref32=worst, ref32_vs_ref64=ref_own, vs_ref64=vs64)))
+    # Against the REFERENCE's own backward (CPU, float32): match head, cross attention, cov_final and the SA attention
+    # projection agree to ~6e-7 of the tensor's scale (bound 1e-5).  The first SA conv's gradient passes through three
     # BatchNorm layers in batch-statistics mode and the max-over-K routing, where a near-tie between two rows of a group
-    # resolved differently by the two summation orders moves a whole gradient row: observed 4.5e-3 of the scale here and
-    # 5e-3 with torch's own GPU autograd on the same graph (round 1), i.e. a property of the comparison, not of the
-    # kernels -- tests/test_gpu_train_ops.py pins the same layer to 2e-4 against torch autograd on identical indices.
-    for k, v in worst.items():
-        assert v < (1e-2 if k == "backbone.SA_modules.0.mlp_convs.0.weight" else 1e-5), worst
+    # resolved differently by two summation orders moves a whole gradient row: the reference's OWN float32 gradient of
+    # that tensor is ~4e-3 of its scale away from the reference's float64 gradient (`grad64:` in the fixture, recorded
+    # by oracle/make_golden.py gen_train_step).  That is the yardstick: the HIP gradient must be no further from the
+    # float64 gradient than twice what the reference's float32 backward is.  (tests/test_gpu_train_ops.py pins the same
+    # layer to 2e-4 against torch autograd on identical indices.)
+    for k in worst:
+        assert worst[k] < 1e-5 or vs64[k] < max(1e-5, 2.0 * ref_own[k]), (k, worst[k], vs64[k], ref_own[k])
     no_grad = sorted(k for k, p in params.items() if p.grad is None)
     assert no_grad == sorted(json.loads(str(g["no_grad_params"])))      # the 24 never-used FP tensors
 
@@ -258,6 +262,50 @@ def test_training_loop_follows_the_reference_over_five_iterations():
     # one: the two runs agree to ~0.05 here (and to 2e-3 when both use THIS graph's gradients, see the test below); the
     # untrained model's logits are ~1 away, which is what this bound is for
     assert np.abs(logits - g["logits"]).max() < 0.15, (logits, g["logits"])
+
+
+def test_training_loop_with_frozen_pre_norm_biases_follows_the_reference_closely():
+    """The explanation of the loose bounds of the test above, demonstrated: with the conv biases in front of a BatchNorm
+    frozen on BOTH sides (their true gradient is zero; trained, AdamW turns the rounding noise of their computed gradient
+    into +-lr steps and the running means inherit that walk) the same five iterations agree an order of magnitude
+    closer -- fixture tests/golden/pt_train_loop_frozen_n128.npz, oracle/make_golden.py gen_train_loop(frozen_bias=True)"""
+    from pcr_amd import train
+    g = load_golden("pt_train_loop_frozen_n128")
+    m, _ = build_pt([128, 64, 32])
+    m.train()
+    for k, p in m.named_parameters():
+        if ".mlp_convs." in k and k.endswith(".bias"):
+            p.requires_grad_(False)
+    s1, s2 = T.synthetic_pairs(8, 128, seed=2, kind="randn")
+    dev = "cuda"
+    ids1 = torch.arange(8)
+    ids2 = torch.tensor([0, 1, 2, 3, 9, 9, 9, 9])
+    data = dict(sparse_1=list(s1.to(dev)), sparse_2=list(s2.to(dev)), dense_1=list(s1.to(dev)), dense_2=list(s2.to(dev)),
+                label_1=[torch.zeros(1, dtype=torch.long, device=dev)] * 8,
+                label_2=[torch.zeros(1, dtype=torch.long, device=dev)] * 8,
+                id_1=[i.view(1).to(dev) for i in ids1], id_2=[i.view(1).to(dev) for i in ids2])
+    tr = train.Trainer(m, max_iters=int(g["max_iters"]), lr=float(g["lr"]), grad_clip=float(g["clip"]))
+    losses, norms = [], []
+    for _ in range(int(g["iters"])):
+        out = tr.step(data)
+        losses.append(float(out["loss"].detach()))
+        norms.append(float(out["grad_norm"]))
+    worst = {}
+    for i, sa in enumerate(m.backbone.SA_modules):
+        for j, bn in enumerate(sa.mlp_bns):
+            for nm, t in (("mean", bn.running_mean), ("var", bn.running_var)):
+                ref = g["bn%d%d_%s" % (i, j, nm)]
+                worst["bn%d%d_%s" % (i, j, nm)] = float(np.abs(t.cpu().numpy() - ref).max() / max(1e-3, np.abs(ref).max()))
+    m.eval()
+    with torch.no_grad():
+        logits = m.match_forward_inference(*_hx(m, s1.to(dev), s2.to(dev))).cpu().numpy()
+    dl = float(np.abs(logits - g["logits"]).max())
+    print(json.dumps(dict(losses=losses, ref=g["losses"].tolist(), norms=norms, ref_norms=g["grad_norms"].tolist(),
+                          bn=max(worst.values()), dlogits=dl)))
+    assert losses == pytest.approx(g["losses"].tolist(), rel=1e-3)
+    assert norms == pytest.approx(g["grad_norms"].tolist(), rel=5e-3)
+    assert max(worst.values()) < 1e-3, worst
+    assert dl < 1e-2, (logits, g["logits"])
 
 
 def test_trainer_checkpoint_resumes_bit_for_bit(tmp_path):
