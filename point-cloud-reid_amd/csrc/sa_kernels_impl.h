@@ -18,6 +18,20 @@
 #ifndef PCR_RING
 #define PCR_RING 2
 #endif
+// bf16 forms: bit 0: the first weight steps of layer 2 are requested early (kernel top / after the previous tile's layer 3),
+// bit 1: those of layer 3 right after layer 2's k-loop.  Both at once cost a workgroup of residency everywhere (the
+// early fragments stay live across the other layer's epilogue); which ONE fits without that depends on the kernel:
+// K-row kernel and 64-row ragged tiles: layer 3 (the longer call; measured -8 % on the 128-channel K-row layer, -2 % on
+// the 64-row ragged one); 128-row ragged tiles: neither (layer 2 early measured +5 %, layer 3 early costs the second workgroup).
+#ifndef PCR_BF_RING_FUSED
+#define PCR_BF_RING_FUSED 2
+#endif
+#ifndef PCR_BF_RING_RAG2
+#define PCR_BF_RING_RAG2 2
+#endif
+#ifndef PCR_BF_RING_RAG4
+#define PCR_BF_RING_RAG4 0
+#endif
 
 namespace {
 constexpr int kPrec = PCR_SA_PREC;
@@ -164,6 +178,15 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
     tile_dense_ring_load<DenseShape<NR2, W2>::nr, DenseShape<NR2, W2>::ways, RK>(a.wp2, c1, ceil32(c2), wres2);
     tile_dense_ring_load<DenseShape<NR, W3>::nr, DenseShape<NR, W3>::ways, RK>(a.wp3, ceil8(c2), ceil32(c3), wres3);
   }
+  // bf16 forms: the first steps of layer 2's weight stream are requested here, behind them the index staging and
+  // layer 1; layer 3's right after layer 2's k-loop (the L2 round trips never sit between a barrier and the first MFMA)
+  constexpr bool kBfR2 = PREC != 0 && (PCR_BF_RING_FUSED & 1), kBfR3 = PREC != 0 && (PCR_BF_RING_FUSED & 2);
+  BfRingOf<NR2, W2> bring2;
+  BfRingOf<NR, W3> bring3;
+  if constexpr (kBfR2) bf_ring_load2<PREC, NR2, W2>(a.wp2, c1, ceil32(c2), bring2);
+  auto hook3 = [&]() {
+    if constexpr (kBfR3) bf_ring_load2<PREC, NR, W3>(a.wp3, ceil8(c2), ceil32(c3), bring3);
+  };
   // MAXE (K % 16 == 0): the max over K is taken from the layer-3 accumulators (16-lane DPP groups ->
   // gmax[c3][ROWS/16]) and the (c3 x rows) layer-3 output is never materialised in LDS
   int rowsC = c1 > ceil32(c2) ? c1 : ceil32(c2);
@@ -340,7 +363,10 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
         tile_dense2p<PREC, TB, NR2, W2, true, true>(buf, c1, a.wp2, ceil32(c2), true,
                                                     [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
           bf_store_tile<kLoImg>(buf, ROWS, acc, cb, tb, l31, h);
-        }, a.sh2);
+        }, a.sh2, nullptr, hook3, 0, kBfR2 ? &bring2 : nullptr);
+      else if constexpr (PREC != 0)
+        tile_dense2p<PREC, TB, NR2, W2>(buf, c1, a.wp2, ceil32(c2), true, epi2, a.sh2, nullptr, hook3, 0,
+                                        kBfR2 ? &bring2 : nullptr);
       else
         tile_dense2p<PREC, TB, NR2, W2>(buf, c1, a.wp2, ceil32(c2), true, epi2, a.sh2);
     }
@@ -363,6 +389,9 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
       if constexpr (kRes)
         tile_dense2<TB, NR, W3, true, decltype(epi3), DenseNoHook, RK, true>(buf, ceil8(c2), a.wp3, ceil32(c3), false,
                                                                              epi3, a.sh3, wres3);
+      else if constexpr (PREC != 0)
+        tile_dense2p<PREC, TB, NR, W3, true, IMG>(buf, ceil8(c2), a.wp3, ceil32(c3), false, epi3, a.sh3, nullptr,
+                                                  DenseNoHook(), 0, kBfR3 ? &bring3 : nullptr);
       else
         tile_dense2p<PREC, TB, NR, W3, true, IMG>(buf, ceil8(c2), a.wp3, ceil32(c3), false, epi3, a.sh3);
     } else {
@@ -692,11 +721,18 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   // shapes only): the L2 round trip then never sits between a barrier and the first MFMA
   constexpr bool kRing = PCR_RING && W2 != 0 && W3 != 0 && PREC == 0;   // (the bf16 tile streams its own ring)
   f32x4 ring2[PCR_PF][DenseShape<NR2, W2>::nr], ring3[PCR_PF][DenseShape<NR, W3>::nr];
+  constexpr int kBfSel = TB == 2 ? PCR_BF_RING_RAG2 : PCR_BF_RING_RAG4;
+  constexpr bool kBfR2 = PREC != 0 && W2 != 0 && W3 != 0 && (kBfSel & 1);
+  constexpr bool kBfR3 = PREC != 0 && W2 != 0 && W3 != 0 && (kBfSel & 2);
+  BfRingOf<NR2, W2> bring2;
+  BfRingOf<NR, W3> bring3;
   auto load_ring2 = [&]() {
     if constexpr (kRing && PCR_RING == 1) tile_dense_ring_load<DenseShape<NR2, W2>::nr, DenseShape<NR2, W2>::ways>(a.wp2, c1, ceil32(c2), ring2);
+    if constexpr (kBfR2) bf_ring_load2<PREC, NR2, W2>(a.wp2, c1, ceil32(c2), bring2);
   };
   auto load_ring3 = [&]() {
     if constexpr (kRing) tile_dense_ring_load<DenseShape<NR, W3>::nr, DenseShape<NR, W3>::ways>(a.wp3, ceil8(c2), C3P, ring3);
+    if constexpr (kBfR3) bf_ring_load2<PREC, NR, W3>(a.wp3, ceil8(c2), C3P, bring3);
   };
   load_ring2();
   const int r = tid % ROWS, q0 = tid / ROWS;   // this thread's row of every tile, its first channel quad
@@ -826,7 +862,11 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
   tile_dense2p<PREC, TB, NR2, W2, true, true>(buf, c1, a.wp2, ceil32(c2), true,
                                               [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
     bf_store_tile<kLoImg>(buf, ROWS, acc, cb, tb, l31, h);
-  }, s_sh2, nullptr, load_ring3);
+  }, s_sh2, nullptr, load_ring3, 0, kBfR2 ? &bring2 : nullptr);
+  else if constexpr (PREC != 0)
+  tile_dense2p<PREC, TB, NR2, W2>(buf, c1, a.wp2, ceil32(c2), true,
+                                  [&](float v, int o, int t) { buf[o * RP + t] = relu_bits(v); }, s_sh2,
+                                  nullptr, load_ring3, 0, kBfR2 ? &bring2 : nullptr);
   else
   tile_dense2p<PREC, TB, NR2, W2>(buf, c1, a.wp2, ceil32(c2), true,
                                   [&](float v, int o, int t) { buf[o * RP + t] = relu_bits(v); }, s_sh2,
@@ -855,7 +895,7 @@ __global__ __launch_bounds__(kThreads) void sa_rag_kernel(RagArgs a) {
 #pragma unroll
       for (int g = 0; g < 4; g++) *reinterpret_cast<f32x4 *>(gq + 8 * g) = g4[g];
     }
-  }, s_sh3, kRing ? ring3 : nullptr, load_ring2);
+  }, s_sh3, kRing ? ring3 : nullptr, load_ring2, 0, kBfR3 ? &bring3 : nullptr);
   PCR_MARK(5);
   if constexpr (kL1M) stash_dxyz();   // next tile's dxyz rows (layer 1 of this tile is long done)
   __syncthreads();

@@ -409,12 +409,45 @@ __device__ __forceinline__ void bf_store_tile(float *img, int ROWS, const f32x16
   }
 }
 
+// The first PF steps of a bf16 dense call's weight stream (what tile_dense_bf_impl loads in its prologue), for callers
+// that request them EARLY -- at the top of the kernel, or right after the previous call's k-loop -- so that the L2 round
+// trip is over before the call starts.  RES callers hold ALL steps of a narrow layer this way (KS <= PF).
+template <int PF, int NR>
+struct BfRing {
+  bf16x8 h[PF][NR], l[PF][NR];
+};
+
+template <int NR, int WAYS, int PF, int NS>
+__device__ __forceinline__ void bf_ring_load(const float *__restrict__ wp_, int CP, int OP, BfRing<PF, NR> &ring,
+                                             int opfull = 0) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3;
+  const int nCB = OP >> 5, KS = (CP + 15) >> 4;
+  const int cb0 = WAYS == 1 ? wave : (WAYS == 2 ? (wave & 1) : 0);
+  const size_t wstride = (size_t)((opfull ? opfull : OP) >> 5) * 128;
+#pragma unroll
+  for (int nr = 0; nr < NR; nr++) {
+    int cb = cb0 + 4 * nr;
+    cb = cb < nCB ? cb : nCB - 1;
+    const bf16x8 *wrow = reinterpret_cast<const bf16x8 *>(wp_) + (size_t)cb * 128 + lane;
+#pragma unroll
+    for (int i = 0; i < PF; i++) {
+      const int ki = i < KS ? i : KS - 1;
+      ring.h[i][nr] = wrow[(size_t)ki * wstride];
+      if constexpr (NS == 3) ring.l[i][nr] = wrow[(size_t)ki * wstride + 64];
+    }
+  }
+}
+
 // BIMG: `in` is a bf image ([CP / 8 pieces][2][32 TB tokens] 16-byte units), not an f32 [CP][RP] tile
-template <int TB, int NR, int WAYS, bool TILE, int NS, class Epi, int PF = bf_pf(NR), class AfterK = DenseNoHook, bool BIMG = false>
+// ring: null, or the steps bf_ring_load fetched for THIS call; RES: the ring holds every step (no weight load inside)
+template <int TB, int NR, int WAYS, bool TILE, int NS, class Epi, int PF = bf_pf(NR), class AfterK = DenseNoHook,
+          bool BIMG = false, bool RES = false>
 __device__ __forceinline__ void tile_dense_bf_impl(const float *__restrict__ in, int CP,
                                                    const float *__restrict__ wp_, int OP, bool sync_epi, Epi epi,
                                                    const float *__restrict__ init = nullptr,
-                                                   AfterK after_k = AfterK(), int opfull = 0) {
+                                                   AfterK after_k = AfterK(), int opfull = 0,
+                                                   const BfRing<PF, NR> *ring = nullptr) {
   static_assert((PF & 1) == 0, "the B-operand double buffer alternates per step");
   constexpr int RP = 32 * TB + 1;
   constexpr int TBW = (TB + WAYS - 1) / WAYS;
@@ -449,8 +482,13 @@ __device__ __forceinline__ void tile_dense_bf_impl(const float *__restrict__ in,
     const int ki = i < KS ? i : KS - 1;
 #pragma unroll
     for (int nr = 0; nr < NR; nr++) {
-      ah[i][nr] = wrow[nr][(size_t)ki * wstride];
-      if constexpr (kLo) al[i][nr] = wrow[nr][(size_t)ki * wstride + 64];
+      if (ring) {
+        ah[i][nr] = ring->h[i][nr];
+        if constexpr (kLo) al[i][nr] = ring->l[i][nr];
+      } else {
+        ah[i][nr] = wrow[nr][(size_t)ki * wstride];
+        if constexpr (kLo) al[i][nr] = wrow[nr][(size_t)ki * wstride + 64];
+      }
     }
   }
   f32x16 acc[NR][TBW];
@@ -524,6 +562,7 @@ __device__ __forceinline__ void tile_dense_bf_impl(const float *__restrict__ in,
     }
   };
   auto refill = [&](int i, int ks) {
+    if constexpr (RES) return;
 #pragma unroll
     for (int nr = 0; nr < NR; nr++) {
       ah[i][nr] = wrow[nr][(size_t)ks * wstride];
@@ -592,20 +631,32 @@ __device__ __forceinline__ void tile_dense_bf_impl(const float *__restrict__ in,
 
 // PREC 0: f32-input MFMA (exact fmaf chains); 1: split bf16 (three MFMAs per product); 2: plain bf16.  The bf16 forms
 // exist for the explicit wave / tile splits only (WSEL 1 / 2 / 4).
+template <int NR, int WSEL>
+using BfRingOf = BfRing<bf_pf(DenseShape<NR, WSEL>::nr), DenseShape<NR, WSEL>::nr>;
+
 template <int PREC, int TB, int NR, int WSEL = 0, bool TILE = false, bool BIMG = false, class Epi,
           class AfterK = DenseNoHook, int PFv = PCR_PF, bool RES = false>
 __device__ __forceinline__ void tile_dense2p(const float *__restrict__ in, int CP, const float *__restrict__ wp, int OP,
                                              bool sync_epi, Epi epi, const float *__restrict__ init = nullptr,
                                              f32x4 (*ring)[DenseShape<NR, WSEL>::nr] = nullptr,
-                                             AfterK after_k = AfterK(), int opfull = 0) {
+                                             AfterK after_k = AfterK(), int opfull = 0,
+                                             const BfRingOf<NR, WSEL> *bfring = nullptr) {
   if constexpr (PREC == 0) {
     static_assert(!BIMG, "bf images feed the bf16 tile only");
     tile_dense2<TB, NR, WSEL, TILE, Epi, AfterK, PFv, RES>(in, CP, wp, OP, sync_epi, epi, init, ring, after_k, opfull);
   } else {
     static_assert(WSEL != 0, "bf16 dense tiles are instantiated for explicit shapes only");
     tile_dense_bf_impl<TB, DenseShape<NR, WSEL>::nr, DenseShape<NR, WSEL>::ways, TILE, PREC == 1 ? 3 : 1, Epi,
-                       bf_pf(DenseShape<NR, WSEL>::nr), AfterK, BIMG>(in, CP, wp, OP, sync_epi, epi, init, after_k, opfull);
+                       bf_pf(DenseShape<NR, WSEL>::nr), AfterK, BIMG>(in, CP, wp, OP, sync_epi, epi, init, after_k, opfull,
+                                                                      bfring);
   }
+}
+
+// the early request of a bf16 call's first steps, in terms of the caller's (NR, WSEL)
+template <int PREC, int NR, int WSEL>
+__device__ __forceinline__ void bf_ring_load2(const float *__restrict__ wp, int CP, int OP, BfRingOf<NR, WSEL> &ring) {
+  bf_ring_load<DenseShape<NR, WSEL>::nr, DenseShape<NR, WSEL>::ways, bf_pf(DenseShape<NR, WSEL>::nr), PREC == 1 ? 3 : 1>(
+      wp, CP, OP, ring);
 }
 
 // elu(x) + 1 = x + 1 (x > 0) | exp(x) (x <= 0); hardware exp2 (v_exp_f32, ~1 ulp) instead of the libm

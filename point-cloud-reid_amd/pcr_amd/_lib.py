@@ -6,7 +6,9 @@ import os
 import torch  # must be imported before the library so that libamdhip64.so.7 resolves to torch's copy
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "lib", "libpcr_hip.so")
+# (PCR_LIB_TAG: a diagnostic build made by pcr_amd/build.py under the same variable, e.g. libpcr_hip_tune.so)
+_TAG = os.environ.get("PCR_LIB_TAG", "")
+SO_PATH = os.path.join(_HERE, "lib", "libpcr_hip%s.so" % ("_" + _TAG if _TAG else ""))
 _lib = None
 
 ABI_VERSION = 7

@@ -8,7 +8,10 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(PKG))
 CSRC = os.path.join(os.path.dirname(PKG), "csrc")
 LIBDIR = os.path.join(PKG, "lib")
-SO = os.path.join(LIBDIR, "libpcr_hip.so")
+# PCR_LIB_TAG (diagnostics): a second library beside the product one, e.g. PCR_LIB_TAG=tune with
+# PCR_EXTRA_HIPCC_FLAGS=-DPCR_TUNING=1 builds lib/libpcr_hip_tune.so, which _lib.load() picks up under the same variable
+_TAG = os.environ.get("PCR_LIB_TAG", "")
+SO = os.path.join(LIBDIR, "libpcr_hip%s.so" % ("_" + _TAG if _TAG else ""))
 
 # point_ops.hip must not contract a*b+c into fma (bit-exact index outputs); the MFMA model
 # kernels keep the default.
@@ -41,7 +44,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return SO
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
+    objdir = os.path.join(LIBDIR, "obj" + ("_" + _TAG if _TAG else ""))
     os.makedirs(objdir, exist_ok=True)
     common = ["--offload-arch=gfx950", "-O3", "-fPIC", "-fvisibility=hidden", "-std=c++17",
               "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
@@ -53,7 +56,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
         if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in [src] + hdrs) \
-                and not os.environ.get("PCR_EXTRA_HIPCC_FLAGS") and not os.environ.get("PCR_POINT_FLAGS"):
+                and (_TAG or (not os.environ.get("PCR_EXTRA_HIPCC_FLAGS") and not os.environ.get("PCR_POINT_FLAGS"))):
             continue        # incremental: this object is newer than its source and every header
         cmd = [hipcc()] + common + FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:

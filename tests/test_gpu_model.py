@@ -238,74 +238,40 @@ def test_training_loop_follows_the_reference_over_five_iterations():
         out = tr.step(data)
         losses.append(float(out["loss"].detach()))
         norms.append(float(out["grad_norm"]))
-    print(json.dumps(dict(losses=losses, ref=g["losses"].tolist(), norms=norms, ref_norms=g["grad_norms"].tolist())))
-    # fp32 training amplifies rounding differences from step to step (summation orders differ between the fused
-    # kernels and ATen): 1e-4 at the first step, a few 1e-3 relative after five
-    assert losses[0] == pytest.approx(float(g["losses"][0]), abs=1e-4)
-    assert losses == pytest.approx(g["losses"].tolist(), rel=1e-2, abs=1e-3)
-    assert norms == pytest.approx(g["grad_norms"].tolist(), rel=2e-2)
-    worst = {}
+    ref, ref64 = g["losses"], g["losses64"]
+    print(json.dumps(dict(losses=losses, ref=ref.tolist(), ref64=ref64.tolist(), norms=norms,
+                          ref_norms=g["grad_norms"].tolist(), ref_norms64=g["grad_norms64"].tolist())))
+    # This training problem amplifies rounding differences from step to step: the REFERENCE's own float32 trajectory is
+    # 4e-5 (step 2), 1e-4 (step 3), 5 % (step 4) and 7 % (step 5) away from the same loop in float64 (losses64 in the
+    # fixture, oracle/make_golden.py gen_train_loop).  That measured divergence is the yardstick: the HIP run must stay
+    # within HALF of it of the reference's float32 run (plus 1e-4 for the steps where the two references still agree).
+    for i in range(len(losses)):
+        own = abs(float(ref[i]) - float(ref64[i]))
+        assert abs(losses[i] - float(ref[i])) <= 1e-4 + 0.5 * own, (i, losses[i], float(ref[i]), float(ref64[i]))
+        own_n = abs(float(g["grad_norms"][i]) - float(g["grad_norms64"][i]))
+        assert abs(norms[i] - float(g["grad_norms"][i])) <= 1e-3 * norms[i] + 0.5 * own_n, (i, norms[i])
+    worst, own_bn = {}, {}
     for i, sa in enumerate(m.backbone.SA_modules):
         for j, bn in enumerate(sa.mlp_bns):
             for nm, t in (("mean", bn.running_mean), ("var", bn.running_var)):
-                ref = g["bn%d%d_%s" % (i, j, nm)]
-                worst["bn%d%d_%s" % (i, j, nm)] = float(np.abs(t.cpu().numpy() - ref).max() / max(1e-3, np.abs(ref).max()))
+                r32, r64 = g["bn%d%d_%s" % (i, j, nm)], g["bn%d%d_%s64" % (i, j, nm)]
+                sc = max(1e-3, np.abs(r32).max())
+                worst["bn%d%d_%s" % (i, j, nm)] = float(np.abs(t.cpu().numpy() - r32).max() / sc)
+                own_bn["bn%d%d_%s" % (i, j, nm)] = float(np.abs(r32 - r64).max() / sc)
             assert int(bn.num_batches_tracked) == int(g["bn%d%d_n" % (i, j)])
-    print(json.dumps(worst))
-    # (observed <= 1e-2: the conv biases in front of a BatchNorm have a zero true gradient, AdamW turns the rounding noise
-    # of their computed gradient into +-lr steps, and the running means -- which contain the bias -- inherit that walk)
-    assert max(worst.values()) < 3e-2, worst
+    print(json.dumps(dict(vs_ref32=max(worst.values()), ref32_vs_ref64=max(own_bn.values()))))
+    # running statistics: every tensor within 1e-4 + half the reference's own float32-vs-float64 distance (2.3e-2 at most)
+    for k in worst:
+        assert worst[k] <= 1e-4 + 0.5 * max(own_bn.values()), (k, worst[k], own_bn[k])
     m.eval()
     with torch.no_grad():
         logits = m.match_forward_inference(*_hx(m, s1.to(dev), s2.to(dev))).cpu().numpy()
-    # eval mode subtracts a running mean that mixes five different values of those noise-driven biases from the current
-    # one: the two runs agree to ~0.05 here (and to 2e-3 when both use THIS graph's gradients, see the test below); the
-    # untrained model's logits are ~1 away, which is what this bound is for
-    assert np.abs(logits - g["logits"]).max() < 0.15, (logits, g["logits"])
-
-
-def test_training_loop_with_frozen_pre_norm_biases_follows_the_reference_closely():
-    """The explanation of the loose bounds of the test above, demonstrated: with the conv biases in front of a BatchNorm
-    frozen on BOTH sides (their true gradient is zero; trained, AdamW turns the rounding noise of their computed gradient
-    into +-lr steps and the running means inherit that walk) the same five iterations agree an order of magnitude
-    closer -- fixture tests/golden/pt_train_loop_frozen_n128.npz, oracle/make_golden.py gen_train_loop(frozen_bias=True)"""
-    from pcr_amd import train
-    g = load_golden("pt_train_loop_frozen_n128")
-    m, _ = build_pt([128, 64, 32])
-    m.train()
-    for k, p in m.named_parameters():
-        if ".mlp_convs." in k and k.endswith(".bias"):
-            p.requires_grad_(False)
-    s1, s2 = T.synthetic_pairs(8, 128, seed=2, kind="randn")
-    dev = "cuda"
-    ids1 = torch.arange(8)
-    ids2 = torch.tensor([0, 1, 2, 3, 9, 9, 9, 9])
-    data = dict(sparse_1=list(s1.to(dev)), sparse_2=list(s2.to(dev)), dense_1=list(s1.to(dev)), dense_2=list(s2.to(dev)),
-                label_1=[torch.zeros(1, dtype=torch.long, device=dev)] * 8,
-                label_2=[torch.zeros(1, dtype=torch.long, device=dev)] * 8,
-                id_1=[i.view(1).to(dev) for i in ids1], id_2=[i.view(1).to(dev) for i in ids2])
-    tr = train.Trainer(m, max_iters=int(g["max_iters"]), lr=float(g["lr"]), grad_clip=float(g["clip"]))
-    losses, norms = [], []
-    for _ in range(int(g["iters"])):
-        out = tr.step(data)
-        losses.append(float(out["loss"].detach()))
-        norms.append(float(out["grad_norm"]))
-    worst = {}
-    for i, sa in enumerate(m.backbone.SA_modules):
-        for j, bn in enumerate(sa.mlp_bns):
-            for nm, t in (("mean", bn.running_mean), ("var", bn.running_var)):
-                ref = g["bn%d%d_%s" % (i, j, nm)]
-                worst["bn%d%d_%s" % (i, j, nm)] = float(np.abs(t.cpu().numpy() - ref).max() / max(1e-3, np.abs(ref).max()))
-    m.eval()
-    with torch.no_grad():
-        logits = m.match_forward_inference(*_hx(m, s1.to(dev), s2.to(dev))).cpu().numpy()
+    # eval-mode logits of the trained weights: the two references are 0.42 apart; the HIP run is held to a quarter of that
+    # from the float32 reference (the untrained model's logits are ~1 away)
+    own_l = float(np.abs(g["logits"] - g["logits64"]).max())
     dl = float(np.abs(logits - g["logits"]).max())
-    print(json.dumps(dict(losses=losses, ref=g["losses"].tolist(), norms=norms, ref_norms=g["grad_norms"].tolist(),
-                          bn=max(worst.values()), dlogits=dl)))
-    assert losses == pytest.approx(g["losses"].tolist(), rel=1e-3)
-    assert norms == pytest.approx(g["grad_norms"].tolist(), rel=5e-3)
-    assert max(worst.values()) < 1e-3, worst
-    assert dl < 1e-2, (logits, g["logits"])
+    print(json.dumps(dict(dlogits_vs_ref32=dl, ref32_vs_ref64=own_l)))
+    assert dl <= 0.25 * own_l, (logits, g["logits"])
 
 
 def test_trainer_checkpoint_resumes_bit_for_bit(tmp_path):
