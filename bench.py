@@ -224,9 +224,11 @@ def train_bench(args, desc, n, bl, pairs, rank, world, steps=None, warmup=None):
                 label_1=[zero] * pairs, label_2=[zero] * pairs,
                 id_1=[i.view(1).to(dev) for i in ids1], id_2=[i.view(1).to(dev) for i in ids2])
     tr = train.Trainer(model, max_iters=steps + warmup + 3, lr=3e-4, grad_clip=1.0)
+    prewarm()
     dt, out = shard.timed(lambda: tr.step(data)["loss"].detach(), steps, warmup,
                           sync=torch.cuda.synchronize, device="cuda")
     assert torch.isfinite(out).all()
+    per_rank = [t / steps * 1e3 for t in shard.LAST_RANK_SECONDS]
     # per-launch device times of one more step (events on the launch stream): the dominant TRAINING launch.  EVERY rank
     # runs that step (it contains the gradient all-reduce: rank 0 alone would wait for the others forever); only rank
     # 0 records it
@@ -268,7 +270,8 @@ def train_bench(args, desc, n, bl, pairs, rank, world, steps=None, warmup=None):
         line = {
             "metric": "siamese training pairs/sec @%d pts" % n, "value": world * pairs * steps / dt,
             "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / steps * 1e3, "per_rank_ms_per_step": per_rank, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (randn clouds, seeded random-init weights)",
             "config": {"workload": "pt128_train: %s" % desc, "pairs_per_gpu_per_step": pairs, "points": n,
                        "backbone_list": bl, "parallelism": "data parallel x%d, one %d-byte gradient bucket per step"
@@ -300,6 +303,24 @@ def clock_probe(iters=20000):
     by_counter = t[:, 0] / wall_s / 1e9
     return dict(clock_ghz=float(by_mfma.median()), shader_counter_ghz=float(by_counter.median()),
                 wall_clock_khz=khz)
+
+
+_PREWARMED = False
+
+
+def prewarm(seconds=0.25):
+    """A freshly leased GPU runs its first ~150 ms at a fraction of its clock (measured: the first 20 steps of a cold
+    process took 2.2x the time of the same steps after 50 warm-up steps, pt128).  Before the W warm-up steps of the
+    contract the device therefore spins on the clock-probe kernel (all CUs, no workload data touched) for about
+    `seconds`; the W warm-up steps and the K timed steps are unchanged."""
+    global _PREWARMED
+    if _PREWARMED:
+        return
+    _PREWARMED = True
+    t0 = time.time()
+    while time.time() - t0 < seconds:
+        if clock_probe(iters=20000) is None:
+            break
 
 
 def ssg_fill(model, s1):
@@ -408,10 +429,12 @@ def measure(workload, args, rank, world, pairs=None, cloud_kind=None, skip_repea
     cloud_kind = cloud_kind or ("box" if kind == "ssg" else "randn")   # ball-query radii are metric: box crops
     s1, s2 = T.synthetic_pairs(pairs, n, seed=1234 + rank, kind=cloud_kind)
     s1, s2 = s1.cuda(), s2.cuda()
+    prewarm()
     with torch.no_grad():
         dt, out = shard.timed(lambda: hot_path(model, s1, s2), steps, warmup,
                               sync=torch.cuda.synchronize, device="cuda")
     assert torch.isfinite(out).all()
+    per_rank = [t / steps * 1e3 for t in shard.LAST_RANK_SECONDS]      # every rank's own time (the max is ms_per_step)
     rec = None
     if rank == 0:
         clk = clock_probe()
@@ -420,7 +443,7 @@ def measure(workload, args, rank, world, pairs=None, cloud_kind=None, skip_repea
         with torch.no_grad(), engine.precision("f32"):
             ref = hot_path(model, s1, s2)
         rec = dict(value=world * pairs * steps / dt, unit="pairs/s", steps=steps, warmup=warmup,
-                   ms_per_step=dt / steps * 1e3, dtype=PREC_INFO[engine.PRECISION][0],
+                   ms_per_step=dt / steps * 1e3, per_rank_ms_per_step=per_rank, dtype=PREC_INFO[engine.PRECISION][0],
                    max_abs_dlogit_vs_f32_path=float((out - ref).abs().max()),
                    data="synthetic (%s clouds, seeded random-init weights with non-trivial BN statistics)" % cloud_kind,
                    config={"workload": "%s: %s" % (workload, desc), "pairs_per_gpu_per_step": pairs, "points": n,
@@ -463,6 +486,7 @@ def gallery_bench(args, desc, n, bl, pairs, rank, world, steps=None, warmup=None
     def step():
         xyz, h = model.forward_inference(clouds)
         return model.match_gallery(h, xyz, combos)
+    prewarm()
     with torch.no_grad():
         dt, out = shard.timed(step, steps, warmup, sync=torch.cuda.synchronize, device="cuda")
     assert torch.isfinite(out).all() and out.numel() == P
@@ -652,7 +676,8 @@ def main():
         line = {
             "metric": "siamese pair-comparisons/sec @%d pts" % n,
             "value": rec["value"], "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": rec["ms_per_step"], "per_rank_ms_per_step": rec["per_rank_ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": rec["dtype"], "max_abs_dlogit_vs_f32_path": rec["max_abs_dlogit_vs_f32_path"],
             "data": rec["data"], "config": rec["config"], "roofline": rec["roofline"],
         }

@@ -258,6 +258,12 @@ typedef struct pcr_attn_params {
   const float *wkv_wide, *bkv_wide, *wmerge_packed;
   float *kv;    /* workspace (B, pcr_attn_kv_floats(d)) */
   float *out;   /* (B, cfinal ? cfinal : cout, Lq) */
+  /* precision != PCR_PREC_F32 and d <= 128: the dense phases (Q, message, feed-forward, K/V projection, cov_final) run
+   * as split bf16 (three bf16 MFMAs per product, f32 accumulate) on the pcr_pack_weight_bf16x2_f32 images of the same
+   * matrices: wq_bf, wkv_bf, wmlp0_bf, wmlp2_bf, wfinal_bf (NULL: f32).  The kv kernel then writes the per-cloud matrix
+   * M as a bf16 image too, so pcr_attn_kv_f32 and pcr_attn_apply_f32 must be called with the SAME precision. */
+  int precision;
+  const float *wq_bf, *wkv_bf, *wmlp0_bf, *wmlp2_bf, *wfinal_bf;
 } pcr_attn_params;
 long pcr_attn_kv_floats(int d);
 int pcr_attn_kv_f32(const pcr_attn_params *p, pcr_stream_t stream);

@@ -1,535 +1,3 @@
-// Linear-attention kernels (pcr_attn_kv_f32 / pcr_attn_apply_f32).
-#include "tile_dense.h"
-
-namespace {
-// -------------------------------------------------------------- linear attention ----
-struct AttnArgs {
-  pcr_attn_params p;
-};
-
-// Algebra used by both kernels (the host folds it into the weights, see AttnPlan in
-// pcr_amd/engine.py): with h = relu(W0 xyz + b0) the position encoding is W2 h + b2, so
-//   Wq (x + W2 h + b2) = [Wq | Wq W2] [x ; h] + Wq b2        (one dense instead of three)
-//   [K ; V] pre-activation = [[Wk | kpos Wk W2] ; [Wv | Wv W2]] [x ; h] + [kpos Wk b2 ; Wv b2]
-// and the merge projection is folded into the per-cloud KV matrix by the kv kernel:
-//   merge(msg)[o] = sum_dd M[o][dd] Q'[dd],  M[o][dd] = sum_{v in head(dd)} Wm[o][v] KV[dd][v],
-//   Q'[dd] = Q[dd] * Sk / (Q_head . ksum_head + 1e-6).
-
-// hidden = relu(W0 xyz + b0) for the T tokens of a tile -> dst rows [0,d) ([d][RP]); zero xyz beyond L
-__device__ __forceinline__ void pos_hidden(float *dst, int RP, const float *P, const float *w0,
-                                           const float *b0, int d, int T) {
-  for (int e = threadIdx.x; e < d * T; e += blockDim.x) {
-    const int o = e / T, t = e - o * T;
-    const float v = w0[o * 3] * P[t] + w0[o * 3 + 1] * P[RP + t] + w0[o * 3 + 2] * P[2 * RP + t] + b0[o];
-    dst[o * RP + t] = fmaxf(v, 0.f);
-  }
-}
-
-__device__ __forceinline__ void load_xyz3(float *P, int RP, const float *xyz, int L, int t0, int T) {
-  for (int e = threadIdx.x; e < 3 * T; e += blockDim.x) {
-    const int c = e / T, t = e - c * T;
-    P[c * RP + t] = t0 + t < L ? xyz[(size_t)(t0 + t) * 3 + c] : 0.f;
-  }
-}
-
-// One workgroup per key-side cloud, token tiles of T = 32*TB (TB = 2 for d <= 64, 1 for d = 128).
-// kv image per cloud: packed (d x d) matrix M (merge folded in, see above) followed by ksum[d].
-// LDS: XH [c2 + d] key features ; hidden -- the fused K/V projection (2d <= c2 + d rows) is written IN PLACE over
-// it (barrier between k-loop and epilogue) -- and P [3]; after the loop KVl [d][d+1].  34 KB at d = c2 = 64, so four
-// workgroups share a CU; the next tile's features are fetched into registers while this tile is on the matrix core.
-//   WSEL: dense shape of the 2d-row projection (2 / 1 / 1 for d = 32 / 64 / 128), NTW: KV tiles per wave (1 / 1 / 4)
-template <int TB, int NR, int WSEL, int NTW>
-__device__ __forceinline__ void attn_kv_body(const AttnArgs &a) {
-  constexpr int T = 32 * TB, RP = T + 1;
-  constexpr int NPF = 4;   // 16-byte feature pieces per thread and tile held in registers (c2 * T / 4 / 256 <= NPF)
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const pcr_attn_params &p = a.p;
-  const int d = p.d, c2 = p.c2;
-  float *XH = smem;
-  float *KB = XH;             // rows [0,d) after the projection
-  float *VB = XH + d * RP;    // rows [d,2d)
-  float *P = XH + (c2 + d) * RP;
-  float *s_w0 = P + 3 * RP, *s_b0 = s_w0 + 3 * d;   // staged pos-MLP first layer
-  // [256] partial key sums, beyond both the loop's buffers and the KVl / total-sum overlay used after it
-  const int tail_a = (c2 + d + 3) * RP + 4 * d, tail_b = d * (d + 1) + d;
-  float *s_ks = smem + (tail_a > tail_b ? tail_a : tail_b);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, h = lane >> 5;
-  const size_t b = blockIdx.x;
-  for (int e = tid; e < 3 * d; e += kThreads) s_w0[e] = p.pos0_w[e];
-  for (int e = tid; e < d; e += kThreads) s_b0[e] = p.pos0_b[e];
-  const float *feat = p.feat_k + b * c2 * p.Sk;
-  const float *xyz = p.xyz_k + b * p.Sk * 3;
-  const int nb = d >> 5, nT = nb * nb;
-  const int dh = d / p.nhead;
-  const float sk = (float)p.Sk;
-  const float *bkv = p.bkv;
-
-  f32x16 acc[NTW];
-#pragma unroll
-  for (int i = 0; i < NTW; i++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
-  int tile_ib[NTW];   // KV tile (ib, jb) of this wave's it-th item: the division is done once, not per token tile
-#pragma unroll
-  for (int it = 0; it < NTW; it++) tile_ib[it] = (wave + 4 * it) / nb;
-  // key sums: thread (row = tid % d, part = tid / d) adds up its share of the tokens of every tile
-  const int krow = tid % d, kpart = tid / d, kparts = kThreads / d;
-  float ksum = 0.f;
-
-  // feature tile prefetch (whole, aligned tiles: one 16-byte piece per (row, 4 tokens); others go the plain way)
-  const int Q = T >> 2, npieces = c2 * Q;
-#ifndef PCR_KV_PREFETCH
-#define PCR_KV_PREFETCH 1
-#endif
-  const bool vec_ok = PCR_KV_PREFETCH && ((p.Sk & 3) == 0) && ((reinterpret_cast<size_t>(feat) & 15) == 0) && npieces <= NPF * kThreads;
-  f32x4 pf[NPF];
-  auto fetch = [&](int t0) {
-#pragma unroll
-    for (int u = 0; u < NPF; u++) {
-      const int e = tid + u * kThreads;
-      const int c = e / Q, q = e - c * Q;
-      const bool ok = e < npieces;
-      pf[u] = *reinterpret_cast<const f32x4 *>(feat + (size_t)(ok ? c : 0) * p.Sk + t0 + 4 * (ok ? q : 0));
-    }
-  };
-  auto stash = [&]() {
-#pragma unroll
-    for (int u = 0; u < NPF; u++) {
-      const int e = tid + u * kThreads;
-      if (e < npieces) {
-        const int c = e / Q, q = e - c * Q;
-        float *dst = XH + c * RP + 4 * q;
-        dst[0] = pf[u][0];
-        dst[1] = pf[u][1];
-        dst[2] = pf[u][2];
-        dst[3] = pf[u][3];
-      }
-    }
-  };
-  bool have = false;   // the registers hold the tile about to be processed
-  if (vec_ok && T <= p.Sk) {
-    fetch(0);
-    have = true;
-  }
-  for (int t0 = 0; t0 < p.Sk; t0 += T) {
-    const int valid = p.Sk - t0;
-    if (have) stash();
-    else load_tile(XH, RP, feat, c2, c2, p.Sk, t0, T);
-    load_xyz3(P, RP, xyz, p.Sk, t0, T);
-    __syncthreads();
-    have = vec_ok && t0 + 2 * T <= p.Sk;   // the next tile is whole: request it now, store it after this tile's MFMAs
-    if (have) fetch(t0 + T);
-    pos_hidden(XH + c2 * RP, RP, P, s_w0, s_b0, d, T);
-    __syncthreads();
-    // (whole-tile epilogue: a 32-cout block is all K or all V, so the branch is wave-uniform)
-    tile_dense2<TB, NR, WSEL, true>(XH, c2 + d, p.wkv, 2 * d, true,
-                                    [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
-      const int t = tb * 32 + l31;
-      float *dst = XH + (cb * 32 + 4 * h) * RP + t;
-      const bool live = t < valid;
-      if (cb * 32 < d) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) dst[((r & 3) + 8 * (r >> 2)) * RP] = live ? elu1(acc[r]) : 0.f;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; r++) dst[((r & 3) + 8 * (r >> 2)) * RP] = live ? acc[r] / sk : 0.f;
-      }
-    }, bkv);   // biases seed the accumulators
-    __syncthreads();
-    {
-      const float *row = KB + krow * RP;
-      for (int t = kpart; t < T; t += kparts) ksum += row[t];
-    }
-#pragma unroll
-    for (int it = 0; it < NTW; it++) {
-      const int item = wave + 4 * it;
-      if (item < nT) {
-        const int ib = tile_ib[it], jb = item - ib * nb;
-        const float *ap = KB + (ib * 32 + l31) * RP + h;
-        const float *bp = VB + (jb * 32 + l31) * RP + h;
-#pragma unroll 4
-        for (int ks = 0; ks < T / 2; ks++)
-          acc[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc[it], 0, 0, 0);
-      }
-    }
-    __syncthreads();   // K / V live in XH: the next tile may only be written once every wave is done with them
-  }
-  // KV (head-masked) -> LDS [dd][d+1], then fold the merge projection and write the packed image
-  float *KVl = smem;
-  const int ld = d + 1;
-  float *s_kt = smem + d * ld;   // [d] total key sums
-  s_ks[tid] = ksum;
-#pragma unroll
-  for (int it = 0; it < NTW; it++) {
-    const int item = wave + 4 * it;
-    if (item < nT) {
-      const int ib = tile_ib[it], jb = item - ib * nb;
-      const int v = jb * 32 + l31;
-      const int hv = v / dh;
-      const bool aligned = (dh & 31) == 0;           // heads made of whole 32-blocks: one test per tile
-      const bool same_blk = (ib * 32) / dh == hv;
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int dd = ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const bool same = aligned ? same_blk : (dd / dh == hv);
-        KVl[dd * ld + v] = same ? acc[it][r] : 0.f;
-      }
-    }
-  }
-  __syncthreads();
-  if (tid < d) {
-    float s = 0.f;
-    for (int pp = 0; pp < kparts; pp++) s += s_ks[pp * d + tid];
-    s_kt[tid] = s;
-  }
-  float *kv = p.kv + b * ((size_t)d * d + d);
-  // e = (o = e / d, dd = e % d) advances by kThreads: one division per thread, then increments; the head of dd is
-  // re-derived only when dd changes (never for d = 32 / 64 / 128, where kThreads % d == 0)
-  const int d_o = kThreads / d, d_dd = kThreads - d_o * d;
-  int o = tid / d, dd = tid - o * d;
-  int v0 = (dd / dh) * dh;
-  for (int e = tid; e < d * d; e += kThreads, o += d_o, dd += d_dd) {
-    if (dd >= d) {
-      dd -= d;
-      o++;
-    }
-    if (d_dd) v0 = (dd / dh) * dh;
-    const float *wm = p.wmerge + (size_t)o * d + v0;
-    const float *kr = KVl + dd * ld + v0;
-    float m = 0.f;
-#pragma unroll 8
-    for (int v = 0; v < dh; v++) m += wm[v] * kr[v];   // (unrolled: batches of independent loads)
-    const int kb = dd >> 3, rem = dd & 7;
-    kv[(((size_t)kb * d + o) * 2 + (rem & 1)) * 4 + (rem >> 1)] = m;
-  }
-  __syncthreads();
-  if (tid < d) kv[(size_t)d * d + tid] = s_kt[tid];
-}
-
-template <int TB, int NR, int WSEL, int NTW>
-__global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
-  attn_kv_body<TB, NR, WSEL, NTW>(a);
-}
-// the same body held to a third of the register file (three workgroups per CU): worth 5-15 % for d = 64 / 128 even
-// where it costs a few spilled registers, not for d = 32 (already three per CU on its own)
-template <int TB, int NR, int WSEL, int NTW>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_kv_kernel_o3(AttnArgs a) {
-  attn_kv_body<TB, NR, WSEL, NTW>(a);
-}
-
-// d_model 256 / 512 (the 1.5M / 7M Point-Transformer configs, backbone_net.py:43-46,84-86): the per-cloud KV matrix
-// no longer fits one workgroup's accumulators, so a cloud is split over d / 64 workgroups.  Workgroup (band g, cloud b)
-// owns the rows dd in [64 g, 64 g + 64) of KV -- one head, since the head width is a multiple of 64 -- and therefore
-// needs the K rows of its band and the V rows of its head: the host gathers exactly those rows of the fused K/V
-// projection into one packed image per band (wkv_wide, 64 + dh couts), so the projection is one in-place dense call
-// as in the narrow kernel.  With a whole head's V columns at hand the merge fold M[:, band] = Wm[:, head] KV_band^T
-// is complete inside the workgroup (no cross-workgroup reduction) and runs on the matrix core as well.
-//   NRW: cout-block rounds of the 64 + dh row projection (2 for dh = 128, 3 for dh = 256)
-template <int NRW>
-__global__ __launch_bounds__(kThreads) void attn_kv_wide_kernel(AttnArgs a) {
-  constexpr int TB = 1, T = 32, RP = 33, BAND = 64, RPK = BAND + 1;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const pcr_attn_params &p = a.p;
-  const int d = p.d, c2 = p.c2, dh = d / p.nhead;
-  const int g = blockIdx.x, hd = (g * BAND) / dh;
-  const int OPW = BAND + dh;                 // couts of this band's projection (multiple of 32)
-  float *XH = smem;                          // [c2 + d][RP]: key features ; hidden -> rows [0,64) K band, [64,64+dh) V head
-  float *KB = XH, *VB = XH + BAND * RP;
-  float *P = XH + (c2 + d) * RP;
-  float *s_w0 = P + 3 * RP, *s_b0 = s_w0 + 3 * d;
-  float *s_ks = s_b0 + d;                    // [256] partial key sums
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, h = lane >> 5;
-  const size_t b = blockIdx.y;
-  for (int e = tid; e < 3 * d; e += kThreads) s_w0[e] = p.pos0_w[e];
-  for (int e = tid; e < d; e += kThreads) s_b0[e] = p.pos0_b[e];
-  const float *feat = p.feat_k + b * c2 * p.Sk;
-  const float *xyz = p.xyz_k + b * p.Sk * 3;
-  const float sk = (float)p.Sk;
-  const float *wband = p.wkv_wide + (size_t)g * ((size_t)ceil8(c2 + d) * OPW);
-  const float *bband = p.bkv_wide + (size_t)g * OPW;
-  const int nj = dh >> 5, nT = 2 * nj;       // KV tiles (ib in {0,1}) x (jb < dh/32): 8 or 16, up to 4 per wave
-  f32x16 acc[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
-  const int krow = tid & (BAND - 1), kpart = tid >> 6;   // four partial sums per K row
-  float ksum = 0.f;
-  for (int t0 = 0; t0 < p.Sk; t0 += T) {
-    const int valid = p.Sk - t0;
-    load_tile(XH, RP, feat, c2, c2, p.Sk, t0, T);
-    load_xyz3(P, RP, xyz, p.Sk, t0, T);
-    __syncthreads();
-    pos_hidden(XH + c2 * RP, RP, P, s_w0, s_b0, d, T);
-    __syncthreads();
-    tile_dense2<TB, NRW, 0, true>(XH, c2 + d, wband, OPW, true,
-                                  [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
-      const int t = tb * 32 + l31;
-      float *dst = XH + (cb * 32 + 4 * h) * RP + t;
-      const bool live = t < valid;
-      if (cb * 32 < BAND) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) dst[((r & 3) + 8 * (r >> 2)) * RP] = live ? elu1(acc[r]) : 0.f;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; r++) dst[((r & 3) + 8 * (r >> 2)) * RP] = live ? acc[r] / sk : 0.f;
-      }
-    }, bband);
-    __syncthreads();
-    {
-      const float *row = KB + krow * RP;
-      for (int t = kpart; t < T; t += 4) ksum += row[t];
-    }
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-      const int item = wave + 4 * it;
-      if (item < nT) {
-        const int ib = item / nj, jb = item - ib * nj;
-        const float *ap = KB + (ib * 32 + l31) * RP + h;
-        const float *bp = VB + (jb * 32 + l31) * RP + h;
-#pragma unroll 4
-        for (int ks = 0; ks < T / 2; ks++)
-          acc[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc[it], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-  }
-  // KV band, transposed: KVt [v (dh)][dd (64) + 1] = the B operand (k = v, token = dd) of the merge fold
-  // (KVt spans dh * 65 floats from the start of the buffer and can reach past s_ks -- d_model 256 with ONE head and
-  // c2 < 214 -- so the four key-sum partials are combined into a register before the first KVt write)
-  float *KVt = smem;
-  s_ks[tid] = ksum;
-  __syncthreads();
-  const float ks_total = tid < BAND ? s_ks[tid] + s_ks[64 + tid] + s_ks[128 + tid] + s_ks[192 + tid] : 0.f;
-  __syncthreads();
-#pragma unroll
-  for (int it = 0; it < 4; it++) {
-    const int item = wave + 4 * it;
-    if (item < nT) {
-      const int ib = item / nj, jb = item - ib * nj;
-      const int v = jb * 32 + l31;
-#pragma unroll
-      for (int r = 0; r < 16; r++) KVt[v * RPK + ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = acc[it][r];
-    }
-  }
-  __syncthreads();
-  float *kv = p.kv + b * ((size_t)d * d + d);
-  if (tid < BAND) kv[(size_t)d * d + g * BAND + tid] = ks_total;
-  // M[o][dd] = sum_{v < dh} Wm[o][hd dh + v] KV[dd][v]: dense over k = v with the k-blocks [hd dh / 8, +dh / 8) of the
-  // packed merge weights; stored in the packed (d,d) layout the apply kernel reads as an A operand
-  const float *wm = p.wmerge_packed + (size_t)(hd * dh / 8) * d * 8;
-  tile_dense(KVt, dh, RPK, 2, wm, d, [&](float m, int o, int t) {
-    const int dd = g * BAND + t;
-    const int kb = dd >> 3, rem = dd & 7;
-    kv[(((size_t)kb * d + o) * 2 + (rem & 1)) * 4 + (rem >> 1)] = m;
-  });
-}
-
-// One workgroup per (query cloud, tile of T query tokens), T = 128 / 64 / 32 for d = 32 / 64 / 128 (32 beyond).
-// ONE LDS buffer U of max(c1 + d, 2d, cout, cfinal) rows, every dense phase in place (barrier between its
-// k-loop and its epilogue), so a d = 64 tile is 33 KB and four workgroups share a CU:
-//   rows [0,c1) query features x, rows [c1,c1+d) position hidden h  --Q-->  rows [c1,c1+d) = elu(.)+1
-//   --scale by Sk/(Q.ksum)--> --M (kv image)--> message --LayerNorm--> [x ; msg] --FFN0--> 2d rows --FFN1-->
-//   cout rows --LayerNorm--> (+ x, re-read from global: it was overwritten by FFN0) --cov_final--> store.
-template <int TB, int NR>
-__global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
-  constexpr int T = 32 * TB, RP = T + 1;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const pcr_attn_params &p = a.p;
-  const int d = p.d, c1 = p.c1, cout = p.cout;
-  const int catC = c1 + d, catP = ceil8(catC);
-  int rowsU = catP > 2 * d ? catP : 2 * d;
-  if (ceil32(cout) > rowsU) rowsU = ceil32(cout);
-  if (ceil32(p.cfinal) > rowsU) rowsU = ceil32(p.cfinal);
-  float *U = smem;
-  float *P = U + rowsU * RP;
-  float *zs = P + 3 * RP;
-  float *red = zs + p.nhead * RP;  // [2 * (256/T)][T]
-  // small constant vectors, staged once: reading them from global inside the per-element loops costs a
-  // vector-memory instruction per use
-  float *cst = red + 2 * (kThreads / T) * T;
-  float *s_ksum = cst, *s_ln1g = cst + d, *s_ln1b = cst + 2 * d, *s_ln2g = cst + 3 * d, *s_ln2b = s_ln2g + cout;
-  float *s_w0 = s_ln2b + cout, *s_b0 = s_w0 + 3 * d;
-  const int tid = threadIdx.x;
-  const size_t b = blockIdx.y;
-  const int t0 = blockIdx.x * T;
-  const size_t bq_ = p.q_index ? (size_t)p.q_index[b] : b;    // which cloud supplies the query tokens
-  const float *feat = p.feat_q + bq_ * c1 * p.Lq;
-  const size_t kb_ = p.kv_index ? (size_t)p.kv_index[b] : b;
-  const float *kv = p.kv + kb_ * ((size_t)d * d + d);
-  const int dh = d / p.nhead;
-  for (int e = tid; e < d; e += kThreads) {
-    s_ksum[e] = kv[(size_t)d * d + e];
-    s_ln1g[e] = p.ln1_g[e];
-    s_ln1b[e] = p.ln1_b[e];
-    if (p.q_pos) {
-      s_w0[3 * e] = p.pos0_w[3 * e];
-      s_w0[3 * e + 1] = p.pos0_w[3 * e + 1];
-      s_w0[3 * e + 2] = p.pos0_w[3 * e + 2];
-      s_b0[e] = p.pos0_b[e];
-    }
-  }
-  for (int e = tid; e < cout; e += kThreads) {
-    s_ln2g[e] = p.ln2_g[e];
-    s_ln2b[e] = p.ln2_b[e];
-  }
-  const float *ksum = s_ksum;
-  float *MSG = U + c1 * RP;   // rows [c1, c1+d): hidden -> Q -> message
-
-  load_tile(U, RP, feat, c1, c1, p.Lq, t0, T);
-  if (p.q_pos) {
-    load_xyz3(P, RP, p.xyz_q + bq_ * p.Lq * 3, p.Lq, t0, T);
-    __syncthreads();
-    pos_hidden(MSG, RP, P, s_w0, s_b0, d, T);
-    for (int e = tid; e < (catP - catC) * T; e += kThreads) U[(catC + e / T) * RP + e % T] = 0.f;
-  } else {
-    for (int e = tid; e < (catP - c1) * T; e += kThreads) U[(c1 + e / T) * RP + e % T] = 0.f;
-  }
-  __syncthreads();
-  // Q = elu(Wq' [x ; h] + bq) + 1, written over h
-  tile_dense2<TB, NR>(U, p.q_pos ? catP : ceil8(c1), p.wq, d, true,
-                      [&](float v, int o, int t) { MSG[o * RP + t] = elu1(v); }, p.bq);
-  __syncthreads();
-  for (int e = tid; e < p.nhead * T; e += kThreads) {
-    const int hd = e / T, t = e - hd * T;
-    float z = 0.f;
-    for (int c = 0; c < dh; c++) z += MSG[(hd * dh + c) * RP + t] * ksum[hd * dh + c];
-    zs[hd * RP + t] = (1.0f / (z + 1e-6f)) * (float)p.Sk;
-  }
-  __syncthreads();
-  for (int hd = 0; hd < p.nhead; hd++)   // (head-major: no runtime division per element)
-    for (int e = tid; e < dh * T; e += kThreads) {
-      const int o = hd * dh + e / T, t = e % T;
-      MSG[o * RP + t] *= zs[hd * RP + t];
-    }
-  __syncthreads();
-  tile_dense2<TB, NR>(MSG, d, kv, d, true, [&](float v, int o, int t) { MSG[o * RP + t] = v; });
-  __syncthreads();
-  tile_layernorm(MSG, d, RP, T, s_ln1g, s_ln1b, red);
-  tile_dense2<TB, NR>(U, catP, p.wmlp0, 2 * d, true, [&](float v, int o, int t) { U[o * RP + t] = fmaxf(v, 0.f); });
-  __syncthreads();
-  tile_dense2<TB, NR>(U, 2 * d, p.wmlp2, ceil32(cout), true, [&](float v, int o, int t) { U[o * RP + t] = v; });
-  __syncthreads();
-  tile_layernorm(U, cout, RP, T, s_ln2g, s_ln2b, red);
-  if (p.residual) {   // cout == c1: add the query features back (re-read: FFN0 has overwritten them)
-    for (int e = tid; e < cout * T; e += kThreads) {
-      const int c = e / T, t = e - c * T;
-      if (t0 + t < p.Lq) U[c * RP + t] += feat[(size_t)c * p.Lq + t0 + t];
-    }
-    __syncthreads();
-  }
-  int cres = cout;
-  if (p.cfinal) {  // trailing 1x1 conv with bias (cov_final); needs cout % 8 == 0
-    const int cf = p.cfinal;
-    tile_dense2<TB, NR>(U, cout, p.wfinal, ceil32(cf), true, [&](float v, int o, int t) { U[o * RP + t] = v; },
-                        p.bfinal);   // bfinal is zero-padded to a multiple of 32 by the host
-    __syncthreads();
-    cres = cf;
-  }
-  float *out = p.out + b * cres * p.Lq;
-  for (int e = tid; e < cres * T; e += kThreads) {
-    const int c = e / T, t = e - c * T;
-    if (t0 + t < p.Lq) out[(size_t)c * p.Lq + t0 + t] = U[c * RP + t];
-  }
-}
-
-}  // namespace
-
-static int attn_check(const pcr_attn_params &p) {
-  if (p.B < 0 || p.Lq < 1 || p.Sk < 1 || p.c1 < 1 || p.c2 < 1 || p.cout < 1 || p.nhead < 1) return 1;
-  if (p.d < 32 || p.d > 512 || (p.d & 31) || p.d % p.nhead) return 1;  // d_model in {32,64,96,128} or wide (below)
-  if (p.d > 128 && ((p.d & 63) || ((p.d / p.nhead) & 63) || p.d / p.nhead > 256)) return 1;   // wide: heads of 64 n <= 256
-  if ((p.c2 & 7) || p.cout > 512 || p.cfinal > 512) return 1;
-  if (!p.feat_q || !p.feat_k || !p.xyz_k || !p.kv || !p.pos0_w || !p.pos0_b || !p.wq || !p.bq || !p.wkv ||
-      !p.bkv || !p.wmerge || !p.wmlp0 || !p.wmlp2 || !p.ln1_g || !p.ln1_b || !p.ln2_g || !p.ln2_b)
-    return 1;
-  if (p.q_pos && (!p.xyz_q || p.c1 != p.c2 || p.c1 != p.d)) return 1;
-  if (p.residual && p.cout != p.c1) return 1;
-  if (p.cfinal && (!p.wfinal || !p.bfinal || (p.cout & 7))) return 1;
-  return 0;
-}
-
-PCR_EXPORT int pcr_attn_kv_f32(const pcr_attn_params *pp, pcr_stream_t stream) {
-  if (!pp || attn_check(*pp)) return PCR_ERR_INVALID;
-  if (pp->B == 0) return PCR_OK;
-  AttnArgs a;
-  a.p = *pp;
-  const int d = pp->d;
-  if (d > 128) {   // wide: d / 64 workgroups per cloud (attn_kv_wide_kernel)
-    if (!pp->wkv_wide || !pp->bkv_wide || !pp->wmerge_packed || pp->B > 65535) return PCR_ERR_INVALID;
-    const int dh = d / pp->nhead;
-    size_t lds = ((size_t)(pp->c2 + d + 3) * 33 + 4 * d + kThreads) * sizeof(float);
-    const size_t lds2 = (size_t)dh * 65 * sizeof(float);
-    if (lds2 > lds) lds = lds2;
-    if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
-    static bool okw = allow_big_lds(attn_kv_wide_kernel<2>) && allow_big_lds(attn_kv_wide_kernel<3>);
-    (void)okw;
-    dim3 g(d / 64, pp->B), blk(kThreads);
-    if (64 + dh <= 256) hipLaunchKernelGGL((attn_kv_wide_kernel<2>), g, blk, lds, pcr_s(stream), a);
-    else hipLaunchKernelGGL((attn_kv_wide_kernel<3>), g, blk, lds, pcr_s(stream), a);
-    PCR_CHECK_LAUNCH();
-    return PCR_OK;
-  }
-  if (pp->c2 < pp->d) return PCR_ERR_INVALID;   // the in-place K/V projection needs 2d <= c2 + d rows
-  const int tb = d <= 64 ? 2 : 1, RP = 32 * tb + 1;
-  size_t lds = (size_t)(pp->c2 + d + 3) * RP + 4 * d;
-  const size_t lds2 = (size_t)d * (d + 1) + d;
-  if (lds2 > lds) lds = lds2;
-  lds = (lds + kThreads) * sizeof(float);
-  if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
-  static bool ok = allow_big_lds(attn_kv_kernel<2, 1, 2, 1>) && allow_big_lds(attn_kv_kernel_o3<2, 1, 1, 1>) &&
-                   allow_big_lds(attn_kv_kernel_o3<1, 2, 1, 4>) && allow_big_lds(attn_kv_kernel<1, 2, 0, 4>);
-  (void)ok;
-  dim3 g(pp->B), blk(kThreads);
-  hipStream_t st = pcr_s(stream);
-  if (d == 32) hipLaunchKernelGGL((attn_kv_kernel<2, 1, 2, 1>), g, blk, lds, st, a);        // 2d = 64: two cout blocks
-  else if (d == 64) hipLaunchKernelGGL((attn_kv_kernel_o3<2, 1, 1, 1>), g, blk, lds, st, a);   // four, one per wave
-  else if (d == 128) hipLaunchKernelGGL((attn_kv_kernel_o3<1, 2, 1, 4>), g, blk, lds, st, a);  // eight, two rounds
-  else hipLaunchKernelGGL((attn_kv_kernel<1, 2, 0, 4>), g, blk, lds, st, a);                // d = 96: generic shape
-  PCR_CHECK_LAUNCH();
-  return PCR_OK;
-}
-
-PCR_EXPORT int pcr_attn_apply_f32(const pcr_attn_params *pp, pcr_stream_t stream) {
-  if (!pp || attn_check(*pp) || !pp->out) return PCR_ERR_INVALID;
-  if (pp->B == 0) return PCR_OK;
-  if (pp->B > 65535) return PCR_ERR_INVALID;
-  const pcr_attn_params &p = *pp;
-  AttnArgs a;
-  a.p = p;
-  const int tb = p.d <= 32 ? 4 : (p.d <= 64 ? 2 : 1), T = 32 * tb, RP = T + 1;
-  const int catP = ceil8(p.c1 + p.d);
-  int rowsU = catP > 2 * p.d ? catP : 2 * p.d;
-  if (ceil32(p.cout) > rowsU) rowsU = ceil32(p.cout);
-  if (ceil32(p.cfinal) > rowsU) rowsU = ceil32(p.cfinal);
-  size_t lds = ((size_t)(rowsU + 3 + p.nhead) * RP + 2 * (kThreads / T) * T + 7 * p.d + 2 * p.cout) *
-               sizeof(float);
-  if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
-  static bool ok = allow_big_lds(attn_apply_kernel<1, 2>) && allow_big_lds(attn_apply_kernel<2, 1>) &&
-                   allow_big_lds(attn_apply_kernel<2, 2>) && allow_big_lds(attn_apply_kernel<4, 1>) &&
-                   allow_big_lds(attn_apply_kernel<4, 2>) && allow_big_lds(attn_apply_kernel<1, 4>) &&
-                   allow_big_lds(attn_apply_kernel<1, 8>);
-  (void)ok;
-  dim3 g((p.Lq + T - 1) / T, p.B), blk(kThreads);
-  hipStream_t st = pcr_s(stream);
-  const bool wide = 2 * p.d > 128 || p.cout > 128 || p.cfinal > 128;   // some layer has > 4 cout blocks
-  if (tb == 4) {
-    if (wide) hipLaunchKernelGGL((attn_apply_kernel<4, 2>), g, blk, lds, st, a);
-    else hipLaunchKernelGGL((attn_apply_kernel<4, 1>), g, blk, lds, st, a);
-  } else if (tb == 2) {
-    if (wide) hipLaunchKernelGGL((attn_apply_kernel<2, 2>), g, blk, lds, st, a);
-    else hipLaunchKernelGGL((attn_apply_kernel<2, 1>), g, blk, lds, st, a);
-  } else {
-    // cout blocks of the widest layer: up to 8 -> two rounds per wave, up to 16 -> four, up to 32 (d_model 512) -> eight
-    int widest = 2 * p.d > p.cout ? 2 * p.d : p.cout;
-    if (p.cfinal > widest) widest = p.cfinal;
-    if (widest > 512) hipLaunchKernelGGL((attn_apply_kernel<1, 8>), g, blk, lds, st, a);
-    else if (widest > 256) hipLaunchKernelGGL((attn_apply_kernel<1, 4>), g, blk, lds, st, a);
-    else hipLaunchKernelGGL((attn_apply_kernel<1, 2>), g, blk, lds, st, a);
-  }
-  PCR_CHECK_LAUNCH();
-  return PCR_OK;
-}
-
+// Linear attention, f32-input MFMA form + the C-ABI entry points (body: attn_kernels_impl.h).
+#define PCR_ATTN_PREC 0
+#include "attn_kernels_impl.h"

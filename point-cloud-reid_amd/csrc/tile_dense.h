@@ -645,10 +645,22 @@ __device__ __forceinline__ void tile_dense2p(const float *__restrict__ in, int C
     static_assert(!BIMG, "bf images feed the bf16 tile only");
     tile_dense2<TB, NR, WSEL, TILE, Epi, AfterK, PFv, RES>(in, CP, wp, OP, sync_epi, epi, init, ring, after_k, opfull);
   } else {
-    static_assert(WSEL != 0, "bf16 dense tiles are instantiated for explicit shapes only");
-    tile_dense_bf_impl<TB, DenseShape<NR, WSEL>::nr, DenseShape<NR, WSEL>::ways, TILE, PREC == 1 ? 3 : 1, Epi,
-                       bf_pf(DenseShape<NR, WSEL>::nr), AfterK, BIMG>(in, CP, wp, OP, sync_epi, epi, init, after_k, opfull,
-                                                                      bfring);
+    constexpr int NS = PREC == 1 ? 3 : 1;
+    if constexpr (WSEL != 0) {
+      tile_dense_bf_impl<TB, DenseShape<NR, WSEL>::nr, DenseShape<NR, WSEL>::ways, TILE, NS, Epi,
+                         bf_pf(DenseShape<NR, WSEL>::nr), AfterK, BIMG>(in, CP, wp, OP, sync_epi, epi, init, after_k,
+                                                                        opfull, bfring);
+    } else {
+      // generic shape: the wave / tile split follows OP at run time, as in tile_dense2 (up to two cout-block rounds)
+      static_assert(NR <= 2, "bf16 dense tiles cover up to eight cout blocks");
+      after_k();
+      const int nCB = OP >> 5;
+      const DenseNoHook nh;
+      if (nCB > 4) tile_dense_bf_impl<TB, NR, 1, TILE, NS, Epi, bf_pf(NR), DenseNoHook, BIMG>(in, CP, wp, OP, sync_epi, epi, init, nh, opfull);
+      else if (nCB >= 3) tile_dense_bf_impl<TB, 1, 1, TILE, NS, Epi, bf_pf(1), DenseNoHook, BIMG>(in, CP, wp, OP, sync_epi, epi, init, nh, opfull);
+      else if (nCB == 2) tile_dense_bf_impl<TB, 1, 2, TILE, NS, Epi, bf_pf(1), DenseNoHook, BIMG>(in, CP, wp, OP, sync_epi, epi, init, nh, opfull);
+      else tile_dense_bf_impl<TB, 1, 4, TILE, NS, Epi, bf_pf(1), DenseNoHook, BIMG>(in, CP, wp, OP, sync_epi, epi, init, nh, opfull);
+    }
   }
 }
 

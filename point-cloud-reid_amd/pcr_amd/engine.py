@@ -102,7 +102,10 @@ class AttnParams(ctypes.Structure):
                 ("ln1_g", c_float_p), ("ln1_b", c_float_p), ("ln2_g", c_float_p), ("ln2_b", c_float_p),
                 ("wfinal", c_float_p), ("bfinal", c_float_p), ("cfinal", ctypes.c_int),
                 ("wkv_wide", c_float_p), ("bkv_wide", c_float_p), ("wmerge_packed", c_float_p),
-                ("kv", c_float_p), ("out", c_float_p)]
+                ("kv", c_float_p), ("out", c_float_p),
+                ("precision", ctypes.c_int),
+                ("wq_bf", c_float_p), ("wkv_bf", c_float_p), ("wmlp0_bf", c_float_p), ("wmlp2_bf", c_float_p),
+                ("wfinal_bf", c_float_p)]
 
 
 class HeadParams(ctypes.Structure):
@@ -308,6 +311,10 @@ class AttnPlan:
             wmlp0=pack_weight(m.mlp[0].weight, device), wmlp2=pack_weight(m.mlp[2].weight, device),
             ln1_g=_dev32(m.norm1.weight, device), ln1_b=_dev32(m.norm1.bias, device),
             ln2_g=_dev32(m.norm2.weight, device), ln2_b=_dev32(m.norm2.bias, device))
+        if d <= 128:
+            # the same matrices as bf16 hi / lo images: the dense phases of both kernels in "bf16x3" / "bf16" mode
+            self.t.update(wq_bf=pack_weight_bf(wq.float(), device), wkv_bf=pack_weight_bf(wkv.float(), device),
+                          wmlp0_bf=pack_weight_bf(m.mlp[0].weight, device), wmlp2_bf=pack_weight_bf(m.mlp[2].weight, device))
         if d > 128:
             # d_model 256 / 512 (mul = 2 / 4 configs): the kv kernel splits a cloud over d/64 workgroups; band g needs
             # the K rows [64g, 64g+64) and the V rows of its head of the fused projection (include/pcr.h)
@@ -326,6 +333,8 @@ class AttnPlan:
         self.cfinal = 0
         if final is not None:
             self.t["wfinal"] = pack_weight(final.weight, device)
+            if d <= 128:
+                self.t["wfinal_bf"] = pack_weight_bf(final.weight, device)
             self.cfinal = final.weight.shape[0]
             bpad = torch.zeros((self.cfinal + 31) // 32 * 32, dtype=torch.float32, device=device)
             bpad[:self.cfinal] = final.bias.detach().to(device).float()
@@ -342,6 +351,7 @@ class AttnPlan:
             setattr(p, k, _p(v))
         p.cfinal = self.cfinal
         p.kv, p.out = _p(kv), _p(out)
+        p.precision = PRECISIONS[PRECISION]
         return p
 
     def kv(self, feat_k, xyz_k):
@@ -357,6 +367,7 @@ class AttnPlan:
         kv_flops = 2.0 * B * Sk * (3 * d + d * c2 + 2 * c2 * d + d * d / self.nhead)   # reference's op count
         with _prof("attn_kv[d=%d,c2=%d,Sk=%d]" % (d, c2, Sk), kv_flops, 4.0 * B * (c2 * Sk + 3 * Sk + d * d + d)):
             L.check(lib.pcr_attn_kv_f32(ctypes.byref(p), L.stream_ptr()), "pcr_attn_kv_f32")
+        kv._pcr_precision = PRECISION      # the per-cloud matrix is an image of this kind: apply() must match
         return kv
 
     def apply(self, feat_q, xyz_q, kv, Sk, kv_index=None, q_index=None, n_out=None):
@@ -366,6 +377,10 @@ class AttnPlan:
         assert feat_q.is_contiguous() and feat_q.dtype == torch.float32 and (xyz_q is None or xyz_q.is_contiguous())
         Bq, c1, Lq = feat_q.shape
         assert c1 == self.c1
+        made = getattr(kv, "_pcr_precision", PRECISION)
+        if (made == "f32") != (PRECISION == "f32") and self.d <= 128:
+            raise L.PcrError("attention state was built in %r mode and is applied in %r mode: the per-cloud matrix is "
+                             "stored in the arithmetic's own layout" % (made, PRECISION))
         B = n_out if n_out is not None else Bq
         out = torch.empty((B, self.cfinal or self.cout, Lq), dtype=torch.float32, device=feat_q.device)
         p = self._params(B, Lq, Sk, feat_q, xyz_q, feat_q, xyz_q if xyz_q is not None else feat_q, kv, out,

@@ -88,11 +88,18 @@ def timed(fn, steps, warmup, sync=None, device=None):
         out = fn()
     barrier(sync)
     dt = time.perf_counter() - t0
+    global LAST_RANK_SECONDS
+    LAST_RANK_SECONDS = [dt]
     if is_dist():
         t = torch.tensor([dt], dtype=torch.float64, device=device or "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, t)                        # (kept for the report: stragglers show as a spread)
+        LAST_RANK_SECONDS = [float(x.item()) for x in every]
+        dt = max(LAST_RANK_SECONDS)
     return dt, out
+
+
+LAST_RANK_SECONDS = []      # elapsed seconds of every rank in the last timed() region (rank order)
 
 
 def broadcast_buffers(module, src=0):

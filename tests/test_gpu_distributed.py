@@ -68,7 +68,7 @@ def test_two_ranks_on_device_tensors(tmp_path):
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
 
 
-@pytest.mark.parametrize("workload", ["pt128", "pt128_train"])
+@pytest.mark.parametrize("workload", ["pt128", "pt128_train", "ssg1024", "pt1024"])
 def test_bench_runs_two_ranks_on_the_gpu(workload):
     """bench.py's multi-rank path end to end on the GPU (pair sharding, barriers, max-over-ranks timing, rank 0's JSON
     line, the gradient bucket under the training workload): two ranks on cuda:0 over gloo through the test hooks"""
@@ -89,3 +89,7 @@ def test_bench_runs_two_ranks_on_the_gpu(workload):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and "roofline" in d
     assert d["config"].get("rccl_ranks", 2) == 2
+    # the companions of the default run and the CPU baseline belong to the one-GPU line only; every rank's own time is
+    # in the line (a straggler shows as a spread; ms_per_step is their maximum)
+    assert "also" not in d and "cpu_baseline" not in d
+    assert len(d["per_rank_ms_per_step"]) == 2 and max(d["per_rank_ms_per_step"]) == pytest.approx(d["ms_per_step"])

@@ -110,3 +110,43 @@ def test_ragged_and_k_row_evaluation_agree_bit_for_bit_in_every_precision(prec):
             sa.skip_repeats = False
         b = _logits(model, s1, s2)
     assert torch.equal(a, b)
+
+
+def test_attention_blocks_in_split_bf16_against_the_f32_path():
+    """the dense phases of the attention kernels (Q, message, feed-forward, K/V projection) in "bf16x3" mode against
+    the f32 kernels on the same inputs: a different kernel (bits differ) within 2e-5 of the output's scale; a key-side
+    state built in one arithmetic cannot be applied in the other (the per-cloud matrix is stored in its layout)"""
+    import bench
+    from pcr_amd import _lib as L
+    from pcr_amd import engine
+    model, _ = bench.build_pt_model([128, 64, 32])
+    g = torch.Generator().manual_seed(3)
+    for d, n in ((64, 128), (64, 100)):
+        h1 = torch.randn(5, d, n, generator=g).cuda()
+        h2 = torch.randn(5, d, n, generator=g).cuda()
+        x1 = torch.randn(5, n, 3, generator=g).cuda()
+        x2 = torch.randn(5, n, 3, generator=g).cuda()
+        out = {}
+        for prec in ("f32", "bf16x3"):
+            with engine.precision(prec), torch.no_grad():
+                out[prec] = model.cross_stage1(h1, x1, h2, x2).cpu()
+        scale = float(out["f32"].abs().max())
+        err = float((out["bf16x3"] - out["f32"]).abs().max()) / scale
+        print(json.dumps(dict(d=d, n=n, err=err)))
+        assert 0 < err < 2e-5, err
+    for i, sa in enumerate(model.backbone.SA_modules):       # d_model 32 / 64 / 128 self-attention
+        d = (32, 64, 128)[i]
+        f = torch.randn(3, d, 96, generator=g).cuda()
+        x = torch.randn(3, 96, 3, generator=g).cuda()
+        out = {}
+        for prec in ("f32", "bf16x3"):
+            with engine.precision(prec), torch.no_grad():
+                out[prec] = sa.self_attention(f, x).cpu()
+        err = float((out["bf16x3"] - out["f32"]).abs().max()) / float(out["f32"].abs().max())
+        print(json.dumps(dict(d=d, err=err)))
+        assert 0 < err < 2e-5, err
+    plan = model.cross_stage1.plan(torch.device("cuda"))
+    with engine.precision("f32"):
+        kv = plan.kv(h2, x2)
+    with engine.precision("bf16x3"), pytest.raises(L.PcrError):
+        plan.apply(h1, None, kv, h2.shape[2])
