@@ -258,12 +258,12 @@ typedef struct pcr_attn_params {
   const float *wkv_wide, *bkv_wide, *wmerge_packed;
   float *kv;    /* workspace (B, pcr_attn_kv_floats(d)) */
   float *out;   /* (B, cfinal ? cfinal : cout, Lq) */
-  /* precision != PCR_PREC_F32 and d <= 128: the dense phases (Q, message, feed-forward, K/V projection, cov_final) run
-   * as split bf16 (three bf16 MFMAs per product, f32 accumulate) on the pcr_pack_weight_bf16x2_f32 images of the same
-   * matrices: wq_bf, wkv_bf, wmlp0_bf, wmlp2_bf, wfinal_bf (NULL: f32).  The kv kernel then writes the per-cloud matrix
-   * M as a bf16 image too, so pcr_attn_kv_f32 and pcr_attn_apply_f32 must be called with the SAME precision. */
+  /* precision != PCR_PREC_F32 and d <= 128: the dense phases of the apply kernel (Q, message, feed-forward, cov_final)
+   * run as split bf16 (three bf16 MFMAs per product, f32 accumulate) on the pcr_pack_weight_bf16x2_f32 images of the same
+   * matrices: wq_bf, wmlp0_bf, wmlp2_bf, wfinal_bf (NULL: f32).  The kv kernel then writes the per-cloud matrix M as a
+   * bf16 image, so pcr_attn_kv_f32 and pcr_attn_apply_f32 must be called with the SAME precision. */
   int precision;
-  const float *wq_bf, *wkv_bf, *wmlp0_bf, *wmlp2_bf, *wfinal_bf;
+  const float *wq_bf, *wmlp0_bf, *wmlp2_bf, *wfinal_bf;
 } pcr_attn_params;
 long pcr_attn_kv_floats(int d);
 int pcr_attn_kv_f32(const pcr_attn_params *p, pcr_stream_t stream);
@@ -433,6 +433,10 @@ typedef struct pcr_bn_fwd_fin {
   float eps, momentum;
   float *running_mean, *running_var;
   float *scale, *shift, *inv_scale, *mean, *invstd;
+  /* optional: the partials are sums of (y - shift0[c * shift0_stride]) and of its square (a per-channel offset close
+   * to the mean removes the cancellation of E[y^2] - mean^2); NULL = plain sums */
+  const float *shift0;
+  int shift0_stride;
 } pcr_bn_fwd_fin;
 int pcr_bn_fwd_finalize_f32(const pcr_bn_fwd_fin *p, pcr_stream_t stream);
 
@@ -444,6 +448,7 @@ typedef struct pcr_bn_bwd_fin {
   double R;
   const float *gamma, *mean, *invstd;
   float *ka, *kb, *kc, *dgamma, *dbeta;
+  const float *centre;   /* optional (C): S2 was taken of dyhat * (y - centre[c]) (centre = mean: no cancellation); NULL = 0 */
 } pcr_bn_bwd_fin;
 int pcr_bn_bwd_finalize_f32(const pcr_bn_bwd_fin *p, pcr_stream_t stream);
 
@@ -509,6 +514,26 @@ int pcr_pool_both_bwd_f32(const float *g, const int *arg, float *dout, int P, in
  * winning channel kept for the backward: x (B,C,L) -> y (B,C/W,L), arg (B,C/W,L); backward dx (B,C,L). */
 int pcr_channel_max_fwd_f32(const float *x, float *y, int *arg, int B, int C, int L, int W, pcr_stream_t stream);
 int pcr_channel_max_bwd_f32(const float *g, const int *arg, float *dx, int B, int C, int L, int W, pcr_stream_t stream);
+
+/* BatchNorm in batch-statistics mode as a stand-alone layer on (B,C,L) channel-major tensors (PointNet's BatchNorm1d
+ * layers, models/pointnet.py:27-45, 103-127; csrc/train_bn_kernels.hip).
+ * pcr_bn_sums_f32: partials [nparts][2][ceil32(C)] for pcr_bn_fwd_finalize_f32 (g NULL: sum y', sum y'^2) or
+ *   pcr_bn_bwd_finalize_f32 (g given: sum g', sum g' y' with g' = g [scale y + shift > 0] when relu, else g), where
+ *   y' = y - centre[c] (centre given), y - y[0][c][0] (centre NULL, centre_first != 0) or y.
+ * pcr_bn_affine_f32: g NULL: out = [relu](a0 y + a1) (a0 = scale, a1 = shift); g given: out = a0 g' + a1 (y - centre[c])
+ *   + a2, the gradient with respect to y: (ka, kb, kc) with centre NULL, or its centred form (ka, kb, -ka dbeta / R) with
+ *   centre = the batch mean. */
+int pcr_bn_sums_f32(const float *y, const float *g, const float *scale, const float *shift, int relu,
+                    const float *centre, int centre_first, float *part, int nparts, int B, int C, int L,
+                    pcr_stream_t stream);
+int pcr_bn_affine_f32(const float *y, const float *g, const float *a0, const float *a1, const float *a2,
+                      const float *scale, const float *shift, const float *centre, int relu, float *out, int B, int C,
+                      int L, pcr_stream_t stream);
+/* Per-cloud transforms (torch.bmm(x^T, T)^T, models/pointnet.py:109-111, 117-119): x (B,k,N), T (B,k,k) ->
+ * y[b][j][n] = sum_i T[b][i][j] x[b][i][n]; transposed = 1 applies T^T instead (the backward's dx from dy);
+ * pcr_bmm_dt_f32: dT[b][i][j] = sum_n x[b][i][n] dy[b][j][n].  k <= 128. */
+int pcr_bmm_apply_f32(const float *x, const float *T, float *y, int B, int k, int N, int transposed, pcr_stream_t stream);
+int pcr_bmm_dt_f32(const float *x, const float *dy, float *dT, int B, int k, int N, pcr_stream_t stream);
 
 /* The packed images of MANY weights in one launch (a training step re-packs every weight after the update: ~76 small
  * launches otherwise).  descs (device): per tensor the contiguous row-major (rows x cols) matrix w and out, which

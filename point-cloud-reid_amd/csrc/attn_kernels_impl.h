@@ -1,7 +1,8 @@
 // Linear-attention kernels (pcr_attn_kv_f32 / pcr_attn_apply_f32).  Body of two translation units:
 //   attn_kernels.hip      PCR_ATTN_PREC 0  f32-input MFMA, every shape, and the C-ABI entry points
-//   attn_kernels_bf3.hip  PCR_ATTN_PREC 1  the dense phases (Q, message, feed-forward, K/V projection) as split bf16 on
-//                                          v_mfma_f32_32x32x16_bf16 for d_model <= 128; exports pcr_attn_{kv,apply}_bf3
+//   attn_kernels_bf3.hip  PCR_ATTN_PREC 1  the dense phases of the apply kernel (Q, message, feed-forward, cov_final) as
+//                                          split bf16 on v_mfma_f32_32x32x16_bf16 for d_model <= 128; the kv kernel
+//                                          writes the per-cloud matrix as a bf16 image; exports pcr_attn_{kv,apply}_bf3
 #pragma once
 #ifndef PCR_ATTN_PREC
 #define PCR_ATTN_PREC 0
@@ -131,8 +132,10 @@ __device__ __forceinline__ void attn_kv_body(const AttnArgs &a) {
     pos_hidden(XH + c2 * RP, RP, P, s_w0, s_b0, d, T);
     __syncthreads();
     // (whole-tile epilogue: a 32-cout block is all K or all V, so the branch is wave-uniform)
-    tile_dense2p<kAPrec, TB, NR, WSEL, true>(XH, c2 + d, p.wkv, 2 * d, true,
-                                             [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
+    // (f32-input MFMA in both units: this kernel is one workgroup per cloud walking its token tiles serially -- latency,
+    // not the matrix pipe, bounds it, and the bf16 form's operand conversion measured 0-15 % SLOWER here)
+    tile_dense2<TB, NR, WSEL, true>(XH, c2 + d, p.wkv, 2 * d, true,
+                                    [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
       const int t = tb * 32 + l31;
       float *dst = XH + (cb * 32 + 4 * h) * RP + t;
       const bool live = t < valid;
@@ -555,11 +558,11 @@ int pcr_attn_apply_bf3(const pcr_attn_params *pp, pcr_stream_t stream);
 // precision != f32, d_model <= 128 and bf16 images given: the same parameters with the images swapped in
 static bool attn_bf(const pcr_attn_params &p, pcr_attn_params &q) {
   const int widest = 2 * p.d > p.cout ? (2 * p.d > p.cfinal ? 2 * p.d : p.cfinal) : (p.cout > p.cfinal ? p.cout : p.cfinal);
-  if (p.precision == 0 || p.d > 128 || widest > 256 || !p.wq_bf || !p.wkv_bf || !p.wmlp0_bf || !p.wmlp2_bf ||
+  if (p.precision == 0 || p.d > 128 || widest > 256 || !p.wq_bf || !p.wmlp0_bf || !p.wmlp2_bf ||
       (p.cfinal && !p.wfinal_bf))
     return false;
-  q = p;
-  q.wq = p.wq_bf; q.wkv = p.wkv_bf; q.wmlp0 = p.wmlp0_bf; q.wmlp2 = p.wmlp2_bf; q.wfinal = p.wfinal_bf;
+  q = p;      // (wkv stays the f32 image: the kv kernel's projection is f32 in both units, only its output M changes form)
+  q.wq = p.wq_bf; q.wmlp0 = p.wmlp0_bf; q.wmlp2 = p.wmlp2_bf; q.wfinal = p.wfinal_bf;
   return true;
 }
 

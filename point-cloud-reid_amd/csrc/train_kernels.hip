@@ -907,6 +907,8 @@ struct BnFwdFin {
   float eps, momentum;
   float *running_mean, *running_var;    // updated in place (may be null)
   float *scale, *shift, *inv_scale, *mean, *invstd;
+  const float *shift0;                  // the sums are of (y - shift0[c * shift0_stride]) and its square (or null)
+  int shift0_stride;
 };
 
 __global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(BnFwdFin a) {
@@ -915,9 +917,10 @@ __global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(BnFwdFin a) {
   double s, sq;
   sum_parts2(a.part, a.nparts, a.CP, c < a.CP ? c : 0, s, sq, red);
   if ((threadIdx.x >> 5) != 0 || c >= a.C) return;
-  const double mean = s / a.R;
-  double var = sq / a.R - mean * mean;
+  const double mean0 = s / a.R;          // (of the shifted values: the variance does not see the shift)
+  double var = sq / a.R - mean0 * mean0;
   if (var < 0.0) var = 0.0;
+  const double mean = mean0 + (a.shift0 ? (double)a.shift0[(size_t)c * a.shift0_stride] : 0.0);
   const double invstd = 1.0 / sqrt(var + (double)a.eps);
   const double sc = (double)a.gamma[c] * invstd;
   a.scale[c] = (float)sc;
@@ -942,6 +945,7 @@ struct BnBwdFin {
   double R;
   const float *gamma, *mean, *invstd;
   float *ka, *kb, *kc, *dgamma, *dbeta;
+  const float *centre;                  // S2 = sum dyhat * (y - centre[c]) (or null: centre 0)
 };
 
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(BnBwdFin a) {
@@ -951,7 +955,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(BnBwdFin a) {
   sum_parts2(a.part, a.nparts, a.CP, c < a.CP ? c : 0, s1, s2, red);
   if ((threadIdx.x >> 5) != 0 || c >= a.C) return;
   const double mean = a.mean[c], invstd = a.invstd[c], gamma = a.gamma[c];
-  const double dgamma = invstd * (s2 - mean * s1);
+  const double dgamma = invstd * (s2 - (mean - (a.centre ? (double)a.centre[c] : 0.0)) * s1);
   const double ka = gamma * invstd;
   a.dgamma[c] = (float)dgamma;
   a.dbeta[c] = (float)s1;
@@ -1224,6 +1228,7 @@ PCR_EXPORT int pcr_bn_fwd_finalize_f32(const pcr_bn_fwd_fin *p, pcr_stream_t str
   a.gamma = p->gamma; a.beta = p->beta; a.eps = p->eps; a.momentum = p->momentum;
   a.running_mean = p->running_mean; a.running_var = p->running_var;
   a.scale = p->scale; a.shift = p->shift; a.inv_scale = p->inv_scale; a.mean = p->mean; a.invstd = p->invstd;
+  a.shift0 = p->shift0; a.shift0_stride = p->shift0_stride;
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(a.CP / 32), dim3(1024), 0, pcr_s(stream), a);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
@@ -1237,6 +1242,7 @@ PCR_EXPORT int pcr_bn_bwd_finalize_f32(const pcr_bn_bwd_fin *p, pcr_stream_t str
   a.part = p->part; a.nparts = p->nparts; a.CP = ceil32(p->C); a.C = p->C; a.R = p->R;
   a.gamma = p->gamma; a.mean = p->mean; a.invstd = p->invstd;
   a.ka = p->ka; a.kb = p->kb; a.kc = p->kc; a.dgamma = p->dgamma; a.dbeta = p->dbeta;
+  a.centre = p->centre;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.CP / 32), dim3(1024), 0, pcr_s(stream), a);
   PCR_CHECK_LAUNCH();
   return PCR_OK;

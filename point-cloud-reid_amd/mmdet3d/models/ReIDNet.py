@@ -171,8 +171,12 @@ class ReIDNet(nn.Module):
             # per-point 1024-d encoder features, reduced per point by `downsample` (ref :316-324)
             xyz, h = self.backbone(both.permute(0, 2, 1).contiguous(), self.backbone_list)
             if self.downsample is not None:
-                from pcr_amd import rows
-                h = rows.downsample_points(self.downsample, h)
+                if self.training:
+                    from pcr_amd import train_graph
+                    h = train_graph.downsample_points(self.downsample, h)
+                else:
+                    from pcr_amd import rows
+                    h = rows.downsample_points(self.downsample, h)
             xyz = xyz.permute(0, 2, 1)
             return xyz[:b], xyz[b:], h[:b], h[b:]
         xyz, h = self.backbone(both, self.backbone_list)

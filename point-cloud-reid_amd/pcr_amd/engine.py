@@ -104,8 +104,7 @@ class AttnParams(ctypes.Structure):
                 ("wkv_wide", c_float_p), ("bkv_wide", c_float_p), ("wmerge_packed", c_float_p),
                 ("kv", c_float_p), ("out", c_float_p),
                 ("precision", ctypes.c_int),
-                ("wq_bf", c_float_p), ("wkv_bf", c_float_p), ("wmlp0_bf", c_float_p), ("wmlp2_bf", c_float_p),
-                ("wfinal_bf", c_float_p)]
+                ("wq_bf", c_float_p), ("wmlp0_bf", c_float_p), ("wmlp2_bf", c_float_p), ("wfinal_bf", c_float_p)]
 
 
 class HeadParams(ctypes.Structure):
@@ -313,7 +312,7 @@ class AttnPlan:
             ln2_g=_dev32(m.norm2.weight, device), ln2_b=_dev32(m.norm2.bias, device))
         if d <= 128:
             # the same matrices as bf16 hi / lo images: the dense phases of both kernels in "bf16x3" / "bf16" mode
-            self.t.update(wq_bf=pack_weight_bf(wq.float(), device), wkv_bf=pack_weight_bf(wkv.float(), device),
+            self.t.update(wq_bf=pack_weight_bf(wq.float(), device),
                           wmlp0_bf=pack_weight_bf(m.mlp[0].weight, device), wmlp2_bf=pack_weight_bf(m.mlp[2].weight, device))
         if d > 128:
             # d_model 256 / 512 (mul = 2 / 4 configs): the kv kernel splits a cloud over d/64 workgroups; band g needs

@@ -60,10 +60,12 @@ class _EncoderPlan:
 def encoder_forward(enc, xyz):
     """xyz (B,3,N) -> (xyz, per-point features (B,1024,N)); eval mode only"""
     L.require_cuda(xyz)
-    if enc.training:
-        raise L.PcrError("PointNetEncoder: the HIP path implements eval-mode inference; call .eval()")
     if not enc.feature_transform:
         raise L.PcrError("PointNetEncoder: the ReID configs build feature_transform=True")
+    if enc.training:
+        # differentiable graph with BatchNorm batch statistics (pcr_amd/train_graph.py); eval mode below
+        from . import train_graph
+        return train_graph.pointnet_encoder(enc, xyz.contiguous().float())
     key = (str(xyz.device), E.param_version(enc))
     if getattr(enc, "_pcr_key", None) != key:
         object.__setattr__(enc, "_pcr_plan", _EncoderPlan(enc, xyz.device))

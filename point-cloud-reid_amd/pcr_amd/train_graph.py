@@ -79,6 +79,47 @@ def backbone(bb, pointcloud, numpoints):
     return xyz, TO.dense(l_feat[0], cf.weight.view(cf.weight.shape[0], -1), cf.bias)
 
 
+def _conv_bn(x, conv, bn, relu=True):
+    return TO.bn_act(TO.dense(x, conv.weight.view(conv.weight.shape[0], -1), conv.bias), bn, relu)
+
+
+def _stn(m, x):
+    """STN3d / STNkd (models/pointnet.py:27-45, 67-85) in training mode: x (B,k,N) -> per-cloud (B,k,k) transforms"""
+    B = x.shape[0]
+    h = _conv_bn(_conv_bn(_conv_bn(x, m.conv1, m.bn1), m.conv2, m.bn2), m.conv3, m.bn3)
+    g = TO.PoolBoth.apply(h)[:, :h.shape[1]]                 # max over the points: (B, 1024)
+    f = g.t().contiguous().unsqueeze(0)                      # (1, 1024, B): clouds as tokens, BatchNorm1d over the batch
+    f = _conv_bn(_conv_bn(f, m.fc1, m.bn4), m.fc2, m.bn5)
+    t = TO.dense(f, m.fc3.weight, m.fc3.bias)                # (1, k*k, B)
+    iden = torch.eye(m.k, dtype=t.dtype, device=t.device).flatten().unsqueeze(0)
+    return (t.squeeze(0).t() + iden).reshape(B, m.k, m.k)
+
+
+def pointnet_encoder(enc, xyz):
+    """PointNetEncoder.forward with feature_transform (models/pointnet.py:103-127) in training mode:
+    xyz (B,3,N) -> (xyz, per-point features (B,1024,N)); every BatchNorm uses batch statistics"""
+    x = xyz.contiguous()
+    x = TO.Bmm.apply(x, _stn(enc.stn, x))
+    x = _conv_bn(x, enc.conv1, enc.bn1)
+    x = TO.Bmm.apply(x, _stn(enc.fstn, x))
+    x = _conv_bn(x, enc.conv2, enc.bn2)
+    return xyz, _conv_bn(x, enc.conv3, enc.bn3, relu=False)
+
+
+def downsample_points(mods, x):
+    """ReIDNet.downsample ([LinearRes, LinearRes, Linear], ReIDNet.py:316-324) per point on (B,C,N) in training mode"""
+    from mmdet3d.models.lanegcn_nets import LinearRes
+    for m in mods:
+        if isinstance(m, LinearRes):
+            x = linear_res_rows(m, x)
+        elif isinstance(m, torch.nn.Linear):
+            x = TO.dense(x, m.weight, m.bias)
+        else:
+            from . import _lib as L
+            raise L.PcrError("downsample: %s has no HIP training form" % type(m).__name__)
+    return x
+
+
 def linear_res_rows(m, x):
     """LinearRes (lanegcn_nets.py:228-241) on (M, n) rows, evaluated channel-major with the rows as tokens (1, n, M):
     relu(GN(W1 x)) -> GN(W2 .) + shortcut -> relu, the ReLUs and the shortcut add inside the norm launches"""

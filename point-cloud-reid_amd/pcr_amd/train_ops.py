@@ -45,13 +45,14 @@ class _BnFwd(ctypes.Structure):
     _fields_ = [("part", c_fp), ("nparts", ctypes.c_int), ("C", ctypes.c_int), ("R", ctypes.c_double),
                 ("gamma", c_fp), ("beta", c_fp), ("eps", ctypes.c_float), ("momentum", ctypes.c_float),
                 ("running_mean", c_fp), ("running_var", c_fp),
-                ("scale", c_fp), ("shift", c_fp), ("inv_scale", c_fp), ("mean", c_fp), ("invstd", c_fp)]
+                ("scale", c_fp), ("shift", c_fp), ("inv_scale", c_fp), ("mean", c_fp), ("invstd", c_fp),
+                ("shift0", c_fp), ("shift0_stride", ctypes.c_int)]
 
 
 class _BnBwd(ctypes.Structure):
     _fields_ = [("part", c_fp), ("nparts", ctypes.c_int), ("C", ctypes.c_int), ("R", ctypes.c_double),
                 ("gamma", c_fp), ("mean", c_fp), ("invstd", c_fp),
-                ("ka", c_fp), ("kb", c_fp), ("kc", c_fp), ("dgamma", c_fp), ("dbeta", c_fp)]
+                ("ka", c_fp), ("kb", c_fp), ("kc", c_fp), ("dgamma", c_fp), ("dbeta", c_fp), ("centre", c_fp)]
 
 
 def _p(t):
@@ -274,25 +275,28 @@ def tdense_bwd(g, x, cout, dy_mode=0, y=None, k=None, argmax=None, pooled=None, 
     return out
 
 
-def bn_fwd_finalize(part, nparts, C, R, gamma, beta, eps, momentum, running_mean=None, running_var=None):
+def bn_fwd_finalize(part, nparts, C, R, gamma, beta, eps, momentum, running_mean=None, running_var=None, shift0=None,
+                    shift0_stride=1):
     dev = part.device
     o = {k: _f32(C, device=dev) for k in ("scale", "shift", "inv_scale", "mean", "invstd")}
     p = _BnFwd()
     p.part, p.nparts, p.C, p.R = _p(part), nparts, C, float(R)
     p.gamma, p.beta, p.eps, p.momentum = _p(gamma.detach()), _p(beta.detach()), eps, momentum
     p.running_mean, p.running_var = _p(running_mean), _p(running_var)
+    p.shift0, p.shift0_stride = _p(shift0), shift0_stride
     for k, v in o.items():
         setattr(p, k, _p(v))
     L.check(L.load().pcr_bn_fwd_finalize_f32(ctypes.byref(p), L.stream_ptr()), "pcr_bn_fwd_finalize_f32")
     return o
 
 
-def bn_bwd_finalize(part, nparts, C, R, gamma, mean, invstd):
+def bn_bwd_finalize(part, nparts, C, R, gamma, mean, invstd, centre=None):
     dev = part.device
     o = {k: _f32(C, device=dev) for k in ("ka", "kb", "kc", "dgamma", "dbeta")}
     p = _BnBwd()
     p.part, p.nparts, p.C, p.R = _p(part), nparts, C, float(R)
     p.gamma, p.mean, p.invstd = _p(gamma.detach()), _p(mean), _p(invstd)
+    p.centre = _p(centre)
     for k, v in o.items():
         setattr(p, k, _p(v))
     L.check(L.load().pcr_bn_bwd_finalize_f32(ctypes.byref(p), L.stream_ptr()), "pcr_bn_bwd_finalize_f32")
@@ -672,3 +676,86 @@ class ChannelMax(Function):
         L.check(L.load().pcr_channel_max_bwd_f32(L.ptr(g), L.ptr(arg), L.ptr(dx), B, C, Ln, W, L.stream_ptr()),
                 "pcr_channel_max_bwd_f32")
         return dx, None
+
+
+# --------------------------------------------------------------- PointNet pieces (csrc/train_bn_kernels.hip) --
+class BnAct(Function):
+    """[relu](BatchNorm(y)) with BATCH statistics over (B, L) per channel on a (B,C,L) tensor; running statistics are
+    updated in place as nn.BatchNorm1d does in training mode.  (The Point-Transformer path folds its BatchNorms into
+    the train-dense launches; PointNet's stand between layers that cannot take them.)"""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, bn, relu):
+        y = _dev(y)
+        B, C, Ln = y.shape
+        lib = L.load()
+        if bn.momentum is None:
+            raise L.PcrError("BatchNorm with momentum=None (cumulative average) is not supported by the HIP training path")
+        nparts = max(1, min(B, 2048 // max(C, 1)))
+        part = _f32(nparts, 2, _c32(C), device=y.device)
+        # sums of y - y[0][c][0] (first element of the channel as the offset): see pcr_bn_fwd_fin.shift0
+        L.check(lib.pcr_bn_sums_f32(L.ptr(y), None, None, None, 0, None, 1, L.ptr(part), nparts, B, C, Ln, L.stream_ptr()),
+                "pcr_bn_sums_f32")
+        n = bn_fwd_finalize(part, nparts, C, B * Ln, gamma, beta, bn.eps, bn.momentum,
+                            bn.running_mean if bn.track_running_stats else None,
+                            bn.running_var if bn.track_running_stats else None, shift0=y, shift0_stride=Ln)
+        if bn.track_running_stats:
+            torch.autograd.graph.increment_version([bn.running_mean, bn.running_var])
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+        z = _f32(B, C, Ln, device=y.device)
+        L.check(lib.pcr_bn_affine_f32(L.ptr(y), None, L.ptr(n["scale"]), L.ptr(n["shift"]), None, None, None, None,
+                                      int(relu), L.ptr(z), B, C, Ln, L.stream_ptr()), "pcr_bn_affine_f32")
+        ctx.save_for_backward(y, gamma)
+        ctx.norm, ctx.relu, ctx.nparts = n, int(relu), nparts
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        y, gamma = ctx.saved_tensors
+        n, relu, nparts = ctx.norm, ctx.relu, ctx.nparts
+        B, C, Ln = y.shape
+        g = g.contiguous()
+        lib = L.load()
+        part = _f32(nparts, 2, _c32(C), device=y.device)
+        L.check(lib.pcr_bn_sums_f32(L.ptr(y), L.ptr(g), L.ptr(n["scale"]), L.ptr(n["shift"]), relu, L.ptr(n["mean"]), 0,
+                                    L.ptr(part), nparts, B, C, Ln, L.stream_ptr()), "pcr_bn_sums_f32")
+        k = bn_bwd_finalize(part, nparts, C, B * Ln, gamma, n["mean"], n["invstd"], centre=n["mean"])
+        dy = _f32(B, C, Ln, device=y.device)
+        kc = k["ka"] * k["dbeta"] * (-1.0 / (B * Ln))        # centred form: dy = ka g' + kb (y - mean) - ka dbeta / R
+        L.check(lib.pcr_bn_affine_f32(L.ptr(y), L.ptr(g), L.ptr(k["ka"]), L.ptr(k["kb"]), L.ptr(kc), L.ptr(n["scale"]),
+                                      L.ptr(n["shift"]), L.ptr(n["mean"]), relu, L.ptr(dy), B, C, Ln, L.stream_ptr()),
+                "pcr_bn_affine_f32")
+        return dy, k["dgamma"], k["dbeta"], None, None
+
+
+def bn_act(y, bn, relu):
+    return BnAct.apply(y, bn.weight, bn.bias, bn, relu)
+
+
+class Bmm(Function):
+    """x (B,k,N), T (B,k,k) -> y[b] = T[b]^T x[b]  (torch.bmm(x^T, T)^T: the PointNet input / feature transforms)"""
+
+    @staticmethod
+    def forward(ctx, x, T):
+        x, T = _dev(x), _dev(T)
+        B, k, N = x.shape
+        y = _f32(B, k, N, device=x.device)
+        L.check(L.load().pcr_bmm_apply_f32(L.ptr(x), L.ptr(T), L.ptr(y), B, k, N, 0, L.stream_ptr()), "pcr_bmm_apply_f32")
+        ctx.save_for_backward(x, T)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, T = ctx.saved_tensors
+        B, k, N = x.shape
+        g = g.contiguous()
+        lib = L.load()
+        dx = dT = None
+        if ctx.needs_input_grad[0]:
+            dx = _f32(B, k, N, device=x.device)
+            L.check(lib.pcr_bmm_apply_f32(L.ptr(g), L.ptr(T), L.ptr(dx), B, k, N, 1, L.stream_ptr()), "pcr_bmm_apply_f32")
+        if ctx.needs_input_grad[1]:
+            dT = _f32(B, k, k, device=x.device)
+            L.check(lib.pcr_bmm_dt_f32(L.ptr(x), L.ptr(g), L.ptr(dT), B, k, N, L.stream_ptr()), "pcr_bmm_dt_f32")
+        return dx, dT

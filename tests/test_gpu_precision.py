@@ -113,7 +113,7 @@ def test_ragged_and_k_row_evaluation_agree_bit_for_bit_in_every_precision(prec):
 
 
 def test_attention_blocks_in_split_bf16_against_the_f32_path():
-    """the dense phases of the attention kernels (Q, message, feed-forward, K/V projection) in "bf16x3" mode against
+    """the dense phases of the attention apply kernel (Q, message, feed-forward, cov_final) in "bf16x3" mode against
     the f32 kernels on the same inputs: a different kernel (bits differ) within 2e-5 of the output's scale; a key-side
     state built in one arithmetic cannot be applied in the other (the per-cloud matrix is stored in its layout)"""
     import bench
