@@ -523,12 +523,20 @@ int pcr_channel_max_bwd_f32(const float *g, const int *arg, float *dx, int B, in
  * pcr_bn_affine_f32: g NULL: out = [relu](a0 y + a1) (a0 = scale, a1 = shift); g given: out = a0 g' + a1 (y - centre[c])
  *   + a2, the gradient with respect to y: (ka, kb, kc) with centre NULL, or its centred form (ka, kb, -ka dbeta / R) with
  *   centre = the batch mean. */
-int pcr_bn_sums_f32(const float *y, const float *g, const float *scale, const float *shift, int relu,
+int pcr_bn_sums_f32(const float *y, const float *g, const float *scale, const float *shift, int relu, float slope,
                     const float *centre, int centre_first, float *part, int nparts, int B, int C, int L,
                     pcr_stream_t stream);
 int pcr_bn_affine_f32(const float *y, const float *g, const float *a0, const float *a1, const float *a2,
-                      const float *scale, const float *shift, const float *centre, int relu, float *out, int B, int C,
-                      int L, pcr_stream_t stream);
+                      const float *scale, const float *shift, const float *centre, int relu, float slope, float *out,
+                      int B, int C, int L, pcr_stream_t stream);
+/* (relu != 0: the activation after the norm is z > 0 ? z : slope z -- ReLU with slope 0, LeakyReLU(0.2) with 0.2.)
+ * EdgeConv tail in training mode (models/dgcnn_orig.py:127-143) on the materialised pre-activation y (B,C,N K):
+ * pooled (B,C,N) = act(max_k (scale y + shift)), arg = the first k attaining it, yraw = y there; and the pooled gradient
+ * routed back to its edge: g (B,C,N K) = gp act'(pooled) at k == arg, 0 elsewhere. */
+int pcr_edge_pool_fwd_f32(const float *y, const float *scale, const float *shift, float slope, float *pooled, int *arg,
+                          float *yraw, int B, int C, int N, int K, pcr_stream_t stream);
+int pcr_edge_pool_route_f32(const float *gp, const float *pooled, const int *arg, float slope, float *g, int B, int C,
+                            int N, int K, pcr_stream_t stream);
 /* Per-cloud transforms (torch.bmm(x^T, T)^T, models/pointnet.py:109-111, 117-119): x (B,k,N), T (B,k,k) ->
  * y[b][j][n] = sum_i T[b][i][j] x[b][i][n]; transposed = 1 applies T^T instead (the backward's dx from dy);
  * pcr_bmm_dt_f32: dT[b][i][j] = sum_n x[b][i][n] dy[b][j][n].  k <= 128. */

@@ -17,11 +17,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // part [G][2][CP]: slice g of the clouds, channel c: (sum y, sum y^2)  -- or, with g2 given, (sum g', sum g' y) where
-// g' = g2 [scale y + shift > 0] (relu) | g2: the two sums of the BatchNorm backward
+// g' = g2 act'(scale y + shift), act' = 1 (z > 0) | slope (ReLU: slope 0, LeakyReLU(0.2): 0.2; `relu` = 0: g' = g2):
+// the two sums of the BatchNorm backward
 __global__ __launch_bounds__(256) void bn_sums_kernel(const float *__restrict__ y, const float *__restrict__ g2,
                                                       const float *__restrict__ scale, const float *__restrict__ shift,
-                                                      int relu, const float *__restrict__ centre, int centre_first,
-                                                      float *__restrict__ part, int B, int C, int CP, int L) {
+                                                      int relu, float slope, const float *__restrict__ centre,
+                                                      int centre_first, float *__restrict__ part, int B, int C, int CP,
+                                                      int L) {
   __shared__ float red[2][4];
   const int c = blockIdx.x, g = blockIdx.y, G = gridDim.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -36,7 +38,7 @@ __global__ __launch_bounds__(256) void bn_sums_kernel(const float *__restrict__ 
       const float v = row[l] - m0;
       if (grow) {
         float gv = grow[l];
-        if (relu && !(sc * row[l] + sh > 0.f)) gv = 0.f;
+        if (relu && !(sc * row[l] + sh > 0.f)) gv *= slope;
         s0 += gv;
         s1 += gv * v;
       } else {
@@ -64,16 +66,17 @@ __global__ __launch_bounds__(256) void bn_affine_kernel(const float *__restrict_
                                                         const float *__restrict__ a0, const float *__restrict__ a1,
                                                         const float *__restrict__ a2, const float *__restrict__ scale,
                                                         const float *__restrict__ shift, const float *__restrict__ centre,
-                                                        int relu, float *__restrict__ out, int C, int L, size_t total) {
+                                                        int relu, float slope, float *__restrict__ out, int C, int L,
+                                                        size_t total) {
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
     const int c = (int)((e / L) % C);
     const float v = y[e];
     if (!g) {
       const float z = a0[c] * v + a1[c];
-      out[e] = relu ? fmaxf(z, 0.f) : z;
+      out[e] = (relu && !(z > 0.f)) ? slope * z : z;
     } else {
       float gv = g[e];
-      if (relu && !(scale[c] * v + shift[c] > 0.f)) gv = 0.f;
+      if (relu && !(scale[c] * v + shift[c] > 0.f)) gv *= slope;
       out[e] = a0[c] * gv + a1[c] * (v - (centre ? centre[c] : 0.f)) + a2[c];
     }
   }
@@ -117,30 +120,92 @@ __global__ __launch_bounds__(256) void bmm_dt_kernel(const float *__restrict__ x
   if (lane == 0) dT[b * k * k + e] = s;
 }
 
+// EdgeConv tail in training mode (dgcnn_orig.py:127-143: BatchNorm2d over all edges, LeakyReLU, max over the k
+// neighbours) on the materialised pre-activation y (B,C,N k): pooled = act(max_k (scale y + shift)) -- the activation
+// is increasing, so it commutes with the max -- arg = the first k attaining it, yraw = y there.
+__global__ __launch_bounds__(256) void edge_pool_fwd_kernel(const float *__restrict__ y, const float *__restrict__ scale,
+                                                            const float *__restrict__ shift, float slope,
+                                                            float *__restrict__ pooled, int *__restrict__ arg,
+                                                            float *__restrict__ yraw, int C, int N, int K, size_t total) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {   // over (B,C,N)
+    const int c = (int)((e / N) % C);
+    const float *row = y + e * K;
+    const float sc = scale[c], sh = shift[c];
+    float best = sc * row[0] + sh, raw = row[0];
+    int bk = 0;
+    for (int k = 1; k < K; k++) {
+      const float v = sc * row[k] + sh;
+      if (v > best) {
+        best = v;
+        bk = k;
+        raw = row[k];
+      }
+    }
+    pooled[e] = best > 0.f ? best : slope * best;
+    arg[e] = bk;
+    yraw[e] = raw;
+  }
+}
+
+// the pooled gradient routed back to its edge: g[b][c][n K + k] = gp[b][c][n] act'(pooled) if k == arg else 0
+__global__ __launch_bounds__(256) void edge_pool_route_kernel(const float *__restrict__ gp, const float *__restrict__ pooled,
+                                                              const int *__restrict__ arg, float slope,
+                                                              float *__restrict__ g, int K, size_t total) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {   // over (B,C,N K)
+    const size_t o = e / K;
+    const int k = (int)(e - o * K);
+    g[e] = arg[o] == k ? gp[o] * (pooled[o] > 0.f ? 1.f : slope) : 0.f;
+  }
+}
+
 }  // namespace
 
+PCR_EXPORT int pcr_edge_pool_fwd_f32(const float *y, const float *scale, const float *shift, float slope, float *pooled,
+                                     int *arg, float *yraw, int B, int C, int N, int K, pcr_stream_t stream) {
+  if (!y || !scale || !shift || !pooled || !arg || !yraw || B < 1 || C < 1 || N < 1 || K < 1) return PCR_ERR_INVALID;
+  const size_t total = (size_t)B * C * N;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(edge_pool_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, pcr_s(stream), y, scale, shift, slope, pooled,
+                     arg, yraw, C, N, K, total);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_edge_pool_route_f32(const float *gp, const float *pooled, const int *arg, float slope, float *g, int B,
+                                       int C, int N, int K, pcr_stream_t stream) {
+  if (!gp || !pooled || !arg || !g || B < 1 || C < 1 || N < 1 || K < 1) return PCR_ERR_INVALID;
+  const size_t total = (size_t)B * C * N * K;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(edge_pool_route_kernel, dim3((unsigned)blocks), dim3(256), 0, pcr_s(stream), gp, pooled, arg, slope, g, K,
+                     total);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
 PCR_EXPORT int pcr_bn_sums_f32(const float *y, const float *g, const float *scale, const float *shift, int relu,
-                               const float *centre, int centre_first, float *part, int nparts, int B, int C, int L,
-                               pcr_stream_t stream) {
+                               float slope, const float *centre, int centre_first, float *part, int nparts, int B, int C,
+                               int L, pcr_stream_t stream) {
   if (!y || !part || nparts < 1 || B < 1 || C < 1 || L < 1 || nparts > 65535 || (g && relu && (!scale || !shift)))
     return PCR_ERR_INVALID;
   const int CP = (C + 31) & ~31;
-  hipLaunchKernelGGL(bn_sums_kernel, dim3(C, nparts), dim3(256), 0, pcr_s(stream), y, g, scale, shift, relu, centre,
-                     centre_first, part, B, C, CP, L);
+  hipLaunchKernelGGL(bn_sums_kernel, dim3(C, nparts), dim3(256), 0, pcr_s(stream), y, g, scale, shift, relu, slope,
+                     centre, centre_first, part, B, C, CP, L);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }
 
 PCR_EXPORT int pcr_bn_affine_f32(const float *y, const float *g, const float *a0, const float *a1, const float *a2,
-                                 const float *scale, const float *shift, const float *centre, int relu, float *out,
-                                 int B, int C, int L, pcr_stream_t stream) {
+                                 const float *scale, const float *shift, const float *centre, int relu, float slope,
+                                 float *out, int B, int C, int L, pcr_stream_t stream) {
   if (!y || !a0 || !a1 || !out || B < 1 || C < 1 || L < 1 || (g && (!a2 || (relu && (!scale || !shift)))))
     return PCR_ERR_INVALID;
   const size_t total = (size_t)B * C * L;
   size_t blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(bn_affine_kernel, dim3((unsigned)blocks), dim3(256), 0, pcr_s(stream), y, g, a0, a1, a2, scale, shift,
-                     centre, relu, out, C, L, total);
+                     centre, relu, slope, out, C, L, total);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }

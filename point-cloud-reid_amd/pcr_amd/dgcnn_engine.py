@@ -58,7 +58,11 @@ def forward(net, xyz, stages=None):
     the layer outputs x1..x4 and neighbour indices knn1..knn4 (for stage-wise parity checks)"""
     L.require_cuda(xyz)
     if net.training:
-        raise L.PcrError("DGCNN: the HIP path implements eval-mode inference; call .eval()")
+        # differentiable graph with BatchNorm batch statistics (pcr_amd/train_graph.py); eval mode below
+        from . import train_graph
+        if stages is not None:
+            raise L.PcrError("DGCNN: stage capture belongs to the eval-mode path")
+        return train_graph.dgcnn(net, xyz.contiguous().float())
     key = (str(xyz.device), E.param_version(net))
     if getattr(net, "_pcr_key", None) != key:
         object.__setattr__(net, "_pcr_plan", _Plan(net, xyz.device))

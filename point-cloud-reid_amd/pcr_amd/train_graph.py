@@ -106,6 +106,26 @@ def pointnet_encoder(enc, xyz):
     return xyz, _conv_bn(x, enc.conv3, enc.bn3, relu=False)
 
 
+def dgcnn(net, xyz):
+    """DGCNN.forward (models/dgcnn_orig.py:127-152) in training mode: xyz (B,3,N) -> (xyz, per-point features
+    (B,emb_dims,N)); feature-space kNN (no gradient, as torch.topk's indices) + EdgeConv with batch statistics"""
+    from . import dgcnn_engine
+    x = xyz.contiguous()
+    outs = []
+    f = x
+    for conv in (net.conv1, net.conv2, net.conv3, net.conv4):
+        idx = dgcnn_engine.knn_feat(f.detach().contiguous(), int(net.k))                 # (B,N,k) int32
+        w = conv[0].weight.view(conv[0].weight.shape[0], -1)                             # (Co, 2C): [W1 | W2]
+        c = w.shape[1] // 2
+        tab = TO.dense(f, torch.cat([w[:, :c], w[:, c:] - w[:, :c]], dim=0))              # (B, 2Co, N)
+        f = TO.EdgeConvTrain.apply(tab, idx, conv[1].weight, conv[1].bias, conv[1], float(conv[2].negative_slope))
+        outs.append(f)
+    cat = torch.cat(outs, dim=1)
+    c5 = net.conv5
+    y = TO.bn_act(TO.dense(cat, c5[0].weight.view(c5[0].weight.shape[0], -1)), c5[1], True, float(c5[2].negative_slope))
+    return xyz, y
+
+
 def downsample_points(mods, x):
     """ReIDNet.downsample ([LinearRes, LinearRes, Linear], ReIDNet.py:316-324) per point on (B,C,N) in training mode"""
     from mmdet3d.models.lanegcn_nets import LinearRes

@@ -680,12 +680,13 @@ class ChannelMax(Function):
 
 # --------------------------------------------------------------- PointNet pieces (csrc/train_bn_kernels.hip) --
 class BnAct(Function):
-    """[relu](BatchNorm(y)) with BATCH statistics over (B, L) per channel on a (B,C,L) tensor; running statistics are
-    updated in place as nn.BatchNorm1d does in training mode.  (The Point-Transformer path folds its BatchNorms into
-    the train-dense launches; PointNet's stand between layers that cannot take them.)"""
+    """act(BatchNorm(y)) with BATCH statistics over (B, L) per channel on a (B,C,L) tensor; act: None, "relu" or
+    ("leaky", slope).  Running statistics are updated in place as nn.BatchNorm1d does in training mode.  (The
+    Point-Transformer path folds its BatchNorms into the train-dense launches; PointNet's and DGCNN's stand between
+    layers that cannot take them.)"""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, bn, relu):
+    def forward(ctx, y, gamma, beta, bn, act, slope):
         y = _dev(y)
         B, C, Ln = y.shape
         lib = L.load()
@@ -694,8 +695,8 @@ class BnAct(Function):
         nparts = max(1, min(B, 2048 // max(C, 1)))
         part = _f32(nparts, 2, _c32(C), device=y.device)
         # sums of y - y[0][c][0] (first element of the channel as the offset): see pcr_bn_fwd_fin.shift0
-        L.check(lib.pcr_bn_sums_f32(L.ptr(y), None, None, None, 0, None, 1, L.ptr(part), nparts, B, C, Ln, L.stream_ptr()),
-                "pcr_bn_sums_f32")
+        L.check(lib.pcr_bn_sums_f32(L.ptr(y), None, None, None, 0, ctypes.c_float(0.0), None, 1, L.ptr(part), nparts, B, C, Ln,
+                                    L.stream_ptr()), "pcr_bn_sums_f32")
         n = bn_fwd_finalize(part, nparts, C, B * Ln, gamma, beta, bn.eps, bn.momentum,
                             bn.running_mean if bn.track_running_stats else None,
                             bn.running_var if bn.track_running_stats else None, shift0=y, shift0_stride=Ln)
@@ -705,32 +706,103 @@ class BnAct(Function):
                 bn.num_batches_tracked += 1
         z = _f32(B, C, Ln, device=y.device)
         L.check(lib.pcr_bn_affine_f32(L.ptr(y), None, L.ptr(n["scale"]), L.ptr(n["shift"]), None, None, None, None,
-                                      int(relu), L.ptr(z), B, C, Ln, L.stream_ptr()), "pcr_bn_affine_f32")
+                                      int(act), ctypes.c_float(slope), L.ptr(z), B, C, Ln, L.stream_ptr()),
+                "pcr_bn_affine_f32")
         ctx.save_for_backward(y, gamma)
-        ctx.norm, ctx.relu, ctx.nparts = n, int(relu), nparts
+        ctx.norm, ctx.act, ctx.slope, ctx.nparts = n, int(act), float(slope), nparts
         return z
 
     @staticmethod
     def backward(ctx, g):
         y, gamma = ctx.saved_tensors
-        n, relu, nparts = ctx.norm, ctx.relu, ctx.nparts
+        n, act, slope, nparts = ctx.norm, ctx.act, ctx.slope, ctx.nparts
         B, C, Ln = y.shape
         g = g.contiguous()
         lib = L.load()
         part = _f32(nparts, 2, _c32(C), device=y.device)
-        L.check(lib.pcr_bn_sums_f32(L.ptr(y), L.ptr(g), L.ptr(n["scale"]), L.ptr(n["shift"]), relu, L.ptr(n["mean"]), 0,
-                                    L.ptr(part), nparts, B, C, Ln, L.stream_ptr()), "pcr_bn_sums_f32")
+        L.check(lib.pcr_bn_sums_f32(L.ptr(y), L.ptr(g), L.ptr(n["scale"]), L.ptr(n["shift"]), act, ctypes.c_float(slope),
+                                    L.ptr(n["mean"]), 0, L.ptr(part), nparts, B, C, Ln, L.stream_ptr()), "pcr_bn_sums_f32")
         k = bn_bwd_finalize(part, nparts, C, B * Ln, gamma, n["mean"], n["invstd"], centre=n["mean"])
         dy = _f32(B, C, Ln, device=y.device)
         kc = k["ka"] * k["dbeta"] * (-1.0 / (B * Ln))        # centred form: dy = ka g' + kb (y - mean) - ka dbeta / R
         L.check(lib.pcr_bn_affine_f32(L.ptr(y), L.ptr(g), L.ptr(k["ka"]), L.ptr(k["kb"]), L.ptr(kc), L.ptr(n["scale"]),
-                                      L.ptr(n["shift"]), L.ptr(n["mean"]), relu, L.ptr(dy), B, C, Ln, L.stream_ptr()),
-                "pcr_bn_affine_f32")
-        return dy, k["dgamma"], k["dbeta"], None, None
+                                      L.ptr(n["shift"]), L.ptr(n["mean"]), act, ctypes.c_float(slope), L.ptr(dy), B, C, Ln,
+                                      L.stream_ptr()), "pcr_bn_affine_f32")
+        return dy, k["dgamma"], k["dbeta"], None, None, None
 
 
-def bn_act(y, bn, relu):
-    return BnAct.apply(y, bn.weight, bn.bias, bn, relu)
+def bn_act(y, bn, relu, slope=0.0):
+    """relu: apply the activation z > 0 ? z : slope z after the norm (slope 0: ReLU)"""
+    return BnAct.apply(y, bn.weight, bn.bias, bn, bool(relu), slope)
+
+
+class EdgeConvTrain(Function):
+    """One EdgeConv layer of DGCNN in training mode (dgcnn_orig.py:32-56, 127-143): Conv2d(2C -> Co, no bias) on
+    [f_j - f_i ; f_i] + BatchNorm2d over all B N k edges (batch statistics) + LeakyReLU + max over the k neighbours.
+    The conv is decomposed as in the inference path, W [f_j - f_i ; f_i] = W1 f_j + (W2 - W1) f_i: `tab` (B,2Co,N) =
+    [W1 f ; (W2 - W1) f] comes from ONE train-dense launch (autograd carries the table gradient back into the weight),
+    and the per-edge pre-activation y = tab[:Co][idx] + tab[Co:][i] is the first layer of the grouped set-abstraction
+    MLP with no coordinate term -- pcr_sa_l1_{fwd,bwd}_f32 with the points as their own centres."""
+
+    @staticmethod
+    def forward(ctx, tab, idx, gamma, beta, bn, slope):
+        lib = L.load()
+        tab, idx = _dev(tab), idx.contiguous()
+        L.require_i32(idx)
+        B, two_co, N = tab.shape
+        Co = two_co // 2
+        K = idx.shape[2]
+        dev = tab.device
+        if bn.momentum is None:
+            raise L.PcrError("BatchNorm with momentum=None (cumulative average) is not supported by the HIP training path")
+        xyz0 = torch.zeros((B, N, 3), dtype=torch.float32, device=dev)       # (no coordinate term: zero weights below)
+        wa0 = torch.zeros((Co, 3), dtype=torch.float32, device=dev)
+        b0 = torch.zeros((Co,), dtype=torch.float32, device=dev)
+        y = _f32(B, Co, N * K, device=dev)
+        st = _f32(B, 2, _c32(Co), device=dev)
+        L.check(lib.pcr_sa_l1_fwd_f32(L.ptr(xyz0), L.ptr(idx), L.ptr(tab), L.ptr(wa0), L.ptr(b0), L.ptr(y), L.ptr(st),
+                                      B, N, N, K, Co, L.stream_ptr()), "pcr_sa_l1_fwd_f32")
+        R = B * N * K
+        n = bn_fwd_finalize(st, B, Co, R, gamma, beta, bn.eps, bn.momentum,
+                            bn.running_mean if bn.track_running_stats else None,
+                            bn.running_var if bn.track_running_stats else None)
+        if bn.track_running_stats:
+            torch.autograd.graph.increment_version([bn.running_mean, bn.running_var])
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+        pooled = _f32(B, Co, N, device=dev)
+        arg = torch.empty((B, Co, N), dtype=torch.int32, device=dev)
+        yraw = _f32(B, Co, N, device=dev)
+        L.check(lib.pcr_edge_pool_fwd_f32(L.ptr(y), L.ptr(n["scale"]), L.ptr(n["shift"]), ctypes.c_float(slope), L.ptr(pooled),
+                                          L.ptr(arg), L.ptr(yraw), B, Co, N, K, L.stream_ptr()), "pcr_edge_pool_fwd_f32")
+        ctx.save_for_backward(idx, y, pooled, arg, yraw, gamma, xyz0)
+        ctx.norm, ctx.slope, ctx.dims = n, float(slope), (B, Co, N, K)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, gp):
+        lib = L.load()
+        idx, y, pooled, arg, yraw, gamma, xyz0 = ctx.saved_tensors
+        n, slope = ctx.norm, ctx.slope
+        B, Co, N, K = ctx.dims
+        dev = y.device
+        gp = gp.contiguous()
+        R = B * N * K
+        # the two sums of the BatchNorm backward: the routed gradient is non-zero on ONE edge per (channel, point)
+        nparts = max(1, min(B, 2048 // max(Co, 1)))
+        part = _f32(nparts, 2, _c32(Co), device=dev)
+        L.check(lib.pcr_bn_sums_f32(L.ptr(yraw), L.ptr(gp), L.ptr(n["scale"]), L.ptr(n["shift"]), 1, ctypes.c_float(slope),
+                                    L.ptr(n["mean"]), 0, L.ptr(part), nparts, B, Co, N, L.stream_ptr()), "pcr_bn_sums_f32")
+        k = bn_bwd_finalize(part, nparts, Co, R, gamma, n["mean"], n["invstd"], centre=n["mean"])
+        g = _f32(B, Co, N * K, device=dev)
+        L.check(lib.pcr_edge_pool_route_f32(L.ptr(gp), L.ptr(pooled), L.ptr(arg), ctypes.c_float(slope), L.ptr(g), B, Co, N, K,
+                                            L.stream_ptr()), "pcr_edge_pool_route_f32")
+        dtab = _f32(B, 2 * Co, N, device=dev)
+        dwa_p = _f32(B, Co, 4, device=dev)
+        L.check(lib.pcr_sa_l1_bwd_f32(L.ptr(xyz0), L.ptr(idx), L.ptr(g), L.ptr(y), L.ptr(k["ka"]), L.ptr(k["kb"]), L.ptr(k["kc"]),
+                                      L.ptr(dtab), L.ptr(dwa_p), B, N, N, K, Co, L.stream_ptr()), "pcr_sa_l1_bwd_f32")
+        return dtab, None, k["dgamma"], k["dbeta"], None, None
+
 
 
 class Bmm(Function):

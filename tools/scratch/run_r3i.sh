@@ -1,7 +1,7 @@
 mkdir -p gpurun_out/r3i
-python -m pytest tests/test_gpu_train_variants.py tests/test_gpu_model.py tests/test_gpu_train_ops.py -q -s -m gpu > gpurun_out/r3i/new.log 2>&1; echo "tests rc $?"
+python -m pytest tests/test_gpu_train_variants.py -q -s -m gpu > gpurun_out/r3i/new.log 2>&1; echo "tests rc $?"
 grep -E "passed|failed|Error" gpurun_out/r3i/new.log | cut -c1-600 | tail -12
-grep -o '{"tag": "pointnet".*}' gpurun_out/r3i/new.log | python -c "
+grep -o '{"tag": "dgcnn".*}' gpurun_out/r3i/new.log | python -c "
 import sys,json
 for ln in sys.stdin:
     d=json.loads(ln); print('loss',d['loss'],d['ref_loss'],'gn',d['grad_norm'],d['ref_grad_norm'])
