@@ -213,6 +213,10 @@ long pcr_sa_tile_ws_ints(int B, int S, int K, int c2, int c3);
  * SA layer (pcr_sa_mlp_f32 runs it itself unless pq_ready is set). */
 int pcr_dense_pm_f32(const float *x, const float *wp, float *y, int B, int cin, int cout, int L,
                      int x_point_major, pcr_stream_t stream);
+/* the same map on the bf16 matrix core: wp_bf = pcr_pack_weight_bf16x2_f32 image of W, precision = PCR_PREC_BF16X3 or
+ * PCR_PREC_BF16 */
+int pcr_dense_pm_prec_f32(const float *x, const float *wp_bf, float *y, int B, int cin, int cout, int L,
+                          int x_point_major, int precision, pcr_stream_t stream);
 
 /* Linear-attention block shared by Self_Attention (models/pointnet2_utils.py:90-114), FP_SA
  * (:407-437) and corss_attention (models/attention.py:192-219), in two kernels.

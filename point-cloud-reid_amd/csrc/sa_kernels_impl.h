@@ -950,7 +950,9 @@ struct DensePmArgs {
 
 // NR: cout-block rounds per wave (2 when cout > 128).  X and Y share one LDS buffer (barrier between the
 // k-loop and the epilogue), so a 128 -> 128 table needs 33 KB and four workgroups fit a CU.
-template <int NR>
+// PREC: 0 = f32-input MFMA; 1 / 2 = the bf16 matrix core (split / plain; wp = the bf16 image, windows of 256 couts are
+// 8 cout blocks = 1024 sixteen-byte units further in)
+template <int NR, int PREC = 0>
 __global__ __launch_bounds__(kThreads) void dense_pm_kernel(DensePmArgs a) {
   constexpr int TB = 2, T = 64, RP = 65;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -965,8 +967,8 @@ __global__ __launch_bounds__(kThreads) void dense_pm_kernel(DensePmArgs a) {
   if (a.x_pm) load_tile_pm(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
   else load_tile(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
   __syncthreads();
-  tile_dense2<TB, NR>(X, cinP, a.wp + (size_t)w0 * 8, ceil32(wc), true, [&](float v, int o, int t) { X[o * RP + t] = v; },
-                      nullptr, nullptr, DenseNoHook(), ceil32(cout));
+  tile_dense2p<PREC, TB, NR>(X, cinP, a.wp + (size_t)w0 * (PREC == 0 ? 8 : 16), ceil32(wc), true,
+                             [&](float v, int o, int t) { X[o * RP + t] = v; }, nullptr, nullptr, DenseNoHook(), ceil32(cout));
   __syncthreads();
   float *out = a.y + (b * a.L + t0) * (size_t)cout + w0;
   if ((cout & 3) == 0) {
@@ -1310,9 +1312,10 @@ PCR_EXPORT long pcr_sa_tile_ws_ints(int B, int S, int K, int c2, int c3) {
   return (long)rag_ws_ints(B, maxT, rows);
 }
 
-PCR_EXPORT int pcr_dense_pm_f32(const float *x, const float *wp, float *y, int B, int cin, int cout, int L,
-                                int x_point_major, pcr_stream_t stream) {
-  if (!x || !wp || !y || B < 0 || cin < 1 || cout < 1 || cout > 1024 || L < 1) return PCR_ERR_INVALID;
+static int dense_pm_launch(const float *x, const float *wp, float *y, int B, int cin, int cout, int L, int x_point_major,
+                           int precision, pcr_stream_t stream) {
+  if (!x || !wp || !y || B < 0 || cin < 1 || cout < 1 || cout > 1024 || L < 1 || precision < 0 || precision > 2)
+    return PCR_ERR_INVALID;
   if (cout > 256 && (cout & 3)) return PCR_ERR_INVALID;   // windows of 256 couts keep the 16-byte store path
   if (B == 0) return PCR_OK;
   if (B > 65535) return PCR_ERR_INVALID;
@@ -1322,17 +1325,35 @@ PCR_EXPORT int pcr_dense_pm_f32(const float *x, const float *wp, float *y, int B
   size_t lds = (size_t)rows * 65 * sizeof(float);
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
   const dim3 grid((L + 63) / 64, B, (cout + 255) / 256);
+#define PCR_PM(NRv, PRv)                                                                          \
+  do {                                                                                            \
+    static bool ok = allow_big_lds(dense_pm_kernel<NRv, PRv>);                                    \
+    (void)ok;                                                                                     \
+    hipLaunchKernelGGL((dense_pm_kernel<NRv, PRv>), grid, dim3(kThreads), lds, pcr_s(stream), d); \
+  } while (0)
   if (cout > 128) {
-    static bool ok = allow_big_lds(dense_pm_kernel<2>);
-    (void)ok;
-    hipLaunchKernelGGL(dense_pm_kernel<2>, grid, dim3(kThreads), lds, pcr_s(stream), d);
+    if (precision == 0) PCR_PM(2, 0);
+    else if (precision == 1) PCR_PM(2, 1);
+    else PCR_PM(2, 2);
   } else {
-    static bool ok = allow_big_lds(dense_pm_kernel<1>);
-    (void)ok;
-    hipLaunchKernelGGL(dense_pm_kernel<1>, grid, dim3(kThreads), lds, pcr_s(stream), d);
+    if (precision == 0) PCR_PM(1, 0);
+    else if (precision == 1) PCR_PM(1, 1);
+    else PCR_PM(1, 2);
   }
+#undef PCR_PM
   PCR_CHECK_LAUNCH();
   return PCR_OK;
+}
+
+PCR_EXPORT int pcr_dense_pm_f32(const float *x, const float *wp, float *y, int B, int cin, int cout, int L,
+                                int x_point_major, pcr_stream_t stream) {
+  return dense_pm_launch(x, wp, y, B, cin, cout, L, x_point_major, 0, stream);
+}
+
+PCR_EXPORT int pcr_dense_pm_prec_f32(const float *x, const float *wp_bf, float *y, int B, int cin, int cout, int L,
+                                     int x_point_major, int precision, pcr_stream_t stream) {
+  if (precision != 1 && precision != 2) return PCR_ERR_INVALID;
+  return dense_pm_launch(x, wp_bf, y, B, cin, cout, L, x_point_major, precision, stream);
 }
 
 PCR_EXPORT int pcr_sa_mlp_f32(const pcr_sa_params *pp, pcr_stream_t stream) {

@@ -211,6 +211,7 @@ class SaPlan:
             else:
                 stacked = w1[:, 3:3 + D] * sc1
             self.wpq = pack_weight(stacked.float(), device)
+            self.wpq_bf = pack_weight_bf(stacked.float(), device)
 
     def run(self, xyz, feat, idx, centre_idx=None, cnt=None, out_point_major=False):
         """cnt (B,S) int32: genuine-hit counts of a ball query (ops.ball_query_cnt); when given (mode 1) the
@@ -261,8 +262,13 @@ class SaPlan:
                 # the per-point tables of the decomposed first layer, as its own (profiled) launch
                 with _prof("sa_tables[D=%d,out=%d,N=%d]" % (D, pqw, N), 2.0 * B * N * D * pqw,
                            4.0 * B * N * (D + pqw)):
-                    L.check(L.load().pcr_dense_pm_f32(L.ptr(feat), L.ptr(self.wpq), L.ptr(ws), B, D, pqw, N,
-                                                      int(feat_pm), L.stream_ptr()), "pcr_dense_pm_f32")
+                    if PRECISION == "f32":
+                        L.check(L.load().pcr_dense_pm_f32(L.ptr(feat), L.ptr(self.wpq), L.ptr(ws), B, D, pqw, N,
+                                                          int(feat_pm), L.stream_ptr()), "pcr_dense_pm_f32")
+                    else:   # the tables on the bf16 matrix core too (the layer-1 MFMAs on the coordinates stay f32)
+                        L.check(L.load().pcr_dense_pm_prec_f32(L.ptr(feat), L.ptr(self.wpq_bf), L.ptr(ws), B, D, pqw, N,
+                                                               int(feat_pm), PRECISIONS[PRECISION], L.stream_ptr()),
+                                "pcr_dense_pm_prec_f32")
                 p.pq_ready = 1
         c1, c2, c3 = self.couts
         flops = 2.0 * B * S * K * (self.cin * c1 + c1 * c2 + c2 * c3)

@@ -53,7 +53,9 @@ def test_point_sa_module_stages_bit_exact_indices():
         rx, ro = MO.ssg_sa_layer(sd, xyz, feats, 96, 0.5, 16, st, "s")
     assert (idx.cpu().numpy() == st["s_fps"].numpy()).all()
     assert torch.equal(new_xyz.cpu(), rx)
-    assert float((out.cpu() - ro).abs().max()) < 2e-5
+    # (default arithmetic bf16x3: tables and layers 2 / 3 on the bf16 matrix core; the f32 mode of the same layers is held
+    # to 2e-6 of the output's scale in tests/test_gpu_precision.py)
+    assert float((out.cpu() - ro).abs().max()) < 5e-5
     # stand-alone grouper = same indices as the C oracle
     from mmdet3d.ops import QueryAndGroup
     grouped, gidx = QueryAndGroup(0.5, 16, return_grouped_idx=True)(xyz.cuda(), new_xyz, feats.cuda())
@@ -144,7 +146,7 @@ def test_point_sa_module_msg_two_scales_match_oracle():
                 outs.append(h.max(dim=3)[0])
         want = torch.cat(outs, dim=1)
         assert out.shape == (2, 96, 64)
-        assert float((out.cpu() - want).abs().max()) < 2e-5, dilated
+        assert float((out.cpu() - want).abs().max()) < 5e-5, dilated
 
 
 def test_group_all_and_base_module_contract():
