@@ -258,11 +258,14 @@ __device__ __forceinline__ uint32_t dpp_max_u32(uint32_t v) {
   return ab > cd ? ab : cd;
 }
 
+// The picked point's coordinates come straight out of the register file: the pick `old` is wave-uniform, so its slot
+// (old / 64) selects a register by a SCALAR switch and v_readlane fetches lane old % 64 of it.  (Round 2 kept a
+// {x,y,z,-} copy of the cloud in LDS for one broadcast read per pick: 16 KB per wave, which held a CU to ten waves --
+// 2.5 per SIMD, 4096 clouds = 1.6 rounds -- and put an LDS round trip on every pick's critical path; without it four
+// waves share a SIMD and the chip takes 4096 clouds in one round.)
 template <int PP>   // point PAIRS per lane: n <= 128 * PP
 __global__ __launch_bounds__(64) void fps_wave_kernel(const float *__restrict__ xyz, float *__restrict__ temp,
                                                       int *__restrict__ idxs, int n, int m, int block, int logb) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  f32x4 *sp = reinterpret_cast<f32x4 *>(smem_raw);   // [n] {x, y, z, -}: one 16-byte broadcast read per pick
   const int lane = threadIdx.x;
   const size_t cloud = blockIdx.x;
   xyz += cloud * n * 3;
@@ -282,19 +285,32 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(const float *__restrict__ 
     py[p >> 1][p & 1] = ok ? y : 0.f;
     pz[p >> 1][p & 1] = ok ? z : 0.f;
     t[p] = ok ? __float_as_uint(tk) : 0u;   // min(d, 0) = 0: a point beyond n never beats a real one (low = 0)
-    if (ok) sp[k] = f32x4{x, y, z, 0.f};
     const uint32_t tr = (uint32_t)k & (uint32_t)(block - 1);
     const uint32_t rev = logb ? (__brev(tr) >> (32 - logb)) : 0u;
     low[p] = ok ? ((((uint32_t)(block - 1) - rev) << 22) | (0x3FFFFFu - (uint32_t)k)) : 0u;
     asm volatile("" : "+v"(low[p]));   // keep the value in a register (else it is re-derived from masks every step)
   }
-  __builtin_amdgcn_s_waitcnt(0xc07f);   // this wave's LDS writes (lgkmcnt(0)); there is no other wave
-  __builtin_amdgcn_wave_barrier();
   int old = 0;
   if (lane == 0) idxs[0] = 0;
   for (int j = 1; j < m; j++) {
-    const f32x4 o = sp[old];
-    const f32x2 x1 = {o[0], o[0]}, y1 = {o[1], o[1]}, z1 = {o[2], o[2]};
+    const int slot = __builtin_amdgcn_readfirstlane(old >> 6), ln = __builtin_amdgcn_readfirstlane(old & 63);
+    float ox = 0.f, oy = 0.f, oz = 0.f;
+#define PCR_FPS_PICK(P)                                                                                      \
+  case P:                                                                                                    \
+    if constexpr (P < 2 * PP) {                                                                              \
+      ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px[(P) >> 1][(P)&1]), ln));               \
+      oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py[(P) >> 1][(P)&1]), ln));               \
+      oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[(P) >> 1][(P)&1]), ln));               \
+    }                                                                                                        \
+    break;
+    switch (slot) {
+      PCR_FPS_PICK(0) PCR_FPS_PICK(1) PCR_FPS_PICK(2) PCR_FPS_PICK(3) PCR_FPS_PICK(4) PCR_FPS_PICK(5) PCR_FPS_PICK(6)
+      PCR_FPS_PICK(7) PCR_FPS_PICK(8) PCR_FPS_PICK(9) PCR_FPS_PICK(10) PCR_FPS_PICK(11) PCR_FPS_PICK(12) PCR_FPS_PICK(13)
+      PCR_FPS_PICK(14) PCR_FPS_PICK(15)
+      default: break;
+    }
+#undef PCR_FPS_PICK
+    const f32x2 x1 = {ox, ox}, y1 = {oy, oy}, z1 = {oz, oz};
     uint32_t mx = 0u;
 #pragma unroll
     for (int p = 0; p < PP; p++) {
@@ -338,7 +354,7 @@ int fps_launch(bool dist, const float *data, float *temp, int *idx, int B, int N
   while ((2 << logb) <= N && logb < 10) logb++;  // block = min(1024, 2^floor(log2 N))
   int block = 1 << logb;
   if (!dist && N <= 1024 && M > 1) {
-    const size_t lds_wave = (size_t)N * 16;
+    const size_t lds_wave = 0;
     dim3 gw(B), bw(64);
 #define PCR_FPS_WAVE(PPv) hipLaunchKernelGGL((fps_wave_kernel<PPv>), gw, bw, lds_wave, st, data, temp, idx, N, M, block, logb)
     if (N <= 128) PCR_FPS_WAVE(1);
