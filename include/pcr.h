@@ -380,6 +380,17 @@ int pcr_train_groups(int B, int L);
 /* ... of a pcr_tdense_bwd_f32 launch that accumulates dW (cout x cin; cout = 0: no dW): wide layers on short clouds use
  * fewer workgroups, each accumulating over more clouds */
 int pcr_train_groups_bwd(int B, int L, int cout, int cin);
+/* ... of THE launch a parameter block describes (ABI 8): the narrow grouped-MLP layers (32 / 64 channels, L a multiple
+ * of 32) run through wave-autonomous kernels with their own grid (csrc/train_stream_kernels.hip); every other launch
+ * returns what the two functions above return.  Size stats / dstats / dwp / dbp with these. */
+struct pcr_tdense_fwd;
+struct pcr_tdense_bwd;
+int pcr_tdense_fwd_groups(const struct pcr_tdense_fwd *p);
+int pcr_tdense_bwd_groups(const struct pcr_tdense_bwd *p);
+/* launch policy: train-dense launches with fewer than n 32-token blocks (B * L / 32) stay on the tile kernels
+ * (default 8192); returns the previous value, n < 0 only reads it.  Process-wide; tests use it to run small shapes
+ * through the wave-autonomous kernels. */
+int pcr_set_stream_min_blocks(int n);
 
 /* y = [relu](W f([x ; x2]) + bias [+ res]),  f(x) = [relu](isc x + ish) on the cin1 channels of x (the previous
  * layer's BatchNorm + ReLU, applied while the tile is loaded; isc NULL = identity).  stats (optional): partials
@@ -400,7 +411,7 @@ int pcr_tdense_fwd_f32(const pcr_tdense_fwd *p, pcr_stream_t stream);
 /* Backward of that layer.  dy is formed while the tiles are loaded: dy_mode 0: dy = g; 1: dy = ka g + kb y + kc
  * (BatchNorm backward, constants from pcr_bn_bwd_finalize_f32; y = the layer's stored raw output); 2: dy = g [y > 0]
  * (layer stored after its ReLU); 3: as 1 with g = the gradient gp (B,cout,S) of the max-pooled output routed to row
- * argmax (B,cout,S) of every centre where pooled (B,cout,S) > 0 (L = S K).
+ * argmax (B,cout,S) of every centre where pooled (B,cout,S) > 0 (L = S K; pooled NULL: gp is already zero there).
  * Outputs (each optional): dx / dx2 = W^T dy masked by f(x) > 0 when in_relu (wpT = packed W^T); dstats = partials
  * [groups][2][ceil32(cin1)] of sum dx and sum dx * (raw x) for the next BatchNorm backward (iinv = 1 / isc);
  * dwp = partials [groups][ceil32(cout)][ceil32(cin)] of dy f(x)^T, dbp = partials [groups][ceil32(cout)] of sum dy
@@ -471,9 +482,10 @@ int pcr_sa_l1_bwd_f32(const float *xyz, const int *idx, const float *g, const fl
  * = the raw y at that row (what the backward's BatchNorm sums need) */
 int pcr_sa_pool_fwd_f32(const float *y, const float *scale, const float *shift, float *pooled, int *argmax, float *ymax,
                         int B, int C, int S, int K, pcr_stream_t stream);
-/* partials [B][2][ceil32(C)] of S1 = sum gp [pooled > 0], S2 = sum gp [pooled > 0] ymax for pcr_bn_bwd_finalize_f32 */
-int pcr_sa_pool_bwd_stats_f32(const float *gp, const float *pooled, const float *ymax, float *part, int B, int C, int S,
-                              pcr_stream_t stream);
+/* partials [B][2][ceil32(C)] of S1 = sum gp [pooled > 0], S2 = sum gp [pooled > 0] ymax for pcr_bn_bwd_finalize_f32;
+ * gz (optional, (B,C,S)) = gp [pooled > 0], the routed gradient: pass it as g with pooled = NULL to dy_mode 3 */
+int pcr_sa_pool_bwd_stats_f32(const float *gp, const float *pooled, const float *ymax, float *part, float *gz, int B, int C,
+                              int S, pcr_stream_t stream);
 
 /* LayerNorm / GroupNorm over the channels of every token of x (B,C,L) (G groups of C/G consecutive channels; LayerNorm:
  * G = 1), y = [relu]((x - mean) rstd gamma + beta [+ res]); mean / rstd (B,G,L) are kept for the backward.  Backward: dx and

@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "tile_dense.h"
+#include "train_stream.h"
 
 namespace {
 
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(kThreads) void tdense_fwd_kernel(TFwd a) {
       const float sc = s_isc[c], sh = s_ish[c];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        v[j] = v[j] * sc + sh;
+        v[j] = fmaf(v[j], sc, sh);
         if (in_relu) v[j] = fmaxf(v[j], 0.f);
       }
     }
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(kThreads) void tdense_fwd_kernel(TFwd a) {
     const bool first = c < cin1;
     float v = (first ? xb + (size_t)c * L : x2b + (size_t)(c - cin1) * L)[tg];
     if (aff && first) {
-      v = v * s_isc[c] + s_ish[c];
+      v = fmaf(v, s_isc[c], s_ish[c]);
       if (in_relu) v = fmaxf(v, 0.f);
     }
     return v;
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(kThreads) void tdense_fwd_kernel(TFwd a) {
           const float sc = s_isc[c], sh = s_ish[c];
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            v[j] = v[j] * sc + sh;
+            v[j] = fmaf(v[j], sc, sh);
             if (in_relu) v[j] = fmaxf(v[j], 0.f);
           }
         }
@@ -352,7 +353,8 @@ __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
   const float *gb = mode == 3 ? a.g + b * a.cout * S : a.g + b * a.cout * L;
   const float *yb = a.y ? a.y + b * a.cout * L : gb;
   const int *amb = mode == 3 ? a.argmax + b * a.cout * S : nullptr;
-  const float *plb = mode == 3 ? a.pooled + b * a.cout * S : nullptr;
+  const bool has_pl = a.pooled != nullptr;      // (null: g is already zero where the pooled activation is)
+  const float *plb = (mode == 3 && has_pl) ? a.pooled + b * a.cout * S : nullptr;
   const float *xb = a.x + b * a.cin1 * L;
   const float *x2b = a.x2 ? a.x2 + b * a.cin2 * L : xb;
   const bool vec = (L & 3) == 0;
@@ -362,7 +364,7 @@ __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
     if (mode != 3) return gb[(size_t)c * L + tg];
     const int s = tg / K, k = tg - s * K;
     const size_t o = (size_t)c * S + s;
-    return (amb[o] == k && plb[o] > 0.f) ? gb[o] : 0.f;
+    return (amb[o] == k && (!has_pl || plb[o] > 0.f)) ? gb[o] : 0.f;
   };
   auto dy4 = [&](int c, int tg) {
     f32x4 g;
@@ -371,7 +373,7 @@ __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
       const int s = tg / K, k = tg - s * K;
       const size_t o = (size_t)c * S + s;
       const int am = amb[o] - k;
-      const float gv = plb[o] > 0.f ? gb[o] : 0.f;
+      const float gv = (!has_pl || plb[o] > 0.f) ? gb[o] : 0.f;
 #pragma unroll
       for (int j = 0; j < 4; j++) g[j] = am == j ? gv : 0.f;
     } else {
@@ -387,7 +389,7 @@ __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
     } else {
       const float ka = s_ka[c], kb = s_kb[c], kc = s_kc[c];
 #pragma unroll
-      for (int j = 0; j < 4; j++) r[j] = ka * g[j] + kb * yv[j] + kc;
+      for (int j = 0; j < 4; j++) r[j] = fmaf(ka, g[j], fmaf(kb, yv[j], kc));
     }
     return r;
   };
@@ -396,7 +398,7 @@ __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
     if (mode == 0) return g;
     const float yv = yb[(size_t)c * L + tg];
     if (mode == 2) return yv > 0.f ? g : 0.f;
-    return s_ka[c] * g + s_kb[c] * yv + s_kc[c];
+    return fmaf(s_ka[c], g, fmaf(s_kb[c], yv, s_kc[c]));
   };
   auto a4 = [&](int c, int tg) {
     const bool first = c < cin1;
@@ -405,7 +407,7 @@ __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
       const float sc = s_isc[c], sh = s_ish[c];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        v[j] = v[j] * sc + sh;
+        v[j] = fmaf(v[j], sc, sh);
         if (in_relu) v[j] = fmaxf(v[j], 0.f);
       }
     }
@@ -415,7 +417,7 @@ __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
     const bool first = c < cin1;
     float v = (first ? xb + (size_t)c * L : x2b + (size_t)(c - cin1) * L)[tg];
     if (aff && first) {
-      v = v * s_isc[c] + s_ish[c];
+      v = fmaf(v, s_isc[c], s_ish[c]);
       if (in_relu) v = fmaxf(v, 0.f);
     }
     return v;
@@ -445,7 +447,7 @@ __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
       if (mode == 3) {
         const int sc = tg / K, k = tg - sc * K;
         const size_t o = (size_t)cc * S + sc;
-        pg[u] = f32x4{__int_as_float(amb[o] - k), plb[o], gb[o], 0.f};
+        pg[u] = f32x4{__int_as_float(amb[o] - k), has_pl ? plb[o] : 1.f, gb[o], 0.f};
       } else {
         pg[u] = ld4(gb + (size_t)cc * L + tg);
       }
@@ -481,7 +483,7 @@ __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
         } else {
           const float ka = s_ka[c], kb = s_kb[c], kc = s_kc[c];
 #pragma unroll
-          for (int j = 0; j < 4; j++) r[j] = ka * g[j] + kb * py[u][j] + kc;
+          for (int j = 0; j < 4; j++) r[j] = fmaf(ka, g[j], fmaf(kb, py[u][j], kc));
         }
       }
       float *d = DY + c * RP + 4 * q;
@@ -500,7 +502,7 @@ __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
         const float sc = s_isc[c], sh = s_ish[c];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          v[j] = v[j] * sc + sh;
+          v[j] = fmaf(v[j], sc, sh);
           if (in_relu) v[j] = fmaxf(v[j], 0.f);
         }
       }
@@ -528,7 +530,7 @@ __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
         if constexpr (M == 3) {
           const int sc = tg / K, k = tg - sc * K;
           const size_t o = (size_t)cc * S + sc;
-          gq[u] = f32x4{__int_as_float(amb[o] - k), plb[o], gb[o], 0.f};
+          gq[u] = f32x4{__int_as_float(amb[o] - k), has_pl ? plb[o] : 1.f, gb[o], 0.f};
         } else {
           gq[u] = ld4(gb + (size_t)cc * L + tg);
         }
@@ -553,7 +555,7 @@ __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
         } else {
           const float ka = s_ka[cc], kb = s_kb[cc], kc = s_kc[cc];
 #pragma unroll
-          for (int j = 0; j < 4; j++) r[j] = ka * g[j] + kb * yq[u][j] + kc;
+          for (int j = 0; j < 4; j++) r[j] = fmaf(ka, g[j], fmaf(kb, yq[u][j], kc));
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) r[j] = ok ? r[j] : 0.f;
@@ -591,7 +593,7 @@ __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
         f32x4 v = xq[u];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          float t = (aff && first) ? v[j] * sc + sh : v[j];
+          float t = (aff && first) ? fmaf(v[j], sc, sh) : v[j];
           t = rl ? fmaxf(t, 0.f) : t;
           v[j] = ok ? t : 0.f;
         }
@@ -625,7 +627,7 @@ __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
     gb = mode == 3 ? a.g + b * a.cout * S : a.g + b * a.cout * L;
     yb = a.y ? a.y + b * a.cout * L : gb;
     amb = mode == 3 ? a.argmax + b * a.cout * S : nullptr;
-    plb = mode == 3 ? a.pooled + b * a.cout * S : nullptr;
+    plb = (mode == 3 && has_pl) ? a.pooled + b * a.cout * S : nullptr;
     xb = a.x + b * a.cin1 * L;
     x2b = a.x2 ? a.x2 + b * a.cin2 * L : xb;
     __syncthreads();     // the previous cloud's last tile has been consumed
@@ -1055,6 +1057,18 @@ PCR_EXPORT int pcr_train_groups_bwd(int B, int L, int cout, int cin) {
   return gx * wg_cloud_rows(B, gx, pf);
 }
 
+PCR_EXPORT int pcr_tdense_fwd_groups(const pcr_tdense_fwd *p) {
+  if (!p) return 0;
+  if (pcr_ts_fwd_ok(p)) return pcr_ts_fwd_grid(p, nullptr);
+  return pcr_train_groups(p->B, p->L);
+}
+
+PCR_EXPORT int pcr_tdense_bwd_groups(const pcr_tdense_bwd *p) {
+  if (!p) return 0;
+  if (pcr_ts_bwd_ok(p)) return pcr_ts_bwd_grid(p, nullptr);
+  return pcr_train_groups_bwd(p->B, p->L, p->dwp ? p->cout : 0, p->cin1 + p->cin2);
+}
+
 PCR_EXPORT int pcr_pack_weight_dev_f32(const float *w, int rows, int cols, int ld, int transpose, float *packed,
                                        pcr_stream_t stream) {
   if (!w || !packed || rows < 1 || cols < 1 || ld < cols || transpose < 0 || transpose > 2) return PCR_ERR_INVALID;
@@ -1082,6 +1096,7 @@ PCR_EXPORT int pcr_tdense_fwd_f32(const pcr_tdense_fwd *p, pcr_stream_t stream) 
   if (p->stats && p->cout > 256) return PCR_ERR_INVALID;   // (statistics are taken by one thread per cout row)
   if (p->B == 0) return PCR_OK;
   if (p->B > 65535) return PCR_ERR_INVALID;
+  if (pcr_ts_fwd_ok(p)) return pcr_ts_fwd_launch(p, pcr_s(stream));
   TFwd a;
   a.x = p->x; a.x2 = p->cin2 ? p->x2 : nullptr; a.cin1 = p->cin1; a.cin2 = p->cin2;
   a.isc = p->isc; a.ish = p->ish; a.in_relu = p->in_relu;
@@ -1129,11 +1144,12 @@ PCR_EXPORT int pcr_tdense_bwd_f32(const pcr_tdense_bwd *p, pcr_stream_t stream) 
     return PCR_ERR_INVALID;
   if ((p->dy_mode == 1 || p->dy_mode == 3) && (!p->ka || !p->kb || !p->kc || !p->y)) return PCR_ERR_INVALID;
   if (p->dy_mode == 2 && !p->y) return PCR_ERR_INVALID;
-  if (p->dy_mode == 3 && (!p->argmax || !p->pooled || p->K < 1 || p->S < 1 || p->S * p->K != p->L)) return PCR_ERR_INVALID;
+  if (p->dy_mode == 3 && (!p->argmax || p->K < 1 || p->S < 1 || p->S * p->K != p->L)) return PCR_ERR_INVALID;
   if (p->wpT && (!p->dx || (p->cin2 && !p->dx2))) return PCR_ERR_INVALID;
   if (p->dwp && !p->dbp) return PCR_ERR_INVALID;
   if (p->B == 0) return PCR_OK;
   if (p->B > 65535) return PCR_ERR_INVALID;
+  if (pcr_ts_bwd_ok(p)) return pcr_ts_bwd_launch(p, pcr_s(stream));
   TBwd a;
   a.g = p->g; a.y = p->y; a.dy_mode = p->dy_mode; a.ka = p->ka; a.kb = p->kb; a.kc = p->kc;
   a.argmax = p->argmax; a.pooled = p->pooled; a.K = p->K; a.S = p->S;

@@ -375,7 +375,8 @@ __global__ __launch_bounds__(kThreads) void sa_pool_fwd_kernel(PoolArgs a) {
 __global__ __launch_bounds__(kThreads) void sa_pool_bwd_stats_kernel(const float *__restrict__ gp,
                                                                      const float *__restrict__ pooled,
                                                                      const float *__restrict__ ymax,
-                                                                     float *__restrict__ part, int C, int S) {
+                                                                     float *__restrict__ part, float *__restrict__ gz, int C,
+                                                                     int S) {
   const size_t b = blockIdx.y;
   const int CP = ceil32(C);
   const int lane = threadIdx.x & 63, c = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
@@ -385,6 +386,7 @@ __global__ __launch_bounds__(kThreads) void sa_pool_bwd_stats_kernel(const float
     const size_t o = (b * C + c) * S;
     for (int s = lane; s < S; s += 64) {
       const float gv = pooled[o + s] > 0.f ? gp[o + s] : 0.f;
+      if (gz) gz[o + s] = gv;          // the routed gradient (zero where the ReLU is closed): what dy_mode 3 consumes
       s1 += gv;
       s2 += gv * ymax[o + s];
     }
@@ -478,14 +480,14 @@ PCR_EXPORT int pcr_sa_pool_fwd_f32(const float *y, const float *scale, const flo
   return PCR_OK;
 }
 
-PCR_EXPORT int pcr_sa_pool_bwd_stats_f32(const float *gp, const float *pooled, const float *ymax, float *part, int B, int C,
-                                         int S, pcr_stream_t stream) {
+PCR_EXPORT int pcr_sa_pool_bwd_stats_f32(const float *gp, const float *pooled, const float *ymax, float *part, float *gz,
+                                         int B, int C, int S, pcr_stream_t stream) {
   if (!gp || !pooled || !ymax || !part || B < 0 || C < 1 || S < 1) return PCR_ERR_INVALID;
   if (B == 0) return PCR_OK;
   if (B > 65535) return PCR_ERR_INVALID;
   const int CP = ceil32(C);
   hipLaunchKernelGGL(sa_pool_bwd_stats_kernel, dim3(CP / (kThreads / 64), B), dim3(kThreads), 0, pcr_s(stream), gp, pooled,
-                     ymax, part, C, S);
+                     ymax, part, gz, C, S);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }

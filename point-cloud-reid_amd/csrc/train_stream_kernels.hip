@@ -1,0 +1,552 @@
+// Wave-autonomous ("streaming") forms of the train-dense launches for the narrow grouped-MLP layers (32 / 64 channels
+// in and out, L a multiple of 32: layers 2 / 3 of the first two set-abstraction modules in training mode, reference
+// models/pointnet2_utils.py:333-357 with BatchNorm2d batch statistics).
+//
+// Why a second form: the workgroup-cooperative kernels of train_kernels.hip walk a 64-token tile through
+// load -> LDS commit -> barrier -> matrix -> barrier -> statistics / store, and on a 32-channel layer those phases of the
+// workgroups sharing a CU simply add up (1.4 - 2.3 TB/s of algorithmic traffic on a part that copies at 5.5 TB/s).
+// Here a WAVE owns a 32-token block end to end and there is no workgroup barrier inside the loop:
+//   * the block's operands are loaded straight into the MFMA B-operand layout (lane = token, register = channel pair
+//     2s + h: one 128-byte line per lane half and instruction), the NEXT block's loads are in flight while this one is
+//     computed, the weights (<= 64 x 64) live in registers for the whole launch;
+//   * BatchNorm affine + ReLU / the BatchNorm backward are applied in registers, the output leaves from the accumulator
+//     layout (again one 128-byte line per lane half and instruction);
+//   * the backward's dW contracts over the TOKENS, i.e. needs dy and f(x) with lane = channel: the two 32 x 32 tiles
+//     are transposed through a wave-private LDS strip (no barrier: a wave's LDS operations complete in order);
+//   * per-channel sums stay per-lane partials across all of a wave's blocks and are folded once at the end.
+// Waves therefore drift apart and the memory, matrix and store phases of the waves on a SIMD overlap by themselves.
+// Results: same MFMA products in the same k order as the tile kernels (y / dx bit-identical), partial sums in a
+// different but fixed order (per wave, then waves 0..3 of a workgroup, then pcr_reduce_parts_f32).
+#include <type_traits>
+
+#include "tile_dense.h"
+#include "train_stream.h"
+
+namespace {
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+__device__ __forceinline__ rsrc_t ts_rsrc(const void *p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes),
+                                           0x00020000);
+}
+__device__ __forceinline__ float ts_ld(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ int ts_ldi(rsrc_t r, int voff, int soff) {
+  return (int)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+}
+__device__ __forceinline__ void ts_st(rsrc_t r, float v, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float ts_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 32 lanes of each wave half; the result is valid in lanes 0 and 32 (all lanes of rows 0 / 2 in fact)
+__device__ __forceinline__ float ts_half_sum(float v) {
+  v += ts_dpp<0xB1>(v);
+  v += ts_dpp<0x4E>(v);
+  v += ts_dpp<0x141>(v);
+  v += ts_dpp<0x140>(v);                               // every lane: the sum of its 16-lane row
+  v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));   // xor 16: rows 0+1, 2+3
+  return v;
+}
+
+__device__ __forceinline__ void ts_wave_sync() {       // orders a wave's own LDS writes before its later LDS reads
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int kTsWaves = 4;
+
+// ---------------------------------------------------------------------------------- forward ----
+struct TSFwd {
+  const float *x;            // (B, 32 NBI, L)
+  const float *isc, *ish;    // input affine (previous BatchNorm) or null
+  int in_relu;
+  const float *wp;           // packed image of W (pcr_pack_weight_f32 layout: [cin / 8][coutP][2][4])
+  const float *bias;         // zero-padded to coutP, or null
+  float *y;                  // (B, 32 NBO, L)
+  float *stats;              // partials [gridDim.x][2][32 NBO] or null
+  int B, L, nblk, per;       // 32-token blocks in all, blocks per wave
+};
+
+template <int NBI, int NBO>
+__global__ __launch_bounds__(64 * kTsWaves) void tstream_fwd_kernel(TSFwd a) {
+  constexpr int CIN = 32 * NBI, COUT = 32 * NBO, KS = CIN / 2;
+  __shared__ f32x2 s_aff[CIN];                   // (scale, shift) of the input affine
+  __shared__ float s_red[kTsWaves][2][COUT];
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = a.L, nbpc = L >> 5;
+  const bool aff = a.isc != nullptr;
+  for (int e = tid; e < CIN; e += 64 * kTsWaves) s_aff[e] = f32x2{aff ? a.isc[e] : 1.f, aff ? a.ish[e] : 0.f};
+  const float lo = (aff && a.in_relu) ? 0.f : -INFINITY;     // relu as max(v, lo): no branch in the k-loop
+  // weights: lane (i = j, h) holds W[32 nbo + i][2 s + h] for every k-step s
+  float aw[NBO][KS];
+#pragma unroll
+  for (int nbo = 0; nbo < NBO; nbo++) {
+    const f32x4 *wv = reinterpret_cast<const f32x4 *>(a.wp) + (size_t)(nbo * 32 + j) * 2 + h;
+#pragma unroll
+    for (int kb = 0; kb < CIN / 8; kb++) {
+      const f32x4 w4 = wv[(size_t)kb * COUT * 2];
+#pragma unroll
+      for (int q = 0; q < 4; q++) aw[nbo][4 * kb + q] = w4[q];
+    }
+  }
+  f32x16 bz[NBO];
+#pragma unroll
+  for (int nbo = 0; nbo < NBO; nbo++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) bz[nbo][r] = a.bias ? a.bias[nbo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
+  f32x16 ssum[NBO], ssq[NBO];
+#pragma unroll
+  for (int nbo = 0; nbo < NBO; nbo++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) ssum[nbo][r] = ssq[nbo][r] = 0.f;
+  __syncthreads();
+  // (every load of the prologue has landed before the loop: its waits would otherwise sit INSIDE the loop, as vmcnt(0),
+  // and drain the block prefetch with them)
+  __builtin_amdgcn_s_waitcnt(0);
+
+  const rsrc_t rx = ts_rsrc(a.x, (size_t)a.B * CIN * L * 4), ry = ts_rsrc(a.y, (size_t)a.B * COUT * L * 4);
+  const int gw = blockIdx.x * kTsWaves + wave;
+  const int n0 = gw * a.per;
+  const int n1 = n0 + a.per < a.nblk ? n0 + a.per : a.nblk;
+  const int vx = (h * L + j) * 4;          // lane part of the B-operand address: channel 2 s + h, token j
+  const int vy = (4 * h * L + j) * 4;      // lane part of the accumulator address: channel 8 g + 4 h + q, token j
+  // The loop body has NO conditional memory operation (the wait counts stay exact): every wave runs a.per (even) rounds,
+  // a round beyond the wave's range re-reads its last block and its stores are dropped by the buffer range check.
+  auto load = [&](float (&xr)[KS], int bb, int tt) {
+    const int so = (bb * CIN * L + tt * 32) * 4;
+#pragma unroll
+    for (int s = 0; s < KS; s++) xr[s] = ts_ld(rx, vx, so + s * 2 * L * 4);
+  };
+  auto compute = [&](float (&xr)[KS], int bb, int tt, bool valid) {
+    f32x16 acc[NBO];
+#pragma unroll
+    for (int nbo = 0; nbo < NBO; nbo++) acc[nbo] = bz[nbo];
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+      const f32x2 sc = s_aff[2 * s + h];
+      const float v = fmaxf(fmaf(xr[s], sc[0], sc[1]), lo);
+#pragma unroll
+      for (int nbo = 0; nbo < NBO; nbo++) acc[nbo] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[nbo][s], v, acc[nbo], 0, 0, 0);
+    }
+    const int so = (bb * COUT * L + tt * 32) * 4;
+    const int vo = valid ? vy : 0x7FFFFF00;
+#pragma unroll
+    for (int nbo = 0; nbo < NBO; nbo++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) ts_st(ry, acc[nbo][r], vo, so + (nbo * 32 + (r & 3) + 8 * (r >> 2)) * L * 4);
+    if (valid) {
+#pragma unroll
+      for (int nbo = 0; nbo < NBO; nbo++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const float v = acc[nbo][r];
+          ssum[nbo][r] += v;
+          ssq[nbo][r] += v * v;
+        }
+    }
+  };
+  auto next = [&](int &bb, int &tt, bool go) {      // scalar only
+    const int t2 = tt + 1;
+    const bool wrap = t2 == nbpc;
+    const int nb = wrap ? bb + 1 : bb, nt = wrap ? 0 : t2;
+    bb = go ? nb : bb;
+    tt = go ? nt : tt;
+  };
+  const int nc = n0 < a.nblk ? n0 : a.nblk - 1;
+  int bA = nc / nbpc, tA = nc - bA * nbpc;
+  float xa[KS], xb[KS];
+  load(xa, bA, tA);
+  for (int it = 0, idx = n0; it < a.per; it += 2, idx += 2) {
+    int bB = bA, tB = tA;
+    next(bB, tB, idx + 1 < n1);
+    load(xb, bB, tB);
+    compute(xa, bA, tA, idx < n1);
+    int bC = bB, tC = tB;
+    next(bC, tC, idx + 2 < n1);
+    load(xa, bC, tC);
+    compute(xb, bB, tB, idx + 1 < n1);
+    bA = bC;
+    tA = tC;
+  }
+  if (!a.stats) return;
+#pragma unroll
+  for (int nbo = 0; nbo < NBO; nbo++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float s1 = ts_half_sum(ssum[nbo][r]), s2 = ts_half_sum(ssq[nbo][r]);
+      if (j == 0) {
+        const int c = nbo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        s_red[wave][0][c] = s1;
+        s_red[wave][1][c] = s2;
+      }
+    }
+  __syncthreads();
+  for (int e = tid; e < 2 * COUT; e += 64 * kTsWaves) {
+    const int st = e / COUT, c = e - st * COUT;
+    float v = s_red[0][st][c];
+#pragma unroll
+    for (int w = 1; w < kTsWaves; w++) v += s_red[w][st][c];
+    a.stats[((size_t)blockIdx.x * 2 + st) * COUT + c] = v;
+  }
+}
+
+// --------------------------------------------------------------------------------- backward ----
+// dy = ka g + kb y + kc (dy_mode 1) or the same with g routed from the max-pooled gradient (dy_mode 3);
+// dx = (W^T dy) [f(x) > 0], f(x) = relu(isc x + ish); dstats = sum dx, sum dx * x; dW += dy f(x)^T; db += sum dy
+struct TSBwd {
+  const float *g, *y;
+  int mode;
+  const float *ka, *kb, *kc;
+  const int *argmax;
+  int K, S;
+  const float *x;
+  const float *isc, *ish, *iinv;
+  const float *wpT;            // packed image of W^T
+  float *dx, *dstats, *dwp, *dbp;
+  long stride;                 // floats between the workgroups' dW (and db) partials
+  int B, L, nblk, per;
+};
+
+template <int NB, int MODE>
+__global__ __launch_bounds__(64 * kTsWaves) void tstream_bwd_kernel(TSBwd a) {
+  constexpr int C = 32 * NB, KS = C / 2, TP = 33;
+  constexpr bool WLDS = NB > 1;                  // W^T from LDS (64 x 64 would take 64 registers per lane)
+  __shared__ __attribute__((aligned(16))) float s_k[C][4];     // ka, kb, kc, -
+  __shared__ __attribute__((aligned(16))) float s_sc[C], s_sh[C];
+  __shared__ float s_w[WLDS ? C * C : 1];        // [k = output channel][input channel]
+  __shared__ float s_t[kTsWaves][2][C * TP];     // the wave's two transposition strips; afterwards the combine buffer
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = a.L, nbpc = L >> 5, K = a.K, S = a.S;
+  for (int e = tid; e < C; e += 64 * kTsWaves) {
+    s_k[e][0] = a.ka[e];
+    s_k[e][1] = a.kb[e];
+    s_k[e][2] = a.kc[e];
+    s_k[e][3] = 0.f;
+    s_sc[e] = a.isc[e];
+    s_sh[e] = a.ish[e];
+  }
+  // W^T: lane (i = j, h) needs W[2 s + h][32 nbi + i] for every k-step s (k = output channel of the layer).
+  // packed image of W^T: element ((kb * C + o) * 2 + hh) * 4 + q = W^T[o][8 kb + 2 q + hh] = W[8 kb + 2 q + hh][o]
+  float wt[WLDS ? 1 : NB][WLDS ? 1 : KS];
+  if constexpr (WLDS) {
+    for (int e = tid; e < C * C; e += 64 * kTsWaves) {
+      const int q = e & 3, hh = (e >> 2) & 1, o = (e >> 3) % C, kb = (e >> 3) / C;
+      s_w[(8 * kb + 2 * q + hh) * C + o] = a.wpT[e];
+    }
+  } else {
+#pragma unroll
+    for (int nbi = 0; nbi < NB; nbi++) {
+      const f32x4 *wv = reinterpret_cast<const f32x4 *>(a.wpT) + (size_t)(nbi * 32 + j) * 2 + h;
+#pragma unroll
+      for (int kb = 0; kb < C / 8; kb++) {
+        const f32x4 w4 = wv[(size_t)kb * C * 2];
+#pragma unroll
+        for (int q = 0; q < 4; q++) wt[nbi][4 * kb + q] = w4[q];
+      }
+    }
+  }
+  f32x16 dw[NB][NB];      // [cout block][cin block]
+  // per-lane partial sums with lane (i, h) = channel 32 nb + i, its tokens of parity h: sum dy | sum dx | sum dx * x
+  float db[NB], s1[NB], s2[NB], shl[NB], invl[NB];
+#pragma unroll
+  for (int p = 0; p < NB; p++) {
+    db[p] = s1[p] = s2[p] = 0.f;
+    shl[p] = a.ish[p * 32 + j];
+    invl[p] = a.iinv[p * 32 + j];
+#pragma unroll
+    for (int q = 0; q < NB; q++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) dw[p][q][r] = 0.f;
+  }
+  __syncthreads();
+  __builtin_amdgcn_s_waitcnt(0);           // (the prologue's loads: see the forward kernel)
+
+  const size_t tbytes = (size_t)a.B * C * L * 4, pbytes = (size_t)a.B * C * S * 4;
+  const rsrc_t rg = MODE == 3 ? ts_rsrc(a.g, pbytes) : ts_rsrc(a.g, tbytes);
+  const rsrc_t ram = ts_rsrc(MODE == 3 ? (const void *)a.argmax : (const void *)a.g, MODE == 3 ? pbytes : 0);
+  const rsrc_t ry = ts_rsrc(a.y, tbytes), rx = ts_rsrc(a.x, tbytes), rdx = ts_rsrc(a.dx, tbytes);
+  const int gw = blockIdx.x * kTsWaves + wave;
+  const int n0 = gw * a.per;
+  const int n1 = n0 + a.per < a.nblk ? n0 + a.per : a.nblk;
+  const int vt = (h * L + j) * 4;          // B-operand layout: channel 2 s + h, token j
+  const int vd = (4 * h * L + j) * 4;      // accumulator layout: channel 8 g + 4 h + q, token j
+  float *sa = s_t[wave][0], *sb = s_t[wave][1];
+
+  // ONE register set per operand, refilled for the NEXT block right after this block has consumed it (y and the gradient
+  // part after dy is formed, the forward input after the mask): the refill then has the rest of the block -- the
+  // transposes and the dW products, most of its time -- to land.  Every load and store below is unconditional.
+  struct BlkG {
+    float g[KS];
+    int am[MODE == 3 ? KS : 1];
+    int k;
+  };
+  float ry_[KS], rx_[NB][16];
+  auto load_y = [&](int bb, int tt) {
+    const int so = (bb * C * L + tt * 32) * 4;
+#pragma unroll
+    for (int s = 0; s < KS; s++) ry_[s] = ts_ld(ry, vt, so + s * 2 * L * 4);
+  };
+  auto load_x = [&](int bb, int tt) {
+    const int so = (bb * C * L + tt * 32) * 4;
+#pragma unroll
+    for (int nbi = 0; nbi < NB; nbi++)
+#pragma unroll
+      for (int q = 0; q < 16; q++) rx_[nbi][q] = ts_ld(rx, vd, so + (nbi * 32 + (q & 3) + 8 * (q >> 2)) * L * 4);
+  };
+  auto load_g = [&](BlkG &r, int bb, int tt) {
+    if constexpr (MODE == 3) {
+      const int t = tt * 32 + j, sc = t / K;
+      r.k = t - sc * K;
+      const int vp = (h * S + sc) * 4, sp = bb * C * S * 4;
+#pragma unroll
+      for (int s = 0; s < KS; s++) {
+        r.am[s] = ts_ldi(ram, vp, sp + s * 2 * S * 4);
+        r.g[s] = ts_ld(rg, vp, sp + s * 2 * S * 4);
+      }
+    } else {
+      const int so = (bb * C * L + tt * 32) * 4;
+#pragma unroll
+      for (int s = 0; s < KS; s++) r.g[s] = ts_ld(rg, vt, so + s * 2 * L * 4);
+    }
+  };
+  BlkG gq;
+  auto compute = [&](int bb, int tt, bool valid, int gb, int gt) {
+    // 1. dy in the B-operand layout (k = output channel), a copy into strip A; dx = W^T dy
+    float dy[KS];
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+      const f32x4 kk = *reinterpret_cast<const f32x4 *>(s_k[2 * s + h]);
+      float gv = gq.g[s];
+      if constexpr (MODE == 3) gv = gq.am[s] == gq.k ? gv : 0.f;
+      const float v = fmaf(kk[0], gv, fmaf(kk[1], ry_[s], kk[2]));
+      dy[s] = valid ? v : 0.f;             // (a round beyond the wave's range adds nothing to dW / db / the sums)
+      sa[(2 * s + h) * TP + j] = dy[s];
+    }
+    load_g(gq, gb, gt);                    // the next block's gradient part and raw output
+    load_y(gb, gt);
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nbi = 0; nbi < NB; nbi++) {
+#pragma unroll
+      for (int q = 0; q < 16; q++) acc[nbi][q] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; s++) {
+        const float wv = WLDS ? s_w[(2 * s + h) * C + nbi * 32 + j] : wt[WLDS ? 0 : nbi][WLDS ? 0 : s];
+        acc[nbi] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, dy[s], acc[nbi], 0, 0, 0);
+      }
+    }
+    ts_wave_sync();
+    // 2. dy with lane = channel: token 2 s' + h of channel 32 nbo + j
+    float dyc[NB][16];
+#pragma unroll
+    for (int nbo = 0; nbo < NB; nbo++)
+#pragma unroll
+      for (int s = 0; s < 16; s++) {
+        dyc[nbo][s] = sa[(nbo * 32 + j) * TP + 2 * s + h];
+        db[nbo] += dyc[nbo][s];
+      }
+    ts_wave_sync();
+    // 3. masked dx: to memory and into strip A; f(x) into strip B
+    const int so = (bb * C * L + tt * 32) * 4;
+    const int vo = valid ? vd : 0x7FFFFF00;
+#pragma unroll
+    for (int nbi = 0; nbi < NB; nbi++)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++) {
+        const int c0 = nbi * 32 + 8 * g4;
+        const f32x4 sc4 = *reinterpret_cast<const f32x4 *>(s_sc + c0 + 4 * h), sh4 = *reinterpret_cast<const f32x4 *>(s_sh + c0 + 4 * h);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int rr = 4 * g4 + q;
+          const float av = fmaf(rx_[nbi][rr], sc4[q], sh4[q]);
+          const float dxm = av > 0.f ? acc[nbi][rr] : 0.f;     // (zero for an invalid round: dy was zeroed)
+          ts_st(rdx, dxm, vo, so + (c0 + q) * L * 4);
+          sa[(c0 + 4 * h + q) * TP + j] = dxm;
+          sb[(c0 + 4 * h + q) * TP + j] = fmaxf(av, 0.f);
+        }
+      }
+    load_x(gb, gt);                        // the next block's forward input
+    ts_wave_sync();
+    // 4. lane = channel again: the two sums the next BatchNorm backward needs, and dW += dy f(x)^T
+#pragma unroll
+    for (int nbi = 0; nbi < NB; nbi++) {
+      float ac[16];
+#pragma unroll
+      for (int s = 0; s < 16; s++) {
+        ac[s] = sb[(nbi * 32 + j) * TP + 2 * s + h];
+        const float dxc = sa[(nbi * 32 + j) * TP + 2 * s + h];
+        s1[nbi] += dxc;
+        s2[nbi] += dxc * ((ac[s] - shl[nbi]) * invl[nbi]);      // (raw input where the mask is open; dxc = 0 elsewhere)
+      }
+#pragma unroll
+      for (int nbo = 0; nbo < NB; nbo++)
+#pragma unroll
+        for (int s = 0; s < 16; s++)
+          dw[nbo][nbi] = __builtin_amdgcn_mfma_f32_32x32x2f32(dyc[nbo][s], ac[s], dw[nbo][nbi], 0, 0, 0);
+    }
+    ts_wave_sync();
+  };
+  auto next = [&](int &bb, int &tt, bool go) {      // scalar only
+    const int t2 = tt + 1;
+    const bool wrap = t2 == nbpc;
+    const int nb = wrap ? bb + 1 : bb, nt = wrap ? 0 : t2;
+    bb = go ? nb : bb;
+    tt = go ? nt : tt;
+  };
+  const int nc = n0 < a.nblk ? n0 : a.nblk - 1;
+  int bA = nc / nbpc, tA = nc - bA * nbpc;
+  load_g(gq, bA, tA);
+  load_y(bA, tA);
+  load_x(bA, tA);
+  for (int it = 0, idx = n0; it < a.per; it++, idx++) {
+    int bB = bA, tB = tA;
+    next(bB, tB, idx + 1 < n1);
+    compute(bA, tA, idx < n1, bB, tB);
+    bA = bB;
+    tA = tB;
+  }
+  // ---- fold: the two lane halves, then the workgroup's waves in order 0..3 through one LDS image ----
+  __syncthreads();
+  float *img = &s_t[0][0][0];                    // [C*C dW | C db | 2 C dstats], C*C + 3 C <= 8 * C * TP floats
+  float *img_db = img + C * C, *img_ds = img_db + C;
+  for (int w = 0; w < kTsWaves; w++) {
+    if (wave == w) {
+#pragma unroll
+      for (int nbo = 0; nbo < NB; nbo++)
+#pragma unroll
+        for (int nbi = 0; nbi < NB; nbi++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            float *d = img + (nbo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * C + nbi * 32 + j;
+            *d = w == 0 ? dw[nbo][nbi][r] : *d + dw[nbo][nbi][r];
+          }
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) {
+        // channel 32 nb + j: the two token parities (lane halves) added in a fixed order
+        const float d0 = db[nb] + __shfl_xor(db[nb], 32, 64), d1 = s1[nb] + __shfl_xor(s1[nb], 32, 64),
+                    d2 = s2[nb] + __shfl_xor(s2[nb], 32, 64);
+        if (h == 0) {
+          const int c = nb * 32 + j;
+          img_db[c] = (w == 0 ? 0.f : img_db[c]) + d0;
+          img_ds[c] = (w == 0 ? 0.f : img_ds[c]) + d1;
+          img_ds[C + c] = (w == 0 ? 0.f : img_ds[C + c]) + d2;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float *dwo = a.dwp + (size_t)blockIdx.x * a.stride, *dbo = a.dbp + (size_t)blockIdx.x * a.stride;
+  for (int e = tid; e < C * C; e += 64 * kTsWaves) dwo[e] = img[e];
+  for (int e = tid; e < C; e += 64 * kTsWaves) dbo[e] = img_db[e];
+  for (int e = tid; e < 2 * C; e += 64 * kTsWaves) a.dstats[(size_t)blockIdx.x * 2 * C + e] = img_ds[e];
+}
+
+int ts_cus() {
+  static int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) return 256;
+    return n;
+  }();
+  return cus;
+}
+
+}  // namespace
+
+// ---- eligibility + grid (shared by the launch paths in train_kernels.hip and the *_groups exports) ----
+// launches with fewer 32-token blocks than this stay on the tile kernels (policy knob, see pcr_set_stream_min_blocks)
+static int g_ts_min_blocks = 8192;
+
+PCR_EXPORT int pcr_set_stream_min_blocks(int n) {
+  const int old = g_ts_min_blocks;
+  if (n >= 0) g_ts_min_blocks = n;
+  return old;
+}
+
+// forward: 32 / 64 channels in and out, one input tensor, no residual / output ReLU, L a multiple of 32, tensors < 4 GB
+bool pcr_ts_fwd_ok(const pcr_tdense_fwd *p) {
+  const int cin = p->cin1, cout = p->cout;
+  if (p->cin2 || p->res || p->out_relu) return false;
+  if (!((cin == 32 || cin == 64) && (cout == 32 || cout == 64))) return false;
+  if ((p->L & 31) || p->B < 1) return false;
+  if ((size_t)p->B * (cin > cout ? cin : cout) * p->L * 4 >= (1ull << 31)) return false;
+  // (worth it only when a wave gets a stream of blocks: the grouped-MLP launches, not the per-point layers)
+  return (long)p->B * (p->L >> 5) >= g_ts_min_blocks;
+}
+
+int pcr_ts_fwd_grid(const pcr_tdense_fwd *p, int *per) {
+  const int nblk = p->B * (p->L >> 5);
+  const int wgs_per_cu = (p->cin1 == 64 || p->cout == 64) ? 2 : 4;
+  int g = ts_cus() * wgs_per_cu;
+  int pw = (nblk + g * kTsWaves - 1) / (g * kTsWaves);
+  pw = (pw + 1) & ~1;                    // rounds come in pairs (two register sets)
+  if (pw < 2) pw = 2;
+  g = (nblk + pw * kTsWaves - 1) / (pw * kTsWaves);
+  if (per) *per = pw;
+  return g;
+}
+
+int pcr_ts_fwd_launch(const pcr_tdense_fwd *p, hipStream_t st) {
+  TSFwd a;
+  a.x = p->x; a.isc = p->isc; a.ish = p->ish; a.in_relu = p->in_relu; a.wp = p->wp; a.bias = p->bias;
+  a.y = p->y; a.stats = p->stats; a.B = p->B; a.L = p->L; a.nblk = p->B * (p->L >> 5);
+  const int g = pcr_ts_fwd_grid(p, &a.per);
+  const dim3 grid(g), blk(64 * kTsWaves);
+  if (p->cin1 == 32 && p->cout == 32) hipLaunchKernelGGL((tstream_fwd_kernel<1, 1>), grid, blk, 0, st, a);
+  else if (p->cin1 == 64 && p->cout == 64) hipLaunchKernelGGL((tstream_fwd_kernel<2, 2>), grid, blk, 0, st, a);
+  else if (p->cin1 == 32) hipLaunchKernelGGL((tstream_fwd_kernel<1, 2>), grid, blk, 0, st, a);
+  else hipLaunchKernelGGL((tstream_fwd_kernel<2, 1>), grid, blk, 0, st, a);
+  return hipGetLastError() == hipSuccess ? PCR_OK : PCR_ERR_LAUNCH;
+}
+
+// backward: square 32 / 64-channel layers behind a BatchNorm (dy_mode 1 / 3) with every output wanted
+bool pcr_ts_bwd_ok(const pcr_tdense_bwd *p) {
+  if (p->cin2 || p->cin1 != p->cout || !(p->cout == 32 || p->cout == 64)) return false;
+  if (!(p->dy_mode == 1 || (p->dy_mode == 3 && !p->pooled && p->argmax))) return false;   // (mode 3: routed gradient)
+  if (!p->isc || !p->ish || !p->iinv || !p->in_relu || !p->wpT || !p->dx || !p->dstats || !p->dwp || !p->dbp) return false;
+  if ((p->L & 31) || p->B < 1) return false;
+  if (p->part_stride < (long)p->cout * p->cin1 + p->cout) return false;   // (one strided block of dW | db partials)
+  if ((size_t)p->B * p->cout * p->L * 4 >= (1ull << 31)) return false;
+  return (long)p->B * (p->L >> 5) >= g_ts_min_blocks;
+}
+
+int pcr_ts_bwd_grid(const pcr_tdense_bwd *p, int *per) {
+  const int nblk = p->B * (p->L >> 5);
+  const int wgs_per_cu = p->cout == 64 ? 1 : 2;      // what registers / LDS admit (one / two waves per SIMD)
+  int g = ts_cus() * wgs_per_cu;
+  int pw = (nblk + g * kTsWaves - 1) / (g * kTsWaves);
+  pw = (pw + 1) & ~1;                    // rounds come in pairs (two register sets)
+  if (pw < 2) pw = 2;
+  g = (nblk + pw * kTsWaves - 1) / (pw * kTsWaves);
+  if (per) *per = pw;
+  return g;
+}
+
+int pcr_ts_bwd_launch(const pcr_tdense_bwd *p, hipStream_t st) {
+  TSBwd a;
+  a.g = p->g; a.y = p->y; a.mode = p->dy_mode; a.ka = p->ka; a.kb = p->kb; a.kc = p->kc;
+  a.argmax = p->argmax; a.K = p->K; a.S = p->S;
+  a.x = p->x; a.isc = p->isc; a.ish = p->ish; a.iinv = p->iinv; a.wpT = p->wpT;
+  a.dx = p->dx; a.dstats = p->dstats; a.dwp = p->dwp; a.dbp = p->dbp;
+  a.stride = p->part_stride ? p->part_stride : 0;
+  a.B = p->B; a.L = p->L; a.nblk = p->B * (p->L >> 5);
+  const int g = pcr_ts_bwd_grid(p, &a.per);
+  const dim3 grid(g), blk(64 * kTsWaves);
+  if (p->cout == 32) {
+    if (p->dy_mode == 3) hipLaunchKernelGGL((tstream_bwd_kernel<1, 3>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((tstream_bwd_kernel<1, 1>), grid, blk, 0, st, a);
+  } else {
+    if (p->dy_mode == 3) hipLaunchKernelGGL((tstream_bwd_kernel<2, 3>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((tstream_bwd_kernel<2, 1>), grid, blk, 0, st, a);
+  }
+  return hipGetLastError() == hipSuccess ? PCR_OK : PCR_ERR_LAUNCH;
+}

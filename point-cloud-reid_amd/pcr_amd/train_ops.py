@@ -208,12 +208,14 @@ def tdense_fwd(x, wp, cout, x2=None, isc=None, ish=None, in_relu=False, bias=Non
         x2 = _dev(x2)
         cin2 = x2.shape[1]
     y = _f32(B, cout, Ln, device=x.device)
-    stats = _f32(groups(B, Ln), 2, _c32(cout), device=x.device) if want_stats else None
     p = _TFwd()
     p.B, p.cin1, p.cin2, p.cout, p.L = B, cin1, cin2, cout, Ln
     p.x, p.x2, p.isc, p.ish, p.in_relu = _p(x), _p(x2), _p(isc), _p(ish), int(in_relu)
     p.wp, p.bias, p.res, p.out_relu = _p(wp), _p(pad32(bias, cout)), _p(res), int(out_relu)
-    p.y, p.stats = _p(y), _p(stats)
+    p.y = _p(y)
+    # rows of the statistics partials = workgroups of THIS launch (the library picks the kernel from the block)
+    stats = _f32(L.load().pcr_tdense_fwd_groups(ctypes.byref(p)), 2, _c32(cout), device=x.device) if want_stats else None
+    p.stats = _p(stats)
     cin = cin1 + cin2
     with _prof("tdense_fwd[cin=%d,cout=%d,L=%d]" % (cin, cout, Ln), 2.0 * B * Ln * cin * cout,
                4.0 * B * Ln * (cin + cout * (2 if res is not None else 1))):
@@ -239,7 +241,6 @@ def tdense_bwd(g, x, cout, dy_mode=0, y=None, k=None, argmax=None, pooled=None, 
         cin2 = x2.shape[1]
     cin = cin1 + cin2
     dev = x.device
-    nwg = L.load().pcr_train_groups_bwd(B, Ln, cout if want_dw else 0, cin)
     out = {}
     p = _TBwd()
     p.B, p.cin1, p.cin2, p.cout, p.L = B, cin1, cin2, cout, Ln
@@ -248,6 +249,17 @@ def tdense_bwd(g, x, cout, dy_mode=0, y=None, k=None, argmax=None, pooled=None, 
         p.ka, p.kb, p.kc = _p(k["ka"]), _p(k["kb"]), _p(k["kc"])
     p.argmax, p.pooled, p.K, p.S = _p(argmax), _p(pooled), K, S
     p.x, p.x2, p.isc, p.ish, p.iinv, p.in_relu = _p(x), _p(x2), _p(isc), _p(ish), _p(iinv), int(in_relu)
+    # workgroups of THIS launch = rows of its partial buffers: asked with the wanted outputs marked non-NULL (the
+    # library picks the kernel -- and with it the grid -- from the parameter block), then the real buffers go in
+    p.wpT = _p(wpT)
+    if wpT is not None:
+        p.dx, p.dx2 = 1, (1 if cin2 else None)
+        p.dstats = 1 if want_dstats else None
+    if want_dw:
+        p.dwp = p.dbp = 1
+        p.part_stride = _c32(cout) * _c32(cin) + _c32(cout)
+    nwg = L.load().pcr_tdense_bwd_groups(ctypes.byref(p))
+    p.dx = p.dx2 = p.dstats = p.dwp = p.dbp = None
     if wpT is not None:
         out["dx"] = _f32(B, cin1, Ln, device=dev)
         out["dx2"] = _f32(B, cin2, Ln, device=dev) if cin2 else None
@@ -432,10 +444,11 @@ class SaEdgeTrain(Function):
         Ln, R, dev = S * K, B * S * K, xyz.device
         gp = gp.contiguous()
         part3 = _f32(B, 2, _c32(c3), device=dev)
-        L.check(lib.pcr_sa_pool_bwd_stats_f32(L.ptr(gp), L.ptr(pooled), L.ptr(ymax), L.ptr(part3), B, c3, S,
+        gz = _f32(B, c3, S, device=dev)          # the pooled gradient where the ReLU is open, zero elsewhere
+        L.check(lib.pcr_sa_pool_bwd_stats_f32(L.ptr(gp), L.ptr(pooled), L.ptr(ymax), L.ptr(part3), L.ptr(gz), B, c3, S,
                                               L.stream_ptr()), "pcr_sa_pool_bwd_stats_f32")
         k3 = bn_bwd_finalize(part3, B, c3, R, g3, n3["mean"], n3["invstd"])
-        r3 = tdense_bwd(gp, y2, c3, dy_mode=3, y=y3, k=k3, argmax=argmax, pooled=pooled, K=K, S=S,
+        r3 = tdense_bwd(gz, y2, c3, dy_mode=3, y=y3, k=k3, argmax=argmax, pooled=None, K=K, S=S,
                         isc=n2["scale"], ish=n2["shift"], iinv=n2["inv_scale"], in_relu=True,
                         wpT=pack_dev(w3, transpose=True), want_dstats=True)
         k2 = bn_bwd_finalize(r3["dstats"], r3["dstats"].shape[0], c2, R, g2, n2["mean"], n2["invstd"])

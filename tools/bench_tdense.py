@@ -4,7 +4,8 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "point-cloud-reid_amd")]
 import torch
-from pcr_amd import train_ops as TO
+from pcr_amd import train_ops as TO, _lib
+if os.environ.get('PCR_STREAM_MIN'): _lib.load().pcr_set_stream_min_blocks(int(os.environ['PCR_STREAM_MIN']))
 c = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 Ln = int(sys.argv[2]) if len(sys.argv) > 2 else 3072
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 512
