@@ -74,39 +74,47 @@ struct TSFwd {
   int B, L, nblk, per;       // 32-token blocks in all, blocks per wave
 };
 
-template <int NBI, int NBO>
+// WLDS: the weights as the A operand come from an LDS image [k = input channel][output channel] (one ds_read_b32 per
+// MFMA: 12 % of the LDS pipe at full matrix rate) instead of registers -- layers wider than 32 x 32, up to 128 x 128.
+template <int NBI, int NBO, bool WLDS>
 __global__ __launch_bounds__(64 * kTsWaves) void tstream_fwd_kernel(TSFwd a) {
-  constexpr int CIN = 32 * NBI, COUT = 32 * NBO, KS = CIN / 2;
-  __shared__ f32x2 s_aff[CIN];                   // (scale, shift) of the input affine
-  __shared__ float s_red[kTsWaves][2][COUT];
+  constexpr int CIN = 32 * NBI, COUT = 32 * NBO, KS = CIN / 2, TP = 33;
+  extern __shared__ __attribute__((aligned(16))) float ts_smem[];
+  f32x2 *s_aff = reinterpret_cast<f32x2 *>(ts_smem);            // [CIN] (scale, shift) of the input affine
+  float *s_bias = ts_smem + 2 * CIN;                            // [COUT]
+  float *s_w = s_bias + COUT;                                   // [CIN][COUT] (WLDS)
+  float *s_t = s_w + (WLDS ? CIN * COUT : 0);                   // [waves][COUT * TP]: transposition strip (statistics)
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int L = a.L, nbpc = L >> 5;
   const bool aff = a.isc != nullptr;
   for (int e = tid; e < CIN; e += 64 * kTsWaves) s_aff[e] = f32x2{aff ? a.isc[e] : 1.f, aff ? a.ish[e] : 0.f};
+  for (int e = tid; e < COUT; e += 64 * kTsWaves) s_bias[e] = a.bias ? a.bias[e] : 0.f;
   const float lo = (aff && a.in_relu) ? 0.f : -INFINITY;     // relu as max(v, lo): no branch in the k-loop
-  // weights: lane (i = j, h) holds W[32 nbo + i][2 s + h] for every k-step s
-  float aw[NBO][KS];
+  // weights: lane (i = j, h) needs W[32 nbo + i][2 s + h] for every k-step s.
+  // packed image: element ((kb * COUT + o) * 2 + hh) * 4 + q = W[o][8 kb + 2 q + hh]
+  float aw[WLDS ? 1 : NBO][WLDS ? 1 : KS];
+  if constexpr (WLDS) {
+    for (int e = tid; e < CIN * COUT; e += 64 * kTsWaves) {
+      const int q = e & 3, hh = (e >> 2) & 1, o = (e >> 3) % COUT, kb = (e >> 3) / COUT;
+      s_w[(8 * kb + 2 * q + hh) * COUT + o] = a.wp[e];
+    }
+  } else {
 #pragma unroll
-  for (int nbo = 0; nbo < NBO; nbo++) {
-    const f32x4 *wv = reinterpret_cast<const f32x4 *>(a.wp) + (size_t)(nbo * 32 + j) * 2 + h;
+    for (int nbo = 0; nbo < NBO; nbo++) {
+      const f32x4 *wv = reinterpret_cast<const f32x4 *>(a.wp) + (size_t)(nbo * 32 + j) * 2 + h;
 #pragma unroll
-    for (int kb = 0; kb < CIN / 8; kb++) {
-      const f32x4 w4 = wv[(size_t)kb * COUT * 2];
+      for (int kb = 0; kb < CIN / 8; kb++) {
+        const f32x4 w4 = wv[(size_t)kb * COUT * 2];
 #pragma unroll
-      for (int q = 0; q < 4; q++) aw[nbo][4 * kb + q] = w4[q];
+        for (int q = 0; q < 4; q++) aw[nbo][4 * kb + q] = w4[q];
+      }
     }
   }
-  f32x16 bz[NBO];
+  // per-lane partial sums with lane (i, h) = channel 32 nbo + i, its tokens of parity h
+  float ssum[NBO], ssq[NBO];
 #pragma unroll
-  for (int nbo = 0; nbo < NBO; nbo++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) bz[nbo][r] = a.bias ? a.bias[nbo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
-  f32x16 ssum[NBO], ssq[NBO];
-#pragma unroll
-  for (int nbo = 0; nbo < NBO; nbo++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) ssum[nbo][r] = ssq[nbo][r] = 0.f;
+  for (int nbo = 0; nbo < NBO; nbo++) ssum[nbo] = ssq[nbo] = 0.f;
   __syncthreads();
   // (every load of the prologue has landed before the loop: its waits would otherwise sit INSIDE the loop, as vmcnt(0),
   // and drain the block prefetch with them)
@@ -118,6 +126,8 @@ __global__ __launch_bounds__(64 * kTsWaves) void tstream_fwd_kernel(TSFwd a) {
   const int n1 = n0 + a.per < a.nblk ? n0 + a.per : a.nblk;
   const int vx = (h * L + j) * 4;          // lane part of the B-operand address: channel 2 s + h, token j
   const int vy = (4 * h * L + j) * 4;      // lane part of the accumulator address: channel 8 g + 4 h + q, token j
+  float *strip = s_t + wave * (COUT * TP);
+  const bool want_stats = a.stats != nullptr;
   // The loop body has NO conditional memory operation (the wait counts stay exact): every wave runs a.per (even) rounds,
   // a round beyond the wave's range re-reads its last block and its stores are dropped by the buffer range check.
   auto load = [&](float (&xr)[KS], int bb, int tt) {
@@ -125,33 +135,65 @@ __global__ __launch_bounds__(64 * kTsWaves) void tstream_fwd_kernel(TSFwd a) {
 #pragma unroll
     for (int s = 0; s < KS; s++) xr[s] = ts_ld(rx, vx, so + s * 2 * L * 4);
   };
-  auto compute = [&](float (&xr)[KS], int bb, int tt, bool valid) {
+  auto round = [&](float (&xr)[KS], int bb, int tt, bool valid) {
     f32x16 acc[NBO];
 #pragma unroll
-    for (int nbo = 0; nbo < NBO; nbo++) acc[nbo] = bz[nbo];
+    for (int nbo = 0; nbo < NBO; nbo++)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(s_bias + nbo * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[nbo][4 * g4 + q] = b4[q];
+      }
+    // LDS operands (weight fragments, affine pairs) are requested PD steps ahead of the MFMAs that use them, in a ring
+    // of register sets; the scheduling barriers pin that order (left alone, hipcc issues each ds_read right before its
+    // use and waits for it: with one wave per SIMD that latency is the matrix pipe's idle time)
+    constexpr int PD = 2;
+    float wr[PD + 1][NBO];
+    f32x2 ar[PD + 1];
+    auto fetch_k = [&](int slot, int s) {
+      ar[slot] = s_aff[2 * s + h];
+      if constexpr (WLDS) {
+#pragma unroll
+        for (int nbo = 0; nbo < NBO; nbo++) wr[slot][nbo] = s_w[(2 * s + h) * COUT + nbo * 32 + j];
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < PD; s++) fetch_k(s, s);
 #pragma unroll
     for (int s = 0; s < KS; s++) {
-      const f32x2 sc = s_aff[2 * s + h];
+      if (s + PD < KS) fetch_k((s + PD) % (PD + 1), s + PD);
+      __builtin_amdgcn_sched_barrier(0);
+      const f32x2 sc = ar[s % (PD + 1)];
       const float v = fmaxf(fmaf(xr[s], sc[0], sc[1]), lo);
 #pragma unroll
-      for (int nbo = 0; nbo < NBO; nbo++) acc[nbo] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[nbo][s], v, acc[nbo], 0, 0, 0);
+      for (int nbo = 0; nbo < NBO; nbo++) {
+        const float wv = WLDS ? wr[s % (PD + 1)][nbo] : aw[WLDS ? 0 : nbo][WLDS ? 0 : s];
+        acc[nbo] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, v, acc[nbo], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     const int so = (bb * COUT * L + tt * 32) * 4;
     const int vo = valid ? vy : 0x7FFFFF00;
 #pragma unroll
     for (int nbo = 0; nbo < NBO; nbo++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) ts_st(ry, acc[nbo][r], vo, so + (nbo * 32 + (r & 3) + 8 * (r >> 2)) * L * 4);
-    if (valid) {
+      for (int r = 0; r < 16; r++) {
+        ts_st(ry, acc[nbo][r], vo, so + (nbo * 32 + (r & 3) + 8 * (r >> 2)) * L * 4);
+        strip[(nbo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * TP + j] = valid ? acc[nbo][r] : 0.f;
+      }
+    ts_wave_sync();
+    if (want_stats) {
 #pragma unroll
       for (int nbo = 0; nbo < NBO; nbo++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const float v = acc[nbo][r];
-          ssum[nbo][r] += v;
-          ssq[nbo][r] += v * v;
+        for (int s = 0; s < 16; s++) {
+          const float v = strip[(nbo * 32 + j) * TP + 2 * s + h];
+          ssum[nbo] += v;
+          ssq[nbo] += v * v;
         }
     }
+    ts_wave_sync();
   };
   auto next = [&](int &bb, int &tt, bool go) {      // scalar only
     const int t2 = tt + 1;
@@ -164,37 +206,238 @@ __global__ __launch_bounds__(64 * kTsWaves) void tstream_fwd_kernel(TSFwd a) {
   int bA = nc / nbpc, tA = nc - bA * nbpc;
   float xa[KS], xb[KS];
   load(xa, bA, tA);
+  // (the other register set is requested BEFORE this set's k-loop: its round trip hides behind the matrix phase)
   for (int it = 0, idx = n0; it < a.per; it += 2, idx += 2) {
     int bB = bA, tB = tA;
     next(bB, tB, idx + 1 < n1);
     load(xb, bB, tB);
-    compute(xa, bA, tA, idx < n1);
+    round(xa, bA, tA, idx < n1);
     int bC = bB, tC = tB;
     next(bC, tC, idx + 2 < n1);
     load(xa, bC, tC);
-    compute(xb, bB, tB, idx + 1 < n1);
+    round(xb, bB, tB, idx + 1 < n1);
     bA = bC;
     tA = tC;
   }
-  if (!a.stats) return;
+  if (!want_stats) return;
+  // fold: the two token parities of a channel, then the workgroup's waves in order
+  __syncthreads();
+  float *red = s_t;                                 // [waves][2][COUT]
 #pragma unroll
-  for (int nbo = 0; nbo < NBO; nbo++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const float s1 = ts_half_sum(ssum[nbo][r]), s2 = ts_half_sum(ssq[nbo][r]);
-      if (j == 0) {
-        const int c = nbo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        s_red[wave][0][c] = s1;
-        s_red[wave][1][c] = s2;
-      }
+  for (int nbo = 0; nbo < NBO; nbo++) {
+    const float d1 = ssum[nbo] + __shfl_xor(ssum[nbo], 32, 64), d2 = ssq[nbo] + __shfl_xor(ssq[nbo], 32, 64);
+    if (h == 0) {
+      red[(wave * 2) * COUT + nbo * 32 + j] = d1;
+      red[(wave * 2 + 1) * COUT + nbo * 32 + j] = d2;
     }
+  }
   __syncthreads();
   for (int e = tid; e < 2 * COUT; e += 64 * kTsWaves) {
     const int st = e / COUT, c = e - st * COUT;
-    float v = s_red[0][st][c];
+    float v = red[st * COUT + c];
 #pragma unroll
-    for (int w = 1; w < kTsWaves; w++) v += s_red[w][st][c];
+    for (int w = 1; w < kTsWaves; w++) v += red[(w * 2 + st) * COUT + c];
     a.stats[((size_t)blockIdx.x * 2 + st) * COUT + c] = v;
+  }
+}
+
+// The 128 x 128 forward (layers 2 / 3 of the third set-abstraction module) is bound by the f32 matrix pipe, not by HBM,
+// and its register sets allow ONE wave per SIMD: nothing overlaps that wave's epilogue with its own k-loop unless the
+// instruction stream does.  This form software-pipelines the blocks INSIDE the wave: k-step s of block i carries, in the
+// shadow of its four MFMAs, item s of block i - 1's epilogue (one output row: store + a copy into the statistics strip)
+// and item s of block i + 1's operand fetch (one B-operand register).  64 k-steps, 64 output rows, 64 operand
+// registers: the mapping is one to one and the memory operations are spread evenly over the round.
+// Everything the k-loop touches besides the accumulators stays in the ARCHITECTURAL registers: an accumulator-file
+// register read (v_accvgpr_read) while MFMAs are in flight waits for the matrix pipe to drain -- with the previous
+// block's rows or spilled operands living there, every k-step took twice its MFMA time (measured: 0.337 ms against
+// 0.15 ms for the bare k-loops).  So the finished block is copied out of the accumulators in one burst at the end of its
+// round, and the per-channel sums are taken lane = channel from the strip (8 registers) instead of per accumulator row
+// (128).  Same MFMA products in the same order as the plain form: y is bit-identical.
+// EIGHT waves per workgroup (two per SIMD, one workgroup per CU, all sharing the LDS weight image): a wave can have 63
+// memory operations in flight (vmcnt is six bits), 256 bytes each in these layouts, and with four waves per CU that
+// window -- 16 MB over the chip against ~6 us of loaded memory latency -- capped the launch at 2.5 TB/s, half of what
+// the matrix pipe asks for.  The statistics strip holds ONE cout block (32 channels x 32 tokens, 4.2 KB per wave): the
+// 16 items of a cout block are consecutive k-steps, the lane = channel sums follow them.
+constexpr int kTpWaves = 8;
+
+template <int NB>
+__global__ __launch_bounds__(64 * kTpWaves, 1) void tstream_fwd_pipe_kernel(TSFwd a) {
+  constexpr int C = 32 * NB, KS = C / 2, TP = 33;
+  static_assert(KS == 16 * NB, "one epilogue item per k-step");
+  extern __shared__ __attribute__((aligned(16))) float ts_smem[];
+  f32x2 *s_aff = reinterpret_cast<f32x2 *>(ts_smem);            // [C] (scale, shift) of the input affine
+  float *s_bias = ts_smem + 2 * C;                              // [C]
+  float *s_w = s_bias + C;                                      // [k = input channel][i = 32 lanes][cout block]: ONE 16-byte read
+                                                                // per lane and k-step, its address an immediate offset
+  float *s_t = s_w + C * C;                                     // [waves][32 * TP]: statistics strip; at the end the fold
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = a.L, nbpc = L >> 5;
+  const bool aff = a.isc != nullptr;
+  for (int e = tid; e < C; e += 64 * kTpWaves) {
+    s_aff[e] = f32x2{aff ? a.isc[e] : 1.f, aff ? a.ish[e] : 0.f};
+    s_bias[e] = a.bias ? a.bias[e] : 0.f;
+  }
+  const float lo = (aff && a.in_relu) ? 0.f : -INFINITY;
+  for (int e = tid; e < C * C; e += 64 * kTpWaves) {
+    const int q = e & 3, hh = (e >> 2) & 1, o = (e >> 3) % C, kb = (e >> 3) / C;
+    s_w[((8 * kb + 2 * q + hh) * 32 + (o & 31)) * NB + (o >> 5)] = a.wp[e];
+  }
+  float ssum[NB], ssq[NB];               // per-lane partials, lane (i, h) = channel 32 nbo + i, its tokens of parity h
+#pragma unroll
+  for (int nbo = 0; nbo < NB; nbo++) ssum[nbo] = ssq[nbo] = 0.f;
+  __syncthreads();
+  __builtin_amdgcn_s_waitcnt(0);
+
+  const rsrc_t rx = ts_rsrc(a.x, (size_t)a.B * C * L * 4), ry = ts_rsrc(a.y, (size_t)a.B * C * L * 4);
+  const int gw = blockIdx.x * kTpWaves + wave;
+  const int n0 = gw * a.per;
+  const int n1 = n0 + a.per < a.nblk ? n0 + a.per : a.nblk;
+  const int vx = (h * L + j) * 4, vy = (4 * h * L + j) * 4;
+  float *strip = s_t + wave * (32 * TP);
+  float pv[KS];                          // the previous block's output rows (row s = cout block s >> 4, accumulator row s & 15)
+#pragma unroll
+  for (int s = 0; s < KS; s++) pv[s] = 0.f;
+  // xc: this block's operands; xp: the previous block's operand set, refilled with the NEXT block's
+  auto round = [&](float (&xc)[KS], float (&xp)[KS], int pb, int pt, bool validp, int nb, int nt) {
+    f32x16 ac[NB];
+#pragma unroll
+    for (int nbo = 0; nbo < NB; nbo++)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(s_bias + nbo * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+        for (int q = 0; q < 4; q++) ac[nbo][4 * g4 + q] = b4[q];
+      }
+    constexpr int PD = 1;      // (two waves per SIMD cover the LDS latency; the registers are at their limit)
+    static_assert(NB == 4, "one 16-byte weight fragment per lane and k-step");
+    f32x4 wr[PD + 1];
+    f32x2 ar[PD + 1];
+    const f32x4 *wl = reinterpret_cast<const f32x4 *>(s_w) + h * 32 + j;
+    auto fetch_k = [&](int slot, int s) {
+      ar[slot] = s_aff[2 * s + h];
+      wr[slot] = wl[s * 64];
+    };
+#pragma unroll
+    for (int s = 0; s < PD; s++) fetch_k(s, s);
+    const int so_p = (pb * C * L + pt * 32) * 4, vo_p = validp ? vy : 0x7FFFFF00;
+    const int so_n = (nb * C * L + nt * 32) * 4;
+    // A k-step's side work sits BETWEEN its four MFMAs, one piece per gap (pinned by scheduling barriers): an MFMA
+    // issues when the matrix pipe is free, so whatever precedes the next MFMA in program order must have issued by
+    // then -- bunched in front of the four MFMAs, the store / fetch / LDS traffic of a step took longer to issue than
+    // the last MFMA takes to execute and the pipe idled every step (82 of 157 TFLOP/s).
+    float v = fmaxf(fmaf(xc[0], ar[0][0], ar[0][1]), lo);
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+      const f32x4 w4 = wr[s % (PD + 1)];
+      const int r32 = (s & 3) + 8 * ((s & 15) >> 2), row = (s >> 4) * 32 + r32;
+      ac[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[0], v, ac[0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ts_st(ry, pv[s], vo_p, so_p + row * L * 4);            // item s of the previous block: output row (s >> 4, s & 15)
+      __builtin_amdgcn_sched_barrier(0);
+      ac[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[1], v, ac[1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      xp[s] = ts_ld(rx, vx, so_n + s * 2 * L * 4);           // item s of the next block's operand fetch
+      if (s + PD < KS) fetch_k((s + PD) % (PD + 1), s + PD);
+      __builtin_amdgcn_sched_barrier(0);
+      ac[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[2], v, ac[2], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      strip[(r32 + 4 * h) * TP + j] = validp ? pv[s] : 0.f;
+      __builtin_amdgcn_sched_barrier(0);
+      ac[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[3], v, ac[3], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < KS) {
+        const f32x2 sc = ar[(s + 1) % (PD + 1)];
+        v = fmaxf(fmaf(xc[s + 1], sc[0], sc[1]), lo);
+      }
+      if ((s & 15) == 15) {    // cout block s >> 4 of the previous block is complete in the strip: its lane = channel sums
+        ts_wave_sync();
+        float t[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) t[q] = strip[j * TP + 2 * q + h];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          ssum[s >> 4] += t[q];
+          ssq[s >> 4] = fmaf(t[q], t[q], ssq[s >> 4]);
+        }
+        ts_wave_sync();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // this block's rows out of the accumulators
+    // (an explicit accumulator -> architectural register move: written as a plain copy the compiler keeps the rows in
+    // the accumulator file and stores from there)
+#pragma unroll
+    for (int s = 0; s < KS; s++) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(pv[s]) : "a"(ac[s >> 4][s & 15]));
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto next = [&](int &bb, int &tt, bool go) {      // scalar only
+    const int t2 = tt + 1;
+    const bool wrap = t2 == nbpc;
+    const int nb = wrap ? bb + 1 : bb, nt = wrap ? 0 : t2;
+    bb = go ? nb : bb;
+    tt = go ? nt : tt;
+  };
+  const int nc = n0 < a.nblk ? n0 : a.nblk - 1;
+  int bA = nc / nbpc, tA = nc - bA * nbpc;
+  float xa[KS], xb[KS];
+  {
+    const int so = (bA * C * L + tA * 32) * 4;
+#pragma unroll
+    for (int s = 0; s < KS; s++) xa[s] = ts_ld(rx, vx, so + s * 2 * L * 4);
+  }
+  int bP = bA, tP = tA;             // previous block (of the round about to run)
+  bool vP = false;
+  for (int it = 0, idx = n0; it < a.per; it += 2, idx += 2) {
+    int bB = bA, tB = tA;
+    next(bB, tB, idx + 1 < n1);
+    round(xa, xb, bP, tP, vP, bB, tB);                           // block idx; block idx - 1 leaves, idx + 1 is fetched
+    int bC = bB, tC = tB;
+    next(bC, tC, idx + 2 < n1);
+    round(xb, xa, bA, tA, idx < n1, bC, tC);                     // block idx + 1; block idx leaves, idx + 2 is fetched
+    bP = bB;
+    tP = tB;
+    vP = idx + 1 < n1;
+    bA = bC;
+    tA = tC;
+  }
+  {   // the last block's rows
+    const int so = (bP * C * L + tP * 32) * 4, vo = vP ? vy : 0x7FFFFF00;
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+      const int r32 = (s & 3) + 8 * ((s & 15) >> 2), row = (s >> 4) * 32 + r32;
+      ts_st(ry, pv[s], vo, so + row * L * 4);
+      strip[(r32 + 4 * h) * TP + j] = vP ? pv[s] : 0.f;
+      if ((s & 15) == 15) {
+        ts_wave_sync();
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          const float t = strip[j * TP + 2 * q + h];
+          ssum[s >> 4] += t;
+          ssq[s >> 4] = fmaf(t, t, ssq[s >> 4]);
+        }
+        ts_wave_sync();
+      }
+    }
+  }
+  if (!a.stats) return;
+  __syncthreads();
+  float *red = s_t;                                 // [waves][2][C]
+#pragma unroll
+  for (int nbo = 0; nbo < NB; nbo++) {
+    const float d1 = ssum[nbo] + __shfl_xor(ssum[nbo], 32, 64), d2 = ssq[nbo] + __shfl_xor(ssq[nbo], 32, 64);
+    if (h == 0) {
+      red[(wave * 2) * C + nbo * 32 + j] = d1;
+      red[(wave * 2 + 1) * C + nbo * 32 + j] = d2;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < 2 * C; e += 64 * kTpWaves) {
+    const int st = e / C, c = e - st * C;
+    float v = red[st * C + c];
+#pragma unroll
+    for (int w = 1; w < kTpWaves; w++) v += red[(w * 2 + st) * C + c];
+    a.stats[((size_t)blockIdx.x * 2 + st) * C + c] = v;
   }
 }
 
@@ -216,7 +459,7 @@ struct TSBwd {
 };
 
 template <int NB, int MODE>
-__global__ __launch_bounds__(64 * kTsWaves) void tstream_bwd_kernel(TSBwd a) {
+__global__ __launch_bounds__(64 * kTsWaves, NB == 1 ? 3 : 1) void tstream_bwd_kernel(TSBwd a) {
   constexpr int C = 32 * NB, KS = C / 2, TP = 33;
   constexpr bool WLDS = NB > 1;                  // W^T from LDS (64 x 64 would take 64 registers per lane)
   __shared__ __attribute__((aligned(16))) float s_k[C][4];     // ka, kb, kc, -
@@ -321,39 +564,68 @@ __global__ __launch_bounds__(64 * kTsWaves) void tstream_bwd_kernel(TSBwd a) {
   BlkG gq;
   auto compute = [&](int bb, int tt, bool valid, int gb, int gt) {
     // 1. dy in the B-operand layout (k = output channel), a copy into strip A; dx = W^T dy
+    // (LDS operands are requested PD steps ahead of their use, in rings of register sets, the order pinned by
+    // scheduling barriers: see the forward kernel)
+    constexpr int PD = 2;
     float dy[KS];
+    {
+      f32x4 kr[PD + 1];
 #pragma unroll
-    for (int s = 0; s < KS; s++) {
-      const f32x4 kk = *reinterpret_cast<const f32x4 *>(s_k[2 * s + h]);
-      float gv = gq.g[s];
-      if constexpr (MODE == 3) gv = gq.am[s] == gq.k ? gv : 0.f;
-      const float v = fmaf(kk[0], gv, fmaf(kk[1], ry_[s], kk[2]));
-      dy[s] = valid ? v : 0.f;             // (a round beyond the wave's range adds nothing to dW / db / the sums)
-      sa[(2 * s + h) * TP + j] = dy[s];
+      for (int s = 0; s < PD; s++) kr[s] = *reinterpret_cast<const f32x4 *>(s_k[2 * s + h]);
+#pragma unroll
+      for (int s = 0; s < KS; s++) {
+        if (s + PD < KS) kr[(s + PD) % (PD + 1)] = *reinterpret_cast<const f32x4 *>(s_k[2 * (s + PD) + h]);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 kk = kr[s % (PD + 1)];
+        float gv = gq.g[s];
+        if constexpr (MODE == 3) gv = gq.am[s] == gq.k ? gv : 0.f;
+        const float v = fmaf(kk[0], gv, fmaf(kk[1], ry_[s], kk[2]));
+        dy[s] = valid ? v : 0.f;             // (a round beyond the wave's range adds nothing to dW / db / the sums)
+        sa[(2 * s + h) * TP + j] = dy[s];
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     load_g(gq, gb, gt);                    // the next block's gradient part and raw output
     load_y(gb, gt);
     f32x16 acc[NB];
 #pragma unroll
-    for (int nbi = 0; nbi < NB; nbi++) {
+    for (int nbi = 0; nbi < NB; nbi++)
 #pragma unroll
       for (int q = 0; q < 16; q++) acc[nbi][q] = 0.f;
+    {
+      float wr[PD + 1][NB];
+      auto fetch_w = [&](int slot, int s) {
+        if constexpr (WLDS) {
+#pragma unroll
+          for (int nbi = 0; nbi < NB; nbi++) wr[slot][nbi] = s_w[(2 * s + h) * C + nbi * 32 + j];
+        }
+      };
+#pragma unroll
+      for (int s = 0; s < PD; s++) fetch_w(s, s);
 #pragma unroll
       for (int s = 0; s < KS; s++) {
-        const float wv = WLDS ? s_w[(2 * s + h) * C + nbi * 32 + j] : wt[WLDS ? 0 : nbi][WLDS ? 0 : s];
-        acc[nbi] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, dy[s], acc[nbi], 0, 0, 0);
+        if (s + PD < KS) fetch_w((s + PD) % (PD + 1), s + PD);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nbi = 0; nbi < NB; nbi++) {
+          const float wv = WLDS ? wr[s % (PD + 1)][nbi] : wt[WLDS ? 0 : nbi][WLDS ? 0 : s];
+          acc[nbi] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, dy[s], acc[nbi], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     ts_wave_sync();
-    // 2. dy with lane = channel: token 2 s' + h of channel 32 nbo + j
+    // 2. dy with lane = channel: token 2 s' + h of channel 32 nbo + j (all reads first, then the sums)
     float dyc[NB][16];
 #pragma unroll
     for (int nbo = 0; nbo < NB; nbo++)
 #pragma unroll
-      for (int s = 0; s < 16; s++) {
-        dyc[nbo][s] = sa[(nbo * 32 + j) * TP + 2 * s + h];
-        db[nbo] += dyc[nbo][s];
-      }
+      for (int s = 0; s < 16; s++) dyc[nbo][s] = sa[(nbo * 32 + j) * TP + 2 * s + h];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nbo = 0; nbo < NB; nbo++)
+#pragma unroll
+      for (int s = 0; s < 16; s++) db[nbo] += dyc[nbo][s];
     ts_wave_sync();
     // 3. masked dx: to memory and into strip A; f(x) into strip B
     const int so = (bb * C * L + tt * 32) * 4;
@@ -379,19 +651,23 @@ __global__ __launch_bounds__(64 * kTsWaves) void tstream_bwd_kernel(TSBwd a) {
     // 4. lane = channel again: the two sums the next BatchNorm backward needs, and dW += dy f(x)^T
 #pragma unroll
     for (int nbi = 0; nbi < NB; nbi++) {
-      float ac[16];
+      float ac[16], dxc[16];
 #pragma unroll
       for (int s = 0; s < 16; s++) {
         ac[s] = sb[(nbi * 32 + j) * TP + 2 * s + h];
-        const float dxc = sa[(nbi * 32 + j) * TP + 2 * s + h];
-        s1[nbi] += dxc;
-        s2[nbi] += dxc * ((ac[s] - shl[nbi]) * invl[nbi]);      // (raw input where the mask is open; dxc = 0 elsewhere)
+        dxc[s] = sa[(nbi * 32 + j) * TP + 2 * s + h];
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int nbo = 0; nbo < NB; nbo++)
 #pragma unroll
         for (int s = 0; s < 16; s++)
           dw[nbo][nbi] = __builtin_amdgcn_mfma_f32_32x32x2f32(dyc[nbo][s], ac[s], dw[nbo][nbi], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 16; s++) {
+        s1[nbi] += dxc[s];
+        s2[nbi] += dxc[s] * ((ac[s] - shl[nbi]) * invl[nbi]);      // (raw input where the mask is open; dxc = 0 elsewhere)
+      }
     }
     ts_wave_sync();
   };
@@ -472,27 +748,48 @@ PCR_EXPORT int pcr_set_stream_min_blocks(int n) {
   return old;
 }
 
-// forward: 32 / 64 channels in and out, one input tensor, no residual / output ReLU, L a multiple of 32, tensors < 4 GB
+// forward: 32 / 64 / 128 channels in and out (32 x 32 with the weights in registers, the rest from an LDS image), one
+// input tensor, no residual / output ReLU, L a multiple of 32, tensors < 2 GB
+static bool ts_width(int c) { return c == 32 || c == 64 || c == 128; }
+
 bool pcr_ts_fwd_ok(const pcr_tdense_fwd *p) {
   const int cin = p->cin1, cout = p->cout;
   if (p->cin2 || p->res || p->out_relu) return false;
-  if (!((cin == 32 || cin == 64) && (cout == 32 || cout == 64))) return false;
+  if (!(ts_width(cin) && ts_width(cout)) || ((cin == 128) != (cout == 128))) return false;
   if ((p->L & 31) || p->B < 1) return false;
   if ((size_t)p->B * (cin > cout ? cin : cout) * p->L * 4 >= (1ull << 31)) return false;
   // (worth it only when a wave gets a stream of blocks: the grouped-MLP launches, not the per-point layers)
   return (long)p->B * (p->L >> 5) >= g_ts_min_blocks;
 }
 
+static size_t ts_fwd_lds(int cin, int cout) {
+  if (cin == 128) return ((size_t)3 * 128 + 128 * 128 + (size_t)kTpWaves * 32 * 33) * sizeof(float);   // (pipe kernel: the strips; the fold reuses them)
+  const bool wlds = !(cin == 32 && cout == 32);
+  return ((size_t)2 * cin + cout + (wlds ? (size_t)cin * cout : 0) + (size_t)kTsWaves * cout * 33) * sizeof(float);
+}
+
 int pcr_ts_fwd_grid(const pcr_tdense_fwd *p, int *per) {
   const int nblk = p->B * (p->L >> 5);
-  const int wgs_per_cu = (p->cin1 == 64 || p->cout == 64) ? 2 : 4;
+  // workgroups per CU: what the LDS image + strips admit, at most four
+  int wgs_per_cu = (int)((size_t)(160 * 1024) / ts_fwd_lds(p->cin1, p->cout));
+  wgs_per_cu = wgs_per_cu < 1 ? 1 : (wgs_per_cu > 4 ? 4 : wgs_per_cu);
+  if (p->cout == 64 || p->cin1 == 64) wgs_per_cu = wgs_per_cu > 3 ? 3 : wgs_per_cu;
+  const int waves = p->cin1 == 128 ? kTpWaves : kTsWaves;
+  if (p->cin1 == 128) wgs_per_cu = 1;
   int g = ts_cus() * wgs_per_cu;
-  int pw = (nblk + g * kTsWaves - 1) / (g * kTsWaves);
+  int pw = (nblk + g * waves - 1) / (g * waves);
   pw = (pw + 1) & ~1;                    // rounds come in pairs (two register sets)
   if (pw < 2) pw = 2;
-  g = (nblk + pw * kTsWaves - 1) / (pw * kTsWaves);
+  g = (nblk + pw * waves - 1) / (pw * waves);
   if (per) *per = pw;
   return g;
+}
+
+template <int NBI, int NBO, bool WLDS>
+static void ts_fwd_go(const TSFwd &a, int g, size_t lds, hipStream_t st) {
+  static bool ok = allow_big_lds(tstream_fwd_kernel<NBI, NBO, WLDS>);
+  (void)ok;
+  hipLaunchKernelGGL((tstream_fwd_kernel<NBI, NBO, WLDS>), dim3(g), dim3(64 * kTsWaves), lds, st, a);
 }
 
 int pcr_ts_fwd_launch(const pcr_tdense_fwd *p, hipStream_t st) {
@@ -500,11 +797,17 @@ int pcr_ts_fwd_launch(const pcr_tdense_fwd *p, hipStream_t st) {
   a.x = p->x; a.isc = p->isc; a.ish = p->ish; a.in_relu = p->in_relu; a.wp = p->wp; a.bias = p->bias;
   a.y = p->y; a.stats = p->stats; a.B = p->B; a.L = p->L; a.nblk = p->B * (p->L >> 5);
   const int g = pcr_ts_fwd_grid(p, &a.per);
-  const dim3 grid(g), blk(64 * kTsWaves);
-  if (p->cin1 == 32 && p->cout == 32) hipLaunchKernelGGL((tstream_fwd_kernel<1, 1>), grid, blk, 0, st, a);
-  else if (p->cin1 == 64 && p->cout == 64) hipLaunchKernelGGL((tstream_fwd_kernel<2, 2>), grid, blk, 0, st, a);
-  else if (p->cin1 == 32) hipLaunchKernelGGL((tstream_fwd_kernel<1, 2>), grid, blk, 0, st, a);
-  else hipLaunchKernelGGL((tstream_fwd_kernel<2, 1>), grid, blk, 0, st, a);
+  const size_t lds = ts_fwd_lds(p->cin1, p->cout);
+  const int ci = p->cin1, co = p->cout;
+  if (ci == 32 && co == 32) ts_fwd_go<1, 1, false>(a, g, lds, st);
+  else if (ci == 64 && co == 64) ts_fwd_go<2, 2, true>(a, g, lds, st);
+  else if (ci == 32 && co == 64) ts_fwd_go<1, 2, true>(a, g, lds, st);
+  else if (ci == 64 && co == 32) ts_fwd_go<2, 1, true>(a, g, lds, st);
+  else {
+    static bool ok = allow_big_lds(tstream_fwd_pipe_kernel<4>);
+    (void)ok;
+    hipLaunchKernelGGL((tstream_fwd_pipe_kernel<4>), dim3(g), dim3(64 * kTpWaves), lds, st, a);
+  }
   return hipGetLastError() == hipSuccess ? PCR_OK : PCR_ERR_LAUNCH;
 }
 
@@ -521,7 +824,7 @@ bool pcr_ts_bwd_ok(const pcr_tdense_bwd *p) {
 
 int pcr_ts_bwd_grid(const pcr_tdense_bwd *p, int *per) {
   const int nblk = p->B * (p->L >> 5);
-  const int wgs_per_cu = p->cout == 64 ? 1 : 2;      // what registers / LDS admit (one / two waves per SIMD)
+  const int wgs_per_cu = p->cout == 64 ? 1 : 3;      // what registers / LDS admit (one / three waves per SIMD)
   int g = ts_cus() * wgs_per_cu;
   int pw = (nblk + g * kTsWaves - 1) / (g * kTsWaves);
   pw = (pw + 1) & ~1;                    // rounds come in pairs (two register sets)

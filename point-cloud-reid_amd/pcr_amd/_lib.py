@@ -33,6 +33,8 @@ def load():
         lib.pcr_sa_tile_ws_ints.restype = ctypes.c_long
         if lib.pcr_abi_version() != ABI_VERSION:
             raise PcrError("libpcr_hip.so ABI %d != binding %d: rebuild" % (lib.pcr_abi_version(), ABI_VERSION))
+        if os.environ.get("PCR_STREAM_MIN_BLOCKS"):      # launch policy of the train-dense kernels (include/pcr.h)
+            lib.pcr_set_stream_min_blocks(int(os.environ["PCR_STREAM_MIN_BLOCKS"]))
         _lib = lib
     return _lib
 

@@ -29,7 +29,8 @@ class _policy:
 
 
 @pytest.mark.parametrize("B,cin,cout,Ln", [(3, 32, 32, 4096), (5, 32, 32, 96), (2, 64, 64, 3072), (7, 64, 64, 32),
-                                           (3, 32, 64, 160), (3, 64, 32, 640), (130, 32, 32, 64)])
+                                           (3, 32, 64, 160), (3, 64, 32, 640), (130, 32, 32, 64), (2, 128, 128, 1536),
+                                           (37, 128, 128, 32)])
 def test_stream_forward_equals_tile_forward(B, cin, cout, Ln):
     from pcr_amd import train_ops as TO
     g = torch.Generator().manual_seed(B * 1000 + Ln)
