@@ -268,8 +268,15 @@ typedef struct pcr_attn_params {
    * bf16 image, so pcr_attn_kv_f32 and pcr_attn_apply_f32 must be called with the SAME precision. */
   int precision;
   const float *wq_bf, *wmlp0_bf, *wmlp2_bf, *wfinal_bf;
+  /* pcr_attn_kv_f32, d <= 128: kv_splits > 1 splits every cloud's key tokens over that many workgroups (raw partial
+   * matrices in kv_part, (B, kv_splits, d d + d) floats) and a second launch adds them in order and folds the merge
+   * projection -- for launches whose one-workgroup-per-cloud grid would leave the last round of the chip mostly empty.
+   * pcr_attn_kv_splits(B, Sk, d) suggests a count (1 = the single-launch form; kv_part may then be NULL). */
+  int kv_splits;
+  float *kv_part;
 } pcr_attn_params;
 long pcr_attn_kv_floats(int d);
+int pcr_attn_kv_splits(int B, int Sk, int d);
 int pcr_attn_kv_f32(const pcr_attn_params *p, pcr_stream_t stream);
 int pcr_attn_apply_f32(const pcr_attn_params *p, pcr_stream_t stream);
 
@@ -432,6 +439,17 @@ typedef struct pcr_tdense_bwd {
   long part_stride;   /* floats between consecutive workgroups' dwp / dbp partials; 0 = two dense arrays */
 } pcr_tdense_bwd;
 int pcr_tdense_bwd_f32(const pcr_tdense_bwd *p, pcr_stream_t stream);
+
+/* Training-mode core of local_self_attention (attention.py:262-296): qkv (B,3C,N) channel-major = the fused q | k | v
+ * projection of feat + pos(xyz) per POINT, idx (B,N,K) feature-space neighbours (pcr_knn_feat_f32).
+ * fwd: msg (B,C,N), msg_i = sum_j a_ij v_j / (sum_j a_ij + eps), a_ij = <elu(q_i)+1, elu(k_j)+1> per head.
+ * bwd: g (B,C,N) -> dq (C rows of N per cloud, clouds dq_bstride floats apart: a slice of the (B,3C,N) gradient) and
+ * the per-edge gradients edge (B,2C,N,K) = [d k_j | d v_j contributions]; pcr_group_bwd_f32(edge, idx, .) folds them
+ * onto the points (no float atomics).  C <= 64, C / nhead a power of two. */
+int pcr_local_attn_train_fwd_f32(const float *qkv, const int *idx, float *msg, int B, int N, int C, int K, int nhead,
+                                 float eps, pcr_stream_t stream);
+int pcr_local_attn_train_bwd_f32(const float *qkv, const int *idx, const float *g, float *dq, long dq_bstride, float *edge,
+                                 int B, int N, int C, int K, int nhead, float eps, pcr_stream_t stream);
 
 /* out[r][c] = sum over p < nparts (increasing p) of part[p * stride + r * ld + c] */
 int pcr_reduce_parts_f32(const float *part, int nparts, long stride, int rows, int cols, int ld, float *out,

@@ -8,6 +8,7 @@ stage boundary of the hot path.  Only tensors (npz) and name/shap
 Run:  python oracle/make_golden.py            (writes tests/golden/*)
 """
 import contextlib
+import copy
 import io
 import json
 import os
@@ -323,6 +324,7 @@ def gen_train_variants(only=None):
     encoders) of 128 points, seeded weights, BatchNorm in batch-statistics mode"""
     ref = ref_loader.load_reference()
     ref.dgcnn_orig.torch = _CpuTorch()
+    ref.attention.torch = _CpuTorch()        # attention.get_graph_feature hard-codes torch.device('cuda') (:114)
     losses = dict(kl=False, match=True, cls=False, shape=False, fp=False, triplet=False)
     cases = (("pt15m", MUL_CFGS[0][1], dict(), 4, 128),
              ("baseline", BASE_CFG, dict(shape_head=None), 8, 128),
@@ -330,12 +332,16 @@ def gen_train_variants(only=None):
              # executes plain config files only, so the `_base_` merge is spelled out)
              ("stnet", PT_CFG, dict(match_type="xcorr-baseline"), 8, 128),
              ("pointnet", PN_CFG, dict(), 4, 128),
-             ("dgcnn", DG_CFG, dict(), 4, 128))
+             ("dgcnn", DG_CFG, dict(), 4, 128),
+             # (reid_pts_point-transformer_baseline_orig.py = the point-cat file + match_type 'xcorr' + the two
+             # local_self_attention stages: reid_waymo_pts/pts_point-transformer_baseline-orig_waymo_det_4x256_400e.py)
+             ("orig", PT_CFG, dict(match_type="xcorr", local_stage1=dict(LOCAL), local_stage2=dict(LOCAL)), 8, 128))
     for tag, cfg, over, pairs, n in cases:
         if only and tag not in only:
             continue
-        model, manifest = build(cfg, seed=0, losses_to_use=losses, **over)
-        if "backbone_list" in over or tag in ("pt15m", "baseline", "stnet"):
+        # (deep copies: the reference's build_module deletes cfg['type'] from the dict it is given)
+        model, manifest = build(cfg, seed=0, losses_to_use=losses, **copy.deepcopy(over))
+        if "backbone_list" in over or tag in ("pt15m", "baseline", "stnet", "orig"):
             model.backbone_list = [128, 64, 32]
         model.train()
         data = _train_data(pairs, n)
@@ -357,8 +363,8 @@ def gen_train_variants(only=None):
         # gradients are from the exact ones.  Tensors in front of a max-over-K / BatchNorm batch statistics move by
         # 1e-3 .. 1e-2 of their scale between float32 and float64 (a near-tie resolved the other way re-routes a whole
         # gradient row), tensors behind the last max by ~1e-6: the yardstick the GPU test holds the HIP gradients to
-        model64, _ = build(cfg, seed=0, losses_to_use=losses, **over)
-        if tag in ("pt15m", "baseline", "stnet"):
+        model64, _ = build(cfg, seed=0, losses_to_use=losses, **copy.deepcopy(over))
+        if tag in ("pt15m", "baseline", "stnet", "orig"):
             model64.backbone_list = [128, 64, 32]
         model64 = model64.double().train()
         data64 = {k: [t.double() if t.is_floating_point() else t for t in v] for k, v in data.items()}

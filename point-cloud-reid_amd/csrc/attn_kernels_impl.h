@@ -41,6 +41,46 @@ __device__ __forceinline__ void load_xyz3(float *P, int RP, const float *xyz, in
   }
 }
 
+// merge fold of one cloud from its head-masked KV in LDS (KVl [dd][d + 1]) and total key sums (s_kt [d]):
+// M[o][dd] = sum_{v in head(dd)} Wm[o][v] KV[dd][v], written as the packed A-operand image (f32 or bf16 hi / lo), then ksum
+__device__ __forceinline__ void attn_kv_fold_write(const pcr_attn_params &p, const float *KVl, const float *s_kt, size_t b) {
+  const int d = p.d, dh = d / p.nhead, ld = d + 1, tid = threadIdx.x;
+  float *kv = p.kv + b * ((size_t)d * d + d);
+  // e = (o = e / d, dd = e % d) advances by kThreads: one division per thread, then increments; the head of dd is
+  // re-derived only when dd changes (never for d = 32 / 64 / 128, where kThreads % d == 0)
+  const int d_o = kThreads / d, d_dd = kThreads - d_o * d;
+  int o = tid / d, dd = tid - o * d;
+  int v0 = (dd / dh) * dh;
+  for (int e = tid; e < d * d; e += kThreads, o += d_o, dd += d_dd) {
+    if (dd >= d) {
+      dd -= d;
+      o++;
+    }
+    if (d_dd) v0 = (dd / dh) * dh;
+    const float *wm = p.wmerge + (size_t)o * d + v0;
+    const float *kr = KVl + dd * ld + v0;
+    float m = 0.f;
+#pragma unroll 8
+    for (int v = 0; v < dh; v++) m += wm[v] * kr[v];   // (unrolled: batches of independent loads)
+    if constexpr (kAPrec == 0) {
+      const int kb = dd >> 3, rem = dd & 7;
+      kv[(((size_t)kb * d + o) * 2 + (rem & 1)) * 4 + (rem >> 1)] = m;
+    } else {
+      // the bf16 A-operand image of M (cout o, cin dd; tile_dense.h: accumulator-order K inside a 16-channel step)
+      const int s16 = dd >> 4, kk = dd & 15;
+      const int hh = (kk >> 2) & 1, jj = (kk & 3) + ((kk >> 3) << 2);
+      const size_t unit = (((size_t)s16 * (d >> 5) + (o >> 5)) * 2) * 64 + hh * 32 + (o & 31);
+      const __bf16 hi = (__bf16)m;
+      const __bf16 lo = (__bf16)(m - (float)hi);
+      __bf16 *img = reinterpret_cast<__bf16 *>(kv);
+      img[unit * 8 + jj] = hi;
+      img[(unit + 64) * 8 + jj] = lo;
+    }
+  }
+  __syncthreads();
+  if (tid < d) kv[(size_t)d * d + tid] = s_kt[tid];
+}
+
 // One workgroup per key-side cloud, token tiles of T = 32*TB (TB = 2 for d <= 64, 1 for d = 128).
 // kv image per cloud: packed (d x d) matrix M (merge folded in, see above) followed by ksum[d].
 // LDS: XH [c2 + d] key features ; hidden -- the fused K/V projection (2d <= c2 + d rows) is written IN PLACE over
@@ -116,18 +156,24 @@ __device__ __forceinline__ void attn_kv_body(const AttnArgs &a) {
       }
     }
   };
+  // token split (kv_splits > 1): workgroup (b, y) takes the tiles [y * tps, (y + 1) * tps) of its cloud and leaves its
+  // raw partial KV / key sums in kv_part; attn_kv_fold_kernel adds the partials in order and folds the merge projection
+  const int nsplit = p.kv_splits > 1 ? p.kv_splits : 1;
+  const int ntile = (p.Sk + T - 1) / T, tps = (ntile + nsplit - 1) / nsplit;
+  const int t_lo = (int)blockIdx.y * tps * T;
+  const int t_hi = (t_lo + tps * T) < p.Sk ? (t_lo + tps * T) : p.Sk;
   bool have = false;   // the registers hold the tile about to be processed
-  if (vec_ok && T <= p.Sk) {
-    fetch(0);
+  if (vec_ok && t_lo + T <= p.Sk && t_lo < t_hi) {
+    fetch(t_lo);
     have = true;
   }
-  for (int t0 = 0; t0 < p.Sk; t0 += T) {
+  for (int t0 = t_lo; t0 < t_hi; t0 += T) {
     const int valid = p.Sk - t0;
     if (have) stash();
     else load_tile(XH, RP, feat, c2, c2, p.Sk, t0, T);
     load_xyz3(P, RP, xyz, p.Sk, t0, T);
     __syncthreads();
-    have = vec_ok && t0 + 2 * T <= p.Sk;   // the next tile is whole: request it now, store it after this tile's MFMAs
+    have = vec_ok && t0 + 2 * T <= p.Sk && t0 + T < t_hi;   // the next tile is whole: request it now, store it after this tile's MFMAs
     if (have) fetch(t0 + T);
     pos_hidden(XH + c2 * RP, RP, P, s_w0, s_b0, d, T);
     __syncthreads();
@@ -166,6 +212,27 @@ __device__ __forceinline__ void attn_kv_body(const AttnArgs &a) {
     }
     __syncthreads();   // K / V live in XH: the next tile may only be written once every wave is done with them
   }
+  if (nsplit > 1) {   // raw partials: [d][d] KV (row dd, column v), then d key sums
+    float *part = p.kv_part + ((size_t)b * nsplit + blockIdx.y) * ((size_t)d * d + d);
+    s_ks[tid] = ksum;
+#pragma unroll
+    for (int it = 0; it < NTW; it++) {
+      const int item = wave + 4 * it;
+      if (item < nT) {
+        const int ib = tile_ib[it], jb = item - ib * nb;
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          part[(size_t)(ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * d + jb * 32 + l31] = acc[it][r];
+      }
+    }
+    __syncthreads();
+    if (tid < d) {
+      float s = 0.f;
+      for (int pp = 0; pp < kparts; pp++) s += s_ks[pp * d + tid];
+      part[(size_t)d * d + tid] = s;
+    }
+    return;
+  }
   // KV (head-masked) -> LDS [dd][d+1], then fold the merge projection and write the packed image
   float *KVl = smem;
   const int ld = d + 1;
@@ -194,40 +261,7 @@ __device__ __forceinline__ void attn_kv_body(const AttnArgs &a) {
     for (int pp = 0; pp < kparts; pp++) s += s_ks[pp * d + tid];
     s_kt[tid] = s;
   }
-  float *kv = p.kv + b * ((size_t)d * d + d);
-  // e = (o = e / d, dd = e % d) advances by kThreads: one division per thread, then increments; the head of dd is
-  // re-derived only when dd changes (never for d = 32 / 64 / 128, where kThreads % d == 0)
-  const int d_o = kThreads / d, d_dd = kThreads - d_o * d;
-  int o = tid / d, dd = tid - o * d;
-  int v0 = (dd / dh) * dh;
-  for (int e = tid; e < d * d; e += kThreads, o += d_o, dd += d_dd) {
-    if (dd >= d) {
-      dd -= d;
-      o++;
-    }
-    if (d_dd) v0 = (dd / dh) * dh;
-    const float *wm = p.wmerge + (size_t)o * d + v0;
-    const float *kr = KVl + dd * ld + v0;
-    float m = 0.f;
-#pragma unroll 8
-    for (int v = 0; v < dh; v++) m += wm[v] * kr[v];   // (unrolled: batches of independent loads)
-    if constexpr (kAPrec == 0) {
-      const int kb = dd >> 3, rem = dd & 7;
-      kv[(((size_t)kb * d + o) * 2 + (rem & 1)) * 4 + (rem >> 1)] = m;
-    } else {
-      // the bf16 A-operand image of M (cout o, cin dd; tile_dense.h: accumulator-order K inside a 16-channel step)
-      const int s16 = dd >> 4, kk = dd & 15;
-      const int hh = (kk >> 2) & 1, jj = (kk & 3) + ((kk >> 3) << 2);
-      const size_t unit = (((size_t)s16 * (d >> 5) + (o >> 5)) * 2) * 64 + hh * 32 + (o & 31);
-      const __bf16 hi = (__bf16)m;
-      const __bf16 lo = (__bf16)(m - (float)hi);
-      __bf16 *img = reinterpret_cast<__bf16 *>(kv);
-      img[unit * 8 + jj] = hi;
-      img[(unit + 64) * 8 + jj] = lo;
-    }
-  }
-  __syncthreads();
-  if (tid < d) kv[(size_t)d * d + tid] = s_kt[tid];
+  attn_kv_fold_write(p, KVl, s_kt, b);
 }
 
 template <int TB, int NR, int WSEL, int NTW>
@@ -239,6 +273,29 @@ __global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
 template <int TB, int NR, int WSEL, int NTW>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_kv_kernel_o3(AttnArgs a) {
   attn_kv_body<TB, NR, WSEL, NTW>(a);
+}
+
+// second launch of the token-split form: one workgroup per cloud adds the splits' partials in order (fixed: the result
+// does not depend on the schedule), applies the head mask and folds the merge projection
+__global__ __launch_bounds__(kThreads) void attn_kv_fold_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const pcr_attn_params &p = a.p;
+  const int d = p.d, dh = d / p.nhead, ld = d + 1, nsplit = p.kv_splits, tid = threadIdx.x;
+  const size_t b = blockIdx.x, per = (size_t)d * d + d;
+  float *KVl = smem, *s_kt = smem + d * ld;
+  const float *part = p.kv_part + b * nsplit * per;
+  for (int e = tid; e < d * d + d; e += kThreads) {
+    float v = part[e];
+    for (int y = 1; y < nsplit; y++) v += part[(size_t)y * per + e];
+    if (e < d * d) {
+      const int dd = e / d, c = e - dd * d;
+      KVl[dd * ld + c] = (dd / dh == c / dh) ? v : 0.f;
+    } else {
+      s_kt[e - d * d] = v;
+    }
+  }
+  __syncthreads();
+  attn_kv_fold_write(p, KVl, s_kt, b);
 }
 
 #if PCR_ATTN_PREC == 0
@@ -492,13 +549,24 @@ static int attn_kv_narrow(const pcr_attn_params *pp, pcr_stream_t stream) {
   static bool ok = allow_big_lds(attn_kv_kernel<2, 1, 2, 1>) && allow_big_lds(attn_kv_kernel_o3<2, 1, 1, 1>) &&
                    allow_big_lds(attn_kv_kernel_o3<1, 2, 1, 4>) && allow_big_lds(attn_kv_kernel<1, 2, 0, 4>);
   (void)ok;
-  dim3 g(pp->B), blk(kThreads);
+  const int ntile = (pp->Sk + 32 * tb - 1) / (32 * tb);
+  int ns = pp->kv_splits > 1 ? pp->kv_splits : 1;
+  if (ns > 1 && (!pp->kv_part || ns > 64)) return PCR_ERR_INVALID;
+  if (ns > ntile) ns = ntile;                 // (kv_part is sized for the requested count: fewer splits use its head)
+  a.p.kv_splits = ns;
+  dim3 g(pp->B, ns), blk(kThreads);
   hipStream_t st = pcr_s(stream);
   if (d == 32) hipLaunchKernelGGL((attn_kv_kernel<2, 1, 2, 1>), g, blk, lds, st, a);        // 2d = 64: two cout blocks
   else if (d == 64) hipLaunchKernelGGL((attn_kv_kernel_o3<2, 1, 1, 1>), g, blk, lds, st, a);   // four, one per wave
   else if (d == 128) hipLaunchKernelGGL((attn_kv_kernel_o3<1, 2, 1, 4>), g, blk, lds, st, a);  // eight, two rounds
   else hipLaunchKernelGGL((attn_kv_kernel<1, 2, 0, 4>), g, blk, lds, st, a);                // d = 96: generic shape
   PCR_CHECK_LAUNCH();
+  if (ns > 1) {
+    static bool okf = allow_big_lds(attn_kv_fold_kernel);
+    (void)okf;
+    hipLaunchKernelGGL(attn_kv_fold_kernel, dim3(pp->B), blk, ((size_t)d * (d + 1) + d) * sizeof(float), st, a);
+    PCR_CHECK_LAUNCH();
+  }
   return PCR_OK;
 }
 
@@ -564,6 +632,29 @@ static bool attn_bf(const pcr_attn_params &p, pcr_attn_params &q) {
   q = p;      // (wkv stays the f32 image: the kv kernel's projection is f32 in both units, only its output M changes form)
   q.wq = p.wq_bf; q.wmlp0 = p.wmlp0_bf; q.wmlp2 = p.wmlp2_bf; q.wfinal = p.wfinal_bf;
   return true;
+}
+
+// Suggested token split of a kv launch.  Measured on pt1024 (1024 clouds, 768 resident workgroups): 1 / 2 / 3 / 4 splits
+// run the d = 64, Sk = 1024 launches in 0.495 / 0.484 / 0.476 / 0.492 ms -- a full grid is bound by its per-tile work, not
+// by the partly filled last round, so a launch that already fills the chip keeps the single-launch form.  A SMALL batch
+// (fewer clouds than resident workgroups: gallery queries, the tests' few pairs) gains the parallelism it lacks:
+// n = slots / B splits, at most four (two at d = 128, whose partial matrices are as large as its inputs), at least
+// two tiles each.
+PCR_EXPORT int pcr_attn_kv_splits(int B, int Sk, int d) {
+  if (B < 1 || Sk < 1 || d > 128) return 1;
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) return 256;
+    return n;
+  }();
+  const int slots = cus * (d <= 32 ? 4 : 3);
+  const int T = d <= 64 ? 64 : 32, ntile = (Sk + T - 1) / T;
+  int n = slots / B;
+  const int nmax = d >= 128 ? 2 : 4;
+  if (n > nmax) n = nmax;
+  if (n > ntile / 2) n = ntile / 2;
+  return n < 1 ? 1 : n;
 }
 
 PCR_EXPORT int pcr_attn_kv_f32(const pcr_attn_params *pp, pcr_stream_t stream) {

@@ -4,6 +4,7 @@ current HIP stream.  Every entry point requires device tensors and raises if lib
 missing -- there is no CPU path here (the CPU restatement lives under oracle/ and is test-only).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -25,6 +26,10 @@ PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2}
 PRECISION = _os.environ.get("PCR_PRECISION", "bf16x3")
 if PRECISION not in PRECISIONS:
     raise L.PcrError("PCR_PRECISION must be one of %s" % sorted(PRECISIONS))
+
+
+KV_SPLITS = int(os.environ["PCR_KV_SPLITS"]) if os.environ.get("PCR_KV_SPLITS") else None   # None: pcr_attn_kv_splits
+# decides; an int forces the token split of the attention kv launches (tests, tuning)
 
 
 def set_precision(name):
@@ -104,7 +109,8 @@ class AttnParams(ctypes.Structure):
                 ("wkv_wide", c_float_p), ("bkv_wide", c_float_p), ("wmerge_packed", c_float_p),
                 ("kv", c_float_p), ("out", c_float_p),
                 ("precision", ctypes.c_int),
-                ("wq_bf", c_float_p), ("wmlp0_bf", c_float_p), ("wmlp2_bf", c_float_p), ("wfinal_bf", c_float_p)]
+                ("wq_bf", c_float_p), ("wmlp0_bf", c_float_p), ("wmlp2_bf", c_float_p), ("wfinal_bf", c_float_p),
+                ("kv_splits", ctypes.c_int), ("kv_part", c_float_p)]
 
 
 class HeadParams(ctypes.Structure):
@@ -369,6 +375,11 @@ class AttnPlan:
         kv = torch.empty((B, lib.pcr_attn_kv_floats(self.d)), dtype=torch.float32, device=feat_k.device)
         p = self._params(B, 1, Sk, feat_k, xyz_k, feat_k, xyz_k, kv, kv)
         d = self.d
+        # token split (the library's suggestion for this launch shape): partial matrices + a fold launch
+        ns = lib.pcr_attn_kv_splits(B, Sk, d) if KV_SPLITS is None else KV_SPLITS
+        if ns > 1:
+            part = torch.empty((B, ns, lib.pcr_attn_kv_floats(d)), dtype=torch.float32, device=feat_k.device)
+            p.kv_splits, p.kv_part = ns, _p(part)
         kv_flops = 2.0 * B * Sk * (3 * d + d * c2 + 2 * c2 * d + d * d / self.nhead)   # reference's op count
         with _prof("attn_kv[d=%d,c2=%d,Sk=%d]" % (d, c2, Sk), kv_flops, 4.0 * B * (c2 * Sk + 3 * Sk + d * d + d)):
             L.check(lib.pcr_attn_kv_f32(ctypes.byref(p), L.stream_ptr()), "pcr_attn_kv_f32")

@@ -56,6 +56,23 @@ def cross_attention(m, search, template, template_xyz_cm):
     return _attention(m, None, search, template, _pos(m.pos_mlp, template_xyz_cm, template), search, True, False)
 
 
+def local_self_attention(m, feat, xyz_cm):
+    """local_self_attention (attention.py:262-296) in training mode: feat (B,C,N), xyz (B,3,N) -> (B,C,N).  The
+    neighbour graph is the feature-space kNN of the block's INPUT (no gradient, as torch.topk's indices); key and value
+    of an edge are the neighbour point's own projections, so q | k | v come from one dense launch over the points"""
+    from . import dgcnn_engine
+    from . import _lib as L
+    if m.pos_mlp_knn[2].weight.shape[0] != m.d_model:
+        raise L.PcrError("local_self_attention: pos_size must equal d_model (the position code is added to the features)")
+    idx = dgcnn_engine.knn_feat(feat.detach().contiguous(), int(m.knum))                 # (B,N,K) int32
+    fp = _pos(m.pos_mlp_knn, xyz_cm, feat)
+    qkv = TO.dense(fp, torch.cat([m.q_proj_knn.weight, m.k_proj_knn.weight, m.v_proj_knn.weight], dim=0))
+    msg = TO.LocalAttn.apply(qkv, idx, int(m.nhead), ATTN_EPS)
+    n1 = TO.tnorm(TO.dense(msg, m.merge_knn.weight), m.norm1_knn)
+    f0 = TO.dense(feat, m.mlp_knn[0].weight, x2=n1, relu=True)
+    return TO.tnorm(TO.dense(f0, m.mlp_knn[2].weight), m.norm2_knn, res=feat)
+
+
 def sa_edge_layer(sa, xyz, feats, s):
     """PointNetSetAbstractionEdgeSA in training mode: (B,N,3), (B,D,N)|None -> (B,S,3), (B,D',S)"""
     xyz = xyz.contiguous()
@@ -168,7 +185,7 @@ def _head(model, pooled):
 
 def supports(model):
     """the training graph covers: xcorr_eff + point-cat + pool 'both' (every point-cat config), xcorr-baseline + pool
-    'both' (reid_pts_point-transformer_baseline_stnet.py) and concat + pool 'max'
+    'both' (reid_pts_point-transformer_baseline_stnet.py), xcorr + pool 'both' (..._baseline_orig.py) and concat + pool 'max'
     (reid_pts_point-transformer_baseline.py); -> None or the reason it does not"""
     head = model.match_head
     if not (isinstance(head, torch.nn.Sequential) and len(head) == 2):
@@ -178,10 +195,14 @@ def supports(model):
         return None
     if mt == "xcorr-baseline" and pool == "both":
         return None
+    if mt == "xcorr" and pool == "both":
+        if model.local_stage1 is None or model.local_stage2 is None:
+            return "match_type='xcorr' needs local_stage1 / local_stage2 (local_self_attention)"
+        return None
     if mt == "concat" and pool == "max":
         return None
     return ("match_type=%r / combine=%r / pool_type=%r has no HIP training graph (covered: xcorr_eff + point-cat + both, "
-            "xcorr-baseline + both, concat + max)" % (mt, model.combine, pool))
+            "xcorr-baseline + both, xcorr + both, concat + max)" % (mt, model.combine, pool))
 
 
 def match_logits(model, h1, xyz1, h2, xyz2):
@@ -207,6 +228,13 @@ def match_logits(model, h1, xyz1, h2, xyz2):
     if model.match_type == "xcorr-baseline":
         a = cross_attention(model.cross_stage1, h1, h2, _cm(xyz2))
         o = cross_attention(model.cross_stage2, a, h2, _cm(xyz2))
+        return _head(model, TO.PoolBoth.apply(o)), None
+    if model.match_type == "xcorr":          # baseline-orig (ReIDNet.py:250-256): cross -> local -> cross -> local
+        x1, x2 = _cm(xyz1), _cm(xyz2)
+        a = cross_attention(model.cross_stage1, h1, h2, x2)
+        bb = local_self_attention(model.local_stage1, a, x1)
+        c = cross_attention(model.cross_stage2, bb, h2, x2)
+        o = local_self_attention(model.local_stage2, c, x1)
         return _head(model, TO.PoolBoth.apply(o)), None
     feats = _joined(h1, h2)
     xyz_cm = _cm(_joined(xyz1, xyz2))

@@ -572,6 +572,44 @@ class LinAttnQKV(Function):
         return buf, None, None
 
 
+class LocalAttn(Function):
+    """core of local_self_attention in training mode (attention.py:262-296): qkv (B,3C,N) = the fused q | k | v
+    projection per POINT, idx (B,N,K) int32 feature-space neighbours (no gradient) -> msg (B,C,N); the backward's
+    per-edge gradients are folded onto the points by the grouping backward (owner-computes, no float atomics)"""
+
+    @staticmethod
+    def forward(ctx, qkv, idx, H, eps):
+        qkv, idx = _dev(qkv), idx.contiguous()
+        L.require_i32(idx)
+        B, C3, N = qkv.shape
+        C, K = C3 // 3, idx.shape[2]
+        msg = _f32(B, C, N, device=qkv.device)
+        L.check(L.load().pcr_local_attn_train_fwd_f32(L.ptr(qkv), L.ptr(idx), L.ptr(msg), B, N, C, K, H,
+                                                      ctypes.c_float(eps), L.stream_ptr()), "pcr_local_attn_train_fwd_f32")
+        ctx.save_for_backward(qkv, idx)
+        ctx.meta = (H, eps)
+        return msg
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv, idx = ctx.saved_tensors
+        H, eps = ctx.meta
+        B, C3, N = qkv.shape
+        C, K = C3 // 3, idx.shape[2]
+        lib = L.load()
+        g = g.contiguous()
+        dqkv = torch.zeros((B, 3 * C, N), dtype=torch.float32, device=qkv.device)      # (k | v rows: accumulated into)
+        edge = _f32(B, 2 * C, N, K, device=qkv.device)
+        L.check(lib.pcr_local_attn_train_bwd_f32(L.ptr(qkv), L.ptr(idx), L.ptr(g), L.ptr(dqkv), ctypes.c_long(3 * C * N),
+                                                 L.ptr(edge), B, N, C, K, H, ctypes.c_float(eps), L.stream_ptr()),
+                "pcr_local_attn_train_bwd_f32")
+        dkv = torch.zeros((B, 2 * C, N), dtype=torch.float32, device=qkv.device)
+        L.check(lib.pcr_group_bwd_f32(L.ptr(edge), L.ptr(idx), L.ptr(dkv), B, 2 * C, N, N, K, L.stream_ptr()),
+                "pcr_group_bwd_f32")
+        dqkv[:, C:] = dkv
+        return dqkv, None, None, None
+
+
 class TNorm(Function):
     """[relu](LayerNorm (G = 1) / GroupNorm over the channels of every token of (B,C,L) [+ res])"""
 

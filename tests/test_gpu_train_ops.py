@@ -397,3 +397,35 @@ def test_fused_adamw_is_reproducible_and_refuses_host_tensors():
     cpu[0].grad = torch.randn(4)
     with pytest.raises(L.PcrError):
         FusedAdamW(cpu).step()
+
+
+@pytest.mark.parametrize("B,C,N,K,H", [(3, 64, 128, 48, 2), (2, 32, 50, 7, 4), (1, 48, 33, 33, 3)])
+def test_local_attention_core_matches_torch_autograd(B, C, N, K, H):
+    """train_ops.LocalAttn (one query token per point over its K neighbours, per-edge gradients folded by the grouping
+    backward) against the reference's formulation in plain torch: LinearAttention on the gathered (B N, K, C) tensor"""
+    from pcr_amd import train_ops as TO
+    g = torch.Generator().manual_seed(C + K)
+    qkv = torch.randn(B, 3 * C, N, generator=g).cuda().requires_grad_(True)
+    idx = torch.stack([torch.stack([torch.randperm(N, generator=g)[:K] for _ in range(N)]) for _ in range(B)]).int().cuda()
+    go = torch.randn(B, C, N, generator=g).cuda()
+    out = TO.LocalAttn.apply(qkv, idx, H, 1e-6)
+    out.backward(go)
+    got = qkv.grad.clone()
+    q2 = qkv.detach().clone().requires_grad_(True)
+    rows = q2.permute(0, 2, 1)                                                   # (B,N,3C)
+    li = idx.long()
+    nb = torch.gather(rows.unsqueeze(1).expand(-1, N, -1, -1), 2, li.unsqueeze(-1).expand(-1, -1, -1, 3 * C))   # (B,N,K,3C)
+    D = C // H
+    Q = (F.elu(rows[..., :C]) + 1).reshape(B * N, 1, H, D)
+    Kf = (F.elu(nb[..., C:2 * C]) + 1).reshape(B * N, K, H, D)
+    V = nb[..., 2 * C:].reshape(B * N, K, H, D) / K
+    KV = torch.einsum("nshd,nshv->nhdv", Kf, V)
+    Z = 1 / (torch.einsum("nlhd,nhd->nlh", Q, Kf.sum(dim=1)) + 1e-6)
+    want = (torch.einsum("nlhd,nhdv,nlh->nlhv", Q, KV, Z) * K).reshape(B, N, C).permute(0, 2, 1)
+    assert _rel(out, want) < 2e-5, _rel(out, want)
+    want.backward(go)
+    assert _rel(got, q2.grad) < 2e-5, _rel(got, q2.grad)
+    # bit-reproducible
+    qkv.grad = None
+    TO.LocalAttn.apply(qkv, idx, H, 1e-6).backward(go)
+    assert torch.equal(qkv.grad, got)

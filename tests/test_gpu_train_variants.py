@@ -19,6 +19,10 @@ pytestmark = pytest.mark.gpu
 
 STNET = copy.deepcopy(_pt_mul(1, 64, 8))
 STNET.update(match_type="xcorr-baseline", hidden_size=128)
+# reid_pts_point-transformer_baseline_orig.py (reid_waymo_pts/pts_point-transformer_baseline-orig_waymo_det_4x256_400e.py)
+_LOCAL = dict(type="local_self_attention", d_model=64, nhead=2, attention="linear", knum=48, pos_size=64)
+ORIG = copy.deepcopy(_pt_mul(1, 64, 8))
+ORIG.update(match_type="xcorr", hidden_size=128, local_stage1=dict(_LOCAL), local_stage2=dict(_LOCAL))
 
 
 def _train_data(pairs, n, dev="cuda"):
@@ -55,7 +59,7 @@ def _dgcnn_cfg():
     return copy.deepcopy(bench.DG_MODEL)
 
 
-@pytest.mark.parametrize("tag,cfg,manifest", [("stnet", STNET, "pt"), ("baseline", BASELINE, "pt_baseline"),
+@pytest.mark.parametrize("tag,cfg,manifest", [("stnet", STNET, "pt"), ("orig", ORIG, "pt_xcorr"), ("baseline", BASELINE, "pt_baseline"),
                                               ("pt15m", _pt_mul(2, 64, 8), "pt15m"), ("pointnet", None, "pointnet"),
                                               ("dgcnn", None, "dgcnn")])
 def test_train_step_of_other_configs_matches_the_reference(tag, cfg, manifest):
@@ -134,8 +138,6 @@ def test_families_without_a_training_graph_fail_cleanly():
     import bench
     m, _ = bench.build_model("ssg", None)                     # BASELINE config 2's own composition: inference only
     _expect_clean_refusal(m, n=1024)
-    m, _ = bench.build_model("ptx", [128, 64, 32])            # baseline-orig: local_self_attention has no backward
-    _expect_clean_refusal(m)
     _expect_clean_refusal(_build(_pt_mul(4, 128, 16), "pt7m"))   # mul = 4: 256-wide attention heads
     # the models still evaluate after the refusal
     m, sd = bench.build_model("pointnet", None)
