@@ -505,10 +505,17 @@ __global__ __launch_bounds__(256) void ball_query_reg_kernel(const float *__rest
                                                              const float *__restrict__ xyz,
                                                              int *__restrict__ idx, int n, int m,
                                                              float min_r2, float max_r2, int K,
-                                                             int *__restrict__ cnt_out, int cpw) {
+                                                             int *__restrict__ cnt_out, int cpw, int nchunk,
+                                                             int nclouds) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const size_t b = blockIdx.y;
+  // XCD-aware order: consecutive workgroup ids go round-robin over the eight XCDs (each with its own L2), so the
+  // chunks of ONE cloud -- which all read that cloud's 12 KB -- are given ids that are congruent modulo 8: the cloud
+  // is fetched from HBM once, not once per chunk (measured before: 424 MB fetched per launch for 50 MB of clouds)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int chunk = slot % nchunk;
+  const size_t b = (size_t)(slot / nchunk) * 8 + xcd;
+  if (b >= (size_t)nclouds) return;
   const float *cloud = xyz + b * n * 3;
   float px[PPL], py[PPL], pz[PPL];
 #pragma unroll
@@ -523,12 +530,18 @@ __global__ __launch_bounds__(256) void ball_query_reg_kernel(const float *__rest
   }
   const unsigned long long lt = (1ull << lane) - 1ull;
   const bool simple = min_r2 == 0.f && max_r2 > 0.f;
-  const int c0 = (blockIdx.x * 4 + wave) * cpw;
+  const int c0 = (chunk * 4 + wave) * cpw;
   const int c1 = c0 + cpw < m ? c0 + cpw : m;
+  // K <= 64: a centre's row is assembled in a wave-private LDS strip and leaves as ONE store of K consecutive ints
+  // (hits and padding together).  Written hit by hit, a row was several partial-line stores; the L2 fetched the lines
+  // it did not own in full: 697 MB fetched per ssg1024 launch pair against 344 MB of algorithmic traffic.
+  __shared__ int s_row[4][64];
+  int *row = s_row[wave];
+  const bool staged = K <= 64;
   for (int c = c0; c < c1; c++) {
     const float *cc = centres + (b * m + c) * 3;
     const float cx = cc[0], cy = cc[1], cz = cc[2];
-    int *out = idx + (b * m + c) * (size_t)K;
+    int *out = staged ? row : idx + (b * m + c) * (size_t)K;
     int cnt = 0, first = 0;
     auto scan = [&](auto simple_tag) {
       constexpr bool kSimple = decltype(simple_tag)::value;
@@ -552,7 +565,18 @@ __global__ __launch_bounds__(256) void ball_query_reg_kernel(const float *__rest
     if (simple) scan(std::true_type{});
     else scan(std::false_type{});
     if (cnt > K) cnt = K;
-    for (int l = cnt + lane; l < K; l += 64) out[l] = first;   // first == 0 when nothing was hit
+    if (staged) {
+      // (a wave's LDS operations complete in order: the hit lanes' writes above are visible to the read below)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int v = lane < cnt ? row[lane < K ? lane : 0] : first;   // first == 0 when nothing was hit
+      if (lane < K) idx[(b * m + c) * (size_t)K + lane] = v;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      for (int l = cnt + lane; l < K; l += 64) out[l] = first;
+    }
     if (cnt_out && lane == 0) cnt_out[b * m + c] = cnt;
   }
 }
@@ -561,13 +585,17 @@ static void ball_query_launch(const float *centres, const float *xyz, int *idx, 
                               float min_r2, float max_r2, int K, hipStream_t st) {
   if (N <= 1024) {
     const int cpw = 16;                                  // centres per wave
-    const dim3 grid((M + 4 * cpw - 1) / (4 * cpw), B), blk(256);
+    const int nchunk = (M + 4 * cpw - 1) / (4 * cpw);
+    const dim3 grid((unsigned)((B + 7) / 8) * 8 * nchunk), blk(256);
     if (N <= 256)
-      hipLaunchKernelGGL(ball_query_reg_kernel<4>, grid, blk, 0, st, centres, xyz, idx, N, M, min_r2, max_r2, K, cnt, cpw);
+      hipLaunchKernelGGL(ball_query_reg_kernel<4>, grid, blk, 0, st, centres, xyz, idx, N, M, min_r2, max_r2, K, cnt, cpw,
+                         nchunk, B);
     else if (N <= 512)
-      hipLaunchKernelGGL(ball_query_reg_kernel<8>, grid, blk, 0, st, centres, xyz, idx, N, M, min_r2, max_r2, K, cnt, cpw);
+      hipLaunchKernelGGL(ball_query_reg_kernel<8>, grid, blk, 0, st, centres, xyz, idx, N, M, min_r2, max_r2, K, cnt, cpw,
+                         nchunk, B);
     else
-      hipLaunchKernelGGL(ball_query_reg_kernel<16>, grid, blk, 0, st, centres, xyz, idx, N, M, min_r2, max_r2, K, cnt, cpw);
+      hipLaunchKernelGGL(ball_query_reg_kernel<16>, grid, blk, 0, st, centres, xyz, idx, N, M, min_r2, max_r2, K, cnt, cpw,
+                         nchunk, B);
   } else {
     hipLaunchKernelGGL(ball_query_kernel<false>, dim3((M + 255) / 256, B), dim3(256), 0, st, centres, xyz, idx, N, M,
                        min_r2, max_r2, K, cnt);
