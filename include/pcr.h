@@ -412,8 +412,19 @@ typedef struct pcr_tdense_fwd {
   int out_relu;
   float *y;
   float *stats;
+  /* optional fused pooling of a grouped MLP's LAST layer (L = S pool_K rows per cloud): the max over the K rows of every
+   * centre of relu(BatchNorm(y)) has its winner at the max of the RAW y where pool_gamma[c] >= 0 and at the min where
+   * it is negative, so the launch can leave pool_ymax (B,cout,S) = the raw y at the winning row and pool_arg (B,cout,S)
+   * = that row -- what pcr_sa_pool_fwd_f32 computes from a second pass over y.  Only the wave-autonomous kernels do
+   * this (pool_K >= 32, L a multiple of lcm(32, pool_K)): pcr_tdense_fwd_pooled() says whether THIS launch will;
+   * otherwise the fields are ignored and the caller runs pcr_sa_pool_fwd_f32. */
+  int pool_K;
+  const float *pool_gamma;
+  float *pool_ymax;
+  int *pool_arg;
 } pcr_tdense_fwd;
 int pcr_tdense_fwd_f32(const pcr_tdense_fwd *p, pcr_stream_t stream);
+int pcr_tdense_fwd_pooled(const pcr_tdense_fwd *p);
 
 /* Backward of that layer.  dy is formed while the tiles are loaded: dy_mode 0: dy = g; 1: dy = ka g + kb y + kc
  * (BatchNorm backward, constants from pcr_bn_bwd_finalize_f32; y = the layer's stored raw output); 2: dy = g [y > 0]
@@ -580,7 +591,9 @@ int pcr_bmm_dt_f32(const float *x, const float *dy, float *dT, int B, int k, int
 /* The packed images of MANY weights in one launch (a training step re-packs every weight after the update: ~76 small
  * launches otherwise).  descs (device): per tensor the contiguous row-major (rows x cols) matrix w and out, which
  * receives the image of W (pcr_packed... ceil8(cols) * ceil32(rows) floats) followed by the image of W^T
- * (ceil8(rows) * ceil32(cols) floats), as pcr_pack_weight_dev_f32(transpose = 2) lays them out. */
+ * (ceil8(rows) * ceil32(cols) floats), as pcr_pack_weight_dev_f32(transpose = 2) lays them out.
+ * cols == 0 marks a BIAS entry: w holds `rows` floats that are copied to the head of out, the caller's zero-padded
+ * ceil32(rows) image (what the train-dense launches seed their accumulators from). */
 typedef struct pcr_pack_desc {
   const float *w;
   float *out;

@@ -997,6 +997,10 @@ static_assert(sizeof(PackDesc) == sizeof(pcr_pack_desc), "pcr_pack_desc layout")
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackDesc *__restrict__ descs) {
   const PackDesc d = descs[blockIdx.y];
   const int rows = d.rows, cols = d.cols;
+  if (cols == 0) {     // a bias vector: `rows` floats into the head of its zero-padded image
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < rows; e += gridDim.x * blockDim.x) d.out[e] = d.w[e];
+    return;
+  }
   const int n0 = ceil8(cols) * ceil32(rows), n1 = ceil8(rows) * ceil32(cols);
   for (int e0 = blockIdx.x * blockDim.x + threadIdx.x; e0 < n0 + n1; e0 += gridDim.x * blockDim.x) {
     const bool tr = e0 >= n0;
@@ -1062,6 +1066,8 @@ PCR_EXPORT int pcr_tdense_fwd_groups(const pcr_tdense_fwd *p) {
   if (pcr_ts_fwd_ok(p)) return pcr_ts_fwd_grid(p, nullptr);
   return pcr_train_groups(p->B, p->L);
 }
+
+PCR_EXPORT int pcr_tdense_fwd_pooled(const pcr_tdense_fwd *p) { return p && pcr_ts_fwd_pools(p) ? 1 : 0; }
 
 PCR_EXPORT int pcr_tdense_bwd_groups(const pcr_tdense_bwd *p) {
   if (!p) return 0;

@@ -62,6 +62,58 @@ __device__ __forceinline__ void ts_wave_sync() {       // orders a wave's own LD
 
 constexpr int kTsWaves = 4;
 
+// Fused max over the K rows of every centre (the grouped MLP's pooling, reference pointnet2_utils.py:357: the max of
+// relu(BatchNorm(y)) over K) inside the LAST layer's forward.  relu(scale y + shift) is monotone in y -- increasing for
+// gamma >= 0, decreasing otherwise, and gamma is known before the batch statistics are -- so the winner of a centre is
+// the max (min) of the RAW output, which the wave has in its strip: no second pass over the (B, C, S K) tensor.
+// A wave's blocks are consecutive and its range starts on a centre boundary (host: per is a multiple of
+// lcm(32, K) / 32 blocks), so a centre's running winner is carried in registers from block to block.
+// t: the lane's 16 tokens (2 q + h) of channel ch; T0: first token of the block inside its cloud; K >= 32.
+// (the carried winner as three scalars: an array of structs handed down by reference ended up in scratch memory)
+// ry / ra: buffer descriptors of pool_ymax / pool_arg, voff: byte offset of the lane's (cloud, channel) row
+__device__ __forceinline__ void ts_pool_block(const float (&t)[16], float sgn, int h, int T0, int K, float &cy_best,
+                                              float &cy_raw, int &cy_k, rsrc_t ry, rsrc_t ra, int voff) {
+  const int cA = T0 / K, k0 = T0 - cA * K, Tb = K - k0;      // tokens [0, Tb) of the block belong to centre cA
+  float bA = -INFINITY, rA = 0.f, bB = -INFINITY, rB = 0.f;
+  int kA = 0, kB = 0;
+  // K is even (host), T0 a multiple of 32: Tb is even, so BOTH tokens 2 q, 2 q + 1 of a step belong to the same centre and
+  // the A / B choice is a wave-uniform branch per step, not two predicated updates
+  const int qs = __builtin_amdgcn_readfirstlane(Tb >> 1);
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    const int tau = 2 * q + h;
+    const float v = sgn * t[q];
+    if (q < qs) {
+      if (v > bA) { bA = v; rA = t[q]; kA = k0 + tau; }
+    } else {
+      if (v > bB) { bB = v; rB = t[q]; kB = tau - Tb; }
+    }
+  }
+  auto comb = [&](float &b, float &r, int &k) __attribute__((always_inline)) {      // the other token parity (lane half): larger value, then smaller k
+    const float ob = __shfl_xor(b, 32, 64), orr = __shfl_xor(r, 32, 64);
+    const int ok = __shfl_xor(k, 32, 64);
+    const bool take = ob > b || (ob == b && ok < k);
+    b = take ? ob : b;
+    r = take ? orr : r;
+    k = take ? ok : k;
+  };
+  comb(bA, rA, kA);
+  comb(bB, rB, kB);
+  if (bA > cy_best) {       // (the carried part holds the centre's earlier rows: it wins ties)
+    cy_best = bA;
+    cy_raw = rA;
+    cy_k = kA;
+  }
+  if (Tb <= 32) {           // centre cA ends inside this block
+    const int vo = h == 0 ? voff : 0x7FFFFF00;      // (one lane half writes; the other's store is dropped by the range check)
+    ts_st(ry, cy_raw, vo, cA * 4);
+    __builtin_amdgcn_raw_buffer_store_b32((unsigned)cy_k, ra, vo, cA * 4, 0);
+    cy_best = bB;           // centre cA + 1 (nothing yet: -inf)
+    cy_raw = rB;
+    cy_k = kB;
+  }
+}
+
 // ---------------------------------------------------------------------------------- forward ----
 struct TSFwd {
   const float *x;            // (B, 32 NBI, L)
@@ -72,6 +124,10 @@ struct TSFwd {
   float *y;                  // (B, 32 NBO, L)
   float *stats;              // partials [gridDim.x][2][32 NBO] or null
   int B, L, nblk, per;       // 32-token blocks in all, blocks per wave
+  int poolK;                 // > 0: fused max over the K rows of every centre (L = S K)
+  const float *pool_gamma;   // (cout): its sign picks max or min of the raw output
+  float *pool_ymax;          // (B, cout, S) raw output at the winning row
+  int *pool_arg;             // (B, cout, S) winning row
 };
 
 // WLDS: the weights as the A operand come from an LDS image [k = input channel][output channel] (one ds_read_b32 per
@@ -121,6 +177,9 @@ __global__ __launch_bounds__(64 * kTsWaves) void tstream_fwd_kernel(TSFwd a) {
   __builtin_amdgcn_s_waitcnt(0);
 
   const rsrc_t rx = ts_rsrc(a.x, (size_t)a.B * CIN * L * 4), ry = ts_rsrc(a.y, (size_t)a.B * COUT * L * 4);
+  const int pS = a.poolK > 0 ? L / a.poolK : 1;
+  const rsrc_t rpy = ts_rsrc(a.poolK > 0 ? (const void *)a.pool_ymax : (const void *)a.y, a.poolK > 0 ? (size_t)a.B * COUT * pS * 4 : 0);
+  const rsrc_t rpa = ts_rsrc(a.poolK > 0 ? (const void *)a.pool_arg : (const void *)a.y, a.poolK > 0 ? (size_t)a.B * COUT * pS * 4 : 0);
   const int gw = blockIdx.x * kTsWaves + wave;
   const int n0 = gw * a.per;
   const int n1 = n0 + a.per < a.nblk ? n0 + a.per : a.nblk;
@@ -128,14 +187,26 @@ __global__ __launch_bounds__(64 * kTsWaves) void tstream_fwd_kernel(TSFwd a) {
   const int vy = (4 * h * L + j) * 4;      // lane part of the accumulator address: channel 8 g + 4 h + q, token j
   float *strip = s_t + wave * (COUT * TP);
   const bool want_stats = a.stats != nullptr;
+  const bool pool = a.poolK > 0;
+  float psgn[NBO], pbest[NBO], praw[NBO];
+  int pk[NBO];
+#pragma unroll
+  for (int nbo = 0; nbo < NBO; nbo++) {
+    // (gamma == 0: every row gives the same activation; sign 0 makes the FIRST row the winner, as the pooling kernel does)
+    const float gmm = pool ? a.pool_gamma[nbo * 32 + j] : 1.f;
+    psgn[nbo] = gmm < 0.f ? -1.f : (gmm > 0.f ? 1.f : 0.f);
+    pbest[nbo] = -INFINITY;
+    praw[nbo] = 0.f;
+    pk[nbo] = 0;
+  }
   // The loop body has NO conditional memory operation (the wait counts stay exact): every wave runs a.per (even) rounds,
   // a round beyond the wave's range re-reads its last block and its stores are dropped by the buffer range check.
-  auto load = [&](float (&xr)[KS], int bb, int tt) {
+  auto load = [&](float (&xr)[KS], int bb, int tt) __attribute__((always_inline)) {
     const int so = (bb * CIN * L + tt * 32) * 4;
 #pragma unroll
     for (int s = 0; s < KS; s++) xr[s] = ts_ld(rx, vx, so + s * 2 * L * 4);
   };
-  auto round = [&](float (&xr)[KS], int bb, int tt, bool valid) {
+  auto round = [&](float (&xr)[KS], int bb, int tt, bool valid) __attribute__((always_inline)) {
     f32x16 acc[NBO];
 #pragma unroll
     for (int nbo = 0; nbo < NBO; nbo++)
@@ -151,7 +222,7 @@ __global__ __launch_bounds__(64 * kTsWaves) void tstream_fwd_kernel(TSFwd a) {
     constexpr int PD = 2;
     float wr[PD + 1][NBO];
     f32x2 ar[PD + 1];
-    auto fetch_k = [&](int slot, int s) {
+    auto fetch_k = [&](int slot, int s) __attribute__((always_inline)) {
       ar[slot] = s_aff[2 * s + h];
       if constexpr (WLDS) {
 #pragma unroll
@@ -183,19 +254,26 @@ __global__ __launch_bounds__(64 * kTsWaves) void tstream_fwd_kernel(TSFwd a) {
         strip[(nbo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * TP + j] = valid ? acc[nbo][r] : 0.f;
       }
     ts_wave_sync();
-    if (want_stats) {
+    if (want_stats || pool) {
 #pragma unroll
-      for (int nbo = 0; nbo < NBO; nbo++)
+      for (int nbo = 0; nbo < NBO; nbo++) {
+        float t[16];
+#pragma unroll
+        for (int s = 0; s < 16; s++) t[s] = strip[(nbo * 32 + j) * TP + 2 * s + h];
 #pragma unroll
         for (int s = 0; s < 16; s++) {
-          const float v = strip[(nbo * 32 + j) * TP + 2 * s + h];
-          ssum[nbo] += v;
-          ssq[nbo] += v * v;
+          ssum[nbo] += t[s];
+          ssq[nbo] += t[s] * t[s];
         }
+        if (pool && valid) {
+          ts_pool_block(t, psgn[nbo], h, tt * 32, a.poolK, pbest[nbo], praw[nbo], pk[nbo], rpy, rpa,
+                        ((bb * COUT + nbo * 32 + j) * pS) * 4);
+        }
+      }
     }
     ts_wave_sync();
   };
-  auto next = [&](int &bb, int &tt, bool go) {      // scalar only
+  auto next = [&](int &bb, int &tt, bool go) __attribute__((always_inline)) {      // scalar only
     const int t2 = tt + 1;
     const bool wrap = t2 == nbpc;
     const int nb = wrap ? bb + 1 : bb, nt = wrap ? 0 : t2;
@@ -260,7 +338,10 @@ __global__ __launch_bounds__(64 * kTsWaves) void tstream_fwd_kernel(TSFwd a) {
 // 16 items of a cout block are consecutive k-steps, the lane = channel sums follow them.
 constexpr int kTpWaves = 8;
 
-template <int NB>
+// POOL: the fused max over K (ts_pool_block) -- compiled out of the eight-wave instantiation, whose 256 registers per
+// lane are spoken for (measured with four waves and 512: the pooling's ~180 VALU instructions per cout block cost the
+// matrix-bound launch more than the separate pooling pass over y it saves; the 32- / 64-channel forms keep it)
+template <int NB, bool POOL>
 __global__ __launch_bounds__(64 * kTpWaves, 1) void tstream_fwd_pipe_kernel(TSFwd a) {
   constexpr int C = 32 * NB, KS = C / 2, TP = 33;
   static_assert(KS == 16 * NB, "one epilogue item per k-step");
@@ -290,16 +371,31 @@ __global__ __launch_bounds__(64 * kTpWaves, 1) void tstream_fwd_pipe_kernel(TSFw
   __builtin_amdgcn_s_waitcnt(0);
 
   const rsrc_t rx = ts_rsrc(a.x, (size_t)a.B * C * L * 4), ry = ts_rsrc(a.y, (size_t)a.B * C * L * 4);
+  const int pS = a.poolK > 0 ? L / a.poolK : 1;
+  const rsrc_t rpy = ts_rsrc(a.poolK > 0 ? (const void *)a.pool_ymax : (const void *)a.y, a.poolK > 0 ? (size_t)a.B * C * pS * 4 : 0);
+  const rsrc_t rpa = ts_rsrc(a.poolK > 0 ? (const void *)a.pool_arg : (const void *)a.y, a.poolK > 0 ? (size_t)a.B * C * pS * 4 : 0);
   const int gw = blockIdx.x * kTpWaves + wave;
   const int n0 = gw * a.per;
   const int n1 = n0 + a.per < a.nblk ? n0 + a.per : a.nblk;
   const int vx = (h * L + j) * 4, vy = (4 * h * L + j) * 4;
   float *strip = s_t + wave * (32 * TP);
+  const bool pool = POOL && a.poolK > 0;
+  float psgn[NB], pbest[NB], praw[NB];
+  int pk[NB];
+#pragma unroll
+  for (int nbo = 0; nbo < NB; nbo++) {
+    // (gamma == 0: every row gives the same activation; sign 0 makes the FIRST row the winner, as the pooling kernel does)
+    const float gmm = pool ? a.pool_gamma[nbo * 32 + j] : 1.f;
+    psgn[nbo] = gmm < 0.f ? -1.f : (gmm > 0.f ? 1.f : 0.f);
+    pbest[nbo] = -INFINITY;
+    praw[nbo] = 0.f;
+    pk[nbo] = 0;
+  }
   float pv[KS];                          // the previous block's output rows (row s = cout block s >> 4, accumulator row s & 15)
 #pragma unroll
   for (int s = 0; s < KS; s++) pv[s] = 0.f;
   // xc: this block's operands; xp: the previous block's operand set, refilled with the NEXT block's
-  auto round = [&](float (&xc)[KS], float (&xp)[KS], int pb, int pt, bool validp, int nb, int nt) {
+  auto round = [&](float (&xc)[KS], float (&xp)[KS], int pb, int pt, bool validp, int nb, int nt) __attribute__((always_inline)) {
     f32x16 ac[NB];
 #pragma unroll
     for (int nbo = 0; nbo < NB; nbo++)
@@ -314,7 +410,7 @@ __global__ __launch_bounds__(64 * kTpWaves, 1) void tstream_fwd_pipe_kernel(TSFw
     f32x4 wr[PD + 1];
     f32x2 ar[PD + 1];
     const f32x4 *wl = reinterpret_cast<const f32x4 *>(s_w) + h * 32 + j;
-    auto fetch_k = [&](int slot, int s) {
+    auto fetch_k = [&](int slot, int s) __attribute__((always_inline)) {
       ar[slot] = s_aff[2 * s + h];
       wr[slot] = wl[s * 64];
     };
@@ -327,8 +423,14 @@ __global__ __launch_bounds__(64 * kTpWaves, 1) void tstream_fwd_pipe_kernel(TSFw
     // then -- bunched in front of the four MFMAs, the store / fetch / LDS traffic of a step took longer to issue than
     // the last MFMA takes to execute and the pipe idled every step (82 of 157 TFLOP/s).
     float v = fmaxf(fmaf(xc[0], ar[0][0], ar[0][1]), lo);
+    // (two nested loops, 4 cout blocks x 16 steps: as ONE 64-step loop carrying the per-cout-block statistics / pooling
+    // code the body exceeded the compiler's full-unroll budget, the loop stayed a loop and every register array it
+    // indexes went to scratch memory)
 #pragma unroll
-    for (int s = 0; s < KS; s++) {
+    for (int cb = 0; cb < NB; cb++) {
+#pragma unroll
+    for (int r16 = 0; r16 < 16; r16++) {
+      const int s = cb * 16 + r16;
       const f32x4 w4 = wr[s % (PD + 1)];
       const int r32 = (s & 3) + 8 * ((s & 15) >> 2), row = (s >> 4) * 32 + r32;
       ac[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[0], v, ac[0], 0, 0, 0);
@@ -350,7 +452,10 @@ __global__ __launch_bounds__(64 * kTpWaves, 1) void tstream_fwd_pipe_kernel(TSFw
         const f32x2 sc = ar[(s + 1) % (PD + 1)];
         v = fmaxf(fmaf(xc[s + 1], sc[0], sc[1]), lo);
       }
-      if ((s & 15) == 15) {    // cout block s >> 4 of the previous block is complete in the strip: its lane = channel sums
+      __builtin_amdgcn_sched_barrier(0);
+    }
+      {    // cout block cb of the previous block is complete in the strip: its lane = channel sums (and pooling)
+        const int s = cb * 16 + 15;
         ts_wave_sync();
         float t[16];
 #pragma unroll
@@ -359,6 +464,10 @@ __global__ __launch_bounds__(64 * kTpWaves, 1) void tstream_fwd_pipe_kernel(TSFw
         for (int q = 0; q < 16; q++) {
           ssum[s >> 4] += t[q];
           ssq[s >> 4] = fmaf(t[q], t[q], ssq[s >> 4]);
+        }
+        if constexpr (POOL) if (pool && validp) {
+          ts_pool_block(t, psgn[s >> 4], h, pt * 32, a.poolK, pbest[s >> 4], praw[s >> 4], pk[s >> 4], rpy, rpa,
+                        ((pb * C + (s >> 4) * 32 + j) * pS) * 4);
         }
         ts_wave_sync();
       }
@@ -371,7 +480,7 @@ __global__ __launch_bounds__(64 * kTpWaves, 1) void tstream_fwd_pipe_kernel(TSFw
     for (int s = 0; s < KS; s++) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(pv[s]) : "a"(ac[s >> 4][s & 15]));
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto next = [&](int &bb, int &tt, bool go) {      // scalar only
+  auto next = [&](int &bb, int &tt, bool go) __attribute__((always_inline)) {      // scalar only
     const int t2 = tt + 1;
     const bool wrap = t2 == nbpc;
     const int nb = wrap ? bb + 1 : bb, nt = wrap ? 0 : t2;
@@ -404,17 +513,28 @@ __global__ __launch_bounds__(64 * kTpWaves, 1) void tstream_fwd_pipe_kernel(TSFw
   {   // the last block's rows
     const int so = (bP * C * L + tP * 32) * 4, vo = vP ? vy : 0x7FFFFF00;
 #pragma unroll
-    for (int s = 0; s < KS; s++) {
-      const int r32 = (s & 3) + 8 * ((s & 15) >> 2), row = (s >> 4) * 32 + r32;
-      ts_st(ry, pv[s], vo, so + row * L * 4);
-      strip[(r32 + 4 * h) * TP + j] = vP ? pv[s] : 0.f;
-      if ((s & 15) == 15) {
+    for (int cb = 0; cb < NB; cb++) {
+#pragma unroll
+      for (int r16 = 0; r16 < 16; r16++) {
+        const int s = cb * 16 + r16;
+        const int r32 = (s & 3) + 8 * ((s & 15) >> 2), row = (s >> 4) * 32 + r32;
+        ts_st(ry, pv[s], vo, so + row * L * 4);
+        strip[(r32 + 4 * h) * TP + j] = vP ? pv[s] : 0.f;
+      }
+      {
+        const int s = cb * 16 + 15;
         ts_wave_sync();
+        float t[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) t[q] = strip[j * TP + 2 * q + h];
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-          const float t = strip[j * TP + 2 * q + h];
-          ssum[s >> 4] += t;
-          ssq[s >> 4] = fmaf(t, t, ssq[s >> 4]);
+          ssum[s >> 4] += t[q];
+          ssq[s >> 4] = fmaf(t[q], t[q], ssq[s >> 4]);
+        }
+        if constexpr (POOL) if (pool && vP) {
+          ts_pool_block(t, psgn[s >> 4], h, tP * 32, a.poolK, pbest[s >> 4], praw[s >> 4], pk[s >> 4], rpy, rpa,
+                        ((bP * C + (s >> 4) * 32 + j) * pS) * 4);
         }
         ts_wave_sync();
       }
@@ -533,19 +653,19 @@ __global__ __launch_bounds__(64 * kTsWaves, NB == 1 ? 3 : 1) void tstream_bwd_ke
     int k;
   };
   float ry_[KS], rx_[NB][16];
-  auto load_y = [&](int bb, int tt) {
+  auto load_y = [&](int bb, int tt) __attribute__((always_inline)) {
     const int so = (bb * C * L + tt * 32) * 4;
 #pragma unroll
     for (int s = 0; s < KS; s++) ry_[s] = ts_ld(ry, vt, so + s * 2 * L * 4);
   };
-  auto load_x = [&](int bb, int tt) {
+  auto load_x = [&](int bb, int tt) __attribute__((always_inline)) {
     const int so = (bb * C * L + tt * 32) * 4;
 #pragma unroll
     for (int nbi = 0; nbi < NB; nbi++)
 #pragma unroll
       for (int q = 0; q < 16; q++) rx_[nbi][q] = ts_ld(rx, vd, so + (nbi * 32 + (q & 3) + 8 * (q >> 2)) * L * 4);
   };
-  auto load_g = [&](BlkG &r, int bb, int tt) {
+  auto load_g = [&](BlkG &r, int bb, int tt) __attribute__((always_inline)) {
     if constexpr (MODE == 3) {
       const int t = tt * 32 + j, sc = t / K;
       r.k = t - sc * K;
@@ -562,7 +682,7 @@ __global__ __launch_bounds__(64 * kTsWaves, NB == 1 ? 3 : 1) void tstream_bwd_ke
     }
   };
   BlkG gq;
-  auto compute = [&](int bb, int tt, bool valid, int gb, int gt) {
+  auto compute = [&](int bb, int tt, bool valid, int gb, int gt) __attribute__((always_inline)) {
     // 1. dy in the B-operand layout (k = output channel), a copy into strip A; dx = W^T dy
     // (LDS operands are requested PD steps ahead of their use, in rings of register sets, the order pinned by
     // scheduling barriers: see the forward kernel)
@@ -594,7 +714,7 @@ __global__ __launch_bounds__(64 * kTsWaves, NB == 1 ? 3 : 1) void tstream_bwd_ke
       for (int q = 0; q < 16; q++) acc[nbi][q] = 0.f;
     {
       float wr[PD + 1][NB];
-      auto fetch_w = [&](int slot, int s) {
+      auto fetch_w = [&](int slot, int s) __attribute__((always_inline)) {
         if constexpr (WLDS) {
 #pragma unroll
           for (int nbi = 0; nbi < NB; nbi++) wr[slot][nbi] = s_w[(2 * s + h) * C + nbi * 32 + j];
@@ -671,7 +791,7 @@ __global__ __launch_bounds__(64 * kTsWaves, NB == 1 ? 3 : 1) void tstream_bwd_ke
     }
     ts_wave_sync();
   };
-  auto next = [&](int &bb, int &tt, bool go) {      // scalar only
+  auto next = [&](int &bb, int &tt, bool go) __attribute__((always_inline)) {      // scalar only
     const int t2 = tt + 1;
     const bool wrap = t2 == nbpc;
     const int nb = wrap ? bb + 1 : bb, nt = wrap ? 0 : t2;
@@ -768,6 +888,18 @@ static size_t ts_fwd_lds(int cin, int cout) {
   return ((size_t)2 * cin + cout + (wlds ? (size_t)cin * cout : 0) + (size_t)kTsWaves * cout * 33) * sizeof(float);
 }
 
+static int ts_gcd(int a, int b) { return b ? ts_gcd(b, a % b) : a; }
+
+// the launch produces the fused max over K (pool_ymax / pool_arg): a streaming launch whose clouds are whole multiples
+// of lcm(32, K) tokens, K >= 32 (a 32-token block then touches at most two centres)
+bool pcr_ts_fwd_pools(const pcr_tdense_fwd *p) {
+  if (!pcr_ts_fwd_ok(p) || p->pool_K < 32 || (p->pool_K & 1) || !p->pool_gamma || !p->pool_ymax || !p->pool_arg) return false;
+  if (p->cout == 128) return false;        // (matrix-bound launch: the separate pooling pass is cheaper, see the pipe kernel)
+  if (p->L % p->pool_K) return false;
+  const int lcm = p->pool_K / ts_gcd(32, p->pool_K) * 32;
+  return p->L % lcm == 0;
+}
+
 int pcr_ts_fwd_grid(const pcr_tdense_fwd *p, int *per) {
   const int nblk = p->B * (p->L >> 5);
   // workgroups per CU: what the LDS image + strips admit, at most four
@@ -778,8 +910,15 @@ int pcr_ts_fwd_grid(const pcr_tdense_fwd *p, int *per) {
   if (p->cin1 == 128) wgs_per_cu = 1;
   int g = ts_cus() * wgs_per_cu;
   int pw = (nblk + g * waves - 1) / (g * waves);
-  pw = (pw + 1) & ~1;                    // rounds come in pairs (two register sets)
-  if (pw < 2) pw = 2;
+  // rounds come in pairs (two register sets); with the fused pooling a wave's range is whole centre groups
+  // (lcm(32, K) / 32 blocks), so that a centre never straddles two waves
+  int unit = 2;
+  if (pcr_ts_fwd_pools(p)) {
+    const int grp = p->pool_K / ts_gcd(32, p->pool_K);
+    unit = (grp & 1) ? 2 * grp : grp;
+  }
+  pw = (pw + unit - 1) / unit * unit;
+  if (pw < unit) pw = unit;
   g = (nblk + pw * waves - 1) / (pw * waves);
   if (per) *per = pw;
   return g;
@@ -796,6 +935,9 @@ int pcr_ts_fwd_launch(const pcr_tdense_fwd *p, hipStream_t st) {
   TSFwd a;
   a.x = p->x; a.isc = p->isc; a.ish = p->ish; a.in_relu = p->in_relu; a.wp = p->wp; a.bias = p->bias;
   a.y = p->y; a.stats = p->stats; a.B = p->B; a.L = p->L; a.nblk = p->B * (p->L >> 5);
+  const bool pools = pcr_ts_fwd_pools(p);
+  a.poolK = pools ? p->pool_K : 0;
+  a.pool_gamma = p->pool_gamma; a.pool_ymax = p->pool_ymax; a.pool_arg = p->pool_arg;
   const int g = pcr_ts_fwd_grid(p, &a.per);
   const size_t lds = ts_fwd_lds(p->cin1, p->cout);
   const int ci = p->cin1, co = p->cout;
@@ -804,9 +946,9 @@ int pcr_ts_fwd_launch(const pcr_tdense_fwd *p, hipStream_t st) {
   else if (ci == 32 && co == 64) ts_fwd_go<1, 2, true>(a, g, lds, st);
   else if (ci == 64 && co == 32) ts_fwd_go<2, 1, true>(a, g, lds, st);
   else {
-    static bool ok = allow_big_lds(tstream_fwd_pipe_kernel<4>);
+    static bool ok = allow_big_lds(tstream_fwd_pipe_kernel<4, false>);
     (void)ok;
-    hipLaunchKernelGGL((tstream_fwd_pipe_kernel<4>), dim3(g), dim3(64 * kTpWaves), lds, st, a);
+    hipLaunchKernelGGL((tstream_fwd_pipe_kernel<4, false>), dim3(g), dim3(64 * kTpWaves), lds, st, a);
   }
   return hipGetLastError() == hipSuccess ? PCR_OK : PCR_ERR_LAUNCH;
 }

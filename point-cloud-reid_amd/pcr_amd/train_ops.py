@@ -16,6 +16,7 @@ from . import _lib as L
 from .engine import _prof
 
 c_fp = ctypes.c_void_p
+FUSE_POOL = True       # SaEdgeTrain: take the max over K inside the last layer's launch where the library offers it
 
 
 def _c32(n):
@@ -29,7 +30,8 @@ def _c8(n):
 class _TFwd(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int), ("cin1", ctypes.c_int), ("cin2", ctypes.c_int), ("cout", ctypes.c_int),
                 ("L", ctypes.c_int), ("x", c_fp), ("x2", c_fp), ("isc", c_fp), ("ish", c_fp), ("in_relu", ctypes.c_int),
-                ("wp", c_fp), ("bias", c_fp), ("res", c_fp), ("out_relu", ctypes.c_int), ("y", c_fp), ("stats", c_fp)]
+                ("wp", c_fp), ("bias", c_fp), ("res", c_fp), ("out_relu", ctypes.c_int), ("y", c_fp), ("stats", c_fp),
+                ("pool_K", ctypes.c_int), ("pool_gamma", c_fp), ("pool_ymax", c_fp), ("pool_arg", c_fp)]
 
 
 class _TBwd(ctypes.Structure):
@@ -81,34 +83,53 @@ class _Prepack:
         self.entries = {}          # data_ptr -> [param, rows, cols, version, wp, wpT]
         self.descs = None
         self.params = []
+        self.biases = {}
 
-    def build(self, params):
+    def build(self, params, biases):
         import numpy as np
         dev = params[0].device
         self.params = params
         self.entries = {}
-        desc = np.zeros(len(params), dtype=np.dtype([("w", "<u8"), ("out", "<u8"), ("rows", "<i4"), ("cols", "<i4")]))
+        self.biases = {}           # id(bias) -> [param, version, zero-padded image]
+        desc = np.zeros(len(params) + len(biases),
+                        dtype=np.dtype([("w", "<u8"), ("out", "<u8"), ("rows", "<i4"), ("cols", "<i4")]))
         for i, p in enumerate(params):
             rows, cols = p.shape[0], p.numel() // p.shape[0]
             n0, n1 = _c8(cols) * _c32(rows), _c8(rows) * _c32(cols)
             out = _f32(n0 + n1, device=dev)
             desc[i] = (p.data_ptr(), out.data_ptr(), rows, cols)
             self.entries[p.data_ptr()] = [p, rows, cols, -1, out[:n0], out[n0:]]
+        for i, b in enumerate(biases):          # cols = 0: a bias, copied into its zero-padded image by the same launch
+            out = torch.zeros(_c32(b.numel()), dtype=torch.float32, device=dev)
+            desc[len(params) + i] = (b.data_ptr(), out.data_ptr(), b.numel(), 0)
+            self.biases[id(b)] = [b, -1, out, b.data_ptr()]
         self.descs = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
-        self.key = tuple(id(p) for p in params)
+        self.key = tuple(id(p) for p in params) + tuple(id(b) for b in biases)
 
-    def refresh(self, params):
+    def refresh(self, params, biases=()):
         params = [p for p in params if p.is_cuda and p.dim() >= 2 and p.dtype == torch.float32 and p.is_contiguous()]
+        biases = [b for b in biases if b.is_cuda and b.dim() == 1 and b.dtype == torch.float32 and b.is_contiguous()]
         if not params:
             return
-        if self.key != tuple(id(p) for p in params) or any(e[0].data_ptr() != k for k, e in self.entries.items()):
-            self.build(params)
-        elif all(e[3] == e[0]._version for e in self.entries.values()):
+        if self.key != tuple(id(p) for p in params) + tuple(id(b) for b in biases) or \
+                any(e[0].data_ptr() != k for k, e in self.entries.items()) or \
+                any(e[0].data_ptr() != e[3] for e in self.biases.values()):
+            self.build(params, biases)
+        elif all(e[3] == e[0]._version for e in self.entries.values()) and \
+                all(e[1] == e[0]._version for e in self.biases.values()):
             return        # nothing changed since the last refresh (micro-steps of a gradient accumulation)
-        L.check(L.load().pcr_pack_weights_multi_f32(ctypes.c_void_p(self.descs.data_ptr()), len(params), L.stream_ptr()),
-                "pcr_pack_weights_multi_f32")
+        L.check(L.load().pcr_pack_weights_multi_f32(ctypes.c_void_p(self.descs.data_ptr()), len(params) + len(biases),
+                                                    L.stream_ptr()), "pcr_pack_weights_multi_f32")
         for e in self.entries.values():
             e[3] = e[0]._version
+        for e in self.biases.values():
+            e[1] = e[0]._version
+
+    def lookup_bias(self, v, n):
+        e = self.biases.get(id(v))
+        if e is None or e[0] is not v or e[1] != v._version or e[2].numel() != _c32(n):
+            return None
+        return e[2]
 
     def lookup(self, w):
         e = self.entries.get(w.data_ptr())
@@ -134,12 +155,12 @@ def prepack(model):
     """refresh the packed images of every conv / linear weight of `model` in one launch (Trainer.step calls this once
     per iteration, after the previous update); pack_dev / pack_both then hit the cache.  Note for callers that keep an
     autograd graph across iterations: the images are overwritten in place by the next refresh."""
-    ws = [m.weight for m in model.modules()
-          if isinstance(m, (torch.nn.Linear, torch.nn.Conv1d, torch.nn.Conv2d)) and m.weight is not None]
+    mods = [m for m in model.modules()
+            if isinstance(m, (torch.nn.Linear, torch.nn.Conv1d, torch.nn.Conv2d)) and m.weight is not None]
     tab = _PREPACKS.get(model)
     if tab is None:
         tab = _PREPACKS[model] = _Prepack()
-    tab.refresh(ws)
+    tab.refresh([m.weight for m in mods], [m.bias for m in mods if m.bias is not None])
 
 
 def pack_dev(w, transpose=False):
@@ -179,6 +200,10 @@ def pad32(v, n):
     (tensor, version): a bias is padded once per optimizer step, not once per launch"""
     if v is None:
         return None
+    for t in _PREPACKS.values():         # refreshed with the weights by the one launch per iteration
+        hit = t.lookup_bias(v, n)
+        if hit is not None:
+            return hit
     # keyed by the tensor OBJECT (kept alive by the entry, so its id and storage cannot be recycled under the cache: a
     # (data_ptr, version) key returned another tensor's bias once the allocator had reused the address) and its version
     hit = _PAD_CACHE.get(id(v))
@@ -200,7 +225,9 @@ def groups(B, Ln):
 
 
 def tdense_fwd(x, wp, cout, x2=None, isc=None, ish=None, in_relu=False, bias=None, res=None, out_relu=False,
-               want_stats=False):
+               want_stats=False, pool=None):
+    """-> (y, stats partials or None[, (ymax, argmax) or None when `pool` = (K, gamma) is given: the fused max over the K
+    rows of every centre, where the launch can provide it (pcr_tdense_fwd_pooled)])"""
     x = _dev(x)
     B, cin1, Ln = x.shape
     cin2 = 0
@@ -214,12 +241,25 @@ def tdense_fwd(x, wp, cout, x2=None, isc=None, ish=None, in_relu=False, bias=Non
     p.wp, p.bias, p.res, p.out_relu = _p(wp), _p(pad32(bias, cout)), _p(res), int(out_relu)
     p.y = _p(y)
     # rows of the statistics partials = workgroups of THIS launch (the library picks the kernel from the block)
+    pooled = None
+    if pool is not None:
+        K, gamma = pool
+        S = Ln // K
+        ymax = _f32(B, cout, S, device=x.device)
+        arg = torch.empty((B, cout, S), dtype=torch.int32, device=x.device)
+        p.pool_K, p.pool_gamma, p.pool_ymax, p.pool_arg = K, _p(gamma.detach()), _p(ymax), _p(arg)
+        if L.load().pcr_tdense_fwd_pooled(ctypes.byref(p)):
+            pooled = (ymax, arg)
+        else:
+            p.pool_K = 0
     stats = _f32(L.load().pcr_tdense_fwd_groups(ctypes.byref(p)), 2, _c32(cout), device=x.device) if want_stats else None
     p.stats = _p(stats)
     cin = cin1 + cin2
     with _prof("tdense_fwd[cin=%d,cout=%d,L=%d]" % (cin, cout, Ln), 2.0 * B * Ln * cin * cout,
                4.0 * B * Ln * (cin + cout * (2 if res is not None else 1))):
         L.check(L.load().pcr_tdense_fwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_tdense_fwd_f32")
+    if pool is not None:
+        return y, stats, pooled
     return y, stats
 
 
@@ -420,14 +460,25 @@ class SaEdgeTrain(Function):
         n1 = fin(st1, B, c1, g1, be1, bns[0])
         y2, st2 = tdense_fwd(y1, pack_dev(w2), c2, isc=n1["scale"], ish=n1["shift"], in_relu=True, bias=b2, want_stats=True)
         n2 = fin(st2, st2.shape[0], c2, g2, be2, bns[1])
-        y3, st3 = tdense_fwd(y2, pack_dev(w3), c3, isc=n2["scale"], ish=n2["shift"], in_relu=True, bias=b3, want_stats=True)
+        # the last layer's launch also finds every centre's winning row where it can (max of the raw output for
+        # gamma >= 0, min otherwise: relu(scale y + shift) is monotone in y); the pooled activation is then one affine +
+        # ReLU over the (B,c3,S) winners instead of a second pass over the (B,c3,S K) tensor
+        y3, st3, won = tdense_fwd(y2, pack_dev(w3), c3, isc=n2["scale"], ish=n2["shift"], in_relu=True, bias=b3,
+                                  want_stats=True, pool=(K, g3) if FUSE_POOL else None) if FUSE_POOL else \
+            tdense_fwd(y2, pack_dev(w3), c3, isc=n2["scale"], ish=n2["shift"], in_relu=True, bias=b3, want_stats=True) + (None,)
         n3 = fin(st3, st3.shape[0], c3, g3, be3, bns[2])
         pooled = _f32(B, c3, S, device=dev)
-        argmax = torch.empty((B, c3, S), dtype=torch.int32, device=dev)
-        ymax = _f32(B, c3, S, device=dev)
-        with _prof("sa_pool_fwd[c=%d,S=%d,K=%d]" % (c3, S, K), 2.0 * B * Ln * c3, 4.0 * B * c3 * (Ln + 2 * S)):
-            L.check(lib.pcr_sa_pool_fwd_f32(L.ptr(y3), L.ptr(n3["scale"]), L.ptr(n3["shift"]), L.ptr(pooled), L.ptr(argmax),
-                                            L.ptr(ymax), B, c3, S, K, L.stream_ptr()), "pcr_sa_pool_fwd_f32")
+        if won is not None:
+            ymax, argmax = won
+            L.check(lib.pcr_bn_affine_f32(L.ptr(ymax), None, L.ptr(n3["scale"]), L.ptr(n3["shift"]), None, None, None, None,
+                                          1, ctypes.c_float(0.0), L.ptr(pooled), B, c3, S, L.stream_ptr()),
+                    "pcr_bn_affine_f32")
+        else:
+            argmax = torch.empty((B, c3, S), dtype=torch.int32, device=dev)
+            ymax = _f32(B, c3, S, device=dev)
+            with _prof("sa_pool_fwd[c=%d,S=%d,K=%d]" % (c3, S, K), 2.0 * B * Ln * c3, 4.0 * B * c3 * (Ln + 2 * S)):
+                L.check(lib.pcr_sa_pool_fwd_f32(L.ptr(y3), L.ptr(n3["scale"]), L.ptr(n3["shift"]), L.ptr(pooled),
+                                                L.ptr(argmax), L.ptr(ymax), B, c3, S, K, L.stream_ptr()), "pcr_sa_pool_fwd_f32")
         ctx.save_for_backward(xyz, idx, y1, y2, y3, pooled, argmax, w2, w3, g1, g2, g3, ymax)
         ctx.norms = (n1, n2, n3)
         ctx.has_tab = tab is not None

@@ -126,3 +126,41 @@ def test_sa_edge_train_through_the_stream_kernels(B, N, S, K, D, widths):
     from test_gpu_train_ops import test_sa_edge_train_matches_torch_autograd as body
     with _policy(0):
         body(B, N, S, K, D, widths)
+
+
+@pytest.mark.parametrize("B,c,S,K", [(3, 32, 128, 32), (2, 64, 64, 48), (2, 32, 32, 48), (5, 32, 6, 64), (4, 64, 3, 96),
+                                     (70, 64, 2, 48)])
+def test_fused_pooling_equals_the_pool_kernel(B, c, S, K):
+    """the last layer's launch with pool=(K, gamma): the winners it leaves (raw y at the winning row, the row) against
+    pcr_sa_pool_fwd_f32 on the stored y with the same scale / shift, for both signs of gamma"""
+    from pcr_amd import train_ops as TO
+    Ln = S * K
+    g = torch.Generator().manual_seed(B + c + K)
+    x = torch.randn(B, c, Ln, generator=g).cuda()
+    W = (torch.randn(c, c, generator=g) / c ** 0.5).cuda()
+    bias = torch.randn(c, generator=g).cuda()
+    isc, ish = (torch.rand(c, generator=g) + 0.5).cuda(), (torch.randn(c, generator=g) * 0.3).cuda()
+    gamma = torch.randn(c, generator=g).cuda()
+    gamma[0] = 0.0
+    wp = TO.pack_dev(W)
+    with _policy(0):
+        y, st, won = TO.tdense_fwd(x, wp, c, isc=isc, ish=ish, in_relu=True, bias=bias, want_stats=True, pool=(K, gamma))
+        y_plain, st_plain = TO.tdense_fwd(x, wp, c, isc=isc, ish=ish, in_relu=True, bias=bias, want_stats=True)
+    assert won is not None
+    assert torch.equal(y, y_plain) and torch.allclose(st.sum(0), st_plain.sum(0), rtol=1e-5, atol=1e-3)
+    ymax, arg = won
+    scale = gamma * 0.7                                   # (invstd > 0: the sign of the BatchNorm scale is gamma's)
+    shift = (torch.randn(c, generator=g) * 0.5).cuda()
+    lib = L.load()
+    pooled = torch.empty(B, c, S, device="cuda")
+    am = torch.empty(B, c, S, dtype=torch.int32, device="cuda")
+    ym = torch.empty(B, c, S, device="cuda")
+    L.check(lib.pcr_sa_pool_fwd_f32(L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(pooled), L.ptr(am), L.ptr(ym), B, c, S, K,
+                                    L.stream_ptr()), "pcr_sa_pool_fwd_f32")
+    fused = torch.relu(ymax * scale[None, :, None] + shift[None, :, None])
+    assert torch.allclose(fused, pooled, rtol=0, atol=1e-6)
+    open_ = pooled > 0                                     # (where the ReLU is closed the row is arbitrary: no gradient)
+    yv = y.view(B, c, S, K)
+    assert torch.equal(torch.gather(yv, 3, arg.long().unsqueeze(-1)).squeeze(-1), ymax)      # arg points at ymax
+    assert torch.equal(ymax[open_], ym[open_])
+    assert torch.equal(arg[open_], am[open_])
