@@ -270,8 +270,9 @@ typedef struct pcr_attn_params {
   const float *wq_bf, *wmlp0_bf, *wmlp2_bf, *wfinal_bf;
   /* pcr_attn_kv_f32, d <= 128: kv_splits > 1 splits every cloud's key tokens over that many workgroups (raw partial
    * matrices in kv_part, (B, kv_splits, d d + d) floats) and a second launch adds them in order and folds the merge
-   * projection -- for launches whose one-workgroup-per-cloud grid would leave the last round of the chip mostly empty.
-   * pcr_attn_kv_splits(B, Sk, d) suggests a count (1 = the single-launch form; kv_part may then be NULL). */
+   * projection -- parallelism for batches of a few clouds; free on a grid that fills the chip.
+   * pcr_attn_kv_splits(B, Sk, d) suggests a count from the launch shape alone (1 = the single-launch form; kv_part may
+   * then be NULL): results do not depend on the batch size. */
   int kv_splits;
   float *kv_part;
 } pcr_attn_params;

@@ -634,27 +634,17 @@ static bool attn_bf(const pcr_attn_params &p, pcr_attn_params &q) {
   return true;
 }
 
-// Suggested token split of a kv launch.  Measured on pt1024 (1024 clouds, 768 resident workgroups): 1 / 2 / 3 / 4 splits
-// run the d = 64, Sk = 1024 launches in 0.495 / 0.484 / 0.476 / 0.492 ms -- a full grid is bound by its per-tile work, not
-// by the partly filled last round, so a launch that already fills the chip keeps the single-launch form.  A SMALL batch
-// (fewer clouds than resident workgroups: gallery queries, the tests' few pairs) gains the parallelism it lacks:
-// n = slots / B splits, at most four (two at d = 128, whose partial matrices are as large as its inputs), at least
-// two tiles each.
+// Suggested token split of a kv launch: a function of the launch SHAPE only (never of the batch size), so that a pair's
+// logits do not depend on how many other pairs share its launch (tests/test_gpu_fullsize.py holds the bench batch to the
+// logits of the same pairs run in small groups, bit for bit).  Measured on pt1024 (1024 clouds): 1 / 2 / 3 / 4 splits
+// run the d = 64, Sk = 1024 launches in 0.495 / 0.484 / 0.476 / 0.492 ms -- a grid that fills the chip is bound by its
+// per-tile work, so the split costs nothing there -- while a few clouds (gallery queries, small batches) gain the
+// parallelism they lack.  d = 128 stays whole: its partial matrices are as large as its inputs (0.73 -> 0.85 ms at two).
 PCR_EXPORT int pcr_attn_kv_splits(int B, int Sk, int d) {
-  if (B < 1 || Sk < 1 || d > 128) return 1;
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) return 256;
-    return n;
-  }();
-  const int slots = cus * (d <= 32 ? 4 : 3);
-  const int T = d <= 64 ? 64 : 32, ntile = (Sk + T - 1) / T;
-  int n = slots / B;
-  const int nmax = d >= 128 ? 2 : 4;
-  if (n > nmax) n = nmax;
-  if (n > ntile / 2) n = ntile / 2;
-  return n < 1 ? 1 : n;
+  (void)B;
+  if (Sk < 1 || d > 64) return 1;
+  const int ntile = (Sk + 63) / 64;
+  return ntile >= 16 ? 4 : (ntile >= 8 ? 2 : 1);
 }
 
 PCR_EXPORT int pcr_attn_kv_f32(const pcr_attn_params *pp, pcr_stream_t stream) {

@@ -49,7 +49,9 @@ __global__ __launch_bounds__(kThreads) void sa_l1_fwd_kernel(L1Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = a.N, S = a.S, K = a.K, c1 = a.c1, L = S * K;
   float *Pl = smem;                                   // [CS][N]
-  float *xl = Pl + (a.tab ? CS * N : 0);              // [N][3]
+  float *Ql = Pl + (a.tab ? CS * N : 0);              // [CS][S]: the centres' columns of Q (a row's 32 loads of it sat
+                                                      // in front of its stores: one L2 round trip per row iteration)
+  float *xl = Ql + (a.tab ? CS * S : 0);              // [N][3]
   float *wl = xl + 3 * N;                             // [CS][4]: wa, bias
   float *red = wl + 4 * CS;                           // [4 waves][2][CS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -73,6 +75,24 @@ __global__ __launch_bounds__(kThreads) void sa_l1_fwd_kernel(L1Args a) {
       }
     }
   }
+  if (tab) {
+    const float *Qg = tab + (size_t)(c1 + c0) * N;
+    constexpr int U = 8;
+    for (int e0 = tid; e0 < CS * S; e0 += U * kThreads) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int e = e0 + u * kThreads;
+        const int c = e / S, s = e - c * S;
+        v[u] = (e < CS * S && c0 + c < c1) ? Qg[(size_t)c * N + s] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int e = e0 + u * kThreads;
+        if (e < CS * S) Ql[e] = v[u];
+      }
+    }
+  }
   for (int e = tid; e < 3 * N; e += kThreads) xl[e] = a.xyz[b * N * 3 + e];
   for (int e = tid; e < CS; e += kThreads) {
     const int c = c0 + e;
@@ -88,7 +108,6 @@ __global__ __launch_bounds__(kThreads) void sa_l1_fwd_kernel(L1Args a) {
   for (int c = 0; c < CS; c++) ssum[c] = ssq[c] = 0.f;
   const int *idx = a.idx + b * L;
   float *y = a.y + (b * c1 + c0) * L;
-  const float *Q = tab ? tab + (size_t)(c1 + c0) * N : nullptr;
   // (two instantiations of the row loop: the table-less first layer must not carry the table's registers and selects)
   auto rows = [&](auto has_tab) {
     constexpr bool TAB = decltype(has_tab)::value;
@@ -99,16 +118,11 @@ __global__ __launch_bounds__(kThreads) void sa_l1_fwd_kernel(L1Args a) {
       const float dx = xl[3 * i] - xl[3 * s], dy = xl[3 * i + 1] - xl[3 * s + 1], dz = xl[3 * i + 2] - xl[3 * s + 2];
       // the centre's table column first, all CS loads in flight: read inside the store loop each one waits behind the
       // previous store to y (the compiler cannot rule out that y aliases the table)
-      float qv[TAB ? CS : 1];
-      if constexpr (TAB) {
-#pragma unroll
-        for (int c = 0; c < CS; c++) qv[c] = c0 + c < c1 ? Q[(size_t)c * N + s] : 0.f;
-      }
 #pragma unroll
       for (int c = 0; c < CS; c++) {
         if (c0 + c < c1) {
           float v = fmaf(wl[4 * c + 2], dz, fmaf(wl[4 * c + 1], dy, fmaf(wl[4 * c], dx, wl[4 * c + 3])));
-          if constexpr (TAB) v += Pl[c * N + i] + qv[c];
+          if constexpr (TAB) v += Pl[c * N + i] + Ql[c * S + s];
           y[(size_t)c * L + r] = v;
           ssum[c] += v;
           ssq[c] += v * v;
@@ -426,7 +440,7 @@ PCR_EXPORT int pcr_sa_l1_fwd_f32(const float *xyz, const int *idx, const float *
   if (B > 65535) return PCR_ERR_INVALID;
   const int cs = l1_pow2(l1_chunk(N, c1));
   L1Args a{xyz, idx, tab, wa, bias, y, stats, N, S, K, c1, cs};
-  const size_t lds = ((tab ? (size_t)cs * N : 0) + 3 * (size_t)N + 4 * cs + 8 * cs) * sizeof(float);
+  const size_t lds = ((tab ? (size_t)cs * (N + S) : 0) + 3 * (size_t)N + 4 * cs + 8 * cs) * sizeof(float);
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
   const dim3 grid((c1 + cs - 1) / cs, B);
   l1_dispatch(cs, [&](auto tag) {
