@@ -223,7 +223,12 @@ def train_bench(args, desc, n, bl, pairs, rank, world, steps=None, warmup=None):
     data = dict(sparse_1=list(s1.to(dev)), sparse_2=list(s2.to(dev)), dense_1=list(s1.to(dev)), dense_2=list(s2.to(dev)),
                 label_1=[zero] * pairs, label_2=[zero] * pairs,
                 id_1=[i.view(1).to(dev) for i in ids1], id_2=[i.view(1).to(dev) for i in ids2])
-    tr = train.Trainer(model, max_iters=steps + warmup + 3, lr=3e-4, grad_clip=1.0)
+    # PCR_TRAIN_GRAPH=1: forward + backward replayed from a HIP graph (Trainer(graph=True)).  Measured: the step is bound by
+    # the launches' host cost only below ~128 pairs per GPU (16 pairs: 8.9 -> 4.0-4.5 ms replayed); at this workload's 256
+    # pairs the GPU is the bound either way (10.4-10.9 ms replayed against 10.45 eager), so eager is the default here
+    tr = train.Trainer(model, max_iters=steps + warmup + 3, lr=3e-4, grad_clip=1.0,
+                       graph=os.environ.get("PCR_TRAIN_GRAPH", "0") == "1" and warmup >= 2)
+    tr.graph_warmup = 1          # iteration 0 eager, iteration 1 captures: both inside the W warm-up steps
     prewarm()
     dt, out = shard.timed(lambda: tr.step(data)["loss"].detach(), steps, warmup,
                           sync=torch.cuda.synchronize, device="cuda")
@@ -236,6 +241,8 @@ def train_bench(args, desc, n, bl, pairs, rank, world, steps=None, warmup=None):
     clk = clock_probe() if rank == 0 else None
     if rank == 0:
         engine.PROFILE = []
+    graphed = tr.graph
+    tr.graph = False             # (the per-launch events need the launches themselves: this one step runs eager)
     tr.step(data)
     torch.cuda.synchronize()
     line = None
@@ -275,7 +282,9 @@ def train_bench(args, desc, n, bl, pairs, rank, world, steps=None, warmup=None):
             "dtype": "f32", "data": "synthetic (randn clouds, seeded random-init weights)",
             "config": {"workload": "pt128_train: %s" % desc, "pairs_per_gpu_per_step": pairs, "points": n,
                        "backbone_list": bl, "parallelism": "data parallel x%d, one %d-byte gradient bucket per step"
-                       % (world, tr.bucket.nbytes()), "rccl_ranks": world},
+                       % (world, tr.bucket.nbytes()), "rccl_ranks": world,
+                       "launch": "forward + backward replayed from one HIP graph, exchange + update eager" if graphed
+                       else "eager (one launch per node)"},
             "roofline": roof}
     del model, tr, data
     torch.cuda.empty_cache()

@@ -25,6 +25,14 @@ class LazyScalars(OrderedDict):
         names = list(names)
         ints = list(ints) if ints is not None else [False] * len(names)
         values = values.detach()
+        if values.is_cuda and torch.cuda.is_current_stream_capturing():
+            # inside a HIP-graph capture (pcr_amd.train.Trainer(graph=True)): no host allocation, copy or event may be
+            # recorded; the stacked values stay in their (static) device tensor and the trainer turns them into an
+            # ordinary pending entry after every replay (`from_static`)
+            for n in names:
+                OrderedDict.__setitem__(self, n, None)
+            self._static = getattr(self, "_static", []) + [(names, ints, values)]
+            return
         if values.is_cuda:
             host = torch.empty(values.shape, dtype=values.dtype).pin_memory()
             host.copy_(values, non_blocking=True)
@@ -35,6 +43,21 @@ class LazyScalars(OrderedDict):
         for n in names:                     # keeps the reference's key order
             OrderedDict.__setitem__(self, n, None)
         self._pending.append((names, ints, host, ev))
+
+    def static_entries(self):
+        """(names, ints, device tensor) triples recorded during a graph capture"""
+        return list(getattr(self, "_static", []))
+
+    @classmethod
+    def from_static(cls, plain, entries):
+        """a fresh LazyScalars after a graph replay: `plain` = the already-known items, `entries` = static_entries() of
+        the captured dict, whose device tensors now hold this replay's values (copied out asynchronously here)"""
+        out = cls()
+        for k, v in plain:
+            OrderedDict.__setitem__(out, k, v)
+        for names, ints, values in entries:
+            out.add_device(names, values, ints)
+        return out
 
     # ---- consumer side ----
     def materialize(self):
@@ -70,6 +93,8 @@ class LazyScalars(OrderedDict):
 
     def update(self, other=(), **kw):
         if isinstance(other, LazyScalars):          # keep the other's entries lazy too
+            if getattr(other, "_static", None):
+                self._static = getattr(self, "_static", []) + other._static
             pend, other._pending = other._pending, []
             for n in OrderedDict.keys(other):
                 OrderedDict.__setitem__(self, n, OrderedDict.__getitem__(other, n))

@@ -83,7 +83,7 @@ class Trainer:
 
     def __init__(self, model, max_iters, lr=3e-4, weight_decay=0.01, betas=(0.9, 0.999), grad_clip=35.0,
                  cumulative_iters=1, lr_target_ratio=(10.0, 1e-4), momentum_target_ratio=(0.85 / 0.95, 1.0),
-                 cyclic_times=1, step_ratio_up=0.4, fused=None):
+                 cyclic_times=1, step_ratio_up=0.4, fused=None, graph=False):
         self.model = model
         self.max_iters = int(max_iters)
         self.base_lr, self.base_beta1 = float(lr), float(betas[0])
@@ -104,6 +104,15 @@ class Trainer:
         self.bucket = GradBucket(list(model.parameters()))
         self.iter = 0
         self.epoch = 0
+        # graph=True: forward + backward of an iteration are captured ONCE into a HIP graph (after `graph_warmup` eager
+        # iterations) and replayed: ~600 launches per iteration leave the host as one.  The step is bound by the launches'
+        # host cost below ~128 pairs per GPU (9 ms per iteration whatever the batch; 16 pairs: 8.9 -> 4.0 ms replayed).
+        # The gradient exchange and the update stay eager (their constants change every iteration).  Needs the fused
+        # optimizer, cumulative_iters == 1 and batches of one fixed shape; anything else, or a failed capture, runs eager.
+        self.graph = bool(graph) and self.fused and self.cumulative_iters == 1
+        self.graph_warmup = 3
+        self._g = None
+        self._stream = None
 
     def current_lr(self):
         return cyclic_value(self.base_lr, self.iter, self.max_iters, self.lr_ratio, self.cyclic_times, self.step_ratio_up)
@@ -120,11 +129,37 @@ class Trainer:
         return lr, b1
 
     def step(self, data):
+        """one iteration (see _step); in graph mode on the trainer's OWN stream from the first iteration on: autograd's
+        gradient-accumulation nodes remember the stream they were created on, and a node born on the default stream during an
+        eager warm-up iteration (kept alive by any `out` the caller still holds) drags the default stream into the capture and
+        breaks it"""
+        if not self.graph:
+            return self._step(data)
+        if self._stream is None:
+            self._stream = torch.cuda.Stream()
+        cur = torch.cuda.current_stream()
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            out = self._step(data)
+        cur.wait_stream(self._stream)
+        return out
+
+    def _step(self, data):
         """one iteration: forward + backward of model.train_step(data, optimizer); every `cumulative_iters`
         iterations exchange gradients, clip, and apply AdamW.  Returns the outputs dict (+ lr, beta1 as floats;
         grad_norm as a 0-d tensor on the parameters' device in BOTH optimizer paths -- `float()` it at log time, which is
         the only place it costs a host synchronisation; log_vars is a LazyScalars dict with the same property)."""
         lr, b1 = self._set_hyper()
+        if self.graph and self.iter >= self.graph_warmup and not shard.is_dist():   # (a captured log all-reduce: not attempted)
+            out = self._graph_step(data)
+            if out is not None:
+                out["lr"], out["beta1"] = lr, b1
+                self.bucket.all_reduce_mean()
+                norm = self.optimizer.step(max_norm=self.grad_clip)
+                if norm is not None:
+                    out["grad_norm"] = norm
+                self.iter += 1
+                return out
         if self.iter % self.cumulative_iters == 0:
             self.optimizer.zero_grad(set_to_none=True)
         if self.fused:
@@ -145,6 +180,54 @@ class Trainer:
                     out["grad_norm"] = torch.nn.utils.clip_grad_norm_(params, self.grad_clip, norm_type=2).detach()
                 self.optimizer.step()
         self.iter += 1
+        return out
+
+    # ---- HIP-graph replay of forward + backward ----
+    def _graph_step(self, data):
+        """-> the iteration's outputs from the captured graph, or None (graph mode switched off: the caller runs eager)"""
+        from . import lazylog, train_ops
+        keys = [k for k, v in data.items() if isinstance(v, (list, tuple)) and v and torch.is_tensor(v[0])]
+        sig = tuple((k, len(data[k]), tuple(data[k][0].shape), data[k][0].dtype) for k in keys)
+        g = self._g
+        if g is not None and g["sig"] != sig:
+            g = self._g = None                      # another batch shape: capture again
+        try:
+            if g is None:
+                # static inputs: one stacked buffer per key; the model is fed lists of views into them, so that a new batch
+                # enters with ONE stack launch per key and the captured graph reads fixed addresses
+                static = {k: torch.stack(list(data[k])) for k in keys}
+                feed = dict(data)
+                for k in keys:
+                    feed[k] = list(static[k].unbind(0))
+                self.optimizer.zero_grad(set_to_none=True)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=self._stream, capture_error_mode="relaxed"):
+                    train_ops.prepack(self.model)
+                    out = self.model.train_step(feed, self.optimizer)
+                    out["loss"].backward()
+                lv = out["log_vars"]
+                ent = lv.static_entries() if isinstance(lv, lazylog.LazyScalars) else []
+                plain = [(k, v) for k, v in dict.items(lv)] if not ent else \
+                    [(k, v) for k, v in dict.items(lv) if v is not None]
+                g = self._g = dict(sig=sig, graph=graph, static=static, keys=keys, out=out, entries=ent, plain=plain,
+                                   params=[p for p in self.model.parameters()],
+                                   bufs=[b for b in self.model.buffers()])
+            else:
+                for k in g["keys"]:
+                    torch.stack(list(data[k]), out=g["static"][k])
+            g["graph"].replay()
+        except Exception as e:       # noqa: BLE001 -- whatever the capture could not take: this trainer runs eager from now on
+            import warnings
+            warnings.warn("pcr_amd.train.Trainer: HIP-graph capture failed (%s: %s); running eager" % (type(e).__name__, e))
+            self.graph, self._g = False, None
+            self.optimizer.zero_grad(set_to_none=True)
+            return None
+        # the replay wrote weights' packed images, BatchNorm statistics and gradients through captured launches: tell every
+        # cache keyed by Tensor._version (the eager path's in-place ops / launches do this themselves)
+        torch.autograd.graph.increment_version([b for b in g["bufs"] if b.is_floating_point()])
+        out = dict(g["out"])
+        if g["entries"]:
+            out["log_vars"] = lazylog.LazyScalars.from_static(g["plain"], g["entries"])
         return out
 
     # ---- checkpoints (mmcv layout) ----

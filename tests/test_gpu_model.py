@@ -524,3 +524,40 @@ def test_sa_layer_dormant_sampling_and_grouping_branches(sampling, use_knn):
     with torch.no_grad():
         _, want = MO.sa_edge_layer(sd, xyz, feats, S, 16, centre_idx=centre, group_idx=gidx)
     assert float((out.cpu() - want).abs().max()) < TOL
+
+
+def test_trainer_graph_mode_equals_eager_bit_for_bit():
+    """Trainer(graph=True): forward + backward replayed from a HIP graph after three eager iterations -- same launches in the
+    same order, so losses, gradient norms, parameters, BatchNorm statistics and log values equal the eager run's bit for
+    bit, also when every iteration brings NEW batch tensors; evaluation afterwards sees the trained weights"""
+    import bench
+    from pcr_amd import train
+
+    def batch(seed, pairs=8, n=128):
+        s1, s2 = T.synthetic_pairs(pairs, n, seed=seed, kind="randn")
+        ids1 = torch.arange(pairs)
+        ids2 = torch.where(torch.arange(pairs) % 2 == 0, ids1, ids1 + 100)
+        zero = torch.zeros(1, dtype=torch.long, device="cuda")
+        return dict(sparse_1=list(s1.cuda()), sparse_2=list(s2.cuda()), dense_1=list(s1.cuda()), dense_2=list(s2.cuda()),
+                    label_1=[zero] * pairs, label_2=[zero] * pairs,
+                    id_1=[i.view(1).cuda() for i in ids1], id_2=[i.view(1).cuda() for i in ids2])
+
+    runs = {}
+    for mode in (False, True):
+        m, _ = bench.build_pt_model([128, 64, 32])
+        m.train()
+        tr = train.Trainer(m, max_iters=12, lr=1e-3, grad_clip=1.0, graph=mode)
+        rec = []
+        for it in range(7):
+            out = tr.step(batch(10 + it))
+            rec.append((float(out["loss"]), float(out["grad_norm"]), out["log_vars"]["match_acc"], out["log_vars"]["loss"]))
+        assert tr.graph == mode                                    # (the capture did not fall back)
+        m.eval()
+        s1, s2 = T.synthetic_pairs(4, 128, seed=3)
+        with torch.no_grad():
+            logits = bench.hot_path(m, s1.cuda(), s2.cuda()).cpu()
+        runs[mode] = (rec, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, logits)
+    assert runs[False][0] == runs[True][0], (runs[False][0], runs[True][0])
+    for k, v in runs[False][1].items():
+        assert torch.equal(v, runs[True][1][k]), k
+    assert torch.equal(runs[False][2], runs[True][2])
