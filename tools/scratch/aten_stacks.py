@@ -18,12 +18,12 @@ for _ in range(3):
     tr.step(data)
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     tr.step(data)
     torch.cuda.synchronize()
-ka = prof.key_averages(group_by_stack_n=12)
-rows = [e for e in ka if e.key in ("aten::copy_", "aten::fill_", "aten::add_", "aten::add", "aten::cat", "aten::clone", "aten::zeros", "aten::contiguous", "aten::zero_", "aten::roll", "aten::stack", "aten::to", "aten::_to_copy")]
-rows.sort(key=lambda e: -e.count)
-for e in rows[:45]:
-    site = [s for s in e.stack if ("point-cloud-reid_amd" in s or "bench.py" in s or "autograd" in s)][:3]
-    print("%4d %-16s %s" % (e.count, e.key, " <- ".join(s.split("/")[-1][:60] for s in site) or (e.stack[:2] if e.stack else "?")))
+ka = prof.key_averages(group_by_input_shape=True)
+want = ("aten::copy_", "aten::fill_", "aten::add_", "aten::add", "aten::cat", "aten::clone", "aten::zeros", "aten::contiguous", "aten::zero_", "aten::roll", "aten::stack", "aten::to", "aten::_to_copy", "aten::sub", "aten::neg", "aten::mul", "aten::div", "aten::sum", "aten::mean", "aten::where", "aten::zeros_like", "aten::empty_like", "aten::slice_backward", "aten::select_backward", "aten::t", "aten::transpose")
+rows = [e for e in ka if e.key in want]
+rows.sort(key=lambda e: (e.key, -e.count))
+for e in rows:
+    print("%4d %-22s %s" % (e.count, e.key, str(e.input_shapes)[:150]))
