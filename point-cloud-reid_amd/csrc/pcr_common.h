@@ -120,6 +120,49 @@ __device__ __forceinline__ uint32_t pcr_wave_sort_u32(uint32_t v, int lane) {
   return v;
 }
 
+// The same network for keys that are the BITS OF NON-NEGATIVE, NON-NaN FLOATS (denormals included: the kernels run
+// with float_denorm_mode_32 = 3), two VALU instructions per step instead of three plus their vcc round trip.  A
+// lane that keeps the larger key of its pair holds the key NEGATED: then both lanes of a pair execute the same
+// x = min(x, -partner(x)) -- for the keeper of the minimum that is min(x, y), for the keeper of the maximum
+// min(-y, -x) = -max(x, y) -- and the negation of the partner is a source modifier of v_min_f32 (on the DPP operand
+// where the exchange is a DPP pattern).  Between two steps a lane whose role changes flips its sign (v_cndmask with a
+// negated source under a constant lane mask).  Float order on these keys is their unsigned order.
+constexpr unsigned long long pcr_lane_bit_mask(int bit) {   // the lanes whose bit `bit` (a power of two, 0 = none) is set
+  return bit == 1 ? 0xAAAAAAAAAAAAAAAAull : bit == 2 ? 0xCCCCCCCCCCCCCCCCull : bit == 4 ? 0xF0F0F0F0F0F0F0F0ull
+       : bit == 8 ? 0xFF00FF00FF00FF00ull : bit == 16 ? 0xFFFF0000FFFF0000ull : bit == 32 ? 0xFFFFFFFF00000000ull : 0ull;
+}
+
+template <int K, int J, int BIT>
+__device__ __forceinline__ uint32_t pcr_sortf_step(uint32_t v, int lane) {
+  // lanes with bit BIT set keep the larger key in this step; in the previous step it was bit PREV
+  constexpr int PREV = J == 0 ? (K == 2 ? 0 : 1) : 2 * BIT;
+  const unsigned long long flip = pcr_lane_bit_mask(PREV) ^ pcr_lane_bit_mask(BIT);
+#define PCR_SORTF_DPP(CTRL)                                                                              \
+  asm("v_cndmask_b32_e64 %0, %0, -%0, %1\n\ts_nop 1\n\t"                                                \
+      "v_min_f32_dpp %0, -%0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(v) : "s"(flip))
+  constexpr bool dpp = (J == 0 && K <= 16) || J == 1 || J == 2;
+  if constexpr (dpp) {
+    if constexpr (J == 1 || (J == 0 && K == 2)) PCR_SORTF_DPP("quad_perm:[1,0,3,2]");
+    else if constexpr (J == 2) PCR_SORTF_DPP("quad_perm:[2,3,0,1]");
+    else if constexpr (K == 4) PCR_SORTF_DPP("quad_perm:[3,2,1,0]");
+    else if constexpr (K == 8) PCR_SORTF_DPP("row_half_mirror");
+    else PCR_SORTF_DPP("row_mirror");
+  } else {
+    asm("v_cndmask_b32_e64 %0, %0, -%0, %1" : "+v"(v) : "s"(flip));
+    const uint32_t o = pcr_sort_partner<K, J>(v, lane);
+    asm("v_min_f32_e64 %0, %1, -%2" : "=v"(v) : "v"(v), "v"(o));
+  }
+#undef PCR_SORTF_DPP
+  return v;
+}
+
+__device__ __forceinline__ uint32_t pcr_wave_sort_posf32(uint32_t v, int lane) {
+#define PCR_STEPF(K, J, BIT) v = pcr_sortf_step<K, J, BIT>(v, lane);
+  PCR_SORT_NETWORK(PCR_STEPF)
+#undef PCR_STEPF
+  return v & 0x7FFFFFFFu;   // the last step's keepers of the maximum (odd lanes) still hold their key negated
+}
+
 __device__ __forceinline__ unsigned long long pcr_wave_sort_u64(unsigned long long key, int lane) {
   uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
 #define PCR_STEP64(K, J, BIT)                                                        \

@@ -914,8 +914,11 @@ __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_reg_kernel(const floa
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *sx = smem, *sy = smem + n, *sz = smem + 2 * n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  unsigned long long *cand =
-      reinterpret_cast<unsigned long long *>(smem + 3 * n + (n & 1)) + wave * kKnnCap;
+  // candidates {index, distance bits} (= a 64-bit (distance, index) key), room for every point of the cloud
+  constexpr int CAPW = 128 * TP > kKnnCap ? 128 * TP : kKnnCap;
+  unsigned long long *cand = reinterpret_cast<unsigned long long *>(smem + 3 * n + (n & 1)) +
+                             __builtin_amdgcn_readfirstlane(wave) * CAPW;   // (a scalar: slot addresses fold it)
+  uint32_t *cand32 = reinterpret_cast<uint32_t *>(cand);
   const size_t b = blockIdx.y;
   const float *cloud = xyz + b * n * 3;
   for (int i = tid; i < n; i += kKnnPThreads) {
@@ -953,33 +956,79 @@ __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_reg_kernel(const floa
       const uint32_t m01 = d[2 * t] < d[2 * t + 1] ? d[2 * t] : d[2 * t + 1];
       m = m01 < m ? m01 : m;
     }
-    // 1. the (truncated, lane-tagged) lane minimum of rank K-1: sort the 64 keys across the lanes (21-step network)
-    const uint32_t mkey = (m & ~63u) | (uint32_t)lane;
-    const uint32_t tau = (uint32_t)__builtin_amdgcn_readlane((int)pcr_wave_sort_u32(mkey, lane), K - 1) | 63u;
-    // 2. candidates d <= tau
-    int cnt = 0;
+    // 1. the (truncated, lane-tagged) lane minimum of rank K-1: sort the 64 keys across the lanes (21-step network
+    // on float bits, pcr_common.h; a lane without a valid point holds +inf: clamped to the largest finite float so
+    // that the tagged key is not a NaN pattern)
+    const uint32_t mc = m < 0x7F7FFFFFu ? m : 0x7F7FFFFFu;
+    const uint32_t mkey = (mc & ~63u) | (uint32_t)lane;
+    const uint32_t ts = (uint32_t)__builtin_amdgcn_readlane((int)pcr_wave_sort_posf32(mkey, lane), K - 1);
+    // (rank K-1 at the clamp = distances overflowed: let every point pass, the rounds below rank them)
+    const uint32_t tau = ts >= 0x7F7FFFC0u ? 0x7F800000u : (ts | 63u);
+    // 2. candidates d <= tau, compacted in (t, lane) order: the slot of a candidate is the number of candidates
+    // before it -- the running total of the earlier t (scalar) + the passing lanes below it (mbcnt of the ballot)
+    int total = 0;
 #pragma unroll
-    for (int t = 0; t < T; t++) cnt += d[t] <= tau ? 1 : 0;
-    int incl = cnt;
-#pragma unroll
-    for (int s2 = 1; s2 < 64; s2 <<= 1) {
-      const int o = __shfl_up(incl, s2, 64);
-      if (lane >= s2) incl += o;
+    for (int t = 0; t < T; t++) {
+      const bool pass = d[t] <= tau;
+      const unsigned long long mask = __ballot(pass);
+      const int pos = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+      if (pass) {
+        cand32[2 * pos] = (uint32_t)(lane + 64 * t);
+        cand32[2 * pos + 1] = d[t];
+      }
+      total += __popcll(mask);
     }
-    const int total = __builtin_amdgcn_readlane(incl, 63);
     int *out = idx + (b * S + q) * K;
     if (total <= kKnnCap) {
-      int off = incl - cnt;
-#pragma unroll
-      for (int t = 0; t < T; t++)
-        if (d[t] <= tau) cand[off++] = ((unsigned long long)(d[t] | 0x80000000u) << 32) | (unsigned)(lane + 64 * t);
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (total > 64 && total <= 128) {
+        // 2b. a few candidates too many for one per lane (K = 48: 62-72 of them): the same bound once more, on the
+        // candidates -- the minimum of a lane's two candidates, rank K-1 of those 64 (K distinct candidates are
+        // <= it) -- and the survivors compacted in place (every lane holds its two before the first write).
+        const uint32_t i0 = cand32[2 * lane], d0 = cand32[2 * lane + 1];
+        const bool has1 = lane + 64 < total;
+        const uint32_t i1 = cand32[2 * lane + 128], d1r = cand32[2 * lane + 129];
+        const uint32_t d1 = has1 ? d1r : 0x7F7FFFFFu;
+        const uint32_t dm = d0 < d1 ? d0 : d1;
+        const uint32_t ts2 =
+            (uint32_t)__builtin_amdgcn_readlane((int)pcr_wave_sort_posf32((dm & ~63u) | (uint32_t)lane, lane), K - 1);
+        const uint32_t tau2 = ts2 | 63u;
+        __builtin_amdgcn_wave_barrier();
+        const bool p0 = d0 <= tau2, p1 = has1 && d1 <= tau2;
+        const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
+        const int s0 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
+        const int n0 = __popcll(m0);
+        const int s1 = n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+        if (p0) {
+          cand32[2 * s0] = i0;
+          cand32[2 * s0 + 1] = d0;
+        }
+        if (p1) {
+          cand32[2 * s1] = i1;
+          cand32[2 * s1 + 1] = d1;
+        }
+        total = n0 + __popcll(m1);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
       if (total <= 64) {
-        // 3a. one candidate per lane: sort the exact 64-bit (distance, index) keys across the lanes; lanes < K hold
-        // the answer in order (K <= total: tau bounds the K-th smallest distance)
-        const unsigned long long own = pcr_wave_sort_u64(lane < total ? cand[lane] : ~0ull, lane);
-        if (lane < K) out[lane] = (int)(uint32_t)own;
+        // 3a. one candidate per lane.  Fast form: sort 32-bit keys (distance bits with the low 6 bits replaced by
+        // the SLOT) with the float network; exact unless two of the first K + 1 ranks share their truncated
+        // distance (~1 % of the queries), which is detected on the sorted keys and sent through the 64-bit sort.
+        const uint32_t dj = cand32[2 * lane + 1];
+        const uint32_t key = lane < total ? ((dj & ~63u) | (uint32_t)lane) : (0x7F7FFFC0u | (uint32_t)lane);
+        const uint32_t sk = pcr_wave_sort_posf32(key, lane);
+        const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)sk, 0x130, 0xF, 0xF, false);   // lane + 1
+        const bool tie = lane < K && ((sk ^ nx) < 64u);
+        if (__ballot(tie) == 0ull) {
+          if (lane < K) out[lane] = (int)cand32[2 * (sk & 63u)];
+        } else {
+          const unsigned long long own = pcr_wave_sort_u64(lane < total ? cand[lane] : ~0ull, lane);
+          if (lane < K) out[lane] = (int)(uint32_t)own;
+        }
       } else {
         // 3b. up to kKnnCap candidates: four per lane, broadcast LDS reads
         unsigned long long own[kKnnCap / 64];
@@ -1286,9 +1335,11 @@ PCR_EXPORT int pcr_knn_prefix_f32(const float *xyz, int *idx, int B, int N, int 
   if (B > 65535) return PCR_ERR_INVALID;
   const int qpw = 32;
   dim3 g((S + qpw - 1) / qpw, B), blk(kKnnPThreads);
-  size_t lds = (size_t)(3 * N + (N & 1)) * sizeof(float) + (size_t)4 * kKnnCap * 8;
+  size_t lds = (size_t)(3 * N + (N & 1)) * sizeof(float);
   hipStream_t st = pcr_s(stream);
-#define PCR_KNN_REG(TP) hipLaunchKernelGGL((knn_prefix_reg_kernel<TP>), g, blk, lds, st, xyz, idx, N, S, K, qpw)
+#define PCR_KNN_REG(TP)                                                                                  \
+  hipLaunchKernelGGL((knn_prefix_reg_kernel<TP>), g, blk,                                                \
+                     lds + (size_t)4 * (128 * TP > kKnnCap ? 128 * TP : kKnnCap) * 8, st, xyz, idx, N, S, K, qpw)
   if (N <= 128) PCR_KNN_REG(1);
   else if (N <= 256) PCR_KNN_REG(2);
   else if (N <= 512) PCR_KNN_REG(4);

@@ -87,12 +87,30 @@ def test_knn_heap_bit_exact(ops, n, m, k, kind):
 @pytest.mark.parametrize("n,s,k,kind", [(128, 128, 32, "randn"), (128, 64, 48, "dup"), (512, 256, 48, "box"),
                                         (1024, 1024, 32, "dup"), (4096, 100, 48, "randn"), (70, 70, 64, "dup"),
                                         (2048, 33, 5, "box"), (4096, 64, 32, "dup"), (3000, 50, 16, "box"),
-                                        (2500, 40, 64, "dup")])
+                                        (2500, 40, 64, "dup"), (1024, 512, 48, "randn"), (1024, 1024, 48, "box"),
+                                        (1000, 700, 40, "randn"), (300, 300, 64, "randn"), (640, 640, 33, "dup"),
+                                        (256, 256, 48, "randn"), (1024, 1024, 64, "randn"), (90, 90, 48, "randn")])
 def test_knn_prefix_bit_exact(n, s, k, kind):
     from pcr_amd import engine
     xyz = T.synthetic_clouds(3, n, seed=21, kind=kind).numpy()
     want = P.knn_prefix(xyz, s, k)
     got = engine.knn_prefix(dev(xyz), s, k).cpu().numpy()
+    assert (got == want).all()
+
+
+@pytest.mark.parametrize("n,k,span", [(1024, 32, 40), (1024, 48, 12), (512, 32, 6), (1024, 32, 3), (700, 64, 25),
+                                      (128, 32, 9)])
+def test_knn_prefix_lattice_ties_bit_exact(n, k, span):
+    """Integer lattice clouds: many EXACTLY equal distances (the index decides) and duplicates -- the truncated
+    32-bit ranking must notice every tie among the first K + 1 ranks and take the exact 64-bit sort (few
+    distinct distances), and the wider spans mix tie-free and tied queries in one launch."""
+    from pcr_amd import engine
+    g = np.random.default_rng(n + k + span)
+    xyz = g.integers(0, span, (3, n, 3)).astype(np.float32)
+    xyz[1] *= np.float32(0.37)          # non-representable steps: ties survive, rounding differs per axis
+    xyz[2] += g.standard_normal((n, 3)).astype(np.float32) * np.float32(1e-6)   # near-ties within a few ulps
+    want = P.knn_prefix(xyz, n, k)
+    got = engine.knn_prefix(dev(xyz), n, k).cpu().numpy()
     assert (got == want).all()
 
 
