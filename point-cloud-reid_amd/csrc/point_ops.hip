@@ -914,8 +914,8 @@ __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_reg_kernel(const floa
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *sx = smem, *sy = smem + n, *sz = smem + 2 * n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // candidates {index, distance bits} (= a 64-bit (distance, index) key), room for every point of the cloud
-  constexpr int CAPW = 128 * TP > kKnnCap ? 128 * TP : kKnnCap;
+  // candidates {index, distance bits} (= a 64-bit (distance, index) key); a round of the compaction adds at most 64
+  constexpr int CAPW = kKnnCap + 64;
   unsigned long long *cand = reinterpret_cast<unsigned long long *>(smem + 3 * n + (n & 1)) +
                              __builtin_amdgcn_readfirstlane(wave) * CAPW;   // (a scalar: slot addresses fold it)
   uint32_t *cand32 = reinterpret_cast<uint32_t *>(cand);
@@ -971,11 +971,12 @@ __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_reg_kernel(const floa
     for (int t = 0; t < T; t++) {
       const bool pass = d[t] <= tau;
       const unsigned long long mask = __ballot(pass);
-      const int pos = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                             __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-      if (pass) {
-        cand32[2 * pos] = (uint32_t)(lane + 64 * t);
-        cand32[2 * pos + 1] = d[t];
+      const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+      uint32_t *wp = cand32 + 2 * total;   // (scalar)
+      if (total <= kKnnCap && pass) {   // (scalar test: past kKnnCap the candidates are not used, only counted)
+        wp[2 * pos] = (uint32_t)(lane + 64 * t);
+        wp[2 * pos + 1] = d[t];
       }
       total += __popcll(mask);
     }
@@ -1339,7 +1340,7 @@ PCR_EXPORT int pcr_knn_prefix_f32(const float *xyz, int *idx, int B, int N, int 
   hipStream_t st = pcr_s(stream);
 #define PCR_KNN_REG(TP)                                                                                  \
   hipLaunchKernelGGL((knn_prefix_reg_kernel<TP>), g, blk,                                                \
-                     lds + (size_t)4 * (128 * TP > kKnnCap ? 128 * TP : kKnnCap) * 8, st, xyz, idx, N, S, K, qpw)
+                     lds + (size_t)4 * (kKnnCap + 64) * 8, st, xyz, idx, N, S, K, qpw)
   if (N <= 128) PCR_KNN_REG(1);
   else if (N <= 256) PCR_KNN_REG(2);
   else if (N <= 512) PCR_KNN_REG(4);
