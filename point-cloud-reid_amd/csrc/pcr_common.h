@@ -140,10 +140,20 @@ __device__ __forceinline__ uint32_t pcr_sortf_step(uint32_t v, int lane) {
 #define PCR_SORTF_DPP(CTRL)                                                                              \
   asm("v_cndmask_b32_e64 %0, %0, -%0, %1\n\ts_nop 1\n\t"                                                \
       "v_min_f32_dpp %0, -%0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(v) : "s"(flip))
-  constexpr bool dpp = (J == 0 && K <= 16) || J == 1 || J == 2;
-  if constexpr (dpp) {
+  constexpr bool dpp = (J == 0 && K <= 16) || J == 1 || J == 2 || J == 8;
+  if constexpr (J == 4) {
+    // xor 4 inside a row of 16: the lanes of banks 0 / 2 take lane + 4, those of banks 1 / 3 lane - 4 -- two DPP
+    // minima under bank masks instead of a ds_swizzle round trip
+    uint32_t w;
+    asm("v_cndmask_b32_e64 %1, %1, -%1, %2\n\ts_nop 1\n\t"
+        "v_min_f32_dpp %0, -%1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_min_f32_dpp %0, -%1, %1 row_shr:4 row_mask:0xf bank_mask:0xa"
+        : "=&v"(w), "+v"(v) : "s"(flip));
+    v = w;
+  } else if constexpr (dpp) {
     if constexpr (J == 1 || (J == 0 && K == 2)) PCR_SORTF_DPP("quad_perm:[1,0,3,2]");
     else if constexpr (J == 2) PCR_SORTF_DPP("quad_perm:[2,3,0,1]");
+    else if constexpr (J == 8) PCR_SORTF_DPP("row_ror:8");
     else if constexpr (K == 4) PCR_SORTF_DPP("quad_perm:[3,2,1,0]");
     else if constexpr (K == 8) PCR_SORTF_DPP("row_half_mirror");
     else PCR_SORTF_DPP("row_mirror");
