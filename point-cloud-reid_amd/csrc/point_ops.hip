@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict
 // evaluations per lane instead of N serial LDS round trips per thread; hits are rare (a few per 1024
 // points), so the ordered compaction (ballot + prefix popcount) sits behind a wave-uniform branch.
 // Same hit predicate, same "first K in index order, pad with the first hit" result as above.
-template <int PPL>
+template <int PPL, bool kSimple>   // kSimple: min_radius = 0 < max_radius (every configuration in the reference)
 __global__ __launch_bounds__(256) void ball_query_reg_kernel(const float *__restrict__ centres,
                                                              const float *__restrict__ xyz,
                                                              int *__restrict__ idx, int n, int m,
@@ -517,21 +517,26 @@ __global__ __launch_bounds__(256) void ball_query_reg_kernel(const float *__rest
   const size_t b = (size_t)(slot / nchunk) * 8 + xcd;
   if (b >= (size_t)nclouds) return;
   const float *cloud = xyz + b * n * 3;
-  float px[PPL], py[PPL], pz[PPL];
+  // two points per register pair (j = 2 t, 2 t + 1): the distance arithmetic is packed f32 -- the same IEEE
+  // subtract / multiply / add per component as pcr_sqdist3, two points per instruction
+  static_assert(PPL % 2 == 0, "points per lane come in pairs");
+  f32x2 px[PPL / 2], py[PPL / 2], pz[PPL / 2];
 #pragma unroll
   for (int j = 0; j < PPL; j++) {
     const int i = j * 64 + lane;
     const bool ok = i < n;
     const float *q = cloud + (size_t)(ok ? i : 0) * 3;
     const float x = q[0], y = q[1], z = q[2];
-    px[j] = ok ? x : INFINITY;   // a point at infinity is never inside a ball
-    py[j] = ok ? y : INFINITY;
-    pz[j] = ok ? z : INFINITY;
+    px[j >> 1][j & 1] = ok ? x : INFINITY;   // a point at infinity is never inside a ball
+    py[j >> 1][j & 1] = ok ? y : INFINITY;
+    pz[j >> 1][j & 1] = ok ? z : INFINITY;
   }
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  const bool simple = min_r2 == 0.f && max_r2 > 0.f;
   const int c0 = (chunk * 4 + wave) * cpw;
   const int c1 = c0 + cpw < m ? c0 + cpw : m;
+  // the wave's centres (cpw <= 21 of them: 3 cpw floats) in ONE register, a float per lane; a centre's coordinates
+  // are three v_readlane instead of a dependent scalar load per centre
+  float cv = 0.f;
+  if (c0 < c1 && lane < 3 * (c1 - c0)) cv = centres[(b * m + c0) * 3 + lane];
   // K <= 64: a centre's row is assembled in a wave-private LDS strip and leaves as ONE store of K consecutive ints
   // (hits and padding together).  Written hit by hit, a row was several partial-line stores; the L2 fetched the lines
   // it did not own in full: 697 MB fetched per ssg1024 launch pair against 344 MB of algorithmic traffic.
@@ -539,31 +544,49 @@ __global__ __launch_bounds__(256) void ball_query_reg_kernel(const float *__rest
   int *row = s_row[wave];
   const bool staged = K <= 64;
   for (int c = c0; c < c1; c++) {
-    const float *cc = centres + (b * m + c) * 3;
-    const float cx = cc[0], cy = cc[1], cz = cc[2];
-    int *out = staged ? row : idx + (b * m + c) * (size_t)K;
+    const int co = 3 * (c - c0);
+    const float cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cv), co));
+    const float cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cv), co + 1));
+    const float cz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cv), co + 2));
+    int *gout = idx + (b * m + c) * (size_t)K;
     int cnt = 0, first = 0;
-    auto scan = [&](auto simple_tag) {
-      constexpr bool kSimple = decltype(simple_tag)::value;
+    {
+      // min_radius = 0: d2 >= 0 always holds and d2 == 0 implies d2 < max_r2, so the predicate is a single compare
+      auto inside = [&](float d2) __attribute__((always_inline)) {
+        return kSimple ? d2 < max_r2 : (bool)((d2 == 0.f) | ((d2 >= min_r2) & (d2 < max_r2)));
+      };
+      // pass 1, straight line: all PPL distances and their hit masks (scalar registers); hits are rare (a few per
+      // 1024 points), so pass 2 -- the ordered compaction -- visits only the non-empty masks behind scalar tests
+      const f32x2 x1 = {cx, cx}, y1 = {cy, cy}, z1 = {cz, cz};
+      float d2[PPL];
+      unsigned long long mk[PPL];
+#pragma unroll
+      for (int t = 0; t < PPL / 2; t++) {
+        const f32x2 dx = x1 - px[t], dy = y1 - py[t], dz = z1 - pz[t];   // pcr_sqdist3(p, centre): centre - p
+        const f32x2 a2 = dx * dx;
+        const f32x2 b2 = dy * dy;
+        const f32x2 c2 = dz * dz;
+        const f32x2 sab = a2 + b2;
+        const f32x2 dd = sab + c2;
+        d2[2 * t] = dd[0];
+        d2[2 * t + 1] = dd[1];
+        mk[2 * t] = __ballot(inside(dd[0]));
+        mk[2 * t + 1] = __ballot(inside(dd[1]));
+      }
 #pragma unroll
       for (int j = 0; j < PPL; j++) {
-        if (cnt < K) {   // wave-uniform
-          const float d2 = pcr_sqdist3(px[j], py[j], pz[j], cx, cy, cz);
-          // min_radius = 0 (every configuration in the reference): d2 >= 0 always holds and d2 == 0 implies
-          // d2 < max_r2, so the predicate is a single compare
-          const bool hit = kSimple ? d2 < max_r2 : (d2 == 0.f || (d2 >= min_r2 && d2 < max_r2));
-          const unsigned long long mask = __ballot(hit);
-          if (mask) {
-            const int pos = cnt + __popcll(mask & lt);
-            if (hit && pos < K) out[pos] = j * 64 + lane;
-            if (cnt == 0) first = j * 64 + (int)__builtin_ctzll(mask);
-            cnt += __popcll(mask);
+        if (mk[j] != 0ull) {   // wave-uniform, ONE scalar test per j (the scalar unit is shared by the CU's four SIMDs)
+          const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk[j] >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mk[j], 0u));
+          if (inside(d2[j]) && pos < K) {
+            if (staged) row[pos] = j * 64 + lane;   // (kept apart: one pointer for both would be a flat store)
+            else gout[pos] = j * 64 + lane;
           }
+          if (cnt == 0) first = j * 64 + (int)__builtin_ctzll(mk[j]);
+          cnt += __popcll(mk[j]);
         }
       }
-    };
-    if (simple) scan(std::true_type{});
-    else scan(std::false_type{});
+    }
     if (cnt > K) cnt = K;
     if (staged) {
       // (a wave's LDS operations complete in order: the hit lanes' writes above are visible to the read below)
@@ -575,7 +598,7 @@ __global__ __launch_bounds__(256) void ball_query_reg_kernel(const float *__rest
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     } else {
-      for (int l = cnt + lane; l < K; l += 64) out[l] = first;
+      for (int l = cnt + lane; l < K; l += 64) gout[l] = first;
     }
     if (cnt_out && lane == 0) cnt_out[b * m + c] = cnt;
   }
@@ -587,15 +610,14 @@ static void ball_query_launch(const float *centres, const float *xyz, int *idx, 
     const int cpw = 16;                                  // centres per wave
     const int nchunk = (M + 4 * cpw - 1) / (4 * cpw);
     const dim3 grid((unsigned)((B + 7) / 8) * 8 * nchunk), blk(256);
-    if (N <= 256)
-      hipLaunchKernelGGL(ball_query_reg_kernel<4>, grid, blk, 0, st, centres, xyz, idx, N, M, min_r2, max_r2, K, cnt, cpw,
-                         nchunk, B);
-    else if (N <= 512)
-      hipLaunchKernelGGL(ball_query_reg_kernel<8>, grid, blk, 0, st, centres, xyz, idx, N, M, min_r2, max_r2, K, cnt, cpw,
-                         nchunk, B);
-    else
-      hipLaunchKernelGGL(ball_query_reg_kernel<16>, grid, blk, 0, st, centres, xyz, idx, N, M, min_r2, max_r2, K, cnt, cpw,
-                         nchunk, B);
+    const bool simple = min_r2 == 0.f && max_r2 > 0.f;
+#define PCR_BQ(PPLv, SIMPLEv)                                                                                    \
+  hipLaunchKernelGGL((ball_query_reg_kernel<PPLv, SIMPLEv>), grid, blk, 0, st, centres, xyz, idx, N, M, min_r2, \
+                     max_r2, K, cnt, cpw, nchunk, B)
+    if (N <= 256) { if (simple) PCR_BQ(4, true); else PCR_BQ(4, false); }
+    else if (N <= 512) { if (simple) PCR_BQ(8, true); else PCR_BQ(8, false); }
+    else { if (simple) PCR_BQ(16, true); else PCR_BQ(16, false); }
+#undef PCR_BQ
   } else {
     hipLaunchKernelGGL(ball_query_kernel<false>, dim3((M + 255) / 256, B), dim3(256), 0, st, centres, xyz, idx, N, M,
                        min_r2, max_r2, K, cnt);
@@ -1334,7 +1356,7 @@ PCR_EXPORT int pcr_knn_prefix_f32(const float *xyz, int *idx, int B, int N, int 
     return PCR_ERR_INVALID;
   if (B == 0 || S == 0) return PCR_OK;
   if (B > 65535) return PCR_ERR_INVALID;
-  const int qpw = 32;
+  const int qpw = 64;   // queries per workgroup: the cloud is staged once per workgroup
   dim3 g((S + qpw - 1) / qpw, B), blk(kKnnPThreads);
   size_t lds = (size_t)(3 * N + (N & 1)) * sizeof(float);
   hipStream_t st = pcr_s(stream);
