@@ -1,5 +1,18 @@
 mkdir -p gpurun_out/r3s
-python -m pytest tests/test_gpu_train_stream.py -x -q -m gpu > gpurun_out/r3s/test.log 2>&1; echo "tests rc $?"; tail -3 gpurun_out/r3s/test.log
-PCR_STREAM_MIN=0 python tools/bench_tdense_fwd.py 128 1536 512
-PCR_STREAM_MIN=0 python tools/bench_tdense_fwd.py 64 3072 512
-python bench.py --workload pt128_train --no-cpu-baseline 2>/dev/null | head -c 300; echo
+python -m pytest tests -q -m gpu > gpurun_out/r3s/all.log 2>&1; echo "all rc $?"
+tail -4 gpurun_out/r3s/all.log
+python bench.py > gpurun_out/r3s/bench_default.json 2> gpurun_out/r3s/bench_default.err; echo "bench rc $?"
+python - <<PY
+import json
+d=json.loads(open("gpurun_out/r3s/bench_default.json").read().strip().splitlines()[-1])
+print("HEAD", d["dtype"], round(d["value"]), round(d["ms_per_step"],2), d["max_abs_dlogit_vs_f32_path"], d["roofline"]["kernel"], round(d["roofline"]["frac"],3))
+for a in d.get("also", []):
+    if "error" in a: print(a["name"], "ERROR", a["error"]); continue
+    r=a["roofline"]
+    print(a["name"], a.get("dtype"), round(a["value"]), round(a["ms_per_step"],2), a.get("max_abs_dlogit_vs_f32_path"), r["kernel"], round(r["frac"],3))
+print("cpu", d.get("cpu_baseline",{}).get("value"))
+PY
+bash tools/collect_profiles.sh r03c "ssg1024 pt1024 pt128_train" > gpurun_out/r3s/prof.log 2>&1
+tail -5 gpurun_out/r3s/prof.log
+cat gpurun_out/prof_r03c/ssg1024_pmc.txt | head -12
+cat gpurun_out/prof_r03c/pt1024_pmc.txt | head -14
