@@ -195,7 +195,10 @@ class ReIDNet(nn.Module):
         b = h1.shape[0]
         feats = self._pair_batch(h1, h2).contiguous()
         xyz = self._pair_batch(xyz1, xyz2).contiguous()
-        partner = torch.cat([torch.arange(b, 2 * b), torch.arange(0, b)]).to(device=feats.device, dtype=torch.int32)
+        # (built on the device: a pageable host-to-device copy here stalls the stream -- measured on the gallery path,
+        # where the same 256 KB index copy cost 45 ms every third step)
+        partner = torch.cat([torch.arange(b, 2 * b, device=feats.device, dtype=torch.int32),
+                             torch.arange(0, b, device=feats.device, dtype=torch.int32)])
         s1 = self.cross_stage1.forward_paired(feats, xyz, partner)
         return self.cross_stage2.forward_paired(s1, xyz, partner)     # (2B,C,N): [o1; o2]
 
@@ -315,8 +318,8 @@ class ReIDNet(nn.Module):
             k_idx = torch.cat([j, i]).contiguous()        # ... and b >= P: object j queries object i
             s1 = p1.apply(h, None, kv1, n_pts, kv_index=k_idx, q_index=q_idx, n_out=2 * n_pairs)
             xyz_v = xyz.index_select(0, q_idx.long()).contiguous()
-            partner = torch.cat([torch.arange(n_pairs, 2 * n_pairs), torch.arange(0, n_pairs)]).to(
-                device=h.device, dtype=torch.int32)
+            partner = torch.cat([torch.arange(n_pairs, 2 * n_pairs, device=h.device, dtype=torch.int32),
+                                 torch.arange(0, n_pairs, device=h.device, dtype=torch.int32)])
             o = p2.apply(s1, None, p2.kv(s1, xyz_v), n_pts, kv_index=partner)
             out.append(self._head(o.device).run(o))
         if not out:

@@ -1,3 +1,13 @@
+#!/bin/bash
+cd /root/repo
 mkdir -p gpurun_out/r3t
-python -m pytest tests -x -q -m gpu -k "train or model or distributed or abi or fuzz" > gpurun_out/r3t/test.log 2>&1; echo "tests rc $?"; tail -4 gpurun_out/r3t/test.log
-python tools/train_detail.py > gpurun_out/r3t/train_detail.log 2>&1; head -30 gpurun_out/r3t/train_detail.log | cut -c1-110
+python -m pytest tests/test_gpu_model.py tests/test_gpu_gallery.py tests/test_gpu_ssg.py -x -q -m gpu 2>&1 | tail -3
+python bench.py > gpurun_out/r3t/bench_default.json 2> gpurun_out/r3t/bench_default.err; echo "bench rc $?"
+python - <<PY
+import json
+d=json.loads(open("gpurun_out/r3t/bench_default.json").read().strip().splitlines()[-1])
+print("HEAD", d["dtype"], round(d["value"]), round(d["ms_per_step"],2))
+for a in d.get("also", []):
+    if "error" in a: print(a["name"], "ERROR", a["error"]); continue
+    print(a["name"], a.get("dtype"), round(a["value"]), round(a["ms_per_step"],2))
+PY
