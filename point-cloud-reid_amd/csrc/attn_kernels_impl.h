@@ -275,6 +275,198 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))
   attn_kv_body<TB, NR, WSEL, NTW>(a);
 }
 
+// ---- wave-autonomous form for d = c2 = 64 (the shape of six of pt1024's eight kv launches, of every gallery / SSG kv
+// launch): a WAVE owns a 32-token block end to end, no workgroup barrier inside a cloud's token loop.
+//   * lane (t = lane % 32, h = lane / 32) loads / computes the channels k = 2 s + h of token t: feature channels
+//     (s < 32, coalesced 128-byte rows of the channel-major input) and the position-MLP hidden channels (s >= 32);
+//     register s IS the A operand of k-step s of the TRANSPOSED projection  Y^T[token][cout] = [x ; h]^T W^T;
+//   * the B operand W^T comes from an LDS copy of the packed weight image, one ds_read_b128 per (cout block, four k-steps);
+//   * the accumulators of the transposed projection hold, in lane (cout c, h), the tokens 8 g + 4 h + q of output channel c
+//     -- which is exactly an MFMA operand of KV[dd][v] += sum_t K[dd][t] V[v][t] with the contraction index (step r,
+//     half h) <-> token 8 (r / 4) + 4 h + r % 4, the same assignment for the K and the V operand: after elu + 1 / the
+//     1 / Sk scale, accumulator register r of a K block and of a V block go straight into the 64 KV MFMAs.  No LDS
+//     round trip, no transposition, no barrier between the 256 projection MFMAs and the 64 KV MFMAs of a block;
+//   * eight waves (two per SIMD: one's loads / hidden layer / epilogue under the other's MFMAs) share one 64 KB weight
+//     image; a workgroup is persistent over clouds and takes CPG = 8 / min(8, Sk / 32) clouds at a time, so short key
+//     sets (gallery: 128 tokens) still occupy every wave; the waves of a cloud add their KV in wave order (fixed).
+// Same per-cloud result whatever the batch (shape-only dispatch); rounding differs from the tile kernel's in the
+// last bits (different summation order, 1 / Sk as a multiplication).
+constexpr int kKvsWaves = 8;
+// DIAG: the heads are at most 32 channels wide (nhead >= 2), so KV[dd][v] is only needed where dd and v lie in the same
+// 32-block: the two off-diagonal 32 x 32 tiles are neither accumulated (32 of a block's 320 MFMAs, 32 registers) nor
+// reduced.  The merge weights sit in LDS (the fold reads d * dh of them per output row; from global that was a chain
+// of L2 latencies per cloud).
+template <bool DIAG>
+__global__ __launch_bounds__(64 * kKvsWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void attn_kv_stream64_kernel(AttnArgs a) {
+  constexpr int D = 64, LD = D + 1, KVS = D * LD + D;   // per-cloud reduction area: KVl [64][65] + key sums [64]
+  constexpr int NKV = DIAG ? 2 : 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const pcr_attn_params &p = a.p;
+  f32x4 *s_w = reinterpret_cast<f32x4 *>(smem);                   // [16 kb][128 couts][2 halves]: 64 KB
+  f32x4 *s_p0 = reinterpret_cast<f32x4 *>(smem + 16384);          // [64] {w0x, w0y, w0z, b0}
+  float *s_bkv = smem + 16384 + 256;                              // [128]
+  float *s_wm = s_bkv + 128;                                      // [64][65] merge weights
+  float *s_red = s_wm + D * LD;                                   // [CPG][KVS]
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(p.wkv);
+    for (int e = tid; e < 4096; e += 64 * kKvsWaves) s_w[e] = src[e];
+    for (int e = tid; e < D * D; e += 64 * kKvsWaves) s_wm[(e >> 6) * LD + (e & 63)] = p.wmerge[e];
+    if (tid < D) s_p0[tid] = f32x4{p.pos0_w[3 * tid], p.pos0_w[3 * tid + 1], p.pos0_w[3 * tid + 2], p.pos0_b[tid]};
+    if (tid < 2 * D) s_bkv[tid] = p.bkv[tid];
+  }
+  __syncthreads();
+  const int nblk = p.Sk >> 5;
+  const int wpc = nblk < kKvsWaves ? nblk : kKvsWaves;            // waves per cloud (1, 2, 4 or 8: Sk / 32 clamps)
+  int wpc2 = 1;
+  while (wpc2 * 2 <= wpc) wpc2 *= 2;                              // a power of two ...
+  if (wpc2 < 2) wpc2 = 2;                                         // ... and at most four clouds per round (LDS)
+  const int cpg = kKvsWaves / wpc2;                               // clouds per workgroup round
+  const int cslot = wave / wpc2, wsub = wave - cslot * wpc2;      // this wave's cloud slot and rank inside it
+  const float inv_sk = 1.0f / (float)p.Sk;
+  float bias[4];
+#pragma unroll
+  for (int cb = 0; cb < 4; cb++) bias[cb] = s_bkv[cb * 32 + j];
+  const int dh = D / p.nhead;
+  for (long c0 = (long)blockIdx.x * cpg; c0 < p.B; c0 += (long)gridDim.x * cpg) {
+    const long b = c0 + cslot;
+    const bool live = b < p.B;
+    f32x16 kv[NKV];
+#pragma unroll
+    for (int i = 0; i < NKV; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) kv[i][r] = 0.f;
+    float ks0 = 0.f, ks1 = 0.f;
+    if (live) {
+      const float *feat = p.feat_k + (size_t)b * D * p.Sk;
+      const float *xyz = p.xyz_k + (size_t)b * p.Sk * 3;
+      const __amdgpu_buffer_rsrc_t rfeat =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(feat), 0, D * p.Sk * 4, 0x00020000);
+      for (int blk = wsub; blk < nblk; blk += wpc2) {
+        asm volatile("" ::: "memory");   // (the weight reads below stay inside the block loop: hoisted, they are 256 registers)
+        const int t = blk * 32 + j;
+        const float px = xyz[3 * t], py = xyz[3 * t + 1], pz = xyz[3 * t + 2];
+        float xr[64];
+        {
+          // buffer loads: ONE address register (lane part) + a scalar offset per channel pair
+          const int vo = (h * p.Sk + t) * 4;
+#pragma unroll
+          for (int s2 = 0; s2 < 32; s2++)
+            xr[s2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rfeat, vo, s2 * 2 * p.Sk * 4, 0));
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 32; s2++) {
+          const f32x4 w = s_p0[2 * s2 + h];
+          const float v = w[0] * px + w[1] * py + w[2] * pz + w[3];
+          xr[32 + s2] = fmaxf(v, 0.f);
+        }
+        // (all 32 feature loads are in flight above and land HERE: left alone, the register allocator sinks each load to
+        // just before its MFMA and every k-step waits out a full memory latency)
+#pragma unroll
+        for (int s2 = 0; s2 < 32; s2++) asm volatile("" : "+v"(xr[s2]));
+        f32x16 acc[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[cb][r] = 0.f;   // (the bias joins in the epilogue: seeded, 64 registers of copies were live through the load phase)
+#pragma unroll
+        for (int kb = 0; kb < 16; kb++) {
+          f32x4 w[4];
+#pragma unroll
+          for (int cb = 0; cb < 4; cb++) w[cb] = s_w[((kb * 128 + cb * 32 + j) << 1) + h];
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int cb = 0; cb < 4; cb++)
+              acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[4 * kb + i], w[cb][i], acc[cb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          acc[0][r] = elu1(acc[0][r] + bias[0]);
+          acc[1][r] = elu1(acc[1][r] + bias[1]);
+          acc[2][r] = (acc[2][r] + bias[2]) * inv_sk;
+          acc[3][r] = (acc[3][r] + bias[3]) * inv_sk;
+          ks0 += acc[0][r];
+          ks1 += acc[1][r];
+        }
+#pragma unroll
+        for (int i = 0; i < NKV; i++) {
+          const int ib = DIAG ? i : (i >> 1), jb = DIAG ? i : (i & 1);
+#pragma unroll
+          for (int r = 0; r < 16; r++)
+            kv[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[ib][r], acc[2 + jb][r], kv[i], 0, 0, 0);
+        }
+      }
+    }
+    // the waves of a cloud add their KV / key sums into the cloud's LDS area in wave order
+    ks0 += __shfl_xor(ks0, 32, 64);
+    ks1 += __shfl_xor(ks1, 32, 64);
+    float *KVl = s_red + cslot * KVS, *s_kt = KVl + D * LD;
+    for (int round = 0; round < wpc2; round++) {
+      if (wsub == round) {
+#pragma unroll
+        for (int i = 0; i < NKV; i++) {
+          const int ib = DIAG ? i : (i >> 1), jb = DIAG ? i : (i & 1);
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int dd = ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, v = jb * 32 + j;
+            float *dst = KVl + dd * LD + v;
+            *dst = round == 0 ? kv[i][r] : *dst + kv[i][r];
+          }
+        }
+        if (h == 0) {
+          s_kt[j] = round == 0 ? ks0 : s_kt[j] + ks0;
+          s_kt[32 + j] = round == 0 ? ks1 : s_kt[32 + j] + ks1;
+        }
+      }
+      __syncthreads();
+    }
+    // merge fold M[o][dd] = sum_{v in head(dd)} Wm[o][v] KV[dd][v] on the matrix core: four 32 x 32 tiles (o block, dd
+    // block) over the cloud's waves, operands straight from LDS (A = Wm rows, B = KV rows with the head mask applied on
+    // the read; DIAG: only the dd block's own 32 columns exist), then the packed image of M and the key sums
+    if (live) {
+      float *kvo = p.kv + (size_t)b * ((size_t)D * D + D);
+      for (int ti = wsub; ti < 4; ti += wpc2) {
+        const int ob = ti >> 1, db = ti & 1;
+        const float *ap = s_wm + (ob * 32 + j) * LD + h;
+        const float *bp = KVl + (db * 32 + j) * LD + h;
+        const int hd = (db * 32 + j) / dh;
+        f32x16 m;
+#pragma unroll
+        for (int r = 0; r < 16; r++) m[r] = 0.f;
+        const int s_lo = DIAG ? db * 16 : 0, s_hi = DIAG ? db * 16 + 16 : 32;
+#pragma unroll 4
+        for (int s2 = s_lo; s2 < s_hi; s2++) {
+          const float bv = bp[2 * s2];
+          m = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s2], (2 * s2 + h) / dh == hd ? bv : 0.f, m, 0, 0, 0);
+        }
+        const int dd = db * 32 + j;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int o = ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if constexpr (kAPrec == 0) {
+            const int kb = dd >> 3, rem = dd & 7;
+            kvo[(((size_t)kb * D + o) * 2 + (rem & 1)) * 4 + (rem >> 1)] = m[r];
+          } else {
+            const int s16 = dd >> 4, kk = dd & 15;
+            const int hh = (kk >> 2) & 1, jj = (kk & 3) + ((kk >> 3) << 2);
+            const size_t unit = (((size_t)s16 * (D >> 5) + (o >> 5)) * 2) * 64 + hh * 32 + (o & 31);
+            const __bf16 hi = (__bf16)m[r];
+            const __bf16 lo = (__bf16)(m[r] - (float)hi);
+            __bf16 *img = reinterpret_cast<__bf16 *>(kvo);
+            img[unit * 8 + jj] = hi;
+            img[(unit + 64) * 8 + jj] = lo;
+          }
+        }
+      }
+      for (int e = wsub * 64 + lane; e < D; e += 64 * wpc2) kvo[(size_t)D * D + e] = s_kt[e];
+    }
+    __syncthreads();   // the next round overwrites the reduction areas
+  }
+}
+
 // second launch of the token-split form: one workgroup per cloud adds the splits' partials in order (fixed: the result
 // does not depend on the schedule), applies the head mask and folds the merge projection
 __global__ __launch_bounds__(kThreads) void attn_kv_fold_kernel(AttnArgs a) {
@@ -556,6 +748,29 @@ static int attn_kv_narrow(const pcr_attn_params *pp, pcr_stream_t stream) {
   a.p.kv_splits = ns;
   dim3 g(pp->B, ns), blk(kThreads);
   hipStream_t st = pcr_s(stream);
+  if (ns == 1 && d == 64 && pp->c2 == 64 && (pp->Sk & 31) == 0 && pp->nhead >= 1 && 64 % pp->nhead == 0) {
+    // wave-autonomous form (shape-only choice; an explicit token split keeps the tile kernel)
+    static bool oks = allow_big_lds(attn_kv_stream64_kernel<true>) && allow_big_lds(attn_kv_stream64_kernel<false>);
+    (void)oks;
+    const int nblk = pp->Sk >> 5;
+    int wpc2 = 1;
+    while (wpc2 * 2 <= (nblk < kKvsWaves ? nblk : kKvsWaves)) wpc2 *= 2;
+    if (wpc2 < 2) wpc2 = 2;                                   // (at most four clouds per round: LDS)
+    const int cpg = kKvsWaves / wpc2;
+    const size_t lds_s = (size_t)(16384 + 256 + 128 + 64 * 65 + cpg * (64 * 65 + 64)) * sizeof(float);
+    const long rounds = ((long)pp->B + cpg - 1) / cpg;
+    static const int ncu = [] {
+      hipDeviceProp_t pr;
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256;
+      return pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    }();
+    const int gs = (int)(rounds < ncu ? rounds : ncu);        // persistent: one workgroup per CU
+    if (pp->nhead >= 2) hipLaunchKernelGGL(attn_kv_stream64_kernel<true>, dim3(gs), dim3(64 * kKvsWaves), lds_s, st, a);
+    else hipLaunchKernelGGL(attn_kv_stream64_kernel<false>, dim3(gs), dim3(64 * kKvsWaves), lds_s, st, a);
+    PCR_CHECK_LAUNCH();
+    return PCR_OK;
+  }
   if (d == 32) hipLaunchKernelGGL((attn_kv_kernel<2, 1, 2, 1>), g, blk, lds, st, a);        // 2d = 64: two cout blocks
   else if (d == 64) hipLaunchKernelGGL((attn_kv_kernel_o3<2, 1, 1, 1>), g, blk, lds, st, a);   // four, one per wave
   else if (d == 128) hipLaunchKernelGGL((attn_kv_kernel_o3<1, 2, 1, 4>), g, blk, lds, st, a);  // eight, two rounds
@@ -643,6 +858,7 @@ static bool attn_bf(const pcr_attn_params &p, pcr_attn_params &q) {
 PCR_EXPORT int pcr_attn_kv_splits(int B, int Sk, int d) {
   (void)B;
   if (Sk < 1 || d > 64) return 1;
+  if (d == 64 && (Sk & 31) == 0) return 1;   // the wave-autonomous kernel's shape (attn_kv_stream64_kernel): whole clouds
   const int ntile = (Sk + 63) / 64;
   return ntile >= 16 ? 4 : (ntile >= 8 ? 2 : 1);
 }

@@ -61,8 +61,10 @@ def test_kv_token_split_equals_single_launch(kind, d, B, Lq, Sk, prec):
 def test_split_suggestion_is_sane():
     from pcr_amd import _lib as L
     lib = L.load()
-    assert lib.pcr_attn_kv_splits(1024, 1024, 64) == lib.pcr_attn_kv_splits(8, 1024, 64) == 4     # shape only, never B
-    assert lib.pcr_attn_kv_splits(8, 512, 64) == 2
+    assert lib.pcr_attn_kv_splits(1024, 1000, 64) == lib.pcr_attn_kv_splits(8, 1000, 64) == 4     # shape only, never B
+    assert lib.pcr_attn_kv_splits(8, 1024, 32) == 4
+    assert lib.pcr_attn_kv_splits(8, 500, 64) == 2
+    assert lib.pcr_attn_kv_splits(8, 1024, 64) == 1                 # whole 32-token blocks at d = 64: the streaming kernel
     assert lib.pcr_attn_kv_splits(8, 64, 64) == 1                   # one tile per cloud: nothing to split
     assert lib.pcr_attn_kv_splits(8, 1024, 256) == 1                # the wide kernel splits by bands already
     assert lib.pcr_attn_kv_splits(4, 4096, 128) == 1
