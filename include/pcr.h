@@ -275,6 +275,9 @@ typedef struct pcr_attn_params {
    * then be NULL): results do not depend on the batch size. */
   int kv_splits;
   float *kv_part;
+  /* precision != PCR_PREC_F32, d = c2 = 64, Sk % 32 == 0 (the wave-autonomous kv kernel): pcr_pack_weight_bf16x2_f32
+   * image of the fused K / V projection wkv -- the projection then runs as split bf16 too.  NULL: f32 projection. */
+  const float *wkv_bf;
 } pcr_attn_params;
 long pcr_attn_kv_floats(int d);
 int pcr_attn_kv_splits(int B, int Sk, int d);

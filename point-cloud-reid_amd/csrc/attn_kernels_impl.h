@@ -296,7 +296,12 @@ constexpr int kKvsWaves = 8;
 // 32-block: the two off-diagonal 32 x 32 tiles are neither accumulated (32 of a block's 320 MFMAs, 32 registers) nor
 // reduced.  The merge weights sit in LDS (the fold reads d * dh of them per output row; from global that was a chain
 // of L2 latencies per cloud).
-template <bool DIAG>
+// BF: the projection as split bf16 (x = hi + lo, W = hi + lo from the pcr_pack_weight_bf16x2_f32 image wkv_bf; the three
+// products W_hi x_hi + W_hi x_lo + W_lo x_hi on v_mfma_f32_32x32x16_bf16, f32 accumulate: 96 MFMAs of 32 cycles instead
+// of 256 of 64 per block).  Lane (t, h) then holds the channels 16 s + bf_kpos(h, .) of a 16-channel step -- the K order
+// of the weight image -- so eight loaded / computed values convert into one A operand (bf_split8); K / V, the KV
+// accumulation and the merge fold stay f32.
+template <bool DIAG, bool BF>
 __global__ __launch_bounds__(64 * kKvsWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void attn_kv_stream64_kernel(AttnArgs a) {
   constexpr int D = 64, LD = D + 1, KVS = D * LD + D;   // per-cloud reduction area: KVl [64][65] + key sums [64]
@@ -311,7 +316,7 @@ void attn_kv_stream64_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   {
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(p.wkv);
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(BF ? p.wkv_bf : p.wkv);   // (both images are 4096 16-byte units)
     for (int e = tid; e < 4096; e += 64 * kKvsWaves) s_w[e] = src[e];
     for (int e = tid; e < D * D; e += 64 * kKvsWaves) s_wm[(e >> 6) * LD + (e & 63)] = p.wmerge[e];
     if (tid < D) s_p0[tid] = f32x4{p.pos0_w[3 * tid], p.pos0_w[3 * tid + 1], p.pos0_w[3 * tid + 2], p.pos0_b[tid]};
@@ -348,39 +353,92 @@ void attn_kv_stream64_kernel(AttnArgs a) {
         asm volatile("" ::: "memory");   // (the weight reads below stay inside the block loop: hoisted, they are 256 registers)
         const int t = blk * 32 + j;
         const float px = xyz[3 * t], py = xyz[3 * t + 1], pz = xyz[3 * t + 2];
-        float xr[64];
-        {
-          // buffer loads: ONE address register (lane part) + a scalar offset per channel pair
-          const int vo = (h * p.Sk + t) * 4;
-#pragma unroll
-          for (int s2 = 0; s2 < 32; s2++)
-            xr[s2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rfeat, vo, s2 * 2 * p.Sk * 4, 0));
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 32; s2++) {
-          const f32x4 w = s_p0[2 * s2 + h];
-          const float v = w[0] * px + w[1] * py + w[2] * pz + w[3];
-          xr[32 + s2] = fmaxf(v, 0.f);
-        }
-        // (all 32 feature loads are in flight above and land HERE: left alone, the register allocator sinks each load to
-        // just before its MFMA and every k-step waits out a full memory latency)
-#pragma unroll
-        for (int s2 = 0; s2 < 32; s2++) asm volatile("" : "+v"(xr[s2]));
         f32x16 acc[4];
+        if constexpr (!BF) {
+          float xr[64];
+          {
+            // buffer loads: ONE address register (lane part) + a scalar offset per channel pair
+            const int vo = (h * p.Sk + t) * 4;
 #pragma unroll
-        for (int cb = 0; cb < 4; cb++)
+            for (int s2 = 0; s2 < 32; s2++)
+              xr[s2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rfeat, vo, s2 * 2 * p.Sk * 4, 0));
+          }
 #pragma unroll
-          for (int r = 0; r < 16; r++) acc[cb][r] = 0.f;   // (the bias joins in the epilogue: seeded, 64 registers of copies were live through the load phase)
+          for (int s2 = 0; s2 < 32; s2++) {
+            const f32x4 w = s_p0[2 * s2 + h];
+            const float v = w[0] * px + w[1] * py + w[2] * pz + w[3];
+            xr[32 + s2] = fmaxf(v, 0.f);
+          }
+          // (all 32 feature loads are in flight above and land HERE: left alone, the register allocator sinks each load
+          // to just before its MFMA and every k-step waits out a full memory latency)
 #pragma unroll
-        for (int kb = 0; kb < 16; kb++) {
-          f32x4 w[4];
+          for (int s2 = 0; s2 < 32; s2++) asm volatile("" : "+v"(xr[s2]));
 #pragma unroll
-          for (int cb = 0; cb < 4; cb++) w[cb] = s_w[((kb * 128 + cb * 32 + j) << 1) + h];
+          for (int cb = 0; cb < 4; cb++)
 #pragma unroll
-          for (int i = 0; i < 4; i++)
+            for (int r = 0; r < 16; r++) acc[cb][r] = 0.f;   // (the bias joins in the epilogue: seeded, 64 registers of copies were live through the load phase)
 #pragma unroll
-            for (int cb = 0; cb < 4; cb++)
-              acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[4 * kb + i], w[cb][i], acc[cb], 0, 0, 0);
+          for (int kb = 0; kb < 16; kb++) {
+            f32x4 w[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; cb++) w[cb] = s_w[((kb * 128 + cb * 32 + j) << 1) + h];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+              for (int cb = 0; cb < 4; cb++)
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[4 * kb + i], w[cb][i], acc[cb], 0, 0, 0);
+          }
+        } else {
+          float xf[32];
+          {
+            const int vo = (4 * h * p.Sk + t) * 4;
+#pragma unroll
+            for (int e = 0; e < 32; e++) {
+              const int ch = 16 * (e >> 3) + bf_kpos(0, e & 7);   // + 4 h: in the lane offset
+              xf[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rfeat, vo, ch * p.Sk * 4, 0));
+            }
+          }
+          bf16x8 ah[8], al[8];
+#pragma unroll
+          for (int s2 = 0; s2 < 4; s2++) {   // hidden channels 16 s2 + bf_kpos(h, .): steps 4 .. 7
+            float hv[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+              const f32x4 w = s_p0[16 * s2 + bf_kpos(0, e) + 4 * h];
+              const float v = w[0] * px + w[1] * py + w[2] * pz + w[3];
+              hv[e] = fmaxf(v, 0.f);
+            }
+            bf_split8(hv, ah[4 + s2], al[4 + s2], true);
+          }
+#pragma unroll
+          for (int e = 0; e < 32; e++) asm volatile("" : "+v"(xf[e]));   // (the loads land here, see the f32 form)
+#pragma unroll
+          for (int s2 = 0; s2 < 4; s2++) {
+            float xv[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) xv[e] = xf[8 * s2 + e];
+            bf_split8(xv, ah[s2], al[s2], true);
+          }
+#pragma unroll
+          for (int cb = 0; cb < 4; cb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[cb][r] = 0.f;
+          const bf16x8 *wb = reinterpret_cast<const bf16x8 *>(s_w) + lane;
+#pragma unroll
+          for (int s2 = 0; s2 < 8; s2++) {
+            bf16x8 wh[4], wl[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; cb++) {
+              wh[cb] = wb[((s2 * 4 + cb) * 2) * 64];
+              wl[cb] = wb[((s2 * 4 + cb) * 2 + 1) * 64];
+            }
+#pragma unroll
+            for (int cb = 0; cb < 4; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s2], wh[cb], acc[cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < 4; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s2], wh[cb], acc[cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < 4; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s2], wl[cb], acc[cb], 0, 0, 0);
+          }
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -750,7 +808,10 @@ static int attn_kv_narrow(const pcr_attn_params *pp, pcr_stream_t stream) {
   hipStream_t st = pcr_s(stream);
   if (ns == 1 && d == 64 && pp->c2 == 64 && (pp->Sk & 31) == 0 && pp->nhead >= 1 && 64 % pp->nhead == 0) {
     // wave-autonomous form (shape-only choice; an explicit token split keeps the tile kernel)
-    static bool oks = allow_big_lds(attn_kv_stream64_kernel<true>) && allow_big_lds(attn_kv_stream64_kernel<false>);
+    constexpr bool kBfUnit = kAPrec != 0;
+    const bool bf = kBfUnit && pp->wkv_bf != nullptr;
+    static bool oks = allow_big_lds(attn_kv_stream64_kernel<true, false>) && allow_big_lds(attn_kv_stream64_kernel<false, false>) &&
+                      allow_big_lds(attn_kv_stream64_kernel<true, kBfUnit>) && allow_big_lds(attn_kv_stream64_kernel<false, kBfUnit>);
     (void)oks;
     const int nblk = pp->Sk >> 5;
     int wpc2 = 1;
@@ -766,8 +827,14 @@ static int attn_kv_narrow(const pcr_attn_params *pp, pcr_stream_t stream) {
       return pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
     }();
     const int gs = (int)(rounds < ncu ? rounds : ncu);        // persistent: one workgroup per CU
-    if (pp->nhead >= 2) hipLaunchKernelGGL(attn_kv_stream64_kernel<true>, dim3(gs), dim3(64 * kKvsWaves), lds_s, st, a);
-    else hipLaunchKernelGGL(attn_kv_stream64_kernel<false>, dim3(gs), dim3(64 * kKvsWaves), lds_s, st, a);
+    const dim3 gg(gs), bb(64 * kKvsWaves);
+    if (bf) {
+      if (pp->nhead >= 2) hipLaunchKernelGGL((attn_kv_stream64_kernel<true, kBfUnit>), gg, bb, lds_s, st, a);
+      else hipLaunchKernelGGL((attn_kv_stream64_kernel<false, kBfUnit>), gg, bb, lds_s, st, a);
+    } else {
+      if (pp->nhead >= 2) hipLaunchKernelGGL((attn_kv_stream64_kernel<true, false>), gg, bb, lds_s, st, a);
+      else hipLaunchKernelGGL((attn_kv_stream64_kernel<false, false>), gg, bb, lds_s, st, a);
+    }
     PCR_CHECK_LAUNCH();
     return PCR_OK;
   }

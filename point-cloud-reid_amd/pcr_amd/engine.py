@@ -110,7 +110,7 @@ class AttnParams(ctypes.Structure):
                 ("kv", c_float_p), ("out", c_float_p),
                 ("precision", ctypes.c_int),
                 ("wq_bf", c_float_p), ("wmlp0_bf", c_float_p), ("wmlp2_bf", c_float_p), ("wfinal_bf", c_float_p),
-                ("kv_splits", ctypes.c_int), ("kv_part", c_float_p)]
+                ("kv_splits", ctypes.c_int), ("kv_part", c_float_p), ("wkv_bf", c_float_p)]
 
 
 class HeadParams(ctypes.Structure):
@@ -324,6 +324,8 @@ class AttnPlan:
             ln2_g=_dev32(m.norm2.weight, device), ln2_b=_dev32(m.norm2.bias, device))
         if d <= 128:
             # the same matrices as bf16 hi / lo images: the dense phases of both kernels in "bf16x3" / "bf16" mode
+            if d == 64 and self.c2 == 64:       # the wave-autonomous kv kernel's shape: its projection in split bf16 too
+                self.t["wkv_bf"] = pack_weight_bf(wkv.float(), device)
             self.t.update(wq_bf=pack_weight_bf(wq.float(), device),
                           wmlp0_bf=pack_weight_bf(m.mlp[0].weight, device), wmlp2_bf=pack_weight_bf(m.mlp[2].weight, device))
         if d > 128:

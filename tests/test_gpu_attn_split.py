@@ -55,7 +55,12 @@ def test_kv_token_split_equals_single_launch(kind, d, B, Lq, Sk, prec):
     tol = 1e-4
     for ns, o in outs.items():
         assert float((o - want).abs().max()) < tol, (ns, float((o - want).abs().max()))
-        assert float((o - outs[1]).abs().max()) < 2e-5, (ns, float((o - outs[1]).abs().max()))
+        # f32: the forms differ by summation order only.  bf16x3 at d = c2 = 64 with whole 32-token blocks: the
+        # single-launch form is the wave-autonomous kernel with a split-bf16 projection, the split form keeps the
+        # tile kernel's f32 projection -- two arithmetics of the same product, both within the oracle tolerance
+        same_arith = prec == "f32" or not (d == 64 and args[-2].shape[1] == 64 and Sk % 32 == 0)
+        lim = 2e-5 if same_arith else 1e-4
+        assert float((o - outs[1]).abs().max()) < lim, (ns, float((o - outs[1]).abs().max()))
 
 
 def test_split_suggestion_is_sane():
