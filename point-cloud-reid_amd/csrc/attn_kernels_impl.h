@@ -768,6 +768,324 @@ __global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
   }
 }
 
+#if PCR_ATTN_PREC != 0
+// ---- wave-autonomous apply kernel, d = c1 = cout = 64, split bf16, no trailing conv, whole 32-token blocks ----------
+// (gallery / SSG matching: every apply launch; pt1024: the three self / cross attention launches of SA2 and the matching
+// stages.)  A wave owns a 32-token block from the feature load to the output store -- NO workgroup barrier after the
+// weights are staged.  Every dense phase is in the normal orientation D[cout][token] with the activations as the B
+// operand held in registers, lane (t, h) = token t, k-group h:
+//   * the bf16 weight images order the 16 channels of a step as 16 s + bf_kpos(h, j) -- the order in which a 32 x 32
+//     accumulator tile hands its rows to a lane -- so registers [8 G, 8 G + 8) of cout block cb of one phase's
+//     accumulators convert (bf_split8) into the B operand of step s = 2 cb + G of the NEXT phase: Q -> message -> FFN0 ->
+//     FFN1 chain through registers, no LDS tile, no transposition;
+//   * the input is loaded in the same order, so element i of the lane's 32 feature values is also element i of the
+//     final accumulators (the residual add) and of the output store;
+//   * LayerNorm over the 64 channels of a token = the lane's 32 registers + its partner lane (lane ^ 32): two
+//     cross-lane adds per moment instead of two barrier-separated passes over an LDS tile; the per-head normaliser of
+//     linear attention likewise;
+//   * the per-cloud matrix M (bf16 image written by the kv kernel) is the A operand of the message phase, read straight
+//     from global memory / L2 by each wave; the three weight images (128 KB) live in LDS, staged once by a persistent
+//     workgroup of eight waves (two per SIMD).
+constexpr int kApsWaves = 8;
+template <bool QPOS>
+__global__ __launch_bounds__(64 * kApsWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void attn_apply_stream64_kernel(AttnArgs a) {
+  constexpr int D = 64, SQ = QPOS ? 8 : 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const pcr_attn_params &p = a.p;
+  bf16x8 *s_wq = reinterpret_cast<bf16x8 *>(smem);   // [SQ][2 cb][hi, lo][64]
+  bf16x8 *s_w0 = s_wq + SQ * 256;                    // [8][4][2][64]
+  bf16x8 *s_w2 = s_w0 + 4096;                        // [8][2][2][64]
+  float *s_c = reinterpret_cast<float *>(s_w2 + 2048);   // bq | ln1 g | ln1 b | ln2 g | ln2 b : 5 x 64
+  f32x4 *s_p0 = reinterpret_cast<f32x4 *>(s_c + 320);    // [64] {w0x, w0y, w0z, b0}
+  float *s_ks = reinterpret_cast<float *>(s_p0 + 64);    // [waves][64] key sums of the wave's current cloud
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {
+    const f32x4 *wq = reinterpret_cast<const f32x4 *>(p.wq), *w0 = reinterpret_cast<const f32x4 *>(p.wmlp0),
+                *w2 = reinterpret_cast<const f32x4 *>(p.wmlp2);
+    f32x4 *dq = reinterpret_cast<f32x4 *>(s_wq), *d0 = reinterpret_cast<f32x4 *>(s_w0), *d2 = reinterpret_cast<f32x4 *>(s_w2);
+    for (int e = tid; e < SQ * 256; e += 64 * kApsWaves) dq[e] = wq[e];
+    for (int e = tid; e < 4096; e += 64 * kApsWaves) d0[e] = w0[e];
+    for (int e = tid; e < 2048; e += 64 * kApsWaves) d2[e] = w2[e];
+    if (tid < D) {
+      s_c[tid] = p.bq[tid];
+      s_c[64 + tid] = p.ln1_g[tid];
+      s_c[128 + tid] = p.ln1_b[tid];
+      s_c[192 + tid] = p.ln2_g[tid];
+      s_c[256 + tid] = p.ln2_b[tid];
+      if (QPOS) s_p0[tid] = f32x4{p.pos0_w[3 * tid], p.pos0_w[3 * tid + 1], p.pos0_w[3 * tid + 2], p.pos0_b[tid]};
+    }
+  }
+  __syncthreads();
+  const int nblk = p.Lq >> 5;
+  const long nitem = (long)p.B * nblk;
+  const int dh = D / p.nhead;
+  const float skf = (float)p.Sk;
+  float *ksw = s_ks + wave * 64;
+  // constants of the lane's registers (cout = 32 cb + 8 g + 4 h + q): 16-byte reads at 32 cb + 8 g + 4 h
+  auto cvec = [&](const float *base, int cb, int g) __attribute__((always_inline)) {
+    return *reinterpret_cast<const f32x4 *>(base + 32 * cb + 8 * g + 4 * h);
+  };
+  auto to_ops = [&](const f32x16 &acc, int G, bf16x8 &oh, bf16x8 &ol) __attribute__((always_inline)) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = acc[8 * G + e];
+    bf_split8(v, oh, ol, true);
+  };
+  for (long it = (long)blockIdx.x * kApsWaves + wave; it < nitem; it += (long)gridDim.x * kApsWaves) {
+    asm volatile("" ::: "memory");   // (weight reads stay inside the item loop)
+    const long b = it / nblk;
+    const int blk = (int)(it - b * nblk);
+    const size_t bq_ = p.q_index ? (size_t)p.q_index[b] : (size_t)b;
+    const size_t kb_ = p.kv_index ? (size_t)p.kv_index[b] : (size_t)b;
+    const float *kvp = p.kv + kb_ * ((size_t)D * D + D);
+    const int t = blk * 32 + j;
+    const __amdgpu_buffer_rsrc_t rfeat = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.feat_q + bq_ * D * p.Lq), 0, D * p.Lq * 4, 0x00020000);
+    const int vo = (4 * h * p.Lq + t) * 4;
+    float xf[32];
+#pragma unroll
+    for (int e = 0; e < 32; e++) {
+      const int ch = 16 * (e >> 3) + bf_kpos(0, e & 7);   // + 4 h: in the lane offset
+      xf[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rfeat, vo, ch * p.Lq * 4, 0));
+    }
+    ksw[lane] = kvp[(size_t)D * D + lane];
+    bf16x8 bh[8], bl[8];
+    if constexpr (QPOS) {
+      const float *xyz = p.xyz_q + (bq_ * p.Lq + t) * 3;
+      const float px = xyz[0], py = xyz[1], pz = xyz[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; s2++) {
+        float hv[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const f32x4 w = s_p0[16 * s2 + bf_kpos(0, e) + 4 * h];
+          const float v = w[0] * px + w[1] * py + w[2] * pz + w[3];
+          hv[e] = fmaxf(v, 0.f);
+        }
+        bf_split8(hv, bh[4 + s2], bl[4 + s2], true);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 32; e++) asm volatile("" : "+v"(xf[e]));   // (the loads land here: see attn_kv_stream64_kernel)
+#pragma unroll
+    for (int s2 = 0; s2 < 4; s2++) {
+      float xv[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) xv[e] = xf[8 * s2 + e];
+      bf_split8(xv, bh[s2], bl[s2], true);
+    }
+    // ---- Q = elu(Wq [x ; h] + bq) + 1
+    f32x16 q[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) q[cb][r] = 0.f;
+    {
+      const bf16x8 *wb = s_wq + lane;
+#pragma unroll
+      for (int s2 = 0; s2 < SQ; s2++) {
+        bf16x8 wh[2], wl[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++) {
+          wh[cb] = wb[((s2 * 2 + cb) * 2) * 64];
+          wl[cb] = wb[((s2 * 2 + cb) * 2 + 1) * 64];
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++) q[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bh[s2], q[cb], 0, 0, 0);
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++) q[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bl[s2], q[cb], 0, 0, 0);
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++) q[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], bh[s2], q[cb], 0, 0, 0);
+      }
+    }
+    // the message-phase A operands (the cloud's matrix M): requested now, used after the normaliser
+    bf16x8 mh[4][2], ml[4][2];
+    {
+      const bf16x8 *mb = reinterpret_cast<const bf16x8 *>(kvp) + lane;
+#pragma unroll
+      for (int s2 = 0; s2 < 4; s2++)
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++) {
+          mh[s2][cb] = mb[((s2 * 2 + cb) * 2) * 64];
+          ml[s2][cb] = mb[((s2 * 2 + cb) * 2 + 1) * 64];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the wave's own key-sum strip: written above, read below)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // z[head][token] = Q_head . ksum_head; partial sums per 16-channel group (cb, G), then by head width
+    float z16[2][2];
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const f32x4 bqv = cvec(s_c, cb, g), ksv = cvec(ksw, cb, g);
+        float zz = 0.f;
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) {
+          const float v = elu1(q[cb][4 * g + qq] + bqv[qq]);
+          q[cb][4 * g + qq] = v;
+          zz += v * ksv[qq];
+        }
+        if ((g & 1) == 0) z16[cb][g >> 1] = zz;
+        else z16[cb][g >> 1] += zz;
+      }
+    float zs[2][2];
+    {
+      float za = z16[0][0], zb = z16[0][1], zc = z16[1][0], zd = z16[1][1];
+      if (dh >= 32) {
+        za += zb; zb = za;
+        zc += zd; zd = zc;
+      }
+      if (dh >= 64) {
+        za += zc; zb = za; zc = za; zd = za;
+      }
+      za += __shfl_xor(za, 32, 64);
+      zb += __shfl_xor(zb, 32, 64);
+      zc += __shfl_xor(zc, 32, 64);
+      zd += __shfl_xor(zd, 32, 64);
+      zs[0][0] = (1.0f / (za + 1e-6f)) * skf;
+      zs[0][1] = (1.0f / (zb + 1e-6f)) * skf;
+      zs[1][0] = (1.0f / (zc + 1e-6f)) * skf;
+      zs[1][1] = (1.0f / (zd + 1e-6f)) * skf;
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) q[cb][r] *= zs[cb][r >> 3];
+    // ---- message = M Q'
+    bf16x8 ch_[4], cl_[4];
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+      for (int G = 0; G < 2; G++) to_ops(q[cb], G, ch_[2 * cb + G], cl_[2 * cb + G]);
+    f32x16 m[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) m[cb][r] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 4; s2++) {
+#pragma unroll
+      for (int cb = 0; cb < 2; cb++) m[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mh[s2][cb], ch_[s2], m[cb], 0, 0, 0);
+#pragma unroll
+      for (int cb = 0; cb < 2; cb++) m[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mh[s2][cb], cl_[s2], m[cb], 0, 0, 0);
+#pragma unroll
+      for (int cb = 0; cb < 2; cb++) m[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml[s2][cb], ch_[s2], m[cb], 0, 0, 0);
+    }
+    // ---- LayerNorm over the 64 channels of a token (two passes, eps inside the sqrt: tile_layernorm's arithmetic)
+    auto layernorm = [&](f32x16 (&v)[2], const float *gam, const float *bet) __attribute__((always_inline)) {
+      float sm = 0.f;
+#pragma unroll
+      for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) sm += v[cb][r];
+      sm += __shfl_xor(sm, 32, 64);
+      const float mean = sm / 64.0f;
+      float vr = 0.f;
+#pragma unroll
+      for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const float dlt = v[cb][r] - mean;
+          vr += dlt * dlt;
+        }
+      vr += __shfl_xor(vr, 32, 64);
+      const float inv = 1.0f / sqrtf(vr / 64.0f + 1e-5f);
+#pragma unroll
+      for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const f32x4 gv = cvec(gam, cb, g), bv = cvec(bet, cb, g);
+#pragma unroll
+          for (int qq = 0; qq < 4; qq++) v[cb][4 * g + qq] = (v[cb][4 * g + qq] - mean) * inv * gv[qq] + bv[qq];
+        }
+    };
+    layernorm(m, s_c + 64, s_c + 128);
+    // ---- FFN0: relu(W0 [x ; msg]) (128 couts), operands: x re-converted from its f32 registers, msg from m
+#pragma unroll
+    for (int s2 = 0; s2 < 4; s2++) {
+      float xv[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) xv[e] = xf[8 * s2 + e];
+      bf_split8(xv, bh[s2], bl[s2], true);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+      for (int G = 0; G < 2; G++) to_ops(m[cb], G, bh[4 + 2 * cb + G], bl[4 + 2 * cb + G]);
+    f32x16 f[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; cb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) f[cb][r] = 0.f;
+    {
+      const bf16x8 *wb = s_w0 + lane;
+#pragma unroll
+      for (int s2 = 0; s2 < 8; s2++) {
+        bf16x8 wh[4], wl[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) {
+          wh[cb] = wb[((s2 * 4 + cb) * 2) * 64];
+          wl[cb] = wb[((s2 * 4 + cb) * 2 + 1) * 64];
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) f[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bh[s2], f[cb], 0, 0, 0);
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) f[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bl[s2], f[cb], 0, 0, 0);
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) f[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], bh[s2], f[cb], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; cb++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) f[cb][r] = fmaxf(f[cb][r], 0.f);
+#pragma unroll
+      for (int G = 0; G < 2; G++) to_ops(f[cb], G, bh[2 * cb + G], bl[2 * cb + G]);
+    }
+    // ---- FFN1 (64 couts), LayerNorm, residual, store
+    f32x16 o[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) o[cb][r] = 0.f;
+    {
+      const bf16x8 *wb = s_w2 + lane;
+#pragma unroll
+      for (int s2 = 0; s2 < 8; s2++) {
+        bf16x8 wh[2], wl[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++) {
+          wh[cb] = wb[((s2 * 2 + cb) * 2) * 64];
+          wl[cb] = wb[((s2 * 2 + cb) * 2 + 1) * 64];
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++) o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bh[s2], o[cb], 0, 0, 0);
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++) o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bl[s2], o[cb], 0, 0, 0);
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++) o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], bh[s2], o[cb], 0, 0, 0);
+      }
+    }
+    layernorm(o, s_c + 192, s_c + 256);
+    {
+      const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)b * D * p.Lq, 0, D * p.Lq * 4, 0x00020000);
+#pragma unroll
+      for (int e = 0; e < 32; e++) {
+        const int ch = 16 * (e >> 3) + bf_kpos(0, e & 7);
+        float v = o[e >> 4][e & 15];
+        if (p.residual) v += xf[e];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, vo, ch * p.Lq * 4, 0);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // (the key-sum strip is rewritten by the next item)
+  }
+}
+#endif
+
 }  // namespace
 
 static int attn_check(const pcr_attn_params &p) {
@@ -866,6 +1184,29 @@ static int attn_apply_launch(const pcr_attn_params *pp, pcr_stream_t stream) {
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
   dim3 g((p.Lq + T - 1) / T, p.B), blk(kThreads);
   hipStream_t st = pcr_s(stream);
+#if PCR_ATTN_PREC != 0
+  if (p.d == 64 && p.c1 == 64 && p.cout == 64 && !p.cfinal && (p.Lq & 31) == 0 &&
+      (p.nhead == 1 || p.nhead == 2 || p.nhead == 4)) {
+    // wave-autonomous form (shape-only choice)
+    static bool oks = allow_big_lds(attn_apply_stream64_kernel<true>) && allow_big_lds(attn_apply_stream64_kernel<false>);
+    (void)oks;
+    const int sq = p.q_pos ? 8 : 4;
+    const size_t lds_s = (size_t)(sq * 256 + 4096 + 2048) * 16 + (size_t)(320 + 256 + 64 * kApsWaves) * sizeof(float);
+    const long nitem = (long)p.B * (p.Lq >> 5);
+    const long nwg = (nitem + kApsWaves - 1) / kApsWaves;
+    static const int ncu = [] {
+      hipDeviceProp_t pr;
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256;
+      return pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    }();
+    const dim3 gg((unsigned)(nwg < ncu ? nwg : ncu)), bb(64 * kApsWaves);
+    if (p.q_pos) hipLaunchKernelGGL(attn_apply_stream64_kernel<true>, gg, bb, lds_s, st, a);
+    else hipLaunchKernelGGL(attn_apply_stream64_kernel<false>, gg, bb, lds_s, st, a);
+    PCR_CHECK_LAUNCH();
+    return PCR_OK;
+  }
+#endif
   const bool wide = 2 * p.d > 128 || p.cout > 128 || p.cfinal > 128;   // some layer has > 4 cout blocks
 #define PCR_APPLY(TBv, NRv)                                                          \
   do {                                                                               \

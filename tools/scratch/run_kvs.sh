@@ -5,6 +5,6 @@ timeout 1200 python -m pytest tests/test_gpu_attn_split.py tests/test_gpu_model.
 tail -8 gpurun_out/kvs/test.log
 for w in pt1024 gallery128 ssg1024; do
 timeout 600 python bench.py --workload $w --no-also --no-cpu-baseline --detail > gpurun_out/kvs/$w.log 2>&1
-grep -i "attn_kv" gpurun_out/kvs/$w.log | head -8
+grep -i "attn_" gpurun_out/kvs/$w.log | head -16
 tail -1 gpurun_out/kvs/$w.log | cut -c1-200
 done
