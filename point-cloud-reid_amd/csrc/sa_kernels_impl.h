@@ -428,6 +428,214 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
   }
 }
 
+#if PCR_SA_PREC != 0
+// ---- wave-autonomous K-row kernel: c1 = c2 = c3 = 32 NCB (the Point-Transformer's kNN-grouped SA layers), K % 16 == 0,
+// layer 1 on the matrix core.  A wave owns 32 rows (tokens) of the grouped tensor from the index load to the 16-row
+// group maxima: layer 1 = two f32 MFMAs on accumulators seeded with the centre's shift + Q row, plus the neighbour's
+// table piece gathered in accumulator layout; its relu converts straight into layer 2's B operand (the bf16 weight
+// images order a 16-channel step the way an accumulator tile hands its rows to a lane: tile_dense.h), layer 2's
+// accumulators into layer 3's, and the max over K starts from layer 3's accumulators (16-lane DPP groups) -- no LDS
+// activation tile, no workgroup barrier after the weights are staged.  The arithmetic (seeds, the order of the three
+// MFMAs of a product, signed-integer maxima, ReLU last) is sa_fused_kernel's, so the bits are the same.
+// Work item = lcm(32, K) rows of one cloud (K = 48: three blocks = two centres): the group maxima of an item meet in a
+// wave-private LDS strip, the item's centres leave from there.  Items of a cloud stay on one XCD (its table rows are
+// gathered by every item of the cloud: one L2 should hold them).
+constexpr int kSasWaves = 8;
+template <int NCB, bool LO>
+__global__ __launch_bounds__(64 * kSasWaves) __attribute__((amdgpu_waves_per_eu(2, NCB == 4 ? 2 : 4)))
+void sa_stream_kernel(Sa2Args a, int nblk_item, int ncen_item) {
+  constexpr int C = 32 * NCB, NS = 2 * NCB;          // channels, 16-channel steps
+  constexpr int WUNITS = NS * NCB * 2 * 64;           // 16-byte units of one weight image
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  bf16x8 *s_w2 = reinterpret_cast<bf16x8 *>(smem);
+  bf16x8 *s_w3 = s_w2 + WUNITS;
+  float *s_sh = reinterpret_cast<float *>(s_w3 + WUNITS);   // sh1 | sh2 | sh3 : 3 C
+  f32x4 *s_wa = reinterpret_cast<f32x4 *>(s_sh + 3 * C);    // [NCB][64] layer-1 A operands
+  float *s_gm = reinterpret_cast<float *>(s_wa + NCB * 64); // [waves][6 groups][C] group maxima of the wave's item
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {
+    const f32x4 *w2 = reinterpret_cast<const f32x4 *>(a.wp2), *w3 = reinterpret_cast<const f32x4 *>(a.wp3);
+    f32x4 *d2 = reinterpret_cast<f32x4 *>(s_w2), *d3 = reinterpret_cast<f32x4 *>(s_w3);
+    for (int e = tid; e < WUNITS; e += 64 * kSasWaves) {
+      d2[e] = w2[e];
+      d3[e] = w3[e];
+    }
+    for (int e = tid; e < C; e += 64 * kSasWaves) {
+      s_sh[e] = a.sh1[e];
+      s_sh[C + e] = a.sh2[e];
+      s_sh[2 * C + e] = a.sh3[e];
+    }
+    for (int e = tid; e < NCB * 64; e += 64 * kSasWaves) s_wa[e] = reinterpret_cast<const f32x4 *>(a.wap)[e];
+  }
+  __syncthreads();
+  const int K = a.K, gpc = K >> 4;                      // 16-row groups per centre
+  const int nitem = (a.S + ncen_item - 1) / ncen_item;  // items per cloud
+  float *gm = s_gm + wave * 6 * C;
+  const bool has_q = a.pq && a.qoff >= 0;
+  // XCD-aware item order: workgroup w sits on XCD w % 8; the clouds b % 8 == x belong to XCD x
+  const int xcd = blockIdx.x & 7, wrank = (blockIdx.x >> 3) * kSasWaves + wave, wstride = ((gridDim.x + 7 - xcd) >> 3) * kSasWaves;
+  const long nq = (long)((a.B + 7 - xcd) >> 3) * nitem;          // items of this XCD's clouds
+  auto cvec = [&](const float *base, int cb, int g) __attribute__((always_inline)) {
+    return *reinterpret_cast<const f32x4 *>(base + 32 * cb + 8 * g + 4 * h);
+  };
+  for (long qi = wrank; qi < nq; qi += wstride) {
+    asm volatile("" ::: "memory");
+    const long bq = qi / nitem;
+    const int item = (int)(qi - bq * nitem);
+    const size_t b = (size_t)bq * 8 + xcd;
+    const int c0 = item * ncen_item;
+    const int nc = a.S - c0 < ncen_item ? a.S - c0 : ncen_item;
+    const int rows = nc * K;
+    const float *xyz = a.xyz + b * a.N * 3;
+    const float *pq = a.pq ? a.pq + b * a.N * (size_t)a.pqw : nullptr;
+    for (int blk = 0; blk < nblk_item; blk++) {
+      if (blk * 32 >= rows) break;                      // (a partial last item: whole blocks of padding are skipped)
+      int r = blk * 32 + j;
+      r = r < rows ? r : rows - 1;                      // padding rows repeat the last one (a max does not care)
+      const int cen = r / K;
+      const int s = c0 + cen;
+      const int ci = a.centre_idx ? a.centre_idx[b * a.S + s] : s;
+      const int i = a.idx[(b * a.S + c0) * (size_t)K + r];
+      const float dxv = xyz[i * 3] - xyz[ci * 3], dyv = xyz[i * 3 + 1] - xyz[ci * 3 + 1], dzv = xyz[i * 3 + 2] - xyz[ci * 3 + 2];
+      const float b0 = h ? dyv : dxv, b1 = h ? 0.f : dzv;      // layer 1's B operand: k = h, 2 + h
+      bf16x8 bh[NS], bl[NS];
+      // ---- layer 1, one cout block at a time (the gathers of a block: 8 + 8 sixteen-byte pieces)
+#pragma unroll
+      for (int cb = 0; cb < NCB; cb++) {
+        f32x4 pp[4], qq[4];
+        const float *pr = pq ? pq + (size_t)i * a.pqw + cb * 32 + 4 * h : nullptr;
+        const float *qr = has_q ? pq + (size_t)ci * a.pqw + a.qoff + cb * 32 + 4 * h : nullptr;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          pp[g] = pr ? *reinterpret_cast<const f32x4 *>(pr + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+          qq[g] = qr ? *reinterpret_cast<const f32x4 *>(qr + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const f32x4 s4 = cvec(s_sh, cb, g);
+#pragma unroll
+          for (int q2 = 0; q2 < 4; q2++) acc[4 * g + q2] = has_q ? s4[q2] + qq[g][q2] : s4[q2];
+        }
+        const f32x4 av = s_wa[cb * 64 + j * 2 + h];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], b1, acc, 0, 0, 0);
+#pragma unroll
+        for (int G = 0; G < 2; G++) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const int rr = 8 * G + e;
+            const float t = pq ? acc[rr] + pp[rr >> 2][rr & 3] : acc[rr];
+            v[e] = relu_bits(t);
+          }
+          bf_split8(v, bh[2 * cb + G], bl[2 * cb + G], LO);
+        }
+      }
+      // ---- layers 2 and 3
+      f32x16 y[NCB];
+      auto dense = [&](const bf16x8 *wimg, const float *shift) __attribute__((always_inline)) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            const f32x4 s4 = cvec(shift, cb, g);
+#pragma unroll
+            for (int q2 = 0; q2 < 4; q2++) y[cb][4 * g + q2] = s4[q2];
+          }
+        const bf16x8 *wb = wimg + lane;
+#pragma unroll
+        for (int s2 = 0; s2 < NS; s2++) {
+          bf16x8 wh[NCB], wl[NCB];
+#pragma unroll
+          for (int cb = 0; cb < NCB; cb++) {
+            wh[cb] = wb[((s2 * NCB + cb) * 2) * 64];
+            if constexpr (LO) wl[cb] = wb[((s2 * NCB + cb) * 2 + 1) * 64];
+          }
+          if constexpr (LO) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) y[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bl[s2], y[cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) y[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], bh[s2], y[cb], 0, 0, 0);
+          }
+#pragma unroll
+          for (int cb = 0; cb < NCB; cb++) y[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bh[s2], y[cb], 0, 0, 0);
+        }
+      };
+      dense(s_w2, s_sh + C);
+#pragma unroll
+      for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+        for (int G = 0; G < 2; G++) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; e++) v[e] = relu_bits(y[cb][8 * G + e]);
+          bf_split8(v, bh[2 * cb + G], bl[2 * cb + G], LO);
+        }
+      // ---- layer 3 TRANSPOSED (activations as the A operand, the same weight image as B): lane (cout, h) then holds the
+      // tokens 8 g + 4 h + q of its channel, and the maximum over a 16-row group is a maximum over eight of the lane's
+      // OWN registers plus one exchange with its partner lane -- 20 instructions per cout block where the token-per-lane
+      // form needs a 4-step DPP reduction of every register (128)
+      {
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+          const float sv = s_sh[2 * C + cb * 32 + j];
+#pragma unroll
+          for (int rr = 0; rr < 16; rr++) y[cb][rr] = sv;
+        }
+        const bf16x8 *wb = s_w3 + lane;
+#pragma unroll
+        for (int s2 = 0; s2 < NS; s2++) {
+          bf16x8 wh[NCB], wl[NCB];
+#pragma unroll
+          for (int cb = 0; cb < NCB; cb++) {
+            wh[cb] = wb[((s2 * NCB + cb) * 2) * 64];
+            if constexpr (LO) wl[cb] = wb[((s2 * NCB + cb) * 2 + 1) * 64];
+          }
+          if constexpr (LO) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) y[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[s2], wh[cb], y[cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) y[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[s2], wl[cb], y[cb], 0, 0, 0);
+          }
+#pragma unroll
+          for (int cb = 0; cb < NCB; cb++) y[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[s2], wh[cb], y[cb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+          int m0 = __float_as_int(y[cb][0]), m1 = __float_as_int(y[cb][8]);   // (signed maxima of the bit patterns, ReLU last)
+#pragma unroll
+          for (int rr = 1; rr < 8; rr++) {
+            m0 = imax(m0, __float_as_int(y[cb][rr]));
+            m1 = imax(m1, __float_as_int(y[cb][8 + rr]));
+          }
+          m0 = imax(m0, __shfl_xor(m0, 32, 64));
+          m1 = imax(m1, __shfl_xor(m1, 32, 64));
+          if (h == 0) {
+            gm[(blk * 2) * C + cb * 32 + j] = __int_as_float(imax(m0, 0));
+            gm[(blk * 2 + 1) * C + cb * 32 + j] = __int_as_float(imax(m1, 0));
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // the item's centres: max over their groups, centre-major so that (B,S,c3) rows leave as whole lines
+    for (int e = lane; e < nc * C; e += 64) {
+      const int c = e / C, o = e - c * C;
+      const float *g = gm + (c * gpc) * C + o;
+      float m = g[0];
+      for (int k = 1; k < gpc; k++) m = fmaxf(m, g[k * C]);
+      if (a.out_pm) a.out[(b * a.S + c0 + c) * (size_t)C + o] = m;
+      else a.out[(b * C + o) * (size_t)a.S + c0 + c] = m;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+#endif
+
 // ------------------------------------------------- ragged SA MLP (ball-query duplicates) ----
 // A ball-query row holds only cnt genuine neighbours; entries [cnt, K) repeat the first one
 // (ball_query_cuda.cu:43-47), and a max over K does not care about repeats.  This variant runs the MLP
@@ -1280,6 +1488,48 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
     // (f32 forms are instantiated for equal classes of layers 2 and 3 only; the bf16 units also hold (2, 1))
     a.l1m = (!no_l1m && p.wa_packed && n1 <= 4 && n2 <= 4 && w1 == w2c && (kPrec != 0 || w2c == w3c) && (p.c1 & 3) == 0) ? 1 : 0;
   }
+#if PCR_SA_PREC != 0
+  {
+    // wave-autonomous form (shape-only choice): equal widths of 32 / 64 / 128, K in whole 16-row groups, at most three
+    // 32-row blocks per item (K = 16, 32, 48, 64, 96)
+    static const int no_stream = pcr_tune_int("PCR_SA_NO_STREAM");   // diagnostics
+    const int ncb = p.c1 >> 5;
+    int nblk_item = 0, ncen_item = 0;
+    for (int nb = 1; nb <= 3 && !nblk_item; nb++)
+      if ((32 * nb) % p.K == 0) { nblk_item = nb; ncen_item = 32 * nb / p.K; }
+    if (!no_stream && maxe && p.c1 == p.c2 && p.c2 == p.c3 && (p.c1 == 32 || p.c1 == 64 || p.c1 == 128) && p.wa_packed &&
+        nblk_item && p.B > 0) {
+      const size_t wunits = (size_t)(2 * ncb) * ncb * 2 * 64;
+      const size_t lds_s = wunits * 16 * 2 + (size_t)3 * p.c1 * 4 + (size_t)ncb * 64 * 16 + (size_t)kSasWaves * 6 * p.c1 * 4;
+      static const int ncu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
+          n = 256;
+        return n;
+      }();
+      const long items = (long)p.B * ((p.S + ncen_item - 1) / ncen_item);
+      long wgs = (items + kSasWaves - 1) / kSasWaves;
+      const long resident = (long)ncu * (ncb == 4 ? 1 : 2);   // two workgroups per CU fit for the narrow layers
+      if (wgs > resident) wgs = resident;
+      wgs = (wgs + 7) / 8 * 8;                         // every XCD gets workgroups (the item order is per XCD)
+      const dim3 gg((unsigned)wgs), bb(64 * kSasWaves);
+      constexpr bool kLoS = kPrec == 1;
+#define PCR_SAS(NCBv)                                                                         \
+  do {                                                                                        \
+    static bool ok = allow_big_lds(sa_stream_kernel<NCBv, kLoS>);                             \
+    (void)ok;                                                                                 \
+    hipLaunchKernelGGL((sa_stream_kernel<NCBv, kLoS>), gg, bb, lds_s, st, a, nblk_item, ncen_item); \
+  } while (0)
+      if (ncb == 1) PCR_SAS(1);
+      else if (ncb == 2) PCR_SAS(2);
+      else PCR_SAS(4);
+#undef PCR_SAS
+      if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
+      return PCR_OK;
+    }
+  }
+#endif
   const size_t lds = lds_bytes(best_tb, best_cpw);
   dim3 grid((p.S + best_cpw - 1) / best_cpw, p.B);
   const int w2 = n2 >= 3 ? 1 : (n2 == 2 ? 2 : 4), w3 = n3 >= 3 ? 1 : (n3 == 2 ? 2 : 4);
