@@ -787,17 +787,20 @@ __global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
 //     from global memory / L2 by each wave; the three weight images (128 KB) live in LDS, staged once by a persistent
 //     workgroup of eight waves (two per SIMD).
 constexpr int kApsWaves = 8;
-template <bool QPOS>
+// C1S: 16-channel steps of the query features (c1 = 64 or 32; 32: the FP_SA blocks, no residual); CF: trailing 64 -> 128
+// conv (cov_final), its weight image read from global memory / L2 like M
+template <bool QPOS, int C1S, bool CF>
 __global__ __launch_bounds__(64 * kApsWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void attn_apply_stream64_kernel(AttnArgs a) {
-  constexpr int D = 64, SQ = QPOS ? 8 : 4;
+  static_assert(!QPOS || C1S == 4, "q_pos needs c1 == d");
+  constexpr int D = 64, C1 = 16 * C1S, SQ = C1S + (QPOS ? 4 : 0), S0 = C1S + 4, NX = 8 * C1S;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const pcr_attn_params &p = a.p;
   bf16x8 *s_wq = reinterpret_cast<bf16x8 *>(smem);   // [SQ][2 cb][hi, lo][64]
-  bf16x8 *s_w0 = s_wq + SQ * 256;                    // [8][4][2][64]
-  bf16x8 *s_w2 = s_w0 + 4096;                        // [8][2][2][64]
-  float *s_c = reinterpret_cast<float *>(s_w2 + 2048);   // bq | ln1 g | ln1 b | ln2 g | ln2 b : 5 x 64
-  f32x4 *s_p0 = reinterpret_cast<f32x4 *>(s_c + 320);    // [64] {w0x, w0y, w0z, b0}
+  bf16x8 *s_w0 = s_wq + SQ * 256;                    // [S0][4][2][64]
+  bf16x8 *s_w2 = s_w0 + S0 * 512;                    // [8][2][2][64]
+  float *s_c = reinterpret_cast<float *>(s_w2 + 2048);   // bq | ln1 g | ln1 b | ln2 g | ln2 b : 5 x 64 | bfinal 128
+  f32x4 *s_p0 = reinterpret_cast<f32x4 *>(s_c + 448);    // [64] {w0x, w0y, w0z, b0}
   float *s_ks = reinterpret_cast<float *>(s_p0 + 64);    // [waves][64] key sums of the wave's current cloud
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -806,7 +809,7 @@ void attn_apply_stream64_kernel(AttnArgs a) {
                 *w2 = reinterpret_cast<const f32x4 *>(p.wmlp2);
     f32x4 *dq = reinterpret_cast<f32x4 *>(s_wq), *d0 = reinterpret_cast<f32x4 *>(s_w0), *d2 = reinterpret_cast<f32x4 *>(s_w2);
     for (int e = tid; e < SQ * 256; e += 64 * kApsWaves) dq[e] = wq[e];
-    for (int e = tid; e < 4096; e += 64 * kApsWaves) d0[e] = w0[e];
+    for (int e = tid; e < S0 * 512; e += 64 * kApsWaves) d0[e] = w0[e];
     for (int e = tid; e < 2048; e += 64 * kApsWaves) d2[e] = w2[e];
     if (tid < D) {
       s_c[tid] = p.bq[tid];
@@ -816,6 +819,7 @@ void attn_apply_stream64_kernel(AttnArgs a) {
       s_c[256 + tid] = p.ln2_b[tid];
       if (QPOS) s_p0[tid] = f32x4{p.pos0_w[3 * tid], p.pos0_w[3 * tid + 1], p.pos0_w[3 * tid + 2], p.pos0_b[tid]};
     }
+    if (CF && tid < 128) s_c[320 + tid] = p.bfinal[tid];
   }
   __syncthreads();
   const int nblk = p.Lq >> 5;
@@ -842,11 +846,11 @@ void attn_apply_stream64_kernel(AttnArgs a) {
     const float *kvp = p.kv + kb_ * ((size_t)D * D + D);
     const int t = blk * 32 + j;
     const __amdgpu_buffer_rsrc_t rfeat = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(p.feat_q + bq_ * D * p.Lq), 0, D * p.Lq * 4, 0x00020000);
+        const_cast<float *>(p.feat_q + bq_ * C1 * p.Lq), 0, C1 * p.Lq * 4, 0x00020000);
     const int vo = (4 * h * p.Lq + t) * 4;
-    float xf[32];
+    float xf[NX];
 #pragma unroll
-    for (int e = 0; e < 32; e++) {
+    for (int e = 0; e < NX; e++) {
       const int ch = 16 * (e >> 3) + bf_kpos(0, e & 7);   // + 4 h: in the lane offset
       xf[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rfeat, vo, ch * p.Lq * 4, 0));
     }
@@ -868,9 +872,9 @@ void attn_apply_stream64_kernel(AttnArgs a) {
       }
     }
 #pragma unroll
-    for (int e = 0; e < 32; e++) asm volatile("" : "+v"(xf[e]));   // (the loads land here: see attn_kv_stream64_kernel)
+    for (int e = 0; e < NX; e++) asm volatile("" : "+v"(xf[e]));   // (the loads land here: see attn_kv_stream64_kernel)
 #pragma unroll
-    for (int s2 = 0; s2 < 4; s2++) {
+    for (int s2 = 0; s2 < C1S; s2++) {
       float xv[8];
 #pragma unroll
       for (int e = 0; e < 8; e++) xv[e] = xf[8 * s2 + e];
@@ -1006,7 +1010,7 @@ void attn_apply_stream64_kernel(AttnArgs a) {
     layernorm(m, s_c + 64, s_c + 128);
     // ---- FFN0: relu(W0 [x ; msg]) (128 couts), operands: x re-converted from its f32 registers, msg from m
 #pragma unroll
-    for (int s2 = 0; s2 < 4; s2++) {
+    for (int s2 = 0; s2 < C1S; s2++) {
       float xv[8];
 #pragma unroll
       for (int e = 0; e < 8; e++) xv[e] = xf[8 * s2 + e];
@@ -1015,7 +1019,7 @@ void attn_apply_stream64_kernel(AttnArgs a) {
 #pragma unroll
     for (int cb = 0; cb < 2; cb++)
 #pragma unroll
-      for (int G = 0; G < 2; G++) to_ops(m[cb], G, bh[4 + 2 * cb + G], bl[4 + 2 * cb + G]);
+      for (int G = 0; G < 2; G++) to_ops(m[cb], G, bh[C1S + 2 * cb + G], bl[C1S + 2 * cb + G]);
     f32x16 f[4];
 #pragma unroll
     for (int cb = 0; cb < 4; cb++)
@@ -1024,7 +1028,7 @@ void attn_apply_stream64_kernel(AttnArgs a) {
     {
       const bf16x8 *wb = s_w0 + lane;
 #pragma unroll
-      for (int s2 = 0; s2 < 8; s2++) {
+      for (int s2 = 0; s2 < S0; s2++) {
         bf16x8 wh[4], wl[4];
 #pragma unroll
         for (int cb = 0; cb < 4; cb++) {
@@ -1071,15 +1075,63 @@ void attn_apply_stream64_kernel(AttnArgs a) {
       }
     }
     layernorm(o, s_c + 192, s_c + 256);
-    {
+    if constexpr (C1S == 4) {
+      if (p.residual) {
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) o[cb][r] += xf[16 * cb + r];
+      }
+    }
+    if constexpr (!CF) {
       const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)b * D * p.Lq, 0, D * p.Lq * 4, 0x00020000);
 #pragma unroll
       for (int e = 0; e < 32; e++) {
         const int ch = 16 * (e >> 3) + bf_kpos(0, e & 7);
-        float v = o[e >> 4][e & 15];
-        if (p.residual) v += xf[e];
+        const float v = o[e >> 4][e & 15];   // (a copy: __builtin_bit_cast of a vector ELEMENT reads element 0)
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, vo, ch * p.Lq * 4, 0);
       }
+    } else {
+      // ---- cov_final: 64 -> 128 with bias, A operands from the global image
+#pragma unroll
+      for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+        for (int G = 0; G < 2; G++) to_ops(o[cb], G, bh[2 * cb + G], bl[2 * cb + G]);
+      f32x16 fo[4];
+#pragma unroll
+      for (int cb = 0; cb < 4; cb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) fo[cb][r] = 0.f;
+      const bf16x8 *wb = reinterpret_cast<const bf16x8 *>(p.wfinal) + lane;
+#pragma unroll
+      for (int s2 = 0; s2 < 4; s2++) {
+        bf16x8 wh[4], wl[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) {
+          wh[cb] = wb[((s2 * 4 + cb) * 2) * 64];
+          wl[cb] = wb[((s2 * 4 + cb) * 2 + 1) * 64];
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) fo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bh[s2], fo[cb], 0, 0, 0);
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) fo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bl[s2], fo[cb], 0, 0, 0);
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) fo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], bh[s2], fo[cb], 0, 0, 0);
+      }
+      const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)b * 128 * p.Lq, 0, 128 * p.Lq * 4, 0x00020000);
+#pragma unroll
+      for (int cb = 0; cb < 4; cb++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const f32x4 bv = cvec(s_c + 320, cb, g);
+#pragma unroll
+          for (int qq = 0; qq < 4; qq++) {
+            const int e = 16 * cb + 4 * g + qq;
+            const int ch = 16 * (e >> 3) + bf_kpos(0, e & 7);
+            const float v = fo[cb][4 * g + qq] + bv[qq];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, vo, ch * p.Lq * 4, 0);
+          }
+        }
     }
     __builtin_amdgcn_wave_barrier();   // (the key-sum strip is rewritten by the next item)
   }
@@ -1185,13 +1237,11 @@ static int attn_apply_launch(const pcr_attn_params *pp, pcr_stream_t stream) {
   dim3 g((p.Lq + T - 1) / T, p.B), blk(kThreads);
   hipStream_t st = pcr_s(stream);
 #if PCR_ATTN_PREC != 0
-  if (p.d == 64 && p.c1 == 64 && p.cout == 64 && !p.cfinal && (p.Lq & 31) == 0 &&
-      (p.nhead == 1 || p.nhead == 2 || p.nhead == 4)) {
+  if (p.d == 64 && (p.c1 == 64 || (p.c1 == 32 && !p.q_pos && !p.residual)) && p.cout == 64 && (p.cfinal == 0 || p.cfinal == 128) &&
+      (p.Lq & 31) == 0 && (p.nhead == 1 || p.nhead == 2 || p.nhead == 4)) {
     // wave-autonomous form (shape-only choice)
-    static bool oks = allow_big_lds(attn_apply_stream64_kernel<true>) && allow_big_lds(attn_apply_stream64_kernel<false>);
-    (void)oks;
-    const int sq = p.q_pos ? 8 : 4;
-    const size_t lds_s = (size_t)(sq * 256 + 4096 + 2048) * 16 + (size_t)(320 + 256 + 64 * kApsWaves) * sizeof(float);
+    const int c1s = p.c1 >> 4, sq = c1s + (p.q_pos ? 4 : 0), s0 = c1s + 4;
+    const size_t lds_s = (size_t)(sq * 256 + s0 * 512 + 2048) * 16 + (size_t)(448 + 256 + 64 * kApsWaves) * sizeof(float);
     const long nitem = (long)p.B * (p.Lq >> 5);
     const long nwg = (nitem + kApsWaves - 1) / kApsWaves;
     static const int ncu = [] {
@@ -1201,8 +1251,17 @@ static int attn_apply_launch(const pcr_attn_params *pp, pcr_stream_t stream) {
       return pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
     }();
     const dim3 gg((unsigned)(nwg < ncu ? nwg : ncu)), bb(64 * kApsWaves);
-    if (p.q_pos) hipLaunchKernelGGL(attn_apply_stream64_kernel<true>, gg, bb, lds_s, st, a);
-    else hipLaunchKernelGGL(attn_apply_stream64_kernel<false>, gg, bb, lds_s, st, a);
+#define PCR_APS(QP, C1Sv, CFv)                                                            \
+  do {                                                                                    \
+    static bool oks = allow_big_lds(attn_apply_stream64_kernel<QP, C1Sv, CFv>);           \
+    (void)oks;                                                                            \
+    hipLaunchKernelGGL((attn_apply_stream64_kernel<QP, C1Sv, CFv>), gg, bb, lds_s, st, a); \
+  } while (0)
+    const bool cf = p.cfinal != 0;
+    if (p.c1 == 32) { if (cf) PCR_APS(false, 2, true); else PCR_APS(false, 2, false); }
+    else if (p.q_pos) { if (cf) PCR_APS(true, 4, true); else PCR_APS(true, 4, false); }
+    else { if (cf) PCR_APS(false, 4, true); else PCR_APS(false, 4, false); }
+#undef PCR_APS
     PCR_CHECK_LAUNCH();
     return PCR_OK;
   }
