@@ -441,44 +441,172 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
 // wave-private LDS strip, the item's centres leave from there.  Items of a cloud stay on one XCD (its table rows are
 // gathered by every item of the cloud: one L2 should hold them).
 constexpr int kSasWaves = 8;
-template <int NCB, bool LO>
-__global__ __launch_bounds__(64 * kSasWaves) __attribute__((amdgpu_waves_per_eu(2, NCB == 4 ? 2 : 4)))
+constexpr int kSasCpi = 16;   // centres per item of the ragged form
+
+// the three layers of one 32-row block, shared by the K-row and the ragged form.  In: the row's neighbour i, its centre
+// point ci; out: y3[NCB3], layer 3 TRANSPOSED (lane (cout, h) holds the tokens 8 g + 4 h + q of its channel).
+template <int NCB, int NCB3, bool LO>
+struct SasBlock {
+  static constexpr int C = 32 * NCB, NS = 2 * NCB;
+  __device__ static __forceinline__ void run(const float *xyz, const float *pq, int pqw, int qoff, bool has_q, int i, int ci,
+                                             const float *s_sh1, const float *s_sh2, const float *s_sh3, const f32x4 *s_wa,
+                                             const bf16x8 *s_w2, const bf16x8 *s_w3, int lane, f32x16 (&y3)[NCB3]) {
+    const int j = lane & 31, h = lane >> 5;
+    auto cvec = [&](const float *base, int cb, int g) __attribute__((always_inline)) {
+      return *reinterpret_cast<const f32x4 *>(base + 32 * cb + 8 * g + 4 * h);
+    };
+    const float dxv = xyz[i * 3] - xyz[ci * 3], dyv = xyz[i * 3 + 1] - xyz[ci * 3 + 1], dzv = xyz[i * 3 + 2] - xyz[ci * 3 + 2];
+    const float b0 = h ? dyv : dxv, b1 = h ? 0.f : dzv;      // layer 1's B operand: k = h, 2 + h
+    bf16x8 bh[NS], bl[NS];
+    // ---- layer 1, one cout block at a time (the gathers of a block: 8 + 8 sixteen-byte pieces)
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) {
+      f32x4 pp[4], qq[4];
+      const float *pr = pq ? pq + (size_t)i * pqw + cb * 32 + 4 * h : nullptr;
+      const float *qr = has_q ? pq + (size_t)ci * pqw + qoff + cb * 32 + 4 * h : nullptr;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        pp[g] = pr ? *reinterpret_cast<const f32x4 *>(pr + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        qq[g] = qr ? *reinterpret_cast<const f32x4 *>(qr + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      f32x16 acc;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const f32x4 s4 = cvec(s_sh1, cb, g);
+#pragma unroll
+        for (int q2 = 0; q2 < 4; q2++) acc[4 * g + q2] = has_q ? s4[q2] + qq[g][q2] : s4[q2];
+      }
+      const f32x4 av = s_wa[cb * 64 + j * 2 + h];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], b0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], b1, acc, 0, 0, 0);
+#pragma unroll
+      for (int G = 0; G < 2; G++) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const int rr = 8 * G + e;
+          const float t = pq ? acc[rr] + pp[rr >> 2][rr & 3] : acc[rr];
+          v[e] = relu_bits(t);
+        }
+        bf_split8(v, bh[2 * cb + G], bl[2 * cb + G], LO);
+      }
+    }
+    // ---- layer 2 (normal orientation: its accumulators convert into layer 3's operand)
+    {
+      f32x16 y[NCB];
+#pragma unroll
+      for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const f32x4 s4 = cvec(s_sh2, cb, g);
+#pragma unroll
+          for (int q2 = 0; q2 < 4; q2++) y[cb][4 * g + q2] = s4[q2];
+        }
+      const bf16x8 *wb = s_w2 + lane;
+#pragma unroll
+      for (int s2 = 0; s2 < NS; s2++) {
+        bf16x8 wh[NCB], wl[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+          wh[cb] = wb[((s2 * NCB + cb) * 2) * 64];
+          if constexpr (LO) wl[cb] = wb[((s2 * NCB + cb) * 2 + 1) * 64];
+        }
+        if constexpr (LO) {
+#pragma unroll
+          for (int cb = 0; cb < NCB; cb++) y[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bl[s2], y[cb], 0, 0, 0);
+#pragma unroll
+          for (int cb = 0; cb < NCB; cb++) y[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], bh[s2], y[cb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) y[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bh[s2], y[cb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+        for (int G = 0; G < 2; G++) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; e++) v[e] = relu_bits(y[cb][8 * G + e]);
+          bf_split8(v, bh[2 * cb + G], bl[2 * cb + G], LO);
+        }
+    }
+    // ---- layer 3 TRANSPOSED (activations as the A operand, the same weight image as B)
+#pragma unroll
+    for (int cb = 0; cb < NCB3; cb++) {
+      const float sv = s_sh3[cb * 32 + j];
+#pragma unroll
+      for (int rr = 0; rr < 16; rr++) y3[cb][rr] = sv;
+    }
+    const bf16x8 *wb = s_w3 + lane;
+#pragma unroll
+    for (int s2 = 0; s2 < NS; s2++) {
+      bf16x8 wh[NCB3], wl[NCB3];
+#pragma unroll
+      for (int cb = 0; cb < NCB3; cb++) {
+        wh[cb] = wb[((s2 * NCB3 + cb) * 2) * 64];
+        if constexpr (LO) wl[cb] = wb[((s2 * NCB3 + cb) * 2 + 1) * 64];
+      }
+      if constexpr (LO) {
+#pragma unroll
+        for (int cb = 0; cb < NCB3; cb++) y3[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[s2], wh[cb], y3[cb], 0, 0, 0);
+#pragma unroll
+        for (int cb = 0; cb < NCB3; cb++) y3[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[s2], wl[cb], y3[cb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int cb = 0; cb < NCB3; cb++) y3[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[s2], wh[cb], y3[cb], 0, 0, 0);
+    }
+  }
+};
+
+// LDS layout shared by both forms: w2 | w3 | sh1 C | sh2 C | sh3 C3 | wa | per-wave area
+template <int NCB, int NCB3>
+struct SasLds {
+  static constexpr int C = 32 * NCB, C3 = 32 * NCB3, NS = 2 * NCB;
+  static constexpr int W2U = NS * NCB * 128, W3U = NS * NCB3 * 128;   // 16-byte units
+  static constexpr size_t kFixed = (size_t)(W2U + W3U) * 16 + (size_t)(2 * C + C3) * 4 + (size_t)NCB * 64 * 16;
+};
+
+template <int NCB, int NCB3>
+__device__ __forceinline__ void sas_stage(float *smem, const float *wp2, const float *wp3, const float *sh1, const float *sh2,
+                                          const float *sh3, const float *wap, int nthr) {
+  using L = SasLds<NCB, NCB3>;
+  f32x4 *d2 = reinterpret_cast<f32x4 *>(smem), *d3 = d2 + L::W2U;
+  float *s_sh = reinterpret_cast<float *>(d3 + L::W3U);
+  f32x4 *s_wa = reinterpret_cast<f32x4 *>(s_sh + 2 * L::C + L::C3);
+  const f32x4 *w2 = reinterpret_cast<const f32x4 *>(wp2), *w3 = reinterpret_cast<const f32x4 *>(wp3);
+  const int tid = threadIdx.x;
+  for (int e = tid; e < L::W2U; e += nthr) d2[e] = w2[e];
+  for (int e = tid; e < L::W3U; e += nthr) d3[e] = w3[e];
+  for (int e = tid; e < L::C; e += nthr) {
+    s_sh[e] = sh1[e];
+    s_sh[L::C + e] = sh2[e];
+  }
+  for (int e = tid; e < L::C3; e += nthr) s_sh[2 * L::C + e] = sh3[e];
+  for (int e = tid; e < NCB * 64; e += nthr) s_wa[e] = reinterpret_cast<const f32x4 *>(wap)[e];
+  __syncthreads();
+}
+
+template <int NCB, int NCB3, bool LO>
+__global__ __launch_bounds__(64 * kSasWaves) __attribute__((amdgpu_waves_per_eu(2, (NCB + NCB3 >= 6) ? 2 : 4)))
 void sa_stream_kernel(Sa2Args a, int nblk_item, int ncen_item) {
-  constexpr int C = 32 * NCB, NS = 2 * NCB;          // channels, 16-channel steps
-  constexpr int WUNITS = NS * NCB * 2 * 64;           // 16-byte units of one weight image
+  using L = SasLds<NCB, NCB3>;
+  constexpr int C = L::C, C3 = L::C3;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  bf16x8 *s_w2 = reinterpret_cast<bf16x8 *>(smem);
-  bf16x8 *s_w3 = s_w2 + WUNITS;
-  float *s_sh = reinterpret_cast<float *>(s_w3 + WUNITS);   // sh1 | sh2 | sh3 : 3 C
-  f32x4 *s_wa = reinterpret_cast<f32x4 *>(s_sh + 3 * C);    // [NCB][64] layer-1 A operands
-  float *s_gm = reinterpret_cast<float *>(s_wa + NCB * 64); // [waves][6 groups][C] group maxima of the wave's item
+  const bf16x8 *s_w2 = reinterpret_cast<const bf16x8 *>(smem);
+  const bf16x8 *s_w3 = s_w2 + L::W2U;
+  const float *s_sh = reinterpret_cast<const float *>(s_w3 + L::W3U);
+  const f32x4 *s_wa = reinterpret_cast<const f32x4 *>(s_sh + 2 * C + C3);
+  float *s_gm = reinterpret_cast<float *>(smem) + L::kFixed / 4;   // [waves][6 groups][C3] group maxima of the wave's item
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  {
-    const f32x4 *w2 = reinterpret_cast<const f32x4 *>(a.wp2), *w3 = reinterpret_cast<const f32x4 *>(a.wp3);
-    f32x4 *d2 = reinterpret_cast<f32x4 *>(s_w2), *d3 = reinterpret_cast<f32x4 *>(s_w3);
-    for (int e = tid; e < WUNITS; e += 64 * kSasWaves) {
-      d2[e] = w2[e];
-      d3[e] = w3[e];
-    }
-    for (int e = tid; e < C; e += 64 * kSasWaves) {
-      s_sh[e] = a.sh1[e];
-      s_sh[C + e] = a.sh2[e];
-      s_sh[2 * C + e] = a.sh3[e];
-    }
-    for (int e = tid; e < NCB * 64; e += 64 * kSasWaves) s_wa[e] = reinterpret_cast<const f32x4 *>(a.wap)[e];
-  }
-  __syncthreads();
+  sas_stage<NCB, NCB3>(smem, a.wp2, a.wp3, a.sh1, a.sh2, a.sh3, a.wap, 64 * kSasWaves);
   const int K = a.K, gpc = K >> 4;                      // 16-row groups per centre
   const int nitem = (a.S + ncen_item - 1) / ncen_item;  // items per cloud
-  float *gm = s_gm + wave * 6 * C;
+  float *gm = s_gm + wave * 6 * C3;
   const bool has_q = a.pq && a.qoff >= 0;
   // XCD-aware item order: workgroup w sits on XCD w % 8; the clouds b % 8 == x belong to XCD x
   const int xcd = blockIdx.x & 7, wrank = (blockIdx.x >> 3) * kSasWaves + wave, wstride = ((gridDim.x + 7 - xcd) >> 3) * kSasWaves;
   const long nq = (long)((a.B + 7 - xcd) >> 3) * nitem;          // items of this XCD's clouds
-  auto cvec = [&](const float *base, int cb, int g) __attribute__((always_inline)) {
-    return *reinterpret_cast<const f32x4 *>(base + 32 * cb + 8 * g + 4 * h);
-  };
   for (long qi = wrank; qi < nq; qi += wstride) {
     asm volatile("" ::: "memory");
     const long bq = qi / nitem;
@@ -493,129 +621,27 @@ void sa_stream_kernel(Sa2Args a, int nblk_item, int ncen_item) {
       if (blk * 32 >= rows) break;                      // (a partial last item: whole blocks of padding are skipped)
       int r = blk * 32 + j;
       r = r < rows ? r : rows - 1;                      // padding rows repeat the last one (a max does not care)
-      const int cen = r / K;
-      const int s = c0 + cen;
+      const int s = c0 + r / K;
       const int ci = a.centre_idx ? a.centre_idx[b * a.S + s] : s;
       const int i = a.idx[(b * a.S + c0) * (size_t)K + r];
-      const float dxv = xyz[i * 3] - xyz[ci * 3], dyv = xyz[i * 3 + 1] - xyz[ci * 3 + 1], dzv = xyz[i * 3 + 2] - xyz[ci * 3 + 2];
-      const float b0 = h ? dyv : dxv, b1 = h ? 0.f : dzv;      // layer 1's B operand: k = h, 2 + h
-      bf16x8 bh[NS], bl[NS];
-      // ---- layer 1, one cout block at a time (the gathers of a block: 8 + 8 sixteen-byte pieces)
+      f32x16 y[NCB3];
+      SasBlock<NCB, NCB3, LO>::run(xyz, pq, a.pqw, a.qoff, has_q, i, ci, s_sh, s_sh + C, s_sh + 2 * C, s_wa, s_w2, s_w3, lane, y);
+      // the maximum over a 16-row group = a maximum over eight of the lane's OWN registers plus one exchange with its
+      // partner lane (20 instructions per cout block; the token-per-lane form needs a 4-step DPP reduction of every
+      // register: 128)
 #pragma unroll
-      for (int cb = 0; cb < NCB; cb++) {
-        f32x4 pp[4], qq[4];
-        const float *pr = pq ? pq + (size_t)i * a.pqw + cb * 32 + 4 * h : nullptr;
-        const float *qr = has_q ? pq + (size_t)ci * a.pqw + a.qoff + cb * 32 + 4 * h : nullptr;
+      for (int cb = 0; cb < NCB3; cb++) {
+        int m0 = __float_as_int(y[cb][0]), m1 = __float_as_int(y[cb][8]);   // (signed maxima of the bit patterns, ReLU last)
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-          pp[g] = pr ? *reinterpret_cast<const f32x4 *>(pr + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-          qq[g] = qr ? *reinterpret_cast<const f32x4 *>(qr + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int rr = 1; rr < 8; rr++) {
+          m0 = imax(m0, __float_as_int(y[cb][rr]));
+          m1 = imax(m1, __float_as_int(y[cb][8 + rr]));
         }
-        f32x16 acc;
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const f32x4 s4 = cvec(s_sh, cb, g);
-#pragma unroll
-          for (int q2 = 0; q2 < 4; q2++) acc[4 * g + q2] = has_q ? s4[q2] + qq[g][q2] : s4[q2];
-        }
-        const f32x4 av = s_wa[cb * 64 + j * 2 + h];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], b1, acc, 0, 0, 0);
-#pragma unroll
-        for (int G = 0; G < 2; G++) {
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 8; e++) {
-            const int rr = 8 * G + e;
-            const float t = pq ? acc[rr] + pp[rr >> 2][rr & 3] : acc[rr];
-            v[e] = relu_bits(t);
-          }
-          bf_split8(v, bh[2 * cb + G], bl[2 * cb + G], LO);
-        }
-      }
-      // ---- layers 2 and 3
-      f32x16 y[NCB];
-      auto dense = [&](const bf16x8 *wimg, const float *shift) __attribute__((always_inline)) {
-#pragma unroll
-        for (int cb = 0; cb < NCB; cb++)
-#pragma unroll
-          for (int g = 0; g < 4; g++) {
-            const f32x4 s4 = cvec(shift, cb, g);
-#pragma unroll
-            for (int q2 = 0; q2 < 4; q2++) y[cb][4 * g + q2] = s4[q2];
-          }
-        const bf16x8 *wb = wimg + lane;
-#pragma unroll
-        for (int s2 = 0; s2 < NS; s2++) {
-          bf16x8 wh[NCB], wl[NCB];
-#pragma unroll
-          for (int cb = 0; cb < NCB; cb++) {
-            wh[cb] = wb[((s2 * NCB + cb) * 2) * 64];
-            if constexpr (LO) wl[cb] = wb[((s2 * NCB + cb) * 2 + 1) * 64];
-          }
-          if constexpr (LO) {
-#pragma unroll
-            for (int cb = 0; cb < NCB; cb++) y[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bl[s2], y[cb], 0, 0, 0);
-#pragma unroll
-            for (int cb = 0; cb < NCB; cb++) y[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], bh[s2], y[cb], 0, 0, 0);
-          }
-#pragma unroll
-          for (int cb = 0; cb < NCB; cb++) y[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bh[s2], y[cb], 0, 0, 0);
-        }
-      };
-      dense(s_w2, s_sh + C);
-#pragma unroll
-      for (int cb = 0; cb < NCB; cb++)
-#pragma unroll
-        for (int G = 0; G < 2; G++) {
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 8; e++) v[e] = relu_bits(y[cb][8 * G + e]);
-          bf_split8(v, bh[2 * cb + G], bl[2 * cb + G], LO);
-        }
-      // ---- layer 3 TRANSPOSED (activations as the A operand, the same weight image as B): lane (cout, h) then holds the
-      // tokens 8 g + 4 h + q of its channel, and the maximum over a 16-row group is a maximum over eight of the lane's
-      // OWN registers plus one exchange with its partner lane -- 20 instructions per cout block where the token-per-lane
-      // form needs a 4-step DPP reduction of every register (128)
-      {
-#pragma unroll
-        for (int cb = 0; cb < NCB; cb++) {
-          const float sv = s_sh[2 * C + cb * 32 + j];
-#pragma unroll
-          for (int rr = 0; rr < 16; rr++) y[cb][rr] = sv;
-        }
-        const bf16x8 *wb = s_w3 + lane;
-#pragma unroll
-        for (int s2 = 0; s2 < NS; s2++) {
-          bf16x8 wh[NCB], wl[NCB];
-#pragma unroll
-          for (int cb = 0; cb < NCB; cb++) {
-            wh[cb] = wb[((s2 * NCB + cb) * 2) * 64];
-            if constexpr (LO) wl[cb] = wb[((s2 * NCB + cb) * 2 + 1) * 64];
-          }
-          if constexpr (LO) {
-#pragma unroll
-            for (int cb = 0; cb < NCB; cb++) y[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[s2], wh[cb], y[cb], 0, 0, 0);
-#pragma unroll
-            for (int cb = 0; cb < NCB; cb++) y[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[s2], wl[cb], y[cb], 0, 0, 0);
-          }
-#pragma unroll
-          for (int cb = 0; cb < NCB; cb++) y[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[s2], wh[cb], y[cb], 0, 0, 0);
-        }
-#pragma unroll
-        for (int cb = 0; cb < NCB; cb++) {
-          int m0 = __float_as_int(y[cb][0]), m1 = __float_as_int(y[cb][8]);   // (signed maxima of the bit patterns, ReLU last)
-#pragma unroll
-          for (int rr = 1; rr < 8; rr++) {
-            m0 = imax(m0, __float_as_int(y[cb][rr]));
-            m1 = imax(m1, __float_as_int(y[cb][8 + rr]));
-          }
-          m0 = imax(m0, __shfl_xor(m0, 32, 64));
-          m1 = imax(m1, __shfl_xor(m1, 32, 64));
-          if (h == 0) {
-            gm[(blk * 2) * C + cb * 32 + j] = __int_as_float(imax(m0, 0));
-            gm[(blk * 2 + 1) * C + cb * 32 + j] = __int_as_float(imax(m1, 0));
-          }
+        m0 = imax(m0, __shfl_xor(m0, 32, 64));
+        m1 = imax(m1, __shfl_xor(m1, 32, 64));
+        if (h == 0) {
+          gm[(blk * 2) * C3 + cb * 32 + j] = __int_as_float(imax(m0, 0));
+          gm[(blk * 2 + 1) * C3 + cb * 32 + j] = __int_as_float(imax(m1, 0));
         }
       }
     }
@@ -623,17 +649,18 @@ void sa_stream_kernel(Sa2Args a, int nblk_item, int ncen_item) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // the item's centres: max over their groups, centre-major so that (B,S,c3) rows leave as whole lines
-    for (int e = lane; e < nc * C; e += 64) {
-      const int c = e / C, o = e - c * C;
-      const float *g = gm + (c * gpc) * C + o;
+    for (int e = lane; e < nc * C3; e += 64) {
+      const int c = e / C3, o = e - c * C3;
+      const float *g = gm + (c * gpc) * C3 + o;
       float m = g[0];
-      for (int k = 1; k < gpc; k++) m = fmaxf(m, g[k * C]);
-      if (a.out_pm) a.out[(b * a.S + c0 + c) * (size_t)C + o] = m;
-      else a.out[(b * C + o) * (size_t)a.S + c0 + c] = m;
+      for (int k = 1; k < gpc; k++) m = fmaxf(m, g[k * C3]);
+      if (a.out_pm) a.out[(b * a.S + c0 + c) * (size_t)C3 + o] = m;
+      else a.out[(b * C3 + o) * (size_t)a.S + c0 + c] = m;
     }
     __builtin_amdgcn_wave_barrier();
   }
 }
+
 #endif
 
 // ------------------------------------------------- ragged SA MLP (ball-query duplicates) ----
@@ -861,6 +888,106 @@ __global__ __launch_bounds__(256) void sa_rag_rows_kernel(RagArgs a) {
     __builtin_amdgcn_wave_barrier();
   }
 }
+
+#if PCR_SA_PREC != 0
+// Ragged form (ball-query groups with hit counts, mode 1): a centre contributes its first rag_ceil(max(cnt, 1)) rows
+// (the rest repeat row 0: a max does not care).  Item = kSasCpi consecutive centres of a cloud: the wave scans their row
+// counts, lays the rows out back to back (row -> (centre, k) map in a wave-private LDS strip) and runs them through the
+// same block routine, 32 at a time.  Rows of a centre come in pairs (counts are even), and with layer 3 transposed a
+// pair is two registers of one lane: their maximum goes to the centre's output row by an LDS integer atomic max
+// (order-independent, hence deterministic) -- no row tables, no tile plan, no descriptors.
+template <int NCB, int NCB3, bool LO>
+__global__ __launch_bounds__(64 * kSasWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void sa_stream_rag_kernel(RagArgs a) {
+  using L = SasLds<NCB, NCB3>;
+  constexpr int C = L::C, C3 = L::C3, CPI = kSasCpi;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const bf16x8 *s_w2 = reinterpret_cast<const bf16x8 *>(smem);
+  const bf16x8 *s_w3 = s_w2 + L::W2U;
+  const float *s_sh = reinterpret_cast<const float *>(s_w3 + L::W3U);
+  const f32x4 *s_wa = reinterpret_cast<const f32x4 *>(s_sh + 2 * C + C3);
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K = a.K, maxrows = CPI * K;
+  int *s_w = reinterpret_cast<int *>(smem) + L::kFixed / 4 + wave * (CPI * C3 + maxrows);
+  int *obuf = s_w;                 // [CPI][C3] running maxima (bit patterns, >= 0)
+  int *rmap = s_w + CPI * C3;      // [maxrows] row -> centre | k << 8
+  sas_stage<NCB, NCB3>(smem, a.wp2, a.wp3, a.sh1, a.sh2, a.sh3, a.wap, 64 * kSasWaves);
+  for (int e = lane; e < CPI * C3; e += 64) obuf[e] = 0;
+  const int nitem = (a.S + CPI - 1) / CPI;
+  const int xcd = blockIdx.x & 7, wrank = (blockIdx.x >> 3) * kSasWaves + wave, wstride = ((gridDim.x + 7 - xcd) >> 3) * kSasWaves;
+  const long nq = (long)((a.B + 7 - xcd) >> 3) * nitem;
+  for (long qi = wrank; qi < nq; qi += wstride) {
+    asm volatile("" ::: "memory");
+    const long bq = qi / nitem;
+    const int item = (int)(qi - bq * nitem);
+    const size_t b = (size_t)bq * 8 + xcd;
+    const int c0 = item * CPI;
+    const int nc = a.S - c0 < CPI ? a.S - c0 : CPI;
+    const float *xyz = a.xyz + b * a.N * 3;
+    const float *pq = a.pq ? a.pq + b * a.N * (size_t)a.pqw : nullptr;
+    // rows per centre (lanes 0 .. CPI-1), their prefix sums, the row map
+    int n = 0;
+    if (lane < nc) {
+      const int cn = a.cnt[b * a.S + c0 + lane];
+      n = rag_ceil(cn > 1 ? cn : 1);
+      n = n < K ? n : K;
+    }
+    int incl = n;
+#pragma unroll
+    for (int d2 = 1; d2 < CPI; d2 <<= 1) {
+      const int o = __shfl_up(incl, d2, 64);
+      if (lane >= d2) incl += o;
+    }
+    const int R = __builtin_amdgcn_readlane(incl, CPI - 1);
+    {
+      const int start = incl - n;
+      for (int k = 0; k < n; k++) rmap[start + k] = lane | (k << 8);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int nb = (R + 31) >> 5;
+    for (int blk = 0; blk < nb; blk++) {
+      int r = blk * 32 + j;
+      r = r < R ? r : R - 1;
+      const int mp = rmap[r];
+      const int c = mp & 0xFF, k = mp >> 8;
+      const int s = c0 + c;
+      const int ci = a.centre_idx ? a.centre_idx[b * a.S + s] : s;
+      const int i = a.idx[(b * a.S + s) * (size_t)K + k];
+      f32x16 y[NCB3];
+      SasBlock<NCB, NCB3, LO>::run(xyz, pq, a.pqw, -1, false, i, ci, s_sh, s_sh + C, s_sh + 2 * C, s_wa, s_w2, s_w3, lane, y);
+      // pairs of rows (tokens 8 g + 4 h + 2 p, + 1) belong to one centre: their maximum joins the centre's output row
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int pr = 0; pr < 2; pr++) {
+          const int t0 = blk * 32 + 8 * g + 4 * h + 2 * pr;
+          if (t0 < R) {
+            int *orow = obuf + (rmap[t0] & 0xFF) * C3 + j;
+#pragma unroll
+            for (int cb = 0; cb < NCB3; cb++) {
+              const int v = imax(__float_as_int(y[cb][4 * g + 2 * pr]), __float_as_int(y[cb][4 * g + 2 * pr + 1]));
+              __hip_atomic_fetch_max(orow + cb * 32, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+          }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int e = lane; e < nc * C3; e += 64) {
+      const int c = e / C3, o = e - c * C3;
+      const float m = __int_as_float(obuf[e]);   // (started at 0: the ReLU)
+      obuf[e] = 0;
+      if (a.out_pm) a.out[(b * a.S + c0 + c) * (size_t)C3 + o] = m;
+      else a.out[(b * C3 + o) * (size_t)a.S + c0 + c] = m;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+#endif
 
 // PCR_SA_TRACE=<file> (diagnostics only): wave 0 of every workgroup stamps the shader clock at the phase
 // boundaries of its first kTraceTiles tiles; the host dumps the buffer after the launch
@@ -1290,6 +1417,32 @@ int pcr_sa2_try_bf3(const pcr_sa_params *p, pcr_stream_t st);   // sa_kernels_bf
 int pcr_sa2_try_bf1(const pcr_sa_params *p, pcr_stream_t st);
 #endif
 
+#if PCR_SA_PREC != 0
+// shapes of the wave-autonomous forms (sa_stream_kernel / sa_stream_rag_kernel).  Ball-query layers (mode 1) can run
+// either form depending on whether hit counts are given, and the tests hold the two to the same bits: such a layer
+// streams only when BOTH forms fit, so both always share one arithmetic.
+static bool sas_k_ok(int K) {
+  for (int nb = 1; nb <= 3; nb++)
+    if ((32 * nb) % K == 0) return (K & 15) == 0;
+  return false;
+}
+static size_t sas_fixed_lds(const pcr_sa_params &p) {
+  const int ncb = p.c1 >> 5, ncb3 = p.c3 >> 5;
+  return ((size_t)(2 * ncb) * ncb * 128 + (size_t)(2 * ncb) * ncb3 * 128) * 16 + (size_t)(2 * p.c1 + p.c3) * 4 + (size_t)ncb * 64 * 16;
+}
+static bool sas_shape_ok(const pcr_sa_params &p, bool ragged) {
+  static const int no_stream = pcr_tune_int("PCR_SA_NO_STREAM");   // diagnostics
+  if (no_stream || p.B < 1 || !p.wa_packed || p.c1 != p.c2 || !(p.c3 == p.c2 || p.c3 == 2 * p.c2) ||
+      !(p.c1 == 32 || p.c1 == 64 || p.c1 == 128) || !sas_k_ok(p.K))
+    return false;
+  const size_t lds_k = sas_fixed_lds(p) + (size_t)kSasWaves * 6 * p.c3 * 4;
+  const size_t lds_r = sas_fixed_lds(p) + (size_t)kSasWaves * (kSasCpi * p.c3 + kSasCpi * p.K) * 4;
+  const size_t cap = (size_t)160 * 1024;
+  if (ragged || p.mode == 1) return lds_k <= cap && lds_r <= cap;
+  return lds_k <= cap;
+}
+#endif
+
 static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   hipStream_t st = pcr_s(st_);
   if (!p.wa || !p.wps[0] || !p.wps[1] || !p.shift_pad[0] || !p.shift_pad[1] || (p.D && (!p.wpq || !p.pq_ws)))
@@ -1324,6 +1477,58 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
                          : ((v2 == 1 && v3 == 1) || (v2 == 2 && v3 == 1) || (v2 == 2 && v3 == 2) || (v2 == 4 && v3 == 4));
     }
     if (!shape_ok) return -1;
+#if PCR_SA_PREC != 0
+    {
+      // wave-autonomous ragged form (shape-only choice, the same shapes as the K-row form so that both paths share one
+      // arithmetic): equal widths of layers 1 / 2, c3 = c2 or 2 c2, weights + per-wave areas within LDS
+      static const int no_stream = pcr_tune_int("PCR_SA_NO_STREAM");
+      const int ncb = p.c1 >> 5, ncb3 = p.c3 >> 5;
+      const size_t fixed = ((size_t)(2 * ncb) * ncb * 128 + (size_t)(2 * ncb) * ncb3 * 128) * 16 + (size_t)(2 * p.c1 + p.c3) * 4 +
+                           (size_t)ncb * 64 * 16;
+      const size_t lds_r = fixed + (size_t)kSasWaves * (kSasCpi * p.c3 + kSasCpi * p.K) * 4;
+      const size_t lds_k = fixed + (size_t)kSasWaves * 6 * p.c3 * 4;     // (the K-row form's condition, see below)
+      (void)no_stream; (void)lds_k;
+      if (sas_shape_ok(p, true)) {
+        if (p.D && !p.pq_ready) {
+          const int rc = pcr_dense_pm_f32(p.feat, p.wpq, p.pq_ws, p.B, p.D, p.c1, p.N, p.feat_point_major, st_);
+          if (rc != PCR_OK) return rc == PCR_ERR_INVALID ? -1 : rc;
+        }
+        RagArgs r;
+        r.B = p.B; r.N = p.N; r.S = p.S; r.K = p.K; r.c1 = p.c1; r.c2 = p.c2; r.c3 = p.c3; r.maxT = 0;
+        r.xyz = p.xyz; r.idx = p.idx; r.cnt = p.cnt; r.centre_idx = p.centre_idx; r.ws = p.tile_ws;
+        r.wa = p.wa; r.pq = p.D ? p.pq_ws : nullptr; r.pqw = p.c1;
+        r.wap = p.wa_packed;
+        r.wp2 = wl2; r.wp3 = wl3; r.sh1 = p.shift[0]; r.sh2 = p.shift_pad[0]; r.sh3 = p.shift_pad[1];
+        r.dbg = 0; r.out = p.out; r.out_pm = p.out_point_major;
+        static const int ncu = [] {
+          int dev = 0, n = 0;
+          if (hipGetDevice(&dev) != hipSuccess ||
+              hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
+            n = 256;
+          return n;
+        }();
+        const long items = (long)p.B * ((p.S + kSasCpi - 1) / kSasCpi);
+        long wgs = (items + kSasWaves - 1) / kSasWaves;
+        if (wgs > ncu) wgs = ncu;
+        wgs = (wgs + 7) / 8 * 8;
+        const dim3 gg((unsigned)wgs), bb(64 * kSasWaves);
+        constexpr bool kLoS = kPrec == 1;
+#define PCR_SASR(NCBv, NCB3v)                                                                 \
+  do {                                                                                        \
+    static bool ok = allow_big_lds(sa_stream_rag_kernel<NCBv, NCB3v, kLoS>);                  \
+    (void)ok;                                                                                 \
+    hipLaunchKernelGGL((sa_stream_rag_kernel<NCBv, NCB3v, kLoS>), gg, bb, lds_r, st, r);      \
+  } while (0)
+        if (ncb == 1 && ncb3 == 1) PCR_SASR(1, 1);
+        else if (ncb == 1) PCR_SASR(1, 2);
+        else if (ncb3 == 2) PCR_SASR(2, 2);
+        else PCR_SASR(2, 4);
+#undef PCR_SASR
+        if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
+        return PCR_OK;
+      }
+    }
+#endif
     if (p.K <= ROWS) {
       const int per_tile = ROWS / rag_ceil(p.K);               // whole centres a tile holds in the worst case
       RagArgs r;
@@ -1493,14 +1698,15 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
     // wave-autonomous form (shape-only choice): equal widths of 32 / 64 / 128, K in whole 16-row groups, at most three
     // 32-row blocks per item (K = 16, 32, 48, 64, 96)
     static const int no_stream = pcr_tune_int("PCR_SA_NO_STREAM");   // diagnostics
-    const int ncb = p.c1 >> 5;
+    const int ncb = p.c1 >> 5, ncb3 = p.c3 >> 5;
     int nblk_item = 0, ncen_item = 0;
     for (int nb = 1; nb <= 3 && !nblk_item; nb++)
       if ((32 * nb) % p.K == 0) { nblk_item = nb; ncen_item = 32 * nb / p.K; }
-    if (!no_stream && maxe && p.c1 == p.c2 && p.c2 == p.c3 && (p.c1 == 32 || p.c1 == 64 || p.c1 == 128) && p.wa_packed &&
-        nblk_item && p.B > 0) {
-      const size_t wunits = (size_t)(2 * ncb) * ncb * 2 * 64;
-      const size_t lds_s = wunits * 16 * 2 + (size_t)3 * p.c1 * 4 + (size_t)ncb * 64 * 16 + (size_t)kSasWaves * 6 * p.c1 * 4;
+    const size_t fixed = ((size_t)(2 * ncb) * ncb * 128 + (size_t)(2 * ncb) * ncb3 * 128) * 16 + (size_t)(2 * p.c1 + p.c3) * 4 +
+                         (size_t)ncb * 64 * 16;
+    const size_t lds_s = fixed + (size_t)kSasWaves * 6 * p.c3 * 4;
+    (void)no_stream;
+    if (maxe && nblk_item && sas_shape_ok(p, false)) {
       static const int ncu = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -1510,20 +1716,22 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
       }();
       const long items = (long)p.B * ((p.S + ncen_item - 1) / ncen_item);
       long wgs = (items + kSasWaves - 1) / kSasWaves;
-      const long resident = (long)ncu * (ncb == 4 ? 1 : 2);   // two workgroups per CU fit for the narrow layers
+      const long resident = (long)ncu * ((ncb + ncb3 >= 6 || lds_s > (size_t)80 * 1024) ? 1 : 2);
       if (wgs > resident) wgs = resident;
       wgs = (wgs + 7) / 8 * 8;                         // every XCD gets workgroups (the item order is per XCD)
       const dim3 gg((unsigned)wgs), bb(64 * kSasWaves);
       constexpr bool kLoS = kPrec == 1;
-#define PCR_SAS(NCBv)                                                                         \
+#define PCR_SAS(NCBv, NCB3v)                                                                  \
   do {                                                                                        \
-    static bool ok = allow_big_lds(sa_stream_kernel<NCBv, kLoS>);                             \
+    static bool ok = allow_big_lds(sa_stream_kernel<NCBv, NCB3v, kLoS>);                      \
     (void)ok;                                                                                 \
-    hipLaunchKernelGGL((sa_stream_kernel<NCBv, kLoS>), gg, bb, lds_s, st, a, nblk_item, ncen_item); \
+    hipLaunchKernelGGL((sa_stream_kernel<NCBv, NCB3v, kLoS>), gg, bb, lds_s, st, a, nblk_item, ncen_item); \
   } while (0)
-      if (ncb == 1) PCR_SAS(1);
-      else if (ncb == 2) PCR_SAS(2);
-      else PCR_SAS(4);
+      if (ncb == 1 && ncb3 == 1) PCR_SAS(1, 1);
+      else if (ncb == 1) PCR_SAS(1, 2);
+      else if (ncb == 2 && ncb3 == 2) PCR_SAS(2, 2);
+      else if (ncb == 2) PCR_SAS(2, 4);
+      else PCR_SAS(4, 4);
 #undef PCR_SAS
       if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
       return PCR_OK;
