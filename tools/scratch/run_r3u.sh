@@ -1,6 +1,18 @@
 mkdir -p gpurun_out/r3u
-python -m pytest tests/test_gpu_attn_split.py -x -q -m gpu > gpurun_out/r3u/test.log 2>&1; echo "tests rc $?"; tail -4 gpurun_out/r3u/test.log
-for ns in 1 2 3 4; do
-PCR_KV_SPLITS=$ns python bench.py --workload pt1024 --no-also --no-cpu-baseline --detail 2> gpurun_out/r3u/pt1024_$ns.err | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print($ns, round(d['value']), round(d['ms_per_step'],2), d['roofline'].get('per_kernel_ms'))"
-grep -E "attn_kv" gpurun_out/r3u/pt1024_$ns.err | head -3
-done
+python -m pytest tests -q -m gpu > gpurun_out/r3u/all.log 2>&1; echo "all rc $?"
+tail -4 gpurun_out/r3u/all.log
+python bench.py > gpurun_out/r3u/bench_default.json 2> gpurun_out/r3u/bench_default.err; echo "bench rc $?"
+python - <<PY
+import json
+d=json.loads(open("gpurun_out/r3u/bench_default.json").read().strip().splitlines()[-1])
+print("HEAD", d["dtype"], round(d["value"]), round(d["ms_per_step"],2), d["max_abs_dlogit_vs_f32_path"], d["roofline"]["kernel"], round(d["roofline"]["frac"],3))
+for a in d.get("also", []):
+    if "error" in a: print(a["name"], "ERROR", a["error"]); continue
+    r=a["roofline"]
+    print(a["name"], a.get("dtype"), round(a["value"]), round(a["ms_per_step"],2), a.get("max_abs_dlogit_vs_f32_path"), r["kernel"], round(r["frac"],3))
+print("cpu", d.get("cpu_baseline",{}).get("value"))
+PY
+bash tools/collect_profiles.sh r03d "ssg1024 pt1024 pt128_train" > gpurun_out/r3u/prof.log 2>&1
+tail -5 gpurun_out/r3u/prof.log
+cat gpurun_out/prof_r03d/ssg1024_pmc.txt | head -12
+cat gpurun_out/prof_r03d/pt1024_pmc.txt | head -14
