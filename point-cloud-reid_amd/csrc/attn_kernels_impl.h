@@ -301,23 +301,26 @@ constexpr int kKvsWaves = 8;
 // of 256 of 64 per block).  Lane (t, h) then holds the channels 16 s + bf_kpos(h, .) of a 16-channel step -- the K order
 // of the weight image -- so eight loaded / computed values convert into one A operand (bf_split8); K / V, the KV
 // accumulation and the merge fold stay f32.
-template <bool DIAG, bool BF>
+// XS: 16-channel steps of the key features in the BF form (c2 = 64 or 128: the FP_SA blocks)
+template <bool DIAG, bool BF, int XS = 4>
 __global__ __launch_bounds__(64 * kKvsWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void attn_kv_stream64_kernel(AttnArgs a) {
+  static_assert(BF || XS == 4, "the f32 form is c2 = 64 only");
   constexpr int D = 64, LD = D + 1, KVS = D * LD + D;   // per-cloud reduction area: KVl [64][65] + key sums [64]
   constexpr int NKV = DIAG ? 2 : 4;
+  constexpr int C2 = 16 * XS, WU = BF ? (XS + 4) * 512 : 4096, MINW = XS == 8 ? 4 : 2;   // weight image: 16-byte units
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const pcr_attn_params &p = a.p;
   f32x4 *s_w = reinterpret_cast<f32x4 *>(smem);                   // [16 kb][128 couts][2 halves]: 64 KB
-  f32x4 *s_p0 = reinterpret_cast<f32x4 *>(smem + 16384);          // [64] {w0x, w0y, w0z, b0}
-  float *s_bkv = smem + 16384 + 256;                              // [128]
+  f32x4 *s_p0 = reinterpret_cast<f32x4 *>(smem + 4 * WU);         // [64] {w0x, w0y, w0z, b0}
+  float *s_bkv = smem + 4 * WU + 256;                             // [128]
   float *s_wm = s_bkv + 128;                                      // [64][65] merge weights
   float *s_red = s_wm + D * LD;                                   // [CPG][KVS]
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   {
     const f32x4 *src = reinterpret_cast<const f32x4 *>(BF ? p.wkv_bf : p.wkv);   // (both images are 4096 16-byte units)
-    for (int e = tid; e < 4096; e += 64 * kKvsWaves) s_w[e] = src[e];
+    for (int e = tid; e < WU; e += 64 * kKvsWaves) s_w[e] = src[e];
     for (int e = tid; e < D * D; e += 64 * kKvsWaves) s_wm[(e >> 6) * LD + (e & 63)] = p.wmerge[e];
     if (tid < D) s_p0[tid] = f32x4{p.pos0_w[3 * tid], p.pos0_w[3 * tid + 1], p.pos0_w[3 * tid + 2], p.pos0_b[tid]};
     if (tid < 2 * D) s_bkv[tid] = p.bkv[tid];
@@ -327,7 +330,7 @@ void attn_kv_stream64_kernel(AttnArgs a) {
   const int wpc = nblk < kKvsWaves ? nblk : kKvsWaves;            // waves per cloud (1, 2, 4 or 8: Sk / 32 clamps)
   int wpc2 = 1;
   while (wpc2 * 2 <= wpc) wpc2 *= 2;                              // a power of two ...
-  if (wpc2 < 2) wpc2 = 2;                                         // ... and at most four clouds per round (LDS)
+  if (wpc2 < MINW) wpc2 = MINW;                                   // ... and at most four (two: c2 = 128) clouds per round (LDS)
   const int cpg = kKvsWaves / wpc2;                               // clouds per workgroup round
   const int cslot = wave / wpc2, wsub = wave - cslot * wpc2;      // this wave's cloud slot and rank inside it
   const float inv_sk = 1.0f / (float)p.Sk;
@@ -345,10 +348,10 @@ void attn_kv_stream64_kernel(AttnArgs a) {
       for (int r = 0; r < 16; r++) kv[i][r] = 0.f;
     float ks0 = 0.f, ks1 = 0.f;
     if (live) {
-      const float *feat = p.feat_k + (size_t)b * D * p.Sk;
+      const float *feat = p.feat_k + (size_t)b * C2 * p.Sk;
       const float *xyz = p.xyz_k + (size_t)b * p.Sk * 3;
       const __amdgpu_buffer_rsrc_t rfeat =
-          __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(feat), 0, D * p.Sk * 4, 0x00020000);
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(feat), 0, C2 * p.Sk * 4, 0x00020000);
       for (int blk = wsub; blk < nblk; blk += wpc2) {
         asm volatile("" ::: "memory");   // (the weight reads below stay inside the block loop: hoisted, they are 256 registers)
         const int t = blk * 32 + j;
@@ -389,18 +392,18 @@ void attn_kv_stream64_kernel(AttnArgs a) {
                 acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[4 * kb + i], w[cb][i], acc[cb], 0, 0, 0);
           }
         } else {
-          float xf[32];
+          float xf[8 * XS];
           {
             const int vo = (4 * h * p.Sk + t) * 4;
 #pragma unroll
-            for (int e = 0; e < 32; e++) {
+            for (int e = 0; e < 8 * XS; e++) {
               const int ch = 16 * (e >> 3) + bf_kpos(0, e & 7);   // + 4 h: in the lane offset
               xf[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rfeat, vo, ch * p.Sk * 4, 0));
             }
           }
-          bf16x8 ah[8], al[8];
+          bf16x8 ah[XS + 4], al[XS + 4];
 #pragma unroll
-          for (int s2 = 0; s2 < 4; s2++) {   // hidden channels 16 s2 + bf_kpos(h, .): steps 4 .. 7
+          for (int s2 = 0; s2 < 4; s2++) {   // hidden channels 16 s2 + bf_kpos(h, .): the steps after the features'' 
             float hv[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) {
@@ -408,12 +411,12 @@ void attn_kv_stream64_kernel(AttnArgs a) {
               const float v = w[0] * px + w[1] * py + w[2] * pz + w[3];
               hv[e] = fmaxf(v, 0.f);
             }
-            bf_split8(hv, ah[4 + s2], al[4 + s2], true);
+            bf_split8(hv, ah[XS + s2], al[XS + s2], true);
           }
 #pragma unroll
-          for (int e = 0; e < 32; e++) asm volatile("" : "+v"(xf[e]));   // (the loads land here, see the f32 form)
+          for (int e = 0; e < 8 * XS; e++) asm volatile("" : "+v"(xf[e]));   // (the loads land here, see the f32 form)
 #pragma unroll
-          for (int s2 = 0; s2 < 4; s2++) {
+          for (int s2 = 0; s2 < XS; s2++) {
             float xv[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) xv[e] = xf[8 * s2 + e];
@@ -425,7 +428,7 @@ void attn_kv_stream64_kernel(AttnArgs a) {
             for (int r = 0; r < 16; r++) acc[cb][r] = 0.f;
           const bf16x8 *wb = reinterpret_cast<const bf16x8 *>(s_w) + lane;
 #pragma unroll
-          for (int s2 = 0; s2 < 8; s2++) {
+          for (int s2 = 0; s2 < XS + 4; s2++) {
             bf16x8 wh[4], wl[4];
 #pragma unroll
             for (int cb = 0; cb < 4; cb++) {
@@ -1176,19 +1179,26 @@ static int attn_kv_narrow(const pcr_attn_params *pp, pcr_stream_t stream) {
   a.p.kv_splits = ns;
   dim3 g(pp->B, ns), blk(kThreads);
   hipStream_t st = pcr_s(stream);
-  if (ns == 1 && d == 64 && pp->c2 == 64 && (pp->Sk & 31) == 0 && pp->nhead >= 1 && 64 % pp->nhead == 0) {
+  constexpr bool kBfUnit = kAPrec != 0;
+  const bool bfk = kBfUnit && pp->wkv_bf != nullptr;
+  if (ns == 1 && d == 64 && (pp->c2 == 64 || (pp->c2 == 128 && bfk && pp->Sk >= 128)) && (pp->Sk & 31) == 0 && pp->nhead >= 1 &&
+      64 % pp->nhead == 0) {
     // wave-autonomous form (shape-only choice; an explicit token split keeps the tile kernel)
-    constexpr bool kBfUnit = kAPrec != 0;
-    const bool bf = kBfUnit && pp->wkv_bf != nullptr;
+    const bool bf = bfk;
+    const bool wide = pp->c2 == 128;
     static bool oks = allow_big_lds(attn_kv_stream64_kernel<true, false>) && allow_big_lds(attn_kv_stream64_kernel<false, false>) &&
-                      allow_big_lds(attn_kv_stream64_kernel<true, kBfUnit>) && allow_big_lds(attn_kv_stream64_kernel<false, kBfUnit>);
+                      allow_big_lds(attn_kv_stream64_kernel<true, kBfUnit>) && allow_big_lds(attn_kv_stream64_kernel<false, kBfUnit>) &&
+                      allow_big_lds(attn_kv_stream64_kernel<true, kBfUnit, kBfUnit ? 8 : 4>) &&
+                      allow_big_lds(attn_kv_stream64_kernel<false, kBfUnit, kBfUnit ? 8 : 4>);
     (void)oks;
     const int nblk = pp->Sk >> 5;
     int wpc2 = 1;
     while (wpc2 * 2 <= (nblk < kKvsWaves ? nblk : kKvsWaves)) wpc2 *= 2;
-    if (wpc2 < 2) wpc2 = 2;                                   // (at most four clouds per round: LDS)
+    const int minw = wide ? 4 : 2;
+    if (wpc2 < minw) wpc2 = minw;                             // (at most four / two clouds per round: LDS)
     const int cpg = kKvsWaves / wpc2;
-    const size_t lds_s = (size_t)(16384 + 256 + 128 + 64 * 65 + cpg * (64 * 65 + 64)) * sizeof(float);
+    const size_t wu = bf ? (size_t)((wide ? 8 : 4) + 4) * 512 : 4096;
+    const size_t lds_s = (wu * 4 + 256 + 128 + 64 * 65 + (size_t)cpg * (64 * 65 + 64)) * sizeof(float);
     const long rounds = ((long)pp->B + cpg - 1) / cpg;
     static const int ncu = [] {
       hipDeviceProp_t pr;
@@ -1198,7 +1208,10 @@ static int attn_kv_narrow(const pcr_attn_params *pp, pcr_stream_t stream) {
     }();
     const int gs = (int)(rounds < ncu ? rounds : ncu);        // persistent: one workgroup per CU
     const dim3 gg(gs), bb(64 * kKvsWaves);
-    if (bf) {
+    if (bf && wide) {
+      if (pp->nhead >= 2) hipLaunchKernelGGL((attn_kv_stream64_kernel<true, kBfUnit, kBfUnit ? 8 : 4>), gg, bb, lds_s, st, a);
+      else hipLaunchKernelGGL((attn_kv_stream64_kernel<false, kBfUnit, kBfUnit ? 8 : 4>), gg, bb, lds_s, st, a);
+    } else if (bf) {
       if (pp->nhead >= 2) hipLaunchKernelGGL((attn_kv_stream64_kernel<true, kBfUnit>), gg, bb, lds_s, st, a);
       else hipLaunchKernelGGL((attn_kv_stream64_kernel<false, kBfUnit>), gg, bb, lds_s, st, a);
     } else {

@@ -324,7 +324,7 @@ class AttnPlan:
             ln2_g=_dev32(m.norm2.weight, device), ln2_b=_dev32(m.norm2.bias, device))
         if d <= 128:
             # the same matrices as bf16 hi / lo images: the dense phases of both kernels in "bf16x3" / "bf16" mode
-            if d == 64 and self.c2 == 64:       # the wave-autonomous kv kernel's shape: its projection in split bf16 too
+            if d == 64 and self.c2 in (64, 128):   # the wave-autonomous kv kernel's shapes: its projection in split bf16 too
                 self.t["wkv_bf"] = pack_weight_bf(wkv.float(), device)
             self.t.update(wq_bf=pack_weight_bf(wq.float(), device),
                           wmlp0_bf=pack_weight_bf(m.mlp[0].weight, device), wmlp2_bf=pack_weight_bf(m.mlp[2].weight, device))
