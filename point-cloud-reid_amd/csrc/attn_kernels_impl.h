@@ -792,17 +792,19 @@ __global__ __launch_bounds__(kThreads) void attn_apply_kernel(AttnArgs a) {
 constexpr int kApsWaves = 8;
 // C1S: 16-channel steps of the query features (c1 = 64 or 32; 32: the FP_SA blocks, no residual); CF: trailing 64 -> 128
 // conv (cov_final), its weight image read from global memory / L2 like M
-template <bool QPOS, int C1S, bool CF>
+// NOB: 32-channel blocks of the block's output (cout = 64, or 128: no residual, no trailing conv)
+template <bool QPOS, int C1S, bool CF, int NOB = 2>
 __global__ __launch_bounds__(64 * kApsWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void attn_apply_stream64_kernel(AttnArgs a) {
   static_assert(!QPOS || C1S == 4, "q_pos needs c1 == d");
+  static_assert(NOB == 2 || (NOB == 4 && !CF), "cout = 128 has no trailing conv");
   constexpr int D = 64, C1 = 16 * C1S, SQ = C1S + (QPOS ? 4 : 0), S0 = C1S + 4, NX = 8 * C1S;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const pcr_attn_params &p = a.p;
   bf16x8 *s_wq = reinterpret_cast<bf16x8 *>(smem);   // [SQ][2 cb][hi, lo][64]
   bf16x8 *s_w0 = s_wq + SQ * 256;                    // [S0][4][2][64]
-  bf16x8 *s_w2 = s_w0 + S0 * 512;                    // [8][2][2][64]
-  float *s_c = reinterpret_cast<float *>(s_w2 + 2048);   // bq | ln1 g | ln1 b | ln2 g | ln2 b : 5 x 64 | bfinal 128
+  bf16x8 *s_w2 = s_w0 + S0 * 512;                    // [8][NOB][2][64]
+  float *s_c = reinterpret_cast<float *>(s_w2 + NOB * 1024);   // bq | ln1 g | ln1 b : 3 x 64 | ln2 g | ln2 b : 2 x 32 NOB | (bfinal 128)
   f32x4 *s_p0 = reinterpret_cast<f32x4 *>(s_c + 448);    // [64] {w0x, w0y, w0z, b0}
   float *s_ks = reinterpret_cast<float *>(s_p0 + 64);    // [waves][64] key sums of the wave's current cloud
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
@@ -813,14 +815,17 @@ void attn_apply_stream64_kernel(AttnArgs a) {
     f32x4 *dq = reinterpret_cast<f32x4 *>(s_wq), *d0 = reinterpret_cast<f32x4 *>(s_w0), *d2 = reinterpret_cast<f32x4 *>(s_w2);
     for (int e = tid; e < SQ * 256; e += 64 * kApsWaves) dq[e] = wq[e];
     for (int e = tid; e < S0 * 512; e += 64 * kApsWaves) d0[e] = w0[e];
-    for (int e = tid; e < 2048; e += 64 * kApsWaves) d2[e] = w2[e];
+    for (int e = tid; e < NOB * 1024; e += 64 * kApsWaves) d2[e] = w2[e];
     if (tid < D) {
       s_c[tid] = p.bq[tid];
       s_c[64 + tid] = p.ln1_g[tid];
       s_c[128 + tid] = p.ln1_b[tid];
-      s_c[192 + tid] = p.ln2_g[tid];
-      s_c[256 + tid] = p.ln2_b[tid];
+
       if (QPOS) s_p0[tid] = f32x4{p.pos0_w[3 * tid], p.pos0_w[3 * tid + 1], p.pos0_w[3 * tid + 2], p.pos0_b[tid]};
+    }
+    if (tid < 32 * NOB) {
+      s_c[192 + tid] = p.ln2_g[tid];
+      s_c[192 + 32 * NOB + tid] = p.ln2_b[tid];
     }
     if (CF && tid < 128) s_c[320 + tid] = p.bfinal[tid];
   }
@@ -983,26 +988,27 @@ void attn_apply_stream64_kernel(AttnArgs a) {
       for (int cb = 0; cb < 2; cb++) m[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml[s2][cb], ch_[s2], m[cb], 0, 0, 0);
     }
     // ---- LayerNorm over the 64 channels of a token (two passes, eps inside the sqrt: tile_layernorm's arithmetic)
-    auto layernorm = [&](f32x16 (&v)[2], const float *gam, const float *bet) __attribute__((always_inline)) {
+    auto layernorm = [&](auto &v, auto nb_tag, const float *gam, const float *bet) __attribute__((always_inline)) {
+      constexpr int NB = decltype(nb_tag)::value;
       float sm = 0.f;
 #pragma unroll
-      for (int cb = 0; cb < 2; cb++)
+      for (int cb = 0; cb < NB; cb++)
 #pragma unroll
         for (int r = 0; r < 16; r++) sm += v[cb][r];
       sm += __shfl_xor(sm, 32, 64);
-      const float mean = sm / 64.0f;
+      const float mean = sm / (32.0f * NB);
       float vr = 0.f;
 #pragma unroll
-      for (int cb = 0; cb < 2; cb++)
+      for (int cb = 0; cb < NB; cb++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const float dlt = v[cb][r] - mean;
           vr += dlt * dlt;
         }
       vr += __shfl_xor(vr, 32, 64);
-      const float inv = 1.0f / sqrtf(vr / 64.0f + 1e-5f);
+      const float inv = 1.0f / sqrtf(vr / (32.0f * NB) + 1e-5f);
 #pragma unroll
-      for (int cb = 0; cb < 2; cb++)
+      for (int cb = 0; cb < NB; cb++)
 #pragma unroll
         for (int g = 0; g < 4; g++) {
           const f32x4 gv = cvec(gam, cb, g), bv = cvec(bet, cb, g);
@@ -1010,7 +1016,7 @@ void attn_apply_stream64_kernel(AttnArgs a) {
           for (int qq = 0; qq < 4; qq++) v[cb][4 * g + qq] = (v[cb][4 * g + qq] - mean) * inv * gv[qq] + bv[qq];
         }
     };
-    layernorm(m, s_c + 64, s_c + 128);
+    layernorm(m, std::integral_constant<int, 2>{}, s_c + 64, s_c + 128);
     // ---- FFN0: relu(W0 [x ; msg]) (128 couts), operands: x re-converted from its f32 registers, msg from m
 #pragma unroll
     for (int s2 = 0; s2 < C1S; s2++) {
@@ -1054,31 +1060,31 @@ void attn_apply_stream64_kernel(AttnArgs a) {
       for (int G = 0; G < 2; G++) to_ops(f[cb], G, bh[2 * cb + G], bl[2 * cb + G]);
     }
     // ---- FFN1 (64 couts), LayerNorm, residual, store
-    f32x16 o[2];
+    f32x16 o[NOB];
 #pragma unroll
-    for (int cb = 0; cb < 2; cb++)
+    for (int cb = 0; cb < NOB; cb++)
 #pragma unroll
       for (int r = 0; r < 16; r++) o[cb][r] = 0.f;
     {
       const bf16x8 *wb = s_w2 + lane;
 #pragma unroll
       for (int s2 = 0; s2 < 8; s2++) {
-        bf16x8 wh[2], wl[2];
+        bf16x8 wh[NOB], wl[NOB];
 #pragma unroll
-        for (int cb = 0; cb < 2; cb++) {
-          wh[cb] = wb[((s2 * 2 + cb) * 2) * 64];
-          wl[cb] = wb[((s2 * 2 + cb) * 2 + 1) * 64];
+        for (int cb = 0; cb < NOB; cb++) {
+          wh[cb] = wb[((s2 * NOB + cb) * 2) * 64];
+          wl[cb] = wb[((s2 * NOB + cb) * 2 + 1) * 64];
         }
 #pragma unroll
-        for (int cb = 0; cb < 2; cb++) o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bh[s2], o[cb], 0, 0, 0);
+        for (int cb = 0; cb < NOB; cb++) o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bh[s2], o[cb], 0, 0, 0);
 #pragma unroll
-        for (int cb = 0; cb < 2; cb++) o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bl[s2], o[cb], 0, 0, 0);
+        for (int cb = 0; cb < NOB; cb++) o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bl[s2], o[cb], 0, 0, 0);
 #pragma unroll
-        for (int cb = 0; cb < 2; cb++) o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], bh[s2], o[cb], 0, 0, 0);
+        for (int cb = 0; cb < NOB; cb++) o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], bh[s2], o[cb], 0, 0, 0);
       }
     }
-    layernorm(o, s_c + 192, s_c + 256);
-    if constexpr (C1S == 4) {
+    layernorm(o, std::integral_constant<int, NOB>{}, s_c + 192, s_c + 192 + 32 * NOB);
+    if constexpr (C1S == 4 && NOB == 2) {
       if (p.residual) {
 #pragma unroll
         for (int cb = 0; cb < 2; cb++)
@@ -1087,9 +1093,10 @@ void attn_apply_stream64_kernel(AttnArgs a) {
       }
     }
     if constexpr (!CF) {
-      const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)b * D * p.Lq, 0, D * p.Lq * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rout =
+          __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)b * (32 * NOB) * p.Lq, 0, 32 * NOB * p.Lq * 4, 0x00020000);
 #pragma unroll
-      for (int e = 0; e < 32; e++) {
+      for (int e = 0; e < 16 * NOB; e++) {
         const int ch = 16 * (e >> 3) + bf_kpos(0, e & 7);
         const float v = o[e >> 4][e & 15];   // (a copy: __builtin_bit_cast of a vector ELEMENT reads element 0)
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, vo, ch * p.Lq * 4, 0);
@@ -1250,11 +1257,15 @@ static int attn_apply_launch(const pcr_attn_params *pp, pcr_stream_t stream) {
   dim3 g((p.Lq + T - 1) / T, p.B), blk(kThreads);
   hipStream_t st = pcr_s(stream);
 #if PCR_ATTN_PREC != 0
-  if (p.d == 64 && (p.c1 == 64 || (p.c1 == 32 && !p.q_pos && !p.residual)) && p.cout == 64 && (p.cfinal == 0 || p.cfinal == 128) &&
-      (p.Lq & 31) == 0 && (p.nhead == 1 || p.nhead == 2 || p.nhead == 4)) {
+  const size_t aps_lds = (size_t)(((p.c1 >> 4) + (p.q_pos ? 4 : 0)) * 256 + ((p.c1 >> 4) + 4) * 512 + (p.cout >> 5) * 1024) * 16 +
+                         (size_t)(448 + 256 + 64 * kApsWaves) * sizeof(float);
+  if (p.d == 64 && (p.c1 == 64 || (p.c1 == 32 && !p.q_pos && !p.residual)) &&
+      ((p.cout == 64 && (p.cfinal == 0 || p.cfinal == 128)) || (p.cout == 128 && !p.cfinal && !p.residual && p.c1 == 64)) &&
+      (p.Lq & 31) == 0 && (p.nhead == 1 || p.nhead == 2 || p.nhead == 4) && aps_lds <= (size_t)kMaxDynLds) {
     // wave-autonomous form (shape-only choice)
     const int c1s = p.c1 >> 4, sq = c1s + (p.q_pos ? 4 : 0), s0 = c1s + 4;
-    const size_t lds_s = (size_t)(sq * 256 + s0 * 512 + 2048) * 16 + (size_t)(448 + 256 + 64 * kApsWaves) * sizeof(float);
+    const int nob = p.cout >> 5;
+    const size_t lds_s = (size_t)(sq * 256 + s0 * 512 + nob * 1024) * 16 + (size_t)(448 + 256 + 64 * kApsWaves) * sizeof(float);
     const long nitem = (long)p.B * (p.Lq >> 5);
     const long nwg = (nitem + kApsWaves - 1) / kApsWaves;
     static const int ncu = [] {
@@ -1271,7 +1282,12 @@ static int attn_apply_launch(const pcr_attn_params *pp, pcr_stream_t stream) {
     hipLaunchKernelGGL((attn_apply_stream64_kernel<QP, C1Sv, CFv>), gg, bb, lds_s, st, a); \
   } while (0)
     const bool cf = p.cfinal != 0;
-    if (p.c1 == 32) { if (cf) PCR_APS(false, 2, true); else PCR_APS(false, 2, false); }
+    if (nob == 4) {
+      static bool ok4 = allow_big_lds(attn_apply_stream64_kernel<true, 4, false, 4>) && allow_big_lds(attn_apply_stream64_kernel<false, 4, false, 4>);
+      (void)ok4;
+      if (p.q_pos) hipLaunchKernelGGL((attn_apply_stream64_kernel<true, 4, false, 4>), gg, bb, lds_s, st, a);
+      else hipLaunchKernelGGL((attn_apply_stream64_kernel<false, 4, false, 4>), gg, bb, lds_s, st, a);
+    } else if (p.c1 == 32) { if (cf) PCR_APS(false, 2, true); else PCR_APS(false, 2, false); }
     else if (p.q_pos) { if (cf) PCR_APS(true, 4, true); else PCR_APS(true, 4, false); }
     else { if (cf) PCR_APS(false, 4, true); else PCR_APS(false, 4, false); }
 #undef PCR_APS
