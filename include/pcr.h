@@ -278,6 +278,10 @@ typedef struct pcr_attn_params {
   /* precision != PCR_PREC_F32, d = c2 = 64, Sk % 32 == 0 (the wave-autonomous kv kernel): pcr_pack_weight_bf16x2_f32
    * image of the fused K / V projection wkv -- the projection then runs as split bf16 too.  NULL: f32 projection. */
   const float *wkv_bf;
+  /* c1 not a multiple of 16 (the first FP_SA block: c1 = 3): pcr_pack_weight_bf16x2_f32 image of mlp[0]'s weight with the
+   * query-feature columns padded to a whole 16-channel step, [W[:, :c1] | 0 | W[:, c1:]] -- the wave-autonomous apply
+   * kernel's contraction steps are 16 channels wide.  NULL: the tile kernel. */
+  const float *wmlp0_bf_xpad;
 } pcr_attn_params;
 long pcr_attn_kv_floats(int d);
 int pcr_attn_kv_splits(int B, int Sk, int d);

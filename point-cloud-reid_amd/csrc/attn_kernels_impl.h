@@ -793,11 +793,12 @@ constexpr int kApsWaves = 8;
 // C1S: 16-channel steps of the query features (c1 = 64 or 32; 32: the FP_SA blocks, no residual); CF: trailing 64 -> 128
 // conv (cov_final), its weight image read from global memory / L2 like M
 // NOB: 32-channel blocks of the block's output (cout = 64, or 128: no residual, no trailing conv)
-template <bool QPOS, int C1S, bool CF, int NOB = 2>
+// (CF as an int: 32-channel blocks of the trailing conv's output, 0 = none -- 64 -> 128 and the first FP_SA block's 32 -> 64)
+template <bool QPOS, int C1S, int CF, int NOB = 2>
 __global__ __launch_bounds__(64 * kApsWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void attn_apply_stream64_kernel(AttnArgs a) {
   static_assert(!QPOS || C1S == 4, "q_pos needs c1 == d");
-  static_assert(NOB == 2 || (NOB == 4 && !CF), "cout = 128 has no trailing conv");
+  static_assert(NOB <= 2 || (NOB == 4 && !CF), "cout = 128 has no trailing conv");
   constexpr int D = 64, C1 = 16 * C1S, SQ = C1S + (QPOS ? 4 : 0), S0 = C1S + 4, NX = 8 * C1S;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const pcr_attn_params &p = a.p;
@@ -810,7 +811,9 @@ void attn_apply_stream64_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   {
-    const f32x4 *wq = reinterpret_cast<const f32x4 *>(p.wq), *w0 = reinterpret_cast<const f32x4 *>(p.wmlp0),
+    // (c1 not a multiple of 16: the padded image of mlp[0]; the packer pads wq's single step with zero columns itself)
+    const f32x4 *wq = reinterpret_cast<const f32x4 *>(p.wq),
+                *w0 = reinterpret_cast<const f32x4 *>((p.c1 & 15) ? p.wmlp0_bf_xpad : p.wmlp0),
                 *w2 = reinterpret_cast<const f32x4 *>(p.wmlp2);
     f32x4 *dq = reinterpret_cast<f32x4 *>(s_wq), *d0 = reinterpret_cast<f32x4 *>(s_w0), *d2 = reinterpret_cast<f32x4 *>(s_w2);
     for (int e = tid; e < SQ * 256; e += 64 * kApsWaves) dq[e] = wq[e];
@@ -827,7 +830,7 @@ void attn_apply_stream64_kernel(AttnArgs a) {
       s_c[192 + tid] = p.ln2_g[tid];
       s_c[192 + 32 * NOB + tid] = p.ln2_b[tid];
     }
-    if (CF && tid < 128) s_c[320 + tid] = p.bfinal[tid];
+    if (CF && tid < 32 * CF) s_c[320 + tid] = p.bfinal[tid];
   }
   __syncthreads();
   const int nblk = p.Lq >> 5;
@@ -854,7 +857,7 @@ void attn_apply_stream64_kernel(AttnArgs a) {
     const float *kvp = p.kv + kb_ * ((size_t)D * D + D);
     const int t = blk * 32 + j;
     const __amdgpu_buffer_rsrc_t rfeat = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(p.feat_q + bq_ * C1 * p.Lq), 0, C1 * p.Lq * 4, 0x00020000);
+        const_cast<float *>(p.feat_q + bq_ * p.c1 * p.Lq), 0, p.c1 * p.Lq * 4, 0x00020000);   // (channels past c1 read as 0)
     const int vo = (4 * h * p.Lq + t) * 4;
     float xf[NX];
 #pragma unroll
@@ -1102,35 +1105,36 @@ void attn_apply_stream64_kernel(AttnArgs a) {
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, vo, ch * p.Lq * 4, 0);
       }
     } else {
-      // ---- cov_final: 64 -> 128 with bias, A operands from the global image
+      // ---- cov_final (32 NOB -> 32 CF channels, bias), A operands from the global image
 #pragma unroll
-      for (int cb = 0; cb < 2; cb++)
+      for (int cb = 0; cb < NOB; cb++)
 #pragma unroll
         for (int G = 0; G < 2; G++) to_ops(o[cb], G, bh[2 * cb + G], bl[2 * cb + G]);
-      f32x16 fo[4];
+      f32x16 fo[CF ? CF : 1];
 #pragma unroll
-      for (int cb = 0; cb < 4; cb++)
+      for (int cb = 0; cb < CF; cb++)
 #pragma unroll
         for (int r = 0; r < 16; r++) fo[cb][r] = 0.f;
       const bf16x8 *wb = reinterpret_cast<const bf16x8 *>(p.wfinal) + lane;
 #pragma unroll
-      for (int s2 = 0; s2 < 4; s2++) {
-        bf16x8 wh[4], wl[4];
+      for (int s2 = 0; s2 < 2 * NOB; s2++) {
+        bf16x8 wh[CF ? CF : 1], wl[CF ? CF : 1];
 #pragma unroll
-        for (int cb = 0; cb < 4; cb++) {
-          wh[cb] = wb[((s2 * 4 + cb) * 2) * 64];
-          wl[cb] = wb[((s2 * 4 + cb) * 2 + 1) * 64];
+        for (int cb = 0; cb < CF; cb++) {
+          wh[cb] = wb[((s2 * CF + cb) * 2) * 64];
+          wl[cb] = wb[((s2 * CF + cb) * 2 + 1) * 64];
         }
 #pragma unroll
-        for (int cb = 0; cb < 4; cb++) fo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bh[s2], fo[cb], 0, 0, 0);
+        for (int cb = 0; cb < CF; cb++) fo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bh[s2], fo[cb], 0, 0, 0);
 #pragma unroll
-        for (int cb = 0; cb < 4; cb++) fo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bl[s2], fo[cb], 0, 0, 0);
+        for (int cb = 0; cb < CF; cb++) fo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bl[s2], fo[cb], 0, 0, 0);
 #pragma unroll
-        for (int cb = 0; cb < 4; cb++) fo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], bh[s2], fo[cb], 0, 0, 0);
+        for (int cb = 0; cb < CF; cb++) fo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], bh[s2], fo[cb], 0, 0, 0);
       }
-      const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)b * 128 * p.Lq, 0, 128 * p.Lq * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rout =
+          __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)b * (32 * CF) * p.Lq, 0, 32 * CF * p.Lq * 4, 0x00020000);
 #pragma unroll
-      for (int cb = 0; cb < 4; cb++)
+      for (int cb = 0; cb < CF; cb++)
 #pragma unroll
         for (int g = 0; g < 4; g++) {
           const f32x4 bv = cvec(s_c + 320, cb, g);
@@ -1257,13 +1261,18 @@ static int attn_apply_launch(const pcr_attn_params *pp, pcr_stream_t stream) {
   dim3 g((p.Lq + T - 1) / T, p.B), blk(kThreads);
   hipStream_t st = pcr_s(stream);
 #if PCR_ATTN_PREC != 0
-  const size_t aps_lds = (size_t)(((p.c1 >> 4) + (p.q_pos ? 4 : 0)) * 256 + ((p.c1 >> 4) + 4) * 512 + (p.cout >> 5) * 1024) * 16 +
+  const int aps_c1s = (p.c1 + 15) >> 4;
+  const size_t aps_lds = (size_t)((aps_c1s + (p.q_pos ? 4 : 0)) * 256 + (aps_c1s + 4) * 512 + (p.cout >> 5) * 1024) * 16 +
                          (size_t)(448 + 256 + 64 * kApsWaves) * sizeof(float);
-  if (p.d == 64 && (p.c1 == 64 || (p.c1 == 32 && !p.q_pos && !p.residual)) &&
-      ((p.cout == 64 && (p.cfinal == 0 || p.cfinal == 128)) || (p.cout == 128 && !p.cfinal && !p.residual && p.c1 == 64)) &&
+  // shapes: (c1 = 64 | 32 | < 16 with the padded mlp[0] image) x (cout = 64 [+ cov_final 128] | cout = 128 | cout = 32 + cov_final 64)
+  const bool aps_in = p.c1 == 64 || ((p.c1 == 32 || (p.c1 < 16 && pp->wmlp0_bf_xpad)) && !p.q_pos && !p.residual);
+  const bool aps_out = (p.cout == 64 && (p.cfinal == 0 || p.cfinal == 128) && p.c1 >= 32) ||
+                       (p.cout == 128 && !p.cfinal && !p.residual && p.c1 == 64) ||
+                       (p.cout == 32 && p.cfinal == 64 && !p.residual && p.c1 < 16);
+  if (p.d == 64 && aps_in && aps_out &&
       (p.Lq & 31) == 0 && (p.nhead == 1 || p.nhead == 2 || p.nhead == 4) && aps_lds <= (size_t)kMaxDynLds) {
     // wave-autonomous form (shape-only choice)
-    const int c1s = p.c1 >> 4, sq = c1s + (p.q_pos ? 4 : 0), s0 = c1s + 4;
+    const int c1s = aps_c1s, sq = c1s + (p.q_pos ? 4 : 0), s0 = c1s + 4;
     const int nob = p.cout >> 5;
     const size_t lds_s = (size_t)(sq * 256 + s0 * 512 + nob * 1024) * 16 + (size_t)(448 + 256 + 64 * kApsWaves) * sizeof(float);
     const long nitem = (long)p.B * (p.Lq >> 5);
@@ -1283,13 +1292,17 @@ static int attn_apply_launch(const pcr_attn_params *pp, pcr_stream_t stream) {
   } while (0)
     const bool cf = p.cfinal != 0;
     if (nob == 4) {
-      static bool ok4 = allow_big_lds(attn_apply_stream64_kernel<true, 4, false, 4>) && allow_big_lds(attn_apply_stream64_kernel<false, 4, false, 4>);
+      static bool ok4 = allow_big_lds(attn_apply_stream64_kernel<true, 4, 0, 4>) && allow_big_lds(attn_apply_stream64_kernel<false, 4, 0, 4>);
       (void)ok4;
-      if (p.q_pos) hipLaunchKernelGGL((attn_apply_stream64_kernel<true, 4, false, 4>), gg, bb, lds_s, st, a);
-      else hipLaunchKernelGGL((attn_apply_stream64_kernel<false, 4, false, 4>), gg, bb, lds_s, st, a);
-    } else if (p.c1 == 32) { if (cf) PCR_APS(false, 2, true); else PCR_APS(false, 2, false); }
-    else if (p.q_pos) { if (cf) PCR_APS(true, 4, true); else PCR_APS(true, 4, false); }
-    else { if (cf) PCR_APS(false, 4, true); else PCR_APS(false, 4, false); }
+      if (p.q_pos) hipLaunchKernelGGL((attn_apply_stream64_kernel<true, 4, 0, 4>), gg, bb, lds_s, st, a);
+      else hipLaunchKernelGGL((attn_apply_stream64_kernel<false, 4, 0, 4>), gg, bb, lds_s, st, a);
+    } else if (p.c1 < 16) {
+      static bool ok1 = allow_big_lds(attn_apply_stream64_kernel<false, 1, 2, 1>);
+      (void)ok1;
+      hipLaunchKernelGGL((attn_apply_stream64_kernel<false, 1, 2, 1>), gg, bb, lds_s, st, a);
+    } else if (p.c1 == 32) { if (cf) PCR_APS(false, 2, 4); else PCR_APS(false, 2, 0); }
+    else if (p.q_pos) { if (cf) PCR_APS(true, 4, 4); else PCR_APS(true, 4, 0); }
+    else { if (cf) PCR_APS(false, 4, 4); else PCR_APS(false, 4, 0); }
 #undef PCR_APS
     PCR_CHECK_LAUNCH();
     return PCR_OK;

@@ -110,7 +110,8 @@ class AttnParams(ctypes.Structure):
                 ("kv", c_float_p), ("out", c_float_p),
                 ("precision", ctypes.c_int),
                 ("wq_bf", c_float_p), ("wmlp0_bf", c_float_p), ("wmlp2_bf", c_float_p), ("wfinal_bf", c_float_p),
-                ("kv_splits", ctypes.c_int), ("kv_part", c_float_p), ("wkv_bf", c_float_p)]
+                ("kv_splits", ctypes.c_int), ("kv_part", c_float_p), ("wkv_bf", c_float_p),
+                ("wmlp0_bf_xpad", c_float_p)]
 
 
 class HeadParams(ctypes.Structure):
@@ -326,6 +327,10 @@ class AttnPlan:
             # the same matrices as bf16 hi / lo images: the dense phases of both kernels in "bf16x3" / "bf16" mode
             if d == 64 and self.c2 in (64, 128):   # the wave-autonomous kv kernel's shapes: its projection in split bf16 too
                 self.t["wkv_bf"] = pack_weight_bf(wkv.float(), device)
+            if d == 64 and self.c1 % 16:        # c1 = 3: mlp[0] with the feature columns padded to a 16-channel step
+                w0 = m.mlp[0].weight.detach().float().cpu()
+                pad = torch.zeros(w0.shape[0], 16 * ((self.c1 + 15) // 16) - self.c1)
+                self.t["wmlp0_bf_xpad"] = pack_weight_bf(torch.cat([w0[:, :self.c1], pad, w0[:, self.c1:]], dim=1), device)
             self.t.update(wq_bf=pack_weight_bf(wq.float(), device),
                           wmlp0_bf=pack_weight_bf(m.mlp[0].weight, device), wmlp2_bf=pack_weight_bf(m.mlp[2].weight, device))
         if d > 128:
