@@ -794,18 +794,20 @@ constexpr int kApsWaves = 8;
 // conv (cov_final), its weight image read from global memory / L2 like M
 // NOB: 32-channel blocks of the block's output (cout = 64, or 128: no residual, no trailing conv)
 // (CF as an int: 32-channel blocks of the trailing conv's output, 0 = none -- 64 -> 128 and the first FP_SA block's 32 -> 64)
-template <bool QPOS, int C1S, int CF, int NOB = 2>
+// ND: d_model / 32 (2: d = 64; 1: d = 32, the SA1 self-attention)
+template <bool QPOS, int C1S, int CF, int NOB = 2, int ND = 2>
 __global__ __launch_bounds__(64 * kApsWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void attn_apply_stream64_kernel(AttnArgs a) {
-  static_assert(!QPOS || C1S == 4, "q_pos needs c1 == d");
+  static_assert(!QPOS || C1S == 2 * ND, "q_pos needs c1 == d");
   static_assert(NOB <= 2 || (NOB == 4 && !CF), "cout = 128 has no trailing conv");
-  constexpr int D = 64, C1 = 16 * C1S, SQ = C1S + (QPOS ? 4 : 0), S0 = C1S + 4, NX = 8 * C1S;
+  constexpr int D = 32 * ND, SD = 2 * ND;   // d_model, its 16-channel steps
+  constexpr int SQ = C1S + (QPOS ? SD : 0), S0 = C1S + SD, NX = 8 * C1S;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const pcr_attn_params &p = a.p;
-  bf16x8 *s_wq = reinterpret_cast<bf16x8 *>(smem);   // [SQ][2 cb][hi, lo][64]
-  bf16x8 *s_w0 = s_wq + SQ * 256;                    // [S0][4][2][64]
-  bf16x8 *s_w2 = s_w0 + S0 * 512;                    // [8][NOB][2][64]
-  float *s_c = reinterpret_cast<float *>(s_w2 + NOB * 1024);   // bq | ln1 g | ln1 b : 3 x 64 | ln2 g | ln2 b : 2 x 32 NOB | (bfinal 128)
+  bf16x8 *s_wq = reinterpret_cast<bf16x8 *>(smem);   // [SQ][ND cb][hi, lo][64]
+  bf16x8 *s_w0 = s_wq + SQ * ND * 128;               // [S0][2 ND][2][64]
+  bf16x8 *s_w2 = s_w0 + S0 * ND * 256;               // [4 ND][NOB][2][64]
+  float *s_c = reinterpret_cast<float *>(s_w2 + ND * NOB * 512);   // bq | ln1 g | ln1 b : 3 x 64 | ln2 g | ln2 b : 2 x 32 NOB | (bfinal 128)
   f32x4 *s_p0 = reinterpret_cast<f32x4 *>(s_c + 448);    // [64] {w0x, w0y, w0z, b0}
   float *s_ks = reinterpret_cast<float *>(s_p0 + 64);    // [waves][64] key sums of the wave's current cloud
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
@@ -816,9 +818,9 @@ void attn_apply_stream64_kernel(AttnArgs a) {
                 *w0 = reinterpret_cast<const f32x4 *>((p.c1 & 15) ? p.wmlp0_bf_xpad : p.wmlp0),
                 *w2 = reinterpret_cast<const f32x4 *>(p.wmlp2);
     f32x4 *dq = reinterpret_cast<f32x4 *>(s_wq), *d0 = reinterpret_cast<f32x4 *>(s_w0), *d2 = reinterpret_cast<f32x4 *>(s_w2);
-    for (int e = tid; e < SQ * 256; e += 64 * kApsWaves) dq[e] = wq[e];
-    for (int e = tid; e < S0 * 512; e += 64 * kApsWaves) d0[e] = w0[e];
-    for (int e = tid; e < NOB * 1024; e += 64 * kApsWaves) d2[e] = w2[e];
+    for (int e = tid; e < SQ * ND * 128; e += 64 * kApsWaves) dq[e] = wq[e];
+    for (int e = tid; e < S0 * ND * 256; e += 64 * kApsWaves) d0[e] = w0[e];
+    for (int e = tid; e < ND * NOB * 512; e += 64 * kApsWaves) d2[e] = w2[e];
     if (tid < D) {
       s_c[tid] = p.bq[tid];
       s_c[64 + tid] = p.ln1_g[tid];
@@ -865,13 +867,13 @@ void attn_apply_stream64_kernel(AttnArgs a) {
       const int ch = 16 * (e >> 3) + bf_kpos(0, e & 7);   // + 4 h: in the lane offset
       xf[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rfeat, vo, ch * p.Lq * 4, 0));
     }
-    ksw[lane] = kvp[(size_t)D * D + lane];
-    bf16x8 bh[8], bl[8];
+    if (lane < D) ksw[lane] = kvp[(size_t)D * D + lane];
+    bf16x8 bh[4 * ND], bl[4 * ND];
     if constexpr (QPOS) {
       const float *xyz = p.xyz_q + (bq_ * p.Lq + t) * 3;
       const float px = xyz[0], py = xyz[1], pz = xyz[2];
 #pragma unroll
-      for (int s2 = 0; s2 < 4; s2++) {
+      for (int s2 = 0; s2 < SD; s2++) {
         float hv[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) {
@@ -879,7 +881,7 @@ void attn_apply_stream64_kernel(AttnArgs a) {
           const float v = w[0] * px + w[1] * py + w[2] * pz + w[3];
           hv[e] = fmaxf(v, 0.f);
         }
-        bf_split8(hv, bh[4 + s2], bl[4 + s2], true);
+        bf_split8(hv, bh[C1S + s2], bl[C1S + s2], true);
       }
     }
 #pragma unroll
@@ -892,48 +894,48 @@ void attn_apply_stream64_kernel(AttnArgs a) {
       bf_split8(xv, bh[s2], bl[s2], true);
     }
     // ---- Q = elu(Wq [x ; h] + bq) + 1
-    f32x16 q[2];
+    f32x16 q[ND];
 #pragma unroll
-    for (int cb = 0; cb < 2; cb++)
+    for (int cb = 0; cb < ND; cb++)
 #pragma unroll
       for (int r = 0; r < 16; r++) q[cb][r] = 0.f;
     {
       const bf16x8 *wb = s_wq + lane;
 #pragma unroll
       for (int s2 = 0; s2 < SQ; s2++) {
-        bf16x8 wh[2], wl[2];
+        bf16x8 wh[ND], wl[ND];
 #pragma unroll
-        for (int cb = 0; cb < 2; cb++) {
-          wh[cb] = wb[((s2 * 2 + cb) * 2) * 64];
-          wl[cb] = wb[((s2 * 2 + cb) * 2 + 1) * 64];
+        for (int cb = 0; cb < ND; cb++) {
+          wh[cb] = wb[((s2 * ND + cb) * 2) * 64];
+          wl[cb] = wb[((s2 * ND + cb) * 2 + 1) * 64];
         }
 #pragma unroll
-        for (int cb = 0; cb < 2; cb++) q[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bh[s2], q[cb], 0, 0, 0);
+        for (int cb = 0; cb < ND; cb++) q[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bh[s2], q[cb], 0, 0, 0);
 #pragma unroll
-        for (int cb = 0; cb < 2; cb++) q[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bl[s2], q[cb], 0, 0, 0);
+        for (int cb = 0; cb < ND; cb++) q[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bl[s2], q[cb], 0, 0, 0);
 #pragma unroll
-        for (int cb = 0; cb < 2; cb++) q[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], bh[s2], q[cb], 0, 0, 0);
+        for (int cb = 0; cb < ND; cb++) q[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], bh[s2], q[cb], 0, 0, 0);
       }
     }
     // the message-phase A operands (the cloud's matrix M): requested now, used after the normaliser
-    bf16x8 mh[4][2], ml[4][2];
+    bf16x8 mh[SD][ND], ml[SD][ND];
     {
       const bf16x8 *mb = reinterpret_cast<const bf16x8 *>(kvp) + lane;
 #pragma unroll
-      for (int s2 = 0; s2 < 4; s2++)
+      for (int s2 = 0; s2 < SD; s2++)
 #pragma unroll
-        for (int cb = 0; cb < 2; cb++) {
-          mh[s2][cb] = mb[((s2 * 2 + cb) * 2) * 64];
-          ml[s2][cb] = mb[((s2 * 2 + cb) * 2 + 1) * 64];
+        for (int cb = 0; cb < ND; cb++) {
+          mh[s2][cb] = mb[((s2 * ND + cb) * 2) * 64];
+          ml[s2][cb] = mb[((s2 * ND + cb) * 2 + 1) * 64];
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the wave's own key-sum strip: written above, read below)
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // z[head][token] = Q_head . ksum_head; partial sums per 16-channel group (cb, G), then by head width
-    float z16[2][2];
+    float z16[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-    for (int cb = 0; cb < 2; cb++)
+    for (int cb = 0; cb < ND; cb++)
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         const f32x4 bqv = cvec(s_c, cb, g), ksv = cvec(ksw, cb, g);
@@ -954,7 +956,7 @@ void attn_apply_stream64_kernel(AttnArgs a) {
         za += zb; zb = za;
         zc += zd; zd = zc;
       }
-      if (dh >= 64) {
+      if (ND == 2 && dh >= 64) {
         za += zc; zb = za; zc = za; zd = za;
       }
       za += __shfl_xor(za, 32, 64);
@@ -967,28 +969,28 @@ void attn_apply_stream64_kernel(AttnArgs a) {
       zs[1][1] = (1.0f / (zd + 1e-6f)) * skf;
     }
 #pragma unroll
-    for (int cb = 0; cb < 2; cb++)
+    for (int cb = 0; cb < ND; cb++)
 #pragma unroll
       for (int r = 0; r < 16; r++) q[cb][r] *= zs[cb][r >> 3];
     // ---- message = M Q'
-    bf16x8 ch_[4], cl_[4];
+    bf16x8 ch_[SD], cl_[SD];
 #pragma unroll
-    for (int cb = 0; cb < 2; cb++)
+    for (int cb = 0; cb < ND; cb++)
 #pragma unroll
       for (int G = 0; G < 2; G++) to_ops(q[cb], G, ch_[2 * cb + G], cl_[2 * cb + G]);
-    f32x16 m[2];
+    f32x16 m[ND];
 #pragma unroll
-    for (int cb = 0; cb < 2; cb++)
+    for (int cb = 0; cb < ND; cb++)
 #pragma unroll
       for (int r = 0; r < 16; r++) m[cb][r] = 0.f;
 #pragma unroll
-    for (int s2 = 0; s2 < 4; s2++) {
+    for (int s2 = 0; s2 < SD; s2++) {
 #pragma unroll
-      for (int cb = 0; cb < 2; cb++) m[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mh[s2][cb], ch_[s2], m[cb], 0, 0, 0);
+      for (int cb = 0; cb < ND; cb++) m[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mh[s2][cb], ch_[s2], m[cb], 0, 0, 0);
 #pragma unroll
-      for (int cb = 0; cb < 2; cb++) m[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mh[s2][cb], cl_[s2], m[cb], 0, 0, 0);
+      for (int cb = 0; cb < ND; cb++) m[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mh[s2][cb], cl_[s2], m[cb], 0, 0, 0);
 #pragma unroll
-      for (int cb = 0; cb < 2; cb++) m[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml[s2][cb], ch_[s2], m[cb], 0, 0, 0);
+      for (int cb = 0; cb < ND; cb++) m[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ml[s2][cb], ch_[s2], m[cb], 0, 0, 0);
     }
     // ---- LayerNorm over the 64 channels of a token (two passes, eps inside the sqrt: tile_layernorm's arithmetic)
     auto layernorm = [&](auto &v, auto nb_tag, const float *gam, const float *bet) __attribute__((always_inline)) {
@@ -1019,7 +1021,7 @@ void attn_apply_stream64_kernel(AttnArgs a) {
           for (int qq = 0; qq < 4; qq++) v[cb][4 * g + qq] = (v[cb][4 * g + qq] - mean) * inv * gv[qq] + bv[qq];
         }
     };
-    layernorm(m, std::integral_constant<int, 2>{}, s_c + 64, s_c + 128);
+    layernorm(m, std::integral_constant<int, ND>{}, s_c + 64, s_c + 128);
     // ---- FFN0: relu(W0 [x ; msg]) (128 couts), operands: x re-converted from its f32 registers, msg from m
 #pragma unroll
     for (int s2 = 0; s2 < C1S; s2++) {
@@ -1029,34 +1031,34 @@ void attn_apply_stream64_kernel(AttnArgs a) {
       bf_split8(xv, bh[s2], bl[s2], true);
     }
 #pragma unroll
-    for (int cb = 0; cb < 2; cb++)
+    for (int cb = 0; cb < ND; cb++)
 #pragma unroll
       for (int G = 0; G < 2; G++) to_ops(m[cb], G, bh[C1S + 2 * cb + G], bl[C1S + 2 * cb + G]);
-    f32x16 f[4];
+    f32x16 f[SD];
 #pragma unroll
-    for (int cb = 0; cb < 4; cb++)
+    for (int cb = 0; cb < SD; cb++)
 #pragma unroll
       for (int r = 0; r < 16; r++) f[cb][r] = 0.f;
     {
       const bf16x8 *wb = s_w0 + lane;
 #pragma unroll
       for (int s2 = 0; s2 < S0; s2++) {
-        bf16x8 wh[4], wl[4];
+        bf16x8 wh[SD], wl[SD];
 #pragma unroll
-        for (int cb = 0; cb < 4; cb++) {
-          wh[cb] = wb[((s2 * 4 + cb) * 2) * 64];
-          wl[cb] = wb[((s2 * 4 + cb) * 2 + 1) * 64];
+        for (int cb = 0; cb < SD; cb++) {
+          wh[cb] = wb[((s2 * SD + cb) * 2) * 64];
+          wl[cb] = wb[((s2 * SD + cb) * 2 + 1) * 64];
         }
 #pragma unroll
-        for (int cb = 0; cb < 4; cb++) f[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bh[s2], f[cb], 0, 0, 0);
+        for (int cb = 0; cb < SD; cb++) f[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bh[s2], f[cb], 0, 0, 0);
 #pragma unroll
-        for (int cb = 0; cb < 4; cb++) f[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bl[s2], f[cb], 0, 0, 0);
+        for (int cb = 0; cb < SD; cb++) f[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bl[s2], f[cb], 0, 0, 0);
 #pragma unroll
-        for (int cb = 0; cb < 4; cb++) f[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], bh[s2], f[cb], 0, 0, 0);
+        for (int cb = 0; cb < SD; cb++) f[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], bh[s2], f[cb], 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int cb = 0; cb < 4; cb++) {
+    for (int cb = 0; cb < SD; cb++) {
 #pragma unroll
       for (int r = 0; r < 16; r++) f[cb][r] = fmaxf(f[cb][r], 0.f);
 #pragma unroll
@@ -1071,7 +1073,7 @@ void attn_apply_stream64_kernel(AttnArgs a) {
     {
       const bf16x8 *wb = s_w2 + lane;
 #pragma unroll
-      for (int s2 = 0; s2 < 8; s2++) {
+      for (int s2 = 0; s2 < 4 * ND; s2++) {
         bf16x8 wh[NOB], wl[NOB];
 #pragma unroll
         for (int cb = 0; cb < NOB; cb++) {
@@ -1087,10 +1089,10 @@ void attn_apply_stream64_kernel(AttnArgs a) {
       }
     }
     layernorm(o, std::integral_constant<int, NOB>{}, s_c + 192, s_c + 192 + 32 * NOB);
-    if constexpr (C1S == 4 && NOB == 2) {
+    if constexpr (C1S == 2 * NOB) {   // cout == c1
       if (p.residual) {
 #pragma unroll
-        for (int cb = 0; cb < 2; cb++)
+        for (int cb = 0; cb < NOB; cb++)
 #pragma unroll
           for (int r = 0; r < 16; r++) o[cb][r] += xf[16 * cb + r];
       }
@@ -1261,9 +1263,28 @@ static int attn_apply_launch(const pcr_attn_params *pp, pcr_stream_t stream) {
   dim3 g((p.Lq + T - 1) / T, p.B), blk(kThreads);
   hipStream_t st = pcr_s(stream);
 #if PCR_ATTN_PREC != 0
-  const int aps_c1s = (p.c1 + 15) >> 4;
-  const size_t aps_lds = (size_t)((aps_c1s + (p.q_pos ? 4 : 0)) * 256 + (aps_c1s + 4) * 512 + (p.cout >> 5) * 1024) * 16 +
+  const int aps_c1s = (p.c1 + 15) >> 4, aps_nd = p.d >> 5;
+  const size_t aps_lds = (size_t)((aps_c1s + (p.q_pos ? 2 * aps_nd : 0)) * aps_nd * 128 + (aps_c1s + 2 * aps_nd) * aps_nd * 256 +
+                                  aps_nd * (p.cout >> 5) * 512) * 16 +
                          (size_t)(448 + 256 + 64 * kApsWaves) * sizeof(float);
+  if (p.d == 32 && p.c1 == 32 && p.cout == 32 && !p.cfinal && (p.Lq & 31) == 0 && (p.nhead == 1 || p.nhead == 2)) {
+    // the SA1 self-attention (d_model 32): the same kernel with one 32-channel block
+    const long nitem = (long)p.B * (p.Lq >> 5);
+    const long nwg = (nitem + kApsWaves - 1) / kApsWaves;
+    static const int ncu = [] {
+      hipDeviceProp_t pr;
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256;
+      return pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    }();
+    const dim3 gg((unsigned)(nwg < ncu ? nwg : ncu)), bb(64 * kApsWaves);
+    static bool ok32 = allow_big_lds(attn_apply_stream64_kernel<true, 2, 0, 1, 1>) && allow_big_lds(attn_apply_stream64_kernel<false, 2, 0, 1, 1>);
+    (void)ok32;
+    if (p.q_pos) hipLaunchKernelGGL((attn_apply_stream64_kernel<true, 2, 0, 1, 1>), gg, bb, aps_lds, st, a);
+    else hipLaunchKernelGGL((attn_apply_stream64_kernel<false, 2, 0, 1, 1>), gg, bb, aps_lds, st, a);
+    PCR_CHECK_LAUNCH();
+    return PCR_OK;
+  }
   // shapes: (c1 = 64 | 32 | < 16 with the padded mlp[0] image) x (cout = 64 [+ cov_final 128] | cout = 128 | cout = 32 + cov_final 64)
   const bool aps_in = p.c1 == 64 || ((p.c1 == 32 || (p.c1 < 16 && pp->wmlp0_bf_xpad)) && !p.q_pos && !p.residual);
   const bool aps_out = (p.cout == 64 && (p.cfinal == 0 || p.cfinal == 128) && p.c1 >= 32) ||
