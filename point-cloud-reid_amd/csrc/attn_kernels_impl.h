@@ -528,6 +528,163 @@ void attn_kv_stream64_kernel(AttnArgs a) {
   }
 }
 
+#if PCR_ATTN_PREC != 0
+// The same kernel shape for d = c2 = 32 (the SA1 self-attention), split-bf16 projection only: one K and one V block,
+// one 32 x 32 KV tile per wave, one fold tile per cloud.
+__global__ __launch_bounds__(64 * kKvsWaves) __attribute__((amdgpu_waves_per_eu(2, 4)))
+void attn_kv_stream32_kernel(AttnArgs a) {
+  constexpr int D = 32, LD = D + 1, KVS = D * LD + D;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const pcr_attn_params &p = a.p;
+  f32x4 *s_w = reinterpret_cast<f32x4 *>(smem);                   // bf image [4 steps][2 cb][hi, lo][64]: 1024 units
+  f32x4 *s_p0 = reinterpret_cast<f32x4 *>(smem + 4096);           // [32] {w0x, w0y, w0z, b0}
+  float *s_bkv = smem + 4096 + 128;                               // [64]
+  float *s_wm = s_bkv + 64;                                       // [32][33] merge weights
+  float *s_red = s_wm + D * LD;                                   // [CPG][KVS]
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(p.wkv_bf);
+    for (int e = tid; e < 1024; e += 64 * kKvsWaves) s_w[e] = src[e];
+    for (int e = tid; e < D * D; e += 64 * kKvsWaves) s_wm[(e >> 5) * LD + (e & 31)] = p.wmerge[e];
+    if (tid < D) s_p0[tid] = f32x4{p.pos0_w[3 * tid], p.pos0_w[3 * tid + 1], p.pos0_w[3 * tid + 2], p.pos0_b[tid]};
+    if (tid < 2 * D) s_bkv[tid] = p.bkv[tid];
+  }
+  __syncthreads();
+  const int nblk = p.Sk >> 5;
+  const int wpc = nblk < kKvsWaves ? nblk : kKvsWaves;
+  int wpc2 = 1;
+  while (wpc2 * 2 <= wpc) wpc2 *= 2;
+  if (wpc2 < 2) wpc2 = 2;
+  const int cpg = kKvsWaves / wpc2;
+  const int cslot = wave / wpc2, wsub = wave - cslot * wpc2;
+  const float inv_sk = 1.0f / (float)p.Sk;
+  const float bias0 = s_bkv[j], bias1 = s_bkv[32 + j];
+  const int dh = D / p.nhead;
+  for (long c0 = (long)blockIdx.x * cpg; c0 < p.B; c0 += (long)gridDim.x * cpg) {
+    const long b = c0 + cslot;
+    const bool live = b < p.B;
+    f32x16 kv;
+#pragma unroll
+    for (int r = 0; r < 16; r++) kv[r] = 0.f;
+    float ks = 0.f;
+    if (live) {
+      const float *feat = p.feat_k + (size_t)b * D * p.Sk;
+      const float *xyz = p.xyz_k + (size_t)b * p.Sk * 3;
+      const __amdgpu_buffer_rsrc_t rfeat =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(feat), 0, D * p.Sk * 4, 0x00020000);
+      for (int blk = wsub; blk < nblk; blk += wpc2) {
+        asm volatile("" ::: "memory");
+        const int t = blk * 32 + j;
+        const float px = xyz[3 * t], py = xyz[3 * t + 1], pz = xyz[3 * t + 2];
+        float xf[16];
+        {
+          const int vo = (4 * h * p.Sk + t) * 4;
+#pragma unroll
+          for (int e = 0; e < 16; e++) {
+            const int ch = 16 * (e >> 3) + bf_kpos(0, e & 7);   // + 4 h: in the lane offset
+            xf[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rfeat, vo, ch * p.Sk * 4, 0));
+          }
+        }
+        bf16x8 ah[4], al[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+          float hv[8];
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const f32x4 w = s_p0[16 * s2 + bf_kpos(0, e) + 4 * h];
+            const float v = w[0] * px + w[1] * py + w[2] * pz + w[3];
+            hv[e] = fmaxf(v, 0.f);
+          }
+          bf_split8(hv, ah[2 + s2], al[2 + s2], true);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; e++) asm volatile("" : "+v"(xf[e]));
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+          float xv[8];
+#pragma unroll
+          for (int e = 0; e < 8; e++) xv[e] = xf[8 * s2 + e];
+          bf_split8(xv, ah[s2], al[s2], true);
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[cb][r] = 0.f;
+        const bf16x8 *wb = reinterpret_cast<const bf16x8 *>(s_w) + lane;
+#pragma unroll
+        for (int s2 = 0; s2 < 4; s2++) {
+          bf16x8 wh[2], wl[2];
+#pragma unroll
+          for (int cb = 0; cb < 2; cb++) {
+            wh[cb] = wb[((s2 * 2 + cb) * 2) * 64];
+            wl[cb] = wb[((s2 * 2 + cb) * 2 + 1) * 64];
+          }
+#pragma unroll
+          for (int cb = 0; cb < 2; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s2], wh[cb], acc[cb], 0, 0, 0);
+#pragma unroll
+          for (int cb = 0; cb < 2; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s2], wh[cb], acc[cb], 0, 0, 0);
+#pragma unroll
+          for (int cb = 0; cb < 2; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s2], wl[cb], acc[cb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          acc[0][r] = elu1(acc[0][r] + bias0);
+          acc[1][r] = (acc[1][r] + bias1) * inv_sk;
+          ks += acc[0][r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) kv = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[0][r], acc[1][r], kv, 0, 0, 0);
+      }
+    }
+    ks += __shfl_xor(ks, 32, 64);
+    float *KVl = s_red + cslot * KVS, *s_kt = KVl + D * LD;
+    for (int round = 0; round < wpc2; round++) {
+      if (wsub == round) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          float *dst = KVl + ((r & 3) + 8 * (r >> 2) + 4 * h) * LD + j;
+          *dst = round == 0 ? kv[r] : *dst + kv[r];
+        }
+        if (h == 0) s_kt[j] = round == 0 ? ks : s_kt[j] + ks;
+      }
+      __syncthreads();
+    }
+    if (live && wsub == 0) {
+      float *kvo = p.kv + (size_t)b * ((size_t)D * D + D);
+      const float *ap = s_wm + j * LD + h;
+      const float *bp = KVl + j * LD + h;
+      const int hd = j / dh;
+      f32x16 m;
+#pragma unroll
+      for (int r = 0; r < 16; r++) m[r] = 0.f;
+#pragma unroll 4
+      for (int s2 = 0; s2 < 16; s2++) {
+        const float bv = bp[2 * s2];
+        m = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s2], (2 * s2 + h) / dh == hd ? bv : 0.f, m, 0, 0, 0);
+      }
+      const int dd = j;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int o = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int s16 = dd >> 4, kk = dd & 15;
+        const int hh = (kk >> 2) & 1, jj = (kk & 3) + ((kk >> 3) << 2);
+        const size_t unit = (((size_t)s16 * (D >> 5) + (o >> 5)) * 2) * 64 + hh * 32 + (o & 31);
+        const float mv = m[r];
+        const __bf16 hi = (__bf16)mv;
+        const __bf16 lo = (__bf16)(mv - (float)hi);
+        __bf16 *img = reinterpret_cast<__bf16 *>(kvo);
+        img[unit * 8 + jj] = hi;
+        img[(unit + 64) * 8 + jj] = lo;
+      }
+      if (lane < D) kvo[(size_t)D * D + lane] = s_kt[lane];
+    }
+    __syncthreads();
+  }
+}
+#endif
+
 // second launch of the token-split form: one workgroup per cloud adds the splits' partials in order (fixed: the result
 // does not depend on the schedule), applies the head mask and folds the merge projection
 __global__ __launch_bounds__(kThreads) void attn_kv_fold_kernel(AttnArgs a) {
@@ -1234,6 +1391,29 @@ static int attn_kv_narrow(const pcr_attn_params *pp, pcr_stream_t stream) {
     PCR_CHECK_LAUNCH();
     return PCR_OK;
   }
+#if PCR_ATTN_PREC != 0
+  if (ns == 1 && d == 32 && pp->c2 == 32 && pp->wkv_bf && (pp->Sk & 31) == 0 && pp->nhead >= 1 && 32 % pp->nhead == 0) {
+    static bool ok32 = allow_big_lds(attn_kv_stream32_kernel);
+    (void)ok32;
+    const int nblk = pp->Sk >> 5;
+    int wpc2 = 1;
+    while (wpc2 * 2 <= (nblk < kKvsWaves ? nblk : kKvsWaves)) wpc2 *= 2;
+    if (wpc2 < 2) wpc2 = 2;
+    const int cpg = kKvsWaves / wpc2;
+    const size_t lds_s = (size_t)(4096 + 128 + 64 + 32 * 33 + cpg * (32 * 33 + 32)) * sizeof(float);
+    const long rounds = ((long)pp->B + cpg - 1) / cpg;
+    static const int ncu = [] {
+      hipDeviceProp_t pr;
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256;
+      return pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    }();
+    const long cap = 2L * ncu;                                // (small footprint: two workgroups per CU)
+    hipLaunchKernelGGL(attn_kv_stream32_kernel, dim3((unsigned)(rounds < cap ? rounds : cap)), dim3(64 * kKvsWaves), lds_s, st, a);
+    PCR_CHECK_LAUNCH();
+    return PCR_OK;
+  }
+#endif
   if (d == 32) hipLaunchKernelGGL((attn_kv_kernel<2, 1, 2, 1>), g, blk, lds, st, a);        // 2d = 64: two cout blocks
   else if (d == 64) hipLaunchKernelGGL((attn_kv_kernel_o3<2, 1, 1, 1>), g, blk, lds, st, a);   // four, one per wave
   else if (d == 128) hipLaunchKernelGGL((attn_kv_kernel_o3<1, 2, 1, 4>), g, blk, lds, st, a);  // eight, two rounds
@@ -1388,7 +1568,7 @@ static bool attn_bf(const pcr_attn_params &p, pcr_attn_params &q) {
 PCR_EXPORT int pcr_attn_kv_splits(int B, int Sk, int d) {
   (void)B;
   if (Sk < 1 || d > 64) return 1;
-  if (d == 64 && (Sk & 31) == 0) return 1;   // the wave-autonomous kernel's shape (attn_kv_stream64_kernel): whole clouds
+  if ((d == 64 || d == 32) && (Sk & 31) == 0) return 1;   // the wave-autonomous kernels' shapes (attn_kv_stream64 / 32): whole clouds
   const int ntile = (Sk + 63) / 64;
   return ntile >= 16 ? 4 : (ntile >= 8 ? 2 : 1);
 }

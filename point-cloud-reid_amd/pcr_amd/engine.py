@@ -325,7 +325,7 @@ class AttnPlan:
             ln2_g=_dev32(m.norm2.weight, device), ln2_b=_dev32(m.norm2.bias, device))
         if d <= 128:
             # the same matrices as bf16 hi / lo images: the dense phases of both kernels in "bf16x3" / "bf16" mode
-            if d == 64 and self.c2 in (64, 128):   # the wave-autonomous kv kernel's shapes: its projection in split bf16 too
+            if (d == 64 and self.c2 in (64, 128)) or (d == 32 and self.c2 == 32):   # the wave-autonomous kv kernels' shapes
                 self.t["wkv_bf"] = pack_weight_bf(wkv.float(), device)
             if d == 64 and self.c1 % 16:        # c1 = 3: mlp[0] with the feature columns padded to a 16-channel step
                 w0 = m.mlp[0].weight.detach().float().cpu()
