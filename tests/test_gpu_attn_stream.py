@@ -1,0 +1,52 @@
+"""GPU: the wave-autonomous attention kernels (attn_kv_stream64 / 32, attn_apply_stream64: whole 32-token blocks at d_model
+64 / 32) against the torch-eager oracle over the shapes their template cases and work split depend on -- head counts
+(1: full KV tiles, 4: sixteen-channel heads), key sets of 1 / 2 / 3 / 5 blocks (1, 2, 4, 8 waves per cloud, several clouds
+per workgroup round), query sets that leave the last workgroup partly filled, batch sizes that are not a multiple of the
+clouds per round -- in both arithmetic modes (f32: the kv kernel's f32 form + the tile apply kernel).
+Reference: models/pointnet2_utils.py:14-47,90-114; attention.py:192-219."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+
+from pcr_amd import engine, testing as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kind,d,nhead,B,Lq,Sk", [
+    ("self", 64, 1, 3, 32, 32), ("self", 64, 2, 7, 96, 96), ("self", 64, 4, 5, 160, 160), ("self", 32, 2, 6, 64, 64),
+    ("self", 32, 1, 3, 224, 224), ("cross", 64, 4, 3, 64, 32), ("cross", 64, 2, 9, 32, 160), ("cross", 64, 1, 2, 288, 64),
+    ("cross", 32, 2, 5, 96, 256)])
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_streaming_attention_matches_oracle(kind, d, nhead, B, Lq, Sk, prec):
+    import model_oracle as MO
+    from mmdet3d.models.attention import corss_attention
+    from mmdet3d.models.pointnet2_utils import Self_Attention
+    g = torch.Generator().manual_seed(17 * d + Lq + Sk + nhead)
+    tt = lambda *s: torch.randn(*s, generator=g)      # noqa: E731
+    if kind == "self":
+        m = Self_Attention(d, nhead)
+        args = (tt(B, d, Lq), tt(B, Lq, 3))
+        oracle = MO.self_attention
+    else:
+        m = corss_attention(d, nhead)
+        args = (tt(B, d, Lq), tt(B, Lq, 3), tt(B, d, Sk), tt(B, Sk, 3))
+        oracle = MO.cross_attention
+    sd = T.seeded_state_dict(T.manifest_of(m), 5)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        want = oracle(sd, *args, nhead=nhead)
+    with engine.precision(prec), torch.no_grad():
+        got = m(*[a.cuda() for a in args]).cpu()
+        again = m(*[a.cuda() for a in args]).cpu()
+    assert torch.equal(got, again)                                   # fixed reduction orders: run to run identical
+    assert float((got - want).abs().max()) < 1e-4, float((got - want).abs().max())
+    # one cloud alone gives the bits it gives inside the batch (persistent workgroups, several clouds per round)
+    with engine.precision(prec), torch.no_grad():
+        one = m(*[a[B - 1:].cuda() for a in args]).cpu()
+    assert torch.equal(one[0], got[B - 1])
