@@ -367,7 +367,12 @@ def test_submodules_refuse_training_mode_on_the_fused_path():
 
 @pytest.mark.parametrize("mode,D,K,S,N,widths", [(0, 0, 32, 100, 128, (32, 32, 32)), (0, 32, 48, 70, 150, (64, 64, 64)),
                                                  (0, 64, 48, 33, 96, (128, 128, 128)), (1, 16, 64, 40, 300, (128, 128, 256)),
-                                                 (1, 5, 20, 17, 64, (24, 40, 72)), (0, 8, 16, 50, 50, (32, 64, 128))])
+                                                 (1, 5, 20, 17, 64, (24, 40, 72)), (0, 8, 16, 50, 50, (32, 64, 128)),
+                                                 # the wave-autonomous forms: two centres per block (K = 16), two / three
+                                                 # blocks per item (K = 64 / 96), partial last items, c3 = 2 c2, no features
+                                                 (0, 16, 16, 37, 80, (32, 32, 32)), (0, 24, 64, 21, 128, (64, 64, 64)),
+                                                 (0, 8, 96, 11, 200, (32, 32, 64)), (1, 12, 32, 45, 256, (64, 64, 128)),
+                                                 (0, 0, 16, 63, 64, (128, 128, 128)), (1, 0, 48, 29, 100, (32, 32, 32))])
 def test_sa_fast_and_generic_paths_agree_with_torch(mode, D, K, S, N, widths):
     """fused SA kernel (decomposed layer 1, in-place LDS) vs the generic kernel vs plain torch fp32"""
     import torch.nn as nn
