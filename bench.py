@@ -138,6 +138,25 @@ def hot_path(model, s1, s2):
     return model.match_forward_inference(h1, h2, xyz1, xyz2)
 
 
+def aggregate_profile(rec, detail=True, elapsed=None):
+    """engine.PROFILE records -> {launch name: [ms, calls, reference flops, algorithmic bytes, issued flops, arithmetic]}.
+    `arithmetic` is what the LIBRARY says the launch ran its matrix phases in (engine._prof, pcr_last_launch_arith), None
+    for launches that do not multiply."""
+    elapsed = elapsed or (lambda e0, e1: e0.elapsed_time(e1))
+    tot = {}
+    for name, e0, e1, flops, nbytes, exec_flops, arith in rec:
+        if not detail:
+            name = name.split("[")[0]
+        t = tot.setdefault(name, [0.0, 0, 0.0, 0.0, 0.0, arith])
+        t[0] += elapsed(e0, e1)
+        t[1] += 1
+        t[2] += flops
+        t[3] += nbytes
+        t[4] += exec_flops
+        t[5] = arith
+    return tot
+
+
 def profile_kernels(model, s1, s2, reps=3, detail=False, fn=None):
     """per-launch device time with events on the launch stream; returns the dominant launch"""
     from pcr_amd import engine
@@ -152,17 +171,7 @@ def profile_kernels(model, s1, s2, reps=3, detail=False, fn=None):
         torch.cuda.synchronize()
         rec = engine.PROFILE
         engine.PROFILE = None
-        tot = {}
-        for name, e0, e1, flops, nbytes, exec_flops in rec:
-            ms = e0.elapsed_time(e1)
-            if not detail:
-                name = name.split("[")[0]
-            t = tot.setdefault(name, [0.0, 0, 0.0, 0.0, 0.0])
-            t[0] += ms
-            t[1] += 1
-            t[2] += flops
-            t[3] += nbytes
-            t[4] += exec_flops
+        tot = aggregate_profile(rec, detail)
         if best is None or sum(v[0] for v in tot.values()) < sum(v[0] for v in best.values()):
             best = tot
     return best
@@ -250,7 +259,7 @@ def train_bench(args, desc, n, bl, pairs, rank, world, steps=None, warmup=None):
         tr.bucket._layout()
         rec, engine.PROFILE = engine.PROFILE, None
         tot = {}
-        for name, e0, e1, flops, nbytes, _ in rec:
+        for name, e0, e1, flops, nbytes, _, _arith in rec:
             t = tot.setdefault(name, [0.0, 0, 0.0, 0.0])
             t[0] += e0.elapsed_time(e1)
             t[1] += 1
@@ -351,57 +360,93 @@ def ssg_fill(model, s1):
     return fill
 
 
-def roofline_of(model, s1, s2, workload, pairs, fn=None):
-    """per-launch device times (events on the launch stream); the roofline object describes the single most
-    expensive LAUNCH"""
-    prof = profile_kernels(model, s1, s2, detail=True, fn=fn)
+HBM_LAUNCHES = ("knn_prefix", "fps", "ball_query", "pool_head", "gather", "edge_max", "knn_feat", "local_attn")
+
+
+def roofline_object(prof):
+    """{launch: [ms, calls, reference flops, bytes, issued flops, arithmetic]} (aggregate_profile) -> the roofline object of
+    the single most expensive LAUNCH.  Pure (tests/test_bench_roofline.py feeds it synthetic profiles).
+    achieved = FLOPs the launch really issues on the matrix core / its duration: the kernel skips work the reference does
+    (first MLP layer via per-point tables, repeated ball-query rows), and in split bf16 every product is three MFMAs, all
+    three counted and priced against the bf16 peak; `product_tflops` is the same launch per PRODUCT, the reference's op
+    count over the same time is `reference_op_tflops`.  The peak is the peak of the arithmetic the launch RAN
+    (prof[..][5], reported by the library per launch), never of the mode that was asked for."""
     dom = max(prof, key=lambda k: prof[k][0] / prof[k][1])
-    ms, cnt, flops, nbytes, exec_flops = prof[dom]
+    ms, cnt, flops, nbytes, exec_flops, arith = prof[dom]
     step_ms_kern = sum(v[0] for v in prof.values())
     groups = {}
     for k, v in prof.items():
         groups[k.split("[")[0]] = groups.get(k.split("[")[0], 0.0) + v[0]
-    # achieved = FLOPs the launch really issues on the matrix core / its duration (the kernel skips work the
-    # reference does: the first MLP layer via per-point tables, repeated ball-query rows); the reference's op
-    # count for the same layer over the same time is reported beside it as reference_op_tflops
-    from pcr_amd import engine
-    # the grouped-SA launches follow engine.PRECISION (bf16x3: three bf16 MFMAs per product, priced against the bf16
-    # peak with all three counted; the f32 figure beside it is the same work over the f32-input peak); every other
-    # MFMA launch of this build is f32-input
-    prec = engine.PRECISION if dom.split("[")[0] in ("sa_ragged", "sa_fused") else "f32"
-    _, peak, mult = PREC_INFO[prec]
-    roof = dict(kernel=dom, bound="mfma", achieved=(exec_flops * mult / cnt) / (ms / cnt * 1e-3) / 1e12,
-                peak=peak, unit="TFLOP/s", avg_launch_ms=ms / cnt, launches_per_step=cnt, traffic=None,
-                kernel_arithmetic=prec, mfma_per_product=mult,
-                product_tflops=(exec_flops / cnt) / (ms / cnt * 1e-3) / 1e12,
-                product_frac_of_f32_mfma_peak=(exec_flops / cnt) / (ms / cnt * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
-                issued_gflop_per_launch=exec_flops * mult / cnt / 1e9,
-                reference_op_gflop_per_launch=flops / cnt / 1e9,
-                reference_op_tflops=(flops / cnt) / (ms / cnt * 1e-3) / 1e12,
-                share_of_step=ms / step_ms_kern,
-                per_kernel_ms={k: round(v, 4) for k, v in sorted(groups.items(), key=lambda kv: -kv[1])})
+    sec = ms / cnt * 1e-3
+    per = {k: round(v, 4) for k, v in sorted(groups.items(), key=lambda kv: -kv[1])}
+    if arith is None or dom.split("[")[0] in HBM_LAUNCHES:
+        # neighbour search / sampling / pooling launches move bytes, they do not multiply: priced against HBM with
+        # their ALGORITHMIC bytes (SURVEY 8d: read xyz, write indices) -- their real limiter today is instruction
+        # issue (DESIGN.md 4.3), which this fraction makes plain
+        roof = dict(kernel=dom, bound="hbm", achieved=(nbytes / cnt) / sec / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                    avg_launch_ms=ms / cnt, launches_per_step=cnt, traffic=None, kernel_arithmetic=arith,
+                    algorithmic_mb_per_launch=nbytes / cnt / 1e6, share_of_step=ms / step_ms_kern, per_kernel_ms=per)
+    else:
+        _, peak, mult = PREC_INFO[arith]
+        roof = dict(kernel=dom, bound="mfma", achieved=(exec_flops * mult / cnt) / sec / 1e12,
+                    peak=peak, unit="TFLOP/s", avg_launch_ms=ms / cnt, launches_per_step=cnt, traffic=None,
+                    kernel_arithmetic=arith, mfma_per_product=mult,
+                    product_tflops=(exec_flops / cnt) / sec / 1e12,
+                    product_frac_of_f32_mfma_peak=(exec_flops / cnt) / sec / 1e12 / MFMA_F32_PEAK_TF,
+                    issued_gflop_per_launch=exec_flops * mult / cnt / 1e9,
+                    reference_op_gflop_per_launch=flops / cnt / 1e9,
+                    reference_op_tflops=(flops / cnt) / sec / 1e12,
+                    share_of_step=ms / step_ms_kern, per_kernel_ms=per)
     roof["frac"] = roof["achieved"] / roof["peak"]
-    if dom.split("[")[0] in ("knn_prefix", "fps", "ball_query", "pool_head", "gather", "edge_max"):
-        # neighbour search / sampling / pooling launches move bytes, they do not multiply: price them against
-        # HBM with their ALGORITHMIC bytes (SURVEY 8d: read xyz, write indices) -- their real limiter today is
-        # instruction issue (DESIGN.md 4.3), which this fraction makes plain
-        roof.update(bound="hbm", achieved=(nbytes / cnt) / (ms / cnt * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
-        roof["frac"] = roof["achieved"] / roof["peak"]
-    # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (profiles/*_pmc.json:
-    # FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 correction 2*FETCH_SIZE + WRITE_SIZE), scaled to
-    # this batch size; null when no profile of this workload is committed
-    try:
-        import glob
-        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc.json" % workload)))[-1]
-        with open(path) as f:
-            pmc = json.load(f)
-        kern = pmc["_launch_to_kernel"][dom]
-        roof["traffic"] = pmc[kern]["hbm_bytes_corrected"] * pairs / pmc["_pairs_per_step"]
-        roof["traffic_source"] = "%s (%s)" % (os.path.relpath(path, ROOT), kern)
-        roof["mfma_pipe_busy_pmc"] = pmc[kern]["mfma_pipe_busy"]
-    except (OSError, KeyError, TypeError, IndexError):
-        pass
+    return roof
+
+
+def attach_pmc(roof, workload, pairs, precision):
+    """HBM bytes per launch and matrix-pipe occupancy of THE kernel the roofline object describes, from the committed
+    rocprofv3 --pmc passes (profiles/rNN_<workload>_pmc.json, tools/pmc_summary.py: FETCH_SIZE and WRITE_SIZE in
+    separate passes, gfx950 correction 2 * FETCH_SIZE + WRITE_SIZE), scaled to this batch size.  Only a profile taken
+    in the SAME arithmetic mode and mapping this launch to a kernel of the SAME arithmetic is quoted; otherwise the
+    fields stay null."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc.json" % workload)), reverse=True):
+        try:
+            with open(path) as f:
+                pmc = json.load(f)
+            if pmc.get("_precision") != precision:      # (files older than round 4 do not say: never quoted)
+                continue
+            kern = pmc["_launch_to_kernel"][roof["kernel"]]
+            ent = pmc[kern]
+            if ent.get("arithmetic") not in (None, roof.get("kernel_arithmetic")):
+                continue
+            roof["traffic"] = ent["hbm_bytes_corrected"] * pairs / pmc["_pairs_per_step"]
+            roof["traffic_source"] = "%s (%s)" % (os.path.relpath(path, ROOT), kern)
+            roof["mfma_pipe_busy_pmc"] = ent["mfma_pipe_busy"]
+            roof["pmc_launch_ms"] = ent["launch_us"] / 1e3 * pairs / pmc["_pairs_per_step"]
+            return roof
+        except (OSError, KeyError, TypeError, IndexError, ValueError):
+            continue
+    return roof
+
+
+def roofline_of(model, s1, s2, workload, pairs, fn=None):
+    """per-launch device times (events on the launch stream); the roofline object describes the single most
+    expensive LAUNCH"""
+    from pcr_amd import engine
+    prof = profile_kernels(model, s1, s2, detail=True, fn=fn)
+    roof = attach_pmc(roofline_object(prof), workload, pairs, engine.PRECISION)
     return roof, prof
+
+
+def precision_text(mode):
+    """what `dtype` means, launch family by launch family (the per-launch truth is roofline.kernel_arithmetic)"""
+    if mode == "f32":
+        return "f32: every matrix phase on the f32-input MFMA (exact fmaf chains, the reference's arithmetic)"
+    how = {"bf16x3": "split bf16 (hi + lo operands, three bf16 MFMAs per product, f32 accumulate)",
+           "bf16": "plain bf16 operands (one MFMA per product, f32 accumulate)"}[mode]
+    return ("%s: grouped-SA layers 2/3 and the layer-1 tables as %s; attention (d_model <= 128) projections, message, "
+            "feed-forward and cov_final as split bf16 in both bf16 modes; f32-input MFMA for the coordinate part of SA "
+            "layer 1, the KV accumulation / merge fold, the tile kv kernel (d = 128 / 96), wide attention (d > 128) and "
+            "the Conv1d / PointNet / DGCNN dense layers; pooling + match head in f32 VALU" % (mode, how))
 
 
 def add_clock(roof, clk):
@@ -458,11 +503,7 @@ def measure(workload, args, rank, world, pairs=None, cloud_kind=None, skip_repea
                    config={"workload": "%s: %s" % (workload, desc), "pairs_per_gpu_per_step": pairs, "points": n,
                            "backbone_list": bl, "parallelism": "independent pair shards x%d" % world,
                            "rccl_ranks": world,
-                           "precision": "%s: grouped-SA layers 2/3 on the %s; tables, attention, head: f32-input MFMA"
-                           % (engine.PRECISION, {"f32": "f32-input MFMA (exact fmaf chains)",
-                                                 "bf16x3": "bf16 MFMA as split bf16 (3 MFMAs per product, f32 accumulate)",
-                                                 "bf16": "bf16 MFMA (bf16 activations / weights, f32 accumulate)"}
-                              [engine.PRECISION])},
+                           "precision": precision_text(engine.PRECISION)},
                    roofline=roof)
         if kind == "ssg":
             rec["config"]["fill"] = ssg_fill(model, s1)
@@ -481,7 +522,7 @@ def measure(workload, args, rank, world, pairs=None, cloud_kind=None, skip_repea
 
 def gallery_bench(args, desc, n, bl, pairs, rank, world, steps=None, warmup=None, cpu=True):
     """G tracks x G detections; encode the 2G objects once, score all G*G combinations"""
-    from pcr_amd import shard
+    from pcr_amd import engine, shard
     from pcr_amd import testing as T
     steps = steps or args.steps
     warmup = args.warmup if warmup is None else warmup
@@ -507,9 +548,9 @@ def gallery_bench(args, desc, n, bl, pairs, rank, world, steps=None, warmup=None
         line = {"metric": "siamese pair-comparisons/sec @%d pts (gallery: every object encoded once)" % n,
                 "value": world * P * steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": steps,
                 "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                "scaling": "weak", "vs_baseline": None, "dtype": PREC_INFO[engine.PRECISION][0],
                 "data": "synthetic (randn clouds, seeded random-init weights with non-trivial BN statistics)",
-                "config": {"workload": "gallery128: %s" % desc, "pairs_per_gpu_per_step": P, "objects_per_gpu_per_step": 2 * G,
+                "config": {"workload": "gallery128: %s" % desc, "precision": precision_text(engine.PRECISION), "pairs_per_gpu_per_step": P, "objects_per_gpu_per_step": 2 * G,
                            "points": n, "backbone_list": bl, "parallelism": "independent galleries x%d" % world,
                            "rccl_ranks": world},
                 "roofline": roof}
@@ -662,7 +703,11 @@ def main():
                              ("ssg1024_dup", "ssg1024", dict(cloud_kind="dup")),
                              ("ssg1024_crop", "ssg1024", dict(cloud_kind="crop")),
                              ("ssg1024_full", "ssg1024", dict(skip_repeats=False, steps=max(4, args.steps // 4))),
-                             ("pt1024", "pt1024", dict())):
+                             ("pt1024", "pt1024", dict()),
+                             # BASELINE configs[0] (PointNet, the reference's CPU-runnable case) and configs[4] (dense
+                             # 4096-pt Waymo-shape pairs: the grouping stress), each with its own roofline object
+                             ("pointnet256", "pointnet256", dict()),
+                             ("pt4096", "pt4096", dict(steps=max(4, args.steps // 2)))):
             try:
                 r, _ = measure(wl, args, rank, world, **kw)
                 r["metric"] = "siamese pair-comparisons/sec @%d pts" % WORKLOADS[wl][2]

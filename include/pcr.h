@@ -641,6 +641,10 @@ int pcr_adamw_step_f32(const pcr_opt_tensor *tab, const int *chunk_tensor, const
  * ticks[2 wg + 1] = constant-rate wall-clock ticks (pcr_wall_clock_khz) spent on them.  The clock the matrix core
  * ran at is iters * 1024 / (wall ticks / rate): what `roofline.clock_ghz` in the bench line reports. */
 int pcr_wall_clock_khz(void);
+/* PCR_PREC_* the matrix phases of the calling thread's LAST pcr_sa_mlp / pcr_dense_pm / pcr_attn_kv / pcr_attn_apply
+ * launch really ran in (-1: none yet).  A requested precision is a request: shapes a bf16 unit does not instantiate run
+ * f32, the tile kv kernel projects in f32 in every mode.  bench.py prices a launch against the peak of THIS arithmetic. */
+int pcr_last_launch_arith(void);
 int pcr_clock_probe(unsigned long long *ticks, int n_wg, int iters, pcr_stream_t stream);
 
 #ifdef __cplusplus

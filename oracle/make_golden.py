@@ -520,8 +520,67 @@ def gen_eval_tables():
     np.savez_compressed(os.path.join(GOLD, "eval_tables.npz"), **rec)
 
 
+def gen_pairs():
+    """the reference's dataset classes (reidentification_nuscenes.py:16-72 train, :78-145 FPVal, :150-249 FPValEven over
+    reidentification_base.py and object_loader_base.py; oracle/ref_datasets.py) on a toy object table whose crops are
+    rebuilt from seeds: the order of `idx` after the constructor's shuffle, three passes of training items (every tensor
+    of the returned dict), and both validation pair sets -- what pcr_amd/loader.py TrainPairs and pcr_amd/pairs.py must
+    reproduce call for call under the same numpy seed."""
+    import tempfile
+    import ref_datasets as RD
+    NS, ND, SEED, MAXC = 32, 16, 5, 3
+    objs = RD.toy_objects(seed=1, n_true=26, n_fp=12)
+    tmp = tempfile.mkdtemp()
+    root = os.path.join(tmp, "crops")
+    RD.write_crops(root, objs)
+    rec = dict(meta=np.array(json.dumps(dict(ns=NS, nd=ND, seed=SEED, item_seed=11, max_combinations=MAXC, toy_seed=1,
+                                             n_true=26, n_fp=12, passes=3))),
+               objects=np.array(json.dumps([dict(token=o["token"], class_name=o["class_name"], fp=o["fp"],
+                                                 frames={str(k): v for k, v in o["frames"].items()},
+                                                 visibility={str(k): v for k, v in o["visibility"].items()}) for o in objs])))
+    ds = RD.build_reference_dataset("train", objs, root, tmp, NS, ND, seed=SEED)
+    rec["train_idx"] = np.asarray(ds.idx, dtype=np.int64)
+    rec["train_classes"] = np.asarray(ds.classes, dtype=np.int64)
+    np.random.seed(11)
+    items = {k: [] for k in ("sparse_1", "sparse_2", "dense_1", "dense_2", "label_1", "label_2", "id_1", "id_2")}
+    for _ in range(3):
+        for i in range(len(ds)):
+            it = ds[i]
+            for k in items:
+                items[k].append(it[k].data.numpy())
+    for k, v in items.items():
+        rec["train_" + k] = np.stack(v)
+    rec["train_rng_after"] = np.random.randint(0, 2 ** 31 - 1, size=4)       # the generator's state after the passes
+    print("train items", len(items["id_1"]), "negatives", int((rec["train_id_1"] != rec["train_id_2"]).sum()),
+          "fp", int((rec["train_id_2"] == -1).sum()))
+    toks = [o["token"] for o in objs]
+
+    def pairs(ps, ns_):
+        pos = np.array([[toks.index(p["tok"]), p["o1"], p["o2"], p["cls"]] for p in ps], dtype=np.int64)
+        neg = np.array([[toks.index(n["tok1"]), n["o1"], toks.index(n["tok2"]), n["o2"], n["cls1"], n["cls2"]]
+                        for n in ns_], dtype=np.int64)
+        return pos, neg
+    for kind in ("val", "val_even"):
+        dv = RD.build_reference_dataset(kind, objs, root, tmp, NS, ND, seed=SEED, max_combinations=MAXC)
+        pos, neg = pairs(dv.val_positives, dv.val_negatives)
+        rec[kind + "_idx"] = np.asarray(dv.idx, dtype=np.int64)
+        rec[kind + "_pos"], rec[kind + "_neg"] = pos, neg
+        print(kind, "positives", len(pos), "negatives", len(neg), "fp negatives", int((neg[:, 5] >= 2).sum()),
+              "self-paired negatives", int((neg[:, 0] == neg[:, 2]).sum()))
+        # two items of the validation set (a positive and a negative) with the size / visibility keys
+        np.random.seed(3)
+        for name, j in (("p", 0), ("n", len(pos))):
+            it = dv[j]
+            for k, v in it.items():
+                rec["%s_item_%s_%s" % (kind, name, k)] = v.data.numpy()
+    np.savez_compressed(os.path.join(GOLD, "pairs_toy.npz"), **rec)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    if "--only-pairs" in sys.argv:
+        gen_pairs()
+        sys.exit(0)
     if "--only-tables" in sys.argv:
         gen_eval_tables()
         sys.exit(0)
@@ -563,3 +622,4 @@ if __name__ == "__main__":
     gen_python_twins()
     gen_eval_metric()
     gen_eval_tables()
+    gen_pairs()

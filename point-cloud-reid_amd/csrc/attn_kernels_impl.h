@@ -1356,6 +1356,7 @@ static int attn_kv_narrow(const pcr_attn_params *pp, pcr_stream_t stream) {
     // wave-autonomous form (shape-only choice; an explicit token split keeps the tile kernel)
     const bool bf = bfk;
     const bool wide = pp->c2 == 128;
+    pcr_note_arith(bf ? PCR_PREC_BF16X3 : PCR_PREC_F32);   // (the projection; the KV accumulation and the fold are f32)
     static bool oks = allow_big_lds(attn_kv_stream64_kernel<true, false>) && allow_big_lds(attn_kv_stream64_kernel<false, false>) &&
                       allow_big_lds(attn_kv_stream64_kernel<true, kBfUnit>) && allow_big_lds(attn_kv_stream64_kernel<false, kBfUnit>) &&
                       allow_big_lds(attn_kv_stream64_kernel<true, kBfUnit, kBfUnit ? 8 : 4>) &&
@@ -1395,6 +1396,7 @@ static int attn_kv_narrow(const pcr_attn_params *pp, pcr_stream_t stream) {
   if (ns == 1 && d == 32 && pp->c2 == 32 && pp->wkv_bf && (pp->Sk & 31) == 0 && pp->nhead >= 1 && 32 % pp->nhead == 0) {
     static bool ok32 = allow_big_lds(attn_kv_stream32_kernel);
     (void)ok32;
+    pcr_note_arith(PCR_PREC_BF16X3);
     const int nblk = pp->Sk >> 5;
     int wpc2 = 1;
     while (wpc2 * 2 <= (nblk < kKvsWaves ? nblk : kKvsWaves)) wpc2 *= 2;
@@ -1414,6 +1416,7 @@ static int attn_kv_narrow(const pcr_attn_params *pp, pcr_stream_t stream) {
     return PCR_OK;
   }
 #endif
+  pcr_note_arith(PCR_PREC_F32);   // the tile kernel projects in f32 in both units (only the form of M differs)
   if (d == 32) hipLaunchKernelGGL((attn_kv_kernel<2, 1, 2, 1>), g, blk, lds, st, a);        // 2d = 64: two cout blocks
   else if (d == 64) hipLaunchKernelGGL((attn_kv_kernel_o3<2, 1, 1, 1>), g, blk, lds, st, a);   // four, one per wave
   else if (d == 128) hipLaunchKernelGGL((attn_kv_kernel_o3<1, 2, 1, 4>), g, blk, lds, st, a);  // eight, two rounds
@@ -1442,6 +1445,7 @@ static int attn_apply_launch(const pcr_attn_params *pp, pcr_stream_t stream) {
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
   dim3 g((p.Lq + T - 1) / T, p.B), blk(kThreads);
   hipStream_t st = pcr_s(stream);
+  pcr_note_arith(kAPrec != 0 ? PCR_PREC_BF16X3 : PCR_PREC_F32);   // (the bf unit is split bf16 whatever was requested)
 #if PCR_ATTN_PREC != 0
   const int aps_c1s = (p.c1 + 15) >> 4, aps_nd = p.d >> 5;
   const size_t aps_lds = (size_t)((aps_c1s + (p.q_pos ? 2 * aps_nd : 0)) * aps_nd * 128 + (aps_c1s + 2 * aps_nd) * aps_nd * 256 +
@@ -1581,6 +1585,7 @@ PCR_EXPORT int pcr_attn_kv_f32(const pcr_attn_params *pp, pcr_stream_t stream) {
     AttnArgs a;
     a.p = *pp;
     if (!pp->wkv_wide || !pp->bkv_wide || !pp->wmerge_packed || pp->B > 65535) return PCR_ERR_INVALID;
+    pcr_note_arith(PCR_PREC_F32);
     const int dh = d / pp->nhead;
     size_t lds = ((size_t)(pp->c2 + d + 3) * 33 + 4 * d + kThreads) * sizeof(float);
     const size_t lds2 = (size_t)dh * 65 * sizeof(float);

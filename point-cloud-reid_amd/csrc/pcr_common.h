@@ -16,6 +16,11 @@ static inline hipStream_t pcr_s(pcr_stream_t s) { return reinterpret_cast<hipStr
 
 constexpr int kWave = 64;
 
+// Diagnostics for bench.py's roofline object: the arithmetic (PCR_PREC_*) of the matrix phases of the model launch the
+// calling thread issued last (pcr_last_launch_arith, probe_kernels.hip).  Every dispatcher of section B notes what the
+// kernel it launches really runs -- the requested precision is only a request (shapes a bf16 unit does not hold run f32).
+void pcr_note_arith(int prec);
+
 // Tuning / ablation knobs (PCR_SA_DBG, PCR_TD_VARIANT, ...) are read from the environment ONLY in builds made with
 // -DPCR_TUNING=1 (PCR_EXTRA_HIPCC_FLAGS); the shipped library ignores the environment on its launch paths.
 #ifndef PCR_TUNING

@@ -1014,7 +1014,8 @@ __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_reg_kernel(const floa
         const bool has1 = lane + 64 < total;
         const uint32_t i1 = cand32[2 * lane + 128], d1r = cand32[2 * lane + 129];
         const uint32_t d1 = has1 ? d1r : 0x7F7FFFFFu;
-        const uint32_t dm = d0 < d1 ? d0 : d1;
+        const uint32_t dmr = d0 < d1 ? d0 : d1;
+        const uint32_t dm = dmr < 0x7F7FFFFFu ? dmr : 0x7F7FFFFFu;   // (+inf / NaN bits: the tagged key must stay a finite float)
         const uint32_t ts2 =
             (uint32_t)__builtin_amdgcn_readlane((int)pcr_wave_sort_posf32((dm & ~63u) | (uint32_t)lane, lane), K - 1);
         const uint32_t tau2 = ts2 | 63u;
@@ -1041,7 +1042,11 @@ __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_reg_kernel(const floa
         // 3a. one candidate per lane.  Fast form: sort 32-bit keys (distance bits with the low 6 bits replaced by
         // the SLOT) with the float network; exact unless two of the first K + 1 ranks share their truncated
         // distance (~1 % of the queries), which is detected on the sorted keys and sent through the 64-bit sort.
-        const uint32_t dj = cand32[2 * lane + 1];
+        // (a distance that overflowed to +inf, or a NaN, would make the tagged key a NaN pattern, which the float-min
+        // network mis-orders: clamped to the largest finite float -- such candidates then share their truncated key and
+        // the tie detector below sends the query through the exact 64-bit path, which sorts the RAW bits)
+        const uint32_t djr = cand32[2 * lane + 1];
+        const uint32_t dj = djr < 0x7F7FFFFFu ? djr : 0x7F7FFFFFu;
         const uint32_t key = lane < total ? ((dj & ~63u) | (uint32_t)lane) : (0x7F7FFFC0u | (uint32_t)lane);
         const uint32_t sk = pcr_wave_sort_posf32(key, lane);
         const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)sk, 0x130, 0xF, 0xF, false);   // lane + 1
@@ -1188,7 +1193,7 @@ __global__ __launch_bounds__(NT) void knn_prefix_lds_kernel(const float *__restr
 }  // namespace
 
 // ------------------------------------------------------------------------------ C ABI ----
-PCR_EXPORT int pcr_abi_version(void) { return 10; }
+PCR_EXPORT int pcr_abi_version(void) { return 11; }
 
 PCR_EXPORT const char *pcr_status_string(int status) {
   switch (status) {

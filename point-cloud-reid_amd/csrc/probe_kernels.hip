@@ -39,6 +39,10 @@ __global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long *ou
 
 }  // namespace
 
+static thread_local int g_last_arith = -1;
+void pcr_note_arith(int prec) { g_last_arith = prec; }
+PCR_EXPORT int pcr_last_launch_arith(void) { return g_last_arith; }
+
 PCR_EXPORT int pcr_wall_clock_khz(void) {
   int dev = 0, khz = 0;
   if (hipGetDevice(&dev) != hipSuccess ||

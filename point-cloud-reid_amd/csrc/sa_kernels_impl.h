@@ -1459,6 +1459,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   if (!p.wps_bf[0] || !p.wps_bf[1] || (p.c1 & 31) || (p.c2 & 31)) return -1;
   const float *const wl2 = p.wps_bf[0], *const wl3 = p.wps_bf[1];
 #endif
+  pcr_note_arith(kPrec);   // (every launch below runs layers 2 / 3 in this unit's arithmetic)
   if ((p.c1 & 7) || p.c1 > 512 || p.c2 > 512 || p.c3 > 512) return -1;
   const int pqw = p.mode == 0 ? 2 * p.c1 : p.c1;
   if (p.D && pqw > 1024) return -1;
@@ -1777,6 +1778,7 @@ static int dense_pm_launch(const float *x, const float *wp, float *y, int B, int
   if (cout > 256 && (cout & 3)) return PCR_ERR_INVALID;   // windows of 256 couts keep the 16-byte store path
   if (B == 0) return PCR_OK;
   if (B > 65535) return PCR_ERR_INVALID;
+  pcr_note_arith(precision);
   DensePmArgs d{x, wp, y, cin, cout, L, x_point_major};
   const int wmax = cout < 256 ? cout : 256;
   const int rows = ceil8(cin) > ceil32(wmax) ? ceil8(cin) : ceil32(wmax);
@@ -1826,6 +1828,7 @@ PCR_EXPORT int pcr_sa_mlp_f32(const pcr_sa_params *pp, pcr_stream_t stream) {
   if (p.B > 65535) return PCR_ERR_INVALID;
   const int fast = sa2_try(p, stream);
   if (fast >= 0) return fast;
+  pcr_note_arith(PCR_PREC_F32);
   SaArgs a;
   a.p = p;
   a.C0 = 3 + (p.mode == 0 ? 2 * p.D : p.D);

@@ -52,11 +52,18 @@ def build(force=False, verbose=False):
     objs = []
     procs = []
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(ROOT, "include", "pcr.h"), os.path.abspath(__file__)]
+    # the objects of a directory were all built with ONE flag set, recorded beside them: another set (a tagged library
+    # first built without -DPCR_TUNING=1 and later with it, say) rebuilds everything instead of reusing stale objects
+    flagset = " ".join(common + ["|"] + ["%s:%s" % (k, " ".join(v)) for k, v in sorted(FLAGS.items())])
+    stamp = os.path.join(objdir, "flags.txt")
+    same_flags = os.path.exists(stamp) and open(stamp).read() == flagset
+    if not same_flags and os.path.exists(stamp):
+        os.remove(stamp)
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
-        if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in [src] + hdrs) \
-                and (_TAG or (not os.environ.get("PCR_EXTRA_HIPCC_FLAGS") and not os.environ.get("PCR_POINT_FLAGS"))):
+        if not force and same_flags and os.path.exists(obj) and \
+                all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in [src] + hdrs):
             continue        # incremental: this object is newer than its source and every header
         cmd = [hipcc()] + common + FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
@@ -66,6 +73,8 @@ def build(force=False, verbose=False):
         out, _ = p.communicate()
         if p.returncode:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode()))
+    with open(stamp, "w") as f:
+        f.write(flagset)
     subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs)
     return SO
 

@@ -23,9 +23,13 @@ What is restated, and from where:
   virtual: the loader swaps numpy's global state per batch, so the samples are the ones those processes would draw, in
   one process and in a reproducible order.
 
-PARITY: unpinned, like pcr_amd/pairs.py -- the reference's dataset classes need `lamtk` and the sampler lives in mmdet,
-both absent; the tests pin reproducibility under a seed, the sharding invariants, and that two ranks fed by this loader
-train to the same weights as one process stepping on the concatenated batches.
+PARITY: the pair rule is pinned -- `tests/golden/pairs_toy.npz` holds the items the reference's own
+`ReIDDatasetNuscenesFP` returns on a toy crop directory (oracle/make_golden.py gen_pairs; the dataset and loader classes
+imported unmodified, stand-ins only for the absent lamtk / mmcv / mmdet imports), and `tests/test_pairs_golden.py`
+requires `TrainPairs` to return the same tensors, labels and ids item for item and to leave numpy's generator in the same
+state.  The sampler stays a restatement of mmdet 2.x (third party, not vendored by the reference, no version pinned
+there): its tests pin the sharding invariants, reproducibility under a seed, and that two ranks fed by this loader train
+to the same weights as one process stepping on the concatenated batches.
 """
 import math
 
@@ -113,16 +117,15 @@ def _frame_even(obj, density):
 
 class TrainPairs:
     """table: pcr_amd.pairs.ObjectTable; `read(token, observation) -> float32 [n, 3]` loads one sparse crop (e.g.
-    `CropDirectory.read`); `read_dense(token) -> [n, 3]` the aggregated cloud (optional: the sparse crop stands in).
-    Item i is built around true object i (the reference indexes `self.idx`, a shuffled list of the objects with at least
-    two observations: `shuffle=True` reproduces that shuffle under the global generator)."""
+    `CropDirectory.read`); `read_dense(token)` the aggregated cloud as the reference's complete loader returns it
+    (None: the sparse crop stands in).  Item i is built around true object `idx[i]` -- the objects with a tracked class
+    and more than two usable observations, shuffled once under the global generator at construction
+    (reidentification_base.py:201-250, `shuffle=False` keeps the table order)."""
 
     def __init__(self, table, read, subsample_sparse, subsample_dense=0, read_dense=None, ids=None, shuffle=True):
         self.table, self.read, self.read_dense = table, read, read_dense
         self.ns, self.nd = int(subsample_sparse), int(subsample_dense)
-        self.idx = np.array([i for i, o in enumerate(table.objects) if not o.get("fp") and len(o["frames"]) >= 2])
-        if shuffle:
-            self.idx = self.idx[np.random.permutation(len(self.idx))]
+        self.idx = table.shuffled_index() if shuffle else np.asarray(table.true_index, dtype=np.int64)
         self.ids = ids if ids is not None else {o["token"]: i for i, o in enumerate(table.objects)}
         self.flag = np.zeros(len(self), dtype=np.uint8)
         nb = len(BUCKETS)
@@ -140,7 +143,7 @@ class TrainPairs:
         t = self.table
         obj = t.objects[self.idx[i]]
         tok, cls = obj["token"], obj["cls"]
-        nums = sorted(obj["frames"])
+        nums = np.asarray(obj["nums"])
         if np.random.choice([0, 1]) == 1:
             a, b = np.random.choice(nums, 2, replace=False)
             s1, s2 = self.read(tok, int(a)), self.read(tok, int(b))
@@ -168,11 +171,54 @@ class TrainPairs:
             d2 = self._dense(other, s2)
         return self._item(s1, s2, d1, d2, cls, cls2, self.ids[tok], id2)
 
-    def _item(self, s1, s2, d1, d2, l1, l2, id1, id2):
-        cm = lambda p: np.moveaxis(np.asarray(p), 0, 1)      # noqa: E731  ([n,3] -> channel-major, as return_item does)
+    def _item(self, s1, s2, d1, d2, l1, l2, id1, id2, **extra):
+        """return_item (reidentification_base.py:427-438): every cloud arrives point-major [n, 3], is turned
+        channel-major and resampled by subsamplePC, sparse clouds first.  (With the reference's FakeCompleteLoader,
+        which returns zeros of shape (3, n), the same two calls see n 'channels' x 3 'points', cut to three rows and
+        resample from three columns: a `read_dense` that returns that shape reproduces it, tests/test_pairs_golden.py.)"""
+        cm = lambda p: np.moveaxis(np.asarray(p), 0, 1)      # noqa: E731
         s1, s2 = D.subsample_pc(cm(s1), self.ns), D.subsample_pc(cm(s2), self.ns)
         d1, d2 = D.subsample_pc(cm(d1), self.nd), D.subsample_pc(cm(d2), self.nd)
-        return dict(sparse_1=s1, sparse_2=s2, dense_1=d1, dense_2=d2, label_1=l1, label_2=l2, id_1=id1, id_2=id2)
+        out = dict(sparse_1=s1, sparse_2=s2, dense_1=d1, dense_2=d2, label_1=l1, label_2=l2, id_1=id1, id_2=id2)
+        out.update(extra)
+        return out
+
+
+class ValPairs:
+    """the validation dataset over a pair set of pcr_amd.pairs.build_val_pairs: positives first, then negatives
+    (ReIDDatasetNuscenesFPVal.__getitem__, reidentification_nuscenes.py:108-145), items with the `size_*` / `vis_*`
+    keys of return_item_size_vis (reidentification_base.py:455-483).  `vis_to_cls_id` maps nuScenes visibility tokens
+    1..4 to 0..3; the reference SWAPS the two visibility entries (`vis1, vis2 = DC(to_tensor(v2)), DC(to_tensor(v1))`,
+    :470) and so does this."""
+
+    VIS = {1: 0, 2: 1, 3: 2, 4: 3}
+
+    def __init__(self, table, positives, negatives, read, subsample_sparse, subsample_dense=0, read_dense=None, ids=None,
+                 visibility=None):
+        self.tp = TrainPairs(table, read, subsample_sparse, subsample_dense, read_dense, ids, shuffle=False)
+        self.table, self.pairs = table, list(positives) + list(negatives)
+        self.visibility = visibility or {}
+        self.flag = np.zeros(len(self), dtype=np.uint8)
+
+    def __len__(self):
+        return len(self.pairs)
+
+    def __getitem__(self, i):
+        p = self.pairs[i]
+        t, tp = self.table, self.tp
+        s1, s2 = tp.read(p["tok1"], p["o1"]), tp.read(p["tok2"], p["o2"])
+        d1 = tp._dense(p["tok1"], s1)
+        o2 = t.by_token[p["tok2"]]
+        if p["tok2"] == p["tok1"] and p["match"]:
+            d2, id2 = d1, tp.ids[p["tok1"]]
+        elif o2.get("fp"):
+            d2, id2 = np.random.randn(tp.nd, 3), -1
+        else:
+            d2, id2 = tp._dense(p["tok2"], s2), tp.ids[p["tok2"]]
+        v1 = self.VIS.get(self.visibility.get(p["tok1"], {}).get(int(p["o1"]), -1), -1)
+        v2 = self.VIS.get(self.visibility.get(p["tok2"], {}).get(int(p["o2"]), -1), -1)
+        return tp._item(s1, s2, d1, d2, p["cls1"], p["cls2"], tp.ids[p["tok1"]], id2,
+                        size_1=np.asarray(s1).shape[0], size_2=np.asarray(s2).shape[0], vis_1=v2, vis_2=v1)
 
 
 class CropDirectory:

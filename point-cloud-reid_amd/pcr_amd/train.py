@@ -150,7 +150,14 @@ class Trainer:
         grad_norm as a 0-d tensor on the parameters' device in BOTH optimizer paths -- `float()` it at log time, which is
         the only place it costs a host synchronisation; log_vars is a LazyScalars dict with the same property)."""
         lr, b1 = self._set_hyper()
-        if self.graph and self.iter >= self.graph_warmup and not shard.is_dist():   # (a captured log all-reduce: not attempted)
+        if self.graph and shard.is_dist():
+            # (a captured log all-reduce was not attempted: N > 1 ranks run eager, and `self.graph` says so -- bench.py
+            # reports the launch mode from this flag)
+            import warnings
+            warnings.warn("pcr_amd.train.Trainer: HIP-graph replay is a single-process mode; running eager on %d ranks"
+                          % shard.env_world()[2])
+            self.graph = False
+        if self.graph and self.iter >= self.graph_warmup:
             out = self._graph_step(data)
             if out is not None:
                 out["lr"], out["beta1"] = lr, b1
@@ -187,7 +194,13 @@ class Trainer:
         """-> the iteration's outputs from the captured graph, or None (graph mode switched off: the caller runs eager)"""
         from . import lazylog, train_ops
         keys = [k for k, v in data.items() if isinstance(v, (list, tuple)) and v and torch.is_tensor(v[0])]
-        sig = tuple((k, len(data[k]), tuple(data[k][0].shape), data[k][0].dtype) for k in keys)
+        sig = self._graph_signature(data, keys)
+        if sig is None:
+            import warnings
+            warnings.warn("pcr_amd.train.Trainer: this batch holds inputs a captured graph cannot take (bare tensors, "
+                          "ragged lists or objects); running eager")
+            self.graph, self._g = False, None
+            return None
         g = self._g
         if g is not None and g["sig"] != sig:
             g = self._g = None                      # another batch shape: capture again
@@ -225,10 +238,37 @@ class Trainer:
         # the replay wrote weights' packed images, BatchNorm statistics and gradients through captured launches: tell every
         # cache keyed by Tensor._version (the eager path's in-place ops / launches do this themselves)
         torch.autograd.graph.increment_version([b for b in g["bufs"] if b.is_floating_point()])
-        out = dict(g["out"])
+        # the captured outputs are STATIC tensors that the next replay overwrites: the caller gets its own copies (eager
+        # iterations hand out fresh tensors too; a caller may hold several iterations' losses before reading any)
+        out = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in g["out"].items()}
         if g["entries"]:
             out["log_vars"] = lazylog.LazyScalars.from_static(g["plain"], g["entries"])
         return out
+
+    def _graph_signature(self, data, keys):
+        """everything a captured iteration has baked in and a replay cannot see change: the shape and dtype of EVERY
+        element of every list input, the values of the non-tensor inputs, the arithmetic mode, the model's mode and
+        which parameters take gradients.  None: the batch holds something a replay cannot refresh (a bare tensor is read
+        at a captured address; a ragged list cannot be stacked)."""
+        from . import engine
+        sig = []
+        for k in sorted(data):
+            v = data[k]
+            if k in keys:
+                shapes = {(tuple(t.shape), t.dtype, t.device) for t in v}
+                if len(shapes) != 1 or not all(torch.is_tensor(t) for t in v):
+                    return None
+                sig.append((k, len(v), shapes.pop()))
+            elif v is None or isinstance(v, (bool, int, float, str)):
+                sig.append((k, type(v).__name__, v))
+            elif isinstance(v, (list, tuple)) and all(x is None or isinstance(x, (bool, int, float, str)) for x in v):
+                sig.append((k, type(v).__name__, tuple(v)))
+            else:
+                return None
+        sig.append(("precision", engine.PRECISION, "training", self.model.training,
+                    "requires_grad", tuple(p.requires_grad for p in self.model.parameters()),
+                    "stream_min_blocks", getattr(engine, "STREAM_MIN_BLOCKS", None)))
+        return tuple(sig)
 
     # ---- checkpoints (mmcv layout) ----
     def state(self):

@@ -92,3 +92,29 @@ def test_reference_configs_load_unchanged_and_build():
                     except FileNotFoundError:      # a few reference configs name bases that do not exist
                         broken.append(f)
     assert n > 80 and len(broken) <= 10, (n, broken)    # 8 misplaced files in the reference itself
+
+
+def test_eval_flip_swaps_every_input_of_the_training_path():
+    """`eval_flip=True` (ReIDNet.py:144-147 of the reference: 276-279) hands the two sides of every pair to the model in
+    swapped order -- clouds, dense clouds, labels and ids together"""
+    import copy
+    import sys
+    import torch
+    from conftest import ROOT
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    from mmdet3d.models import build_model
+    a = dict(sparse_1=[torch.full((4, 3), float(i)) for i in range(3)], sparse_2=[torch.full((4, 3), 10.0 + i) for i in range(3)],
+             dense_1=[torch.full((5, 3), 20.0 + i) for i in range(3)], dense_2=[torch.full((5, 3), 30.0 + i) for i in range(3)],
+             label_1=[torch.tensor([i]) for i in range(3)], label_2=[torch.tensor([5 + i]) for i in range(3)],
+             id_1=[torch.tensor([40 + i]) for i in range(3)], id_2=[torch.tensor([50 + i]) for i in range(3)])
+    outs = {}
+    for flip in (False, True):
+        cfg = copy.deepcopy(bench.PT_MODEL)
+        cfg["eval_flip"] = flip
+        outs[flip] = build_model(cfg).preprocess_inputs(**a)
+    s1, s2, d1, d2, l1, l2, i1, i2 = outs[False]
+    assert s1.shape == (3, 4, 3) and l2.tolist() == [5, 6, 7] and i1.tolist() == [40, 41, 42]
+    for x, y in zip(outs[True], (s2, s1, d2, d1, l2, l1, i2, i1)):
+        assert torch.equal(x, y)

@@ -552,11 +552,16 @@ def test_trainer_graph_mode_equals_eager_bit_for_bit():
         m, _ = bench.build_pt_model([128, 64, 32])
         m.train()
         tr = train.Trainer(m, max_iters=12, lr=1e-3, grad_clip=1.0, graph=mode)
-        rec = []
+        rec, held = [], []
         for it in range(7):
             out = tr.step(batch(10 + it))
+            held.append((out["loss"], out["log_vars"]))             # read only AFTER the loop (loader.run_epochs does that)
             rec.append((float(out["loss"]), float(out["grad_norm"]), out["log_vars"]["match_acc"], out["log_vars"]["loss"]))
         assert tr.graph == mode                                    # (the capture did not fall back)
+        # an iteration's outputs stay that iteration's: a replay must not overwrite what an earlier replay handed out
+        assert [float(l) for l, _ in held] == [r[0] for r in rec]
+        assert [lv["loss"] for _, lv in held] == [r[3] for r in rec]
+        assert len({l.data_ptr() for l, _ in held}) == len(held)
         m.eval()
         s1, s2 = T.synthetic_pairs(4, 128, seed=3)
         with torch.no_grad():
@@ -566,3 +571,32 @@ def test_trainer_graph_mode_equals_eager_bit_for_bit():
     for k, v in runs[False][1].items():
         assert torch.equal(v, runs[True][1][k]), k
     assert torch.equal(runs[False][2], runs[True][2])
+
+
+def test_eval_flip_equals_the_swapped_batch():
+    """eval_flip (ReIDNet.py:144-147): the training path on a batch with eval_flip=True computes, bit for bit, what it
+    computes on the batch with its two sides swapped"""
+    import copy
+    import bench
+    from mmdet3d.models import build_model
+    s1, s2 = T.synthetic_pairs(6, 128, seed=21, kind="randn")
+    ids1 = torch.arange(6)
+    ids2 = torch.where(torch.arange(6) % 2 == 0, ids1, ids1 + 100)
+    zero = torch.zeros(1, dtype=torch.long, device="cuda")
+
+    def batch(a, b, ia, ib):
+        return dict(sparse_1=list(a.cuda()), sparse_2=list(b.cuda()), dense_1=list(a.cuda()), dense_2=list(b.cuda()),
+                    label_1=[zero] * 6, label_2=[zero] * 6, id_1=[i.view(1).cuda() for i in ia], id_2=[i.view(1).cuda() for i in ib])
+    man = T.load_manifest(os.path.join(bench.ROOT, "tests", "golden", "pt_manifest.json"))
+    sd = T.seeded_state_dict(man, 0)
+    loss = {}
+    for flip in (False, True):
+        cfg = copy.deepcopy(bench.PT_MODEL)
+        cfg["eval_flip"] = flip
+        m = build_model(cfg)
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda().train()
+        data = batch(s1, s2, ids1, ids2) if flip else batch(s2, s1, ids2, ids1)
+        out = m.train_step(data, None)
+        loss[flip] = (float(out["loss"]), out["log_vars"]["match_acc"])
+    assert loss[False] == loss[True]

@@ -65,7 +65,8 @@ def test_training_pair_rule(tmp_path):
     meta = make_crops(str(tmp_path))
     ds = dataset(str(tmp_path), meta)
     t = ds.table
-    assert len(ds) == sum(1 for o in t.objects if not o["fp"] and len(o["frames"]) >= 2)
+    # (the reference keeps objects with MORE than two observations: `temp > 2`, reidentification_base.py:214)
+    assert len(ds) == sum(1 for o in t.objects if not o["fp"] and len(o["frames"]) >= 3)
     np.random.seed(1)
     items = [ds[i % len(ds)] for i in range(200)]
     pos = [it for it in items if it["id_1"] == it["id_2"]]

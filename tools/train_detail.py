@@ -24,7 +24,7 @@ tr.step(data)
 torch.cuda.synchronize()
 rec, engine.PROFILE = engine.PROFILE, None
 tot = {}
-for name, e0, e1, flops, nbytes, _ in rec:
+for name, e0, e1, flops, nbytes, _, _arith in rec:
     t = tot.setdefault(name, [0.0, 0, 0.0, 0.0])
     t[0] += e0.elapsed_time(e1); t[1] += 1; t[2] += flops; t[3] += nbytes
 for k, v in sorted(tot.items(), key=lambda kv: -kv[1][0]):
