@@ -497,7 +497,11 @@ def measure(workload, args, rank, world, pairs=None, cloud_kind=None, skip_repea
         with torch.no_grad(), engine.precision("f32"):
             ref = hot_path(model, s1, s2)
         rec = dict(value=world * pairs * steps / dt, unit="pairs/s", steps=steps, warmup=warmup,
-                   ms_per_step=dt / steps * 1e3, per_rank_ms_per_step=per_rank, dtype=PREC_INFO[engine.PRECISION][0],
+                   ms_per_step=dt / steps * 1e3, per_rank_ms_per_step=per_rank,
+                   # the arithmetic the workload's dominant matrix launch ran in (PointNet / DGCNN: their encoder GEMMs
+                   # are f32-input MFMA whatever the mode; only their matching attention follows it)
+                   dtype=(roof.get("kernel_arithmetic") if roof["bound"] == "mfma" and roof.get("kernel_arithmetic")
+                          else PREC_INFO[engine.PRECISION][0]),
                    max_abs_dlogit_vs_f32_path=float((out - ref).abs().max()),
                    data="synthetic (%s clouds, seeded random-init weights with non-trivial BN statistics)" % cloud_kind,
                    config={"workload": "%s: %s" % (workload, desc), "pairs_per_gpu_per_step": pairs, "points": n,

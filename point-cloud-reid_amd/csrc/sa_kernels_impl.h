@@ -989,6 +989,210 @@ void sa_stream_rag_kernel(RagArgs a) {
 }
 #endif
 
+#if PCR_SA_PREC != 0
+// ---- cout-split ragged kernel (round 4): the layers whose weight images do not fit LDS beside anything else (SSG SA2:
+// 128 / 128 / 256 = 192 KB of hi + lo images) and whose tile form therefore streamed 192 KB of weights from L2 for every
+// 64-row tile (13 GB per ssg1024 launch; the dense phases ran at 0.45 of their MFMA floor).  Here the WEIGHTS never move:
+// a workgroup has eight waves, wave w keeps cout block w % NCB of layer 2 and cout block w % NCB3 of layer 3 in its
+// registers for the whole (persistent) kernel -- 64 + 64 VGPRs at 128 / 128 / 256 -- and the ACTIVATIONS of a tile of
+// 32 RB rows (RB = 8 / NCB row blocks) travel through LDS as bf images (tile_dense.h), whose pieces are exactly the MFMA
+// operands: two ds_read_b128 per three MFMAs, nothing else.  Per tile:
+//   A  layer 1: wave (cb = w % NCB, rb = w / NCB) gathers the four 16-byte table pieces of its rows' neighbours in
+//      accumulator layout, two f32 MFMAs add Wa dxyz to the shift seeds, ReLU + split -> image X1      | barrier
+//   B  layer 2: the same (cb, rb): NS steps of {2 LDS reads, 3 MFMAs} against the resident weights -> image X2 | barrier
+//   C  layer 3 TRANSPOSED (activations as the A operand): wave w, cout block w % NCB3, row blocks w / NCB3 + k G3; lane
+//      (cout, h) then holds tokens 8 g + 4 h + q of its channel: a row pair is two registers of one lane, and its
+//      maximum joins the centre's row of `obuf` by an LDS integer max (order-independent: deterministic)  | barrier
+//   D  the tile's centres leave obuf as whole 16-byte pieces; obuf returns to 0 (= the ReLU).
+// The row entry {neighbour, dxyz} of the NEXT tile is requested after A, its table pieces after B's MFMAs are issued:
+// both round trips run under the matrix phases.  Tiles, row tables and segment masks are sa_rag_kernel's (the same
+// pre-kernels); every row goes through the same instruction sequence wherever it sits, so ragged and K-row evaluation
+// (counts absent: K rows per centre) agree bit for bit.
+template <int NCB, int NCB3, bool LO>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void sa_wsplit_rag_kernel(RagArgs a) {
+  constexpr int NS = 2 * NCB, RB = 8 / NCB, ROWS = 32 * RB, NG = ROWS / kRagG, CT = kRagCT;
+  constexpr int G3 = 8 / NCB3, NRB3 = RB / G3, C = 32 * NCB, C3 = 32 * NCB3;
+  static_assert(NCB * RB == 8 && NCB3 * G3 == 8 && NRB3 * G3 == RB, "eight waves cover every (cout block, row block)");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *x1 = smem;                                    // bf image [C / 8 pieces][hi, lo][ROWS] 16-byte units
+  float *x2 = x1 + C * ROWS;                           // (hi + lo of C x ROWS = the bytes of the f32 tile)
+  int *obuf = reinterpret_cast<int *>(x2 + C * ROWS);  // [NG centres][C3] running maxima (bit patterns >= 0)
+  float *s_sh1 = reinterpret_cast<float *>(obuf + NG * C3);
+  float *s_sh2 = s_sh1 + C, *s_sh3 = s_sh2 + C;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cb2 = w % NCB, rb2 = w / NCB;              // layers 1 / 2: this wave's tile
+  const int cb3 = w % NCB3, rb3 = w / NCB3;            // layer 3: cout block, first row block (then + G3)
+  for (int e = tid; e < C; e += 512) {
+    s_sh1[e] = a.sh1[e];
+    s_sh2[e] = a.sh2[e];
+  }
+  for (int e = tid; e < C3; e += 512) s_sh3[e] = a.sh3[e];
+  for (int e = tid; e < NG * C3; e += 512) obuf[e] = 0;
+  // resident weights (the images' unit of (step s, cout block cb, part) is ((s nCB + cb) 2 + part) 64 + lane)
+  bf16x8 w2h[NS], w2l[NS], w3h[NS], w3l[NS];
+  {
+    const bf16x8 *i2 = reinterpret_cast<const bf16x8 *>(a.wp2) + lane, *i3 = reinterpret_cast<const bf16x8 *>(a.wp3) + lane;
+#pragma unroll
+    for (int s2 = 0; s2 < NS; s2++) {
+      w2h[s2] = i2[((s2 * NCB + cb2) * 2) * 64];
+      w3h[s2] = i3[((s2 * NCB3 + cb3) * 2) * 64];
+      if constexpr (LO) {
+        w2l[s2] = i2[((s2 * NCB + cb2) * 2 + 1) * 64];
+        w3l[s2] = i3[((s2 * NCB3 + cb3) * 2 + 1) * 64];
+      }
+    }
+  }
+  const f32x4 av = reinterpret_cast<const f32x4 *>(a.wap)[cb2 * 64 + j * 2 + h];   // layer 1's A operand (k = h, 2 + h)
+  const float sv3 = a.sh3[cb3 * 32 + j];
+  // XCD-aware tile ranges, as sa_rag_kernel: the tiles of a cloud gather rows of one table -> one L2
+  const int n_all = a.ws[a.B];
+  const bool xaware = gridDim.x >= 8;
+  const int xcd = blockIdx.x & 7;
+  const int t_step = xaware ? ((int)gridDim.x + 7 - xcd) >> 3 : (int)gridDim.x;
+  const int t_lo = xaware ? (int)((long long)n_all * xcd / 8) : 0;
+  const int total = xaware ? (int)((long long)n_all * (xcd + 1) / 8) : n_all;
+  const int t_first = xaware ? t_lo + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int4 *flat = reinterpret_cast<const int4 *>(a.ws + rag_flat_off(a.B, a.maxT));
+  const int *ctab = a.ws + rag_ctab_off(a.B, a.maxT);
+  const f32x4 *rowtab = reinterpret_cast<const f32x4 *>(a.ws + rag_rowtab_off(a.B, a.maxT, ROWS));
+  const bf16x8 *x1u = reinterpret_cast<const bf16x8 *>(x1), *x2u = reinterpret_cast<const bf16x8 *>(x2);
+  const int r1 = rb2 * 32 + j;                         // this lane's row in phases A / B
+  f32x4 rv = {__int_as_float(-1), 0.f, 0.f, 0.f};
+  f32x4 p4[4];
+#pragma unroll
+  for (int g = 0; g < 4; g++) p4[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto fetch_row = [&](int tile) {
+    if (tile < total) rv = rowtab[(size_t)tile * ROWS + r1];
+  };
+  auto gather = [&](int tile) {
+    if (tile < total && a.pq) {
+      const size_t bt = (size_t)flat[tile].x;
+      const int i = __float_as_int(rv[0]);
+      const float *pr = a.pq + (bt * a.N + (size_t)(i < 0 ? 0 : i)) * a.pqw + cb2 * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; g++) p4[g] = *reinterpret_cast<const f32x4 *>(pr + 8 * g);
+    }
+  };
+  fetch_row(t_first);
+  gather(t_first);
+  __syncthreads();
+  for (int tile = t_first; tile < total; tile += t_step) {
+    const int4 td = flat[tile];
+    const size_t b = (size_t)td.x;
+    const int first = td.y, nc = td.z;
+    const unsigned ends_lo = (unsigned)ctab[(size_t)tile * CT], ends_hi = (unsigned)ctab[(size_t)tile * CT + 1];
+    const int ngr = ctab[(size_t)tile * CT + 2];       // row groups (pairs) in use
+    // ---- A: layer 1 of (cb2, rb2)   (a.dbg: PCR_SA_DBG ablation mask of tuning builds, 0 in production)
+    if (!(a.dbg & 1)) {
+      f32x16 acc;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const f32x4 s4 = *reinterpret_cast<const f32x4 *>(s_sh1 + 32 * cb2 + 8 * g + 4 * h);
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[4 * g + q] = s4[q];
+      }
+      const float b0 = h ? rv[2] : rv[1], b1 = h ? 0.f : rv[3];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], b0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], b1, acc, 0, 0, 0);
+      if (a.pq) {
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) acc[rr] += p4[rr >> 2][rr & 3];
+      }
+      bf_store_tile<LO>(x1, ROWS, acc, cb2, rb2, j, h);
+    }
+    fetch_row(tile + t_step);                          // (lands during layer 2)
+    __syncthreads();
+    // ---- B: layer 2 of (cb2, rb2)
+    {
+      f32x16 y;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const f32x4 s4 = *reinterpret_cast<const f32x4 *>(s_sh2 + 32 * cb2 + 8 * g + 4 * h);
+#pragma unroll
+        for (int q = 0; q < 4; q++) y[4 * g + q] = s4[q];
+      }
+      const bf16x8 *xb = x1u + 2 * h * ROWS + r1;      // piece 2 s + h of step s: unit (2 (2 s + h) + part) ROWS + row
+      if (!(a.dbg & 2))
+#pragma unroll
+      for (int s2 = 0; s2 < NS; s2++) {
+        const bf16x8 xh = xb[(4 * s2) * ROWS];
+        if constexpr (LO) {
+          const bf16x8 xl = xb[(4 * s2 + 1) * ROWS];
+          y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2h[s2], xl, y, 0, 0, 0);
+          y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2l[s2], xh, y, 0, 0, 0);
+        }
+        y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2h[s2], xh, y, 0, 0, 0);
+      }
+      gather(tile + t_step);                           // next tile's table pieces: in flight during layer 3
+      if (!(a.dbg & 32)) bf_store_tile<LO>(x2, ROWS, y, cb2, rb2, j, h);
+    }
+    __syncthreads();
+    // ---- C: layer 3 (transposed) of cout block cb3, row blocks rb3 + k G3; pair maxima -> obuf
+    {
+      f32x16 y3[NRB3];
+#pragma unroll
+      for (int k = 0; k < NRB3; k++)
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) y3[k][rr] = sv3;
+      if (!(a.dbg & 4))
+#pragma unroll
+      for (int s2 = 0; s2 < NS; s2++) {
+#pragma unroll
+        for (int k = 0; k < NRB3; k++) {
+          const bf16x8 *xa = x2u + 2 * h * ROWS + (rb3 + k * G3) * 32 + j;
+          const bf16x8 ah = xa[(4 * s2) * ROWS];
+          if constexpr (LO) {
+            const bf16x8 al = xa[(4 * s2 + 1) * ROWS];
+            y3[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, w3h[s2], y3[k], 0, 0, 0);
+            y3[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, w3l[s2], y3[k], 0, 0, 0);
+          }
+          y3[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, w3h[s2], y3[k], 0, 0, 0);
+        }
+      }
+      // token 8 g + 4 h + 2 pr (+ 1) of row block rb = row group q = 16 rb + 4 g + 2 h + pr; its centre = the number of
+      // centre-closing groups before q (ctab's `ends` mask)
+      if (!(a.dbg & 8))
+#pragma unroll
+      for (int k = 0; k < NRB3; k++)
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+          for (int pr = 0; pr < 2; pr++) {
+            const int q = 16 * (rb3 + k * G3) + 4 * g + 2 * h + pr;
+            if (q < ngr) {
+              int c;
+              if (NG <= 32 || q < 32) c = __popc(ends_lo & ((1u << q) - 1u));
+              else c = __popc(ends_lo) + __popc(ends_hi & ((1u << (q - 32)) - 1u));
+              const int v = imax(__float_as_int(y3[k][4 * g + 2 * pr]), __float_as_int(y3[k][4 * g + 2 * pr + 1]));
+              __hip_atomic_fetch_max(obuf + c * C3 + cb3 * 32 + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
+    }
+    __syncthreads();
+    // ---- D: the tile's centres; obuf back to +0
+    if (a.dbg & 16) continue;
+    if (a.out_pm) {
+      int4 *ob4 = reinterpret_cast<int4 *>(obuf);
+      int4 *dst = reinterpret_cast<int4 *>(a.out + (b * a.S + first) * (size_t)C3);
+      for (int e = tid; e < nc * (C3 / 4); e += 512) {
+        dst[e] = ob4[e];
+        ob4[e] = make_int4(0, 0, 0, 0);
+      }
+    } else {
+      for (int e = tid; e < nc * C3; e += 512) {
+        const int c = e / C3, o = e - c * C3;
+        a.out[(b * C3 + o) * (size_t)a.S + first + c] = __int_as_float(obuf[e]);
+        obuf[e] = 0;
+      }
+    }
+    // (no barrier here: the next tile's phase A writes X1, dead since this tile's phase B; obuf is next touched by the
+    // atomics of phase C, two barriers from now)
+  }
+}
+#endif
+
 // PCR_SA_TRACE=<file> (diagnostics only): wave 0 of every workgroup stamps the shader clock at the phase
 // boundaries of its first kTraceTiles tiles; the host dumps the buffer after the launch
 constexpr int kTraceWgs = 1024, kTraceTiles = 24, kTraceMarks = 8;
@@ -1573,6 +1777,23 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
         }();
         const long long max_tiles = (long long)p.B * r.maxT;
         const int w2 = n2r >= 3 ? 1 : (n2r == 2 ? 2 : 4), w3 = n3r >= 3 ? 1 : (n3r == 2 ? 2 : 4);
+#if PCR_SA_PREC != 0
+        {
+          // cout-split form with register-resident weights (shape-only choice): 128 / 128 / 256 on 64-row tiles
+          static const int no_wsplit = pcr_tune_int("PCR_SA_NO_WSPLIT");   // diagnostics
+          if (!no_wsplit && tb == 2 && p.c1 == 128 && p.c2 == 128 && p.c3 == 256 && p.wa_packed) {
+            constexpr bool kLoW = kPrec == 1;
+            static bool okw = allow_big_lds(sa_wsplit_rag_kernel<4, 8, kLoW>);
+            (void)okw;
+            const size_t lds_w = ((size_t)2 * 128 * 64 + (size_t)32 * 256 + 2 * 128 + 256) * sizeof(float);
+            long long want = n_cu;                                           // persistent: one 8-wave workgroup per CU
+            if (want > max_tiles) want = max_tiles;
+            hipLaunchKernelGGL((sa_wsplit_rag_kernel<4, 8, kLoW>), dim3((unsigned)want), dim3(512), lds_w, st, r);
+            if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
+            return PCR_OK;
+          }
+        }
+#endif
 #define PCR_RAG(TBv, NRv, A2, A3, NR2v, W1v)                                                             \
   do {                                                                                                   \
     auto kern = sa_rag_kernel<TBv, NRv, A2, A3, NR2v, W1v, kPrec>;                                       \

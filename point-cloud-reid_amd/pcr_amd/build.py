@@ -32,6 +32,23 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def includes_of(src, _seen=None):
+    """src and every project header it includes, transitively (`#include "x.h"` resolved against csrc/ and include/)"""
+    import re
+    seen = _seen if _seen is not None else {}
+    if src in seen:
+        return list(seen)
+    seen[src] = True
+    with open(src) as f:
+        for name in re.findall(r'^\s*#\s*include\s*"([^"]+)"', f.read(), flags=re.M):
+            for d in (os.path.dirname(src), CSRC, os.path.join(ROOT, "include")):
+                cand = os.path.join(d, name)
+                if os.path.exists(cand):
+                    includes_of(cand, seen)
+                    break
+    return list(seen)
+
+
 def needs_build():
     if not os.path.exists(SO):
         return True
@@ -51,7 +68,6 @@ def build(force=False, verbose=False):
     common += os.environ.get("PCR_EXTRA_HIPCC_FLAGS", "").split()      # diagnostic builds only
     objs = []
     procs = []
-    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(ROOT, "include", "pcr.h"), os.path.abspath(__file__)]
     # the objects of a directory were all built with ONE flag set, recorded beside them: another set (a tagged library
     # first built without -DPCR_TUNING=1 and later with it, say) rebuilds everything instead of reusing stale objects
     flagset = " ".join(common + ["|"] + ["%s:%s" % (k, " ".join(v)) for k, v in sorted(FLAGS.items())])
@@ -63,7 +79,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
         if not force and same_flags and os.path.exists(obj) and \
-                all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in [src] + hdrs):
+                all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in includes_of(src)):
             continue        # incremental: this object is newer than its source and every header
         cmd = [hipcc()] + common + FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:

@@ -77,7 +77,7 @@ def dense_gn(x, wp, cout, gn, res=None, relu=False):
     if res is not None:
         res = res.contiguous()
     with _E._prof("dense_gn[cin=%d,cout=%d,L=%d]" % (cin, cout, Ln), 2.0 * B * Ln * cin * cout,
-                  4.0 * B * Ln * (cin + cout * (2 if res is not None else 1))):
+                  4.0 * B * Ln * (cin + cout * (2 if res is not None else 1)), arith="f32"):
         L.check(L.load().pcr_dense_gn_f32(L.ptr(x), L.ptr(wp), L.ptr(g), L.ptr(b), L.ptr(res), L.ptr(y), B, cin, cout,
                                           Ln, gn.num_groups, 1 if relu else 0, L.stream_ptr()), "pcr_dense_gn_f32")
     return y
