@@ -203,10 +203,18 @@ typedef struct pcr_sa_params {
    * images of the matrices wps[l] holds.  Shapes the bf16 kernels do not cover run in f32. */
   int precision;
   const float *wps_bf[2];
+  /* optional (ABI 11): pcr_pack_weight_f32 image of the (c1, 4) matrix [wa | shift[0]] -- the cout-split kernel feeds
+   * (dx, dy, dz, 1) to the matrix core, so that layer 1's shift arrives with the coordinate term and costs no seed
+   * reads.  Without it that kernel is not chosen. */
+  const float *wa_shift_packed;
 } pcr_sa_params;
 int pcr_sa_mlp_f32(const pcr_sa_params *p, pcr_stream_t stream);
 /* ints of pcr_sa_params.tile_ws for the duplicate-free evaluation (tile lists + per-tile row tables) */
 long pcr_sa_tile_ws_ints(int B, int S, int K, int c2, int c3);
+/* 1: a launch of this shape WITHOUT hit counts (cnt NULL: all K rows of every group) also runs on the tile plan and
+ * wants tile_ws (the cout-split kernel with register-resident weights, 128 / 128 / 256 in the bf16 modes): ragged and
+ * K-row evaluation of such a layer then share one kernel, hence one arithmetic. */
+int pcr_sa_krow_uses_tiles(int c1, int c2, int c3, int K, int precision);
 
 /* Per-point linear map with POINT-major output: x (B,cin,L) channel-major (or (B,L,cin) when x_point_major)
  * -> y (B,L,cout) = W x, wp packed (cout,cin), cout <= 1024 (a multiple of 4 beyond 256).  This is the table builder of the decomposed first

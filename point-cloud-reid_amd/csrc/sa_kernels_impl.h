@@ -688,6 +688,7 @@ struct RagArgs {
   int *ws;
   const float *wa, *pq;
   const float *wap;         // packed (c1, 3) image of wa (layer 1 on the matrix core), or null
+  const float *wap4;        // packed (c1, 4) image of [wa | shift of layer 1] (sa_wsplit_rag_kernel), or null
   int pqw;
   int dbg;                  // PCR_SA_DBG ablation mask (diagnostics only; 0 in production)
   int out_pm;               // out is (B,S,c3)
@@ -989,6 +990,9 @@ void sa_stream_rag_kernel(RagArgs a) {
 }
 #endif
 
+constexpr int kTraceWgs = 1024, kTraceTiles = 24, kTraceMarks = 8;
+__device__ unsigned long long g_rag_trace[kTraceWgs * (2 + kTraceTiles * kTraceMarks)];
+
 #if PCR_SA_PREC != 0
 // ---- cout-split ragged kernel (round 4): the layers whose weight images do not fit LDS beside anything else (SSG SA2:
 // 128 / 128 / 256 = 192 KB of hi + lo images) and whose tile form therefore streamed 192 KB of weights from L2 for every
@@ -996,18 +1000,24 @@ void sa_stream_rag_kernel(RagArgs a) {
 // a workgroup has eight waves, wave w keeps cout block w % NCB of layer 2 and cout block w % NCB3 of layer 3 in its
 // registers for the whole (persistent) kernel -- 64 + 64 VGPRs at 128 / 128 / 256 -- and the ACTIVATIONS of a tile of
 // 32 RB rows (RB = 8 / NCB row blocks) travel through LDS as bf images (tile_dense.h), whose pieces are exactly the MFMA
-// operands: two ds_read_b128 per three MFMAs, nothing else.  Per tile:
-//   A  layer 1: wave (cb = w % NCB, rb = w / NCB) gathers the four 16-byte table pieces of its rows' neighbours in
-//      accumulator layout, two f32 MFMAs add Wa dxyz to the shift seeds, ReLU + split -> image X1      | barrier
-//   B  layer 2: the same (cb, rb): NS steps of {2 LDS reads, 3 MFMAs} against the resident weights -> image X2 | barrier
+// operands: two ds_read_b128 per three MFMAs, nothing else.  The work of a tile:
+//   A  layer 1: wave (cb = w % NCB, rb = w / NCB) holds the four 16-byte table pieces of its rows' neighbours in
+//      accumulator layout, two f32 MFMAs add Wa dxyz to the shift seeds, ReLU + split -> image X1;
+//   B  layer 2: the same (cb, rb): NS steps of {2 LDS reads, 3 MFMAs} against the resident weights -> image X2;
 //   C  layer 3 TRANSPOSED (activations as the A operand): wave w, cout block w % NCB3, row blocks w / NCB3 + k G3; lane
 //      (cout, h) then holds tokens 8 g + 4 h + q of its channel: a row pair is two registers of one lane, and its
-//      maximum joins the centre's row of `obuf` by an LDS integer max (order-independent: deterministic)  | barrier
-//   D  the tile's centres leave obuf as whole 16-byte pieces; obuf returns to 0 (= the ReLU).
-// The row entry {neighbour, dxyz} of the NEXT tile is requested after A, its table pieces after B's MFMAs are issued:
-// both round trips run under the matrix phases.  Tiles, row tables and segment masks are sa_rag_kernel's (the same
-// pre-kernels); every row goes through the same instruction sequence wherever it sits, so ragged and K-row evaluation
-// (counts absent: K rows per centre) agree bit for bit.
+//      maximum goes to row `pair` of obuf with one plain LDS store;
+//   D  every centre is reduced over its own pairs (signed maxima of the bit patterns from +0: the ReLU) and leaves as
+//      whole 16-byte pieces.
+// Eight waves in lockstep would run these phases one after the other, the matrix pipe idle during A, D and both
+// epilogues (first version: 1.5 ms per ssg1024 launch, ablations: MFMA phases 0.65 ms, everything else 0.9).  So the
+// tiles are SOFTWARE-PIPELINED inside every wave, two barriers per tile:
+//   step 1 (i):  B(i)'s MFMA steps, between them the pair maxima of tile i - 1 -> obuf | X2 | barrier
+//   step 2 (i):  C(i)'s MFMA steps, between them gather(i + 1), D(i - 1), A(i + 1) -> the other X1 buffer, the row entry
+//                of tile i + 2 | barrier
+// (one piece of side work per MFMA triple, pinned by scheduling barriers: the vector unit issues while the matrix pipe
+// is busy).  Tiles, row tables and segment masks are sa_rag_kernel's (the same pre-kernels); every row goes through the
+// same instruction sequence wherever it sits, so ragged and K-row evaluation agree bit for bit.
 template <int NCB, int NCB3, bool LO>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void sa_wsplit_rag_kernel(RagArgs a) {
@@ -1015,21 +1025,16 @@ void sa_wsplit_rag_kernel(RagArgs a) {
   constexpr int G3 = 8 / NCB3, NRB3 = RB / G3, C = 32 * NCB, C3 = 32 * NCB3;
   static_assert(NCB * RB == 8 && NCB3 * G3 == 8 && NRB3 * G3 == RB, "eight waves cover every (cout block, row block)");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *x1 = smem;                                    // bf image [C / 8 pieces][hi, lo][ROWS] 16-byte units
-  float *x2 = x1 + C * ROWS;                           // (hi + lo of C x ROWS = the bytes of the f32 tile)
-  int *obuf = reinterpret_cast<int *>(x2 + C * ROWS);  // [NG centres][C3] running maxima (bit patterns >= 0)
-  float *s_sh1 = reinterpret_cast<float *>(obuf + NG * C3);
-  float *s_sh2 = s_sh1 + C, *s_sh3 = s_sh2 + C;
+  float *x1 = smem;                                    // 2 x bf image [C / 8 pieces][hi, lo][ROWS] 16-byte units
+  float *x2 = x1 + 2 * C * ROWS;                       // (hi + lo of C x ROWS = the bytes of the f32 tile)
+  int *obuf = reinterpret_cast<int *>(x2 + C * ROWS);  // [NG row pairs][C3] pair maxima of the tile before (bit patterns)
+  float *s_sh2 = reinterpret_cast<float *>(obuf + NG * C3);
+  int *coff = reinterpret_cast<int *>(s_sh2 + C);      // [NG + 1] first row pair of every centre of that tile
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cb2 = w % NCB, rb2 = w / NCB;              // layers 1 / 2: this wave's tile
   const int cb3 = w % NCB3, rb3 = w / NCB3;            // layer 3: cout block, first row block (then + G3)
-  for (int e = tid; e < C; e += 512) {
-    s_sh1[e] = a.sh1[e];
-    s_sh2[e] = a.sh2[e];
-  }
-  for (int e = tid; e < C3; e += 512) s_sh3[e] = a.sh3[e];
-  for (int e = tid; e < NG * C3; e += 512) obuf[e] = 0;
+  for (int e = tid; e < C; e += 512) s_sh2[e] = a.sh2[e];
   // resident weights (the images' unit of (step s, cout block cb, part) is ((s nCB + cb) 2 + part) 64 + lane)
   bf16x8 w2h[NS], w2l[NS], w3h[NS], w3l[NS];
   {
@@ -1044,7 +1049,9 @@ void sa_wsplit_rag_kernel(RagArgs a) {
       }
     }
   }
-  const f32x4 av = reinterpret_cast<const f32x4 *>(a.wap)[cb2 * 64 + j * 2 + h];   // layer 1's A operand (k = h, 2 + h)
+  // layer 1's A operand, k = h and 2 + h of [wa | shift]: the B operand is (dx, dy, dz, 1), so the shift arrives with
+  // the coordinate term (no seed reads; the accumulator starts from the gathered table pieces)
+  const f32x4 av = reinterpret_cast<const f32x4 *>(a.wap4)[cb2 * 64 + j * 2 + h];
   const float sv3 = a.sh3[cb3 * 32 + j];
   // XCD-aware tile ranges, as sa_rag_kernel: the tiles of a cloud gather rows of one table -> one L2
   const int n_all = a.ws[a.B];
@@ -1057,54 +1064,164 @@ void sa_wsplit_rag_kernel(RagArgs a) {
   const int4 *flat = reinterpret_cast<const int4 *>(a.ws + rag_flat_off(a.B, a.maxT));
   const int *ctab = a.ws + rag_ctab_off(a.B, a.maxT);
   const f32x4 *rowtab = reinterpret_cast<const f32x4 *>(a.ws + rag_rowtab_off(a.B, a.maxT, ROWS));
-  const bf16x8 *x1u = reinterpret_cast<const bf16x8 *>(x1), *x2u = reinterpret_cast<const bf16x8 *>(x2);
-  const int r1 = rb2 * 32 + j;                         // this lane's row in phases A / B
+  const bf16x8 *x2u = reinterpret_cast<const bf16x8 *>(x2);
+  const int r1 = rb2 * 32 + j;                         // this lane's row in layers 1 / 2
   f32x4 rv = {__int_as_float(-1), 0.f, 0.f, 0.f};
-  f32x4 p4[4];
+  // layer 1's accumulator doubles as the gather destination: the table pieces land in it, the shift seeds are added
+  // when they have, the two coordinate MFMAs accumulate on top ((P + shift) + Wa dxyz)
+  f32x16 acc1;
 #pragma unroll
-  for (int g = 0; g < 4; g++) p4[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int rr = 0; rr < 16; rr++) acc1[rr] = 0.f;
+  // buffer addressing (scalar base + one 32-bit lane offset): 64-bit lane addresses of the row table, the feature
+  // table and the output were hoisted out of the tile loop as invariants and spilled
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<f32x4 *>(rowtab), 0, (int)((size_t)n_all * ROWS * 16 > 0x7FFFFFFFull ? 0x7FFFFFFF : (size_t)n_all * ROWS * 16), 0x00020000);
+  const int vo_row = r1 * 16, vo_pq = (cb2 * 32 + 4 * h) * 4;
   auto fetch_row = [&](int tile) {
-    if (tile < total) rv = rowtab[(size_t)tile * ROWS + r1];
+    if (tile < total)
+      rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrow, vo_row, tile * (ROWS * 16), 0));
   };
-  auto gather = [&](int tile) {
-    if (tile < total && a.pq) {
-      const size_t bt = (size_t)flat[tile].x;
-      const int i = __float_as_int(rv[0]);
-      const float *pr = a.pq + (bt * a.N + (size_t)(i < 0 ? 0 : i)) * a.pqw + cb2 * 32 + 4 * h;
+  auto gather = [&](int tile, int cloud) {             // table pieces of the row in rv
+    if (tile < total && !a.pq) {
 #pragma unroll
-      for (int g = 0; g < 4; g++) p4[g] = *reinterpret_cast<const f32x4 *>(pr + 8 * g);
+      for (int rr = 0; rr < 16; rr++) acc1[rr] = 0.f;
     }
-  };
-  fetch_row(t_first);
-  gather(t_first);
-  __syncthreads();
-  for (int tile = t_first; tile < total; tile += t_step) {
-    const int4 td = flat[tile];
-    const size_t b = (size_t)td.x;
-    const int first = td.y, nc = td.z;
-    const unsigned ends_lo = (unsigned)ctab[(size_t)tile * CT], ends_hi = (unsigned)ctab[(size_t)tile * CT + 1];
-    const int ngr = ctab[(size_t)tile * CT + 2];       // row groups (pairs) in use
-    // ---- A: layer 1 of (cb2, rb2)   (a.dbg: PCR_SA_DBG ablation mask of tuning builds, 0 in production)
-    if (!(a.dbg & 1)) {
-      f32x16 acc;
+    if (tile < total && a.pq) {
+      const __amdgpu_buffer_rsrc_t rpq = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float *>(a.pq) + (size_t)cloud * a.N * a.pqw, 0, a.N * a.pqw * 4, 0x00020000);
+      const int i = __float_as_int(rv[0]);
+      const int vo = (i < 0 ? 0 : i) * (a.pqw * 4) + vo_pq;
 #pragma unroll
       for (int g = 0; g < 4; g++) {
-        const f32x4 s4 = *reinterpret_cast<const f32x4 *>(s_sh1 + 32 * cb2 + 8 * g + 4 * h);
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rpq, vo + 32 * g, 0, 0));
 #pragma unroll
-        for (int q = 0; q < 4; q++) acc[4 * g + q] = s4[q];
+        for (int q = 0; q < 4; q++) acc1[4 * g + q] = v[q];
       }
-      const float b0 = h ? rv[2] : rv[1], b1 = h ? 0.f : rv[3];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], b0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], b1, acc, 0, 0, 0);
-      if (a.pq) {
-#pragma unroll
-        for (int rr = 0; rr < 16; rr++) acc[rr] += p4[rr >> 2][rr & 3];
-      }
-      bf_store_tile<LO>(x1, ROWS, acc, cb2, rb2, j, h);
     }
-    fetch_row(tile + t_step);                          // (lands during layer 2)
-    __syncthreads();
-    // ---- B: layer 2 of (cb2, rb2)
+  };
+  // layer 1 of this wave's (cb2, rb2) tile, in pieces (one per MFMA triple of the phase it hides under)
+  auto a_mfma = [&]() {
+    const float b0 = h ? rv[2] : rv[1], b1 = h ? 1.f : rv[3];
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], b0, acc1, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], b1, acc1, 0, 0, 0);
+  };
+  // a quarter of bf_store_tile: accumulator rows 8 gp + 4 hf .. + 3 = elements 4 hf .. + 3 of piece 4 cb2 + 2 gp + h
+  // (8 bytes of the piece's hi unit, 8 of its lo unit)
+  auto a_store = [&](float *img, int gp, int hf) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 *u = reinterpret_cast<bf16x4 *>(img);
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const f32x2 v = {relu_bits(acc1[8 * gp + 4 * hf + 2 * q]), relu_bits(acc1[8 * gp + 4 * hf + 2 * q + 1])};
+      const bf16x2 h2 = __builtin_convertvector(v, bf16x2);
+      hi[2 * q] = h2[0];
+      hi[2 * q + 1] = h2[1];
+      if constexpr (LO) {
+        const bf16x2 l2 = __builtin_convertvector(v - __builtin_convertvector(h2, f32x2), bf16x2);
+        lo[2 * q] = l2[0];
+        lo[2 * q + 1] = l2[1];
+      }
+    }
+    const int P = 4 * cb2 + 2 * gp + h;
+    u[2 * ((2 * P) * ROWS + r1) + hf] = hi;
+    if constexpr (LO) u[2 * ((2 * P + 1) * ROWS + r1) + hf] = lo;
+  };
+  // pair maxima of layer 3 (tile i) -> obuf; pm[k][4 g + 2 h' ..]: see phase C
+  int pm[NRB3][8];
+  // Row pair q = 16 rb + 4 g + 2 h + pr holds tokens 8 g + 4 h + 2 pr (+ 1) of row block rb.  Its maximum goes to
+  // obuf[q][cout] with ONE plain ds_write_b32 (the lane's address is fixed, q's compile-time part is the instruction's
+  // offset field) -- the first version sent it to the centre's row with an LDS integer max: ~45 cycles of wave time per
+  // instruction, sixteen per tile.  The centres' pair ranges come from the tile's `ends` mask (bit q: pair q closes a
+  // centre): the lane of wave 0 whose bit is set knows the centre it closes (the set bits below it) and writes that
+  // centre's end = the next centre's start into coff; phase D then reduces every centre over its own pairs.
+  auto c_epi = [&](int k, int g, int *obase) {
+#pragma unroll
+    for (int pr = 0; pr < 2; pr++) obase[(16 * k * G3 + 4 * g + pr) * C3] = pm[k][2 * g + pr];
+  };
+  auto c_offsets = [&](unsigned ends_lo, unsigned ends_hi) {   // wave 0
+    if (w == 0) {
+      const unsigned bits = NG <= 32 ? ends_lo : (lane < 32 ? ends_lo : ends_hi);
+      const int below = NG <= 32 || lane < 32 ? __popc(ends_lo & ((1u << (lane & 31)) - 1u))
+                                              : __popc(ends_lo) + __popc(ends_hi & ((1u << (lane & 31)) - 1u));
+      if (lane < NG && ((bits >> (lane & 31)) & 1u)) coff[below + 1] = lane + 1;
+      if (lane == 0) coff[0] = 0;
+    }
+  };
+  auto d_out = [&](int cloud, int first, int nc) {     // the tile's centres: max over their pairs, then the ReLU (>= +0)
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const i32x4 *ob4 = reinterpret_cast<const i32x4 *>(obuf);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+        a.out_pm ? a.out + ((size_t)cloud * a.S + first) * (size_t)C3 : a.out + (size_t)cloud * C3 * a.S, 0,
+        a.out_pm ? nc * C3 * 4 : C3 * a.S * 4, 0x00020000);
+    for (int e = tid; e < nc * (C3 / 4); e += 512) {
+      const int c = e / (C3 / 4), o4 = e - c * (C3 / 4);
+      const int qa = coff[c], qb = coff[c + 1];
+      i32x4 m = {0, 0, 0, 0};
+      for (int q = qa; q < qb; q += 4) {               // four pairs per round trip (a clamped re-read leaves a max alone)
+        i32x4 v[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) v[t] = ob4[(q + t < qb ? q + t : qb - 1) * (C3 / 4) + o4];
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+          for (int u = 0; u < 4; u++) m[u] = imax(m[u], v[t][u]);
+      }
+      if (a.out_pm) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m), rout, e * 16, 0, 0);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          __builtin_amdgcn_raw_buffer_store_b32((unsigned)m[u], rout, ((4 * o4 + u) * a.S + first + c) * 4, 0, 0);
+      }
+    }
+  };
+#define PCR_SB() __builtin_amdgcn_sched_barrier(0)
+#ifdef PCR_SA_TRACE_BUILD   // diagnostic builds only: wave 0 and wave 7 stamp the shader clock at the step boundaries
+  const bool tracing = (a.dbg & 256) && lane == 0 && (w == 0 || w == 7) && blockIdx.x < kTraceWgs / 2;
+  unsigned long long *trace = g_rag_trace + (size_t)(2 * blockIdx.x + (w ? 1 : 0)) * (2 + kTraceTiles * kTraceMarks);
+  int trace_it = 0;
+#define PCR_WMARK(m)                                                                                   \
+  do {                                                                                                 \
+    if (tracing && trace_it < kTraceTiles) trace[2 + trace_it * kTraceMarks + (m)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define PCR_WMARK(m) do { } while (0)
+#endif
+  // ---- prologue: tile 0's layer 1, tile 1's row entry
+  int4 td_prev = make_int4(0, 0, 0, 0), td_cur = make_int4(0, 0, 0, 0), td_next = make_int4(0, 0, 0, 0);
+  unsigned pe_lo = 0u, pe_hi = 0u;                     // previous tile's segment mask / group count (its pair maxima)
+  int p_ngr = 0;
+  bool have_prev = false;
+  if (t_first < total) {
+    td_cur = flat[t_first];
+    fetch_row(t_first);
+    gather(t_first, td_cur.x);
+    a_mfma();
+    a_store(x1, 0, 0);
+    a_store(x1, 0, 1);
+    a_store(x1, 1, 0);
+    a_store(x1, 1, 1);
+    if (t_first + t_step < total) td_next = flat[t_first + t_step];
+    fetch_row(t_first + t_step);
+  }
+  __syncthreads();
+  int par = 0;
+  for (int tile = t_first; tile < total; tile += t_step, par ^= 1) {
+    const bool have_next = tile + t_step < total;
+    const unsigned e_lo = (unsigned)ctab[(size_t)tile * CT], e_hi = (unsigned)ctab[(size_t)tile * CT + 1];
+    const int ngr = ctab[(size_t)tile * CT + 2];       // row groups (pairs) in use
+    int4 td_nn = make_int4(0, 0, 0, 0);
+    if (tile + 2 * t_step < total) td_nn = flat[tile + 2 * t_step];
+    const bf16x8 *x1u = reinterpret_cast<const bf16x8 *>(x1 + par * C * ROWS);
+    float *x1n = x1 + (par ^ 1) * C * ROWS;
+    // ---- step 1: layer 2 of (cb2, rb2); between its MFMA triples the pair maxima of the previous tile
+    PCR_WMARK(0);
+    int *obase = obuf + (16 * rb3 + 2 * h) * C3 + cb3 * 32 + j;
+    gather(tile + t_step, td_next.x);                  // (its row entry was requested most of a tile ago; the pieces land
+                                                       //  in layer 1's accumulator during this step)
+    if (have_prev) c_offsets(pe_lo, pe_hi);
     {
       f32x16 y;
 #pragma unroll
@@ -1114,89 +1231,129 @@ void sa_wsplit_rag_kernel(RagArgs a) {
         for (int q = 0; q < 4; q++) y[4 * g + q] = s4[q];
       }
       const bf16x8 *xb = x1u + 2 * h * ROWS + r1;      // piece 2 s + h of step s: unit (2 (2 s + h) + part) ROWS + row
-      if (!(a.dbg & 2))
+      constexpr int NE = NRB3 * 4;                      // pieces of the previous tile's epilogue
+      // per step: a piece of side work, the NEXT step's operands (they have this step's MFMAs to land), the MFMAs
+      bf16x8 xh = xb[0], xl;
+      if constexpr (LO) xl = xb[ROWS];
 #pragma unroll
       for (int s2 = 0; s2 < NS; s2++) {
-        const bf16x8 xh = xb[(4 * s2) * ROWS];
-        if constexpr (LO) {
-          const bf16x8 xl = xb[(4 * s2 + 1) * ROWS];
-          y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2h[s2], xl, y, 0, 0, 0);
-          y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2l[s2], xh, y, 0, 0, 0);
+        if (have_prev && !(a.dbg & 1)) {     // (a.dbg: PCR_SA_DBG ablation mask of tuning builds, 0 in production)
+#pragma unroll
+          for (int e = (s2 * NE) / NS; e < ((s2 + 1) * NE) / NS; e++) c_epi(e >> 2, e & 3, obase);
         }
-        y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2h[s2], xh, y, 0, 0, 0);
-      }
-      gather(tile + t_step);                           // next tile's table pieces: in flight during layer 3
-      if (!(a.dbg & 32)) bf_store_tile<LO>(x2, ROWS, y, cb2, rb2, j, h);
-    }
-    __syncthreads();
-    // ---- C: layer 3 (transposed) of cout block cb3, row blocks rb3 + k G3; pair maxima -> obuf
-    {
-      f32x16 y3[NRB3];
-#pragma unroll
-      for (int k = 0; k < NRB3; k++)
-#pragma unroll
-        for (int rr = 0; rr < 16; rr++) y3[k][rr] = sv3;
-      if (!(a.dbg & 4))
-#pragma unroll
-      for (int s2 = 0; s2 < NS; s2++) {
-#pragma unroll
-        for (int k = 0; k < NRB3; k++) {
-          const bf16x8 *xa = x2u + 2 * h * ROWS + (rb3 + k * G3) * 32 + j;
-          const bf16x8 ah = xa[(4 * s2) * ROWS];
+        PCR_SB();
+        bf16x8 nh, nl;
+        if (s2 + 1 < NS) {
+          nh = xb[(4 * (s2 + 1)) * ROWS];
+          if constexpr (LO) nl = xb[(4 * (s2 + 1) + 1) * ROWS];
+        }
+        PCR_SB();
+        if (!(a.dbg & 4)) {
           if constexpr (LO) {
-            const bf16x8 al = xa[(4 * s2 + 1) * ROWS];
-            y3[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, w3h[s2], y3[k], 0, 0, 0);
-            y3[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, w3l[s2], y3[k], 0, 0, 0);
+            y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2h[s2], xl, y, 0, 0, 0);
+            y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2l[s2], xh, y, 0, 0, 0);
           }
-          y3[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, w3h[s2], y3[k], 0, 0, 0);
+          y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2h[s2], xh, y, 0, 0, 0);
+        }
+        PCR_SB();
+        if (s2 + 1 < NS) {
+          xh = nh;
+          if constexpr (LO) xl = nl;
         }
       }
-      // token 8 g + 4 h + 2 pr (+ 1) of row block rb = row group q = 16 rb + 4 g + 2 h + pr; its centre = the number of
-      // centre-closing groups before q (ctab's `ends` mask)
-      if (!(a.dbg & 8))
+      PCR_WMARK(1);
+      bf_store_tile<LO>(x2, ROWS, y, cb2, rb2, j, h);
+    }
+    PCR_WMARK(2);
+    __syncthreads();
+    PCR_WMARK(3);
+    // ---- step 2: layer 3 (transposed) of cout block cb3, row blocks rb3 + k G3; between its MFMA triples layer 1 of the
+    // next tile and the previous tile's output
+    {
 #pragma unroll
-      for (int k = 0; k < NRB3; k++)
+      for (int k = 0; k < NRB3; k++) {                 // (one row block at a time: 16 accumulator registers, not 32)
+        f32x16 y3;
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) y3[rr] = sv3;
+        const bf16x8 *xa = x2u + 2 * h * ROWS + (rb3 + k * G3) * 32 + j;
+        bf16x8 ah = xa[0], al;
+        if constexpr (LO) al = xa[ROWS];
+#pragma unroll
+        for (int s2 = 0; s2 < NS; s2++) {
+          const int slot = k * NS + s2;
+          if (a.dbg & 2) {
+          } else if (slot == 0 || slot == 1) {
+            // (the two waves of a SIMD take their share of the previous tile's output one triple apart: one of them
+            // always has matrix work while the other waits for its LDS reads)
+            if (have_prev && slot == (w >> 2)) d_out(td_prev.x, td_prev.y, td_prev.z);
+          } else if (have_next) {
+            // layer 1 of the next tile (its table pieces landed during step 1), early in the step: the row entry of the
+            // tile after it then has the rest of the step to arrive, and the step's tail stays free of vector work
+            if (slot == 2) {
+              a_mfma();
+              fetch_row(tile + 2 * t_step);              // (rv is free once the two MFMAs hold their operands)
+            }
+            if (slot == 4) a_store(x1n, 0, 0);
+            if (slot == 5) a_store(x1n, 0, 1);
+            if (slot == 6) a_store(x1n, 1, 0);
+            if (slot == 7) a_store(x1n, 1, 1);
+          }
+          PCR_SB();
+          bf16x8 nh, nl;
+          if (s2 + 1 < NS) {
+            nh = xa[(4 * (s2 + 1)) * ROWS];
+            if constexpr (LO) nl = xa[(4 * (s2 + 1) + 1) * ROWS];
+          }
+          PCR_SB();
+          if (!(a.dbg & 8)) {
+            if constexpr (LO) {
+              y3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, w3h[s2], y3, 0, 0, 0);
+              y3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, w3l[s2], y3, 0, 0, 0);
+            }
+            y3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, w3h[s2], y3, 0, 0, 0);
+          }
+          PCR_SB();
+          if (s2 + 1 < NS) {
+            ah = nh;
+            if constexpr (LO) al = nl;
+          }
+        }
 #pragma unroll
         for (int g = 0; g < 4; g++)
 #pragma unroll
-          for (int pr = 0; pr < 2; pr++) {
-            const int q = 16 * (rb3 + k * G3) + 4 * g + 2 * h + pr;
-            if (q < ngr) {
-              int c;
-              if (NG <= 32 || q < 32) c = __popc(ends_lo & ((1u << q) - 1u));
-              else c = __popc(ends_lo) + __popc(ends_hi & ((1u << (q - 32)) - 1u));
-              const int v = imax(__float_as_int(y3[k][4 * g + 2 * pr]), __float_as_int(y3[k][4 * g + 2 * pr + 1]));
-              __hip_atomic_fetch_max(obuf + c * C3 + cb3 * 32 + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-          }
+          for (int pr = 0; pr < 2; pr++)
+            pm[k][2 * g + pr] = imax(__float_as_int(y3[4 * g + 2 * pr]), __float_as_int(y3[4 * g + 2 * pr + 1]));
+      }
     }
+    PCR_WMARK(4);
     __syncthreads();
-    // ---- D: the tile's centres; obuf back to +0
-    if (a.dbg & 16) continue;
-    if (a.out_pm) {
-      int4 *ob4 = reinterpret_cast<int4 *>(obuf);
-      int4 *dst = reinterpret_cast<int4 *>(a.out + (b * a.S + first) * (size_t)C3);
-      for (int e = tid; e < nc * (C3 / 4); e += 512) {
-        dst[e] = ob4[e];
-        ob4[e] = make_int4(0, 0, 0, 0);
-      }
-    } else {
-      for (int e = tid; e < nc * C3; e += 512) {
-        const int c = e / C3, o = e - c * C3;
-        a.out[(b * C3 + o) * (size_t)a.S + first + c] = __int_as_float(obuf[e]);
-        obuf[e] = 0;
-      }
-    }
-    // (no barrier here: the next tile's phase A writes X1, dead since this tile's phase B; obuf is next touched by the
-    // atomics of phase C, two barriers from now)
+    PCR_WMARK(5);
+#ifdef PCR_SA_TRACE_BUILD
+    trace_it++;
+#endif
+    td_prev = td_cur;
+    td_cur = td_next;
+    td_next = td_nn;
+    pe_lo = e_lo;
+    pe_hi = e_hi;
+    p_ngr = ngr;
+    have_prev = true;
   }
+  // ---- drain: the last tile's pair maxima and output
+  if (have_prev) {
+    int *obase = obuf + (16 * rb3 + 2 * h) * C3 + cb3 * 32 + j;
+    c_offsets(pe_lo, pe_hi);
+#pragma unroll
+    for (int e = 0; e < NRB3 * 4; e++) c_epi(e >> 2, e & 3, obase);
+    __syncthreads();
+    d_out(td_prev.x, td_prev.y, td_prev.z);
+  }
+#undef PCR_SB
 }
 #endif
 
 // PCR_SA_TRACE=<file> (diagnostics only): wave 0 of every workgroup stamps the shader clock at the phase
 // boundaries of its first kTraceTiles tiles; the host dumps the buffer after the launch
-constexpr int kTraceWgs = 1024, kTraceTiles = 24, kTraceMarks = 8;
-__device__ unsigned long long g_rag_trace[kTraceWgs * (2 + kTraceTiles * kTraceMarks)];
 
 // W1 != 0: layer 1 on the matrix core as well.  relu(Wa dxyz + P[i] + shift) is a one-k-block dense call on the
 // [dx;dy;dz;0..] rows of the tile (seeded with the shift) whose epilogue adds the table pieces, which each lane
@@ -1597,7 +1754,9 @@ extern "C" int pcr_dense_pm_f32(const float *, const float *, float *, int, int,
 // diagnostics only (PCR_SA_TRACE): synchronises, appends one launch's phase stamps to the file
 static void rag_dump_trace(const char *path, const char *tag, int wgs) {
   static int launches = 0;
-  if (launches++ >= 8) return;   // the first few launches are enough
+  static const int skip = pcr_tune_int("PCR_SA_TRACE_SKIP");   // (a freshly started process runs its first launches cold)
+  launches++;
+  if (launches <= skip || launches > skip + 8) return;   // a few launches are enough
   static std::vector<unsigned long long> host(kTraceWgs * (2 + kTraceTiles * kTraceMarks));
   if (hipDeviceSynchronize() != hipSuccess) return;
   if (hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(g_rag_trace), host.size() * sizeof(unsigned long long)) != hipSuccess)
@@ -1670,7 +1829,11 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   // the persistent, register-pipelined kernel: ball-query groups with hit counts (only the distinct rows are
   // evaluated).  (It also runs count-less featureless layers -- all K rows -- but the K-row kernel with resident
   // weights is faster there: 2.2 vs 2.9 ms on the 32-channel kNN layer, its row tables are 0.5 GB of extra traffic.)
-  if (p.tile_ws && p.cnt && p.mode == 1 && p.c1 <= 256 && p.c2 <= 256 && p.c3 <= 256) {
+  // (the cout-split kernel's shape also takes count-less launches -- all K rows of every centre -- through the same tile
+  // plan, so that ragged and K-row evaluation of that layer share one kernel and one arithmetic)
+  const bool wsplit_shape = kPrec != 0 && p.c1 == 128 && p.c2 == 128 && p.c3 == 256 && p.wa_shift_packed && p.K <= 64 &&
+                            (size_t)p.B * ((p.S + (64 / rag_ceil(p.K)) - 1) / (64 / rag_ceil(p.K))) * 64 * 16 < 0x7FFFFFFFull;
+  if (p.tile_ws && (p.cnt || wsplit_shape) && p.mode == 1 && p.c1 <= 256 && p.c2 <= 256 && p.c3 <= 256) {
     const int n2r = ceil32(p.c2) >> 5, n3r = ceil32(p.c3) >> 5;
     const int nrr = (n2r > 4 || n3r > 4) ? 2 : 1;
     const int tb = nrr == 2 ? 2 : 4;
@@ -1742,6 +1905,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
       r.xyz = p.xyz; r.idx = p.idx; r.cnt = p.cnt; r.centre_idx = p.centre_idx; r.ws = p.tile_ws;
       r.wa = p.wa; r.pq = p.D ? p.pq_ws : nullptr; r.pqw = p.c1;
       r.wap = p.wa_packed;
+      r.wap4 = p.wa_shift_packed;
       r.wp2 = wl2; r.wp3 = wl3; r.sh1 = p.shift[0]; r.sh2 = p.shift_pad[0]; r.sh3 = p.shift_pad[1];
       static const int rdbg = pcr_tune_int("PCR_SA_DBG");
       static const char *rtrace = pcr_tune_str("PCR_SA_TRACE");
@@ -1781,14 +1945,15 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
         {
           // cout-split form with register-resident weights (shape-only choice): 128 / 128 / 256 on 64-row tiles
           static const int no_wsplit = pcr_tune_int("PCR_SA_NO_WSPLIT");   // diagnostics
-          if (!no_wsplit && tb == 2 && p.c1 == 128 && p.c2 == 128 && p.c3 == 256 && p.wa_packed) {
+          if (!no_wsplit && tb == 2 && wsplit_shape) {
             constexpr bool kLoW = kPrec == 1;
             static bool okw = allow_big_lds(sa_wsplit_rag_kernel<4, 8, kLoW>);
             (void)okw;
-            const size_t lds_w = ((size_t)2 * 128 * 64 + (size_t)32 * 256 + 2 * 128 + 256) * sizeof(float);
+            const size_t lds_w = ((size_t)3 * 128 * 64 + (size_t)32 * 256 + 2 * 128 + 64) * sizeof(float);   // X1 x 2, X2, obuf, seeds, coff
             long long want = n_cu;                                           // persistent: one 8-wave workgroup per CU
             if (want > max_tiles) want = max_tiles;
             hipLaunchKernelGGL((sa_wsplit_rag_kernel<4, 8, kLoW>), dim3((unsigned)want), dim3(512), lds_w, st, r);
+            if (rtrace) rag_dump_trace(rtrace, "wsplit", (int)(2 * want));
             if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
             return PCR_OK;
           }
@@ -1982,6 +2147,12 @@ int pcr_sa2_try_bf3(const pcr_sa_params *p, pcr_stream_t st) { return sa2_try(*p
 #elif PCR_SA_PREC == 2
 int pcr_sa2_try_bf1(const pcr_sa_params *p, pcr_stream_t st) { return sa2_try(*p, st); }
 #else
+
+// 1: launches of this shape WITHOUT hit counts (all K rows of every group) also run on the tile plan and want the
+// workspace of pcr_sa_tile_ws_ints -- the cout-split kernel's shape, sa2_try's `wsplit_shape` (bf16 modes)
+PCR_EXPORT int pcr_sa_krow_uses_tiles(int c1, int c2, int c3, int K, int precision) {
+  return precision != 0 && c1 == 128 && c2 == 128 && c3 == 256 && K >= 1 && K <= 64;
+}
 
 PCR_EXPORT long pcr_sa_tile_ws_ints(int B, int S, int K, int c2, int c3) {
   if (B < 1 || S < 1 || K < 1 || c2 < 1 || c3 < 1) return 0;

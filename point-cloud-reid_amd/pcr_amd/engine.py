@@ -99,7 +99,7 @@ class SaParams(ctypes.Structure):
                 ("pq_ws", c_float_p), ("pq_ready", ctypes.c_int),
                 ("feat_point_major", ctypes.c_int), ("out_point_major", ctypes.c_int),
                 ("out", c_float_p), ("wa_packed", c_float_p),
-                ("precision", ctypes.c_int), ("wps_bf", c_float_p * 2)]
+                ("precision", ctypes.c_int), ("wps_bf", c_float_p * 2), ("wa_shift_packed", c_float_p)]
 
 
 class AttnParams(ctypes.Structure):
@@ -206,6 +206,9 @@ class SaPlan:
         sc1 = self.scale[0].detach().double().cpu().unsqueeze(1)      # fast path wants scale[0] folded in
         self.wa = _dev32((w1[:, :3] * sc1).float(), device)
         self.wa_packed = pack_weight((w1[:, :3] * sc1).float(), device)    # the same (c1,3) matrix as an MFMA operand
+        # [wa | shift]: the cout-split kernel multiplies it with (dx, dy, dz, 1)
+        self.wa_shift_packed = pack_weight(torch.cat([w1[:, :3] * sc1, self.shift[0].detach().double().cpu().unsqueeze(1)],
+                                                     dim=1).float(), device)
         self.wpq = None
         self.fast = fast
         # layers 2, 3 with the BatchNorm scale folded into the weights and the shift padded to 32
@@ -254,7 +257,10 @@ class SaPlan:
         ragged = cnt is not None and self.fast and self.mode == 1
         if cnt is not None:
             assert cnt.is_contiguous() and cnt.dtype == torch.int32 and cnt.shape == (B, S)
-        if ragged:
+        # (shapes whose K-row evaluation runs on the tile plan as well -- the cout-split kernel -- take the workspace too)
+        tiled = ragged or (self.fast and self.mode == 1 and L.load().pcr_sa_krow_uses_tiles(
+            self.couts[0], self.couts[1], self.couts[2], K, PRECISIONS[PRECISION]))
+        if tiled:
             # the persistent tile-list kernel (distinct rows only)
             n_ws = L.load().pcr_sa_tile_ws_ints(B, S, K, self.couts[1], self.couts[2])
             if n_ws > 0:
@@ -265,6 +271,7 @@ class SaPlan:
         if self.fast:
             p.wa = _p(self.wa)
             p.wa_packed = _p(self.wa_packed)
+            p.wa_shift_packed = _p(self.wa_shift_packed)
             p.precision = PRECISIONS[PRECISION]
             for i in range(2):
                 p.wps[i], p.shift_pad[i] = _p(self.wps[i]), _p(self.shift_pad[i])
