@@ -336,6 +336,17 @@ int pcr_dense_xpm_f32(const float *x, const float *wp, const float *scale, const
  * res (optional) is (B,cout,L). */
 int pcr_dense_gn_f32(const float *x, const float *wp, const float *gamma, const float *beta, const float *res,
                      float *y, int B, int cin, int cout, int L, int groups, int relu, pcr_stream_t stream);
+/* The same two launches on the bf16 matrix core (round 4; ABI 11): wp_bf = pcr_pack_weight_bf16x2_f32 image of W,
+ * precision = PCR_PREC_BF16X3 (split bf16, three MFMAs per product, f32 accumulate) or PCR_PREC_BF16.  Covered shapes:
+ * pcr_dense_prec_ok(cin, cout, L) != 0 (cin a multiple of 64, cout a multiple of 32, channel-major x, shared weights);
+ * anything else returns PCR_ERR_INVALID and belongs to the f32 launches.  Reference: the 1x1 convs / Linear layers of
+ * models/pointnet.py:27-127, dgcnn_orig.py:147, lanegcn_nets.py:228-241 (LinearRes). */
+int pcr_dense_prec_ok(int cin, int cout, int L);
+int pcr_dense_prec_f32(const float *x, const float *wp_bf, const float *scale, const float *shift, float *y, int B, int cin,
+                       int cout, int L, int act, int precision, pcr_stream_t stream);
+int pcr_dense_gn_prec_f32(const float *x, const float *wp_bf, const float *gamma, const float *beta, const float *res,
+                          float *y, int B, int cin, int cout, int L, int groups, int relu, int precision,
+                          pcr_stream_t stream);
 
 /* ---- PointNet encoder pieces (models/pointnet.py:10-127) and LinearRes rows (lanegcn_nets.py:228-241) ---- */
 

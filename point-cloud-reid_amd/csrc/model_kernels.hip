@@ -304,6 +304,153 @@ __global__ __launch_bounds__(kThreads) void dense_kernel(DenseArgs a) {
   }
 }
 
+// ---- the wide per-point layers on the bf16 matrix core (round 4): PointNet's 1x1 convs, DGCNN's conv5 and the LinearRes
+// downsample rows were the last MFMA-bound launches in f32 (0.7 of a 157 TFLOP/s roof).  Same tiling as the chunked f32
+// form -- 64 tokens x up to 256 couts per workgroup, the cin extent walked in chunks of KC channels with the accumulators
+// carried -- but a chunk sits in LDS as a bf IMAGE (tile_dense.h): every thread loads the eight channels of a 16-byte piece
+// for its token (coalesced along the tokens), splits them into bf16 hi / lo ONCE, and the four waves read the pieces as
+// MFMA operands (two ds_read_b128 per three MFMAs per token block).  wp: pcr_pack_weight_bf16x2_f32 image.
+// NS = 3: split bf16 (W x ~ W_hi x_hi + W_hi x_lo + W_lo x_hi, f32 accumulate), NS = 1: plain bf16.
+template <bool GN, int NS, int NR>
+__global__ __launch_bounds__(kThreads) void dense_bf_kernel(DenseArgs a, int KC) {
+  constexpr int TB = 2, T = 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *img = smem;                 // [KC / 8 pieces][hi, lo][T] 16-byte units
+  float *s_sc = img + KC * T;
+  float *s_sh = s_sc + 256;
+  const int coutP = ceil32(a.cout);
+  const size_t b = blockIdx.y;
+  const int t0 = blockIdx.x * T;
+  const int chunk0 = blockIdx.z * 256;
+  const int chunkP = coutP - chunk0 < 256 ? coutP - chunk0 : 256;
+  {
+    const int oc = chunk0 + threadIdx.x;   // kThreads == 256
+    s_sc[threadIdx.x] = (a.scale && oc < a.cout) ? a.scale[oc] : 1.0f;
+    s_sh[threadIdx.x] = (a.shift && oc < a.cout) ? a.shift[oc] : 0.0f;
+  }
+  const int cout = a.cout, act = a.act, L = a.L;
+  float *out = a.y + b * a.cout * a.L;
+  auto epi = [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
+    const int t = tb * 32 + l31;
+    float v[16];
+    if constexpr (GN) {
+      switch (a.gn_gs) {
+        case 4: gn_tile<4>(acc, v); break;
+        case 8: gn_tile<8>(acc, v); break;
+        case 16: gn_tile<16>(acc, v); break;
+        default: gn_tile<32>(acc, v); break;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; r++) v[r] = acc[r];
+    }
+    if (t0 + t < L) {
+      const float *res = (GN && a.res) ? a.res + b * a.cout * a.L : nullptr;
+      // the residual's sixteen values as ONE batch of loads from clamped addresses (a load inside the store loop below
+      // is a load + s_waitcnt vmcnt(0) per element)
+      float rs[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int oc = chunk0 + cb * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        rs[r] = res ? res[(size_t)(oc < cout ? oc : cout - 1) * L + t0 + t] : 0.f;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int o = cb * 32 + 8 * g + 4 * h;
+        const f32x4 s4 = *reinterpret_cast<const f32x4 *>(s_sc + o), b4 = *reinterpret_cast<const f32x4 *>(s_sh + o);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int oc = chunk0 + o + q;
+          if (oc < cout) {
+            const float r = v[4 * g + q] * s4[q] + b4[q] + rs[4 * g + q];
+            out[(size_t)oc * L + t0 + t] = act == 1 ? fmaxf(r, 0.f) : (act == 2 && r < 0.f) ? r * 0.2f : r;
+          }
+        }
+      }
+    }
+  };
+  f32x16 carry[NR][TB];
+#pragma unroll
+  for (int nr = 0; nr < NR; nr++)
+#pragma unroll
+    for (int j = 0; j < TB; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) carry[nr][j][r] = 0.f;
+  const float *xb = a.x + b * a.cin * a.L;
+  const int nch = a.cin / KC, npiece = KC >> 3;
+  const size_t wstep = (size_t)(coutP >> 5) * 128 * 4;               // floats of one 16-channel step of the image
+  const float *wp = a.wp + (size_t)(chunk0 >> 5) * 128 * 4;
+  const int tt = threadIdx.x & 63, pg = threadIdx.x >> 6;
+  const bool tok_ok = t0 + tt < L;
+  const float *xt = xb + (tok_ok ? t0 + tt : 0);
+  bf16x8 *u = reinterpret_cast<bf16x8 *>(img);
+  const DenseNoHook nh;
+  const bool vec = (L & 3) == 0 && t0 + T <= L && (reinterpret_cast<size_t>(xb) & 15) == 0;
+  for (int c = 0; c < nch; c++) {
+    if (c) __syncthreads();   // everyone is done with the previous chunk's operands
+    if (vec) {
+      // 16-byte loads: lane (u, pgrp) takes tokens 4 u .. + 3 of the eight channels of piece pgrp, pgrp + 16, ...
+      // (16 lanes x 16 bytes = one 256-byte run per channel) and forms the four tokens' pieces in registers
+      const int uq = threadIdx.x & 15, pgrp = threadIdx.x >> 4;
+      for (int P = pgrp; P < npiece; P += 16) {
+        const int cbase = c * KC + 16 * (P >> 1);
+        f32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+          v[j] = *reinterpret_cast<const f32x4 *>(xb + (size_t)(cbase + bf_kpos(P & 1, j)) * L + t0 + 4 * uq);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          float x8[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) x8[j] = v[j][k];
+          bf16x8 hi, lo;
+          bf_split8(x8, hi, lo, NS == 3);
+          u[(2 * P) * T + 4 * uq + k] = hi;
+          if constexpr (NS == 3) u[(2 * P + 1) * T + 4 * uq + k] = lo;
+        }
+      }
+    } else
+    // pieces pg, pg + 4, ...: piece P = channels 16 (P >> 1) + bf_kpos(P & 1, j) of the chunk, two at a time in flight
+    for (int P0 = pg; P0 < npiece; P0 += 8) {
+      float x[2][8];
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int P = P0 + 4 * k;
+        const int cbase = c * KC + 16 * (P >> 1);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int ch = cbase + bf_kpos(P & 1, j);
+          x[k][j] = P < npiece ? xt[(size_t)ch * L] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int P = P0 + 4 * k;
+        if (P < npiece) {
+          if (!tok_ok) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) x[k][j] = 0.f;
+          }
+          bf16x8 hi, lo;
+          bf_split8(x[k], hi, lo, NS == 3);
+          u[(2 * P) * T + tt] = hi;
+          if constexpr (NS == 3) u[(2 * P + 1) * T + tt] = lo;
+        }
+      }
+    }
+    __syncthreads();
+    tile_dense_bf_impl<TB, NR, 1, true, NS, decltype(epi), bf_pf(NR), DenseNoHook, true, false, true, true>(
+        img, KC, wp + (size_t)c * (KC >> 4) * wstep, chunkP, false, epi, nullptr, nh, coutP, nullptr, carry);
+  }
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+#pragma unroll
+  for (int nr = 0; nr < NR; nr++)
+    if (wave + 4 * nr < (chunkP >> 5)) {
+#pragma unroll
+      for (int j = 0; j < TB; j++) epi(carry[nr][j], wave + 4 * nr, j, lane & 31, lane >> 5);
+    }
+}
+
 // (B,C,L) -> out[c * B + b] = max over L   (channel-major with the clouds as tokens: (1,C,B))
 __global__ __launch_bounds__(kThreads) void max_over_l_kernel(const float *__restrict__ x,
                                                               float *__restrict__ out, int B, int C, int L) {
@@ -483,6 +630,57 @@ static int dense_launch(const float *x, const float *wp, long w_bstride, const f
   else hipLaunchKernelGGL((dense_kernel<1, false>), g, dim3(kThreads), lds, pcr_s(stream), a);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
+}
+
+// bf16 forms: cin a multiple of 64 (chunks of 256 / 128 / 64 channels), cout a multiple of 32, channel-major x, shared
+// weights.  pcr_dense_prec_ok tells a caller whether a shape is covered (else it keeps the f32 launch).
+PCR_EXPORT int pcr_dense_prec_ok(int cin, int cout, int L) {
+  return cin >= 64 && cin % 64 == 0 && cout >= 32 && cout % 32 == 0 && L >= 1;
+}
+
+static int dense_bf_launch(const float *x, const float *wp_bf, const float *scale, const float *shift, float *y, int B,
+                           int cin, int cout, int L, int act, int precision, pcr_stream_t stream, int gn_gs = 0,
+                           const float *res = nullptr) {
+  if (!x || !wp_bf || !y || B < 0 || (precision != PCR_PREC_BF16X3 && precision != PCR_PREC_BF16) ||
+      !pcr_dense_prec_ok(cin, cout, L))
+    return PCR_ERR_INVALID;
+  if (B == 0) return PCR_OK;
+  if (B > 65535) return PCR_ERR_INVALID;
+  DenseArgs a{x, wp_bf, scale, shift, y, cin, cout, L, act, 0, 0, gn_gs, res};
+  const int KC = cin % 256 == 0 ? 256 : (cin % 128 == 0 ? 128 : 64);
+  const size_t lds = ((size_t)KC * 64 + 512) * sizeof(float);
+  const dim3 g((L + 63) / 64, B, (cout + 255) / 256);
+  const bool wide = cout > 128;      // more than four cout blocks in a workgroup's window: two rounds per wave
+#define PCR_DBF(GNv, NSv, NRv)                                                                    \
+  do {                                                                                            \
+    static bool ok = allow_big_lds(dense_bf_kernel<GNv, NSv, NRv>);                               \
+    (void)ok;                                                                                     \
+    hipLaunchKernelGGL((dense_bf_kernel<GNv, NSv, NRv>), g, dim3(kThreads), lds, pcr_s(stream), a, KC); \
+  } while (0)
+  if (precision == PCR_PREC_BF16X3) {
+    if (gn_gs) { if (wide) PCR_DBF(true, 3, 2); else PCR_DBF(true, 3, 1); }
+    else { if (wide) PCR_DBF(false, 3, 2); else PCR_DBF(false, 3, 1); }
+  } else {
+    if (gn_gs) { if (wide) PCR_DBF(true, 1, 2); else PCR_DBF(true, 1, 1); }
+    else { if (wide) PCR_DBF(false, 1, 2); else PCR_DBF(false, 1, 1); }
+  }
+#undef PCR_DBF
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_dense_prec_f32(const float *x, const float *wp_bf, const float *scale, const float *shift, float *y,
+                                  int B, int cin, int cout, int L, int act, int precision, pcr_stream_t stream) {
+  return dense_bf_launch(x, wp_bf, scale, shift, y, B, cin, cout, L, act, precision, stream);
+}
+
+PCR_EXPORT int pcr_dense_gn_prec_f32(const float *x, const float *wp_bf, const float *gamma, const float *beta,
+                                     const float *res, float *y, int B, int cin, int cout, int L, int groups, int relu,
+                                     int precision, pcr_stream_t stream) {
+  if (!gamma || !beta || groups < 1 || cout % groups) return PCR_ERR_INVALID;
+  const int gs = cout / groups;
+  if (gs != 4 && gs != 8 && gs != 16 && gs != 32) return PCR_ERR_INVALID;
+  return dense_bf_launch(x, wp_bf, gamma, beta, y, B, cin, cout, L, relu ? 1 : 0, precision, stream, gs, res);
 }
 
 PCR_EXPORT int pcr_dense_gn_f32(const float *x, const float *wp, const float *gamma, const float *beta,

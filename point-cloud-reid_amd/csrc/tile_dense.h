@@ -441,13 +441,16 @@ __device__ __forceinline__ void bf_ring_load(const float *__restrict__ wp_, int 
 
 // BIMG: `in` is a bf image ([CP / 8 pieces][2][32 TB tokens] 16-byte units), not an f32 [CP][RP] tile
 // ring: null, or the steps bf_ring_load fetched for THIS call; RES: the ring holds every step (no weight load inside)
+// CIN / COUT (split contraction, as tile_dense_impl): the accumulators come from / go back to `carry`, so a caller walks a
+// long cin extent chunk by chunk through a small LDS image (dense_bf_kernel, model_kernels.hip)
 template <int TB, int NR, int WAYS, bool TILE, int NS, class Epi, int PF = bf_pf(NR), class AfterK = DenseNoHook,
-          bool BIMG = false, bool RES = false>
+          bool BIMG = false, bool RES = false, bool CIN = false, bool COUT = false>
 __device__ __forceinline__ void tile_dense_bf_impl(const float *__restrict__ in, int CP,
                                                    const float *__restrict__ wp_, int OP, bool sync_epi, Epi epi,
                                                    const float *__restrict__ init = nullptr,
                                                    AfterK after_k = AfterK(), int opfull = 0,
-                                                   const BfRing<PF, NR> *ring = nullptr) {
+                                                   const BfRing<PF, NR> *ring = nullptr,
+                                                   f32x16 (*carry)[(TB + WAYS - 1) / WAYS] = nullptr) {
   static_assert((PF & 1) == 0, "the B-operand double buffer alternates per step");
   constexpr int RP = 32 * TB + 1;
   constexpr int TBW = (TB + WAYS - 1) / WAYS;
@@ -496,7 +499,10 @@ __device__ __forceinline__ void tile_dense_bf_impl(const float *__restrict__ in,
   for (int nr = 0; nr < NR; nr++) {
     int cbi = cb0 + 4 * nr;
     cbi = cbi < nCB ? cbi : nCB - 1;
-    if (init != nullptr) {
+    if constexpr (CIN) {
+#pragma unroll
+      for (int j = 0; j < TBW; j++) acc[nr][j] = carry[nr][j];
+    } else if (init != nullptr) {
       const f32x4 *ip = reinterpret_cast<const f32x4 *>(init + cbi * 32 + 4 * h);
 #pragma unroll
       for (int g = 0; g < 4; g++) {
@@ -605,6 +611,13 @@ __device__ __forceinline__ void tile_dense_bf_impl(const float *__restrict__ in,
         load_x(xr[(i + 1) & 1], sx);
         mma(i, xr[i & 1], s + i == KS - 1);
       }
+  }
+  if constexpr (COUT) {
+#pragma unroll
+    for (int nr = 0; nr < NR; nr++)
+#pragma unroll
+      for (int j = 0; j < TBW; j++) carry[nr][j] = acc[nr][j];
+    return;
   }
   after_k();
   if (sync_epi) __syncthreads();

@@ -26,7 +26,7 @@ class _Plan:
             wb = E.pack_weight((s * (w2 - w1)).float(), device)
             self.layers.append((c, co, wa, wb, sh))
         sc5, sh5 = E.fold_bn(net.conv5[1], None, device)
-        self.w5 = E.pack_weight(net.conv5[0].weight, device)
+        self.w5 = E.pack_weight_dual(net.conv5[0].weight, device)
         self.c5 = net.conv5[0].weight.shape[0]
         self.sc5, self.sh5 = sc5, sh5
         self.cat = sum(l[1] for l in self.layers)

@@ -161,6 +161,17 @@ def pack_weight_bf(w, device):
     return torch.from_numpy(out).to(device)
 
 
+def pack_weight_dual(w, device):
+    """the packed f32 image of `w` with its bf16 hi / lo image attached (`._pcr_bf`): what `dense` / `rows.dense_gn` need to
+    run a wide per-point layer on the bf16 matrix core in the "bf16x3" / "bf16" modes (pcr_dense_prec_f32); layers whose
+    shape the bf16 kernel does not cover simply never look at it"""
+    wp = pack_weight(w, device)
+    cout, cin = w.shape[0], int(np.prod(w.shape[1:]))
+    if L.load().pcr_dense_prec_ok(cin, cout, 1):
+        wp._pcr_bf = pack_weight_bf(w, device)
+    return wp
+
+
 def fold_bn(bn, conv_bias, device):
     """eval-mode BatchNorm after a conv with bias -> per-channel (scale, shift) applied to W x."""
     scale = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
@@ -492,7 +503,16 @@ def dense(x, wp, cout, scale=None, shift=None, act=0):
     x, x_pm = as_cm_or_pm(x)
     B, cin, Ln = x.shape
     y = torch.empty((B, cout, Ln), dtype=torch.float32, device=x.device)
-    fn = L.load().pcr_dense_xpm_f32 if x_pm else L.load().pcr_dense_f32
+    lib = L.load()
+    bf = getattr(wp, "_pcr_bf", None)
+    if PRECISION != "f32" and bf is not None and not x_pm and lib.pcr_dense_prec_ok(cin, cout, Ln):
+        # the wide per-point layers (PointNet convs, DGCNN conv5, LinearRes rows) on the bf16 matrix core
+        with _prof("dense[cin=%d,cout=%d,L=%d]" % (cin, cout, Ln), 2.0 * B * Ln * cin * cout, 4.0 * B * Ln * (cin + cout),
+                   arith=PRECISION):
+            L.check(lib.pcr_dense_prec_f32(L.ptr(x), L.ptr(bf), L.ptr(scale), L.ptr(shift), L.ptr(y), B, cin, cout, Ln, act,
+                                           PRECISIONS[PRECISION], L.stream_ptr()), "pcr_dense_prec_f32")
+        return y
+    fn = lib.pcr_dense_xpm_f32 if x_pm else lib.pcr_dense_f32
     with _prof("dense[cin=%d,cout=%d,L=%d]" % (cin, cout, Ln), 2.0 * B * Ln * cin * cout, 4.0 * B * Ln * (cin + cout),
                arith="f32"):
         L.check(fn(L.ptr(x), L.ptr(wp), L.ptr(scale), L.ptr(shift), L.ptr(y), B, cin, cout, Ln, act, L.stream_ptr()),

@@ -15,11 +15,11 @@ class _StnPlan:
         self.convs = []
         for conv, bn in ((stn.conv1, stn.bn1), (stn.conv2, stn.bn2), (stn.conv3, stn.bn3)):
             sc, sh = E.fold_bn(bn, conv.bias, device)
-            self.convs.append((E.pack_weight(conv.weight, device), conv.weight.shape[0], sc, sh))
+            self.convs.append((E.pack_weight_dual(conv.weight, device), conv.weight.shape[0], sc, sh))
         self.fcs = []
         for fc, bn in ((stn.fc1, stn.bn4), (stn.fc2, stn.bn5)):
             sc, sh = E.fold_bn(bn, fc.bias, device)
-            self.fcs.append((E.pack_weight(fc.weight, device), fc.weight.shape[0], sc, sh, 1))
+            self.fcs.append((E.pack_weight_dual(fc.weight, device), fc.weight.shape[0], sc, sh, 1))
         iden = torch.eye(self.k, dtype=torch.float64).flatten()
         shift = (stn.fc3.bias.detach().double().cpu() + iden).float().to(device).contiguous()
         self.fcs.append((E.pack_weight(stn.fc3.weight, device), self.k * self.k, None, shift, 0))
@@ -54,7 +54,7 @@ class _EncoderPlan:
         self.layers = []
         for conv, bn, act in ((enc.conv1, enc.bn1, 1), (enc.conv2, enc.bn2, 1), (enc.conv3, enc.bn3, 0)):
             sc, sh = E.fold_bn(bn, conv.bias, device)
-            self.layers.append((E.pack_weight(conv.weight, device), conv.weight.shape[0], sc, sh, act))
+            self.layers.append((E.pack_weight_dual(conv.weight, device), conv.weight.shape[0], sc, sh, act))
 
 
 def encoder_forward(enc, xyz):

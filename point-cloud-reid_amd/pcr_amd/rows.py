@@ -48,9 +48,9 @@ def groupnorm(x, gn, res=None, relu=False):
 
 class _LinResPlan:
     def __init__(self, m, device):
-        self.w1 = _E.pack_weight(m.linear1.weight, device)
-        self.w2 = _E.pack_weight(m.linear2.weight, device)
-        self.wt = _E.pack_weight(m.transform[0].weight, device) if m.transform is not None else None
+        self.w1 = _E.pack_weight_dual(m.linear1.weight, device)
+        self.w2 = _E.pack_weight_dual(m.linear2.weight, device)
+        self.wt = _E.pack_weight_dual(m.transform[0].weight, device) if m.transform is not None else None
         self.n_out = m.linear1.weight.shape[0]
 
 
@@ -76,6 +76,14 @@ def dense_gn(x, wp, cout, gn, res=None, relu=False):
     b = gn.bias.detach().to(x.device).float().contiguous()
     if res is not None:
         res = res.contiguous()
+    bf = getattr(wp, "_pcr_bf", None)
+    if _E.PRECISION != "f32" and bf is not None and L.load().pcr_dense_prec_ok(cin, cout, Ln):
+        with _E._prof("dense_gn[cin=%d,cout=%d,L=%d]" % (cin, cout, Ln), 2.0 * B * Ln * cin * cout,
+                      4.0 * B * Ln * (cin + cout * (2 if res is not None else 1)), arith=_E.PRECISION):
+            L.check(L.load().pcr_dense_gn_prec_f32(L.ptr(x), L.ptr(bf), L.ptr(g), L.ptr(b), L.ptr(res), L.ptr(y), B, cin,
+                                                   cout, Ln, gn.num_groups, 1 if relu else 0,
+                                                   _E.PRECISIONS[_E.PRECISION], L.stream_ptr()), "pcr_dense_gn_prec_f32")
+        return y
     with _E._prof("dense_gn[cin=%d,cout=%d,L=%d]" % (cin, cout, Ln), 2.0 * B * Ln * cin * cout,
                   4.0 * B * Ln * (cin + cout * (2 if res is not None else 1)), arith="f32"):
         L.check(L.load().pcr_dense_gn_f32(L.ptr(x), L.ptr(wp), L.ptr(g), L.ptr(b), L.ptr(res), L.ptr(y), B, cin, cout,

@@ -90,7 +90,7 @@ def test_sa_layer_in_every_precision_against_torch(shape):
     print(json.dumps(dict(shape=shape, scale=scale, **err)))
     assert err["f32"] < 2e-6 and err["bf16x3"] < 2e-5, err
     if c1 == 512:       # no bf16 SA kernel for this width: layers 2 / 3 ran in f32 (only the layer-1 tables follow the mode)
-        assert err["bf16x3"] < 5e-6 and err["bf16"] < 2e-3
+        assert err["bf16x3"] < 5e-6 and err["bf16"] < 3e-3
     else:
         assert 1e-5 < err["bf16"] < 3e-2, err
         assert not torch.equal(out["bf16x3"], out["f32"])
