@@ -15,7 +15,7 @@ for W in $WLS; do
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${W}_fetch -o t -- python3 bench.py $ARGS > /dev/null 2> $OUT/${W}_fetch.err
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${W}_write -o t -- python3 bench.py $ARGS > /dev/null 2> $OUT/${W}_write.err
     PAIRS=$(python3 -c "import json,sys; print(json.loads(open('$OUT/${W}_bench.json').read().strip().splitlines()[-1])['config']['pairs_per_gpu_per_step'])")
-    python3 tools/pmc_summary.py $OUT/${TAG}_${W}_pmc.json $PAIRS $OUT/${W}_busy $OUT/${W}_fetch $OUT/${W}_write > $OUT/${W}_pmc.txt 2>&1
+    python3 tools/pmc_summary.py $OUT/${TAG}_${W}_pmc.json $PAIRS $OUT/${W}_busy $OUT/${W}_fetch $OUT/${W}_write ${PCR_PRECISION:-bf16x3} > $OUT/${W}_pmc.txt 2>&1
     rm -rf $OUT/${W}_busy $OUT/${W}_fetch $OUT/${W}_write
   fi
   rm -rf $OUT/${W}_stats
