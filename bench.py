@@ -217,7 +217,7 @@ def train_bench(args, desc, n, bl, pairs, rank, world, steps=None, warmup=None):
     """training throughput (reported separately from the inference metric): pairs/s of
     Trainer.step = ReIDNet.train_step forward + backward, ONE flat-bucket gradient all-reduce over RCCL, gradient
     clipping and AdamW with the cyclic schedule, on a fixed synthetic batch already resident in HBM"""
-    from pcr_amd import shard, train
+    from pcr_amd import shard, train, train_ops
     from pcr_amd import testing as T
     steps = steps or args.steps
     warmup = args.warmup if warmup is None else warmup
@@ -259,24 +259,27 @@ def train_bench(args, desc, n, bl, pairs, rank, world, steps=None, warmup=None):
         tr.bucket._layout()
         rec, engine.PROFILE = engine.PROFILE, None
         tot = {}
-        for name, e0, e1, flops, nbytes, _, _arith in rec:
-            t = tot.setdefault(name, [0.0, 0, 0.0, 0.0])
+        for name, e0, e1, flops, nbytes, _, arith in rec:
+            t = tot.setdefault(name, [0.0, 0, 0.0, 0.0, arith])
             t[0] += e0.elapsed_time(e1)
             t[1] += 1
             t[2] += flops
             t[3] += nbytes
         dom = max(tot, key=lambda k: tot[k][0] / tot[k][1])
-        ms, cnt, flops, nbytes = tot[dom]
+        ms, cnt, flops, nbytes, dom_arith = tot[dom]
+        dom_arith = dom_arith or "f32"
+        _, mfma_peak, mult = PREC_INFO[dom_arith]
         groups = {}
         for k, v in tot.items():
             groups[k.split("[")[0]] = groups.get(k.split("[")[0], 0.0) + v[0]
-        t_mfma, t_hbm = flops / cnt / (MFMA_F32_PEAK_TF * 1e12), nbytes / cnt / (HBM_PEAK_GBS * 1e9)
+        # (split bf16 issues three MFMAs per product: all three counted against the bf16 peak)
+        t_mfma, t_hbm = mult * flops / cnt / (mfma_peak * 1e12), nbytes / cnt / (HBM_PEAK_GBS * 1e9)
         if t_mfma >= t_hbm:
-            roof = dict(bound="mfma", achieved=(flops / cnt) / (ms / cnt * 1e-3) / 1e12, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s")
+            roof = dict(bound="mfma", achieved=mult * (flops / cnt) / (ms / cnt * 1e-3) / 1e12, peak=mfma_peak, unit="TFLOP/s")
         else:
             roof = dict(bound="hbm", achieved=(nbytes / cnt) / (ms / cnt * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
-        roof.update(kernel=dom, frac=roof["achieved"] / roof["peak"], avg_launch_ms=ms / cnt, launches_per_step=cnt,
-                    traffic=None, algorithmic_gflop_per_launch=flops / cnt / 1e9,
+        roof.update(kernel=dom, kernel_arithmetic=dom_arith, frac=roof["achieved"] / roof["peak"], avg_launch_ms=ms / cnt,
+                    launches_per_step=cnt, traffic=None, algorithmic_gflop_per_launch=flops / cnt / 1e9,
                     algorithmic_mb_per_launch=nbytes / cnt / 1e6,
                     profiled_kernels_ms={k: round(v, 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1])},
                     note="the step has ~450 launches; `profiled_kernels_ms` covers the train-dense / grouped-SA launches "
@@ -288,7 +291,9 @@ def train_bench(args, desc, n, bl, pairs, rank, world, steps=None, warmup=None):
             "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": dt / steps * 1e3, "per_rank_ms_per_step": per_rank, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (randn clouds, seeded random-init weights)",
+            "dtype": ("f32" if train_ops.TRAIN_PRECISION == "f32" else
+                      "f32; split bf16 (three bf16 MFMAs per product) for the backward of the 128 x 128 grouped-MLP layers"),
+            "data": "synthetic (randn clouds, seeded random-init weights)",
             "config": {"workload": "pt128_train: %s" % desc, "pairs_per_gpu_per_step": pairs, "points": n,
                        "backbone_list": bl, "parallelism": "data parallel x%d, one %d-byte gradient bucket per step"
                        % (world, tr.bucket.nbytes()), "rccl_ranks": world,

@@ -475,8 +475,17 @@ typedef struct pcr_tdense_bwd {
   const float *wpT;
   float *dx, *dx2, *dstats, *dwp, *dbp;
   long part_stride;   /* floats between consecutive workgroups' dwp / dbp partials; 0 = two dense arrays */
+  /* optional (ABI 11): precision = PCR_PREC_BF16X3 with wpT_bf = the bf16 hi / lo image of W^T
+   * (pcr_pack_weight_bf16_dev_f32, transpose = 1) runs the 128 x 128 layers' dx and dW as split bf16 on the bf16 matrix
+   * core (three MFMAs per product, f32 accumulation); every other shape ignores both fields */
+  int precision;
+  const float *wpT_bf;
 } pcr_tdense_bwd;
 int pcr_tdense_bwd_f32(const pcr_tdense_bwd *p, pcr_stream_t stream);
+/* device-side pcr_pack_weight_bf16x2_f32: the bf16 hi / lo image of W (rows x cols, leading dimension ld; transpose = 0)
+ * or of W^T (transpose = 1); packed holds pcr_packed_weight_bf16_floats(cout, cin) floats */
+int pcr_pack_weight_bf16_dev_f32(const float *w, int rows, int cols, int ld, int transpose, float *packed,
+                                 pcr_stream_t stream);
 
 /* Training-mode core of local_self_attention (attention.py:262-296): qkv (B,3C,N) channel-major = the fused q | k | v
  * projection of feat + pos(xyz) per POINT, idx (B,N,K) feature-space neighbours (pcr_knn_feat_f32).

@@ -312,6 +312,7 @@ struct TBwd {
   const float *isc, *ish, *iinv;    // input affine (+ 1 / isc: recovers the raw input for the next BN backward)
   int in_relu;
   const float *wpT;                 // packed (cin, cout) = W^T, or null: no input gradient wanted
+  const float *wpT_bf;              // (BF kernels) the same matrix as a bf16 hi / lo image
   float *dx, *dx2;
   float *dstats;                    // partials [workgroups][2][ceil32(cin1)]: sum dxm, sum dxm * raw x (dxm = masked dx)
   float *dwp, *dbp;                 // partials [workgroups][ceil32(cout)][ceil32(cin)], [workgroups][ceil32(cout)]
@@ -323,7 +324,11 @@ struct TBwd {
 
 // QY / QX > 0: register prefetch of the NEXT tile (QY pieces of g and of y, QX pieces of the forward input per thread),
 // requested once the current tile sits in LDS: the HBM round trip hides behind the two matrix phases
-template <int WSX, int NRX, int NTW, int QY, int QX>
+// BF (128 x 128 layers, round 4): both matrix phases on the bf16 matrix core as split bf16 (three MFMAs per product, f32
+// accumulation) -- dx through tile_dense2p on the f32 tile (operands converted where they are consumed), dW by
+// contracting the tile's 64 tokens in four steps of 16 (A = dy rows of a cout block, B = f(x) rows of the wave's cin
+// block; token k of a step = 16 s + 8 h + j for both operands).
+template <int WSX, int NRX, int NTW, int QY, int QX, bool BF = false>
 __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
   constexpr int TB = 2, T = kTT, RP = kTRP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -677,6 +682,32 @@ __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
         }
       }
     }
+    if constexpr (BF) {
+      // (128 x 128: sixteen dW tiles, item = wave + 4 it -> cout block it, cin block wave)
+      if (a.dwp && !(a.dbg & 1)) {
+#pragma unroll
+        for (int s = 0; s < T / 16; s++) {
+          float xb8[8];
+          const float *bp = AT + (wave * 32 + l31) * RP + 16 * s + 8 * h;
+#pragma unroll
+          for (int j = 0; j < 8; j++) xb8[j] = bp[j];
+          bf16x8 bh, bl;
+          bf_split8(xb8, bh, bl, true);
+#pragma unroll
+          for (int it = 0; it < NTW; it++) {
+            float xa8[8];
+            const float *ap = DY + (it * 32 + l31) * RP + 16 * s + 8 * h;
+#pragma unroll
+            for (int j = 0; j < 8; j++) xa8[j] = ap[j];
+            bf16x8 ah, al;
+            bf_split8(xa8, ah, al, true);
+            acc[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[it], 0, 0, 0);
+            acc[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[it], 0, 0, 0);
+            acc[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[it], 0, 0, 0);
+          }
+        }
+      }
+    } else
     if (a.dwp && !(a.dbg & 1)) {
 #pragma unroll
       for (int it = 0; it < NTW; it++) {
@@ -694,6 +725,9 @@ __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
     if (want_dx && !(a.dbg & 2)) {
       // (the barrier between this call's k-loop and its epilogue also orders the dW reads of DY above before the
       // in-place overwrite)
+      if constexpr (BF)
+        tile_dense2p<1, TB, NRX, WSX>(DY, a.cout, a.wpT_bf, cinP, true, [&](float v, int o, int t) { DY[o * RP + t] = v; });
+      else
       tile_dense2<TB, NRX, WSX>(DY, ceil8(a.cout), a.wpT, cinP, true, [&](float v, int o, int t) { DY[o * RP + t] = v; });
       __syncthreads();
       if (a.dstats && !(a.dbg & 4)) {   // sums of the masked dx and of dx * (raw input) per input channel, quarter rows
@@ -794,6 +828,9 @@ __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
 template <int WSX, int NRX, int NTW, int QY, int QX>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void tdense_bwd_kernel(TBwd a) {
   tdense_bwd_body<WSX, NRX, NTW, QY, QX>(a);
+}
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void tdense_bwd_bf_kernel(TBwd a) {
+  tdense_bwd_body<1, 1, 4, 0, 0, true>(a);
 }
 // narrow layers (at most four dW tiles: one accumulator tile per wave): held to a quarter of the register file, so that
 // four workgroups share a CU and the load / LDS-commit / matrix / store phases of different workgroups overlap -- the
@@ -986,6 +1023,26 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, int rows, int co
   }
 }
 
+// the bf16 hi / lo image (pcr_pack_weight_bf16x2_f32's layout: [ceil16(cin) / 16 steps][ceil32(cout) / 32][hi, lo][64
+// lanes][8 bf16], channel 16 s + bf_kpos(lane >> 5, e) in element e) of W (transpose = 0) or W^T (1), on the device
+__global__ void pack_weight_bf_kernel(const float *__restrict__ w, int rows, int cols, int ld, int transpose,
+                                      unsigned short *__restrict__ packed) {
+  const int cout = transpose ? cols : rows, cin = transpose ? rows : cols;
+  const int S = (cin + 15) >> 4, nCB = ceil32(cout) >> 5;
+  const int total = S * nCB * 64 * 8;      // (hi, lo) pairs
+  for (int e0 = blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += gridDim.x * blockDim.x) {
+    const int e = e0 & 7, lane = (e0 >> 3) & 63, cb = (e0 >> 9) % nCB, s = (e0 >> 9) / nCB;
+    const int o = cb * 32 + (lane & 31), k = 16 * s + bf_kpos(lane >> 5, e);
+    float v = 0.f;
+    if (o < cout && k < cin) v = transpose ? w[(size_t)k * ld + o] : w[(size_t)o * ld + k];
+    const __bf16 hi = (__bf16)v;
+    const __bf16 lo = (__bf16)(v - (float)hi);
+    const size_t u = ((size_t)(s * nCB + cb) * 2) * 64 + lane;
+    packed[u * 8 + e] = __builtin_bit_cast(unsigned short, hi);
+    packed[(u + 64) * 8 + e] = __builtin_bit_cast(unsigned short, lo);
+  }
+}
+
 // every weight of a model in ONE launch: blockIdx.y = tensor (descriptor table on the device), both images per tensor
 struct PackDesc {      // = pcr_pack_desc
   const float *w;
@@ -1086,6 +1143,17 @@ PCR_EXPORT int pcr_pack_weight_dev_f32(const float *w, int rows, int cols, int l
   return PCR_OK;
 }
 
+PCR_EXPORT int pcr_pack_weight_bf16_dev_f32(const float *w, int rows, int cols, int ld, int transpose, float *packed,
+                                            pcr_stream_t stream) {
+  if (!w || !packed || rows < 1 || cols < 1 || ld < cols || transpose < 0 || transpose > 1) return PCR_ERR_INVALID;
+  const int cout = transpose ? cols : rows, cin = transpose ? rows : cols;
+  const int total = ((cin + 15) >> 4) * (ceil32(cout) >> 5) * 512;
+  hipLaunchKernelGGL(pack_weight_bf_kernel, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0,
+                     pcr_s(stream), w, rows, cols, ld, transpose, reinterpret_cast<unsigned short *>(packed));
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
 PCR_EXPORT int pcr_pack_weights_multi_f32(const pcr_pack_desc *descs_dev, int n, pcr_stream_t stream) {
   if (!descs_dev || n < 0 || n > 65535) return PCR_ERR_INVALID;
   if (n == 0) return PCR_OK;
@@ -1102,6 +1170,7 @@ PCR_EXPORT int pcr_tdense_fwd_f32(const pcr_tdense_fwd *p, pcr_stream_t stream) 
   if (p->stats && p->cout > 256) return PCR_ERR_INVALID;   // (statistics are taken by one thread per cout row)
   if (p->B == 0) return PCR_OK;
   if (p->B > 65535) return PCR_ERR_INVALID;
+  pcr_note_arith(PCR_PREC_F32);
   if (pcr_ts_fwd_ok(p)) return pcr_ts_fwd_launch(p, pcr_s(stream));
   TFwd a;
   a.x = p->x; a.x2 = p->cin2 ? p->x2 : nullptr; a.cin1 = p->cin1; a.cin2 = p->cin2;
@@ -1155,13 +1224,14 @@ PCR_EXPORT int pcr_tdense_bwd_f32(const pcr_tdense_bwd *p, pcr_stream_t stream) 
   if (p->dwp && !p->dbp) return PCR_ERR_INVALID;
   if (p->B == 0) return PCR_OK;
   if (p->B > 65535) return PCR_ERR_INVALID;
+  pcr_note_arith(PCR_PREC_F32);   // (every training launch but the 128 x 128 bf16 backward below)
   if (pcr_ts_bwd_ok(p)) return pcr_ts_bwd_launch(p, pcr_s(stream));
   TBwd a;
   a.g = p->g; a.y = p->y; a.dy_mode = p->dy_mode; a.ka = p->ka; a.kb = p->kb; a.kc = p->kc;
   a.argmax = p->argmax; a.pooled = p->pooled; a.K = p->K; a.S = p->S;
   a.x = p->x; a.x2 = p->cin2 ? p->x2 : nullptr; a.cin1 = p->cin1; a.cin2 = p->cin2;
   a.isc = p->isc; a.ish = p->ish; a.iinv = p->iinv; a.in_relu = p->in_relu;
-  a.wpT = p->wpT; a.dx = p->dx; a.dx2 = p->dx2; a.dstats = p->dstats; a.dwp = p->dwp; a.dbp = p->dbp;
+  a.wpT = p->wpT; a.wpT_bf = p->wpT_bf; a.dx = p->dx; a.dx2 = p->dx2; a.dstats = p->dstats; a.dwp = p->dwp; a.dbp = p->dbp;
   a.dw_stride = p->part_stride; a.db_stride = p->part_stride;
   a.cout = p->cout; a.L = p->L; a.B = p->B;
   static const int dbg = pcr_tune_int("PCR_TD_DBG");
@@ -1214,6 +1284,14 @@ PCR_EXPORT int pcr_tdense_bwd_f32(const pcr_tdense_bwd *p, pcr_stream_t stream) 
     hipLaunchKernelGGL((tdense_bwd_kernel_p1<4, 1, 2, 2>), grid, blk, lds, st, a);
   }
   else if (rowsY == 64 && cinP == 64) PCR_TB(2, 1, 4, 4);
+  else if (p->precision == PCR_PREC_BF16X3 && p->wpT_bf && p->wpT && coutP == 128 && cinP == 128 && p->cout == 128 &&
+           p->cin1 == 128 && !p->cin2 && gz == 1) {
+    // the 128 x 128 grouped-MLP layers on the bf16 matrix core (split bf16: dx and dW)
+    static bool okb = big_lds(tdense_bwd_bf_kernel);
+    (void)okb;
+    pcr_note_arith(PCR_PREC_BF16X3);
+    hipLaunchKernelGGL(tdense_bwd_bf_kernel, grid, blk, lds, st, a);
+  }
   else if (nx == 1) PCR_TB(4, 1, 0, 0);
   else if (nx == 2) PCR_TB(2, 1, 0, 0);
   else if (nx <= 4) PCR_TB(1, 1, 0, 0);

@@ -9,17 +9,21 @@ from . import _lib as L
 from . import engine as E
 
 
+# (The encoder's convs and both transform nets stay on the f32-input MFMA in every mode: measured in split bf16, the
+# 1024-wide features (|x| ~ 90) come out 1.2e-3 off and the per-point embeddings behind them 1.6e-4 -- outside the 1e-4
+# parity bound -- because an error in the learned 3 x 3 / 64 x 64 transforms multiplies every feature.  The LinearRes
+# downsample rows, which hold most of the encoder's flops, do run on the bf16 matrix core: rows.py.)
 class _StnPlan:
     def __init__(self, stn, device):
         self.k = stn.k
         self.convs = []
         for conv, bn in ((stn.conv1, stn.bn1), (stn.conv2, stn.bn2), (stn.conv3, stn.bn3)):
             sc, sh = E.fold_bn(bn, conv.bias, device)
-            self.convs.append((E.pack_weight_dual(conv.weight, device), conv.weight.shape[0], sc, sh))
+            self.convs.append((E.pack_weight(conv.weight, device), conv.weight.shape[0], sc, sh))
         self.fcs = []
         for fc, bn in ((stn.fc1, stn.bn4), (stn.fc2, stn.bn5)):
             sc, sh = E.fold_bn(bn, fc.bias, device)
-            self.fcs.append((E.pack_weight_dual(fc.weight, device), fc.weight.shape[0], sc, sh, 1))
+            self.fcs.append((E.pack_weight(fc.weight, device), fc.weight.shape[0], sc, sh, 1))
         iden = torch.eye(self.k, dtype=torch.float64).flatten()
         shift = (stn.fc3.bias.detach().double().cpu() + iden).float().to(device).contiguous()
         self.fcs.append((E.pack_weight(stn.fc3.weight, device), self.k * self.k, None, shift, 0))
@@ -54,7 +58,7 @@ class _EncoderPlan:
         self.layers = []
         for conv, bn, act in ((enc.conv1, enc.bn1, 1), (enc.conv2, enc.bn2, 1), (enc.conv3, enc.bn3, 0)):
             sc, sh = E.fold_bn(bn, conv.bias, device)
-            self.layers.append((E.pack_weight_dual(conv.weight, device), conv.weight.shape[0], sc, sh, act))
+            self.layers.append((E.pack_weight(conv.weight, device), conv.weight.shape[0], sc, sh, act))
 
 
 def encoder_forward(enc, xyz):

@@ -7,6 +7,7 @@ projections / feed-forward layers and the match head -- is a HIP launch forward 
 matrix core; autograd only strings the Functions together.  Nothing here has a CPU path.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -40,7 +41,8 @@ class _TBwd(ctypes.Structure):
                 ("ka", c_fp), ("kb", c_fp), ("kc", c_fp), ("argmax", c_fp), ("pooled", c_fp),
                 ("K", ctypes.c_int), ("S", ctypes.c_int), ("x", c_fp), ("x2", c_fp),
                 ("isc", c_fp), ("ish", c_fp), ("iinv", c_fp), ("in_relu", ctypes.c_int), ("wpT", c_fp),
-                ("dx", c_fp), ("dx2", c_fp), ("dstats", c_fp), ("dwp", c_fp), ("dbp", c_fp), ("part_stride", ctypes.c_long)]
+                ("dx", c_fp), ("dx2", c_fp), ("dstats", c_fp), ("dwp", c_fp), ("dbp", c_fp), ("part_stride", ctypes.c_long),
+                ("precision", ctypes.c_int), ("wpT_bf", c_fp)]
 
 
 class _BnFwd(ctypes.Structure):
@@ -256,7 +258,7 @@ def tdense_fwd(x, wp, cout, x2=None, isc=None, ish=None, in_relu=False, bias=Non
     p.stats = _p(stats)
     cin = cin1 + cin2
     with _prof("tdense_fwd[cin=%d,cout=%d,L=%d]" % (cin, cout, Ln), 2.0 * B * Ln * cin * cout,
-               4.0 * B * Ln * (cin + cout * (2 if res is not None else 1))):
+               4.0 * B * Ln * (cin + cout * (2 if res is not None else 1)), arith="lib"):
         L.check(L.load().pcr_tdense_fwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_tdense_fwd_f32")
     if pool is not None:
         return y, stats, pooled
@@ -270,8 +272,37 @@ def reduce_parts(part, nparts, stride, rows, cols, ld):
     return out
 
 
+# Arithmetic of the training launches' matrix phases: "f32" (f32-input MFMA, exact fmaf chains) or "bf16x3" (split bf16
+# on the bf16 matrix core, three MFMAs per product, f32 accumulation) -- today the backward of the 128 x 128 grouped-MLP
+# layers (dx and dW; include/pcr.h pcr_tdense_bwd.precision), every other launch is f32 whatever this says.
+# PCR_TRAIN_PRECISION in the environment or set_train_precision() select it.
+TRAIN_PRECISION = os.environ.get("PCR_TRAIN_PRECISION", "bf16x3")
+if TRAIN_PRECISION not in ("f32", "bf16x3"):
+    raise L.PcrError("PCR_TRAIN_PRECISION must be f32 or bf16x3")
+
+
+def set_train_precision(name):
+    """-> previous setting"""
+    global TRAIN_PRECISION
+    if name not in ("f32", "bf16x3"):
+        raise L.PcrError("training precision must be f32 or bf16x3")
+    prev, TRAIN_PRECISION = TRAIN_PRECISION, name
+    return prev
+
+
+def pack_bf_T(w):
+    """(rows, cols) device weight -> bf16 hi / lo image of W^T (the dx operand of the bf16 backward), packed on the device:
+    one small launch per layer and iteration (the weights change every step)"""
+    wd = _dev(w.detach())
+    rows, cols = wd.shape
+    out = _f32(L.load().pcr_packed_weight_bf16_floats(cols, rows), device=wd.device)
+    L.check(L.load().pcr_pack_weight_bf16_dev_f32(L.ptr(wd), rows, cols, cols, 1, L.ptr(out), L.stream_ptr()),
+            "pcr_pack_weight_bf16_dev_f32")
+    return out
+
+
 def tdense_bwd(g, x, cout, dy_mode=0, y=None, k=None, argmax=None, pooled=None, K=0, S=0, x2=None, isc=None, ish=None,
-               iinv=None, in_relu=False, wpT=None, want_dstats=False, want_dw=True):
+               iinv=None, in_relu=False, wpT=None, want_dstats=False, want_dw=True, wpT_bf=None):
     """-> dict(dx, dx2, dstats, dW (cout, cin1+cin2), db (cout)); see pcr_tdense_bwd in include/pcr.h"""
     x = _dev(x)
     B, cin1, Ln = x.shape
@@ -292,6 +323,8 @@ def tdense_bwd(g, x, cout, dy_mode=0, y=None, k=None, argmax=None, pooled=None, 
     # workgroups of THIS launch = rows of its partial buffers: asked with the wanted outputs marked non-NULL (the
     # library picks the kernel -- and with it the grid -- from the parameter block), then the real buffers go in
     p.wpT = _p(wpT)
+    if wpT_bf is not None and TRAIN_PRECISION == "bf16x3":
+        p.wpT_bf, p.precision = _p(wpT_bf), 1
     if wpT is not None:
         p.dx, p.dx2 = 1, (1 if cin2 else None)
         p.dstats = 1 if want_dstats else None
@@ -318,7 +351,7 @@ def tdense_bwd(g, x, cout, dy_mode=0, y=None, k=None, argmax=None, pooled=None, 
     flops = 2.0 * B * Ln * cout * cin * ((1 if want_dw else 0) + (1 if wpT is not None else 0))
     nbytes = 4.0 * B * Ln * ((cout if dy_mode != 3 else 0) + (cout if dy_mode != 0 else 0) + cin +
                              (cin if wpT is not None else 0))
-    with _prof("tdense_bwd[mode=%d,cin=%d,cout=%d,L=%d]" % (dy_mode, cin, cout, Ln), flops, nbytes):
+    with _prof("tdense_bwd[mode=%d,cin=%d,cout=%d,L=%d]" % (dy_mode, cin, cout, Ln), flops, nbytes, arith="lib"):
         L.check(L.load().pcr_tdense_bwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_tdense_bwd_f32")
     if want_dw:
         flat = reduce_parts(parts, nwg, per, 1, per, per).view(per)
@@ -499,12 +532,15 @@ class SaEdgeTrain(Function):
         L.check(lib.pcr_sa_pool_bwd_stats_f32(L.ptr(gp), L.ptr(pooled), L.ptr(ymax), L.ptr(part3), L.ptr(gz), B, c3, S,
                                               L.stream_ptr()), "pcr_sa_pool_bwd_stats_f32")
         k3 = bn_bwd_finalize(part3, B, c3, R, g3, n3["mean"], n3["invstd"])
+        # (128 x 128 layers: dx and dW on the bf16 matrix core when TRAIN_PRECISION says so)
+        bf3 = pack_bf_T(w3) if (TRAIN_PRECISION == "bf16x3" and c3 == 128 and c2 == 128) else None
+        bf2 = pack_bf_T(w2) if (TRAIN_PRECISION == "bf16x3" and c2 == 128 and c1 == 128) else None
         r3 = tdense_bwd(gz, y2, c3, dy_mode=3, y=y3, k=k3, argmax=argmax, pooled=None, K=K, S=S,
                         isc=n2["scale"], ish=n2["shift"], iinv=n2["inv_scale"], in_relu=True,
-                        wpT=pack_dev(w3, transpose=True), want_dstats=True)
+                        wpT=pack_dev(w3, transpose=True), want_dstats=True, wpT_bf=bf3)
         k2 = bn_bwd_finalize(r3["dstats"], r3["dstats"].shape[0], c2, R, g2, n2["mean"], n2["invstd"])
         r2 = tdense_bwd(r3["dx"], y1, c2, dy_mode=1, y=y2, k=k2, isc=n1["scale"], ish=n1["shift"], iinv=n1["inv_scale"],
-                        in_relu=True, wpT=pack_dev(w2, transpose=True), want_dstats=True)
+                        in_relu=True, wpT=pack_dev(w2, transpose=True), want_dstats=True, wpT_bf=bf2)
         k1 = bn_bwd_finalize(r2["dstats"], r2["dstats"].shape[0], c1, R, g1, n1["mean"], n1["invstd"])
         dtab = _f32(B, 2 * c1, N, device=dev) if ctx.has_tab else None
         dwa_p = _f32(B, c1, 4, device=dev)

@@ -23,9 +23,10 @@ import json
 import re
 import sys
 
-ONE_FORM_F32 = ("attn_kv_kernel", "attn_kv_kernel_o3", "attn_kv_wide_kernel", "dense_kernel", "dense_gn_kernel")
+ONE_FORM_F32 = ("attn_kv_kernel", "attn_kv_kernel_o3", "attn_kv_wide_kernel", "dense_kernel", "dense_gn_kernel",
+                "tdense_bwd_kernel", "tdense_fwd_kernel", "tstream_fwd_pipe_kernel", "tstream_fwd_kernel", "tstream_bwd_kernel")
 ONE_FORM_BF3 = ("attn_kv_stream32_kernel", "attn_apply_stream64_kernel", "attn_kv_stream128_kernel",
-                "attn_apply_stream128_kernel", "gallery_tail_kernel", "dense_bf_kernel")
+                "attn_apply_stream128_kernel", "gallery_tail_kernel", "tdense_bwd_bf_kernel")
 
 
 def short(name):
@@ -53,6 +54,8 @@ def arithmetic_of(k):
         return "bf16x3" if a[2] == "true" else "bf16"
     if base == "attn_kv_stream64_kernel" and len(a) >= 2:
         return "bf16x3" if a[1] == "true" else "f32"
+    if base == "dense_bf_kernel" and len(a) >= 2:
+        return "bf16x3" if a[1] == "3" else "bf16"
     if base in ONE_FORM_BF3:
         return "bf16x3"
     if base in ONE_FORM_F32:
@@ -105,7 +108,10 @@ KNOWN = {
     "attn_apply[d=64,c1=64,out=64,Lq=128]": ["gallery_tail_kernel", "attn_apply_stream64_kernel<false, 4, 0, 2",
                                              "attn_apply_kernel<2, 1>"],
     "attn_kv[d=64,c2=64,Sk=128]": ["attn_kv_stream64_kernel<true, true, 4", "attn_kv_stream64_kernel<true, false, 4"],
-    "dense_gn[cin=1024,cout=512,L=256]": ["dense_bf_kernel<", "dense_gn_kernel<", "dense_kernel<"],
+    "dense_gn[cin=1024,cout=512,L=256]": ["dense_bf_kernel<true, 3, 2", "dense_bf_kernel<true", "dense_kernel<2, true, true"],
+    "dense[cin=512,cout=1024,L=256]": ["dense_bf_kernel<false, 3, 2", "dense_kernel<2, false, true"],
+    "tdense_bwd[mode=1,cin=128,cout=128,L=1536]": ["tdense_bwd_bf_kernel", "tdense_bwd_kernel<1, 1, 4, 0, 0>"],
+    "tdense_bwd[mode=3,cin=128,cout=128,L=1536]": ["tdense_bwd_bf_kernel", "tdense_bwd_kernel<1, 1, 4, 0, 0>"],
 }
 
 
