@@ -18,6 +18,36 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// the same reductions without LDS round trips: four DPP steps inside a row of 16 lanes (xor 1, xor 2, half-row mirror, row
+// mirror: afterwards every lane holds its row's result), then the four rows' results by v_readlane.  (__shfl_xor is
+// ds_bpermute: six dependent LDS round trips per reduction, and pool_head_kernel does 128 of them per pair.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_f32<0xB1>(v);
+  v += dpp_f32<0x4E>(v);
+  v += dpp_f32<0x141>(v);
+  v += dpp_f32<0x140>(v);
+  const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return (a + b) + (c + d);
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  v = fmaxf(v, dpp_f32<0xB1>(v));
+  v = fmaxf(v, dpp_f32<0x4E>(v));
+  v = fmaxf(v, dpp_f32<0x141>(v));
+  v = fmaxf(v, dpp_f32<0x140>(v));
+  const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+
 // GroupNorm of a length-n vector in LDS (one sample), groups of n/g channels; in place.
 __device__ __forceinline__ void vec_groupnorm(float *v, int n, int g, const float *gamma, const float *beta) {
   const int gs = n / g;
@@ -45,9 +75,47 @@ __global__ __launch_bounds__(kThreads) void pool_head_kernel(pcr_head_params p) 
   const int C = p.C, L = p.L, n = 2 * C;
   const float *o1 = p.o + pr * C * L;
   const float *o2 = p.o + (pr + p.P) * C * L;
+  constexpr int NW = kThreads / 64;
+  if ((L & 3) == 0 && (reinterpret_cast<size_t>(p.o) & 15) == 0) {
+    // round 4: 16-byte loads, BOTH clouds of a channel in one instruction (lanes 0-31: points 4 q .. + 3 of o1, lanes 32-63
+    // of o2), eight channels of a wave in flight, DPP reductions.  The gallery's 36 k pairs read 2.1 GB here at 2.3 TB/s with
+    // 4-byte loads, four channels in flight and bpermute reductions (0.9 ms).
+    constexpr int CH = 8;
+    const int q = lane & 31;
+    const float *ob = lane < 32 ? o1 : o2;
+    for (int c0 = wave * CH; c0 < C; c0 += NW * CH) {
+      float mx[CH], sm[CH];
+#pragma unroll
+      for (int u = 0; u < CH; u++) {
+        mx[u] = -INFINITY;
+        sm[u] = 0.f;
+      }
+      for (int i0 = 0; i0 < L; i0 += 128) {
+        const bool ok = i0 + 4 * q < L;
+        f32x4 v[CH];
+#pragma unroll
+        for (int u = 0; u < CH; u++) {
+          const int c = c0 + u < C ? c0 + u : c0;
+          v[u] = *reinterpret_cast<const f32x4 *>(ob + (size_t)c * L + (ok ? i0 + 4 * q : 0));
+        }
+        if (ok) {
+#pragma unroll
+          for (int u = 0; u < CH; u++) {
+            mx[u] = fmaxf(mx[u], fmaxf(fmaxf(v[u][0], v[u][1]), fmaxf(v[u][2], v[u][3])));
+            sm[u] += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < CH; u++) {
+        const int c = c0 + u;
+        const float m1 = wave_max_dpp(mx[u]), s1 = wave_sum_dpp(sm[u]);
+        if (lane == 0 && c < C) { x[c] = m1; x[C + c] = s1 / (float)(2 * L); }
+      }
+    }
+  } else
   // four channels of a wave in flight at a time (one channel per trip left every load waiting on the previous trip's
   // reductions: 42 us per pair at 36 k pairs); same per-lane order of the sums
-  constexpr int NW = kThreads / 64;
   for (int c0 = wave; c0 < C; c0 += 4 * NW) {
     float mx[4], sm[4];
 #pragma unroll
