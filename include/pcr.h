@@ -70,6 +70,18 @@ int pcr_ball_query_f32(const float *centres, const float *xyz, int *idx, int B, 
 int pcr_ball_query_cnt_f32(const float *centres, const float *xyz, int *idx, int *cnt, int B, int N, int M,
                            float min_r, float max_r, int K, pcr_stream_t stream);
 
+/* pcr_ball_query_cnt_f32 that ALSO writes the compact row table the wave-autonomous ragged SA kernel reads
+ * (pcr_sa_params.row_tab; ABI 12).  rows: pcr_ball_query_rows_floats(B, M, K) floats, 16-byte aligned, = for every
+ * (cloud, run of 16 consecutive centres) a region of 16 K entries of 4 floats {bits of the neighbour index, dx, dy, dz}
+ * (point - centre): centre after centre its first ceil2(max(cnt, 1)) rows of idx (odd counts and empty balls padded
+ * with the row's first entry, exactly as idx pads), then zero entries up to the next multiple of 32 rows; the rest of
+ * a region is not written.  idx may be NULL (not written).  Needs pcr_ball_query_rows_ok(N, K, min_r): N <= 1024,
+ * K even, min_r == 0 (every ball-query layer of the reference's configs); PCR_ERR_INVALID otherwise. */
+long pcr_ball_query_rows_floats(int B, int M, int K);
+int pcr_ball_query_rows_ok(int N, int K, float min_r);
+int pcr_ball_query_rows_f32(const float *centres, const float *xyz, int *idx, int *cnt, float *rows, int B, int N, int M,
+                            float min_r, float max_r, int K, pcr_stream_t stream);
+
 /* The model path's own (dormant) Python samplers / groupers, semantics of the PYTHON code rather than of the CUDA ops:
  *
  * farthest_point_sample (models/pointnet2_utils.py:116-137): first pick = start[b] (the reference draws it with
@@ -207,6 +219,11 @@ typedef struct pcr_sa_params {
    * (dx, dy, dz, 1) to the matrix core, so that layer 1's shift arrives with the coordinate term and costs no seed
    * reads.  Without it that kernel is not chosen. */
   const float *wa_shift_packed;
+  /* optional (ABI 12): the ball query's row table of THIS launch's groups (pcr_ball_query_rows_f32, same B / S / K),
+   * for ball-query layers with hit counts whose shape pcr_sa_uses_row_table accepts: the wave-autonomous ragged kernel
+   * then reads a row's {neighbour, point - centre} with one load instead of chasing cnt -> idx -> xyz.  idx may be
+   * NULL when it is given (cnt is still read).  Ignored by every other kernel. */
+  const float *row_tab;
 } pcr_sa_params;
 int pcr_sa_mlp_f32(const pcr_sa_params *p, pcr_stream_t stream);
 /* ints of pcr_sa_params.tile_ws for the duplicate-free evaluation (tile lists + per-tile row tables) */
@@ -215,6 +232,8 @@ long pcr_sa_tile_ws_ints(int B, int S, int K, int c2, int c3);
  * wants tile_ws (the cout-split kernel with register-resident weights, 128 / 128 / 256 in the bf16 modes): ragged and
  * K-row evaluation of such a layer then share one kernel, hence one arithmetic. */
 int pcr_sa_krow_uses_tiles(int c1, int c2, int c3, int K, int precision);
+/* 1: a ball-query layer of this shape with hit counts reads pcr_sa_params.row_tab when given (shape-only) */
+int pcr_sa_uses_row_table(int c1, int c2, int c3, int K, int precision);
 
 /* Per-point linear map with POINT-major output: x (B,cin,L) channel-major (or (B,L,cin) when x_point_major)
  * -> y (B,L,cout) = W x, wp packed (cout,cin), cout <= 1024 (a multiple of 4 beyond 256).  This is the table builder of the decomposed first

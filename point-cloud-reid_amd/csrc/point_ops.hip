@@ -500,13 +500,18 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict
 // evaluations per lane instead of N serial LDS round trips per thread; hits are rare (a few per 1024
 // points), so the ordered compaction (ballot + prefix popcount) sits behind a wave-uniform branch.
 // Same hit predicate, same "first K in index order, pad with the first hit" result as above.
-template <int PPL, bool kSimple>   // kSimple: min_radius = 0 < max_radius (every configuration in the reference)
+// kRows (round 4): the wave ALSO writes the compact row table of its 16 centres -- what the wave-autonomous ragged SA
+// kernel otherwise rebuilds per item from cnt -> prefix -> idx -> xyz (three dependent loads deep): entries {neighbour index,
+// dx, dy, dz} (point - centre), a centre's first rag rows = ceil2(max(cnt, 1)) back to back (odd counts and empty balls are
+// padded with the row's first entry, as the index tensor pads), the run of the wave's centres (= one SA item) in its own
+// 16 K-entry region, zero entries up to the next multiple of 32 rows.  idx may then be NULL (nobody reads it).
+template <int PPL, bool kSimple, bool kRows = false>   // kSimple: min_radius = 0 < max_radius (every configuration in the reference)
 __global__ __launch_bounds__(256) void ball_query_reg_kernel(const float *__restrict__ centres,
                                                              const float *__restrict__ xyz,
                                                              int *__restrict__ idx, int n, int m,
                                                              float min_r2, float max_r2, int K,
                                                              int *__restrict__ cnt_out, int cpw, int nchunk,
-                                                             int nclouds) {
+                                                             int nclouds, f32x4 *__restrict__ rows_out = nullptr) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // XCD-aware order: consecutive workgroup ids go round-robin over the eight XCDs (each with its own L2), so the
@@ -543,13 +548,17 @@ __global__ __launch_bounds__(256) void ball_query_reg_kernel(const float *__rest
   __shared__ int s_row[4][64];
   int *row = s_row[wave];
   const bool staged = K <= 64;
+  // (kRows) this wave's region of the row table and its running row offset
+  f32x4 *rbase = kRows ? rows_out + ((size_t)b * ((m + cpw - 1) / cpw) + (size_t)(chunk * 4 + wave)) * (size_t)(cpw * K) : nullptr;
+  int roff = 0;
   for (int c = c0; c < c1; c++) {
     const int co = 3 * (c - c0);
     const float cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cv), co));
     const float cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cv), co + 1));
     const float cz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cv), co + 2));
-    int *gout = idx + (b * m + c) * (size_t)K;
+    int *gout = idx ? idx + (b * m + c) * (size_t)K : nullptr;
     int cnt = 0, first = 0;
+    float fdx = 0.f, fdy = 0.f, fdz = 0.f;   // (kRows) point - centre of the first hit
     {
       // min_radius = 0: d2 >= 0 always holds and d2 == 0 implies d2 < max_r2, so the predicate is a single compare
       auto inside = [&](float d2) __attribute__((always_inline)) {
@@ -579,16 +588,39 @@ __global__ __launch_bounds__(256) void ball_query_reg_kernel(const float *__rest
           const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk[j] >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)mk[j], 0u));
           if (inside(d2[j]) && pos < K) {
-            if (staged) row[pos] = j * 64 + lane;   // (kept apart: one pointer for both would be a flat store)
-            else gout[pos] = j * 64 + lane;
+            if (gout) {
+              if (staged) row[pos] = j * 64 + lane;   // (kept apart: one pointer for both would be a flat store)
+              else gout[pos] = j * 64 + lane;
+            }
+            if constexpr (kRows)
+              rbase[roff + pos] = f32x4{__int_as_float(j * 64 + lane), px[j >> 1][j & 1] - cx, py[j >> 1][j & 1] - cy,
+                                        pz[j >> 1][j & 1] - cz};
           }
-          if (cnt == 0) first = j * 64 + (int)__builtin_ctzll(mk[j]);
+          if (cnt == 0) {
+            const int fl = (int)__builtin_ctzll(mk[j]);
+            first = j * 64 + fl;
+            if constexpr (kRows) {
+              fdx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px[j >> 1][j & 1]), fl)) - cx;
+              fdy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py[j >> 1][j & 1]), fl)) - cy;
+              fdz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[j >> 1][j & 1]), fl)) - cz;
+            }
+          }
           cnt += __popcll(mk[j]);
         }
       }
     }
     if (cnt > K) cnt = K;
-    if (staged) {
+    if constexpr (kRows) {
+      if (cnt == 0) {   // nothing inside: the index tensor's row is all `first` = point 0
+        fdx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px[0][0]), 0)) - cx;
+        fdy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py[0][0]), 0)) - cy;
+        fdz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[0][0]), 0)) - cz;
+      }
+      const int nrow = cnt < 1 ? 2 : ((cnt + 1) & ~1);
+      if (lane < nrow - cnt) rbase[roff + cnt + lane] = f32x4{__int_as_float(first), fdx, fdy, fdz};
+      roff += nrow;
+    }
+    if (gout && staged) {
       // (a wave's LDS operations complete in order: the hit lanes' writes above are visible to the read below)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -597,15 +629,31 @@ __global__ __launch_bounds__(256) void ball_query_reg_kernel(const float *__rest
       if (lane < K) idx[(b * m + c) * (size_t)K + lane] = v;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-    } else {
+    } else if (gout) {
       for (int l = cnt + lane; l < K; l += 64) gout[l] = first;
     }
     if (cnt_out && lane == 0) cnt_out[b * m + c] = cnt;
   }
+  if constexpr (kRows) {   // whole 32-row blocks: the consumer reads them without a clamp (and skips the padding's pairs)
+    if (c0 < c1 && roff + lane < ((roff + 31) & ~31)) rbase[roff + lane] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 }
 
 static void ball_query_launch(const float *centres, const float *xyz, int *idx, int *cnt, int B, int N, int M,
-                              float min_r2, float max_r2, int K, hipStream_t st) {
+                              float min_r2, float max_r2, int K, hipStream_t st, float *rows = nullptr) {
+  if (rows) {   // (validated by the caller: N <= 1024, min radius 0, K even)
+    const int cpw = 16, nchunk = (M + 4 * cpw - 1) / (4 * cpw);
+    const dim3 grid((unsigned)((B + 7) / 8) * 8 * nchunk), blk(256);
+    f32x4 *r4 = reinterpret_cast<f32x4 *>(rows);
+#define PCR_BQR(PPLv)                                                                                            \
+  hipLaunchKernelGGL((ball_query_reg_kernel<PPLv, true, true>), grid, blk, 0, st, centres, xyz, idx, N, M, min_r2, \
+                     max_r2, K, cnt, cpw, nchunk, B, r4)
+    if (N <= 256) PCR_BQR(4);
+    else if (N <= 512) PCR_BQR(8);
+    else PCR_BQR(16);
+#undef PCR_BQR
+    return;
+  }
   if (N <= 1024) {
     const int cpw = 16;                                  // centres per wave
     const int nchunk = (M + 4 * cpw - 1) / (4 * cpw);
@@ -1193,7 +1241,7 @@ __global__ __launch_bounds__(NT) void knn_prefix_lds_kernel(const float *__restr
 }  // namespace
 
 // ------------------------------------------------------------------------------ C ABI ----
-PCR_EXPORT int pcr_abi_version(void) { return 11; }
+PCR_EXPORT int pcr_abi_version(void) { return 12; }
 
 PCR_EXPORT const char *pcr_status_string(int status) {
   switch (status) {
@@ -1273,6 +1321,25 @@ PCR_EXPORT int pcr_ball_query_cnt_f32(const float *centres, const float *xyz, in
   if (B > 65535) return PCR_ERR_INVALID;
   float max_r2 = max_r * max_r, min_r2 = min_r * min_r;
   ball_query_launch(centres, xyz, idx, cnt, B, N, M, min_r2, max_r2, K, pcr_s(stream));
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT long pcr_ball_query_rows_floats(int B, int M, int K) {
+  if (B < 1 || M < 1 || K < 1) return 0;
+  return (long)B * ((M + 15) / 16) * 16 * K * 4;
+}
+
+PCR_EXPORT int pcr_ball_query_rows_ok(int N, int K, float min_r) { return N >= 1 && N <= 1024 && K >= 2 && !(K & 1) && min_r == 0.f; }
+
+PCR_EXPORT int pcr_ball_query_rows_f32(const float *centres, const float *xyz, int *idx, int *cnt, float *rows, int B,
+                                       int N, int M, float min_r, float max_r, int K, pcr_stream_t stream) {
+  if (!centres || !xyz || !cnt || !rows || B < 0 || N < 1 || M < 0 || K < 1 || !(max_r > 0.f) ||
+      !pcr_ball_query_rows_ok(N, K, min_r))
+    return PCR_ERR_INVALID;
+  if (B == 0 || M == 0) return PCR_OK;
+  if (B > 65535) return PCR_ERR_INVALID;
+  ball_query_launch(centres, xyz, idx, cnt, B, N, M, 0.f, max_r * max_r, K, pcr_s(stream), rows);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }

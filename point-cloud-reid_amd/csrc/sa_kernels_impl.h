@@ -428,6 +428,15 @@ __global__ __launch_bounds__(kThreads) void sa_fused_kernel(Sa2Args a) {
   }
 }
 
+// per-wave LDS of the ragged form, in ints: pair maxima [16][C3] | row map [16 K] (indexed form only) | end-of-centre
+// flags, a byte per pair of the item
+__host__ __device__ constexpr int sas_rag_wave_ints(int c3, int K, bool tab) {
+  return 16 * c3 + (tab ? 0 : 16 * K) + ((16 * K / 2 + 15) / 16) * 4;
+}
+
+constexpr int kTraceWgs = 1024, kTraceTiles = 24, kTraceMarks = 8;
+__device__ unsigned long long g_rag_trace[kTraceWgs * (2 + kTraceTiles * kTraceMarks)];
+
 #if PCR_SA_PREC != 0
 // ---- wave-autonomous K-row kernel: c1 = c2 = c3 = 32 NCB (the Point-Transformer's kNN-grouped SA layers), K % 16 == 0,
 // layer 1 on the matrix core.  A wave owns 32 rows (tokens) of the grouped tensor from the index load to the 16-row
@@ -445,36 +454,73 @@ constexpr int kSasCpi = 16;   // centres per item of the ragged form
 
 // the three layers of one 32-row block, shared by the K-row and the ragged form.  In: the row's neighbour i, its centre
 // point ci; out: y3[NCB3], layer 3 TRANSPOSED (lane (cout, h) holds the tokens 8 g + 4 h + q of its channel).
+// lane p of the value's DPP row (16 lanes) to every lane of the row (row_newbcast; p is a constant after unrolling)
+__device__ __forceinline__ float row_bcast_f32(float v, int p) {
+  const int x = __float_as_int(v);
+  int r;
+  switch (p & 15) {
+#define PCR_RB(P) case P: r = __builtin_amdgcn_update_dpp(0, x, 0x150 + P, 0xF, 0xF, false); break;
+    PCR_RB(0) PCR_RB(1) PCR_RB(2) PCR_RB(3) PCR_RB(4) PCR_RB(5) PCR_RB(6) PCR_RB(7)
+    PCR_RB(8) PCR_RB(9) PCR_RB(10) PCR_RB(11) PCR_RB(12) PCR_RB(13) PCR_RB(14)
+    default: r = __builtin_amdgcn_update_dpp(0, x, 0x15F, 0xF, 0xF, false); break;
+#undef PCR_RB
+  }
+  return __int_as_float(r);
+}
+
 template <int NCB, int NCB3, bool LO>
 struct SasBlock {
   static constexpr int C = 32 * NCB, NS = 2 * NCB;
   __device__ static __forceinline__ void run(const float *xyz, const float *pq, int pqw, int qoff, bool has_q, int i, int ci,
                                              const float *s_sh1, const float *s_sh2, const float *s_sh3, const f32x4 *s_wa,
-                                             const bf16x8 *s_w2, const bf16x8 *s_w3, int lane, f32x16 (&y3)[NCB3]) {
+                                             const bf16x8 *s_w2, const bf16x8 *s_w3, int lane, f32x16 (&y3)[NCB3],
+                                             unsigned long long *tr = nullptr) {
+    const float dxv = xyz[i * 3] - xyz[ci * 3], dyv = xyz[i * 3 + 1] - xyz[ci * 3 + 1], dzv = xyz[i * 3 + 2] - xyz[ci * 3 + 2];
+    run_d(dxv, dyv, dzv, pq, pqw, qoff, has_q, i, ci, s_sh1, s_sh2, s_sh3, s_wa, s_w2, s_w3, lane, y3, tr);
+  }
+  // the same with the row's point - centre given (the ball query's row table holds it)
+  __device__ static __forceinline__ void run_d(float dxv, float dyv, float dzv, const float *pq, int pqw, int qoff, bool has_q,
+                                               int i, int ci, const float *s_sh1, const float *s_sh2, const float *s_sh3,
+                                               const f32x4 *s_wa, const bf16x8 *s_w2, const bf16x8 *s_w3, int lane,
+                                               f32x16 (&y3)[NCB3], unsigned long long *tr = nullptr) {
+#ifdef PCR_SA_TRACE_BUILD   // (diagnostic builds: tr = the caller's record of this block, marks 6 / 7 = layer 1 / layer 2 done)
+#define PCR_BMARK(m) do { if (tr) tr[m] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PCR_BMARK(m) do { (void)tr; } while (0)
+#endif
     const int j = lane & 31, h = lane >> 5;
     auto cvec = [&](const float *base, int cb, int g) __attribute__((always_inline)) {
       return *reinterpret_cast<const f32x4 *>(base + 32 * cb + 8 * g + 4 * h);
     };
-    const float dxv = xyz[i * 3] - xyz[ci * 3], dyv = xyz[i * 3 + 1] - xyz[ci * 3 + 1], dzv = xyz[i * 3 + 2] - xyz[ci * 3 + 2];
     const float b0 = h ? dyv : dxv, b1 = h ? 0.f : dzv;      // layer 1's B operand: k = h, 2 + h
     bf16x8 bh[NS], bl[NS];
-    // ---- layer 1, one cout block at a time (the gathers of a block: 8 + 8 sixteen-byte pieces)
+    // the centre's Q row: the 16 lanes of a DPP row (one half h of one 16-row group: K is a multiple of 16) all want the
+    // same 4 NCB pieces, so each of them fetches ONE (lane p: cout block p / 4, piece p % 4) and the accumulator seeds take
+    // them by row broadcast -- one gather instruction per block instead of 4 NCB (the memory pipe, not the matrix pipe,
+    // paced the K-row kernels: trace, tools/trace_stream.py)
+    f32x4 qv = {0.f, 0.f, 0.f, 0.f};
+    if (has_q) {
+      const int p16 = lane & 15;
+      if (p16 < 4 * NCB)
+        qv = *reinterpret_cast<const f32x4 *>(pq + (size_t)ci * pqw + qoff + (p16 >> 2) * 32 + 8 * (p16 & 3) + 4 * h);
+    }
+    // ---- layer 1, one cout block at a time (the gathers of a block: 4 sixteen-byte pieces of the neighbour's row)
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++) {
-      f32x4 pp[4], qq[4];
+      f32x4 pp[4];
       const float *pr = pq ? pq + (size_t)i * pqw + cb * 32 + 4 * h : nullptr;
-      const float *qr = has_q ? pq + (size_t)ci * pqw + qoff + cb * 32 + 4 * h : nullptr;
 #pragma unroll
-      for (int g = 0; g < 4; g++) {
-        pp[g] = pr ? *reinterpret_cast<const f32x4 *>(pr + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-        qq[g] = qr ? *reinterpret_cast<const f32x4 *>(qr + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      for (int g = 0; g < 4; g++) pp[g] = pr ? *reinterpret_cast<const f32x4 *>(pr + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
       f32x16 acc;
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         const f32x4 s4 = cvec(s_sh1, cb, g);
 #pragma unroll
-        for (int q2 = 0; q2 < 4; q2++) acc[4 * g + q2] = has_q ? s4[q2] + qq[g][q2] : s4[q2];
+        for (int q2 = 0; q2 < 4; q2++) {
+          // row_newbcast: lane 4 cb + g of the row
+          const float qb = row_bcast_f32(qv[q2], 4 * cb + g);
+          acc[4 * g + q2] = has_q ? s4[q2] + qb : s4[q2];
+        }
       }
       const f32x4 av = s_wa[cb * 64 + j * 2 + h];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], b0, acc, 0, 0, 0);
@@ -491,6 +537,7 @@ struct SasBlock {
         bf_split8(v, bh[2 * cb + G], bl[2 * cb + G], LO);
       }
     }
+    PCR_BMARK(6);
     // ---- layer 2 (normal orientation: its accumulators convert into layer 3's operand)
     {
       f32x16 y[NCB];
@@ -530,6 +577,8 @@ struct SasBlock {
           bf_split8(v, bh[2 * cb + G], bl[2 * cb + G], LO);
         }
     }
+    PCR_BMARK(7);
+#undef PCR_BMARK
     // ---- layer 3 TRANSPOSED (activations as the A operand, the same weight image as B)
 #pragma unroll
     for (int cb = 0; cb < NCB3; cb++) {
@@ -606,26 +655,65 @@ void sa_stream_kernel(Sa2Args a, int nblk_item, int ncen_item) {
   const bool has_q = a.pq && a.qoff >= 0;
   // XCD-aware item order: workgroup w sits on XCD w % 8; the clouds b % 8 == x belong to XCD x
   const int xcd = blockIdx.x & 7, wrank = (blockIdx.x >> 3) * kSasWaves + wave, wstride = ((gridDim.x + 7 - xcd) >> 3) * kSasWaves;
-  const long nq = (long)((a.B + 7 - xcd) >> 3) * nitem;          // items of this XCD's clouds
-  for (long qi = wrank; qi < nq; qi += wstride) {
+  const int nq = ((a.B + 7 - xcd) >> 3) * nitem;                 // items of this XCD's clouds (the host keeps B x items < 2^31)
+  // the wave's item walk without a division per item: (cloud rank on the XCD, item) advance by fixed steps
+  const int step_b = wstride / nitem, step_i = wstride - step_b * nitem;
+  int bq = wrank / nitem, item = wrank - bq * nitem;
+  // a block's row indices {neighbour, centre point} are requested one block ahead (the next item's first block during
+  // the current item's last): nothing else stands between a wave and its table gathers
+  int i_pre = 0, ci_pre = 0;
+  auto fetch_rows = [&](int bq2, int it2, int blk2) __attribute__((always_inline)) {
+    const size_t b2 = (size_t)bq2 * 8 + xcd;
+    const int c02 = it2 * ncen_item;
+    const int nc2 = a.S - c02 < ncen_item ? a.S - c02 : ncen_item;
+    int r2 = blk2 * 32 + j;
+    r2 = r2 < nc2 * K ? r2 : nc2 * K - 1;               // padding rows repeat the last one (a max does not care)
+    const int s2 = c02 + r2 / K;
+    ci_pre = a.centre_idx ? a.centre_idx[b2 * a.S + s2] : s2;
+    i_pre = a.idx[(b2 * a.S + c02) * (size_t)K + r2];
+  };
+  if (wrank < nq) fetch_rows(bq, item, 0);
+#ifdef PCR_SA_TRACE_BUILD   // diagnostic builds only: waves 0 and 5 of a workgroup stamp the shader clock (one record per block)
+  const bool tracing = (a.dbg & 256) && lane == 0 && (wave == 0 || wave == 5) && blockIdx.x < kTraceWgs / 2;
+  unsigned long long *trace = g_rag_trace + (size_t)(2 * blockIdx.x + (wave ? 1 : 0)) * (2 + kTraceTiles * kTraceMarks);
+  int trace_it = 0;
+#define PCR_SMARK(m)                                                                                   \
+  do {                                                                                                 \
+    if (tracing && trace_it < kTraceTiles) trace[2 + trace_it * kTraceMarks + (m)] = __builtin_readcyclecounter(); \
+  } while (0)
+#define PCR_STR() ((tracing && trace_it < kTraceTiles) ? trace + 2 + trace_it * kTraceMarks : nullptr)
+#define PCR_SNEXT() trace_it++
+#else
+#define PCR_SMARK(m) do { } while (0)
+#define PCR_STR() nullptr
+#define PCR_SNEXT() do { } while (0)
+#endif
+  for (int qi = wrank; qi < nq; qi += wstride) {
     asm volatile("" ::: "memory");
-    const long bq = qi / nitem;
-    const int item = (int)(qi - bq * nitem);
+    PCR_SMARK(4);
     const size_t b = (size_t)bq * 8 + xcd;
     const int c0 = item * ncen_item;
     const int nc = a.S - c0 < ncen_item ? a.S - c0 : ncen_item;
     const int rows = nc * K;
     const float *xyz = a.xyz + b * a.N * 3;
     const float *pq = a.pq ? a.pq + b * a.N * (size_t)a.pqw : nullptr;
+    const int bq_cur = bq, item_cur = item;
+    item += step_i;                                     // the next item of this wave
+    bq += step_b;
+    if (item >= nitem) {
+      item -= nitem;
+      bq++;
+    }
     for (int blk = 0; blk < nblk_item; blk++) {
       if (blk * 32 >= rows) break;                      // (a partial last item: whole blocks of padding are skipped)
-      int r = blk * 32 + j;
-      r = r < rows ? r : rows - 1;                      // padding rows repeat the last one (a max does not care)
-      const int s = c0 + r / K;
-      const int ci = a.centre_idx ? a.centre_idx[b * a.S + s] : s;
-      const int i = a.idx[(b * a.S + c0) * (size_t)K + r];
+      PCR_SMARK(0);
+      const int i = i_pre, ci = ci_pre;
+      if (blk + 1 < nblk_item && (blk + 1) * 32 < rows) fetch_rows(bq_cur, item_cur, blk + 1);
+      else if (qi + wstride < nq) fetch_rows(bq, item, 0);
       f32x16 y[NCB3];
-      SasBlock<NCB, NCB3, LO>::run(xyz, pq, a.pqw, a.qoff, has_q, i, ci, s_sh, s_sh + C, s_sh + 2 * C, s_wa, s_w2, s_w3, lane, y);
+      SasBlock<NCB, NCB3, LO>::run(xyz, pq, a.pqw, a.qoff, has_q, i, ci, s_sh, s_sh + C, s_sh + 2 * C, s_wa, s_w2, s_w3, lane, y,
+                                   PCR_STR());
+      PCR_SMARK(1);
       // the maximum over a 16-row group = a maximum over eight of the lane's OWN registers plus one exchange with its
       // partner lane (20 instructions per cout block; the token-per-lane form needs a 4-step DPP reduction of every
       // register: 128)
@@ -644,6 +732,8 @@ void sa_stream_kernel(Sa2Args a, int nblk_item, int ncen_item) {
           gm[(blk * 2 + 1) * C3 + cb * 32 + j] = __int_as_float(imax(m1, 0));
         }
       }
+      PCR_SMARK(2);
+      PCR_SNEXT();
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -659,6 +749,9 @@ void sa_stream_kernel(Sa2Args a, int nblk_item, int ncen_item) {
     }
     __builtin_amdgcn_wave_barrier();
   }
+#undef PCR_SMARK
+#undef PCR_STR
+#undef PCR_SNEXT
 }
 
 #endif
@@ -689,6 +782,7 @@ struct RagArgs {
   const float *wa, *pq;
   const float *wap;         // packed (c1, 3) image of wa (layer 1 on the matrix core), or null
   const float *wap4;        // packed (c1, 4) image of [wa | shift of layer 1] (sa_wsplit_rag_kernel), or null
+  const float *rowtab;      // the ball query's row table (pcr_ball_query_rows_f32), or null: sa_stream_rag_kernel<.., true>
   int pqw;
   int dbg;                  // PCR_SA_DBG ablation mask (diagnostics only; 0 in production)
   int out_pm;               // out is (B,S,c3)
@@ -890,15 +984,26 @@ __global__ __launch_bounds__(256) void sa_rag_rows_kernel(RagArgs a) {
   }
 }
 
+
 #if PCR_SA_PREC != 0
 // Ragged form (ball-query groups with hit counts, mode 1): a centre contributes its first rag_ceil(max(cnt, 1)) rows
 // (the rest repeat row 0: a max does not care).  Item = kSasCpi consecutive centres of a cloud: the wave scans their row
 // counts, lays the rows out back to back (row -> (centre, k) map in a wave-private LDS strip) and runs them through the
 // same block routine, 32 at a time.  Rows of a centre come in pairs (counts are even), and with layer 3 transposed a
-// pair is two registers of one lane: their maximum goes to the centre's output row by an LDS integer atomic max
-// (order-independent, hence deterministic) -- no row tables, no tile plan, no descriptors.
-template <int NCB, int NCB3, bool LO>
-__global__ __launch_bounds__(64 * kSasWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// pair is two registers of one lane: their maximum goes to a wave-private LDS strip (one row per pair of the block), and
+// the lanes -- now one or two channels each -- walk the block's 16 pairs in row order with a running maximum that
+// leaves for the output whenever a centre closes (signed maxima of bit patterns from +0: order-independent, the ReLU
+// included) -- no tile plan, no descriptors.
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+// TAB (round 4): the rows' {neighbour, point - centre} come from the ball query's row table (one 16-byte load per row
+// at an address that depends on nothing but the item: it is requested a block ahead, the next item's first block and
+// counts during the current item) instead of the cnt -> row map -> idx -> xyz chain of dependent loads, which left the
+// matrix pipe idle ~1000 cycles per 32-row block (two waves per SIMD cannot hide it).  Same rows, same values, same bits.
+// WAVES: 8, or 12 where the per-wave strips leave room (the table form of every shape at K <= 32): three waves per SIMD.
+// A block is ~2.6 k cycles of MFMAs and about as many of everything else (splits, LDS traffic, the reduction over pairs,
+// the item prologue); two waves per SIMD left the matrix pipe idle half of the time (trace: tools/trace_stream.py).
+template <int NCB, int NCB3, bool LO, bool TAB = false, int WAVES = kSasWaves>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES / 4, WAVES / 4)))
 void sa_stream_rag_kernel(RagArgs a) {
   using L = SasLds<NCB, NCB3>;
   constexpr int C = L::C, C3 = L::C3, CPI = kSasCpi;
@@ -910,38 +1015,83 @@ void sa_stream_rag_kernel(RagArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int K = a.K, maxrows = CPI * K;
-  int *s_w = reinterpret_cast<int *>(smem) + L::kFixed / 4 + wave * (CPI * C3 + maxrows);
-  int *obuf = s_w;                 // [CPI][C3] running maxima (bit patterns, >= 0)
-  int *rmap = s_w + CPI * C3;      // [maxrows] row -> centre | k << 8
-  sas_stage<NCB, NCB3>(smem, a.wp2, a.wp3, a.sh1, a.sh2, a.sh3, a.wap, 64 * kSasWaves);
-  for (int e = lane; e < CPI * C3; e += 64) obuf[e] = 0;
+  int *s_w = reinterpret_cast<int *>(smem) + L::kFixed / 4 + wave * sas_rag_wave_ints(C3, K, TAB);
+  int *pbuf = s_w;                 // [16 pairs][C3] maxima of the current block's row pairs (bit patterns)
+  int *rmap = s_w + CPI * C3;      // [maxrows] row -> centre | k << 8 (indexed form)
+  unsigned char *eflag = reinterpret_cast<unsigned char *>(rmap + (TAB ? 0 : maxrows));   // [maxrows / 2] pair closes a centre
+  constexpr int CPL = C3 >= 128 ? C3 / 64 : 1;   // channels of the lane in the reduction over pairs
+  static_assert(CPL <= 2, "wider layers do not fit this kernel's LDS anyway");
+  const bool lane_on = lane * CPL < C3;
+  sas_stage<NCB, NCB3>(smem, a.wp2, a.wp3, a.sh1, a.sh2, a.sh3, a.wap, 64 * WAVES);
+  for (int e = lane; e < (maxrows / 2 + 3) / 4; e += 64) reinterpret_cast<int *>(eflag)[e] = 0;
   const int nitem = (a.S + CPI - 1) / CPI;
-  const int xcd = blockIdx.x & 7, wrank = (blockIdx.x >> 3) * kSasWaves + wave, wstride = ((gridDim.x + 7 - xcd) >> 3) * kSasWaves;
-  const long nq = (long)((a.B + 7 - xcd) >> 3) * nitem;
-  for (long qi = wrank; qi < nq; qi += wstride) {
+  const int xcd = blockIdx.x & 7, wrank = (blockIdx.x >> 3) * WAVES + wave, wstride = ((gridDim.x + 7 - xcd) >> 3) * WAVES;
+  const int nq = ((a.B + 7 - xcd) >> 3) * nitem;       // (the host keeps B x items below 2^31)
+  // the wave's item walk without a division per item: (cloud rank on the XCD, item) advance by fixed steps
+  const int step_b = wstride / nitem, step_i = wstride - step_b * nitem;
+  int bq = wrank / nitem, item = wrank - bq * nitem;
+  // (TAB) what the next item needs first, requested an item ahead: its centres' counts and its first block of rows
+  const f32x4 *const tab = reinterpret_cast<const f32x4 *>(a.rowtab);
+  int cn_pre = 0;
+  f32x4 e_pre = {0.f, 0.f, 0.f, 0.f};
+  auto prefetch_item = [&](bool live, int bq2, int it2) __attribute__((always_inline)) {
+    if (live) {
+      const size_t b2 = (size_t)bq2 * 8 + xcd;
+      const int lc = lane < CPI ? lane : CPI - 1;
+      cn_pre = it2 * CPI + lc < a.S ? a.cnt[b2 * a.S + it2 * CPI + lc] : 0;
+      e_pre = tab[(b2 * nitem + it2) * (size_t)maxrows + j];
+    }
+  };
+  if constexpr (TAB) prefetch_item(wrank < nq, bq, item);
+#ifdef PCR_SA_TRACE_BUILD   // diagnostic builds only: waves 0 and 5 of a workgroup stamp the shader clock (one record per block)
+  const bool tracing = (a.dbg & 256) && lane == 0 && (wave == 0 || wave == 5) && blockIdx.x < kTraceWgs / 2;
+  unsigned long long *trace = g_rag_trace + (size_t)(2 * blockIdx.x + (wave ? 1 : 0)) * (2 + kTraceTiles * kTraceMarks);
+  int trace_it = 0;
+#define PCR_SMARK(m)                                                                                   \
+  do {                                                                                                 \
+    if (tracing && trace_it < kTraceTiles) trace[2 + trace_it * kTraceMarks + (m)] = __builtin_readcyclecounter(); \
+  } while (0)
+#define PCR_STR() ((tracing && trace_it < kTraceTiles) ? trace + 2 + trace_it * kTraceMarks : nullptr)
+#define PCR_SNEXT() trace_it++
+#else
+#define PCR_SMARK(m) do { } while (0)
+#define PCR_STR() nullptr
+#define PCR_SNEXT() do { } while (0)
+#endif
+  for (int qi = wrank; qi < nq; qi += wstride) {
     asm volatile("" ::: "memory");
-    const long bq = qi / nitem;
-    const int item = (int)(qi - bq * nitem);
+    PCR_SMARK(4);
     const size_t b = (size_t)bq * 8 + xcd;
     const int c0 = item * CPI;
     const int nc = a.S - c0 < CPI ? a.S - c0 : CPI;
     const float *xyz = a.xyz + b * a.N * 3;
     const float *pq = a.pq ? a.pq + b * a.N * (size_t)a.pqw : nullptr;
+    const f32x4 *rt = TAB ? tab + (b * nitem + item) * (size_t)maxrows : nullptr;
+    float *const obase = a.out_pm ? a.out + (b * a.S + c0) * (size_t)C3 : a.out + b * C3 * (size_t)a.S + c0;
+    f32x4 e_nb = e_pre;
     // rows per centre (lanes 0 .. CPI-1), their prefix sums, the row map
     int n = 0;
     if (lane < nc) {
-      const int cn = a.cnt[b * a.S + c0 + lane];
+      const int cn = TAB ? cn_pre : a.cnt[b * a.S + c0 + lane];
       n = rag_ceil(cn > 1 ? cn : 1);
       n = n < K ? n : K;
     }
-    int incl = n;
-#pragma unroll
-    for (int d2 = 1; d2 < CPI; d2 <<= 1) {
-      const int o = __shfl_up(incl, d2, 64);
-      if (lane >= d2) incl += o;
+    // the next item of this wave
+    item += step_i;
+    bq += step_b;
+    if (item >= nitem) {
+      item -= nitem;
+      bq++;
     }
+    if constexpr (TAB) prefetch_item(qi + wstride < nq, bq, item);
+    int incl = n;   // inclusive prefix over the 16-lane row (DPP row shifts: lanes >= 16 hold zeros and are not read)
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);   // row_shr:1
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);   // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);   // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);   // row_shr:8
     const int R = __builtin_amdgcn_readlane(incl, CPI - 1);
-    {
+    if (lane < nc) eflag[(incl >> 1) - 1] = 1;          // the centre's last pair
+    if constexpr (!TAB) {
       const int start = incl - n;
       for (int k = 0; k < n; k++) rmap[start + k] = lane | (k << 8);
     }
@@ -949,49 +1099,101 @@ void sa_stream_rag_kernel(RagArgs a) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int nb = (R + 31) >> 5;
+    int cur[CPL], cc = 0;            // the open centre's running maxima, the number of centres closed so far
+#pragma unroll
+    for (int e = 0; e < CPL; e++) cur[e] = 0;
+    PCR_SMARK(5);
     for (int blk = 0; blk < nb; blk++) {
-      int r = blk * 32 + j;
-      r = r < R ? r : R - 1;
-      const int mp = rmap[r];
-      const int c = mp & 0xFF, k = mp >> 8;
-      const int s = c0 + c;
-      const int ci = a.centre_idx ? a.centre_idx[b * a.S + s] : s;
-      const int i = a.idx[(b * a.S + s) * (size_t)K + k];
       f32x16 y[NCB3];
-      SasBlock<NCB, NCB3, LO>::run(xyz, pq, a.pqw, -1, false, i, ci, s_sh, s_sh + C, s_sh + 2 * C, s_wa, s_w2, s_w3, lane, y);
-      // pairs of rows (tokens 8 g + 4 h + 2 p, + 1) belong to one centre: their maximum joins the centre's output row
+      PCR_SMARK(0);
+      // which of the block's pairs close a centre (lane p < 16 looks at pair p and takes the flag down again)
+      const int np = (R >> 1) - blk * 16 < 16 ? (R >> 1) - blk * 16 : 16;
+      bool is_end = false;
+      if (lane < np) {
+        is_end = eflag[blk * 16 + lane] != 0;
+        if (is_end) eflag[blk * 16 + lane] = 0;
+      }
+      if constexpr (TAB) {
+        const f32x4 e = e_nb;
+        if (blk + 1 < nb) e_nb = rt[(blk + 1) * 32 + j];   // (whole blocks are written: rows past R are zero entries)
+        SasBlock<NCB, NCB3, LO>::run_d(e[1], e[2], e[3], pq, a.pqw, -1, false, __float_as_int(e[0]), 0, s_sh, s_sh + C,
+                                       s_sh + 2 * C, s_wa, s_w2, s_w3, lane, y, PCR_STR());
+      } else {
+        int r = blk * 32 + j;
+        r = r < R ? r : R - 1;
+        const int mp = rmap[r];
+        const int c = mp & 0xFF, k = mp >> 8;
+        const int s = c0 + c;
+        const int ci = a.centre_idx ? a.centre_idx[b * a.S + s] : s;
+        const int i = a.idx[(b * a.S + s) * (size_t)K + k];
+        SasBlock<NCB, NCB3, LO>::run(xyz, pq, a.pqw, -1, false, i, ci, s_sh, s_sh + C, s_sh + 2 * C, s_wa, s_w2, s_w3, lane, y);
+      }
+      PCR_SMARK(1);
+      // pairs of rows (tokens 8 g + 4 h + 2 p, + 1) belong to one centre: pair 4 g + 2 h + p of the block puts its maximum
+      // into row `pair` of pbuf with plain stores (the first version sent it to the centre's row with LDS integer atomics:
+      // 32 per lane and block, each far slower than a store on an LDS unit that eight waves share)
 #pragma unroll
       for (int g = 0; g < 4; g++)
 #pragma unroll
         for (int pr = 0; pr < 2; pr++) {
-          const int t0 = blk * 32 + 8 * g + 4 * h + 2 * pr;
-          if (t0 < R) {
-            int *orow = obuf + (rmap[t0] & 0xFF) * C3 + j;
+          int *prow = pbuf + (4 * g + 2 * h + pr) * C3 + j;
 #pragma unroll
-            for (int cb = 0; cb < NCB3; cb++) {
-              const int v = imax(__float_as_int(y[cb][4 * g + 2 * pr]), __float_as_int(y[cb][4 * g + 2 * pr + 1]));
-              __hip_atomic_fetch_max(orow + cb * 32, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          for (int cb = 0; cb < NCB3; cb++)
+            prow[cb * 32] = imax(__float_as_int(y[cb][4 * g + 2 * pr]), __float_as_int(y[cb][4 * g + 2 * pr + 1]));
+        }
+      const unsigned ends = (unsigned)__ballot(is_end);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      PCR_SMARK(2);
+      // the lane's channels over the block's pairs in row order: a running maximum (from +0: the ReLU, signed maxima of
+      // the bit patterns) that leaves for the output whenever a centre closes and carries over to the next block otherwise
+      int v[16][CPL];
+#pragma unroll
+      for (int p2 = 0; p2 < 16; p2++) {
+        const int *src = pbuf + p2 * C3 + (lane_on ? lane * CPL : 0);
+        if constexpr (CPL == 2) {
+          const i32x2 t = *reinterpret_cast<const i32x2 *>(src);
+          v[p2][0] = t[0];
+          v[p2][1] = t[1];
+        } else {
+          v[p2][0] = src[0];
+        }
+      }
+#pragma unroll
+      for (int p2 = 0; p2 < 16; p2++) {
+        if (p2 < np) {
+#pragma unroll
+          for (int e = 0; e < CPL; e++) cur[e] = imax(cur[e], v[p2][e]);
+          if ((ends >> p2) & 1u) {
+            if (lane_on) {
+              if (a.out_pm) {
+                float *dst = obase + cc * C3 + lane * CPL;
+                if constexpr (CPL == 2) *reinterpret_cast<f32x2 *>(dst) = f32x2{__int_as_float(cur[0]), __int_as_float(cur[1])};
+                else dst[0] = __int_as_float(cur[0]);
+              } else {
+#pragma unroll
+                for (int e = 0; e < CPL; e++) obase[(lane * CPL + e) * (size_t)a.S + cc] = __int_as_float(cur[e]);
+              }
             }
+#pragma unroll
+            for (int e = 0; e < CPL; e++) cur[e] = 0;
+            cc++;
           }
         }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();   // (the next block's pair maxima overwrite pbuf)
+      PCR_SMARK(3);
+      PCR_SNEXT();
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int e = lane; e < nc * C3; e += 64) {
-      const int c = e / C3, o = e - c * C3;
-      const float m = __int_as_float(obuf[e]);   // (started at 0: the ReLU)
-      obuf[e] = 0;
-      if (a.out_pm) a.out[(b * a.S + c0 + c) * (size_t)C3 + o] = m;
-      else a.out[(b * C3 + o) * (size_t)a.S + c0 + c] = m;
-    }
-    __builtin_amdgcn_wave_barrier();
   }
+#undef PCR_SMARK
+#undef PCR_STR
+#undef PCR_SNEXT
 }
 #endif
 
-constexpr int kTraceWgs = 1024, kTraceTiles = 24, kTraceMarks = 8;
-__device__ unsigned long long g_rag_trace[kTraceWgs * (2 + kTraceTiles * kTraceMarks)];
 
 #if PCR_SA_PREC != 0
 // ---- cout-split ragged kernel (round 4): the layers whose weight images do not fit LDS beside anything else (SSG SA2:
@@ -1799,8 +2001,9 @@ static bool sas_shape_ok(const pcr_sa_params &p, bool ragged) {
       !(p.c1 == 32 || p.c1 == 64 || p.c1 == 128) || !sas_k_ok(p.K))
     return false;
   const size_t lds_k = sas_fixed_lds(p) + (size_t)kSasWaves * 6 * p.c3 * 4;
-  const size_t lds_r = sas_fixed_lds(p) + (size_t)kSasWaves * (kSasCpi * p.c3 + kSasCpi * p.K) * 4;
+  const size_t lds_r = sas_fixed_lds(p) + (size_t)kSasWaves * sas_rag_wave_ints(p.c3, p.K, false) * 4;
   const size_t cap = (size_t)160 * 1024;
+  if ((long)p.B * p.S >= 0x7FFFFFFFl) return false;    // (the kernels count items in 32 bits)
   if (ragged || p.mode == 1) return lds_k <= cap && lds_r <= cap;
   return lds_k <= cap;
 }
@@ -1817,10 +2020,12 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
     const int rc = p.precision == 1 ? pcr_sa2_try_bf3(&p, st_) : pcr_sa2_try_bf1(&p, st_);
     if (rc >= 0) return rc;
   }
+  if (!p.idx) return -1;
   const float *const wl2 = p.wps[0], *const wl3 = p.wps[1];
 #else
   if (!p.wps_bf[0] || !p.wps_bf[1] || (p.c1 & 31) || (p.c2 & 31)) return -1;
   const float *const wl2 = p.wps_bf[0], *const wl3 = p.wps_bf[1];
+  if (!p.idx && !(p.row_tab && p.cnt && p.tile_ws && p.mode == 1 && sas_shape_ok(p, true))) return -1;
 #endif
   pcr_note_arith(kPrec);   // (every launch below runs layers 2 / 3 in this unit's arithmetic)
   if ((p.c1 & 7) || p.c1 > 512 || p.c2 > 512 || p.c3 > 512) return -1;
@@ -1853,9 +2058,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
       const int ncb = p.c1 >> 5, ncb3 = p.c3 >> 5;
       const size_t fixed = ((size_t)(2 * ncb) * ncb * 128 + (size_t)(2 * ncb) * ncb3 * 128) * 16 + (size_t)(2 * p.c1 + p.c3) * 4 +
                            (size_t)ncb * 64 * 16;
-      const size_t lds_r = fixed + (size_t)kSasWaves * (kSasCpi * p.c3 + kSasCpi * p.K) * 4;
-      const size_t lds_k = fixed + (size_t)kSasWaves * 6 * p.c3 * 4;     // (the K-row form's condition, see below)
-      (void)no_stream; (void)lds_k;
+      (void)no_stream;
       if (sas_shape_ok(p, true)) {
         if (p.D && !p.pq_ready) {
           const int rc = pcr_dense_pm_f32(p.feat, p.wpq, p.pq_ws, p.B, p.D, p.c1, p.N, p.feat_point_major, st_);
@@ -1866,8 +2069,11 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
         r.xyz = p.xyz; r.idx = p.idx; r.cnt = p.cnt; r.centre_idx = p.centre_idx; r.ws = p.tile_ws;
         r.wa = p.wa; r.pq = p.D ? p.pq_ws : nullptr; r.pqw = p.c1;
         r.wap = p.wa_packed;
+        r.rowtab = p.row_tab;
+        if (!p.row_tab && (!p.idx || !p.cnt)) return PCR_ERR_INVALID;
         r.wp2 = wl2; r.wp3 = wl3; r.sh1 = p.shift[0]; r.sh2 = p.shift_pad[0]; r.sh3 = p.shift_pad[1];
-        r.dbg = 0; r.out = p.out; r.out_pm = p.out_point_major;
+        static const char *strace = pcr_tune_str("PCR_SA_TRACE");
+        r.dbg = strace ? 256 : 0; r.out = p.out; r.out_pm = p.out_point_major;
         static const int ncu = [] {
           int dev = 0, n = 0;
           if (hipGetDevice(&dev) != hipSuccess ||
@@ -1876,27 +2082,39 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
           return n;
         }();
         const long items = (long)p.B * ((p.S + kSasCpi - 1) / kSasCpi);
-        long wgs = (items + kSasWaves - 1) / kSasWaves;
+        const size_t cap = (size_t)160 * 1024;
+        const size_t lds_r8 = fixed + (size_t)8 * sas_rag_wave_ints(p.c3, p.K, r.rowtab != nullptr) * 4;
+        const size_t lds_r12 = fixed + (size_t)12 * sas_rag_wave_ints(p.c3, p.K, true) * 4;
+        static const int no12 = pcr_tune_int("PCR_SA_NO_W12");   // diagnostics
+        const bool w12 = r.rowtab && lds_r12 <= cap && !no12;    // three waves per SIMD (see the kernel)
+        const int nw = w12 ? 12 : 8;
+        long wgs = (items + nw - 1) / nw;
         if (wgs > ncu) wgs = ncu;
         wgs = (wgs + 7) / 8 * 8;
-        const dim3 gg((unsigned)wgs), bb(64 * kSasWaves);
+        const dim3 gg((unsigned)wgs), bb(64 * nw);
         constexpr bool kLoS = kPrec == 1;
 #define PCR_SASR(NCBv, NCB3v)                                                                 \
   do {                                                                                        \
     static bool ok = allow_big_lds(sa_stream_rag_kernel<NCBv, NCB3v, kLoS>);                  \
-    (void)ok;                                                                                 \
-    hipLaunchKernelGGL((sa_stream_rag_kernel<NCBv, NCB3v, kLoS>), gg, bb, lds_r, st, r);      \
+    static bool okt = allow_big_lds(sa_stream_rag_kernel<NCBv, NCB3v, kLoS, true>);           \
+    static bool okw = allow_big_lds(sa_stream_rag_kernel<NCBv, NCB3v, kLoS, true, 12>);       \
+    (void)ok; (void)okt; (void)okw;                                                           \
+    if (w12) hipLaunchKernelGGL((sa_stream_rag_kernel<NCBv, NCB3v, kLoS, true, 12>), gg, bb, lds_r12, st, r); \
+    else if (r.rowtab) hipLaunchKernelGGL((sa_stream_rag_kernel<NCBv, NCB3v, kLoS, true>), gg, bb, lds_r8, st, r); \
+    else hipLaunchKernelGGL((sa_stream_rag_kernel<NCBv, NCB3v, kLoS>), gg, bb, lds_r8, st, r); \
   } while (0)
         if (ncb == 1 && ncb3 == 1) PCR_SASR(1, 1);
         else if (ncb == 1) PCR_SASR(1, 2);
         else if (ncb3 == 2) PCR_SASR(2, 2);
         else PCR_SASR(2, 4);
 #undef PCR_SASR
+        if (strace) rag_dump_trace(strace, "stream", (int)(2 * wgs));
         if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
         return PCR_OK;
       }
     }
 #endif
+    if (!p.idx) return -1;
     if (p.K <= ROWS) {
       const int per_tile = ROWS / rag_ceil(p.K);               // whole centres a tile holds in the worst case
       RagArgs r;
@@ -2108,6 +2326,8 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
       wgs = (wgs + 7) / 8 * 8;                         // every XCD gets workgroups (the item order is per XCD)
       const dim3 gg((unsigned)wgs), bb(64 * kSasWaves);
       constexpr bool kLoS = kPrec == 1;
+      static const char *ktrace = pcr_tune_str("PCR_SA_TRACE");
+      if (ktrace) a.dbg |= 256;
 #define PCR_SAS(NCBv, NCB3v)                                                                  \
   do {                                                                                        \
     static bool ok = allow_big_lds(sa_stream_kernel<NCBv, NCB3v, kLoS>);                      \
@@ -2120,6 +2340,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
       else if (ncb == 2) PCR_SAS(2, 4);
       else PCR_SAS(4, 4);
 #undef PCR_SAS
+      if (ktrace) rag_dump_trace(ktrace, "krow", (int)(2 * wgs));
       if (hipGetLastError() != hipSuccess) return PCR_ERR_LAUNCH;
       return PCR_OK;
     }
@@ -2150,6 +2371,25 @@ int pcr_sa2_try_bf1(const pcr_sa_params *p, pcr_stream_t st) { return sa2_try(*p
 
 // 1: launches of this shape WITHOUT hit counts (all K rows of every group) also run on the tile plan and want the
 // workspace of pcr_sa_tile_ws_ints -- the cout-split kernel's shape, sa2_try's `wsplit_shape` (bf16 modes)
+// does a ball-query layer with hit counts of this shape read the ball query's row table (pcr_ball_query_rows_f32)?
+// = the wave-autonomous ragged form runs it (sas_shape_ok, shape only)
+PCR_EXPORT int pcr_sa_uses_row_table(int c1, int c2, int c3, int K, int precision) {
+  if (precision == 0 || c1 != c2 || !(c3 == c2 || c3 == 2 * c2) || !(c1 == 32 || c1 == 64 || c1 == 128)) return 0;
+  bool kok = false;
+  for (int nb = 1; nb <= 3; nb++)
+    if ((32 * nb) % K == 0) { kok = (K & 15) == 0; break; }
+  if (!kok) return 0;
+  const int ncb = c1 >> 5, ncb3 = c3 >> 5;
+  {   // (sa2_try asks for a tile-kernel instantiation of the shape before it looks at the wave-autonomous form)
+    const int v2 = ncb >= 3 ? 1 : (ncb == 2 ? 2 : 4), v3 = ncb3 >= 3 ? 1 : (ncb3 == 2 ? 2 : 4);
+    if (!((v2 == 1 && v3 == 1) || (v2 == 2 && v3 == 1) || (v2 == 2 && v3 == 2) || (v2 == 4 && v3 == 4))) return 0;
+  }
+  const size_t fixed = ((size_t)(2 * ncb) * ncb * 128 + (size_t)(2 * ncb) * ncb3 * 128) * 16 + (size_t)(2 * c1 + c3) * 4 +
+                       (size_t)ncb * 64 * 16;
+  const size_t cap = (size_t)160 * 1024;
+  return fixed + (size_t)8 * 6 * c3 * 4 <= cap && fixed + (size_t)8 * sas_rag_wave_ints(c3, K, false) * 4 <= cap;
+}
+
 PCR_EXPORT int pcr_sa_krow_uses_tiles(int c1, int c2, int c3, int K, int precision) {
   return precision != 0 && c1 == 128 && c2 == 128 && c3 == 256 && K >= 1 && K <= 64;
 }
@@ -2212,7 +2452,7 @@ PCR_EXPORT int pcr_sa_mlp_f32(const pcr_sa_params *pp, pcr_stream_t stream) {
   if (!pp) return PCR_ERR_INVALID;
   const pcr_sa_params &p = *pp;
   if (p.B < 0 || p.N < 1 || p.S < 0 || p.K < 1 || p.D < 0 || p.c1 < 1 || p.c2 < 1 || p.c3 < 1 ||
-      !p.xyz || !p.idx || !p.out || (p.D && !p.feat) || (p.mode != 0 && p.mode != 1))
+      !p.xyz || (!p.idx && !(p.row_tab && p.cnt)) || !p.out || (p.D && !p.feat) || (p.mode != 0 && p.mode != 1))
     return PCR_ERR_INVALID;
   for (int l = 0; l < 3; l++)
     if (!p.wp[l] || !p.scale[l] || !p.shift[l]) return PCR_ERR_INVALID;
@@ -2220,6 +2460,7 @@ PCR_EXPORT int pcr_sa_mlp_f32(const pcr_sa_params *pp, pcr_stream_t stream) {
   if (p.B > 65535) return PCR_ERR_INVALID;
   const int fast = sa2_try(p, stream);
   if (fast >= 0) return fast;
+  if (!p.idx) return PCR_ERR_INVALID;   // (a row table without an index tensor: only the kernel that reads the table will do)
   pcr_note_arith(PCR_PREC_F32);
   SaArgs a;
   a.p = p;

@@ -129,6 +129,27 @@ class BallQueryCnt(Function):
         return None, None, None, None, None
 
 
+def ball_query_rows(max_radius, sample_num, xyz, center_xyz, want_idx=False):
+    """ball query (min_radius 0) -> (idx or None, cnt, rows): hit counts and the compact row table that the
+    wave-autonomous ragged SA kernel reads (include/pcr.h pcr_ball_query_rows_f32); idx only on request"""
+    assert center_xyz.is_contiguous() and xyz.is_contiguous()
+    B, N, _ = xyz.size()
+    npoint = center_xyz.size(1)
+    with torch.cuda.device(xyz.device):
+        L.require_cuda(xyz, center_xyz)
+        L.require_f32(xyz, center_xyz)
+        idx = _i32(B, npoint, sample_num, device=xyz.device) if want_idx else None
+        cnt = _i32(B, npoint, device=xyz.device)
+        rows = torch.empty((L.load().pcr_ball_query_rows_floats(B, npoint, sample_num),), dtype=torch.float32,
+                           device=xyz.device)
+        with _prof("ball_query[N=%d,M=%d,K=%d]" % (N, npoint, sample_num), 8.0 * B * N * npoint,
+                   4.0 * B * (3 * N + 3 * npoint + npoint * sample_num)):
+            L.check(L.load().pcr_ball_query_rows_f32(L.ptr(center_xyz), L.ptr(xyz), L.ptr(idx), L.ptr(cnt), L.ptr(rows),
+                                                     B, N, npoint, ctypes.c_float(0.0), ctypes.c_float(max_radius),
+                                                     sample_num, L.stream_ptr()), "pcr_ball_query_rows_f32")
+    return idx, cnt, rows
+
+
 class KNN(Function):
     @_on_device
     def forward(ctx, k, xyz, center_xyz=None, transposed=False):

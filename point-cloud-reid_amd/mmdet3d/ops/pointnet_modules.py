@@ -15,13 +15,15 @@ Eval-mode forward of a 3-layer SA scale is ONE fused launch (pcr_sa_mlp_f32, mod
 ball query; nothing of shape (B,C,S,K) is materialised.  `QueryAndGroup` / `grouping_operation`
 remain available as stand-alone ops for callers that want the grouped tensor.
 """
+import os
+
 import torch
 from torch import nn as nn
 
 from pcr_amd import engine
 from pcr_amd import _lib as L
 from ..models.builder import Registry
-from .point_ops import (ball_query, ball_query_cnt, furthest_point_sample, furthest_point_sample_with_dist, gather_points,
+from .point_ops import (ball_query, ball_query_cnt, ball_query_rows, furthest_point_sample, furthest_point_sample_with_dist, gather_points,
                         grouping_operation, knn, three_interpolate, three_nn)
 
 SA_MODULES = Registry("point_sa_module")
@@ -245,14 +247,23 @@ class BasePointSAModule(nn.Module):
         for i, grouper in enumerate(self.groupers):
             if not isinstance(grouper, QueryAndGroup):
                 raise L.PcrError("GroupAll scales are not on the ReID path")
+            plan = self._plan(i, points_xyz.device)
+            if (self.skip_repeats and not _NO_ROW_TABLE and grouper.max_radius is not None and not grouper.min_radius and
+                    plan.wants_row_table(points_xyz.shape[1], grouper.sample_num, 0.0)):
+                # the ball query hands the SA kernel its rows ready-made ({neighbour, point - centre}); no index tensor
+                _, cnt, rows = ball_query_rows(grouper.max_radius, grouper.sample_num, points_xyz, new_xyz)
+                outs.append(plan.run(points_xyz, features, None, centre_idx=indices.contiguous(), cnt=cnt, rows=rows,
+                                     K=grouper.sample_num, out_point_major=len(self.groupers) == 1))
+                continue
             idx, cnt = grouper.query_cnt(points_xyz, new_xyz)
             # single-scale modules hand out the (B,C,S) view of a point-major buffer (a centre's channels are
             # stored as one run); SaPlan / engine.dense read either layout, anyone else may call .contiguous()
-            outs.append(self._plan(i, points_xyz.device).run(points_xyz, features, idx,
-                                                             centre_idx=indices.contiguous(),
-                                                             cnt=cnt if self.skip_repeats else None,
-                                                             out_point_major=len(self.groupers) == 1))
+            outs.append(plan.run(points_xyz, features, idx, centre_idx=indices.contiguous(),
+                                 cnt=cnt if self.skip_repeats else None, out_point_major=len(self.groupers) == 1))
         return new_xyz, torch.cat(outs, dim=1) if len(outs) > 1 else outs[0], indices
+
+
+_NO_ROW_TABLE = bool(os.environ.get("PCR_NO_ROW_TABLE"))   # diagnostics: the indexed ragged launch instead
 
 
 @SA_MODULES.register_module()

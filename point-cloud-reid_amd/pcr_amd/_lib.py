@@ -11,7 +11,7 @@ _TAG = os.environ.get("PCR_LIB_TAG", "")
 SO_PATH = os.path.join(_HERE, "lib", "libpcr_hip%s.so" % ("_" + _TAG if _TAG else ""))
 _lib = None
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class PcrError(RuntimeError):
@@ -31,6 +31,7 @@ def load():
         lib.pcr_packed_weight_bf16_floats.restype = ctypes.c_long
         lib.pcr_attn_kv_floats.restype = ctypes.c_long
         lib.pcr_sa_tile_ws_ints.restype = ctypes.c_long
+        lib.pcr_ball_query_rows_floats.restype = ctypes.c_long
         if lib.pcr_abi_version() != ABI_VERSION:
             raise PcrError("libpcr_hip.so ABI %d != binding %d: rebuild" % (lib.pcr_abi_version(), ABI_VERSION))
         if os.environ.get("PCR_STREAM_MIN_BLOCKS"):      # launch policy of the train-dense kernels (include/pcr.h)

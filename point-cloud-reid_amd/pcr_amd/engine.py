@@ -99,7 +99,8 @@ class SaParams(ctypes.Structure):
                 ("pq_ws", c_float_p), ("pq_ready", ctypes.c_int),
                 ("feat_point_major", ctypes.c_int), ("out_point_major", ctypes.c_int),
                 ("out", c_float_p), ("wa_packed", c_float_p),
-                ("precision", ctypes.c_int), ("wps_bf", c_float_p * 2), ("wa_shift_packed", c_float_p)]
+                ("precision", ctypes.c_int), ("wps_bf", c_float_p * 2), ("wa_shift_packed", c_float_p),
+                ("row_tab", c_float_p)]
 
 
 class AttnParams(ctypes.Structure):
@@ -241,20 +242,33 @@ class SaPlan:
             self.wpq = pack_weight(stacked.float(), device)
             self.wpq_bf = pack_weight_bf(stacked.float(), device)
 
-    def run(self, xyz, feat, idx, centre_idx=None, cnt=None, out_point_major=False):
-        """cnt (B,S) int32: genuine-hit counts of a ball query (ops.ball_query_cnt); when given (mode 1) the
+    def wants_row_table(self, N, K, min_radius):
+        """does the ragged launch of this layer read the ball query's row table (ops.ball_query_rows)?"""
+        lib = L.load()
+        return bool(self.fast and self.mode == 1 and lib.pcr_ball_query_rows_ok(N, K, ctypes.c_float(min_radius or 0.0)) and
+                    lib.pcr_sa_uses_row_table(self.couts[0], self.couts[1], self.couts[2], K, PRECISIONS[PRECISION]))
+
+    def run(self, xyz, feat, idx, centre_idx=None, cnt=None, out_point_major=False, rows=None, K=None):
+        """rows: the ball query's row table (ops.ball_query_rows, with cnt; idx may then be None and K is given).
+        cnt (B,S) int32: genuine-hit counts of a ball query (ops.ball_query_cnt); when given (mode 1) the
         MLP runs only on the distinct rows of every group -- same result, K/cnt times less work.
         feat (B,D,N) may be contiguous or the transposed view of a contiguous (B,N,D) tensor (point-major);
         out_point_major: the result is the (B,c3,S) VIEW of a contiguous (B,S,c3) tensor (a centre's channels
         are written as one run; our own consumers read that layout directly)."""
-        L.require_cuda(xyz, idx)
         B, N, _ = xyz.shape
-        _, S, K = idx.shape
+        if rows is not None:
+            assert cnt is not None and self.wants_row_table(N, K, 0.0), "row table given to a layer that does not read it"
+            L.require_cuda(xyz, cnt, rows)
+            S = cnt.shape[1]
+            assert rows.is_contiguous() and rows.numel() == L.load().pcr_ball_query_rows_floats(B, S, K)
+        else:
+            L.require_cuda(xyz, idx)
+            _, S, K = idx.shape
         D = 0 if feat is None else feat.shape[1]
         want = 3 + (2 * D if self.mode == 0 else D)
         assert want == self.cin, "feature width %d does not match the first conv (%d)" % (want, self.cin)
         feat, feat_pm = as_cm_or_pm(feat)
-        assert xyz.is_contiguous() and idx.is_contiguous()
+        assert xyz.is_contiguous() and (idx is None or idx.is_contiguous())
         out = torch.empty((B, S, self.couts[2]) if out_point_major else (B, self.couts[2], S),
                           dtype=torch.float32, device=xyz.device)
         p = SaParams()
@@ -279,6 +293,7 @@ class SaPlan:
                 p.tile_ws = _p(tile_ws)
             if ragged:
                 p.cnt = _p(cnt)
+                p.row_tab = _p(rows)
         if self.fast:
             p.wa = _p(self.wa)
             p.wa_packed = _p(self.wa_packed)
