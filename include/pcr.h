@@ -366,6 +366,12 @@ int pcr_dense_prec_f32(const float *x, const float *wp_bf, const float *scale, c
 int pcr_dense_gn_prec_f32(const float *x, const float *wp_bf, const float *gamma, const float *beta, const float *res,
                           float *y, int B, int cin, int cout, int L, int groups, int relu, int precision,
                           pcr_stream_t stream);
+/* pcr_dense_prec_f32 for a POINT-major input x (B,L,cin) (ABI 12; pcr_dense_xpm_f32's shapes on the bf16 matrix core):
+ * cin a multiple of 64, cout <= 128, the weight image within LDS (pcr_dense_xpm_prec_ok).  Reference: the Conv1d after
+ * the last set-abstraction layer of models/pointnet2_ssg.py (PointNet2SSG.cov_final). */
+int pcr_dense_xpm_prec_ok(int cin, int cout, int L);
+int pcr_dense_xpm_prec_f32(const float *x, const float *wp_bf, const float *scale, const float *shift, float *y, int B,
+                           int cin, int cout, int L, int act, int precision, pcr_stream_t stream);
 
 /* ---- PointNet encoder pieces (models/pointnet.py:10-127) and LinearRes rows (lanegcn_nets.py:228-241) ---- */
 

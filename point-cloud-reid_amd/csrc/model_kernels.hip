@@ -581,6 +581,113 @@ __global__ void pack_bmm_kernel(const float *__restrict__ t, float *__restrict__
   }
 }
 
+
+// ---- point-major input, split bf16, wave-autonomous (round 4): y (B,cout,L) = act(scale (W x) + shift) for x (B,L,cin),
+// cout = 32 NCB <= 128, cin a multiple of 64 (SSG's Conv1d 256 -> 64 after the last set-abstraction layer, whose output is
+// point-major).  The f32 tile kernel spent 128 f32 MFMAs of 64 cycles per cout block and 32 tokens on it (as long as the
+// tensor takes to stream from HBM) behind LDS tiles and barriers: 0.27 ms where the bytes take 0.13.  Here a token's row
+// IS the B operand: lane (t, h) reads the two 16-byte pieces 16 s + 4 h, 16 s + 8 + 4 h of its token's row per 16-channel
+// step -- the k order of the pcr_pack_weight_bf16x2_f32 image (bf_kpos) -- splits them into bf16 hi / lo and feeds three
+// v_mfma_f32_32x32x16_bf16 per cout block; the weight image sits in LDS (staged once by a persistent workgroup of eight
+// waves); accumulators leave through the usual scale / shift / activation as coalesced 128-byte channel rows.  No LDS
+// tile, no barrier after the staging; the rows of the next four steps are requested before the current four are used.
+constexpr int kDpsWaves = 8;
+template <int NCB, bool LO>
+__global__ __launch_bounds__(64 * kDpsWaves) __attribute__((amdgpu_waves_per_eu(2, 4)))
+void dense_pm_stream_kernel(DenseArgs a, int B) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int KS = a.cin >> 4, WU = KS * NCB * 128;               // 16-channel steps; 16-byte units of the weight image
+  bf16x8 *s_w = reinterpret_cast<bf16x8 *>(smem);
+  float *s_sc = smem + 4 * WU, *s_sh = s_sc + 32 * NCB;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(a.wp);
+    f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
+    for (int e = tid; e < WU; e += 64 * kDpsWaves) dst[e] = src[e];
+    if (tid < 32 * NCB) {
+      s_sc[tid] = (a.scale && tid < a.cout) ? a.scale[tid] : 1.0f;
+      s_sh[tid] = (a.shift && tid < a.cout) ? a.shift[tid] : 0.0f;
+    }
+  }
+  __syncthreads();
+  const int L = a.L, cin = a.cin, cout = a.cout, act = a.act;
+  const int nblk = (L + 31) >> 5, nitem = B * nblk;
+  for (int it = blockIdx.x * kDpsWaves + wave; it < nitem; it += gridDim.x * kDpsWaves) {
+    asm volatile("" ::: "memory");   // (the weight reads stay inside the item loop)
+    const int b = it / nblk, blk = it - b * nblk;
+    const int t = blk * 32 + j;
+    const float *row = a.x + ((size_t)b * L + (t < L ? t : L - 1)) * cin + 4 * h;
+    f32x16 acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[cb][r] = 0.f;
+    f32x4 xa[4][2], xn[4][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; s2++) {
+      xa[s2][0] = *reinterpret_cast<const f32x4 *>(row + 16 * s2);
+      xa[s2][1] = *reinterpret_cast<const f32x4 *>(row + 16 * s2 + 8);
+    }
+    const bf16x8 *wb = s_w + lane;
+    for (int q4 = 0; q4 < KS; q4 += 4) {
+      if (q4 + 4 < KS) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; s2++) {
+          xn[s2][0] = *reinterpret_cast<const f32x4 *>(row + 16 * (q4 + 4 + s2));
+          xn[s2][1] = *reinterpret_cast<const f32x4 *>(row + 16 * (q4 + 4 + s2) + 8);
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 4; s2++) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          v[e] = xa[s2][0][e];
+          v[4 + e] = xa[s2][1][e];
+        }
+        bf16x8 bh, bl;
+        bf_split8(v, bh, bl, LO);
+        bf16x8 wh[NCB], wl[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+          wh[cb] = wb[(((q4 + s2) * NCB + cb) * 2) * 64];
+          if constexpr (LO) wl[cb] = wb[(((q4 + s2) * NCB + cb) * 2 + 1) * 64];
+        }
+        if constexpr (LO) {
+#pragma unroll
+          for (int cb = 0; cb < NCB; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bl, acc[cb], 0, 0, 0);
+#pragma unroll
+          for (int cb = 0; cb < NCB; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], bh, acc[cb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cb], bh, acc[cb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 4; s2++) {
+        xa[s2][0] = xn[s2][0];
+        xa[s2][1] = xn[s2][1];
+      }
+    }
+    if (t < L) {
+      float *out = a.y + (size_t)b * cout * L + t;
+#pragma unroll
+      for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int o = cb * 32 + 8 * g + 4 * h;
+          const f32x4 s4 = *reinterpret_cast<const f32x4 *>(s_sc + o), b4 = *reinterpret_cast<const f32x4 *>(s_sh + o);
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            if (o + q < cout) {
+              const float r = acc[cb][4 * g + q] * s4[q] + b4[q];
+              out[(size_t)(o + q) * L] = act == 1 ? fmaxf(r, 0.f) : (act == 2 && r < 0.f) ? r * 0.2f : r;
+            }
+          }
+        }
+    }
+  }
+}
 }  // namespace
 
 // ------------------------------------------------------------------------------ C ABI ----
@@ -740,6 +847,52 @@ static int dense_bf_launch(const float *x, const float *wp_bf, const float *scal
 PCR_EXPORT int pcr_dense_prec_f32(const float *x, const float *wp_bf, const float *scale, const float *shift, float *y,
                                   int B, int cin, int cout, int L, int act, int precision, pcr_stream_t stream) {
   return dense_bf_launch(x, wp_bf, scale, shift, y, B, cin, cout, L, act, precision, stream);
+}
+
+// the point-major-input form of pcr_dense_prec_f32 (x is (B,L,cin)): shapes pcr_dense_xpm_prec_ok accepts
+PCR_EXPORT int pcr_dense_xpm_prec_ok(int cin, int cout, int L) {
+  if (!(cin >= 64 && cin % 64 == 0 && cout >= 1 && cout <= 128 && L >= 1)) return 0;
+  const int ncb = (cout + 31) / 32;
+  return (size_t)(cin / 16) * ncb * 2048 + 1024 <= (size_t)144 * 1024;   // the weight image must fit LDS
+}
+
+PCR_EXPORT int pcr_dense_xpm_prec_f32(const float *x, const float *wp_bf, const float *scale, const float *shift, float *y,
+                                      int B, int cin, int cout, int L, int act, int precision, pcr_stream_t stream) {
+  if (!x || !wp_bf || !y || B < 0 || (precision != PCR_PREC_BF16X3 && precision != PCR_PREC_BF16) ||
+      !pcr_dense_xpm_prec_ok(cin, cout, L))
+    return PCR_ERR_INVALID;
+  if (B == 0) return PCR_OK;
+  const long items = (long)B * ((L + 31) / 32);
+  if (B > 65535 || items >= 0x7FFFFFFFl) return PCR_ERR_INVALID;
+  pcr_note_arith(precision);
+  DenseArgs a{x, wp_bf, scale, shift, y, cin, cout, L, act, 0, 1, 0, nullptr};
+  const int ncb = (cout + 31) / 32;
+  const size_t lds = (size_t)(cin / 16) * ncb * 2048 + (size_t)64 * ncb * sizeof(float);
+  static const int ncu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        n < 1)
+      n = 256;
+    return n;
+  }();
+  long wgs = (items + kDpsWaves - 1) / kDpsWaves;
+  const long resident = (long)ncu * (lds <= (size_t)78 * 1024 ? 2 : 1);
+  if (wgs > resident) wgs = resident;
+#define PCR_DPS(NCBv, LOv)                                                                                  \
+  do {                                                                                                      \
+    static bool ok = allow_big_lds(dense_pm_stream_kernel<NCBv, LOv>);                                      \
+    (void)ok;                                                                                               \
+    hipLaunchKernelGGL((dense_pm_stream_kernel<NCBv, LOv>), dim3((unsigned)wgs), dim3(64 * kDpsWaves), lds, \
+                       pcr_s(stream), a, B);                                                                \
+  } while (0)
+  if (precision == PCR_PREC_BF16X3) {
+    if (ncb == 1) PCR_DPS(1, true); else if (ncb == 2) PCR_DPS(2, true); else if (ncb == 3) PCR_DPS(3, true); else PCR_DPS(4, true);
+  } else {
+    if (ncb == 1) PCR_DPS(1, false); else if (ncb == 2) PCR_DPS(2, false); else if (ncb == 3) PCR_DPS(3, false); else PCR_DPS(4, false);
+  }
+#undef PCR_DPS
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
 }
 
 PCR_EXPORT int pcr_dense_gn_prec_f32(const float *x, const float *wp_bf, const float *gamma, const float *beta,

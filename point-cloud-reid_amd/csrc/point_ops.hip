@@ -549,7 +549,17 @@ __global__ __launch_bounds__(256) void ball_query_reg_kernel(const float *__rest
   int *row = s_row[wave];
   const bool staged = K <= 64;
   // (kRows) this wave's region of the row table and its running row offset
+  // (buffer stores: the region's base is a scalar, a lane contributes 16 x its row -- no 64-bit address arithmetic per
+  // hit.  The scalar-offset field stays 0 ON PURPOSE: with a REGISTER there, this compiler schedules a write to the
+  // store's data registers directly behind a 16-byte store -- it assumes the store-data hazard does not exist in that
+  // form -- and gfx950 then stores the overwritten value now and then: ~100 wrong dx per 2 M rows, found the hard way)
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   f32x4 *rbase = kRows ? rows_out + ((size_t)b * ((m + cpw - 1) / cpw) + (size_t)(chunk * 4 + wave)) * (size_t)(cpw * K) : nullptr;
+  const __amdgpu_buffer_rsrc_t rrows = __builtin_amdgcn_make_buffer_rsrc(rbase, 0, kRows ? cpw * K * 16 : 0, 0x00020000);
+  auto put_row = [&](int slot, int soff, int i, float dx, float dy, float dz) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{__int_as_float(i), dx, dy, dz}), rrows,
+                                           (slot + soff) * 16, 0, 0);
+  };
   int roff = 0;
   for (int c = c0; c < c1; c++) {
     const int co = 3 * (c - c0);
@@ -593,8 +603,7 @@ __global__ __launch_bounds__(256) void ball_query_reg_kernel(const float *__rest
               else gout[pos] = j * 64 + lane;
             }
             if constexpr (kRows)
-              rbase[roff + pos] = f32x4{__int_as_float(j * 64 + lane), px[j >> 1][j & 1] - cx, py[j >> 1][j & 1] - cy,
-                                        pz[j >> 1][j & 1] - cz};
+              put_row(pos, roff, j * 64 + lane, px[j >> 1][j & 1] - cx, py[j >> 1][j & 1] - cy, pz[j >> 1][j & 1] - cz);
           }
           if (cnt == 0) {
             const int fl = (int)__builtin_ctzll(mk[j]);
@@ -617,7 +626,7 @@ __global__ __launch_bounds__(256) void ball_query_reg_kernel(const float *__rest
         fdz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[0][0]), 0)) - cz;
       }
       const int nrow = cnt < 1 ? 2 : ((cnt + 1) & ~1);
-      if (lane < nrow - cnt) rbase[roff + cnt + lane] = f32x4{__int_as_float(first), fdx, fdy, fdz};
+      if (lane < nrow - cnt) put_row(lane, roff + cnt, first, fdx, fdy, fdz);
       roff += nrow;
     }
     if (gout && staged) {
@@ -635,7 +644,7 @@ __global__ __launch_bounds__(256) void ball_query_reg_kernel(const float *__rest
     if (cnt_out && lane == 0) cnt_out[b * m + c] = cnt;
   }
   if constexpr (kRows) {   // whole 32-row blocks: the consumer reads them without a clamp (and skips the padding's pairs)
-    if (c0 < c1 && roff + lane < ((roff + 31) & ~31)) rbase[roff + lane] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c0 < c1 && roff + lane < ((roff + 31) & ~31)) put_row(lane, roff, 0, 0.f, 0.f, 0.f);
   }
 }
 

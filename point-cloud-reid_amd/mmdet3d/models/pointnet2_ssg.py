@@ -34,7 +34,7 @@ class PointNet2SSG(nn.Module):
             xyz, feats, _ = sa(xyz, feats)
         key = (str(feats.device), engine.param_version(self.cov_final))
         if getattr(self, "_cf_key", None) != key:
-            object.__setattr__(self, "_cf_w", engine.pack_weight(self.cov_final.weight, feats.device))
+            object.__setattr__(self, "_cf_w", engine.pack_weight_dual(self.cov_final.weight, feats.device))
             object.__setattr__(self, "_cf_b", self.cov_final.bias.detach().to(feats.device).float().contiguous())
             object.__setattr__(self, "_cf_key", key)
         return xyz, engine.dense(feats, self._cf_w, self.cov_final.weight.shape[0], None, self._cf_b, 0)

@@ -168,7 +168,7 @@ def pack_weight_dual(w, device):
     shape the bf16 kernel does not cover simply never look at it"""
     wp = pack_weight(w, device)
     cout, cin = w.shape[0], int(np.prod(w.shape[1:]))
-    if L.load().pcr_dense_prec_ok(cin, cout, 1):
+    if L.load().pcr_dense_prec_ok(cin, cout, 1) or L.load().pcr_dense_xpm_prec_ok(cin, cout, 1):
         wp._pcr_bf = pack_weight_bf(w, device)
     return wp
 
@@ -526,6 +526,13 @@ def dense(x, wp, cout, scale=None, shift=None, act=0):
                    arith=PRECISION):
             L.check(lib.pcr_dense_prec_f32(L.ptr(x), L.ptr(bf), L.ptr(scale), L.ptr(shift), L.ptr(y), B, cin, cout, Ln, act,
                                            PRECISIONS[PRECISION], L.stream_ptr()), "pcr_dense_prec_f32")
+        return y
+    if PRECISION != "f32" and bf is not None and x_pm and lib.pcr_dense_xpm_prec_ok(cin, cout, Ln):
+        # a point-major tensor (the last SA layer's output) straight into the bf16 matrix core: a token's row is the operand
+        with _prof("dense[cin=%d,cout=%d,L=%d]" % (cin, cout, Ln), 2.0 * B * Ln * cin * cout, 4.0 * B * Ln * (cin + cout),
+                   arith="lib"):
+            L.check(lib.pcr_dense_xpm_prec_f32(L.ptr(x), L.ptr(bf), L.ptr(scale), L.ptr(shift), L.ptr(y), B, cin, cout, Ln,
+                                               act, PRECISIONS[PRECISION], L.stream_ptr()), "pcr_dense_xpm_prec_f32")
         return y
     fn = lib.pcr_dense_xpm_f32 if x_pm else lib.pcr_dense_f32
     with _prof("dense[cin=%d,cout=%d,L=%d]" % (cin, cout, Ln), 2.0 * B * Ln * cin * cout, 4.0 * B * Ln * (cin + cout),

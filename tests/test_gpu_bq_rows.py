@@ -55,7 +55,8 @@ def _table_from_idx(xyz, centres, idx, cnt, K):
 
 
 @pytest.mark.parametrize("B,N,M,K,radius", [(3, 1024, 512, 32, 0.2), (9, 512, 128, 64, 0.4), (2, 200, 37, 16, 0.3),
-                                            (1, 1000, 100, 32, 1e-4), (2, 64, 16, 32, 10.0), (17, 700, 50, 48, 0.25)])
+                                            (1, 1000, 100, 32, 1e-4), (2, 64, 16, 32, 10.0), (17, 700, 50, 48, 0.25),
+                                            (96, 1024, 512, 32, 0.08)])   # (50 k centres: rare hazards show at this size)
 def test_row_table_matches_the_index_tensor(B, N, M, K, radius):
     from mmdet3d.ops.point_ops import ball_query_cnt, ball_query_rows
     from pcr_amd import _lib as L
@@ -73,6 +74,9 @@ def test_row_table_matches_the_index_tensor(B, N, M, K, radius):
     for got in (rows, rows2):
         got = got.cpu().numpy().reshape(want.shape)
         assert np.array_equal(got.view(np.int32)[written], want.view(np.int32)[written])
+    for _ in range(3):                       # the same launch again: the same bits
+        again = ball_query_rows(radius, K, xyz.cuda(), centres.cuda())[2].cpu().numpy().reshape(want.shape)
+        assert np.array_equal(again.view(np.int32)[written], want.view(np.int32)[written])
     if radius < 1e-3:
         assert int(cnt0.max()) == 1          # a centre is its own (only) neighbour
     if radius > 5:
