@@ -1157,54 +1157,89 @@ __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_reg_kernel(const floa
 }
 
 // Larger clouds (1024 < n <= 4096): 32-64 points per lane do not fit in registers next to their distances, so the
-// cloud sits in LDS as {x,y,z,-} (one 16-byte read per point) and the distances are computed TWICE instead of
-// stored: pass 1 keeps only the lane minimum (-> tau as above), pass 2 recomputes them and compacts the candidates
-// d <= tau chunk by chunk (ballot + prefix popcount, in index order).  Ranking as in the register kernel; if more
+// cloud sits in LDS (as the point PAIRS a lane evaluates with packed arithmetic) and only the T distances of a query
+// live in registers: pass 1 computes them and the lane minimum (-> tau as above), pass 2 compacts the candidates
+// d <= tau chunk by chunk (ballot + prefix popcount, in index order).  (Rounds 2-3 recomputed the distances in pass 2
+// from a second sweep of the LDS copy: 128 KB of LDS reads per query, the kernel's bound; pt4096's 4096 x 4096 launch
+// 5.9 -> 3.8 ms with the distances kept; the packed pairs changed nothing measurable)  Ranking as in the register kernel; if more
 // than kKnnCap points pass (heavily duplicated clouds) the K nearest are emitted one per round as "the smallest
 // (distance, index) key above the previous one", which needs no per-point state either.
 template <int T, int NT>   // points per lane: n <= 64 * T; NT threads (NT / 64 waves share the cloud in LDS)
 __global__ __launch_bounds__(NT) void knn_prefix_lds_kernel(const float *__restrict__ xyz,
                                                                   int *__restrict__ idx, int n, int S,
                                                                   int K, int qpw) {
+  static_assert(T % 2 == 0, "points per lane come in pairs");
+  constexpr int TP = T / 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  f32x4 *pts = reinterpret_cast<f32x4 *>(smem);   // [64 * T], padded with points at infinity
+  // the cloud in LDS as the PAIRS a lane evaluates together (points lane + 64 (2 tp) and lane + 64 (2 tp + 1)):
+  // {x0, x1, y0, y1} + {z0, z1} -- register pairs for packed f32 arithmetic (the same IEEE operations as pcr_sqdist3,
+  // two points per instruction), 24 bytes per pair instead of two 16-byte points; padded with points at infinity
+  f32x4 *sP = reinterpret_cast<f32x4 *>(smem);            // [TP][64]
+  f32x2 *sZ = reinterpret_cast<f32x2 *>(sP + 64 * TP);    // [TP][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  unsigned long long *cand = reinterpret_cast<unsigned long long *>(pts + 64 * T) + wave * kKnnCap;
+  unsigned long long *cand = reinterpret_cast<unsigned long long *>(sZ + 64 * TP) + wave * kKnnCap;
   const size_t b = blockIdx.y;
   const float *cloud = xyz + b * n * 3;
   for (int i = tid; i < 64 * T; i += NT) {
     const bool ok = i < n;
     const float *q = cloud + (size_t)(ok ? i : 0) * 3;
-    const float x = q[0], y = q[1], z = q[2];
-    pts[i] = ok ? f32x4{x, y, z, 0.f} : f32x4{INFINITY, INFINITY, INFINITY, 0.f};
+    const float x = ok ? q[0] : INFINITY, y = ok ? q[1] : INFINITY, z = ok ? q[2] : INFINITY;
+    const int t = i >> 6, l = i & 63, unit = (t >> 1) * 64 + l, sl = t & 1;
+    reinterpret_cast<float *>(sP + unit)[sl] = x;
+    reinterpret_cast<float *>(sP + unit)[2 + sl] = y;
+    reinterpret_cast<float *>(sZ + unit)[sl] = z;
   }
   __syncthreads();
   const unsigned long long lt = (1ull << lane) - 1ull;
   const int q0 = blockIdx.x * qpw;
   const int q1 = (q0 + qpw < S) ? q0 + qpw : S;
   for (int q = q0 + wave; q < q1; q += NT / 64) {
-    const f32x4 qp = pts[q];
-    auto dist_bits = [&](int t) {   // pcr_sqdist3(query, point) as bits (>= +0; +inf sorts last)
-      const f32x4 pp = pts[lane + 64 * t];
-      return __float_as_uint(pcr_sqdist3(qp[0], qp[1], qp[2], pp[0], pp[1], pp[2]));
+    const int qu = ((q >> 7) * 64) + (q & 63), qs = (q >> 6) & 1;
+    const float qx = reinterpret_cast<const float *>(sP + qu)[qs], qy = reinterpret_cast<const float *>(sP + qu)[2 + qs],
+                qz = reinterpret_cast<const float *>(sZ + qu)[qs];
+    const f32x2 x1 = {qx, qx}, y1 = {qy, qy}, z1 = {qz, qz};
+    auto dist_pair = [&](int tp) {   // pcr_sqdist3(query, point) of the pair's two points (bits >= +0; +inf sorts last)
+      const f32x4 pp = sP[tp * 64 + lane];
+      const f32x2 pz = sZ[tp * 64 + lane];
+      const f32x2 dx = f32x2{pp[0], pp[1]} - x1, dy = f32x2{pp[2], pp[3]} - y1, dz = pz - z1;   // (p - q, as pcr_sqdist3)
+      const f32x2 a = dx * dx;
+      const f32x2 bb = dy * dy;
+      const f32x2 c = dz * dz;
+      const f32x2 sab = a + bb;
+      return sab + c;
     };
+    auto dist_bits = [&](int t) {
+      const f32x2 dd = dist_pair(t >> 1);
+      return __float_as_uint((t & 1) ? dd[1] : dd[0]);
+    };
+    // (round 4: the T distances of pass 1 STAY in registers -- 64 VGPRs at T = 64, inside the 128 of four waves per SIMD --
+    // instead of being recomputed from a second 64 KB sweep of the LDS copy: the kernel was bound by LDS bandwidth, 128 KB
+    // per query; the rare overflow path below still recomputes)
+    uint32_t dk[T];
     uint32_t m = 0xFFFFFFFFu;
-#pragma unroll 8
-    for (int t = 0; t < T; t++) {
-      const uint32_t d = dist_bits(t);
-      m = d < m ? d : m;
+#pragma unroll
+    for (int tp = 0; tp < TP; tp++) {
+      if ((tp & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // (eight points in flight: all T reads at once would spill)
+      const f32x2 dd = dist_pair(tp);
+      dk[2 * tp] = __float_as_uint(dd[0]);
+      dk[2 * tp + 1] = __float_as_uint(dd[1]);
+      const uint32_t m01 = dk[2 * tp] < dk[2 * tp + 1] ? dk[2 * tp] : dk[2 * tp + 1];
+      m = m01 < m ? m01 : m;
     }
+    __builtin_amdgcn_sched_barrier(0);
     const uint32_t mkey = (m & ~63u) | (uint32_t)lane;
     const uint32_t tau = (uint32_t)__builtin_amdgcn_readlane((int)pcr_wave_sort_u32(mkey, lane), K - 1) | 63u;
     int total = 0;
-#pragma unroll 4
+    int lane_q = lane;
+    asm volatile("" : "+v"(lane_q));   // (opaque per query: else the T values lane + 64 t are hoisted out of the query loop and spill)
+#pragma unroll
     for (int t = 0; t < T; t++) {
-      const uint32_t d = dist_bits(t);
+      const uint32_t d = dk[t];
       const bool in = d <= tau;
       const unsigned long long mask = __ballot(in);
       if (mask) {
         const int pos = total + __popcll(mask & lt);
-        if (in && pos < kKnnCap) cand[pos] = ((unsigned long long)(d | 0x80000000u) << 32) | (unsigned)(lane + 64 * t);
+        if (in && pos < kKnnCap) cand[pos] = ((unsigned long long)(d | 0x80000000u) << 32) | (unsigned)(lane_q + 64 * t);
         total += __popcll(mask);
       }
     }
@@ -1455,13 +1490,13 @@ PCR_EXPORT int pcr_knn_prefix_f32(const float *xyz, int *idx, int B, int N, int 
     if (N <= 1024) {
       PCR_KNN_REG(8);   // (the two-pass LDS form measures 1.79 ms against 1.60 here: registers win while they fit)
     } else if (N <= 2048) {
-      lds = (size_t)64 * 32 * 16 + (size_t)(NT / 64) * kKnnCap * 8;
+      lds = (size_t)64 * 32 * 12 + (size_t)(NT / 64) * kKnnCap * 8;
       static bool big = hipFuncSetAttribute(reinterpret_cast<const void *>(knn_prefix_lds_kernel<32, NT>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
       (void)big;
       hipLaunchKernelGGL((knn_prefix_lds_kernel<32, NT>), gl, dim3(NT), lds, st, xyz, idx, N, S, K, qpw_l);
     } else {
-      lds = (size_t)64 * 64 * 16 + (size_t)(NT / 64) * kKnnCap * 8;
+      lds = (size_t)64 * 64 * 12 + (size_t)(NT / 64) * kKnnCap * 8;
       static bool big = hipFuncSetAttribute(reinterpret_cast<const void *>(knn_prefix_lds_kernel<64, NT>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
       (void)big;
