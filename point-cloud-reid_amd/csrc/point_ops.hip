@@ -967,6 +967,84 @@ __global__ void three_interp_bwd_kernel(const float *__restrict__ grad_out,
 
 constexpr int kKnnPThreads = 256;
 constexpr int kKnnCap = 256;  // candidates per query the fast path can rank (4 per lane)
+
+// Ranks 0 .. K-1 of `total` <= kKnnCap candidates {index, distance bits} (= 64-bit (distance, index) keys) in the wave's
+// LDS strip `cand` -> out[0 .. K), in (distance, index) order.  Shared by the register and the LDS kNN kernels.
+__device__ __forceinline__ void knn_emit_from_candidates(unsigned long long *cand, int total, int K, int lane, int *out) {
+  uint32_t *cand32 = reinterpret_cast<uint32_t *>(cand);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (total > 64 && total <= 128) {
+    // 2b. a few candidates too many for one per lane (K = 48: 62-72 of them): the same bound once more, on the
+    // candidates -- the minimum of a lane's two candidates, rank K-1 of those 64 (K distinct candidates are
+    // <= it) -- and the survivors compacted in place (every lane holds its two before the first write).
+    const uint32_t i0 = cand32[2 * lane], d0 = cand32[2 * lane + 1];
+    const bool has1 = lane + 64 < total;
+    const uint32_t i1 = cand32[2 * lane + 128], d1r = cand32[2 * lane + 129];
+    const uint32_t d1 = has1 ? d1r : 0x7F7FFFFFu;
+    const uint32_t dmr = d0 < d1 ? d0 : d1;
+    const uint32_t dm = dmr < 0x7F7FFFFFu ? dmr : 0x7F7FFFFFu;   // (+inf / NaN bits: the tagged key must stay a finite float)
+    const uint32_t ts2 =
+        (uint32_t)__builtin_amdgcn_readlane((int)pcr_wave_sort_posf32((dm & ~63u) | (uint32_t)lane, lane), K - 1);
+    const uint32_t tau2 = ts2 | 63u;
+    __builtin_amdgcn_wave_barrier();
+    const bool p0 = d0 <= tau2, p1 = has1 && d1 <= tau2;
+    const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
+    const int s0 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
+    const int n0 = __popcll(m0);
+    const int s1 = n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32),
+                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+    if (p0) {
+      cand32[2 * s0] = i0;
+      cand32[2 * s0 + 1] = d0;
+    }
+    if (p1) {
+      cand32[2 * s1] = i1;
+      cand32[2 * s1 + 1] = d1;
+    }
+    total = n0 + __popcll(m1);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  if (total <= 64) {
+    // 3a. one candidate per lane.  Fast form: sort 32-bit keys (distance bits with the low 6 bits replaced by
+    // the SLOT) with the float network; exact unless two of the first K + 1 ranks share their truncated
+    // distance (~1 % of the queries), which is detected on the sorted keys and sent through the 64-bit sort.
+    // (a distance that overflowed to +inf, or a NaN, would make the tagged key a NaN pattern, which the float-min
+    // network mis-orders: clamped to the largest finite float -- such candidates then share their truncated key and
+    // the tie detector below sends the query through the exact 64-bit path, which sorts the RAW bits)
+    const uint32_t djr = cand32[2 * lane + 1];
+    const uint32_t dj = djr < 0x7F7FFFFFu ? djr : 0x7F7FFFFFu;
+    const uint32_t key = lane < total ? ((dj & ~63u) | (uint32_t)lane) : (0x7F7FFFC0u | (uint32_t)lane);
+    const uint32_t sk = pcr_wave_sort_posf32(key, lane);
+    const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)sk, 0x130, 0xF, 0xF, false);   // lane + 1
+    const bool tie = lane < K && ((sk ^ nx) < 64u);
+    if (__ballot(tie) == 0ull) {
+      if (lane < K) out[lane] = (int)cand32[2 * (sk & 63u)];
+    } else {
+      const unsigned long long own = pcr_wave_sort_u64(lane < total ? cand[lane] : ~0ull, lane);
+      if (lane < K) out[lane] = (int)(uint32_t)own;
+    }
+  } else {
+    // 3b. up to kKnnCap candidates: four per lane, broadcast LDS reads
+    unsigned long long own[kKnnCap / 64];
+    int rk[kKnnCap / 64];
+#pragma unroll
+    for (int u = 0; u < kKnnCap / 64; u++) {
+      own[u] = lane + 64 * u < total ? cand[lane + 64 * u] : ~0ull;
+      rk[u] = 0;
+    }
+    for (int j = 0; j < total; j++) {
+      const unsigned long long cj = cand[j];
+#pragma unroll
+      for (int u = 0; u < kKnnCap / 64; u++) rk[u] += cj < own[u] ? 1 : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < kKnnCap / 64; u++)
+      if (lane + 64 * u < total && rk[u] < K) out[rk[u]] = (int)(own[u] & 0xFFFFFFFFull);
+  }
+}
+
 // -------------------------------------------------------------- PT neighbour search ----
 // knn_point(K, xyz, xyz[:, :S]) of the Point-Transformer (pointnet2_utils.py:205-216): for each of the first S
 // points its K nearest points in (distance, index) order, distance = pcr_sqdist3.  One wave per query; selection
@@ -1061,77 +1139,7 @@ __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_reg_kernel(const floa
     }
     int *out = idx + (b * S + q) * K;
     if (total <= kKnnCap) {
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      if (total > 64 && total <= 128) {
-        // 2b. a few candidates too many for one per lane (K = 48: 62-72 of them): the same bound once more, on the
-        // candidates -- the minimum of a lane's two candidates, rank K-1 of those 64 (K distinct candidates are
-        // <= it) -- and the survivors compacted in place (every lane holds its two before the first write).
-        const uint32_t i0 = cand32[2 * lane], d0 = cand32[2 * lane + 1];
-        const bool has1 = lane + 64 < total;
-        const uint32_t i1 = cand32[2 * lane + 128], d1r = cand32[2 * lane + 129];
-        const uint32_t d1 = has1 ? d1r : 0x7F7FFFFFu;
-        const uint32_t dmr = d0 < d1 ? d0 : d1;
-        const uint32_t dm = dmr < 0x7F7FFFFFu ? dmr : 0x7F7FFFFFu;   // (+inf / NaN bits: the tagged key must stay a finite float)
-        const uint32_t ts2 =
-            (uint32_t)__builtin_amdgcn_readlane((int)pcr_wave_sort_posf32((dm & ~63u) | (uint32_t)lane, lane), K - 1);
-        const uint32_t tau2 = ts2 | 63u;
-        __builtin_amdgcn_wave_barrier();
-        const bool p0 = d0 <= tau2, p1 = has1 && d1 <= tau2;
-        const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
-        const int s0 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
-        const int n0 = __popcll(m0);
-        const int s1 = n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32),
-                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
-        if (p0) {
-          cand32[2 * s0] = i0;
-          cand32[2 * s0 + 1] = d0;
-        }
-        if (p1) {
-          cand32[2 * s1] = i1;
-          cand32[2 * s1 + 1] = d1;
-        }
-        total = n0 + __popcll(m1);
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      }
-      if (total <= 64) {
-        // 3a. one candidate per lane.  Fast form: sort 32-bit keys (distance bits with the low 6 bits replaced by
-        // the SLOT) with the float network; exact unless two of the first K + 1 ranks share their truncated
-        // distance (~1 % of the queries), which is detected on the sorted keys and sent through the 64-bit sort.
-        // (a distance that overflowed to +inf, or a NaN, would make the tagged key a NaN pattern, which the float-min
-        // network mis-orders: clamped to the largest finite float -- such candidates then share their truncated key and
-        // the tie detector below sends the query through the exact 64-bit path, which sorts the RAW bits)
-        const uint32_t djr = cand32[2 * lane + 1];
-        const uint32_t dj = djr < 0x7F7FFFFFu ? djr : 0x7F7FFFFFu;
-        const uint32_t key = lane < total ? ((dj & ~63u) | (uint32_t)lane) : (0x7F7FFFC0u | (uint32_t)lane);
-        const uint32_t sk = pcr_wave_sort_posf32(key, lane);
-        const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)sk, 0x130, 0xF, 0xF, false);   // lane + 1
-        const bool tie = lane < K && ((sk ^ nx) < 64u);
-        if (__ballot(tie) == 0ull) {
-          if (lane < K) out[lane] = (int)cand32[2 * (sk & 63u)];
-        } else {
-          const unsigned long long own = pcr_wave_sort_u64(lane < total ? cand[lane] : ~0ull, lane);
-          if (lane < K) out[lane] = (int)(uint32_t)own;
-        }
-      } else {
-        // 3b. up to kKnnCap candidates: four per lane, broadcast LDS reads
-        unsigned long long own[kKnnCap / 64];
-        int rk[kKnnCap / 64];
-#pragma unroll
-        for (int u = 0; u < kKnnCap / 64; u++) {
-          own[u] = lane + 64 * u < total ? cand[lane + 64 * u] : ~0ull;
-          rk[u] = 0;
-        }
-        for (int j = 0; j < total; j++) {
-          const unsigned long long cj = cand[j];
-#pragma unroll
-          for (int u = 0; u < kKnnCap / 64; u++) rk[u] += cj < own[u] ? 1 : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < kKnnCap / 64; u++)
-          if (lane + 64 * u < total && rk[u] < K) out[rk[u]] = (int)(own[u] & 0xFFFFFFFFull);
-      }
+      knn_emit_from_candidates(cand, total, K, lane, out);
       __builtin_amdgcn_wave_barrier();
     } else {
       int mine = 0;
@@ -1239,32 +1247,15 @@ __global__ __launch_bounds__(NT) void knn_prefix_lds_kernel(const float *__restr
       const unsigned long long mask = __ballot(in);
       if (mask) {
         const int pos = total + __popcll(mask & lt);
-        if (in && pos < kKnnCap) cand[pos] = ((unsigned long long)(d | 0x80000000u) << 32) | (unsigned)(lane_q + 64 * t);
+        if (in && pos < kKnnCap) cand[pos] = ((unsigned long long)d << 32) | (unsigned)(lane_q + 64 * t);
         total += __popcll(mask);
       }
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     int *out = idx + (b * S + q) * K;
-    if (total <= 64) {
-      const unsigned long long own = pcr_wave_sort_u64(lane < total ? cand[lane] : ~0ull, lane);
-      if (lane < K) out[lane] = (int)(uint32_t)own;
-    } else if (total <= kKnnCap) {
-      unsigned long long own[kKnnCap / 64];
-      int rk[kKnnCap / 64];
-#pragma unroll
-      for (int u = 0; u < kKnnCap / 64; u++) {
-        own[u] = lane + 64 * u < total ? cand[lane + 64 * u] : ~0ull;
-        rk[u] = 0;
-      }
-      for (int j = 0; j < total; j++) {
-        const unsigned long long cj = cand[j];
-#pragma unroll
-        for (int u = 0; u < kKnnCap / 64; u++) rk[u] += cj < own[u] ? 1 : 0;
-      }
-#pragma unroll
-      for (int u = 0; u < kKnnCap / 64; u++)
-        if (lane + 64 * u < total && rk[u] < K) out[rk[u]] = (int)(own[u] & 0xFFFFFFFFull);
+    if (total <= kKnnCap) {
+      knn_emit_from_candidates(cand, total, K, lane, out);
     } else {
       unsigned long long last = 0ull;   // every real key has bit 63 set
       for (int k = 0; k < K; k++) {
