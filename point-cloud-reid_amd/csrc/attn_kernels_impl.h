@@ -9,12 +9,22 @@
 #endif
 #include "tile_dense.h"
 
+#include <stdio.h>
+
+#include <vector>
+
 namespace {
 constexpr int kAPrec = PCR_ATTN_PREC;
 // -------------------------------------------------------------- linear attention ----
 struct AttnArgs {
   pcr_attn_params p;
+  int dbg;   // diagnostics (trace builds): 256 = stamp the shader clock
 };
+
+// shader-clock stamps of the wave-autonomous kv kernel (trace builds only: -DPCR_SA_TRACE_BUILD, PCR_ATTN_TRACE=<file>);
+// one record of kATraceMarks stamps per cloud round of waves 0 and 5 of the first workgroups
+constexpr int kATraceWgs = 512, kATraceRecs = 24, kATraceMarks = 8;
+__device__ unsigned long long g_attn_trace[2 * kATraceWgs * kATraceRecs * kATraceMarks];
 
 // Algebra used by both kernels (the host folds it into the weights, see AttnPlan in
 // pcr_amd/engine.py): with h = relu(W0 xyz + b0) the position encoding is W2 h + b2, so
@@ -302,7 +312,14 @@ constexpr int kKvsWaves = 8;
 // of the weight image -- so eight loaded / computed values convert into one A operand (bf_split8); K / V, the KV
 // accumulation and the merge fold stay f32.
 // XS: 16-channel steps of the key features in the BF form (c2 = 64 or 128: the FP_SA blocks)
-template <bool DIAG, bool BF, int XS = 4>
+// ONEW (round 4; short key sets, Sk <= 128: every gallery / SSG matching launch): ONE wave per cloud.  The trace of the
+// 36864-cloud gallery launch (tools/trace_attn.py) put 58 % of a workgroup round into what follows the blocks: four
+// wave-order reduction rounds through LDS with a barrier each, the fold, the closing barrier.  A wave that takes all of a
+// cloud's blocks needs none of it: the KV tile is accumulated TRANSPOSED (V as the A operand: lane = dd, register r =
+// v 8 g + 4 h + q), which makes register r of the tile the A operand of fold step r as it stands (contraction over the v
+// pairs (v_r, v_r + 4) instead of (2 s, 2 s + 1): other rounding in the last bits, still one fixed order per cloud), the
+// key sums never leave the wave, and eight clouds are in flight per workgroup with no barrier after the staging.
+template <bool DIAG, bool BF, int XS = 4, bool ONEW = false>
 __global__ __launch_bounds__(64 * kKvsWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void attn_kv_stream64_kernel(AttnArgs a) {
   static_assert(BF || XS == 4, "the f32 form is c2 = 64 only");
@@ -331,6 +348,7 @@ void attn_kv_stream64_kernel(AttnArgs a) {
   int wpc2 = 1;
   while (wpc2 * 2 <= wpc) wpc2 *= 2;                              // a power of two ...
   if (wpc2 < MINW) wpc2 = MINW;                                   // ... and at most four (two: c2 = 128) clouds per round (LDS)
+  if constexpr (ONEW) wpc2 = 1;
   const int cpg = kKvsWaves / wpc2;                               // clouds per workgroup round
   const int cslot = wave / wpc2, wsub = wave - cslot * wpc2;      // this wave's cloud slot and rank inside it
   const float inv_sk = 1.0f / (float)p.Sk;
@@ -338,9 +356,23 @@ void attn_kv_stream64_kernel(AttnArgs a) {
 #pragma unroll
   for (int cb = 0; cb < 4; cb++) bias[cb] = s_bkv[cb * 32 + j];
   const int dh = D / p.nhead;
+#ifdef PCR_SA_TRACE_BUILD
+  const bool tracing = (a.dbg & 256) && lane == 0 && (wave == 0 || wave == 5) && blockIdx.x < kATraceWgs;
+  unsigned long long *trace = g_attn_trace + (size_t)(2 * blockIdx.x + (wave ? 1 : 0)) * (kATraceRecs * kATraceMarks);
+  int trace_it = 0;
+#define PCR_AMARK(m)                                                                                       \
+  do {                                                                                                     \
+    if (tracing && trace_it < kATraceRecs) trace[trace_it * kATraceMarks + (m)] = __builtin_readcyclecounter(); \
+  } while (0)
+#define PCR_ANEXT() trace_it++
+#else
+#define PCR_AMARK(m) do { } while (0)
+#define PCR_ANEXT() do { } while (0)
+#endif
   for (long c0 = (long)blockIdx.x * cpg; c0 < p.B; c0 += (long)gridDim.x * cpg) {
     const long b = c0 + cslot;
     const bool live = b < p.B;
+    PCR_AMARK(4);
     f32x16 kv[NKV];
 #pragma unroll
     for (int i = 0; i < NKV; i++)
@@ -354,6 +386,7 @@ void attn_kv_stream64_kernel(AttnArgs a) {
           __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(feat), 0, C2 * p.Sk * 4, 0x00020000);
       for (int blk = wsub; blk < nblk; blk += wpc2) {
         asm volatile("" ::: "memory");   // (the weight reads below stay inside the block loop: hoisted, they are 256 registers)
+        PCR_AMARK(0);
         const int t = blk * 32 + j;
         const float px = xyz[3 * t], py = xyz[3 * t + 1], pz = xyz[3 * t + 2];
         f32x16 acc[4];
@@ -426,6 +459,7 @@ void attn_kv_stream64_kernel(AttnArgs a) {
           for (int cb = 0; cb < 4; cb++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[cb][r] = 0.f;
+          PCR_AMARK(1);
           const bf16x8 *wb = reinterpret_cast<const bf16x8 *>(s_w) + lane;
 #pragma unroll
           for (int s2 = 0; s2 < XS + 4; s2++) {
@@ -443,6 +477,7 @@ void attn_kv_stream64_kernel(AttnArgs a) {
             for (int cb = 0; cb < 4; cb++) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s2], wl[cb], acc[cb], 0, 0, 0);
           }
         }
+        PCR_AMARK(2);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           acc[0][r] = elu1(acc[0][r] + bias[0]);
@@ -456,14 +491,66 @@ void attn_kv_stream64_kernel(AttnArgs a) {
         for (int i = 0; i < NKV; i++) {
           const int ib = DIAG ? i : (i >> 1), jb = DIAG ? i : (i & 1);
 #pragma unroll
-          for (int r = 0; r < 16; r++)
-            kv[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[ib][r], acc[2 + jb][r], kv[i], 0, 0, 0);
+          for (int r = 0; r < 16; r++) {
+            if constexpr (ONEW) kv[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[2 + jb][r], acc[ib][r], kv[i], 0, 0, 0);
+            else kv[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[ib][r], acc[2 + jb][r], kv[i], 0, 0, 0);
+          }
         }
+        PCR_AMARK(3);
       }
     }
-    // the waves of a cloud add their KV / key sums into the cloud's LDS area in wave order
+    PCR_AMARK(5);
     ks0 += __shfl_xor(ks0, 32, 64);
     ks1 += __shfl_xor(ks1, 32, 64);
+    if constexpr (ONEW) {
+      // kv[i]: lane (dd = 32 ib + j, h), register r <-> v = 32 jb + 8 g + 4 h + q; fold tile (o block, dd block) from registers
+      if (live) {
+        float *kvo = p.kv + (size_t)b * ((size_t)D * D + D);
+        bf16x8 *img = reinterpret_cast<bf16x8 *>(kvo);
+#pragma unroll
+        for (int db = 0; db < 2; db++) {
+          const int hd = (db * 32 + j) / dh;
+#pragma unroll
+          for (int ob = 0; ob < 2; ob++) {
+            f32x16 m;
+#pragma unroll
+            for (int r = 0; r < 16; r++) m[r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NKV; i++) {
+              const int ib = DIAG ? i : (i >> 1), jb = DIAG ? i : (i & 1);
+              if (ib != db) continue;
+              const float *wr = s_wm + (ob * 32 + j) * LD + jb * 32 + 4 * h;
+#pragma unroll
+              for (int r = 0; r < 16; r++) {
+                const int vl = (r & 3) + 8 * (r >> 2);
+                const float av = (jb * 32 + vl + 4 * h) / dh == hd ? kv[i][r] : 0.f;
+                m = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wr[vl], m, 0, 0, 0);
+              }
+            }
+#pragma unroll
+            for (int G = 0; G < 2; G++) {
+              float v[8];
+#pragma unroll
+              for (int e = 0; e < 8; e++) v[e] = m[8 * G + e];
+              bf16x8 hi, lo;
+              bf_split8(v, hi, lo, true);
+              const size_t unit = (((size_t)(db * 2 + G) * (D >> 5) + ob) * 2) * 64 + h * 32 + j;
+              img[unit] = hi;
+              img[unit + 64] = lo;
+            }
+          }
+        }
+        if (h == 0) {
+          kvo[(size_t)D * D + j] = ks0;
+          kvo[(size_t)D * D + 32 + j] = ks1;
+        }
+      }
+      PCR_AMARK(6);
+      PCR_AMARK(7);
+      PCR_ANEXT();
+      continue;
+    }
+    // the waves of a cloud add their KV / key sums into the cloud's LDS area in wave order
     float *KVl = s_red + cslot * KVS, *s_kt = KVl + D * LD;
     for (int round = 0; round < wpc2; round++) {
       if (wsub == round) {
@@ -484,6 +571,7 @@ void attn_kv_stream64_kernel(AttnArgs a) {
       }
       __syncthreads();
     }
+    PCR_AMARK(6);
     // merge fold M[o][dd] = sum_{v in head(dd)} Wm[o][v] KV[dd][v] on the matrix core: four 32 x 32 tiles (o block, dd
     // block) over the cloud's waves, operands straight from LDS (A = Wm rows, B = KV rows with the head mask applied on
     // the read; DIAG: only the dd block's own 32 columns exist), then the packed image of M and the key sums
@@ -498,34 +586,52 @@ void attn_kv_stream64_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; r++) m[r] = 0.f;
         const int s_lo = DIAG ? db * 16 : 0, s_hi = DIAG ? db * 16 + 16 : 32;
+        if constexpr (kAPrec == 0) {
 #pragma unroll 4
-        for (int s2 = s_lo; s2 < s_hi; s2++) {
-          const float bv = bp[2 * s2];
-          m = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s2], (2 * s2 + h) / dh == hd ? bv : 0.f, m, 0, 0, 0);
-        }
-        const int dd = db * 32 + j;
+          for (int s2 = s_lo; s2 < s_hi; s2++) {
+            const float bv = bp[2 * s2];
+            m = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s2], (2 * s2 + h) / dh == hd ? bv : 0.f, m, 0, 0, 0);
+          }
+          const int dd = db * 32 + j;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int o = ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if constexpr (kAPrec == 0) {
+          for (int r = 0; r < 16; r++) {
+            const int o = ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             const int kb = dd >> 3, rem = dd & 7;
             kvo[(((size_t)kb * D + o) * 2 + (rem & 1)) * 4 + (rem >> 1)] = m[r];
-          } else {
-            const int s16 = dd >> 4, kk = dd & 15;
-            const int hh = (kk >> 2) & 1, jj = (kk & 3) + ((kk >> 3) << 2);
-            const size_t unit = (((size_t)s16 * (D >> 5) + (o >> 5)) * 2) * 64 + hh * 32 + (o & 31);
-            const __bf16 hi = (__bf16)m[r];
-            const __bf16 lo = (__bf16)(m[r] - (float)hi);
-            __bf16 *img = reinterpret_cast<__bf16 *>(kvo);
-            img[unit * 8 + jj] = hi;
-            img[(unit + 64) * 8 + jj] = lo;
+          }
+        } else {
+          // the bf16 image wants, per (output row o, half h), the eight cin values 16 s + bf_kpos(h, .) as ONE 16-byte unit:
+          // with the fold TRANSPOSED (KV rows as the A operand, Wm rows as B: the same products summed in the same order,
+          // so the same bits) lane (o, h) holds dd = 8 g + 4 h + q in register 4 g + q -- registers [8 G, 8 G + 8) are
+          // exactly the unit of step 2 db + G.  (Round 3 stored the untransposed tile element by element: 32 scattered
+          // 2-byte stores per lane and tile, 0.5 ms of a 36864-cloud gallery launch.)
+#pragma unroll 4
+          for (int s2 = s_lo; s2 < s_hi; s2++) {
+            const float bv = bp[2 * s2];
+            m = __builtin_amdgcn_mfma_f32_32x32x2f32((2 * s2 + h) / dh == hd ? bv : 0.f, ap[2 * s2], m, 0, 0, 0);
+          }
+          bf16x8 *img = reinterpret_cast<bf16x8 *>(kvo);
+#pragma unroll
+          for (int G = 0; G < 2; G++) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = m[8 * G + e];
+            bf16x8 hi, lo;
+            bf_split8(v, hi, lo, true);
+            const size_t unit = (((size_t)(db * 2 + G) * (D >> 5) + ob) * 2) * 64 + h * 32 + j;
+            img[unit] = hi;
+            img[unit + 64] = lo;
           }
         }
       }
       for (int e = wsub * 64 + lane; e < D; e += 64 * wpc2) kvo[(size_t)D * D + e] = s_kt[e];
     }
+    PCR_AMARK(7);
+    PCR_ANEXT();
     __syncthreads();   // the next round overwrites the reduction areas
   }
+#undef PCR_AMARK
+#undef PCR_ANEXT
 }
 
 #if PCR_ATTN_PREC != 0
@@ -659,24 +765,23 @@ void attn_kv_stream32_kernel(AttnArgs a) {
       f32x16 m;
 #pragma unroll
       for (int r = 0; r < 16; r++) m[r] = 0.f;
+      // (transposed fold, whole 16-byte units per lane: see attn_kv_stream64_kernel)
 #pragma unroll 4
       for (int s2 = 0; s2 < 16; s2++) {
         const float bv = bp[2 * s2];
-        m = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s2], (2 * s2 + h) / dh == hd ? bv : 0.f, m, 0, 0, 0);
+        m = __builtin_amdgcn_mfma_f32_32x32x2f32((2 * s2 + h) / dh == hd ? bv : 0.f, ap[2 * s2], m, 0, 0, 0);
       }
-      const int dd = j;
+      bf16x8 *img = reinterpret_cast<bf16x8 *>(kvo);
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int o = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int s16 = dd >> 4, kk = dd & 15;
-        const int hh = (kk >> 2) & 1, jj = (kk & 3) + ((kk >> 3) << 2);
-        const size_t unit = (((size_t)s16 * (D >> 5) + (o >> 5)) * 2) * 64 + hh * 32 + (o & 31);
-        const float mv = m[r];
-        const __bf16 hi = (__bf16)mv;
-        const __bf16 lo = (__bf16)(mv - (float)hi);
-        __bf16 *img = reinterpret_cast<__bf16 *>(kvo);
-        img[unit * 8 + jj] = hi;
-        img[(unit + 64) * 8 + jj] = lo;
+      for (int G = 0; G < 2; G++) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = m[8 * G + e];
+        bf16x8 hi, lo;
+        bf_split8(v, hi, lo, true);
+        const size_t unit = (((size_t)G * (D >> 5)) * 2) * 64 + h * 32 + j;
+        img[unit] = hi;
+        img[unit + 64] = lo;
       }
       if (lane < D) kvo[(size_t)D * D + lane] = s_kt[lane];
     }
@@ -1327,10 +1432,32 @@ static int attn_check(const pcr_attn_params &p) {
   return 0;
 }
 
+static void attn_dump_trace(const char *path, const char *tag, int wgs, int B, int Sk) {
+  static int launches = 0;
+  static const int skip = pcr_tune_int("PCR_SA_TRACE_SKIP");
+  launches++;
+  if (launches <= skip || launches > skip + 8) return;
+  static std::vector<unsigned long long> host(2 * kATraceWgs * kATraceRecs * kATraceMarks);
+  if (hipDeviceSynchronize() != hipSuccess) return;
+  if (hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(g_attn_trace), host.size() * sizeof(unsigned long long)) != hipSuccess) return;
+  FILE *f = fopen(path, "a");
+  if (!f) return;
+  const int n = 2 * (wgs < kATraceWgs ? wgs : kATraceWgs);
+  fprintf(f, "launch %d kernel %s wgs %d B %d Sk %d\n", launches, tag, wgs, B, Sk);
+  for (int w = 0; w < n; w++) {
+    const unsigned long long *t = host.data() + (size_t)w * (kATraceRecs * kATraceMarks);
+    fprintf(f, "wg %d", w);
+    for (int i = 0; i < kATraceRecs * kATraceMarks; i++) fprintf(f, " %llu", t[i]);
+    fprintf(f, "\n");
+  }
+  fclose(f);
+}
+
 // d_model <= 128: one workgroup per key-side cloud (both precisions; wq / wkv / ... are images of THIS unit's kind)
 static int attn_kv_narrow(const pcr_attn_params *pp, pcr_stream_t stream) {
   AttnArgs a;
   a.p = *pp;
+  a.dbg = 0;
   const int d = pp->d;
   if (pp->c2 < pp->d) return PCR_ERR_INVALID;   // the in-place K/V projection needs 2d <= c2 + d rows
   const int tb = d <= 64 ? 2 : 1, RP = 32 * tb + 1;
@@ -1367,9 +1494,13 @@ static int attn_kv_narrow(const pcr_attn_params *pp, pcr_stream_t stream) {
     while (wpc2 * 2 <= (nblk < kKvsWaves ? nblk : kKvsWaves)) wpc2 *= 2;
     const int minw = wide ? 4 : 2;
     if (wpc2 < minw) wpc2 = minw;                             // (at most four / two clouds per round: LDS)
+    // short key sets: one wave per cloud (ONEW; shape-only, the bf16 unit's image only)
+    static const int no_onew = pcr_tune_int("PCR_ATTN_NO_ONEW");   // diagnostics
+    const bool onew = kBfUnit && bf && !wide && nblk <= 4 && !no_onew;
+    if (onew) wpc2 = 1;
     const int cpg = kKvsWaves / wpc2;
     const size_t wu = bf ? (size_t)((wide ? 8 : 4) + 4) * 512 : 4096;
-    const size_t lds_s = (wu * 4 + 256 + 128 + 64 * 65 + (size_t)cpg * (64 * 65 + 64)) * sizeof(float);
+    const size_t lds_s = (wu * 4 + 256 + 128 + 64 * 65 + (onew ? (size_t)0 : (size_t)cpg * (64 * 65 + 64))) * sizeof(float);
     const long rounds = ((long)pp->B + cpg - 1) / cpg;
     static const int ncu = [] {
       hipDeviceProp_t pr;
@@ -1383,8 +1514,17 @@ static int attn_kv_narrow(const pcr_attn_params *pp, pcr_stream_t stream) {
       if (pp->nhead >= 2) hipLaunchKernelGGL((attn_kv_stream64_kernel<true, kBfUnit, kBfUnit ? 8 : 4>), gg, bb, lds_s, st, a);
       else hipLaunchKernelGGL((attn_kv_stream64_kernel<false, kBfUnit, kBfUnit ? 8 : 4>), gg, bb, lds_s, st, a);
     } else if (bf) {
-      if (pp->nhead >= 2) hipLaunchKernelGGL((attn_kv_stream64_kernel<true, kBfUnit>), gg, bb, lds_s, st, a);
+      static const char *atrace = pcr_tune_str("PCR_ATTN_TRACE");
+      if (atrace) a.dbg = 256;
+      if (onew) {
+        static bool oko = allow_big_lds(attn_kv_stream64_kernel<true, kBfUnit, 4, kBfUnit>) &&
+                          allow_big_lds(attn_kv_stream64_kernel<false, kBfUnit, 4, kBfUnit>);
+        (void)oko;
+        if (pp->nhead >= 2) hipLaunchKernelGGL((attn_kv_stream64_kernel<true, kBfUnit, 4, kBfUnit>), gg, bb, lds_s, st, a);
+        else hipLaunchKernelGGL((attn_kv_stream64_kernel<false, kBfUnit, 4, kBfUnit>), gg, bb, lds_s, st, a);
+      } else if (pp->nhead >= 2) hipLaunchKernelGGL((attn_kv_stream64_kernel<true, kBfUnit>), gg, bb, lds_s, st, a);
       else hipLaunchKernelGGL((attn_kv_stream64_kernel<false, kBfUnit>), gg, bb, lds_s, st, a);
+      if (atrace) attn_dump_trace(atrace, "kv64", gs, (int)pp->B, pp->Sk);
     } else {
       if (pp->nhead >= 2) hipLaunchKernelGGL((attn_kv_stream64_kernel<true, false>), gg, bb, lds_s, st, a);
       else hipLaunchKernelGGL((attn_kv_stream64_kernel<false, false>), gg, bb, lds_s, st, a);
@@ -1435,6 +1575,7 @@ static int attn_apply_launch(const pcr_attn_params *pp, pcr_stream_t stream) {
   const pcr_attn_params &p = *pp;
   AttnArgs a;
   a.p = p;
+  a.dbg = 0;
   const int tb = p.d <= 32 ? 4 : (p.d <= 64 ? 2 : 1), T = 32 * tb, RP = T + 1;
   const int catP = ceil8(p.c1 + p.d);
   int rowsU = catP > 2 * p.d ? catP : 2 * p.d;
@@ -1584,6 +1725,7 @@ PCR_EXPORT int pcr_attn_kv_f32(const pcr_attn_params *pp, pcr_stream_t stream) {
   if (d > 128) {   // wide: d / 64 workgroups per cloud (attn_kv_wide_kernel)
     AttnArgs a;
     a.p = *pp;
+    a.dbg = 0;
     if (!pp->wkv_wide || !pp->bkv_wide || !pp->wmerge_packed || pp->B > 65535) return PCR_ERR_INVALID;
     pcr_note_arith(PCR_PREC_F32);
     const int dh = d / pp->nhead;
