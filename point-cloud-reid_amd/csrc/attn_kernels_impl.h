@@ -1112,8 +1112,22 @@ void attn_apply_stream64_kernel(AttnArgs a) {
     for (int e = 0; e < 8; e++) v[e] = acc[8 * G + e];
     bf_split8(v, oh, ol, true);
   };
+#ifdef PCR_SA_TRACE_BUILD
+  const bool tracing = (a.dbg & 256) && lane == 0 && (wave == 0 || wave == 5) && blockIdx.x < kATraceWgs;
+  unsigned long long *trace = g_attn_trace + (size_t)(2 * blockIdx.x + (wave ? 1 : 0)) * (kATraceRecs * kATraceMarks);
+  int trace_it = 0;
+#define PCR_AMARK(m)                                                                                       \
+  do {                                                                                                     \
+    if (tracing && trace_it < kATraceRecs) trace[trace_it * kATraceMarks + (m)] = __builtin_readcyclecounter(); \
+  } while (0)
+#define PCR_ANEXT() trace_it++
+#else
+#define PCR_AMARK(m) do { } while (0)
+#define PCR_ANEXT() do { } while (0)
+#endif
   for (long it = (long)blockIdx.x * kApsWaves + wave; it < nitem; it += (long)gridDim.x * kApsWaves) {
     asm volatile("" ::: "memory");   // (weight reads stay inside the item loop)
+    PCR_AMARK(0);
     const long b = it / nblk;
     const int blk = (int)(it - b * nblk);
     const size_t bq_ = p.q_index ? (size_t)p.q_index[b] : (size_t)b;
@@ -1155,6 +1169,7 @@ void attn_apply_stream64_kernel(AttnArgs a) {
       for (int e = 0; e < 8; e++) xv[e] = xf[8 * s2 + e];
       bf_split8(xv, bh[s2], bl[s2], true);
     }
+    PCR_AMARK(1);
     // ---- Q = elu(Wq [x ; h] + bq) + 1
     f32x16 q[ND];
 #pragma unroll
@@ -1179,6 +1194,7 @@ void attn_apply_stream64_kernel(AttnArgs a) {
         for (int cb = 0; cb < ND; cb++) q[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], bh[s2], q[cb], 0, 0, 0);
       }
     }
+    PCR_AMARK(2);
     // the message-phase A operands (the cloud's matrix M): requested now, used after the normaliser
     bf16x8 mh[SD][ND], ml[SD][ND];
     {
@@ -1283,7 +1299,9 @@ void attn_apply_stream64_kernel(AttnArgs a) {
           for (int qq = 0; qq < 4; qq++) v[cb][4 * g + qq] = (v[cb][4 * g + qq] - mean) * inv * gv[qq] + bv[qq];
         }
     };
+    PCR_AMARK(3);
     layernorm(m, std::integral_constant<int, ND>{}, s_c + 64, s_c + 128);
+    PCR_AMARK(4);
     // ---- FFN0: relu(W0 [x ; msg]) (128 couts), operands: x re-converted from its f32 registers, msg from m
 #pragma unroll
     for (int s2 = 0; s2 < C1S; s2++) {
@@ -1326,6 +1344,7 @@ void attn_apply_stream64_kernel(AttnArgs a) {
 #pragma unroll
       for (int G = 0; G < 2; G++) to_ops(f[cb], G, bh[2 * cb + G], bl[2 * cb + G]);
     }
+    PCR_AMARK(5);
     // ---- FFN1 (64 couts), LayerNorm, residual, store
     f32x16 o[NOB];
 #pragma unroll
@@ -1350,6 +1369,7 @@ void attn_apply_stream64_kernel(AttnArgs a) {
         for (int cb = 0; cb < NOB; cb++) o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[cb], bh[s2], o[cb], 0, 0, 0);
       }
     }
+    PCR_AMARK(6);
     layernorm(o, std::integral_constant<int, NOB>{}, s_c + 192, s_c + 192 + 32 * NOB);
     if constexpr (C1S == 2 * NOB) {   // cout == c1
       if (p.residual) {
@@ -1412,7 +1432,11 @@ void attn_apply_stream64_kernel(AttnArgs a) {
         }
     }
     __builtin_amdgcn_wave_barrier();   // (the key-sum strip is rewritten by the next item)
+    PCR_AMARK(7);
+    PCR_ANEXT();
   }
+#undef PCR_AMARK
+#undef PCR_ANEXT
 }
 #endif
 
@@ -1637,6 +1661,8 @@ static int attn_apply_launch(const pcr_attn_params *pp, pcr_stream_t stream) {
     hipLaunchKernelGGL((attn_apply_stream64_kernel<QP, C1Sv, CFv>), gg, bb, lds_s, st, a); \
   } while (0)
     const bool cf = p.cfinal != 0;
+    static const char *aptrace = pcr_tune_str("PCR_ATTN_TRACE");
+    if (aptrace) a.dbg = 256;
     if (nob == 4) {
       static bool ok4 = allow_big_lds(attn_apply_stream64_kernel<true, 4, 0, 4>) && allow_big_lds(attn_apply_stream64_kernel<false, 4, 0, 4>);
       (void)ok4;
@@ -1650,6 +1676,7 @@ static int attn_apply_launch(const pcr_attn_params *pp, pcr_stream_t stream) {
     else if (p.q_pos) { if (cf) PCR_APS(true, 4, 4); else PCR_APS(true, 4, 0); }
     else { if (cf) PCR_APS(false, 4, 4); else PCR_APS(false, 4, 0); }
 #undef PCR_APS
+    if (aptrace) attn_dump_trace(aptrace, "apply64", (int)gg.x, (int)p.B, p.Lq);
     PCR_CHECK_LAUNCH();
     return PCR_OK;
   }
