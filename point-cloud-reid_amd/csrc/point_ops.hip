@@ -327,16 +327,37 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(const float *__restrict__ 
       mx = m01 > mx ? m01 : mx;
     }
     const uint32_t best = dpp_max_u32(mx);
-    uint32_t lo = 0u;
+    // which point holds it?  Almost always ONE lane and, in it, ONE slot: then the pick is 64 slot + lane, found by a scalar
+    // walk over the slots' equality masks (16 compares + scalar bit tests instead of the 40-instruction tie-break pass and
+    // its second wave reduction).  Anything else -- two lanes, or two slots of the lane -- takes the reference's tie rule
+    // below, unchanged.
+    const unsigned long long lm = __ballot(mx == best);
+    bool unique = __popcll(lm) == 1;
+    if (unique) {
+      const int L = (int)__builtin_ctzll(lm);
+      int hits = 0, slot_found = 0;
 #pragma unroll
-    for (int p = 0; p < PP; p++) {   // (pairs: the two selects feed one three-way max)
-      const uint32_t l0 = t[2 * p] == best ? low[2 * p] : 0u;
-      const uint32_t l1 = t[2 * p + 1] == best ? low[2 * p + 1] : 0u;
-      const uint32_t l01 = l0 > l1 ? l0 : l1;
-      lo = l01 > lo ? l01 : lo;
+      for (int p = 0; p < 2 * PP; p++) {
+        const unsigned long long mp = __ballot(t[p] == best);
+        const int bit = (int)((mp >> L) & 1ull);
+        hits += bit;
+        slot_found = bit ? p : slot_found;
+      }
+      if (hits == 1) old = 64 * slot_found + L;
+      else unique = false;
     }
-    lo = dpp_max_u32(lo);
-    old = (int)(0x3FFFFFu - (lo & 0x3FFFFFu));
+    if (!unique) {
+      uint32_t lo = 0u;
+#pragma unroll
+      for (int p = 0; p < PP; p++) {   // (pairs: the two selects feed one three-way max)
+        const uint32_t l0 = t[2 * p] == best ? low[2 * p] : 0u;
+        const uint32_t l1 = t[2 * p + 1] == best ? low[2 * p + 1] : 0u;
+        const uint32_t l01 = l0 > l1 ? l0 : l1;
+        lo = l01 > lo ? l01 : lo;
+      }
+      lo = dpp_max_u32(lo);
+      old = (int)(0x3FFFFFu - (lo & 0x3FFFFFu));
+    }
     if (lane == 0) idxs[j] = old;
   }
 #pragma unroll
