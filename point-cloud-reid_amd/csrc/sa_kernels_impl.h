@@ -504,13 +504,32 @@ struct SasBlock {
       if (p16 < 4 * NCB)
         qv = *reinterpret_cast<const f32x4 *>(pq + (size_t)ci * pqw + qoff + (p16 >> 2) * 32 + 8 * (p16 & 3) + 4 * h);
     }
-    // ---- layer 1, one cout block at a time (the gathers of a block: 4 sixteen-byte pieces of the neighbour's row)
+    // ---- layer 1, one cout block at a time (the gathers of a block: 4 sixteen-byte pieces of the neighbour's row).
+    // The 128-channel form has the registers (200 of its 256) to request ALL 16 pieces before the first block's MFMAs
+    // instead of block by block -- four L2 round trips in a row were 30 % of its block (tools/trace_stream.py)
+    constexpr bool kAllP = NCB >= 4;
+    f32x4 ppa[kAllP ? NCB : 1][4];
+    if constexpr (kAllP) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; cb++) {
+        const float *pr = pq ? pq + (size_t)i * pqw + cb * 32 + 4 * h : nullptr;
+#pragma unroll
+        for (int g = 0; g < 4; g++) ppa[cb][g] = pr ? *reinterpret_cast<const f32x4 *>(pr + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) asm volatile("" : "+v"(ppa[cb][g]));   // (the loads land here, not before each use)
+    }
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++) {
       f32x4 pp[4];
       const float *pr = pq ? pq + (size_t)i * pqw + cb * 32 + 4 * h : nullptr;
 #pragma unroll
-      for (int g = 0; g < 4; g++) pp[g] = pr ? *reinterpret_cast<const f32x4 *>(pr + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < 4; g++) {
+        if constexpr (kAllP) pp[g] = ppa[cb][g];
+        else pp[g] = pr ? *reinterpret_cast<const f32x4 *>(pr + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
       f32x16 acc;
 #pragma unroll
       for (int g = 0; g < 4; g++) {
