@@ -86,6 +86,23 @@ def main(budget=None, seed=None, max_cases=None):
         err = float((out.cpu() - want).abs().max())
         worst = max(worst, err)
         key = "mode%d%s" % (mode, "_ragged" if cnt is not None else "")
+        if cnt is not None and plan.wants_row_table(N, K, 0.0):
+            # the same launch fed with the ball query's row table layout (built here from idx / cnt): the same bits
+            tab = np.zeros((B, (S + 15) // 16, 16 * K, 4), dtype=np.float32)
+            xn, cn, ixn, cin_ = xyz.numpy(), cnt.numpy(), idx.numpy(), cidx.numpy()
+            for b in range(B):
+                for it in range((S + 15) // 16):
+                    r = 0
+                    for c in range(it * 16, min(S, it * 16 + 16)):
+                        for k in range((max(int(cn[b, c]), 1) + 1) & ~1):
+                            i = int(ixn[b, c, k])
+                            tab[b, it, r, 0] = np.int32(i).view(np.float32)
+                            tab[b, it, r, 1:] = xn[b, i] - xn[b, int(cin_[b, c])]
+                            r += 1
+            out2 = plan.run(xyz.cuda(), fg, None, cidx.cuda(), cnt=cnt.cuda(), out_point_major=opm,
+                            rows=torch.from_numpy(tab).reshape(-1).cuda(), K=K)
+            assert torch.equal(out2, out), (mode, D, K, S, N, widths, B, "row table")
+            key += "_table"
         kinds[key] = kinds.get(key, 0) + 1
         assert err < 5e-5 * max(1.0, float(want.abs().max())), (mode, D, K, S, N, widths, B, cnt is not None, fpm, opm, err)
         n += 1
