@@ -103,3 +103,33 @@ def test_product_package_never_imports_oracle():
                 src = open(os.path.join(d, f)).read()
                 assert "model_oracle" not in src and "point_ops as P" not in src and "import oracle" not in src, f
                 assert "pcr_oracle" not in src, f
+
+
+def test_no_wide_buffer_store_with_a_register_scalar_offset(lib, tmp_path):
+    """gfx950 hazard found in round 4: a 12- / 16-byte buffer store whose scalar-offset field is a REGISTER
+    lets this compiler schedule a write to the store's data registers directly behind it (its hazard recogniser
+    assumes the store-data hazard does not exist in that form), and the hardware then stores the overwritten value now
+    and then.  No kernel of the library may contain such a store: disassemble every gfx950 code object of the built
+    library and look."""
+    import glob
+    import re
+    import shutil
+    import subprocess
+    from pcr_amd import _lib
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(objdump) and os.path.exists(_lib.SO_PATH)):
+        pytest.skip("needs the built library and llvm-objdump")
+    so = shutil.copy(_lib.SO_PATH, str(tmp_path / "lib.so"))
+    subprocess.run([objdump, "--offloading", so], cwd=str(tmp_path), check=True, capture_output=True)
+    objs = glob.glob(str(tmp_path / "lib.so.*gfx950"))
+    assert objs, "no gfx950 code object in the library"
+    wide, bad = 0, []
+    pat = re.compile(r"buffer_store_dwordx[34]\s+v\[\d+:\d+\],\s*\S+,\s*s\[\d+:\d+\],\s*(\S+)")
+    for o in objs:
+        text = subprocess.run([objdump, "-d", o], check=True, capture_output=True, text=True).stdout
+        for m in pat.finditer(text):
+            wide += 1
+            if re.match(r"s\d+", m.group(1)):
+                bad.append(m.group(0))
+    assert wide > 0                      # (the pattern still matches this toolchain's syntax)
+    assert not bad, bad[:3]
