@@ -326,6 +326,10 @@ typedef struct pcr_head_params {
   const float *gn1_g, *gn1_b, *gn2_g, *gn2_b;
   const float *w_out, *b_out;      /* (1,2C), (1) */
   float *pooled, *logits;
+  /* optional (ABI 12, appended): the TRANSPOSES of w1 / w2 ((2C,2C) row-major: w1t[i][o] = w1[o][i]).  With them the
+   * matrix-vector products read 256 contiguous bytes per wave and step instead of 64 scattered 16-byte pieces (the
+   * head of a 32 k-pair gallery launch was bound by exactly those reads); same products, same summation order. */
+  const float *w1t, *w2t;
 } pcr_head_params;
 int pcr_pool_head_f32(const pcr_head_params *p, pcr_stream_t stream);
 

@@ -146,8 +146,24 @@ __global__ __launch_bounds__(kThreads) void pool_head_kernel(pcr_head_params p) 
   }
   __syncthreads();
   if (p.pooled && tid < n) p.pooled[pr * n + tid] = x[tid];
-  // (the matvec rows in 16-byte pieces, the products added in the original order)
-  auto matvec = [&](const float *wm, const float *v) {
+  // (the matvec rows in 16-byte pieces, the products added in the original order; with the transposed matrix the lanes of
+  // a wave read consecutive floats -- one 256-byte run per step instead of 64 separate 16-byte pieces per load, which was
+  // what bound a gallery launch: 8192 pieces per pair through one CU's address unit -- eight steps in flight, the same sums)
+  auto matvec = [&](const float *wm, const float *wt, const float *v) {
+    if (wt) {
+      const float *w = wt + tid;
+      float s = 0.f;
+      int i = 0;
+      for (; i + 8 <= n; i += 8) {
+        float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) wv[u] = w[(size_t)(i + u) * n];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += wv[u] * v[i + u];
+      }
+      for (; i < n; i++) s += w[(size_t)i * n] * v[i];
+      return s;
+    }
     const float *w = wm + (size_t)tid * n;
     float s = 0.f;
     if ((n & 3) == 0 && (reinterpret_cast<size_t>(wm) & 15) == 0) {
@@ -163,12 +179,12 @@ __global__ __launch_bounds__(kThreads) void pool_head_kernel(pcr_head_params p) 
     }
     return s;
   };
-  if (tid < n) y[tid] = matvec(p.w1, x);
+  if (tid < n) y[tid] = matvec(p.w1, p.w1t, x);
   __syncthreads();
   vec_groupnorm(y, n, p.groups, p.gn1_g, p.gn1_b);
   if (tid < n) y[tid] = fmaxf(y[tid], 0.f);
   __syncthreads();
-  if (tid < n) z[tid] = matvec(p.w2, y);
+  if (tid < n) z[tid] = matvec(p.w2, p.w2t, y);
   __syncthreads();
   vec_groupnorm(z, n, p.groups, p.gn2_g, p.gn2_b);
   float part = 0.f;

@@ -127,7 +127,7 @@ class HeadParams(ctypes.Structure):
                 ("o", c_float_p), ("w1", c_float_p), ("w2", c_float_p),
                 ("gn1_g", c_float_p), ("gn1_b", c_float_p), ("gn2_g", c_float_p), ("gn2_b", c_float_p),
                 ("w_out", c_float_p), ("b_out", c_float_p),
-                ("pooled", c_float_p), ("logits", c_float_p)]
+                ("pooled", c_float_p), ("logits", c_float_p), ("w1t", c_float_p), ("w2t", c_float_p)]
 
 
 def _p(t):
@@ -477,7 +477,9 @@ class HeadPlan:
         self.t = dict(w1=_dev32(linres.linear1.weight, device), w2=_dev32(linres.linear2.weight, device),
                       gn1_g=_dev32(linres.norm1.weight, device), gn1_b=_dev32(linres.norm1.bias, device),
                       gn2_g=_dev32(linres.norm2.weight, device), gn2_b=_dev32(linres.norm2.bias, device),
-                      w_out=_dev32(out_linear.weight, device), b_out=_dev32(out_linear.bias, device))
+                      w_out=_dev32(out_linear.weight, device), b_out=_dev32(out_linear.bias, device),
+                      w1t=_dev32(linres.linear1.weight.detach().t().contiguous(), device),
+                      w2t=_dev32(linres.linear2.weight.detach().t().contiguous(), device))
 
     def run(self, o, want_pooled=False):
         """o (2P, C, L): clouds p and p+P are pair p -> logits (P) [, pooled (P,2C)]"""
