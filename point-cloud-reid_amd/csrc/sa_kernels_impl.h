@@ -507,54 +507,67 @@ struct SasBlock {
     // ---- layer 1, one cout block at a time (the gathers of a block: 4 sixteen-byte pieces of the neighbour's row).
     // The 128-channel form has the registers (200 of its 256) to request ALL 16 pieces before the first block's MFMAs
     // instead of block by block -- four L2 round trips in a row were 30 % of its block (tools/trace_stream.py)
+    // (has_q / pq are launch constants: the three cases are separate straight-line bodies behind wave-uniform branches --
+    // as per-element selects they were 72 v_cndmask of a 64-channel block's 730 VALU instructions)
     constexpr bool kAllP = NCB >= 4;
-    f32x4 ppa[kAllP ? NCB : 1][4];
-    if constexpr (kAllP) {
+    auto layer1 = [&](auto hq_tag, auto pq_tag) __attribute__((always_inline)) {
+      constexpr bool HQ = decltype(hq_tag)::value, PQ = decltype(pq_tag)::value;
+      f32x4 ppa[kAllP ? NCB : 1][4];
+      if constexpr (kAllP && PQ) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+          const float *pr = pq + (size_t)i * pqw + cb * 32 + 4 * h;
+#pragma unroll
+          for (int g = 0; g < 4; g++) ppa[cb][g] = *reinterpret_cast<const f32x4 *>(pr + 8 * g);
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+          for (int g = 0; g < 4; g++) asm volatile("" : "+v"(ppa[cb][g]));   // (the loads land here, not before each use)
+      }
 #pragma unroll
       for (int cb = 0; cb < NCB; cb++) {
-        const float *pr = pq ? pq + (size_t)i * pqw + cb * 32 + 4 * h : nullptr;
+        f32x4 pp[4];
+        if constexpr (PQ) {
+          const float *pr = pq + (size_t)i * pqw + cb * 32 + 4 * h;
 #pragma unroll
-        for (int g = 0; g < 4; g++) ppa[cb][g] = pr ? *reinterpret_cast<const f32x4 *>(pr + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+          for (int g = 0; g < 4; g++) {
+            if constexpr (kAllP) pp[g] = ppa[cb][g];
+            else pp[g] = *reinterpret_cast<const f32x4 *>(pr + 8 * g);
+          }
+        }
+        f32x16 acc;
 #pragma unroll
-      for (int cb = 0; cb < NCB; cb++)
+        for (int g = 0; g < 4; g++) {
+          const f32x4 s4 = cvec(s_sh1, cb, g);
 #pragma unroll
-        for (int g = 0; g < 4; g++) asm volatile("" : "+v"(ppa[cb][g]));   // (the loads land here, not before each use)
-    }
+          for (int q2 = 0; q2 < 4; q2++) {
+            if constexpr (HQ) acc[4 * g + q2] = s4[q2] + row_bcast_f32(qv[q2], 4 * cb + g);   // row_newbcast: lane 4 cb + g of the row
+            else acc[4 * g + q2] = s4[q2];
+          }
+        }
+        const f32x4 av = s_wa[cb * 64 + j * 2 + h];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], b1, acc, 0, 0, 0);
 #pragma unroll
-    for (int cb = 0; cb < NCB; cb++) {
-      f32x4 pp[4];
-      const float *pr = pq ? pq + (size_t)i * pqw + cb * 32 + 4 * h : nullptr;
+        for (int G = 0; G < 2; G++) {
+          float v[8];
 #pragma unroll
-      for (int g = 0; g < 4; g++) {
-        if constexpr (kAllP) pp[g] = ppa[cb][g];
-        else pp[g] = pr ? *reinterpret_cast<const f32x4 *>(pr + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      f32x16 acc;
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const f32x4 s4 = cvec(s_sh1, cb, g);
-#pragma unroll
-        for (int q2 = 0; q2 < 4; q2++) {
-          // row_newbcast: lane 4 cb + g of the row
-          const float qb = row_bcast_f32(qv[q2], 4 * cb + g);
-          acc[4 * g + q2] = has_q ? s4[q2] + qb : s4[q2];
+          for (int e = 0; e < 8; e++) {
+            const int rr = 8 * G + e;
+            float t = acc[rr];
+            if constexpr (PQ) t = acc[rr] + pp[rr >> 2][rr & 3];
+            v[e] = relu_bits(t);
+          }
+          bf_split8(v, bh[2 * cb + G], bl[2 * cb + G], LO);
         }
       }
-      const f32x4 av = s_wa[cb * 64 + j * 2 + h];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], b0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], b1, acc, 0, 0, 0);
-#pragma unroll
-      for (int G = 0; G < 2; G++) {
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-          const int rr = 8 * G + e;
-          const float t = pq ? acc[rr] + pp[rr >> 2][rr & 3] : acc[rr];
-          v[e] = relu_bits(t);
-        }
-        bf_split8(v, bh[2 * cb + G], bl[2 * cb + G], LO);
-      }
+    };
+    if (pq) {
+      if (has_q) layer1(std::true_type{}, std::true_type{});
+      else layer1(std::false_type{}, std::true_type{});
+    } else {
+      layer1(std::false_type{}, std::false_type{});
     }
     PCR_BMARK(6);
     // ---- layer 2 (normal orientation: its accumulators convert into layer 3's operand)
@@ -655,7 +668,7 @@ __device__ __forceinline__ void sas_stage(float *smem, const float *wp2, const f
 }
 
 template <int NCB, int NCB3, bool LO>
-__global__ __launch_bounds__(64 * kSasWaves) __attribute__((amdgpu_waves_per_eu(2, (NCB + NCB3 >= 6) ? 2 : 4)))
+__global__ __launch_bounds__(64 * kSasWaves) __attribute__((amdgpu_waves_per_eu((NCB + NCB3 >= 6) ? 2 : 4, (NCB + NCB3 >= 6) ? 2 : 4)))
 void sa_stream_kernel(Sa2Args a, int nblk_item, int ncen_item) {
   using L = SasLds<NCB, NCB3>;
   constexpr int C = L::C, C3 = L::C3;
