@@ -359,7 +359,7 @@ def graph_step(fn):
             te = pilot(fn)                          # (BEFORE the capture: the first eager calls after one are not the steady state)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # (other threads -- RCCL's watchdog -- may call HIP meanwhile)
                 out = fn()
             g.replay()
             torch.cuda.synchronize()

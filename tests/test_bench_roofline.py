@@ -108,3 +108,20 @@ def test_bench_quotes_pmc_only_from_a_profile_of_the_same_mode_and_arithmetic(tm
     assert roof["mfma_pipe_busy_pmc"] == 0.363 and roof["traffic"] == pytest.approx(1.877e9 / 2)
     wrong = bench.attach_pmc({"kernel": SA2, "kernel_arithmetic": "f32", "traffic": None}, "ssg1024", 2048, "f32")
     assert wrong["traffic"] is None
+
+
+def test_graph_step_falls_back_to_the_eager_callable(monkeypatch):
+    """bench.graph_step is an optimisation of the measurement: without a device to capture on (this box), or with
+    PCR_BENCH_GRAPH=0, it must hand back the callable it was given and say why"""
+    import bench
+    calls = []
+
+    def fn():
+        calls.append(1)
+        import torch
+        return torch.zeros(3)
+    got, mode = bench.graph_step(fn)
+    assert got is fn and mode.startswith("eager"), mode
+    monkeypatch.setenv("PCR_BENCH_GRAPH", "0")
+    got, mode = bench.graph_step(fn)
+    assert got is fn and mode == "eager: PCR_BENCH_GRAPH=0"
