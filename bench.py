@@ -44,7 +44,8 @@ WORKLOADS = {
     "pt128": ("Point-Transformer ReIDNet (reid_nuscenes_pts/testing_pts_point-transformer_r_nus_det_500e.py), "
               "128-pt synthetic pairs, eval", "pt", 128, [128, 64, 32], 512),
     "ssg1024": ("PointNet++ SSG siamese (BASELINE config 2; SA(512,r.2,K32,[64,64,128]) -> SA(128,r.4,K64,[128,128,256]) "
-                "-> Conv1d 64; D-FPS + ball query), 1024-pt synthetic pairs, eval", "ssg", 1024, None, 2048),
+                "-> Conv1d 64; D-FPS + ball query), 1024-pt synthetic pairs, eval", "ssg", 1024, None, 4096),   # (2048 until
+    # the end of round 4: 4096 pairs per pass measure 4-5 % more pairs/s -- launch tails amortised -- 8192 fewer again)
     "pointnet256": ("PointNet ReIDNet (configs_reid/_base_/reidentifiers/reid_pts_pointnet_point-cat.py), 256-pt "
                     "synthetic pairs, eval (BASELINE config 1 shape)", "pointnet", 256, None, 256),
     "gallery128": ("amortised gallery matching (SURVEY 8f rank 1; forward_inference ReIDNet.py:189-191 + "
