@@ -47,7 +47,8 @@ WORKLOADS = {
                 "-> Conv1d 64; D-FPS + ball query), 1024-pt synthetic pairs, eval", "ssg", 1024, None, 4096),   # (2048 until
     # the end of round 4: 4096 pairs per pass measure 4-5 % more pairs/s -- launch tails amortised -- 8192 fewer again)
     "pointnet256": ("PointNet ReIDNet (configs_reid/_base_/reidentifiers/reid_pts_pointnet_point-cat.py), 256-pt "
-                    "synthetic pairs, eval (BASELINE config 1 shape)", "pointnet", 256, None, 256),
+                    "synthetic pairs, eval (BASELINE config 1 shape)", "pointnet", 256, None, 1024),   # (256 pairs per pass until the end
+    # of round 4: 62.9 k pairs/s at 256, 67.0 k at 512, 71.2 k at 1024 on one box)
     "gallery128": ("amortised gallery matching (SURVEY 8f rank 1; forward_inference ReIDNet.py:189-191 + "
                    "match_forward_inference :444-462, the tracker use-case): G tracks x G detections of 128 pts -- every "
                    "object is encoded ONCE, then all G*G combinations go through the matching head (match_gallery); "

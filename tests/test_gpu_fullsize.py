@@ -20,7 +20,7 @@ def _logits(model, s1, s2):
         return bench.hot_path(model, s1, s2)
 
 
-@pytest.mark.parametrize("workload,pairs,group", [("ssg1024", 4096, 64), ("pt1024", 512, 32), ("pointnet256", 256, 16),
+@pytest.mark.parametrize("workload,pairs,group", [("ssg1024", 4096, 64), ("pt1024", 512, 32), ("pointnet256", 1024, 16),
                                                   ("dgcnn128", 512, 32), ("dgcnn1024", 128, 8),
                                                   ("pt4096", 256, 8)])      # BASELINE config 5: 256 pairs/GPU @4096
 def test_bench_batch_equals_small_groups(workload, pairs, group):
