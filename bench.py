@@ -335,30 +335,36 @@ def clock_probe(iters=20000):
 _PREWARMED = False
 
 
+LAST_PILOT = {}              # {"eager_ms": .., "hipgraph_ms": ..} of the last graph_step() (both go into the record)
+
+
 def graph_step(fn):
     """fn (a forward pass over resident inputs, no host round trip inside) captured ONCE into a HIP graph and replayed:
     -> (callable returning fn's output tensor, "hipgraph") or (fn, "eager: <why>").  Same launches, same bits -- the
     replay is checked against an eager call before it is used -- but the step no longer depends on how fast this box's
-    host can issue ~25 launches and their tensor allocations: on a loaded host of the pool the eager headline step
-    measured 6.7 ms against 5.1 (round 4; the launch-heavy PointNet line 7.6 against 4.0, pt128 5.7 against 1.6).  A
-    three-step pilot of both ways (inside the untimed part) picks the faster one for this box.  PCR_BENCH_GRAPH=0 keeps
-    the eager loop."""
-    if os.environ.get("PCR_BENCH_GRAPH", "1") == "0":
-        return fn, "eager: PCR_BENCH_GRAPH=0"
+    host can issue ~25 launches and their tensor allocations (a loaded host of the pool: 6.7 ms eager against 5.1).
+    The mode is FIXED, never picked by a race: PCR_BENCH_GRAPH=1 (the default) times the replay, PCR_BENCH_GRAPH=0 the
+    eager loop; an untimed three-step pilot of BOTH ways is recorded beside the result (LAST_PILOT -> config.eager_ms /
+    config.hipgraph_ms) so that lines of either mode stay comparable."""
+    LAST_PILOT.clear()
+    want_graph = os.environ.get("PCR_BENCH_GRAPH", "1") != "0"
+
+    def pilot(f, n=3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for _ in range(n):
+                f()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
     try:
-        def pilot(f, n=3):                          # (untimed by the contract: which way does THIS box issue the step faster?)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            with torch.no_grad():
-                for _ in range(n):
-                    f()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / n * 1e3
+        if not torch.cuda.is_available():
+            raise RuntimeError("no device to capture on")
         with torch.no_grad():
             ref = None
             for _ in range(2):                      # lazy plans, LDS attributes, allocator pools: all set up eagerly
                 ref = fn()
-            te = pilot(fn)                          # (BEFORE the capture: the first eager calls after one are not the steady state)
+            LAST_PILOT["eager_ms"] = pilot(fn)      # (BEFORE the capture: the first eager calls after one are not the steady state)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):   # (other threads -- RCCL's watchdog -- may call HIP meanwhile)
@@ -372,16 +378,18 @@ def graph_step(fn):
             g.replay()
             return out
         run._graph = g
-        tg = pilot(run)
-        if te < tg:                                 # a quiet host overlaps the launches' tails slightly better than a replay
+        LAST_PILOT["hipgraph_ms"] = pilot(run)
+        if not want_graph:
             del run, g
-            return fn, "eager (pilot: eager %.3f ms, hipgraph %.3f ms per step)" % (te, tg)
-        return run, "hipgraph (pilot: eager %.3f ms, hipgraph %.3f ms per step)" % (te, tg)
+            return fn, "eager: PCR_BENCH_GRAPH=0"
+        return run, "hipgraph"
     except Exception as e:                          # (capture is an optimisation of the MEASUREMENT, never a requirement)
         try:
             torch.cuda.synchronize()
         except Exception:
             pass
+        if not want_graph:
+            return fn, "eager: PCR_BENCH_GRAPH=0"
         return fn, "eager: capture failed (%s: %s)" % (type(e).__name__, str(e)[:120])
 
 
@@ -544,6 +552,7 @@ def measure(workload, args, rank, world, pairs=None, cloud_kind=None, skip_repea
     s1, s2 = s1.cuda(), s2.cuda()
     prewarm()
     step_fn, launch_mode = graph_step(lambda: hot_path(model, s1, s2))
+    pilot_ms = {k: round(v, 4) for k, v in LAST_PILOT.items()}
     with torch.no_grad():
         dt, out = shard.timed(step_fn, steps, warmup, sync=torch.cuda.synchronize, device="cuda")
     assert torch.isfinite(out).all()
@@ -568,8 +577,8 @@ def measure(workload, args, rank, world, pairs=None, cloud_kind=None, skip_repea
                    config={"workload": "%s: %s" % (workload, desc), "pairs_per_gpu_per_step": pairs, "points": n,
                            "backbone_list": bl, "parallelism": "independent pair shards x%d" % world,
                            "rccl_ranks": world,
-                           "precision": precision_text(engine.PRECISION),
-                           "launch": launch_mode},
+                           "precision": precision_text(engine.PRECISION), "precision_tag": engine.PRECISION,
+                           "launch": launch_mode, **pilot_ms},
                    roofline=roof)
         if kind == "ssg":
             rec["config"]["fill"] = ssg_fill(model, s1)
@@ -604,6 +613,7 @@ def gallery_bench(args, desc, n, bl, pairs, rank, world, steps=None, warmup=None
         return model.match_gallery(h, xyz, combos)
     prewarm()
     step_fn, launch_mode = graph_step(step)
+    pilot_ms = {k: round(v, 4) for k, v in LAST_PILOT.items()}
     with torch.no_grad():
         dt, out = shard.timed(step_fn, steps, warmup, sync=torch.cuda.synchronize, device="cuda")
     assert torch.isfinite(out).all() and out.numel() == P
@@ -620,7 +630,7 @@ def gallery_bench(args, desc, n, bl, pairs, rank, world, steps=None, warmup=None
                 "data": "synthetic (randn clouds, seeded random-init weights with non-trivial BN statistics)",
                 "config": {"workload": "gallery128: %s" % desc, "precision": precision_text(engine.PRECISION), "pairs_per_gpu_per_step": P, "objects_per_gpu_per_step": 2 * G,
                            "points": n, "backbone_list": bl, "parallelism": "independent galleries x%d" % world,
-                           "rccl_ranks": world, "launch": launch_mode},
+                           "rccl_ranks": world, "launch": launch_mode, "precision_tag": engine.PRECISION, **pilot_ms},
                 "roofline": roof}
         if cpu and world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = gallery_cpu_baseline(sd, n, bl, G)
@@ -629,11 +639,116 @@ def gallery_bench(args, desc, n, bl, pairs, rank, world, steps=None, warmup=None
     return line
 
 
+COMPACT_LIMIT = 8000        # bytes of the LAST stdout line (the driver's parser lost a 27 KB line in round 4; target <= 4 KB)
+FULL_RECORD = "bench_full.json"
+
+
+def _r(x, nd=4):
+    return round(x, nd) if isinstance(x, float) else x
+
+
+def compact_roofline(roof):
+    """the contract's roofline object (bound / achieved / peak / unit / frac / traffic) plus the few figures needed to
+    re-derive it; the prose (`clock_source`, `traffic_source`) and the long per-launch maps stay in the full record"""
+    if not roof:
+        return roof
+    keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_per_step",
+            "kernel_arithmetic", "mfma_per_product", "issued_gflop_per_launch", "algorithmic_mb_per_launch",
+            "algorithmic_gflop_per_launch", "mfma_pipe_busy_pmc", "share_of_step", "clock_ghz", "valu_issue")
+    out = {k: _r(roof[k]) for k in keep if k in roof}
+    out.setdefault("traffic", None)
+    per = roof.get("per_kernel_ms") or roof.get("profiled_kernels_ms")
+    if per:
+        out["per_kernel_ms"] = {k: _r(v, 3) for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:10]}
+    return out
+
+
+def compact_config(cfg):
+    keep = ("pairs_per_gpu_per_step", "objects_per_gpu_per_step", "points", "rccl_ranks", "skip_repeats", "eager_ms",
+            "hipgraph_ms", "guard")
+    out = {"workload": str(cfg.get("workload", ""))[:110]}
+    out.update({k: _r(cfg[k], 3) for k in keep if k in cfg})
+    if "launch" in cfg:
+        out["launch"] = str(cfg["launch"]).split(" ")[0].rstrip(":")
+    if "precision_tag" in cfg:
+        out["precision"] = cfg["precision_tag"]
+    if isinstance(cfg.get("fill"), dict):
+        out["fill"] = {k: _r(v["fill"], 3) for k, v in cfg["fill"].items()}
+    if "parallelism" in cfg:
+        out["parallelism"] = str(cfg["parallelism"])[:80]
+    return out
+
+
+def compact_also(rec):
+    if "error" in rec:
+        return {"name": rec.get("name"), "error": str(rec["error"])[:160]}
+    roof = rec.get("roofline") or {}
+    out = {"name": rec.get("name"), "value": _r(rec.get("value"), 1), "unit": rec.get("unit"),
+           "ms_per_step": _r(rec.get("ms_per_step"), 3), "dtype": str(rec.get("dtype"))[:16],
+           "pairs": (rec.get("config") or {}).get("pairs_per_gpu_per_step"),
+           "kernel": str(roof.get("kernel", "")).split("[")[0], "bound": roof.get("bound"), "frac": _r(roof.get("frac"), 3)}
+    if rec.get("n_gpus", 1) != 1:
+        out["n_gpus"] = rec["n_gpus"]
+    if "mfma_pipe_busy_pmc" in roof:
+        out["mfma_pipe_busy_pmc"] = _r(roof["mfma_pipe_busy_pmc"], 3)
+    if "max_abs_dlogit_vs_f32_path" in rec:
+        out["dlogit_vs_f32"] = float("%.2e" % rec["max_abs_dlogit_vs_f32_path"])
+    return out
+
+
+def compact_line(full):
+    """full record (everything measured) -> the ONE line the contract asks for, a few KB: headline fields, the headline's
+    roofline, cpu_baseline, companions as {name, value, unit, ms_per_step, dtype, frac, ..}.  Pure (CPU-tested)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data")
+    line = {k: full[k] for k in keep if k in full}
+    line["data"] = str(line.get("data", ""))[:110]
+    line["config"] = compact_config(full.get("config", {}))
+    line["roofline"] = compact_roofline(full.get("roofline"))
+    if "cpu_baseline" in full:
+        cb = dict(full["cpu_baseline"])
+        cb["sample"] = str(cb.get("sample", ""))[:110]
+        cb["value"] = _r(cb.get("value"), 3)
+        line["cpu_baseline"] = cb
+    if "max_abs_dlogit_vs_f32_path" in full:
+        line["max_abs_dlogit_vs_f32_path"] = full["max_abs_dlogit_vs_f32_path"]
+    if "per_rank_ms_per_step" in full and len(full["per_rank_ms_per_step"]) > 1:
+        line["per_rank_ms_per_step"] = list(full["per_rank_ms_per_step"])
+    if full.get("also"):
+        line["also"] = [compact_also(a) for a in full["also"]]
+    line["full_record"] = FULL_RECORD
+    return line
+
+
+def emit(full, out=None, err=None):
+    """the FULL record goes to bench_full.json beside this file (and to stderr, one line, prefixed); the LAST stdout line
+    is the compact record.  Nothing is printed after it."""
+    out = out or sys.stdout
+    err = err or sys.stderr
+    blob = json.dumps(full)
+    try:
+        with open(os.path.join(ROOT, FULL_RECORD), "w") as f:
+            f.write(blob + "\n")
+    except OSError:
+        pass
+    err.write("bench full record: " + blob + "\n")
+    err.flush()
+    line = json.dumps(compact_line(full))
+    if len(line) >= COMPACT_LIMIT:                  # never lose the headline to a parser again: drop the companions first
+        slim = compact_line(full)
+        slim["also"] = [{"name": a.get("name"), "value": a.get("value"), "ms_per_step": a.get("ms_per_step")}
+                        for a in slim.get("also", [])]
+        slim["roofline"].pop("per_kernel_ms", None)
+        line = json.dumps(slim)
+    out.write(line + "\n")
+    out.flush()
+
+
 def finish(line, rank):
     """rank 0 prints the ONE JSON line; every rank leaves the process group"""
     from pcr_amd import shard
     if rank == 0 and line is not None:
-        print(json.dumps(line), flush=True)
+        emit(line)
     if shard.is_dist():
         import torch.distributed as dist
         dist.barrier()
@@ -760,13 +875,26 @@ def main():
                       skip_repeats=not args.full_groups)
     default_run = (args.workload == "ssg1024" and not args.pairs and not args.clouds and not args.full_groups)
     also = []
+    if default_run and world > 1 and not args.no_also:
+        # N > 1: the inference headline has no collective at all, so a scaling run would never exercise the gradient
+        # all-reduce north_star names (reference: mmdet3d/apis/train.py:35-56).  The training companion (BASELINE config 4:
+        # forward + backward + ONE flat-bucket RCCL all-reduce + clip + AdamW) therefore runs on every rank here too.
+        d, _, n_, bl_, p_ = WORKLOADS["pt128_train"]
+        try:
+            r = train_bench(args, d, n_, bl_, p_, rank, world)
+        except Exception as e:
+            r = {"error": "%s: %s" % (type(e).__name__, e)}
+        if r is not None:
+            r["name"] = "pt128_train"
+            also.append(r)
     if default_run and world == 1 and not args.no_also:
         # The headline workload's uniform box clouds leave the ball-query groups nearly empty (config.fill), and
         # the ragged SA kernel skips the repeated rows.  Beside it, in the same run: the same model on clouds
         # with 50 % duplicated points, on crops of 32..512 surface returns resampled to 1024 WITH replacement (what the
         # reference's subsamplePC hands the model: fuller groups), the same model evaluating all K rows of every group, and the reference's own 1024-pt Point-Transformer
         # config (BASELINE configs[2]; kNN groups, always full).
-        for name, wl, kw in (("ssg1024_f32", "ssg1024", dict(precision="f32")),
+        for name, wl, kw in (("ssg1024_b2048", "ssg1024", dict(pairs=2048)),     # (the batch of rounds 3-4: comparable across rounds)
+                             ("ssg1024_f32", "ssg1024", dict(precision="f32")),
                              ("ssg1024_bf16", "ssg1024", dict(precision="bf16")),
                              ("ssg1024_dup", "ssg1024", dict(cloud_kind="dup")),
                              ("ssg1024_crop", "ssg1024", dict(cloud_kind="crop")),
@@ -807,7 +935,7 @@ def main():
             line["also"] = also
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, sd)
-        print(json.dumps(line), flush=True)
+        emit(line)
     if shard.is_dist():
         import torch.distributed as dist
         dist.barrier()

@@ -249,7 +249,7 @@ class BasePointSAModule(nn.Module):
                 raise L.PcrError("GroupAll scales are not on the ReID path")
             plan = self._plan(i, points_xyz.device)
             if (self.skip_repeats and not _NO_ROW_TABLE and grouper.max_radius is not None and not grouper.min_radius and
-                    plan.wants_row_table(points_xyz.shape[1], grouper.sample_num, 0.0)):
+                    plan.wants_row_table(points_xyz.shape[1], grouper.sample_num, 0.0, points_xyz.shape[0], new_xyz.shape[1])):
                 # the ball query hands the SA kernel its rows ready-made ({neighbour, point - centre}); no index tensor
                 _, cnt, rows = ball_query_rows(grouper.max_radius, grouper.sample_num, points_xyz, new_xyz)
                 outs.append(plan.run(points_xyz, features, None, centre_idx=indices.contiguous(), cnt=cnt, rows=rows,

@@ -242,9 +242,14 @@ class SaPlan:
             self.wpq = pack_weight(stacked.float(), device)
             self.wpq_bf = pack_weight_bf(stacked.float(), device)
 
-    def wants_row_table(self, N, K, min_radius):
-        """does the ragged launch of this layer read the ball query's row table (ops.ball_query_rows)?"""
+    def wants_row_table(self, N, K, min_radius, B=1, S=1):
+        """does the ragged launch of this layer read the ball query's row table (ops.ball_query_rows)?  Everything the
+        library's own dispatch (sa2_try / sas_shape_ok) looks at besides the shape is honoured here too -- the
+        PCR_SA_NO_STREAM diagnostic and the 32-bit centre count -- so that a caller which drops its index tensor on this
+        answer is never refused by the launch."""
         lib = L.load()
+        if os.environ.get("PCR_SA_NO_STREAM") or int(B) * int(S) >= 2 ** 31:
+            return False
         return bool(self.fast and self.mode == 1 and lib.pcr_ball_query_rows_ok(N, K, ctypes.c_float(min_radius or 0.0)) and
                     lib.pcr_sa_uses_row_table(self.couts[0], self.couts[1], self.couts[2], K, PRECISIONS[PRECISION]))
 
@@ -257,9 +262,9 @@ class SaPlan:
         are written as one run; our own consumers read that layout directly)."""
         B, N, _ = xyz.shape
         if rows is not None:
-            assert cnt is not None and self.wants_row_table(N, K, 0.0), "row table given to a layer that does not read it"
-            L.require_cuda(xyz, cnt, rows)
             S = cnt.shape[1]
+            assert cnt is not None and self.wants_row_table(N, K, 0.0, B, S), "row table given to a layer that does not read it"
+            L.require_cuda(xyz, cnt, rows)
             assert rows.is_contiguous() and rows.numel() == L.load().pcr_ball_query_rows_floats(B, S, K)
         else:
             L.require_cuda(xyz, idx)

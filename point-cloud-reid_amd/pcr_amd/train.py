@@ -250,13 +250,15 @@ class Trainer:
         element of every list input, the values of the non-tensor inputs, the arithmetic mode, the model's mode and
         which parameters take gradients.  None: the batch holds something a replay cannot refresh (a bare tensor is read
         at a captured address; a ragged list cannot be stacked)."""
-        from . import engine
+        from . import engine, train_ops
         sig = []
         for k in sorted(data):
             v = data[k]
             if k in keys:
+                if not all(torch.is_tensor(t) for t in v):
+                    return None
                 shapes = {(tuple(t.shape), t.dtype, t.device) for t in v}
-                if len(shapes) != 1 or not all(torch.is_tensor(t) for t in v):
+                if len(shapes) != 1:
                     return None
                 sig.append((k, len(v), shapes.pop()))
             elif v is None or isinstance(v, (bool, int, float, str)):
@@ -265,7 +267,8 @@ class Trainer:
                 sig.append((k, type(v).__name__, tuple(v)))
             else:
                 return None
-        sig.append(("precision", engine.PRECISION, "training", self.model.training,
+        sig.append(("precision", engine.PRECISION, "train_precision", train_ops.TRAIN_PRECISION,
+                    "training", self.model.training,
                     "requires_grad", tuple(p.requires_grad for p in self.model.parameters()),
                     "stream_min_blocks", getattr(engine, "STREAM_MIN_BLOCKS", None)))
         return tuple(sig)

@@ -112,8 +112,9 @@ def test_bench_quotes_pmc_only_from_a_profile_of_the_same_mode_and_arithmetic(tm
 
 def test_graph_step_falls_back_to_the_eager_callable(monkeypatch):
     """bench.graph_step is an optimisation of the measurement: without a device to capture on (this box), or with
-    PCR_BENCH_GRAPH=0, it must hand back the callable it was given and say why"""
-    import bench
+    PCR_BENCH_GRAPH=0, it must hand back the callable it was given and say why; the mode is fixed by the environment,
+    never by which way a pilot ran faster"""
+    import inspect
     calls = []
 
     def fn():
@@ -125,3 +126,82 @@ def test_graph_step_falls_back_to_the_eager_callable(monkeypatch):
     monkeypatch.setenv("PCR_BENCH_GRAPH", "0")
     got, mode = bench.graph_step(fn)
     assert got is fn and mode == "eager: PCR_BENCH_GRAPH=0"
+    src = inspect.getsource(bench.graph_step)
+    assert "te < tg" not in src and "want_graph" in src
+
+
+# ---- the line the driver parses (a 27 KB line came back `parsed: null`) -----------------------------
+def _full_record(n_also=12):
+    """a default-run record the size of round 4's: long prose in every companion, per-kernel maps, PMC sources"""
+    prose = bench.precision_text("bf16x3")
+    per = {"kernel_%02d[D=128,c=128/128/256,N=512,S=128,K=64]" % i: 0.123456789 * (i + 1) for i in range(14)}
+
+    def roof(kernel):
+        return {"kernel": kernel, "bound": "mfma", "achieved": 884.123456789, "peak": 2500.0, "unit": "TFLOP/s",
+                "avg_launch_ms": 2.8971234, "launches_per_step": 1, "traffic": 3.38e9, "kernel_arithmetic": "bf16x3",
+                "mfma_per_product": 3, "product_tflops": 294.7, "product_frac_of_f32_mfma_peak": 1.87,
+                "issued_gflop_per_launch": 2561.8, "reference_op_gflop_per_launch": 8847.6, "reference_op_tflops": 3054.0,
+                "share_of_step": 0.3078, "per_kernel_ms": per, "frac": 0.3536, "traffic_source": "profiles/x.json (k)" * 3,
+                "mfma_pipe_busy_pmc": 0.5151, "pmc_launch_ms": 2.93, "clock_ghz": 2.37, "clock_source": "probe " * 60}
+
+    def comp(name):
+        return {"value": 57512.123, "unit": "pairs/s", "steps": 20, "warmup": 5, "ms_per_step": 8.9023, "name": name,
+                "per_rank_ms_per_step": [8.9023], "dtype": "bf16x3", "max_abs_dlogit_vs_f32_path": 2.2e-5,
+                "data": "synthetic " * 9, "metric": "siamese pair-comparisons/sec @1024 pts",
+                "config": {"workload": "%s: %s" % (name, "description " * 30), "pairs_per_gpu_per_step": 512,
+                           "points": 1024, "backbone_list": [1024, 512, 256], "parallelism": "independent pair shards x1",
+                           "rccl_ranks": 1, "precision": prose, "precision_tag": "bf16x3", "launch": "hipgraph",
+                           "eager_ms": 8.95, "hipgraph_ms": 8.9, "fill": "kNN groups: every row genuine " * 3},
+                "roofline": roof("sa_fused[D=64,c=128/128/128,N=512,S=256,K=48]")}
+    full = comp("ssg1024")
+    del full["name"]
+    full.update(n_gpus=1, higher_is_better=True, scaling="weak", vs_baseline=None,
+                roofline=roof("sa_ragged[D=128,c=128/128/256,N=512,S=128,K=64]"))
+    full["config"]["fill"] = {"sa1": {"K": 32, "radius": 0.2, "mean_hits": 2.86, "fill": 0.0894},
+                              "sa2": {"K": 64, "radius": 0.4, "mean_hits": 7.78, "fill": 0.1216}}
+    full["also"] = [comp("companion_%d" % i) for i in range(n_also - 1)] + [{"name": "broken", "error": "E: " + "x" * 900}]
+    full["cpu_baseline"] = {"value": 21.1, "unit": "pairs/s", "cores": 32, "kind": "port", "sample": "8 pairs " * 40}
+    return full
+
+
+def test_the_last_stdout_line_is_compact_and_complete():
+    import io
+    full = _full_record()
+    assert len(json.dumps(full)) > 25000                       # (the size that was lost)
+    out, err = io.StringIO(), io.StringIO()
+    bench.emit(full, out=out, err=err)
+    lines = out.getvalue().splitlines()
+    assert len(lines) == 1                                     # ONE stdout line, and it is the last thing printed
+    assert len(lines[0]) < bench.COMPACT_LIMIT and len(lines[0]) < 5500
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["config"]["workload"].startswith("ssg1024") and d["config"]["pairs_per_gpu_per_step"] == 512
+    assert d["config"]["launch"] == "hipgraph" and d["config"]["precision"] == "bf16x3"
+    assert d["config"]["fill"] == {"sa1": 0.089, "sa2": 0.122}
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    assert d["roofline"]["frac"] == pytest.approx(full["roofline"]["achieved"] / full["roofline"]["peak"], abs=1e-3)
+    assert "clock_source" not in d["roofline"] and len(d["roofline"]["per_kernel_ms"]) <= 10
+    assert {k for k in ("value", "unit", "cores", "kind", "sample")} <= set(d["cpu_baseline"])
+    assert [a["name"] for a in d["also"]] == [a["name"] for a in full["also"]]
+    a0 = d["also"][0]
+    assert a0["value"] == pytest.approx(57512.1) and a0["ms_per_step"] == 8.902 and a0["frac"] == 0.354
+    assert a0["dtype"] == "bf16x3" and a0["kernel"] == "sa_fused" and "error" in d["also"][-1]
+    # the full record survives beside it: one prefixed stderr line + bench_full.json
+    blob = err.getvalue()
+    assert blob.startswith("bench full record: ") and json.loads(blob[len("bench full record: "):]) == full
+    with open(os.path.join(bench.ROOT, bench.FULL_RECORD)) as f:
+        assert json.load(f) == full
+
+
+def test_an_oversized_record_still_yields_a_parseable_headline():
+    import io
+    full = _full_record(n_also=60)
+    out = io.StringIO()
+    bench.emit(full, out=out, err=io.StringIO())
+    line = out.getvalue().splitlines()[-1]
+    assert len(line) < bench.COMPACT_LIMIT
+    d = json.loads(line)
+    assert d["value"] == full["value"] and d["roofline"]["frac"] and len(d["also"]) == 60

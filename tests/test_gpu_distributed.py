@@ -93,3 +93,27 @@ def test_bench_runs_two_ranks_on_the_gpu(workload):
     # in the line (a straggler shows as a spread; ms_per_step is their maximum)
     assert "also" not in d and "cpu_baseline" not in d
     assert len(d["per_rank_ms_per_step"]) == 2 and max(d["per_rank_ms_per_step"]) == pytest.approx(d["ms_per_step"])
+
+
+def test_default_two_rank_run_carries_the_training_companion():
+    """the default `bench.py --gpus N` line at N > 1 also records the training step (forward + backward +
+    ONE gradient-bucket all-reduce + clip + AdamW on every rank), so that a scaling run exercises the collective
+    north_star names; the last stdout line stays compact"""
+    import json
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PCR_BENCH_TEST_BACKEND="gloo",
+               PCR_BENCH_TEST_SAME_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--steps", "2", "--warmup", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last) < 8000
+    d = json.loads(last)
+    assert d["n_gpus"] == 2 and d["config"]["workload"].startswith("ssg1024") and "cpu_baseline" not in d
+    (tr,) = d["also"]
+    assert tr["name"] == "pt128_train" and tr["n_gpus"] == 2 and tr["value"] > 0 and tr["pairs"] == 256

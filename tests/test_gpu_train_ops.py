@@ -70,6 +70,44 @@ def test_sa_edge_train_matches_torch_autograd(B, N, S, K, D, widths):
             assert _rel(p.float(), q.float()) < 1e-5, k      # running statistics, num_batches_tracked
 
 
+def test_split_bf16_backward_of_the_128_wide_layers_stays_on_the_f32_gradients():
+    """TRAIN_PRECISION defaults to bf16x3 (dx and dW of the 128 x 128 grouped-MLP backward on the bf16 matrix
+    core, three MFMAs per product); set_train_precision('f32') restores the reference's arithmetic.  Both ways on the same
+    inputs: every gradient within 2e-5 of its tensor's scale, and the modes really differ (the switch is live)."""
+    import copy
+    from mmdet3d.models.pointnet2_utils import PointNetSetAbstractionEdgeSA
+    from pcr_amd import engine, train_ops
+    B, N, S, K, D, widths = 2, 64, 32, 48, 64, (128, 128, 128)
+    sa = PointNetSetAbstractionEdgeSA(npoint=None, radius=0.3, nsample=K, mlp=[2 * D] + list(widths),
+                                      sampling="RANDOM", use_xyz=True, use_knn=True)
+    sa.load_state_dict(T.seeded_state_dict(T.manifest_of(sa), 5))
+    xyz = T.synthetic_clouds(B, N, seed=3, kind="randn").cuda()
+    g = torch.Generator().manual_seed(1)
+    feats0 = torch.randn(B, D, N, generator=g).cuda()
+    idx = engine.knn_prefix(xyz, S, K)
+    w = torch.randn(B, widths[2], S, generator=g).cuda()
+    grads = {}
+    prev = train_ops.TRAIN_PRECISION
+    try:
+        for mode in ("f32", "bf16x3"):
+            train_ops.set_train_precision(mode)
+            m = copy.deepcopy(sa).cuda().train()
+            f = feats0.clone().requires_grad_(True)
+            (train_ops.sa_edge_train(m, xyz, f, idx) * w).sum().backward()
+            grads[mode] = dict({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}, feats=f.grad.clone())
+    finally:
+        train_ops.set_train_precision(prev)
+    worst, differ = 0.0, False
+    for k, a in grads["f32"].items():
+        b = grads["bf16x3"][k]
+        if "convs" in k and k.endswith("bias"):      # (zero up to rounding in front of a BatchNorm: no scale to compare on)
+            continue
+        worst = max(worst, _rel(b, a))
+        differ = differ or not torch.equal(a, b)
+    assert worst < 2e-5, worst
+    assert differ
+
+
 def test_train_dense_and_gradients_are_reproducible():
     from pcr_amd import train_ops
     g = torch.Generator().manual_seed(2)

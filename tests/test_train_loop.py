@@ -76,6 +76,23 @@ def test_trainer_single_process_and_checkpoint(tmp_path):
     assert "grad_norm" not in outs3[0] and "grad_norm" in outs3[1]
 
 
+def test_graph_signature_refuses_what_a_replay_cannot_refresh_and_sees_the_training_arithmetic():
+    """a list input with a non-tensor member -> None (eager with a warning), not an AttributeError; the
+    captured iteration's arithmetic (train_ops.TRAIN_PRECISION) is part of the signature"""
+    from pcr_amd import train_ops
+    tr = train.Trainer(Toy(), max_iters=2, lr=1e-2)
+    good = dict(x=[torch.zeros(3), torch.zeros(3)], flag=True)
+    assert tr._graph_signature(good, {"x"}) is not None
+    assert tr._graph_signature(dict(x=[torch.zeros(3), "oops"]), {"x"}) is None
+    assert tr._graph_signature(dict(x=[torch.zeros(3), torch.zeros(4)]), {"x"}) is None
+    a = tr._graph_signature(good, {"x"})
+    prev = train_ops.set_train_precision("f32" if train_ops.TRAIN_PRECISION != "f32" else "bf16x3")
+    try:
+        assert tr._graph_signature(good, {"x"}) != a
+    finally:
+        train_ops.set_train_precision(prev)
+
+
 WORKER = textwrap.dedent("""
     import os, sys
     sys.path.insert(0, os.path.join(%r, "point-cloud-reid_amd"))
