@@ -683,14 +683,16 @@ def compact_also(rec):
     if "error" in rec:
         return {"name": rec.get("name"), "error": str(rec["error"])[:160]}
     roof = rec.get("roofline") or {}
-    out = {"name": rec.get("name"), "value": _r(rec.get("value"), 1), "unit": rec.get("unit"),
-           "ms_per_step": _r(rec.get("ms_per_step"), 3), "dtype": str(rec.get("dtype"))[:16],
+    out = {"name": rec.get("name"), "value": _r(rec.get("value"), 1),
+           "ms_per_step": _r(rec.get("ms_per_step"), 3), "dtype": str(rec.get("dtype")).split(";")[0][:16],
            "pairs": (rec.get("config") or {}).get("pairs_per_gpu_per_step"),
            "kernel": str(roof.get("kernel", "")).split("[")[0], "bound": roof.get("bound"), "frac": _r(roof.get("frac"), 3)}
     if rec.get("n_gpus", 1) != 1:
         out["n_gpus"] = rec["n_gpus"]
+    if rec.get("unit") not in (None, "pairs/s"):
+        out["unit"] = rec["unit"]
     if "mfma_pipe_busy_pmc" in roof:
-        out["mfma_pipe_busy_pmc"] = _r(roof["mfma_pipe_busy_pmc"], 3)
+        out["pipe_busy_pmc"] = _r(roof["mfma_pipe_busy_pmc"], 3)
     if "max_abs_dlogit_vs_f32_path" in rec:
         out["dlogit_vs_f32"] = float("%.2e" % rec["max_abs_dlogit_vs_f32_path"])
     return out
@@ -707,7 +709,7 @@ def compact_line(full):
     line["roofline"] = compact_roofline(full.get("roofline"))
     if "cpu_baseline" in full:
         cb = dict(full["cpu_baseline"])
-        cb["sample"] = str(cb.get("sample", ""))[:110]
+        cb["sample"] = str(cb.get("sample", ""))[:80]
         cb["value"] = _r(cb.get("value"), 3)
         line["cpu_baseline"] = cb
     if "max_abs_dlogit_vs_f32_path" in full:

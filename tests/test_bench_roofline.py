@@ -188,7 +188,7 @@ def test_the_last_stdout_line_is_compact_and_complete():
     assert [a["name"] for a in d["also"]] == [a["name"] for a in full["also"]]
     a0 = d["also"][0]
     assert a0["value"] == pytest.approx(57512.1) and a0["ms_per_step"] == 8.902 and a0["frac"] == 0.354
-    assert a0["dtype"] == "bf16x3" and a0["kernel"] == "sa_fused" and "error" in d["also"][-1]
+    assert a0["dtype"] == "bf16x3" and "unit" not in a0 and a0["kernel"] == "sa_fused" and "error" in d["also"][-1]
     # the full record survives beside it: one prefixed stderr line + bench_full.json
     blob = err.getvalue()
     assert blob.startswith("bench full record: ") and json.loads(blob[len("bench full record: "):]) == full
