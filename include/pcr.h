@@ -610,6 +610,61 @@ typedef struct pcr_linattn {
 int pcr_linattn_fwd_f32(const pcr_linattn *p, pcr_stream_t stream);
 int pcr_linattn_bwd_f32(const pcr_linattn *p, pcr_stream_t stream);
 
+/* Fused per-token chain: the TAIL of an attention block in training mode (round 5, csrc/train_chain_kernels.hip) --
+ * Self_Attention (models/pointnet2_utils.py:105-114), FP_SA (:428-437), corss_attention (models/attention.py:210-219):
+ *   out = LN2(W2 relu(W0 [res ; LN1(Wm msg)])) [+ res]        msg (B,d,L) = the attention core's output, res (B,c1,L)
+ * as ONE forward and ONE backward launch (the unfused graph: merge, norm, two dense layers, norm = 5 + 7 launches and
+ * five partial-sum reductions).  A 64-token tile walks the chain inside LDS; the backward recomputes the chain for its
+ * tile (bit-identically: same code) and keeps nothing but msg and res.  wm / w0 / w2 are pcr_pack_weight images of merge
+ * (d,d), mlp[0] (hid, c1+d), mlp[2] (out,hid); w*T of their transposes; g1 b1 (d), g2 b2 (out) the LayerNorm affines;
+ * residual needs out == c1.  Backward outputs: dmsg (B,d,L), dres (B,c1,L) and per-workgroup partial records
+ * [pcr_attn_tail_groups][part_stride >= pcr_attn_tail_part_floats] =
+ *   dWm [d][d] | dW0 [hid][ceil32(c1+d)] | dW2 [out][hid] | dgamma1 [d] | dbeta1 [d] | dgamma2 [out] | dbeta2 [out]
+ * to be summed by pcr_reduce_parts_f32 (fixed order: gradients are bit-identical from run to run).
+ * pcr_attn_tail_ok: is (d, c1, hid, out) one of the instantiated shapes (the reference's mul = 1 blocks with d <= 64)? */
+typedef struct pcr_attn_tail {
+  int B, L, d, c1, hid, out, residual;
+  float eps;
+  const float *msg, *res;
+  const float *wm, *w0, *w2, *wmT, *w0T, *w2T;
+  const float *g1, *b1, *g2, *b2;
+  float *outp;                /* forward */
+  const float *dout;          /* backward */
+  float *dmsg, *dres, *parts;
+  long part_stride;
+} pcr_attn_tail;
+int pcr_attn_tail_ok(int d, int c1, int hid, int out, int residual);
+int pcr_attn_tail_part_floats(int d, int c1, int hid, int out);
+int pcr_attn_tail_groups(const pcr_attn_tail *p);
+int pcr_attn_tail_fwd_f32(const pcr_attn_tail *p, pcr_stream_t stream);
+int pcr_attn_tail_bwd_f32(const pcr_attn_tail *p, pcr_stream_t stream);
+
+/* Fused per-token chain: the HEAD of an attention block in training mode (csrc/train_chain_kernels.hip) -- position MLP,
+ * residual add and the projections that read the result (models/pointnet2_utils.py:92-100 Self_Attention, :410-421 FP_SA;
+ * models/attention.py:195-205 corss_attention):
+ *   fp = x + P2 relu(P1 xyz + c1) + c2          x (B,c,L), xyz (B,3,L) channel-major, P1 (hd,3), P2 (c,hd)
+ *   out (B, np d, L) = [W_0 s_0 ; ... ; W_{np-1} s_{np-1}],  s_j = fp if bit j of src is set, else x;  W_j (d,c)
+ * (self block: q | k | v of fp, src = 7; cross / FP block: k of x | v of fp, src = 2) as one launch each way; the backward
+ * recomputes the chain for its tile.  p1 / p2 / w[j] are pcr_pack_weight images, p2T / wT[j] of the transposes, c1 / c2
+ * zero-padded to a multiple of 32 floats.  Backward outputs: dx (B,c,L) and per-workgroup partial records
+ * [pcr_attn_head_groups][part_stride >= pcr_attn_head_part_floats] =
+ *   dP1 [hd][32] | dP2 [c][hd] | dW_0 [d][c] | .. | dc1 [hd] | dc2 [c]        for pcr_reduce_parts_f32. */
+typedef struct pcr_attn_head {
+  int B, L, c, hd, d, np, src;
+  const float *x, *xyz;
+  const float *p1, *p2, *c1, *c2, *p2T;
+  const float *w[3], *wT[3];
+  float *outp;                /* forward */
+  const float *dout;          /* backward */
+  float *dx, *parts;
+  long part_stride;
+} pcr_attn_head;
+int pcr_attn_head_ok(int c, int hd, int d, int np, int src);
+int pcr_attn_head_part_floats(int c, int hd, int d, int np, int src);
+int pcr_attn_head_groups(const pcr_attn_head *p);
+int pcr_attn_head_fwd_f32(const pcr_attn_head *p, pcr_stream_t stream);
+int pcr_attn_head_bwd_f32(const pcr_attn_head *p, pcr_stream_t stream);
+
 /* Match-head pooling in training (get_pooled_feats 'both' over the point-concatenated pair, models/ReIDNet.py:529-532):
  * o (2P,C,L) -> pooled (P,2C) = [max, mean] over the 2L points of pair p (clouds p, p+P), arg (P,C) = position of the
  * maximum; backward: dout (2P,C,L) from g (P,2C). */

@@ -22,16 +22,12 @@ def _cm(xyz):
     return xyz.transpose(1, 2).contiguous()
 
 
-def _attention(m, pos, q_in, k_in, v_in, res_in, residual, fused_qkv):
-    """shared tail of Self_Attention / FP_SA / corss_attention: projections, linear attention, merge, LayerNorm,
-    feed-forward on [res_in ; msg], LayerNorm (+ residual)"""
-    d, H = m.q_proj.weight.shape[0], m.nhead
-    if fused_qkv:      # q, k, v all project the same tensor: one dense launch, slices feed the attention core
-        qkv = TO.dense(q_in, torch.cat([m.q_proj.weight, m.k_proj.weight, m.v_proj.weight], dim=0))
-        msg = TO.LinAttnQKV.apply(qkv, H, ATTN_EPS)
-    else:
-        q, k, v = TO.dense(q_in, m.q_proj.weight), TO.dense(k_in, m.k_proj.weight), TO.dense(v_in, m.v_proj.weight)
-        msg = TO.LinAttn.apply(q, k, v, H, ATTN_EPS)
+def _tail(m, msg, res_in, residual):
+    """merge, LayerNorm, feed-forward on [res_in ; msg], LayerNorm (+ residual): ONE launch each way where the chain
+    kernel is instantiated (train_ops.attn_tail, round 5), else one launch per layer"""
+    fused = TO.attn_tail(m, msg, res_in, residual)
+    if fused is not None:
+        return fused
     n1 = TO.tnorm(TO.dense(msg, m.merge.weight), m.norm1)
     f0 = TO.dense(res_in, m.mlp[0].weight, x2=n1, relu=True)
     return TO.tnorm(TO.dense(f0, m.mlp[2].weight), m.norm2, res=res_in if residual else None)
@@ -44,16 +40,32 @@ def _pos(pos_mlp, xyz_cm, add_to):
 
 
 def self_attention(m, feat, xyz_cm):
-    fp = _pos(m.pos_mlp, xyz_cm, feat)
-    return _attention(m, None, fp, fp, fp, feat, True, True)
+    """Self_Attention (pointnet2_utils.py:90-114): q, k, v all project feat + position code"""
+    ws = (m.q_proj.weight, m.k_proj.weight, m.v_proj.weight)
+    qkv = TO.attn_head(m.pos_mlp, feat, xyz_cm, ws, 7)      # position MLP + the three projections: ONE launch each way
+    if qkv is None:
+        qkv = TO.dense(_pos(m.pos_mlp, xyz_cm, feat), torch.cat(ws, dim=0))
+    return _tail(m, TO.LinAttnQKV.apply(qkv, m.nhead, ATTN_EPS), feat, True)
+
+
+def _cross(m, pos_mlp, q_in, kv_in, kv_xyz_cm, residual):
+    """q from q_in; k from kv_in, v from kv_in + position code (FP_SA :407-437, corss_attention attention.py:192-219)"""
+    q = TO.dense(q_in, m.q_proj.weight)
+    kv = TO.attn_head(pos_mlp, kv_in, kv_xyz_cm, (m.k_proj.weight, m.v_proj.weight), 2)
+    if kv is not None:
+        msg = TO.LinAttnKV.apply(q, kv, m.nhead, ATTN_EPS)
+    else:
+        k, v = TO.dense(kv_in, m.k_proj.weight), TO.dense(_pos(pos_mlp, kv_xyz_cm, kv_in), m.v_proj.weight)
+        msg = TO.LinAttn.apply(q, k, v, m.nhead, ATTN_EPS)
+    return _tail(m, msg, q_in, residual)
 
 
 def fp_sa(m, feat1, feat2, xyz2_cm):
-    return _attention(m, None, feat1, feat2, _pos(m.pos_mlp2, xyz2_cm, feat2), feat1, False, False)
+    return _cross(m, m.pos_mlp2, feat1, feat2, xyz2_cm, False)
 
 
 def cross_attention(m, search, template, template_xyz_cm):
-    return _attention(m, None, search, template, _pos(m.pos_mlp, template_xyz_cm, template), search, True, False)
+    return _cross(m, m.pos_mlp, search, template, template_xyz_cm, True)
 
 
 def local_self_attention(m, feat, xyz_cm):

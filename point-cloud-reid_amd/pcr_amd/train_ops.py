@@ -736,6 +736,201 @@ def tnorm(x, norm, res=None, relu=False):
     return TNorm.apply(x, norm.weight, norm.bias, res, G, norm.eps, relu)
 
 
+# ------------------------------------------------------------------------------- fused per-token chains --
+# PCR_TRAIN_FUSED=0 keeps the unfused graph (one launch per layer: the form of rounds 2-4, and the yardstick of
+# tests/test_gpu_train_chain.py)
+FUSED_CHAINS = os.environ.get("PCR_TRAIN_FUSED", "1") != "0"
+
+
+class _AttnTailP(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int), ("L", ctypes.c_int), ("d", ctypes.c_int), ("c1", ctypes.c_int), ("hid", ctypes.c_int),
+                ("out", ctypes.c_int), ("residual", ctypes.c_int), ("eps", ctypes.c_float),
+                ("msg", c_fp), ("res", c_fp), ("wm", c_fp), ("w0", c_fp), ("w2", c_fp), ("wmT", c_fp), ("w0T", c_fp),
+                ("w2T", c_fp), ("g1", c_fp), ("b1", c_fp), ("g2", c_fp), ("b2", c_fp), ("outp", c_fp), ("dout", c_fp),
+                ("dmsg", c_fp), ("dres", c_fp), ("parts", c_fp), ("part_stride", ctypes.c_long)]
+
+
+def _tail_params(msg, res, Wm, g1, b1, W0, W2, g2, b2, residual, eps, images):
+    B, d, Ln = msg.shape
+    c1, hid, out = res.shape[1], W0.shape[0], W2.shape[0]
+    p = _AttnTailP()
+    p.B, p.L, p.d, p.c1, p.hid, p.out, p.residual, p.eps = B, Ln, d, c1, hid, out, int(residual), eps
+    p.msg, p.res = _p(msg), _p(res)
+    (p.wm, p.wmT), (p.w0, p.w0T), (p.w2, p.w2T) = [(_p(a), _p(b)) for a, b in images]
+    p.g1, p.b1, p.g2, p.b2 = _p(g1.detach()), _p(b1.detach()), _p(g2.detach()), _p(b2.detach())
+    return p, (B, d, Ln, c1, hid, out)
+
+
+class AttnTail(Function):
+    """the tail of an attention block as ONE launch each way (pcr_attn_tail_{fwd,bwd}_f32):
+    out = LN2(W2 relu(W0 [res ; LN1(Wm msg)])) [+ res]; nothing but msg and res is kept for the backward"""
+
+    @staticmethod
+    def forward(ctx, msg, res, Wm, g1, b1, W0, W2, g2, b2, residual, eps):
+        msg, res = _dev(msg), _dev(res)
+        images = [pack_both(Wm), pack_both(W0), pack_both(W2)]
+        p, (B, d, Ln, c1, hid, out) = _tail_params(msg, res, Wm, g1, b1, W0, W2, g2, b2, residual, eps, images)
+        y = _f32(B, out, Ln, device=msg.device)
+        p.outp = _p(y)
+        flops = 2.0 * B * Ln * (d * d + (c1 + d) * hid + hid * out)
+        with _prof("attn_tail_fwd[d=%d,c1=%d,hid=%d,out=%d,L=%d]" % (d, c1, hid, out, Ln), flops,
+                   4.0 * B * Ln * (d + c1 + out)):
+            L.check(L.load().pcr_attn_tail_fwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_attn_tail_fwd_f32")
+        ctx.save_for_backward(msg, res, Wm, g1, b1, W0, W2, g2, b2, *[t for im in images for t in im])
+        ctx.meta = (residual, eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        msg, res, Wm, g1, b1, W0, W2, g2, b2, *flat = ctx.saved_tensors
+        residual, eps = ctx.meta
+        images = [(flat[0], flat[1]), (flat[2], flat[3]), (flat[4], flat[5])]
+        p, (B, d, Ln, c1, hid, out) = _tail_params(msg, res, Wm, g1, b1, W0, W2, g2, b2, residual, eps, images)
+        lib = L.load()
+        g = _dev(g)
+        dev = msg.device
+        dmsg, dres = torch.empty_like(msg), torch.empty_like(res)
+        rec = lib.pcr_attn_tail_part_floats(d, c1, hid, out)
+        nwg = lib.pcr_attn_tail_groups(ctypes.byref(p))
+        parts = _f32(nwg, rec, device=dev)
+        p.dout, p.dmsg, p.dres, p.parts, p.part_stride = _p(g), _p(dmsg), _p(dres), _p(parts), rec
+        flops = 2.0 * B * Ln * (d * d + (c1 + d) * hid + hid * out)
+        with _prof("attn_tail_bwd[d=%d,c1=%d,hid=%d,out=%d,L=%d]" % (d, c1, hid, out, Ln), 3.0 * flops,
+                   4.0 * B * Ln * (2 * d + 2 * c1 + out)):
+            L.check(lib.pcr_attn_tail_bwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_attn_tail_bwd_f32")
+        f = reduce_parts(parts, nwg, rec, 1, rec, rec).view(rec)
+        cup = _c32(c1 + d)
+        o0, o2 = d * d, d * d + hid * cup
+        og = o2 + out * hid
+        dWm = f[:o0].view(d, d)
+        dW0 = f[o0:o2].view(hid, cup)[:, :c1 + d]
+        dW2 = f[o2:og].view(out, hid)
+        dg1, db1, dg2, db2 = f[og:og + d], f[og + d:og + 2 * d], f[og + 2 * d:og + 2 * d + out], f[og + 2 * d + out:]
+        return dmsg, dres, dWm, dg1, db1, dW0, dW2, dg2, db2, None, None
+
+
+def attn_tail(m, msg, res, residual, names=("merge", "norm1", "mlp", "norm2")):
+    """fused tail of attention block `m` (merge / norm1 / mlp[0], mlp[2] / norm2; `names` for local_self_attention's
+    *_knn members), or None when the shape has no fused instantiation (the caller then runs the unfused graph)"""
+    if not FUSED_CHAINS:
+        return None
+    merge, n1, mlp, n2 = (getattr(m, k) for k in names)
+    d, c1 = msg.shape[1], res.shape[1]
+    hid, out = mlp[0].weight.shape[0], mlp[2].weight.shape[0]
+    if (merge.weight.shape != (d, d) or mlp[0].weight.shape[1] != c1 + d or mlp[2].weight.shape[1] != hid or
+            getattr(n1, "num_groups", 1) != 1 or getattr(n2, "num_groups", 1) != 1 or
+            n1.weight.numel() != d or n2.weight.numel() != out or n1.eps != n2.eps or
+            not L.load().pcr_attn_tail_ok(d, c1, hid, out, int(bool(residual)))):
+        return None
+    L.require_default_eps(n1)
+    return AttnTail.apply(msg, res, merge.weight, n1.weight, n1.bias, mlp[0].weight, mlp[2].weight, n2.weight, n2.bias,
+                          bool(residual), float(n1.eps))
+
+
+class _AttnHeadP(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int), ("L", ctypes.c_int), ("c", ctypes.c_int), ("hd", ctypes.c_int), ("d", ctypes.c_int),
+                ("np", ctypes.c_int), ("src", ctypes.c_int), ("x", c_fp), ("xyz", c_fp), ("p1", c_fp), ("p2", c_fp),
+                ("c1", c_fp), ("c2", c_fp), ("p2T", c_fp), ("w", c_fp * 3), ("wT", c_fp * 3), ("outp", c_fp),
+                ("dout", c_fp), ("dx", c_fp), ("parts", c_fp), ("part_stride", ctypes.c_long)]
+
+
+def _head_params(x, xyz, P1, c1, P2, c2, src, Ws, images):
+    B, C, Ln = x.shape
+    hd, d, n = P1.shape[0], Ws[0].shape[0], len(Ws)
+    p = _AttnHeadP()
+    p.B, p.L, p.c, p.hd, p.d, p.np, p.src = B, Ln, C, hd, d, n, src
+    p.x, p.xyz = _p(x), _p(xyz)
+    p.p1, p.p2, p.p2T = _p(images[0][0]), _p(images[1][0]), _p(images[1][1])
+    p.c1, p.c2 = _p(pad32(c1, hd)), _p(pad32(c2, C))
+    for j in range(n):
+        p.w[j], p.wT[j] = _p(images[2 + j][0]), _p(images[2 + j][1])
+    return p, (B, C, Ln, hd, d, n)
+
+
+class AttnHead(Function):
+    """the head of an attention block as ONE launch each way (pcr_attn_head_{fwd,bwd}_f32): fp = x + P2 relu(P1 xyz + c1)
+    + c2, out (B, n d, L) = [W_j s_j] with s_j = fp (bit j of src) or x; nothing but x and xyz is kept for the backward"""
+
+    @staticmethod
+    def forward(ctx, x, xyz, P1, c1, P2, c2, src, *Ws):
+        x, xyz = _dev(x), _dev(xyz)
+        images = [pack_both(P1), pack_both(P2)] + [pack_both(W) for W in Ws]
+        p, (B, C, Ln, hd, d, n) = _head_params(x, xyz, P1, c1, P2, c2, src, Ws, images)
+        out = _f32(B, n * d, Ln, device=x.device)
+        p.outp = _p(out)
+        flops = 2.0 * B * Ln * (3 * hd + hd * C + n * d * C)
+        with _prof("attn_head_fwd[c=%d,hd=%d,d=%d,n=%d,L=%d]" % (C, hd, d, n, Ln), flops, 4.0 * B * Ln * (C + 3 + n * d)):
+            L.check(L.load().pcr_attn_head_fwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_attn_head_fwd_f32")
+        ctx.save_for_backward(x, xyz, P1, c1, P2, c2, *Ws, *[t for im in images for t in im])
+        ctx.meta = (src, len(Ws))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        src, n = ctx.meta
+        x, xyz, P1, c1, P2, c2, *rest = ctx.saved_tensors
+        Ws, flat = rest[:n], rest[n:]
+        images = [(flat[2 * i], flat[2 * i + 1]) for i in range(2 + n)]
+        p, (B, C, Ln, hd, d, n) = _head_params(x, xyz, P1, c1, P2, c2, src, Ws, images)
+        lib = L.load()
+        g = _dev(g)
+        dx = torch.empty_like(x)
+        rec = lib.pcr_attn_head_part_floats(C, hd, d, n, src)
+        nwg = lib.pcr_attn_head_groups(ctypes.byref(p))
+        parts = _f32(nwg, rec, device=x.device)
+        p.dout, p.dx, p.parts, p.part_stride = _p(g), _p(dx), _p(parts), rec
+        flops = 2.0 * B * Ln * (3 * hd + hd * C + n * d * C)
+        with _prof("attn_head_bwd[c=%d,hd=%d,d=%d,n=%d,L=%d]" % (C, hd, d, n, Ln), 3.0 * flops,
+                   4.0 * B * Ln * (2 * C + 3 + n * d)):
+            L.check(lib.pcr_attn_head_bwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_attn_head_bwd_f32")
+        f = reduce_parts(parts, nwg, rec, 1, rec, rec).view(rec)
+        o_p2 = hd * 32
+        o_w = o_p2 + C * hd
+        o_c1 = o_w + n * d * C
+        dP1 = f[:o_p2].view(hd, 32)[:, :3]
+        dP2 = f[o_p2:o_w].view(C, hd)
+        dWs = [f[o_w + j * d * C:o_w + (j + 1) * d * C].view(d, C) for j in range(n)]
+        return (dx, None, dP1, f[o_c1:o_c1 + hd], dP2, f[o_c1 + hd:o_c1 + hd + C], None, *dWs)
+
+
+def attn_head(pos_mlp, x, xyz_cm, Ws, src):
+    """fused head: position MLP `pos_mlp` = [Linear(3, hd), ReLU, Linear(hd, c)] added to x, then the projections Ws
+    ((d, c) weights; bit j of src: projection j reads x + position code, else x) -> (B, len(Ws) d, L), or None when the
+    shape has no fused instantiation"""
+    if not FUSED_CHAINS:
+        return None
+    p1, p2 = pos_mlp[0], pos_mlp[2]
+    C, d = x.shape[1], Ws[0].shape[0]
+    if (p1.weight.shape[1] != 3 or p2.weight.shape != (C, p1.weight.shape[0]) or p1.bias is None or p2.bias is None or
+            any(W.shape != (d, C) for W in Ws) or xyz_cm.shape[1] != 3 or xyz_cm.shape[2] != x.shape[2] or
+            not L.load().pcr_attn_head_ok(C, p1.weight.shape[0], d, len(Ws), src)):
+        return None
+    return AttnHead.apply(x, xyz_cm, p1.weight, p1.bias, p2.weight, p2.bias, src, *Ws)
+
+
+class LinAttnKV(Function):
+    """LinAttn with k | v as the two channel halves of ONE (B,2d,Sk) tensor (the fused head's output): the gradient comes
+    back as one buffer -- no slice / pad / add nodes in the autograd graph"""
+
+    @staticmethod
+    def forward(ctx, q, kv, H, eps):
+        q, kv = _dev(q), _dev(kv)
+        d = q.shape[1]
+        out, A, ks = _linattn_fwd(q, kv[:, :d], kv[:, d:], H, eps)
+        ctx.save_for_backward(q, kv, A, ks)
+        ctx.meta = (H, eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, kv, A, ks = ctx.saved_tensors
+        H, eps = ctx.meta
+        d = q.shape[1]
+        dq, buf = torch.empty_like(q), torch.empty_like(kv)
+        _linattn_bwd(q, kv[:, :d], kv[:, d:], A, ks, g.contiguous(), dq, buf[:, :d], buf[:, d:], H, eps)
+        return dq, buf, None, None
+
+
 class PoolPair(Function):
     """o (2P,C,L) -> (P,2C): [max, mean] over the point-concatenated pair (clouds p and p + P)"""
 
