@@ -606,6 +606,8 @@ typedef struct pcr_linattn {
   const float *dout;
   float *dq, *dk, *dv;
   long dq_bs, dk_bs, dv_bs;
+  int kv_roll;                /* (ABI 13, appended) query cloud b reads the keys / values of cloud (b + kv_roll) % B and writes
+                               * their gradients there: the matching stage's "halves swapped" without a rolled copy */
 } pcr_linattn;
 int pcr_linattn_fwd_f32(const pcr_linattn *p, pcr_stream_t stream);
 int pcr_linattn_bwd_f32(const pcr_linattn *p, pcr_stream_t stream);

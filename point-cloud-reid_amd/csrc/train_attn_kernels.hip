@@ -254,7 +254,13 @@ struct LinAttn {
   const float *dout;
   float *dq, *dk, *dv;
   long dq_bs, dk_bs, dv_bs;
+  int B, kv_roll;              // keys / values (and their gradients) of cloud b live at cloud (b + kv_roll) % B
 };
+
+// the cloud whose keys / values query cloud b reads (a permutation of the batch: every dk / dv block has one writer)
+__device__ __forceinline__ size_t linattn_kv_cloud(const LinAttn &a, size_t b) {
+  return a.kv_roll ? (b + (size_t)a.kv_roll) % (size_t)a.B : b;
+}
 
 constexpr int kAT = 64;        // tokens per staged chunk
 
@@ -271,8 +277,9 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(LinAttn a) {
   const int h = blockIdx.x;
   const size_t b = blockIdx.y;
   const float *q = a.q + b * a.q_bs + (size_t)h * DH * a.Lq;
-  const float *k = a.k + b * a.k_bs + (size_t)h * DH * a.Sk;
-  const float *v = a.v + b * a.v_bs + (size_t)h * DH * a.Sk;
+  const size_t bk = linattn_kv_cloud(a, b);
+  const float *k = a.k + bk * a.k_bs + (size_t)h * DH * a.Sk;
+  const float *v = a.v + bk * a.v_bs + (size_t)h * DH * a.Sk;
   const float sk = (float)a.Sk;
   float acc[NP];
 #pragma unroll
@@ -356,12 +363,13 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(LinAttn a) {
   const int h = blockIdx.x;
   const size_t b = blockIdx.y;
   const float *q = a.q + b * a.q_bs + (size_t)h * DH * a.Lq;
-  const float *k = a.k + b * a.k_bs + (size_t)h * DH * a.Sk;
-  const float *v = a.v + b * a.v_bs + (size_t)h * DH * a.Sk;
+  const size_t bk = linattn_kv_cloud(a, b);
+  const float *k = a.k + bk * a.k_bs + (size_t)h * DH * a.Sk;
+  const float *v = a.v + bk * a.v_bs + (size_t)h * DH * a.Sk;
   const float *go = a.dout + (b * a.d + (size_t)h * DH) * a.Lq;
   float *dq = a.dq + b * a.dq_bs + (size_t)h * DH * a.Lq;
-  float *dk = a.dk + b * a.dk_bs + (size_t)h * DH * a.Sk;
-  float *dv = a.dv + b * a.dv_bs + (size_t)h * DH * a.Sk;
+  float *dk = a.dk + bk * a.dk_bs + (size_t)h * DH * a.Sk;
+  float *dv = a.dv + bk * a.dv_bs + (size_t)h * DH * a.Sk;
   const float sk = (float)a.Sk;
   const float *Ag = a.A + (b * a.H + h) * DH * DH;
   for (int e = tid; e < DH * DH; e += 256) Al[(e / DH) * (DH + 1) + e % DH] = Ag[e];
@@ -525,8 +533,9 @@ __global__ __launch_bounds__(256) void linattn_fwd_mfma_kernel(LinAttn a) {
   const int h = blockIdx.x;
   const size_t b = blockIdx.y;
   const float *q = a.q + b * a.q_bs + (size_t)h * DH * a.Lq;
-  const float *k = a.k + b * a.k_bs + (size_t)h * DH * a.Sk;
-  const float *v = a.v + b * a.v_bs + (size_t)h * DH * a.Sk;
+  const size_t bk = linattn_kv_cloud(a, b);
+  const float *k = a.k + bk * a.k_bs + (size_t)h * DH * a.Sk;
+  const float *v = a.v + bk * a.v_bs + (size_t)h * DH * a.Sk;
   const float sk = (float)a.Sk;
   f32x16 accA = zero16();              // tile `wave` of A (MT x MT tiles; DH = 32: wave 0 only)
   const bool a_owner = wave < MT * MT;
@@ -596,12 +605,13 @@ __global__ __launch_bounds__(256) void linattn_bwd_mfma_kernel(LinAttn a) {
   const int h = blockIdx.x;
   const size_t b = blockIdx.y;
   const float *q = a.q + b * a.q_bs + (size_t)h * DH * a.Lq;
-  const float *k = a.k + b * a.k_bs + (size_t)h * DH * a.Sk;
-  const float *v = a.v + b * a.v_bs + (size_t)h * DH * a.Sk;
+  const size_t bk = linattn_kv_cloud(a, b);
+  const float *k = a.k + bk * a.k_bs + (size_t)h * DH * a.Sk;
+  const float *v = a.v + bk * a.v_bs + (size_t)h * DH * a.Sk;
   const float *go = a.dout + (b * a.d + (size_t)h * DH) * a.Lq;
   float *dq = a.dq + b * a.dq_bs + (size_t)h * DH * a.Lq;
-  float *dk = a.dk + b * a.dk_bs + (size_t)h * DH * a.Sk;
-  float *dv = a.dv + b * a.dv_bs + (size_t)h * DH * a.Sk;
+  float *dk = a.dk + bk * a.dk_bs + (size_t)h * DH * a.Sk;
+  float *dv = a.dv + bk * a.dv_bs + (size_t)h * DH * a.Sk;
   const float sk = (float)a.Sk;
   const float *Ag = a.A + (b * a.H + h) * DH * DH;
   {
@@ -907,6 +917,7 @@ static LinAttn linattn_args(const pcr_linattn *p) {
   a.Lq = p->Lq; a.Sk = p->Sk; a.d = p->d; a.H = p->H; a.eps = p->eps;
   a.out = p->out; a.A = p->A; a.ks = p->ks; a.dout = p->dout;
   a.dq = p->dq; a.dk = p->dk; a.dv = p->dv; a.dq_bs = p->dq_bs; a.dk_bs = p->dk_bs; a.dv_bs = p->dv_bs;
+  a.B = p->B; a.kv_roll = p->B > 0 ? ((p->kv_roll % p->B) + p->B) % p->B : 0;
   return a;
 }
 

@@ -242,6 +242,41 @@ __device__ __forceinline__ void ck_store_tile(float *dst, int C, int L, int t0, 
   }
 }
 
+// Up to three [R_i][64] tiles of (R_i, L) tensors into LDS with ALL of a thread's 16-byte loads in flight before the first
+// LDS write (three load_tile calls are three serial HBM round trips for a workgroup that has the CU to itself).  Whole,
+// 16-byte aligned tiles only (the caller falls back to load_tile otherwise); a null src skips that tile.
+template <int R0, int R1, int R2>
+__device__ __forceinline__ void ck_load3(float *d0, const float *s0, float *d1, const float *s1, float *d2, const float *s2,
+                                         int L, int t0) {
+  constexpr int RP = kCRP, TOT = (R0 + R1 + R2) * 16, NP = (TOT + kThreads - 1) / kThreads;
+  f32x4 v[NP];
+#pragma unroll
+  for (int u = 0; u < NP; u++) {
+    const int e = threadIdx.x + u * kThreads;
+    const int r = e >> 4, q = e & 15;
+    const float *src = r < R0 ? s0 + (size_t)r * L : (r < R0 + R1 ? s1 + (size_t)(r - R0) * L : s2 + (size_t)(r - R0 - R1) * L);
+    const bool ok = e < TOT && (r < R0 ? s0 != nullptr : (r < R0 + R1 ? s1 != nullptr : s2 != nullptr));
+    v[u] = ok ? *reinterpret_cast<const f32x4 *>(src + t0 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int u = 0; u < NP; u++) {
+    const int e = threadIdx.x + u * kThreads;
+    const int r = e >> 4, q = e & 15;
+    const bool ok = e < TOT && (r < R0 ? s0 != nullptr : (r < R0 + R1 ? s1 != nullptr : s2 != nullptr));
+    if (ok) {
+      float *d = (r < R0 ? d0 + r * RP : (r < R0 + R1 ? d1 + (r - R0) * RP : d2 + (r - R0 - R1) * RP)) + 4 * q;
+      d[0] = v[u][0];
+      d[1] = v[u][1];
+      d[2] = v[u][2];
+      d[3] = v[u][3];
+    }
+  }
+}
+__device__ __forceinline__ bool ck_whole(const float *p0, const float *p1, const float *p2, int L, int t0) {
+  return (L & 3) == 0 && t0 + kCT <= L &&
+         (((reinterpret_cast<size_t>(p0) | reinterpret_cast<size_t>(p1) | reinterpret_cast<size_t>(p2)) & 15) == 0);
+}
+
 // ------------------------------------------------------------------------------------------ attention tail ----
 struct TailArgs {
   const float *msg, *res;             // (B,D,L), (B,C1,L)
@@ -266,7 +301,10 @@ struct TailShape {
   // partial record of one workgroup (floats)
   static constexpr int O_WM = 0, O_W0 = D * D, O_W2 = O_W0 + HID * CUP32, O_G1 = O_W2 + OUT * HID, O_B1 = O_G1 + D,
                        O_G2 = O_B1 + D, O_B2 = O_G2 + OUT, REC = O_B2 + OUT;
-  static constexpr int rowsA(bool bwd) { return bwd ? (D > OUT ? D : OUT) : D; }
+  // backward: d out gets its own buffer (all three input tiles of a tile are then requested at once and msg is not loaded
+  // twice) where the 160 KB allow it; else it shares msg's rows
+  static constexpr bool SEP = (size_t)(D + OUT + D + CUP32 + HID + OUT) * kCRP * 4 + 10 * kCT * 4 <= (size_t)kMaxDynLds;
+  static constexpr int rowsA(bool bwd) { return bwd ? (SEP ? D + OUT : (D > OUT ? D : OUT)) : D; }
   static constexpr size_t lds(bool bwd) {
     return ((size_t)(rowsA(bwd) + D + CUP32 + HID + OUT) * kCRP + 8 * kCT + 2 * kCT) * sizeof(float);
   }
@@ -278,7 +316,8 @@ __global__ __launch_bounds__(kThreads) void attn_tail_kernel(TailArgs a) {
   constexpr int RP = kCRP, T = kCT, CU = S::CU, CUP8 = S::CUP8, CUP32 = S::CUP32, NTW = S::NTW;
   static_assert(D % 32 == 0 && HID % 32 == 0 && OUT % 32 == 0 && (!RESID || OUT == C1), "chain shape");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *A = smem;                                   // msg; backward: d out, then msg again, then d msg
+  float *A = smem;                                   // msg (backward without SEP: d out, then msg again); then d msg
+  float *F = (BWD && S::SEP) ? A + D * RP : A;       // backward: d out
   float *Bm = A + S::rowsA(BWD) * RP;                // merge output -> normalised (x hat)
   float *Cb = Bm + D * RP;                           // U = [res ; norm1]; backward: dU
   float *Dh = Cb + CUP32 * RP;                       // relu(W0 U); backward: its gradient
@@ -305,9 +344,16 @@ __global__ __launch_bounds__(kThreads) void attn_tail_kernel(TailArgs a) {
   for (int tile = blockIdx.x; tile < a.total; tile += gridDim.x) {
     const int b = tile / a.tpc, t0 = (tile - b * a.tpc) * T;
     const float *msgb = a.msg + (size_t)b * D * L, *resb = a.res + (size_t)b * C1 * L;
+    const float *doutb = BWD ? a.dout + (size_t)b * OUT * L : nullptr;
     __syncthreads();     // the previous tile's stores have read their buffers
-    load_tile(A, RP, msgb, D, D, L, t0, T);
-    load_tile(Cb, RP, resb, C1, C1, L, t0, T);
+    // (the one shape without a buffer of its own for d out is also at the register limit: it keeps the serial loads)
+    if ((!BWD || S::SEP) && ck_whole(msgb, resb, (BWD && S::SEP) ? doutb : nullptr, L, t0)) {
+      ck_load3<D, C1, (BWD && S::SEP) ? OUT : 0>(A, msgb, Cb, resb, F, doutb, L, t0);
+    } else {
+      load_tile(A, RP, msgb, D, D, L, t0, T);
+      load_tile(Cb, RP, resb, C1, C1, L, t0, T);
+      if constexpr (BWD && S::SEP) load_tile(F, RP, doutb, OUT, OUT, L, t0, T);
+    }
     __syncthreads();
     cdense<D / 32>(A, D, a.wm, false, [&](float v, int o, int t) { Bm[o * RP + t] = v; });
     __syncthreads();
@@ -326,11 +372,13 @@ __global__ __launch_bounds__(kThreads) void attn_tail_kernel(TailArgs a) {
     } else {
       ck_ln_fwd<OUT, true>(E, a.g2, a.b2, a.eps, nullptr, rstd2, red);
       // ---- backward ----
-      load_tile(A, RP, a.dout + (size_t)b * OUT * L, OUT, OUT, L, t0, T);      // (msg is reloaded for dWm below)
+      if constexpr (!S::SEP) {
+        load_tile(F, RP, doutb, OUT, OUT, L, t0, T);    // (over msg, which is reloaded for dWm below)
+        __syncthreads();
+      }
+      ck_rowsum<OUT>(F, E, sb2, sg2);                   // d beta2 += sum dout, d gamma2 += sum dout * xhat2
       __syncthreads();
-      ck_rowsum<OUT>(A, E, sb2, sg2);                   // d beta2 += sum dout, d gamma2 += sum dout * xhat2
-      __syncthreads();
-      ck_ln_bwd<OUT>(A, E, E, a.g2, rstd2, red);        // E = dG
+      ck_ln_bwd<OUT>(F, E, E, a.g2, rstd2, red);        // E = dG
       ck_dw_acc<NTW, S::B_W2, OUT / 32, HID / 32>(acc, E, Dh);
       cdense<HID / 32>(E, OUT, a.w2T, true, [&](float v, int o, int t) {
         const float f = Dh[o * RP + t];
@@ -343,12 +391,12 @@ __global__ __launch_bounds__(kThreads) void attn_tail_kernel(TailArgs a) {
       // d res = dU[0, C1) (+ d out: the residual), then msg comes back into A
       ck_store_tile(a.dres + (size_t)b * C1 * L, C1, L, t0, [&](int c, int t) {
         float v = Cb[c * RP + t];
-        if constexpr (RESID) v += A[c * RP + t];
+        if constexpr (RESID) v += F[c * RP + t];
         return v;
       });
       ck_rowsum<D>(Cb + C1 * RP, Bm, sb1, sg1);         // d beta1, d gamma1
       __syncthreads();
-      load_tile(A, RP, msgb, D, D, L, t0, T);
+      if constexpr (!S::SEP) load_tile(A, RP, msgb, D, D, L, t0, T);
       ck_ln_bwd<D>(Cb + C1 * RP, Bm, Bm, a.g1, rstd1, red);   // Bm = dM (its barrier also covers the msg tile)
       ck_dw_acc<NTW, S::B_WM, D / 32, D / 32>(acc, Bm, A);
       cdense<D / 32>(Bm, D, a.wmT, true, [&](float v, int o, int t) { A[o * RP + t] = v; });
@@ -503,9 +551,16 @@ __global__ __launch_bounds__(kThreads) void attn_head_kernel(HeadArgs a) {
 
   for (int tile = blockIdx.x; tile < a.total; tile += gridDim.x) {
     const int b = tile / a.tpc, t0 = (tile - b * a.tpc) * T;
+    const float *xb = a.x + (size_t)b * C * L, *xzb = a.xyz + (size_t)b * 3 * L;
+    const float *doutb = BWD ? a.dout + (size_t)b * NP * D * L : nullptr;
     __syncthreads();
-    load_tile(XZ, RP, a.xyz + (size_t)b * 3 * L, 3, 3, L, t0, T);
-    load_tile(X, RP, a.x + (size_t)b * C * L, C, C, L, t0, T);
+    if (ck_whole(xb, xzb, doutb, L, t0)) {
+      ck_load3<3, C, BWD ? NP * D : 0>(XZ, xzb, X, xb, G, doutb, L, t0);
+    } else {
+      load_tile(XZ, RP, xzb, 3, 3, L, t0, T);
+      load_tile(X, RP, xb, C, C, L, t0, T);
+      if constexpr (BWD) load_tile(G, RP, doutb, NP * D, NP * D, L, t0, T);
+    }
     __syncthreads();
     cdense<HD / 32>(XZ, 8, a.p1, false, [&](float v, int o, int t) { Hb[o * RP + t] = fmaxf(v, 0.f); }, a.c1);
     __syncthreads();
@@ -520,8 +575,6 @@ __global__ __launch_bounds__(kThreads) void attn_head_kernel(HeadArgs a) {
       __syncthreads();
       ck_store_tile(a.out + (size_t)b * NP * D * L, NP * D, L, t0, [&](int c, int t) { return G[c * RP + t]; });
     } else {
-      load_tile(G, RP, a.dout + (size_t)b * NP * D * L, NP * D, NP * D, L, t0, T);
-      __syncthreads();
       // dW_j += G_j s_j^T (x and fp are both still in place)
       ck_static_for<NP>([&](auto jc) {
         constexpr int j = decltype(jc)::value;

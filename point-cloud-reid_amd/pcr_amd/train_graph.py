@@ -45,7 +45,7 @@ def self_attention(m, feat, xyz_cm):
     qkv = TO.attn_head(m.pos_mlp, feat, xyz_cm, ws, 7)      # position MLP + the three projections: ONE launch each way
     if qkv is None:
         qkv = TO.dense(_pos(m.pos_mlp, xyz_cm, feat), torch.cat(ws, dim=0))
-    return _tail(m, TO.LinAttnQKV.apply(qkv, m.nhead, ATTN_EPS), feat, True)
+    return _tail(m, TO.LinAttnQKV.apply(qkv, m.nhead, ATTN_EPS, 0), feat, True)
 
 
 def _cross(m, pos_mlp, q_in, kv_in, kv_xyz_cm, residual):
@@ -58,6 +58,16 @@ def _cross(m, pos_mlp, q_in, kv_in, kv_xyz_cm, residual):
         k, v = TO.dense(kv_in, m.k_proj.weight), TO.dense(_pos(pos_mlp, kv_xyz_cm, kv_in), m.v_proj.weight)
         msg = TO.LinAttn.apply(q, k, v, m.nhead, ATTN_EPS)
     return _tail(m, msg, q_in, residual)
+
+
+def cross_attention_pairs(m, feats, xyz_cm, b):
+    """corss_attention of every cloud of a (2b, C, N) batch against its pair partner (cloud i <-> cloud i +- b): q | k | v
+    of every cloud from ONE head launch (q, k of x; v of x + position code), the partner's keys / values addressed by the
+    attention core (kv_roll) -- no swapped copies of the batch, no separate q projection.  None: no fused instantiation."""
+    qkv = TO.attn_head(m.pos_mlp, feats, xyz_cm, (m.q_proj.weight, m.k_proj.weight, m.v_proj.weight), 4)
+    if qkv is None:
+        return None
+    return _tail(m, TO.LinAttnQKV.apply(qkv, m.nhead, ATTN_EPS, b), feats, True)
 
 
 def fp_sa(m, feat1, feat2, xyz2_cm):
@@ -250,7 +260,10 @@ def match_logits(model, h1, xyz1, h2, xyz2):
         return _head(model, TO.PoolBoth.apply(o)), None
     feats = _joined(h1, h2)
     xyz_cm = _cm(_joined(xyz1, xyz2))
-    swap = lambda t: torch.roll(t, b, 0)                    # noqa: E731  (halves exchanged: one launch each way)
-    a = cross_attention(model.cross_stage1, feats, swap(feats), swap(xyz_cm))
-    o = cross_attention(model.cross_stage2, a, swap(a), swap(xyz_cm))
+    a = cross_attention_pairs(model.cross_stage1, feats, xyz_cm, b)
+    o = None if a is None else cross_attention_pairs(model.cross_stage2, a, xyz_cm, b)
+    if o is None:
+        swap = lambda t: torch.roll(t, b, 0)                # noqa: E731  (halves exchanged: one launch each way)
+        a = cross_attention(model.cross_stage1, feats, swap(feats), swap(xyz_cm))
+        o = cross_attention(model.cross_stage2, a, swap(a), swap(xyz_cm))
     return _head(model, TO.PoolPair.apply(o)), o

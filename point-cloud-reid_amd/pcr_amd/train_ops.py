@@ -578,7 +578,7 @@ class _LinAttnP(ctypes.Structure):
                 ("eps", ctypes.c_float), ("q", c_fp), ("k", c_fp), ("v", c_fp),
                 ("q_bs", ctypes.c_long), ("k_bs", ctypes.c_long), ("v_bs", ctypes.c_long),
                 ("out", c_fp), ("A", c_fp), ("ks", c_fp), ("dout", c_fp), ("dq", c_fp), ("dk", c_fp), ("dv", c_fp),
-                ("dq_bs", ctypes.c_long), ("dk_bs", ctypes.c_long), ("dv_bs", ctypes.c_long)]
+                ("dq_bs", ctypes.c_long), ("dk_bs", ctypes.c_long), ("dv_bs", ctypes.c_long), ("kv_roll", ctypes.c_int)]
 
 
 def _block(t, d):
@@ -588,7 +588,7 @@ def _block(t, d):
     return t.data_ptr(), t.stride(0)
 
 
-def _linattn_fwd(q, k, v, H, eps):
+def _linattn_fwd(q, k, v, H, eps, kv_roll=0):
     L.require_cuda(q, k, v)
     B, d, Lq = q.shape
     Sk = k.shape[2]
@@ -597,17 +597,17 @@ def _linattn_fwd(q, k, v, H, eps):
     A = _f32(B, H, d // H, d // H, device=dev)
     ks = _f32(B, H, d // H, device=dev)
     p = _LinAttnP()
-    p.B, p.Lq, p.Sk, p.d, p.H, p.eps = B, Lq, Sk, d, H, eps
+    p.B, p.Lq, p.Sk, p.d, p.H, p.eps, p.kv_roll = B, Lq, Sk, d, H, eps, kv_roll
     (p.q, p.q_bs), (p.k, p.k_bs), (p.v, p.v_bs) = _block(q, d), _block(k, d), _block(v, d)
     p.out, p.A, p.ks = _p(out), _p(A), _p(ks)
     L.check(L.load().pcr_linattn_fwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_linattn_fwd_f32")
     return out, A, ks
 
 
-def _linattn_bwd(q, k, v, A, ks, g, dq, dk, dv, H, eps):
+def _linattn_bwd(q, k, v, A, ks, g, dq, dk, dv, H, eps, kv_roll=0):
     B, d, Lq = q.shape
     p = _LinAttnP()
-    p.B, p.Lq, p.Sk, p.d, p.H, p.eps = B, Lq, k.shape[2], d, H, eps
+    p.B, p.Lq, p.Sk, p.d, p.H, p.eps, p.kv_roll = B, Lq, k.shape[2], d, H, eps, kv_roll
     (p.q, p.q_bs), (p.k, p.k_bs), (p.v, p.v_bs) = _block(q, d), _block(k, d), _block(v, d)
     p.A, p.ks, p.dout = _p(A), _p(ks), _p(g)
     (p.dq, p.dq_bs), (p.dk, p.dk_bs), (p.dv, p.dv_bs) = _block(dq, d), _block(dk, d), _block(dv, d)
@@ -640,23 +640,25 @@ class LinAttnQKV(Function):
     in the autograd graph"""
 
     @staticmethod
-    def forward(ctx, qkv, H, eps):
+    def forward(ctx, qkv, H, eps, kv_roll=0):
+        """kv_roll: query cloud b attends to the keys / values of cloud (b + kv_roll) % B of the same buffer (the matching
+        stages: every cloud against its pair partner, ReIDNet.py:231-247) -- no rolled copy of the batch"""
         qkv = _dev(qkv)
         d = qkv.shape[1] // 3
-        out, A, ks = _linattn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], H, eps)
+        out, A, ks = _linattn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], H, eps, kv_roll)
         ctx.save_for_backward(qkv, A, ks)
-        ctx.meta = (H, eps)
+        ctx.meta = (H, eps, kv_roll)
         return out
 
     @staticmethod
     def backward(ctx, g):
         qkv, A, ks = ctx.saved_tensors
-        H, eps = ctx.meta
+        H, eps, kv_roll = ctx.meta
         d = qkv.shape[1] // 3
         buf = torch.empty_like(qkv)
         _linattn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], A, ks, g.contiguous(),
-                     buf[:, :d], buf[:, d:2 * d], buf[:, 2 * d:], H, eps)
-        return buf, None, None
+                     buf[:, :d], buf[:, d:2 * d], buf[:, 2 * d:], H, eps, kv_roll)
+        return buf, None, None, None
 
 
 class LocalAttn(Function):

@@ -182,3 +182,56 @@ def test_key_value_attention_on_the_fused_buffer_equals_separate_tensors():
     (ref * go).sum().backward()
     assert torch.equal(out, ref) and torch.equal(q.grad, q2.grad)
     assert torch.equal(kv.grad[:, :d], k2.grad) and torch.equal(kv.grad[:, d:], v2.grad)
+
+
+def test_attention_core_reads_the_partner_clouds_keys_without_a_rolled_copy():
+    """LinAttnQKV(kv_roll = b) on one (2b, 3d, L) buffer == LinAttn(q, roll(k, b), roll(v, b)): the matching stages' "halves
+    swapped" (ReIDNet.py:231-247) addressed inside the core, forward and every gradient bit for bit"""
+    from pcr_amd import train_ops as TO
+    g = torch.Generator().manual_seed(4)
+    b, d, Ln = 5, 64, 100
+    qkv = torch.randn(2 * b, 3 * d, Ln, generator=g).cuda().requires_grad_(True)
+    go = torch.randn(2 * b, d, Ln, generator=g).cuda()
+    out = TO.LinAttnQKV.apply(qkv, 2, 1e-6, b)
+    (out * go).sum().backward()
+    x = qkv.detach().clone().requires_grad_(True)
+    ref = TO.LinAttn.apply(x[:, :d].contiguous(), torch.roll(x[:, d:2 * d], b, 0).contiguous(),
+                           torch.roll(x[:, 2 * d:], b, 0).contiguous(), 2, 1e-6)
+    (ref * go).sum().backward()
+    assert torch.equal(out, ref) and torch.equal(qkv.grad, x.grad)
+
+
+def test_matching_stages_on_the_fused_path_equal_the_unfused_graph():
+    """train_graph.match_logits (xcorr_eff + point-cat): fused heads / tails with the partner addressed by the attention
+    core against the graph of rounds 2-4 (rolled copies of the batch, one launch per layer): logits and the gradients of
+    the encodings and of every matching parameter"""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from pcr_amd import train_graph as TG
+    from pcr_amd import train_ops as TO
+    model, _ = bench.build_pt_model([128, 64, 32])
+    model.train()
+    g = torch.Generator().manual_seed(8)
+    b, n = 6, 128
+    h = torch.randn(2 * b, 64, n, generator=g).cuda()
+    xyz = torch.randn(2 * b, n, 3, generator=g).cuda()
+
+    def run(fused):
+        prev, TO.FUSED_CHAINS = TO.FUSED_CHAINS, fused
+        try:
+            model.zero_grad(set_to_none=True)
+            hh = h.clone().requires_grad_(True)
+            logits, _ = TG.match_logits(model, hh[:b], xyz[:b], hh[b:], xyz[b:])
+            (logits * torch.arange(1, b + 1, device="cuda").float()).sum().backward()
+            grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+            return logits.detach(), hh.grad.clone(), grads
+        finally:
+            TO.FUSED_CHAINS = prev
+    lf, hf, gf = run(True)
+    lu, hu, gu = run(False)
+    assert _rel(lf, lu) < 1e-5 and _rel(hf, hu) < 3e-5, (_rel(lf, lu), _rel(hf, hu))
+    assert set(gf) == set(gu) and len(gf) >= 30
+    for k in gu:
+        assert _rel(gf[k], gu[k]) < 1e-4, (k, _rel(gf[k], gu[k]))
