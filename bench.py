@@ -551,6 +551,9 @@ def measure(workload, args, rank, world, pairs=None, cloud_kind=None, skip_repea
     s1, s2 = T.synthetic_pairs(pairs, n, seed=1234 + rank, kind=cloud_kind)
     s1, s2 = s1.cuda(), s2.cuda()
     prewarm()
+    # split-bf16 guard (pcr_amd/engine.py): the level these weights run at is calibrated on the first 64 pairs, untimed
+    # (what ReIDNet.forward_test does on its first batch); level and measured deviations go into config.guard
+    guard = model.calibrate_precision(s1, s2) if (engine.GUARD and engine.PRECISION == "bf16x3") else None
     step_fn, launch_mode = graph_step(lambda: hot_path(model, s1, s2))
     pilot_ms = {k: round(v, 4) for k, v in LAST_PILOT.items()}
     with torch.no_grad():
@@ -580,6 +583,9 @@ def measure(workload, args, rank, world, pairs=None, cloud_kind=None, skip_repea
                            "precision": precision_text(engine.PRECISION), "precision_tag": engine.PRECISION,
                            "launch": launch_mode, **pilot_ms},
                    roofline=roof)
+        if guard is not None:
+            rec["config"]["guard"] = {"level": guard["level"], "bound": guard["bound"],
+                                      "dlogit": {str(k): float("%.2e" % v) for k, v in guard["dlogit"].items()}}
         if kind == "ssg":
             rec["config"]["fill"] = ssg_fill(model, s1)
             rec["config"]["skip_repeats"] = bool(skip_repeats)
@@ -612,6 +618,7 @@ def gallery_bench(args, desc, n, bl, pairs, rank, world, steps=None, warmup=None
         xyz, h = model.forward_inference(clouds)
         return model.match_gallery(h, xyz, combos)
     prewarm()
+    guard = model.calibrate_precision(clouds[:G], clouds[G:]) if (engine.GUARD and engine.PRECISION == "bf16x3") else None
     step_fn, launch_mode = graph_step(step)
     pilot_ms = {k: round(v, 4) for k, v in LAST_PILOT.items()}
     with torch.no_grad():
@@ -632,6 +639,9 @@ def gallery_bench(args, desc, n, bl, pairs, rank, world, steps=None, warmup=None
                            "points": n, "backbone_list": bl, "parallelism": "independent galleries x%d" % world,
                            "rccl_ranks": world, "launch": launch_mode, "precision_tag": engine.PRECISION, **pilot_ms},
                 "roofline": roof}
+        if guard is not None:
+            line["config"]["guard"] = {"level": guard["level"], "bound": guard["bound"],
+                                       "dlogit": {str(k): float("%.2e" % v) for k, v in guard["dlogit"].items()}}
         if cpu and world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = gallery_cpu_baseline(sd, n, bl, G)
     del model, clouds, combos

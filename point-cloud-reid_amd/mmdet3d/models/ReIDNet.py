@@ -157,12 +157,70 @@ class ReIDNet(nn.Module):
         return (sparse_1, sparse_2, dense_1, dense_2,
                 *self._cat(label_1, label_2, id_1, id_2, size_1, size_2, vis_1, vis_2))
 
+    # ------------------------------------------------------------------ split-bf16 guard (pcr_amd/engine.py)
+    def _weights_key(self):
+        ts = self.__dict__.get("_pcr_tensors")
+        if ts is None or len(ts[0]) != sum(1 for _ in self.parameters()):
+            ts = (list(self.parameters()), list(self.buffers()))
+            self.__dict__["_pcr_tensors"] = ts
+        return (sum(t._version for t in ts[0]) + sum(t._version for t in ts[1]), ts[0][0].data_ptr() if ts[0] else 0)
+
+    def precision_level(self):
+        """guard level of these weights (0 until calibrate_precision has run for them; always 0 in training mode, with
+        the guard off, or outside "bf16x3" mode)"""
+        if self.training or not engine.GUARD or engine.PRECISION != "bf16x3":
+            return 0
+        st = self.__dict__.get("_pcr_guard")
+        return st["level"] if st is not None and st["key"] == self._weights_key() else 0
+
+    def guard_state(self):
+        """what calibrate_precision measured for the current weights, or None"""
+        st = self.__dict__.get("_pcr_guard")
+        if st is None or st["key"] != self._weights_key():
+            return None
+        return {k: v for k, v in st.items() if k != "key"}
+
+    def calibrate_precision(self, sparse_1, sparse_2, bound=None, max_pairs=64):
+        """split-bf16 guard: run the hot path on (up to max_pairs of) this batch in f32 and at guard levels 0, 1, 2, keep the
+        first level whose logits stay within `bound` (engine.GUARD_BOUND, half the 1e-4 parity bound) of the f32 path's,
+        for as long as the weights do not change.  -> {"level", "dlogit": {level: max |logit - f32 logit|}, ...}"""
+        bound = engine.GUARD_BOUND if bound is None else float(bound)
+        s1, s2 = sparse_1[:max_pairs].contiguous(), sparse_2[:max_pairs].contiguous()
+        self.__dict__.pop("_pcr_guard", None)                      # (uncalibrated: the entry points apply no level of their own)
+        dl, level = {}, 0
+        if engine.PRECISION == "bf16x3" and not self.training:
+            with torch.no_grad():
+                def hot():
+                    xyz1, xyz2, h1, h2 = self.siamese_forward(s1, s2)
+                    return self.match_forward_inference(h1, h2, xyz1, xyz2)
+                with engine.precision("f32"):
+                    ref = hot()
+                for level in (0, 1, 2):
+                    with engine.guard_level(level):
+                        dl[level] = float((hot() - ref).abs().max())
+                    if dl[level] <= bound:
+                        break
+        st = dict(key=self._weights_key(), level=level, dlogit=dl, bound=bound, pairs=int(s1.shape[0]))
+        self.__dict__["_pcr_guard"] = st
+        return self.guard_state()
+
     # ------------------------------------------------------------------ encoder
     def forward_inference(self, pts_batched):
+        lvl = self.precision_level()
         with torch.no_grad():
+            if lvl:
+                with engine.guard_level(lvl):
+                    return self.backbone(pts_batched, self.backbone_list)
             return self.backbone(pts_batched, self.backbone_list)
 
     def siamese_forward(self, sparse_1, sparse_2):
+        lvl = self.precision_level()
+        if lvl:
+            with engine.guard_level(lvl):
+                return self._siamese_forward(sparse_1, sparse_2)
+        return self._siamese_forward(sparse_1, sparse_2)
+
+    def _siamese_forward(self, sparse_1, sparse_2):
         """(B,N,3) x 2 -> xyz1, xyz2 (B,N,3), h1, h2 (B,C,N); one backbone pass over 2B clouds"""
         assert sparse_1.shape == sparse_2.shape
         b, num_points, _ = sparse_1.shape
@@ -291,9 +349,20 @@ class ReIDNet(nn.Module):
         raise NotImplementedError("match_type=%r" % self.match_type)
 
     def match_forward_inference(self, h1, h2, xyz1, xyz2):
+        lvl = self.precision_level()
+        if lvl:
+            with engine.guard_level(lvl):
+                return self._match_logits(h1, h2, xyz1, xyz2, inference=True)[0]
         return self._match_logits(h1, h2, xyz1, xyz2, inference=True)[0]
 
     def match_gallery(self, h, xyz, pairs):
+        lvl = self.precision_level()
+        if lvl:
+            with engine.guard_level(lvl):
+                return self._match_gallery(h, xyz, pairs)
+        return self._match_gallery(h, xyz, pairs)
+
+    def _match_gallery(self, h, xyz, pairs):
         """Amortised matching (the reference's tracker use-case of forward_inference +
         match_forward_inference, ReIDNet.py:189-191, 444-462): every object is encoded ONCE, then any list
         of (i, j) combinations is scored.  h (M,C,N), xyz (M,N,3) from forward_inference / siamese_forward;
@@ -333,7 +402,12 @@ class ReIDNet(nn.Module):
         if not self.losses_to_use["match"]:
             return None, torch.tensor(0.0, requires_grad=True, device=device), (None, None)
         b = h1.shape[0]
-        match_preds, o = self._match_logits(h1, h2, xyz1, xyz2)
+        lvl = self.precision_level()
+        if lvl:
+            with engine.guard_level(lvl):
+                match_preds, o = self._match_logits(h1, h2, xyz1, xyz2)
+        else:
+            match_preds, o = self._match_logits(h1, h2, xyz1, xyz2)
         match_loss = self.bce(match_preds, match) * self.alpha["match"]
         if o is None:
             o = [None] * (2 * b)
@@ -391,6 +465,9 @@ class ReIDNet(nn.Module):
          vis_2) = self.preprocess_inputs_size_vis(sparse_1, sparse_2, dense_1, dense_2, label_1, label_2, id_1,
                                                   id_2, size_1, size_2, vis_1, vis_2)
         device = sparse_1.device
+        if (engine.GUARD and engine.PRECISION == "bf16x3" and not self.training and sparse_1.is_cuda and
+                self.guard_state() is None):
+            self.calibrate_precision(sparse_1, sparse_2)      # first batch after the weights changed (engine.py: the guard)
         xyz1, xyz2, h1, h2 = self.siamese_forward(sparse_1, sparse_2)
         h1, h2, xyz1, xyz2, match = self.get_match_supervision(h1, h2, xyz1, xyz2, id_1, id_2)
         match_preds, match_loss, _ = self.match_forward(h1, h2, xyz1, xyz2, match, None, device)

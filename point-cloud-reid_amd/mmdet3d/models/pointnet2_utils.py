@@ -151,7 +151,7 @@ class PointNetSetAbstractionEdgeSA(_Planned):
         points = None if points is None else points.contiguous()
         if self.sampling == "RANDOM" and self.use_knn:      # the configuration every ReID config builds
             idx = engine.knn_prefix(xyz, numpoints, self.nsample)
-            pooled = plan.run(xyz, points, idx)
+            pooled = engine.guarded(lambda: plan.run(xyz, points, idx))   # folded BatchNorm: f32 from guard level 1
             new_xyz = xyz[:, :numpoints].contiguous()
             return new_xyz, self.self_attention(pooled, new_xyz)
         # the dormant branches of sample_and_group_edge (:262-272): FPS centres and / or ball-query groups
@@ -160,7 +160,7 @@ class PointNetSetAbstractionEdgeSA(_Planned):
         new_xyz = index_points(xyz, centre)
         idx = (knn_point(self.nsample, xyz, new_xyz) if self.use_knn
                else query_ball_point(self.radius, self.nsample, xyz, new_xyz)).to(torch.int32).contiguous()
-        pooled = plan.run(xyz, points, idx, centre_idx=centre)
+        pooled = engine.guarded(lambda: plan.run(xyz, points, idx, centre_idx=centre))
         return new_xyz, self.self_attention(pooled, new_xyz)
 
 

@@ -237,6 +237,20 @@ class BasePointSAModule(nn.Module):
             self._plans[i] = (key, engine.SaPlan([l.conv for l in layers], [l.bn for l in layers], device, mode=1))
         return self._plans[i][1]
 
+    def _scale(self, plan, grouper, points_xyz, new_xyz, features, indices):
+        """one grouping scale under the current engine.PRECISION: neighbour query + grouped MLP + max"""
+        if (self.skip_repeats and not _NO_ROW_TABLE and grouper.max_radius is not None and not grouper.min_radius and
+                plan.wants_row_table(points_xyz.shape[1], grouper.sample_num, 0.0, points_xyz.shape[0], new_xyz.shape[1])):
+            # the ball query hands the SA kernel its rows ready-made ({neighbour, point - centre}); no index tensor
+            _, cnt, rows = ball_query_rows(grouper.max_radius, grouper.sample_num, points_xyz, new_xyz)
+            return plan.run(points_xyz, features, None, centre_idx=indices.contiguous(), cnt=cnt, rows=rows,
+                            K=grouper.sample_num, out_point_major=len(self.groupers) == 1)
+        idx, cnt = grouper.query_cnt(points_xyz, new_xyz)
+        # single-scale modules hand out the (B,C,S) view of a point-major buffer (a centre's channels are
+        # stored as one run); SaPlan / engine.dense read either layout, anyone else may call .contiguous()
+        return plan.run(points_xyz, features, idx, centre_idx=indices.contiguous(),
+                        cnt=cnt if self.skip_repeats else None, out_point_major=len(self.groupers) == 1)
+
     def forward(self, points_xyz, features=None, indices=None, target_xyz=None):
         """points_xyz (B,N,3), features (B,C,N) -> new_xyz (B,M,3), new_features (B,sum C',M), indices (B,M)"""
         points_xyz = points_xyz.contiguous()
@@ -248,18 +262,9 @@ class BasePointSAModule(nn.Module):
             if not isinstance(grouper, QueryAndGroup):
                 raise L.PcrError("GroupAll scales are not on the ReID path")
             plan = self._plan(i, points_xyz.device)
-            if (self.skip_repeats and not _NO_ROW_TABLE and grouper.max_radius is not None and not grouper.min_radius and
-                    plan.wants_row_table(points_xyz.shape[1], grouper.sample_num, 0.0, points_xyz.shape[0], new_xyz.shape[1])):
-                # the ball query hands the SA kernel its rows ready-made ({neighbour, point - centre}); no index tensor
-                _, cnt, rows = ball_query_rows(grouper.max_radius, grouper.sample_num, points_xyz, new_xyz)
-                outs.append(plan.run(points_xyz, features, None, centre_idx=indices.contiguous(), cnt=cnt, rows=rows,
-                                     K=grouper.sample_num, out_point_major=len(self.groupers) == 1))
-                continue
-            idx, cnt = grouper.query_cnt(points_xyz, new_xyz)
-            # single-scale modules hand out the (B,C,S) view of a point-major buffer (a centre's channels are
-            # stored as one run); SaPlan / engine.dense read either layout, anyone else may call .contiguous()
-            outs.append(plan.run(points_xyz, features, idx, centre_idx=indices.contiguous(),
-                                 cnt=cnt if self.skip_repeats else None, out_point_major=len(self.groupers) == 1))
+            # the launches of one scale (ball query in the form this arithmetic's SA kernel reads + the grouped MLP): these
+            # layers carry folded BatchNorm scales -- f32 from guard level 1 on (engine.guarded)
+            outs.append(engine.guarded(lambda: self._scale(plan, grouper, points_xyz, new_xyz, features, indices)))
         return new_xyz, torch.cat(outs, dim=1) if len(outs) > 1 else outs[0], indices
 
 

@@ -56,6 +56,55 @@ class precision:
         return False
 
 
+# ---- split-bf16 guard (round 5) --------------------------------------------------------------------
+# "bf16x3" drops the lo x lo term of every product: ~2^-17 of |w| |x| per term.  Against the 1e-4 parity bound that is a
+# comfortable 1-3e-5 on the logits for the seeded weights, but a checkpoint whose FOLDED BatchNorm layers cancel large
+# terms (running statistics far from the data: variance / 4 with means x 3 put the SSG logits at 9.7e-5) spends nearly
+# all of it.  Nothing in the weights alone tells -- the cancellation depends on the data -- and neither does the deviation
+# of a single launch (measured, tools/guard_sweep.py: the grouped-SA launches deviate by 0.8-1.1e-5 of their output's
+# scale for the seeded AND for the shifted statistics; what differs is how the layers behind them amplify it).  So the
+# guard measures what the bound is about: ReIDNet.calibrate_precision() runs the hot path on a calibration batch in f32
+# and in split bf16 and picks, per model and weight version, the first LEVEL whose logits stay within GUARD_BOUND (half the
+# parity bound) of the f32 path's:
+#   0  every matrix phase in split bf16 (what "bf16x3" means for a well-conditioned checkpoint);
+#   1  the launches that carry folded BatchNorm scales (the grouped SA MLPs: `guarded`) in f32, the rest in split bf16;
+#   2  the whole path in f32.
+# ReIDNet applies the level on every inference entry point; forward_test calibrates on its first batch after the weights
+# changed, bench.py before its timed region (and reports level + measured deviations as config.guard).  PCR_GUARD=0
+# switches it off; PCR_GUARD_BOUND moves the bound.
+GUARD = _os.environ.get("PCR_GUARD", "1") != "0"
+GUARD_BOUND = float(_os.environ.get("PCR_GUARD_BOUND", "5e-5"))
+_LEVEL = 0
+
+
+class guard_level:
+    """with engine.guard_level(n): the launches inside run at guard level n (see above); a no-op unless the arithmetic
+    mode is bf16x3"""
+
+    def __init__(self, level):
+        self.level = int(level)
+
+    def __enter__(self):
+        global _LEVEL
+        self.prev_level, _LEVEL = _LEVEL, self.level
+        self.prev_prec = set_precision("f32") if (self.level >= 2 and PRECISION == "bf16x3") else None
+
+    def __exit__(self, *exc):
+        global _LEVEL
+        _LEVEL = self.prev_level
+        if self.prev_prec is not None:
+            set_precision(self.prev_prec)
+        return False
+
+
+def guarded(fn):
+    """fn() = the launches of a plan that carries folded BatchNorm scales: in f32 from guard level 1 on"""
+    if _LEVEL >= 1 and PRECISION == "bf16x3":
+        with precision("f32"):
+            return fn()
+    return fn()
+
+
 # bench.py sets this to a list to collect (kernel, start_event, end_event, algorithmic flops,
 # algorithmic bytes, issued flops, arithmetic) per launch; events are recorded on the stream the kernels are launched on.
 PROFILE = None
