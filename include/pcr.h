@@ -82,6 +82,16 @@ int pcr_ball_query_rows_ok(int N, int K, float min_r);
 int pcr_ball_query_rows_f32(const float *centres, const float *xyz, int *idx, int *cnt, float *rows, int B, int N, int M,
                             float min_r, float max_r, int K, pcr_stream_t stream);
 
+/* pcr_fps_f32 and pcr_ball_query_rows_f32 of the picked centres as ONE launch (round 5): a pick's distances to the cloud
+ * are the ball query's distances of that centre, bit for bit, so the query costs one compare per point on top of the
+ * sampling.  xyz (B,N,3), temp (B,N) as pcr_fps_f32 -> idx (B,M) the pick order, new_xyz (B,M,3) the centres' coordinates
+ * (no gather launch), cnt (B,M) and rows exactly what pcr_ball_query_rows_f32(new_xyz, xyz, NULL, cnt, rows, .., 0, max_r,
+ * K) writes.  Needs pcr_fps_ball_query_rows_ok(N, M, K): N <= 1024, 2 <= M <= N, K even.  (The reference runs the two
+ * ops back to back: ops/pointnet_modules/point_sa_module.py:166-216 -> points_sampler.py:107-119, ball_query.py:14-47.) */
+int pcr_fps_ball_query_rows_ok(int N, int M, int K);
+int pcr_fps_ball_query_rows_f32(const float *xyz, float *temp, int *idx, float *new_xyz, int *cnt, float *rows, int B,
+                                int N, int M, float max_r, int K, pcr_stream_t stream);
+
 /* The model path's own (dormant) Python samplers / groupers, semantics of the PYTHON code rather than of the CUDA ops:
  *
  * farthest_point_sample (models/pointnet2_utils.py:116-137): first pick = start[b] (the reference draws it with

@@ -367,6 +367,190 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(const float *__restrict__ 
   }
 }
 
+// D-FPS and the ball query of the picked centres in ONE pass (round 5).  A pick's distances to every point of the cloud
+// are exactly what the ball query of that centre needs -- (p - c)^2 summed in the same order, so the bits are those of
+// ball_query_reg_kernel's (c - p)^2 -- and fps_wave_kernel computes them anyway for its running minimum: the fused
+// kernel tests them against the radius while they are in registers (one compare per point) and compacts the few hits
+// exactly as ball_query_reg_kernel<.., kRows> does.  Output: the pick order (idxs), the centres' coordinates
+// (new_xyz: no gather launch), the hit counts and the SA kernel's row table -- entry for entry what the two separate
+// launches write (tests/test_gpu_fps_bq.py).  One wave per cloud, up to 1024 points, K even, min radius 0.
+template <int PP>
+__global__ __launch_bounds__(64) void fps_bq_wave_kernel(const float *__restrict__ xyz, float *__restrict__ temp,
+                                                         int *__restrict__ idxs, float *__restrict__ new_xyz,
+                                                         int *__restrict__ cnt_out, f32x4 *__restrict__ rows_out,
+                                                         int n, int m, int block, int logb, float max_r2, int K) {
+  const int lane = threadIdx.x;
+  const size_t cloud = blockIdx.x;
+  xyz += cloud * n * 3;
+  temp += cloud * n;
+  idxs += cloud * m;
+  new_xyz += cloud * m * 3;
+  cnt_out += cloud * m;
+  constexpr int cpw = 16;
+  const int nitems = (m + cpw - 1) / cpw;
+  f32x4 *rcloud = rows_out + cloud * (size_t)nitems * (size_t)(cpw * K);
+  f32x2 px[PP], py[PP], pz[PP];
+  uint32_t t[2 * PP];
+#pragma unroll
+  for (int p = 0; p < 2 * PP; p++) {
+    const int k = lane + 64 * p;
+    const bool ok = k < n;
+    const float *q = xyz + (size_t)(ok ? k : 0) * 3;
+    const float x = q[0], y = q[1], z = q[2], tk = temp[ok ? k : 0];
+    px[p >> 1][p & 1] = ok ? x : INFINITY;    // a point at infinity is never inside a ball (and min(inf, 0) = 0 below)
+    py[p >> 1][p & 1] = ok ? y : INFINITY;
+    pz[p >> 1][p & 1] = ok ? z : INFINITY;
+    t[p] = ok ? __float_as_uint(tk) : 0u;     // min(d, 0) = 0: a point beyond n never beats a real one
+  }
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  int old = 0, roff = 0;
+  for (int j = 0; j < m; j++) {
+    if (j == m - 1) {   // the running minima as pcr_fps_f32 leaves them: the last centre does not enter them
+#pragma unroll
+      for (int p = 0; p < 2 * PP; p++) {
+        const int k = lane + 64 * p;
+        if (k < n) temp[k] = __uint_as_float(t[p]);
+      }
+    }
+    // ---- centre j = point `old`: its coordinates out of the register file
+    const int slot = __builtin_amdgcn_readfirstlane(old >> 6), ln = __builtin_amdgcn_readfirstlane(old & 63);
+    float ox = 0.f, oy = 0.f, oz = 0.f;
+#define PCR_FPS_PICK(P)                                                                                      \
+  case P:                                                                                                    \
+    if constexpr (P < 2 * PP) {                                                                              \
+      ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px[(P) >> 1][(P)&1]), ln));               \
+      oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py[(P) >> 1][(P)&1]), ln));               \
+      oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[(P) >> 1][(P)&1]), ln));               \
+    }                                                                                                        \
+    break;
+    switch (slot) {
+      PCR_FPS_PICK(0) PCR_FPS_PICK(1) PCR_FPS_PICK(2) PCR_FPS_PICK(3) PCR_FPS_PICK(4) PCR_FPS_PICK(5) PCR_FPS_PICK(6)
+      PCR_FPS_PICK(7) PCR_FPS_PICK(8) PCR_FPS_PICK(9) PCR_FPS_PICK(10) PCR_FPS_PICK(11) PCR_FPS_PICK(12) PCR_FPS_PICK(13)
+      PCR_FPS_PICK(14) PCR_FPS_PICK(15)
+      default: break;
+    }
+#undef PCR_FPS_PICK
+    if (lane == 0) {
+      idxs[j] = old;
+      new_xyz[3 * j] = ox;
+      new_xyz[3 * j + 1] = oy;
+      new_xyz[3 * j + 2] = oz;
+    }
+    // ---- every point's distance to it: hit masks, the running minimum and its lane maximum
+    const f32x2 x1 = {ox, ox}, y1 = {oy, oy}, z1 = {oz, oz};
+    unsigned long long mk[2 * PP];
+    uint32_t mx = 0u;
+#pragma unroll
+    for (int p = 0; p < PP; p++) {
+      const f32x2 dx = px[p] - x1, dy = py[p] - y1, dz = pz[p] - z1;
+      const f32x2 a = dx * dx;
+      const f32x2 b = dy * dy;
+      const f32x2 c = dz * dz;
+      const f32x2 s = a + b;
+      const f32x2 d = s + c;
+      mk[2 * p] = __ballot(d[0] < max_r2);
+      mk[2 * p + 1] = __ballot(d[1] < max_r2);
+      const uint32_t d0 = __float_as_uint(d[0]), d1 = __float_as_uint(d[1]);
+      t[2 * p] = d0 < t[2 * p] ? d0 : t[2 * p];
+      t[2 * p + 1] = d1 < t[2 * p + 1] ? d1 : t[2 * p + 1];
+      // (pins the update and the running maximum HERE: left alone the compiler sinks the minima and the maximum chain
+      // below the ball section and keeps the 2 PP distances -- or a second copy of t -- alive across it)
+      asm volatile("" : "+v"(t[2 * p]), "+v"(t[2 * p + 1]));
+      const uint32_t m01 = t[2 * p] > t[2 * p + 1] ? t[2 * p] : t[2 * p + 1];
+      mx = m01 > mx ? m01 : mx;
+      asm volatile("" : "+v"(mx));
+    }
+    // ---- the ball of centre j: ordered compaction of the hits into the item's row region (ball_query_reg_kernel).
+    // (opaque copies of the centre for the hit branch: with the same values the compiler keeps all 6 PP differences of the
+    // distance loop alive for the rare rows -- 48 registers, half the occupancy)
+    {
+      int oxi = __float_as_int(ox), oyi = __float_as_int(oy), ozi = __float_as_int(oz);
+      asm volatile("" : "+s"(oxi), "+s"(oyi), "+s"(ozi));
+      const float cx = __int_as_float(oxi), cy = __int_as_float(oyi), cz = __int_as_float(ozi);
+      const int item = j >> 4;
+      f32x4 *rbase = rcloud + (size_t)item * (size_t)(cpw * K);
+      const __amdgpu_buffer_rsrc_t rrows = __builtin_amdgcn_make_buffer_rsrc(rbase, 0, cpw * K * 16, 0x00020000);
+      auto put_row = [&](int rslot, int soff, int i, float dx, float dy, float dz) __attribute__((always_inline)) {
+        // (scalar-offset field 0 on purpose: see ball_query_reg_kernel)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{__int_as_float(i), dx, dy, dz}), rrows,
+                                               (rslot + soff) * 16, 0, 0);
+      };
+      int cnt = 0, first = 0;
+      float fdx = 0.f, fdy = 0.f, fdz = 0.f;
+#pragma unroll
+      for (int q = 0; q < 2 * PP; q++) {
+        if (mk[q] != 0ull) {   // wave-uniform: hits are rare (a few per 1024 points)
+          const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk[q] >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mk[q], 0u));
+          const bool mine = ((mk[q] >> lane) & 1ull) != 0ull;
+          // (the point's coordinates through an opaque copy INSIDE the branch: left alone the compiler speculates the row
+          // data of all 2 PP slots above the wave-uniform branches)
+          float qx = px[q >> 1][q & 1], qy = py[q >> 1][q & 1], qz = pz[q >> 1][q & 1];
+          asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));
+          if (mine && pos < K) put_row(pos, roff, q * 64 + lane, qx - cx, qy - cy, qz - cz);
+          if (cnt == 0) {
+            const int fl = (int)__builtin_ctzll(mk[q]);
+            first = q * 64 + fl;
+            fdx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), fl)) - cx;
+            fdy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), fl)) - cy;
+            fdz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), fl)) - cz;
+          }
+          cnt += __popcll(mk[q]);
+        }
+      }
+      if (cnt > K) cnt = K;
+      if (cnt == 0) {   // (cannot happen for a centre that is a point of the cloud; kept for the generic contract)
+        fdx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px[0][0]), 0)) - cx;
+        fdy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py[0][0]), 0)) - cy;
+        fdz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[0][0]), 0)) - cz;
+      }
+      const int nrow = cnt < 1 ? 2 : ((cnt + 1) & ~1);
+      if (lane < nrow - cnt) put_row(lane, roff + cnt, first, fdx, fdy, fdz);
+      roff += nrow;
+      if (lane == 0) cnt_out[j] = cnt;
+      if ((j & (cpw - 1)) == cpw - 1 || j == m - 1) {   // the item is complete: zero entries up to a whole 32-row block
+        if (roff + lane < ((roff + 31) & ~31)) put_row(lane, roff, 0, 0.f, 0.f, 0.f);
+        roff = 0;
+      }
+    }
+    if (j + 1 >= m) break;
+    // ---- the next pick (fps_wave_kernel): the maximum of the running minima, the reference's tie rule
+    const uint32_t best = dpp_max_u32(mx);
+    const unsigned long long lm = __ballot(mx == best);
+    bool unique = __popcll(lm) == 1;
+    if (unique) {
+      const int L = (int)__builtin_ctzll(lm);
+      int hits = 0, slot_found = 0;
+#pragma unroll
+      for (int p = 0; p < 2 * PP; p++) {
+        const unsigned long long mp = __ballot(t[p] == best);
+        const int bit = (int)((mp >> L) & 1ull);
+        hits += bit;
+        slot_found = bit ? p : slot_found;
+      }
+      if (hits == 1) old = 64 * slot_found + L;
+      else unique = false;
+    }
+    if (!unique) {   // rare: the tie keys are derived here, not kept in registers (the opaque lane keeps them from
+      // being hoisted out of the pick loop again)
+      uint32_t lo = 0u;
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+#pragma unroll
+      for (int p = 0; p < 2 * PP; p++) {
+        const int k = lane_o + 64 * p;
+        const uint32_t tr = (uint32_t)k & (uint32_t)(block - 1);
+        const uint32_t rev = logb ? (__brev(tr) >> (32 - logb)) : 0u;
+        const uint32_t lowp = k < n ? ((((uint32_t)(block - 1) - rev) << 22) | (0x3FFFFFu - (uint32_t)k)) : 0u;
+        const uint32_t l0 = t[p] == best ? lowp : 0u;
+        lo = l0 > lo ? l0 : lo;
+      }
+      lo = dpp_max_u32(lo);
+      old = (int)(0x3FFFFFu - (lo & 0x3FFFFFu));
+    }
+  }
+}
+
 int fps_launch(bool dist, const float *data, float *temp, int *idx, int B, int N, int M,
                hipStream_t st) {
   if (!data || !temp || !idx || B < 0 || N < 1 || N >= (1 << 22) || M < 0) return PCR_ERR_INVALID;
@@ -1396,6 +1580,32 @@ PCR_EXPORT int pcr_ball_query_rows_f32(const float *centres, const float *xyz, i
   if (B == 0 || M == 0) return PCR_OK;
   if (B > 65535) return PCR_ERR_INVALID;
   ball_query_launch(centres, xyz, idx, cnt, B, N, M, 0.f, max_r * max_r, K, pcr_s(stream), rows);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_fps_ball_query_rows_ok(int N, int M, int K) {
+  return N >= 1 && N <= 1024 && M >= 2 && M <= N && K >= 2 && K <= 64 * 16 && !(K & 1);
+}
+
+PCR_EXPORT int pcr_fps_ball_query_rows_f32(const float *xyz, float *temp, int *idx, float *new_xyz, int *cnt, float *rows,
+                                           int B, int N, int M, float max_r, int K, pcr_stream_t stream) {
+  if (!xyz || !temp || !idx || !new_xyz || !cnt || !rows || B < 0 || !(max_r > 0.f) || !pcr_fps_ball_query_rows_ok(N, M, K))
+    return PCR_ERR_INVALID;
+  if (B == 0) return PCR_OK;
+  int logb = 0;
+  while ((2 << logb) <= N && logb < 10) logb++;   // block = min(1024, 2^floor(log2 N)): fps_launch's tie-order block
+  const int block = 1 << logb;
+  const float max_r2 = max_r * max_r;
+  f32x4 *r4 = reinterpret_cast<f32x4 *>(rows);
+  hipStream_t st = pcr_s(stream);
+#define PCR_FPS_BQ(PPv) \
+  hipLaunchKernelGGL((fps_bq_wave_kernel<PPv>), dim3(B), dim3(64), 0, st, xyz, temp, idx, new_xyz, cnt, r4, N, M, block, logb, max_r2, K)
+  if (N <= 128) PCR_FPS_BQ(1);
+  else if (N <= 256) PCR_FPS_BQ(2);
+  else if (N <= 512) PCR_FPS_BQ(4);
+  else PCR_FPS_BQ(8);
+#undef PCR_FPS_BQ
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }

@@ -150,6 +150,32 @@ def ball_query_rows(max_radius, sample_num, xyz, center_xyz, want_idx=False):
     return idx, cnt, rows
 
 
+def fps_ball_query_rows_ok(N, M, K):
+    return bool(L.load().pcr_fps_ball_query_rows_ok(int(N), int(M), int(K)))
+
+
+def fps_ball_query_rows(xyz, num_points, max_radius, sample_num):
+    """D-FPS of `num_points` centres AND the ball query of those centres in one launch (pcr_fps_ball_query_rows_f32: a
+    pick's distances to the cloud are the ball query's distances of that centre) -> (indices (B,M) int32, new_xyz (B,M,3),
+    cnt (B,M), rows): what furthest_point_sample + gather_points + ball_query_rows return, entry for entry"""
+    assert xyz.is_contiguous()
+    B, N, _ = xyz.size()
+    with torch.cuda.device(xyz.device):
+        L.require_cuda(xyz)
+        L.require_f32(xyz)
+        dev = xyz.device
+        idx, cnt = _i32(B, num_points, device=dev), _i32(B, num_points, device=dev)
+        new_xyz = torch.empty((B, num_points, 3), dtype=torch.float32, device=dev)
+        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=dev)
+        rows = torch.empty((L.load().pcr_ball_query_rows_floats(B, num_points, sample_num),), dtype=torch.float32, device=dev)
+        with _prof("fps_ball_query[N=%d,M=%d,K=%d]" % (N, num_points, sample_num), 8.0 * B * N * num_points,
+                   4.0 * B * (3 * N + 4 * num_points + num_points * sample_num)):
+            L.check(L.load().pcr_fps_ball_query_rows_f32(L.ptr(xyz), L.ptr(temp), L.ptr(idx), L.ptr(new_xyz), L.ptr(cnt),
+                                                         L.ptr(rows), B, N, num_points, ctypes.c_float(max_radius),
+                                                         sample_num, L.stream_ptr()), "pcr_fps_ball_query_rows_f32")
+    return idx, new_xyz, cnt, rows
+
+
 class KNN(Function):
     @_on_device
     def forward(ctx, k, xyz, center_xyz=None, transposed=False):

@@ -23,7 +23,7 @@ from torch import nn as nn
 from pcr_amd import engine
 from pcr_amd import _lib as L
 from ..models.builder import Registry
-from .point_ops import (ball_query, ball_query_cnt, ball_query_rows, furthest_point_sample, furthest_point_sample_with_dist, gather_points,
+from .point_ops import (ball_query, ball_query_cnt, ball_query_rows, fps_ball_query_rows, fps_ball_query_rows_ok, furthest_point_sample, furthest_point_sample_with_dist, gather_points,
                         grouping_operation, knn, three_interpolate, three_nn)
 
 SA_MODULES = Registry("point_sa_module")
@@ -237,6 +237,27 @@ class BasePointSAModule(nn.Module):
             self._plans[i] = (key, engine.SaPlan([l.conv for l in layers], [l.bn for l in layers], device, mode=1))
         return self._plans[i][1]
 
+    def _fused_sample_and_query(self, points_xyz, features, indices, target_xyz):
+        """D-FPS over the whole cloud + ONE ball-query scale whose SA kernel reads the row table: sampling, the centres'
+        coordinates, hit counts and the row table come from one launch (ops.fps_ball_query_rows) -- the sampler's
+        distances ARE the query's.  None: not that configuration (the caller runs the separate ops)."""
+        if (_NO_FPS_BQ or indices is not None or target_xyz is not None or len(self.groupers) != 1 or
+                not self.skip_repeats or _NO_ROW_TABLE or engine.PRECISION == "f32" or engine._LEVEL >= 1 or
+                len(self.points_sampler.samplers) != 1 or not isinstance(self.points_sampler.samplers[0], DFPS_Sampler) or
+                self.points_sampler.fps_sample_range_list[0] != -1):
+            return None
+        grouper = self.groupers[0]
+        if not isinstance(grouper, QueryAndGroup) or grouper.max_radius is None or grouper.min_radius:
+            return None
+        B, N, _ = points_xyz.shape
+        M, K = self.num_point[0], grouper.sample_num
+        plan = self._plan(0, points_xyz.device)
+        if not (fps_ball_query_rows_ok(N, M, K) and plan.wants_row_table(N, K, 0.0, B, M)):
+            return None
+        indices, new_xyz, cnt, rows = fps_ball_query_rows(points_xyz, M, grouper.max_radius, K)
+        out = plan.run(points_xyz, features, None, centre_idx=indices, cnt=cnt, rows=rows, K=K, out_point_major=True)
+        return new_xyz, out, indices
+
     def _scale(self, plan, grouper, points_xyz, new_xyz, features, indices):
         """one grouping scale under the current engine.PRECISION: neighbour query + grouped MLP + max"""
         if (self.skip_repeats and not _NO_ROW_TABLE and grouper.max_radius is not None and not grouper.min_radius and
@@ -254,6 +275,9 @@ class BasePointSAModule(nn.Module):
     def forward(self, points_xyz, features=None, indices=None, target_xyz=None):
         """points_xyz (B,N,3), features (B,C,N) -> new_xyz (B,M,3), new_features (B,sum C',M), indices (B,M)"""
         points_xyz = points_xyz.contiguous()
+        fused = self._fused_sample_and_query(points_xyz, features, indices, target_xyz)
+        if fused is not None:
+            return fused
         new_xyz, indices = self._sample_points(points_xyz, features, indices, target_xyz)
         if indices is None:
             raise L.PcrError("the fused SA launch gathers centres by index; pass `indices` or let the sampler run")
@@ -269,6 +293,7 @@ class BasePointSAModule(nn.Module):
 
 
 _NO_ROW_TABLE = bool(os.environ.get("PCR_NO_ROW_TABLE"))   # diagnostics: the indexed ragged launch instead
+_NO_FPS_BQ = bool(os.environ.get("PCR_NO_FPS_BQ"))         # diagnostics: sampling and ball query as separate launches
 
 
 @SA_MODULES.register_module()
