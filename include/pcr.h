@@ -541,6 +541,18 @@ int pcr_local_attn_train_bwd_f32(const float *qkv, const int *idx, const float *
 int pcr_reduce_parts_f32(const float *part, int nparts, long stride, int rows, int cols, int ld, float *out,
                          pcr_stream_t stream);
 
+/* n reductions of that kind in ONE launch (round 5): out (rows x cols, contiguous) = sum over p < nparts (increasing p) of
+ * part[p stride + r ld + c].  `jobs` is a HOST array (passed by value in the kernel arguments, 64 per launch): the
+ * regions of a backward launch's partial record are summed into compact per-parameter tensors (pcr_amd/train_ops.py:
+ * reduce_regions). */
+typedef struct pcr_reduce_job {
+  const float *part;
+  float *out;
+  long stride;
+  int nparts, rows, cols, ld;
+} pcr_reduce_job;
+int pcr_reduce_multi_f32(const pcr_reduce_job *jobs, int n, pcr_stream_t stream);
+
 /* BatchNorm (training) from the statistics partials [nparts][2][ceil32(C)] over R rows: mean, biased variance ->
  * scale = gamma invstd, shift = beta - mean scale, inv_scale = 1 / scale; running statistics updated in place
  * (momentum, unbiased variance) when given.  nn.BatchNorm2d semantics (pointnet2_utils.py:353-355). */

@@ -1303,6 +1303,100 @@ PCR_EXPORT int pcr_tdense_bwd_f32(const pcr_tdense_bwd *p, pcr_stream_t stream) 
   return PCR_OK;
 }
 
+// Many reductions in ONE launch (round 5): a training step's backward leaves ~40 partial-sum buffers (weight / bias /
+// norm gradients), each summed by its own 6 us launch so far.  The jobs travel by value in the kernel arguments (no
+// descriptor table to upload); workgroup (x, y) reduces 32 elements of job y, jobs shorter than x 32 elements leave.
+constexpr int kReduceJobs = 64;
+struct ReduceJobs {
+  pcr_reduce_job j[kReduceJobs];
+};
+
+__global__ __launch_bounds__(256) void reduce_multi_kernel(ReduceJobs jobs) {
+  __shared__ f32x4 red4[32][8];
+  const pcr_reduce_job jb = jobs.j[blockIdx.y];
+  const int total = jb.rows * jb.cols;
+  if ((int)blockIdx.x * 32 >= total) return;
+  const size_t stride = (size_t)jb.stride;
+  const bool vec = ((jb.cols | jb.ld) & 3) == 0 && (stride & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(jb.part) | reinterpret_cast<uintptr_t>(jb.out)) & 15) == 0;
+  if (vec) {
+    // reduce_parts4_kernel's scheme: 8 quads of elements x 32 part lanes, 16-byte loads on eight chains per lane (the
+    // big records -- the chain kernels' dW partials, 30 MB per launch -- need the bytes in flight)
+    const int ql = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int e = (blockIdx.x * 8 + ql) * 4;
+    const bool ok = e < total;
+    const int r = ok ? e / jb.cols : 0, c = ok ? e - r * jb.cols : 0;
+    const float *p = jb.part + (size_t)r * jb.ld + c;
+    f32x4 s[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int q = pl;
+    for (; q + 224 < jb.nparts; q += 256) {
+      f32x4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = ld4(p + (size_t)(q + 32 * k) * stride);
+#pragma unroll
+      for (int k = 0; k < 8; k++) s[k] += v[k];
+    }
+    for (; q < jb.nparts; q += 32) s[0] += ld4(p + (size_t)q * stride);
+    red4[pl][ql] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (pl == 0 && ok) {
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 32; i++) t += red4[i][ql];
+      *reinterpret_cast<f32x4 *>(jb.out + e) = t;
+    }
+    return;
+  }
+  float (*red)[32] = reinterpret_cast<float (*)[32]>(&red4[0][0]);     // [8][32]
+  const int el = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + el;
+  const bool ok = e < total;
+  const int r = ok ? e / jb.cols : 0, c = ok ? e - r * jb.cols : 0;
+  const float *p = jb.part + (size_t)r * jb.ld + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int q = pl;
+  for (; q + 24 < jb.nparts; q += 32) {
+    const float v0 = p[(size_t)q * stride], v1 = p[(size_t)(q + 8) * stride], v2 = p[(size_t)(q + 16) * stride],
+                v3 = p[(size_t)(q + 24) * stride];
+    s0 += v0;
+    s1 += v1;
+    s2 += v2;
+    s3 += v3;
+  }
+  for (; q < jb.nparts; q += 8) s0 += p[(size_t)q * stride];
+  red[pl][el] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (pl == 0 && ok) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) t += red[i][el];
+    jb.out[e] = t;
+  }
+}
+
+PCR_EXPORT int pcr_reduce_multi_f32(const pcr_reduce_job *jobs, int n, pcr_stream_t stream) {
+  if (n < 0 || (n && !jobs)) return PCR_ERR_INVALID;
+  for (int i = 0; i < n; i++)
+    if (!jobs[i].part || !jobs[i].out || jobs[i].nparts < 1 || jobs[i].rows < 1 || jobs[i].cols < 1 || jobs[i].ld < jobs[i].cols)
+      return PCR_ERR_INVALID;
+  for (int lo = 0; lo < n; lo += kReduceJobs) {
+    const int m = n - lo < kReduceJobs ? n - lo : kReduceJobs;
+    ReduceJobs a;
+    int most = 0;
+    for (int i = 0; i < m; i++) {
+      a.j[i] = jobs[lo + i];
+      const int total = jobs[lo + i].rows * jobs[lo + i].cols;
+      most = total > most ? total : most;
+    }
+    for (int i = m; i < kReduceJobs; i++) a.j[i] = a.j[0];
+    hipLaunchKernelGGL(reduce_multi_kernel, dim3((most + 31) / 32, m), dim3(256), 0, pcr_s(stream), a);
+    PCR_CHECK_LAUNCH();
+  }
+  return PCR_OK;
+}
+
 PCR_EXPORT int pcr_reduce_parts_f32(const float *part, int nparts, long stride, int rows, int cols, int ld, float *out,
                                     pcr_stream_t stream) {
   if (!part || !out || nparts < 1 || rows < 1 || cols < 1 || ld < cols) return PCR_ERR_INVALID;

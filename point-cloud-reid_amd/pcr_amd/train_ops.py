@@ -272,6 +272,30 @@ def reduce_parts(part, nparts, stride, rows, cols, ld):
     return out
 
 
+# ---- partial-sum reductions -------------------------------------------------------------------------------------------
+# A backward launch leaves per-workgroup partial records (weight / bias / norm gradients side by side); ONE launch
+# (pcr_reduce_multi_f32) sums every region of the record into its own compact tensor -- no padded views, so autograd's
+# AccumulateGrad takes the gradients as they are instead of cloning them.  (Tried in round 5 and removed: deferring all
+# reductions of a backward pass to one launch at its end through an autograd-engine callback.  It measured no faster --
+# the cost is the bytes of the partial records, not the ~35 launches -- and it is only safe for a parameter used ONCE in
+# the graph: a second use makes the engine add the still-unreduced buffer.)
+class _ReduceJob(ctypes.Structure):
+    _fields_ = [("part", c_fp), ("out", c_fp), ("stride", ctypes.c_long), ("nparts", ctypes.c_int), ("rows", ctypes.c_int),
+                ("cols", ctypes.c_int), ("ld", ctypes.c_int)]
+
+
+def reduce_regions(part, nparts, stride, regions):
+    """regions [(offset in floats, rows, cols, ld)] of every partial record -> compact (rows, cols) tensors, summed over the
+    nparts records (increasing record order, fixed: bit-reproducible)"""
+    dev = part.device
+    outs = [_f32(rows, cols, device=dev) for _, rows, cols, _ in regions]
+    jobs = [_ReduceJob(part.data_ptr() + 4 * off, o.data_ptr(), stride, nparts, rows, cols, ld)
+            for (off, rows, cols, ld), o in zip(regions, outs)]
+    arr = (_ReduceJob * len(jobs))(*jobs)
+    L.check(L.load().pcr_reduce_multi_f32(arr, len(jobs), L.stream_ptr()), "pcr_reduce_multi_f32")
+    return outs
+
+
 # Arithmetic of the training launches' matrix phases: "f32" (f32-input MFMA, exact fmaf chains) or "bf16x3" (split bf16
 # on the bf16 matrix core, three MFMAs per product, f32 accumulation) -- today the backward of the 128 x 128 grouped-MLP
 # layers (dx and dW; include/pcr.h pcr_tdense_bwd.precision), every other launch is f32 whatever this says.
@@ -354,9 +378,8 @@ def tdense_bwd(g, x, cout, dy_mode=0, y=None, k=None, argmax=None, pooled=None, 
     with _prof("tdense_bwd[mode=%d,cin=%d,cout=%d,L=%d]" % (dy_mode, cin, cout, Ln), flops, nbytes, arith="lib"):
         L.check(L.load().pcr_tdense_bwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_tdense_bwd_f32")
     if want_dw:
-        flat = reduce_parts(parts, nwg, per, 1, per, per).view(per)
-        out["dW"] = flat[:coutP * cinP].view(coutP, cinP)[:cout, :cin]
-        out["db"] = flat[coutP * cinP:coutP * cinP + cout]
+        dW, db = reduce_regions(parts, nwg, per, [(0, cout, cin, cinP), (coutP * cinP, 1, cout, cout)])
+        out["dW"], out["db"] = dW, db.view(cout)
     return out
 
 
@@ -728,8 +751,8 @@ class TNorm(Function):
         L.check(L.load().pcr_tnorm_bwd_f32(L.ptr(g), L.ptr(x), L.ptr(gamma.detach()), L.ptr(mean), L.ptr(rstd), L.ptr(y),
                                            L.ptr(dx), L.ptr(dres), L.ptr(part), B, C, Ln, G, L.stream_ptr()),
                 "pcr_tnorm_bwd_f32")
-        gb = reduce_parts(part, nparts, 2 * C, 2, C, C)
-        return dx, gb[0], gb[1], (dres if dres is not None else g) if has_res else None, None, None, None
+        dgam, dbet = reduce_regions(part, nparts, 2 * C, [(0, 1, C, C), (C, 1, C, C)])
+        return dx, dgam.view(C), dbet.view(C), (dres if dres is not None else g) if has_res else None, None, None, None
 
 
 def tnorm(x, norm, res=None, relu=False):
@@ -800,15 +823,13 @@ class AttnTail(Function):
         with _prof("attn_tail_bwd[d=%d,c1=%d,hid=%d,out=%d,L=%d]" % (d, c1, hid, out, Ln), 3.0 * flops,
                    4.0 * B * Ln * (2 * d + 2 * c1 + out)):
             L.check(lib.pcr_attn_tail_bwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_attn_tail_bwd_f32")
-        f = reduce_parts(parts, nwg, rec, 1, rec, rec).view(rec)
         cup = _c32(c1 + d)
         o0, o2 = d * d, d * d + hid * cup
         og = o2 + out * hid
-        dWm = f[:o0].view(d, d)
-        dW0 = f[o0:o2].view(hid, cup)[:, :c1 + d]
-        dW2 = f[o2:og].view(out, hid)
-        dg1, db1, dg2, db2 = f[og:og + d], f[og + d:og + 2 * d], f[og + 2 * d:og + 2 * d + out], f[og + 2 * d + out:]
-        return dmsg, dres, dWm, dg1, db1, dW0, dW2, dg2, db2, None, None
+        dWm, dW0, dW2, dg1, db1, dg2, db2 = reduce_regions(
+            parts, nwg, rec, [(0, d, d, d), (o0, hid, c1 + d, cup), (o2, out, hid, hid), (og, 1, d, d), (og + d, 1, d, d),
+                              (og + 2 * d, 1, out, out), (og + 2 * d + out, 1, out, out)])
+        return dmsg, dres, dWm, dg1.view(d), db1.view(d), dW0, dW2, dg2.view(out), db2.view(out), None, None
 
 
 def attn_tail(m, msg, res, residual, names=("merge", "norm1", "mlp", "norm2")):
@@ -885,14 +906,13 @@ class AttnHead(Function):
         with _prof("attn_head_bwd[c=%d,hd=%d,d=%d,n=%d,L=%d]" % (C, hd, d, n, Ln), 3.0 * flops,
                    4.0 * B * Ln * (2 * C + 3 + n * d)):
             L.check(lib.pcr_attn_head_bwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_attn_head_bwd_f32")
-        f = reduce_parts(parts, nwg, rec, 1, rec, rec).view(rec)
         o_p2 = hd * 32
         o_w = o_p2 + C * hd
         o_c1 = o_w + n * d * C
-        dP1 = f[:o_p2].view(hd, 32)[:, :3]
-        dP2 = f[o_p2:o_w].view(C, hd)
-        dWs = [f[o_w + j * d * C:o_w + (j + 1) * d * C].view(d, C) for j in range(n)]
-        return (dx, None, dP1, f[o_c1:o_c1 + hd], dP2, f[o_c1 + hd:o_c1 + hd + C], None, *dWs)
+        regs = [(0, hd, 3, 32), (o_c1, 1, hd, hd), (o_p2, C, hd, hd), (o_c1 + hd, 1, C, C)] + \
+               [(o_w + j * d * C, d, C, C) for j in range(n)]
+        dP1, dc1, dP2, dc2, *dWs = reduce_regions(parts, nwg, rec, regs)
+        return (dx, None, dP1, dc1.view(hd), dP2, dc2.view(C), None, *dWs)
 
 
 def attn_head(pos_mlp, x, xyz_cm, Ws, src):

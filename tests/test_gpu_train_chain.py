@@ -235,3 +235,28 @@ def test_matching_stages_on_the_fused_path_equal_the_unfused_graph():
     assert set(gf) == set(gu) and len(gf) >= 30
     for k in gu:
         assert _rel(gf[k], gu[k]) < 1e-4, (k, _rel(gf[k], gu[k]))
+
+
+# ---- partial-sum reductions into compact gradients ------------------------------------------------------------------------
+def test_gradients_arrive_compact_and_a_parameter_used_twice_is_summed_correctly():
+    """train_ops.reduce_regions hands autograd compact contiguous gradients (no padded views to clone), and a parameter that
+    enters the graph twice -- once through a fused chain, once sliced and re-joined into a dense layer -- gets the sum of
+    both contributions (the hazard that ruled out deferring the reductions to the end of the pass)"""
+    from pcr_amd import train_ops as TO
+    m = Tail(64, 64, 128, 64, seed=2).cuda()
+    g = torch.Generator().manual_seed(12)
+    msg, x = torch.randn(9, 64, 128, generator=g).cuda(), torch.randn(9, 64, 128, generator=g).cuda()
+    go = torch.randn(9, 64, 128, generator=g).cuda()
+
+    def run(tail):
+        for p in m.parameters():
+            p.grad = None
+        w_cat = torch.cat([m.merge.weight[:32], m.merge.weight[32:]], dim=0)
+        y = TO.dense(tail(m, msg, x, True), w_cat)
+        (y * go).sum().backward()
+        return {k: p.grad.clone() for k, p in m.named_parameters()}
+    a = run(lambda mm, a_, b_, r: TO.attn_tail(mm, a_, b_, r))
+    b = run(_unfused)
+    assert all(v.is_contiguous() for v in a.values())
+    for k in a:
+        assert _rel(a[k], b[k]) < 3e-5, (k, _rel(a[k], b[k]))
