@@ -234,11 +234,14 @@ def train_bench(args, desc, n, bl, pairs, rank, world, steps=None, warmup=None):
     data = dict(sparse_1=list(s1.to(dev)), sparse_2=list(s2.to(dev)), dense_1=list(s1.to(dev)), dense_2=list(s2.to(dev)),
                 label_1=[zero] * pairs, label_2=[zero] * pairs,
                 id_1=[i.view(1).to(dev) for i in ids1], id_2=[i.view(1).to(dev) for i in ids2])
-    # PCR_TRAIN_GRAPH=1: forward + backward replayed from a HIP graph (Trainer(graph=True)).  Measured: the step is bound by
-    # the launches' host cost only below ~128 pairs per GPU (16 pairs: 8.9 -> 4.0-4.5 ms replayed); at this workload's 256
-    # pairs the GPU is the bound either way (10.4-10.9 ms replayed against 10.45 eager), so eager is the default here
+    # forward + backward replayed from a HIP graph (Trainer(graph=True)); the exchange and the update stay eager.  Until round
+    # 4 the GPU was the bound at this workload's 256 pairs either way (10.4-10.9 ms replayed against 10.45 eager) and eager
+    # was the default.  (Round 5: the fused chains brought the step's GPU time down to about what the host needs to issue its ~400 launches --
+    # inside the default run, after nine other workloads, the eager step measured 10.4 ms against 9.2 alone.  One rank
+    # therefore times the REPLAYED iteration by default, a fixed mode like the inference lines'; PCR_TRAIN_GRAPH=0 keeps
+    # one launch per node; N > 1 ranks run eager -- Trainer says so -- and config.launch names what ran)
     tr = train.Trainer(model, max_iters=steps + warmup + 3, lr=3e-4, grad_clip=1.0,
-                       graph=os.environ.get("PCR_TRAIN_GRAPH", "0") == "1" and warmup >= 2)
+                       graph=os.environ.get("PCR_TRAIN_GRAPH", "1") == "1" and warmup >= 2 and world == 1)
     tr.graph_warmup = 1          # iteration 0 eager, iteration 1 captures: both inside the W warm-up steps
     prewarm()
     # (a pilot of both ways like the inference lines' was tried: an eager step AFTER a replay runs on the trainer's own
