@@ -394,6 +394,14 @@ int pcr_dense_xpm_prec_f32(const float *x, const float *wp_bf, const float *scal
  * follow are plain pcr_dense_f32 calls on a (1,C,B) tensor. */
 int pcr_max_over_l_f32(const float *x, float *out, int B, int C, int L, pcr_stream_t stream);
 
+/* pcr_dense_f32 followed by pcr_max_over_l_f32 as ONE launch that never writes the (B,cout,L) tensor (round 5): the conv3 +
+ * BN + ReLU + max over the points of STN3d / STNkd (models/pointnet.py:27-33, 67-73).  out (cout,B) as pcr_max_over_l_f32
+ * writes it; bit-equal to the two-launch form (a maximum does not depend on the order).  pcr_dense_max_ok: cout a multiple
+ * of 256 and cin small enough for a 64-token tile of the whole input extent in 64 KB of LDS (cin <= 232). */
+int pcr_dense_max_ok(int cin, int cout, int L);
+int pcr_dense_max_f32(const float *x, const float *wp, const float *scale, const float *shift, float *out, int B, int cin,
+                      int cout, int L, int act, pcr_stream_t stream);
+
 /* t (1,k*k,B) = the fc3 output of an STN (+identity), entry [c*k + c2][b] = T_b[c][c2] -> per-cloud packed
  * weight images (B, packed(k,k)) of W_b = T_b^T; pcr_dense_bmm_f32(x, images) then equals
  * torch.bmm(x^T, T)^T (pointnet.py:110,118). */

@@ -388,6 +388,78 @@ __global__ __launch_bounds__(kThreads) void dense_kernel(DenseArgs a) {
   }
 }
 
+// The same layer followed by the max over the points (STN3d / STNkd: conv3 + BN + ReLU, then torch.max over N,
+// models/pointnet.py:27-33, 67-73) WITHOUT the (B,cout,L) tensor: one workgroup owns a cloud's 256-cout chunk, walks the
+// cloud's 64-token tiles and keeps the running maximum of every (cout, token lane) in registers; at the end the 32 token
+// lanes of a cout meet by DPP and one lane stores out[c * B + b].  (Round 4: the dense launch wrote 2.1 GB per 2048
+// clouds and pcr_max_over_l_f32 read them back, 0.64 ms, twice per forward.)  A maximum is order-independent: bit-equal
+// to the two-launch form.
+__global__ __launch_bounds__(kThreads) void dense_max_kernel(DenseArgs a, int B) {
+  constexpr int TB = 2, T = 64, RP = T + 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int cinP = ceil8(a.cin), coutP = ceil32(a.cout);
+  float *X = smem;
+  float *s_sc = X + cinP * RP;
+  float *s_sh = s_sc + 256;
+  const size_t b = blockIdx.y;
+  const int chunk0 = blockIdx.z * 256;
+  const int chunkP = coutP - chunk0 < 256 ? coutP - chunk0 : 256;
+  {
+    const int oc = chunk0 + threadIdx.x;
+    s_sc[threadIdx.x] = (a.scale && oc < a.cout) ? a.scale[oc] : 1.0f;
+    s_sh[threadIdx.x] = (a.shift && oc < a.cout) ? a.shift[oc] : 0.0f;
+  }
+  const int act = a.act, L = a.L;
+  const float *wp = a.wp + (size_t)chunk0 * 8;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  float vmax[2][16];
+#pragma unroll
+  for (int nr = 0; nr < 2; nr++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) vmax[nr][r] = -INFINITY;
+  for (int t0 = 0; t0 < L; t0 += T) {
+    if (t0) __syncthreads();   // everyone is done with the previous tile's operands
+    load_tile(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
+    __syncthreads();
+    auto epi = [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
+      const int nr = cb >> 2;       // cout blocks wave, wave + 4 (chunkP <= 256: at most two rounds)
+      if (t0 + tb * 32 + l31 < L) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int o = cb * 32 + 8 * g + 4 * h;
+          const f32x4 s4 = *reinterpret_cast<const f32x4 *>(s_sc + o), b4 = *reinterpret_cast<const f32x4 *>(s_sh + o);
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            float r = acc[4 * g + q] * s4[q] + b4[q];
+            r = act == 1 ? fmaxf(r, 0.f) : (act == 2 && r < 0.f) ? r * 0.2f : r;
+            if (nr == 0) vmax[0][4 * g + q] = fmaxf(vmax[0][4 * g + q], r);
+            else vmax[1][4 * g + q] = fmaxf(vmax[1][4 * g + q], r);
+          }
+        }
+      }
+    };
+    tile_dense2<TB, 2, 0, true>(X, cinP, wp, chunkP, false, epi, nullptr, nullptr, DenseNoHook(), coutP);
+  }
+  // the 32 token lanes of a half (h) hold the same 16 couts: maximum across them, then lanes 0 and 32 store
+#pragma unroll
+  for (int nr = 0; nr < 2; nr++) {
+    const int cb = wave + 4 * nr;
+    if (cb < (chunkP >> 5)) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float v = vmax[nr][r];
+        v = fmaxf(v, __shfl_xor(v, 1, 64));
+        v = fmaxf(v, __shfl_xor(v, 2, 64));
+        v = fmaxf(v, __shfl_xor(v, 4, 64));
+        v = fmaxf(v, __shfl_xor(v, 8, 64));
+        v = fmaxf(v, __shfl_xor(v, 16, 64));
+        const int oc = chunk0 + cb * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+        if ((lane & 31) == 0 && oc < a.cout) a.y[(size_t)oc * B + b] = v;
+      }
+    }
+  }
+}
+
 // ---- the wide per-point layers on the bf16 matrix core (round 4): PointNet's 1x1 convs, DGCNN's conv5 and the LinearRes
 // downsample rows were the last MFMA-bound launches in f32 (0.7 of a 157 TFLOP/s roof).  Same tiling as the chunked f32
 // form -- 64 tokens x up to 256 couts per workgroup, the cin extent walked in chunks of KC channels with the accumulators
@@ -972,6 +1044,25 @@ PCR_EXPORT int pcr_max_over_l_f32(const float *x, float *out, int B, int C, int 
   size_t rows = (size_t)B * C;
   hipLaunchKernelGGL(max_over_l_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(kThreads), 0, pcr_s(stream), x, out,
                      B, C, L);
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
+PCR_EXPORT int pcr_dense_max_ok(int cin, int cout, int L) {
+  // (whole 256-cout chunks: eight cout blocks per workgroup, every wave owns ALL token blocks of its two)
+  return cin >= 1 && cout >= 256 && cout % 256 == 0 && L >= 1 && (size_t)ceil8(cin) * 65 * 4 + 2048 <= (size_t)64 * 1024;
+}
+
+PCR_EXPORT int pcr_dense_max_f32(const float *x, const float *wp, const float *scale, const float *shift, float *out,
+                                 int B, int cin, int cout, int L, int act, pcr_stream_t stream) {
+  if (!x || !wp || !out || B < 0 || !pcr_dense_max_ok(cin, cout, L)) return PCR_ERR_INVALID;
+  if (B == 0) return PCR_OK;
+  if (B > 65535) return PCR_ERR_INVALID;
+  DenseArgs a{x, wp, scale, shift, out, cin, cout, L, act, 0, 0, 0, nullptr};
+  const size_t lds = ((size_t)ceil8(cin) * 65 + 512) * sizeof(float);
+  static bool ok = allow_big_lds(dense_max_kernel);
+  (void)ok;
+  hipLaunchKernelGGL(dense_max_kernel, dim3(1, B, (ceil32(cout) + 255) / 256), dim3(kThreads), lds, pcr_s(stream), a, B);
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }

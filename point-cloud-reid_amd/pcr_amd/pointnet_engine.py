@@ -5,8 +5,12 @@ no transposes), the learned 3x3 / 64x64 input and feature transforms are applied
 packed weights (pcr_pack_bmm_f32 + pcr_dense_bmm_f32)."""
 import torch
 
+import os
+
 from . import _lib as L
 from . import engine as E
+
+_NO_DENSE_MAX = bool(os.environ.get("PCR_NO_DENSE_MAX"))     # diagnostics: conv3 and the max over the points as two launches
 
 
 # (The encoder's convs and both transform nets stay on the f32-input MFMA in every mode: measured in split bf16, the
@@ -31,11 +35,21 @@ class _StnPlan:
     def run(self, x):
         """x (B,k,N) -> per-cloud packed transform images"""
         B = x.shape[0]
-        for wp, cout, sc, sh in self.convs:
+        lib = L.load()
+        for wp, cout, sc, sh in self.convs[:2]:
             x = E.dense(x, wp, cout, sc, sh, act=1)
-        C = x.shape[1]
+        wp, C, sc, sh = self.convs[2]
         g = torch.empty((1, C, B), dtype=torch.float32, device=x.device)
-        L.check(L.load().pcr_max_over_l_f32(L.ptr(x), L.ptr(g), B, C, x.shape[2], L.stream_ptr()), "pcr_max_over_l_f32")
+        cin, Ln = x.shape[1], x.shape[2]
+        if not _NO_DENSE_MAX and x.is_contiguous() and lib.pcr_dense_max_ok(cin, C, Ln):
+            # conv3 + BN + ReLU + max over the points in one launch: the (B,1024,N) tensor is never written
+            with E._prof("dense_max[cin=%d,cout=%d,L=%d]" % (cin, C, Ln), 2.0 * B * Ln * cin * C, 4.0 * B * (Ln * cin + C),
+                         arith="f32"):
+                L.check(lib.pcr_dense_max_f32(L.ptr(x), L.ptr(wp), L.ptr(sc), L.ptr(sh), L.ptr(g), B, cin, C, Ln, 1,
+                                              L.stream_ptr()), "pcr_dense_max_f32")
+        else:
+            x = E.dense(x, wp, C, sc, sh, act=1)
+            L.check(lib.pcr_max_over_l_f32(L.ptr(x), L.ptr(g), B, C, x.shape[2], L.stream_ptr()), "pcr_max_over_l_f32")
         for wp, cout, sc, sh, act in self.fcs:
             g = E.dense(g, wp, cout, sc, sh, act=act)
         lib = L.load()

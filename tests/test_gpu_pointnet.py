@@ -111,3 +111,29 @@ def test_chunked_dense_ragged_token_counts(cin, cout, L, B):
             want = gn2(y.permute(0, 2, 1).reshape(-1, cout)).reshape(B, L, cout).permute(0, 2, 1)
         got = rows.dense_gn(x.cuda(), wp, cout, gn2).cpu()
         assert float((got - want).abs().max()) < 2e-4, groups
+
+
+@pytest.mark.parametrize("B,cin,cout,Ln", [(5, 128, 1024, 256), (3, 128, 1024, 100), (2, 64, 256, 37), (70, 128, 512, 64)])
+def test_dense_with_fused_max_over_points_equals_the_two_launches(B, cin, cout, Ln):
+    """pcr_dense_max_f32 (round 5: STN conv3 + BN + ReLU + max over the points without the (B,cout,L) tensor) against
+    pcr_dense_f32 + pcr_max_over_l_f32: bit-equal (a maximum is order-independent), ragged point counts included"""
+    import ctypes
+    from pcr_amd import _lib as L
+    from pcr_amd import engine as E
+    lib = L.load()
+    assert lib.pcr_dense_max_ok(cin, cout, Ln) == 1 and lib.pcr_dense_max_ok(cin, 96, Ln) == 0
+    g = torch.Generator().manual_seed(cin + Ln)
+    x = torch.randn(B, cin, Ln, generator=g).cuda()
+    w = torch.randn(cout, cin, generator=g) / cin ** 0.5
+    sc = (1.0 + 0.2 * torch.randn(cout, generator=g)).cuda()
+    sh = (0.3 * torch.randn(cout, generator=g)).cuda()
+    wp = E.pack_weight(w, x.device)
+    with E.precision("f32"):
+        y = E.dense(x, wp, cout, sc, sh, act=1)
+    want = torch.empty((1, cout, B), dtype=torch.float32, device="cuda")
+    L.check(lib.pcr_max_over_l_f32(L.ptr(y), L.ptr(want), B, cout, Ln, L.stream_ptr()), "pcr_max_over_l_f32")
+    got = torch.full((1, cout, B), float("nan"), dtype=torch.float32, device="cuda")
+    L.check(lib.pcr_dense_max_f32(L.ptr(x), L.ptr(wp), L.ptr(sc), L.ptr(sh), L.ptr(got), B, cin, cout, Ln, 1,
+                                  L.stream_ptr()), "pcr_dense_max_f32")
+    assert torch.equal(got, want)
+    assert torch.equal(want[0].t(), y.max(dim=2)[0])
