@@ -298,8 +298,11 @@ def train_bench(args, desc, n, bl, pairs, rank, world, steps=None, warmup=None):
             "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": dt / steps * 1e3, "per_rank_ms_per_step": per_rank, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32" if train_ops.TRAIN_PRECISION == "f32" else
-                      "f32; split bf16 (three bf16 MFMAs per product) for the backward of the 128 x 128 grouped-MLP layers"),
+            "dtype": {"f32": "f32",
+                      "bf16x3": "f32 forward; split bf16 (three bf16 MFMAs per product) for the gradient products of the "
+                                "128 x 128 grouped-MLP layers and of the fused attention chains",
+                      "bf16x3_all": "f32; split bf16 for the fused attention chains (forward too) and the gradient "
+                                    "products of the 128 x 128 grouped-MLP layers"}[train_ops.TRAIN_PRECISION],
             "data": "synthetic (randn clouds, seeded random-init weights)",
             "config": {"workload": "pt128_train: %s" % desc, "pairs_per_gpu_per_step": pairs, "points": n,
                        "backbone_list": bl, "parallelism": "data parallel x%d, one %d-byte gradient bucket per step"

@@ -664,6 +664,14 @@ typedef struct pcr_attn_tail {
   const float *dout;          /* backward */
   float *dmsg, *dres, *parts;
   long part_stride;
+  int precision;              /* (ABI 14, appended) arithmetic of the BACKWARD's matrix phases (dx, dW): PCR_PREC_F32 =
+                               * f32-input MFMAs, wmT / w0T / w2T pcr_pack_weight images; PCR_PREC_BF16X3 = split bf16 on the
+                               * bf16 matrix core, wmT / w0T / w2T pcr_pack_weight_bf16x2_f32 images (pcr_pack_weights_multi_f32
+                               * kind 1), the f32 tile in LDS converted where it is consumed.  The forward chain and its
+                               * recomputation keep the unfused launches' f32 fmaf chains: same ReLU masks, same values */
+  int fwd_precision;          /* (ABI 14) PCR_PREC_BF16X3: the forward chain (and the recomputation, and then the backward
+                               * whatever `precision` says) as split bf16 too, wm / w0 / w2 bf16 images -- an opt-in: a
+                               * ReLU whose argument is within ~1e-5 of zero may open where the f32 graph keeps it shut */
 } pcr_attn_tail;
 int pcr_attn_tail_ok(int d, int c1, int hid, int out, int residual);
 int pcr_attn_tail_part_floats(int d, int c1, int hid, int out);
@@ -690,6 +698,10 @@ typedef struct pcr_attn_head {
   const float *dout;          /* backward */
   float *dx, *parts;
   long part_stride;
+  int precision;              /* (ABI 14, appended) as pcr_attn_tail.precision: p2T, wT[] bf16 hi / lo images when
+                               * PCR_PREC_BF16X3 */
+  int fwd_precision;          /* as pcr_attn_tail.fwd_precision: p2, w[] bf16 images; p1 (three input channels) stays an f32
+                               * image either way */
 } pcr_attn_head;
 int pcr_attn_head_ok(int c, int hd, int d, int np, int src);
 int pcr_attn_head_part_floats(int c, int hd, int d, int np, int src);
@@ -750,6 +762,10 @@ typedef struct pcr_pack_desc {
   const float *w;
   float *out;
   int rows, cols;
+  int kind;                   /* (ABI 14) 0: the f32 images above (or a bias); 1: the bf16 hi / lo images instead --
+                               * pcr_pack_weight_bf16_dev_f32's image of W (pcr_packed_weight_bf16_floats(rows, cols)
+                               * floats) followed by that of W^T (pcr_packed_weight_bf16_floats(cols, rows) floats) */
+  int reserved;
 } pcr_pack_desc;
 int pcr_pack_weights_multi_f32(const pcr_pack_desc *descs_dev, int n, pcr_stream_t stream);
 

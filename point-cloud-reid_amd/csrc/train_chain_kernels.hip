@@ -35,6 +35,14 @@ __device__ __forceinline__ void ck_static_for(F &&f) {
 }
 
 constexpr int kCT = 64, kCRP = 65;      // tokens per tile (TB = 2), LDS row pitch
+#ifndef PCR_CHAIN_PF
+#define PCR_CHAIN_PF 2
+#endif
+constexpr int kChainPF = PCR_CHAIN_PF;
+// steps of the bf16 dW contraction unrolled together (all four: the wide backward kernels spill 36-167 registers)
+#ifndef PCR_DW_UNROLL
+#define PCR_DW_UNROLL 2
+#endif
 
 template <int CTRL>
 __device__ __forceinline__ float ck_dpp(float v) {
@@ -47,12 +55,20 @@ __device__ __forceinline__ float ck_quad_sum(float v) {
 }
 
 // dense layer with a compile-time number of 32-row output blocks (wave / tile split and rounds follow from it)
-template <int NCB, class Epi>
+// PREC 0: f32-input MFMAs on a pcr_pack_weight image; 1: split bf16 (three bf16 MFMAs per product, f32 accumulation) on a
+// bf16 hi / lo image, the f32 tile converted where it is consumed (tile_dense.h)
+template <int PREC, int NCB, class Epi>
 __device__ __forceinline__ void cdense(const float *in, int CP, const float *wp, bool sync_epi, Epi epi,
                                        const float *init = nullptr) {
   constexpr int WSEL = NCB >= 3 ? 1 : (NCB == 2 ? 2 : 4);
   constexpr int NR = NCB >= 3 ? (NCB + 3) / 4 : 1;
-  tile_dense2<2, NR, WSEL>(in, CP, wp, NCB * 32, sync_epi, epi, init);
+  if constexpr (PREC == 0) {
+    tile_dense2<2, NR, WSEL>(in, CP, wp, NCB * 32, sync_epi, epi, init);
+  } else {
+    // (weight ring of kChainPF steps instead of tile_dense2p's four: the backward kernels sit at the register limit)
+    tile_dense_bf_impl<2, DenseShape<NR, WSEL>::nr, DenseShape<NR, WSEL>::ways, false, 3, Epi, kChainPF>(
+        in, CP, wp, NCB * 32, sync_epi, epi, init);
+  }
 }
 
 // LayerNorm over the C channel rows of buf for each of the 64 token columns.  Thread (token t = tid & 63, part = wave):
@@ -181,7 +197,10 @@ __device__ __forceinline__ void ck_rowsum_store(float *dst_a, float *dst_b, cons
 // dW tiles (32 x 32 blocks of dY X^T, contraction over the tile's 64 tokens) dealt round-robin to the waves over ALL the
 // weight matrices of a chain: global item i belongs to wave i & 3, accumulator i >> 2; a stage owns the items
 // [BASE, BASE + NOB * NIB) = (row block of dY, row block of X).
-template <int NTW, int BASE, int NOB, int NIB>
+// PREC 1: the contraction over the tile's 64 tokens in four steps of 16 on the bf16 matrix core (A = dY rows, B = X rows,
+// token 16 s + 8 h + j in element j of lane half h for both; operands split where they are consumed, as the 128 x 128
+// grouped backward does: train_kernels.hip)
+template <int PREC, int NTW, int BASE, int NOB, int NIB>
 __device__ __forceinline__ void ck_dw_acc(f32x16 (&acc)[NTW], const float *DY, const float *X) {
   constexpr int RP = kCRP, T = kCT;
   const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
@@ -192,11 +211,31 @@ __device__ __forceinline__ void ck_dw_acc(f32x16 (&acc)[NTW], const float *DY, c
       const int item = wave + 4 * it - BASE;
       if (item >= 0 && item < NOB * NIB) {
         const int ob = item / NIB, ib = item - ob * NIB;
-        const float *ap = DY + (ob * 32 + l31) * RP + h;
-        const float *bp = X + (ib * 32 + l31) * RP + h;
+        if constexpr (PREC == 0) {
+          const float *ap = DY + (ob * 32 + l31) * RP + h;
+          const float *bp = X + (ib * 32 + l31) * RP + h;
 #pragma unroll 8
-        for (int ks = 0; ks < T / 2; ks++)
-          acc[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc[it], 0, 0, 0);
+          for (int ks = 0; ks < T / 2; ks++)
+            acc[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc[it], 0, 0, 0);
+        } else {
+          const float *ap = DY + (ob * 32 + l31) * RP + 8 * h;
+          const float *bp = X + (ib * 32 + l31) * RP + 8 * h;
+#pragma unroll PCR_DW_UNROLL
+          for (int s = 0; s < T / 16; s++) {
+            float xa8[8], xb8[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              xa8[j] = ap[16 * s + j];
+              xb8[j] = bp[16 * s + j];
+            }
+            bf16x8 ah, al, bh, bl;
+            bf_split8(xa8, ah, al, true);
+            bf_split8(xb8, bh, bl, true);
+            acc[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[it], 0, 0, 0);
+            acc[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[it], 0, 0, 0);
+            acc[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[it], 0, 0, 0);
+          }
+        }
       }
     }
   });
@@ -310,10 +349,14 @@ struct TailShape {
   }
 };
 
-template <int D, int C1, int HID, int OUT, bool RESID, bool BWD>
+template <int D, int C1, int HID, int OUT, bool RESID, bool BWD, int PREC>
 __global__ __launch_bounds__(kThreads) void attn_tail_kernel(TailArgs a) {
   using S = TailShape<D, C1, HID, OUT>;
   constexpr int RP = kCRP, T = kCT, CU = S::CU, CUP8 = S::CUP8, CUP32 = S::CUP32, NTW = S::NTW;
+  // PREC: bit 0 = the backward's matrix phases (dx, dW), bit 1 = the forward chain (and its recomputation) as split bf16.
+  // 1 (the default of training): the forward stays on the unfused launches' own fmaf chains -- every ReLU mask and the
+  // values the next layers see are those of the f32 graph -- and only the gradient products run on the bf16 matrix core
+  constexpr int PF = (PREC >> 1) & 1, PB = PREC & 1;
   static_assert(D % 32 == 0 && HID % 32 == 0 && OUT % 32 == 0 && (!RESID || OUT == C1), "chain shape");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *A = smem;                                   // msg (backward without SEP: d out, then msg again); then d msg
@@ -355,12 +398,12 @@ __global__ __launch_bounds__(kThreads) void attn_tail_kernel(TailArgs a) {
       if constexpr (BWD && S::SEP) load_tile(F, RP, doutb, OUT, OUT, L, t0, T);
     }
     __syncthreads();
-    cdense<D / 32>(A, D, a.wm, false, [&](float v, int o, int t) { Bm[o * RP + t] = v; });
+    cdense<PF, D / 32>(A, D, a.wm, false, [&](float v, int o, int t) { Bm[o * RP + t] = v; });
     __syncthreads();
     ck_ln_fwd<D, true>(Bm, a.g1, a.b1, a.eps, Cb + C1 * RP, rstd1, red);
-    cdense<HID / 32>(Cb, CUP8, a.w0, false, [&](float v, int o, int t) { Dh[o * RP + t] = fmaxf(v, 0.f); });
+    cdense<PF, HID / 32>(Cb, CUP8, a.w0, false, [&](float v, int o, int t) { Dh[o * RP + t] = fmaxf(v, 0.f); });
     __syncthreads();
-    cdense<OUT / 32>(Dh, HID, a.w2, false, [&](float v, int o, int t) { E[o * RP + t] = v; });
+    cdense<PF, OUT / 32>(Dh, HID, a.w2, false, [&](float v, int o, int t) { E[o * RP + t] = v; });
     __syncthreads();
     if constexpr (!BWD) {
       ck_ln_fwd<OUT, false>(E, a.g2, a.b2, a.eps, nullptr, nullptr, red);
@@ -379,14 +422,14 @@ __global__ __launch_bounds__(kThreads) void attn_tail_kernel(TailArgs a) {
       ck_rowsum<OUT>(F, E, sb2, sg2);                   // d beta2 += sum dout, d gamma2 += sum dout * xhat2
       __syncthreads();
       ck_ln_bwd<OUT>(F, E, E, a.g2, rstd2, red);        // E = dG
-      ck_dw_acc<NTW, S::B_W2, OUT / 32, HID / 32>(acc, E, Dh);
-      cdense<HID / 32>(E, OUT, a.w2T, true, [&](float v, int o, int t) {
+      ck_dw_acc<PB, NTW, S::B_W2, OUT / 32, HID / 32>(acc, E, Dh);
+      cdense<PB, HID / 32>(E, OUT, a.w2T, true, [&](float v, int o, int t) {
         const float f = Dh[o * RP + t];
         Dh[o * RP + t] = f > 0.f ? v : 0.f;
       });                                               // Dh = dF0 (masked)
       __syncthreads();
-      ck_dw_acc<NTW, S::B_W0, HID / 32, CUP32 / 32>(acc, Dh, Cb);
-      cdense<CUP32 / 32>(Dh, HID, a.w0T, true, [&](float v, int o, int t) { Cb[o * RP + t] = v; });   // Cb = dU
+      ck_dw_acc<PB, NTW, S::B_W0, HID / 32, CUP32 / 32>(acc, Dh, Cb);
+      cdense<PB, CUP32 / 32>(Dh, HID, a.w0T, true, [&](float v, int o, int t) { Cb[o * RP + t] = v; });   // Cb = dU
       __syncthreads();
       // d res = dU[0, C1) (+ d out: the residual), then msg comes back into A
       ck_store_tile(a.dres + (size_t)b * C1 * L, C1, L, t0, [&](int c, int t) {
@@ -398,8 +441,8 @@ __global__ __launch_bounds__(kThreads) void attn_tail_kernel(TailArgs a) {
       __syncthreads();
       if constexpr (!S::SEP) load_tile(A, RP, msgb, D, D, L, t0, T);
       ck_ln_bwd<D>(Cb + C1 * RP, Bm, Bm, a.g1, rstd1, red);   // Bm = dM (its barrier also covers the msg tile)
-      ck_dw_acc<NTW, S::B_WM, D / 32, D / 32>(acc, Bm, A);
-      cdense<D / 32>(Bm, D, a.wmT, true, [&](float v, int o, int t) { A[o * RP + t] = v; });
+      ck_dw_acc<PB, NTW, S::B_WM, D / 32, D / 32>(acc, Bm, A);
+      cdense<PB, D / 32>(Bm, D, a.wmT, true, [&](float v, int o, int t) { A[o * RP + t] = v; });
       __syncthreads();
       ck_store_tile(a.dmsg + (size_t)b * D * L, D, L, t0, [&](int c, int t) { return A[c * RP + t]; });
     }
@@ -412,6 +455,13 @@ __global__ __launch_bounds__(kThreads) void attn_tail_kernel(TailArgs a) {
     ck_rowsum_store<D>(rec + S::O_B1, rec + S::O_G1, sb1, sg1);
     ck_rowsum_store<OUT>(rec + S::O_B2, rec + S::O_G2, sb2, sg2);
   }
+}
+
+// kernel PREC code from the two ABI fields (a forward on the bf16 core implies the backward there too: the recomputation
+// must reproduce the forward bit for bit, and the opt-in exists for speed)
+int chain_prec(int precision, int fwd_precision) {
+  if (fwd_precision == PCR_PREC_BF16X3) return 3;
+  return precision == PCR_PREC_BF16X3 ? 1 : 0;
 }
 
 int ck_ncu() {
@@ -468,11 +518,18 @@ int tail_launch(const pcr_attn_tail *p, bool bwd, hipStream_t st) {
   const int grid = tail_grid(p, bwd);
   const size_t lds = TailShape<D, C1, HID, OUT>::lds(bwd);
   const bool resid = p->residual != 0;
-#define PCR_TL(R, BW)                                                                              \
+  const int prec = chain_prec(p->precision, p->fwd_precision);
+#define PCR_TL1(R, BW, PR)                                                                         \
   do {                                                                                             \
-    static bool ok = allow_big_lds(attn_tail_kernel<D, C1, HID, OUT, R, BW>);                      \
+    static bool ok = allow_big_lds(attn_tail_kernel<D, C1, HID, OUT, R, BW, PR>);                  \
     (void)ok;                                                                                      \
-    hipLaunchKernelGGL((attn_tail_kernel<D, C1, HID, OUT, R, BW>), dim3(grid), dim3(kThreads), lds, st, a); \
+    hipLaunchKernelGGL((attn_tail_kernel<D, C1, HID, OUT, R, BW, PR>), dim3(grid), dim3(kThreads), lds, st, a); \
+  } while (0)
+#define PCR_TL(R, BW)                                \
+  do {                                               \
+    if (prec == 3) PCR_TL1(R, BW, 3);                \
+    else if (prec == 1 && BW) PCR_TL1(R, BW, (BW ? 1 : 0)); \
+    else PCR_TL1(R, BW, 0);                          \
   } while (0)
   if constexpr (OUT == C1) {
     if (resid) {
@@ -486,6 +543,7 @@ int tail_launch(const pcr_attn_tail *p, bool bwd, hipStream_t st) {
   if (bwd) PCR_TL(false, true);
   else PCR_TL(false, false);
 #undef PCR_TL
+#undef PCR_TL1
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }
@@ -522,10 +580,11 @@ struct HeadShape {
                        REC = O_C2 + C;
 };
 
-template <int C, int HD, int D, int NP, int SRC, bool BWD>
+template <int C, int HD, int D, int NP, int SRC, bool BWD, int PREC>
 __global__ __launch_bounds__(kThreads) void attn_head_kernel(HeadArgs a) {
   using S = HeadShape<C, HD, D, NP>;
   constexpr int RP = kCRP, T = kCT, NTW = S::NTW;
+  constexpr int PF = (PREC >> 1) & 1, PB = PREC & 1;      // (as attn_tail_kernel)
   static_assert(C % 32 == 0 && HD % 32 == 0 && D % 32 == 0 && NP >= 1 && NP <= 3, "chain shape");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *XZ = smem;                    // [32]: xyz in rows 0..2, zeros below
@@ -562,15 +621,15 @@ __global__ __launch_bounds__(kThreads) void attn_head_kernel(HeadArgs a) {
       if constexpr (BWD) load_tile(G, RP, doutb, NP * D, NP * D, L, t0, T);
     }
     __syncthreads();
-    cdense<HD / 32>(XZ, 8, a.p1, false, [&](float v, int o, int t) { Hb[o * RP + t] = fmaxf(v, 0.f); }, a.c1);
+    cdense<0, HD / 32>(XZ, 8, a.p1, false, [&](float v, int o, int t) { Hb[o * RP + t] = fmaxf(v, 0.f); }, a.c1);
     __syncthreads();
-    cdense<C / 32>(Hb, HD, a.p2, false, [&](float v, int o, int t) { FP[o * RP + t] = v + X[o * RP + t]; }, a.c2);
+    cdense<PF, C / 32>(Hb, HD, a.p2, false, [&](float v, int o, int t) { FP[o * RP + t] = v + X[o * RP + t]; }, a.c2);
     __syncthreads();
     if constexpr (!BWD) {
       ck_static_for<NP>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         const float *src = ((SRC >> j) & 1) ? FP : X;
-        cdense<D / 32>(src, C, a.w[j], false, [&](float v, int o, int t) { G[(j * D + o) * RP + t] = v; });
+        cdense<PF, D / 32>(src, C, a.w[j], false, [&](float v, int o, int t) { G[(j * D + o) * RP + t] = v; });
       });
       __syncthreads();
       ck_store_tile(a.out + (size_t)b * NP * D * L, NP * D, L, t0, [&](int c, int t) { return G[c * RP + t]; });
@@ -579,7 +638,7 @@ __global__ __launch_bounds__(kThreads) void attn_head_kernel(HeadArgs a) {
       ck_static_for<NP>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         const float *src = ((SRC >> j) & 1) ? FP : X;
-        ck_dw_acc<NTW, S::B_W + j * S::T_W, D / 32, C / 32>(acc, G + j * D * RP, src);
+        ck_dw_acc<PB, NTW, S::B_W + j * S::T_W, D / 32, C / 32>(acc, G + j * D * RP, src);
       });
       __syncthreads();                  // x is dead from here: its rows take d fp
       // d fp = sum over the fp-sourced projections of W_j^T G_j
@@ -588,27 +647,27 @@ __global__ __launch_bounds__(kThreads) void attn_head_kernel(HeadArgs a) {
         ck_static_for<NP>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
           if constexpr ((SRC >> j) & 1) {
-            if (first) cdense<C / 32>(G + j * D * RP, D, a.wT[j], false, [&](float v, int o, int t) { X[o * RP + t] = v; });
-            else cdense<C / 32>(G + j * D * RP, D, a.wT[j], false, [&](float v, int o, int t) { X[o * RP + t] += v; });
+            if (first) cdense<PB, C / 32>(G + j * D * RP, D, a.wT[j], false, [&](float v, int o, int t) { X[o * RP + t] = v; });
+            else cdense<PB, C / 32>(G + j * D * RP, D, a.wT[j], false, [&](float v, int o, int t) { X[o * RP + t] += v; });
             first = false;
             __syncthreads();
           }
         });
       }
       ck_rowsum<C>(X, nullptr, sc2, dummy2);                  // d c2 += sum d fp
-      ck_dw_acc<NTW, S::B_P2, C / 32, HD / 32>(acc, X, Hb);   // d P2 += d fp h^T
-      cdense<HD / 32>(X, C, a.p2T, true, [&](float v, int o, int t) {
+      ck_dw_acc<PB, NTW, S::B_P2, C / 32, HD / 32>(acc, X, Hb);   // d P2 += d fp h^T
+      cdense<PB, HD / 32>(X, C, a.p2T, true, [&](float v, int o, int t) {
         const float hv = Hb[o * RP + t];
         Hb[o * RP + t] = hv > 0.f ? v : 0.f;
       });                                                     // Hb = d h (masked)
       __syncthreads();
       ck_rowsum<HD>(Hb, nullptr, sc1, dummy1);                // d c1
-      ck_dw_acc<NTW, S::B_P1, HD / 32, 1>(acc, Hb, XZ);       // d P1 += d h xyz^T
+      ck_dw_acc<PB, NTW, S::B_P1, HD / 32, 1>(acc, Hb, XZ);       // d P1 += d h xyz^T
       // d x = d fp + sum over the x-sourced projections of W_j^T G_j
       ck_static_for<NP>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         if constexpr (!((SRC >> j) & 1)) {
-          cdense<C / 32>(G + j * D * RP, D, a.wT[j], false, [&](float v, int o, int t) { X[o * RP + t] += v; });
+          cdense<PB, C / 32>(G + j * D * RP, D, a.wT[j], false, [&](float v, int o, int t) { X[o * RP + t] += v; });
           __syncthreads();
         }
       });
@@ -669,15 +728,22 @@ int head_launch(const pcr_attn_head *p, bool bwd, hipStream_t st) {
   a.B = p->B; a.L = p->L; a.tpc = (p->L + kCT - 1) / kCT; a.total = p->B * a.tpc;
   const int grid = head_grid(p);
   const size_t lds = head_lds(C, HD, D, NP);
+#define PCR_HL(BW, PR)                                                                              \
+  do {                                                                                             \
+    static bool ok = allow_big_lds(attn_head_kernel<C, HD, D, NP, SRC, BW, PR>);                   \
+    (void)ok;                                                                                      \
+    hipLaunchKernelGGL((attn_head_kernel<C, HD, D, NP, SRC, BW, PR>), dim3(grid), dim3(kThreads), lds, st, a); \
+  } while (0)
+  const int prec = chain_prec(p->precision, p->fwd_precision);
   if (bwd) {
-    static bool ok = allow_big_lds(attn_head_kernel<C, HD, D, NP, SRC, true>);
-    (void)ok;
-    hipLaunchKernelGGL((attn_head_kernel<C, HD, D, NP, SRC, true>), dim3(grid), dim3(kThreads), lds, st, a);
+    if (prec == 3) PCR_HL(true, 3);
+    else if (prec == 1) PCR_HL(true, 1);
+    else PCR_HL(true, 0);
   } else {
-    static bool ok = allow_big_lds(attn_head_kernel<C, HD, D, NP, SRC, false>);
-    (void)ok;
-    hipLaunchKernelGGL((attn_head_kernel<C, HD, D, NP, SRC, false>), dim3(grid), dim3(kThreads), lds, st, a);
+    if (prec == 3) PCR_HL(false, 3);
+    else PCR_HL(false, 0);
   }
+#undef PCR_HL
   PCR_CHECK_LAUNCH();
   return PCR_OK;
 }
@@ -709,7 +775,7 @@ PCR_EXPORT int pcr_attn_head_groups(const pcr_attn_head *p) { return p ? head_gr
 PCR_EXPORT int pcr_attn_head_fwd_f32(const pcr_attn_head *p, pcr_stream_t stream) {
   if (!head_common_ok(p) || !p->outp) return PCR_ERR_INVALID;
   if (p->B == 0) return PCR_OK;
-  pcr_note_arith(PCR_PREC_F32);
+  pcr_note_arith(p->fwd_precision == PCR_PREC_BF16X3 ? PCR_PREC_BF16X3 : PCR_PREC_F32);
   return head_dispatch(p, false, pcr_s(stream));
 }
 
@@ -720,7 +786,7 @@ PCR_EXPORT int pcr_attn_head_bwd_f32(const pcr_attn_head *p, pcr_stream_t stream
   for (int j = 0; j < p->np; j++)
     if (!p->wT[j]) return PCR_ERR_INVALID;
   if (p->B == 0) return PCR_OK;
-  pcr_note_arith(PCR_PREC_F32);
+  pcr_note_arith(chain_prec(p->precision, p->fwd_precision) ? PCR_PREC_BF16X3 : PCR_PREC_F32);
   return head_dispatch(p, true, pcr_s(stream));
 }
 
@@ -737,7 +803,7 @@ PCR_EXPORT int pcr_attn_tail_fwd_f32(const pcr_attn_tail *p, pcr_stream_t stream
       p->B < 0 || p->L < 1 || !pcr_attn_tail_ok(p->d, p->c1, p->hid, p->out, p->residual))
     return PCR_ERR_INVALID;
   if (p->B == 0) return PCR_OK;
-  pcr_note_arith(PCR_PREC_F32);
+  pcr_note_arith(p->fwd_precision == PCR_PREC_BF16X3 ? PCR_PREC_BF16X3 : PCR_PREC_F32);
   return tail_dispatch(p, false, pcr_s(stream));
 }
 
@@ -748,6 +814,6 @@ PCR_EXPORT int pcr_attn_tail_bwd_f32(const pcr_attn_tail *p, pcr_stream_t stream
       p->part_stride < pcr_attn_tail_part_floats(p->d, p->c1, p->hid, p->out))
     return PCR_ERR_INVALID;
   if (p->B == 0) return PCR_OK;
-  pcr_note_arith(PCR_PREC_F32);
+  pcr_note_arith(chain_prec(p->precision, p->fwd_precision) ? PCR_PREC_BF16X3 : PCR_PREC_F32);
   return tail_dispatch(p, true, pcr_s(stream));
 }

@@ -1048,14 +1048,40 @@ struct PackDesc {      // = pcr_pack_desc
   const float *w;
   float *out;
   int rows, cols;
+  int kind, reserved;
 };
 static_assert(sizeof(PackDesc) == sizeof(pcr_pack_desc), "pcr_pack_desc layout");
+
+// one (hi, lo) element pair of the bf16 image of W (transpose = 0) or W^T (1): pack_weight_bf_kernel's body
+__device__ __forceinline__ void pack_bf_pair(const float *__restrict__ w, int rows, int cols, int transpose, int e0,
+                                             unsigned short *__restrict__ packed) {
+  const int cout = transpose ? cols : rows, cin = transpose ? rows : cols;
+  const int nCB = ceil32(cout) >> 5;
+  const int e = e0 & 7, lane = (e0 >> 3) & 63, cb = (e0 >> 9) % nCB, s = (e0 >> 9) / nCB;
+  const int o = cb * 32 + (lane & 31), k = 16 * s + bf_kpos(lane >> 5, e);
+  float v = 0.f;
+  if (o < cout && k < cin) v = transpose ? w[(size_t)k * cols + o] : w[(size_t)o * cols + k];
+  const __bf16 hi = (__bf16)v;
+  const __bf16 lo = (__bf16)(v - (float)hi);
+  const size_t u = ((size_t)(s * nCB + cb) * 2) * 64 + lane;
+  packed[u * 8 + e] = __builtin_bit_cast(unsigned short, hi);
+  packed[(u + 64) * 8 + e] = __builtin_bit_cast(unsigned short, lo);
+}
 
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackDesc *__restrict__ descs) {
   const PackDesc d = descs[blockIdx.y];
   const int rows = d.rows, cols = d.cols;
   if (cols == 0) {     // a bias vector: `rows` floats into the head of its zero-padded image
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < rows; e += gridDim.x * blockDim.x) d.out[e] = d.w[e];
+    return;
+  }
+  if (d.kind == 1) {   // bf16 hi / lo images: W, then W^T
+    const int p0 = ((cols + 15) >> 4) * (ceil32(rows) >> 5) * 512, p1 = ((rows + 15) >> 4) * (ceil32(cols) >> 5) * 512;
+    unsigned short *img = reinterpret_cast<unsigned short *>(d.out);
+    for (int e0 = blockIdx.x * blockDim.x + threadIdx.x; e0 < p0 + p1; e0 += gridDim.x * blockDim.x) {
+      if (e0 < p0) pack_bf_pair(d.w, rows, cols, 0, e0, img);
+      else pack_bf_pair(d.w, rows, cols, 1, e0 - p0, img + (size_t)p0 * 2);
+    }
     return;
   }
   const int n0 = ceil8(cols) * ceil32(rows), n1 = ceil8(rows) * ceil32(cols);

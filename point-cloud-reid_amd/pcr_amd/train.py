@@ -213,6 +213,7 @@ class Trainer:
                 for k in keys:
                     feed[k] = list(static[k].unbind(0))
                 self.optimizer.zero_grad(set_to_none=True)
+                train_ops.prepack(self.model, build_only=True)   # (table rebuilds -- allocations, a copy -- outside the capture)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=self._stream, capture_error_mode="relaxed"):
                     train_ops.prepack(self.model)

@@ -82,45 +82,73 @@ class _Prepack:
 
     def __init__(self):
         self.key = None
-        self.entries = {}          # data_ptr -> [param, rows, cols, version, wp, wpT]
+        self.entries = {}          # data_ptr -> [param, rows, cols, version, wp, wpT, wp_bf, wpT_bf]
         self.descs = None
+        self.ndesc = 0
         self.params = []
         self.biases = {}
+        self.want_bf = set()       # data_ptrs whose bf16 hi / lo images are refreshed too (asked for once: pack_both_bf)
 
     def build(self, params, biases):
         import numpy as np
         dev = params[0].device
         self.params = params
+        old = self.entries
         self.entries = {}
         self.biases = {}           # id(bias) -> [param, version, zero-padded image]
-        desc = np.zeros(len(params) + len(biases),
-                        dtype=np.dtype([("w", "<u8"), ("out", "<u8"), ("rows", "<i4"), ("cols", "<i4")]))
+        self.want_bf &= {p.data_ptr() for p in params}
+        desc = np.zeros(len(params) + len(biases) + len(self.want_bf),
+                        dtype=np.dtype([("w", "<u8"), ("out", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("kind", "<i4"),
+                                        ("reserved", "<i4")]))
+        nbf = 0
         for i, p in enumerate(params):
             rows, cols = p.shape[0], p.numel() // p.shape[0]
             n0, n1 = _c8(cols) * _c32(rows), _c8(rows) * _c32(cols)
-            out = _f32(n0 + n1, device=dev)
-            desc[i] = (p.data_ptr(), out.data_ptr(), rows, cols)
-            self.entries[p.data_ptr()] = [p, rows, cols, -1, out[:n0], out[n0:]]
+            prev = old.get(p.data_ptr())
+            if prev is not None and prev[0] is p and prev[1] == rows and prev[2] == cols:
+                e = list(prev)         # (a rebuild that only adds bf images keeps the f32 images where they are)
+                e[3] = -1
+                out = e[4]._base if e[4]._base is not None else e[4]
+            else:
+                out = _f32(n0 + n1, device=dev)
+                e = [p, rows, cols, -1, out[:n0], out[n0:], None, None]
+            desc[i] = (p.data_ptr(), out.data_ptr(), rows, cols, 0, 0)
+            if p.data_ptr() in self.want_bf:
+                b0 = L.load().pcr_packed_weight_bf16_floats(rows, cols)
+                b1 = L.load().pcr_packed_weight_bf16_floats(cols, rows)
+                if e[6] is None:
+                    ob = _f32(b0 + b1, device=dev)
+                    e[6], e[7] = ob[:b0], ob[b0:]
+                base = e[6]._base if e[6]._base is not None else e[6]
+                desc[len(params) + len(biases) + nbf] = (p.data_ptr(), base.data_ptr(), rows, cols, 1, 0)
+                nbf += 1
+            else:
+                e[6] = e[7] = None
+            self.entries[p.data_ptr()] = e
         for i, b in enumerate(biases):          # cols = 0: a bias, copied into its zero-padded image by the same launch
             out = torch.zeros(_c32(b.numel()), dtype=torch.float32, device=dev)
-            desc[len(params) + i] = (b.data_ptr(), out.data_ptr(), b.numel(), 0)
+            desc[len(params) + i] = (b.data_ptr(), out.data_ptr(), b.numel(), 0, 0, 0)
             self.biases[id(b)] = [b, -1, out, b.data_ptr()]
+        self.ndesc = len(desc)
         self.descs = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
         self.key = tuple(id(p) for p in params) + tuple(id(b) for b in biases)
 
-    def refresh(self, params, biases=()):
+    def refresh(self, params, biases=(), build_only=False):
         params = [p for p in params if p.is_cuda and p.dim() >= 2 and p.dtype == torch.float32 and p.is_contiguous()]
         biases = [b for b in biases if b.is_cuda and b.dim() == 1 and b.dtype == torch.float32 and b.is_contiguous()]
         if not params:
             return
         if self.key != tuple(id(p) for p in params) + tuple(id(b) for b in biases) or \
                 any(e[0].data_ptr() != k for k, e in self.entries.items()) or \
-                any(e[0].data_ptr() != e[3] for e in self.biases.values()):
+                any(e[0].data_ptr() != e[3] for e in self.biases.values()) or \
+                any((k in self.want_bf) != (e[6] is not None) for k, e in self.entries.items()):
             self.build(params, biases)
-        elif all(e[3] == e[0]._version for e in self.entries.values()) and \
+            if build_only:
+                return
+        elif build_only or all(e[3] == e[0]._version for e in self.entries.values()) and \
                 all(e[1] == e[0]._version for e in self.biases.values()):
             return        # nothing changed since the last refresh (micro-steps of a gradient accumulation)
-        L.check(L.load().pcr_pack_weights_multi_f32(ctypes.c_void_p(self.descs.data_ptr()), len(params) + len(biases),
+        L.check(L.load().pcr_pack_weights_multi_f32(ctypes.c_void_p(self.descs.data_ptr()), self.ndesc,
                                                     L.stream_ptr()), "pcr_pack_weights_multi_f32")
         for e in self.entries.values():
             e[3] = e[0]._version
@@ -140,6 +168,16 @@ class _Prepack:
             return None
         return e[4], e[5]
 
+    def lookup_bf(self, w):
+        """-> (bf image of W, of W^T) | None (not registered / stale); registers the weight for the NEXT refresh"""
+        e = self.entries.get(w.data_ptr())
+        if e is None or w.dim() != 2 or w.shape[0] != e[1] or w.shape[1] != e[2] or not w.is_contiguous():
+            return None
+        self.want_bf.add(w.data_ptr())
+        if e[6] is None or e[3] != w._version:
+            return None
+        return e[6], e[7]
+
 
 # one table per model, owned by the model (dropped with it); `lookup` below searches the live tables
 _PREPACKS = weakref.WeakKeyDictionary()
@@ -153,16 +191,19 @@ def _lookup(w):
     return None
 
 
-def prepack(model):
+def prepack(model, build_only=False):
     """refresh the packed images of every conv / linear weight of `model` in one launch (Trainer.step calls this once
     per iteration, after the previous update); pack_dev / pack_both then hit the cache.  Note for callers that keep an
-    autograd graph across iterations: the images are overwritten in place by the next refresh."""
+    autograd graph across iterations: the images are overwritten in place by the next refresh.
+    build_only: only (re)build the descriptor table and the image buffers if the set of weights or of requested bf16
+    images changed -- allocations and a host-to-device copy, which a stream capture cannot take: the Trainer calls this
+    right before it captures an iteration, whose own prepack() then is the one launch and nothing else."""
     mods = [m for m in model.modules()
             if isinstance(m, (torch.nn.Linear, torch.nn.Conv1d, torch.nn.Conv2d)) and m.weight is not None]
     tab = _PREPACKS.get(model)
     if tab is None:
         tab = _PREPACKS[model] = _Prepack()
-    tab.refresh([m.weight for m in mods], [m.bias for m in mods if m.bias is not None])
+    tab.refresh([m.weight for m in mods], [m.bias for m in mods if m.bias is not None], build_only=build_only)
 
 
 def pack_dev(w, transpose=False):
@@ -296,22 +337,53 @@ def reduce_regions(part, nparts, stride, regions):
     return outs
 
 
-# Arithmetic of the training launches' matrix phases: "f32" (f32-input MFMA, exact fmaf chains) or "bf16x3" (split bf16
-# on the bf16 matrix core, three MFMAs per product, f32 accumulation) -- today the backward of the 128 x 128 grouped-MLP
-# layers (dx and dW; include/pcr.h pcr_tdense_bwd.precision), every other launch is f32 whatever this says.
+# Arithmetic of the training launches' matrix phases:
+#   "f32"         f32-input MFMA, exact fmaf chains everywhere;
+#   "bf16x3"      (default) split bf16 on the bf16 matrix core (three MFMAs per product, f32 accumulation) for the
+#                 GRADIENT products only -- dx and dW of the 128 x 128 grouped-MLP layers (pcr_tdense_bwd.precision) and of
+#                 the fused attention chains (pcr_attn_tail / pcr_attn_head .precision); every forward value, and with it
+#                 every ReLU mask and max-pool winner, is the f32 graph's;
+#   "bf16x3_all"  opt-in: the fused chains' forward (and its recomputation) as split bf16 too.  ~0.3 ms per pt128_train
+#                 step faster, and ~1 ReLU in 10^5 whose argument lies within 1e-5 of zero opens where the f32 graph keeps
+#                 it shut: that token's gradient row moves by per cent, a weight gradient by ~1e-4 of its scale.
 # PCR_TRAIN_PRECISION in the environment or set_train_precision() select it.
+_TRAIN_PRECISIONS = ("f32", "bf16x3", "bf16x3_all")
 TRAIN_PRECISION = os.environ.get("PCR_TRAIN_PRECISION", "bf16x3")
-if TRAIN_PRECISION not in ("f32", "bf16x3"):
-    raise L.PcrError("PCR_TRAIN_PRECISION must be f32 or bf16x3")
+if TRAIN_PRECISION not in _TRAIN_PRECISIONS:
+    raise L.PcrError("PCR_TRAIN_PRECISION must be one of %s" % (_TRAIN_PRECISIONS,))
 
 
 def set_train_precision(name):
     """-> previous setting"""
     global TRAIN_PRECISION
-    if name not in ("f32", "bf16x3"):
-        raise L.PcrError("training precision must be f32 or bf16x3")
+    if name not in _TRAIN_PRECISIONS:
+        raise L.PcrError("training precision must be one of %s" % (_TRAIN_PRECISIONS,))
     prev, TRAIN_PRECISION = TRAIN_PRECISION, name
     return prev
+
+
+def _bwd_bf():
+    return TRAIN_PRECISION != "f32"
+
+
+def pack_both_bf(w):
+    """-> (bf16 hi / lo image of W, of W^T): the operands of the fused chains on the bf16 matrix core.  A weight of a
+    prepacked model is registered on its first request and refreshed by the one launch per iteration from then on; a
+    miss packs on the spot (two small launches)"""
+    for t in _PREPACKS.values():
+        hit = t.lookup_bf(w)
+        if hit is not None:
+            return hit
+    wd = _dev(w.detach())
+    rows, cols = wd.shape
+    lib = L.load()
+    a = _f32(lib.pcr_packed_weight_bf16_floats(rows, cols), device=wd.device)
+    b = _f32(lib.pcr_packed_weight_bf16_floats(cols, rows), device=wd.device)
+    L.check(lib.pcr_pack_weight_bf16_dev_f32(L.ptr(wd), rows, cols, cols, 0, L.ptr(a), L.stream_ptr()),
+            "pcr_pack_weight_bf16_dev_f32")
+    L.check(lib.pcr_pack_weight_bf16_dev_f32(L.ptr(wd), rows, cols, cols, 1, L.ptr(b), L.stream_ptr()),
+            "pcr_pack_weight_bf16_dev_f32")
+    return a, b
 
 
 def pack_bf_T(w):
@@ -347,7 +419,7 @@ def tdense_bwd(g, x, cout, dy_mode=0, y=None, k=None, argmax=None, pooled=None, 
     # workgroups of THIS launch = rows of its partial buffers: asked with the wanted outputs marked non-NULL (the
     # library picks the kernel -- and with it the grid -- from the parameter block), then the real buffers go in
     p.wpT = _p(wpT)
-    if wpT_bf is not None and TRAIN_PRECISION == "bf16x3":
+    if wpT_bf is not None and _bwd_bf():
         p.wpT_bf, p.precision = _p(wpT_bf), 1
     if wpT is not None:
         p.dx, p.dx2 = 1, (1 if cin2 else None)
@@ -556,8 +628,8 @@ class SaEdgeTrain(Function):
                                               L.stream_ptr()), "pcr_sa_pool_bwd_stats_f32")
         k3 = bn_bwd_finalize(part3, B, c3, R, g3, n3["mean"], n3["invstd"])
         # (128 x 128 layers: dx and dW on the bf16 matrix core when TRAIN_PRECISION says so)
-        bf3 = pack_bf_T(w3) if (TRAIN_PRECISION == "bf16x3" and c3 == 128 and c2 == 128) else None
-        bf2 = pack_bf_T(w2) if (TRAIN_PRECISION == "bf16x3" and c2 == 128 and c1 == 128) else None
+        bf3 = pack_bf_T(w3) if (_bwd_bf() and c3 == 128 and c2 == 128) else None
+        bf2 = pack_bf_T(w2) if (_bwd_bf() and c2 == 128 and c1 == 128) else None
         r3 = tdense_bwd(gz, y2, c3, dy_mode=3, y=y3, k=k3, argmax=argmax, pooled=None, K=K, S=S,
                         isc=n2["scale"], ish=n2["shift"], iinv=n2["inv_scale"], in_relu=True,
                         wpT=pack_dev(w3, transpose=True), want_dstats=True, wpT_bf=bf3)
@@ -772,10 +844,24 @@ class _AttnTailP(ctypes.Structure):
                 ("out", ctypes.c_int), ("residual", ctypes.c_int), ("eps", ctypes.c_float),
                 ("msg", c_fp), ("res", c_fp), ("wm", c_fp), ("w0", c_fp), ("w2", c_fp), ("wmT", c_fp), ("w0T", c_fp),
                 ("w2T", c_fp), ("g1", c_fp), ("b1", c_fp), ("g2", c_fp), ("b2", c_fp), ("outp", c_fp), ("dout", c_fp),
-                ("dmsg", c_fp), ("dres", c_fp), ("parts", c_fp), ("part_stride", ctypes.c_long)]
+                ("dmsg", c_fp), ("dres", c_fp), ("parts", c_fp), ("part_stride", ctypes.c_long),
+                ("precision", ctypes.c_int), ("fwd_precision", ctypes.c_int)]
 
 
-def _tail_params(msg, res, Wm, g1, b1, W0, W2, g2, b2, residual, eps, images):
+def _chain_bf():
+    """-> (backward matrix phases on the bf16 core, forward chain too)"""
+    return TRAIN_PRECISION != "f32", TRAIN_PRECISION == "bf16x3_all"
+
+
+def _chain_images(w, bf):
+    """(image of W for the forward chain, image of W^T for the backward) in the formats the arithmetic `bf` = (bwd, fwd)
+    reads: bf16 hi / lo images where that side runs on the bf16 matrix core, pcr_pack_weight images where it does not"""
+    f32 = pack_both(w) if not (bf[0] and bf[1]) else None
+    b16 = pack_both_bf(w) if (bf[0] or bf[1]) else None
+    return (b16[0] if bf[1] else f32[0]), (b16[1] if (bf[0] or bf[1]) else f32[1])
+
+
+def _tail_params(msg, res, Wm, g1, b1, W0, W2, g2, b2, residual, eps, images, bf):
     B, d, Ln = msg.shape
     c1, hid, out = res.shape[1], W0.shape[0], W2.shape[0]
     p = _AttnTailP()
@@ -783,6 +869,7 @@ def _tail_params(msg, res, Wm, g1, b1, W0, W2, g2, b2, residual, eps, images):
     p.msg, p.res = _p(msg), _p(res)
     (p.wm, p.wmT), (p.w0, p.w0T), (p.w2, p.w2T) = [(_p(a), _p(b)) for a, b in images]
     p.g1, p.b1, p.g2, p.b2 = _p(g1.detach()), _p(b1.detach()), _p(g2.detach()), _p(b2.detach())
+    p.precision, p.fwd_precision = int(bf[0] or bf[1]), int(bf[1])
     return p, (B, d, Ln, c1, hid, out)
 
 
@@ -793,24 +880,25 @@ class AttnTail(Function):
     @staticmethod
     def forward(ctx, msg, res, Wm, g1, b1, W0, W2, g2, b2, residual, eps):
         msg, res = _dev(msg), _dev(res)
-        images = [pack_both(Wm), pack_both(W0), pack_both(W2)]
-        p, (B, d, Ln, c1, hid, out) = _tail_params(msg, res, Wm, g1, b1, W0, W2, g2, b2, residual, eps, images)
+        bf = _chain_bf()
+        images = [_chain_images(Wm, bf), _chain_images(W0, bf), _chain_images(W2, bf)]
+        p, (B, d, Ln, c1, hid, out) = _tail_params(msg, res, Wm, g1, b1, W0, W2, g2, b2, residual, eps, images, bf)
         y = _f32(B, out, Ln, device=msg.device)
         p.outp = _p(y)
         flops = 2.0 * B * Ln * (d * d + (c1 + d) * hid + hid * out)
         with _prof("attn_tail_fwd[d=%d,c1=%d,hid=%d,out=%d,L=%d]" % (d, c1, hid, out, Ln), flops,
-                   4.0 * B * Ln * (d + c1 + out)):
+                   4.0 * B * Ln * (d + c1 + out), arith="lib"):
             L.check(L.load().pcr_attn_tail_fwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_attn_tail_fwd_f32")
         ctx.save_for_backward(msg, res, Wm, g1, b1, W0, W2, g2, b2, *[t for im in images for t in im])
-        ctx.meta = (residual, eps)
+        ctx.meta = (residual, eps, bf)
         return y
 
     @staticmethod
     def backward(ctx, g):
         msg, res, Wm, g1, b1, W0, W2, g2, b2, *flat = ctx.saved_tensors
-        residual, eps = ctx.meta
+        residual, eps, bf = ctx.meta
         images = [(flat[0], flat[1]), (flat[2], flat[3]), (flat[4], flat[5])]
-        p, (B, d, Ln, c1, hid, out) = _tail_params(msg, res, Wm, g1, b1, W0, W2, g2, b2, residual, eps, images)
+        p, (B, d, Ln, c1, hid, out) = _tail_params(msg, res, Wm, g1, b1, W0, W2, g2, b2, residual, eps, images, bf)
         lib = L.load()
         g = _dev(g)
         dev = msg.device
@@ -821,7 +909,7 @@ class AttnTail(Function):
         p.dout, p.dmsg, p.dres, p.parts, p.part_stride = _p(g), _p(dmsg), _p(dres), _p(parts), rec
         flops = 2.0 * B * Ln * (d * d + (c1 + d) * hid + hid * out)
         with _prof("attn_tail_bwd[d=%d,c1=%d,hid=%d,out=%d,L=%d]" % (d, c1, hid, out, Ln), 3.0 * flops,
-                   4.0 * B * Ln * (2 * d + 2 * c1 + out)):
+                   4.0 * B * Ln * (2 * d + 2 * c1 + out), arith="lib"):
             L.check(lib.pcr_attn_tail_bwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_attn_tail_bwd_f32")
         cup = _c32(c1 + d)
         o0, o2 = d * d, d * d + hid * cup
@@ -854,10 +942,11 @@ class _AttnHeadP(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int), ("L", ctypes.c_int), ("c", ctypes.c_int), ("hd", ctypes.c_int), ("d", ctypes.c_int),
                 ("np", ctypes.c_int), ("src", ctypes.c_int), ("x", c_fp), ("xyz", c_fp), ("p1", c_fp), ("p2", c_fp),
                 ("c1", c_fp), ("c2", c_fp), ("p2T", c_fp), ("w", c_fp * 3), ("wT", c_fp * 3), ("outp", c_fp),
-                ("dout", c_fp), ("dx", c_fp), ("parts", c_fp), ("part_stride", ctypes.c_long)]
+                ("dout", c_fp), ("dx", c_fp), ("parts", c_fp), ("part_stride", ctypes.c_long),
+                ("precision", ctypes.c_int), ("fwd_precision", ctypes.c_int)]
 
 
-def _head_params(x, xyz, P1, c1, P2, c2, src, Ws, images):
+def _head_params(x, xyz, P1, c1, P2, c2, src, Ws, images, bf):
     B, C, Ln = x.shape
     hd, d, n = P1.shape[0], Ws[0].shape[0], len(Ws)
     p = _AttnHeadP()
@@ -867,6 +956,7 @@ def _head_params(x, xyz, P1, c1, P2, c2, src, Ws, images):
     p.c1, p.c2 = _p(pad32(c1, hd)), _p(pad32(c2, C))
     for j in range(n):
         p.w[j], p.wT[j] = _p(images[2 + j][0]), _p(images[2 + j][1])
+    p.precision, p.fwd_precision = int(bf[0] or bf[1]), int(bf[1])
     return p, (B, C, Ln, hd, d, n)
 
 
@@ -877,24 +967,26 @@ class AttnHead(Function):
     @staticmethod
     def forward(ctx, x, xyz, P1, c1, P2, c2, src, *Ws):
         x, xyz = _dev(x), _dev(xyz)
-        images = [pack_both(P1), pack_both(P2)] + [pack_both(W) for W in Ws]
-        p, (B, C, Ln, hd, d, n) = _head_params(x, xyz, P1, c1, P2, c2, src, Ws, images)
+        bf = _chain_bf()                                  # (P1: three input channels, an f32 image either way)
+        images = [pack_both(P1), _chain_images(P2, bf)] + [_chain_images(W, bf) for W in Ws]
+        p, (B, C, Ln, hd, d, n) = _head_params(x, xyz, P1, c1, P2, c2, src, Ws, images, bf)
         out = _f32(B, n * d, Ln, device=x.device)
         p.outp = _p(out)
         flops = 2.0 * B * Ln * (3 * hd + hd * C + n * d * C)
-        with _prof("attn_head_fwd[c=%d,hd=%d,d=%d,n=%d,L=%d]" % (C, hd, d, n, Ln), flops, 4.0 * B * Ln * (C + 3 + n * d)):
+        with _prof("attn_head_fwd[c=%d,hd=%d,d=%d,n=%d,L=%d]" % (C, hd, d, n, Ln), flops, 4.0 * B * Ln * (C + 3 + n * d),
+                   arith="lib"):
             L.check(L.load().pcr_attn_head_fwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_attn_head_fwd_f32")
         ctx.save_for_backward(x, xyz, P1, c1, P2, c2, *Ws, *[t for im in images for t in im])
-        ctx.meta = (src, len(Ws))
+        ctx.meta = (src, len(Ws), bf)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        src, n = ctx.meta
+        src, n, bf = ctx.meta
         x, xyz, P1, c1, P2, c2, *rest = ctx.saved_tensors
         Ws, flat = rest[:n], rest[n:]
         images = [(flat[2 * i], flat[2 * i + 1]) for i in range(2 + n)]
-        p, (B, C, Ln, hd, d, n) = _head_params(x, xyz, P1, c1, P2, c2, src, Ws, images)
+        p, (B, C, Ln, hd, d, n) = _head_params(x, xyz, P1, c1, P2, c2, src, Ws, images, bf)
         lib = L.load()
         g = _dev(g)
         dx = torch.empty_like(x)
@@ -904,7 +996,7 @@ class AttnHead(Function):
         p.dout, p.dx, p.parts, p.part_stride = _p(g), _p(dx), _p(parts), rec
         flops = 2.0 * B * Ln * (3 * hd + hd * C + n * d * C)
         with _prof("attn_head_bwd[c=%d,hd=%d,d=%d,n=%d,L=%d]" % (C, hd, d, n, Ln), 3.0 * flops,
-                   4.0 * B * Ln * (2 * C + 3 + n * d)):
+                   4.0 * B * Ln * (2 * C + 3 + n * d), arith="lib"):
             L.check(lib.pcr_attn_head_bwd_f32(ctypes.byref(p), L.stream_ptr()), "pcr_attn_head_bwd_f32")
         o_p2 = hd * 32
         o_w = o_p2 + C * hd

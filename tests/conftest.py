@@ -33,3 +33,15 @@ def golden():
 def has_gpu():
     import torch
     return torch.cuda.is_available()
+
+
+@pytest.fixture(params=["f32", "bf16x3"])
+def grad_floor(request):
+    """runs a training test once per arithmetic of the gradient products (pcr_amd.train_ops.TRAIN_PRECISION) and yields the
+    floor of its gradient yardsticks, relative to a tensor's scale: "f32" (f32-input MFMAs, the reference's arithmetic):
+    1e-5, as since round 2; "bf16x3" (the default: dx / dW of the 128 x 128 grouped layers and of the fused attention
+    chains as split bf16, ~2^-17 per product, forward values untouched): 3e-5 -- measured worst 1.2e-5."""
+    from pcr_amd import train_ops
+    prev = train_ops.set_train_precision(request.param)
+    yield {"f32": 1e-5, "bf16x3": 3e-5}[request.param]
+    train_ops.set_train_precision(prev)

@@ -152,7 +152,7 @@ def test_forward_test_api_and_decisions():
     assert ((torch.sigmoid(r["val_match_preds"]) > 0.5).cpu().numpy() == (1 / (1 + np.exp(-g["logits"])) > 0.5)).all()
 
 
-def test_train_step_matches_reference_loss_and_grads():
+def test_train_step_matches_reference_loss_and_grads(grad_floor):
     """ReIDNet.train_step in training mode (every forward / backward node a HIP launch: pcr_amd/train_graph.py,
     train_ops.py) against loss and gradients recorded from the reference's own train_step"""
     g = load_golden("pt_train_step_n128")
@@ -190,7 +190,7 @@ def test_train_step_matches_reference_loss_and_grads():
     # float64 gradient than twice what the reference's float32 backward is.  (tests/test_gpu_train_ops.py pins the same
     # layer to 2e-4 against torch autograd on identical indices.)
     for k in worst:
-        assert worst[k] < 1e-5 or vs64[k] < max(1e-5, 2.0 * ref_own[k]), (k, worst[k], vs64[k], ref_own[k])
+        assert worst[k] < grad_floor or vs64[k] < max(grad_floor, 2.0 * ref_own[k]), (k, worst[k], vs64[k], ref_own[k])
     no_grad = sorted(k for k, p in params.items() if p.grad is None)
     assert no_grad == sorted(json.loads(str(g["no_grad_params"])))      # the 24 never-used FP tensors
 
@@ -347,7 +347,7 @@ def _hx(m, a, b):
     return h1, h2, xyz1, xyz2
 
 
-def test_training_steps_agree_between_the_hip_and_torch_optimizers():
+def test_training_steps_agree_between_the_hip_and_torch_optimizers(grad_floor):
     """four Trainer iterations on the same HIP forward / backward graph, once with the HIP norm + clip + AdamW launches
     and once with clip_grad_norm_ + torch.optim.AdamW: losses and parameters must agree.  (Guards the caches keyed by
     Tensor._version -- padded biases, inference launch plans -- against an update that does not bump it: with stale
@@ -370,7 +370,17 @@ def test_training_steps_agree_between_the_hip_and_torch_optimizers():
         losses = [float(tr.step(data)["loss"].detach()) for _ in range(4)]
         runs.append((m, losses))
     (ma, la), (mb, lb) = runs
-    assert la == pytest.approx(lb, rel=2e-4, abs=2e-5), (la, lb)
+    # This 8-pair trajectory at lr 1e-3 is touchy: scaling every weight by 1 + 1e-7 before the first step moves the
+    # step-3 / step-4 losses by 7e-4 / 4e-3 and the evaluation logits afterwards by 2.6e-2 (f32 arithmetic; the same with
+    # split-bf16 gradient products: tools/train_sensitivity.py).  The two optimizers see bit-identical
+    # gradients at step 1 (tests/test_gpu_train_ops.py) and round their updates differently by ~1e-7: with f32 gradient
+    # products the runs happen to stay within 2e-4 / 2e-3, with split bf16 (whose rounding re-draws itself when a weight
+    # moves by an ulp) they spread to the trajectory's own sensitivity, 1.6e-3 / 2.1e-2.  What this test guards -- a cache
+    # keyed by Tensor._version that misses an update -- parts the losses by per cent at step TWO: that is held to 1e-5
+    # in both arithmetics.
+    strict = grad_floor == 1e-5
+    assert la[:2] == pytest.approx(lb[:2], rel=1e-5, abs=2e-6), (la, lb)
+    assert la == pytest.approx(lb, rel=2e-4 if strict else 1e-2, abs=2e-5), (la, lb)
     # (parameters are not compared one by one: conv biases in front of a BatchNorm have a zero true gradient, and AdamW
     # turns their rounding noise into +-lr steps -- the FUNCTION is what must agree: losses above, eval logits below)
     # eval after training: the launch plans are rebuilt from the updated weights
@@ -378,7 +388,7 @@ def test_training_steps_agree_between_the_hip_and_torch_optimizers():
     with torch.no_grad():
         ea = ma.match_forward_inference(*_hx(ma, s1.to(dev), s2.to(dev)))
         eb = mb.match_forward_inference(*_hx(mb, s1.to(dev), s2.to(dev)))
-    assert float((ea - eb).abs().max()) < 2e-3 * max(1.0, float(eb.abs().max()))
+    assert float((ea - eb).abs().max()) < (2e-3 if strict else 6e-2) * max(1.0, float(eb.abs().max()))
 
 
 def test_submodules_refuse_training_mode_on_the_fused_path():

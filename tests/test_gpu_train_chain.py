@@ -44,6 +44,21 @@ def _torch(m, msg, res, residual):
     return y.permute(0, 2, 1)
 
 
+def _well_conditioned_tokens(m, msg, res, margin=2e-4):
+    """(B,1,L) mask of the tokens none of whose hidden pre-activations W0 [res ; LN1(Wm msg)] lies within `margin` of
+    zero (float64).  A ReLU whose argument is ~1e-5 from zero opens in one arithmetic and stays shut in another -- ~1 token
+    in 5000 between the f32 chains and split bf16 -- and that token's whole gradient row then differs by several per
+    cent: the same near-tie effect the max-pool tests meet.  Every layer of the chain is per token,
+    so zeroing the upstream gradient of those tokens removes them from every gradient of the comparison."""
+    with torch.no_grad():
+        m64 = m.double()
+        x = m64.norm1(m64.merge(msg.double().permute(0, 2, 1)))
+        h = m64.mlp[0](torch.cat([res.double().permute(0, 2, 1), x], dim=2))
+        ok = (h.abs().amin(dim=2) > margin).float().unsqueeze(1)
+        m.float()
+    return ok
+
+
 def _run(fn, m, msg, res, residual, go):
     msg = msg.detach().clone().requires_grad_(True)
     res = res.detach().clone().requires_grad_(True)
@@ -56,20 +71,36 @@ def _run(fn, m, msg, res, residual, go):
     return out.detach(), grads
 
 
+# arithmetic of the chains' matrix phases (train_ops.TRAIN_PRECISION): "f32" = the unfused launches' own fmaf chains;
+# "bf16x3" (the default) = the gradient products (dx, dW) as split bf16 on the bf16 matrix core, forward and recomputation
+# f32: forward values and ReLU masks are the unfused graph's, gradients carry ~2^-17 per product; "bf16x3_all" (opt-in) =
+# the forward as split bf16 too.  Bounds per arithmetic:
+# (forward vs unfused, forward vs torch, gradient floor vs torch, gradient vs unfused)
+TOL = {"f32": (2e-6, 1e-5, 2e-5, 3e-5), "bf16x3": (2e-6, 1e-5, 3e-5, 3e-5), "bf16x3_all": (3e-5, 3e-5, 5e-5, 5e-5)}
+
+
+@pytest.fixture(params=["f32", "bf16x3", "bf16x3_all"])
+def prec(request):
+    from pcr_amd import train_ops as TO
+    prev = TO.set_train_precision(request.param)
+    yield request.param
+    TO.set_train_precision(prev)
+
+
 SHAPES = [(32, 32, 64, 32, True), (64, 64, 128, 64, True), (64, 64, 128, 64, False), (64, 64, 128, 128, False),
           (64, 32, 128, 64, False), (64, 3, 128, 32, False)]
 
 
 @pytest.mark.parametrize("d,c1,hid,out,residual", SHAPES)
 @pytest.mark.parametrize("B,Ln", [(5, 128), (3, 100), (7, 37), (300, 64)])
-def test_fused_tail_equals_the_unfused_launches_and_torch(d, c1, hid, out, residual, B, Ln):
+def test_fused_tail_equals_the_unfused_launches_and_torch(d, c1, hid, out, residual, B, Ln, prec):
     from pcr_amd import train_ops as TO
     from pcr_amd import _lib as L
     assert L.load().pcr_attn_tail_ok(d, c1, hid, out, int(residual)) == 1
     m = Tail(d, c1, hid, out, seed=d + c1 + out).cuda()
     g = torch.Generator().manual_seed(B * 1000 + Ln)
     msg, res = torch.randn(B, d, Ln, generator=g).cuda(), torch.randn(B, c1, Ln, generator=g).cuda()
-    go = torch.randn(B, out, Ln, generator=g).cuda()
+    go = torch.randn(B, out, Ln, generator=g).cuda() * _well_conditioned_tokens(m, msg, res)
 
     def fused(mm, a, b, r):
         y = TO.attn_tail(mm, a, b, r)
@@ -78,12 +109,13 @@ def test_fused_tail_equals_the_unfused_launches_and_torch(d, c1, hid, out, resid
     o_f, g_f = _run(fused, m, msg, res, residual, go)
     o_u, g_u = _run(_unfused, m, msg, res, residual, go)
     o_t, g_t = _run(_torch, m, msg, res, residual, go)
-    assert _rel(o_f, o_u) < 2e-6 and _rel(o_f, o_t) < 1e-5, (_rel(o_f, o_u), _rel(o_f, o_t))
+    t_fu, t_ft, t_g, t_gu = TOL[prec]
+    assert _rel(o_f, o_u) < t_fu and _rel(o_f, o_t) < t_ft, (_rel(o_f, o_u), _rel(o_f, o_t))
     for k in g_t:
         # against torch autograd the fused launch must be no further away than the unfused launches are (+ rounding)
         e_f, e_u = _rel(g_f[k], g_t[k]), _rel(g_u[k], g_t[k])
-        assert e_f < max(2e-5, 2 * e_u), (k, e_f, e_u)
-        assert _rel(g_f[k], g_u[k]) < 3e-5, (k, _rel(g_f[k], g_u[k]))
+        assert e_f < max(t_g, 2 * e_u), (k, e_f, e_u)
+        assert _rel(g_f[k], g_u[k]) < t_gu, (k, _rel(g_f[k], g_u[k]))
     # bit-reproducible: partial sums are reduced in a fixed order, no float atomics
     o_f2, g_f2 = _run(fused, m, msg, res, residual, go)
     assert torch.equal(o_f, o_f2) and all(torch.equal(g_f[k], g_f2[k]) for k in g_f)
@@ -143,7 +175,7 @@ HEADS = [(32, 32, 32, 3, 7), (64, 64, 64, 3, 7), (64, 64, 64, 2, 2), (128, 64, 6
 
 @pytest.mark.parametrize("c,hd,d,n,src", HEADS)
 @pytest.mark.parametrize("B,Ln", [(5, 128), (3, 100), (7, 37), (300, 32)])
-def test_fused_head_equals_the_unfused_launches_and_torch(c, hd, d, n, src, B, Ln):
+def test_fused_head_equals_the_unfused_launches_and_torch(c, hd, d, n, src, B, Ln, prec):
     from pcr_amd import train_ops as TO
     m = Head(c, hd, d, n, seed=c + d + n).cuda()
     g = torch.Generator().manual_seed(B * 1000 + Ln)
@@ -157,11 +189,12 @@ def test_fused_head_equals_the_unfused_launches_and_torch(c, hd, d, n, src, B, L
     o_f, g_f = _run_head(fused, m, x, xyz, src, go)
     o_u, g_u = _run_head(_head_unfused, m, x, xyz, src, go)
     o_t, g_t = _run_head(_head_torch, m, x, xyz, src, go)
-    assert _rel(o_f, o_u) < 2e-6 and _rel(o_f, o_t) < 1e-5, (_rel(o_f, o_u), _rel(o_f, o_t))
+    t_fu, t_ft, t_g, t_gu = TOL[prec]
+    assert _rel(o_f, o_u) < t_fu and _rel(o_f, o_t) < t_ft, (_rel(o_f, o_u), _rel(o_f, o_t))
     for k in g_t:
         e_f, e_u = _rel(g_f[k], g_t[k]), _rel(g_u[k], g_t[k])
-        assert e_f < max(2e-5, 2 * e_u), (k, e_f, e_u)
-        assert _rel(g_f[k], g_u[k]) < 3e-5, (k, _rel(g_f[k], g_u[k]))
+        assert e_f < max(t_g, 2 * e_u), (k, e_f, e_u)
+        assert _rel(g_f[k], g_u[k]) < t_gu, (k, _rel(g_f[k], g_u[k]))
     o_f2, g_f2 = _run_head(fused, m, x, xyz, src, go)
     assert torch.equal(o_f, o_f2) and all(torch.equal(g_f[k], g_f2[k]) for k in g_f)
 
@@ -213,6 +246,9 @@ def test_matching_stages_on_the_fused_path_equal_the_unfused_graph():
     from pcr_amd import train_ops as TO
     model, _ = bench.build_pt_model([128, 64, 32])
     model.train()
+    # (the chains in the unfused launches' own arithmetic: this test is about the graph -- partner addressing, fused
+    # buffers -- and split bf16 would add its ReLU near-tie flips to the comparison; the arithmetic itself is bounded above)
+    prev_prec = TO.set_train_precision("f32")
     g = torch.Generator().manual_seed(8)
     b, n = 6, 128
     h = torch.randn(2 * b, 64, n, generator=g).cuda()
@@ -229,8 +265,11 @@ def test_matching_stages_on_the_fused_path_equal_the_unfused_graph():
             return logits.detach(), hh.grad.clone(), grads
         finally:
             TO.FUSED_CHAINS = prev
-    lf, hf, gf = run(True)
-    lu, hu, gu = run(False)
+    try:
+        lf, hf, gf = run(True)
+        lu, hu, gu = run(False)
+    finally:
+        TO.set_train_precision(prev_prec)
     assert _rel(lf, lu) < 1e-5 and _rel(hf, hu) < 3e-5, (_rel(lf, lu), _rel(hf, hu))
     assert set(gf) == set(gu) and len(gf) >= 30
     for k in gu:
@@ -238,7 +277,7 @@ def test_matching_stages_on_the_fused_path_equal_the_unfused_graph():
 
 
 # ---- partial-sum reductions into compact gradients ------------------------------------------------------------------------
-def test_gradients_arrive_compact_and_a_parameter_used_twice_is_summed_correctly():
+def test_gradients_arrive_compact_and_a_parameter_used_twice_is_summed_correctly(prec):
     """train_ops.reduce_regions hands autograd compact contiguous gradients (no padded views to clone), and a parameter that
     enters the graph twice -- once through a fused chain, once sliced and re-joined into a dense layer -- gets the sum of
     both contributions (the hazard that ruled out deferring the reductions to the end of the pass)"""
@@ -246,7 +285,7 @@ def test_gradients_arrive_compact_and_a_parameter_used_twice_is_summed_correctly
     m = Tail(64, 64, 128, 64, seed=2).cuda()
     g = torch.Generator().manual_seed(12)
     msg, x = torch.randn(9, 64, 128, generator=g).cuda(), torch.randn(9, 64, 128, generator=g).cuda()
-    go = torch.randn(9, 64, 128, generator=g).cuda()
+    go = torch.randn(9, 64, 128, generator=g).cuda() * _well_conditioned_tokens(m, msg, x)
 
     def run(tail):
         for p in m.parameters():
@@ -259,4 +298,4 @@ def test_gradients_arrive_compact_and_a_parameter_used_twice_is_summed_correctly
     b = run(_unfused)
     assert all(v.is_contiguous() for v in a.values())
     for k in a:
-        assert _rel(a[k], b[k]) < 3e-5, (k, _rel(a[k], b[k]))
+        assert _rel(a[k], b[k]) < TOL[prec][3], (k, _rel(a[k], b[k]))

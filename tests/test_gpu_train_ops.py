@@ -417,6 +417,77 @@ def test_prepacked_weights_equal_fresh_packs_and_follow_updates():
     TO._PREPACKS.clear()
 
 
+def test_prepacked_bf16_images_equal_fresh_packs_and_follow_updates():
+    """the bf16 hi / lo images of the fused chains' weights (train_ops.pack_both_bf): the first request packs on the spot and
+    registers the weight, the next prepack() launch refreshes it with the f32 images (pcr_pack_weights_multi_f32 kind 1) --
+    same bits as the per-layer launches, for row / column counts that are not multiples of 16 / 32 too -- and a stale image
+    is never handed out"""
+    from pcr_amd import train_ops as TO
+    net = torch.nn.Sequential(torch.nn.Linear(67, 128), torch.nn.Linear(128, 32), torch.nn.Linear(40, 96),
+                              torch.nn.Linear(64, 64)).cuda()
+    ws = [m.weight for m in net]
+    TO._PREPACKS.clear()
+    fresh = [tuple(t.clone() for t in TO.pack_both_bf(w)) for w in ws]       # no table yet: per-layer launches
+    TO.prepack(net)
+    tab = TO._PREPACKS[net]
+    for w in ws[:3]:
+        assert tab.lookup_bf(w) is None          # registered by this request, packed by the NEXT refresh
+    for w, (f0, f1) in zip(ws[:3], fresh):       # (misses pack on the spot: still the right bits)
+        c0, c1 = TO.pack_both_bf(w)
+        assert torch.equal(c0, f0) and torch.equal(c1, f1)
+    f32_before = [tuple(t.clone() for t in TO.pack_both(w)) for w in ws]
+    TO.prepack(net)                              # table rebuilt with the three bf16 entries, one launch
+    for w, (f0, f1), (g0, g1) in zip(ws[:3], fresh, f32_before):
+        hit = tab.lookup_bf(w)
+        assert hit is not None and torch.equal(hit[0], f0) and torch.equal(hit[1], f1)
+        c0, c1 = TO.pack_both(w)                 # the f32 images stayed where they were, same bits
+        assert torch.equal(c0, g0) and torch.equal(c1, g1)
+    assert tab.entries[ws[3].data_ptr()][6] is None          # never requested: no bf16 image kept for it
+    with torch.no_grad():
+        ws[0].mul_(0.5)
+    assert tab.lookup_bf(ws[0]) is None          # stale: not handed out
+    c0, c1 = TO.pack_both_bf(ws[0])
+    assert not torch.equal(c0, fresh[0][0])
+    TO.prepack(net)
+    hit = tab.lookup_bf(ws[0])
+    assert hit is not None and torch.equal(hit[0], c0) and torch.equal(hit[1], c1)
+    TO._PREPACKS.clear()
+
+
+def test_trainer_gradients_do_not_depend_on_where_the_weight_images_come_from(grad_floor):
+    """one Trainer iteration with the one-launch weight refresh (fused=True: images from the prepack table, the bf16 ones
+    after their registration) against the same iteration with per-layer packs (fused=False): identical weights in, so
+    every gradient must come out bit for bit the same -- at iteration 0 (bf16 images packed on the spot in both) and at
+    iteration 2 (prepacked in one, on the spot in the other; the optimizers are bypassed so the weights stay equal)"""
+    import bench
+    from pcr_amd import train
+    s1, s2 = T.synthetic_pairs(8, 128, seed=2, kind="randn")
+    dev = "cuda"
+    ids1, ids2 = torch.arange(8), torch.tensor([0, 1, 2, 3, 9, 9, 9, 9])
+    data = dict(sparse_1=list(s1.to(dev)), sparse_2=list(s2.to(dev)), dense_1=list(s1.to(dev)), dense_2=list(s2.to(dev)),
+                label_1=[torch.zeros(1, dtype=torch.long, device=dev)] * 8,
+                label_2=[torch.zeros(1, dtype=torch.long, device=dev)] * 8,
+                id_1=[i.view(1).to(dev) for i in ids1], id_2=[i.view(1).to(dev) for i in ids2])
+    grads = []
+    for fused in (True, False):
+        m, _ = bench.build_pt_model([128, 64, 32])
+        m.train()
+        tr = train.Trainer(m, max_iters=8, lr=0.0, grad_clip=None, fused=fused)    # lr 0: the weights never move ...
+        per_iter = []
+        for _ in range(3):
+            tr.step(data)
+            per_iter.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+            with torch.no_grad():
+                for p in m.parameters():
+                    p.add_(0.0)                                                  # ... but their versions do
+        grads.append(per_iter)
+    for it in (0, 2):
+        a, b = grads[0][it], grads[1][it]
+        assert set(a) == set(b) and len(a) > 100
+        for k in a:
+            assert torch.equal(a[k], b[k]), (it, k, float((a[k] - b[k]).abs().max()))
+
+
 def test_fused_adamw_is_reproducible_and_refuses_host_tensors():
     from pcr_amd import _lib as L
     from pcr_amd.optim import FusedAdamW

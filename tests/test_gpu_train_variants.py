@@ -62,7 +62,7 @@ def _dgcnn_cfg():
 @pytest.mark.parametrize("tag,cfg,manifest", [("stnet", STNET, "pt"), ("orig", ORIG, "pt_xcorr"), ("baseline", BASELINE, "pt_baseline"),
                                               ("pt15m", _pt_mul(2, 64, 8), "pt15m"), ("pointnet", None, "pointnet"),
                                               ("dgcnn", None, "dgcnn")])
-def test_train_step_of_other_configs_matches_the_reference(tag, cfg, manifest):
+def test_train_step_of_other_configs_matches_the_reference(tag, cfg, manifest, grad_floor):
     cfg = cfg if cfg is not None else (_pointnet_cfg() if tag == "pointnet" else _dgcnn_cfg())
     g = load_golden("train_step_%s_n128" % tag)
     meta = g["meta"]
@@ -101,9 +101,9 @@ def test_train_step_of_other_configs_matches_the_reference(tag, cfg, manifest):
     # output's scale, sequential in k) are ~5x coarser than torch's blocked CPU matmul.  Observed: 1.4e-5 on the loss,
     # <= 2.7e-4 on the gradients behind the transforms (the reference's own float32: 1e-5 .. 2e-5), while the encoder's
     # own tensors sit at or below the reference's float32 error.  Floor for this family: 5e-4.
-    floor = 5e-4 if tag == "pointnet" else 1e-5
+    floor = 5e-4 if tag == "pointnet" else grad_floor
     for k in worst:
-        assert worst[k] < 1e-5 or vs64[k] < max(floor, 2.0 * ref_own[k]), (k, worst[k], vs64[k], ref_own[k])
+        assert worst[k] < grad_floor or vs64[k] < max(floor, 2.0 * ref_own[k]), (k, worst[k], vs64[k], ref_own[k])
     assert gn == pytest.approx(float(g["grad_norm"]), rel=2e-3)
     assert all(v < 1e-5 for v in bw.values()), bw
     no_grad = sorted(k for k, p in params.items() if p.grad is None)

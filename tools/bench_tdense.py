@@ -14,8 +14,10 @@ W = torch.randn(c, c, device="cuda") / c ** 0.5
 k = dict(ka=torch.rand(c, device="cuda"), kb=torch.rand(c, device="cuda") * 0.01, kc=torch.rand(c, device="cuda") * 0.01)
 isc, ish, iinv = torch.rand(c, device="cuda") + 0.5, torch.randn(c, device="cuda") * 0.1, torch.rand(c, device="cuda") + 0.5
 wpT = TO.pack_dev(W, transpose=True)
+wpT_bf = TO.pack_bf_T(W) if (c == 128 and TO.TRAIN_PRECISION != "f32") else None      # (the 128 x 128 launch on the bf16 core)
 def run():
-    return TO.tdense_bwd(g, x, c, dy_mode=1, y=y, k=k, isc=isc, ish=ish, iinv=iinv, in_relu=True, wpT=wpT, want_dstats=True)
+    return TO.tdense_bwd(g, x, c, dy_mode=1, y=y, k=k, isc=isc, ish=ish, iinv=iinv, in_relu=True, wpT=wpT, want_dstats=True,
+                         wpT_bf=wpT_bf)
 for _ in range(3): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
