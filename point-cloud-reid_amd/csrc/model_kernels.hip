@@ -607,6 +607,226 @@ __global__ __launch_bounds__(kThreads) void dense_bf_kernel(DenseArgs a, int KC)
     }
 }
 
+// ---- the same layer with the two halves of the work on DIFFERENT waves (round 5): 128 tokens x 256 couts per workgroup of
+// eight waves.  Waves 4-7 ("producers") fetch a chunk of 128 input channels, split it into bf16 hi / lo once and write the
+// bf image; waves 0-3 ("consumers") run the MFMAs of the previous chunk out of the other image buffer with their weights
+// streamed from L2 through the register ring -- one workgroup barrier per chunk, nothing else shared.  Why two roles and not
+// a register prefetch inside one wave: a wave's vector-memory loads retire in order, so an HBM fetch of the NEXT chunk
+// (~2 us) that is older than a weight load of the CURRENT one (L2, needed two k-steps later) stalls the first s_waitcnt of
+// the ring for the whole HBM latency; in separate waves the two streams have separate counters.  Against the one-role
+// kernel above (64-token tiles, load -> split -> barrier -> MFMA in every wave, two workgroups per CU: matrix pipe 0.36
+// busy, every weight byte fetched from L2 per 64 tokens = ~13 TB/s of L2 reads at the 1024 -> 512 layers) a weight
+// byte now feeds 128 tokens and the consumers never wait for HBM.  Shapes: cin % 128 == 0, L % 128 == 0, 16-byte aligned x;
+// everything else keeps dense_bf_kernel.  Same arithmetic, same order of the k-steps: bit-identical outputs.
+constexpr int kPcT = 128, kPcKC = 128, kPcThreads = 512;
+constexpr int kPcOP = 136;           // floats per cout row of the output staging tile (4 rows apart = 32 banks apart)
+constexpr size_t kPcLds = ((size_t)256 * kPcOP + 512) * sizeof(float);   // >= the two images (2 x 64 KB)
+
+template <bool GN, int NS, int NCH>
+__global__ __launch_bounds__(kPcThreads) void dense_bf_pc_kernel(DenseArgs a) {
+  constexpr int TB = 4, T = kPcT, KC = kPcKC, NR = 2, OP = kPcOP;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *img0 = smem;                // two images of [KC / 8 pieces][hi, lo][T] 16-byte units; then the output staging tile
+  float *s_sc = smem + 256 * OP;
+  float *s_sh = s_sc + 256;
+  const int coutP = ceil32(a.cout);
+  // XCD-aware order of a 1-D grid: workgroup n runs on XCD n % 8 (round-robin dispatch); the nz cout windows of one
+  // token tile take consecutive slots of ONE XCD, so they are resident together and the tile's input comes from HBM once
+  // and from that XCD's L2 for the other windows (as a 3-D grid the windows of a tile were a whole grid apart: the
+  // 1024 -> 512 layers read their 2.1 GB input twice, 6.3 GB per launch against ~5.5 TB/s)
+  const int nz = (coutP + 255) >> 8, tpc = a.L / T;
+  const int m = blockIdx.x >> 3;
+  const long tile = (long)(m / nz) * 8 + (blockIdx.x & 7);
+  if (tile >= a.w_bstride) return;             // (w_bstride = B x tiles per cloud here; the grid is rounded up to 8 nz)
+  const size_t b = (size_t)(tile / tpc);
+  const int t0 = (int)(tile - (long)b * tpc) * T;
+  const int chunk0 = (m % nz) * 256;
+  const int chunkP = coutP - chunk0 < 256 ? coutP - chunk0 : 256;
+  const int tid = threadIdx.x;
+  const bool producer = tid >= 256;            // wave-uniform: waves 4..7
+  if (tid < 256) {
+    const int oc = chunk0 + tid;
+    s_sc[tid] = (a.scale && oc < a.cout) ? a.scale[oc] : 1.0f;
+    s_sh[tid] = (a.shift && oc < a.cout) ? a.shift[oc] : 0.0f;
+  }
+  const int cout = a.cout, act = a.act, L = a.L;
+  const float *xb = a.x + b * a.cin * a.L;
+  // NCH = cin / 128 is a template argument and the chunk loop is unrolled completely: with a loop the compiler's s_waitcnt
+  // bookkeeping gives up at the back edge and makes a commit wait for the YOUNGER request too (vmcnt(14) .. vmcnt(0) with 32
+  // loads outstanding) -- the producers then wait out the HBM latency every chunk with the consumers at the barrier
+  constexpr int nch = NCH;
+  const size_t wstep = (size_t)(coutP >> 5) * 128 * 4;               // floats of one 16-channel step of the image
+  const float *wp = a.wp + (size_t)(chunk0 >> 5) * 128 * 4;
+  const DenseNoHook nh;
+  auto noepi = [](const f32x16 &, int, int, int, int) {};
+  f32x16 carry[NR][TB];
+  if (!producer) {
+#pragma unroll
+    for (int nr = 0; nr < NR; nr++)
+#pragma unroll
+      for (int j = 0; j < TB; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) carry[nr][j][r] = 0.f;
+  }
+  // producer lane (uq, pgrp): tokens 4 uq .. + 3 of the eight channels of pieces pgrp and pgrp + 8 of a chunk: 32 lanes x 16
+  // bytes = one 512-byte run per channel row, sixteen loads per chunk and lane.  TWO chunks are in flight per lane (a chunk
+  // requested during chunk c is committed during chunk c + 2: with one, every barrier waited ~1 us for the fetch), and
+  // their 2 x 16 pieces live IN the consumers' accumulator array -- piece (i, j) of set s = registers 4 (j & 3) .. + 3 of
+  // carry[s][2 i + (j >> 2)]: the register file is allocated per kernel, not per role, and as arrays of their own the
+  // pieces pushed the kernel 90-200 registers into scratch
+  const int q = tid & 255, uq = q & 31, pgrp = q >> 5;
+#define PCR_PV(s, i, j, k) carry[s][2 * (i) + ((j) >> 2)][4 * ((j) & 3) + (k)]
+  // (buffer loads: one lane offset register + a scalar offset per piece; sixteen 64-bit lane addresses per request and set
+  // were another 80 registers of scratch)
+  const int dbg = a.x_pm;              // (PCR_DPC_DBG of a tuning build: 1 = no MFMAs, 2 = no fetches, 4 = no split / image stores,
+                                       //  8 = every fetch from the first tile of the first cloud: L2 hits)
+  // (the descriptor's base is the same in every lane; said explicitly, or each load sits in a waterfall loop)
+  const size_t xbase = reinterpret_cast<size_t>((PCR_TUNING != 0 && (dbg & 8)) ? a.x : xb);
+  const size_t xbase_u = (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xbase) |
+                         ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(xbase >> 32)) << 32);
+  const __amdgpu_buffer_rsrc_t rx =
+      __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float *>(xbase_u), 0, a.cin * L * 4, 0x00020000);
+  const int vo_x = ((16 * (pgrp >> 1) + 4 * (pgrp & 1)) * L + ((PCR_TUNING != 0 && (dbg & 8)) ? 0 : t0) + 4 * uq) * 4;
+  auto request = [&](auto stag, int c) __attribute__((always_inline)) {
+    constexpr int S = decltype(stag)::value;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        // piece P = pgrp + 8 i: channel c KC + 16 (P >> 1) + bf_kpos(P & 1, j) = [lane part in vo_x] + c KC + 64 i + bf_kpos(0, j)
+        const int so = (((PCR_TUNING != 0 && (dbg & 8)) ? 0 : c) * KC + 64 * i + bf_kpos(0, j)) * L * 4;
+        const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo_x, so, 0));
+        PCR_PV(S, i, j, 0) = t[0];
+        PCR_PV(S, i, j, 1) = t[1];
+        PCR_PV(S, i, j, 2) = t[2];
+        PCR_PV(S, i, j, 3) = t[3];
+      }
+    }
+  };
+  auto commit = [&](auto stag, float *img) __attribute__((always_inline)) {
+    constexpr int S = decltype(stag)::value;
+    bf16x8 *u = reinterpret_cast<bf16x8 *>(img);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int P = pgrp + 8 * i;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        float x8[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x8[j] = PCR_PV(S, i, j, k);
+        bf16x8 hi, lo;
+        bf_split8(x8, hi, lo, NS == 3);
+        u[(2 * P) * T + bf_tok_swz(4 * uq + k)] = hi;          // (swizzled token positions: tile_dense.h, BSWZ)
+        if constexpr (NS == 3) u[(2 * P + 1) * T + bf_tok_swz(4 * uq + k)] = lo;
+      }
+    }
+  };
+  const std::integral_constant<int, 0> set0;
+  const std::integral_constant<int, 1> set1;
+  // The two roles are two SEPARATE straight-line instruction streams that meet the same number of s_barrier instructions
+  // (the hardware counts arrivals, not program counters).  Written as one loop with `if (producer)` blocks the compiler's
+  // s_waitcnt bookkeeping merges the consumers' pending weight loads with the producers' pending fetches at every join and
+  // makes a commit wait for the YOUNGER request as well (vmcnt(14) .. vmcnt(0) with 32 loads outstanding): the producers
+  // then wait out the HBM latency every chunk with the consumers at the barrier, and the roles' times simply add up.
+  // The barrier is NOT __syncthreads() either: its workgroup-scope fence is `s_waitcnt vmcnt(0) lgkmcnt(0)`; only LDS
+  // traffic has to be ordered here.
+#define PCR_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  // (the PCR_DPC_DBG ablation switches exist in tuning builds only: as run-time branches they are joins again, and the
+  // production stream must be straight-line)
+  auto off = [&](int bit) __attribute__((always_inline)) { return PCR_TUNING != 0 && (dbg & bit) != 0; };
+  if (producer) {
+    if (!off(2)) {
+      request(set0, 0);
+      request(set1, 1);
+    }
+#pragma unroll
+    for (int c = 0; c < nch; c += 2) {
+      // (chunk c - 2's readers passed the previous barrier: the buffer is free)
+      if (!off(4)) commit(set0, img0);
+      if (c + 2 < nch && !off(2)) request(set0, c + 2);
+      PCR_LDS_BARRIER();               // chunk c is in LDS
+      if (!off(4)) commit(set1, img0 + KC * T);
+      if (c + 3 < nch && !off(2)) request(set1, c + 3);
+      PCR_LDS_BARRIER();               // chunk c + 1 is in LDS
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < nch; c++) {
+      PCR_LDS_BARRIER();               // chunk c is in LDS; every consumer is done with chunk c - 1
+      if (!off(1))
+        tile_dense_bf_impl<TB, NR, 1, true, NS, decltype(noepi), bf_pf(NR), DenseNoHook, true, false, true, true, true>(
+            img0 + (c & 1) * (KC * T), KC, wp + (size_t)c * (KC >> 4) * wstep, chunkP, false, noepi, nullptr, nh, coutP, nullptr,
+            carry);
+    }
+  }
+#undef PCR_LDS_BARRIER
+  // ---- epilogue by ALL eight waves: the consumers normalise their tiles in registers (GN) and put them into a [cout][token]
+  // staging tile (the images are dead), then every thread takes sixteen 16-byte pieces of it -- scale, shift, residual,
+  // activation -- with all its residual loads in flight at once and whole 512-byte rows per 32 lanes.  (From the accumulator
+  // layout the residual came as sixteen 4-byte loads per tile and lane, eight dependent HBM round trips per workgroup with
+  // nothing else resident on the CU: 0.97 of the launch's 2.4 ms.)
+  __syncthreads();                     // every consumer is done with the last image
+  float *stage = smem;
+  if (!producer) {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int nr = 0; nr < NR; nr++) {
+      const int cb = wave + 4 * nr;
+      if (cb < (chunkP >> 5)) {
+#pragma unroll
+        for (int j = 0; j < TB; j++) {
+          float v[16];
+          if constexpr (GN) {
+            switch (a.gn_gs) {
+              case 4: gn_tile<4>(carry[nr][j], v); break;
+              case 8: gn_tile<8>(carry[nr][j], v); break;
+              case 16: gn_tile<16>(carry[nr][j], v); break;
+              default: gn_tile<32>(carry[nr][j], v); break;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) v[r] = carry[nr][j][r];
+          }
+#pragma unroll
+          for (int r = 0; r < 16; r++)
+            stage[(cb * 32 + 8 * (r >> 2) + 4 * h + (r & 3)) * OP + j * 32 + l31] = v[r];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {
+    float *out = a.y + b * a.cout * a.L;
+    const float *res = (GN && a.res) ? a.res + b * a.cout * a.L : nullptr;
+    const int qd = tid & 31, r0 = tid >> 5;          // rows r0 + 16 i, tokens 4 qd .. + 3; two rounds of eight rows
+#pragma unroll 1
+    for (int half = 0; half < 2; half++) {
+      f32x4 rs[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int row = r0 + 16 * (8 * half + i), oc = chunk0 + row;
+        rs[i] = (res && oc < cout) ? *reinterpret_cast<const f32x4 *>(res + (size_t)oc * L + t0 + 4 * qd) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int row = r0 + 16 * (8 * half + i), oc = chunk0 + row;
+        if (row < chunkP && oc < cout) {
+          const f32x4 v4 = *reinterpret_cast<const f32x4 *>(stage + row * OP + 4 * qd);
+          const float sc = s_sc[row], sh = s_sh[row];
+          f32x4 o4;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const float r = v4[k] * sc + sh + rs[i][k];
+            o4[k] = act == 1 ? fmaxf(r, 0.f) : (act == 2 && r < 0.f) ? r * 0.2f : r;
+          }
+          *reinterpret_cast<f32x4 *>(out + (size_t)oc * L + t0 + 4 * qd) = o4;
+        }
+      }
+    }
+  }
+#undef PCR_PV
+}
+
 // (B,C,L) -> out[c * B + b] = max over L   (channel-major with the clouds as tokens: (1,C,B))
 __global__ __launch_bounds__(kThreads) void max_over_l_kernel(const float *__restrict__ x,
                                                               float *__restrict__ out, int B, int C, int L) {
@@ -910,6 +1130,33 @@ static int dense_bf_launch(const float *x, const float *wp_bf, const float *scal
   if (B == 0) return PCR_OK;
   if (B > 65535) return PCR_ERR_INVALID;
   DenseArgs a{x, wp_bf, scale, shift, y, cin, cout, L, act, 0, 0, gn_gs, res};
+  if ((cin == 256 || cin == 512 || cin == 1024) && L % kPcT == 0 && (reinterpret_cast<size_t>(x) & 15) == 0 && cout > 128 &&
+      (size_t)cin * L * 4 < 0x7FFFFFFFull &&
+      !pcr_tune_str("PCR_DENSE_NO_PC")) {
+    const size_t ldsp = kPcLds;
+    a.x_pm = pcr_tune_int("PCR_DPC_DBG");
+    const long tiles = (long)B * (L / kPcT), nzw = (ceil32(cout) + 255) / 256;
+    if (((tiles + 7) / 8) * 8 * nzw > 0x7FFFFFFFl) return PCR_ERR_INVALID;
+    a.w_bstride = tiles;
+#define PCR_DPC1(GNv, NSv, NCHv)                                                                  \
+  do {                                                                                            \
+    static bool ok = allow_big_lds(dense_bf_pc_kernel<GNv, NSv, NCHv>);                           \
+    (void)ok;                                                                                     \
+    hipLaunchKernelGGL((dense_bf_pc_kernel<GNv, NSv, NCHv>), dim3((unsigned)(((tiles + 7) / 8) * 8 * nzw)), dim3(kPcThreads), ldsp, pcr_s(stream), a); \
+  } while (0)
+#define PCR_DPC(GNv, NSv)                  \
+  do {                                     \
+    if (cin == 1024) PCR_DPC1(GNv, NSv, 8); \
+    else if (cin == 512) PCR_DPC1(GNv, NSv, 4); \
+    else PCR_DPC1(GNv, NSv, 2);            \
+  } while (0)
+    if (precision == PCR_PREC_BF16X3) { if (gn_gs) PCR_DPC(true, 3); else PCR_DPC(false, 3); }
+    else { if (gn_gs) PCR_DPC(true, 1); else PCR_DPC(false, 1); }
+#undef PCR_DPC1
+#undef PCR_DPC
+    PCR_CHECK_LAUNCH();
+    return PCR_OK;
+  }
   const int KC = cin % 256 == 0 ? 256 : (cin % 128 == 0 ? 128 : 64);
   const size_t lds = ((size_t)KC * 64 + 512) * sizeof(float);
   const dim3 g((L + 63) / 64, B, (cout + 255) / 256);

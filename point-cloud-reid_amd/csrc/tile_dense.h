@@ -443,8 +443,14 @@ __device__ __forceinline__ void bf_ring_load(const float *__restrict__ wp_, int 
 // ring: null, or the steps bf_ring_load fetched for THIS call; RES: the ring holds every step (no weight load inside)
 // CIN / COUT (split contraction, as tile_dense_impl): the accumulators come from / go back to `carry`, so a caller walks a
 // long cin extent chunk by chunk through a small LDS image (dense_bf_kernel, model_kernels.hip)
+// BSWZ (bf images only): token t of the image sits at unit position bf_tok_swz(t) = t ^ ((t >> 4) & 3) -- a permutation inside
+// aligned groups of four, so a consumer's 32 lanes still read 32 consecutive units, while a PRODUCER whose lane holds four
+// consecutive tokens (a 16-byte global load per channel) writes, per store instruction, units that fall into 16 different
+// 16-byte bank groups instead of 4 (an 8-way -> 2-way conflict on every ds_write_b128 of the fill)
+__host__ __device__ constexpr int bf_tok_swz(int t) { return t ^ ((t >> 4) & 3); }
+
 template <int TB, int NR, int WAYS, bool TILE, int NS, class Epi, int PF = bf_pf(NR), class AfterK = DenseNoHook,
-          bool BIMG = false, bool RES = false, bool CIN = false, bool COUT = false>
+          bool BIMG = false, bool RES = false, bool CIN = false, bool COUT = false, bool BSWZ = false>
 __device__ __forceinline__ void tile_dense_bf_impl(const float *__restrict__ in, int CP,
                                                    const float *__restrict__ wp_, int OP, bool sync_epi, Epi epi,
                                                    const float *__restrict__ init = nullptr,
@@ -477,7 +483,8 @@ __device__ __forceinline__ void tile_dense_bf_impl(const float *__restrict__ in,
     int tb = tb0 + j * WAYS;
     tb = tb < TB ? tb : TB - 1;
     brow[j] = in + 4 * h * RP + tb * 32 + l31;                                            // rows bf_kpos(h, .) of a step
-    bimg[j] = reinterpret_cast<const bf16x8 *>(in) + 2 * h * (32 * TB) + tb * 32 + l31;   // piece 2 s + h of a step
+    bimg[j] = reinterpret_cast<const bf16x8 *>(in) + 2 * h * (32 * TB) +
+              (BSWZ ? bf_tok_swz(tb * 32 + l31) : tb * 32 + l31);                         // piece 2 s + h of a step
   }
   bf16x8 ah[PF][NR], al[PF][NR];
 #pragma unroll

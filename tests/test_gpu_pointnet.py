@@ -137,3 +137,41 @@ def test_dense_with_fused_max_over_points_equals_the_two_launches(B, cin, cout, 
                                   L.stream_ptr()), "pcr_dense_max_f32")
     assert torch.equal(got, want)
     assert torch.equal(want[0].t(), y.max(dim=2)[0])
+
+
+@pytest.mark.parametrize("B,cin,cout,Ln", [(3, 1024, 512, 256), (2, 256, 256, 128), (5, 384, 160, 384), (1, 512, 1024, 256)])
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+def test_two_role_dense_kernel_equals_the_one_role_kernel_bit_for_bit(B, cin, cout, Ln, prec):
+    """dense_bf_pc_kernel (round 5: 128-token tiles, producer waves fetch + split the next 128-channel chunk while the
+    consumer waves multiply the current one; token counts that are multiples of 128) against dense_bf_kernel (64-token
+    tiles, one role), which the same tokens take when the cloud is cut to a length that is no multiple of 128: every output
+    is a function of its own token, both kernels walk the 16-channel steps in the same order -> the same bits.  Plain
+    (scale / shift / activation) and GroupNorm + residual + ReLU epilogues, cout windows of 256 and a partial window; and
+    both stay on the torch result."""
+    import torch.nn.functional as F
+    from pcr_amd import engine as E, rows
+    g = torch.Generator().manual_seed(cin + cout + Ln)
+    x = torch.randn(B, cin, Ln, generator=g).cuda()
+    w = torch.randn(cout, cin, generator=g) / cin ** 0.5
+    sc, sh = (torch.rand(cout, generator=g) + 0.5).cuda(), torch.randn(cout, generator=g).cuda()
+    res = torch.randn(B, cout, Ln, generator=g).cuda()
+    gn = torch.nn.GroupNorm(cout // 8, cout)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(cout, generator=g))
+        gn.bias.copy_(torch.randn(cout, generator=g))
+    cut = Ln - 64                      # not a multiple of 128: the one-role kernel
+    with E.precision(prec):
+        wp = E.pack_weight_dual(w, "cuda")
+        assert getattr(wp, "_pcr_bf", None) is not None
+        for act in (0, 1, 2):
+            full = E.dense(x, wp, cout, sc, sh, act=act)
+            part = E.dense(x[:, :, :cut].contiguous(), wp, cout, sc, sh, act=act)
+            assert torch.equal(full[:, :, :cut], part), act
+        full = rows.dense_gn(x, wp, cout, gn, res=res, relu=True)
+        part = rows.dense_gn(x[:, :, :cut].contiguous(), wp, cout, gn, res=res[:, :, :cut].contiguous(), relu=True)
+        assert torch.equal(full[:, :, :cut], part)
+    with torch.no_grad():
+        y = torch.einsum("oc,bcl->bol", w, x.cpu())
+        want = F.relu(gn(y.permute(0, 2, 1).reshape(-1, cout)).reshape(B, Ln, cout).permute(0, 2, 1) + res.cpu())
+    tol = 2e-4 if prec == "bf16x3" else 6e-2
+    assert float((full.cpu() - want).abs().max()) < tol
