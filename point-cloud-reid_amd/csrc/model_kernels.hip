@@ -460,6 +460,173 @@ __global__ __launch_bounds__(kThreads) void dense_max_kernel(DenseArgs a, int B)
   }
 }
 
+// ---- f32 layers with a short contraction (cin <= 128: PointNet's conv2 / conv3 and the STN convs, which stay on the
+// f32-input MFMA: DESIGN section 5) with the WEIGHTS RESIDENT (round 5).  The chunked / whole-extent kernels above stream the
+// packed weights from L2 through a register ring for every 64-token tile and run load -> barrier -> MFMA -> epilogue as
+// serial phases of a workgroup (dense_max[128 -> 1024]: 0.44 of the f32-MFMA peak).  Here a workgroup owns 128 couts of one
+// cloud for ALL of the cloud's tiles: wave w keeps cout block w's whole A operand in registers (cin / 8 x 16 bytes per
+// lane: 64 registers at cin = 128), so the tile loop contains no weight load at all -- which is what lets the NEXT tile's
+// input be fetched into registers during the current tile's MFMAs (a wave's vector loads retire in order: behind a
+// weight ring the prefetch would be waited for at the ring's first use) -- and ~150 registers leave three workgroups per CU.
+// The k-steps run in the order of tile_dense_impl: the same bits as the kernels above.
+//   MAXE: out[c * B + b] = max over the cloud's tokens (dense_max_kernel's contract), else y (B,cout,L).
+template <int KB, bool MAXE>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(KB >= 16 ? 2 : 3, KB >= 16 ? 2 : 3))) void dense_rw_kernel(DenseArgs a, int B) {
+  constexpr int TB = 2, T = 64, RP = T + 1, CP = 8 * KB, NQ = (CP * T / 4 + kThreads - 1) / kThreads;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *X = smem;                    // [CP][RP]
+  float *s_sc = X + CP * RP;          // [128] scale / shift of this workgroup's cout window
+  float *s_sh = s_sc + 128;
+  const int coutP = ceil32(a.cout);
+  const size_t b = blockIdx.y;
+  const int chunk0 = blockIdx.x * 128;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cb = (chunk0 >> 5) + wave;                 // this wave's cout block (may lie beyond coutP: clamped, dropped)
+  const bool cb_ok = cb * 32 < coutP;
+  if (tid < 128) {
+    const int oc = chunk0 + tid;
+    s_sc[tid] = (a.scale && oc < a.cout) ? a.scale[oc] : 1.0f;
+    s_sh[tid] = (a.shift && oc < a.cout) ? a.shift[oc] : 0.0f;
+  }
+  const int cin = a.cin, cout = a.cout, act = a.act, L = a.L;
+  // the wave's A operand: k-block kb = four k-steps, f32x4 at [kb][cout][h]
+  f32x4 wreg[KB];
+  {
+    const int cbc = cb_ok ? cb : (coutP >> 5) - 1;
+    const f32x4 *wv = reinterpret_cast<const f32x4 *>(a.wp) + (size_t)(cbc * 32 + l31) * 2 + h;
+    const size_t wstride = (size_t)coutP * 2;
+    const int kbn = ceil8(cin) >> 3;             // k-blocks the packed image really has (KB is the template's bound)
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+      const f32x4 wv4 = wv[(size_t)(kb < kbn ? kb : kbn - 1) * wstride];
+      wreg[kb] = kb < kbn ? wv4 : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const float *xb = a.x + b * (size_t)cin * L;
+  const bool vecL = (L & 3) == 0 && (reinterpret_cast<size_t>(xb) & 15) == 0;
+  // the tile's 16-byte pieces of this thread: piece e = tid + u 256 -> (channel e / 16, token quad e % 16)
+  f32x4 pre[NQ];
+  auto request = [&](int t0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < NQ; u++) {
+      const int e = tid + u * kThreads;
+      const int c = e >> 4, qd = e & 15;
+      const bool ok = e < CP * 16 && c < cin;
+      const float *src = xb + (size_t)(ok ? c : 0) * L + t0 + 4 * qd;
+      if (vecL && t0 + T <= L) {
+        pre[u] = *reinterpret_cast<const f32x4 *>(src);
+      } else {                                   // ragged / unaligned tiles: element loads from clamped addresses
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int t = t0 + 4 * qd + k;
+          pre[u][k] = xb[(size_t)(ok ? c : 0) * L + (t < L ? t : L - 1)];
+        }
+      }
+    }
+  };
+  auto commit = [&](int t0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < NQ; u++) {
+      const int e = tid + u * kThreads;
+      const int c = e >> 4, qd = e & 15;
+      if (e < CP * 16) {
+        float *d = X + c * RP + 4 * qd;
+#pragma unroll
+        for (int k = 0; k < 4; k++) d[k] = (c < cin && t0 + 4 * qd + k < L) ? pre[u][k] : 0.f;
+      }
+    }
+  };
+  float vmax[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) vmax[r] = -INFINITY;
+  float *out = MAXE ? nullptr : a.y + b * (size_t)cout * L;
+  request(0);
+  for (int t0 = 0; t0 < L; t0 += T) {
+    if (t0) __syncthreads();             // every wave is done with the previous tile's operands
+    commit(t0);
+    __syncthreads();
+    if (t0 + T < L) request(t0 + T);     // (lands during this tile's MFMAs: nothing else of this wave loads from memory)
+    f32x16 acc[TB];
+#pragma unroll
+    for (int j = 0; j < TB; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+    const float *bp = X + h * RP + l31;
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+      float xq[TB][4];
+#pragma unroll
+      for (int j = 0; j < TB; j++)
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) xq[j][qq] = bp[(kb * 8 + 2 * qq) * RP + j * 32];
+#pragma unroll
+      for (int qq = 0; qq < 4; qq++)
+#pragma unroll
+        for (int j = 0; j < TB; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[kb][qq], xq[j][qq], acc[j], 0, 0, 0);
+    }
+    if (cb_ok) {
+#pragma unroll
+      for (int j = 0; j < TB; j++) {
+        const int t = t0 + j * 32 + l31;
+        if (t < L) {
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            const int o = wave * 32 + 8 * g + 4 * h;       // row of the 128-cout window
+            const f32x4 s4 = *reinterpret_cast<const f32x4 *>(s_sc + o), b4 = *reinterpret_cast<const f32x4 *>(s_sh + o);
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+              float r = acc[j][4 * g + qq] * s4[qq] + b4[qq];
+              r = act == 1 ? fmaxf(r, 0.f) : (act == 2 && r < 0.f) ? r * 0.2f : r;
+              if constexpr (MAXE) {
+                vmax[4 * g + qq] = fmaxf(vmax[4 * g + qq], r);
+              } else {
+                const int oc = chunk0 + o + qq;
+                if (oc < cout) out[(size_t)oc * L + t] = r;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  if constexpr (MAXE) {
+    if (cb_ok) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float v = vmax[r];
+        v = fmaxf(v, __shfl_xor(v, 1, 64));
+        v = fmaxf(v, __shfl_xor(v, 2, 64));
+        v = fmaxf(v, __shfl_xor(v, 4, 64));
+        v = fmaxf(v, __shfl_xor(v, 8, 64));
+        v = fmaxf(v, __shfl_xor(v, 16, 64));
+        const int oc = chunk0 + wave * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        if (l31 == 0 && oc < cout) a.y[(size_t)oc * B + b] = v;
+      }
+    }
+  }
+}
+
+// shapes the resident-weight kernel takes: cin <= 128 (a multiple of 8 after padding: the packed image's k-blocks)
+static bool dense_rw_ok(int cin, int cout, int L) { return cin >= 16 && cin <= 128 && cout >= 128 && L >= 128; }
+
+template <bool MAXE>
+static int dense_rw_launch(const DenseArgs &a, int B, hipStream_t st) {
+  const int KB = ceil8(a.cin) / 8;
+  const dim3 g((ceil32(a.cout) + 127) / 128, B);
+#define PCR_DRW(KBv)                                                                                       \
+  do {                                                                                                     \
+    const size_t lds = ((size_t)8 * KBv * 65 + 256) * sizeof(float);                                       \
+    hipLaunchKernelGGL((dense_rw_kernel<KBv, MAXE>), g, dim3(kThreads), lds, st, a, B);                    \
+  } while (0)
+  if (KB <= 4) PCR_DRW(4);
+  else if (KB <= 8) PCR_DRW(8);
+  else PCR_DRW(16);
+#undef PCR_DRW
+  PCR_CHECK_LAUNCH();
+  return PCR_OK;
+}
+
 // ---- the wide per-point layers on the bf16 matrix core (round 4): PointNet's 1x1 convs, DGCNN's conv5 and the LinearRes
 // downsample rows were the last MFMA-bound launches in f32 (0.7 of a 157 TFLOP/s roof).  Same tiling as the chunked f32
 // form -- 64 tokens x up to 256 couts per workgroup, the cin extent walked in chunks of KC channels with the accumulators
@@ -726,10 +893,8 @@ __global__ __launch_bounds__(kPcThreads) void dense_bf_pc_kernel(DenseArgs a) {
   // The two roles are two SEPARATE straight-line instruction streams that meet the same number of s_barrier instructions
   // (the hardware counts arrivals, not program counters).  Written as one loop with `if (producer)` blocks the compiler's
   // s_waitcnt bookkeeping merges the consumers' pending weight loads with the producers' pending fetches at every join and
-  // makes a commit wait for the YOUNGER request as well (vmcnt(14) .. vmcnt(0) with 32 loads outstanding): the producers
-  // then wait out the HBM latency every chunk with the consumers at the barrier, and the roles' times simply add up.
-  // The barrier is NOT __syncthreads() either: its workgroup-scope fence is `s_waitcnt vmcnt(0) lgkmcnt(0)`; only LDS
-  // traffic has to be ordered here.
+  // makes a commit wait for the YOUNGER request as well (vmcnt(14) .. vmcnt(0) with 32 loads outstanding; as separate
+  // streams vmcnt(31) .. vmcnt(16): only the older set).  The barrier orders LDS traffic only.
 #define PCR_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
   // (the PCR_DPC_DBG ablation switches exist in tuning builds only: as run-time branches they are joins again, and the
   // production stream must be straight-line)
@@ -1086,6 +1251,8 @@ static int dense_launch(const float *x, const float *wp, long w_bstride, const f
   if (B == 0) return PCR_OK;
   if (B > 65535) return PCR_ERR_INVALID;
   DenseArgs a{x, wp, scale, shift, y, cin, cout, L, act, w_bstride, x_pm, gn_gs, res};
+  if (!w_bstride && !x_pm && !gn_gs && dense_rw_ok(cin, cout, L) && !pcr_tune_str("PCR_DENSE_NO_RW"))
+    return dense_rw_launch<false>(a, B, pcr_s(stream));
   const int cinP = ceil8(cin);
   if (cin >= 2 * kChunk && cin % kChunk == 0 && cout % 256 == 0 && !x_pm && !w_bstride && L > 32 &&
       !pcr_tune_str("PCR_DENSE_NO_CHUNK")) {
@@ -1306,6 +1473,7 @@ PCR_EXPORT int pcr_dense_max_f32(const float *x, const float *wp, const float *s
   if (B == 0) return PCR_OK;
   if (B > 65535) return PCR_ERR_INVALID;
   DenseArgs a{x, wp, scale, shift, out, cin, cout, L, act, 0, 0, 0, nullptr};
+  if (dense_rw_ok(cin, cout, L) && !pcr_tune_str("PCR_DENSE_NO_RW")) return dense_rw_launch<true>(a, B, pcr_s(stream));
   const size_t lds = ((size_t)ceil8(cin) * 65 + 512) * sizeof(float);
   static bool ok = allow_big_lds(dense_max_kernel);
   (void)ok;

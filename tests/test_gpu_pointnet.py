@@ -175,3 +175,37 @@ def test_two_role_dense_kernel_equals_the_one_role_kernel_bit_for_bit(B, cin, co
         want = F.relu(gn(y.permute(0, 2, 1).reshape(-1, cout)).reshape(B, Ln, cout).permute(0, 2, 1) + res.cpu())
     tol = 2e-4 if prec == "bf16x3" else 6e-2
     assert float((full.cpu() - want).abs().max()) < tol
+
+
+@pytest.mark.parametrize("B,cin,cout,Ln", [(5, 128, 1024, 256), (3, 64, 128, 200), (2, 128, 160, 131), (4, 24, 256, 128)])
+def test_resident_weight_dense_kernel_equals_the_streaming_kernels_bit_for_bit(B, cin, cout, Ln):
+    """dense_rw_kernel (round 5: f32 layers with cin <= 128 keep their weights in registers for all tiles of a cloud and
+    fetch the next tile during the MFMAs; clouds of >= 128 tokens) against the kernels that stream the weights per tile,
+    which the same tokens take in a cloud cut below 128 tokens: same k order -> same bits, ragged last tiles, cout
+    windows that are not multiples of 128, every activation; the fused max over the points equals the max of the stored
+    layer; and both stay on torch."""
+    import ctypes
+    import torch.nn.functional as F
+    from pcr_amd import _lib as L
+    from pcr_amd import engine as E
+    g = torch.Generator().manual_seed(cin + cout + Ln)
+    x = torch.randn(B, cin, Ln, generator=g).cuda()
+    w = torch.randn(cout, cin, generator=g) / cin ** 0.5
+    sc, sh = (torch.rand(cout, generator=g) + 0.5).cuda(), torch.randn(cout, generator=g).cuda()
+    wp = E.pack_weight(w, "cuda")
+    cut = 96
+    with E.precision("f32"):
+        for act in (0, 1, 2):
+            full = E.dense(x, wp, cout, sc, sh, act=act)
+            part = E.dense(x[:, :, :cut].contiguous(), wp, cout, sc, sh, act=act)
+            assert torch.equal(full[:, :, :cut], part), act
+            want = torch.einsum("oc,bcl->bol", w, x.cpu()) * sc.cpu().view(1, -1, 1) + sh.cpu().view(1, -1, 1)
+            want = F.relu(want) if act == 1 else F.leaky_relu(want, 0.2) if act == 2 else want
+            assert float((full.cpu() - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+        lib = L.load()
+        if lib.pcr_dense_max_ok(cin, cout, Ln):
+            full = E.dense(x, wp, cout, sc, sh, act=1)
+            got = torch.full((1, cout, B), float("nan"), dtype=torch.float32, device="cuda")
+            L.check(lib.pcr_dense_max_f32(L.ptr(x), L.ptr(wp), L.ptr(sc), L.ptr(sh), L.ptr(got), B, cin, cout, Ln, 1,
+                                          L.stream_ptr()), "pcr_dense_max_f32")
+            assert torch.equal(got[0].t(), full.max(dim=2)[0])
