@@ -478,6 +478,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(KB >= 
   float *s_sc = X + CP * RP;          // [128] scale / shift of this workgroup's cout window
   float *s_sh = s_sc + 128;
   const int coutP = ceil32(a.cout);
+  // (grid (window, cloud): the eight windows of a cloud sit on eight XCDs and each fetches the cloud's input itself -- 2.1 GB
+  // of HBM reads for dense_max[128 -> 1024]'s 268 MB input, 1.4 TB/s, not the bound.  Measured and dropped: an XCD-aware
+  // 1-D order that puts a cloud's windows on ONE XCD -- 1.42 -> 1.52 ms, the eight workgroups then ask one L2 for the same
+  // lines at the same moment)
   const size_t b = blockIdx.y;
   const int chunk0 = blockIdx.x * 128;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;

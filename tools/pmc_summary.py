@@ -23,7 +23,7 @@ import json
 import re
 import sys
 
-ONE_FORM_F32 = ("attn_kv_kernel", "attn_kv_kernel_o3", "attn_kv_wide_kernel", "dense_kernel", "dense_gn_kernel",
+ONE_FORM_F32 = ("attn_kv_kernel", "attn_kv_kernel_o3", "attn_kv_wide_kernel", "dense_kernel", "dense_gn_kernel", "dense_rw_kernel",
                 "tdense_bwd_kernel", "tdense_fwd_kernel", "tstream_fwd_pipe_kernel", "tstream_fwd_kernel", "tstream_bwd_kernel")
 ONE_FORM_BF3 = ("attn_kv_stream32_kernel", "attn_apply_stream64_kernel", "attn_kv_stream128_kernel",
                 "attn_apply_stream128_kernel", "gallery_tail_kernel", "tdense_bwd_bf_kernel")
@@ -54,7 +54,7 @@ def arithmetic_of(k):
         return "bf16x3" if a[2] == "true" else "bf16"
     if base == "attn_kv_stream64_kernel" and len(a) >= 2:
         return "bf16x3" if a[1] == "true" else "f32"
-    if base == "dense_bf_kernel" and len(a) >= 2:
+    if base in ("dense_bf_kernel", "dense_bf_pc_kernel") and len(a) >= 2:
         return "bf16x3" if a[1] == "3" else "bf16"
     if base == "dense_pm_stream_kernel" and len(a) >= 2:
         return "bf16x3" if a[1] == "true" else "bf16"
@@ -111,7 +111,10 @@ KNOWN = {
     "attn_apply[d=64,c1=64,out=64,Lq=128]": ["gallery_tail_kernel", "attn_apply_stream64_kernel<false, 4, 0, 2",
                                              "attn_apply_kernel<2, 1>"],
     "attn_kv[d=64,c2=64,Sk=128]": ["attn_kv_stream64_kernel<true, true, 4", "attn_kv_stream64_kernel<true, false, 4"],
-    "dense_gn[cin=1024,cout=512,L=256]": ["dense_bf_kernel<true, 3, 2", "dense_bf_kernel<true", "dense_kernel<2, true, true"],
+    "dense_gn[cin=1024,cout=512,L=256]": ["dense_bf_pc_kernel<true, 3, 8", "dense_bf_pc_kernel<true", "dense_bf_kernel<true, 3, 2",
+                                          "dense_bf_kernel<true", "dense_kernel<2, true, true"],
+    "dense_max[cin=128,cout=1024,L=256]": ["dense_rw_kernel<16, true", "dense_max_kernel"],
+    "dense[cin=128,cout=1024,L=256]": ["dense_rw_kernel<16, false", "dense_kernel<2, false, false"],
     "dense[cin=512,cout=1024,L=256]": ["dense_bf_kernel<false, 3, 2", "dense_kernel<2, false, true"],
     "tdense_bwd[mode=1,cin=128,cout=128,L=1536]": ["tdense_bwd_bf_kernel", "tdense_bwd_kernel<1, 1, 4, 0, 0>"],
     "tdense_bwd[mode=3,cin=128,cout=128,L=1536]": ["tdense_bwd_bf_kernel", "tdense_bwd_kernel<1, 1, 4, 0, 0>"],
@@ -130,7 +133,26 @@ def map_launches(res, precision, known=KNOWN):
     return l2k
 
 
+def remap(path):
+    """python tools/pmc_summary.py --remap FILE: recompute the arithmetic labels and the launch -> kernel map of an existing
+    summary with THIS file's tables (kernels added after the counters were collected)"""
+    res = json.load(open(path))
+    precision = res.get("_precision", "bf16x3")
+    for k, v in res.items():
+        if isinstance(v, dict) and "launch_us" in v:
+            v["arithmetic"] = arithmetic_of(k)
+    l2k = map_launches(res, precision)
+    for launch, k in l2k.items():
+        if res[k]["arithmetic"] is None and launch.startswith("attn_apply"):
+            res[k]["arithmetic"] = "f32" if precision == "f32" else "bf16x3"
+    res["_launch_to_kernel"] = l2k
+    json.dump(res, open(path, "w"), indent=1)
+    print(json.dumps(l2k, indent=1))
+
+
 def main():
+    if sys.argv[1] == "--remap":
+        return remap(sys.argv[2])
     out, pairs, d_busy, d_fetch, d_write = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
     precision = sys.argv[6] if len(sys.argv) > 6 else "bf16x3"
     busy, fetch, write, dur = counters(d_busy), counters(d_fetch), counters(d_write), durations(d_busy)
