@@ -1446,8 +1446,16 @@ void sa_wsplit_rag_kernel(RagArgs a) {
     const bool have_next = tile + t_step < total;
     const unsigned e_lo = (unsigned)ctab[(size_t)tile * CT], e_hi = (unsigned)ctab[(size_t)tile * CT + 1];
     const int ngr = ctab[(size_t)tile * CT + 2];       // row groups (pairs) in use
-    int4 td_nn = make_int4(0, 0, 0, 0);
-    if (tile + 2 * t_step < total) td_nn = flat[tile + 2 * t_step];
+    // the descriptor of the tile after next.  Its fields are wave-uniform and the compiler turns the load into
+    // `global_load ; s_waitcnt vmcnt(0) ; v_readfirstlane` on the spot -- an exposed L2 round trip at the top of EVERY tile
+    // for values that are needed two tiles later.  They stay in vector registers (the empty asm at the bottom of the loop
+    // is their first use) and move to scalars there, a whole tile after the request.  (Measured: no change of the launch
+    // time -- the other wave of the SIMD covered that wait; kept because it costs nothing.)
+    // (loaded unconditionally from a clamped index: behind an `if` the merge with the zero default is a register copy
+    // right after the load, with the same wait)
+    const int nn_i = tile + 2 * t_step < total ? tile + 2 * t_step : total - 1;
+    const int4 t4 = flat[nn_i];
+    int nn_x = t4.x, nn_y = t4.y, nn_z = t4.z;
     const bf16x8 *x1u = reinterpret_cast<const bf16x8 *>(x1 + par * C * ROWS);
     float *x1n = x1 + (par ^ 1) * C * ROWS;
     // ---- step 1: layer 2 of (cb2, rb2); between its MFMA triples the pair maxima of the previous tile
@@ -1567,7 +1575,9 @@ void sa_wsplit_rag_kernel(RagArgs a) {
 #endif
     td_prev = td_cur;
     td_cur = td_next;
-    td_next = td_nn;
+    asm volatile("" : "+v"(nn_x), "+v"(nn_y), "+v"(nn_z));
+    td_next = make_int4(__builtin_amdgcn_readfirstlane(nn_x), __builtin_amdgcn_readfirstlane(nn_y),
+                        __builtin_amdgcn_readfirstlane(nn_z), 0);
     pe_lo = e_lo;
     pe_hi = e_hi;
     p_ngr = ngr;
