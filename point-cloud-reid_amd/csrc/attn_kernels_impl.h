@@ -183,8 +183,12 @@ __device__ __forceinline__ void attn_kv_body(const AttnArgs &a) {
     else load_tile(XH, RP, feat, c2, c2, p.Sk, t0, T);
     load_xyz3(P, RP, xyz, p.Sk, t0, T);
     __syncthreads();
-    have = vec_ok && t0 + 2 * T <= p.Sk && t0 + T < t_hi;   // the next tile is whole: request it now, store it after this tile's MFMAs
-    if (have) fetch(t0 + T);
+    // the next tile is whole: it is requested AFTER the projection's k-loop (the dense call's hook) and stored at the top of
+    // the next round.  (Requested here, before the projection, it was older than the first refill of the projection's
+    // weight ring -- a wave's vector loads retire in order, so the ring's first wait sat out the whole HBM round trip
+    // and the prefetch overlapped nothing; behind the k-loop it has the epilogue and the KV MFMAs to land.  Explicit wave /
+    // tile splits only: the generic split runs the hook before its k-loop, i.e. as before.)
+    have = vec_ok && t0 + 2 * T <= p.Sk && t0 + T < t_hi;
     pos_hidden(XH + c2 * RP, RP, P, s_w0, s_b0, d, T);
     __syncthreads();
     // (whole-tile epilogue: a 32-cout block is all K or all V, so the branch is wave-uniform)
@@ -202,7 +206,7 @@ __device__ __forceinline__ void attn_kv_body(const AttnArgs &a) {
 #pragma unroll
         for (int r = 0; r < 16; r++) dst[((r & 3) + 8 * (r >> 2)) * RP] = live ? acc[r] / sk : 0.f;
       }
-    }, bkv);   // biases seed the accumulators
+    }, bkv, nullptr, [&]() { if (have) fetch(t0 + T); });   // biases seed the accumulators
     __syncthreads();
     {
       const float *row = KB + krow * RP;
