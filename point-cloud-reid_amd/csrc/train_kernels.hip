@@ -328,6 +328,15 @@ struct TBwd {
 // accumulation) -- dx through tile_dense2p on the f32 tile (operands converted where they are consumed), dW by
 // contracting the tile's 64 tokens in four steps of 16 (A = dy rows of a cout block, B = f(x) rows of the wave's cin
 // block; token k of a step = 16 s + 8 h + j for both operands).
+// (BF kernel) depth of the dx phase's weight ring in 16-channel steps.  tile_dense2p's default of four put the kernel 119
+// registers into scratch -- in the dx k-loop, i.e. in every tile of the step's most expensive launch -- and nobody had
+// looked (`tools/kres.py` lists registers / spills per kernel); two steps: 16 spilled, 0.708 -> 0.604 ms per launch.
+#ifndef PCR_TDBF_DW_UNROLL
+#define PCR_TDBF_DW_UNROLL 4
+#endif
+#ifndef PCR_TDBF_PF
+#define PCR_TDBF_PF 2
+#endif
 template <int WSX, int NRX, int NTW, int QY, int QX, bool BF = false>
 __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
   constexpr int TB = 2, T = kTT, RP = kTRP;
@@ -685,7 +694,7 @@ __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
     if constexpr (BF) {
       // (128 x 128: sixteen dW tiles, item = wave + 4 it -> cout block it, cin block wave)
       if (a.dwp && !(a.dbg & 1)) {
-#pragma unroll
+#pragma unroll PCR_TDBF_DW_UNROLL
         for (int s = 0; s < T / 16; s++) {
           float xb8[8];
           const float *bp = AT + (wave * 32 + l31) * RP + 16 * s + 8 * h;
@@ -725,8 +734,11 @@ __device__ __forceinline__ void tdense_bwd_body(const TBwd &a) {
     if (want_dx && !(a.dbg & 2)) {
       // (the barrier between this call's k-loop and its epilogue also orders the dW reads of DY above before the
       // in-place overwrite)
-      if constexpr (BF)
-        tile_dense2p<1, TB, NRX, WSX>(DY, a.cout, a.wpT_bf, cinP, true, [&](float v, int o, int t) { DY[o * RP + t] = v; });
+      if constexpr (BF) {
+        auto epi_bf = [&](float v, int o, int t) { DY[o * RP + t] = v; };
+        tile_dense_bf_impl<TB, DenseShape<NRX, WSX>::nr, DenseShape<NRX, WSX>::ways, false, 3, decltype(epi_bf), PCR_TDBF_PF>(
+            DY, a.cout, a.wpT_bf, cinP, true, epi_bf);
+      }
       else
       tile_dense2<TB, NRX, WSX>(DY, ceil8(a.cout), a.wpT, cinP, true, [&](float v, int o, int t) { DY[o * RP + t] = v; });
       __syncthreads();
