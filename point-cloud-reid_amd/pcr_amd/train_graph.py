@@ -39,12 +39,40 @@ def _pos(pos_mlp, xyz_cm, add_to):
     return TO.dense(h, pos_mlp[2].weight, pos_mlp[2].bias, res=add_to)
 
 
+def _flat(x):
+    """(B,C,L) -> (1,C,B L): the batch as ONE token axis (a copy)"""
+    B, C, Ln = x.shape
+    return x.permute(1, 0, 2).reshape(1, C, B * Ln)
+
+
+def _unflat(x, B):
+    """(1,C,B L) -> (B,C,L)"""
+    C = x.shape[1]
+    return x.reshape(C, B, -1).permute(1, 0, 2).contiguous()
+
+
+# clouds of at most this many tokens run the per-token layers of an UNFUSED attention block on the flattened batch
+FLAT_TOKENS = 32
+
+
 def self_attention(m, feat, xyz_cm):
     """Self_Attention (pointnet2_utils.py:90-114): q, k, v all project feat + position code"""
     ws = (m.q_proj.weight, m.k_proj.weight, m.v_proj.weight)
     qkv = TO.attn_head(m.pos_mlp, feat, xyz_cm, ws, 7)      # position MLP + the three projections: ONE launch each way
-    if qkv is None:
-        qkv = TO.dense(_pos(m.pos_mlp, xyz_cm, feat), torch.cat(ws, dim=0))
+    if qkv is not None:
+        return _tail(m, TO.LinAttnQKV.apply(qkv, m.nhead, ATTN_EPS, 0), feat, True)
+    B, _, Ln = feat.shape
+    if B > 1 and Ln <= FLAT_TOKENS:
+        # SA3's block (d_model 128: no fused chain) on 32-token clouds: every train-dense launch works on 64-token tiles of
+        # ONE cloud, so half of every tile is padding and every cloud is a workgroup with its own dW partial record (134 MB
+        # of partials for the 256 x 256 layer at 512 clouds).  Everything except the attention core maps a token to a
+        # token: those layers run on the batch flattened to one token axis (full tiles, half the workgroups and partials);
+        # the core gets its (B, 3 d, L) view back.  Five extra copies of 8-25 MB each way.
+        ff, xf = _flat(feat), _flat(xyz_cm)
+        qkv = _unflat(TO.dense(_pos(m.pos_mlp, xf, ff), torch.cat(ws, dim=0)), B)
+        msg = _flat(TO.LinAttnQKV.apply(qkv, m.nhead, ATTN_EPS, 0))
+        return _unflat(_tail(m, msg, ff, True), B)
+    qkv = TO.dense(_pos(m.pos_mlp, xyz_cm, feat), torch.cat(ws, dim=0))
     return _tail(m, TO.LinAttnQKV.apply(qkv, m.nhead, ATTN_EPS, 0), feat, True)
 
 
