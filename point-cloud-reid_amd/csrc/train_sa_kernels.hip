@@ -152,6 +152,12 @@ __global__ __launch_bounds__(kThreads) void sa_l1_fwd_kernel(L1Args a) {
   }
 }
 
+#ifndef PCR_L1_TR
+#define PCR_L1_TR 64
+#endif
+constexpr int kL1Tr = PCR_L1_TR;   // 64 or 128 rows per staged tile of sa_l1_bwd_kernel (round 5, measured: 128 halves the barriers
+                                    // but needs 193 registers -- 0.29 -> 0.41 ms on the K = 48 layers, 0.183 -> 0.164 on K = 32: 64 stays)
+
 struct L1BwdArgs {
   const float *xyz;
   const int *idx;
@@ -166,7 +172,7 @@ struct L1BwdArgs {
 // congruent to `part` modulo the number of parts; rows are visited in increasing order by every owner
 template <int CS>
 __global__ __launch_bounds__(kThreads) void sa_l1_bwd_kernel(L1BwdArgs a) {
-  constexpr int PARTS = kThreads / CS, TR = 64;   // rows per staged tile
+  constexpr int PARTS = kThreads / CS, TR = kL1Tr;   // rows per staged tile
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = a.N, S = a.S, K = a.K, c1 = a.c1, L = S * K;
   const int NP = N | 1, SP = S | 1;            // odd pitches: the lanes of a wave differ in cl, not in i / s
@@ -232,12 +238,13 @@ __global__ __launch_bounds__(kThreads) void sa_l1_bwd_kernel(L1BwdArgs a) {
     // per owner class p: which rows of this tile gather a point congruent to p (one ballot by wave 0): an owner then
     // visits ITS rows only (~1/PARTS of them), in row order
     if (tid < 64) {
-      const int iv = tid < nr ? it[tid] : -1;
 #pragma unroll
-      for (int p = 0; p < PARTS; p++) {
-        const unsigned long long mp = __ballot(iv >= 0 && (iv % PARTS) == p);
-        if (tid == 0) {
-          msk[2 * p] = mp;
+      for (int w64 = 0; w64 < TR / 64; w64++) {
+        const int iv = tid + 64 * w64 < nr ? it[tid + 64 * w64] : -1;
+#pragma unroll
+        for (int p = 0; p < PARTS; p++) {
+          const unsigned long long mp = __ballot(iv >= 0 && (iv % PARTS) == p);
+          if (tid == 0) msk[2 * p + w64] = mp;
         }
       }
     }
@@ -253,11 +260,14 @@ __global__ __launch_bounds__(kThreads) void sa_l1_bwd_kernel(L1BwdArgs a) {
         wb += v;
       }
       if (a.dtab) {
-        unsigned long long m = msk[2 * part];
-        while (m) {
-          const int rr = __builtin_ctzll(m);
-          m &= m - 1;
-          dP[cl * NP + it[rr]] += row[rr];
+#pragma unroll
+        for (int w64 = 0; w64 < TR / 64; w64++) {      // (rows in increasing order: word 0, then word 1)
+          unsigned long long m = msk[2 * part + w64];
+          while (m) {
+            const int rr = __builtin_ctzll(m) + 64 * w64;
+            m &= m - 1;
+            dP[cl * NP + it[rr]] += row[rr];
+          }
         }
         // centre sums: the rows of a centre are CONTIGUOUS (K per centre), so the tile holds at most 64 / K + 2 segments;
         // owner class j mod PARTS adds segment j's rows in a register (independent LDS reads) and touches dQ once.
@@ -464,7 +474,7 @@ PCR_EXPORT int pcr_sa_l1_bwd_f32(const float *xyz, const int *idx, const float *
   if (cs > 32) cs = 32;
   L1BwdArgs a{xyz, idx, g, y, ka, kb, kc, dtab, dwa, N, S, K, c1, cs};
   const int parts = kThreads / cs;
-  const size_t lds = ((dtab ? (size_t)cs * ((N | 1) + (S | 1)) : 0) + 3 * (size_t)N + (size_t)cs * 65 + 3 * 64 + 2 * 64 +
+  const size_t lds = ((dtab ? (size_t)cs * ((N | 1) + (S | 1)) : 0) + 3 * (size_t)N + (size_t)cs * (kL1Tr + 1) + 3 * kL1Tr + 2 * kL1Tr +
                       (size_t)parts * cs * 4 + 4 * (size_t)parts + 2) * sizeof(float);
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
   const dim3 grid((c1 + cs - 1) / cs, B);
