@@ -91,6 +91,38 @@ __device__ __forceinline__ void attn_kv_fold_write(const pcr_attn_params &p, con
   if (tid < d) kv[(size_t)d * d + tid] = s_kt[tid];
 }
 
+// The same fold on the matrix core (round 5): per head, M[:, head] = Wm[:, head] KV_head^T is a dense call over k = v with
+// the head's k-blocks of the packed merge weights (p.wmerge_packed) as the A operand and the TRANSPOSED KV tile in LDS as
+// the B operand (KVt [v][ld], token = dd).  The scalar loop above costs every thread d d / 256 dot products of dh terms
+// whose weights it fetches from global memory one float at a time -- 40-100 us per cloud at d = 128, the larger part of
+// the tile kernel's launch (pt128: one 32-token tile per cloud and 0.27 ms; pt1024: a third of 0.72 ms) -- against ~4 us of
+// MFMAs.  Heads of whole 32-channel blocks only (the caller falls back otherwise); the k-steps run in the loop's order.
+__device__ __forceinline__ void attn_kv_fold_mfma(const pcr_attn_params &p, const float *KVt, const float *s_kt, size_t b) {
+  const int d = p.d, dh = d / p.nhead, ld = d + 1, tid = threadIdx.x;
+  float *kv = p.kv + b * ((size_t)d * d + d);
+  for (int hd = 0; hd < p.nhead; hd++) {
+    const float *wm = p.wmerge_packed + (size_t)(hd * dh / 8) * d * 8;
+    tile_dense(KVt + (size_t)(hd * dh) * ld + hd * dh, dh, ld, dh >> 5, wm, d, [&](float m, int o, int t) {
+      const int dd = hd * dh + t;
+      if constexpr (kAPrec == 0) {
+        const int kb = dd >> 3, rem = dd & 7;
+        kv[(((size_t)kb * d + o) * 2 + (rem & 1)) * 4 + (rem >> 1)] = m;
+      } else {
+        const int s16 = dd >> 4, kk = dd & 15;
+        const int hh = (kk >> 2) & 1, jj = (kk & 3) + ((kk >> 3) << 2);
+        const size_t unit = (((size_t)s16 * (d >> 5) + (o >> 5)) * 2) * 64 + hh * 32 + (o & 31);
+        const __bf16 hi = (__bf16)m;
+        const __bf16 lo = (__bf16)(m - (float)hi);
+        __bf16 *img = reinterpret_cast<__bf16 *>(kv);
+        img[unit * 8 + jj] = hi;
+        img[(unit + 64) * 8 + jj] = lo;
+      }
+    });
+  }
+  __syncthreads();
+  if (tid < d) kv[(size_t)d * d + tid] = s_kt[tid];
+}
+
 // One workgroup per key-side cloud, token tiles of T = 32*TB (TB = 2 for d <= 64, 1 for d = 128).
 // kv image per cloud: packed (d x d) matrix M (merge folded in, see above) followed by ksum[d].
 // LDS: XH [c2 + d] key features ; hidden -- the fused K/V projection (2d <= c2 + d rows) is written IN PLACE over
@@ -250,6 +282,7 @@ __device__ __forceinline__ void attn_kv_body(const AttnArgs &a) {
   // KV (head-masked) -> LDS [dd][d+1], then fold the merge projection and write the packed image
   float *KVl = smem;
   const int ld = d + 1;
+  const bool mfma_fold = p.wmerge_packed != nullptr && (dh & 31) == 0 && (d & 31) == 0;
   float *s_kt = smem + d * ld;   // [d] total key sums
   s_ks[tid] = ksum;
 #pragma unroll
@@ -265,7 +298,8 @@ __device__ __forceinline__ void attn_kv_body(const AttnArgs &a) {
       for (int r = 0; r < 16; r++) {
         const int dd = ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const bool same = aligned ? same_blk : (dd / dh == hv);
-        KVl[dd * ld + v] = same ? acc[it][r] : 0.f;
+        if (mfma_fold) KVl[v * ld + dd] = same ? acc[it][r] : 0.f;     // (transposed: the fold's B operand)
+        else KVl[dd * ld + v] = same ? acc[it][r] : 0.f;
       }
     }
   }
@@ -275,7 +309,8 @@ __device__ __forceinline__ void attn_kv_body(const AttnArgs &a) {
     for (int pp = 0; pp < kparts; pp++) s += s_ks[pp * d + tid];
     s_kt[tid] = s;
   }
-  attn_kv_fold_write(p, KVl, s_kt, b);
+  if (mfma_fold) attn_kv_fold_mfma(p, KVl, s_kt, b);
+  else attn_kv_fold_write(p, KVl, s_kt, b);
 }
 
 template <int TB, int NR, int WSEL, int NTW>
@@ -286,6 +321,11 @@ __global__ __launch_bounds__(kThreads) void attn_kv_kernel(AttnArgs a) {
 // where it costs a few spilled registers, not for d = 32 (already three per CU on its own)
 template <int TB, int NR, int WSEL, int NTW>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_kv_kernel_o3(AttnArgs a) {
+  attn_kv_body<TB, NR, WSEL, NTW>(a);
+}
+// ... and to half of it: the d = 128 shape, whose LDS allows two workgroups per CU and no more
+template <int TB, int NR, int WSEL, int NTW>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_kv_kernel_o2(AttnArgs a) {
   attn_kv_body<TB, NR, WSEL, NTW>(a);
 }
 
@@ -1587,7 +1627,14 @@ static int attn_kv_narrow(const pcr_attn_params *pp, pcr_stream_t stream) {
   pcr_note_arith(PCR_PREC_F32);   // the tile kernel projects in f32 in both units (only the form of M differs)
   if (d == 32) hipLaunchKernelGGL((attn_kv_kernel<2, 1, 2, 1>), g, blk, lds, st, a);        // 2d = 64: two cout blocks
   else if (d == 64) hipLaunchKernelGGL((attn_kv_kernel_o3<2, 1, 1, 1>), g, blk, lds, st, a);   // four, one per wave
-  else if (d == 128) hipLaunchKernelGGL((attn_kv_kernel_o3<1, 2, 1, 4>), g, blk, lds, st, a);  // eight, two rounds
+  else if (d == 128) {
+    // eight cout blocks, two rounds.  NOT the three-workgroups-per-CU form: this shape's fold buffer (d (d + 1) floats =
+    // 66 KB) allows two workgroups per CU whatever the registers say, and held to a third of the register file the body
+    // spilled 93 registers inside its tile loop for nothing (round 5, tools/kres.py)
+    static bool ok2 = allow_big_lds(attn_kv_kernel_o2<1, 2, 1, 4>);
+    (void)ok2;
+    hipLaunchKernelGGL((attn_kv_kernel_o2<1, 2, 1, 4>), g, blk, lds, st, a);
+  }
   else hipLaunchKernelGGL((attn_kv_kernel<1, 2, 0, 4>), g, blk, lds, st, a);                // d = 96: generic shape
   PCR_CHECK_LAUNCH();
   if (ns > 1) {

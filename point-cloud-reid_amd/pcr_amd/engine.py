@@ -419,6 +419,10 @@ class AttnPlan:
             ln1_g=_dev32(m.norm1.weight, device), ln1_b=_dev32(m.norm1.bias, device),
             ln2_g=_dev32(m.norm2.weight, device), ln2_b=_dev32(m.norm2.bias, device))
         if d <= 128:
+            if d % 32 == 0 and (d // nhead) % 32 == 0:
+                # the tile kv kernel folds the merge projection on the matrix core from this image (heads of whole
+                # 32-channel blocks; else its scalar loop)
+                self.t["wmerge_packed"] = pack_weight(m.merge.weight, device)
             # the same matrices as bf16 hi / lo images: the dense phases of both kernels in "bf16x3" / "bf16" mode
             if (d == 64 and self.c2 in (64, 128)) or (d == 32 and self.c2 == 32):   # the wave-autonomous kv kernels' shapes
                 self.t["wkv_bf"] = pack_weight_bf(wkv.float(), device)
