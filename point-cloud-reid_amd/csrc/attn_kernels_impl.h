@@ -129,7 +129,8 @@ __device__ __forceinline__ void attn_kv_fold_mfma(const pcr_attn_params &p, cons
 // it (barrier between k-loop and epilogue) -- and P [3]; after the loop KVl [d][d+1].  34 KB at d = c2 = 64, so four
 // workgroups share a CU; the next tile's features are fetched into registers while this tile is on the matrix core.
 //   WSEL: dense shape of the 2d-row projection (2 / 1 / 1 for d = 32 / 64 / 128), NTW: KV tiles per wave (1 / 1 / 4)
-template <int TB, int NR, int WSEL, int NTW>
+// BFP (bf unit only): the K / V projection as split bf16 on the wkv_bf image (the caller checks it is there)
+template <int TB, int NR, int WSEL, int NTW, bool BFP = false>
 __device__ __forceinline__ void attn_kv_body(const AttnArgs &a) {
   constexpr int T = 32 * TB, RP = T + 1;
   constexpr int NPF = 4;   // 16-byte feature pieces per thread and tile held in registers (c2 * T / 4 / 256 <= NPF)
@@ -226,8 +227,7 @@ __device__ __forceinline__ void attn_kv_body(const AttnArgs &a) {
     // (whole-tile epilogue: a 32-cout block is all K or all V, so the branch is wave-uniform)
     // (f32-input MFMA in both units: this kernel is one workgroup per cloud walking its token tiles serially -- latency,
     // not the matrix pipe, bounds it, and the bf16 form's operand conversion measured 0-15 % SLOWER here)
-    tile_dense2<TB, NR, WSEL, true>(XH, c2 + d, p.wkv, 2 * d, true,
-                                    [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
+    auto kv_epi = [&](const f32x16 &acc, int cb, int tb, int l31, int h) {
       const int t = tb * 32 + l31;
       float *dst = XH + (cb * 32 + 4 * h) * RP + t;
       const bool live = t < valid;
@@ -238,7 +238,15 @@ __device__ __forceinline__ void attn_kv_body(const AttnArgs &a) {
 #pragma unroll
         for (int r = 0; r < 16; r++) dst[((r & 3) + 8 * (r >> 2)) * RP] = live ? acc[r] / sk : 0.f;
       }
-    }, bkv, nullptr, [&]() { if (have) fetch(t0 + T); });   // biases seed the accumulators
+    };
+    auto kv_hook = [&]() { if (have) fetch(t0 + T); };
+    // (biases seed the accumulators.  Round 5: with the fold on the matrix core and the prefetch behind the k-loop the
+    // projection's 256 f32 MFMAs of 64 cycles per wave and tile ARE the tile's time for long key sets, so the bf unit runs
+    // them as split bf16 like the streaming kernels do -- explicit wave / tile splits, wkv_bf given)
+    if constexpr (BFP && kAPrec != 0 && WSEL != 0)
+      tile_dense2p<kAPrec, TB, NR, WSEL, true>(XH, c2 + d, p.wkv_bf, 2 * d, true, kv_epi, bkv, nullptr, kv_hook);
+    else
+      tile_dense2<TB, NR, WSEL, true>(XH, c2 + d, p.wkv, 2 * d, true, kv_epi, bkv, nullptr, kv_hook);
     __syncthreads();
     {
       const float *row = KB + krow * RP;
@@ -324,9 +332,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3))
   attn_kv_body<TB, NR, WSEL, NTW>(a);
 }
 // ... and to half of it: the d = 128 shape, whose LDS allows two workgroups per CU and no more
-template <int TB, int NR, int WSEL, int NTW>
+template <int TB, int NR, int WSEL, int NTW, bool BFP = false>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_kv_kernel_o2(AttnArgs a) {
-  attn_kv_body<TB, NR, WSEL, NTW>(a);
+  attn_kv_body<TB, NR, WSEL, NTW, BFP>(a);
 }
 
 // ---- wave-autonomous form for d = c2 = 64 (the shape of six of pt1024's eight kv launches, of every gallery / SSG kv
@@ -1631,9 +1639,13 @@ static int attn_kv_narrow(const pcr_attn_params *pp, pcr_stream_t stream) {
     // eight cout blocks, two rounds.  NOT the three-workgroups-per-CU form: this shape's fold buffer (d (d + 1) floats =
     // 66 KB) allows two workgroups per CU whatever the registers say, and held to a third of the register file the body
     // spilled 93 registers inside its tile loop for nothing (round 5, tools/kres.py)
-    static bool ok2 = allow_big_lds(attn_kv_kernel_o2<1, 2, 1, 4>);
+    static bool ok2 = allow_big_lds(attn_kv_kernel_o2<1, 2, 1, 4>) && allow_big_lds(attn_kv_kernel_o2<1, 2, 1, 4, true>);
     (void)ok2;
-    hipLaunchKernelGGL((attn_kv_kernel_o2<1, 2, 1, 4>), g, blk, lds, st, a);
+    // (split-bf16 projection for key sets of >= 256 tokens -- a shape-only rule: the KV state is a mean over the key
+    // tokens, so the projection's rounding averages out with their number; at Sk = 32 (the Point-Transformer @128) the
+    // guard's sweep of tests/test_gpu_precision.py went from 4.5e-5 to 5.2e-5 with it, for 0.014 ms)
+    if (kBfUnit && pp->wkv_bf && pp->Sk >= 256) hipLaunchKernelGGL((attn_kv_kernel_o2<1, 2, 1, 4, true>), g, blk, lds, st, a);
+    else hipLaunchKernelGGL((attn_kv_kernel_o2<1, 2, 1, 4>), g, blk, lds, st, a);
   }
   else hipLaunchKernelGGL((attn_kv_kernel<1, 2, 0, 4>), g, blk, lds, st, a);                // d = 96: generic shape
   PCR_CHECK_LAUNCH();

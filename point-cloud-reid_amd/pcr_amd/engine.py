@@ -424,7 +424,7 @@ class AttnPlan:
                 # 32-channel blocks; else its scalar loop)
                 self.t["wmerge_packed"] = pack_weight(m.merge.weight, device)
             # the same matrices as bf16 hi / lo images: the dense phases of both kernels in "bf16x3" / "bf16" mode
-            if (d == 64 and self.c2 in (64, 128)) or (d == 32 and self.c2 == 32):   # the wave-autonomous kv kernels' shapes
+            if (d == 64 and self.c2 in (64, 128)) or (d == 32 and self.c2 == 32) or d == 128:   # the wave-autonomous kv kernels' shapes; d = 128: the tile kernel's projection
                 self.t["wkv_bf"] = pack_weight_bf(wkv.float(), device)
             if d == 64 and self.c1 % 16:        # c1 = 3: mlp[0] with the feature columns padded to a 16-channel step
                 w0 = m.mlp[0].weight.detach().float().cpu()
