@@ -23,7 +23,7 @@ import json
 import re
 import sys
 
-ONE_FORM_F32 = ("attn_kv_kernel", "attn_kv_kernel_o3", "attn_kv_wide_kernel", "dense_kernel", "dense_gn_kernel", "dense_rw_kernel",
+ONE_FORM_F32 = ("attn_kv_kernel", "attn_kv_kernel_o3", "attn_kv_kernel_o2", "attn_kv_wide_kernel", "dense_kernel", "dense_gn_kernel", "dense_rw_kernel",
                 "tdense_bwd_kernel", "tdense_fwd_kernel", "tstream_fwd_pipe_kernel", "tstream_fwd_kernel", "tstream_bwd_kernel")
 ONE_FORM_BF3 = ("attn_kv_stream32_kernel", "attn_apply_stream64_kernel", "attn_kv_stream128_kernel",
                 "attn_apply_stream128_kernel", "gallery_tail_kernel", "tdense_bwd_bf_kernel")
@@ -102,7 +102,8 @@ KNOWN = {
     "sa_fused[D=0,c=32/32/32,N=1024,S=1024,K=32]": ["sa_stream_kernel<1, 1", "sa_fused_kernel<4, 1, 4, 4, true, 1,"],
     "attn_apply[d=64,c1=64,out=64,Lq=1024]": ["attn_apply_stream64_kernel<true, 4, 0", "attn_apply_kernel<2, 1>"],
     "attn_kv[d=64,c2=64,Sk=1024]": ["attn_kv_stream64_kernel<true, true, 4", "attn_kv_stream64_kernel<true, false, 4"],
-    "attn_kv[d=128,c2=128,Sk=256]": ["attn_kv_stream128_kernel", "attn_kv_kernel_o3<1, 2, 1, 4>"],
+    "attn_kv[d=128,c2=128,Sk=256]": ["attn_kv_stream128_kernel", "attn_kv_kernel_o2<1, 2, 1, 4", "attn_kv_kernel_o3<1, 2, 1, 4>"],
+    "attn_kv[d=128,c2=128,Sk=1024]": ["attn_kv_kernel_o2<1, 2, 1, 4", "attn_kv_kernel_o3<1, 2, 1, 4>"],
     "attn_apply[d=128,c1=128,out=128,Lq=256]": ["attn_apply_stream128_kernel", "attn_apply_kernel<1, 2>"],
     "knn_prefix[N=1024,S=1024,K=32]": ["knn_prefix_reg_kernel<8>"],
     # pt4096 / gallery128 / pointnet256
