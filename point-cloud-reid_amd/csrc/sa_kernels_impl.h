@@ -1933,6 +1933,60 @@ __global__ __launch_bounds__(kThreads) void dense_pm_kernel(DensePmArgs a) {
   }
 }
 
+// The same tables for POINT-major input on the bf16 matrix core, cin = 16 NPI in {32, 64, 128}, cout = 16 NPO in {64, 128},
+// whole 64-token tiles of the flattened (B L) token axis (round 5).  dense_pm_kernel is a one-shot workgroup per tile:
+// 32 KB in, 32 KB out and the 64 KB weight image streamed from L2 behind every tile, its load -> k-loop -> store phases
+// end to end with nothing of the next tile in flight (ssg1024's SA2 table: 2.1 GB in 0.88 ms).  Here a PERSISTENT
+// workgroup keeps every step of its waves' weight rows in registers (tile_dense_bf_impl's RES ring: 8 steps x hi / lo =
+// 64 VGPRs), so the k-loop issues no vector-memory load at all -- which is what lets the NEXT tile's rows, requested
+// into registers before the k-loop, arrive behind it (a wave's loads retire in order: with a weight ring in the loop
+// the first refill would wait for them).  Same per-tile arithmetic in the same order: bit-identical to dense_pm_kernel.
+template <int NS, int NPI, int NPO>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NPI == 8 ? 2 : 4, NPI == 8 ? 2 : 4)))
+void dense_pm_res_kernel(DensePmArgs a, long ntile) {
+  constexpr int TB = 2, T = 64, RP = 65, PF = 8;
+  constexpr int CIN = 16 * NPI, COUT = 16 * NPO, Q = CIN / 4, Q2 = COUT / 4;
+  constexpr int LQ = NPI == 8 ? 5 : (NPI == 4 ? 4 : 3), LQ2 = NPO == 8 ? 5 : 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *X = smem;   // [max(CIN, COUT)][RP]
+  const int tid = threadIdx.x;
+  BfRing<PF, 1> ring;
+  bf_ring_load<1, 1, PF, NS>(a.wp, CIN, ceil32(COUT), ring);
+  const int tq = tid >> LQ, q = tid & (Q - 1);          // piece u of a thread: token tq + u (256 / Q), channel quad q
+  const int tq2 = tid >> LQ2, q2 = tid & (Q2 - 1);
+  f32x4 v[NPI];
+  auto request = [&](long tile) __attribute__((always_inline)) {
+    const float *src = a.x + ((size_t)tile * T + tq) * CIN + 4 * q;
+#pragma unroll
+    for (int u = 0; u < NPI; u++) v[u] = *reinterpret_cast<const f32x4 *>(src + (size_t)u * (kThreads / Q) * CIN);
+  };
+  auto epi = [&](float r, int o, int t) { X[o * RP + t] = r; };
+  long tile = blockIdx.x;
+  if (tile < ntile) request(tile);
+  for (; tile < ntile; tile += gridDim.x) {
+#pragma unroll
+    for (int u = 0; u < NPI; u++) {
+      float *d = X + 4 * q * RP + tq + u * (kThreads / Q);
+      d[0] = v[u][0];
+      d[RP] = v[u][1];
+      d[2 * RP] = v[u][2];
+      d[3 * RP] = v[u][3];
+    }
+    if (tile + gridDim.x < ntile) request(tile + gridDim.x);
+    __syncthreads();
+    tile_dense_bf_impl<TB, 1, 1, false, NS, decltype(epi), PF, DenseNoHook, false, true>(
+        X, CIN, a.wp, ceil32(COUT), true, epi, nullptr, DenseNoHook(), 0, &ring);
+    __syncthreads();
+    float *out = a.y + ((size_t)tile * T + tq2) * COUT + 4 * q2;
+#pragma unroll
+    for (int u = 0; u < NPO; u++) {
+      const float *xs = X + 4 * q2 * RP + tq2 + u * (kThreads / Q2);
+      *reinterpret_cast<f32x4 *>(out + (size_t)u * (kThreads / Q2) * COUT) = f32x4{xs[0], xs[RP], xs[2 * RP], xs[3 * RP]};
+    }
+    __syncthreads();
+  }
+}
+
 #endif   // PCR_SA_PREC == 0 (table kernel)
 
 }  // namespace
@@ -2454,6 +2508,46 @@ static int dense_pm_launch(const float *x, const float *wp, float *y, int B, int
   if (B > 65535) return PCR_ERR_INVALID;
   pcr_note_arith(precision);
   DensePmArgs d{x, wp, y, cin, cout, L, x_point_major};
+  {
+    // point-major in and out, whole tiles, the weight rows of a wave in registers: the persistent form (shape-only choice)
+    static const int no_res = pcr_tune_int("PCR_DENSE_PM_NO_RES");   // diagnostics
+    const long ntok = (long)B * L;
+    if (!no_res && precision != 0 && x_point_major && (cin == 32 || cin == 64 || cin == 128) && (cout == 64 || cout == 128) &&
+        ntok % 64 == 0 && (reinterpret_cast<size_t>(x) & 15) == 0 && (reinterpret_cast<size_t>(y) & 15) == 0) {
+      static const int ncu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+          n = 256;
+        return n;
+      }();
+      const long ntile = ntok / 64;
+      const long res = (long)ncu * (cin == 128 ? 2 : 4);   // (the kernel's registers: two or four workgroups per CU)
+      const long wgs = ntile < res ? ntile : res;
+      const size_t lds_r = (size_t)(cin > cout ? cin : cout) * 65 * sizeof(float);
+#define PCR_PMR(NSv, NPIv, NPOv)                                                                      \
+  hipLaunchKernelGGL((dense_pm_res_kernel<NSv, NPIv, NPOv>), dim3((unsigned)wgs), dim3(kThreads), lds_r, \
+                     pcr_s(stream), d, ntile)
+#define PCR_PMR_O(NSv, NPIv)                             \
+  do {                                                   \
+    if (cout == 128) PCR_PMR(NSv, NPIv, 8);              \
+    else PCR_PMR(NSv, NPIv, 4);                          \
+  } while (0)
+#define PCR_PMR_I(NSv)                                   \
+  do {                                                   \
+    if (cin == 128) PCR_PMR_O(NSv, 8);                   \
+    else if (cin == 64) PCR_PMR_O(NSv, 4);               \
+    else PCR_PMR_O(NSv, 2);                              \
+  } while (0)
+      if (precision == 1) PCR_PMR_I(3);
+      else PCR_PMR_I(1);
+#undef PCR_PMR_I
+#undef PCR_PMR_O
+#undef PCR_PMR
+      PCR_CHECK_LAUNCH();
+      return PCR_OK;
+    }
+  }
   const int wmax = cout < 256 ? cout : 256;
   const int rows = ceil8(cin) > ceil32(wmax) ? ceil8(cin) : ceil32(wmax);
   size_t lds = (size_t)rows * 65 * sizeof(float);

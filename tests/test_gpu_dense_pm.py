@@ -53,3 +53,34 @@ def test_unsupported_shapes_keep_the_f32_launch():
     assert lib.pcr_dense_xpm_prec_ok(256, 160, 128) == 0        # more than four cout blocks
     assert lib.pcr_dense_xpm_prec_ok(2048, 128, 128) == 0       # weight image beyond LDS
     assert lib.pcr_dense_xpm_prec_ok(512, 64, 1) == 1
+
+
+@pytest.mark.parametrize("B,cin,cout,L", [(6, 128, 128, 256), (4, 32, 128, 64), (3, 64, 64, 128), (2, 128, 64, 96), (1, 64, 128, 4096)])
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+def test_layer1_tables_persistent_kernel_equals_the_tile_kernel_bit_for_bit(B, cin, cout, L, prec):
+    """pcr_dense_pm_prec_f32 (the per-point tables of a set-abstraction layer's decomposed first conv) with point-major
+    input: token counts B L that are whole 64-token tiles run dense_pm_res_kernel (round 5: persistent workgroups, weight
+    rows resident in registers, the next tile requested behind the k-loop), any other count the one-shot tile kernel.
+    A table row is a function of its own token and both kernels walk the 16-channel steps in the same order: the rows of
+    a batch cut to a token count that is no multiple of 64 must carry the same bits.  And both stay on torch fp64."""
+    from pcr_amd import engine as E, _lib as Lb
+    g = torch.Generator().manual_seed(B + cin + cout + L)
+    x = torch.randn(B, L, cin, generator=g).cuda()
+    w = torch.randn(cout, cin, generator=g) / cin ** 0.5
+    wp = E.pack_weight_bf(w, torch.device("cuda"))
+    lib = Lb.load()
+
+    def table(xs):
+        b, l, _ = xs.shape
+        y = torch.full((b, l, cout), float("nan"), device="cuda")
+        Lb.check(lib.pcr_dense_pm_prec_f32(Lb.ptr(xs), Lb.ptr(wp), Lb.ptr(y), b, cin, cout, l, 1, E.PRECISIONS[prec],
+                                           Lb.stream_ptr()), "pcr_dense_pm_prec_f32")
+        return y
+
+    full = table(x)
+    assert (B * L) % 64 == 0 and (B * (L - 8)) % 64 != 0
+    part = table(x[:, :L - 8].contiguous())
+    assert torch.equal(full[:, :L - 8], part)
+    ref = torch.einsum("oc,blc->blo", w.double().cuda(), x.double())
+    tol = 2e-5 if prec == "bf16x3" else 2e-2
+    assert float((full.double() - ref).abs().max()) / float(ref.abs().max()) < tol

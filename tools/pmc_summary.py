@@ -50,6 +50,8 @@ def arithmetic_of(k):
         return prec.get(a[7])
     if base == "dense_pm_kernel" and len(a) >= 2:
         return prec.get(a[1])
+    if base == "dense_pm_res_kernel" and len(a) >= 1:
+        return "bf16x3" if a[0] == "3" else "bf16"
     if base in ("sa_stream_kernel", "sa_stream_rag_kernel", "sa_wsplit_rag_kernel") and len(a) >= 3:
         return "bf16x3" if a[2] == "true" else "bf16"
     if base == "attn_kv_stream64_kernel" and len(a) >= 2:
@@ -92,7 +94,7 @@ def durations(d):
 KNOWN = {
     "sa_ragged[D=128,c=128/128/256,N=512,S=128,K=64]": ["sa_wsplit_rag_kernel<", "sa_rag_kernel<2, 2, 1, 1, 1, 1"],
     "sa_ragged[D=0,c=64/64/128,N=1024,S=512,K=32]": ["sa_stream_rag_kernel<2, 4", "sa_rag_kernel<4, 1, 2, 1, 1, 2"],
-    "sa_tables[D=128,out=128,N=512]": ["dense_pm_kernel<1,"],
+    "sa_tables[D=128,out=128,N=512]": ["dense_pm_res_kernel<", "dense_pm_kernel<1,"],
     "dense[cin=256,cout=64,L=128]": ["dense_pm_stream_kernel<2", "dense_kernel<2, false, false"],
     "fps[N=1024,M=512]": ["fps_pair_kernel<", "fps_wave_kernel<8"],
     "ball_query[N=1024,M=512,K=32]": ["ball_query_rows_kernel<16", "ball_query_reg_kernel<16"],
