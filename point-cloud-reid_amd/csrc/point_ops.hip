@@ -258,8 +258,40 @@ __device__ __forceinline__ uint32_t dpp_max_u32(uint32_t v) {
   return ab > cd ? ab : cd;
 }
 
+// Which of a lane's NS slots hold the wave maximum `best`?  Every lane shifts one compare per slot into a private word
+// (v_cmp_eq + v_addc_co: word = 2 word + carry, slot p ends up at bit NS - 1 - p) and ONE v_readlane takes lane L's word
+// to the scalar side: 2 NS vector + 3 scalar instructions.  (Before: a ballot per slot and a scalar bit test of each mask
+// -- 85 scalar instructions per pick of a 1024-point cloud, more than its distance arithmetic; a wave's scalar and
+// vector instructions share its issue slots)
+template <int NS>
+__device__ __forceinline__ uint32_t fps_slot_bits(const uint32_t (&t)[NS], uint32_t best, int L) {
+  static_assert(NS % 2 == 0, "slots come in pairs");
+  uint32_t w = 0u;
+  // (one asm statement per group of slots: the compiler pads every statement's end with an s_nop)
+#define PCR_SB1(a) "v_cmp_eq_u32 vcc, %[b], %[" #a "]\n\tv_addc_co_u32 %[w], vcc, %[w], %[w], vcc\n\t"
+  if constexpr (NS % 8 == 0) {
+#pragma unroll
+    for (int p = 0; p < NS; p += 8)
+      asm(PCR_SB1(t0) PCR_SB1(t1) PCR_SB1(t2) PCR_SB1(t3) PCR_SB1(t4) PCR_SB1(t5) PCR_SB1(t6) PCR_SB1(t7)
+          : [w] "+v"(w)
+          : [b] "v"(best), [t0] "v"(t[p]), [t1] "v"(t[p + 1]), [t2] "v"(t[p + 2]), [t3] "v"(t[p + 3]), [t4] "v"(t[p + 4]),
+            [t5] "v"(t[p + 5]), [t6] "v"(t[p + 6]), [t7] "v"(t[p + 7])
+          : "vcc");
+  } else {
+#pragma unroll
+    for (int p = 0; p < NS; p += 2)
+      asm(PCR_SB1(t0) PCR_SB1(t1) : [w] "+v"(w) : [b] "v"(best), [t0] "v"(t[p]), [t1] "v"(t[p + 1]) : "vcc");
+  }
+#undef PCR_SB1
+  return (uint32_t)__builtin_amdgcn_readlane((int)w, L);
+}
+
 // The picked point's coordinates come straight out of the register file: the pick `old` is wave-uniform, so its slot
-// (old / 64) selects a register by a SCALAR switch and v_readlane fetches lane old % 64 of it.  (Round 2 kept a
+// (old / 64) selects a REGISTER -- a wave-uniform dynamic index into the per-axis vector of a lane's coordinates, which
+// the compiler turns into relative register addressing (s_set_gpr_idx_on + v_mov_b32) -- and v_readlane fetches lane
+// old % 64 of it: ~12 instructions, no branch.  (Rounds 2-4, and still for clouds of <= 512 points: a scalar `switch` over
+// the slot, which the structuriser compiles into a chain of fall-through flags -- ~35 scalar instructions and eight
+// branches per pick of a 1024-point cloud.)  (Round 2 kept a
 // {x,y,z,-} copy of the cloud in LDS for one broadcast read per pick: 16 KB per wave, which held a CU to ten waves --
 // 2.5 per SIMD, 4096 clouds = 1.6 rounds -- and put an LDS round trip on every pick's critical path; without it four
 // waves share a SIMD and the chip takes 4096 clouds in one round.)
@@ -273,7 +305,14 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(const float *__restrict__ 
   idxs += cloud * m;
   // the running minimum distances are kept as BITS: for floats >= +0 the unsigned order of the bit
   // patterns is the float order, and integer min / max need no NaN canonicalisation instructions
-  f32x2 px[PP], py[PP], pz[PP];
+  // a lane's coordinates as ONE vector per axis: slot p = element p (pairs (2 p, 2 p + 1) feed the packed arithmetic; the
+  // pick reads element `slot` with a wave-uniform DYNAMIC index, i.e. relative register addressing, see fps_pick_coord)
+  typedef float fvec __attribute__((ext_vector_type(2 * PP)));
+  fvec vx, vy, vz;
+  // the vector forms of the slot search and of the coordinate fetch move ~100 scalar instructions per pick of a
+  // 1024-point cloud to ~40 vector ones; clouds of <= 512 points have half the slots, run at higher occupancy (scalar
+  // and vector instructions of different waves issue side by side) and are faster with the scalar forms (measured)
+  constexpr bool kVecPick = PP >= 8;
   uint32_t t[2 * PP], low[2 * PP];
 #pragma unroll
   for (int p = 0; p < 2 * PP; p++) {
@@ -281,9 +320,9 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(const float *__restrict__ 
     const bool ok = k < n;
     const float *q = xyz + (size_t)(ok ? k : 0) * 3;
     const float x = q[0], y = q[1], z = q[2], tk = temp[ok ? k : 0];
-    px[p >> 1][p & 1] = ok ? x : 0.f;
-    py[p >> 1][p & 1] = ok ? y : 0.f;
-    pz[p >> 1][p & 1] = ok ? z : 0.f;
+    vx[p] = ok ? x : 0.f;
+    vy[p] = ok ? y : 0.f;
+    vz[p] = ok ? z : 0.f;
     t[p] = ok ? __float_as_uint(tk) : 0u;   // min(d, 0) = 0: a point beyond n never beats a real one (low = 0)
     const uint32_t tr = (uint32_t)k & (uint32_t)(block - 1);
     const uint32_t rev = logb ? (__brev(tr) >> (32 - logb)) : 0u;
@@ -295,26 +334,32 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(const float *__restrict__ 
   for (int j = 1; j < m; j++) {
     const int slot = __builtin_amdgcn_readfirstlane(old >> 6), ln = __builtin_amdgcn_readfirstlane(old & 63);
     float ox = 0.f, oy = 0.f, oz = 0.f;
-#define PCR_FPS_PICK(P)                                                                                      \
-  case P:                                                                                                    \
-    if constexpr (P < 2 * PP) {                                                                              \
-      ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px[(P) >> 1][(P)&1]), ln));               \
-      oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py[(P) >> 1][(P)&1]), ln));               \
-      oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[(P) >> 1][(P)&1]), ln));               \
-    }                                                                                                        \
+    if constexpr (kVecPick) {
+      ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vx[slot]), ln));
+      oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vy[slot]), ln));
+      oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vz[slot]), ln));
+    } else {
+#define PCR_FPS_PICK(P)                                                               \
+  case P:                                                                             \
+    if constexpr (P < 2 * PP) {                                                       \
+      ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vx[P]), ln));      \
+      oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vy[P]), ln));      \
+      oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vz[P]), ln));      \
+    }                                                                                 \
     break;
-    switch (slot) {
-      PCR_FPS_PICK(0) PCR_FPS_PICK(1) PCR_FPS_PICK(2) PCR_FPS_PICK(3) PCR_FPS_PICK(4) PCR_FPS_PICK(5) PCR_FPS_PICK(6)
-      PCR_FPS_PICK(7) PCR_FPS_PICK(8) PCR_FPS_PICK(9) PCR_FPS_PICK(10) PCR_FPS_PICK(11) PCR_FPS_PICK(12) PCR_FPS_PICK(13)
-      PCR_FPS_PICK(14) PCR_FPS_PICK(15)
-      default: break;
-    }
+      switch (slot) {
+        PCR_FPS_PICK(0) PCR_FPS_PICK(1) PCR_FPS_PICK(2) PCR_FPS_PICK(3) PCR_FPS_PICK(4) PCR_FPS_PICK(5) PCR_FPS_PICK(6)
+        PCR_FPS_PICK(7)
+        default: break;
+      }
 #undef PCR_FPS_PICK
+    }
     const f32x2 x1 = {ox, ox}, y1 = {oy, oy}, z1 = {oz, oz};
     uint32_t mx = 0u;
 #pragma unroll
     for (int p = 0; p < PP; p++) {
-      const f32x2 dx = px[p] - x1, dy = py[p] - y1, dz = pz[p] - z1;
+      const f32x2 dx = f32x2{vx[2 * p], vx[2 * p + 1]} - x1, dy = f32x2{vy[2 * p], vy[2 * p + 1]} - y1,
+                  dz = f32x2{vz[2 * p], vz[2 * p + 1]} - z1;
       const f32x2 a = dx * dx;
       const f32x2 b = dy * dy;
       const f32x2 c = dz * dz;
@@ -335,16 +380,22 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(const float *__restrict__ 
     bool unique = __popcll(lm) == 1;
     if (unique) {
       const int L = (int)__builtin_ctzll(lm);
-      int hits = 0, slot_found = 0;
+      if constexpr (kVecPick) {
+        const uint32_t sb = fps_slot_bits<2 * PP>(t, best, L);
+        if (__popc(sb) == 1) old = 64 * (2 * PP - 1 - (int)__builtin_ctz(sb)) + L;
+        else unique = false;
+      } else {
+        int hits = 0, slot_found = 0;
 #pragma unroll
-      for (int p = 0; p < 2 * PP; p++) {
-        const unsigned long long mp = __ballot(t[p] == best);
-        const int bit = (int)((mp >> L) & 1ull);
-        hits += bit;
-        slot_found = bit ? p : slot_found;
+        for (int p = 0; p < 2 * PP; p++) {
+          const unsigned long long mp = __ballot(t[p] == best);
+          const int bit = (int)((mp >> L) & 1ull);
+          hits += bit;
+          slot_found = bit ? p : slot_found;
+        }
+        if (hits == 1) old = 64 * slot_found + L;
+        else unique = false;
       }
-      if (hits == 1) old = 64 * slot_found + L;
-      else unique = false;
     }
     if (!unique) {
       uint32_t lo = 0u;
@@ -389,7 +440,14 @@ __global__ __launch_bounds__(64) void fps_bq_wave_kernel(const float *__restrict
   constexpr int cpw = 16;
   const int nitems = (m + cpw - 1) / cpw;
   f32x4 *rcloud = rows_out + cloud * (size_t)nitems * (size_t)(cpw * K);
-  f32x2 px[PP], py[PP], pz[PP];
+  // a lane's coordinates as ONE vector per axis: slot p = element p (pairs (2 p, 2 p + 1) feed the packed arithmetic; the
+  // pick reads element `slot` with a wave-uniform DYNAMIC index, i.e. relative register addressing, see fps_pick_coord)
+  typedef float fvec __attribute__((ext_vector_type(2 * PP)));
+  fvec vx, vy, vz;
+  // the vector forms of the slot search and of the coordinate fetch move ~100 scalar instructions per pick of a
+  // 1024-point cloud to ~40 vector ones; clouds of <= 512 points have half the slots, run at higher occupancy (scalar
+  // and vector instructions of different waves issue side by side) and are faster with the scalar forms (measured)
+  constexpr bool kVecPick = PP >= 8;
   uint32_t t[2 * PP];
 #pragma unroll
   for (int p = 0; p < 2 * PP; p++) {
@@ -397,9 +455,9 @@ __global__ __launch_bounds__(64) void fps_bq_wave_kernel(const float *__restrict
     const bool ok = k < n;
     const float *q = xyz + (size_t)(ok ? k : 0) * 3;
     const float x = q[0], y = q[1], z = q[2], tk = temp[ok ? k : 0];
-    px[p >> 1][p & 1] = ok ? x : INFINITY;    // a point at infinity is never inside a ball (and min(inf, 0) = 0 below)
-    py[p >> 1][p & 1] = ok ? y : INFINITY;
-    pz[p >> 1][p & 1] = ok ? z : INFINITY;
+    vx[p] = ok ? x : INFINITY;    // a point at infinity is never inside a ball (and min(inf, 0) = 0 below)
+    vy[p] = ok ? y : INFINITY;
+    vz[p] = ok ? z : INFINITY;
     t[p] = ok ? __float_as_uint(tk) : 0u;     // min(d, 0) = 0: a point beyond n never beats a real one
   }
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -415,21 +473,26 @@ __global__ __launch_bounds__(64) void fps_bq_wave_kernel(const float *__restrict
     // ---- centre j = point `old`: its coordinates out of the register file
     const int slot = __builtin_amdgcn_readfirstlane(old >> 6), ln = __builtin_amdgcn_readfirstlane(old & 63);
     float ox = 0.f, oy = 0.f, oz = 0.f;
-#define PCR_FPS_PICK(P)                                                                                      \
-  case P:                                                                                                    \
-    if constexpr (P < 2 * PP) {                                                                              \
-      ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px[(P) >> 1][(P)&1]), ln));               \
-      oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py[(P) >> 1][(P)&1]), ln));               \
-      oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[(P) >> 1][(P)&1]), ln));               \
-    }                                                                                                        \
+    if constexpr (kVecPick) {
+      ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vx[slot]), ln));
+      oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vy[slot]), ln));
+      oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vz[slot]), ln));
+    } else {
+#define PCR_FPS_PICK(P)                                                               \
+  case P:                                                                             \
+    if constexpr (P < 2 * PP) {                                                       \
+      ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vx[P]), ln));      \
+      oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vy[P]), ln));      \
+      oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vz[P]), ln));      \
+    }                                                                                 \
     break;
-    switch (slot) {
-      PCR_FPS_PICK(0) PCR_FPS_PICK(1) PCR_FPS_PICK(2) PCR_FPS_PICK(3) PCR_FPS_PICK(4) PCR_FPS_PICK(5) PCR_FPS_PICK(6)
-      PCR_FPS_PICK(7) PCR_FPS_PICK(8) PCR_FPS_PICK(9) PCR_FPS_PICK(10) PCR_FPS_PICK(11) PCR_FPS_PICK(12) PCR_FPS_PICK(13)
-      PCR_FPS_PICK(14) PCR_FPS_PICK(15)
-      default: break;
-    }
+      switch (slot) {
+        PCR_FPS_PICK(0) PCR_FPS_PICK(1) PCR_FPS_PICK(2) PCR_FPS_PICK(3) PCR_FPS_PICK(4) PCR_FPS_PICK(5) PCR_FPS_PICK(6)
+        PCR_FPS_PICK(7)
+        default: break;
+      }
 #undef PCR_FPS_PICK
+    }
     if (lane == 0) {
       idxs[j] = old;
       new_xyz[3 * j] = ox;
@@ -442,7 +505,8 @@ __global__ __launch_bounds__(64) void fps_bq_wave_kernel(const float *__restrict
     uint32_t mx = 0u;
 #pragma unroll
     for (int p = 0; p < PP; p++) {
-      const f32x2 dx = px[p] - x1, dy = py[p] - y1, dz = pz[p] - z1;
+      const f32x2 dx = f32x2{vx[2 * p], vx[2 * p + 1]} - x1, dy = f32x2{vy[2 * p], vy[2 * p + 1]} - y1,
+                  dz = f32x2{vz[2 * p], vz[2 * p + 1]} - z1;
       const f32x2 a = dx * dx;
       const f32x2 b = dy * dy;
       const f32x2 c = dz * dz;
@@ -485,7 +549,7 @@ __global__ __launch_bounds__(64) void fps_bq_wave_kernel(const float *__restrict
           const bool mine = ((mk[q] >> lane) & 1ull) != 0ull;
           // (the point's coordinates through an opaque copy INSIDE the branch: left alone the compiler speculates the row
           // data of all 2 PP slots above the wave-uniform branches)
-          float qx = px[q >> 1][q & 1], qy = py[q >> 1][q & 1], qz = pz[q >> 1][q & 1];
+          float qx = vx[q], qy = vy[q], qz = vz[q];
           asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));
           if (mine && pos < K) put_row(pos, roff, q * 64 + lane, qx - cx, qy - cy, qz - cz);
           if (cnt == 0) {
@@ -500,9 +564,9 @@ __global__ __launch_bounds__(64) void fps_bq_wave_kernel(const float *__restrict
       }
       if (cnt > K) cnt = K;
       if (cnt == 0) {   // (cannot happen for a centre that is a point of the cloud; kept for the generic contract)
-        fdx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px[0][0]), 0)) - cx;
-        fdy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py[0][0]), 0)) - cy;
-        fdz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[0][0]), 0)) - cz;
+        fdx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vx[0]), 0)) - cx;
+        fdy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vy[0]), 0)) - cy;
+        fdz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vz[0]), 0)) - cz;
       }
       const int nrow = cnt < 1 ? 2 : ((cnt + 1) & ~1);
       if (lane < nrow - cnt) put_row(lane, roff + cnt, first, fdx, fdy, fdz);
@@ -520,16 +584,22 @@ __global__ __launch_bounds__(64) void fps_bq_wave_kernel(const float *__restrict
     bool unique = __popcll(lm) == 1;
     if (unique) {
       const int L = (int)__builtin_ctzll(lm);
-      int hits = 0, slot_found = 0;
+      if constexpr (kVecPick) {
+        const uint32_t sb = fps_slot_bits<2 * PP>(t, best, L);
+        if (__popc(sb) == 1) old = 64 * (2 * PP - 1 - (int)__builtin_ctz(sb)) + L;
+        else unique = false;
+      } else {
+        int hits = 0, slot_found = 0;
 #pragma unroll
-      for (int p = 0; p < 2 * PP; p++) {
-        const unsigned long long mp = __ballot(t[p] == best);
-        const int bit = (int)((mp >> L) & 1ull);
-        hits += bit;
-        slot_found = bit ? p : slot_found;
+        for (int p = 0; p < 2 * PP; p++) {
+          const unsigned long long mp = __ballot(t[p] == best);
+          const int bit = (int)((mp >> L) & 1ull);
+          hits += bit;
+          slot_found = bit ? p : slot_found;
+        }
+        if (hits == 1) old = 64 * slot_found + L;
+        else unique = false;
       }
-      if (hits == 1) old = 64 * slot_found + L;
-      else unique = false;
     }
     if (!unique) {   // rare: the tie keys are derived here, not kept in registers (the opaque lane keeps them from
       // being hoisted out of the pick loop again)
