@@ -258,6 +258,20 @@ __device__ __forceinline__ uint32_t dpp_max_u32(uint32_t v) {
   return ab > cd ? ab : cd;
 }
 
+// lane `l` (wave-uniform) of a register := a wave-uniform value (v_writelane_b32; this clang has no builtin for it, and on
+// gfx9 a second scalar operand must be M0: one scalar register per vector instruction)
+__device__ __forceinline__ int pcr_writelane(int v, int l, int into) {
+  asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(into) : "s"(v), "s"(l) : "m0");
+  return into;
+}
+__device__ __forceinline__ void pcr_writelane4(int v0, int v1, int v2, int v3, int l, int &a0, int &a1, int &a2, int &a3) {
+  asm("s_mov_b32 m0, %8\n\ts_nop 0\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\t"
+      "v_writelane_b32 %2, %6, m0\n\tv_writelane_b32 %3, %7, m0"
+      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+      : "s"(v0), "s"(v1), "s"(v2), "s"(v3), "s"(l)
+      : "m0");
+}
+
 // Which of a lane's NS slots hold the wave maximum `best`?  Every lane shifts one compare per slot into a private word
 // (v_cmp_eq + v_addc_co: word = 2 word + carry, slot p ends up at bit NS - 1 - p) and ONE v_readlane takes lane L's word
 // to the scalar side: 2 NS vector + 3 scalar instructions.  (Before: a ballot per slot and a scalar bit test of each mask
@@ -462,6 +476,7 @@ __global__ __launch_bounds__(64) void fps_bq_wave_kernel(const float *__restrict
   }
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   int old = 0, roff = 0;
+  int acc_i = 0, acc_x = 0, acc_y = 0, acc_z = 0, acc_c = 0;
   for (int j = 0; j < m; j++) {
     if (j == m - 1) {   // the running minima as pcr_fps_f32 leaves them: the last centre does not enter them
 #pragma unroll
@@ -493,12 +508,12 @@ __global__ __launch_bounds__(64) void fps_bq_wave_kernel(const float *__restrict
       }
 #undef PCR_FPS_PICK
     }
-    if (lane == 0) {
-      idxs[j] = old;
-      new_xyz[3 * j] = ox;
-      new_xyz[3 * j + 1] = oy;
-      new_xyz[3 * j + 2] = oz;
-    }
+    // (what a pick leaves behind -- index, centre, hit count -- is parked in lane j % 64 of five registers by v_writelane
+    // and leaves as whole stores every 64 picks: a lane-0 store per pick and value was ~20 instructions behind an exec
+    // mask)
+    const int jl = j & 63;
+    pcr_writelane4(__builtin_amdgcn_readfirstlane(old), __float_as_int(ox), __float_as_int(oy), __float_as_int(oz), jl, acc_i,
+                   acc_x, acc_y, acc_z);
     // ---- every point's distance to it: hit masks, the running minimum and its lane maximum
     const f32x2 x1 = {ox, ox}, y1 = {oy, oy}, z1 = {oz, oz};
     unsigned long long mk[2 * PP];
@@ -543,7 +558,7 @@ __global__ __launch_bounds__(64) void fps_bq_wave_kernel(const float *__restrict
       float fdx = 0.f, fdy = 0.f, fdz = 0.f;
 #pragma unroll
       for (int q = 0; q < 2 * PP; q++) {
-        if (mk[q] != 0ull) {   // wave-uniform: hits are rare (a few per 1024 points)
+        if (__builtin_expect(mk[q] != 0ull, 0)) {   // wave-uniform: hits are rare (a few per 1024 points; out of line)
           const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk[q] >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)mk[q], 0u));
           const bool mine = ((mk[q] >> lane) & 1ull) != 0ull;
@@ -571,7 +586,17 @@ __global__ __launch_bounds__(64) void fps_bq_wave_kernel(const float *__restrict
       const int nrow = cnt < 1 ? 2 : ((cnt + 1) & ~1);
       if (lane < nrow - cnt) put_row(lane, roff + cnt, first, fdx, fdy, fdz);
       roff += nrow;
-      if (lane == 0) cnt_out[j] = cnt;
+      acc_c = pcr_writelane(cnt, jl, acc_c);
+      if (jl == 63 || j == m - 1) {
+        const int k = (j & ~63) + lane;
+        if (k <= j) {
+          idxs[k] = acc_i;
+          new_xyz[3 * k] = __int_as_float(acc_x);
+          new_xyz[3 * k + 1] = __int_as_float(acc_y);
+          new_xyz[3 * k + 2] = __int_as_float(acc_z);
+          cnt_out[k] = acc_c;
+        }
+      }
       if ((j & (cpw - 1)) == cpw - 1 || j == m - 1) {   // the item is complete: zero entries up to a whole 32-row block
         if (roff + lane < ((roff + 31) & ~31)) put_row(lane, roff, 0, 0.f, 0.f, 0.f);
         roff = 0;
