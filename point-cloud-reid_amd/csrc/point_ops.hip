@@ -475,6 +475,10 @@ __global__ __launch_bounds__(64) void fps_bq_wave_kernel(const float *__restrict
     t[p] = ok ? __float_as_uint(tk) : 0u;     // min(d, 0) = 0: a point beyond n never beats a real one
   }
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  // one buffer descriptor for the cloud's whole row region (items of cpw K rows follow each other; a descriptor per item
+  // was a 64-bit multiply + rebuild per pick); roff = the next free row counted from the cloud's first
+  const __amdgpu_buffer_rsrc_t rrows =
+      __builtin_amdgcn_make_buffer_rsrc(rcloud, 0, (int)((size_t)nitems * (size_t)(cpw * K) * 16), 0x00020000);
   int old = 0, roff = 0;
   int acc_i = 0, acc_x = 0, acc_y = 0, acc_z = 0, acc_c = 0;
   for (int j = 0; j < m; j++) {
@@ -546,9 +550,6 @@ __global__ __launch_bounds__(64) void fps_bq_wave_kernel(const float *__restrict
       int oxi = __float_as_int(ox), oyi = __float_as_int(oy), ozi = __float_as_int(oz);
       asm volatile("" : "+s"(oxi), "+s"(oyi), "+s"(ozi));
       const float cx = __int_as_float(oxi), cy = __int_as_float(oyi), cz = __int_as_float(ozi);
-      const int item = j >> 4;
-      f32x4 *rbase = rcloud + (size_t)item * (size_t)(cpw * K);
-      const __amdgpu_buffer_rsrc_t rrows = __builtin_amdgcn_make_buffer_rsrc(rbase, 0, cpw * K * 16, 0x00020000);
       auto put_row = [&](int rslot, int soff, int i, float dx, float dy, float dz) __attribute__((always_inline)) {
         // (scalar-offset field 0 on purpose: see ball_query_reg_kernel)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{__int_as_float(i), dx, dy, dz}), rrows,
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(64) void fps_bq_wave_kernel(const float *__restrict
       }
       if ((j & (cpw - 1)) == cpw - 1 || j == m - 1) {   // the item is complete: zero entries up to a whole 32-row block
         if (roff + lane < ((roff + 31) & ~31)) put_row(lane, roff, 0, 0.f, 0.f, 0.f);
-        roff = 0;
+        roff = ((j >> 4) + 1) * (cpw * K);   // (cpw K is a multiple of 32: K is even)
       }
     }
     if (j + 1 >= m) break;
