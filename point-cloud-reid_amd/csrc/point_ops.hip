@@ -1266,6 +1266,17 @@ __global__ void three_interp_bwd_kernel(const float *__restrict__ grad_out,
   }
 }
 
+// inclusive prefix sum over the 64 lanes (row shifts inside the 16-lane rows, then the two row broadcasts)
+__device__ __forceinline__ int pcr_wave_incl_scan_i32(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);   // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);   // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);   // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);   // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+  return x;
+}
+
 constexpr int kKnnPThreads = 256;
 constexpr int kKnnCap = 256;  // candidates per query the fast path can rank (4 per lane)
 
@@ -1538,18 +1549,61 @@ __global__ __launch_bounds__(NT) void knn_prefix_lds_kernel(const float *__restr
     __builtin_amdgcn_sched_barrier(0);
     const uint32_t mkey = (m & ~63u) | (uint32_t)lane;
     const uint32_t tau = (uint32_t)__builtin_amdgcn_readlane((int)pcr_wave_sort_u32(mkey, lane), K - 1) | 63u;
-    int total = 0;
-    int lane_q = lane;
-    asm volatile("" : "+v"(lane_q));   // (opaque per query: else the T values lane + 64 t are hoisted out of the query loop and spill)
+    // ---- pass 2 (round 5): the candidates d <= tau WITHOUT a ballot per register.  Every lane shifts one compare per
+    // register into private words (v_cmp + v_addc_co: w = 2 w + carry; bit t % 32 of word t / 32 = "my point t passed"),
+    // a wave scan of the lanes' counts gives every lane the first slot of its own candidates, and a short divergent
+    // loop over the set bits (about one per lane) writes their INDICES; the distances are then recomputed one candidate
+    // per lane from the LDS copy -- the same operations on the same operands, so the same bits.  (Before: a compare, a
+    // wave-uniform branch and, for the half of the registers with a hit, mbcnt + masked 8-byte store + scalar
+    // bookkeeping: ~750 of the query's ~1250 issue slots at T = 64.  The ranking does not depend on the candidates'
+    // order in the strip.)
+    constexpr int NW = T / 32;
+    uint32_t w[NW];
 #pragma unroll
-    for (int t = 0; t < T; t++) {
-      const uint32_t d = dk[t];
-      const bool in = d <= tau;
-      const unsigned long long mask = __ballot(in);
-      if (mask) {
-        const int pos = total + __popcll(mask & lt);
-        if (in && pos < kKnnCap) cand[pos] = ((unsigned long long)d << 32) | (unsigned)(lane_q + 64 * t);
-        total += __popcll(mask);
+    for (int u = 0; u < NW; u++) w[u] = 0u;
+#define PCR_KW1(a) "v_cmp_ge_u32 vcc, %[tau], %[" #a "]\n\tv_addc_co_u32 %[w], vcc, %[w], %[w], vcc\n\t"
+#pragma unroll
+    for (int u = 0; u < NW; u++)
+#pragma unroll
+      for (int g = 3; g >= 0; g--) {   // (registers in descending order: the last one shifted in is bit 0)
+        const int t0 = 32 * u + 8 * g;
+        asm(PCR_KW1(t7) PCR_KW1(t6) PCR_KW1(t5) PCR_KW1(t4) PCR_KW1(t3) PCR_KW1(t2) PCR_KW1(t1) PCR_KW1(t0)
+            : [w] "+v"(w[u])
+            : [tau] "s"(tau), [t0] "v"(dk[t0]), [t1] "v"(dk[t0 + 1]), [t2] "v"(dk[t0 + 2]), [t3] "v"(dk[t0 + 3]),
+              [t4] "v"(dk[t0 + 4]), [t5] "v"(dk[t0 + 5]), [t6] "v"(dk[t0 + 6]), [t7] "v"(dk[t0 + 7])
+            : "vcc");
+      }
+#undef PCR_KW1
+    int mycnt = 0;
+#pragma unroll
+    for (int u = 0; u < NW; u++) mycnt += __popc(w[u]);
+    const int incl = pcr_wave_incl_scan_i32(mycnt);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    if (total <= kKnnCap) {
+      uint32_t *cand32 = reinterpret_cast<uint32_t *>(cand);
+      int pos = incl - mycnt;
+#pragma unroll
+      for (int u = 0; u < NW; u++) {
+        uint32_t ww = w[u];
+        while (ww) {
+          const int t = 32 * u + (int)__builtin_ctz(ww);
+          ww &= ww - 1u;
+          cand32[2 * pos] = (uint32_t)(lane + 64 * t);
+          pos++;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const float *sPf = reinterpret_cast<const float *>(sP), *sZf = reinterpret_cast<const float *>(sZ);
+      for (int c = lane; c < total; c += 64) {
+        const int i = (int)cand32[2 * c];
+        const int t = i >> 6, unit = (t >> 1) * 64 + (i & 63), sl = t & 1;
+        const float dx = sPf[4 * unit + sl] - qx, dy = sPf[4 * unit + 2 + sl] - qy, dz = sZf[2 * unit + sl] - qz;
+        const float a = dx * dx;
+        const float bb = dy * dy;
+        const float cc = dz * dz;
+        const float sab = a + bb;
+        cand32[2 * c + 1] = __float_as_uint(sab + cc);
       }
     }
     __builtin_amdgcn_wave_barrier();

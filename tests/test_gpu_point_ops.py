@@ -99,11 +99,12 @@ def test_knn_prefix_bit_exact(n, s, k, kind):
 
 
 @pytest.mark.parametrize("n,k,span", [(1024, 32, 40), (1024, 48, 12), (512, 32, 6), (1024, 32, 3), (700, 64, 25),
-                                      (128, 32, 9)])
+                                      (128, 32, 9), (4096, 32, 30), (2048, 48, 14), (3000, 16, 5)])
 def test_knn_prefix_lattice_ties_bit_exact(n, k, span):
     """Integer lattice clouds: many EXACTLY equal distances (the index decides) and duplicates -- the truncated
     32-bit ranking must notice every tie among the first K + 1 ranks and take the exact 64-bit sort (few
-    distinct distances), and the wider spans mix tie-free and tied queries in one launch."""
+    distinct distances), and the wider spans mix tie-free and tied queries in one launch.  Clouds above 1024 points run
+    the LDS kernel, whose candidates reach the ranking in lane-major order with recomputed distances (round 5)."""
     from pcr_amd import engine
     g = np.random.default_rng(n + k + span)
     xyz = g.integers(0, span, (3, n, 3)).astype(np.float32)
