@@ -1436,6 +1436,49 @@ __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_reg_kernel(const floa
     // 2. candidates d <= tau, compacted in (t, lane) order: the slot of a candidate is the number of candidates
     // before it -- the running total of the earlier t (scalar) + the passing lanes below it (mbcnt of the ballot)
     int total = 0;
+    if constexpr (T >= 16) {
+      // (round 5, clouds of 513-1024 points: the lane-local form of knn_prefix_lds_kernel's pass 2 -- one compare word per
+      // lane, a wave scan of the counts, the indices written by a short divergent loop and the candidates' distances
+      // recomputed one per lane from the staged cloud: ~100 issue slots instead of 12 per register = 192)
+      static_assert(T == 16, "one 16-bit compare word per lane");
+      uint32_t w = 0u;
+#define PCR_KW1(a) "v_cmp_ge_u32 vcc, %[tau], %[" #a "]\n\tv_addc_co_u32 %[w], vcc, %[w], %[w], vcc\n\t"
+#pragma unroll
+      for (int g = 1; g >= 0; g--) {   // (registers in descending order: the last one shifted in is bit 0)
+        const int t0 = 8 * g;
+        asm(PCR_KW1(t7) PCR_KW1(t6) PCR_KW1(t5) PCR_KW1(t4) PCR_KW1(t3) PCR_KW1(t2) PCR_KW1(t1) PCR_KW1(t0)
+            : [w] "+v"(w)
+            : [tau] "s"(tau), [t0] "v"(d[t0]), [t1] "v"(d[t0 + 1]), [t2] "v"(d[t0 + 2]), [t3] "v"(d[t0 + 3]),
+              [t4] "v"(d[t0 + 4]), [t5] "v"(d[t0 + 5]), [t6] "v"(d[t0 + 6]), [t7] "v"(d[t0 + 7])
+            : "vcc");
+      }
+#undef PCR_KW1
+      const int mycnt = __popc(w);
+      const int incl = pcr_wave_incl_scan_i32(mycnt);
+      total = __builtin_amdgcn_readlane(incl, 63);
+      if (total <= kKnnCap) {
+        int pos = incl - mycnt;
+        while (w) {
+          const int t = (int)__builtin_ctz(w);
+          w &= w - 1u;
+          cand32[2 * pos] = (uint32_t)(lane + 64 * t);
+          pos++;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int c = lane; c < total; c += 64) {
+          const int i = (int)cand32[2 * c];
+          const bool ok = i < n;                       // (a lane's padding points sit at infinity: distance +inf)
+          const int ii = ok ? i : 0;
+          const float dx = sx[ii] - qx, dy = sy[ii] - qy, dz = sz[ii] - qz;
+          const float a = dx * dx;
+          const float bb = dy * dy;
+          const float cc = dz * dz;
+          const float sab = a + bb;
+          cand32[2 * c + 1] = ok ? __float_as_uint(sab + cc) : 0x7F800000u;
+        }
+      }
+    } else {
 #pragma unroll
     for (int t = 0; t < T; t++) {
       const bool pass = d[t] <= tau;
@@ -1448,6 +1491,7 @@ __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_reg_kernel(const floa
         wp[2 * pos + 1] = d[t];
       }
       total += __popcll(mask);
+    }
     }
     int *out = idx + (b * S + q) * K;
     if (total <= kKnnCap) {
