@@ -521,6 +521,7 @@ __global__ __launch_bounds__(64) void fps_bq_wave_kernel(const float *__restrict
     // ---- every point's distance to it: hit masks, the running minimum and its lane maximum
     const f32x2 x1 = {ox, ox}, y1 = {oy, oy}, z1 = {oz, oz};
     unsigned long long mk[2 * PP];
+    bool hit[2 * PP];
     uint32_t mx = 0u;
 #pragma unroll
     for (int p = 0; p < PP; p++) {
@@ -531,8 +532,10 @@ __global__ __launch_bounds__(64) void fps_bq_wave_kernel(const float *__restrict
       const f32x2 c = dz * dz;
       const f32x2 s = a + b;
       const f32x2 d = s + c;
-      mk[2 * p] = __ballot(d[0] < max_r2);
-      mk[2 * p + 1] = __ballot(d[1] < max_r2);
+      hit[2 * p] = d[0] < max_r2;         // (kept as lane masks: the hit blocks below take "my point" from them)
+      hit[2 * p + 1] = d[1] < max_r2;
+      mk[2 * p] = __ballot(hit[2 * p]);
+      mk[2 * p + 1] = __ballot(hit[2 * p + 1]);
       const uint32_t d0 = __float_as_uint(d[0]), d1 = __float_as_uint(d[1]);
       t[2 * p] = d0 < t[2 * p] ? d0 : t[2 * p];
       t[2 * p + 1] = d1 < t[2 * p + 1] ? d1 : t[2 * p + 1];
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(64) void fps_bq_wave_kernel(const float *__restrict
         if (__builtin_expect(mk[q] != 0ull, 0)) {   // wave-uniform: hits are rare (a few per 1024 points; out of line)
           const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk[q] >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)mk[q], 0u));
-          const bool mine = ((mk[q] >> lane) & 1ull) != 0ull;
+          const bool mine = hit[q];
           // (the point's coordinates through an opaque copy INSIDE the branch: left alone the compiler speculates the row
           // data of all 2 PP slots above the wave-uniform branches)
           float qx = vx[q], qy = vy[q], qz = vz[q];
@@ -878,7 +881,7 @@ __global__ __launch_bounds__(256) void ball_query_reg_kernel(const float *__rest
       // pass 1, straight line: all PPL distances and their hit masks (scalar registers); hits are rare (a few per
       // 1024 points), so pass 2 -- the ordered compaction -- visits only the non-empty masks behind scalar tests
       const f32x2 x1 = {cx, cx}, y1 = {cy, cy}, z1 = {cz, cz};
-      float d2[PPL];
+      bool hit[PPL];   // (lane masks in scalar registers, like their ballots: "my point is inside" costs nothing below)
       unsigned long long mk[PPL];
 #pragma unroll
       for (int t = 0; t < PPL / 2; t++) {
@@ -888,17 +891,17 @@ __global__ __launch_bounds__(256) void ball_query_reg_kernel(const float *__rest
         const f32x2 c2 = dz * dz;
         const f32x2 sab = a2 + b2;
         const f32x2 dd = sab + c2;
-        d2[2 * t] = dd[0];
-        d2[2 * t + 1] = dd[1];
-        mk[2 * t] = __ballot(inside(dd[0]));
-        mk[2 * t + 1] = __ballot(inside(dd[1]));
+        hit[2 * t] = inside(dd[0]);
+        hit[2 * t + 1] = inside(dd[1]);
+        mk[2 * t] = __ballot(hit[2 * t]);
+        mk[2 * t + 1] = __ballot(hit[2 * t + 1]);
       }
 #pragma unroll
       for (int j = 0; j < PPL; j++) {
         if (mk[j] != 0ull) {   // wave-uniform, ONE scalar test per j (the scalar unit is shared by the CU's four SIMDs)
           const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk[j] >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)mk[j], 0u));
-          if (inside(d2[j]) && pos < K) {
+          if (hit[j] && pos < K) {
             if (gout) {
               if (staged) row[pos] = j * 64 + lane;   // (kept apart: one pointer for both would be a flat store)
               else gout[pos] = j * 64 + lane;
