@@ -154,6 +154,14 @@ int pcr_three_interp_bwd_f32(const float *grad_out, const int *idx, const float 
  * order.  The consumer is a max over K, so only the K-SET matters (hard part 1).
  * xyz (B,N,3).  K <= N, K <= 64, N <= 16384. */
 int pcr_knn_prefix_f32(const float *xyz, int *idx, int B, int N, int S, int K, pcr_stream_t stream);
+/* The same search for TWO set-abstraction levels that query the same cloud (ABI 15; the Point-Transformer's first level
+ * keeps all N points, so its second level -- S2 <= S centres, K2 >= K neighbours -- searches the cloud the first one
+ * did): the K nearest of a query are the first K of its K2 nearest in (distance, index) order, so the first S2 queries are
+ * ranked ONCE for K2 and write both lists.  idx (B,S,K) and idx2 (B,S2,K2) = what pcr_knn_prefix_f32(.., S, K) and
+ * pcr_knn_prefix_f32(.., S2, K2) write, entry for entry (pointnet2_utils.py:139-149, 205-216 called by two layers,
+ * backbone_net.py:50-81). */
+int pcr_knn_prefix2_f32(const float *xyz, int *idx, int *idx2, int B, int N, int S, int K, int S2, int K2,
+                        pcr_stream_t stream);
 
 /* Packed weight image of one dense layer out = W x (W is (cout, cin) row-major as in
  * nn.Linear / 1x1 conv).  Returns the number of floats of the packed image for (cout, cin);

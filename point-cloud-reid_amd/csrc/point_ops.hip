@@ -1285,7 +1285,10 @@ constexpr int kKnnCap = 256;  // candidates per query the fast path can rank (4 
 
 // Ranks 0 .. K-1 of `total` <= kKnnCap candidates {index, distance bits} (= 64-bit (distance, index) keys) in the wave's
 // LDS strip `cand` -> out[0 .. K), in (distance, index) order.  Shared by the register and the LDS kNN kernels.
-__device__ __forceinline__ void knn_emit_from_candidates(unsigned long long *cand, int total, int K, int lane, int *out) {
+// out_b / Kb (optional): the first Kb <= K ranks are ALSO written there (pcr_knn_prefix2_f32: the K-nearest list of a
+// query is the prefix of its K2-nearest list, so one ranking serves two set-abstraction levels on the same cloud)
+__device__ __forceinline__ void knn_emit_from_candidates(unsigned long long *cand, int total, int K, int lane, int *out,
+                                                         int *out_b = nullptr, int Kb = 0) {
   uint32_t *cand32 = reinterpret_cast<uint32_t *>(cand);
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1335,10 +1338,13 @@ __device__ __forceinline__ void knn_emit_from_candidates(unsigned long long *can
     const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)sk, 0x130, 0xF, 0xF, false);   // lane + 1
     const bool tie = lane < K && ((sk ^ nx) < 64u);
     if (__ballot(tie) == 0ull) {
-      if (lane < K) out[lane] = (int)cand32[2 * (sk & 63u)];
+      const int v = (int)cand32[2 * (sk & 63u)];
+      if (lane < K) out[lane] = v;
+      if (out_b && lane < Kb) out_b[lane] = v;
     } else {
       const unsigned long long own = pcr_wave_sort_u64(lane < total ? cand[lane] : ~0ull, lane);
       if (lane < K) out[lane] = (int)(uint32_t)own;
+      if (out_b && lane < Kb) out_b[lane] = (int)(uint32_t)own;
     }
   } else {
     // 3b. up to kKnnCap candidates: four per lane, broadcast LDS reads
@@ -1356,7 +1362,10 @@ __device__ __forceinline__ void knn_emit_from_candidates(unsigned long long *can
     }
 #pragma unroll
     for (int u = 0; u < kKnnCap / 64; u++)
-      if (lane + 64 * u < total && rk[u] < K) out[rk[u]] = (int)(own[u] & 0xFFFFFFFFull);
+      if (lane + 64 * u < total && rk[u] < K) {
+        out[rk[u]] = (int)(own[u] & 0xFFFFFFFFull);
+        if (out_b && rk[u] < Kb) out_b[rk[u]] = (int)(own[u] & 0xFFFFFFFFull);
+      }
   }
 }
 
@@ -1381,7 +1390,7 @@ __device__ __forceinline__ void knn_emit_from_candidates(unsigned long long *can
 template <int TP>   // point PAIRS per lane: n <= 128 * TP
 __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_reg_kernel(const float *__restrict__ xyz,
                                                                   int *__restrict__ idx, int n, int S,
-                                                                  int K, int qpw) {
+                                                                  int K0, int qpw, int *__restrict__ idx2, int S2, int K2) {
   constexpr int T = 2 * TP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *sx = smem, *sy = smem + n, *sz = smem + 2 * n;
@@ -1411,6 +1420,9 @@ __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_reg_kernel(const floa
   const int q0 = blockIdx.x * qpw;
   const int q1 = (q0 + qpw < S) ? q0 + qpw : S;
   for (int q = q0 + wave; q < q1; q += kKnnPThreads / 64) {
+    // (pcr_knn_prefix2_f32: the first S2 queries rank K2 >= K0 neighbours and write both lists; wave-uniform)
+    const bool two = q < S2;
+    const int K = two ? K2 : K0;
     const float qx = sx[q], qy = sy[q], qz = sz[q];
     const f32x2 x1 = {qx, qx}, y1 = {qy, qy}, z1 = {qz, qz};
     uint32_t d[T];   // distances as BITS (>= +0: unsigned order = float order; +inf = 0x7f800000 sorts last)
@@ -1496,9 +1508,11 @@ __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_reg_kernel(const floa
       total += __popcll(mask);
     }
     }
-    int *out = idx + (b * S + q) * K;
+    int *out0 = idx + (b * S + q) * K0;
+    int *out = two ? idx2 + (b * S2 + q) * K2 : out0;   // the list of K ranks; out_b: its first K0 (two lists only)
+    int *out_b = two ? out0 : nullptr;
     if (total <= kKnnCap) {
-      knn_emit_from_candidates(cand, total, K, lane, out);
+      knn_emit_from_candidates(cand, total, K, lane, out, out_b, K0);
       __builtin_amdgcn_wave_barrier();
     } else {
       int mine = 0;
@@ -1519,6 +1533,7 @@ __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_reg_kernel(const floa
         }
       }
       if (lane < K) out[lane] = mine;
+      if (out_b && lane < K0) out_b[lane] = mine;
     }
   }
 }
@@ -1534,7 +1549,7 @@ __global__ __launch_bounds__(kKnnPThreads) void knn_prefix_reg_kernel(const floa
 template <int T, int NT>   // points per lane: n <= 64 * T; NT threads (NT / 64 waves share the cloud in LDS)
 __global__ __launch_bounds__(NT) void knn_prefix_lds_kernel(const float *__restrict__ xyz,
                                                                   int *__restrict__ idx, int n, int S,
-                                                                  int K, int qpw) {
+                                                                  int K0, int qpw, int *__restrict__ idx2, int S2, int K2) {
   static_assert(T % 2 == 0, "points per lane come in pairs");
   constexpr int TP = T / 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1561,6 +1576,8 @@ __global__ __launch_bounds__(NT) void knn_prefix_lds_kernel(const float *__restr
   const int q0 = blockIdx.x * qpw;
   const int q1 = (q0 + qpw < S) ? q0 + qpw : S;
   for (int q = q0 + wave; q < q1; q += NT / 64) {
+    const bool two = q < S2;            // (pcr_knn_prefix2_f32, as in the register kernel)
+    const int K = two ? K2 : K0;
     const int qu = ((q >> 7) * 64) + (q & 63), qs = (q >> 6) & 1;
     const float qx = reinterpret_cast<const float *>(sP + qu)[qs], qy = reinterpret_cast<const float *>(sP + qu)[2 + qs],
                 qz = reinterpret_cast<const float *>(sZ + qu)[qs];
@@ -1655,9 +1672,11 @@ __global__ __launch_bounds__(NT) void knn_prefix_lds_kernel(const float *__restr
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    int *out = idx + (b * S + q) * K;
+    int *out0 = idx + (b * S + q) * K0;
+    int *out = two ? idx2 + (b * S2 + q) * K2 : out0;
+    int *out_b = two ? out0 : nullptr;
     if (total <= kKnnCap) {
-      knn_emit_from_candidates(cand, total, K, lane, out);
+      knn_emit_from_candidates(cand, total, K, lane, out, out_b, K0);
     } else {
       unsigned long long last = 0ull;   // every real key has bit 63 set
       for (int k = 0; k < K; k++) {
@@ -1667,7 +1686,10 @@ __global__ __launch_bounds__(NT) void knn_prefix_lds_kernel(const float *__restr
           best = (key > last && key < best) ? key : best;
         }
         best = pcr_wave_min_u64(best);
-        if (lane == 0) out[k] = (int)(best & 0xFFFFFFFFull);
+        if (lane == 0) {
+          out[k] = (int)(best & 0xFFFFFFFFull);
+          if (out_b && k < K0) out_b[k] = (int)(best & 0xFFFFFFFFull);
+        }
         last = best;
       }
     }
@@ -1678,7 +1700,7 @@ __global__ __launch_bounds__(NT) void knn_prefix_lds_kernel(const float *__restr
 }  // namespace
 
 // ------------------------------------------------------------------------------ C ABI ----
-PCR_EXPORT int pcr_abi_version(void) { return 14; }
+PCR_EXPORT int pcr_abi_version(void) { return 15; }
 
 PCR_EXPORT const char *pcr_status_string(int status) {
   switch (status) {
@@ -1885,10 +1907,12 @@ PCR_EXPORT int pcr_three_interp_bwd_f32(const float *grad_out, const int *idx, c
   return PCR_OK;
 }
 
-PCR_EXPORT int pcr_knn_prefix_f32(const float *xyz, int *idx, int B, int N, int S, int K,
-                                  pcr_stream_t stream) {
+static int knn_prefix_launch(const float *xyz, int *idx, int B, int N, int S, int K, int *idx2, int S2, int K2,
+                             pcr_stream_t stream) {
   if (!xyz || !idx || B < 0 || N < 1 || S < 0 || S > N || K < 1 || K > 64 || K > N || N > 4096)
     return PCR_ERR_INVALID;
+  if (idx2 && (S2 < 0 || S2 > S || K2 < K || K2 > 64 || K2 > N)) return PCR_ERR_INVALID;
+  if (!idx2) S2 = K2 = 0;
   if (B == 0 || S == 0) return PCR_OK;
   if (B > 65535) return PCR_ERR_INVALID;
   const int qpw = 64;   // queries per workgroup: the cloud is staged once per workgroup
@@ -1897,7 +1921,7 @@ PCR_EXPORT int pcr_knn_prefix_f32(const float *xyz, int *idx, int B, int N, int 
   hipStream_t st = pcr_s(stream);
 #define PCR_KNN_REG(TP)                                                                                  \
   hipLaunchKernelGGL((knn_prefix_reg_kernel<TP>), g, blk,                                                \
-                     lds + (size_t)4 * (kKnnCap + 64) * 8, st, xyz, idx, N, S, K, qpw)
+                     lds + (size_t)4 * (kKnnCap + 64) * 8, st, xyz, idx, N, S, K, qpw, idx2, S2, K2)
   if (N <= 128) PCR_KNN_REG(1);
   else if (N <= 256) PCR_KNN_REG(2);
   else if (N <= 512) PCR_KNN_REG(4);
@@ -1913,17 +1937,27 @@ PCR_EXPORT int pcr_knn_prefix_f32(const float *xyz, int *idx, int B, int N, int 
       static bool big = hipFuncSetAttribute(reinterpret_cast<const void *>(knn_prefix_lds_kernel<32, NT>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
       (void)big;
-      hipLaunchKernelGGL((knn_prefix_lds_kernel<32, NT>), gl, dim3(NT), lds, st, xyz, idx, N, S, K, qpw_l);
+      hipLaunchKernelGGL((knn_prefix_lds_kernel<32, NT>), gl, dim3(NT), lds, st, xyz, idx, N, S, K, qpw_l, idx2, S2, K2);
     } else {
       lds = (size_t)64 * 64 * 12 + (size_t)(NT / 64) * kKnnCap * 8;
       static bool big = hipFuncSetAttribute(reinterpret_cast<const void *>(knn_prefix_lds_kernel<64, NT>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
       (void)big;
-      hipLaunchKernelGGL((knn_prefix_lds_kernel<64, NT>), gl, dim3(NT), lds, st, xyz, idx, N, S, K, qpw_l);
+      hipLaunchKernelGGL((knn_prefix_lds_kernel<64, NT>), gl, dim3(NT), lds, st, xyz, idx, N, S, K, qpw_l, idx2, S2, K2);
     }
   }
 #undef PCR_KNN_REG
   PCR_CHECK_LAUNCH();
   return PCR_OK;
+}
+
+PCR_EXPORT int pcr_knn_prefix_f32(const float *xyz, int *idx, int B, int N, int S, int K, pcr_stream_t stream) {
+  return knn_prefix_launch(xyz, idx, B, N, S, K, nullptr, 0, 0, stream);
+}
+
+PCR_EXPORT int pcr_knn_prefix2_f32(const float *xyz, int *idx, int *idx2, int B, int N, int S, int K, int S2, int K2,
+                                   pcr_stream_t stream) {
+  if (!idx2) return PCR_ERR_INVALID;
+  return knn_prefix_launch(xyz, idx, B, N, S, K, idx2, S2, K2, stream);
 }
 

@@ -6,6 +6,9 @@ import torch.nn as nn
 from .pointnet2_utils import PointNetFeaturePropagationSA, PointNetSetAbstractionEdgeSA
 
 
+_NO_KNN2 = bool(__import__("os").environ.get("PCR_NO_KNN2"))   # diagnostics: one neighbour search per level
+
+
 class Pointnet_Backbone(nn.Module):
     def __init__(self, input_channels=3, use_xyz=True, conv_out=32, mul=1, radius=[0.3, 0.5, 0.7],
                  nsample=[32, 48, 48]):
@@ -39,8 +42,18 @@ class Pointnet_Backbone(nn.Module):
             return train_graph.backbone(self, pointcloud, numpoints)
         xyz, features = self._break_up_pc(pointcloud)
         l_xyz, l_features = [xyz], [features]
+        shared = None       # the second level's neighbours, when the first level's search ranked them too
         for i, sa in enumerate(self.SA_modules):
-            li_xyz, li_features = sa(l_xyz[i], l_features[i], numpoints[i])
+            knn_idx = None
+            if i == 0 and len(self.SA_modules) > 1 and hasattr(sa, "shares_knn_with") and not _NO_KNN2 and \
+                    sa.shares_knn_with(self.SA_modules[1], xyz.shape[1], numpoints[0], numpoints[1]):
+                from pcr_amd import engine
+                knn_idx, shared = engine.knn_prefix2(xyz.contiguous(), numpoints[0], sa.nsample, numpoints[1],
+                                                     self.SA_modules[1].nsample)
+            elif i == 1 and shared is not None:
+                knn_idx = shared
+            li_xyz, li_features = sa(l_xyz[i], l_features[i], numpoints[i]) if knn_idx is None else \
+                sa(l_xyz[i], l_features[i], numpoints[i], knn_idx=knn_idx)
             l_xyz.append(li_xyz)
             l_features.append(li_features)
         l_features[0] = xyz.transpose(1, 2).contiguous()

@@ -144,13 +144,23 @@ class PointNetSetAbstractionEdgeSA(_Planned):
             last = out_channel
         self.self_attention = Self_Attention(last, 2, "linear")
 
-    def forward(self, xyz, points, numpoints):
-        """xyz (B,N,3); points (B,D,N) or None -> (new_xyz (B,S,3), (B,D',S)); S = numpoints"""
+    def shares_knn_with(self, nxt, n, numpoints, numpoints_next):
+        """may this level and the next one take their neighbours from ONE search (engine.knn_prefix2)?  This level keeps
+        all n points (so the next level queries the same cloud), both sample a prefix and search by kNN, and the next
+        level asks for at least as many neighbours of at most as many centres."""
+        return (isinstance(nxt, PointNetSetAbstractionEdgeSA) and self.sampling == "RANDOM" and self.use_knn and
+                nxt.sampling == "RANDOM" and nxt.use_knn and numpoints == n and numpoints_next <= numpoints and
+                self.nsample <= nxt.nsample <= min(64, n))
+
+    def forward(self, xyz, points, numpoints, knn_idx=None):
+        """xyz (B,N,3); points (B,D,N) or None -> (new_xyz (B,S,3), (B,D',S)); S = numpoints
+        knn_idx: this level's (B,S,K) neighbour indices when the caller has already searched (engine.knn_prefix2)"""
         plan = self._plan(xyz.device, lambda dev: engine.SaPlan(list(self.mlp_convs), list(self.mlp_bns), dev, mode=0))
         xyz = xyz.contiguous()
         points = None if points is None else points.contiguous()
         if self.sampling == "RANDOM" and self.use_knn:      # the configuration every ReID config builds
-            idx = engine.knn_prefix(xyz, numpoints, self.nsample)
+            idx = knn_idx if knn_idx is not None else engine.knn_prefix(xyz, numpoints, self.nsample)
+            assert idx.shape == (xyz.shape[0], numpoints, self.nsample)
             pooled = engine.guarded(lambda: plan.run(xyz, points, idx))   # folded BatchNorm: f32 from guard level 1
             new_xyz = xyz[:, :numpoints].contiguous()
             return new_xyz, self.self_attention(pooled, new_xyz)

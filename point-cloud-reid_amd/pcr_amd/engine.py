@@ -248,6 +248,23 @@ def knn_prefix(xyz, S, K):
     return idx
 
 
+def knn_prefix2(xyz, S, K, S2, K2):
+    """two levels on the same cloud in one launch (pcr_knn_prefix2_f32): -> idx (B,S,K), idx2 (B,S2,K2), entry for entry
+    what knn_prefix(xyz, S, K) and knn_prefix(xyz, S2, K2) return; S2 <= S, K2 >= K"""
+    L.require_cuda(xyz)
+    assert xyz.is_contiguous() and xyz.dtype == torch.float32 and S2 <= S and K2 >= K
+    B, N, _ = xyz.shape
+    if S2 == 0 or B == 0:
+        return knn_prefix(xyz, S, K), torch.empty((B, S2, K2), dtype=torch.int32, device=xyz.device)
+    idx = torch.empty((B, S, K), dtype=torch.int32, device=xyz.device)
+    idx2 = torch.empty((B, S2, K2), dtype=torch.int32, device=xyz.device)
+    with _prof("knn_prefix2[N=%d,S=%d,K=%d,S2=%d,K2=%d]" % (N, S, K, S2, K2), 8.0 * B * S * N,
+               12.0 * B * N + 4.0 * B * (S * K + S2 * K2)):
+        L.check(L.load().pcr_knn_prefix2_f32(L.ptr(xyz), L.ptr(idx), L.ptr(idx2), B, N, S, K, S2, K2, L.stream_ptr()),
+                "pcr_knn_prefix2_f32")
+    return idx, idx2
+
+
 class SaPlan:
     """packed 3-layer grouped MLP (conv+BN(eval)+ReLU x3 + max over K)"""
 

@@ -123,10 +123,11 @@ def local_self_attention(m, feat, xyz_cm):
     return TO.tnorm(TO.dense(f0, m.mlp_knn[2].weight), m.norm2_knn, res=feat)
 
 
-def sa_edge_layer(sa, xyz, feats, s):
-    """PointNetSetAbstractionEdgeSA in training mode: (B,N,3), (B,D,N)|None -> (B,S,3), (B,D',S)"""
+def sa_edge_layer(sa, xyz, feats, s, knn_idx=None):
+    """PointNetSetAbstractionEdgeSA in training mode: (B,N,3), (B,D,N)|None -> (B,S,3), (B,D',S)
+    knn_idx: the level's neighbours when the caller searched already (engine.knn_prefix2)"""
     xyz = xyz.contiguous()
-    idx = engine.knn_prefix(xyz, s, sa.nsample)                               # HIP, (B,S,K) int32
+    idx = knn_idx if knn_idx is not None else engine.knn_prefix(xyz, s, sa.nsample)   # HIP, (B,S,K) int32
     new_xyz = xyz[:, :s].contiguous()
     x = TO.sa_edge_train(sa, xyz, None if feats is None else feats.contiguous(), idx)
     return new_xyz, self_attention(sa.self_attention, x, _cm(new_xyz))
@@ -135,8 +136,17 @@ def sa_edge_layer(sa, xyz, feats, s):
 def backbone(bb, pointcloud, numpoints):
     xyz = pointcloud[..., 0:3].detach().contiguous()
     l_xyz, l_feat = [xyz], [None]
+    from mmdet3d.models import backbone_net as BN
+    shared = None
     for i, sa in enumerate(bb.SA_modules):
-        nx, nf = sa_edge_layer(sa, l_xyz[i], l_feat[i], numpoints[i])
+        knn_idx = None
+        if i == 0 and len(bb.SA_modules) > 1 and hasattr(sa, "shares_knn_with") and not BN._NO_KNN2 and \
+                sa.shares_knn_with(bb.SA_modules[1], xyz.shape[1], numpoints[0], numpoints[1]):
+            # the first level keeps every point: the second one searches the same cloud (one launch ranks both)
+            knn_idx, shared = engine.knn_prefix2(xyz, numpoints[0], sa.nsample, numpoints[1], bb.SA_modules[1].nsample)
+        elif i == 1:
+            knn_idx = shared
+        nx, nf = sa_edge_layer(sa, l_xyz[i], l_feat[i], numpoints[i], knn_idx=knn_idx)
         l_xyz.append(nx)
         l_feat.append(nf)
     l_feat[0] = _cm(xyz)

@@ -463,6 +463,30 @@ def test_sa_fast_and_generic_paths_agree_with_torch(mode, D, K, S, N, widths):
         assert np.abs(outs[fast] - want).max() < 2e-5, (fast, np.abs(outs[fast] - want).max())
 
 
+def test_backbone_shares_the_neighbour_search_of_its_first_two_levels():
+    """the first Point-Transformer level keeps every point, so the second level queries the same cloud: one
+    pcr_knn_prefix2_f32 launch ranks both levels' neighbours (round 5) -- same index tensors, hence bit-identical
+    features; the profile shows one knn_prefix2 + one knn_prefix instead of three knn_prefix launches"""
+    from pcr_amd import engine
+    from mmdet3d.models import backbone_net as BN
+    m, _ = build_pt([128, 64, 32])
+    clouds = T.synthetic_clouds(5, 128, seed=3, kind="randn").cuda()
+    with torch.no_grad():
+        engine.PROFILE = []
+        try:
+            xyz_a, h_a = m.forward_inference(clouds)
+            names = [r[0].split("[")[0] for r in engine.PROFILE]
+        finally:
+            engine.PROFILE = None
+        prev, BN._NO_KNN2 = BN._NO_KNN2, True
+        try:
+            xyz_b, h_b = m.forward_inference(clouds)
+        finally:
+            BN._NO_KNN2 = prev
+    assert names.count("knn_prefix2") == 1 and names.count("knn_prefix") == 1, names
+    assert torch.equal(xyz_a, xyz_b) and torch.equal(h_a, h_b)
+
+
 def test_match_gallery_equals_pairwise_matching():
     """encode once, score arbitrary (i, j) combinations"""
     import model_oracle as MO

@@ -115,6 +115,28 @@ def test_knn_prefix_lattice_ties_bit_exact(n, k, span):
     assert (got == want).all()
 
 
+@pytest.mark.parametrize("n,s,k,s2,k2,kind", [(1024, 1024, 32, 512, 48, "randn"), (4096, 4096, 32, 2048, 48, "box"),
+                                              (128, 128, 32, 64, 48, "dup"), (700, 700, 16, 300, 64, "randn"),
+                                              (2048, 2048, 48, 1024, 48, "dup"), (512, 400, 8, 400, 33, "box"),
+                                              (3000, 2500, 20, 1, 64, "dup"), (256, 256, 32, 0, 48, "randn")])
+def test_knn_prefix2_equals_two_searches(n, s, k, s2, k2, kind):
+    """pcr_knn_prefix2_f32 (ABI 15): one launch for two set-abstraction levels on the same cloud -- the first s2 queries are
+    ranked once for k2 >= k neighbours and write both lists.  Both outputs must equal what two pcr_knn_prefix_f32 launches
+    write, entry for entry: random / box / duplicate-heavy clouds (the overflow paths), every kernel size class, s2 = 0 / 1 /
+    s, k2 = k."""
+    from pcr_amd import engine
+    xyz = T.synthetic_clouds(3, n, seed=n + k2, kind=kind).cuda().contiguous()
+    g = np.random.default_rng(n)
+    lat = torch.from_numpy(g.integers(0, 6, (2, n, 3)).astype(np.float32)).cuda()   # lattice: exact ties everywhere
+    for cloud in (xyz, lat):
+        a, b = engine.knn_prefix2(cloud, s, k, s2, k2)
+        assert torch.equal(a, engine.knn_prefix(cloud, s, k))
+        if s2:
+            assert torch.equal(b, engine.knn_prefix(cloud, s2, k2))
+        else:
+            assert b.shape == (cloud.shape[0], 0, k2)
+
+
 def test_gather_group_fwd_bwd(ops):
     g = np.random.default_rng(0)
     feat = g.standard_normal((3, 19, 257)).astype(np.float32)

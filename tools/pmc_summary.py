@@ -108,8 +108,10 @@ KNOWN = {
     "attn_kv[d=128,c2=128,Sk=1024]": ["attn_kv_kernel_o2<1, 2, 1, 4", "attn_kv_kernel_o3<1, 2, 1, 4>"],
     "attn_apply[d=128,c1=128,out=128,Lq=256]": ["attn_apply_stream128_kernel", "attn_apply_kernel<1, 2>"],
     "knn_prefix[N=1024,S=1024,K=32]": ["knn_prefix_reg_kernel<8>"],
+    "knn_prefix2[N=1024,S=1024,K=32,S2=512,K2=48]": ["knn_prefix_reg_kernel<8>"],
     # pt4096 / gallery128 / pointnet256
     "knn_prefix[N=4096,S=4096,K=32]": ["knn_prefix_lds_kernel"],
+    "knn_prefix2[N=4096,S=4096,K=32,S2=2048,K2=48]": ["knn_prefix_lds_kernel"],
     "sa_fused[D=64,c=128/128/128,N=2048,S=1024,K=48]": ["sa_stream_kernel<4, 4"],
     "attn_apply[d=64,c1=64,out=64,Lq=128]": ["gallery_tail_kernel", "attn_apply_stream64_kernel<false, 4, 0, 2",
                                              "attn_apply_kernel<2, 1>"],
