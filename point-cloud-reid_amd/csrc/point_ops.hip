@@ -1611,8 +1611,12 @@ __global__ __launch_bounds__(NT) void knn_prefix_lds_kernel(const float *__restr
       m = m01 < m ? m01 : m;
     }
     __builtin_amdgcn_sched_barrier(0);
-    const uint32_t mkey = (m & ~63u) | (uint32_t)lane;
-    const uint32_t tau = (uint32_t)__builtin_amdgcn_readlane((int)pcr_wave_sort_u32(mkey, lane), K - 1) | 63u;
+    // (the float-bits network of the register kernel: two VALU instructions per step instead of the integer network's four;
+    // a lane whose points are all padding holds +inf: clamped so that the tagged key is not a NaN pattern)
+    const uint32_t mc = m < 0x7F7FFFFFu ? m : 0x7F7FFFFFu;
+    const uint32_t mkey = (mc & ~63u) | (uint32_t)lane;
+    const uint32_t ts = (uint32_t)__builtin_amdgcn_readlane((int)pcr_wave_sort_posf32(mkey, lane), K - 1);
+    const uint32_t tau = ts >= 0x7F7FFFC0u ? 0x7F800000u : (ts | 63u);
     // ---- pass 2 (round 5): the candidates d <= tau WITHOUT a ballot per register.  Every lane shifts one compare per
     // register into private words (v_cmp + v_addc_co: w = 2 w + carry; bit t % 32 of word t / 32 = "my point t passed"),
     // a wave scan of the lanes' counts gives every lane the first slot of its own candidates, and a short divergent
