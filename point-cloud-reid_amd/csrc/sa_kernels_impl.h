@@ -2401,8 +2401,11 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
     static const int no_stream = pcr_tune_int("PCR_SA_NO_STREAM");   // diagnostics
     const int ncb = p.c1 >> 5, ncb3 = p.c3 >> 5;
     int nblk_item = 0, ncen_item = 0;
-    for (int nb = 1; nb <= 3 && !nblk_item; nb++)
-      if ((32 * nb) % p.K == 0) { nblk_item = nb; ncen_item = 32 * nb / p.K; }
+    // (the LARGEST item of whole centres within three blocks: K = 32 / 16 take three blocks = 3 / 6 centres per item, so the
+    // per-item work -- the maxima's fold and store, the item walk -- is paid once per 96 rows)
+    static const int small_items = pcr_tune_int("PCR_SAS_SMALL_ITEMS");   // diagnostics: the smallest item instead
+    for (int nb = 3; nb >= 1; nb--)
+      if ((32 * nb) % p.K == 0 && (!nblk_item || small_items)) { nblk_item = nb; ncen_item = 32 * nb / p.K; }
     const size_t fixed = ((size_t)(2 * ncb) * ncb * 128 + (size_t)(2 * ncb) * ncb3 * 128) * 16 + (size_t)(2 * p.c1 + p.c3) * 4 +
                          (size_t)ncb * 64 * 16;
     const size_t lds_s = fixed + (size_t)kSasWaves * 6 * p.c3 * 4;
