@@ -566,10 +566,10 @@ __global__ __launch_bounds__(64) void fps_bq_wave_kernel(const float *__restrict
           const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk[q] >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)mk[q], 0u));
           const bool mine = hit[q];
-          // (the point's coordinates through an opaque copy INSIDE the branch: left alone the compiler speculates the row
-          // data of all 2 PP slots above the wave-uniform branches)
-          float qx = vx[q], qy = vy[q], qz = vz[q];
-          asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));
+          // (rounds 5a-5f routed the point's coordinates through an opaque copy inside the branch, because the compiler
+          // speculated the row data of all 2 PP slots above the wave-uniform branches; with the hit blocks out of line
+          // it no longer does, and the three copies per non-empty slot are gone)
+          const float qx = vx[q], qy = vy[q], qz = vz[q];
           if (mine && pos < K) put_row(pos, roff, q * 64 + lane, qx - cx, qy - cy, qz - cz);
           if (cnt == 0) {
             const int fl = (int)__builtin_ctzll(mk[q]);
