@@ -158,54 +158,153 @@ class ReIDNet(nn.Module):
                 *self._cat(label_1, label_2, id_1, id_2, size_1, size_2, vis_1, vis_2))
 
     # ------------------------------------------------------------------ split-bf16 guard (pcr_amd/engine.py)
-    def _weights_key(self):
-        ts = self.__dict__.get("_pcr_tensors")
-        if ts is None or len(ts[0]) != sum(1 for _ in self.parameters()):
-            ts = (list(self.parameters()), list(self.buffers()))
+    def _weights_key(self, full=True):
+        """identity + version of every parameter and buffer.  full: one walk over the module tree (~150 us for the ~230
+        tensors of a ReID model; every guard tick and guard_state() do it), so that REPLACED Parameters
+        (load_state_dict(assign=True), m.weight = nn.Parameter(..), re-registered buffers) are seen, not only in-place
+        writes; not full: the versions of the tensors found by the last walk (~25 us; precision_level(), several times
+        per pass between two ticks)"""
+        ts = None if full else self.__dict__.get("_pcr_tensors")
+        if ts is None:
+            tensors, h, stack = [], 0, [self]
+            while stack:
+                mod = stack.pop()
+                for d in (mod._parameters, mod._buffers):
+                    for t in d.values():
+                        if t is not None:
+                            tensors.append(t)
+                            h = ((h * 1000003) ^ id(t)) & 0xFFFFFFFFFFFFFFFF
+                for c in mod._modules.values():
+                    if c is not None:
+                        stack.append(c)
+            ts = (tensors, h)
             self.__dict__["_pcr_tensors"] = ts
-        return (sum(t._version for t in ts[0]) + sum(t._version for t in ts[1]), ts[0][0].data_ptr() if ts[0] else 0)
+        v = 0
+        for t in ts[0]:
+            v += t._version
+        return (v, ts[1], len(ts[0]))
+
+    def _guard_active(self):
+        return engine.GUARD and engine.PRECISION == "bf16x3" and not self.training
 
     def precision_level(self):
-        """guard level of these weights (0 until calibrate_precision has run for them; always 0 in training mode, with
-        the guard off, or outside "bf16x3" mode)"""
-        if self.training or not engine.GUARD or engine.PRECISION != "bf16x3":
+        """guard level of these weights: the calibrated one (0 before calibration -- every inference entry point
+        calibrates on its first batch, _guard_tick / _match_level, so an uncalibrated 0 is only seen inside a HIP-graph
+        capture or on host tensors; always 0 in training mode, with the guard off, or outside "bf16x3" mode)"""
+        if not self._guard_active():
             return 0
         st = self.__dict__.get("_pcr_guard")
-        return st["level"] if st is not None and st["key"] == self._weights_key() else 0
+        return st["level"] if st is not None and st["key"] == self._weights_key(full=False) else 0
 
     def guard_state(self):
-        """what calibrate_precision measured for the current weights, or None"""
+        """what calibrate_precision (and the sentinel since) measured for the current weights, or None"""
         st = self.__dict__.get("_pcr_guard")
         if st is None or st["key"] != self._weights_key():
             return None
         return {k: v for k, v in st.items() if k != "key"}
 
+    def _hot(self, s1, s2):
+        xyz1, xyz2, h1, h2 = self._siamese_forward(s1, s2)
+        return self._match_logits(h1, h2, xyz1, xyz2, inference=True)[0]
+
     def calibrate_precision(self, sparse_1, sparse_2, bound=None, max_pairs=64):
         """split-bf16 guard: run the hot path on (up to max_pairs of) this batch in f32 and at guard levels 0, 1, 2, keep the
         first level whose logits stay within `bound` (engine.GUARD_BOUND, half the 1e-4 parity bound) of the f32 path's,
-        for as long as the weights do not change.  -> {"level", "dlogit": {level: max |logit - f32 logit|}, ...}"""
+        for as long as the weights do not change (the sentinel re-checks it on live batches: _guard_tick).
+        -> {"level", "dlogit": {level: max |logit - f32 logit|}, ...}"""
         bound = engine.GUARD_BOUND if bound is None else float(bound)
         s1, s2 = sparse_1[:max_pairs].contiguous(), sparse_2[:max_pairs].contiguous()
-        self.__dict__.pop("_pcr_guard", None)                      # (uncalibrated: the entry points apply no level of their own)
+        self.__dict__.pop("_pcr_guard", None)
         dl, level = {}, 0
         if engine.PRECISION == "bf16x3" and not self.training:
-            with torch.no_grad():
-                def hot():
-                    xyz1, xyz2, h1, h2 = self.siamese_forward(s1, s2)
-                    return self.match_forward_inference(h1, h2, xyz1, xyz2)
-                with engine.precision("f32"):
-                    ref = hot()
-                for level in (0, 1, 2):
-                    with engine.guard_level(level):
-                        dl[level] = float((hot() - ref).abs().max())
-                    if dl[level] <= bound:
-                        break
-        st = dict(key=self._weights_key(), level=level, dlogit=dl, bound=bound, pairs=int(s1.shape[0]))
+            self.__dict__["_pcr_guard_busy"] = True
+            try:
+                with torch.no_grad():
+                    with engine.precision("f32"):
+                        ref = self._hot(s1, s2)
+                    for level in (0, 1, 2):
+                        with engine.guard_level(level):
+                            dl[level] = float((self._hot(s1, s2) - ref).abs().max())
+                        if dl[level] <= bound:
+                            break
+            finally:
+                self.__dict__["_pcr_guard_busy"] = False
+        st = dict(key=self._weights_key(), level=level, dlogit=dl, bound=bound, pairs=int(s1.shape[0]), calls=0,
+                  sentinel=dict(every=engine.GUARD_EVERY, checks=0, worst=0.0, raised=[]))
         self.__dict__["_pcr_guard"] = st
         return self.guard_state()
 
+    def _sentinel(self, c1, c2, st):
+        """run-time re-check of the calibrated level on (up to engine.GUARD_SENTINEL_PAIRS of) the LIVE batch: the f32 path
+        against the current level; on a breach of the bound the level of this weight version is raised to the first
+        one that holds (2 = the f32 path always does) BEFORE the batch itself is computed, and the event is logged.
+        The sampled pairs rotate through the batch from check to check."""
+        sen = st["sentinel"]
+        m = min(engine.GUARD_SENTINEL_PAIRS, int(c1.shape[0]))
+        lo = (sen["checks"] * m) % max(1, int(c1.shape[0]) - m + 1)
+        s1, s2 = c1[lo:lo + m].contiguous(), c2[lo:lo + m].contiguous()
+        self.__dict__["_pcr_guard_busy"] = True
+        try:
+            with torch.no_grad():
+                with engine.precision("f32"):
+                    ref = self._hot(s1, s2)
+                level = st["level"]
+                while True:
+                    with engine.guard_level(level):
+                        d = float((self._hot(s1, s2) - ref).abs().max()) if level < 2 else 0.0
+                    if d <= st["bound"] or level >= 2:
+                        break
+                    level += 1
+        finally:
+            self.__dict__["_pcr_guard_busy"] = False
+        sen["checks"] += 1
+        if level != st["level"]:
+            import logging
+            logging.getLogger("pcr_amd.guard").warning(
+                "split-bf16 guard: live batch %d deviates from the f32 path beyond %.1e at level %d; these weights run "
+                "at level %d from here on", st["calls"], st["bound"], st["level"], level)
+            sen["raised"].append(dict(call=st["calls"], was=st["level"], now=level))
+            st["level"] = level
+        else:
+            sen["worst"] = max(sen["worst"], d)
+
+    def _guard_tick(self, c1, c2):
+        """top of every inference entry point that sees raw clouds (c1, c2: (B,N,3) halves of pairs, or the two halves of a
+        gallery): lazy calibration on the first batch of a weight version (the tracker entry points ran
+        unguarded until someone called calibrate_precision by hand), then the sentinel every engine.GUARD_EVERY batches.
+        Inside a HIP-graph capture nothing can be measured (host reads): the captured launches keep the level the model
+        has -- calibrate before capturing, as bench.py does."""
+        if not self._guard_active() or self.__dict__.get("_pcr_guard_busy") or not c1.is_cuda or c1.shape[0] == 0:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            return
+        st = self.__dict__.get("_pcr_guard")
+        if st is None or st["key"] != self._weights_key():
+            self.calibrate_precision(c1, c2)
+            return
+        st["calls"] += 1
+        every = engine.GUARD_EVERY
+        if every > 0 and st["level"] < 2 and st["calls"] % every == 0:
+            self._sentinel(c1, c2, st)
+
+    @staticmethod
+    def _halves(pts):
+        """a batch of single clouds (forward_inference) as pairs for the guard: first half against second half"""
+        m = pts.shape[0] // 2
+        return (pts[:m], pts[m:2 * m]) if m else (pts, pts)
+
+    def _raw_clouds(self, xyz1, xyz2):
+        """match-only entry (features computed elsewhere): the raw clouds are what the point-major backbones return as
+        xyz; PointNet / DGCNN hand back a transformed, channel-major xyz that cannot be re-encoded"""
+        if self.use_dgcnn or isinstance(self.backbone, PointNet):
+            return None
+        return xyz1, xyz2
+
     # ------------------------------------------------------------------ encoder
     def forward_inference(self, pts_batched):
+        # (PointNet / DGCNN take channel-major clouds (B,3,N); the guard's pairs are point-major like siamese_forward's)
+        cm = self.use_dgcnn or isinstance(self.backbone, PointNet)
+        self._guard_tick(*self._halves(pts_batched.permute(0, 2, 1) if cm else pts_batched))
         lvl = self.precision_level()
         with torch.no_grad():
             if lvl:
@@ -214,6 +313,7 @@ class ReIDNet(nn.Module):
             return self.backbone(pts_batched, self.backbone_list)
 
     def siamese_forward(self, sparse_1, sparse_2):
+        self._guard_tick(sparse_1, sparse_2)
         lvl = self.precision_level()
         if lvl:
             with engine.guard_level(lvl):
@@ -348,15 +448,31 @@ class ReIDNet(nn.Module):
             return self._head_rows(cat), None
         raise NotImplementedError("match_type=%r" % self.match_type)
 
+    def _match_level(self, xyz1, xyz2):
+        """level for an entry point that only sees features: the calibrated one; an uncalibrated weight version is
+        calibrated from the raw clouds (xyz of the point-major backbones) or, where they cannot be recovered, runs the
+        matching in f32 (level 2) -- never unguarded"""
+        if not self._guard_active() or self.__dict__.get("_pcr_guard_busy"):
+            return self.precision_level()
+        st = self.__dict__.get("_pcr_guard")
+        if st is not None and st["key"] == self._weights_key(full=False):
+            return st["level"]
+        if self.guard_state() is None and xyz1.is_cuda and not torch.cuda.is_current_stream_capturing():
+            raw = self._raw_clouds(xyz1, xyz2)
+            if raw is None or raw[0].shape[0] == 0:
+                return 2
+            self.calibrate_precision(*raw)
+        return self.precision_level()
+
     def match_forward_inference(self, h1, h2, xyz1, xyz2):
-        lvl = self.precision_level()
+        lvl = self._match_level(xyz1, xyz2)
         if lvl:
             with engine.guard_level(lvl):
                 return self._match_logits(h1, h2, xyz1, xyz2, inference=True)[0]
         return self._match_logits(h1, h2, xyz1, xyz2, inference=True)[0]
 
     def match_gallery(self, h, xyz, pairs):
-        lvl = self.precision_level()
+        lvl = self._match_level(*self._halves(xyz))
         if lvl:
             with engine.guard_level(lvl):
                 return self._match_gallery(h, xyz, pairs)
@@ -465,9 +581,8 @@ class ReIDNet(nn.Module):
          vis_2) = self.preprocess_inputs_size_vis(sparse_1, sparse_2, dense_1, dense_2, label_1, label_2, id_1,
                                                   id_2, size_1, size_2, vis_1, vis_2)
         device = sparse_1.device
-        if (engine.GUARD and engine.PRECISION == "bf16x3" and not self.training and sparse_1.is_cuda and
-                self.guard_state() is None):
-            self.calibrate_precision(sparse_1, sparse_2)      # first batch after the weights changed (engine.py: the guard)
+        # (siamese_forward calibrates the split-bf16 guard on the first batch after the weights changed and re-checks it
+        # every engine.GUARD_EVERY batches: _guard_tick)
         xyz1, xyz2, h1, h2 = self.siamese_forward(sparse_1, sparse_2)
         h1, h2, xyz1, xyz2, match = self.get_match_supervision(h1, h2, xyz1, xyz2, id_1, id_2)
         match_preds, match_loss, _ = self.match_forward(h1, h2, xyz1, xyz2, match, None, device)

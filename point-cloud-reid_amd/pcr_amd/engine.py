@@ -69,11 +69,23 @@ class precision:
 #   0  every matrix phase in split bf16 (what "bf16x3" means for a well-conditioned checkpoint);
 #   1  the launches that carry folded BatchNorm scales (the grouped SA MLPs: `guarded`) in f32, the rest in split bf16;
 #   2  the whole path in f32.
-# ReIDNet applies the level on every inference entry point; forward_test calibrates on its first batch after the weights
-# changed, bench.py before its timed region (and reports level + measured deviations as config.guard).  PCR_GUARD=0
-# switches it off; PCR_GUARD_BOUND moves the bound.
+# ReIDNet applies the level on every inference entry point, and every one of them that sees raw clouds (siamese_forward,
+# forward_inference, forward_test; the match-only ones through the xyz they are handed) calibrates on its first batch
+# after the weights changed (round 6; ADVICE r5: the tracker entry points ran unguarded until calibrate_precision was
+# called by hand); bench.py calibrates before its capture (and reports level + measured deviations as config.guard).
+# Run-time SENTINEL (round 6): the cancellation is data dependent, so one calibration batch is a
+# margin, not a property -- every GUARD_EVERY-th inference batch of a weight version, up to GUARD_SENTINEL_PAIRS pairs of
+# the LIVE batch (rotating through it) are re-run in f32 and at the current level BEFORE the batch itself is computed;
+# on a breach of GUARD_BOUND the level of that weight version is raised to the first one that holds and the event is
+# logged ("pcr_amd.guard") and kept in guard_state()["sentinel"].  The bound is half the parity bound, so a drift is
+# caught at 5e-5 on the sample before it costs 1e-4 on a logit; PCR_GUARD_EVERY=1 checks every batch (a property at
+# ~2 x 8 small pairs per batch), 0 switches the sentinel off.  Nothing is measured inside a HIP-graph capture (host
+# reads): captured launches keep the level the model had when they were captured.
+# PCR_GUARD=0 switches the guard off; PCR_GUARD_BOUND moves the bound.
 GUARD = _os.environ.get("PCR_GUARD", "1") != "0"
 GUARD_BOUND = float(_os.environ.get("PCR_GUARD_BOUND", "5e-5"))
+GUARD_EVERY = int(_os.environ.get("PCR_GUARD_EVERY", "64"))
+GUARD_SENTINEL_PAIRS = int(_os.environ.get("PCR_GUARD_SENTINEL_PAIRS", "8"))
 _LEVEL = 0
 
 

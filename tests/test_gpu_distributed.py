@@ -114,6 +114,6 @@ def test_default_two_rank_run_carries_the_training_companion():
     last = r.stdout.strip().splitlines()[-1]
     assert len(last) < 8000
     d = json.loads(last)
-    assert d["n_gpus"] == 2 and d["config"]["workload"].startswith("ssg1024") and "cpu_baseline" not in d
+    assert d["n_gpus"] == 2 and d["config"]["workload"].startswith("pt1024") and "cpu_baseline" not in d
     (tr,) = d["also"]
     assert tr["name"] == "pt128_train" and tr["n_gpus"] == 2 and tr["value"] > 0 and tr["pairs"] == 256

@@ -269,3 +269,133 @@ def test_guard_levels_move_the_folded_batchnorm_launches_to_f32():
         with torch.no_grad():
             next(model.parameters()).mul_(1.0)                                # new weight version: not calibrated any more
         assert model.guard_state() is None and model.precision_level() == 0
+
+
+# ---- round 6: lazy calibration at every entry point + the run-time sentinel ---------
+def _dev0(model, s1, s2):
+    """max |logit(level 0) - logit(f32)| per pair, measured explicitly (no guard state touched)"""
+    from pcr_amd import engine
+    with torch.no_grad():
+        with engine.precision("f32"):
+            ref = model._hot(s1, s2)
+        with engine.precision("bf16x3"), engine.guard_level(0):
+            got = model._hot(s1, s2)
+    return (got - ref).abs(), ref
+
+
+def test_every_inference_entry_point_calibrates_on_its_first_batch():
+    """forward_inference / siamese_forward / match_forward_inference / match_gallery only READ the level, so a
+    tracker that never called calibrate_precision ran unguarded.  Now the first batch of a weight version calibrates,
+    whichever entry point sees it; a replaced Parameter (not an in-place write) invalidates the state too."""
+    import bench
+    from pcr_amd import engine
+    s1, s2 = [t.cuda() for t in T.synthetic_pairs(6, 128, seed=9, kind="randn")]
+    with engine.precision("bf16x3"):
+        for entry in ("siamese_forward", "forward_inference", "match_forward_inference", "match_gallery"):
+            model, _ = bench.build_pt_model([128, 64, 32])
+            assert model.guard_state() is None
+            with torch.no_grad(), engine.guard_level(0):
+                xyz1, xyz2, h1, h2 = model._siamese_forward(s1, s2)          # (features from "elsewhere": no entry point)
+            assert model.guard_state() is None
+            with torch.no_grad():
+                if entry == "siamese_forward":
+                    model.siamese_forward(s1, s2)
+                elif entry == "forward_inference":
+                    model.forward_inference(torch.cat([s1, s2]))
+                elif entry == "match_forward_inference":
+                    model.match_forward_inference(h1, h2, xyz1, xyz2)
+                else:
+                    pairs = torch.tensor([[0, 6], [1, 7]])
+                    model.match_gallery(torch.cat([h1, h2]), torch.cat([xyz1, xyz2]), pairs)
+            st = model.guard_state()
+            assert st is not None and st["dlogit"][st["level"]] <= engine.GUARD_BOUND, (entry, st)
+        # a REPLACED parameter (same shape, new object) is a new weight version (ADVICE r5 low: the cached tensor list)
+        w = model.match_head[1].weight
+        model.match_head[1].weight = torch.nn.Parameter(w.detach().clone())
+        assert model.guard_state() is None
+        model.load_state_dict({k: v.clone() for k, v in model.state_dict().items()}, assign=True)
+        assert model.guard_state() is None
+        with torch.no_grad():
+            model.siamese_forward(s1, s2)
+        assert model.guard_state() is not None
+        # PointNet returns a transformed xyz: a match-only call on an uncalibrated model runs the matching in f32
+        pn, _ = bench.build_model("pointnet", None)
+        p1, p2 = [t.cuda() for t in T.synthetic_pairs(3, 256, seed=4, kind="randn")]
+        with torch.no_grad(), engine.guard_level(0):
+            xyz1, xyz2, h1, h2 = pn._siamese_forward(p1, p2)
+        assert pn._match_level(xyz1, xyz2) == 2 and pn.guard_state() is None
+    with engine.precision("f32"):
+        model, _ = bench.build_pt_model([128, 64, 32])
+        with torch.no_grad():
+            model.siamese_forward(s1, s2)
+        assert model.guard_state() is None          # (nothing to guard in the reference's arithmetic)
+
+
+def test_sentinel_raises_the_level_before_a_hostile_batch_is_returned(monkeypatch):
+    """Batch 1 is benign, batch k is not: the weights are the shifted-statistics checkpoint that measured 9.7e-5 unguarded
+    (SSG, variance / 4, means x 3), the bound sits between the level-0 deviations of two live batches, the model is
+    calibrated (lazily) on the benign one and keeps level 0; when the hostile batch arrives the sentinel re-checks it
+    against the f32 path BEFORE computing it, raises the level of this weight version and the logits that come back are
+    inside the bound -- at no point is a returned logit off by more than the bound."""
+    import bench
+    from pcr_amd import engine
+    model, _ = bench.build_model("ssg", None)
+    sd = _rescale_bn(T.seeded_state_dict(T.manifest_of(model), 0), 0.25, 3.0)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    cands = []
+    for seed, scale in ((40, 0.1), (41, 0.5), (42, 1.0), (43, 2.0), (44, 10.0)):
+        a, b = T.synthetic_pairs(6, 1024, seed=seed, kind="box")
+        a, b = (a * scale).cuda(), (b * scale).cuda()
+        d, _ = _dev0(model, a, b)
+        cands.append((float(d.max()), a, b))
+    cands.sort(key=lambda c: c[0])
+    (d_lo, a1, a2), (d_hi, b1, b2) = cands[0], cands[-1]
+    print(json.dumps(dict(level0_deviation=[c[0] for c in cands])))
+    assert d_hi > 1.5 * d_lo > 0, (d_lo, d_hi)
+    bound = (d_lo * d_hi) ** 0.5
+    monkeypatch.setattr(engine, "GUARD_BOUND", bound)
+    monkeypatch.setattr(engine, "GUARD_EVERY", 1)
+    assert engine.GUARD_SENTINEL_PAIRS >= 6
+    with engine.precision("bf16x3"), torch.no_grad():
+        out = bench.hot_path(model, a1, a2)                          # batch 1: calibrates lazily, level 0
+        st = model.guard_state()
+        assert st["level"] == 0 and st["sentinel"]["checks"] == 0
+        out = bench.hot_path(model, a1, a2)                          # batch 2: sentinel check, still benign
+        st = model.guard_state()
+        assert st["level"] == 0 and st["sentinel"]["checks"] == 1 and st["sentinel"]["worst"] <= bound
+        with engine.precision("f32"):
+            ref = model._hot(b1, b2)
+        got = bench.hot_path(model, b1, b2)                          # batch k: hostile
+        st = model.guard_state()
+        assert st["level"] >= 1 and st["sentinel"]["raised"] and st["sentinel"]["raised"][0]["was"] == 0, st
+        assert float((got - ref).abs().max()) <= bound, (float((got - ref).abs().max()), bound, st)
+        # the level stays raised for this weight version (benign batches included) ...
+        bench.hot_path(model, a1, a2)
+        assert model.guard_state()["level"] == st["level"]
+        # ... and the sentinel switched off (PCR_GUARD_EVERY=0) would have let the hostile batch through
+        monkeypatch.setattr(engine, "GUARD_EVERY", 0)
+        model.calibrate_precision(a1, a2)
+        got0 = bench.hot_path(model, b1, b2)
+        assert model.guard_state()["level"] == 0 and float((got0 - ref).abs().max()) > bound
+    del out
+
+
+def test_sentinel_is_silent_inside_a_graph_capture_and_cheap():
+    """the bench's captured pass: nothing can be read back inside a capture, so the tick is a no-op there and the replay
+    equals the eager pass bit for bit; the default period is 64 batches"""
+    import bench
+    from pcr_amd import engine
+    assert engine.GUARD_EVERY == 64 and engine.GUARD_SENTINEL_PAIRS == 8
+    model, _ = bench.build_pt_model([128, 64, 32])
+    s1, s2 = [t.cuda() for t in T.synthetic_pairs(16, 128, seed=2, kind="randn")]
+    with engine.precision("bf16x3"), torch.no_grad():
+        ref = bench.hot_path(model, s1, s2)
+        calls = model.guard_state()["calls"]
+        step, mode = bench.graph_step(lambda: bench.hot_path(model, s1, s2))
+        assert mode == "hipgraph", mode
+        for _ in range(3):
+            out = step()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+        assert model.guard_state()["calls"] > calls          # (the eager pilot calls ticked; the capture and replays did not)
