@@ -241,9 +241,11 @@ def train_bench(args, desc, n, bl, pairs, rank, world, steps=None, warmup=None):
     # was the default.  (Round 5: the fused chains brought the step's GPU time down to about what the host needs to issue its ~400 launches --
     # inside the default run, after nine other workloads, the eager step measured 10.4 ms against 9.2 alone.  One rank
     # therefore times the REPLAYED iteration by default, a fixed mode like the inference lines'; PCR_TRAIN_GRAPH=0 keeps
-    # one launch per node; N > 1 ranks run eager -- Trainer says so -- and config.launch names what ran)
+    # one launch per node.  Round 6: N > 1 ranks replay too -- the logged loss scalars that mmdet all-reduces inside
+    # train_step ride in the tail of the gradient bucket, so the captured region holds no collective -- and config.launch
+    # names what ran)
     tr = train.Trainer(model, max_iters=steps + warmup + 3, lr=3e-4, grad_clip=1.0,
-                       graph=os.environ.get("PCR_TRAIN_GRAPH", "1") == "1" and warmup >= 2 and world == 1)
+                       graph=os.environ.get("PCR_TRAIN_GRAPH", "1") == "1" and warmup >= 2)
     tr.graph_warmup = 1          # iteration 0 eager, iteration 1 captures: both inside the W warm-up steps
     prewarm()
     # (a pilot of both ways like the inference lines' was tried: an eager step AFTER a replay runs on the trainer's own
@@ -309,8 +311,8 @@ def train_bench(args, desc, n, bl, pairs, rank, world, steps=None, warmup=None):
             "config": {"workload": "pt128_train: %s" % desc, "pairs_per_gpu_per_step": pairs, "points": n,
                        "backbone_list": bl, "parallelism": "data parallel x%d, one %d-byte gradient bucket per step"
                        % (world, tr.bucket.nbytes()), "rccl_ranks": world,
-                       "launch": "forward + backward replayed from one HIP graph, exchange + update eager" if graphed
-                       else "eager (one launch per node)"},
+                       "launch": "hipgraph: forward + backward replayed from one HIP graph, exchange + update eager"
+                       if graphed else "eager (one launch per node)"},
             "roofline": roof}
     del model, tr, data
     torch.cuda.empty_cache()

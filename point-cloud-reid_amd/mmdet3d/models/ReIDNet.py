@@ -624,12 +624,18 @@ class ReIDNet(nn.Module):
         # mmdet reduces and reads every entry on its own (one all-reduce + one .item() each); here the entries travel as
         # ONE stacked tensor: one all-reduce, one asynchronous copy, read on first access (pcr_amd/lazylog.py)
         import torch.distributed as dist
+        from pcr_amd import lazylog
         names = list(log_vars.keys())
         stacked = torch.stack([log_vars[k].detach().reshape(()).float() for k in names])
+        log_vars = LazyScalars()
         if dist.is_available() and dist.is_initialized():
+            if lazylog.DEFER_REDUCE:
+                # under pcr_amd.train.Trainer: averaged in the tail of the gradient bucket -- no collective inside the
+                # (capturable) forward + backward, one all-reduce per iteration in total
+                log_vars.add_device(names, stacked, reduce=True)
+                return loss, log_vars
             stacked = stacked.clone()
             dist.all_reduce(stacked.div_(dist.get_world_size()))
-        log_vars = LazyScalars()
         log_vars.add_device(names, stacked)
         return loss, log_vars
 

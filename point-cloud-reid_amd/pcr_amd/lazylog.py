@@ -11,6 +11,25 @@ from collections import OrderedDict
 
 import torch
 
+# True while a pcr_amd.train.Trainer runs the model's train_step on N > 1 ranks: the scalars mmdet's `_parse_losses`
+# averages over the ranks are NOT all-reduced on the spot (`add_device(.., reduce=True)` keeps them on the device); the
+# trainer averages them in the tail of its gradient bucket -- one collective per iteration, outside any graph capture.
+DEFER_REDUCE = False
+
+
+class defer_reduce:
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global DEFER_REDUCE
+        self.prev, DEFER_REDUCE = DEFER_REDUCE, self.on
+
+    def __exit__(self, *exc):
+        global DEFER_REDUCE
+        DEFER_REDUCE = self.prev
+        return False
+
 
 class LazyScalars(OrderedDict):
     """an OrderedDict whose pending entries live in device tensors until the first read"""
@@ -20,18 +39,25 @@ class LazyScalars(OrderedDict):
         super().__init__(*a, **kw)
 
     # ---- producer side ----
-    def add_device(self, names, values, ints=None):
-        """names: list of keys; values: 1-d tensor (same length) on any device; ints: per-key flag -> int(value)"""
+    def add_device(self, names, values, ints=None, reduce=False):
+        """names: list of keys; values: 1-d tensor (same length) on any device; ints: per-key flag -> int(value);
+        reduce: the values still have to be averaged over the ranks -- they stay on the device until `resolve` hands in
+        the averaged vector (eager) or ride as a flagged static entry (capture)"""
         names = list(names)
         ints = list(ints) if ints is not None else [False] * len(names)
         values = values.detach()
+        if reduce and not (values.is_cuda and torch.cuda.is_current_stream_capturing()):
+            for n in names:
+                OrderedDict.__setitem__(self, n, None)
+            self._deferred = getattr(self, "_deferred", []) + [(names, ints, values)]
+            return
         if values.is_cuda and torch.cuda.is_current_stream_capturing():
             # inside a HIP-graph capture (pcr_amd.train.Trainer(graph=True)): no host allocation, copy or event may be
             # recorded; the stacked values stay in their (static) device tensor and the trainer turns them into an
             # ordinary pending entry after every replay (`from_static`)
             for n in names:
                 OrderedDict.__setitem__(self, n, None)
-            self._static = getattr(self, "_static", []) + [(names, ints, values)]
+            self._static = getattr(self, "_static", []) + [(names, ints, values, bool(reduce))]
             return
         if values.is_cuda:
             host = torch.empty(values.shape, dtype=values.dtype).pin_memory()
@@ -45,8 +71,18 @@ class LazyScalars(OrderedDict):
         self._pending.append((names, ints, host, ev))
 
     def static_entries(self):
-        """(names, ints, device tensor) triples recorded during a graph capture"""
+        """(names, ints, device tensor, reduce flag) recorded during a graph capture"""
         return list(getattr(self, "_static", []))
+
+    def deferred(self):
+        """(names, ints, device tensor) of the entries that wait for their average over the ranks"""
+        return list(getattr(self, "_deferred", []))
+
+    def resolve(self, reduced):
+        """`reduced`: one averaged vector per deferred() entry, in order"""
+        pend, self._deferred = self.deferred(), []
+        for (names, ints, _), v in zip(pend, reduced):
+            self.add_device(names, v, ints)
 
     @classmethod
     def from_static(cls, plain, entries):
@@ -55,12 +91,15 @@ class LazyScalars(OrderedDict):
         out = cls()
         for k, v in plain:
             OrderedDict.__setitem__(out, k, v)
-        for names, ints, values in entries:
-            out.add_device(names, values, ints)
+        for e in entries:
+            out.add_device(e[0], e[2], e[1])
         return out
 
     # ---- consumer side ----
     def materialize(self):
+        if getattr(self, "_deferred", None):
+            # nobody averaged them (a train_step outside a Trainer while DEFER_REDUCE was set): this rank's own values
+            self.resolve([v for _, _, v in self.deferred()])
         pend, self._pending = self._pending, []
         for names, ints, host, ev in pend:
             if ev is not None:
@@ -95,6 +134,9 @@ class LazyScalars(OrderedDict):
         if isinstance(other, LazyScalars):          # keep the other's entries lazy too
             if getattr(other, "_static", None):
                 self._static = getattr(self, "_static", []) + other._static
+            if getattr(other, "_deferred", None):
+                self._deferred = getattr(self, "_deferred", []) + other._deferred
+                other._deferred = []
             pend, other._pending = other._pending, []
             for n in OrderedDict.keys(other):
                 OrderedDict.__setitem__(self, n, OrderedDict.__getitem__(other, n))

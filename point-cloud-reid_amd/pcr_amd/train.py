@@ -47,35 +47,52 @@ def cyclic_value(base, it, max_iters, target_ratio=(10.0, 1e-4), cyclic_times=1,
 
 
 class GradBucket:
-    """every existing gradient of `params` in one flat fp32 buffer: pack -> one all-reduce (sum) -> / world -> unpack"""
+    """every existing gradient of `params` in one flat fp32 buffer: pack -> one all-reduce (sum) -> / world -> unpack.
+    `extra`: small fp32 device vectors that must be averaged over the ranks in the same iteration (the logged loss
+    scalars of mmdet's `_parse_losses`) ride in the TAIL of the same buffer, so that the iteration still has ONE
+    collective -- and none of it inside the captured forward + backward (Trainer graph mode)."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         self.live = None
         self.flat = None
+        self.tail = 0
 
-    def _layout(self):
+    def _layout(self, tail=None):
+        tail = self.tail if tail is None else tail
         live = [p for p in self.params if p.grad is not None]
-        if self.live is None or len(live) != len(self.live) or any(a is not b for a, b in zip(live, self.live)):
-            self.live = live
+        if (self.live is None or len(live) != len(self.live) or any(a is not b for a, b in zip(live, self.live))
+                or tail != self.tail):
+            self.live, self.tail = live, tail
             n = sum(p.numel() for p in live)
             dev = live[0].device if live else torch.device("cpu")
-            self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+            self.flat = torch.zeros(n + tail, dtype=torch.float32, device=dev)
         return self.live
 
     def nbytes(self):
         return 0 if self.flat is None else self.flat.numel() * 4
 
-    def all_reduce_mean(self):
-        live = self._layout()
-        if not live or not shard.is_dist():
-            return
-        views = [v.view_as(p.grad) for v, p in zip(self.flat.split([p.numel() for p in live]), live)]
+    def all_reduce_mean(self, extra=()):
+        """-> the averaged `extra` vectors (fresh tensors; the inputs themselves on one rank)"""
+        extra = [e.detach().reshape(-1).float() for e in extra]
+        if not shard.is_dist():
+            self._layout()
+            return extra
+        live = self._layout(sum(e.numel() for e in extra))
+        if not live and not extra:
+            return extra
+        sizes = [p.numel() for p in live] + [e.numel() for e in extra]
+        parts = self.flat.split(sizes) if sizes else []
+        views = [v.view_as(p.grad) for v, p in zip(parts, live)]
         grads = [p.grad for p in live]
-        torch._foreach_copy_(views, grads)                 # pack: one multi-tensor launch, not one copy per tensor
+        tails = list(parts[len(live):])
+        if views or tails:
+            torch._foreach_copy_(views + tails, grads + extra)     # pack: one multi-tensor launch, not one copy per tensor
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self.flat.div_(dist.get_world_size())
-        torch._foreach_copy_(grads, views)
+        if views:
+            torch._foreach_copy_(grads, views)
+        return [t.clone() for t in tails]
 
 
 class Trainer:
@@ -150,18 +167,26 @@ class Trainer:
         grad_norm as a 0-d tensor on the parameters' device in BOTH optimizer paths -- `float()` it at log time, which is
         the only place it costs a host synchronisation; log_vars is a LazyScalars dict with the same property)."""
         lr, b1 = self._set_hyper()
-        if self.graph and shard.is_dist():
-            # (a captured log all-reduce was not attempted: N > 1 ranks run eager, and `self.graph` says so -- bench.py
-            # reports the launch mode from this flag)
-            import warnings
-            warnings.warn("pcr_amd.train.Trainer: HIP-graph replay is a single-process mode; running eager on %d ranks"
-                          % shard.env_world()[2])
-            self.graph = False
-        if self.graph and self.iter >= self.graph_warmup:
-            out = self._graph_step(data)
-            if out is not None:
+        # N > 1 ranks: mmdet's `_parse_losses` all-reduces the logged loss scalars inside train_step -- a collective in the
+        # middle of the captured region.  Here the model DEFERS them (lazylog.DEFER_REDUCE) and they travel in the tail
+        # of the gradient bucket: still ONE collective per iteration, none of it captured, and graph replay works on any
+        # number of ranks (round 6; until round 5 N > 1 ranks fell back to the eager step).  With gradient accumulation
+        # the exchange does not happen every iteration, so the scalars keep their own small all-reduce there.
+        from . import lazylog
+        defer = shard.is_dist() and self.cumulative_iters == 1
+        # (graph_warmup >= 1 is enforced: the fused chains register their weights' bf16 images on the first EAGER
+        # iteration; a capture of iteration 0 would bake their on-the-spot pack launches into every replay -- ADVICE r5)
+        if self.graph and self.iter >= max(1, self.graph_warmup):
+            with lazylog.defer_reduce(defer):
+                got = self._graph_step(data)
+            if got is not None:
+                out, (plain, entries) = got
                 out["lr"], out["beta1"] = lr, b1
-                self.bucket.all_reduce_mean()
+                idx = [i for i, e in enumerate(entries) if e[3]]
+                reduced = dict(zip(idx, self.bucket.all_reduce_mean([entries[i][2] for i in idx])))
+                if entries:
+                    out["log_vars"] = lazylog.LazyScalars.from_static(
+                        plain, [(n, ints, reduced.get(i, v)) for i, (n, ints, v, _) in enumerate(entries)])
                 norm = self.optimizer.step(max_norm=self.grad_clip)
                 if norm is not None:
                     out["grad_norm"] = norm
@@ -172,11 +197,16 @@ class Trainer:
         if self.fused:
             from . import train_ops
             train_ops.prepack(self.model)      # every weight's packed images in one launch (they changed last step)
-        out = self.model.train_step(data, self.optimizer)
+        with lazylog.defer_reduce(defer):
+            out = self.model.train_step(data, self.optimizer)
         (out["loss"] / self.cumulative_iters).backward()
         out["lr"], out["beta1"] = lr, b1
         if (self.iter + 1) % self.cumulative_iters == 0:
-            self.bucket.all_reduce_mean()
+            lv = out.get("log_vars")
+            pend = lv.deferred() if isinstance(lv, lazylog.LazyScalars) else []
+            reduced = self.bucket.all_reduce_mean([v for _, _, v in pend])
+            if pend:
+                lv.resolve(reduced)
             if self.fused:
                 norm = self.optimizer.step(max_norm=self.grad_clip)     # a device scalar: no host round trip
                 if norm is not None:
@@ -191,7 +221,9 @@ class Trainer:
 
     # ---- HIP-graph replay of forward + backward ----
     def _graph_step(self, data):
-        """-> the iteration's outputs from the captured graph, or None (graph mode switched off: the caller runs eager)"""
+        """-> (the iteration's outputs from the captured graph, (plain log items, static log entries)) -- the caller turns
+        the entries into the iteration's log_vars after the exchange, which averages the ones flagged for it -- or None
+        (graph mode switched off: the caller runs eager)"""
         from . import lazylog, train_ops
         keys = [k for k, v in data.items() if isinstance(v, (list, tuple)) and v and torch.is_tensor(v[0])]
         sig = self._graph_signature(data, keys)
@@ -242,9 +274,7 @@ class Trainer:
         # the captured outputs are STATIC tensors that the next replay overwrites: the caller gets its own copies (eager
         # iterations hand out fresh tensors too; a caller may hold several iterations' losses before reading any)
         out = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in g["out"].items()}
-        if g["entries"]:
-            out["log_vars"] = lazylog.LazyScalars.from_static(g["plain"], g["entries"])
-        return out
+        return out, (g["plain"], g["entries"])
 
     def _graph_signature(self, data, keys):
         """everything a captured iteration has baked in and a replay cannot see change: the shape and dtype of EVERY

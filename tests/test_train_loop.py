@@ -129,3 +129,73 @@ def test_two_rank_gradient_exchange(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+class ToyParsed(Toy):
+    """the same model logging through the reference's path: ReIDNet._parse_losses (mmdet's all-reduce of the log scalars)"""
+
+    def train_step(self, data, optimizer):
+        from mmdet3d.models.ReIDNet import ReIDNet
+        y = self.b(torch.tanh(self.a(data["x"]))).squeeze(1)
+        loss, log_vars = ReIDNet._parse_losses({"reid_loss": torch.nn.functional.binary_cross_entropy_with_logits(y, data["t"])})
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data["t"]))
+
+
+WORKER_LOG = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, os.path.join(%r, "point-cloud-reid_amd"))
+    sys.path.insert(0, os.path.join(%r, "tests"))
+    import torch, torch.distributed as dist
+    from pcr_amd import shard, train
+    import test_train_loop as T
+    rank, local, world = shard.init(backend="gloo")
+    calls = []
+    real = dist.all_reduce
+    def counted(t, *a, **k):
+        calls.append(t.numel())
+        return real(t, *a, **k)
+    dist.all_reduce = counted
+    m = T.ToyParsed()
+    tr = train.Trainer(m, max_iters=4, lr=1e-2, grad_clip=0.5)
+    for b in T._batches():
+        lo, hi = shard.shard_range(8, rank, world)
+        n0 = len(calls)
+        out = tr.step(dict(x=b["x"][lo:hi], t=b["t"][lo:hi]))
+        assert len(calls) == n0 + 1, calls                          # ONE collective per iteration: gradients + log scalars
+        mine = torch.tensor([float(out["loss"])], dtype=torch.float64)
+        both = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        mean = float((both[0] + both[1]) / 2)
+        assert abs(out["log_vars"]["loss"] - mean) < 1e-6 and abs(out["log_vars"]["reid_loss"] - mean) < 1e-6
+        assert abs(float(both[0]) - float(both[1])) > 1e-4          # (the ranks really saw different shards)
+    assert tr.bucket.tail == 2 and calls[-1] == (6 * 8 + 8 + 8 + 1) + 2
+    # outside a Trainer the model keeps mmdet's behaviour: its own all-reduce of the log scalars
+    n0 = len(calls)
+    out = m.train_step(dict(x=T._batches()[0]["x"], t=T._batches()[0]["t"]), None)
+    assert len(calls) == n0 + 1 and calls[-1] == 2 and not out["log_vars"].deferred()
+    # gradient accumulation: no exchange every iteration, so the scalars keep their own collective
+    tr2 = train.Trainer(T.ToyParsed(), max_iters=4, lr=1e-2, cumulative_iters=2)
+    n0 = len(calls)
+    tr2.step(dict(x=T._batches()[0]["x"], t=T._batches()[0]["t"]))
+    assert calls[n0:] == [2], calls[n0:]
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.stdout.write("rank %%d ok\\n" %% rank); sys.stdout.flush()
+""")
+
+
+def test_two_rank_log_scalars_ride_in_the_gradient_bucket(tmp_path):
+    """the log-scalar all-reduce of `_parse_losses` is hoisted out of the (capturable) forward +
+    backward into the tail of the gradient bucket -- one collective per iteration, same logged values"""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER_LOG % (ROOT, ROOT))
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
