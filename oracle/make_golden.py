@@ -473,6 +473,77 @@ def gen_python_twins():
     print("twins", fps.shape, ball.shape, knn.shape)
 
 
+
+def cuda_semantics_cases():
+    """the hand-built tie / boundary inputs of tests/golden/ops_cuda_semantics.npz: integer or dyadic coordinates, so
+    that every distance is exact in binary32 and the ties are real (no dependence on fma contraction)"""
+    rng = np.random.RandomState(20261005)
+    cases = {}
+    # ---- FPS (furthest_point_sample_cuda.cu:17-23, 56-71): non-power-of-two N, N > 1024, exact ties, duplicates ----
+    a = np.zeros((1, 12, 3), np.float32)
+    a[0, 1:, 0] = 1.0                                             # test_oracle_ops' [0, 8, 0] case
+    b = rng.randint(0, 3, size=(2, 12, 3)).astype(np.float32)     # block 8, heavy duplication
+    lat = np.stack(np.meshgrid(np.arange(5), np.arange(5), np.arange(4), indexing="ij"), -1).reshape(-1, 3)
+    c = np.stack([lat[rng.permutation(100)], lat[rng.permutation(100)]]).astype(np.float32)      # N = 100: block 64
+    d = rng.randint(0, 14, size=(1, 3000, 3)).astype(np.float32)  # N = 3000: block 1024, three strided rounds per thread
+    e = rng.randint(0, 6, size=(1, 1024, 3)).astype(np.float32)   # power of two, duplicates everywhere
+    for name, xyz, m in (("fps_n12", a, 3), ("fps_n12_dup", b, 9), ("fps_n100", c, 24), ("fps_n3000", d, 40),
+                         ("fps_n1024_dup", e, 32)):
+        cases[name] = dict(kind="fps", xyz=xyz, m=m)
+    dl = c[0][:, None, :] - c[0][None, :, :]
+    cases["fpsd_n100"] = dict(kind="fps_dist", dist=(dl * dl).sum(-1)[None].astype(np.float32), m=16)
+    cases["fpsd_n40_asym"] = dict(kind="fps_dist", dist=rng.randint(0, 9, size=(2, 40, 40)).astype(np.float32), m=12)
+    # ---- ball query (ball_query_cuda.cu:38-52): d2 == max_r^2 excluded, d2 == min_r^2 included, d2 == 0 always
+    # included (also below min_r), first nsample by index, padded with the first hit, zeros when nothing is in range ----
+    g = (np.stack(np.meshgrid(np.arange(4), np.arange(4), np.arange(4), indexing="ij"), -1).reshape(-1, 3) * 0.25)
+    g = g[rng.permutation(64)].astype(np.float32)
+    pts = np.concatenate([g, g[:8]], 0)[None]                     # 72 points, the first 8 lattice points twice
+    ctr = np.concatenate([g[:10], np.array([[9, 9, 9], [0.125, 0.125, 0.125]], np.float32)], 0)[None]
+    for name, lo, hi, k in (("bq_r050", 0.0, 0.5, 5), ("bq_r100_k16", 0.0, 1.0, 16), ("bq_min050_r075", 0.5, 0.75, 6),
+                            ("bq_min025_r025", 0.25, 0.25, 4)):
+        cases[name] = dict(kind="ball", xyz=pts, centres=ctr, min_r=lo, max_r=hi, k=k)
+    # ---- heap kNN (knn_cuda.cu:27-94): equal distances leave the heap in the order its sift sequence produces ----
+    for name, k, nq in (("knn_k8", 8, 12), ("knn_k1", 1, 12), ("knn_k64_all", 64, 4), ("knn_k100", 100, 3)):
+        cases[name] = dict(kind="knn", xyz=pts if k <= 72 else np.concatenate([pts, pts], 1), centres=ctr[:, :nq], k=k)
+    # ---- three_nn (three_nn_cuda.cu:11-65): strict '<' cascade on equal distances, float d against double bests ----
+    cases["nn3_lattice"] = dict(kind="three_nn", unknown=ctr, known=pts)
+    cases["nn3_three_known"] = dict(kind="three_nn", unknown=ctr, known=pts[:, :3])
+    cases["nn3_two_known"] = dict(kind="three_nn", unknown=ctr, known=pts[:, :2])     # the third best stays 1e40 -> +inf, index 0
+    return cases
+
+
+def gen_cuda_semantics():
+    """tests/golden/ops_cuda_semantics.npz: expected outputs of the reference's dormant CUDA ops on tie / boundary inputs
+    the Python twins cannot cover, produced by oracle/cuda_sim.py -- a thread-faithful simulation of the .cu kernels'
+    execution (block / tid loops, shared arrays, barrier phases), independent of the C oracle.  Needs no reference import:
+    the kernels are CUDA and cannot run anywhere in this build; the simulator IS the second transliteration."""
+    import cuda_sim as S
+    out = {}
+    meta = {}
+    for name, c in cuda_semantics_cases().items():
+        kind = c["kind"]
+        if kind == "fps":
+            out[name + "_xyz"], out[name + "_idx"] = c["xyz"], S.fps(c["xyz"], c["m"])
+            meta[name] = dict(kind=kind, m=c["m"], block=S.launch_block_size(c["xyz"].shape[1]))
+        elif kind == "fps_dist":
+            out[name + "_dist"], out[name + "_idx"] = c["dist"], S.fps_with_dist(c["dist"], c["m"])
+            meta[name] = dict(kind=kind, m=c["m"], block=S.launch_block_size(c["dist"].shape[1]))
+        elif kind == "ball":
+            out[name + "_xyz"], out[name + "_centres"] = c["xyz"], c["centres"]
+            out[name + "_idx"] = S.ball_query(c["min_r"], c["max_r"], c["k"], c["xyz"], c["centres"])
+            meta[name] = dict(kind=kind, min_r=c["min_r"], max_r=c["max_r"], k=c["k"])
+        elif kind == "knn":
+            out[name + "_xyz"], out[name + "_centres"] = c["xyz"], c["centres"]
+            out[name + "_idx"], out[name + "_d2"] = S.knn(c["k"], c["xyz"], c["centres"])
+            meta[name] = dict(kind=kind, k=c["k"])
+        else:
+            out[name + "_unknown"], out[name + "_known"] = c["unknown"], c["known"]
+            out[name + "_d2"], out[name + "_idx"] = S.three_nn(c["unknown"], c["known"])
+            meta[name] = dict(kind=kind)
+        print("cuda semantics", name, meta[name])
+    np.savez_compressed(os.path.join(GOLD, "ops_cuda_semantics.npz"), meta=np.array(json.dumps(meta)), **out)
+
+
 def gen_eval_metric():
     """val_match_acc (reidentification_base.py:104) and the reference's own MatchingEval.f1_precision_recall
     (datasets/utils.py:254-277) on a seeded (logits, gt) sample"""
@@ -600,6 +671,9 @@ if __name__ == "__main__":
     if "--only-train-loop" in sys.argv:
         gen_train_loop()
         sys.exit(0)
+    if "--only-cuda-semantics" in sys.argv:
+        gen_cuda_semantics()
+        sys.exit(0)
     if "--only-mul" in sys.argv:
         gen_pt_mul()
     if "--only-train-step" in sys.argv:
@@ -620,6 +694,7 @@ if __name__ == "__main__":
     gen_train_variants()
     gen_train_loop()
     gen_python_twins()
+    gen_cuda_semantics()
     gen_eval_metric()
     gen_eval_tables()
     gen_pairs()

@@ -236,3 +236,36 @@ def test_python_ball_query_twin_matches_oracle(B, N, S, K, radius, kind):
     safe = ((d - radius ** 2).abs() > 1e-5 * max(1.0, radius ** 2)).all(dim=-1)
     assert safe.float().mean() > 0.9
     assert torch.equal(got[safe], want[safe])
+
+
+def test_hip_ops_equal_the_simulated_execution_of_the_cuda_kernels(ops):
+    """tests/golden/ops_cuda_semantics.npz (oracle/cuda_sim.py: the .cu kernels' block / tid loops simulated thread by
+    thread, independent of the C oracle): exact ties, N = 12 / 100 / 3000, points at exactly r, d2 == 0 below min_r, heaps
+    of equal distances, fewer than three known points -- the HIP ops must reproduce every index (and every squared
+    distance) bit for bit.  VERDICT r5 next 9a."""
+    from test_oracle_ops import _cuda_cases, run_cuda_case
+
+    def knn(k, xyz, c):
+        idx = ops.knn(k, dev(xyz), dev(c), False).cpu().numpy().transpose(0, 2, 1)      # (B,k,M) -> (B,M,k)
+        # the op returns indices only (KNN.forward, knn.py:16-64); the distances of the golden follow from them
+        d = np.take_along_axis(xyz[:, None, :, :].repeat(c.shape[1], 1), idx[..., None].astype(np.int64).repeat(3, -1), 2) \
+            - c[:, :, None, :]
+        d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+        return np.ascontiguousarray(idx), d2.astype(np.float32)
+
+    def three_nn(unk, kn):
+        dist, idx = ops.three_nn(dev(unk), dev(kn))
+        return (dist * dist).cpu().numpy(), idx.cpu().numpy()      # (sqrt of dyadic squares: exact both ways; inf stays inf)
+    g, meta = _cuda_cases()
+    for name, m in meta.items():
+        pairs = run_cuda_case(
+            name, m, g,
+            lambda xyz, mm: ops.furthest_point_sample(dev(xyz), mm).cpu().numpy(),
+            lambda dist, mm: ops.furthest_point_sample_with_dist(dev(dist), mm).cpu().numpy(),
+            lambda lo, hi, k, xyz, c: ops.ball_query(lo, hi, k, dev(xyz), dev(c)).cpu().numpy(),
+            knn, three_nn)
+        for got, want in pairs:
+            if name.startswith("nn3") and want.dtype == np.float32:
+                assert np.allclose(got, want, rtol=2e-7, atol=0) and (np.isinf(got) == np.isinf(want)).all(), name
+            else:
+                assert got.dtype == want.dtype and np.array_equal(got, want), name

@@ -106,3 +106,63 @@ def test_gather_group_interp_roundtrip():
     assert np.allclose(o[0, 1, 2], (w[0, 2] * f2[0, 1, i3[0, 2]]).sum(), atol=1e-6)
     gr = g.standard_normal(o.shape).astype(np.float32)
     assert abs((o.astype(np.float64) * gr).sum() - (f2.astype(np.float64) * P.three_interp_bwd(gr, i3, w, 6)).sum()) < 1e-3
+
+
+# ---- round 6: the tie / boundary rules of the CUDA kernels, pinned by a vector --------------
+# tests/golden/ops_cuda_semantics.npz holds the outputs of oracle/cuda_sim.py -- a thread-faithful simulation of the .cu
+# kernels' EXECUTION (one object per CUDA thread, the shared arrays, the barrier phases; furthest_point_sample_cuda.cu:
+# 17-141,213-331, ball_query_cuda.cu:11-54, knn_cuda.cu:27-94, three_nn_cuda.cu:11-65), written independently of the C
+# oracle -- on inputs with exact ties (integer / dyadic lattices, duplicated points), non-power-of-two N, N > 1024, points
+# at exactly r, d2 == 0 below min_r, heaps full of equal distances, fewer than three known points.
+def _cuda_cases():
+    import json
+    g = load_golden("ops_cuda_semantics")
+    meta = g["meta"] if isinstance(g["meta"], dict) else json.loads(str(g["meta"]))
+    return g, meta
+
+
+def run_cuda_case(name, m, g, fps, fps_dist, ball_query, knn, three_nn):
+    """-> list of (got, want) array pairs for one case, through the five callables (C oracle here, HIP ops on the GPU)"""
+    k = m["kind"]
+    if k == "fps":
+        return [(fps(g[name + "_xyz"], m["m"]), g[name + "_idx"])]
+    if k == "fps_dist":
+        return [(fps_dist(g[name + "_dist"], m["m"]), g[name + "_idx"])]
+    if k == "ball":
+        return [(ball_query(m["min_r"], m["max_r"], m["k"], g[name + "_xyz"], g[name + "_centres"]), g[name + "_idx"])]
+    if k == "knn":
+        i, d = knn(m["k"], g[name + "_xyz"], g[name + "_centres"])
+        return [(i, g[name + "_idx"]), (d, g[name + "_d2"])]
+    d, i = three_nn(g[name + "_unknown"], g[name + "_known"])
+    return [(i, g[name + "_idx"]), (d, g[name + "_d2"])]
+
+
+def test_c_oracle_equals_the_simulated_execution_of_the_cuda_kernels():
+    g, meta = _cuda_cases()
+    assert {m["kind"] for m in meta.values()} == {"fps", "fps_dist", "ball", "knn", "three_nn"} and len(meta) >= 18
+    for name, m in meta.items():
+        for got, want in run_cuda_case(name, m, g, P.fps, P.fps_dist, P.ball_query, P.knn, P.three_nn):
+            assert got.dtype == want.dtype and np.array_equal(got, want), name
+    # the cases really exercise what the Python twins cannot: ties broken away from the lowest index, a block of 1024
+    # threads over 3000 points, the strict upper boundary, d2 == 0 below min_r, an infinite third neighbour
+    assert g["fps_n12_idx"].tolist() == [[0, 8, 0]] and meta["fps_n3000"]["block"] == 1024 and meta["fps_n100"]["block"] == 64
+    xyz, c = g["bq_min025_r025_xyz"][0], g["bq_min025_r025_centres"][0]
+    assert (g["bq_min025_r025_idx"][0, 0] == [0, 64, 0, 0]).all() and np.array_equal(xyz[0], xyz[64]) and np.array_equal(c[0], xyz[0])
+    assert (g["bq_r050_idx"][0, 10] == 0).all()                          # the far centre: nothing in range, zeros
+    d = np.linalg.norm(g["bq_r050_xyz"][0][:, None] - g["bq_r050_centres"][0][None], axis=-1)
+    assert (d == 0.5).sum() > 10                                         # points at exactly r exist (and are excluded)
+    assert np.isinf(g["nn3_two_known_d2"][..., 2]).all() and (g["nn3_two_known_idx"][..., 2] == 0).all()
+    tied = g["knn_k8_d2"][0]
+    assert (np.diff(tied, axis=-1) == 0).sum() > 20                      # equal distances inside the returned heaps
+
+
+def test_the_vectors_are_what_the_simulator_produces():
+    """the committed file is reproducible from oracle/cuda_sim.py (cheap cases re-simulated here), and the simulator's
+    launch shape follows the launcher's opt_n_threads"""
+    import cuda_sim as S
+    g, meta = _cuda_cases()
+    for n, want in [(1, 1), (3, 2), (12, 8), (100, 64), (1000, 512), (1024, 1024), (3000, 1024)]:
+        assert S.launch_block_size(n) == want
+    for name in ("fps_n12", "fps_n12_dup", "fps_n100", "fpsd_n40_asym", "bq_min050_r075", "knn_k8", "nn3_lattice"):
+        for got, want in run_cuda_case(name, meta[name], g, S.fps, S.fps_with_dist, S.ball_query, S.knn, S.three_nn):
+            assert np.array_equal(got, want), name
