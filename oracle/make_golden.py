@@ -494,13 +494,14 @@ def cuda_semantics_cases():
     cases["fpsd_n100"] = dict(kind="fps_dist", dist=(dl * dl).sum(-1)[None].astype(np.float32), m=16)
     cases["fpsd_n40_asym"] = dict(kind="fps_dist", dist=rng.randint(0, 9, size=(2, 40, 40)).astype(np.float32), m=12)
     # ---- ball query (ball_query_cuda.cu:38-52): d2 == max_r^2 excluded, d2 == min_r^2 included, d2 == 0 always
-    # included (also below min_r), first nsample by index, padded with the first hit, zeros when nothing is in range ----
+    # included (also below min_r), first nsample by index, padded with the first hit, zeros when nothing is in range
+    # (min_r < max_r always: BallQuery.forward asserts it, ball_query.py:31) ----
     g = (np.stack(np.meshgrid(np.arange(4), np.arange(4), np.arange(4), indexing="ij"), -1).reshape(-1, 3) * 0.25)
     g = g[rng.permutation(64)].astype(np.float32)
     pts = np.concatenate([g, g[:8]], 0)[None]                     # 72 points, the first 8 lattice points twice
     ctr = np.concatenate([g[:10], np.array([[9, 9, 9], [0.125, 0.125, 0.125]], np.float32)], 0)[None]
     for name, lo, hi, k in (("bq_r050", 0.0, 0.5, 5), ("bq_r100_k16", 0.0, 1.0, 16), ("bq_min050_r075", 0.5, 0.75, 6),
-                            ("bq_min025_r025", 0.25, 0.25, 4)):
+                            ("bq_min025_r030", 0.25, 0.3, 8)):
         cases[name] = dict(kind="ball", xyz=pts, centres=ctr, min_r=lo, max_r=hi, k=k)
     # ---- heap kNN (knn_cuda.cu:27-94): equal distances leave the heap in the order its sift sequence produces ----
     for name, k, nq in (("knn_k8", 8, 12), ("knn_k1", 1, 12), ("knn_k64_all", 64, 4), ("knn_k100", 100, 3)):

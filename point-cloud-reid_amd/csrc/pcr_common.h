@@ -193,3 +193,36 @@ __device__ __forceinline__ unsigned long long pcr_wave_sort_u64(unsigned long lo
 #undef PCR_STEP64
   return ((unsigned long long)hi << 32) | lo;
 }
+
+// ---- MFMA token (round 6).  The counters say the wave-autonomous kernels overlap almost nothing: matrix pipe busy 0.57 +
+// VALU issue 0.31 of a launch's cycles with 0.10 of them in both states (SQ_VALU_MFMA_COEXEC_CYCLES; 0.014 for the kv
+// kernel) -- the two waves of a SIMD run the same phases on equal blocks and fall into step, so the VALU phase of one
+// does not sit under the MFMA phase of the other.  A token per SIMD (an LDS word: the waves of a workgroup that share a
+// SIMD are found by HW_ID.SIMD_ID) makes the matrix phases of the SIMD's waves mutually exclusive: while one wave holds
+// it and runs layers 2 / 3, the other gathers, seeds, splits, reduces -- or sleeps at the gate.
+// Measured (tools/scratch/probe_coexec*.hip, one wave per SIMD with an instruction-level interleave): under a running
+// v_mfma_f32_32x32x16_bf16 integer / transcendental / LDS instructions are nearly free, plain f32 VALU instructions keep
+// about two of their three cycles, packed f32 instructions (v_pk_add / mul / fma_f32) hide NOTHING -- the matrix pipe and
+// the f32 vector lanes are one datapath.  So the token buys what the integer part of the other wave's VALU phase is worth:
+// sa_stream_kernel<4,4> 2.20-2.26 -> 2.06-2.09 ms (pt1024 SA3, same bits); the attention stream kernels (four short matrix
+// phases per block, f32-heavy LayerNorm / normaliser between them) gain nothing from it (measured: 0 to -2 %): not used there.
+__device__ __forceinline__ int pcr_simd_id() { return __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4); }   // HW_ID[5:4]
+__device__ __forceinline__ void mfma_token_acquire(int *tok, int lane) {
+  if (!tok) return;
+  __builtin_amdgcn_sched_barrier(0);
+  int busy;
+  do {
+    int old = 1;
+    if (lane == 0) old = atomicCAS(tok, 0, 1);
+    busy = __builtin_amdgcn_readfirstlane(old);
+    if (busy) __builtin_amdgcn_s_sleep(1);
+  } while (busy);
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void mfma_token_release(int *tok, int lane) {
+  if (!tok) return;
+  __builtin_amdgcn_sched_barrier(0);
+  if (lane == 0) __hip_atomic_store(tok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __builtin_amdgcn_sched_barrier(0);
+}
+

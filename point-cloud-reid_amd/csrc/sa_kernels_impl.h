@@ -474,15 +474,15 @@ struct SasBlock {
   __device__ static __forceinline__ void run(const float *xyz, const float *pq, int pqw, int qoff, bool has_q, int i, int ci,
                                              const float *s_sh1, const float *s_sh2, const float *s_sh3, const f32x4 *s_wa,
                                              const bf16x8 *s_w2, const bf16x8 *s_w3, int lane, f32x16 (&y3)[NCB3],
-                                             unsigned long long *tr = nullptr) {
+                                             unsigned long long *tr = nullptr, int *tok = nullptr) {
     const float dxv = xyz[i * 3] - xyz[ci * 3], dyv = xyz[i * 3 + 1] - xyz[ci * 3 + 1], dzv = xyz[i * 3 + 2] - xyz[ci * 3 + 2];
-    run_d(dxv, dyv, dzv, pq, pqw, qoff, has_q, i, ci, s_sh1, s_sh2, s_sh3, s_wa, s_w2, s_w3, lane, y3, tr);
+    run_d(dxv, dyv, dzv, pq, pqw, qoff, has_q, i, ci, s_sh1, s_sh2, s_sh3, s_wa, s_w2, s_w3, lane, y3, tr, tok);
   }
   // the same with the row's point - centre given (the ball query's row table holds it)
   __device__ static __forceinline__ void run_d(float dxv, float dyv, float dzv, const float *pq, int pqw, int qoff, bool has_q,
                                                int i, int ci, const float *s_sh1, const float *s_sh2, const float *s_sh3,
                                                const f32x4 *s_wa, const bf16x8 *s_w2, const bf16x8 *s_w3, int lane,
-                                               f32x16 (&y3)[NCB3], unsigned long long *tr = nullptr) {
+                                               f32x16 (&y3)[NCB3], unsigned long long *tr = nullptr, int *tok = nullptr) {
 #ifdef PCR_SA_TRACE_BUILD   // (diagnostic builds: tr = the caller's record of this block, marks 6 / 7 = layer 1 / layer 2 done)
 #define PCR_BMARK(m) do { if (tr) tr[m] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -570,6 +570,7 @@ struct SasBlock {
       layer1(std::false_type{}, std::false_type{});
     }
     PCR_BMARK(6);
+    mfma_token_acquire(tok, lane);
     // ---- layer 2 (normal orientation: its accumulators convert into layer 3's operand)
     {
       f32x16 y[NCB];
@@ -582,6 +583,9 @@ struct SasBlock {
           for (int q2 = 0; q2 < 4; q2++) y[cb][4 * g + q2] = s4[q2];
         }
       const bf16x8 *wb = s_w2 + lane;
+      // (round 6, measured and dropped: requesting step s2 + 1's weight units before the MFMAs of step s2 -- hi units
+      // double-buffered, +16 registers -- made the three K-row launches of pt1024 0-5 % SLOWER: the other wave's MFMAs
+      // already cover a wave's LDS round trips)
 #pragma unroll
       for (int s2 = 0; s2 < NS; s2++) {
         bf16x8 wh[NCB], wl[NCB];
@@ -636,6 +640,7 @@ struct SasBlock {
 #pragma unroll
       for (int cb = 0; cb < NCB3; cb++) y3[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[s2], wh[cb], y3[cb], 0, 0, 0);
     }
+    mfma_token_release(tok, lane);
   }
 };
 
@@ -680,7 +685,13 @@ void sa_stream_kernel(Sa2Args a, int nblk_item, int ncen_item) {
   float *s_gm = reinterpret_cast<float *>(smem) + L::kFixed / 4;   // [waves][6 groups][C3] group maxima of the wave's item
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int *s_tok = reinterpret_cast<int *>(s_gm + kSasWaves * 6 * C3);   // [4 SIMDs] MFMA tokens
+  if (tid < 4) s_tok[tid] = 0;
   sas_stage<NCB, NCB3>(smem, a.wp2, a.wp3, a.sh1, a.sh2, a.sh3, a.wap, 64 * kSasWaves);
+  // on for the shapes that run two waves per SIMD (128-wide layers; measured -6..-9 % on pt1024's SA3 launch, same bits);
+  // with four waves per SIMD (two workgroups, two tokens) the narrow shapes gain 0-1.5 %: off.  (PCR_SA_DBG bit 1024 of a
+  // tuning build flips the choice; releasing the token for the relu / split between the two layers was measured too: no gain)
+  int *tok = ((NCB + NCB3 >= 6) != ((a.dbg & 1024) != 0)) ? s_tok + pcr_simd_id() : nullptr;
   const int K = a.K, gpc = K >> 4;                      // 16-row groups per centre
   const int nitem = (a.S + ncen_item - 1) / ncen_item;  // items per cloud
   float *gm = s_gm + wave * 6 * C3;
@@ -744,7 +755,7 @@ void sa_stream_kernel(Sa2Args a, int nblk_item, int ncen_item) {
       else if (qi + wstride < nq) fetch_rows(bq, item, 0);
       f32x16 y[NCB3];
       SasBlock<NCB, NCB3, LO>::run(xyz, pq, a.pqw, a.qoff, has_q, i, ci, s_sh, s_sh + C, s_sh + 2 * C, s_wa, s_w2, s_w3, lane, y,
-                                   PCR_STR());
+                                   PCR_STR(), tok);
       PCR_SMARK(1);
       // the maximum over a 16-row group = a maximum over eight of the lane's OWN registers plus one exchange with its
       // partner lane (20 instructions per cout block; the token-per-lane form needs a 4-step DPP reduction of every
@@ -2096,7 +2107,7 @@ static bool sas_shape_ok(const pcr_sa_params &p, bool ragged) {
   if (no_stream || p.B < 1 || !p.wa_packed || p.c1 != p.c2 || !(p.c3 == p.c2 || p.c3 == 2 * p.c2) ||
       !(p.c1 == 32 || p.c1 == 64 || p.c1 == 128) || !sas_k_ok(p.K))
     return false;
-  const size_t lds_k = sas_fixed_lds(p) + (size_t)kSasWaves * 6 * p.c3 * 4;
+  const size_t lds_k = sas_fixed_lds(p) + (size_t)kSasWaves * 6 * p.c3 * 4 + 16;
   const size_t lds_r = sas_fixed_lds(p) + (size_t)kSasWaves * sas_rag_wave_ints(p.c3, p.K, false) * 4;
   const size_t cap = (size_t)160 * 1024;
   if ((long)p.B * p.S >= 0x7FFFFFFFl) return false;    // (the kernels count items in 32 bits)
@@ -2408,7 +2419,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
       if ((32 * nb) % p.K == 0 && (!nblk_item || small_items)) { nblk_item = nb; ncen_item = 32 * nb / p.K; }
     const size_t fixed = ((size_t)(2 * ncb) * ncb * 128 + (size_t)(2 * ncb) * ncb3 * 128) * 16 + (size_t)(2 * p.c1 + p.c3) * 4 +
                          (size_t)ncb * 64 * 16;
-    const size_t lds_s = fixed + (size_t)kSasWaves * 6 * p.c3 * 4;
+    const size_t lds_s = fixed + (size_t)kSasWaves * 6 * p.c3 * 4 + 16;   // (+ the four MFMA tokens)
     (void)no_stream;
     if (maxe && nblk_item && sas_shape_ok(p, false)) {
       static const int ncu = [] {

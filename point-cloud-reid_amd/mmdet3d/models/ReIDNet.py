@@ -218,6 +218,7 @@ class ReIDNet(nn.Module):
         dl, level = {}, 0
         if engine.PRECISION == "bf16x3" and not self.training:
             self.__dict__["_pcr_guard_busy"] = True
+            prof, engine.PROFILE = engine.PROFILE, None          # (the guard's own passes are not part of a profiled pass)
             try:
                 with torch.no_grad():
                     with engine.precision("f32"):
@@ -229,6 +230,7 @@ class ReIDNet(nn.Module):
                             break
             finally:
                 self.__dict__["_pcr_guard_busy"] = False
+                engine.PROFILE = prof
         st = dict(key=self._weights_key(), level=level, dlogit=dl, bound=bound, pairs=int(s1.shape[0]), calls=0,
                   sentinel=dict(every=engine.GUARD_EVERY, checks=0, worst=0.0, raised=[]))
         self.__dict__["_pcr_guard"] = st
@@ -244,6 +246,7 @@ class ReIDNet(nn.Module):
         lo = (sen["checks"] * m) % max(1, int(c1.shape[0]) - m + 1)
         s1, s2 = c1[lo:lo + m].contiguous(), c2[lo:lo + m].contiguous()
         self.__dict__["_pcr_guard_busy"] = True
+        prof, engine.PROFILE = engine.PROFILE, None
         try:
             with torch.no_grad():
                 with engine.precision("f32"):
@@ -257,6 +260,7 @@ class ReIDNet(nn.Module):
                     level += 1
         finally:
             self.__dict__["_pcr_guard_busy"] = False
+            engine.PROFILE = prof
         sen["checks"] += 1
         if level != st["level"]:
             import logging

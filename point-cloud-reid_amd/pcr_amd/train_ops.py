@@ -375,6 +375,8 @@ def pack_both_bf(w):
         if hit is not None:
             return hit
     wd = _dev(w.detach())
+    if wd.dim() != 2:                     # (a 1x1 Conv1d / Conv2d weight (d, c, 1[, 1]): its matrix, as _Prepack.build takes it)
+        wd = wd.reshape(wd.shape[0], -1)
     rows, cols = wd.shape
     lib = L.load()
     a = _f32(lib.pcr_packed_weight_bf16_floats(rows, cols), device=wd.device)

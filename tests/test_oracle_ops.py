@@ -146,8 +146,10 @@ def test_c_oracle_equals_the_simulated_execution_of_the_cuda_kernels():
     # the cases really exercise what the Python twins cannot: ties broken away from the lowest index, a block of 1024
     # threads over 3000 points, the strict upper boundary, d2 == 0 below min_r, an infinite third neighbour
     assert g["fps_n12_idx"].tolist() == [[0, 8, 0]] and meta["fps_n3000"]["block"] == 1024 and meta["fps_n100"]["block"] == 64
-    xyz, c = g["bq_min025_r025_xyz"][0], g["bq_min025_r025_centres"][0]
-    assert (g["bq_min025_r025_idx"][0, 0] == [0, 64, 0, 0]).all() and np.array_equal(xyz[0], xyz[64]) and np.array_equal(c[0], xyz[0])
+    xyz, c, row = g["bq_min025_r030_xyz"][0], g["bq_min025_r030_centres"][0], g["bq_min025_r030_idx"][0, 0]
+    assert np.array_equal(xyz[0], xyz[64]) and np.array_equal(c[0], xyz[0]) and {0, 64} <= set(row.tolist())   # d2 == 0 < min_r^2
+    at_min = [k for k in row.tolist() if abs(np.linalg.norm(xyz[k] - c[0]) - 0.25) < 1e-7]
+    assert at_min and len(set(row.tolist())) == 2 + len(set(at_min))     # d2 == min_r^2 is inside, nothing else is
     assert (g["bq_r050_idx"][0, 10] == 0).all()                          # the far centre: nothing in range, zeros
     d = np.linalg.norm(g["bq_r050_xyz"][0][:, None] - g["bq_r050_centres"][0][None], axis=-1)
     assert (d == 0.5).sum() > 10                                         # points at exactly r exist (and are excluded)
