@@ -327,11 +327,20 @@ typedef struct pcr_attn_params {
    * query-feature columns padded to a whole 16-channel step, [W[:, :c1] | 0 | W[:, c1:]] -- the wave-autonomous apply
    * kernel's contraction steps are 16 channels wide.  NULL: the tile kernel. */
   const float *wmlp0_bf_xpad;
+  /* ABI 16 (round 6): pooled output.  NULL: the block output goes to `out` as before.  Non-NULL (only where
+   * pcr_attn_apply_pool_ok says yes: the wave-autonomous d = c1 = cout = 64 form without q_pos / trailing conv, i.e. the
+   * matching stages' corss_attention, models/attention.py:192-219): `out` is NOT written (may be NULL); instead every
+   * virtual cloud leaves its per-channel maximum and SUM over its Lq tokens, pool_out (B, 2, 64) = [max | sum] -- what
+   * get_pooled_feats 'both' (models/ReIDNet.py:526-534) needs of the block output, 512 bytes instead of 256 Lq. */
+  float *pool_out;
 } pcr_attn_params;
 long pcr_attn_kv_floats(int d);
 int pcr_attn_kv_splits(int B, int Sk, int d);
 int pcr_attn_kv_f32(const pcr_attn_params *p, pcr_stream_t stream);
 int pcr_attn_apply_f32(const pcr_attn_params *p, pcr_stream_t stream);
+/* 1 if pcr_attn_apply_f32 honours p->pool_out for these parameters (a function of the launch SHAPE and the arithmetic
+ * mode, never of B: a pair's result does not depend on the batch it travels in), else 0 */
+int pcr_attn_apply_pool_ok(const pcr_attn_params *p);
 
 /* Matching head tail: pool 'both' over the point-concatenated pair (get_pooled_feats,
  * models/ReIDNet.py:526-534: [max over 2L points, mean over 2L points]) followed by

@@ -542,6 +542,11 @@ void attn_kv_stream64_kernel(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < NKV; i++) {
           const int ib = DIAG ? i : (i >> 1), jb = DIAG ? i : (i & 1);
+          // (round 6, measured and dropped: this accumulation as split bf16 too -- registers [8 st, 8 st + 8) of a K block and of a
+          // V block hold the same eight tokens, so one bf_split8 of each feeds a 16-token step: 6 MFMAs of 32 cycles instead of 16
+          // of 64 per tile.  kv[d=64,Sk=1024] 0.177 -> 0.166 ms, gallery128 -0.12 ms -- and the headline's deviation from the f32
+          // path 2.7e-5 -> 3.2e-5, one case of the margin sweep past 5e-5: the KV state feeds every query token, its rounding does
+          // not average out.  Stays f32.)
 #pragma unroll
           for (int r = 0; r < 16; r++) {
             if constexpr (ONEW) kv[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[2 + jb][r], acc[ib][r], kv[i], 0, 0, 0);
@@ -1109,11 +1114,16 @@ constexpr int kApsWaves = 8;
 // NOB: 32-channel blocks of the block's output (cout = 64, or 128: no residual, no trailing conv)
 // (CF as an int: 32-channel blocks of the trailing conv's output, 0 = none -- 64 -> 128 and the first FP_SA block's 32 -> 64)
 // ND: d_model / 32 (2: d = 64; 1: d = 32, the SA1 self-attention)
-template <bool QPOS, int C1S, int CF, int NOB = 2, int ND = 2>
+// POOL (round 6; the gallery's stage-2 launch): the block's output is not stored -- the wave keeps ALL blocks of a virtual
+// cloud, reduces every block's 32 tokens per channel with a TRANSPOSING butterfly (five exchange steps; a lane keeps half
+// of its registers per step, so the steps cost 16 + 8 + 4 + 2 + 1 registers, not 5 x 32) and writes the cloud's
+// per-channel maximum and sum: p.pool_out (B, 2, 64) -- 512 bytes per cloud instead of 32 KB that pool_head would read back.
+template <bool QPOS, int C1S, int CF, int NOB = 2, int ND = 2, bool POOL = false>
 __global__ __launch_bounds__(64 * kApsWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void attn_apply_stream64_kernel(AttnArgs a) {
   static_assert(!QPOS || C1S == 2 * ND, "q_pos needs c1 == d");
   static_assert(NOB <= 2 || (NOB == 4 && !CF), "cout = 128 has no trailing conv");
+  static_assert(!POOL || (!CF && NOB == 2), "pooled output: cout = 64, no trailing conv");
   constexpr int D = 32 * ND, SD = 2 * ND;   // d_model, its 16-channel steps
   constexpr int SQ = C1S + (QPOS ? SD : 0), S0 = C1S + SD, NX = 8 * C1S;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1177,11 +1187,17 @@ void attn_apply_stream64_kernel(AttnArgs a) {
 #define PCR_AMARK(m) do { } while (0)
 #define PCR_ANEXT() do { } while (0)
 #endif
-  for (long it = (long)blockIdx.x * kApsWaves + wave; it < nitem; it += (long)gridDim.x * kApsWaves) {
+  // item walk: (cloud, block) dealt block by block over the waves -- or, POOL, cloud by cloud (all blocks of a cloud on one
+  // wave, in order: the running maximum / sum of the cloud live in two registers)
+  const long nwav = (long)gridDim.x * kApsWaves, gw = (long)blockIdx.x * kApsWaves + wave;
+  long pc = gw;
+  int pblk = 0;
+  float pmax = -INFINITY, psum = 0.f;
+  for (long it = gw; POOL ? pc < p.B : it < nitem; it += POOL ? 0 : nwav) {
     asm volatile("" ::: "memory");   // (weight reads stay inside the item loop)
     PCR_AMARK(0);
-    const long b = it / nblk;
-    const int blk = (int)(it - b * nblk);
+    const long b = POOL ? pc : it / nblk;
+    const int blk = POOL ? pblk : (int)(it - b * nblk);
     const size_t bq_ = p.q_index ? (size_t)p.q_index[b] : (size_t)b;
     const size_t kb_ = p.kv_index ? (size_t)p.kv_index[b] : (size_t)b;
     const float *kvp = p.kv + kb_ * ((size_t)D * D + D);
@@ -1431,7 +1447,52 @@ void attn_apply_stream64_kernel(AttnArgs a) {
           for (int r = 0; r < 16; r++) o[cb][r] += xf[16 * cb + r];
       }
     }
-    if constexpr (!CF) {
+    if constexpr (POOL) {
+      // lane (j, h) holds the block's token j in the 32 channels ch(e) = 16 (e >> 3) + bf_kpos(h, e & 7), e = 0 .. 31.  Step s
+      // exchanges with lane j ^ (1 << s): the lane with bit s set keeps the upper half of its register list, its partner
+      // the lower half (t = what I keep, u = what my partner keeps), so after five steps lane j holds the maximum and the
+      // sum over the 32 tokens of ONE channel: e = bitreverse5(j).  (Sums: a fixed pairwise tree per block, blocks in order.)
+      float vm[16], vs[16];
+      {
+        const bool up = (j & 1) != 0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const float lo_ = o[r >> 4][r & 15], hi_ = o[(r + 16) >> 4][(r + 16) & 15];
+          const float tk = up ? hi_ : lo_, uk = up ? lo_ : hi_;
+          const float pu = __uint_as_float(pcr_sort_partner<2, 1>(__float_as_uint(uk), lane));
+          vm[r] = fmaxf(tk, pu);
+          vs[r] = tk + pu;
+        }
+      }
+#define PCR_POOL_STEP(N, J, BIT)                                                                      \
+      {                                                                                               \
+        const bool up = (j & BIT) != 0;                                                               \
+        _Pragma("unroll") for (int r = 0; r < N; r++) {                                               \
+          const float tm = up ? vm[r + N] : vm[r], um = up ? vm[r] : vm[r + N];                       \
+          const float ts = up ? vs[r + N] : vs[r], us = up ? vs[r] : vs[r + N];                       \
+          vm[r] = fmaxf(tm, __uint_as_float(pcr_sort_partner<2 * J, J>(__float_as_uint(um), lane)));  \
+          vs[r] = ts + __uint_as_float(pcr_sort_partner<2 * J, J>(__float_as_uint(us), lane));        \
+        }                                                                                             \
+      }
+      PCR_POOL_STEP(8, 2, 2)
+      PCR_POOL_STEP(4, 4, 4)
+      PCR_POOL_STEP(2, 8, 8)
+      PCR_POOL_STEP(1, 16, 16)
+#undef PCR_POOL_STEP
+      pmax = fmaxf(pmax, vm[0]);
+      psum += vs[0];
+      if (++pblk == nblk) {
+        const int e = ((j & 1) << 4) | ((j & 2) << 2) | (j & 4) | ((j & 8) >> 2) | ((j & 16) >> 4);
+        const int ch = 16 * (e >> 3) + bf_kpos(h, e & 7);
+        float *po = p.pool_out + (size_t)b * 128;
+        po[ch] = pmax;
+        po[64 + ch] = psum;
+        pmax = -INFINITY;
+        psum = 0.f;
+        pblk = 0;
+        pc += nwav;
+      }
+    } else if constexpr (!CF) {
       const __amdgpu_buffer_rsrc_t rout =
           __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)b * (32 * NOB) * p.Lq, 0, 32 * NOB * p.Lq * 4, 0x00020000);
 #pragma unroll
@@ -1726,6 +1787,16 @@ static int attn_apply_launch(const pcr_attn_params *pp, pcr_stream_t stream) {
     const bool cf = p.cfinal != 0;
     static const char *aptrace = pcr_tune_str("PCR_ATTN_TRACE");
     if (aptrace) a.dbg = 256;
+    if (pp->pool_out) {
+      // pooled output (pcr_attn_apply_pool_ok said yes): whole clouds per wave
+      static bool okp = allow_big_lds(attn_apply_stream64_kernel<false, 4, 0, 2, 2, true>);
+      (void)okp;
+      const long nwgp = ((long)p.B + kApsWaves - 1) / kApsWaves;
+      const dim3 ggp((unsigned)(nwgp < ncu ? nwgp : ncu));
+      hipLaunchKernelGGL((attn_apply_stream64_kernel<false, 4, 0, 2, 2, true>), ggp, bb, lds_s, st, a);
+      PCR_CHECK_LAUNCH();
+      return PCR_OK;
+    }
     if (nob == 4) {
       static bool ok4 = allow_big_lds(attn_apply_stream64_kernel<true, 4, 0, 4>) && allow_big_lds(attn_apply_stream64_kernel<false, 4, 0, 4>);
       (void)ok4;
@@ -1836,8 +1907,19 @@ PCR_EXPORT int pcr_attn_kv_f32(const pcr_attn_params *pp, pcr_stream_t stream) {
   return attn_kv_narrow(pp, stream);
 }
 
+static bool attn_pool_ok(const pcr_attn_params &p) {
+  pcr_attn_params q;
+  return p.d == 64 && p.c1 == 64 && p.cout == 64 && !p.cfinal && !p.q_pos && (p.Lq & 31) == 0 &&
+         (p.nhead == 1 || p.nhead == 2 || p.nhead == 4) && attn_bf(p, q);
+}
+
+PCR_EXPORT int pcr_attn_apply_pool_ok(const pcr_attn_params *pp) {
+  return (pp && !attn_check(*pp) && attn_pool_ok(*pp)) ? 1 : 0;
+}
+
 PCR_EXPORT int pcr_attn_apply_f32(const pcr_attn_params *pp, pcr_stream_t stream) {
-  if (!pp || attn_check(*pp) || !pp->out) return PCR_ERR_INVALID;
+  if (!pp || attn_check(*pp) || (!pp->out && !pp->pool_out)) return PCR_ERR_INVALID;
+  if (pp->pool_out && !attn_pool_ok(*pp)) return PCR_ERR_INVALID;
   if (pp->B == 0) return PCR_OK;
   if (pp->B > 65535) return PCR_ERR_INVALID;
   pcr_attn_params q;

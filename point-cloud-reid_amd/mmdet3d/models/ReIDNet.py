@@ -495,6 +495,10 @@ class ReIDNet(nn.Module):
         p1 = self.cross_stage1.plan(h.device)
         p2 = self.cross_stage2.plan(h.device)
         kv1 = p1.kv(h, xyz)                                  # stage-1 key/value state: once per OBJECT
+        # round 6: the stage-2 apply launch leaves every virtual cloud's per-channel maximum and sum (512 bytes) instead of
+        # its 32 KB output for pool_head to read back; the head then runs over the pooled ROWS on the matrix core
+        # (pcr_attn_apply_pool_ok: the launch shape and the arithmetic decide, never the number of pairs)
+        pooled_ok = p2.pool_ok(n_pts, n_pts)
         out = []
         # the launches index clouds by a 16-bit grid dimension: at most 32 k pairs (64 k virtual clouds) per pass
         chunk = 32000
@@ -509,8 +513,14 @@ class ReIDNet(nn.Module):
             xyz_v = xyz.index_select(0, q_idx.long()).contiguous()
             partner = torch.cat([torch.arange(n_pairs, 2 * n_pairs, device=h.device, dtype=torch.int32),
                                  torch.arange(0, n_pairs, device=h.device, dtype=torch.int32)])
-            o = p2.apply(s1, None, p2.kv(s1, xyz_v), n_pts, kv_index=partner)
-            out.append(self._head(o.device).run(o))
+            if pooled_ok:
+                pl = p2.apply(s1, None, p2.kv(s1, xyz_v), n_pts, kv_index=partner, pooled=True)     # (2n, 2, C): [max | sum]
+                a, b2 = pl[:n_pairs], pl[n_pairs:]
+                feat = torch.cat([torch.maximum(a[:, 0], b2[:, 0]), (a[:, 1] + b2[:, 1]) / float(2 * n_pts)], dim=1)
+                out.append(self._head_rows(feat))
+            else:
+                o = p2.apply(s1, None, p2.kv(s1, xyz_v), n_pts, kv_index=partner)
+                out.append(self._head(o.device).run(o))
         if not out:
             return torch.empty(0, dtype=torch.float32, device=h.device)
         return out[0] if len(out) == 1 else torch.cat(out, dim=0)

@@ -180,7 +180,7 @@ class AttnParams(ctypes.Structure):
                 ("precision", ctypes.c_int),
                 ("wq_bf", c_float_p), ("wmlp0_bf", c_float_p), ("wmlp2_bf", c_float_p), ("wfinal_bf", c_float_p),
                 ("kv_splits", ctypes.c_int), ("kv_part", c_float_p), ("wkv_bf", c_float_p),
-                ("wmlp0_bf_xpad", c_float_p)]
+                ("wmlp0_bf_xpad", c_float_p), ("pool_out", c_float_p)]
 
 
 class HeadParams(ctypes.Structure):
@@ -522,9 +522,19 @@ class AttnPlan:
         kv._pcr_precision = PRECISION      # the per-cloud matrix is an image of this kind: apply() must match
         return kv
 
-    def apply(self, feat_q, xyz_q, kv, Sk, kv_index=None, q_index=None, n_out=None):
+    def pool_ok(self, Lq, Sk):
+        """can apply(.., pooled=True) be honoured for this block in the current arithmetic (pcr_attn_apply_pool_ok: the
+        launch shape and the mode decide, never the batch)?"""
+        dummy = torch.empty(0)
+        p = self._params(1, Lq, Sk, dummy, None, dummy, None, dummy, dummy)
+        p.feat_q = p.feat_k = p.xyz_k = p.kv = p.out = 1        # (only tested against NULL)
+        return bool(L.load().pcr_attn_apply_pool_ok(ctypes.byref(p)))
+
+    def apply(self, feat_q, xyz_q, kv, Sk, kv_index=None, q_index=None, n_out=None, pooled=False):
         """query side: n_out virtual clouds (default: one per query cloud); virtual cloud b takes its tokens
-        from cloud q_index[b] (default b) and the key-side state kv[kv_index[b]] (default b)"""
+        from cloud q_index[b] (default b) and the key-side state kv[kv_index[b]] (default b).
+        pooled (ABI 16; only where pool_ok says so): the block output is not written -- returns (B, 2, cout) = every
+        virtual cloud's per-channel [maximum | sum] over its Lq tokens"""
         L.require_cuda(feat_q, kv)
         assert feat_q.is_contiguous() and feat_q.dtype == torch.float32 and (xyz_q is None or xyz_q.is_contiguous())
         Bq, c1, Lq = feat_q.shape
@@ -534,14 +544,20 @@ class AttnPlan:
             raise L.PcrError("attention state was built in %r mode and is applied in %r mode: the per-cloud matrix is "
                              "stored in the arithmetic's own layout" % (made, PRECISION))
         B = n_out if n_out is not None else Bq
-        out = torch.empty((B, self.cfinal or self.cout, Lq), dtype=torch.float32, device=feat_q.device)
-        p = self._params(B, Lq, Sk, feat_q, xyz_q, feat_q, xyz_q if xyz_q is not None else feat_q, kv, out,
-                         kv_index, q_index)
+        if pooled:
+            out = torch.empty((B, 2, self.cout), dtype=torch.float32, device=feat_q.device)
+            p = self._params(B, Lq, Sk, feat_q, xyz_q, feat_q, xyz_q if xyz_q is not None else feat_q, kv, None,
+                             kv_index, q_index)
+            p.pool_out = _p(out)
+        else:
+            out = torch.empty((B, self.cfinal or self.cout, Lq), dtype=torch.float32, device=feat_q.device)
+            p = self._params(B, Lq, Sk, feat_q, xyz_q, feat_q, xyz_q if xyz_q is not None else feat_q, kv, out,
+                             kv_index, q_index)
         d = self.d
         ap_flops = 2.0 * B * Lq * (c1 * d + d * d / self.nhead + d * d + (c1 + d) * 2 * d + 2 * d * self.cout
                                    + self.cout * self.cfinal + (self.q_pos * (3 * d + d * c1)))
-        with _prof("attn_apply[d=%d,c1=%d,out=%d,Lq=%d]" % (d, c1, self.cfinal or self.cout, Lq), ap_flops,
-                   4.0 * B * (c1 * Lq + d * d + d + (self.cfinal or self.cout) * Lq), arith="lib"):
+        with _prof("attn_apply[d=%d,c1=%d,out=%d,Lq=%d%s]" % (d, c1, self.cfinal or self.cout, Lq, ",pooled" if pooled else ""),
+                   ap_flops, 4.0 * B * (c1 * Lq + d * d + d + (2 if pooled else Lq) * (self.cfinal or self.cout)), arith="lib"):
             L.check(L.load().pcr_attn_apply_f32(ctypes.byref(p), L.stream_ptr()), "pcr_attn_apply_f32")
         return out
 

@@ -50,3 +50,39 @@ def test_streaming_attention_matches_oracle(kind, d, nhead, B, Lq, Sk, prec):
     with engine.precision(prec), torch.no_grad():
         one = m(*[a[B - 1:].cuda() for a in args]).cpu()
     assert torch.equal(one[0], got[B - 1])
+
+
+@pytest.mark.parametrize("nhead,B,L", [(2, 1, 32), (2, 7, 128), (4, 300, 96), (1, 20, 160)])
+def test_pooled_apply_equals_the_pooling_of_the_block_output(nhead, B, L):
+    """ABI 16: the matching stage's apply launch with `pool_out` (the gallery path, ReIDNet.match_gallery) leaves every
+    cloud's per-channel maximum and sum instead of its output tile: the maximum must be the maximum of the values the
+    unpooled launch stores (same arithmetic, same bits), the sum their sum up to its order; a cloud alone gives the bits it
+    gives inside a batch; the f32 mode (tile kernel) says it cannot pool.  Reference: attention.py:192-219 +
+    ReIDNet.py:526-534 (get_pooled_feats 'both')."""
+    from mmdet3d.models.attention import corss_attention
+    g = torch.Generator().manual_seed(100 * nhead + L)
+    m = corss_attention(64, nhead)
+    m.load_state_dict(T.seeded_state_dict(T.manifest_of(m), 3))
+    m = m.cuda().eval()
+    plan = m.plan(torch.device("cuda"))
+    feat = torch.randn(B, 64, L, generator=g).cuda()
+    xyz = torch.randn(B, L, 3, generator=g).cuda()
+    partner = torch.arange(B - 1, -1, -1, dtype=torch.int32).cuda()
+    with engine.precision("bf16x3"), torch.no_grad():
+        assert plan.pool_ok(L, L)
+        kv = plan.kv(feat, xyz)
+        o = plan.apply(feat, None, kv, L, kv_index=partner)
+        pl = plan.apply(feat, None, kv, L, kv_index=partner, pooled=True)
+        assert pl.shape == (B, 2, 64)
+        assert torch.equal(pl[:, 0], o.max(dim=2).values)
+        ref_sum = o.double().sum(dim=2)
+        assert float((pl[:, 1].double() - ref_sum).abs().max()) < 1e-5 * max(1.0, float(ref_sum.abs().max()))
+        again = plan.apply(feat, None, kv, L, kv_index=partner, pooled=True)
+        assert torch.equal(pl, again)
+        one = plan.apply(feat[B - 1:], None, kv, L, kv_index=partner[B - 1:], pooled=True)
+        assert torch.equal(one[0], pl[B - 1])
+    with engine.precision("f32"):
+        assert not plan.pool_ok(L, L)
+        kv32 = plan.kv(feat, xyz)
+        with pytest.raises(Exception):
+            plan.apply(feat, None, kv32, L, kv_index=partner, pooled=True)
