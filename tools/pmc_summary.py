@@ -113,8 +113,10 @@ KNOWN = {
     "knn_prefix[N=4096,S=4096,K=32]": ["knn_prefix_lds_kernel"],
     "knn_prefix2[N=4096,S=4096,K=32,S2=2048,K2=48]": ["knn_prefix_lds_kernel"],
     "sa_fused[D=64,c=128/128/128,N=2048,S=1024,K=48]": ["sa_stream_kernel<4, 4"],
-    "attn_apply[d=64,c1=64,out=64,Lq=128]": ["gallery_tail_kernel", "attn_apply_stream64_kernel<false, 4, 0, 2",
-                                             "attn_apply_kernel<2, 1>"],
+    "attn_apply[d=64,c1=64,out=64,Lq=128]": ["gallery_tail_kernel", "attn_apply_stream64_kernel<false, 4, 0, 2, 2, false",
+                                             "attn_apply_stream64_kernel<false, 4, 0, 2", "attn_apply_kernel<2, 1>"],
+    # round 6 (ABI 16): the gallery's stage-2 launch with pooled output
+    "attn_apply[d=64,c1=64,out=64,Lq=128,pooled]": ["attn_apply_stream64_kernel<false, 4, 0, 2, 2, true"],
     "attn_kv[d=64,c2=64,Sk=128]": ["attn_kv_stream64_kernel<true, true, 4", "attn_kv_stream64_kernel<true, false, 4"],
     "dense_gn[cin=1024,cout=512,L=256]": ["dense_bf_pc_kernel<true, 3, 8", "dense_bf_pc_kernel<true", "dense_bf_kernel<true, 3, 2",
                                           "dense_bf_kernel<true", "dense_kernel<2, true, true"],
