@@ -18,7 +18,11 @@ from pcr_amd import testing as T   # noqa: E402
 def forced_ptx(model, sd, a, b):
     """stage-wise parity of the xcorr matching with the GPU's own stage inputs fed to the oracle (feature-space kNN
     is discontinuous, so END-TO-END agreement can break at a near-tie without any stage being wrong)"""
-    with torch.no_grad():
+    from pcr_amd import engine
+    # (round 6: every entry point applies the model's guard level -- an xcorr model calibrates to level 2, the f32 path --
+    # so the stages called directly here must run at that level too, or the two chains differ by arithmetic and flip
+    # neighbours between themselves)
+    with torch.no_grad(), engine.guard_level(model.precision_level()):
         xyz1, xyz2, h1, h2 = model.siamese_forward(a.cuda(), b.cuda())
         ga = model.cross_stage1(h1, xyz1, h2, xyz2)
         gb = model.local_stage1(ga, xyz1)
