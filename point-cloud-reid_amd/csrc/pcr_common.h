@@ -202,7 +202,7 @@ __device__ __forceinline__ unsigned long long pcr_wave_sort_u64(unsigned long lo
 // it and runs layers 2 / 3, the other gathers, seeds, splits, reduces -- or sleeps at the gate.
 // Measured (tools/scratch/probe_coexec*.hip, one wave per SIMD with an instruction-level interleave): under a running
 // v_mfma_f32_32x32x16_bf16 integer / transcendental / LDS instructions are nearly free, plain f32 VALU instructions keep
-// about two of their three cycles, packed f32 instructions (v_pk_add / mul / fma_f32) hide NOTHING -- the matrix pipe and
+// about two of their three cycles, packed f32 instructions (v_pk_add / mul / fma_f32) hide almost nothing -- the matrix pipe and
 // the f32 vector lanes are one datapath.  So the token buys what the integer part of the other wave's VALU phase is worth:
 // sa_stream_kernel<4,4> 2.20-2.26 -> 2.06-2.09 ms (pt1024 SA3, same bits); the attention stream kernels (four short matrix
 // phases per block, f32-heavy LayerNorm / normaliser between them) gain nothing from it (measured: 0 to -2 %): not used there.
