@@ -242,8 +242,16 @@ typedef struct pcr_sa_params {
    * then reads a row's {neighbour, point - centre} with one load instead of chasing cnt -> idx -> xyz.  idx may be
    * NULL when it is given (cnt is still read).  Ignored by every other kernel. */
   const float *row_tab;
+  /* optional (ABI 16): pcr_sa_claim_ws_ints(..) ints of scratch for the wave-autonomous K-row kernel on clouds of >= 2048
+   * points: its waves then CLAIM their work items from counters in it (zeroed by the launch itself, on `stream`) instead
+   * of walking a fixed stride, which keeps the waves of an XCD on consecutive items -- one or two clouds' tables live in
+   * its L2 instead of three or four.  Same results bit for bit (an item's arithmetic does not depend on who runs it).
+   * NULL, or a shape the query answers 0 for: fixed-stride items. */
+  int *claim_ws;
 } pcr_sa_params;
 int pcr_sa_mlp_f32(const pcr_sa_params *p, pcr_stream_t stream);
+/* ints of pcr_sa_params.claim_ws a launch of this shape would use (0: it would not use any); shape-only */
+long pcr_sa_claim_ws_ints(int c1, int c2, int c3, int K, int N, int precision);
 /* ints of pcr_sa_params.tile_ws for the duplicate-free evaluation (tile lists + per-tile row tables) */
 long pcr_sa_tile_ws_ints(int B, int S, int K, int c2, int c3);
 /* 1: a launch of this shape WITHOUT hit counts (cnt NULL: all K rows of every group) also runs on the tile plan and

@@ -155,6 +155,7 @@ struct Sa2Args {
   const float *wap;         // packed (c1,3) image of wa, or null
   int l1m;                  // layer 1 on the matrix core (wap given and c1 in layer 2's cout-block class)
   float *out;
+  int *claim;               // sa_stream_kernel: eight item counters, 1024 ints apart, zeroed by the launch; null = dealt items
 };
 
 // NR / NR2: cout-block rounds per wave of layer 3 / layer 2 (2 when the layer has more than 4 x 32 couts)
@@ -434,6 +435,10 @@ __host__ __device__ constexpr int sas_rag_wave_ints(int c3, int K, bool tab) {
   return 16 * c3 + (tab ? 0 : 16 * K) + ((16 * K / 2 + 15) / 16) * 4;
 }
 
+constexpr int kSasClaimInts = 8 * 1024;   // sa_stream_kernel's item counters: one per XCD slot, 4 KB apart
+// which K-row launches claim their items: the narrow shapes on clouds whose tables crowd the L2 (measured: 64 channels -5.5 %,
+// 32 channels -3 %, 128 channels unchanged -- their table is the same size but their blocks are 2.5x longer)
+__host__ __device__ inline bool sas_claims(int c1, int c3, int N) { return N >= 2048 && c1 <= 64 && c3 <= 64; }
 constexpr int kTraceWgs = 1024, kTraceTiles = 24, kTraceMarks = 8;
 __device__ unsigned long long g_rag_trace[kTraceWgs * (2 + kTraceTiles * kTraceMarks)];
 
@@ -702,6 +707,28 @@ void sa_stream_kernel(Sa2Args a, int nblk_item, int ncen_item) {
   // the wave's item walk without a division per item: (cloud rank on the XCD, item) advance by fixed steps
   const int step_b = wstride / nitem, step_i = wstride - step_b * nitem;
   int bq = wrank / nitem, item = wrank - bq * nitem;
+  // ---- CLAIMED items (round 6; clouds of >= 2048 points, where one cloud's tables are 1-2 MB of a 4 MB L2).  Dealt items
+  // (item = rank + n x stride) let a wave that misses fall behind and keep an older cloud's table alive: with 512 waves per
+  // XCD the live span grows from half a cloud to three or four, and the 64-channel launch of pt4096 fetches every table
+  // line ~4 times (8.2 GB per launch against 1.55 GB algorithmic; `TCC_HIT / TCC_MISS`).  Here the waves of
+  // an XCD slot take items from a shared counter instead -- TWO at a time at agent scope (correct whatever XCD a workgroup
+  // really runs on: the slot only decides which clouds it shares with whom), counters 4 KB apart, the next claim
+  // requested when the current pair starts so that its memory-side latency hides behind two items.
+  const bool claimed = a.claim != nullptr;
+  int *ctr = claimed ? a.claim + xcd * 1024 : nullptr;
+  auto claim2 = [&]() __attribute__((always_inline)) {
+    int v = 0;
+    if (lane == 0) v = __hip_atomic_fetch_add(ctr, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+  };
+  int q_first = wrank, q_end = 0, pend = 0;
+  if (claimed) {
+    q_first = __builtin_amdgcn_readfirstlane(claim2());
+    q_end = q_first + 2;
+    pend = claim2();
+    bq = q_first / nitem;
+    item = q_first - bq * nitem;
+  }
   // a block's row indices {neighbour, centre point} are requested one block ahead (the next item's first block during
   // the current item's last): nothing else stands between a wave and its table gathers
   int i_pre = 0, ci_pre = 0;
@@ -715,7 +742,7 @@ void sa_stream_kernel(Sa2Args a, int nblk_item, int ncen_item) {
     ci_pre = a.centre_idx ? a.centre_idx[b2 * a.S + s2] : s2;
     i_pre = a.idx[(b2 * a.S + c02) * (size_t)K + r2];
   };
-  if (wrank < nq) fetch_rows(bq, item, 0);
+  if (q_first < nq) fetch_rows(bq, item, 0);
 #ifdef PCR_SA_TRACE_BUILD   // diagnostic builds only: waves 0 and 5 of a workgroup stamp the shader clock (one record per block)
   const bool tracing = (a.dbg & 256) && lane == 0 && (wave == 0 || wave == 5) && blockIdx.x < kTraceWgs / 2;
   unsigned long long *trace = g_rag_trace + (size_t)(2 * blockIdx.x + (wave ? 1 : 0)) * (2 + kTraceTiles * kTraceMarks);
@@ -731,7 +758,7 @@ void sa_stream_kernel(Sa2Args a, int nblk_item, int ncen_item) {
 #define PCR_STR() nullptr
 #define PCR_SNEXT() do { } while (0)
 #endif
-  for (int qi = wrank; qi < nq; qi += wstride) {
+  for (int qi = q_first, qn = 0; qi < nq; qi = qn) {
     asm volatile("" ::: "memory");
     PCR_SMARK(4);
     const size_t b = (size_t)bq * 8 + xcd;
@@ -741,18 +768,31 @@ void sa_stream_kernel(Sa2Args a, int nblk_item, int ncen_item) {
     const float *xyz = a.xyz + b * a.N * 3;
     const float *pq = a.pq ? a.pq + b * a.N * (size_t)a.pqw : nullptr;
     const int bq_cur = bq, item_cur = item;
-    item += step_i;                                     // the next item of this wave
-    bq += step_b;
-    if (item >= nitem) {
-      item -= nitem;
-      bq++;
+    if (!claimed) {
+      qn = qi + wstride;
+      item += step_i;                                   // the next item of this wave
+      bq += step_b;
+      if (item >= nitem) {
+        item -= nitem;
+        bq++;
+      }
+    } else {
+      if (qi + 1 < q_end) {
+        qn = qi + 1;
+      } else {                                          // the pair is used up: take the claim requested when it started
+        qn = __builtin_amdgcn_readfirstlane(pend);
+        q_end = qn + 2;
+        pend = claim2();
+      }
+      bq = qn / nitem;                                  // (qn >= nq: never used)
+      item = qn - bq * nitem;
     }
     for (int blk = 0; blk < nblk_item; blk++) {
       if (blk * 32 >= rows) break;                      // (a partial last item: whole blocks of padding are skipped)
       PCR_SMARK(0);
       const int i = i_pre, ci = ci_pre;
       if (blk + 1 < nblk_item && (blk + 1) * 32 < rows) fetch_rows(bq_cur, item_cur, blk + 1);
-      else if (qi + wstride < nq) fetch_rows(bq, item, 0);
+      else if (qn < nq) fetch_rows(bq, item, 0);
       f32x16 y[NCB3];
       SasBlock<NCB, NCB3, LO>::run(xyz, pq, a.pqw, a.qoff, has_q, i, ci, s_sh, s_sh + C, s_sh + 2 * C, s_wa, s_w2, s_w3, lane, y,
                                    PCR_STR(), tok);
@@ -2391,6 +2431,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   a.qoff = p.mode == 0 ? p.c1 : -1;
   static const int dbg = pcr_tune_int("PCR_SA_DBG");
   a.dbg = dbg;
+  a.claim = nullptr;
   a.wp2 = wl2; a.wp3 = wl3;
   a.sh1 = p.shift[0]; a.sh2 = p.shift_pad[0]; a.sh3 = p.shift_pad[1];
   a.out = p.out;
@@ -2438,6 +2479,9 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
       constexpr bool kLoS = kPrec == 1;
       static const char *ktrace = pcr_tune_str("PCR_SA_TRACE");
       if (ktrace) a.dbg |= 256;
+      // claimed items (shape-only: pcr_sa_claim_ws_ints says when; PCR_SA_DBG bit 4096 of a tuning build switches them off)
+      a.claim = (p.claim_ws && sas_claims(p.c1, p.c3, p.N) && !(a.dbg & 4096)) ? p.claim_ws : nullptr;
+      if (a.claim && hipMemsetAsync(a.claim, 0, (size_t)kSasClaimInts * sizeof(int), st) != hipSuccess) return PCR_ERR_LAUNCH;
 #define PCR_SAS(NCBv, NCB3v)                                                                  \
   do {                                                                                        \
     static bool ok = allow_big_lds(sa_stream_kernel<NCBv, NCB3v, kLoS>);                      \
@@ -2502,6 +2546,12 @@ PCR_EXPORT int pcr_sa_uses_row_table(int c1, int c2, int c3, int K, int precisio
 
 PCR_EXPORT int pcr_sa_krow_uses_tiles(int c1, int c2, int c3, int K, int precision) {
   return precision != 0 && c1 == 128 && c2 == 128 && c3 == 256 && K >= 1 && K <= 64;
+}
+
+PCR_EXPORT long pcr_sa_claim_ws_ints(int c1, int c2, int c3, int K, int N, int precision) {
+  // the wave-autonomous K-row form's shapes (equal widths, whole 16-row groups) in a bf16 mode, on large clouds
+  if (precision == 0 || c1 != c2 || c2 != c3 || (K & 15) || K < 16) return 0;
+  return sas_claims(c1, c3, N) ? (long)kSasClaimInts : 0;
 }
 
 PCR_EXPORT long pcr_sa_tile_ws_ints(int B, int S, int K, int c2, int c3) {

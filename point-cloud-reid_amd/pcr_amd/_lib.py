@@ -31,6 +31,7 @@ def load():
         lib.pcr_packed_weight_bf16_floats.restype = ctypes.c_long
         lib.pcr_attn_kv_floats.restype = ctypes.c_long
         lib.pcr_sa_tile_ws_ints.restype = ctypes.c_long
+        lib.pcr_sa_claim_ws_ints.restype = ctypes.c_long
         lib.pcr_ball_query_rows_floats.restype = ctypes.c_long
         if lib.pcr_abi_version() != ABI_VERSION:
             raise PcrError("libpcr_hip.so ABI %d != binding %d: rebuild" % (lib.pcr_abi_version(), ABI_VERSION))

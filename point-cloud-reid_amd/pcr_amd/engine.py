@@ -117,6 +117,10 @@ def guarded(fn):
     return fn()
 
 
+# claimed work items for the wave-autonomous K-row SA kernel on clouds of >= 2048 points (pcr_sa_params.claim_ws, ABI 16;
+# PCR_SA_CLAIMS=0 / engine.SA_CLAIMS = False: fixed-stride items -- same bits, tests/test_gpu_sa_claims.py)
+SA_CLAIMS = _os.environ.get("PCR_SA_CLAIMS", "1") != "0"
+
 # bench.py sets this to a list to collect (kernel, start_event, end_event, algorithmic flops,
 # algorithmic bytes, issued flops, arithmetic) per launch; events are recorded on the stream the kernels are launched on.
 PROFILE = None
@@ -161,7 +165,7 @@ class SaParams(ctypes.Structure):
                 ("feat_point_major", ctypes.c_int), ("out_point_major", ctypes.c_int),
                 ("out", c_float_p), ("wa_packed", c_float_p),
                 ("precision", ctypes.c_int), ("wps_bf", c_float_p * 2), ("wa_shift_packed", c_float_p),
-                ("row_tab", c_float_p)]
+                ("row_tab", c_float_p), ("claim_ws", c_int_p)]
 
 
 class AttnParams(ctypes.Structure):
@@ -382,6 +386,12 @@ class SaPlan:
             p.wa_packed = _p(self.wa_packed)
             p.wa_shift_packed = _p(self.wa_shift_packed)
             p.precision = PRECISIONS[PRECISION]
+            # ABI 16: item counters for the wave-autonomous K-row kernel on large clouds (the launch zeroes them itself)
+            n_claim = 0 if (ragged or not SA_CLAIMS) else L.load().pcr_sa_claim_ws_ints(
+                self.couts[0], self.couts[1], self.couts[2], K, N, PRECISIONS[PRECISION])
+            if n_claim > 0:
+                claim_ws = torch.empty((n_claim,), dtype=torch.int32, device=xyz.device)
+                p.claim_ws = _p(claim_ws)
             for i in range(2):
                 p.wps[i], p.shift_pad[i] = _p(self.wps[i]), _p(self.shift_pad[i])
                 p.wps_bf[i] = _p(self.wps_bf[i])
