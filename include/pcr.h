@@ -242,7 +242,7 @@ typedef struct pcr_sa_params {
    * then reads a row's {neighbour, point - centre} with one load instead of chasing cnt -> idx -> xyz.  idx may be
    * NULL when it is given (cnt is still read).  Ignored by every other kernel. */
   const float *row_tab;
-  /* optional (ABI 16): pcr_sa_claim_ws_ints(..) ints of scratch for the wave-autonomous K-row kernel on clouds of >= 2048
+  /* optional (ABI 16): pcr_sa_claim_ws_ints(..) ints of scratch for the wave-autonomous K-row kernel on clouds of >= 1024
    * points: its waves then CLAIM their work items from counters in it (zeroed by the launch itself, on `stream`) instead
    * of walking a fixed stride, which keeps the waves of an XCD on consecutive items -- one or two clouds' tables live in
    * its L2 instead of three or four.  Same results bit for bit (an item's arithmetic does not depend on who runs it).

@@ -436,9 +436,15 @@ __host__ __device__ constexpr int sas_rag_wave_ints(int c3, int K, bool tab) {
 }
 
 constexpr int kSasClaimInts = 8 * 1024;   // sa_stream_kernel's item counters: one per XCD slot, 4 KB apart
-// which K-row launches claim their items: the narrow shapes on clouds whose tables crowd the L2 (measured: 64 channels -5.5 %,
-// 32 channels -3 %, 128 channels unchanged -- their table is the same size but their blocks are 2.5x longer)
-__host__ __device__ inline bool sas_claims(int c1, int c3, int N) { return N >= 2048 && c1 <= 64 && c3 <= 64; }
+// which K-row launches claim their items (measured at the bench batches, same box: <= 64 channels gain 5-8 % at N = 1024 and
+// 8-16 % at N = 4096 -- besides keeping the XCD's waves on one or two clouds, claiming is a dynamic schedule without a tail;
+// 128 channels LOSE 1-3 % at every size (their blocks are 2.5x longer, the claim buys nothing and costs its atomics);
+// N = 128 loses too (items are short, the claim's latency sits on every one))
+inline bool sas_claims(int c1, int c3, int N) {
+  static const int min_n_t = pcr_tune_int("PCR_SA_CLAIM_MIN_N"), max_c_t = pcr_tune_int("PCR_SA_CLAIM_MAX_C");   // tuning builds only
+  const int max_c = max_c_t > 0 ? max_c_t : 64;
+  return N >= (min_n_t > 0 ? min_n_t : 1024) && c1 <= max_c && c3 <= max_c;
+}
 constexpr int kTraceWgs = 1024, kTraceTiles = 24, kTraceMarks = 8;
 __device__ unsigned long long g_rag_trace[kTraceWgs * (2 + kTraceTiles * kTraceMarks)];
 
@@ -707,7 +713,7 @@ void sa_stream_kernel(Sa2Args a, int nblk_item, int ncen_item) {
   // the wave's item walk without a division per item: (cloud rank on the XCD, item) advance by fixed steps
   const int step_b = wstride / nitem, step_i = wstride - step_b * nitem;
   int bq = wrank / nitem, item = wrank - bq * nitem;
-  // ---- CLAIMED items (round 6; clouds of >= 2048 points, where one cloud's tables are 1-2 MB of a 4 MB L2).  Dealt items
+  // ---- CLAIMED items (round 6; clouds of >= 1024 points, <= 64 channels: sas_claims).  Dealt items
   // (item = rank + n x stride) let a wave that misses fall behind and keep an older cloud's table alive: with 512 waves per
   // XCD the live span grows from half a cloud to three or four, and the 64-channel launch of pt4096 fetches every table
   // line ~4 times (8.2 GB per launch against 1.55 GB algorithmic; `TCC_HIT / TCC_MISS`).  Here the waves of
@@ -2429,7 +2435,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   a.pq = p.D ? p.pq_ws : nullptr;
   a.pqw = pqw;
   a.qoff = p.mode == 0 ? p.c1 : -1;
-  static const int dbg = pcr_tune_int("PCR_SA_DBG");
+  const int dbg = pcr_tune_int("PCR_SA_DBG");    // (0 in production; a tuning build re-reads it per launch: in-process A/Bs)
   a.dbg = dbg;
   a.claim = nullptr;
   a.wp2 = wl2; a.wp3 = wl3;

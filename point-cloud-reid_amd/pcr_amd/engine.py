@@ -117,7 +117,7 @@ def guarded(fn):
     return fn()
 
 
-# claimed work items for the wave-autonomous K-row SA kernel on clouds of >= 2048 points (pcr_sa_params.claim_ws, ABI 16;
+# claimed work items for the wave-autonomous K-row SA kernel on clouds of >= 1024 points (pcr_sa_params.claim_ws, ABI 16;
 # PCR_SA_CLAIMS=0 / engine.SA_CLAIMS = False: fixed-stride items -- same bits, tests/test_gpu_sa_claims.py)
 SA_CLAIMS = _os.environ.get("PCR_SA_CLAIMS", "1") != "0"
 

@@ -1,4 +1,4 @@
-"""GPU: claimed work items of the wave-autonomous K-row SA kernel (pcr_sa_params.claim_ws, ABI 16).  On clouds of >= 2048
+"""GPU: claimed work items of the wave-autonomous K-row SA kernel (pcr_sa_params.claim_ws, ABI 16).  On clouds of >= 1024
 points the waves of an XCD slot take their items from a shared counter instead of a fixed stride, so that they stay on
 consecutive items and one or two clouds' tables live in the L2 instead of three or four (profiles/r06f_pt4096_pmc.json:
 2.9 GB per launch instead of 7.2 GB).  Which wave evaluates an item cannot change its arithmetic: the outputs must be
@@ -33,12 +33,13 @@ def test_the_query_is_shape_only():
     bf = engine.PRECISIONS["bf16x3"]
     assert lib.pcr_sa_claim_ws_ints(64, 64, 64, 48, 4096, bf) == 8192
     assert lib.pcr_sa_claim_ws_ints(32, 32, 32, 32, 2048, bf) == 8192
-    assert lib.pcr_sa_claim_ws_ints(64, 64, 64, 48, 1024, bf) == 0          # small clouds: tables fit whatever the order
+    assert lib.pcr_sa_claim_ws_ints(64, 64, 64, 48, 1024, bf) == 8192
+    assert lib.pcr_sa_claim_ws_ints(64, 64, 64, 48, 512, bf) == 0           # small clouds: short items, the claim's latency shows
     assert lib.pcr_sa_claim_ws_ints(128, 128, 128, 48, 4096, bf) == 0       # 128 channels: measured, no gain
     assert lib.pcr_sa_claim_ws_ints(64, 64, 64, 48, 4096, 0) == 0           # f32: the tile kernel
 
 
-@pytest.mark.parametrize("D,c,K,B,N,S", [(32, 64, 48, 5, 2048, 1000), (0, 32, 32, 3, 4096, 4096), (32, 64, 16, 2, 2048, 2048),
+@pytest.mark.parametrize("D,c,K,B,N,S", [(32, 64, 48, 9, 1024, 512), (32, 64, 48, 5, 2048, 1000), (0, 32, 32, 3, 4096, 4096), (32, 64, 16, 2, 2048, 2048),
                                          (0, 32, 48, 70, 2048, 301)])
 def test_claimed_items_give_the_bits_of_dealt_items(D, c, K, B, N, S, monkeypatch):
     g = torch.Generator().manual_seed(N + S + K)
