@@ -539,6 +539,36 @@ def add_clock(roof, clk):
         roof["frac_at_clock"] = roof["achieved"] / roof["peak_at_clock"]
 
 
+def add_sustained(roof):
+    """informational, beside the contract's nominal `peak` / `frac` (which stay as they are): what a dense
+    v_mfma_f32_32x32x16_bf16 loop on all CUs SUSTAINS when its operands are random numbers instead of constants -- the chip
+    lowers its shader clock under that load (tools/probe_clock.hip; committed output profiles/r*_clock_probe.txt: mode 0 =
+    constant operands = the nominal 2.5 PFLOP/s at 2.39 GHz, mode 1 = random operands, mode 7 = random operands fetched from
+    LDS with a quarter of the issue slots VALU work, the mix of the K-row SA kernel)"""
+    import glob
+    import re
+    if roof.get("bound") != "mfma" or not str(roof.get("kernel_arithmetic", "")).startswith("bf16"):
+        return
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_clock_probe.txt")), reverse=True):
+        try:
+            best = {}
+            with open(path) as f:
+                for ln in f:
+                    m = re.match(r"mode (\d)\s+launch\s+([\d.]+) ms\s+([\d.]+) TFLOP/s.*median\s+(\d+)", ln)
+                    if m and float(m.group(2)) > 50.0:            # the long launches
+                        best[int(m.group(1))] = (float(m.group(3)), int(m.group(4)))
+            if 1 in best and 0 in best:
+                roof["sustained_bf16"] = {
+                    "constant_operands_tflops": best[0][0], "random_operands_tflops": best[1][0],
+                    "random_operands_clock_mhz": best[1][1],
+                    "kernel_mix_tflops": best.get(7, (None, None))[0],
+                    "frac_of_random_operands": round(roof["achieved"] / best[1][0], 4),
+                    "source": os.path.relpath(path, ROOT)}
+                return
+        except (OSError, ValueError):
+            continue
+
+
 def measure(workload, args, rank, world, pairs=None, cloud_kind=None, skip_repeats=True, steps=None, warmup=None,
             precision=None):
     """one workload: timed region + (rank 0) roofline of its dominant launch; returns (record, state_dict)"""
@@ -580,6 +610,7 @@ def measure(workload, args, rank, world, pairs=None, cloud_kind=None, skip_repea
         clk = clock_probe()
         roof, _ = roofline_of(model, s1, s2, workload, pairs)
         add_clock(roof, clk)
+        add_sustained(roof)
         with torch.no_grad(), engine.precision("f32"):
             ref = hot_path(model, s1, s2)
         rec = dict(value=world * pairs * steps / dt, unit="pairs/s", steps=steps, warmup=warmup,
@@ -700,7 +731,7 @@ def compact_roofline(roof):
         return roof
     keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_per_step",
             "kernel_arithmetic", "mfma_per_product", "issued_gflop_per_launch", "algorithmic_mb_per_launch",
-            "algorithmic_gflop_per_launch", "mfma_pipe_busy_pmc", "share_of_step", "clock_ghz", "valu_issue")
+            "algorithmic_gflop_per_launch", "mfma_pipe_busy_pmc", "share_of_step", "clock_ghz", "valu_issue", "sustained_bf16")
     out = {k: _r(roof[k]) for k in keep if k in roof}
     out.setdefault("traffic", None)
     per = roof.get("per_kernel_ms") or roof.get("profiled_kernels_ms")

@@ -1724,6 +1724,8 @@ static int attn_apply_launch(const pcr_attn_params *pp, pcr_stream_t stream) {
   AttnArgs a;
   a.p = p;
   a.dbg = 0;
+  // (round 6, measured and dropped: 64-token tiles for d = 128 -- half the weight traffic from L2, half the waves per CU:
+  // pt1024's attn_apply[d=128] 0.455 -> 0.518 ms, profiles/r06_inproc_ab.txt)
   const int tb = p.d <= 32 ? 4 : (p.d <= 64 ? 2 : 1), T = 32 * tb, RP = T + 1;
   const int catP = ceil8(p.c1 + p.d);
   int rowsU = catP > 2 * p.d ? catP : 2 * p.d;

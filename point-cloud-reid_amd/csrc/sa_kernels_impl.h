@@ -581,7 +581,10 @@ struct SasBlock {
       layer1(std::false_type{}, std::false_type{});
     }
     PCR_BMARK(6);
+    // (round 6, measured and dropped: taking the token BEFORE layer 1 -- after its gathers have landed -- so that all of a
+    // block's f32 VALU work runs inside the holder: pt1024 SA3 2.117 -> 2.200 ms, profiles/r06_inproc_ab.txt)
     mfma_token_acquire(tok, lane);
+    PCR_BMARK(3);      // (K-row form: token taken; the ragged form's caller overwrites mark 3 with its own)
     // ---- layer 2 (normal orientation: its accumulators convert into layer 3's operand)
     {
       f32x16 y[NCB];
@@ -752,12 +755,12 @@ void sa_stream_kernel(Sa2Args a, int nblk_item, int ncen_item) {
 #ifdef PCR_SA_TRACE_BUILD   // diagnostic builds only: waves 0 and 5 of a workgroup stamp the shader clock (one record per block)
   const bool tracing = (a.dbg & 256) && lane == 0 && (wave == 0 || wave == 5) && blockIdx.x < kTraceWgs / 2;
   unsigned long long *trace = g_rag_trace + (size_t)(2 * blockIdx.x + (wave ? 1 : 0)) * (2 + kTraceTiles * kTraceMarks);
-  int trace_it = 0;
+  int trace_it = -(a.dbg >> 16);       // (PCR_SA_DBG bits 16..: blocks to skip before the kTraceTiles recorded ones)
 #define PCR_SMARK(m)                                                                                   \
   do {                                                                                                 \
-    if (tracing && trace_it < kTraceTiles) trace[2 + trace_it * kTraceMarks + (m)] = __builtin_readcyclecounter(); \
+    if (tracing && trace_it >= 0 && trace_it < kTraceTiles) trace[2 + trace_it * kTraceMarks + (m)] = __builtin_readcyclecounter(); \
   } while (0)
-#define PCR_STR() ((tracing && trace_it < kTraceTiles) ? trace + 2 + trace_it * kTraceMarks : nullptr)
+#define PCR_STR() ((tracing && trace_it >= 0 && trace_it < kTraceTiles) ? trace + 2 + trace_it * kTraceMarks : nullptr)
 #define PCR_SNEXT() trace_it++
 #else
 #define PCR_SMARK(m) do { } while (0)
@@ -796,6 +799,9 @@ void sa_stream_kernel(Sa2Args a, int nblk_item, int ncen_item) {
     for (int blk = 0; blk < nblk_item; blk++) {
       if (blk * 32 >= rows) break;                      // (a partial last item: whole blocks of padding are skipped)
       PCR_SMARK(0);
+#ifdef PCR_SA_TRACE_BUILD   // (mark 5 of the K-row form: the constant 100 MHz counter at the block top -> the clock the launch runs at)
+      if (tracing && trace_it >= 0 && trace_it < kTraceTiles) trace[2 + trace_it * kTraceMarks + 5] = __builtin_amdgcn_s_memrealtime();
+#endif
       const int i = i_pre, ci = ci_pre;
       if (blk + 1 < nblk_item && (blk + 1) * 32 < rows) fetch_rows(bq_cur, item_cur, blk + 1);
       else if (qn < nq) fetch_rows(bq, item, 0);

@@ -235,3 +235,21 @@ def test_the_default_workload_is_the_reference_models_config():
     for name in ("pt1024_f32", "pt4096_f32", "ssg1024", "ssg1024_full", "pointnet256"):
         assert '"%s"' % name in src
     assert bench.WORKLOADS["pt1024"][3] == [1024, 512, 256] and bench.WORKLOADS["pt1024"][4] == 512
+
+
+def test_the_sustained_rate_is_informational_and_leaves_peak_and_frac_alone():
+    """`roofline.sustained_bf16` quotes the committed probe output (profiles/r*_clock_probe.txt: what a dense bf16 MFMA loop
+    sustains with random operands); the contract's `peak` / `frac` are the nominal ones whatever it says"""
+    roof = {"bound": "mfma", "kernel_arithmetic": "bf16x3", "achieved": 1150.0, "peak": 2500.0, "frac": 0.46, "unit": "TFLOP/s"}
+    bench.add_sustained(roof)
+    assert roof["peak"] == 2500.0 and roof["frac"] == 0.46
+    s = roof["sustained_bf16"]
+    assert s["source"].startswith("profiles/") and s["source"].endswith("_clock_probe.txt")
+    assert 2300 < s["constant_operands_tflops"] < 2600          # the nominal peak, reproduced by the probe
+    assert 1000 < s["random_operands_tflops"] < s["constant_operands_tflops"]
+    assert abs(s["frac_of_random_operands"] - 1150.0 / s["random_operands_tflops"]) < 1e-3
+    assert "sustained_bf16" in bench.compact_roofline(roof)
+    for other in ({"bound": "hbm", "kernel_arithmetic": "bf16x3", "achieved": 1.0},
+                  {"bound": "mfma", "kernel_arithmetic": "f32", "achieved": 1.0}):
+        bench.add_sustained(other)
+        assert "sustained_bf16" not in other

@@ -29,5 +29,13 @@ for wv, nm in ((0, "wave 0"), (1, "wave 5")):
            "layer 3 %.0f" % m(r[:, :, 1] - r[:, :, 7]), "maxima %.0f" % m(r[:, :, 2] - r[:, :, 1])]
     if tag == "stream":
         out.append("reduce %.0f" % m(r[:, :, 3] - r[:, :, 2]))
+    elif (r[:, :, 3][ok] > 0).all():      # K-row form, round 6: mark 3 = MFMA token taken (inside 'layer 2')
+        out.append("of layer 2: wait for the token %.0f" % m(r[:, :, 3] - r[:, :, 6]))
     out.append("block to block %.0f" % m(nx - r[:, :, 0]))
+    if tag == "krow" and (r[:, :, 5][ok] > 0).all():      # round 6: mark 5 = s_memrealtime (100 MHz) at the block top
+        full = rows[wv::2]
+        dc = (full[:, -1, 0] - full[:, 0, 0]).astype(np.float64)
+        dr = (full[:, -1, 5] - full[:, 0, 5]).astype(np.float64)
+        good = (dr > 0) & (dc > 0)
+        out.append("shader clock %.0f MHz" % (100.0 * float(np.median(dc[good] / dr[good]))))
     print(nm, " | ".join(out))
