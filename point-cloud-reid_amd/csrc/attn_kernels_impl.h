@@ -494,7 +494,7 @@ void attn_kv_stream64_kernel(AttnArgs a) {
             for (int e = 0; e < 8; e++) {
               const f32x4 w = s_p0[16 * s2 + bf_kpos(0, e) + 4 * h];
               const float v = w[0] * px + w[1] * py + w[2] * pz + w[3];
-              hv[e] = fmaxf(v, 0.f);
+              hv[e] = relu_i(v);
             }
             bf_split8(hv, ah[XS + s2], al[XS + s2], true);
           }
@@ -757,7 +757,7 @@ void attn_kv_stream32_kernel(AttnArgs a) {
           for (int e = 0; e < 8; e++) {
             const f32x4 w = s_p0[16 * s2 + bf_kpos(0, e) + 4 * h];
             const float v = w[0] * px + w[1] * py + w[2] * pz + w[3];
-            hv[e] = fmaxf(v, 0.f);
+            hv[e] = relu_i(v);
           }
           bf_split8(hv, ah[2 + s2], al[2 + s2], true);
         }
@@ -1223,7 +1223,7 @@ void attn_apply_stream64_kernel(AttnArgs a) {
         for (int e = 0; e < 8; e++) {
           const f32x4 w = s_p0[16 * s2 + bf_kpos(0, e) + 4 * h];
           const float v = w[0] * px + w[1] * py + w[2] * pz + w[3];
-          hv[e] = fmaxf(v, 0.f);
+          hv[e] = relu_i(v);
         }
         bf_split8(hv, bh[C1S + s2], bl[C1S + s2], true);
       }
@@ -1408,7 +1408,7 @@ void attn_apply_stream64_kernel(AttnArgs a) {
 #pragma unroll
     for (int cb = 0; cb < SD; cb++) {
 #pragma unroll
-      for (int r = 0; r < 16; r++) f[cb][r] = fmaxf(f[cb][r], 0.f);
+      for (int r = 0; r < 16; r++) f[cb][r] = relu_i(f[cb][r]);
 #pragma unroll
       for (int G = 0; G < 2; G++) to_ops(f[cb], G, bh[2 * cb + G], bl[2 * cb + G]);
     }

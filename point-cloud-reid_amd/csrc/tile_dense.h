@@ -694,6 +694,13 @@ __device__ __forceinline__ void bf_ring_load2(const float *__restrict__ wp, int 
 // elu(x) + 1 = x + 1 (x > 0) | exp(x) (x <= 0); hardware exp2 (v_exp_f32, ~1 ulp) instead of the libm
 // expansion: this runs once per projected Q/K element and was a third of the attention kernels' VALU time
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x + 1.0f : __expf(x); }
+// ReLU on the bit pattern (signed integer max; sa_kernels_impl.h relu_bits): the same value for every non-NaN input, one
+// INTEGER VALU instruction -- no canonicalisation prefix, and an integer instruction runs under another wave's MFMAs
+// where an f32 one does not.  (The same swap for elu1's compare measured nothing: profiles/r06_attn_relu_ab.txt.)
+__device__ __forceinline__ float relu_i(float v) {
+  const int b = __float_as_int(v);
+  return __int_as_float(b > 0 ? b : 0);
+}
 
 // LayerNorm over the channel rows [0,C) of buf ([C][RP]) for each of the T token columns, in
 // place; part = tid / T handles channels part, part+np, ...; partial sums meet in `red`

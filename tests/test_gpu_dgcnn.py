@@ -183,10 +183,17 @@ def test_xcorr_pairs_match_reference_golden():
     meta = g["meta"]
     m, _ = build_xcorr()
     s1, s2 = T.synthetic_pairs(meta["pairs"], meta["n"], meta["input_seed"], meta["kind"])
+    from pcr_amd import engine
     with torch.no_grad():
+        # stage by stage in the reference's arithmetic (level 2 = the f32 kernels for the whole chain): local_self_attention
+        # searches its neighbours in FEATURE space, so a last-bit difference in `a` can swap a neighbour and move `b` by 1e-2
+        # without any stage being wrong (tools/fuzz_models.py forced_ptx) -- the stages are held to the golden in the arithmetic
+        # the golden was recorded in, the logits through the guarded entry points in whatever level the guard chose
+        with engine.guard_level(2):
+            xyz1, xyz2, h1, h2 = m.siamese_forward(s1.cuda(), s2.cuda())
+            a = m.cross_stage1(h1, xyz1, h2, xyz2)
+            b = m.local_stage1(a, xyz1)
         xyz1, xyz2, h1, h2 = m.siamese_forward(s1.cuda(), s2.cuda())
-        a = m.cross_stage1(h1, xyz1, h2, xyz2)
-        b = m.local_stage1(a, xyz1)
         logits = m.match_forward_inference(h1, h2, xyz1, xyz2)
     assert np.abs(a.cpu().numpy() - g["xc_a"]).max() < TOL
     assert np.abs(b.cpu().numpy() - g["xc_b"]).max() < TOL
