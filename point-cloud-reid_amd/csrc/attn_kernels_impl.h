@@ -349,8 +349,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 //     1 / Sk scale, accumulator register r of a K block and of a V block go straight into the 64 KV MFMAs.  No LDS
 //     round trip, no transposition, no barrier between the 256 projection MFMAs and the 64 KV MFMAs of a block;
 //   * eight waves (two per SIMD: one's loads / hidden layer / epilogue under the other's MFMAs) share one 64 KB weight
-//     image; a workgroup is persistent over clouds and takes CPG = 8 / min(8, Sk / 32) clouds at a time, so short key
-//     sets (gallery: 128 tokens) still occupy every wave; the waves of a cloud add their KV in wave order (fixed).
+//     image; a workgroup is persistent over clouds and takes CPG = 8 / min(4, Sk / 32) clouds at a time (round 6; before:
+//     min(8, Sk / 32) waves per cloud), so key sets of any length occupy every wave; the waves of a cloud add their KV in
+//     wave order (fixed).
 // Same per-cloud result whatever the batch (shape-only dispatch); rounding differs from the tile kernel's in the
 // last bits (different summation order, 1 / Sk as a multiplication).
 constexpr int kKvsWaves = 8;
@@ -396,10 +397,18 @@ void attn_kv_stream64_kernel(AttnArgs a) {
   }
   __syncthreads();
   const int nblk = p.Sk >> 5;
-  const int wpc = nblk < kKvsWaves ? nblk : kKvsWaves;            // waves per cloud (1, 2, 4 or 8: Sk / 32 clamps)
+  // waves per cloud: min(4, Sk / 32) rounded down to a power of two, at least MINW -- i.e. two or four clouds per workgroup
+  // round.  (Until round 6 a cloud took up to EIGHT waves: at Sk = 1024 the eight partial KV tiles then met in eight
+  // barrier-separated rounds, and that reduction + the fold were 30 % of a round; with four waves a cloud's blocks amortise
+  // them twice as well.  In-process A/B, profiles/r06_kv_wpc_ab.txt: kv[c2=64,Sk=1024] 0.182 -> 0.162 ms, [Sk=512] 0.119 ->
+  // 0.095, [c2=128,Sk=512] 0.174 -> 0.149, [c2=128,Sk=256] 0.127 -> 0.095.  TWO waves per cloud measured another 5 % at
+  // 1024 clouds per launch but leave half the chip idle from 512 clouds down -- pt4096's batch: 0.30 -> 0.51 ms -- and the
+  // choice may not look at the batch: a pair's bits must not depend on the batch it travels in.)  Shape-only, like the rest.
+  constexpr int kMaxWpc = 4;
+  const int wpc = nblk < kMaxWpc ? nblk : kMaxWpc;
   int wpc2 = 1;
-  while (wpc2 * 2 <= wpc) wpc2 *= 2;                              // a power of two ...
-  if (wpc2 < MINW) wpc2 = MINW;                                   // ... and at most four (two: c2 = 128) clouds per round (LDS)
+  while (wpc2 * 2 <= wpc) wpc2 *= 2;
+  if (wpc2 < MINW) wpc2 = MINW;                                   // (c2 = 128: LDS holds two clouds' reduction areas)
   if constexpr (ONEW) wpc2 = 1;
   const int cpg = kKvsWaves / wpc2;                               // clouds per workgroup round
   const int cslot = wave / wpc2, wsub = wave - cslot * wpc2;      // this wave's cloud slot and rank inside it
@@ -1627,10 +1636,10 @@ static int attn_kv_narrow(const pcr_attn_params *pp, pcr_stream_t stream) {
                       allow_big_lds(attn_kv_stream64_kernel<false, kBfUnit, kBfUnit ? 8 : 4>);
     (void)oks;
     const int nblk = pp->Sk >> 5;
-    int wpc2 = 1;
-    while (wpc2 * 2 <= (nblk < kKvsWaves ? nblk : kKvsWaves)) wpc2 *= 2;
     const int minw = wide ? 4 : 2;
-    if (wpc2 < minw) wpc2 = minw;                             // (at most four / two clouds per round: LDS)
+    int wpc2 = 1;
+    while (wpc2 * 2 <= (nblk < 4 ? nblk : 4)) wpc2 *= 2;      // (at most four waves per cloud: the kernel's comment)
+    if (wpc2 < minw) wpc2 = minw;
     // short key sets: one wave per cloud (ONEW; shape-only, the bf16 unit's image only)
     static const int no_onew = pcr_tune_int("PCR_ATTN_NO_ONEW");   // diagnostics
     const bool onew = kBfUnit && bf && !wide && nblk <= 4 && !no_onew;
@@ -1652,7 +1661,7 @@ static int attn_kv_narrow(const pcr_attn_params *pp, pcr_stream_t stream) {
       else hipLaunchKernelGGL((attn_kv_stream64_kernel<false, kBfUnit, kBfUnit ? 8 : 4>), gg, bb, lds_s, st, a);
     } else if (bf) {
       static const char *atrace = pcr_tune_str("PCR_ATTN_TRACE");
-      if (atrace) a.dbg = 256;
+      if (atrace) a.dbg |= 256;
       if (onew) {
         static bool oko = allow_big_lds(attn_kv_stream64_kernel<true, kBfUnit, 4, kBfUnit>) &&
                           allow_big_lds(attn_kv_stream64_kernel<false, kBfUnit, 4, kBfUnit>);
