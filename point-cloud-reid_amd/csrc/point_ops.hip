@@ -1919,7 +1919,7 @@ static int knn_prefix_launch(const float *xyz, int *idx, int B, int N, int S, in
   if (!idx2) S2 = K2 = 0;
   if (B == 0 || S == 0) return PCR_OK;
   if (B > 65535) return PCR_ERR_INVALID;
-  const int qpw = 64;   // queries per workgroup: the cloud is staged once per workgroup
+  const int qpw = 64;   // queries per workgroup: the cloud is staged once per workgroup (32 / 128 / 256 measured: no better)
   dim3 g((S + qpw - 1) / qpw, B), blk(kKnnPThreads);
   size_t lds = (size_t)(3 * N + (N & 1)) * sizeof(float);
   hipStream_t st = pcr_s(stream);
@@ -1932,7 +1932,11 @@ static int knn_prefix_launch(const float *xyz, int *idx, int B, int N, int S, in
   else {
     // sixteen waves share one copy of the cloud in LDS (4 waves per SIMD already at one workgroup per CU)
     constexpr int NT = 1024;
-    const int qpw_l = 128;
+    // queries per workgroup of the LDS form: 512 for clouds of more than 2048 points when that still leaves four workgroups
+    // per CU (its 48 KB staging is then amortised over 32 queries per wave instead of 8: the 4096 x 4096 launch of pt4096
+    // 3.95 -> 3.71 ms in one process, profiles/r06_knn_qpw_ab.txt; the 2048-point launch loses 3 % with it), else 128.
+    // (May look at B: the output is an index list, the same whatever the split.)
+    const int qpw_l = (N > 2048 && (long)((S + 511) / 512) * B >= 1024) ? 512 : 128;
     const dim3 gl((S + qpw_l - 1) / qpw_l, B);
     if (N <= 1024) {
       PCR_KNN_REG(8);   // (the two-pass LDS form measures 1.79 ms against 1.60 here: registers win while they fit)
