@@ -465,18 +465,21 @@ constexpr int kSasCpi = 16;   // centres per item of the ragged form
 
 // the three layers of one 32-row block, shared by the K-row and the ragged form.  In: the row's neighbour i, its centre
 // point ci; out: y3[NCB3], layer 3 TRANSPOSED (lane (cout, h) holds the tokens 8 g + 4 h + q of its channel).
-// lane p of the value's DPP row (16 lanes) to every lane of the row (row_newbcast; p is a constant after unrolling)
-__device__ __forceinline__ float row_bcast_f32(float v, int p) {
-  const int x = __float_as_int(v);
-  int r;
+// s + (lane p of q's DPP row (16 lanes), row_newbcast; p is a constant after unrolling), ONE instruction: the add takes the
+// broadcast as its DPP operand.  (Until round 6 an update_dpp builtin + an add: v_mov_b32 0 / v_mov_b32_dpp / half a
+// v_pk_add_f32 per element, 160 instructions per 128-channel block for its 64 seeds; same bits.  pt1024's three K-row launches
+// 4.145 -> 4.08 ms over six alternations, profiles/r06k_seed_dpp_ab.txt.)  The DPP operand is read two wait states after its
+// last VALU write at the earliest: q comes from a memory load, the caller's s_nop covers the case of a copy.
+__device__ __forceinline__ float add_row_bcast_f32(float s, float q, int p) {
+  float r;
   switch (p & 15) {
-#define PCR_RB(P) case P: r = __builtin_amdgcn_update_dpp(0, x, 0x150 + P, 0xF, 0xF, false); break;
+#define PCR_RB(P) case P: asm("v_add_f32_dpp %0, %1, %2 row_newbcast:" #P " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(q), "v"(s)); break;
     PCR_RB(0) PCR_RB(1) PCR_RB(2) PCR_RB(3) PCR_RB(4) PCR_RB(5) PCR_RB(6) PCR_RB(7)
     PCR_RB(8) PCR_RB(9) PCR_RB(10) PCR_RB(11) PCR_RB(12) PCR_RB(13) PCR_RB(14)
-    default: r = __builtin_amdgcn_update_dpp(0, x, 0x15F, 0xF, 0xF, false); break;
+    default: asm("v_add_f32_dpp %0, %1, %2 row_newbcast:15 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(q), "v"(s)); break;
 #undef PCR_RB
   }
-  return __int_as_float(r);
+  return r;
 }
 
 template <int NCB, int NCB3, bool LO>
@@ -485,15 +488,16 @@ struct SasBlock {
   __device__ static __forceinline__ void run(const float *xyz, const float *pq, int pqw, int qoff, bool has_q, int i, int ci,
                                              const float *s_sh1, const float *s_sh2, const float *s_sh3, const f32x4 *s_wa,
                                              const bf16x8 *s_w2, const bf16x8 *s_w3, int lane, f32x16 (&y3)[NCB3],
-                                             unsigned long long *tr = nullptr, int *tok = nullptr) {
+                                             unsigned long long *tr = nullptr, int *tok = nullptr, const f32x4 *s_sh3r = nullptr) {
     const float dxv = xyz[i * 3] - xyz[ci * 3], dyv = xyz[i * 3 + 1] - xyz[ci * 3 + 1], dzv = xyz[i * 3 + 2] - xyz[ci * 3 + 2];
-    run_d(dxv, dyv, dzv, pq, pqw, qoff, has_q, i, ci, s_sh1, s_sh2, s_sh3, s_wa, s_w2, s_w3, lane, y3, tr, tok);
+    run_d(dxv, dyv, dzv, pq, pqw, qoff, has_q, i, ci, s_sh1, s_sh2, s_sh3, s_wa, s_w2, s_w3, lane, y3, tr, tok, s_sh3r);
   }
   // the same with the row's point - centre given (the ball query's row table holds it)
   __device__ static __forceinline__ void run_d(float dxv, float dyv, float dzv, const float *pq, int pqw, int qoff, bool has_q,
                                                int i, int ci, const float *s_sh1, const float *s_sh2, const float *s_sh3,
                                                const f32x4 *s_wa, const bf16x8 *s_w2, const bf16x8 *s_w3, int lane,
-                                               f32x16 (&y3)[NCB3], unsigned long long *tr = nullptr, int *tok = nullptr) {
+                                               f32x16 (&y3)[NCB3], unsigned long long *tr = nullptr, int *tok = nullptr,
+                                               const f32x4 *s_sh3r = nullptr) {
 #ifdef PCR_SA_TRACE_BUILD   // (diagnostic builds: tr = the caller's record of this block, marks 6 / 7 = layer 1 / layer 2 done)
 #define PCR_BMARK(m) do { if (tr) tr[m] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -536,6 +540,7 @@ struct SasBlock {
 #pragma unroll
           for (int g = 0; g < 4; g++) asm volatile("" : "+v"(ppa[cb][g]));   // (the loads land here, not before each use)
       }
+      if constexpr (HQ) asm volatile("s_nop 1" : "+v"(qv));   // (add_row_bcast_f32: the DPP operand's wait states)
 #pragma unroll
       for (int cb = 0; cb < NCB; cb++) {
         f32x4 pp[4];
@@ -553,7 +558,7 @@ struct SasBlock {
           const f32x4 s4 = cvec(s_sh1, cb, g);
 #pragma unroll
           for (int q2 = 0; q2 < 4; q2++) {
-            if constexpr (HQ) acc[4 * g + q2] = s4[q2] + row_bcast_f32(qv[q2], 4 * cb + g);   // row_newbcast: lane 4 cb + g of the row
+            if constexpr (HQ) acc[4 * g + q2] = add_row_bcast_f32(s4[q2], qv[q2], 4 * cb + g);   // row_newbcast: lane 4 cb + g of the row
             else acc[4 * g + q2] = s4[q2];
           }
         }
@@ -630,11 +635,24 @@ struct SasBlock {
     PCR_BMARK(7);
 #undef PCR_BMARK
     // ---- layer 3 TRANSPOSED (activations as the A operand, the same weight image as B)
+    // (s_sh3r: the shifts four times over, [C3] 16-byte units -- a lane's sixteen seeds of a cout block are ONE value, and four
+    // LDS reads that land in the accumulator registers replace sixteen v_mov: 64 of a 128-channel block's VALU instructions)
+    if (s_sh3r) {
 #pragma unroll
-    for (int cb = 0; cb < NCB3; cb++) {
-      const float sv = s_sh3[cb * 32 + j];
+      for (int cb = 0; cb < NCB3; cb++)
 #pragma unroll
-      for (int rr = 0; rr < 16; rr++) y3[cb][rr] = sv;
+        for (int g = 0; g < 4; g++) {
+          const f32x4 v = *reinterpret_cast<const volatile f32x4 *>(s_sh3r + cb * 32 + j);
+#pragma unroll
+          for (int q2 = 0; q2 < 4; q2++) y3[cb][4 * g + q2] = v[q2];
+        }
+    } else {
+#pragma unroll
+      for (int cb = 0; cb < NCB3; cb++) {
+        const float sv = s_sh3[cb * 32 + j];
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) y3[cb][rr] = sv;
+      }
     }
     const bf16x8 *wb = s_w3 + lane;
 #pragma unroll
@@ -701,6 +719,12 @@ void sa_stream_kernel(Sa2Args a, int nblk_item, int ncen_item) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int *s_tok = reinterpret_cast<int *>(s_gm + kSasWaves * 6 * C3);   // [4 SIMDs] MFMA tokens
   if (tid < 4) s_tok[tid] = 0;
+#ifdef PCR_SEED3_LDS
+  f32x4 *s_sh3r = reinterpret_cast<f32x4 *>(s_tok + 4);              // [C3] the layer-3 shifts, four times over
+  for (int e = tid; e < C3; e += 64 * kSasWaves) s_sh3r[e] = f32x4{a.sh3[e], a.sh3[e], a.sh3[e], a.sh3[e]};
+#else
+  const f32x4 *s_sh3r = nullptr;
+#endif
   sas_stage<NCB, NCB3>(smem, a.wp2, a.wp3, a.sh1, a.sh2, a.sh3, a.wap, 64 * kSasWaves);
   // on for the shapes that run two waves per SIMD (128-wide layers; measured -6..-9 % on pt1024's SA3 launch, same bits);
   // with four waves per SIMD (two workgroups, two tokens) the narrow shapes gain 0-1.5 %: off.  (PCR_SA_DBG bit 1024 of a
@@ -807,7 +831,7 @@ void sa_stream_kernel(Sa2Args a, int nblk_item, int ncen_item) {
       else if (qn < nq) fetch_rows(bq, item, 0);
       f32x16 y[NCB3];
       SasBlock<NCB, NCB3, LO>::run(xyz, pq, a.pqw, a.qoff, has_q, i, ci, s_sh, s_sh + C, s_sh + 2 * C, s_wa, s_w2, s_w3, lane, y,
-                                   PCR_STR(), tok);
+                                   PCR_STR(), tok, s_sh3r);
       PCR_SMARK(1);
       // the maximum over a 16-row group = a maximum over eight of the lane's OWN registers plus one exchange with its
       // partner lane (20 instructions per cout block; the token-per-lane form needs a 4-step DPP reduction of every
@@ -1416,7 +1440,7 @@ void sa_wsplit_rag_kernel(RagArgs a) {
       hi[2 * q] = h2[0];
       hi[2 * q + 1] = h2[1];
       if constexpr (LO) {
-        const bf16x2 l2 = __builtin_convertvector(v - __builtin_convertvector(h2, f32x2), bf16x2);
+        const bf16x2 l2 = __builtin_convertvector(bf_residual2(v, h2), bf16x2);
         lo[2 * q] = l2[0];
         lo[2 * q + 1] = l2[1];
       }
@@ -2472,7 +2496,11 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
       if ((32 * nb) % p.K == 0 && (!nblk_item || small_items)) { nblk_item = nb; ncen_item = 32 * nb / p.K; }
     const size_t fixed = ((size_t)(2 * ncb) * ncb * 128 + (size_t)(2 * ncb) * ncb3 * 128) * 16 + (size_t)(2 * p.c1 + p.c3) * 4 +
                          (size_t)ncb * 64 * 16;
+#ifdef PCR_SEED3_LDS
+    const size_t lds_s = fixed + (size_t)kSasWaves * 6 * p.c3 * 4 + 16 + (size_t)p.c3 * 16;   // (+ the four MFMA tokens, the replicated shifts)
+#else
     const size_t lds_s = fixed + (size_t)kSasWaves * 6 * p.c3 * 4 + 16;   // (+ the four MFMA tokens)
+#endif
     (void)no_stream;
     if (maxe && nblk_item && sas_shape_ok(p, false)) {
       static const int ncu = [] {

@@ -373,6 +373,15 @@ constexpr int bf_pf(int nr) { return nr >= 2 ? 2 : 4; }
 
 __host__ __device__ constexpr int bf_kpos(int h, int j) { return j < 4 ? 4 * h + j : 8 + 4 * h + (j - 4); }
 
+// x - hi for a converted pair (exact: hi is x rounded to 8 significant bits).  Per eight values the split is 4 v_cvt_pk_bf16_f32,
+// 8 v_and / v_lshlrev (hi back to f32), 4 v_pk_add_f32, 4 v_cvt_pk_bf16_f32.  (Round 6, measured and dropped: the residual as
+// v_dot2c_f32_bf16 (hi . {-1, 0} + x; 16 instructions instead of 20) -- not full rate on gfx950 (tools/probe_split.hip: 3 % on a
+// split-only loop, profiles/r06k_split_probe.txt), and hipcc 7.2 folds the two packed constants {-1, 0} and {0, -1} into the same
+// operand (the inline constant -1.0 is the f32 pattern 0xbf800000 = {0, -1}), so the even element comes out wrong.)
+__device__ __forceinline__ f32x2 bf_residual2(const f32x2 v, const bf16x2 h2) {
+  return v - __builtin_convertvector(h2, f32x2);
+}
+
 __device__ __forceinline__ void bf_split8(const float (&x)[8], bf16x8 &hi, bf16x8 &lo, bool want_lo) {
 #pragma unroll
   for (int q = 0; q < 4; q++) {
@@ -381,7 +390,7 @@ __device__ __forceinline__ void bf_split8(const float (&x)[8], bf16x8 &hi, bf16x
     hi[2 * q] = h2[0];
     hi[2 * q + 1] = h2[1];
     if (want_lo) {
-      const f32x2 r = v - __builtin_convertvector(h2, f32x2);
+      const f32x2 r = bf_residual2(v, h2);
       const bf16x2 l2 = __builtin_convertvector(r, bf16x2);
       lo[2 * q] = l2[0];
       lo[2 * q + 1] = l2[1];
