@@ -248,6 +248,12 @@ typedef struct pcr_sa_params {
    * its L2 instead of three or four.  Same results bit for bit (an item's arithmetic does not depend on who runs it).
    * NULL, or a shape the query answers 0 for: fixed-stride items. */
   int *claim_ws;
+  /* optional (ABI 17): nonzero = pq_ws was built by pcr_dense_pm_xyz_f32 (pq_ready must be set): the tables carry the
+   * coordinate term of layer 1 and its shift -- P'[i] = P[i] + wa xyz[i], Q'[c] = Q[c] - wa xyz[c] + shift[0] -- so a row of
+   * layer 1 is relu(P'[i] + Q'[c]): no coordinate loads, no layer-1 MFMAs, one add per element in the launch.  Only the
+   * wave-autonomous K-row kernel reads such tables: set it ONLY when pcr_sa_tables_take_xyz answers 1 for the launch;
+   * any other dispatch returns PCR_ERR_INVALID rather than evaluating the wrong formula. */
+  int pq_has_xyz;
 } pcr_sa_params;
 int pcr_sa_mlp_f32(const pcr_sa_params *p, pcr_stream_t stream);
 /* ints of pcr_sa_params.claim_ws a launch of this shape would use (0: it would not use any); shape-only */
@@ -270,6 +276,17 @@ int pcr_dense_pm_f32(const float *x, const float *wp, float *y, int B, int cin, 
  * PCR_PREC_BF16 */
 int pcr_dense_pm_prec_f32(const float *x, const float *wp_bf, float *y, int B, int cin, int cout, int L,
                           int x_point_major, int precision, pcr_stream_t stream);
+/* (ABI 17) the same tables WITH the coordinate term of the decomposed first layer (reference: the dxyz columns of
+ * sample_and_group_edge's new_points, models/pointnet2_utils.py:242-288): y[b][l][o] = (W x)[o] + wxyz[o][3] +
+ * wxyz[o][0] xyz[b][l][0] + wxyz[o][1] xyz[b][l][1] + wxyz[o][2] xyz[b][l][2], the coordinate products as f32 fmas on the
+ * f32 sum (added z, y, x in that order), whatever `precision` the feature product W x runs in.  xyz (B,L,3), wxyz (cout,4)
+ * row-major: the caller puts {+wa, 0} in the P rows and {-wa, shift} in the Q rows.  cout % 4 == 0. */
+int pcr_dense_pm_xyz_f32(const float *x, const float *wp_bf, const float *xyz, const float *wxyz, float *y, int B, int cin,
+                         int cout, int L, int x_point_major, int precision, pcr_stream_t stream);
+/* shape-only: does the pcr_sa_mlp_f32 launch of this shape run on the wave-autonomous K-row kernel, i.e. may its tables be
+ * built with pcr_dense_pm_xyz_f32 (pcr_sa_params.pq_has_xyz)?  Edge mode (0) with features, c1 == c2 == c3 in {32, 64, 128},
+ * K a multiple of 16 that divides 32, 64 or 96, a bf16 precision. */
+int pcr_sa_tables_take_xyz(int mode, int D, int c1, int c2, int c3, int K, int precision);
 
 /* Linear-attention block shared by Self_Attention (models/pointnet2_utils.py:90-114), FP_SA
  * (:407-437) and corss_attention (models/attention.py:192-219), in two kernels.

@@ -1704,7 +1704,7 @@ __global__ __launch_bounds__(NT) void knn_prefix_lds_kernel(const float *__restr
 }  // namespace
 
 // ------------------------------------------------------------------------------ C ABI ----
-PCR_EXPORT int pcr_abi_version(void) { return 16; }
+PCR_EXPORT int pcr_abi_version(void) { return 17; }
 
 PCR_EXPORT const char *pcr_status_string(int status) {
   switch (status) {

@@ -156,6 +156,7 @@ struct Sa2Args {
   int l1m;                  // layer 1 on the matrix core (wap given and c1 in layer 2's cout-block class)
   float *out;
   int *claim;               // sa_stream_kernel: eight item counters, 1024 ints apart, zeroed by the launch; null = dealt items
+  int xt;                   // sa_stream_kernel: the tables carry layer 1's coordinate term and shift (pcr_sa_params.pq_has_xyz)
 };
 
 // NR / NR2: cout-block rounds per wave of layer 3 / layer 2 (2 when the layer has more than 4 x 32 couts)
@@ -488,16 +489,22 @@ struct SasBlock {
   __device__ static __forceinline__ void run(const float *xyz, const float *pq, int pqw, int qoff, bool has_q, int i, int ci,
                                              const float *s_sh1, const float *s_sh2, const float *s_sh3, const f32x4 *s_wa,
                                              const bf16x8 *s_w2, const bf16x8 *s_w3, int lane, f32x16 (&y3)[NCB3],
-                                             unsigned long long *tr = nullptr, int *tok = nullptr, const f32x4 *s_sh3r = nullptr) {
-    const float dxv = xyz[i * 3] - xyz[ci * 3], dyv = xyz[i * 3 + 1] - xyz[ci * 3 + 1], dzv = xyz[i * 3 + 2] - xyz[ci * 3 + 2];
-    run_d(dxv, dyv, dzv, pq, pqw, qoff, has_q, i, ci, s_sh1, s_sh2, s_sh3, s_wa, s_w2, s_w3, lane, y3, tr, tok, s_sh3r);
+                                             unsigned long long *tr = nullptr, int *tok = nullptr, bool xt = false) {
+    // xt (pcr_sa_params.pq_has_xyz): the tables carry the coordinate term and layer 1's shift -- no coordinates are read
+    float dxv = 0.f, dyv = 0.f, dzv = 0.f;
+    if (!xt) {
+      dxv = xyz[i * 3] - xyz[ci * 3];
+      dyv = xyz[i * 3 + 1] - xyz[ci * 3 + 1];
+      dzv = xyz[i * 3 + 2] - xyz[ci * 3 + 2];
+    }
+    run_d(dxv, dyv, dzv, pq, pqw, qoff, has_q, i, ci, s_sh1, s_sh2, s_sh3, s_wa, s_w2, s_w3, lane, y3, tr, tok, xt);
   }
   // the same with the row's point - centre given (the ball query's row table holds it)
   __device__ static __forceinline__ void run_d(float dxv, float dyv, float dzv, const float *pq, int pqw, int qoff, bool has_q,
                                                int i, int ci, const float *s_sh1, const float *s_sh2, const float *s_sh3,
                                                const f32x4 *s_wa, const bf16x8 *s_w2, const bf16x8 *s_w3, int lane,
                                                f32x16 (&y3)[NCB3], unsigned long long *tr = nullptr, int *tok = nullptr,
-                                               const f32x4 *s_sh3r = nullptr) {
+                                               bool xt = false) {
 #ifdef PCR_SA_TRACE_BUILD   // (diagnostic builds: tr = the caller's record of this block, marks 6 / 7 = layer 1 / layer 2 done)
 #define PCR_BMARK(m) do { if (tr) tr[m] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -579,7 +586,48 @@ struct SasBlock {
         }
       }
     };
-    if (pq) {
+    // xt: a row of layer 1 is relu(P'[i] + Q'[c]) -- the table pieces gathered in accumulator layout plus the centre's row by
+    // row broadcast, ONE v_add_f32_dpp per element: no coordinate loads, no seeds, none of the two f32 MFMAs per cout block
+    // (512 matrix cycles of a 128-channel block) and no second add.  (Round 6: -x % on pt1024's SA2 / SA3 launches.)
+    auto layer1_xt = [&]() __attribute__((always_inline)) {
+      f32x4 ppa[kAllP ? NCB : 1][4];
+      if constexpr (kAllP) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+          const float *pr = pq + (size_t)i * pqw + cb * 32 + 4 * h;
+#pragma unroll
+          for (int g = 0; g < 4; g++) ppa[cb][g] = *reinterpret_cast<const f32x4 *>(pr + 8 * g);
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+          for (int g = 0; g < 4; g++) asm volatile("" : "+v"(ppa[cb][g]));
+      }
+      asm volatile("s_nop 1" : "+v"(qv));   // (add_row_bcast_f32: the DPP operand's wait states)
+#pragma unroll
+      for (int cb = 0; cb < NCB; cb++) {
+        f32x4 pp[4];
+        const float *pr = pq + (size_t)i * pqw + cb * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          if constexpr (kAllP) pp[g] = ppa[cb][g];
+          else pp[g] = *reinterpret_cast<const f32x4 *>(pr + 8 * g);
+        }
+#pragma unroll
+        for (int G = 0; G < 2; G++) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const int rr = 8 * G + e;
+            v[e] = relu_bits(add_row_bcast_f32(pp[rr >> 2][rr & 3], qv[rr & 3], 4 * cb + (rr >> 2)));
+          }
+          bf_split8(v, bh[2 * cb + G], bl[2 * cb + G], LO);
+        }
+      }
+    };
+    if (xt) {
+      layer1_xt();
+    } else if (pq) {
       if (has_q) layer1(std::true_type{}, std::true_type{});
       else layer1(std::false_type{}, std::true_type{});
     } else {
@@ -635,24 +683,15 @@ struct SasBlock {
     PCR_BMARK(7);
 #undef PCR_BMARK
     // ---- layer 3 TRANSPOSED (activations as the A operand, the same weight image as B)
-    // (s_sh3r: the shifts four times over, [C3] 16-byte units -- a lane's sixteen seeds of a cout block are ONE value, and four
-    // LDS reads that land in the accumulator registers replace sixteen v_mov: 64 of a 128-channel block's VALU instructions)
-    if (s_sh3r) {
+    // (round 6, measured and dropped: these seeds from an LDS table that holds every shift four times over -- four
+    // ds_read_b128 that land in the accumulator registers instead of sixteen v_mov per cout block: the three K-row launches of
+    // pt1024 4.04 -> 4.19 ms, of pt4096 8.07 -> 8.48, profiles/r06k_seed3_lds_ab.txt.  A v_mov runs under the other wave's
+    // MFMAs; the LDS round trip sits in front of this wave's first one.)
 #pragma unroll
-      for (int cb = 0; cb < NCB3; cb++)
+    for (int cb = 0; cb < NCB3; cb++) {
+      const float sv = s_sh3[cb * 32 + j];
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const f32x4 v = *reinterpret_cast<const volatile f32x4 *>(s_sh3r + cb * 32 + j);
-#pragma unroll
-          for (int q2 = 0; q2 < 4; q2++) y3[cb][4 * g + q2] = v[q2];
-        }
-    } else {
-#pragma unroll
-      for (int cb = 0; cb < NCB3; cb++) {
-        const float sv = s_sh3[cb * 32 + j];
-#pragma unroll
-        for (int rr = 0; rr < 16; rr++) y3[cb][rr] = sv;
-      }
+      for (int rr = 0; rr < 16; rr++) y3[cb][rr] = sv;
     }
     const bf16x8 *wb = s_w3 + lane;
 #pragma unroll
@@ -719,12 +758,6 @@ void sa_stream_kernel(Sa2Args a, int nblk_item, int ncen_item) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int *s_tok = reinterpret_cast<int *>(s_gm + kSasWaves * 6 * C3);   // [4 SIMDs] MFMA tokens
   if (tid < 4) s_tok[tid] = 0;
-#ifdef PCR_SEED3_LDS
-  f32x4 *s_sh3r = reinterpret_cast<f32x4 *>(s_tok + 4);              // [C3] the layer-3 shifts, four times over
-  for (int e = tid; e < C3; e += 64 * kSasWaves) s_sh3r[e] = f32x4{a.sh3[e], a.sh3[e], a.sh3[e], a.sh3[e]};
-#else
-  const f32x4 *s_sh3r = nullptr;
-#endif
   sas_stage<NCB, NCB3>(smem, a.wp2, a.wp3, a.sh1, a.sh2, a.sh3, a.wap, 64 * kSasWaves);
   // on for the shapes that run two waves per SIMD (128-wide layers; measured -6..-9 % on pt1024's SA3 launch, same bits);
   // with four waves per SIMD (two workgroups, two tokens) the narrow shapes gain 0-1.5 %: off.  (PCR_SA_DBG bit 1024 of a
@@ -734,6 +767,7 @@ void sa_stream_kernel(Sa2Args a, int nblk_item, int ncen_item) {
   const int nitem = (a.S + ncen_item - 1) / ncen_item;  // items per cloud
   float *gm = s_gm + wave * 6 * C3;
   const bool has_q = a.pq && a.qoff >= 0;
+  const bool xt = a.xt != 0 && has_q;
   // XCD-aware item order: workgroup w sits on XCD w % 8; the clouds b % 8 == x belong to XCD x
   const int xcd = blockIdx.x & 7, wrank = (blockIdx.x >> 3) * kSasWaves + wave, wstride = ((gridDim.x + 7 - xcd) >> 3) * kSasWaves;
   const int nq = ((a.B + 7 - xcd) >> 3) * nitem;                 // items of this XCD's clouds (the host keeps B x items < 2^31)
@@ -831,7 +865,7 @@ void sa_stream_kernel(Sa2Args a, int nblk_item, int ncen_item) {
       else if (qn < nq) fetch_rows(bq, item, 0);
       f32x16 y[NCB3];
       SasBlock<NCB, NCB3, LO>::run(xyz, pq, a.pqw, a.qoff, has_q, i, ci, s_sh, s_sh + C, s_sh + 2 * C, s_wa, s_w2, s_w3, lane, y,
-                                   PCR_STR(), tok, s_sh3r);
+                                   PCR_STR(), tok, xt);
       PCR_SMARK(1);
       // the maximum over a 16-row group = a maximum over eight of the lane's OWN registers plus one exchange with its
       // partner lane (20 instructions per cout block; the token-per-lane form needs a 4-step DPP reduction of every
@@ -1973,6 +2007,7 @@ struct DensePmArgs {
   const float *x, *wp;
   float *y;
   int cin, cout, L, x_pm;
+  const float *xyz, *wxyz;  // pcr_dense_pm_xyz_f32: (B,L,3) and (cout,4) {wx, wy, wz, bias}, or null
 };
 
 // NR: cout-block rounds per wave (2 when cout > 128).  X and Y share one LDS buffer (barrier between the
@@ -1993,6 +2028,17 @@ __global__ __launch_bounds__(kThreads) void dense_pm_kernel(DensePmArgs a) {
   const int t0 = blockIdx.x * T;
   if (a.x_pm) load_tile_pm(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
   else load_tile(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
+  // pcr_dense_pm_xyz_f32: the tile's coordinates and the window's rows of {wx, wy, wz, bias}, behind the activation buffer
+  // (the launcher sized it), for the store phase
+  float *s_xyz = X + (cinP > ceil32(wc) ? cinP : ceil32(wc)) * RP;
+  f32x4 *s_wx = reinterpret_cast<f32x4 *>(s_xyz + 3 * T);     // [wc] the window's rows {wx, wy, wz, bias}
+  if (a.xyz) {
+    if (threadIdx.x < 3 * T) {
+      const int t = threadIdx.x / 3;
+      s_xyz[threadIdx.x] = t0 + t < a.L ? a.xyz[(b * a.L + t0) * 3 + threadIdx.x] : 0.f;
+    }
+    if (threadIdx.x < wc) s_wx[threadIdx.x] = reinterpret_cast<const f32x4 *>(a.wxyz)[w0 + threadIdx.x];
+  }
   __syncthreads();
   tile_dense2p<PREC, TB, NR>(X, cinP, a.wp + (size_t)w0 * (PREC == 0 ? 8 : 16), ceil32(wc), true,
                              [&](float v, int o, int t) { X[o * RP + t] = v; }, nullptr, nullptr, DenseNoHook(), ceil32(cout));
@@ -2006,7 +2052,16 @@ __global__ __launch_bounds__(kThreads) void dense_pm_kernel(DensePmArgs a) {
     for (int e = threadIdx.x; e < total; e += kThreads) {
       if (t0 + t < a.L) {
         const float *xs = X + 4 * q * RP + t;
-        *reinterpret_cast<f32x4 *>(out + (size_t)t * cout + 4 * q) = f32x4{xs[0], xs[RP], xs[2 * RP], xs[3 * RP]};
+        f32x4 v = {xs[0], xs[RP], xs[2 * RP], xs[3 * RP]};
+        if (a.xyz) {
+          const float px = s_xyz[3 * t], py = s_xyz[3 * t + 1], pz = s_xyz[3 * t + 2];
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            const f32x4 w = s_wx[4 * q + c];
+            v[c] = __builtin_fmaf(w[0], px, __builtin_fmaf(w[1], py, __builtin_fmaf(w[2], pz, v[c] + w[3])));
+          }
+        }
+        *reinterpret_cast<f32x4 *>(out + (size_t)t * cout + 4 * q) = v;
       }
       t += dt;
       q += dq;
@@ -2468,6 +2523,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
   const int dbg = pcr_tune_int("PCR_SA_DBG");    // (0 in production; a tuning build re-reads it per launch: in-process A/Bs)
   a.dbg = dbg;
   a.claim = nullptr;
+  a.xt = 0;
   a.wp2 = wl2; a.wp3 = wl3;
   a.sh1 = p.shift[0]; a.sh2 = p.shift_pad[0]; a.sh3 = p.shift_pad[1];
   a.out = p.out;
@@ -2496,11 +2552,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
       if ((32 * nb) % p.K == 0 && (!nblk_item || small_items)) { nblk_item = nb; ncen_item = 32 * nb / p.K; }
     const size_t fixed = ((size_t)(2 * ncb) * ncb * 128 + (size_t)(2 * ncb) * ncb3 * 128) * 16 + (size_t)(2 * p.c1 + p.c3) * 4 +
                          (size_t)ncb * 64 * 16;
-#ifdef PCR_SEED3_LDS
-    const size_t lds_s = fixed + (size_t)kSasWaves * 6 * p.c3 * 4 + 16 + (size_t)p.c3 * 16;   // (+ the four MFMA tokens, the replicated shifts)
-#else
     const size_t lds_s = fixed + (size_t)kSasWaves * 6 * p.c3 * 4 + 16;   // (+ the four MFMA tokens)
-#endif
     (void)no_stream;
     if (maxe && nblk_item && sas_shape_ok(p, false)) {
       static const int ncu = [] {
@@ -2520,6 +2572,8 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
       static const char *ktrace = pcr_tune_str("PCR_SA_TRACE");
       if (ktrace) a.dbg |= 256;
       // claimed items (shape-only: pcr_sa_claim_ws_ints says when; PCR_SA_DBG bit 4096 of a tuning build switches them off)
+      a.xt = (p.pq_has_xyz && p.D && p.pq_ready && p.mode == 0) ? 1 : 0;
+      if (p.pq_has_xyz && !a.xt) return PCR_ERR_INVALID;
       a.claim = (p.claim_ws && sas_claims(p.c1, p.c3, p.N) && !(a.dbg & 4096)) ? p.claim_ws : nullptr;
       if (a.claim && hipMemsetAsync(a.claim, 0, (size_t)kSasClaimInts * sizeof(int), st) != hipSuccess) return PCR_ERR_LAUNCH;
 #define PCR_SAS(NCBv, NCB3v)                                                                  \
@@ -2540,6 +2594,7 @@ static int sa2_try(const pcr_sa_params &p, pcr_stream_t st_) {
     }
   }
 #endif
+  if (p.pq_has_xyz) return PCR_ERR_INVALID;   // (tables with the coordinate term: the K-row kernel above is their only reader)
   const size_t lds = lds_bytes(best_tb, best_cpw);
   dim3 grid((p.S + best_cpw - 1) / best_cpw, p.B);
   const int w2 = n2 >= 3 ? 1 : (n2 == 2 ? 2 : 4), w3 = n3 >= 3 ? 1 : (n3 == 2 ? 2 : 4);
@@ -2588,6 +2643,17 @@ PCR_EXPORT int pcr_sa_krow_uses_tiles(int c1, int c2, int c3, int K, int precisi
   return precision != 0 && c1 == 128 && c2 == 128 && c3 == 256 && K >= 1 && K <= 64;
 }
 
+// sa2_try's K-row dispatch for the shapes whose tables may carry the coordinate term (pcr_sa_params.pq_has_xyz)
+PCR_EXPORT int pcr_sa_tables_take_xyz(int mode, int D, int c1, int c2, int c3, int K, int precision) {
+  static const int no_stream = pcr_tune_int("PCR_SA_NO_STREAM"), no_xt = pcr_tune_int("PCR_SA_NO_XYZ_TABLES");   // diagnostics
+  if (no_stream || no_xt || precision == 0 || mode != 0 || D < 1 || c1 != c2 || c2 != c3 || !(c1 == 32 || c1 == 64 || c1 == 128))
+    return 0;
+  if (K < 16 || (K & 15) || !(32 % K == 0 || 64 % K == 0 || 96 % K == 0)) return 0;
+  const int ncb = c1 >> 5;
+  const size_t fixed = ((size_t)(2 * ncb) * ncb * 128 * 2) * 16 + (size_t)(3 * c1) * 4 + (size_t)ncb * 64 * 16;
+  return fixed + (size_t)8 * 6 * c3 * 4 + 16 <= (size_t)160 * 1024;
+}
+
 PCR_EXPORT long pcr_sa_claim_ws_ints(int c1, int c2, int c3, int K, int N, int precision) {
   // the wave-autonomous K-row form's shapes (equal widths, whole 16-row groups) in a bf16 mode, on large clouds
   if (precision == 0 || c1 != c2 || c2 != c3 || (K & 15) || K < 16) return 0;
@@ -2604,19 +2670,20 @@ PCR_EXPORT long pcr_sa_tile_ws_ints(int B, int S, int K, int c2, int c3) {
 }
 
 static int dense_pm_launch(const float *x, const float *wp, float *y, int B, int cin, int cout, int L, int x_point_major,
-                           int precision, pcr_stream_t stream) {
+                           int precision, pcr_stream_t stream, const float *xyz = nullptr, const float *wxyz = nullptr) {
   if (!x || !wp || !y || B < 0 || cin < 1 || cout < 1 || cout > 1024 || L < 1 || precision < 0 || precision > 2)
     return PCR_ERR_INVALID;
+  if ((xyz != nullptr) != (wxyz != nullptr) || (xyz && (cout & 3))) return PCR_ERR_INVALID;
   if (cout > 256 && (cout & 3)) return PCR_ERR_INVALID;   // windows of 256 couts keep the 16-byte store path
   if (B == 0) return PCR_OK;
   if (B > 65535) return PCR_ERR_INVALID;
   pcr_note_arith(precision);
-  DensePmArgs d{x, wp, y, cin, cout, L, x_point_major};
+  DensePmArgs d{x, wp, y, cin, cout, L, x_point_major, xyz, wxyz};
   {
     // point-major in and out, whole tiles, the weight rows of a wave in registers: the persistent form (shape-only choice)
     static const int no_res = pcr_tune_int("PCR_DENSE_PM_NO_RES");   // diagnostics
     const long ntok = (long)B * L;
-    if (!no_res && precision != 0 && x_point_major && (cin == 32 || cin == 64 || cin == 128) && (cout == 64 || cout == 128) &&
+    if (!no_res && !xyz && precision != 0 && x_point_major && (cin == 32 || cin == 64 || cin == 128) && (cout == 64 || cout == 128) &&
         ntok % 64 == 0 && (reinterpret_cast<size_t>(x) & 15) == 0 && (reinterpret_cast<size_t>(y) & 15) == 0) {
       static const int ncu = [] {
         int dev = 0, n = 0;
@@ -2654,7 +2721,7 @@ static int dense_pm_launch(const float *x, const float *wp, float *y, int B, int
   }
   const int wmax = cout < 256 ? cout : 256;
   const int rows = ceil8(cin) > ceil32(wmax) ? ceil8(cin) : ceil32(wmax);
-  size_t lds = (size_t)rows * 65 * sizeof(float);
+  size_t lds = (size_t)rows * 65 * sizeof(float) + (xyz ? (size_t)(3 * 64 + 4 * wmax) * sizeof(float) : 0);
   if (lds > (size_t)kMaxDynLds) return PCR_ERR_INVALID;
   const dim3 grid((L + 63) / 64, B, (cout + 255) / 256);
 #define PCR_PM(NRv, PRv)                                                                          \
@@ -2688,6 +2755,12 @@ PCR_EXPORT int pcr_dense_pm_prec_f32(const float *x, const float *wp_bf, float *
   return dense_pm_launch(x, wp_bf, y, B, cin, cout, L, x_point_major, precision, stream);
 }
 
+PCR_EXPORT int pcr_dense_pm_xyz_f32(const float *x, const float *wp_bf, const float *xyz, const float *wxyz, float *y, int B,
+                                    int cin, int cout, int L, int x_point_major, int precision, pcr_stream_t stream) {
+  if ((precision != 1 && precision != 2) || !xyz || !wxyz) return PCR_ERR_INVALID;
+  return dense_pm_launch(x, wp_bf, y, B, cin, cout, L, x_point_major, precision, stream, xyz, wxyz);
+}
+
 PCR_EXPORT int pcr_sa_mlp_f32(const pcr_sa_params *pp, pcr_stream_t stream) {
   if (!pp) return PCR_ERR_INVALID;
   const pcr_sa_params &p = *pp;
@@ -2698,8 +2771,13 @@ PCR_EXPORT int pcr_sa_mlp_f32(const pcr_sa_params *pp, pcr_stream_t stream) {
     if (!p.wp[l] || !p.scale[l] || !p.shift[l]) return PCR_ERR_INVALID;
   if (p.B == 0 || p.S == 0) return PCR_OK;
   if (p.B > 65535) return PCR_ERR_INVALID;
+  // tables with the coordinate term (ABI 17): edge mode with features, built by the caller, a shape the query accepts
+  if (p.pq_has_xyz && (p.mode != 0 || !p.D || !p.pq_ready || !p.pq_ws ||
+                       !pcr_sa_tables_take_xyz(p.mode, p.D, p.c1, p.c2, p.c3, p.K, p.precision)))
+    return PCR_ERR_INVALID;
   const int fast = sa2_try(p, stream);
   if (fast >= 0) return fast;
+  if (p.pq_has_xyz) return PCR_ERR_INVALID;   // (only the wave-autonomous K-row kernel reads such tables)
   if (!p.idx) return PCR_ERR_INVALID;   // (a row table without an index tensor: only the kernel that reads the table will do)
   pcr_note_arith(PCR_PREC_F32);
   SaArgs a;

@@ -209,7 +209,7 @@ class ReIDNet(nn.Module):
 
     def calibrate_precision(self, sparse_1, sparse_2, bound=None, max_pairs=64):
         """split-bf16 guard: run the hot path on (up to max_pairs of) this batch in f32 and at guard levels 0, 1, 2, keep the
-        first level whose logits stay within `bound` (engine.GUARD_BOUND, half the 1e-4 parity bound) of the f32 path's,
+        first level whose logits stay within engine.GUARD_ACCEPT x `bound` (engine.GUARD_BOUND, half the 1e-4 parity bound) of the f32 path's,
         for as long as the weights do not change (the sentinel re-checks it on live batches: _guard_tick).
         -> {"level", "dlogit": {level: max |logit - f32 logit|}, ...}"""
         bound = engine.GUARD_BOUND if bound is None else float(bound)
@@ -226,7 +226,7 @@ class ReIDNet(nn.Module):
                     for level in (0, 1, 2):
                         with engine.guard_level(level):
                             dl[level] = float((self._hot(s1, s2) - ref).abs().max())
-                        if dl[level] <= bound:
+                        if dl[level] <= bound * engine.GUARD_ACCEPT:      # (a margin for the next batch: engine.GUARD_ACCEPT)
                             break
             finally:
                 self.__dict__["_pcr_guard_busy"] = False

@@ -11,7 +11,7 @@ _TAG = os.environ.get("PCR_LIB_TAG", "")
 SO_PATH = os.path.join(_HERE, "lib", "libpcr_hip%s.so" % ("_" + _TAG if _TAG else ""))
 _lib = None
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class PcrError(RuntimeError):

@@ -84,6 +84,11 @@ class precision:
 # PCR_GUARD=0 switches the guard off; PCR_GUARD_BOUND moves the bound.
 GUARD = _os.environ.get("PCR_GUARD", "1") != "0"
 GUARD_BOUND = float(_os.environ.get("PCR_GUARD_BOUND", "5e-5"))
+# CALIBRATION accepts a level only at GUARD_ACCEPT x the bound: the deviation of a fresh batch of the same distribution was
+# measured at up to 1.3x (near the bound; 1.5x further below it) that of the calibration batch (tools/guard_cases.py,
+# profiles/r06m_guard_cases.txt: a 128-point Point-Transformer at input scale 0.1 calibrated at 4.65e-5 and returned 5.95e-5
+# on the next batch).  The sentinel keeps the bound itself: it measures the live batch.
+GUARD_ACCEPT = float(_os.environ.get("PCR_GUARD_ACCEPT", "0.9"))
 GUARD_EVERY = int(_os.environ.get("PCR_GUARD_EVERY", "64"))
 GUARD_SENTINEL_PAIRS = int(_os.environ.get("PCR_GUARD_SENTINEL_PAIRS", "8"))
 _LEVEL = 0
@@ -120,6 +125,11 @@ def guarded(fn):
 # claimed work items for the wave-autonomous K-row SA kernel on clouds of >= 1024 points (pcr_sa_params.claim_ws, ABI 16;
 # PCR_SA_CLAIMS=0 / engine.SA_CLAIMS = False: fixed-stride items -- same bits, tests/test_gpu_sa_claims.py)
 SA_CLAIMS = _os.environ.get("PCR_SA_CLAIMS", "1") != "0"
+
+# tables WITH the coordinate term for the wave-autonomous K-row SA kernel in the bf16 modes (pcr_dense_pm_xyz_f32 /
+# pcr_sa_params.pq_has_xyz, ABI 17; PCR_SA_XYZ_TABLES=0 / engine.SA_XYZ_TABLES = False: the coordinate term on the matrix core
+# inside the launch, as in the f32 mode -- tests/test_gpu_sa_xyz_tables.py holds the two forms against each other)
+SA_XYZ_TABLES = _os.environ.get("PCR_SA_XYZ_TABLES", "1") != "0"
 
 # bench.py sets this to a list to collect (kernel, start_event, end_event, algorithmic flops,
 # algorithmic bytes, issued flops, arithmetic) per launch; events are recorded on the stream the kernels are launched on.
@@ -165,7 +175,7 @@ class SaParams(ctypes.Structure):
                 ("feat_point_major", ctypes.c_int), ("out_point_major", ctypes.c_int),
                 ("out", c_float_p), ("wa_packed", c_float_p),
                 ("precision", ctypes.c_int), ("wps_bf", c_float_p * 2), ("wa_shift_packed", c_float_p),
-                ("row_tab", c_float_p), ("claim_ws", c_int_p)]
+                ("row_tab", c_float_p), ("claim_ws", c_int_p), ("pq_has_xyz", ctypes.c_int)]
 
 
 class AttnParams(ctypes.Structure):
@@ -323,6 +333,13 @@ class SaPlan:
                 stacked = w1[:, 3:3 + D] * sc1
             self.wpq = pack_weight(stacked.float(), device)
             self.wpq_bf = pack_weight_bf(stacked.float(), device)
+            if mode == 0:
+                # (ABI 17) the coordinate term and the shift as table columns (pcr_dense_pm_xyz_f32): P rows {+wa, 0}, Q rows
+                # {-wa, shift}, so that a row of layer 1 is relu(P'[i] + Q'[c]) in the wave-autonomous K-row kernel
+                wa64 = w1[:, :3] * sc1
+                sh64 = self.shift[0].detach().double().cpu().unsqueeze(1)
+                self.wxyz = _dev32(torch.cat([torch.cat([wa64, torch.zeros_like(sh64)], dim=1),
+                                              torch.cat([-wa64, sh64], dim=1)], dim=0).float().contiguous(), device)
 
     def wants_row_table(self, N, K, min_radius, B=1, S=1):
         """does the ragged launch of this layer read the ball query's row table (ops.ball_query_rows)?  Everything the
@@ -396,6 +413,7 @@ class SaPlan:
                 p.wps[i], p.shift_pad[i] = _p(self.wps[i]), _p(self.shift_pad[i])
                 p.wps_bf[i] = _p(self.wps_bf[i])
             if D:
+                c1_, c2_, c3_ = self.couts
                 pqw = (2 if self.mode == 0 else 1) * self.couts[0]
                 ws = torch.empty((B, N, pqw), dtype=torch.float32, device=xyz.device)
                 p.wpq, p.pq_ws = _p(self.wpq), _p(ws)
@@ -405,6 +423,14 @@ class SaPlan:
                     if PRECISION == "f32":
                         L.check(L.load().pcr_dense_pm_f32(L.ptr(feat), L.ptr(self.wpq), L.ptr(ws), B, D, pqw, N,
                                                           int(feat_pm), L.stream_ptr()), "pcr_dense_pm_f32")
+                    elif (SA_XYZ_TABLES and not ragged and not tiled and idx is not None and
+                          L.load().pcr_sa_tables_take_xyz(self.mode, D, c1_, c2_, c3_, K, PRECISIONS[PRECISION])):
+                        # the K-row kernel's shapes: tables WITH the coordinate term and the shift (exact f32 fmas on top of
+                        # the feature product), and the launch below adds P'[i] + Q'[c] and nothing else in its first layer
+                        L.check(L.load().pcr_dense_pm_xyz_f32(L.ptr(feat), L.ptr(self.wpq_bf), L.ptr(xyz), L.ptr(self.wxyz),
+                                                              L.ptr(ws), B, D, pqw, N, int(feat_pm), PRECISIONS[PRECISION],
+                                                              L.stream_ptr()), "pcr_dense_pm_xyz_f32")
+                        p.pq_has_xyz = 1
                     else:   # the tables on the bf16 matrix core too (the layer-1 MFMAs on the coordinates stay f32)
                         L.check(L.load().pcr_dense_pm_prec_f32(L.ptr(feat), L.ptr(self.wpq_bf), L.ptr(ws), B, D, pqw, N,
                                                                int(feat_pm), PRECISIONS[PRECISION], L.stream_ptr()),

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert len(syms) >= 20
     for s in syms:
         assert hasattr(lib, s), "libpcr_hip.so does not export %s" % s
-    assert lib.pcr_abi_version() == 16
+    assert lib.pcr_abi_version() == 17
     assert lib.pcr_status_string(0) == b"ok"
 
 
