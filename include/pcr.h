@@ -280,9 +280,12 @@ int pcr_dense_pm_prec_f32(const float *x, const float *wp_bf, float *y, int B, i
  * sample_and_group_edge's new_points, models/pointnet2_utils.py:242-288): y[b][l][o] = (W x)[o] + wxyz[o][3] +
  * wxyz[o][0] xyz[b][l][0] + wxyz[o][1] xyz[b][l][1] + wxyz[o][2] xyz[b][l][2], the coordinate products as f32 fmas on the
  * f32 sum (added z, y, x in that order), whatever `precision` the feature product W x runs in.  xyz (B,L,3), wxyz (cout,4)
- * row-major: the caller puts {+wa, 0} in the P rows and {-wa, shift} in the Q rows.  cout % 4 == 0. */
+ * row-major: the caller puts {+wa, 0} in the P rows and {-wa, shift} in the Q rows.  cout % 4 == 0.
+ * q_rows / q_off: tokens l >= q_rows receive the couts [0, q_off) only, the rest of their rows is left unwritten -- the Q
+ * half of an SA table is read for CENTRES only, which under prefix sampling (centre_idx == NULL) are the first S points:
+ * q_rows = S rounded up to a multiple of 64, q_off = c1.  q_rows = L, q_off = cout: every token, every cout. */
 int pcr_dense_pm_xyz_f32(const float *x, const float *wp_bf, const float *xyz, const float *wxyz, float *y, int B, int cin,
-                         int cout, int L, int x_point_major, int precision, pcr_stream_t stream);
+                         int cout, int L, int x_point_major, int precision, int q_rows, int q_off, pcr_stream_t stream);
 /* shape-only: does the pcr_sa_mlp_f32 launch of this shape run on the wave-autonomous K-row kernel, i.e. may its tables be
  * built with pcr_dense_pm_xyz_f32 (pcr_sa_params.pq_has_xyz)?  Edge mode (0) with features, c1 == c2 == c3 in {32, 64, 128},
  * K a multiple of 16 that divides 32, 64 or 96, a bf16 precision. */

@@ -2008,6 +2008,7 @@ struct DensePmArgs {
   float *y;
   int cin, cout, L, x_pm;
   const float *xyz, *wxyz;  // pcr_dense_pm_xyz_f32: (B,L,3) and (cout,4) {wx, wy, wz, bias}, or null
+  int q_rows, q_off;        // pcr_dense_pm_xyz_f32: tokens >= q_rows get the couts [0, q_off) only (q_rows = L: all couts)
 };
 
 // NR: cout-block rounds per wave (2 when cout > 128).  X and Y share one LDS buffer (barrier between the
@@ -2022,10 +2023,16 @@ __global__ __launch_bounds__(kThreads) void dense_pm_kernel(DensePmArgs a) {
   // of the packed image start 8 floats per cout further in, the k-block stride stays that of the whole image
   const int cinP = ceil8(a.cin), cout = a.cout;
   const int w0 = blockIdx.z * 256;
-  const int wc = cout - w0 < 256 ? cout - w0 : 256;
+  int wc = cout - w0 < 256 ? cout - w0 : 256;
   float *X = smem;   // [max(cinP, ceil32(wc))][RP]
   const size_t b = blockIdx.y;
   const int t0 = blockIdx.x * T;
+  // (pcr_dense_pm_xyz_f32 with q_rows < L: the Q half of the SA tables is read for CENTRES only -- the first q_rows points
+  // under prefix sampling -- so the tiles behind them compute and store the P half alone)
+  if (a.xyz && t0 >= a.q_rows) {
+    if (w0 >= a.q_off) return;
+    if (w0 + wc > a.q_off) wc = a.q_off - w0;
+  }
   if (a.x_pm) load_tile_pm(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
   else load_tile(X, RP, a.x + b * a.cin * a.L, a.cin, cinP, a.L, t0, T);
   // pcr_dense_pm_xyz_f32: the tile's coordinates and the window's rows of {wx, wy, wz, bias}, behind the activation buffer
@@ -2670,15 +2677,17 @@ PCR_EXPORT long pcr_sa_tile_ws_ints(int B, int S, int K, int c2, int c3) {
 }
 
 static int dense_pm_launch(const float *x, const float *wp, float *y, int B, int cin, int cout, int L, int x_point_major,
-                           int precision, pcr_stream_t stream, const float *xyz = nullptr, const float *wxyz = nullptr) {
+                           int precision, pcr_stream_t stream, const float *xyz = nullptr, const float *wxyz = nullptr,
+                           int q_rows = 0, int q_off = 0) {
   if (!x || !wp || !y || B < 0 || cin < 1 || cout < 1 || cout > 1024 || L < 1 || precision < 0 || precision > 2)
     return PCR_ERR_INVALID;
   if ((xyz != nullptr) != (wxyz != nullptr) || (xyz && (cout & 3))) return PCR_ERR_INVALID;
+  if (xyz && (q_rows < 0 || q_rows > L || (q_rows != L && (q_rows & 63)) || q_off < 4 || q_off > cout || (q_off & 3))) return PCR_ERR_INVALID;
   if (cout > 256 && (cout & 3)) return PCR_ERR_INVALID;   // windows of 256 couts keep the 16-byte store path
   if (B == 0) return PCR_OK;
   if (B > 65535) return PCR_ERR_INVALID;
   pcr_note_arith(precision);
-  DensePmArgs d{x, wp, y, cin, cout, L, x_point_major, xyz, wxyz};
+  DensePmArgs d{x, wp, y, cin, cout, L, x_point_major, xyz, wxyz, q_rows, q_off};
   {
     // point-major in and out, whole tiles, the weight rows of a wave in registers: the persistent form (shape-only choice)
     static const int no_res = pcr_tune_int("PCR_DENSE_PM_NO_RES");   // diagnostics
@@ -2756,9 +2765,10 @@ PCR_EXPORT int pcr_dense_pm_prec_f32(const float *x, const float *wp_bf, float *
 }
 
 PCR_EXPORT int pcr_dense_pm_xyz_f32(const float *x, const float *wp_bf, const float *xyz, const float *wxyz, float *y, int B,
-                                    int cin, int cout, int L, int x_point_major, int precision, pcr_stream_t stream) {
+                                    int cin, int cout, int L, int x_point_major, int precision, int q_rows, int q_off,
+                                    pcr_stream_t stream) {
   if ((precision != 1 && precision != 2) || !xyz || !wxyz) return PCR_ERR_INVALID;
-  return dense_pm_launch(x, wp_bf, y, B, cin, cout, L, x_point_major, precision, stream, xyz, wxyz);
+  return dense_pm_launch(x, wp_bf, y, B, cin, cout, L, x_point_major, precision, stream, xyz, wxyz, q_rows, q_off);
 }
 
 PCR_EXPORT int pcr_sa_mlp_f32(const pcr_sa_params *pp, pcr_stream_t stream) {

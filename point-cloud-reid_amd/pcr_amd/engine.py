@@ -427,8 +427,12 @@ class SaPlan:
                           L.load().pcr_sa_tables_take_xyz(self.mode, D, c1_, c2_, c3_, K, PRECISIONS[PRECISION])):
                         # the K-row kernel's shapes: tables WITH the coordinate term and the shift (exact f32 fmas on top of
                         # the feature product), and the launch below adds P'[i] + Q'[c] and nothing else in its first layer
+                        # (prefix sampling: the centres are the first S points, and only centres' Q rows are ever read)
+                        q_rows = min(N, (S + 63) // 64 * 64) if centre_idx is None else N
+                        q_rows = q_rows if q_rows % 64 == 0 else N
                         L.check(L.load().pcr_dense_pm_xyz_f32(L.ptr(feat), L.ptr(self.wpq_bf), L.ptr(xyz), L.ptr(self.wxyz),
                                                               L.ptr(ws), B, D, pqw, N, int(feat_pm), PRECISIONS[PRECISION],
+                                                              q_rows, c1_ if q_rows < N else pqw,
                                                               L.stream_ptr()), "pcr_dense_pm_xyz_f32")
                         p.pq_has_xyz = 1
                     else:   # the tables on the bf16 matrix core too (the layer-1 MFMAs on the coordinates stay f32)

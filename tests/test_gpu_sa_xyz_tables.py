@@ -116,18 +116,33 @@ def test_the_table_builder_against_torch():
     wp = engine.pack_weight_bf(w, torch.device("cuda"))
     for pm in (0, 1):
         x = feat.transpose(1, 2).contiguous() if pm else feat
-        L.check(lib.pcr_dense_pm_xyz_f32(L.ptr(x), L.ptr(wp), L.ptr(xyz), L.ptr(wxyz), L.ptr(y), B, D, cout, N, pm,
-                                         engine.PRECISIONS["bf16x3"], L.stream_ptr()), "pcr_dense_pm_xyz_f32")
         want = (torch.einsum("od,bdn->bno", w.double(), feat.cpu().double()) +
                 torch.einsum("oc,bnc->bno", wxyz[:, :3].cpu().double(), xyz.cpu().double()) + wxyz[:, 3].cpu().double())
-        assert float((y.cpu().double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+        for q_rows, q_off in ((N, cout), (128, 64), (64, 32), (0, 96)):
+            y.fill_(-7.0)
+            L.check(lib.pcr_dense_pm_xyz_f32(L.ptr(x), L.ptr(wp), L.ptr(xyz), L.ptr(wxyz), L.ptr(y), B, D, cout, N, pm,
+                                             engine.PRECISIONS["bf16x3"], q_rows, q_off, L.stream_ptr()), "pcr_dense_pm_xyz_f32")
+            got = y.cpu().double()
+            tol = 1e-5 * float(want.abs().max())
+            if q_rows:
+                assert float((got[:, :q_rows] - want[:, :q_rows]).abs().max()) <= tol
+            if q_rows < N:
+                assert float((got[:, q_rows:, :q_off] - want[:, q_rows:, :q_off]).abs().max()) <= tol
+                # the couts [q_off, cout) of the tokens behind q_rows: left alone
+                assert bool((got[:, q_rows:, q_off:] == -7.0).all())
     # cout not a multiple of four, or only one of the two coordinate operands: refused
-    assert lib.pcr_dense_pm_xyz_f32(L.ptr(feat), L.ptr(wp), L.ptr(xyz), L.ptr(wxyz), L.ptr(y), B, D, 126, N, 0,
-                                    engine.PRECISIONS["bf16x3"], L.stream_ptr()) != 0
-    assert lib.pcr_dense_pm_xyz_f32(L.ptr(feat), L.ptr(wp), None, L.ptr(wxyz), L.ptr(y), B, D, cout, N, 0,
-                                    engine.PRECISIONS["bf16x3"], L.stream_ptr()) != 0
-    assert lib.pcr_dense_pm_xyz_f32(L.ptr(feat), L.ptr(wp), L.ptr(xyz), L.ptr(wxyz), L.ptr(y), B, D, cout, N, 0,
-                                    0, L.stream_ptr()) != 0
+    bf = engine.PRECISIONS["bf16x3"]
+    assert lib.pcr_dense_pm_xyz_f32(L.ptr(feat), L.ptr(wp), L.ptr(xyz), L.ptr(wxyz), L.ptr(y), B, D, 126, N, 0, bf, N, 124,
+                                    L.stream_ptr()) != 0
+    assert lib.pcr_dense_pm_xyz_f32(L.ptr(feat), L.ptr(wp), None, L.ptr(wxyz), L.ptr(y), B, D, cout, N, 0, bf, N, cout,
+                                    L.stream_ptr()) != 0
+    assert lib.pcr_dense_pm_xyz_f32(L.ptr(feat), L.ptr(wp), L.ptr(xyz), L.ptr(wxyz), L.ptr(y), B, D, cout, N, 0, 0, N, cout,
+                                    L.stream_ptr()) != 0
+    # q_rows not a whole number of 64-token tiles, q_off not a multiple of four
+    assert lib.pcr_dense_pm_xyz_f32(L.ptr(feat), L.ptr(wp), L.ptr(xyz), L.ptr(wxyz), L.ptr(y), B, D, cout, N, 0, bf, 100, 64,
+                                    L.stream_ptr()) != 0
+    assert lib.pcr_dense_pm_xyz_f32(L.ptr(feat), L.ptr(wp), L.ptr(xyz), L.ptr(wxyz), L.ptr(y), B, D, cout, N, 0, bf, 128, 62,
+                                    L.stream_ptr()) != 0
 
 
 def test_such_tables_are_refused_by_every_launch_that_would_not_read_them():
