@@ -588,7 +588,8 @@ struct SasBlock {
     };
     // xt: a row of layer 1 is relu(P'[i] + Q'[c]) -- the table pieces gathered in accumulator layout plus the centre's row by
     // row broadcast, ONE v_add_f32_dpp per element: no coordinate loads, no seeds, none of the two f32 MFMAs per cout block
-    // (512 matrix cycles of a 128-channel block) and no second add.  (Round 6: -x % on pt1024's SA2 / SA3 launches.)
+    // (512 matrix cycles of a 128-channel block) and no second add.  (Round 6, one process: pt1024's SA2 launch 1.375 -> 1.181 ms,
+    // SA3 2.095 -> 1.909, profiles/r06m_xyz_tables_ab.txt; the bench batch's logits 2.9e-5 -> 2.5e-5 from the f32 path.)
     auto layer1_xt = [&]() __attribute__((always_inline)) {
       f32x4 ppa[kAllP ? NCB : 1][4];
       if constexpr (kAllP) {
