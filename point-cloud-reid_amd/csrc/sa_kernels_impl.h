@@ -2137,6 +2137,93 @@ void dense_pm_res_kernel(DensePmArgs a, long ntile) {
   }
 }
 
+// The tables WITH the coordinate term (pcr_dense_pm_xyz_f32) in the persistent form, for CHANNEL-major input -- what the
+// attention blocks hand the Point-Transformer's SA layers: cin = 16 NPI in {32, 64}, cout = 16 NPO in {128, 256}, clouds of
+// whole 64-token tiles.  As dense_pm_res_kernel: every step of a wave's weight rows in registers (NPI steps x hi / lo x one
+// or two cout blocks), the NEXT tile's rows and coordinates requested into registers before the k-loop; the window's
+// {wx, wy, wz, bias} rows of the thread's cout quad are read once per workgroup.  (The one-shot dense_pm_kernel ran these
+// launches latency-bound: 0.19 / 0.22 ms for pt1024's two tables against 0.11 each at 5 TB/s.)  Same per-tile arithmetic in the
+// same order as dense_pm_kernel with the term in its store phase: bit-identical tables.
+template <int NS, int NPI, int NPO>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NPO == 16 ? 2 : 3, NPO == 16 ? 2 : 3)))
+void dense_pm_xyz_res_kernel(DensePmArgs a, int tpc, long ntile) {
+  constexpr int TB = 2, T = 64, RP = 65, PF = NPI, NR = NPO == 16 ? 2 : 1;
+  constexpr int CIN = 16 * NPI, COUT = 16 * NPO, Q2 = COUT / 4, LQ2 = NPO == 16 ? 6 : 5;
+  static_assert((PF & 1) == 0 && (NPO == 8 || NPO == 16), "cin in {32, 64}, cout in {128, 256}");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *X = smem;                                        // [COUT][RP]
+  float *s_xyz = X + COUT * RP;                           // [3 T]
+  const int tid = threadIdx.x;
+  BfRing<PF, NR> ring;
+  bf_ring_load<NR, 1, PF, NS>(a.wp, CIN, ceil32(COUT), ring);
+  const int ch0 = tid >> 4, tq4 = tid & 15;               // piece u of a thread: channel ch0 + 16 u, tokens 4 tq4 .. + 3
+  const int tq2 = tid >> LQ2, q2 = tid & (Q2 - 1);        // store phase: token tq2 + u (256 / Q2), cout quad q2
+  f32x4 wq[4];
+  {
+    const f32x4 *wr = reinterpret_cast<const f32x4 *>(a.wxyz) + 4 * q2;
+#pragma unroll
+    for (int c = 0; c < 4; c++) wq[c] = wr[c];
+  }
+  f32x4 v[NPI];
+  float vx = 0.f;
+  auto request = [&](long tile) __attribute__((always_inline)) {
+    const long b = tile / tpc;
+    const int t0 = (int)(tile - b * tpc) * T;
+    const float *src = a.x + ((size_t)b * CIN + ch0) * a.L + t0 + 4 * tq4;
+#pragma unroll
+    for (int u = 0; u < NPI; u++) v[u] = *reinterpret_cast<const f32x4 *>(src + (size_t)16 * u * a.L);
+    if (tid < 3 * T) vx = a.xyz[((size_t)b * a.L + t0) * 3 + tid];
+  };
+  auto epi = [&](float r, int o, int t) { X[o * RP + t] = r; };
+  long tile = blockIdx.x;
+  if (tile < ntile) request(tile);
+  for (; tile < ntile; tile += gridDim.x) {
+#pragma unroll
+    for (int u = 0; u < NPI; u++) {
+      float *d = X + (ch0 + 16 * u) * RP + 4 * tq4;
+      d[0] = v[u][0];
+      d[1] = v[u][1];
+      d[2] = v[u][2];
+      d[3] = v[u][3];
+    }
+    if (tid < 3 * T) s_xyz[tid] = vx;
+    if (tile + gridDim.x < ntile) request(tile + gridDim.x);
+    __syncthreads();
+    tile_dense_bf_impl<TB, NR, 1, false, NS, decltype(epi), PF, DenseNoHook, false, true>(
+        X, CIN, a.wp, ceil32(COUT), true, epi, nullptr, DenseNoHook(), 0, &ring);
+    __syncthreads();
+    const long b = tile / tpc;
+    const int t0 = (int)(tile - b * tpc) * T;
+    // (tokens behind q_rows: the couts [0, q_off) only -- the Q half is read for centres alone)
+    if (!(t0 >= a.q_rows && 4 * q2 >= a.q_off)) {
+      float *out = a.y + ((size_t)b * a.L + t0 + tq2) * COUT + 4 * q2;
+#pragma unroll
+      for (int u = 0; u < NPO; u++) {
+        const int t = tq2 + u * (kThreads / Q2);
+        const float *xs = X + 4 * q2 * RP + t;
+        f32x4 r = {xs[0], xs[RP], xs[2 * RP], xs[3 * RP]};
+        const float px = s_xyz[3 * t], py = s_xyz[3 * t + 1], pz = s_xyz[3 * t + 2];
+        // SCALAR fmas, pinned: left to the vectoriser this chain became v_pk_fma_f32 pairs over (c, c + 1) and (t, t + 8) with
+        // op_sel halves and a destination that overlaps the coordinate operand -- and that form returned wrong LOW halves in
+        // lanes 48-63 of about 0.03 % of the tiles once three workgroups shared a CU (every operand register verified intact in
+        // the ISA; the scalar form is bit-equal to the one-shot kernel over 1.3e8 elements: test_gpu_sa_xyz_tables.py)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          float acc = r[c] + wq[c][3];
+          asm volatile("" : "+v"(acc));
+          acc = __builtin_fmaf(wq[c][2], pz, acc);
+          asm volatile("" : "+v"(acc));
+          acc = __builtin_fmaf(wq[c][1], py, acc);
+          asm volatile("" : "+v"(acc));
+          r[c] = __builtin_fmaf(wq[c][0], px, acc);
+        }
+        *reinterpret_cast<f32x4 *>(out + (size_t)u * (kThreads / Q2) * COUT) = r;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 #endif   // PCR_SA_PREC == 0 (table kernel)
 
 }  // namespace
@@ -2725,6 +2812,46 @@ static int dense_pm_launch(const float *x, const float *wp, float *y, int B, int
 #undef PCR_PMR_I
 #undef PCR_PMR_O
 #undef PCR_PMR
+      PCR_CHECK_LAUNCH();
+      return PCR_OK;
+    }
+  }
+  if (xyz && !x_point_major && (cin == 32 || cin == 64) && (cout == 128 || cout == 256) && (L & 63) == 0 &&
+      (reinterpret_cast<size_t>(x) & 15) == 0 && (reinterpret_cast<size_t>(y) & 15) == 0 &&
+      (reinterpret_cast<size_t>(wxyz) & 15) == 0) {
+    // channel-major input, whole tiles per cloud: the persistent form with the coordinate term (shape-only choice)
+    static const int no_res = pcr_tune_int("PCR_DENSE_PM_NO_RES");   // diagnostics
+    if (!no_res) {
+      static const int ncu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+          n = 256;
+        return n;
+      }();
+      const int tpc = L / 64;
+      const long ntile = (long)B * tpc;
+      const long res = (long)ncu * (cout == 256 ? 2 : 3);     // (the kernel's registers: two or three workgroups per CU)
+      const long wgs = ntile < res ? ntile : res;
+      const size_t lds_r = ((size_t)cout * 65 + 3 * 64) * sizeof(float);
+#define PCR_PMX(NSv, NPIv, NPOv)                                                                            \
+  do {                                                                                                      \
+    static bool ok = allow_big_lds(dense_pm_xyz_res_kernel<NSv, NPIv, NPOv>);                               \
+    (void)ok;                                                                                               \
+    hipLaunchKernelGGL((dense_pm_xyz_res_kernel<NSv, NPIv, NPOv>), dim3((unsigned)wgs), dim3(kThreads), lds_r, \
+                       pcr_s(stream), d, tpc, ntile);                                                       \
+  } while (0)
+#define PCR_PMX_S(NSv)                                      \
+  do {                                                      \
+    if (cin == 32 && cout == 128) PCR_PMX(NSv, 2, 8);       \
+    else if (cin == 32) PCR_PMX(NSv, 2, 16);                \
+    else if (cout == 128) PCR_PMX(NSv, 4, 8);               \
+    else PCR_PMX(NSv, 4, 16);                               \
+  } while (0)
+      if (precision == 1) PCR_PMX_S(3);
+      else PCR_PMX_S(1);
+#undef PCR_PMX_S
+#undef PCR_PMX
       PCR_CHECK_LAUNCH();
       return PCR_OK;
     }

@@ -145,6 +145,36 @@ def test_the_table_builder_against_torch():
                                     L.stream_ptr()) != 0
 
 
+@pytest.mark.parametrize("D,cout,B,N", [(32, 128, 5, 256), (64, 256, 3, 512), (32, 256, 2, 64), (64, 128, 70, 128),
+                                        (32, 128, 600, 256), (64, 256, 520, 256)])   # (the last two: more tiles than resident workgroups)
+def test_the_persistent_form_gives_the_bits_of_the_one_shot_kernel(D, cout, B, N):
+    """channel-major input in whole 64-token tiles per cloud runs dense_pm_xyz_res_kernel (persistent workgroups, weight rows
+    and the next tile in registers); point-major input of the same values runs the one-shot dense_pm_kernel with the term in
+    its store phase.  Same per-tile arithmetic in the same order: the same bits, for every q_rows / q_off, and nothing
+    written outside them."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(D + cout + N)
+    feat = torch.randn(B, D, N, generator=g).cuda()
+    feat_pm = feat.transpose(1, 2).contiguous()
+    xyz = (torch.randn(B, N, 3, generator=g) * 2.0).cuda()
+    w = torch.randn(cout, D, generator=g) * 0.2
+    wxyz = torch.randn(cout, 4, generator=g).cuda()
+    wp = engine.pack_weight_bf(w, torch.device("cuda"))
+    for prec in ("bf16x3", "bf16"):
+        for q_rows, q_off in ((N, cout), (64 if N > 64 else 0, cout // 2), (0, 32)):
+            ys = []
+            for x, pm in ((feat, 0), (feat_pm, 1)):
+                y = torch.full((B, N, cout), float("nan"), device="cuda")          # (a value no launch can compute)
+                L.check(lib.pcr_dense_pm_xyz_f32(L.ptr(x), L.ptr(wp), L.ptr(xyz), L.ptr(wxyz), L.ptr(y), B, D, cout, N, pm,
+                                                 engine.PRECISIONS[prec], q_rows, q_off, L.stream_ptr()), "pcr_dense_pm_xyz_f32")
+                ys.append(y)
+            same = (ys[0] == ys[1]) | (torch.isnan(ys[0]) & torch.isnan(ys[1]))
+            assert bool(same.all()), (prec, q_rows, q_off, int((~same).sum()))
+            if q_rows < N:
+                assert bool(torch.isnan(ys[0][:, q_rows:, q_off:]).all())
+            assert not bool(torch.isnan(ys[0][:, :q_rows]).any()) and not bool(torch.isnan(ys[0][:, q_rows:, :q_off]).any())
+
+
 def test_such_tables_are_refused_by_every_launch_that_would_not_read_them():
     """pq_has_xyz on a launch whose dispatch is not the wave-autonomous K-row kernel must fail, not evaluate Wa dxyz twice"""
     g = torch.Generator().manual_seed(9)
