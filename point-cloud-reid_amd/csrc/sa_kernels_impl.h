@@ -2064,9 +2064,15 @@ __global__ __launch_bounds__(kThreads) void dense_pm_kernel(DensePmArgs a) {
         if (a.xyz) {
           const float px = s_xyz[3 * t], py = s_xyz[3 * t + 1], pz = s_xyz[3 * t + 2];
 #pragma unroll
-          for (int c = 0; c < 4; c++) {
+          for (int c = 0; c < 4; c++) {   // (scalar fmas, pinned: see dense_pm_xyz_res_kernel)
             const f32x4 w = s_wx[4 * q + c];
-            v[c] = __builtin_fmaf(w[0], px, __builtin_fmaf(w[1], py, __builtin_fmaf(w[2], pz, v[c] + w[3])));
+            float acc = v[c] + w[3];
+            asm volatile("" : "+v"(acc));
+            acc = __builtin_fmaf(w[2], pz, acc);
+            asm volatile("" : "+v"(acc));
+            acc = __builtin_fmaf(w[1], py, acc);
+            asm volatile("" : "+v"(acc));
+            v[c] = __builtin_fmaf(w[0], px, acc);
           }
         }
         *reinterpret_cast<f32x4 *>(out + (size_t)t * cout + 4 * q) = v;
@@ -2203,10 +2209,17 @@ void dense_pm_xyz_res_kernel(DensePmArgs a, int tpc, long ntile) {
         const float *xs = X + 4 * q2 * RP + t;
         f32x4 r = {xs[0], xs[RP], xs[2 * RP], xs[3 * RP]};
         const float px = s_xyz[3 * t], py = s_xyz[3 * t + 1], pz = s_xyz[3 * t + 2];
-        // SCALAR fmas, pinned: left to the vectoriser this chain became v_pk_fma_f32 pairs over (c, c + 1) and (t, t + 8) with
-        // op_sel halves and a destination that overlaps the coordinate operand -- and that form returned wrong LOW halves in
-        // lanes 48-63 of about 0.03 % of the tiles once three workgroups shared a CU (every operand register verified intact in
-        // the ISA; the scalar form is bit-equal to the one-shot kernel over 1.3e8 elements: test_gpu_sa_xyz_tables.py)
+        // SCALAR fmas, pinned -- here and in dense_pm_kernel's store phase.  Left to the vectoriser this chain becomes
+        // v_pk_fma_f32 pairs over (c, c + 1) and (t, t + 8) whose 64-bit operands are assembled by v_mov_b32 pairs right in
+        // front of them, and that form returns a wrong half of ONE packed result in lanes 48-63 now and then, a different
+        // place every run: ~3e-4 of the elements in this kernel, ~1e-8 in the one-shot kernel (tools/stress_tables.py against
+        // torch fp64; profiles/r06t_stress_tables.txt).  Not an LDS race (no prefetch, weights reloaded per tile, an extra
+        // barrier + sleep in front of this phase, no weight ring: each changed nothing; the dense part, the bias and xyz = 0
+        // were always exact; every operand register is written only by its loads), and the same signature in two kernels of
+        // different structure that goes away with the packed instructions points at that instruction sequence, not at the
+        // data flow.  Root cause not found (hipcc 7.2 / gfx950); the general shape -- a packed read of a pair a 32-bit
+        // instruction has just written -- is everywhere in this library (every bf16 split) and exact there.  With scalar chains:
+        // 0 differing of 1.3e10 elements between the two kernels (tools/stress_tables.py).
 #pragma unroll
         for (int c = 0; c < 4; c++) {
           float acc = r[c] + wq[c][3];
