@@ -59,6 +59,35 @@ def forced_dgcnn(model, sd, a, b):
     return worst
 
 
+def pt_near_tie(a, b, bl):
+    """A Point-Transformer case off by >= 1e-4 in BOTH arithmetics: is it a near-tie of the K-th neighbour between the distance the
+    kernels rank by (squared differences, pcr_sqdist3) and the expanded form -2 a.b + |a|^2 + |b|^2 of the reference's
+    square_distance (models/pointnet2_utils.py:169-188), whose rounding at |x| ~ 1 is ~1e-7?  -> the differing (kept, dropped)
+    pairs' relative distance gaps, or None if the neighbour sets agree / differ by more than a rounding."""
+    from pcr_amd import engine
+    gaps = []
+    for cl in (a, b):
+        pts = cl
+        for S, K in zip(bl, (32, 48, 48)):
+            idx = engine.knn_prefix(pts.cuda().contiguous(), S, K).cpu().long()
+            src, dst = pts[:, :S], pts
+            d_exp = -2 * torch.matmul(src, dst.transpose(1, 2)) + (src ** 2).sum(-1)[:, :, None] + (dst ** 2).sum(-1)[:, None, :]
+            ref = d_exp.topk(K, dim=-1, largest=False)[1]
+            d_dir = ((src[:, :, None, :] - dst[:, None, :, :]) ** 2).sum(-1)
+            for bi in range(pts.shape[0]):
+                for c in range(S):
+                    g, r = set(idx[bi, c].tolist()), set(ref[bi, c].tolist())
+                    if g != r:
+                        dg = torch.tensor([float(d_dir[bi, c, i]) for i in sorted(g - r)])
+                        dr = torch.tensor([float(d_dir[bi, c, i]) for i in sorted(r - g)])
+                        gap = float((dr.max() - dg.min()).abs() / max(1e-12, float(dr.max())))
+                        if gap > 2e-6:
+                            return None
+                        gaps.append(gap)
+            pts = pts[:, :S]
+    return gaps or None
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -110,6 +139,15 @@ def main():
             counts[case + "_flip"] = counts.get(case + "_flip", 0) + 1
             worst[case + "_flip"] = max(worst.get(case + "_flip", 0.0), err)
             err = ferr
+        if err >= 1e-4 and case == "pt":
+            # the xyz-space search ranks by squared differences, the reference by the expanded form: a near-tie of the K-th
+            # neighbour flips under the expanded form's own rounding (seed 1234 of round 6: 3.6e-7 between two candidates)
+            gaps = pt_near_tie(a, b, bl)
+            assert gaps, (case, n0, pairs, seed, err, "no near-tie explains it")
+            counts["pt_tie"] = counts.get("pt_tie", 0) + 1
+            worst["pt_tie"] = max(worst.get("pt_tie", 0.0), err)
+            n += 1
+            continue
         worst[case] = max(worst.get(case, 0.0), err)
         counts[case] = counts.get(case, 0) + 1
         assert err < 1e-4, (case, n0, pairs, seed, err)
